@@ -1,0 +1,796 @@
+/* to_query.c — CPU ORACLE (test infrastructure): TermScorer, Intersection, union,
+ * block-WAND executors, PhraseScorer, TopNHeap, merge_top_k.  See tantivy_oracle.h. */
+#include "tantivy_oracle.h"
+
+#include <assert.h>
+#include <stdlib.h>
+#include <string.h>
+
+/* ------------------------------------------------------------------ TopNHeap
+ * src/collector/sort_key/sort_by_score.rs:86-161.
+ * Min-heap under ScoreHeapEntry::cmp: score asc, then doc DESC (higher doc = "smaller"). */
+static int entry_less(const to_hit *a, const to_hit *b) {
+  /* a < b under ScoreHeapEntry::cmp */
+  if (a->score < b->score) return 1;
+  if (a->score > b->score) return 0;
+  return a->doc > b->doc; /* other.doc.cmp(&self.doc) */
+}
+void to_topn_init(to_topn_heap *h, size_t top_n) {
+  h->heap = (to_hit *)malloc(sizeof(to_hit) * (top_n ? top_n : 1));
+  h->len = 0;
+  h->top_n = top_n;
+  h->has_threshold = 0;
+  h->threshold = 0.0f;
+}
+void to_topn_free(to_topn_heap *h) {
+  free(h->heap);
+  h->heap = NULL;
+}
+static void sift_up(to_hit *a, size_t i) {
+  while (i > 0) {
+    size_t p = (i - 1) / 2;
+    if (entry_less(&a[i], &a[p])) {
+      to_hit t = a[i];
+      a[i] = a[p];
+      a[p] = t;
+      i = p;
+    } else
+      break;
+  }
+}
+static void sift_down(to_hit *a, size_t n, size_t i) {
+  for (;;) {
+    size_t l = 2 * i + 1, r = l + 1, m = i;
+    if (l < n && entry_less(&a[l], &a[m])) m = l;
+    if (r < n && entry_less(&a[r], &a[m])) m = r;
+    if (m == i) break;
+    to_hit t = a[i];
+    a[i] = a[m];
+    a[m] = t;
+    i = m;
+  }
+}
+void to_topn_push(to_topn_heap *h, float score, uint32_t doc) {
+  /* :137-152 */
+  if (h->len < h->top_n) {
+    h->heap[h->len].score = score;
+    h->heap[h->len].doc = doc;
+    sift_up(h->heap, h->len);
+    h->len++;
+    if (h->len == h->top_n) {
+      h->has_threshold = 1;
+      h->threshold = h->heap[0].score;
+    }
+  } else if (h->has_threshold) {
+    if (score > h->threshold) {
+      h->heap[0].score = score;
+      h->heap[0].doc = doc;
+      sift_down(h->heap, h->len, 0);
+      h->threshold = h->heap[0].score;
+    }
+  }
+}
+size_t to_topn_into_vec(const to_topn_heap *h, to_hit *out) {
+  memcpy(out, h->heap, h->len * sizeof(to_hit));
+  return h->len;
+}
+static int hit_cmp(const void *pa, const void *pb) {
+  const to_hit *a = (const to_hit *)pa, *b = (const to_hit *)pb;
+  if (a->score > b->score) return -1;
+  if (a->score < b->score) return 1;
+  return (a->doc > b->doc) - (a->doc < b->doc);
+}
+void to_sort_hits(to_hit *hits, size_t n) { qsort(hits, n, sizeof(to_hit), hit_cmp); }
+
+static int ghit_cmp(const void *pa, const void *pb) {
+  /* top_score_collector.rs:590-600: sort_key desc, then DocAddress (segment_ord, doc) asc */
+  const to_global_hit *a = (const to_global_hit *)pa, *b = (const to_global_hit *)pb;
+  if (a->score > b->score) return -1;
+  if (a->score < b->score) return 1;
+  if (a->segment_ord != b->segment_ord) return a->segment_ord < b->segment_ord ? -1 : 1;
+  return (a->doc > b->doc) - (a->doc < b->doc);
+}
+size_t to_merge_top_k(const to_global_hit *hits, size_t n, size_t offset, size_t limit,
+                      to_global_hit *out) {
+  /* sort_key_top_collector.rs:76-95.  TopNComputer::into_sorted_vec of the top (offset+limit)
+   * == the first (offset+limit) of the full sort under compare_for_top_k. */
+  if (limit == 0) return 0;
+  to_global_hit *tmp = (to_global_hit *)malloc(sizeof(to_global_hit) * (n ? n : 1));
+  memcpy(tmp, hits, n * sizeof(to_global_hit));
+  qsort(tmp, n, sizeof(to_global_hit), ghit_cmp);
+  size_t end = offset + limit < n ? offset + limit : n;
+  size_t w = 0;
+  for (size_t i = offset; i < end; i++) out[w++] = tmp[i];
+  free(tmp);
+  return w;
+}
+
+/* ------------------------------------------------------------------ TermScorer
+ * src/query/term_query/term_scorer.rs:9-150 */
+typedef struct {
+  to_segment_postings sp;
+  const uint8_t *fieldnorm; /* NULL => constant id */
+  uint8_t const_fieldnorm_id;
+  to_bm25 w;
+  float max_score; /* TermScorerWithMaxScore cache (block_wand_union.rs:267-277) */
+} term_scorer;
+
+static uint8_t ts_fieldnorm_id(const term_scorer *t, uint32_t doc) {
+  return t->fieldnorm ? t->fieldnorm[doc] : t->const_fieldnorm_id;
+}
+static uint32_t ts_doc(const term_scorer *t) { return to_sp_doc(&t->sp); }
+static float ts_score(const term_scorer *t) {
+  return to_bm25_score(&t->w, ts_fieldnorm_id(t, ts_doc(t)), to_sp_term_freq(&t->sp));
+}
+static float ts_block_max_score(term_scorer *t) {
+  return to_block_postings_block_max_score(&t->sp.bp, t->fieldnorm, t->const_fieldnorm_id, &t->w);
+}
+static uint32_t ts_last_doc_in_block(const term_scorer *t) {
+  return t->sp.bp.skip.last_doc_in_block;
+}
+static int ts_open(term_scorer *t, const to_segment_view *seg, const to_term_info *ti,
+                   const to_bm25 *w, int requested) {
+  const uint8_t *body = seg->idx + 8; /* inverted_index_reader.rs:72-73 */
+  const uint8_t *pos = seg->pos ? seg->pos + ti->positions_start : NULL;
+  size_t pos_len = seg->pos ? (size_t)(ti->positions_end - ti->positions_start) : 0;
+  if (to_segment_postings_open(&t->sp, ti->doc_freq, body + ti->postings_start,
+                               (size_t)(ti->postings_end - ti->postings_start), pos, pos_len,
+                               seg->record_option, requested))
+    return -1;
+  t->fieldnorm = seg->fieldnorm;
+  t->const_fieldnorm_id = 1; /* FieldNormReader::constant(max_doc, 1): term_weight.rs:209-219 */
+  if (w) t->w = *w;
+  t->max_score = w ? to_bm25_max_score(w) : 0.0f;
+  return 0;
+}
+
+/* ------------------------------------------------------------------ callback plumbing */
+typedef struct {
+  to_topn_heap *heap;
+} pruning_cb;
+static float cb_push(pruning_cb *cb, uint32_t doc, float score) {
+  /* sort_by_score.rs:55-58 */
+  to_topn_push(cb->heap, score, doc);
+  return cb->heap->has_threshold ? cb->heap->threshold : -3.40282347e+38f;
+}
+
+/* ------------------------------------------------------------------ block_wand_intersection
+ * src/query/boolean_query/block_wand_intersection.rs:19-179 */
+static void sort_by_size_hint(term_scorer **s, size_t n) {
+  /* stable insertion sort on doc_freq (Vec::sort_by_key is stable) */
+  for (size_t i = 1; i < n; i++) {
+    term_scorer *x = s[i];
+    size_t j = i;
+    while (j > 0 && s[j - 1]->sp.bp.doc_freq > x->sp.bp.doc_freq) {
+      s[j] = s[j - 1];
+      j--;
+    }
+    s[j] = x;
+  }
+}
+static void block_wand_intersection(term_scorer **scorers, size_t n, float threshold,
+                                    pruning_cb *cb) {
+  assert(n >= 2);
+  sort_by_size_hint(scorers, n);
+  term_scorer *leader = scorers[0];
+  term_scorer **sec = scorers + 1;
+  size_t ns = n - 1;
+  float leader_max = leader->max_score;
+  float sec_global_max_sum = 0.0f;
+  for (size_t i = 0; i < ns; i++) sec_global_max_sum += sec[i]->max_score;
+  if (leader_max + sec_global_max_sum <= threshold) return;
+
+  uint32_t doc = ts_doc(leader);
+  float sec_bms[64], sec_suffix[64];
+  assert(ns <= 64);
+  while (doc < TO_TERMINATED) {
+    to_block_postings_seek_block(&leader->sp.bp, doc);
+    float leader_block_max = ts_block_max_score(leader);
+    uint32_t window_end = ts_last_doc_in_block(leader);
+    float sec_bm_sum = 0.0f;
+    for (size_t i = 0; i < ns; i++) {
+      to_block_postings_seek_block(&sec[i]->sp.bp, doc);
+      if (sec[i]->sp.bp.skip.remaining_docs == 0) return;
+      uint32_t ld = ts_last_doc_in_block(sec[i]);
+      if (ld < window_end) window_end = ld;
+      float bms = ts_block_max_score(sec[i]);
+      sec_bms[i] = bms;
+      sec_bm_sum += bms;
+    }
+    if (leader_block_max + sec_bm_sum <= threshold) {
+      doc = window_end + 1;
+      continue;
+    }
+    to_block_postings *bc = &leader->sp.bp;
+    size_t start_idx = to_block_postings_seek(bc, doc);
+    size_t end_idx = to_search_block(bc->docs, window_end + 1);
+    if (end_idx > bc->block_len) end_idx = bc->block_len;
+
+    float score_threshold = threshold - sec_bm_sum;
+    uint32_t cand_docs[TO_BLOCK_LEN];
+    float cand_scores[TO_BLOCK_LEN];
+    size_t ncand = 0;
+    for (size_t i = start_idx; i < end_idx; i++) {
+      uint32_t d = bc->docs[i];
+      float ls = to_bm25_score(&leader->w, ts_fieldnorm_id(leader, d), bc->freqs[i]);
+      cand_docs[ncand] = d;
+      cand_scores[ncand] = ls;
+      ncand += (ls > score_threshold) ? 1u : 0u;
+    }
+    if (ncand == 0) {
+      doc = window_end + 1;
+      continue;
+    }
+    float running = 0.0f;
+    for (size_t i = ns; i-- > 0;) {
+      sec_suffix[i] = running;
+      running += sec_bms[i];
+    }
+    for (size_t c = 0; c < ncand; c++) {
+      uint32_t cd = cand_docs[c];
+      float total = cand_scores[c];
+      int ok = 1;
+      for (size_t i = 0; i < ns; i++) {
+        if (ts_doc(sec[i]) > cd) {
+          ok = 0;
+          break;
+        }
+        uint32_t r = to_sp_seek(&sec[i]->sp, cd);
+        if (r != cd) {
+          ok = 0;
+          break;
+        }
+        total += ts_score(sec[i]);
+        if (total + sec_suffix[i] <= threshold) {
+          ok = 0;
+          break;
+        }
+      }
+      if (!ok) continue;
+      if (total > threshold) {
+        threshold = cb_push(cb, cd, total);
+        if (leader_max + sec_global_max_sum <= threshold) return;
+      }
+    }
+    doc = window_end + 1;
+  }
+}
+
+/* ------------------------------------------------------------------ block_wand (union)
+ * src/query/boolean_query/block_wand_union.rs:16-265 */
+static void bw_sort_by_doc(term_scorer **s, size_t n) {
+  for (size_t i = 1; i < n; i++) { /* stable */
+    term_scorer *x = s[i];
+    size_t j = i;
+    while (j > 0 && ts_doc(s[j - 1]) > ts_doc(x)) {
+      s[j] = s[j - 1];
+      j--;
+    }
+    s[j] = x;
+  }
+}
+static void bw_restore_ordering(term_scorer **s, size_t n, size_t ord) {
+  uint32_t doc = ts_doc(s[ord]);
+  for (size_t i = ord + 1; i < n; i++) {
+    if (ts_doc(s[i]) >= doc) break;
+    term_scorer *t = s[i];
+    s[i] = s[i - 1];
+    s[i - 1] = t;
+  }
+}
+static void bw_swap_remove(term_scorer **s, size_t *n, size_t i) {
+  s[i] = s[*n - 1];
+  (*n)--;
+}
+static void block_wand_single_scorer(term_scorer *sc, float threshold, pruning_cb *cb) {
+  /* :226-265 */
+  uint32_t doc = ts_doc(sc);
+  for (;;) {
+    while (ts_block_max_score(sc) <= threshold) {
+      uint32_t last = ts_last_doc_in_block(sc);
+      if (last == TO_TERMINATED) return;
+      doc = last + 1;
+      to_block_postings_seek_block(&sc->sp.bp, doc);
+    }
+    doc = to_sp_seek(&sc->sp, doc);
+    if (doc == TO_TERMINATED) break;
+    for (;;) {
+      float s = ts_score(sc);
+      if (s > threshold) threshold = cb_push(cb, doc, s);
+      if (doc == ts_last_doc_in_block(sc)) break;
+      doc = to_sp_advance(&sc->sp);
+      if (doc == TO_TERMINATED) return;
+    }
+    doc += 1;
+    to_block_postings_seek_block(&sc->sp.bp, doc);
+  }
+}
+static void block_wand(term_scorer **s, size_t n, float threshold, pruning_cb *cb) {
+  /* retain non-terminated (:152) */
+  size_t w = 0;
+  for (size_t i = 0; i < n; i++)
+    if (ts_doc(s[i]) < TO_TERMINATED) s[w++] = s[i];
+  n = w;
+  if (n == 0) return;
+  if (n == 1) {
+    block_wand_single_scorer(s[0], threshold, cb);
+    return;
+  }
+  bw_sort_by_doc(s, n);
+  for (;;) {
+    /* find_pivot_doc :16-43 */
+    float max_score = 0.0f;
+    size_t before = 0;
+    uint32_t pivot_doc = TO_TERMINATED;
+    while (before < n) {
+      max_score += s[before]->max_score;
+      if (max_score > threshold) {
+        pivot_doc = ts_doc(s[before]);
+        break;
+      }
+      before++;
+    }
+    if (pivot_doc == TO_TERMINATED) return;
+    size_t pivot_len = before + 1;
+    while (pivot_len < n && ts_doc(s[pivot_len]) == pivot_doc) pivot_len++;
+
+    float ub = 0.0f;
+    for (size_t i = 0; i < pivot_len; i++) {
+      to_block_postings_seek_block(&s[i]->sp.bp, pivot_doc);
+      ub += ts_block_max_score(s[i]);
+    }
+    if (ub <= threshold) {
+      /* block_max_was_too_low_advance_one_scorer :49-80 */
+      size_t to_seek = pivot_len - 1;
+      float gmax = s[to_seek]->max_score;
+      uint32_t after = ts_last_doc_in_block(s[to_seek]);
+      for (size_t o = pivot_len - 1; o-- > 0;) {
+        if (ts_last_doc_in_block(s[o]) <= after) after = ts_last_doc_in_block(s[o]);
+        if (s[o]->max_score > gmax) {
+          gmax = s[o]->max_score;
+          to_seek = o;
+        }
+      }
+      if (after != TO_TERMINATED) after += 1;
+      for (size_t i = pivot_len; i < n; i++)
+        if (ts_doc(s[i]) <= after) after = ts_doc(s[i]);
+      to_sp_seek(&s[to_seek]->sp, after);
+      bw_restore_ordering(s, n, to_seek);
+      continue;
+    }
+    /* align_scorers :101-124 */
+    int aligned = 1;
+    for (size_t i = before; i-- > 0;) {
+      uint32_t nd = to_sp_seek(&s[i]->sp, pivot_doc);
+      if (nd != pivot_doc) {
+        if (nd == TO_TERMINATED) bw_swap_remove(s, &n, i);
+        if (i < n) bw_restore_ordering(s, n, i);
+        aligned = 0;
+        break;
+      }
+    }
+    if (!aligned) continue;
+    float score = 0.0f;
+    for (size_t i = 0; i < pivot_len; i++) score += ts_score(s[i]);
+    if (score > threshold) threshold = cb_push(cb, pivot_doc, score);
+    /* advance_all_scorers_on_pivot :129-143 */
+    for (size_t i = 0; i < pivot_len; i++) to_sp_advance(&s[i]->sp);
+    size_t i = 0;
+    while (i != n) {
+      if (ts_doc(s[i]) == TO_TERMINATED)
+        bw_swap_remove(s, &n, i);
+      else
+        i++;
+    }
+    /* sort_by_key is a stable sort */
+    bw_sort_by_doc(s, n);
+  }
+}
+
+/* ------------------------------------------------------------------ exhaustive AND
+ * Doc set: Intersection (src/query/intersection.rs:120-179).  Score: summed leader-first then
+ * secondaries in ascending doc_freq, the order block_wand_intersection uses (:144-165), which
+ * is what TopDocs actually observes for an all-term AND. */
+typedef void (*match_fn)(void *ctx, uint32_t doc, float score);
+static void exhaustive_and(term_scorer **s, size_t n, match_fn fn, void *ctx) {
+  sort_by_size_hint(s, n);
+  /* go_to_first_doc :66-79 */
+  uint32_t cand = 0;
+  for (size_t i = 0; i < n; i++)
+    if (ts_doc(s[i]) > cand) cand = ts_doc(s[i]);
+  for (;;) {
+    int again = 0;
+    for (size_t i = 0; i < n; i++) {
+      uint32_t d = to_sp_seek(&s[i]->sp, cand);
+      if (d > cand) {
+        cand = d;
+        again = 1;
+        break;
+      }
+    }
+    if (!again) break;
+  }
+  while (cand < TO_TERMINATED) {
+    float total = ts_score(s[0]);
+    for (size_t i = 1; i < n; i++) total += ts_score(s[i]);
+    fn(ctx, cand, total);
+    /* advance :121-179 */
+    uint32_t c = ts_doc(s[0]) + 1;
+    for (;;) {
+      if (c >= TO_TERMINATED) {
+        cand = TO_TERMINATED;
+        break;
+      }
+      c = to_sp_seek(&s[0]->sp, c);
+      if (c == TO_TERMINATED) {
+        cand = TO_TERMINATED;
+        break;
+      }
+      int all = 1;
+      for (size_t i = 1; i < n; i++) {
+        uint32_t d = to_sp_seek(&s[i]->sp, c);
+        if (d != c) {
+          c = d;
+          all = 0;
+          break;
+        }
+      }
+      if (all) {
+        cand = c;
+        break;
+      }
+    }
+  }
+}
+
+/* ------------------------------------------------------------------ exhaustive OR
+ * BufferedUnionScorer (src/query/union/buffered_union.rs:11-12,63-158) with SumCombiner
+ * (score_combiner.rs:39-56): 4096-doc horizon, per-doc accumulators updated scorer by scorer
+ * in the given term order. */
+#define TO_HORIZON 4096u
+static void exhaustive_or(term_scorer **s, size_t n, match_fn fn, void *ctx) {
+  static __thread float acc[TO_HORIZON];
+  static __thread uint8_t present[TO_HORIZON];
+  for (;;) {
+    uint32_t min_doc = TO_TERMINATED;
+    for (size_t i = 0; i < n; i++)
+      if (ts_doc(s[i]) < min_doc) min_doc = ts_doc(s[i]);
+    if (min_doc == TO_TERMINATED) return;
+    memset(present, 0, sizeof present);
+    for (uint32_t i = 0; i < TO_HORIZON; i++) acc[i] = 0.0f;
+    for (size_t i = 0; i < n; i++) {
+      for (;;) {
+        uint32_t d = ts_doc(s[i]);
+        if (d == TO_TERMINATED || d - min_doc >= TO_HORIZON) break;
+        acc[d - min_doc] += ts_score(s[i]);
+        present[d - min_doc] = 1;
+        to_sp_advance(&s[i]->sp);
+      }
+    }
+    for (uint32_t i = 0; i < TO_HORIZON; i++)
+      if (present[i]) fn(ctx, min_doc + i, acc[i]);
+  }
+}
+
+/* ------------------------------------------------------------------ exact phrase
+ * src/query/phrase_query/phrase_scorer.rs:82-136,347-587 (slop = 0) */
+typedef struct {
+  term_scorer *ts;
+  uint32_t offset; /* max_offset - term_offset (:372-385) */
+} phrase_term;
+
+static size_t pos_intersection(uint32_t *left, size_t ln, const uint32_t *right, size_t rn) {
+  size_t li = 0, ri = 0, c = 0;
+  while (li < ln && ri < rn) {
+    if (left[li] < right[ri])
+      li++;
+    else if (left[li] == right[ri]) {
+      left[c++] = left[li];
+      li++;
+      ri++;
+    } else
+      ri++;
+  }
+  return c;
+}
+static size_t pos_intersection_count(const uint32_t *left, size_t ln, const uint32_t *right,
+                                     size_t rn) {
+  size_t li = 0, ri = 0, c = 0;
+  while (li < ln && ri < rn) {
+    if (left[li] < right[ri])
+      li++;
+    else if (left[li] == right[ri]) {
+      c++;
+      li++;
+      ri++;
+    } else
+      ri++;
+  }
+  return c;
+}
+typedef struct {
+  uint32_t *left, *right;
+  size_t cap;
+} pos_bufs;
+static void pos_bufs_reserve(pos_bufs *b, size_t n) {
+  if (n <= b->cap) return;
+  size_t cap = b->cap ? b->cap : 256;
+  while (cap < n) cap *= 2;
+  b->left = (uint32_t *)realloc(b->left, cap * sizeof(uint32_t));
+  b->right = (uint32_t *)realloc(b->right, cap * sizeof(uint32_t));
+  b->cap = cap;
+}
+static uint32_t phrase_count(phrase_term *pt, size_t n, pos_bufs *b) {
+  /* compute_phrase_match :463-507 + intersection_count :437-461 */
+  pos_bufs_reserve(b, to_sp_term_freq(&pt[0].ts->sp));
+  size_t ln = to_sp_positions_with_offset(&pt[0].ts->sp, pt[0].offset, b->left);
+  for (size_t i = 1; i + 1 < n; i++) {
+    pos_bufs_reserve(b, to_sp_term_freq(&pt[i].ts->sp));
+    size_t rn = to_sp_positions_with_offset(&pt[i].ts->sp, pt[i].offset, b->right);
+    ln = pos_intersection(b->left, ln, b->right, rn);
+    if (ln == 0) return 0;
+  }
+  pos_bufs_reserve(b, to_sp_term_freq(&pt[n - 1].ts->sp));
+  size_t rn = to_sp_positions_with_offset(&pt[n - 1].ts->sp, pt[n - 1].offset, b->right);
+  return (uint32_t)pos_intersection_count(b->left, ln, b->right, rn);
+}
+static void exhaustive_phrase(phrase_term *pt, size_t n, const to_bm25 *w, match_fn fn,
+                              void *ctx) {
+  /* Intersection::new sorts by cost (= doc_freq for SegmentPostings), stable */
+  for (size_t i = 1; i < n; i++) {
+    phrase_term x = pt[i];
+    size_t j = i;
+    while (j > 0 && pt[j - 1].ts->sp.bp.doc_freq > x.ts->sp.bp.doc_freq) {
+      pt[j] = pt[j - 1];
+      j--;
+    }
+    pt[j] = x;
+  }
+  pos_bufs b = {0};
+  uint32_t cand = 0;
+  for (size_t i = 0; i < n; i++)
+    if (ts_doc(pt[i].ts) > cand) cand = ts_doc(pt[i].ts);
+  for (;;) {
+    int again = 0;
+    for (size_t i = 0; i < n; i++) {
+      uint32_t d = to_sp_seek(&pt[i].ts->sp, cand);
+      if (d > cand) {
+        cand = d;
+        again = 1;
+        break;
+      }
+    }
+    if (!again) break;
+  }
+  while (cand < TO_TERMINATED) {
+    uint32_t cnt = phrase_count(pt, n, &b);
+    if (cnt > 0) {
+      uint8_t fid = ts_fieldnorm_id(pt[0].ts, cand);
+      fn(ctx, cand, to_bm25_score(w, fid, cnt)); /* :578-586 */
+    }
+    uint32_t c = ts_doc(pt[0].ts) + 1;
+    for (;;) {
+      if (c >= TO_TERMINATED) {
+        cand = TO_TERMINATED;
+        break;
+      }
+      c = to_sp_seek(&pt[0].ts->sp, c);
+      if (c == TO_TERMINATED) {
+        cand = TO_TERMINATED;
+        break;
+      }
+      int all = 1;
+      for (size_t i = 1; i < n; i++) {
+        uint32_t d = to_sp_seek(&pt[i].ts->sp, c);
+        if (d != c) {
+          c = d;
+          all = 0;
+          break;
+        }
+      }
+      if (all) {
+        cand = c;
+        break;
+      }
+    }
+  }
+  free(b.left);
+  free(b.right);
+}
+
+/* ------------------------------------------------------------------ top-level */
+typedef struct {
+  to_topn_heap heap;
+  float threshold;
+} topk_ctx;
+static void topk_match(void *ctx, uint32_t doc, float score) {
+  /* for_each_pruning_scorer (query/weight.rs:47-60): score > threshold => callback */
+  topk_ctx *c = (topk_ctx *)ctx;
+  if (score > c->threshold) {
+    to_topn_push(&c->heap, score, doc);
+    c->threshold = c->heap.has_threshold ? c->heap.threshold : -3.40282347e+38f;
+  }
+}
+typedef struct {
+  uint32_t *docs;
+  float *scores;
+  size_t cap, n;
+} all_ctx;
+static void all_match(void *ctx, uint32_t doc, float score) {
+  all_ctx *c = (all_ctx *)ctx;
+  if (c->n < c->cap) {
+    c->docs[c->n] = doc;
+    c->scores[c->n] = score;
+  }
+  c->n++;
+}
+
+#define TO_MAX_TERMS 64
+static int open_scorers(const to_segment_view *seg, const to_query *q, term_scorer *store,
+                        term_scorer **ptrs, int requested) {
+  if (q->n_terms > TO_MAX_TERMS) return -1;
+  for (uint32_t i = 0; i < q->n_terms; i++) {
+    const to_bm25 *w = (q->mode == TO_MODE_PHRASE) ? &q->weights[0] : &q->weights[i];
+    if (ts_open(&store[i], seg, &q->terms[i], w, requested)) return -1;
+    ptrs[i] = &store[i];
+  }
+  return 0;
+}
+static void run_exhaustive(const to_segment_view *seg, const to_query *q, match_fn fn,
+                           void *ctx) {
+  term_scorer *store = (term_scorer *)malloc(sizeof(term_scorer) * (q->n_terms ? q->n_terms : 1));
+  term_scorer *ptrs[TO_MAX_TERMS];
+  if (q->mode == TO_MODE_AND) {
+    /* an absent term => empty intersection (EmptyScorer, term_weight.rs:179-190) */
+    for (uint32_t i = 0; i < q->n_terms; i++)
+      if (q->terms[i].doc_freq == 0) goto done;
+    if (open_scorers(seg, q, store, ptrs, TO_WITH_FREQS)) goto done;
+    if (q->n_terms == 1) {
+      term_scorer *t = ptrs[0];
+      for (uint32_t d = ts_doc(t); d < TO_TERMINATED; d = to_sp_advance(&t->sp))
+        fn(ctx, d, ts_score(t));
+    } else {
+      exhaustive_and(ptrs, q->n_terms, fn, ctx);
+    }
+  } else if (q->mode == TO_MODE_OR) {
+    size_t n = 0;
+    for (uint32_t i = 0; i < q->n_terms; i++) {
+      if (q->terms[i].doc_freq == 0) continue;
+      if (ts_open(&store[n], seg, &q->terms[i], &q->weights[i], TO_WITH_FREQS)) goto done;
+      ptrs[n] = &store[n];
+      n++;
+    }
+    if (n) exhaustive_or(ptrs, n, fn, ctx);
+  } else {
+    /* phrase_weight.rs:53-62: any absent term => no scorer */
+    for (uint32_t i = 0; i < q->n_terms; i++)
+      if (q->terms[i].doc_freq == 0) goto done;
+    if (open_scorers(seg, q, store, ptrs, TO_WITH_FREQS_AND_POSITIONS)) goto done;
+    phrase_term pt[TO_MAX_TERMS];
+    uint32_t max_off = 0;
+    for (uint32_t i = 0; i < q->n_terms; i++)
+      if (q->phrase_offsets[i] > max_off) max_off = q->phrase_offsets[i];
+    for (uint32_t i = 0; i < q->n_terms; i++) {
+      pt[i].ts = ptrs[i];
+      pt[i].offset = max_off - q->phrase_offsets[i];
+    }
+    exhaustive_phrase(pt, q->n_terms, &q->weights[0], fn, ctx);
+  }
+done:
+  free(store);
+}
+
+size_t to_search_exhaustive(const to_segment_view *seg, const to_query *q, to_hit *out) {
+  topk_ctx c;
+  to_topn_init(&c.heap, q->k);
+  c.threshold = -3.40282347e+38f;
+  run_exhaustive(seg, q, topk_match, &c);
+  size_t n = to_topn_into_vec(&c.heap, out);
+  to_topn_free(&c.heap);
+  return n;
+}
+size_t to_match_all(const to_segment_view *seg, const to_query *q, uint32_t *docs, float *scores,
+                    size_t cap) {
+  all_ctx c = {docs, scores, cap, 0};
+  run_exhaustive(seg, q, all_match, &c);
+  return c.n;
+}
+size_t to_search_pruned(const to_segment_view *seg, const to_query *q, to_hit *out) {
+  to_topn_heap heap;
+  to_topn_init(&heap, q->k);
+  pruning_cb cb = {&heap};
+  const float MINF = -3.40282347e+38f; /* Score::MIN */
+  term_scorer *store = (term_scorer *)malloc(sizeof(term_scorer) * (q->n_terms ? q->n_terms : 1));
+  term_scorer *ptrs[TO_MAX_TERMS];
+  if (q->mode == TO_MODE_AND) {
+    int absent = 0;
+    for (uint32_t i = 0; i < q->n_terms; i++)
+      if (q->terms[i].doc_freq == 0) absent = 1;
+    if (!absent && open_scorers(seg, q, store, ptrs, TO_WITH_FREQS) == 0) {
+      if (q->n_terms == 1)
+        block_wand_single_scorer(ptrs[0], MINF, &cb); /* term_weight.rs:118-141 */
+      else
+        block_wand_intersection(ptrs, q->n_terms, MINF, &cb);
+    }
+  } else if (q->mode == TO_MODE_OR) {
+    size_t n = 0;
+    int bad = 0;
+    for (uint32_t i = 0; i < q->n_terms; i++) {
+      if (q->terms[i].doc_freq == 0) continue;
+      if (ts_open(&store[n], seg, &q->terms[i], &q->weights[i], TO_WITH_FREQS)) bad = 1;
+      ptrs[n] = &store[n];
+      n++;
+    }
+    if (!bad && n) block_wand(ptrs, n, MINF, &cb);
+  } else {
+    free(store);
+    to_topn_free(&heap);
+    /* PhraseWeight has no specialised pruning: for_each_pruning_scorer over the scorer */
+    return to_search_exhaustive(seg, q, out);
+  }
+  size_t n = to_topn_into_vec(&heap, out);
+  free(store);
+  to_topn_free(&heap);
+  return n;
+}
+
+/* ------------------------------------------------------------------ decode helpers */
+size_t to_decode_postings(const to_segment_view *seg, const to_term_info *ti, uint32_t *docs,
+                          uint32_t *tfs) {
+  term_scorer t;
+  if (ti->doc_freq == 0) return 0;
+  if (ts_open(&t, seg, ti, NULL, TO_WITH_FREQS)) return 0;
+  size_t n = 0;
+  for (uint32_t d = ts_doc(&t); d < TO_TERMINATED; d = to_sp_advance(&t.sp)) {
+    docs[n] = d;
+    if (tfs) tfs[n] = to_sp_term_freq(&t.sp);
+    n++;
+  }
+  return n;
+}
+size_t to_decode_positions(const to_segment_view *seg, const to_term_info *ti, uint32_t *out,
+                           size_t cap) {
+  term_scorer t;
+  if (ti->doc_freq == 0) return 0;
+  if (ts_open(&t, seg, ti, NULL, TO_WITH_FREQS_AND_POSITIONS)) return 0;
+  size_t n = 0;
+  uint32_t *tmp = NULL;
+  size_t tmp_cap = 0;
+  for (uint32_t d = ts_doc(&t); d < TO_TERMINATED; d = to_sp_advance(&t.sp)) {
+    uint32_t tf = to_sp_term_freq(&t.sp);
+    if (tf > tmp_cap) {
+      tmp_cap = tf * 2;
+      tmp = (uint32_t *)realloc(tmp, tmp_cap * sizeof(uint32_t));
+    }
+    to_sp_positions_with_offset(&t.sp, 0, tmp);
+    for (uint32_t i = 0; i < tf; i++) {
+      if (n < cap) out[n] = tmp[i];
+      n++;
+    }
+  }
+  free(tmp);
+  return n;
+}
+
+/* ------------------------------------------------------------------ TermScorer handle API
+ * (lets tests replay the reference's TermScorer unit tests step by step) */
+void *to_ts_new(const to_segment_view *seg, const to_term_info *ti, const to_bm25 *w) {
+  term_scorer *t = (term_scorer *)malloc(sizeof *t);
+  if (ts_open(t, seg, ti, w, TO_WITH_FREQS)) {
+    free(t);
+    return NULL;
+  }
+  return t;
+}
+void to_ts_free(void *t) { free(t); }
+uint32_t to_ts_doc(void *t) { return ts_doc((term_scorer *)t); }
+uint32_t to_ts_advance(void *t) { return to_sp_advance(&((term_scorer *)t)->sp); }
+uint32_t to_ts_seek(void *t, uint32_t target) { return to_sp_seek(&((term_scorer *)t)->sp, target); }
+void to_ts_seek_block(void *t, uint32_t target) {
+  to_block_postings_seek_block(&((term_scorer *)t)->sp.bp, target);
+}
+uint32_t to_ts_term_freq(void *t) { return to_sp_term_freq(&((term_scorer *)t)->sp); }
+float to_ts_score(void *t) { return ts_score((term_scorer *)t); }
+float to_ts_block_max_score(void *t) { return ts_block_max_score((term_scorer *)t); }
+float to_ts_max_score(void *t) { return ((term_scorer *)t)->max_score; }
+uint32_t to_ts_last_doc_in_block(void *t) { return ts_last_doc_in_block((term_scorer *)t); }
