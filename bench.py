@@ -1,0 +1,263 @@
+#!/usr/bin/env python
+"""bench.py — headline benchmark: 2-term AND + BM25 top-10 QPS on a 10M-doc synthetic Zipf
+segment per GPU (BASELINE.json configs[1]), with the HBM roofline of the scan
+kernel and the CPU restatement of tantivy's own executor timed beside it.
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+
+One step = one pass of the hot path over one batch of queries (posting lists resident in HBM;
+query weights prepared outside the timed region, like `query.weight()` in tantivy's benches).
+Roles of oracle/ here: (1) workload generator — it serialises the synthetic index into tantivy's
+byte format before anything is timed; (2) the cpu_baseline leg; (3) a post-hoc parity spot check.
+The timed GPU leg runs only tantivy_amd (HIP kernels + C ABI + C++ host mirror).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--docs", type=int, default=10_000_000)
+    ap.add_argument("--queries", type=int, default=10_000)
+    ap.add_argument("--workload", default="and2", choices=["and2", "or5", "phrase3", "mixed"])
+    ap.add_argument("--k", type=int, default=None)
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--latency-queries", type=int, default=200)
+    ap.add_argument("--pruned", action="store_true", help="allow block-max pruning on the device")
+    return ap.parse_args()
+
+
+def build_queries(O, workload, n, k):
+    if workload == "and2":
+        ids = O.zipf_queries(n, 2, 256, seed=20260921)
+        return [(O.MODE_AND, q.tolist()) for q in ids], k or 10
+    if workload == "or5":
+        ids = O.zipf_queries(n, 5, 256, seed=20260922)
+        return [(O.MODE_OR, q.tolist()) for q in ids], k or 100
+    if workload == "phrase3":
+        rng = np.random.default_rng(20260923)
+        starts = rng.integers(0, 30, size=n)
+        return [(O.MODE_PHRASE, [int(s), int(s) + 1, int(s) + 2]) for s in starts], k or 10
+    a = O.zipf_queries(n // 2, 2, 256, seed=20260921)
+    o = O.zipf_queries(n - n // 2, 5, 256, seed=20260922)
+    qs = []
+    for i in range(n):
+        qs.append((O.MODE_AND, a[i // 2].tolist()) if i % 2 == 0 else (O.MODE_OR, o[i // 2].tolist()))
+    return qs, k or 10
+
+
+def main():
+    args = parse_args()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    import torch
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (no CPU fallback exists for the product path)")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    from oracle import oracle as O  # workload generator + cpu baseline + spot check only
+    import tantivy_amd
+    from tantivy_amd import distributed as D
+
+    with_pos = args.workload == "phrase3"
+    t0 = time.time()
+    seg = O.synth_segment(args.docs, n_terms=256, segment_ord=rank, with_positions=with_pos,
+                          phrase_terms=32)
+    t_gen = time.time() - t0
+    dev = tantivy_amd.DeviceIndex([seg], devices=[local_rank])
+    dev.set_option("timing", 1)
+    dev.set_option("exhaustive", 0 if args.pruned else 1)
+    my_stats = (seg.max_doc, seg.total_num_tokens, [t.doc_freq for t in seg.terms])
+    all_stats = [my_stats]
+    if world > 1:
+        all_stats = [None] * world
+        dist.all_gather_object(all_stats, my_stats)
+        for r, st in enumerate(all_stats):
+            if r != rank:
+                dev.add_remote_stats(*st)
+    queries, k = build_queries(O, args.workload, args.queries, args.k)
+    n_q = len(queries)
+    dev.prepare(queries)  # Query::weight: global BM25 statistics, executor choice
+
+    # a non-default stream: the library's kernels, the RCCL all-gather and the merge kernel are
+    # all ordered on it (the legacy null stream would not order against the library's own stream)
+    ts = torch.cuda.Stream()
+    torch.cuda.set_stream(ts)
+    stream = ts.cuda_stream
+    d_scores = torch.empty((n_q, k), dtype=torch.float32, device="cuda")
+    d_docs = torch.empty((n_q, k), dtype=torch.int32, device="cuda")
+    d_counts = torch.empty(n_q, dtype=torch.int32, device="cuda")
+    h_out = [torch.empty((n_q, k), dtype=torch.float32).pin_memory(),
+             torch.empty((n_q, k), dtype=torch.int32).pin_memory(),
+             torch.empty((n_q, k), dtype=torch.int32).pin_memory(),
+             torch.empty(n_q, dtype=torch.int32).pin_memory()]
+
+    def step():
+        """collect_segment on this rank's segment -> (all-gather) -> merge_top_k -> host."""
+        dev.collect_segment_prepared_device(0, k, d_scores, d_docs, d_counts, stream)
+        if world > 1:
+            g = D.allgather_topk(d_scores, d_docs, d_counts)
+        else:
+            g = (d_scores.unsqueeze(0), d_docs.unsqueeze(0), d_counts.unsqueeze(0))
+        m = D.merge_gathered_device(dev.ctx, local_rank, g[0], g[1], g[2], 0, k, stream)
+        for h, t in zip(h_out, m):
+            h.copy_(t, non_blocking=True)
+        torch.cuda.synchronize()
+        return dev.last_batch_stats()
+
+    for _ in range(args.warmup):
+        step()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t_start = time.perf_counter()
+    kernel_ms, algo_bytes, matches = [], 0, 0
+    for _ in range(args.steps):
+        st = step()
+        kernel_ms.append(st["kernel_ms"])
+        algo_bytes, matches = st["algorithmic_bytes"], st["matches"]
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t_start
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    final = [h.clone().numpy() for h in h_out]
+
+    # ---- single-query latency (p50), outside the timed region
+    lat = []
+    if rank == 0 and args.latency_queries > 0:
+        for i in range(min(args.latency_queries, n_q)):
+            dev.prepare([queries[i]])
+            t1 = time.perf_counter()
+            dev.search_prepared(k)
+            lat.append(time.perf_counter() - t1)
+        dev.prepare(queries)
+
+    if rank != 0:
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
+
+    # ---- post-hoc parity spot check against the oracle (N=1 only: local stats == global)
+    parity_checked = 0
+    if world == 1:
+        for i in list(range(0, n_q, max(1, n_q // 16)))[:16]:
+            mode, terms = queries[i][0], queries[i][1]
+            want = O.search(seg, terms, mode, k, pruned=False)
+            got = [(float(final[0][i, j]), int(final[2][i, j])) for j in range(int(final[3][i]))]
+            assert len(got) == len(want), (i, got, want)
+            for (gs, gd), (ws, wd) in zip(got, want):
+                assert gd == wd and abs(gs - ws) <= 1e-5 * abs(ws), (i, got, want)
+            parity_checked += 1
+
+    # ---- CPU baseline: the oracle's restatement of tantivy's block-WAND executors
+    cpu = None
+    if world == 1 and not args.no_cpu_baseline:
+        cores = os.cpu_count() or 1
+        specs, done, wall_total = [], 0, 0.0
+        chunk = max(64, cores * 16)
+        while wall_total < args.cpu_seconds and done < n_q:
+            part = queries[done:done + chunk]
+            sp = [O.QuerySpec(seg, q[1], O.default_weights(seg, q[1], q[0]), q[0], k,
+                              list(range(len(q[1]))) if q[0] == O.MODE_PHRASE else None)
+                  for q in part]
+            wall, _, _ = O.baseline_run(seg, sp, cores)
+            wall_total += wall
+            done += len(part)
+        sp1 = [O.QuerySpec(seg, q[1], O.default_weights(seg, q[1], q[0]), q[0], k,
+                           list(range(len(q[1]))) if q[0] == O.MODE_PHRASE else None)
+               for q in queries[:48]]
+        _, lat1, _ = O.baseline_run(seg, sp1, 1)
+        cpu = {"value": round(done / wall_total, 2), "unit": "queries/s", "cores": cores,
+               "kind": "port",
+               "sample": "first %d queries of the same stream, query-level parallelism on %d "
+                         "threads, %.1f s; C restatement of tantivy's block_wand_intersection/"
+                         "block_wand (oracle/), not the tantivy binary" % (done, cores, wall_total),
+               "p50_latency_ms_1core": round(float(np.median(lat1)) * 1e3, 3)}
+
+    total_units = n_q * args.steps * world  # one unit = one query evaluated on one segment
+    value = total_units / elapsed
+    k_ms = float(np.mean(kernel_ms)) if kernel_ms else 0.0
+    achieved = (algo_bytes / (k_ms * 1e-3) / 1e9) if k_ms > 0 else 0.0
+    out = {
+        "metric": "queries_per_sec_2term_AND_bm25_top10" if args.workload == "and2"
+        else "queries_per_sec_" + args.workload,
+        "value": round(value, 1),
+        "unit": "queries/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "u32+f32",
+        "data": "synthetic",
+        "config": {
+            "workload": "%s: %d queries/batch, k=%d, one %dM-doc Zipf segment per GPU (256 terms, "
+                        "df_r=0.5N/r, WithFreqs%s); term ranks ~ Zipf(1)" %
+                        (args.workload, n_q, k, args.docs // 1_000_000,
+                         "AndPositions" if with_pos else ""),
+            "unit_note": "one unit = one query evaluated on one segment; at N GPUs every query "
+                         "runs on N segments (N x %dM docs) and the per-segment top-k are "
+                         "all-gathered over RCCL and merged" % (args.docs // 1_000_000),
+            "timed_region": "collect_segment (plan + H2D of query descriptors + scan + merge "
+                            "kernels) -> all-gather -> merge_top_k -> D2H, synchronised per step",
+            "mode": "pruned" if args.pruned else "exhaustive",
+            "index_bytes": int(seg.idx_len),
+            "index_build_s": round(t_gen, 2),
+        },
+        "roofline": {
+            "bound": "hbm",
+            "achieved": round(achieved, 1),
+            "peak": HBM_PEAK_GBS,
+            "unit": "GB/s",
+            "frac": round(achieved / HBM_PEAK_GBS, 4),
+            "traffic": None,
+            "kernel": "and_kernel" if args.workload == "and2" else args.workload + " scan kernels",
+            "kernel_ms_avg": round(k_ms, 4),
+            "algorithmic_bytes_per_launch": int(algo_bytes),
+            "matches_per_launch": int(matches),
+        },
+        "cpu_baseline": cpu,
+        "p50_latency_ms": round(float(np.median(lat)) * 1e3, 4) if lat else None,
+        "parity_checked_queries": parity_checked,
+    }
+    print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,167 @@
+/*
+ * tantivy_amd.h — C ABI of the MI355X-native query-execution path for tantivy.
+ *
+ * This is the drop-in boundary: everything below
+ * `Weight::for_each_pruning` / `Collector::collect_segment` — posting-list decode, AND / OR /
+ * exact-phrase evaluation, BM25, per-segment top-k and the cross-segment merge — runs on the
+ * GPU behind these entry points.  Plain pointers and sizes only; callable from Rust through a
+ * thin `extern "C"` crate (binding shown in INTEGRATION.md), from C++ (tantivy_amd/host/) and
+ * from Python ctypes (tantivy_amd/binding.py).
+ *
+ * Ownership: inputs are borrowed for the duration of the call (segment bytes are copied to HBM
+ * by tq_segment_upload); outputs are caller-allocated; handles are opaque and freed explicitly.
+ * Every function returns TQ_OK (0) or an error code; tq_last_error() gives the message of the
+ * last failure on the calling thread.  Nothing here panics or throws across the boundary.
+ *
+ * Thread-safety: one tq_segment may be searched from one thread at a time (it owns one HIP
+ * stream and its scratch buffers); different segments may be searched concurrently — that is
+ * tantivy's own "one task per segment" executor model (src/core/executor.rs:44-106).
+ */
+#ifndef TANTIVY_AMD_H
+#define TANTIVY_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TQ_TERMINATED 0x7FFFFFFFu /* src/docset.rs:12 */
+#define TQ_MAX_TERMS 16u          /* terms per device query */
+#define TQ_MAX_K 1024u            /* largest per-segment k (offset+limit) the device heap holds */
+
+enum tq_status {
+  TQ_OK = 0,
+  TQ_ERR_INVALID = 1,     /* bad argument */
+  TQ_ERR_HIP = 2,         /* HIP runtime failure (maps to TantivyError::SystemError) */
+  TQ_ERR_FORMAT = 3,      /* malformed index bytes (maps to TantivyError::DataCorruption) */
+  TQ_ERR_UNSUPPORTED = 4, /* query shape the device path does not take (caller falls back) */
+  TQ_ERR_NO_DEVICE = 5
+};
+
+/* IndexRecordOption of the *indexed* field (src/schema/index_record_option.rs); it fixes the
+ * skip-entry size (5/8/12 B, src/postings/skip.rs:205-253). */
+enum tq_record_option { TQ_BASIC = 0, TQ_WITH_FREQS = 1, TQ_WITH_FREQS_AND_POSITIONS = 2 };
+
+/* Which executor the reference would pick (src/query/boolean_query/boolean_weight.rs:236-431):
+ * AND    = all-Must term clauses   -> block_wand_intersection
+ * OR     = all-Should term clauses -> block_wand / BufferedUnionScorer
+ * PHRASE = PhraseQuery (slop 0)    -> PhraseScorer */
+enum tq_mode { TQ_MODE_AND = 0, TQ_MODE_OR = 1, TQ_MODE_PHRASE = 2 };
+
+typedef struct tq_ctx tq_ctx;
+typedef struct tq_segment tq_segment;
+typedef uint32_t tq_term_handle;
+#define TQ_TERM_ABSENT 0xFFFFFFFFu /* term not in this segment (TermInfo lookup returned None) */
+
+/* One query against one segment.  Replaces the per-segment scorer tree the reference builds in
+ * BooleanWeight::complex_scorer / TermWeight::specialized_scorer / PhraseWeight::phrase_scorer.
+ * The BM25 statistics are computed by the caller from *global* (cross-segment) counts exactly as
+ * Bm25Weight::for_terms does (src/query/bm25.rs:95-129): */
+typedef struct tq_query {
+  uint32_t n_terms;              /* 1..TQ_MAX_TERMS */
+  const tq_term_handle *terms;   /* from tq_term_prepare, or TQ_TERM_ABSENT */
+  const float *weights;          /* AND/OR: n_terms x (idf*(1+K1)*boost); PHRASE: weights[0] */
+  const float *tf_cache;         /* Bm25Weight.cache: 256 f32, K1*(1-B+B*fieldnorm/avg) */
+  uint8_t mode;                  /* enum tq_mode */
+  const uint32_t *phrase_offsets; /* PHRASE: term offsets inside the phrase; else NULL */
+  uint32_t k;                    /* TopDocs offset+limit, 1..TQ_MAX_K */
+} tq_query;
+
+/* ---- lifecycle ---- */
+/* replaces: nothing in the reference (device bring-up).  device_ids==NULL => {0}. */
+int tq_init(const int *device_ids, int n_devices, tq_ctx **out);
+void tq_shutdown(tq_ctx *ctx);
+const char *tq_last_error(void);
+
+/* ---- segment residency ----
+ * replaces: SegmentReader::inverted_index(field) + InvertedIndexReader::new
+ * (src/index/segment_reader.rs:221-283, src/index/inverted_index_reader.rs:66-81) and
+ * FieldNormReader::open (src/fieldnorm/reader.rs:99-105): the field's raw sub-files are copied
+ * to HBM unchanged.  idx = the field's `.idx` sub-file including its 8-byte total_num_tokens
+ * header; pos = the field's `.pos` sub-file (NULL if no positions); fieldnorm = max_doc bytes
+ * (NULL => FieldNormReader::constant(max_doc, 1), src/query/term_query/term_weight.rs:209-219).
+ * The natural caller is a Warmer (src/reader/warming.rs:14-20). */
+int tq_segment_upload(tq_ctx *ctx, int device, uint32_t max_doc, const uint8_t *idx,
+                      size_t idx_len, const uint8_t *pos, size_t pos_len,
+                      const uint8_t *fieldnorm, size_t fn_len, uint8_t record_option,
+                      tq_segment **out);
+void tq_segment_free(tq_segment *seg);
+
+/* replaces: InvertedIndexReader::read_postings_from_terminfo + BlockSegmentPostings::open +
+ * SkipReader::new + PositionReader::open (inverted_index_reader.rs:204-247,
+ * block_segment_postings.rs:97-140, skip.rs:131-151, positions/reader.rs:43-56).
+ * Arguments are the fields of TermInfo (src/postings/term_info.rs:10-17): ranges are relative to
+ * the sub-file body (after the 8-byte header for .idx).  Walks the sequential skip list once and
+ * keeps it on the device as a random-access table; idempotent per (postings_off). */
+int tq_term_prepare(tq_segment *seg, uint64_t postings_off, uint32_t postings_len,
+                    uint64_t positions_off, uint32_t positions_len, uint32_t doc_freq,
+                    tq_term_handle *out);
+
+/* ---- search ----
+ * replaces, for each query: TopBySortKeyCollector::collect_segment ->
+ * SortBySimilarityScore::collect_segment_top_k -> Weight::for_each_pruning -> {block_wand,
+ * block_wand_intersection, for_each_pruning_scorer(PhraseScorer)} -> TopNHeap
+ * (src/collector/sort_key_top_collector.rs:62-73, sort_key/sort_by_score.rs:35-161,
+ *  src/query/boolean_query/{block_wand_union,block_wand_intersection}.rs,
+ *  src/query/phrase_query/phrase_scorer.rs).
+ * Output per query q (row stride = out_stride >= max k): the segment's top-k sorted by
+ * (score desc, doc asc) — i.e. TopNHeap::into_vec after the sort merge_top_k applies — padded
+ * with (0.0, TQ_TERMINATED); out_counts[q] = number of real hits.  Host buffers. */
+int tq_search_batch(tq_segment *seg, const tq_query *queries, uint32_t n_queries,
+                    uint32_t out_stride, float *out_scores, uint32_t *out_docs,
+                    uint32_t *out_counts);
+
+/* Same, but the outputs are DEVICE pointers on the segment's device and the call only enqueues
+ * work on `hip_stream` (a hipStream_t; NULL = the segment's own stream) without a final host
+ * synchronisation — for callers that feed an RCCL all-gather (tq_merge_topk_device) next. */
+int tq_search_batch_device(tq_segment *seg, const tq_query *queries, uint32_t n_queries,
+                           uint32_t out_stride, float *d_out_scores, uint32_t *d_out_docs,
+                           uint32_t *d_out_counts, void *hip_stream);
+
+/* replaces: TopBySortKeyCollector::merge_fruits -> merge_top_k
+ * (src/collector/sort_key_top_collector.rs:54-95; ordering top_score_collector.rs:590-600):
+ * merges n_segments per-segment results (layout [segment][query][stride], as gathered by an
+ * all-gather over ranks) into the global top-(offset+limit) by (score desc, segment_ord asc,
+ * doc asc), then skips `offset`.  Host version. */
+int tq_merge_topk(const float *scores, const uint32_t *docs, const uint32_t *counts,
+                  uint32_t n_segments, uint32_t n_queries, uint32_t stride, uint32_t offset,
+                  uint32_t limit, float *out_scores, uint32_t *out_segment_ords,
+                  uint32_t *out_docs, uint32_t *out_counts);
+/* Device version of the same merge (inputs/outputs are device pointers on `device`; enqueued on
+ * hip_stream).  segment_ords[s] gives the segment ordinal of slab s (NULL => s). */
+int tq_merge_topk_device(tq_ctx *ctx, int device, const float *d_scores, const uint32_t *d_docs,
+                         const uint32_t *d_counts, const uint32_t *segment_ords,
+                         uint32_t n_segments, uint32_t n_queries, uint32_t stride,
+                         uint32_t offset, uint32_t limit, float *d_out_scores,
+                         uint32_t *d_out_segment_ords, uint32_t *d_out_docs,
+                         uint32_t *d_out_counts, void *hip_stream);
+
+/* ---- codec access (parity tests / tooling) ----
+ * replaces: BlockSegmentPostings::load_block over a whole list (block_segment_postings.rs:343-391;
+ * BitPacker4x decode + strict-delta prefix sum + vint tail).  docs/tfs: doc_freq u32 each (host). */
+int tq_decode_postings(tq_segment *seg, tq_term_handle term, uint32_t *docs, uint32_t *tfs);
+/* replaces: PositionReader::read over the whole term (positions/reader.rs:104-148): raw position
+ * deltas, n_positions values (host); *n_out = number available. */
+int tq_decode_position_deltas(tq_segment *seg, tq_term_handle term, uint32_t *out, uint64_t cap,
+                              uint64_t *n_out);
+
+/* ---- introspection ---- */
+typedef struct tq_batch_stats {
+  uint64_t algorithmic_bytes; /* sum len(postings_range) [+positions] + matches + 8k */
+  uint64_t matches;           /* docs whose BM25 was evaluated (AND/phrase matches, OR union) */
+  float kernel_ms;            /* HIP-event time of the dominant (scan) kernel, last batch */
+  float total_ms;             /* HIP-event time of the whole batch on the stream */
+  uint32_t tiles;
+  uint32_t chunks;
+} tq_batch_stats;
+int tq_last_batch_stats(tq_segment *seg, tq_batch_stats *out);
+/* knobs: "exhaustive" (0/1, default 1: score every match; 0: block-max pruning),
+ *        "timing" (0/1: record HIP events per batch), "count_matches" (0/1) */
+int tq_set_option(tq_segment *seg, const char *name, int64_t value);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

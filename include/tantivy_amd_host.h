@@ -1,0 +1,70 @@
+/*
+ * tantivy_amd_host.h — flat C entry points over the C++ host mirror (tantivy_amd/host/): the
+ * Searcher / Query::weight / TopDocs surface of the reference (src/core/searcher.rs:180-238,
+ * src/query/query.rs:128-160, src/collector/top_score_collector.rs:61-96) driving the device
+ * through tantivy_amd.h.  Used by the Python tests and bench; a C++ application includes
+ * tantivy_amd/host/searcher.hpp directly.
+ */
+#ifndef TANTIVY_AMD_HOST_H
+#define TANTIVY_AMD_HOST_H
+#include "tantivy_amd.h"
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct tqh_searcher tqh_searcher;
+
+/* TermInfo (src/postings/term_info.rs:10-17) keyed by a caller-chosen term id; stands in for the
+ * reference's TermDictionary, which stays with the caller (termdict untouched). */
+typedef struct tqh_term_info {
+  uint32_t term_id;
+  uint32_t doc_freq;
+  uint64_t postings_start, postings_end, positions_start, positions_end;
+} tqh_term_info;
+
+/* mode: 0 = BooleanQuery of Must term clauses, 1 = BooleanQuery of Should term clauses,
+ *       2 = PhraseQuery (offsets 0..n unless phrase_offsets given), 3 = TermQuery */
+typedef struct tqh_query {
+  uint8_t mode;
+  uint32_t n_terms;
+  const uint32_t *terms;
+  const uint32_t *phrase_offsets;
+} tqh_query;
+
+const char *tqh_last_error(void);
+int tqh_searcher_new(tq_ctx *ctx, tqh_searcher **out);
+void tqh_searcher_free(tqh_searcher *s);
+/* SegmentReader for one field of one segment; segment_ord = order of addition. */
+int tqh_searcher_add_segment(tqh_searcher *s, int device, uint32_t max_doc, uint8_t record_option,
+                             const uint8_t *idx, size_t idx_len, const uint8_t *pos,
+                             size_t pos_len, const uint8_t *fieldnorm, size_t fn_len,
+                             const tqh_term_info *terms, uint32_t n_terms);
+/* Bm25StatisticsProvider input for segments held by other ranks (src/query/bm25.rs:11-50):
+ * their max_doc, total_num_tokens and per-term doc_freq are added to the local sums. */
+int tqh_searcher_add_remote_stats(tqh_searcher *s, uint64_t max_doc, uint64_t total_num_tokens,
+                                  const uint32_t *term_ids, const uint32_t *doc_freqs,
+                                  uint32_t n_terms);
+/* Query::weight for every query of a batch (global BM25 statistics + executor choice). */
+int tqh_prepare_batch(tqh_searcher *s, const tqh_query *queries, uint32_t n);
+/* Searcher::search of the prepared batch with TopDocs::with_limit(limit).and_offset(offset):
+ * outputs [n][limit], (score desc, segment_ord asc, doc asc). */
+int tqh_search_prepared(tqh_searcher *s, uint32_t offset, uint32_t limit, float *scores,
+                        uint32_t *segment_ords, uint32_t *docs, uint32_t *counts);
+/* Collector::collect_segment of the prepared batch on one segment: [n][k] sorted. */
+int tqh_collect_segment_prepared(tqh_searcher *s, uint32_t segment_ord, uint32_t k, float *scores,
+                                 uint32_t *docs, uint32_t *counts);
+/* Same with DEVICE output pointers, enqueued on hip_stream without a host sync. */
+int tqh_collect_segment_prepared_device(tqh_searcher *s, uint32_t segment_ord, uint32_t k,
+                                        float *d_scores, uint32_t *d_docs, uint32_t *d_counts,
+                                        void *hip_stream);
+/* Bm25Weight::for_terms(...).boost_by(boost): weight + 256-entry tf cache. */
+int tqh_bm25_for_terms(const uint64_t *term_doc_freqs, uint32_t n_terms, uint64_t total_num_docs,
+                       uint64_t total_num_tokens, float boost, float *weight_out,
+                       float *cache_out);
+tq_segment *tqh_segment_raw(tqh_searcher *s, uint32_t segment_ord);
+uint32_t tqh_term_handle(tqh_searcher *s, uint32_t segment_ord, uint32_t term_id);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

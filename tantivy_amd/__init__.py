@@ -1,0 +1,6 @@
+"""tantivy_amd — MI355X-native query-execution path for tantivy (posting decode, AND/OR/phrase,
+BM25, top-k) behind a C ABI (include/tantivy_amd.h).  This package is only the Python binding of
+that library; there is no CPU fallback: importing `binding` without the built HIP library raises.
+"""
+from .binding import (DeviceIndex, TantivyAmdError, lib, MODE_AND, MODE_OR, MODE_PHRASE,  # noqa: F401
+                      MODE_TERM, TERMINATED)

@@ -1,0 +1,324 @@
+"""ctypes binding of libtantivy_amd.so: the raw C ABI (tq_*) and the C++ host mirror (tqh_*)."""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libtantivy_amd.so")
+
+TERMINATED = 0x7FFFFFFF
+TERM_ABSENT = 0xFFFFFFFF
+MODE_AND, MODE_OR, MODE_PHRASE, MODE_TERM = 0, 1, 2, 3
+BASIC, WITH_FREQS, WITH_FREQS_AND_POSITIONS = 0, 1, 2
+
+
+class TantivyAmdError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("tantivy_amd error %d: %s" % (code, msg))
+        self.code = code
+
+
+class TqQuery(C.Structure):
+    _fields_ = [("n_terms", C.c_uint32), ("terms", C.POINTER(C.c_uint32)),
+                ("weights", C.POINTER(C.c_float)), ("tf_cache", C.POINTER(C.c_float)),
+                ("mode", C.c_uint8), ("phrase_offsets", C.POINTER(C.c_uint32)),
+                ("k", C.c_uint32)]
+
+
+class TqBatchStats(C.Structure):
+    _fields_ = [("algorithmic_bytes", C.c_uint64), ("matches", C.c_uint64),
+                ("kernel_ms", C.c_float), ("total_ms", C.c_float), ("tiles", C.c_uint32),
+                ("chunks", C.c_uint32)]
+
+
+class TqhTermInfo(C.Structure):
+    _fields_ = [("term_id", C.c_uint32), ("doc_freq", C.c_uint32), ("postings_start", C.c_uint64),
+                ("postings_end", C.c_uint64), ("positions_start", C.c_uint64),
+                ("positions_end", C.c_uint64)]
+
+
+class TqhQuery(C.Structure):
+    _fields_ = [("mode", C.c_uint8), ("n_terms", C.c_uint32), ("terms", C.POINTER(C.c_uint32)),
+                ("phrase_offsets", C.POINTER(C.c_uint32))]
+
+
+_lib = None
+
+EXPORTS = [
+    "tq_init", "tq_shutdown", "tq_last_error", "tq_segment_upload", "tq_segment_free",
+    "tq_term_prepare", "tq_search_batch", "tq_search_batch_device", "tq_merge_topk",
+    "tq_merge_topk_device", "tq_decode_postings", "tq_decode_position_deltas",
+    "tq_last_batch_stats", "tq_set_option",
+    "tqh_last_error", "tqh_searcher_new", "tqh_searcher_free", "tqh_searcher_add_segment",
+    "tqh_prepare_batch", "tqh_search_prepared", "tqh_collect_segment_prepared",
+    "tqh_collect_segment_prepared_device", "tqh_searcher_add_remote_stats",
+    "tqh_bm25_for_terms", "tqh_segment_raw", "tqh_term_handle",
+]
+
+
+def lib():
+    """Loads the HIP library.  No fallback: a missing library is an error."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise TantivyAmdError(-1, "%s not built (run `python -m tantivy_amd.build` or "
+                                  "__graft_entry__.build())" % LIB_PATH)
+    L = C.CDLL(LIB_PATH)
+    vp, u8p, u32p, f32p = C.c_void_p, C.POINTER(C.c_uint8), C.POINTER(C.c_uint32), C.POINTER(C.c_float)
+    L.tq_last_error.restype = C.c_char_p
+    L.tqh_last_error.restype = C.c_char_p
+    L.tq_init.argtypes = [C.POINTER(C.c_int), C.c_int, C.POINTER(vp)]
+    L.tq_shutdown.argtypes = [vp]
+    L.tq_segment_upload.argtypes = [vp, C.c_int, C.c_uint32, vp, C.c_size_t, vp, C.c_size_t, vp,
+                                    C.c_size_t, C.c_uint8, C.POINTER(vp)]
+    L.tq_segment_free.argtypes = [vp]
+    L.tq_term_prepare.argtypes = [vp, C.c_uint64, C.c_uint32, C.c_uint64, C.c_uint32, C.c_uint32,
+                                  u32p]
+    L.tq_search_batch.argtypes = [vp, C.POINTER(TqQuery), C.c_uint32, C.c_uint32, f32p, u32p, u32p]
+    L.tq_search_batch_device.argtypes = [vp, C.POINTER(TqQuery), C.c_uint32, C.c_uint32, vp, vp,
+                                         vp, vp]
+    L.tq_merge_topk.argtypes = [f32p, u32p, u32p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
+                                C.c_uint32, f32p, u32p, u32p, u32p]
+    L.tq_merge_topk_device.argtypes = [vp, C.c_int, vp, vp, vp, vp, C.c_uint32, C.c_uint32,
+                                       C.c_uint32, C.c_uint32, C.c_uint32, vp, vp, vp, vp, vp]
+    L.tq_decode_postings.argtypes = [vp, C.c_uint32, u32p, u32p]
+    L.tq_decode_position_deltas.argtypes = [vp, C.c_uint32, u32p, C.c_uint64,
+                                            C.POINTER(C.c_uint64)]
+    L.tq_last_batch_stats.argtypes = [vp, C.POINTER(TqBatchStats)]
+    L.tq_set_option.argtypes = [vp, C.c_char_p, C.c_int64]
+    L.tqh_searcher_new.argtypes = [vp, C.POINTER(vp)]
+    L.tqh_searcher_free.argtypes = [vp]
+    L.tqh_searcher_add_segment.argtypes = [vp, C.c_int, C.c_uint32, C.c_uint8, vp, C.c_size_t, vp,
+                                           C.c_size_t, vp, C.c_size_t, C.POINTER(TqhTermInfo),
+                                           C.c_uint32]
+    L.tqh_prepare_batch.argtypes = [vp, C.POINTER(TqhQuery), C.c_uint32]
+    L.tqh_search_prepared.argtypes = [vp, C.c_uint32, C.c_uint32, f32p, u32p, u32p, u32p]
+    L.tqh_collect_segment_prepared.argtypes = [vp, C.c_uint32, C.c_uint32, f32p, u32p, u32p]
+    L.tqh_collect_segment_prepared_device.argtypes = [vp, C.c_uint32, C.c_uint32, vp, vp, vp, vp]
+    L.tqh_searcher_add_remote_stats.argtypes = [vp, C.c_uint64, C.c_uint64, u32p, u32p, C.c_uint32]
+    L.tqh_bm25_for_terms.argtypes = [C.POINTER(C.c_uint64), C.c_uint32, C.c_uint64, C.c_uint64,
+                                     C.c_float, f32p, f32p]
+    L.tqh_segment_raw.restype = vp
+    L.tqh_segment_raw.argtypes = [vp, C.c_uint32]
+    L.tqh_term_handle.restype = C.c_uint32
+    L.tqh_term_handle.argtypes = [vp, C.c_uint32, C.c_uint32]
+    _lib = L
+    return L
+
+
+def _check(rc, host=False):
+    if rc != 0:
+        L = lib()
+        msg = (L.tqh_last_error() if host else L.tq_last_error()) or b""
+        if host and not msg:
+            msg = L.tq_last_error() or b""
+        raise TantivyAmdError(rc, msg.decode("utf-8", "replace"))
+
+
+def _f32(a):
+    return a.ctypes.data_as(C.POINTER(C.c_float))
+
+
+def _u32(a):
+    return a.ctypes.data_as(C.POINTER(C.c_uint32))
+
+
+def bm25_for_terms(doc_freqs, total_num_docs, total_num_tokens, boost=1.0):
+    """Product-side Bm25Weight::for_terms: returns (weight, cache[256])."""
+    dfs = (C.c_uint64 * len(doc_freqs))(*[int(d) for d in doc_freqs])
+    w = C.c_float()
+    cache = np.zeros(256, np.float32)
+    _check(lib().tqh_bm25_for_terms(dfs, len(doc_freqs), int(total_num_docs), int(total_num_tokens),
+                                    C.c_float(boost), C.byref(w), _f32(cache)), host=True)
+    return float(w.value), cache
+
+
+class DeviceIndex:
+    """A Searcher over device-resident segments (C++ host mirror, tantivy_amd/host/searcher.hpp).
+
+    segments: iterable of objects with max_doc, record_option, idx (np.uint8, header included),
+    pos, fieldnorm (or None) and terms: list of (doc_freq, postings_start, postings_end,
+    positions_start, positions_end); term id = list index.
+    """
+
+    def __init__(self, segments=(), devices=None):
+        L = lib()
+        self._ctx = C.c_void_p()
+        devs = list(devices) if devices is not None else [0]
+        arr = (C.c_int * len(devs))(*devs)
+        _check(L.tq_init(arr, len(devs), C.byref(self._ctx)))
+        self._s = C.c_void_p()
+        _check(L.tqh_searcher_new(self._ctx, C.byref(self._s)), host=True)
+        self._devs = devs
+        self.n_segments = 0
+        self._keep = []
+        self._n_prepared = 0
+        for i, seg in enumerate(segments):
+            self.add_segment(seg, devs[i % len(devs)])
+
+    def add_segment(self, seg, device=0):
+        L = lib()
+        idx = np.ascontiguousarray(seg.idx[: seg.idx_len] if hasattr(seg, "idx_len") else seg.idx,
+                                   dtype=np.uint8)
+        pos_len = getattr(seg, "pos_len", len(seg.pos) if seg.pos is not None else 0)
+        pos = np.ascontiguousarray(seg.pos[:pos_len], dtype=np.uint8) if pos_len else None
+        fn = None if seg.fieldnorm is None else np.ascontiguousarray(seg.fieldnorm, dtype=np.uint8)
+        n = len(seg.terms)
+        tis = (TqhTermInfo * max(1, n))()
+        for i, t in enumerate(seg.terms):
+            if isinstance(t, (tuple, list)):
+                df, ps, pe, qs, qe = t
+            else:
+                df, ps, pe, qs, qe = (t.doc_freq, t.postings_start, t.postings_end,
+                                      t.positions_start, t.positions_end)
+            tis[i] = TqhTermInfo(i, int(df), int(ps), int(pe), int(qs), int(qe))
+        _check(L.tqh_searcher_add_segment(
+            self._s, int(device), int(seg.max_doc), int(seg.record_option),
+            idx.ctypes.data, idx.size, pos.ctypes.data if pos is not None else None,
+            pos.size if pos is not None else 0, fn.ctypes.data if fn is not None else None,
+            fn.size if fn is not None else 0, tis, n), host=True)
+        self.n_segments += 1
+
+    def add_remote_stats(self, max_doc, total_num_tokens, doc_freqs):
+        """doc_freqs: sequence indexed by term id (segments held by other ranks)."""
+        ids = np.arange(len(doc_freqs), dtype=np.uint32)
+        dfs = np.ascontiguousarray(doc_freqs, dtype=np.uint32)
+        _check(lib().tqh_searcher_add_remote_stats(self._s, int(max_doc), int(total_num_tokens),
+                                                   _u32(ids), _u32(dfs), len(dfs)), host=True)
+
+    def close(self):
+        L = lib()
+        if self._s:
+            L.tqh_searcher_free(self._s)
+            self._s = C.c_void_p()
+        if self._ctx:
+            L.tq_shutdown(self._ctx)
+            self._ctx = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- host-mirror path (Query::weight + Searcher::search)
+    def prepare(self, queries):
+        """queries: list of (mode, [term ids]) or (MODE_PHRASE, [term ids], [offsets])."""
+        n = len(queries)
+        qs = (TqhQuery * max(1, n))()
+        keep = []
+        for i, q in enumerate(queries):
+            mode, terms = q[0], q[1]
+            ta = (C.c_uint32 * len(terms))(*[int(t) for t in terms])
+            keep.append(ta)
+            qs[i].mode = mode
+            qs[i].n_terms = len(terms)
+            qs[i].terms = C.cast(ta, C.POINTER(C.c_uint32))
+            if len(q) > 2 and q[2] is not None:
+                oa = (C.c_uint32 * len(terms))(*[int(o) for o in q[2]])
+                keep.append(oa)
+                qs[i].phrase_offsets = C.cast(oa, C.POINTER(C.c_uint32))
+        _check(lib().tqh_prepare_batch(self._s, qs, n), host=True)
+        self._n_prepared = n
+
+    def search_prepared(self, limit, offset=0):
+        n = self._n_prepared
+        scores = np.zeros((n, limit), np.float32)
+        ords = np.zeros((n, limit), np.uint32)
+        docs = np.zeros((n, limit), np.uint32)
+        counts = np.zeros(n, np.uint32)
+        _check(lib().tqh_search_prepared(self._s, int(offset), int(limit), _f32(scores),
+                                         _u32(ords), _u32(docs), _u32(counts)), host=True)
+        return scores, ords, docs, counts
+
+    def collect_segment_prepared(self, segment_ord, k):
+        n = self._n_prepared
+        scores = np.zeros((n, k), np.float32)
+        docs = np.zeros((n, k), np.uint32)
+        counts = np.zeros(n, np.uint32)
+        _check(lib().tqh_collect_segment_prepared(self._s, int(segment_ord), int(k), _f32(scores),
+                                                  _u32(docs), _u32(counts)), host=True)
+        return scores, docs, counts
+
+    def collect_segment_prepared_device(self, segment_ord, k, d_scores, d_docs, d_counts,
+                                        stream=None):
+        """torch tensors (float32 [n,k], int32 [n,k], int32 [n]) on the segment's GPU."""
+        _check(lib().tqh_collect_segment_prepared_device(
+            self._s, int(segment_ord), int(k), d_scores.data_ptr(), d_docs.data_ptr(),
+            d_counts.data_ptr(), C.c_void_p(stream) if stream else None), host=True)
+
+    @property
+    def ctx(self):
+        return self._ctx
+
+    def search(self, queries, limit, offset=0):
+        self.prepare(queries)
+        return self.search_prepared(limit, offset)
+
+    # ---- raw C ABI access (parity tests)
+    def segment_raw(self, segment_ord=0):
+        return C.c_void_p(lib().tqh_segment_raw(self._s, segment_ord))
+
+    def term_handle(self, term_id, segment_ord=0):
+        return lib().tqh_term_handle(self._s, segment_ord, int(term_id))
+
+    def decode_postings(self, term_id, doc_freq, segment_ord=0):
+        h = self.term_handle(term_id, segment_ord)
+        if h == TERM_ABSENT:
+            raise TantivyAmdError(1, lib().tq_last_error().decode() or "term absent")
+        docs = np.zeros(max(1, doc_freq), np.uint32)
+        tfs = np.zeros(max(1, doc_freq), np.uint32)
+        _check(lib().tq_decode_postings(self.segment_raw(segment_ord), h, _u32(docs), _u32(tfs)))
+        return docs[:doc_freq], tfs[:doc_freq]
+
+    def decode_position_deltas(self, term_id, cap, segment_ord=0):
+        h = self.term_handle(term_id, segment_ord)
+        out = np.zeros(max(1, cap), np.uint32)
+        n = C.c_uint64()
+        _check(lib().tq_decode_position_deltas(self.segment_raw(segment_ord), h, _u32(out), cap,
+                                               C.byref(n)))
+        return out[: min(cap, n.value)], n.value
+
+    def set_option(self, name, value, segment_ord=None):
+        ords = range(self.n_segments) if segment_ord is None else [segment_ord]
+        for o in ords:
+            _check(lib().tq_set_option(self.segment_raw(o), name.encode(), int(value)))
+
+    def last_batch_stats(self, segment_ord=0):
+        st = TqBatchStats()
+        _check(lib().tq_last_batch_stats(self.segment_raw(segment_ord), C.byref(st)))
+        return {"algorithmic_bytes": st.algorithmic_bytes, "matches": st.matches,
+                "kernel_ms": st.kernel_ms, "total_ms": st.total_ms, "tiles": st.tiles,
+                "chunks": st.chunks}
+
+    def raw_search(self, queries, weights, cache, k, segment_ord=0, stride=None):
+        """Direct tq_search_batch: queries = list of (mode, [term ids], offsets|None);
+        weights = list of per-query float lists; cache = np.float32[256]."""
+        n = len(queries)
+        stride = k if stride is None else stride
+        qs = (TqQuery * max(1, n))()
+        keep = []
+        cache = np.ascontiguousarray(cache, np.float32)
+        for i, q in enumerate(queries):
+            mode, terms = q[0], q[1]
+            hs = (C.c_uint32 * len(terms))(*[self.term_handle(t, segment_ord) for t in terms])
+            ws = (C.c_float * len(weights[i]))(*weights[i])
+            keep += [hs, ws]
+            qs[i].n_terms = len(terms)
+            qs[i].terms = C.cast(hs, C.POINTER(C.c_uint32))
+            qs[i].weights = C.cast(ws, C.POINTER(C.c_float))
+            qs[i].tf_cache = _f32(cache)
+            qs[i].mode = mode
+            if len(q) > 2 and q[2] is not None:
+                oa = (C.c_uint32 * len(terms))(*q[2])
+                keep.append(oa)
+                qs[i].phrase_offsets = C.cast(oa, C.POINTER(C.c_uint32))
+            qs[i].k = k
+        scores = np.zeros((n, stride), np.float32)
+        docs = np.zeros((n, stride), np.uint32)
+        counts = np.zeros(n, np.uint32)
+        _check(lib().tq_search_batch(self.segment_raw(segment_ord), qs, n, stride, _f32(scores),
+                                     _u32(docs), _u32(counts)))
+        return scores, docs, counts

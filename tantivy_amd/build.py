@@ -1,0 +1,50 @@
+"""Builds tantivy_amd/lib/libtantivy_amd.so (HIP kernels + C ABI + C++ host mirror) for gfx950.
+
+hipcc cross-compiles without a GPU.  -ffp-contract=off: BM25 is add / IEEE divide / multiply with
+no fused multiply-add, like the reference."""
+import os
+import subprocess
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB = os.path.join(HERE, "lib", "libtantivy_amd.so")
+SOURCES = [
+    os.path.join(HERE, "csrc", "tq_kernels.hip"),
+    os.path.join(HERE, "csrc", "tq_api.cpp"),
+    os.path.join(HERE, "host", "searcher.cpp"),
+    os.path.join(HERE, "host", "host_capi.cpp"),
+]
+HEADERS = [
+    os.path.join(HERE, "csrc", "tq_device.h"),
+    os.path.join(HERE, "csrc", "tq_launch.h"),
+    os.path.join(HERE, "host", "searcher.hpp"),
+    os.path.join(HERE, "host", "bm25.hpp"),
+    os.path.join(os.path.dirname(HERE), "include", "tantivy_amd.h"),
+    os.path.join(os.path.dirname(HERE), "include", "tantivy_amd_host.h"),
+]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared",
+         "-Wall", "-Wno-unused-function"]
+
+
+def up_to_date():
+    if not os.path.exists(LIB):
+        return False
+    m = os.path.getmtime(LIB)
+    return all(os.path.getmtime(p) <= m for p in SOURCES + HEADERS)
+
+
+def build(force=False, verbose=False):
+    if not force and up_to_date():
+        return LIB
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    if not os.path.exists(hipcc):
+        hipcc = "hipcc"
+    os.makedirs(os.path.dirname(LIB), exist_ok=True)
+    cmd = [hipcc] + FLAGS + ["-o", LIB] + SOURCES
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force=True, verbose=True))

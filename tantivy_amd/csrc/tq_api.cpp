@@ -1,0 +1,933 @@
+// tq_api.cpp — the C ABI of include/tantivy_amd.h: segment residency, skip-list unrolling,
+// batch planning (tiles / chunks / partial lists) and kernel launches.  Compiled with hipcc.
+//
+// Host-side format walkers restate (file:line under the tantivy checkout):
+//   skip entries        src/postings/skip.rs:205-253,275-302
+//   list framing        src/postings/block_segment_postings.rs:78-88,107-116
+//   vint tail           src/postings/compression/vint.rs:44-108
+//   positions framing   src/positions/reader.rs:43-56,84-101
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "../../include/tantivy_amd.h"
+#include "tq_device.h"
+#include "tq_launch.h"
+
+namespace {
+
+thread_local std::string g_last_error;
+
+int fail(int code, const char *fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  g_last_error = buf;
+  return code;
+}
+#define HIP_TRY(expr)                                                                    \
+  do {                                                                                   \
+    hipError_t e__ = (expr);                                                             \
+    if (e__ != hipSuccess)                                                               \
+      return fail(TQ_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e__),    \
+                  __FILE__, __LINE__);                                                   \
+  } while (0)
+
+constexpr size_t PAD = 64;  // over-read slack after every device byte buffer
+
+// A grow-only device buffer.
+struct DevBuf {
+  void *p = nullptr;
+  size_t cap = 0;
+  int ensure(size_t n) {
+    if (n <= cap) return TQ_OK;
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    size_t ncap = std::max(n, cap * 2);
+    HIP_TRY(hipMalloc(&p, ncap));
+    cap = ncap;
+    return TQ_OK;
+  }
+  void release() {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    cap = 0;
+  }
+};
+struct PinnedBuf {
+  void *p = nullptr;
+  size_t cap = 0;
+  int ensure(size_t n) {
+    if (n <= cap) return TQ_OK;
+    if (p) (void)hipHostFree(p);
+    p = nullptr;
+    size_t ncap = std::max(n, cap * 2);
+    HIP_TRY(hipHostMalloc(&p, ncap, hipHostMallocDefault));
+    cap = ncap;
+    return TQ_OK;
+  }
+  void release() {
+    if (p) (void)hipHostFree(p);
+    p = nullptr;
+    cap = 0;
+  }
+};
+
+struct TermHost {
+  void *blob = nullptr;  // one device allocation holding every per-term array
+  uint32_t doc_freq = 0, n_blocks = 0, n_full = 0, n_tail = 0;
+  uint32_t last_doc = 0;
+  uint64_t postings_len = 0, positions_len = 0;
+  uint64_t n_positions = 0;
+};
+
+inline uint32_t rd32(const uint8_t *p) {
+  return (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24);
+}
+// common VInt (common/src/vint.rs:61-112): stop bit on the LAST byte
+bool read_vint(const uint8_t *d, size_t len, size_t &at, uint64_t &out) {
+  uint64_t r = 0;
+  unsigned shift = 0;
+  while (at < len) {
+    uint8_t b = d[at++];
+    r |= (uint64_t)(b & 127u) << shift;
+    if (b & 128u) {
+      out = r;
+      return true;
+    }
+    shift += 7;
+    if (shift > 63) return false;
+  }
+  return false;
+}
+bool read_vint32_block(const uint8_t *d, size_t len, size_t &at, uint32_t &out) {
+  uint32_t r = 0, shift = 0;
+  while (at < len) {
+    uint8_t b = d[at++];
+    r += (uint32_t)(b & 127u) << shift;
+    if (b & 128u) {
+      out = r;
+      return true;
+    }
+    shift += 7;
+  }
+  return false;
+}
+
+struct Options {
+  int exhaustive = 1;
+  int timing = 0;
+  int use_dpp = 1;
+};
+
+}  // namespace
+
+struct tq_ctx {
+  std::vector<int> devices;
+};
+
+struct tq_segment {
+  tq_ctx *ctx = nullptr;
+  int device = 0;
+  hipStream_t stream = nullptr;
+  uint32_t max_doc = 0;
+  uint8_t record_option = 0;
+  std::vector<uint8_t> h_idx, h_pos;
+  uint8_t *d_idx = nullptr, *d_pos = nullptr, *d_fn = nullptr;
+  TqdSegment dseg{};
+  std::vector<TermHost> terms;
+  std::vector<TqdTerm> h_dterms;
+  TqdTerm *d_terms = nullptr;
+  size_t d_terms_cap = 0;
+  bool d_terms_dirty = false;
+  std::unordered_map<uint64_t, uint32_t> term_by_off;
+  // batch scratch
+  DevBuf d_stage, d_partials, d_out_scores, d_out_docs, d_out_counts, d_misc;
+  PinnedBuf h_stage, h_out;
+  hipEvent_t ev_stage_done = nullptr, ev_t0 = nullptr, ev_t1 = nullptr, ev_k0 = nullptr,
+             ev_k1 = nullptr;
+  bool stage_in_flight = false;
+  unsigned long long *d_match_counter = nullptr;
+  Options opt;
+  tq_batch_stats stats{};
+  bool stats_pending = false;
+};
+
+extern "C" {
+
+const char *tq_last_error(void) { return g_last_error.c_str(); }
+
+int tq_init(const int *device_ids, int n_devices, tq_ctx **out) {
+  if (!out) return fail(TQ_ERR_INVALID, "tq_init: out is null");
+  int count = 0;
+  hipError_t e = hipGetDeviceCount(&count);
+  if (e != hipSuccess || count == 0)
+    return fail(TQ_ERR_NO_DEVICE, "tq_init: no HIP device visible (%s)",
+                e == hipSuccess ? "count=0" : hipGetErrorString(e));
+  tq_ctx *ctx = new tq_ctx();
+  if (!device_ids || n_devices <= 0) {
+    ctx->devices.push_back(0);
+  } else {
+    for (int i = 0; i < n_devices; ++i) {
+      if (device_ids[i] < 0 || device_ids[i] >= count) {
+        delete ctx;
+        return fail(TQ_ERR_INVALID, "tq_init: device %d out of range (%d visible)", device_ids[i],
+                    count);
+      }
+      ctx->devices.push_back(device_ids[i]);
+    }
+  }
+  *out = ctx;
+  return TQ_OK;
+}
+
+void tq_shutdown(tq_ctx *ctx) { delete ctx; }
+
+int tq_segment_upload(tq_ctx *ctx, int device, uint32_t max_doc, const uint8_t *idx,
+                      size_t idx_len, const uint8_t *pos, size_t pos_len, const uint8_t *fieldnorm,
+                      size_t fn_len, uint8_t record_option, tq_segment **out) {
+  if (!ctx || !out || !idx) return fail(TQ_ERR_INVALID, "tq_segment_upload: null argument");
+  if (idx_len < 8) return fail(TQ_ERR_FORMAT, "idx sub-file shorter than its 8-byte header");
+  if (record_option > TQ_WITH_FREQS_AND_POSITIONS)
+    return fail(TQ_ERR_INVALID, "bad record_option %u", record_option);
+  if (fieldnorm && fn_len < max_doc)
+    return fail(TQ_ERR_FORMAT, "fieldnorm file has %zu bytes for max_doc %u", fn_len, max_doc);
+  if (std::find(ctx->devices.begin(), ctx->devices.end(), device) == ctx->devices.end())
+    return fail(TQ_ERR_INVALID, "device %d not part of this context", device);
+  HIP_TRY(hipSetDevice(device));
+  tq_segment *s = new tq_segment();
+  s->ctx = ctx;
+  s->device = device;
+  s->max_doc = max_doc;
+  s->record_option = record_option;
+  s->h_idx.assign(idx, idx + idx_len);
+  if (pos && pos_len) s->h_pos.assign(pos, pos + pos_len);
+  auto up = [&](uint8_t **dst, const uint8_t *src, size_t n) -> int {
+    HIP_TRY(hipMalloc((void **)dst, n + PAD));
+    HIP_TRY(hipMemset(*dst + n, 0, PAD));
+    HIP_TRY(hipMemcpy(*dst, src, n, hipMemcpyHostToDevice));
+    return TQ_OK;
+  };
+  int rc = up(&s->d_idx, idx, idx_len);
+  if (rc == TQ_OK && pos && pos_len) rc = up(&s->d_pos, pos, pos_len);
+  if (rc == TQ_OK && fieldnorm) rc = up(&s->d_fn, fieldnorm, max_doc);
+  if (rc == TQ_OK) {
+    hipError_t e = hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&s->ev_stage_done, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreate(&s->ev_t0);
+    if (e == hipSuccess) e = hipEventCreate(&s->ev_t1);
+    if (e == hipSuccess) e = hipEventCreate(&s->ev_k0);
+    if (e == hipSuccess) e = hipEventCreate(&s->ev_k1);
+    if (e == hipSuccess) e = hipMalloc((void **)&s->d_match_counter, sizeof(unsigned long long));
+    if (e != hipSuccess) rc = fail(TQ_ERR_HIP, "segment setup: %s", hipGetErrorString(e));
+  }
+  if (rc != TQ_OK) {
+    tq_segment_free(s);
+    return rc;
+  }
+  s->dseg.idx = s->d_idx;
+  s->dseg.pos = s->d_pos;
+  s->dseg.fieldnorm = s->d_fn;
+  s->dseg.max_doc = max_doc;
+  s->dseg.const_fieldnorm_id = 1;  // FieldNormReader::constant(max_doc, 1)
+  *out = s;
+  return TQ_OK;
+}
+
+void tq_segment_free(tq_segment *s) {
+  if (!s) return;
+  (void)hipSetDevice(s->device);
+  if (s->stream) (void)hipStreamSynchronize(s->stream);
+  for (auto &t : s->terms)
+    if (t.blob) (void)hipFree(t.blob);
+  if (s->d_terms) (void)hipFree(s->d_terms);
+  if (s->d_idx) (void)hipFree(s->d_idx);
+  if (s->d_pos) (void)hipFree(s->d_pos);
+  if (s->d_fn) (void)hipFree(s->d_fn);
+  if (s->d_match_counter) (void)hipFree(s->d_match_counter);
+  s->d_stage.release();
+  s->d_partials.release();
+  s->d_out_scores.release();
+  s->d_out_docs.release();
+  s->d_out_counts.release();
+  s->d_misc.release();
+  s->h_stage.release();
+  s->h_out.release();
+  for (hipEvent_t ev : {s->ev_stage_done, s->ev_t0, s->ev_t1, s->ev_k0, s->ev_k1})
+    if (ev) (void)hipEventDestroy(ev);
+  if (s->stream) (void)hipStreamDestroy(s->stream);
+  delete s;
+}
+
+int tq_term_prepare(tq_segment *s, uint64_t postings_off, uint32_t postings_len,
+                    uint64_t positions_off, uint32_t positions_len, uint32_t doc_freq,
+                    tq_term_handle *out) {
+  if (!s || !out) return fail(TQ_ERR_INVALID, "tq_term_prepare: null argument");
+  auto it = s->term_by_off.find(postings_off);
+  if (it != s->term_by_off.end()) {
+    *out = it->second;
+    return TQ_OK;
+  }
+  if (doc_freq == 0) return fail(TQ_ERR_INVALID, "tq_term_prepare: doc_freq 0 (term absent)");
+  const size_t body_len = s->h_idx.size() - 8;
+  if (postings_off > body_len || (uint64_t)postings_len > body_len - postings_off)
+    return fail(TQ_ERR_FORMAT, "postings_range [%llu,+%u) outside the idx body (%zu)",
+                (unsigned long long)postings_off, postings_len, body_len);
+  HIP_TRY(hipSetDevice(s->device));
+  const uint8_t *data = s->h_idx.data() + 8 + postings_off;
+  const size_t len = postings_len;
+  const uint64_t abs0 = 8 + postings_off;  // offset of `data` inside the uploaded sub-file
+
+  int record = s->record_option;
+  const uint32_t n_full = doc_freq / 128u, n_tail = doc_freq % 128u;
+  size_t at = 0;
+  const uint8_t *skip = nullptr;
+  size_t skip_len = 0;
+  if (doc_freq >= 128u) {  // block_segment_postings.rs:78-88
+    uint64_t sl;
+    if (!read_vint(data, len, at, sl) || sl > len - at)
+      return fail(TQ_ERR_FORMAT, "bad skip_len for term at %llu", (unsigned long long)postings_off);
+    skip = data + at;
+    skip_len = (size_t)sl;
+    at += skip_len;
+    if (skip_len < 8ull * n_full) record = TQ_BASIC;  // :107-116 (JSON terms without freqs)
+  }
+  const size_t entry = record == TQ_BASIC ? 5 : (record == TQ_WITH_FREQS ? 8 : 12);
+  if (skip_len < entry * n_full)
+    return fail(TQ_ERR_FORMAT, "skip data too short: %zu < %zu", skip_len, entry * n_full);
+  const bool has_freq = record != TQ_BASIC;
+  const size_t payload = at;
+
+  const uint32_t n_blocks = n_full + (n_tail ? 1u : 0u);
+  std::vector<TqdBlock> blocks(n_blocks);
+  std::vector<uint64_t> block_pos(n_blocks + 1, 0);
+  size_t running = 0;
+  uint64_t running_pos = 0;
+  uint32_t last_doc = 0, max_tf_code = 0;
+  for (uint32_t i = 0; i < n_full; ++i) {  // skip.rs:205-253,275-302
+    const uint8_t *e = skip + entry * i;
+    const uint32_t ld = rd32(e);
+    const uint32_t doc_bits = e[4] & 0x1Fu, strict = (e[4] >> 6) & 1u;
+    uint32_t tf_bits = 0, tf_sum = 0, bm_fn = 0, bm_tf = 0;
+    if (record == TQ_WITH_FREQS) {
+      tf_bits = e[5];
+      bm_fn = e[6];
+      bm_tf = e[7];
+    } else if (record == TQ_WITH_FREQS_AND_POSITIONS) {
+      tf_bits = e[5];
+      tf_sum = rd32(e + 6);
+      bm_fn = e[10];
+      bm_tf = e[11];
+    }
+    if (tf_bits > 32u) return fail(TQ_ERR_FORMAT, "tf bit width %u > 32", tf_bits);
+    if (i && ld <= last_doc) return fail(TQ_ERR_FORMAT, "skip last_doc not increasing");
+    blocks[i].last_doc = ld;
+    blocks[i].bits = doc_bits | (strict << 6) | (tf_bits << 8) | (bm_fn << 16) | (bm_tf << 24);
+    blocks[i].byte_off = abs0 + payload + running;
+    block_pos[i] = running_pos;
+    running += 16u * (size_t)(doc_bits + tf_bits);
+    running_pos += tf_sum;
+    last_doc = ld;
+    max_tf_code = std::max(max_tf_code, bm_tf);
+  }
+  if (payload + running > len) return fail(TQ_ERR_FORMAT, "bitpacked payload exceeds the list");
+  std::vector<uint32_t> tail_docs(n_tail), tail_tfs(n_tail, 1u);
+  if (n_tail) {  // vint.rs:44-108; docs delta from the last full block (0 if none)
+    size_t t = payload + running;
+    uint32_t prev = n_full ? last_doc : 0u;
+    for (uint32_t i = 0; i < n_tail; ++i) {
+      uint32_t d;
+      if (!read_vint32_block(data, len, t, d)) return fail(TQ_ERR_FORMAT, "truncated vint docs");
+      prev += d;
+      tail_docs[i] = prev;
+    }
+    if (has_freq && t < len) {
+      for (uint32_t i = 0; i < n_tail; ++i)
+        if (!read_vint32_block(data, len, t, tail_tfs[i]))
+          return fail(TQ_ERR_FORMAT, "truncated vint term freqs");
+    }
+    blocks[n_full].last_doc = tail_docs[n_tail - 1];
+    blocks[n_full].bits = 0xFFFFFFFFu;
+    blocks[n_full].byte_off = 0;
+    block_pos[n_full] = running_pos;
+    for (uint32_t i = 0; i < n_tail; ++i) running_pos += tail_tfs[i];
+    last_doc = tail_docs[n_tail - 1];
+  }
+  block_pos[n_blocks] = running_pos;
+  if (running_pos > 0xFFFFFFFFull)
+    return fail(TQ_ERR_UNSUPPORTED, "term with more than 2^32 positions");
+  if (last_doc >= TQ_TERMINATED) return fail(TQ_ERR_FORMAT, "doc id >= TERMINATED");
+
+  // positions stream (positions/reader.rs:43-56,84-101)
+  std::vector<uint64_t> pos_block_off;
+  std::vector<uint8_t> pos_widths;
+  std::vector<uint32_t> pos_tail;
+  const bool want_pos = s->record_option == TQ_WITH_FREQS_AND_POSITIONS && !s->h_pos.empty() &&
+                        record == TQ_WITH_FREQS_AND_POSITIONS;
+  if (want_pos) {
+    if (positions_off > s->h_pos.size() || (uint64_t)positions_len > s->h_pos.size() - positions_off)
+      return fail(TQ_ERR_FORMAT, "positions_range outside the pos file");
+    const uint8_t *pd = s->h_pos.data() + positions_off;
+    size_t pa = 0;
+    uint64_t nb;
+    if (!read_vint(pd, positions_len, pa, nb) || nb > positions_len - pa)
+      return fail(TQ_ERR_FORMAT, "bad positions header");
+    pos_widths.assign(pd + pa, pd + pa + nb);
+    pa += (size_t)nb;
+    size_t prun = 0;
+    pos_block_off.resize((size_t)nb);
+    for (size_t i = 0; i < nb; ++i) {
+      if (pos_widths[i] > 32) return fail(TQ_ERR_FORMAT, "position bit width > 32");
+      pos_block_off[i] = positions_off + pa + prun;
+      prun += 16u * (size_t)pos_widths[i];
+    }
+    size_t t = pa + prun;
+    if (t > positions_len) return fail(TQ_ERR_FORMAT, "bitpacked positions exceed the range");
+    while (t < positions_len) {  // uncompress_vint_unsorted_until_end
+      uint32_t v;
+      if (!read_vint32_block(pd, positions_len, t, v))
+        return fail(TQ_ERR_FORMAT, "truncated vint positions");
+      pos_tail.push_back(v);
+    }
+    const uint64_t n_pos = (uint64_t)nb * 128u + pos_tail.size();
+    if (n_pos != running_pos)
+      return fail(TQ_ERR_FORMAT, "positions stream holds %llu values, postings say %llu",
+                  (unsigned long long)n_pos, (unsigned long long)running_pos);
+  }
+
+  // one blob: blocks | tail_docs | tail_tfs | block_pos | pos_block_off | pos_tail | pos_widths
+  auto align16 = [](size_t x) { return (x + 15) & ~(size_t)15; };
+  const size_t o_blocks = 0;
+  const size_t o_tdocs = align16(o_blocks + sizeof(TqdBlock) * n_blocks);
+  const size_t o_ttfs = align16(o_tdocs + 4 * (size_t)n_tail);
+  const size_t o_bpos = align16(o_ttfs + 4 * (size_t)n_tail);
+  const size_t o_pboff = align16(o_bpos + 8 * (size_t)(n_blocks + 1));
+  const size_t o_ptail = align16(o_pboff + 8 * pos_block_off.size());
+  const size_t o_pw = align16(o_ptail + 4 * pos_tail.size());
+  const size_t total = align16(o_pw + pos_widths.size()) + PAD;
+  std::vector<uint8_t> hb(total, 0);
+  memcpy(hb.data() + o_blocks, blocks.data(), sizeof(TqdBlock) * n_blocks);
+  if (n_tail) {
+    memcpy(hb.data() + o_tdocs, tail_docs.data(), 4 * (size_t)n_tail);
+    memcpy(hb.data() + o_ttfs, tail_tfs.data(), 4 * (size_t)n_tail);
+  }
+  memcpy(hb.data() + o_bpos, block_pos.data(), 8 * (size_t)(n_blocks + 1));
+  if (!pos_block_off.empty()) memcpy(hb.data() + o_pboff, pos_block_off.data(), 8 * pos_block_off.size());
+  if (!pos_tail.empty()) memcpy(hb.data() + o_ptail, pos_tail.data(), 4 * pos_tail.size());
+  if (!pos_widths.empty()) memcpy(hb.data() + o_pw, pos_widths.data(), pos_widths.size());
+  uint8_t *blob = nullptr;
+  HIP_TRY(hipMalloc((void **)&blob, total));
+  hipError_t ce = hipMemcpy(blob, hb.data(), total, hipMemcpyHostToDevice);
+  if (ce != hipSuccess) {
+    (void)hipFree(blob);
+    return fail(TQ_ERR_HIP, "term upload: %s", hipGetErrorString(ce));
+  }
+  TqdTerm dt{};
+  dt.blocks = (const TqdBlock *)(blob + o_blocks);
+  dt.tail_docs = (const uint32_t *)(blob + o_tdocs);
+  dt.tail_tfs = (const uint32_t *)(blob + o_ttfs);
+  dt.block_pos = (const uint64_t *)(blob + o_bpos);
+  dt.pos_block_off = (const uint64_t *)(blob + o_pboff);
+  dt.pos_widths = (const uint8_t *)(blob + o_pw);
+  dt.pos_tail = (const uint32_t *)(blob + o_ptail);
+  dt.n_full = n_full;
+  dt.n_tail = n_tail;
+  dt.n_blocks = n_blocks;
+  dt.doc_freq = doc_freq;
+  dt.n_pos_blocks = (uint32_t)pos_block_off.size();
+  dt.n_pos_tail = (uint32_t)pos_tail.size();
+  dt.has_freq = has_freq ? 1u : 0u;
+  dt.max_bm_tf_code = max_tf_code;
+
+  TermHost th;
+  th.blob = blob;
+  th.doc_freq = doc_freq;
+  th.n_blocks = n_blocks;
+  th.n_full = n_full;
+  th.n_tail = n_tail;
+  th.last_doc = last_doc;
+  th.postings_len = postings_len;
+  th.positions_len = want_pos ? positions_len : 0;
+  th.n_positions = want_pos ? running_pos : 0;
+  const uint32_t handle = (uint32_t)s->terms.size();
+  s->terms.push_back(th);
+  s->h_dterms.push_back(dt);
+  s->d_terms_dirty = true;
+  s->term_by_off.emplace(postings_off, handle);
+  *out = handle;
+  return TQ_OK;
+}
+
+}  // extern "C"
+
+namespace {
+
+int sync_terms(tq_segment *s, hipStream_t st) {
+  if (!s->d_terms_dirty) return TQ_OK;
+  const size_t n = s->h_dterms.size();
+  if (n > s->d_terms_cap) {
+    // make sure nothing in flight still reads the old table
+    HIP_TRY(hipStreamSynchronize(st));
+    if (s->d_terms) (void)hipFree(s->d_terms);
+    s->d_terms = nullptr;
+    size_t cap = std::max<size_t>(256, n * 2);
+    HIP_TRY(hipMalloc((void **)&s->d_terms, cap * sizeof(TqdTerm)));
+    s->d_terms_cap = cap;
+  }
+  HIP_TRY(hipMemcpy(s->d_terms, s->h_dterms.data(), n * sizeof(TqdTerm), hipMemcpyHostToDevice));
+  s->d_terms_dirty = false;
+  return TQ_OK;
+}
+
+struct Group {
+  int mode;
+  std::vector<TqdQuery> queries;
+  std::vector<uint32_t> out_index;
+  std::vector<uint32_t> tile_starts;
+  uint32_t total_tiles = 0, tiles_per_chunk = 1, n_chunks = 0, max_k = 1;
+  int kpl = 1;
+  // offsets inside the staging blob
+  size_t o_queries = 0, o_tiles = 0, o_outidx = 0;
+};
+
+int kpl_for(uint32_t k) { return k <= 64 ? 1 : (k <= 128 ? 2 : (k <= 256 ? 4 : 16)); }
+
+}  // namespace
+
+extern "C" {
+
+int tq_search_batch_device(tq_segment *s, const tq_query *queries, uint32_t n_queries,
+                           uint32_t out_stride, float *d_out_scores, uint32_t *d_out_docs,
+                           uint32_t *d_out_counts, void *hip_stream) {
+  if (!s || (!queries && n_queries) || !d_out_scores || !d_out_docs || !d_out_counts)
+    return fail(TQ_ERR_INVALID, "tq_search_batch: null argument");
+  if (n_queries == 0) return TQ_OK;
+  HIP_TRY(hipSetDevice(s->device));
+  hipStream_t st = hip_stream ? (hipStream_t)hip_stream : s->stream;
+  int rc = sync_terms(s, st);
+  if (rc != TQ_OK) return rc;
+
+  // ---- plan
+  Group groups[3];
+  groups[0].mode = TQ_MODE_AND;
+  groups[1].mode = TQ_MODE_OR;
+  groups[2].mode = TQ_MODE_PHRASE;
+  std::vector<const float *> caches;
+  uint64_t algo_bytes = 0;
+  for (uint32_t qi = 0; qi < n_queries; ++qi) {
+    const tq_query &q = queries[qi];
+    if (q.n_terms == 0 || q.n_terms > TQ_MAX_TERMS)
+      return fail(TQ_ERR_INVALID, "query %u: n_terms %u not in 1..%u", qi, q.n_terms, TQ_MAX_TERMS);
+    if (q.k == 0 || q.k > TQ_MAX_K || q.k > out_stride)
+      return fail(TQ_ERR_INVALID, "query %u: k %u not in 1..min(%u, out_stride %u)", qi, q.k,
+                  TQ_MAX_K, out_stride);
+    if (!q.terms || !q.weights || !q.tf_cache)
+      return fail(TQ_ERR_INVALID, "query %u: null terms/weights/tf_cache", qi);
+    if (q.mode > TQ_MODE_PHRASE) return fail(TQ_ERR_INVALID, "query %u: bad mode", qi);
+    if (q.mode == TQ_MODE_PHRASE && (q.n_terms < 2 || !q.phrase_offsets))
+      return fail(TQ_ERR_INVALID, "query %u: a phrase needs >= 2 terms and offsets", qi);
+    if (q.mode == TQ_MODE_PHRASE && q.n_terms > 8)
+      return fail(TQ_ERR_UNSUPPORTED, "query %u: device phrases take at most 8 terms", qi);
+    uint32_t cache_idx = 0;
+    for (; cache_idx < caches.size(); ++cache_idx)
+      if (caches[cache_idx] == q.tf_cache) break;
+    if (cache_idx == caches.size()) caches.push_back(q.tf_cache);
+
+    TqdQuery dq{};
+    dq.k = q.k;
+    dq.cache_idx = cache_idx;
+    dq.mode = q.mode;
+    bool any_absent = false;
+    for (uint32_t i = 0; i < q.n_terms; ++i) {
+      if (q.terms[i] == TQ_TERM_ABSENT) {
+        any_absent = true;
+        continue;
+      }
+      if (q.terms[i] >= s->terms.size())
+        return fail(TQ_ERR_INVALID, "query %u: unknown term handle %u", qi, q.terms[i]);
+    }
+    int mode = q.mode;
+    uint32_t n_tiles = 0;
+    uint64_t qbytes = 8ull * q.k;
+    if (mode == TQ_MODE_AND || mode == TQ_MODE_PHRASE) {
+      if (!any_absent) {
+        // stable sort by doc_freq asc (block_wand_intersection.rs:26-29 / intersection.rs:93)
+        uint32_t order[TQ_MAX_TERMS];
+        for (uint32_t i = 0; i < q.n_terms; ++i) order[i] = i;
+        std::stable_sort(order, order + q.n_terms, [&](uint32_t a, uint32_t b) {
+          return s->terms[q.terms[a]].doc_freq < s->terms[q.terms[b]].doc_freq;
+        });
+        uint32_t max_off = 0;
+        if (mode == TQ_MODE_PHRASE)
+          for (uint32_t i = 0; i < q.n_terms; ++i) max_off = std::max(max_off, q.phrase_offsets[i]);
+        for (uint32_t i = 0; i < q.n_terms; ++i) {
+          const uint32_t src = order[i];
+          dq.term[i] = q.terms[src];
+          dq.weight[i] = mode == TQ_MODE_PHRASE ? q.weights[0] : q.weights[src];
+          if (mode == TQ_MODE_PHRASE) dq.phrase_off[i] = max_off - q.phrase_offsets[src];
+          if (mode == TQ_MODE_AND && q.n_terms > 2 && !(dq.weight[i] >= 0.0f))
+            return fail(TQ_ERR_UNSUPPORTED, "query %u: negative weight in a 3+ term AND", qi);
+          qbytes += s->terms[q.terms[src]].postings_len;
+          if (mode == TQ_MODE_PHRASE) {
+            if (s->terms[q.terms[src]].positions_len == 0)
+              return fail(TQ_ERR_UNSUPPORTED, "query %u: phrase on a field without positions", qi);
+            qbytes += s->terms[q.terms[src]].positions_len;
+          }
+        }
+        dq.n_terms = q.n_terms;
+        if (mode == TQ_MODE_AND && q.n_terms == 1) {
+          mode = TQ_MODE_OR;  // TermWeight::for_each_pruning: every doc of the list
+        } else {
+          const uint32_t drv_blocks = s->terms[dq.term[q.n_terms - 1]].n_blocks;
+          n_tiles = (drv_blocks + TQD_AND_M - 1) / TQD_AND_M;
+        }
+      }
+    }
+    if (mode == TQ_MODE_OR) {
+      if (q.mode == TQ_MODE_OR) {
+        uint32_t n = 0;
+        for (uint32_t i = 0; i < q.n_terms; ++i) {
+          if (q.terms[i] == TQ_TERM_ABSENT) continue;
+          dq.term[n] = q.terms[i];
+          dq.weight[n] = q.weights[i];
+          qbytes += s->terms[q.terms[i]].postings_len;
+          ++n;
+        }
+        dq.n_terms = n;
+      }
+      uint32_t max_last = 0;
+      for (uint32_t i = 0; i < dq.n_terms; ++i)
+        max_last = std::max(max_last, s->terms[dq.term[i]].last_doc);
+      if (dq.n_terms) n_tiles = max_last / TQD_OR_WINDOW + 1;
+    }
+    algo_bytes += qbytes;
+    dq.n_tiles = n_tiles;
+    Group &g = groups[mode];
+    dq.mode = (uint32_t)mode;
+    g.queries.push_back(dq);
+    g.out_index.push_back(qi);
+    g.max_k = std::max(g.max_k, q.k);
+  }
+  // tiles -> chunks -> partial lists
+  uint32_t total_parts = 0;
+  size_t partial_bytes = 0;
+  for (Group &g : groups) {
+    if (g.queries.empty()) continue;
+    g.kpl = kpl_for(g.max_k);
+    g.tile_starts.resize(g.queries.size() + 1);
+    uint64_t acc = 0;
+    for (size_t i = 0; i < g.queries.size(); ++i) {
+      g.tile_starts[i] = (uint32_t)acc;
+      g.queries[i].tile_start = (uint32_t)acc;
+      acc += g.queries[i].n_tiles;
+      if (acc > 0x7FFFFFFFull) return fail(TQ_ERR_UNSUPPORTED, "batch too large (tiles)");
+    }
+    g.tile_starts[g.queries.size()] = (uint32_t)acc;
+    g.total_tiles = (uint32_t)acc;
+    const uint32_t target = g.mode == TQ_MODE_OR ? 8192u : 20480u;
+    g.tiles_per_chunk = std::max<uint32_t>(1, (g.total_tiles + target - 1) / target);
+    g.n_chunks = (g.total_tiles + g.tiles_per_chunk - 1) / g.tiles_per_chunk;
+    const uint32_t per_chunk = g.mode == TQ_MODE_OR ? TQD_WAVES_PER_WG : 1u;
+    for (TqdQuery &dq : g.queries) {
+      dq.part_start = 0;
+      dq.n_parts = 0;
+      if (dq.n_tiles) {
+        const uint32_t first = dq.tile_start / g.tiles_per_chunk;
+        const uint32_t last = (dq.tile_start + dq.n_tiles - 1) / g.tiles_per_chunk;
+        dq.n_parts = (last - first + 1) * per_chunk;
+      }
+    }
+  }
+  // partial lists of all groups share one buffer; its stride is per group (kpl*64 keys)
+  size_t part_off_bytes[3] = {0, 0, 0};
+  for (int gi = 0; gi < 3; ++gi) {
+    Group &g = groups[gi];
+    part_off_bytes[gi] = partial_bytes;
+    uint32_t parts = 0;
+    for (TqdQuery &dq : g.queries) {
+      dq.part_start = parts;
+      parts += dq.n_parts;
+    }
+    total_parts += parts;
+    partial_bytes += (size_t)parts * (size_t)g.kpl * 64u * sizeof(uint64_t);
+  }
+  rc = s->d_partials.ensure(partial_bytes + 256);
+  if (rc != TQ_OK) return rc;
+
+  // ---- stage: [caches][per group: queries | tile_starts | out_index]
+  size_t stage = 0;
+  const size_t o_caches = 0;
+  stage += caches.size() * 256 * sizeof(float);
+  for (Group &g : groups) {
+    if (g.queries.empty()) continue;
+    stage = (stage + 15) & ~(size_t)15;
+    g.o_queries = stage;
+    stage += g.queries.size() * sizeof(TqdQuery);
+    stage = (stage + 15) & ~(size_t)15;
+    g.o_tiles = stage;
+    stage += g.tile_starts.size() * sizeof(uint32_t);
+    stage = (stage + 15) & ~(size_t)15;
+    g.o_outidx = stage;
+    stage += g.out_index.size() * sizeof(uint32_t);
+  }
+  if (s->stage_in_flight) {
+    HIP_TRY(hipEventSynchronize(s->ev_stage_done));
+    s->stage_in_flight = false;
+  }
+  rc = s->h_stage.ensure(stage);
+  if (rc == TQ_OK) rc = s->d_stage.ensure(stage);
+  if (rc != TQ_OK) return rc;
+  uint8_t *hs = (uint8_t *)s->h_stage.p;
+  for (size_t c = 0; c < caches.size(); ++c)
+    memcpy(hs + o_caches + c * 256 * sizeof(float), caches[c], 256 * sizeof(float));
+  for (Group &g : groups) {
+    if (g.queries.empty()) continue;
+    memcpy(hs + g.o_queries, g.queries.data(), g.queries.size() * sizeof(TqdQuery));
+    memcpy(hs + g.o_tiles, g.tile_starts.data(), g.tile_starts.size() * sizeof(uint32_t));
+    memcpy(hs + g.o_outidx, g.out_index.data(), g.out_index.size() * sizeof(uint32_t));
+  }
+  if (s->opt.timing) HIP_TRY(hipEventRecord(s->ev_t0, st));
+  HIP_TRY(hipMemcpyAsync(s->d_stage.p, hs, stage, hipMemcpyHostToDevice, st));
+  HIP_TRY(hipEventRecord(s->ev_stage_done, st));
+  s->stage_in_flight = true;
+  HIP_TRY(hipMemsetAsync(s->d_match_counter, 0, sizeof(unsigned long long), st));
+
+  // ---- launch
+  const uint8_t *ds = (const uint8_t *)s->d_stage.p;
+  if (s->opt.timing) HIP_TRY(hipEventRecord(s->ev_k0, st));
+  uint32_t tiles_total = 0, chunks_total = 0;
+  for (int gi = 0; gi < 3; ++gi) {
+    Group &g = groups[gi];
+    if (g.queries.empty()) continue;
+    TqkScanParams p{};
+    p.seg = s->dseg;
+    p.terms = s->d_terms;
+    p.queries = (const TqdQuery *)(ds + g.o_queries);
+    p.tile_starts = (const uint32_t *)(ds + g.o_tiles);
+    p.caches = (const float *)(ds + o_caches);
+    p.partials = (uint64_t *)((uint8_t *)s->d_partials.p + part_off_bytes[gi]);
+    p.match_counter = s->d_match_counter;
+    p.n_queries = (uint32_t)g.queries.size();
+    p.total_tiles = g.total_tiles;
+    p.tiles_per_chunk = g.tiles_per_chunk;
+    p.n_chunks = g.n_chunks;
+    p.exhaustive = (uint32_t)s->opt.exhaustive;
+    tiles_total += g.total_tiles;
+    chunks_total += g.n_chunks;
+    hipError_t e = hipSuccess;
+    if (g.mode == TQ_MODE_AND)
+      e = tqk_launch_and(p, g.kpl, s->opt.use_dpp != 0, st);
+    else if (g.mode == TQ_MODE_OR)
+      e = tqk_launch_or(p, g.kpl, s->opt.use_dpp != 0, st);
+    else
+      e = tqk_launch_phrase(p, g.kpl, s->opt.use_dpp != 0, st);
+    if (e != hipSuccess) return fail(TQ_ERR_HIP, "scan kernel launch: %s", hipGetErrorString(e));
+  }
+  if (s->opt.timing) HIP_TRY(hipEventRecord(s->ev_k1, st));
+  for (int gi = 0; gi < 3; ++gi) {
+    Group &g = groups[gi];
+    if (g.queries.empty()) continue;
+    TqkMergeParams m{};
+    m.queries = (const TqdQuery *)(ds + g.o_queries);
+    m.partials = (const uint64_t *)((const uint8_t *)s->d_partials.p + part_off_bytes[gi]);
+    m.out_index = (const uint32_t *)(ds + g.o_outidx);
+    m.out_scores = d_out_scores;
+    m.out_docs = d_out_docs;
+    m.out_counts = d_out_counts;
+    m.n_queries = (uint32_t)g.queries.size();
+    m.out_stride = out_stride;
+    hipError_t e = tqk_launch_merge(m, g.kpl, st);
+    if (e != hipSuccess) return fail(TQ_ERR_HIP, "merge kernel launch: %s", hipGetErrorString(e));
+  }
+  if (s->opt.timing) HIP_TRY(hipEventRecord(s->ev_t1, st));
+  s->stats.algorithmic_bytes = algo_bytes;
+  s->stats.tiles = tiles_total;
+  s->stats.chunks = chunks_total;
+  s->stats.matches = 0;
+  s->stats.kernel_ms = 0;
+  s->stats.total_ms = 0;
+  s->stats_pending = true;
+  (void)total_parts;
+  return TQ_OK;
+}
+
+int tq_search_batch(tq_segment *s, const tq_query *queries, uint32_t n_queries,
+                    uint32_t out_stride, float *out_scores, uint32_t *out_docs,
+                    uint32_t *out_counts) {
+  if (!s || !out_scores || !out_docs || !out_counts)
+    return fail(TQ_ERR_INVALID, "tq_search_batch: null argument");
+  if (n_queries == 0) return TQ_OK;
+  HIP_TRY(hipSetDevice(s->device));
+  const size_t n = (size_t)n_queries * out_stride;
+  int rc = s->d_out_scores.ensure(n * sizeof(float));
+  if (rc == TQ_OK) rc = s->d_out_docs.ensure(n * sizeof(uint32_t));
+  if (rc == TQ_OK) rc = s->d_out_counts.ensure((size_t)n_queries * sizeof(uint32_t));
+  if (rc != TQ_OK) return rc;
+  rc = tq_search_batch_device(s, queries, n_queries, out_stride, (float *)s->d_out_scores.p,
+                              (uint32_t *)s->d_out_docs.p, (uint32_t *)s->d_out_counts.p, nullptr);
+  if (rc != TQ_OK) return rc;
+  HIP_TRY(hipMemcpyAsync(out_scores, s->d_out_scores.p, n * sizeof(float), hipMemcpyDeviceToHost,
+                         s->stream));
+  HIP_TRY(hipMemcpyAsync(out_docs, s->d_out_docs.p, n * sizeof(uint32_t), hipMemcpyDeviceToHost,
+                         s->stream));
+  HIP_TRY(hipMemcpyAsync(out_counts, s->d_out_counts.p, (size_t)n_queries * sizeof(uint32_t),
+                         hipMemcpyDeviceToHost, s->stream));
+  HIP_TRY(hipStreamSynchronize(s->stream));
+  return TQ_OK;
+}
+
+int tq_last_batch_stats(tq_segment *s, tq_batch_stats *out) {
+  if (!s || !out) return fail(TQ_ERR_INVALID, "tq_last_batch_stats: null argument");
+  HIP_TRY(hipSetDevice(s->device));
+  if (s->stats_pending) {
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    unsigned long long m = 0;
+    HIP_TRY(hipMemcpy(&m, s->d_match_counter, sizeof m, hipMemcpyDeviceToHost));
+    s->stats.matches = m;
+    s->stats.algorithmic_bytes += m;  // 1 fieldnorm byte per scored doc
+    if (s->opt.timing) {
+      float ms = 0;
+      if (hipEventElapsedTime(&ms, s->ev_k0, s->ev_k1) == hipSuccess) s->stats.kernel_ms = ms;
+      if (hipEventElapsedTime(&ms, s->ev_t0, s->ev_t1) == hipSuccess) s->stats.total_ms = ms;
+    }
+    s->stats_pending = false;
+  }
+  *out = s->stats;
+  return TQ_OK;
+}
+
+int tq_set_option(tq_segment *s, const char *name, int64_t value) {
+  if (!s || !name) return fail(TQ_ERR_INVALID, "tq_set_option: null argument");
+  if (!strcmp(name, "exhaustive"))
+    s->opt.exhaustive = value != 0;
+  else if (!strcmp(name, "timing"))
+    s->opt.timing = value != 0;
+  else if (!strcmp(name, "use_dpp"))
+    s->opt.use_dpp = value != 0;
+  else
+    return fail(TQ_ERR_INVALID, "unknown option '%s'", name);
+  return TQ_OK;
+}
+
+int tq_decode_postings(tq_segment *s, tq_term_handle term, uint32_t *docs, uint32_t *tfs) {
+  if (!s || !docs || !tfs) return fail(TQ_ERR_INVALID, "tq_decode_postings: null argument");
+  if (term >= s->terms.size()) return fail(TQ_ERR_INVALID, "unknown term handle %u", term);
+  HIP_TRY(hipSetDevice(s->device));
+  int rc = sync_terms(s, s->stream);
+  if (rc != TQ_OK) return rc;
+  const TermHost &t = s->terms[term];
+  const size_t bytes = (size_t)t.doc_freq * sizeof(uint32_t);
+  rc = s->d_misc.ensure(2 * bytes + 64);
+  if (rc != TQ_OK) return rc;
+  uint32_t *dd = (uint32_t *)s->d_misc.p, *dt = dd + t.doc_freq;
+  hipError_t e = tqk_launch_decode_list(s->dseg, s->d_terms, term, t.n_blocks, dd, dt,
+                                        s->opt.use_dpp != 0, s->stream);
+  if (e != hipSuccess) return fail(TQ_ERR_HIP, "decode launch: %s", hipGetErrorString(e));
+  HIP_TRY(hipMemcpyAsync(docs, dd, bytes, hipMemcpyDeviceToHost, s->stream));
+  HIP_TRY(hipMemcpyAsync(tfs, dt, bytes, hipMemcpyDeviceToHost, s->stream));
+  HIP_TRY(hipStreamSynchronize(s->stream));
+  return TQ_OK;
+}
+
+int tq_decode_position_deltas(tq_segment *s, tq_term_handle term, uint32_t *out, uint64_t cap,
+                              uint64_t *n_out) {
+  if (!s || !n_out) return fail(TQ_ERR_INVALID, "tq_decode_position_deltas: null argument");
+  if (term >= s->terms.size()) return fail(TQ_ERR_INVALID, "unknown term handle %u", term);
+  const TermHost &t = s->terms[term];
+  if (t.positions_len == 0) return fail(TQ_ERR_UNSUPPORTED, "term has no positions on the device");
+  *n_out = t.n_positions;
+  const uint64_t n = std::min<uint64_t>(cap, t.n_positions);
+  if (n == 0 || !out) return TQ_OK;
+  HIP_TRY(hipSetDevice(s->device));
+  int rc = sync_terms(s, s->stream);
+  if (rc != TQ_OK) return rc;
+  rc = s->d_misc.ensure(n * sizeof(uint32_t));
+  if (rc != TQ_OK) return rc;
+  hipError_t e = tqk_launch_decode_positions(s->dseg, s->d_terms, term, (uint32_t *)s->d_misc.p, n,
+                                             s->stream);
+  if (e != hipSuccess) return fail(TQ_ERR_HIP, "decode launch: %s", hipGetErrorString(e));
+  HIP_TRY(hipMemcpyAsync(out, s->d_misc.p, n * sizeof(uint32_t), hipMemcpyDeviceToHost, s->stream));
+  HIP_TRY(hipStreamSynchronize(s->stream));
+  return TQ_OK;
+}
+
+// ---- cross-segment merge (merge_top_k)
+int tq_merge_topk(const float *scores, const uint32_t *docs, const uint32_t *counts,
+                  uint32_t n_segments, uint32_t n_queries, uint32_t stride, uint32_t offset,
+                  uint32_t limit, float *out_scores, uint32_t *out_segment_ords,
+                  uint32_t *out_docs, uint32_t *out_counts) {
+  if (!scores || !docs || !counts || !out_scores || !out_segment_ords || !out_docs || !out_counts)
+    return fail(TQ_ERR_INVALID, "tq_merge_topk: null argument");
+  struct H {
+    float s;
+    uint32_t o, d;
+  };
+  std::vector<H> all;
+  for (uint32_t q = 0; q < n_queries; ++q) {
+    all.clear();
+    for (uint32_t sg = 0; sg < n_segments; ++sg) {
+      const uint32_t c = std::min(counts[(size_t)sg * n_queries + q], stride);
+      const size_t b = ((size_t)sg * n_queries + q) * stride;
+      for (uint32_t i = 0; i < c; ++i) all.push_back({scores[b + i], sg, docs[b + i]});
+    }
+    // top_score_collector.rs:590-600: sort key desc, then DocAddress asc
+    std::sort(all.begin(), all.end(), [](const H &a, const H &b) {
+      if (a.s != b.s) return a.s > b.s;
+      if (a.o != b.o) return a.o < b.o;
+      return a.d < b.d;
+    });
+    uint32_t w = 0;
+    for (size_t i = offset; i < all.size() && w < limit; ++i, ++w) {
+      out_scores[(size_t)q * limit + w] = all[i].s;
+      out_segment_ords[(size_t)q * limit + w] = all[i].o;
+      out_docs[(size_t)q * limit + w] = all[i].d;
+    }
+    out_counts[q] = w;
+    for (; w < limit; ++w) {
+      out_scores[(size_t)q * limit + w] = 0.0f;
+      out_segment_ords[(size_t)q * limit + w] = 0xFFFFFFFFu;
+      out_docs[(size_t)q * limit + w] = TQ_TERMINATED;
+    }
+  }
+  return TQ_OK;
+}
+
+int tq_merge_topk_device(tq_ctx *ctx, int device, const float *d_scores, const uint32_t *d_docs,
+                         const uint32_t *d_counts, const uint32_t *segment_ords,
+                         uint32_t n_segments, uint32_t n_queries, uint32_t stride,
+                         uint32_t offset, uint32_t limit, float *d_out_scores,
+                         uint32_t *d_out_segment_ords, uint32_t *d_out_docs,
+                         uint32_t *d_out_counts, void *hip_stream) {
+  if (!ctx || !d_scores || !d_docs || !d_counts || !d_out_scores || !d_out_segment_ords ||
+      !d_out_docs || !d_out_counts)
+    return fail(TQ_ERR_INVALID, "tq_merge_topk_device: null argument");
+  if (limit == 0) return fail(TQ_ERR_INVALID, "tq_merge_topk_device: limit 0");
+  HIP_TRY(hipSetDevice(device));
+  TqkSegMergeParams p{};
+  p.scores = d_scores;
+  p.docs = d_docs;
+  p.counts = d_counts;
+  p.segment_ords = segment_ords;
+  p.out_scores = d_out_scores;
+  p.out_segment_ords = d_out_segment_ords;
+  p.out_docs = d_out_docs;
+  p.out_counts = d_out_counts;
+  p.n_segments = n_segments;
+  p.n_queries = n_queries;
+  p.stride = stride;
+  p.offset = offset;
+  p.limit = limit;
+  hipError_t e = tqk_launch_merge_segments(p, (hipStream_t)hip_stream);
+  if (e != hipSuccess) return fail(TQ_ERR_HIP, "merge launch: %s", hipGetErrorString(e));
+  return TQ_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,55 @@
+// tq_launch.h — kernel parameter blocks and launch entry points (tq_kernels.hip <-> tq_api.cpp)
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "tq_device.h"
+
+struct TqkScanParams {
+  TqdSegment seg;
+  const TqdTerm *terms;
+  const TqdQuery *queries;      // the launch group's queries, contiguous
+  const uint32_t *tile_starts;  // n_queries + 1, non-decreasing
+  const float *caches;          // n_caches x 256
+  uint64_t *partials;           // partial top-k lists, KPL*64 keys each
+  unsigned long long *match_counter;
+  uint32_t n_queries;
+  uint32_t total_tiles;
+  uint32_t tiles_per_chunk;
+  uint32_t n_chunks;
+  uint32_t exhaustive;  // 1: score every match; 0: block-max pruning allowed
+};
+
+struct TqkMergeParams {
+  const TqdQuery *queries;
+  const uint64_t *partials;
+  const uint32_t *out_index;  // query -> output row (null = identity)
+  float *out_scores;
+  uint32_t *out_docs;
+  uint32_t *out_counts;
+  uint32_t n_queries;
+  uint32_t out_stride;
+};
+
+struct TqkSegMergeParams {
+  const float *scores;          // [segment][query][stride]
+  const uint32_t *docs;
+  const uint32_t *counts;       // [segment][query]
+  const uint32_t *segment_ords; // [segment] or null
+  float *out_scores;            // [query][limit]
+  uint32_t *out_segment_ords;
+  uint32_t *out_docs;
+  uint32_t *out_counts;
+  uint32_t n_segments, n_queries, stride, offset, limit;
+};
+
+hipError_t tqk_launch_and(const TqkScanParams &p, int kpl, bool use_dpp, hipStream_t st);
+hipError_t tqk_launch_or(const TqkScanParams &p, int kpl, bool use_dpp, hipStream_t st);
+hipError_t tqk_launch_phrase(const TqkScanParams &p, int kpl, bool use_dpp, hipStream_t st);
+hipError_t tqk_launch_merge(const TqkMergeParams &p, int kpl, hipStream_t st);
+hipError_t tqk_launch_decode_list(const TqdSegment &seg, const TqdTerm *terms, uint32_t handle,
+                                  uint32_t n_blocks, uint32_t *docs, uint32_t *tfs, bool use_dpp,
+                                  hipStream_t st);
+hipError_t tqk_launch_decode_positions(const TqdSegment &seg, const TqdTerm *terms,
+                                       uint32_t handle, uint32_t *out, uint64_t n, hipStream_t st);
+hipError_t tqk_launch_merge_segments(const TqkSegMergeParams &p, hipStream_t st);

@@ -1,0 +1,204 @@
+// host_capi.cpp — flat C entry points over the C++ host mirror (searcher.hpp), so that the
+// Python tests/bench drive exactly the host code a C++ application would.  Exceptions never
+// cross this boundary: they become status codes + tqh_last_error().
+#include <cstring>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "searcher.hpp"
+
+using namespace tantivy_amd;
+
+namespace {
+thread_local std::string g_err;
+template <typename F>
+int guard(F &&f) {
+  try {
+    f();
+    return TQ_OK;
+  } catch (const TantivyError &e) {
+    g_err = e.what();
+    switch (e.kind) {
+      case TantivyError::InvalidArgument: return TQ_ERR_INVALID;
+      case TantivyError::DataCorruption: return TQ_ERR_FORMAT;
+      case TantivyError::Unsupported: return TQ_ERR_UNSUPPORTED;
+      default: return TQ_ERR_HIP;
+    }
+  } catch (const std::exception &e) {
+    g_err = e.what();
+    return TQ_ERR_INVALID;
+  }
+}
+}  // namespace
+
+struct tqh_searcher {
+  tq_ctx *ctx = nullptr;
+  std::vector<std::shared_ptr<SegmentReader>> segments;
+  std::unique_ptr<Searcher> searcher;
+  std::vector<Weight> prepared;  // weights of the last tqh_prepare_batch
+};
+
+extern "C" {
+
+struct tqh_term_info {
+  uint32_t term_id;
+  uint32_t doc_freq;
+  uint64_t postings_start, postings_end, positions_start, positions_end;
+};
+// mode: 0 AND (all Must), 1 OR (all Should), 2 PHRASE (offsets 0..n or explicit), 3 single term
+struct tqh_query {
+  uint8_t mode;
+  uint32_t n_terms;
+  const uint32_t *terms;
+  const uint32_t *phrase_offsets;  // may be null
+};
+
+const char *tqh_last_error(void) { return g_err.c_str(); }
+
+int tqh_searcher_new(tq_ctx *ctx, tqh_searcher **out) {
+  return guard([&] {
+    if (!ctx || !out) throw TantivyError(TantivyError::InvalidArgument, "null argument");
+    auto *s = new tqh_searcher();
+    s->ctx = ctx;
+    *out = s;
+  });
+}
+void tqh_searcher_free(tqh_searcher *s) { delete s; }
+
+int tqh_searcher_add_segment(tqh_searcher *s, int device, uint32_t max_doc, uint8_t record_option,
+                             const uint8_t *idx, size_t idx_len, const uint8_t *pos,
+                             size_t pos_len, const uint8_t *fieldnorm, size_t fn_len,
+                             const tqh_term_info *terms, uint32_t n_terms) {
+  return guard([&] {
+    if (!s) throw TantivyError(TantivyError::InvalidArgument, "null searcher");
+    auto seg = std::make_shared<SegmentReader>(s->ctx, device, (uint32_t)s->segments.size(),
+                                               max_doc, record_option, idx, idx_len, pos, pos_len,
+                                               fieldnorm, fn_len);
+    for (uint32_t i = 0; i < n_terms; ++i) {
+      TermInfo ti;
+      ti.doc_freq = terms[i].doc_freq;
+      ti.postings_start = terms[i].postings_start;
+      ti.postings_end = terms[i].postings_end;
+      ti.positions_start = terms[i].positions_start;
+      ti.positions_end = terms[i].positions_end;
+      seg->add_term(terms[i].term_id, ti);
+    }
+    s->segments.push_back(seg);
+    s->searcher.reset(new Searcher(s->segments));
+  });
+}
+
+// Bm25 statistics of a segment that lives on another rank (one segment per GPU).
+int tqh_searcher_add_remote_stats(tqh_searcher *s, uint64_t max_doc, uint64_t total_num_tokens,
+                                  const uint32_t *term_ids, const uint32_t *doc_freqs,
+                                  uint32_t n_terms) {
+  return guard([&] {
+    if (!s || !s->searcher) throw TantivyError(TantivyError::InvalidArgument, "no segments");
+    std::vector<std::pair<uint32_t, uint32_t>> v;
+    for (uint32_t i = 0; i < n_terms; ++i) v.emplace_back(term_ids[i], doc_freqs[i]);
+    s->searcher->add_remote_statistics(max_doc, total_num_tokens, v);
+  });
+}
+
+// Query::weight for a batch (global statistics, executor choice).  Kept so that a benchmark can
+// time execution separately from weight construction, like tantivy's own benches do.
+int tqh_prepare_batch(tqh_searcher *s, const tqh_query *queries, uint32_t n) {
+  return guard([&] {
+    if (!s || !s->searcher) throw TantivyError(TantivyError::InvalidArgument, "no segments");
+    s->prepared.clear();
+    s->prepared.reserve(n);
+    for (uint32_t i = 0; i < n; ++i) {
+      const tqh_query &q = queries[i];
+      Query query;
+      if (q.mode == 3 || (q.n_terms == 1 && q.mode != 2)) {
+        query = Query::term_query(q.terms[0]);
+      } else if (q.mode == 2) {
+        std::vector<std::pair<uint32_t, uint32_t>> pt;
+        for (uint32_t t = 0; t < q.n_terms; ++t)
+          pt.emplace_back(q.phrase_offsets ? q.phrase_offsets[t] : t, q.terms[t]);
+        query = Query::phrase_with_offsets(std::move(pt));
+      } else {
+        std::vector<std::pair<Occur, Query>> clauses;
+        for (uint32_t t = 0; t < q.n_terms; ++t)
+          clauses.emplace_back(q.mode == 0 ? Occur::Must : Occur::Should,
+                               Query::term_query(q.terms[t]));
+        query = Query::boolean(std::move(clauses));
+      }
+      s->prepared.push_back(s->searcher->weight(query));
+    }
+  });
+}
+
+// Searcher::search for the prepared batch with TopDocs::with_limit(limit).and_offset(offset).
+int tqh_search_prepared(tqh_searcher *s, uint32_t offset, uint32_t limit, float *scores,
+                        uint32_t *segment_ords, uint32_t *docs, uint32_t *counts) {
+  return guard([&] {
+    if (!s || !s->searcher) throw TantivyError(TantivyError::InvalidArgument, "no segments");
+    const TopDocs td = TopDocs::with_limit(limit).and_offset(offset);
+    std::vector<Fruit> res = s->searcher->search_batch(s->prepared, td);
+    for (size_t q = 0; q < res.size(); ++q) {
+      counts[q] = (uint32_t)res[q].size();
+      for (uint32_t i = 0; i < limit; ++i) {
+        const bool real = i < res[q].size();
+        scores[q * limit + i] = real ? res[q][i].first : 0.0f;
+        segment_ords[q * limit + i] = real ? res[q][i].second.segment_ord : 0xFFFFFFFFu;
+        docs[q * limit + i] = real ? res[q][i].second.doc_id : TERMINATED;
+      }
+    }
+  });
+}
+
+// Per-segment results of the prepared batch (collect_segment), for multi-process runs where
+// each rank holds one segment and the cross-segment merge happens after an all-gather.
+int tqh_collect_segment_prepared(tqh_searcher *s, uint32_t segment_ord, uint32_t k, float *scores,
+                                 uint32_t *docs, uint32_t *counts) {
+  return guard([&] {
+    if (!s || !s->searcher || segment_ord >= s->segments.size())
+      throw TantivyError(TantivyError::InvalidArgument, "bad segment");
+    std::vector<float> sc;
+    std::vector<uint32_t> dc, ct;
+    s->searcher->collect_segment_batch(segment_ord, s->prepared, k, sc, dc, ct);
+    std::memcpy(scores, sc.data(), sc.size() * sizeof(float));
+    std::memcpy(docs, dc.data(), dc.size() * sizeof(uint32_t));
+    std::memcpy(counts, ct.data(), ct.size() * sizeof(uint32_t));
+  });
+}
+
+int tqh_collect_segment_prepared_device(tqh_searcher *s, uint32_t segment_ord, uint32_t k,
+                                        float *d_scores, uint32_t *d_docs, uint32_t *d_counts,
+                                        void *hip_stream) {
+  return guard([&] {
+    if (!s || !s->searcher || segment_ord >= s->segments.size())
+      throw TantivyError(TantivyError::InvalidArgument, "bad segment");
+    s->searcher->collect_segment_batch_device(segment_ord, s->prepared, k, d_scores, d_docs,
+                                              d_counts, hip_stream);
+  });
+}
+
+// Bm25Weight for tests / tools: weight and 256-entry cache from global statistics.
+int tqh_bm25_for_terms(const uint64_t *term_doc_freqs, uint32_t n_terms, uint64_t total_num_docs,
+                       uint64_t total_num_tokens, float boost, float *weight_out,
+                       float *cache_out /*256 or null*/) {
+  return guard([&] {
+    if (!term_doc_freqs || !n_terms || !weight_out)
+      throw TantivyError(TantivyError::InvalidArgument, "null argument");
+    std::vector<uint64_t> dfs(term_doc_freqs, term_doc_freqs + n_terms);
+    Bm25Weight w = Bm25Weight::for_terms(dfs, total_num_docs, total_num_tokens).boost_by(boost);
+    *weight_out = w.weight;
+    if (cache_out) std::memcpy(cache_out, w.cache, sizeof w.cache);
+  });
+}
+
+tq_segment *tqh_segment_raw(tqh_searcher *s, uint32_t segment_ord) {
+  if (!s || segment_ord >= s->segments.size()) return nullptr;
+  return s->segments[segment_ord]->raw();
+}
+uint32_t tqh_term_handle(tqh_searcher *s, uint32_t segment_ord, uint32_t term_id) {
+  if (!s || segment_ord >= s->segments.size()) return TQ_TERM_ABSENT;
+  uint32_t h = TQ_TERM_ABSENT;
+  guard([&] { h = s->segments[segment_ord]->term_handle(term_id); });
+  return h;
+}
+
+}  // extern "C"

@@ -1,0 +1,238 @@
+// searcher.cpp — see searcher.hpp.
+#include "searcher.hpp"
+
+#include <algorithm>
+#include <cstring>
+
+namespace tantivy_amd {
+
+namespace {
+[[noreturn]] void throw_tq(int code) {
+  const std::string msg = tq_last_error();
+  switch (code) {
+    case TQ_ERR_INVALID: throw TantivyError(TantivyError::InvalidArgument, msg);
+    case TQ_ERR_FORMAT: throw TantivyError(TantivyError::DataCorruption, msg);
+    case TQ_ERR_UNSUPPORTED: throw TantivyError(TantivyError::Unsupported, msg);
+    default: throw TantivyError(TantivyError::SystemError, msg);
+  }
+}
+}  // namespace
+
+SegmentReader::SegmentReader(tq_ctx *ctx, int device, uint32_t segment_ord, uint32_t max_doc,
+                             uint8_t record_option, const uint8_t *idx, size_t idx_len,
+                             const uint8_t *pos, size_t pos_len, const uint8_t *fieldnorm,
+                             size_t fn_len)
+    : segment_ord_(segment_ord), max_doc_(max_doc), record_option_(record_option) {
+  const int rc = tq_segment_upload(ctx, device, max_doc, idx, idx_len, pos, pos_len, fieldnorm,
+                                   fn_len, record_option, &seg_);
+  if (rc != TQ_OK) throw_tq(rc);
+  uint64_t t = 0;
+  for (int i = 0; i < 8; ++i) t |= (uint64_t)idx[i] << (8 * i);
+  total_num_tokens_ = t;
+}
+SegmentReader::~SegmentReader() { tq_segment_free(seg_); }
+
+void SegmentReader::add_term(uint32_t term_id, const TermInfo &info) { terms_[term_id] = info; }
+const TermInfo *SegmentReader::get_term_info(uint32_t term_id) const {
+  auto it = terms_.find(term_id);
+  if (it == terms_.end() || it->second.doc_freq == 0) return nullptr;
+  return &it->second;
+}
+tq_term_handle SegmentReader::term_handle(uint32_t term_id) {
+  auto h = handles_.find(term_id);
+  if (h != handles_.end()) return h->second;
+  const TermInfo *ti = get_term_info(term_id);
+  tq_term_handle handle = TQ_TERM_ABSENT;
+  if (ti) {
+    const int rc = tq_term_prepare(seg_, ti->postings_start,
+                                   (uint32_t)(ti->postings_end - ti->postings_start),
+                                   ti->positions_start,
+                                   (uint32_t)(ti->positions_end - ti->positions_start),
+                                   ti->doc_freq, &handle);
+    if (rc != TQ_OK) throw_tq(rc);
+  }
+  handles_[term_id] = handle;
+  return handle;
+}
+
+Searcher::Searcher(std::vector<std::shared_ptr<SegmentReader>> segments)
+    : segments_(std::move(segments)) {}
+
+void Searcher::add_remote_statistics(
+    uint64_t max_doc, uint64_t total_num_tokens,
+    const std::vector<std::pair<uint32_t, uint32_t>> &term_doc_freqs) {
+  remote_docs_ += max_doc;
+  remote_tokens_ += total_num_tokens;
+  for (auto &tf : term_doc_freqs) remote_doc_freq_[tf.first] += tf.second;
+  shared_cache_.reset();
+}
+uint64_t Searcher::total_num_docs() const {
+  uint64_t n = remote_docs_;
+  for (auto &s : segments_) n += s->max_doc();
+  return n;
+}
+uint64_t Searcher::total_num_tokens() const {
+  uint64_t n = remote_tokens_;
+  for (auto &s : segments_) n += s->total_num_tokens();
+  return n;
+}
+uint64_t Searcher::doc_freq(uint32_t term) const {
+  uint64_t n = 0;
+  auto it = remote_doc_freq_.find(term);
+  if (it != remote_doc_freq_.end()) n = it->second;
+  for (auto &s : segments_)
+    if (const TermInfo *ti = s->get_term_info(term)) n += ti->doc_freq;
+  return n;
+}
+
+Weight Searcher::weight(const Query &query) const {
+  const uint64_t nd = total_num_docs(), nt = total_num_tokens();
+  if (!shared_cache_) {
+    const Score avg = (Score)nt / (Score)nd;
+    shared_cache_ = std::make_shared<Bm25Weight>(Bm25Weight::from_idf(0.0f, avg));
+  }
+  Weight w;
+  w.bm25 = shared_cache_;
+  auto term_weight = [&](uint32_t term) {
+    // TermQuery::specialized_weight -> Bm25Weight::for_terms(statistics, [term])
+    return idf(doc_freq(term), nd) * (1.0f + K1);
+  };
+  switch (query.kind) {
+    case Query::Term:
+      // TermWeight::for_each_pruning == one-scorer block-WAND == every doc of the list
+      w.mode = TQ_MODE_OR;
+      w.terms = {query.term};
+      w.weights = {term_weight(query.term)};
+      return w;
+    case Query::Phrase: {
+      if (query.phrase_terms.size() < 2)
+        throw TantivyError(TantivyError::InvalidArgument,
+                           "A phrase query is required to have strictly more than one term.");
+      w.mode = TQ_MODE_PHRASE;
+      Score idf_sum = 0.0f;  // bm25.rs:121-128
+      for (auto &ot : query.phrase_terms) {
+        w.phrase_offsets.push_back(ot.first);
+        w.terms.push_back(ot.second);
+        idf_sum += idf(doc_freq(ot.second), nd);
+      }
+      w.weights = {idf_sum * (1.0f + K1)};
+      return w;
+    }
+    case Query::Boolean: {
+      // BooleanWeight::complex_scorer specialisations (boolean_weight.rs:287-330):
+      // all clauses are term queries and either all Must or all Should.
+      bool all_must = true, all_should = true;
+      for (auto &c : query.clauses) {
+        if (c.second.kind != Query::Term)
+          throw TantivyError(TantivyError::Unsupported,
+                             "nested boolean trees stay on the CPU scorer path");
+        all_must &= c.first == Occur::Must;
+        all_should &= c.first == Occur::Should;
+      }
+      if (query.clauses.empty() || !(all_must || all_should))
+        throw TantivyError(TantivyError::Unsupported,
+                           "mixed Must/Should/MustNot clauses stay on the CPU scorer path");
+      w.mode = all_must ? TQ_MODE_AND : TQ_MODE_OR;
+      for (auto &c : query.clauses) {
+        w.terms.push_back(c.second.term);
+        w.weights.push_back(term_weight(c.second.term));
+      }
+      return w;
+    }
+  }
+  throw TantivyError(TantivyError::InvalidArgument, "unknown query kind");
+}
+
+namespace {
+// builds the tq_query array of a batch for one segment (scorer construction of
+// Weight::scorer per segment: term lookups only, the device owns the rest)
+struct SegmentBatch {
+  std::vector<tq_query> qs;
+  std::vector<tq_term_handle> handles;
+  SegmentBatch(SegmentReader &seg, const std::vector<Weight> &weights, uint32_t k) {
+    const size_t n = weights.size();
+    qs.resize(n);
+    size_t total_terms = 0;
+    for (auto &w : weights) total_terms += w.terms.size();
+    handles.reserve(total_terms);
+    for (size_t i = 0; i < n; ++i) {
+      const Weight &w = weights[i];
+      const size_t at = handles.size();
+      for (uint32_t t : w.terms) handles.push_back(seg.term_handle(t));
+      tq_query &q = qs[i];
+      q.n_terms = (uint32_t)w.terms.size();
+      q.terms = handles.data() + at;  // stable: reserved up front
+      q.weights = w.weights.data();
+      q.tf_cache = w.bm25->cache;
+      q.mode = w.mode;
+      q.phrase_offsets = w.phrase_offsets.empty() ? nullptr : w.phrase_offsets.data();
+      q.k = k;
+    }
+  }
+};
+}  // namespace
+
+void Searcher::collect_segment_batch(size_t segment_ord, const std::vector<Weight> &weights,
+                                     uint32_t k, std::vector<float> &scores,
+                                     std::vector<uint32_t> &docs, std::vector<uint32_t> &counts) {
+  SegmentReader &seg = *segments_[segment_ord];
+  const size_t n = weights.size();
+  SegmentBatch b(seg, weights, k);
+  scores.assign(n * k, 0.0f);
+  docs.assign(n * k, TERMINATED);
+  counts.assign(n, 0);
+  const int rc = tq_search_batch(seg.raw(), b.qs.data(), (uint32_t)n, k, scores.data(),
+                                 docs.data(), counts.data());
+  if (rc != TQ_OK) throw_tq(rc);
+}
+
+void Searcher::collect_segment_batch_device(size_t segment_ord, const std::vector<Weight> &weights,
+                                            uint32_t k, float *d_scores, uint32_t *d_docs,
+                                            uint32_t *d_counts, void *hip_stream) {
+  SegmentReader &seg = *segments_[segment_ord];
+  SegmentBatch b(seg, weights, k);
+  const int rc = tq_search_batch_device(seg.raw(), b.qs.data(), (uint32_t)weights.size(), k,
+                                        d_scores, d_docs, d_counts, hip_stream);
+  if (rc != TQ_OK) throw_tq(rc);
+}
+
+std::vector<Fruit> Searcher::search_batch(const std::vector<Weight> &weights,
+                                          const TopDocs &collector) {
+  const size_t n = weights.size(), S = segments_.size();
+  const uint32_t k = (uint32_t)(collector.offset() + collector.limit());  // collect_segment: k = doc_range.end
+  if (k > TQ_MAX_K)
+    throw TantivyError(TantivyError::Unsupported, "offset+limit above the device heap size");
+  std::vector<float> all_scores(S * n * k);
+  std::vector<uint32_t> all_docs(S * n * k), all_counts(S * n);
+  std::vector<float> sc;
+  std::vector<uint32_t> dc, ct;
+  for (size_t s = 0; s < S; ++s) {  // Executor::SingleThread order (executor.rs:52-59)
+    collect_segment_batch(s, weights, k, sc, dc, ct);
+    std::memcpy(all_scores.data() + s * n * k, sc.data(), n * k * sizeof(float));
+    std::memcpy(all_docs.data() + s * n * k, dc.data(), n * k * sizeof(uint32_t));
+    std::memcpy(all_counts.data() + s * n, ct.data(), n * sizeof(uint32_t));
+  }
+  const uint32_t limit = (uint32_t)collector.limit(), offset = (uint32_t)collector.offset();
+  std::vector<float> out_s(n * limit);
+  std::vector<uint32_t> out_o(n * limit), out_d(n * limit), out_c(n);
+  const int rc = tq_merge_topk(all_scores.data(), all_docs.data(), all_counts.data(), (uint32_t)S,
+                               (uint32_t)n, k, offset, limit, out_s.data(), out_o.data(),
+                               out_d.data(), out_c.data());
+  if (rc != TQ_OK) throw_tq(rc);
+  std::vector<Fruit> res(n);
+  for (size_t q = 0; q < n; ++q) {
+    res[q].reserve(out_c[q]);
+    for (uint32_t i = 0; i < out_c[q]; ++i)
+      res[q].push_back({out_s[q * limit + i],
+                        DocAddress{segments_[out_o[q * limit + i]]->segment_ord(),
+                                   out_d[q * limit + i]}});
+  }
+  return res;
+}
+
+Fruit Searcher::search(const Query &query, const TopDocs &collector) {
+  std::vector<Weight> w{weight(query)};
+  return search_batch(w, collector)[0];
+}
+
+}  // namespace tantivy_amd

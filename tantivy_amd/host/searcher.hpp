@@ -1,0 +1,186 @@
+// searcher.hpp — C++ host side above the C ABI, mirroring the slice of tantivy's public API that
+// sits on the hot path: Searcher / Query / Weight / TopDocs (src/core/searcher.rs,
+// src/query/{query,weight}.rs, src/query/boolean_query/boolean_query.rs,
+// src/query/term_query/term_query.rs, src/query/phrase_query/phrase_query.rs,
+// src/collector/top_score_collector.rs).  Same names, argument meaning and error behaviour;
+// execution is delegated to the device through include/tantivy_amd.h.
+//
+// Not mirrored (out of scope): the term dictionary (FST), Directory/CompositeFile,
+// schema, tokenizers.  A SegmentReader is therefore built from the field's raw sub-file bytes
+// plus a term -> TermInfo table that the reference's TermDictionary would supply.
+#pragma once
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <unordered_map>
+#include <utility>
+#include <vector>
+
+#include "../../include/tantivy_amd.h"
+#include "bm25.hpp"
+
+namespace tantivy_amd {
+
+// src/error.rs: the variants the hot path can produce
+struct TantivyError : std::runtime_error {
+  enum Kind { InvalidArgument, SchemaError, SystemError, DataCorruption, Unsupported } kind;
+  TantivyError(Kind k, const std::string &msg) : std::runtime_error(msg), kind(k) {}
+};
+
+// src/postings/term_info.rs:10-17
+struct TermInfo {
+  uint32_t doc_freq = 0;
+  uint64_t postings_start = 0, postings_end = 0;
+  uint64_t positions_start = 0, positions_end = 0;
+};
+
+// src/lib.rs:337-344 — ordered by (segment_ord, doc_id)
+struct DocAddress {
+  uint32_t segment_ord = 0;
+  DocId doc_id = 0;
+  bool operator==(const DocAddress &o) const {
+    return segment_ord == o.segment_ord && doc_id == o.doc_id;
+  }
+};
+
+// A device-resident single-field segment (SegmentReader + InvertedIndexReader + FieldNormReader
+// of the reference, for one indexed text field).
+class SegmentReader {
+ public:
+  SegmentReader(tq_ctx *ctx, int device, uint32_t segment_ord, uint32_t max_doc,
+                uint8_t record_option, const uint8_t *idx, size_t idx_len, const uint8_t *pos,
+                size_t pos_len, const uint8_t *fieldnorm, size_t fn_len);
+  ~SegmentReader();
+  SegmentReader(const SegmentReader &) = delete;
+  SegmentReader &operator=(const SegmentReader &) = delete;
+
+  void add_term(uint32_t term_id, const TermInfo &info);  // TermDictionary substitute
+  const TermInfo *get_term_info(uint32_t term_id) const;  // None => nullptr
+  tq_term_handle term_handle(uint32_t term_id);            // prepares on first use
+  uint32_t max_doc() const { return max_doc_; }
+  uint32_t segment_ord() const { return segment_ord_; }
+  uint64_t total_num_tokens() const { return total_num_tokens_; }  // inverted_index_reader.rs:72-73
+  uint8_t record_option() const { return record_option_; }
+  tq_segment *raw() const { return seg_; }
+
+ private:
+  tq_segment *seg_ = nullptr;
+  uint32_t segment_ord_, max_doc_;
+  uint8_t record_option_;
+  uint64_t total_num_tokens_ = 0;
+  std::unordered_map<uint32_t, TermInfo> terms_;
+  std::unordered_map<uint32_t, tq_term_handle> handles_;
+};
+
+enum class Occur { Should, Must, MustNot };  // src/query/occur.rs
+
+// The query shapes the device path takes.  Anything else is reported as
+// TantivyError::Unsupported so that the caller keeps tantivy's own CPU scorer for it
+// (the `SpecializedScorer::Other` branch, boolean_weight.rs:595-597).
+struct Query {
+  enum Kind { Term, Boolean, Phrase } kind;
+  // Term
+  uint32_t term = 0;
+  // Boolean: clauses of (Occur, sub query)
+  std::vector<std::pair<Occur, Query>> clauses;
+  // Phrase: (offset, term), slop 0 (phrase_query.rs:28-63)
+  std::vector<std::pair<uint32_t, uint32_t>> phrase_terms;
+
+  static Query term_query(uint32_t term) {
+    Query q;
+    q.kind = Term;
+    q.term = term;
+    return q;
+  }
+  static Query boolean(std::vector<std::pair<Occur, Query>> clauses) {
+    Query q;
+    q.kind = Boolean;
+    q.clauses = std::move(clauses);
+    return q;
+  }
+  // PhraseQuery::new(terms): offsets 0..n
+  static Query phrase(const std::vector<uint32_t> &terms) {
+    Query q;
+    q.kind = Phrase;
+    for (uint32_t i = 0; i < terms.size(); ++i) q.phrase_terms.emplace_back(i, terms[i]);
+    return q;
+  }
+  static Query phrase_with_offsets(std::vector<std::pair<uint32_t, uint32_t>> terms) {
+    Query q;
+    q.kind = Phrase;
+    q.phrase_terms = std::move(terms);
+    return q;
+  }
+};
+
+// src/collector/top_score_collector.rs:61-96
+class TopDocs {
+ public:
+  static TopDocs with_limit(size_t limit) {
+    if (limit == 0) throw TantivyError(TantivyError::InvalidArgument, "Limit must be strictly greater than 0.");
+    TopDocs t;
+    t.limit_ = limit;
+    return t;
+  }
+  TopDocs and_offset(size_t offset) const {
+    TopDocs t = *this;
+    t.offset_ = offset;
+    return t;
+  }
+  TopDocs order_by_score() const { return *this; }
+  size_t limit() const { return limit_; }
+  size_t offset() const { return offset_; }
+
+ private:
+  size_t limit_ = 10, offset_ = 0;
+};
+
+using Fruit = std::vector<std::pair<Score, DocAddress>>;
+
+// Query -> per-index Weight: executor choice + global BM25 statistics (Query::weight,
+// src/query/query.rs:128-160; BooleanQuery::weight boolean_query.rs:157-169).
+struct Weight {
+  uint8_t mode = TQ_MODE_AND;
+  std::vector<uint32_t> terms;           // term ids in query order
+  std::vector<Score> weights;            // per term (AND/OR) or one (phrase)
+  std::vector<uint32_t> phrase_offsets;  // phrase
+  std::shared_ptr<Bm25Weight> bm25;      // holds the shared tf cache
+};
+
+class Searcher {
+ public:
+  explicit Searcher(std::vector<std::shared_ptr<SegmentReader>> segments);
+  // Bm25StatisticsProvider (bm25.rs:27-50)
+  uint64_t total_num_docs() const;
+  uint64_t total_num_tokens() const;
+  uint64_t doc_freq(uint32_t term) const;
+  size_t num_segments() const { return segments_.size(); }
+  SegmentReader &segment_reader(size_t ord) { return *segments_[ord]; }
+
+  // Statistics of segments held by OTHER ranks (one segment per GPU): the reference lets the
+  // caller supply its own Bm25StatisticsProvider (bm25.rs:11-25) for exactly this.
+  void add_remote_statistics(uint64_t max_doc, uint64_t total_num_tokens,
+                             const std::vector<std::pair<uint32_t, uint32_t>> &term_doc_freqs);
+
+  Weight weight(const Query &query) const;
+  // Searcher::search (searcher.rs:180-238) for one query / a batch of queries
+  Fruit search(const Query &query, const TopDocs &collector);
+  std::vector<Fruit> search_batch(const std::vector<Weight> &weights, const TopDocs &collector);
+  // collect_segment for a batch on one segment: per-segment top-(offset+limit), sorted
+  void collect_segment_batch(size_t segment_ord, const std::vector<Weight> &weights, uint32_t k,
+                             std::vector<float> &scores, std::vector<uint32_t> &docs,
+                             std::vector<uint32_t> &counts);
+  // same, results left in device memory (enqueued on hip_stream, no host sync): feeds the
+  // cross-rank all-gather of the one-segment-per-GPU deployment
+  void collect_segment_batch_device(size_t segment_ord, const std::vector<Weight> &weights,
+                                    uint32_t k, float *d_scores, uint32_t *d_docs,
+                                    uint32_t *d_counts, void *hip_stream);
+
+ private:
+  std::vector<std::shared_ptr<SegmentReader>> segments_;
+  mutable std::shared_ptr<Bm25Weight> shared_cache_;  // one tf cache per field (avg fieldnorm)
+  uint64_t remote_docs_ = 0, remote_tokens_ = 0;
+  std::unordered_map<uint32_t, uint64_t> remote_doc_freq_;
+};
+
+}  // namespace tantivy_amd

@@ -1,0 +1,460 @@
+"""GPU parity tests: the HIP path (through the C ABI / C++ host mirror) against the CPU oracle.
+Doc ids and 2-term scores bit-exact; scores otherwise within 1e-5 relative (BASELINE.json)."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+from tests.helpers import corpus_segment, random_postings, rel_close
+
+pytestmark = pytest.mark.gpu
+
+MODE_NAMES = {O.MODE_AND: "AND", O.MODE_OR: "OR", O.MODE_PHRASE: "PHRASE"}
+
+
+@pytest.fixture(scope="module")
+def ta():
+    import tantivy_amd
+
+    return tantivy_amd
+
+
+@pytest.fixture(scope="module")
+def synth(ta):
+    seg = O.synth_segment(200_000, n_terms=96, with_positions=True, phrase_terms=16)
+    dev = ta.DeviceIndex([seg])
+    yield seg, dev
+    dev.close()
+
+
+def _oracle_topk(seg, terms, mode, k, offsets=None):
+    return O.search(seg, terms, mode, k, pruned=False, phrase_offsets=offsets)
+
+
+def _device_topk(dev, queries, k):
+    scores, ords, docs, counts = dev.search(queries, k)
+    out = []
+    for i in range(len(queries)):
+        c = int(counts[i])
+        out.append([(float(scores[i, j]), int(docs[i, j])) for j in range(c)])
+        assert np.all(docs[i, c:] == 0x7FFFFFFF)
+    return out
+
+
+def _assert_hits_equal(got, want, exact=True):
+    assert len(got) == len(want)
+    for (gs, gd), (ws, wd) in zip(got, want):
+        assert gd == wd
+        if exact:
+            assert np.float32(gs) == np.float32(ws), (gs, ws)
+        else:
+            assert rel_close(gs, ws, 1e-5)
+
+
+# ------------------------------------------------------------------ codec
+@pytest.mark.parametrize("use_dpp", [1, 0])
+def test_decode_postings_synth(synth, use_dpp):
+    seg, dev = synth
+    dev.set_option("use_dpp", use_dpp)
+    try:
+        for t in list(range(0, 96, 5)) + [95]:
+            docs, tfs = O.decode_postings(seg, t)
+            gd, gt = dev.decode_postings(t, seg.terms[t].doc_freq)
+            assert np.array_equal(gd, docs), "term %d docs" % t
+            assert np.array_equal(gt, tfs), "term %d tfs" % t
+    finally:
+        dev.set_option("use_dpp", 1)
+
+
+def test_decode_positions_synth(synth):
+    seg, dev = synth
+    for t in (0, 3, 15, 40, 95):
+        docs, tfs = O.decode_postings(seg, t)
+        total = int(tfs.sum())
+        want, n = O.decode_positions(seg, t, total)
+        assert n == total
+        deltas, n2 = dev.decode_position_deltas(t, total)
+        assert n2 == total
+        # oracle returns per-doc prefix sums; rebuild them from the raw deltas
+        ends = np.cumsum(tfs)
+        starts = ends - tfs
+        cs = np.cumsum(deltas.astype(np.int64))
+        base = np.repeat(cs[starts] - deltas[starts].astype(np.int64), tfs)
+        assert np.array_equal((cs - base).astype(np.uint32), want)
+
+
+def test_decode_all_bit_widths(ta):
+    """Doc-delta widths 0..31 (offset-seeded and None-seeded blocks) and tf widths 0..32,
+    exact multiples of 128, vint-only lists."""
+    lists = []
+    for b in range(0, 31):   # block 1 starts after a gap of (1<<b)-1  => width b, offset seed
+        docs = list(range(128))
+        start = 127 + (1 << b)
+        docs += list(range(start, start + 128)) + [start + 200, start + 300]
+        tf_hi = (1 << (b + 2)) - 1 if b + 2 < 32 else 0xFFFFFFFF
+        tfs = [1 + ((i * 2654435761) % tf_hi) for i in range(len(docs))]
+        tfs[130] = tf_hi  # force the full tf width in block 1
+        lists.append(list(zip(docs, tfs)))
+    for b in range(1, 32):   # first block None-seeded with a raw first doc of b bits
+        first = (1 << (b - 1)) + (12345 % (1 << (b - 1)) if b > 1 else 0)
+        docs = [first + 3 * i for i in range(128)] + [first + 1000]
+        lists.append([(d, 1) for d in docs])
+    lists.append([(d, 0xFFFFFFFF) for d in range(0, 256, 2)])   # tf-1 needs 32 bits
+    lists.append([(d, 1) for d in range(0, 128)])            # exactly one full block, doc 0 first
+    lists.append([(d, 1) for d in range(5, 5 + 256)])        # two full blocks, zero-width deltas
+    lists.append([(7, 3)])                                   # single posting
+    lists.append([(d * 3, 1 + d % 7) for d in range(127)])   # vint only
+    lists.append([(d * 2, 2) for d in range(129)])           # one block + 1 tail
+    max_doc = max(pl[-1][0] for pl in lists) + 1
+    seg = O.build_segment(max_doc, lists, None, record_option=O.WITH_FREQS)
+    dev = ta.DeviceIndex([seg])
+    try:
+        for use_dpp in (1, 0):
+            dev.set_option("use_dpp", use_dpp)
+            for t, pl in enumerate(lists):
+                gd, gt = dev.decode_postings(t, len(pl))
+                assert gd.tolist() == [d for d, _ in pl], "list %d" % t
+                assert gt.tolist() == [f for _, f in pl], "list %d" % t
+    finally:
+        dev.close()
+
+
+def test_decode_basic_field_has_tf_one(ta):
+    docs = sorted(set(np.random.default_rng(1).integers(0, 50_000, size=3000).tolist()))
+    seg = O.build_segment(50_000, [[(d, 1) for d in docs]], None, record_option=O.BASIC)
+    dev = ta.DeviceIndex([seg])
+    try:
+        gd, gt = dev.decode_postings(0, len(docs))
+        assert gd.tolist() == docs and set(gt.tolist()) == {1}
+    finally:
+        dev.close()
+
+
+# ------------------------------------------------------------------ AND / OR / phrase on the synthetic index
+def test_and_two_terms_bit_exact(synth):
+    seg, dev = synth
+    rng = np.random.default_rng(5)
+    pairs = [(0, 1), (1, 0), (0, 95), (94, 95), (2, 7), (10, 50), (3, 3)]
+    pairs += [tuple(rng.choice(96, size=2, replace=False).tolist()) for _ in range(40)]
+    got = _device_topk(dev, [(O.MODE_AND, list(p)) for p in pairs], 10)
+    for p, g in zip(pairs, got):
+        _assert_hits_equal(g, _oracle_topk(seg, list(p), O.MODE_AND, 10))
+    # matched doc sets: stats count == oracle intersection size
+    dev.search([(O.MODE_AND, [0, 1])], 10)
+    st = dev.last_batch_stats()
+    d, _ = O.match_all(seg, [0, 1], O.MODE_AND)
+    assert st["matches"] == len(d)
+
+
+def test_and_full_match_set_via_large_k(synth):
+    """doc-id intersection bit-exact: ask for more hits than there are matches."""
+    seg, dev = synth
+    for terms in ([60, 90], [30, 95], [80, 81, 82]):
+        d, s = O.match_all(seg, terms, O.MODE_AND)
+        k = 1024
+        assert len(d) <= k
+        got = _device_topk(dev, [(O.MODE_AND, terms)], k)[0]
+        assert sorted(doc for _, doc in got) == d.tolist()
+        by_doc = dict((doc, sc) for sc, doc in got)
+        for doc, sc in zip(d.tolist(), s.tolist()):
+            assert np.float32(by_doc[doc]) == np.float32(sc)
+
+
+def test_and_three_and_four_terms(synth):
+    seg, dev = synth
+    qs = [[0, 1, 2], [5, 1, 40], [0, 50, 95], [3, 2, 1, 0], [10, 20, 30, 40], [0, 1, 2, 3, 4]]
+    got = _device_topk(dev, [(O.MODE_AND, q) for q in qs], 10)
+    for q, g in zip(qs, got):
+        _assert_hits_equal(g, _oracle_topk(seg, q, O.MODE_AND, 10))
+
+
+@pytest.mark.parametrize("k", [1, 10, 100, 300])
+def test_or_union(synth, k):
+    seg, dev = synth
+    rng = np.random.default_rng(k)
+    qs = [[0, 1, 2, 3, 4], [90, 91, 92, 93, 94], [0, 95], [7], [95]]
+    qs += [rng.choice(96, size=5, replace=False).tolist() for _ in range(8)]
+    got = _device_topk(dev, [(O.MODE_OR, q) for q in qs], k)
+    for q, g in zip(qs, got):
+        _assert_hits_equal(g, _oracle_topk(seg, q, O.MODE_OR, k))
+
+
+def test_or_matches_count(synth):
+    seg, dev = synth
+    dev.search([(O.MODE_OR, [20, 40, 60])], 10)
+    d, _ = O.match_all(seg, [20, 40, 60], O.MODE_OR)
+    assert dev.last_batch_stats()["matches"] == len(d)
+
+
+def test_phrase(synth):
+    seg, dev = synth
+    qs = [[0, 1, 2], [1, 2, 3], [5, 6, 7], [0, 1], [10, 11, 12], [2, 1, 0], [0, 5, 9], [13, 14, 15]]
+    got = _device_topk(dev, [(O.MODE_PHRASE, q) for q in qs], 10)
+    n_nonempty = 0
+    for q, g in zip(qs, got):
+        want = _oracle_topk(seg, q, O.MODE_PHRASE, 10)
+        _assert_hits_equal(g, want)
+        n_nonempty += bool(want)
+    assert n_nonempty >= 4
+    # phrase with explicit offsets ("a ? b")
+    got = _device_topk(dev, [(O.MODE_PHRASE, [0, 2], [0, 2])], 10)[0]
+    _assert_hits_equal(got, _oracle_topk(seg, [0, 2], O.MODE_PHRASE, 10, offsets=[0, 2]))
+
+
+def test_mixed_batch_and_stride(synth):
+    seg, dev = synth
+    qs = [(O.MODE_AND, [0, 1]), (O.MODE_OR, [3, 4, 5]), (O.MODE_PHRASE, [0, 1, 2]),
+          (O.MODE_AND, [50, 60]), (O.MODE_OR, [95]), (O.MODE_AND, [0])]
+    got = _device_topk(dev, qs, 10)
+    for q, g in zip(qs, got):
+        _assert_hits_equal(g, _oracle_topk(seg, q[1], q[0], 10))
+
+
+# ------------------------------------------------------------------ edge cases
+def test_edge_cases(ta):
+    rng = np.random.default_rng(9)
+    md = 5000
+    lists = [
+        random_postings(rng, md, 100),        # 0: < 128: no skip data
+        random_postings(rng, md, 128),        # 1: exactly one block
+        random_postings(rng, md, 256),        # 2: two blocks, no tail
+        random_postings(rng, md, 129),        # 3
+        [(0, 3)],                             # 4: doc 0 only
+        [(md - 1, 2)],                        # 5: last doc only
+        random_postings(rng, md, 2500),       # 6
+        [(d, 1) for d in range(1000, 1100)],  # 7: disjoint from 8
+        [(d, 1) for d in range(3000, 3100)],  # 8
+        [],                                   # 9: absent term
+    ]
+    fieldnorms = rng.integers(1, 400, size=md).tolist()
+    seg = O.build_segment(md, lists, fieldnorms)
+    dev = ta.DeviceIndex([seg])
+    try:
+        qs = [(O.MODE_AND, [0, 1]), (O.MODE_AND, [1, 2]), (O.MODE_AND, [2, 3]), (O.MODE_AND, [4, 6]),
+              (O.MODE_AND, [5, 6]), (O.MODE_AND, [7, 8]), (O.MODE_AND, [0, 9]), (O.MODE_OR, [9]),
+              (O.MODE_OR, [9, 4]), (O.MODE_OR, [4, 5]), (O.MODE_AND, [6, 6]), (O.MODE_OR, [6, 6]),
+              (O.MODE_OR, [0, 1, 2, 3, 4, 5, 6, 7]), (O.MODE_AND, [6, 2, 3]), (O.MODE_AND, [4])]
+        for k in (1, 3, 64, 65, 1000):
+            got = _device_topk(dev, qs, k)
+            for q, g in zip(qs, got):
+                _assert_hits_equal(g, _oracle_topk(seg, q[1], q[0], k))
+    finally:
+        dev.close()
+
+
+def test_ties_prefer_lower_doc(ta):
+    md = 1000
+    lists = [[(d, 2) for d in range(0, md, 2)], [(d, 2) for d in range(0, md, 3)]]
+    seg = O.build_segment(md, lists, [10] * md)  # identical scores for every match
+    dev = ta.DeviceIndex([seg])
+    try:
+        got = _device_topk(dev, [(O.MODE_AND, [0, 1]), (O.MODE_OR, [0, 1])], 7)
+        assert [d for _, d in got[0]] == [0, 6, 12, 18, 24, 30, 36]
+        _assert_hits_equal(got[0], _oracle_topk(seg, [0, 1], O.MODE_AND, 7))
+        _assert_hits_equal(got[1], _oracle_topk(seg, [0, 1], O.MODE_OR, 7))
+    finally:
+        dev.close()
+
+
+def test_error_paths(synth, ta):
+    seg, dev = synth
+    with pytest.raises(ta.TantivyAmdError):
+        dev.search([(O.MODE_PHRASE, [0])], 10)          # phrase needs >= 2 terms
+    with pytest.raises(ta.TantivyAmdError):
+        dev.search([(O.MODE_AND, [0, 1])], 5000)        # k above the device heap
+    with pytest.raises(ta.TantivyAmdError):
+        dev.search([(O.MODE_AND, list(range(20)))], 10)  # too many terms
+    # the segment still works afterwards
+    _assert_hits_equal(_device_topk(dev, [(O.MODE_AND, [0, 1])], 3)[0],
+                       _oracle_topk(seg, [0, 1], O.MODE_AND, 3))
+
+
+# ------------------------------------------------------------------ the reference's own corpora through the device
+def test_reference_kat_corpora(ta):
+    seg, v = corpus_segment(["Hello happy tax payer.", "Droopy says hello happy tax payer",
+                             "I like Droopy"])
+    dev = ta.DeviceIndex([seg])
+    try:
+        sc, ords, docs, cnt = dev.search([(O.MODE_OR, [v["droopy"], v["tax"]])], 4)
+        assert cnt[0] == 3 and docs[0, :3].tolist() == [1, 2, 0]
+        for got, want in zip(sc[0, :3], (0.81221175, 0.5376842, 0.48527452)):
+            assert np.float32(got) == np.float32(want)
+        sc, ords, docs, cnt = dev.search([(O.MODE_OR, [v["droopy"], v["tax"]])], 2, offset=1)
+        assert docs[0, :2].tolist() == [2, 0]
+    finally:
+        dev.close()
+    seg, v = corpus_segment(["a b c", "a b c a b"])
+    dev = ta.DeviceIndex([seg])
+    try:
+        sc, ords, docs, cnt = dev.search([(O.MODE_PHRASE, [v["a"], v["b"]])], 10)
+        assert sorted(docs[0, :2].tolist()) == [0, 1]
+        by = dict(zip(docs[0, :2].tolist(), sc[0, :2].tolist()))
+        assert abs(by[0] - 0.40618482) < 5e-4 and abs(by[1] - 0.46844664) < 5e-4
+    finally:
+        dev.close()
+    seg, v = corpus_segment(["a b c", "a c", "b c", "a b c d", "d"])
+    dev = ta.DeviceIndex([seg])
+    try:
+        sc, ords, docs, cnt = dev.search([(O.MODE_AND, [v["a"], v["b"]])], 10)
+        assert docs[0, :2].tolist() == [0, 3]
+        assert abs(sc[0, 0] - 0.977973) < 5e-4 and abs(sc[0, 1] - 0.84699446) < 5e-4
+    finally:
+        dev.close()
+
+
+def test_block_wand_regression_inputs(ta):
+    """The reference's pinned block-WAND inputs: the device's exhaustive top-k must agree with
+    the oracle's *pruned* executors under the reference's own fuzzy comparison."""
+    gold = json.load(open(os.path.join(os.path.dirname(__file__), "golden",
+                                       "block_wand_regressions.json")))
+
+    def nearly(a, b):
+        return abs(a - b) < 0.0001 * abs(a + b)
+
+    for name, mode in (("union_reproduce_proptest", O.MODE_OR),
+                       ("intersection_three_scorers_regression", O.MODE_AND)):
+        g = gold[name]
+        fn = [f for f in g["fieldnorms"] for _ in range(64)]
+        pls = [[(d * 64 + o, tf if o == 0 else 1) for d, tf in pl for o in range(64)]
+               for pl in g["posting_lists"]]
+        seg = O.build_segment(len(fn), pls, fn)
+        dev = ta.DeviceIndex([seg])
+        try:
+            for k in (1, 2, 3, 10):
+                got = _device_topk(dev, [(mode, [0, 1, 2])], k)[0]
+                want = O.search(seg, [0, 1, 2], mode, k, pruned=True)
+                exact = _oracle_topk(seg, [0, 1, 2], mode, k)
+                _assert_hits_equal(got, exact)
+                assert len(got) == len(want)
+                kth = want[-1][0] if want else 0.0
+                for (gs, gd), (ws, wd) in zip(got, want):
+                    assert nearly(gs, ws)
+                    if not nearly(ws, kth):
+                        assert gd == wd
+        finally:
+            dev.close()
+
+
+# ------------------------------------------------------------------ multi-segment merge
+def test_two_segments_global_stats_and_merge(ta):
+    segs = [O.synth_segment(60_000, n_terms=32, segment_ord=o) for o in range(2)]
+    dev = ta.DeviceIndex(segs)
+    try:
+        nd = sum(s.max_doc for s in segs)
+        nt = sum(s.total_num_tokens for s in segs)
+        qs = [(O.MODE_AND, [0, 1]), (O.MODE_OR, [2, 9, 30]), (O.MODE_AND, [5, 20, 31])]
+        sc, ords, docs, cnt = dev.search(qs, 10, offset=3)
+        for qi, (mode, terms) in enumerate(qs):
+            dfs = [sum(s.terms[t].doc_freq for s in segs) for t in terms]
+            hits = []
+            for o, s in enumerate(segs):
+                w = O.default_weights(s, terms, mode, total_num_docs=nd, total_num_tokens=nt, dfs=dfs)
+                for score, doc in O.search(s, terms, mode, 13, weights=w, pruned=False):
+                    hits.append((score, o, doc))
+            want = O.merge_top_k(hits, 3, 10)
+            got = [(float(sc[qi, j]), int(ords[qi, j]), int(docs[qi, j])) for j in range(int(cnt[qi]))]
+            assert len(got) == len(want)
+            for g, w in zip(got, want):
+                assert g[1:] == w[1:]
+                assert rel_close(g[0], w[0], 1e-5)
+    finally:
+        dev.close()
+
+
+def test_device_merge_kernel_matches_host(ta):
+    import ctypes as C
+
+    import torch
+
+    from tantivy_amd import binding as B
+
+    rng = np.random.default_rng(3)
+    S, Q, K = 4, 37, 10
+    scores = np.round(rng.random((S, Q, K)).astype(np.float32), 2)  # plenty of ties
+    scores = -np.sort(-scores, axis=2)
+    docs = rng.integers(0, 1000, size=(S, Q, K)).astype(np.uint32)
+    counts = rng.integers(0, K + 1, size=(S, Q)).astype(np.uint32)
+    for offset, limit in ((0, 10), (3, 5), (0, 64)):
+        hs = np.zeros((Q, limit), np.float32)
+        ho = np.zeros((Q, limit), np.uint32)
+        hd = np.zeros((Q, limit), np.uint32)
+        hc = np.zeros(Q, np.uint32)
+        L = B.lib()
+        assert L.tq_merge_topk(B._f32(scores), B._u32(docs), B._u32(counts), S, Q, K, offset, limit,
+                               B._f32(hs), B._u32(ho), B._u32(hd), B._u32(hc)) == 0
+        ctx = C.c_void_p()
+        assert L.tq_init(None, 0, C.byref(ctx)) == 0
+        ds, dd, dc = (torch.from_numpy(a.view(np.int32) if a.dtype == np.uint32 else a).cuda()
+                      for a in (scores, docs, counts))
+        os_ = torch.zeros((Q, limit), dtype=torch.float32, device="cuda")
+        oo = torch.zeros((Q, limit), dtype=torch.int32, device="cuda")
+        od = torch.zeros((Q, limit), dtype=torch.int32, device="cuda")
+        oc = torch.zeros(Q, dtype=torch.int32, device="cuda")
+        torch.cuda.synchronize()
+        rc = L.tq_merge_topk_device(ctx, 0, ds.data_ptr(), dd.data_ptr(), dc.data_ptr(), None, S, Q,
+                                    K, offset, limit, os_.data_ptr(), oo.data_ptr(), od.data_ptr(),
+                                    oc.data_ptr(), None)
+        assert rc == 0, L.tq_last_error()
+        torch.cuda.synchronize()
+        assert np.array_equal(oc.cpu().numpy().view(np.uint32), hc)
+        assert np.array_equal(os_.cpu().numpy(), hs)
+        assert np.array_equal(oo.cpu().numpy().view(np.uint32), ho)
+        assert np.array_equal(od.cpu().numpy().view(np.uint32), hd)
+        L.tq_shutdown(ctx)
+
+
+# ------------------------------------------------------------------ BASELINE-size properties (10M docs)
+@pytest.fixture(scope="module")
+def big(ta):
+    seg = O.synth_segment(10_000_000, n_terms=256)
+    dev = ta.DeviceIndex([seg])
+    yield seg, dev
+    dev.close()
+
+
+def test_full_size_and_against_oracle(big):
+    seg, dev = big
+    qs = [[0, 1], [0, 255], [1, 2], [100, 200], [254, 255], [3, 17]]
+    got = _device_topk(dev, [(O.MODE_AND, q) for q in qs], 10)
+    for q, g in zip(qs, got):
+        _assert_hits_equal(g, _oracle_topk(seg, q, O.MODE_AND, 10))
+    dev.search([(O.MODE_AND, [0, 1])], 10)
+    st = dev.last_batch_stats()
+    spec = O.QuerySpec(seg, [0, 1], O.default_weights(seg, [0, 1], O.MODE_AND), O.MODE_AND, 1)
+    import ctypes as C
+    n = O.lib().to_match_all(C.byref(seg.view), C.byref(spec.q), None, None, 0)
+    assert st["matches"] == n
+
+
+def test_full_size_properties(big):
+    seg, dev = big
+    qid = O.zipf_queries(400, 2, 256, seed=1234)
+    sc, ords, docs, cnt = dev.search([(O.MODE_AND, q.tolist()) for q in qid], 10)
+    for i in range(len(qid)):
+        c = int(cnt[i])
+        s, d = sc[i, :c], docs[i, :c]
+        # sortedness: score desc, ties doc asc
+        assert np.all(s[:-1] >= s[1:])
+        tie = s[:-1] == s[1:]
+        assert np.all(d[:-1][tie] < d[1:][tie])
+        assert len(set(d.tolist())) == c
+    # idempotence: same batch twice gives identical bytes
+    sc2, _, docs2, cnt2 = dev.search([(O.MODE_AND, q.tolist()) for q in qid], 10)
+    assert np.array_equal(sc, sc2) and np.array_equal(docs, docs2) and np.array_equal(cnt, cnt2)
+    # k-monotonicity: top-10 is a prefix of top-50
+    sc50, _, docs50, _ = dev.search([(O.MODE_AND, q.tolist()) for q in qid[:50]], 50)
+    assert np.array_equal(docs50[:, :10], docs[:50]) and np.array_equal(sc50[:, :10], sc[:50])
+    # a sample against the oracle
+    for i in (0, 7, 99, 250):
+        _assert_hits_equal([(float(sc[i, j]), int(docs[i, j])) for j in range(int(cnt[i]))],
+                           _oracle_topk(seg, qid[i].tolist(), O.MODE_AND, 10))
+
+
+def test_full_size_or_top100(big):
+    seg, dev = big
+    qs = [[0, 1, 2, 3, 4], [10, 50, 100, 150, 200], [251, 252, 253, 254, 255]]
+    got = _device_topk(dev, [(O.MODE_OR, q) for q in qs], 100)
+    for q, g in zip(qs, got):
+        _assert_hits_equal(g, _oracle_topk(seg, q, O.MODE_OR, 100))
