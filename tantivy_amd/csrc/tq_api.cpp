@@ -150,7 +150,7 @@ struct tq_segment {
   bool d_terms_dirty = false;
   std::unordered_map<uint64_t, uint32_t> term_by_off;
   // batch scratch
-  DevBuf d_stage, d_partials, d_out_scores, d_out_docs, d_out_counts, d_misc;
+  DevBuf d_stage, d_partials, d_out_scores, d_out_docs, d_out_counts, d_misc, d_thr;
   PinnedBuf h_stage, h_out;
   hipEvent_t ev_stage_done = nullptr, ev_t0 = nullptr, ev_t1 = nullptr, ev_k0 = nullptr,
              ev_k1 = nullptr;
@@ -259,6 +259,7 @@ void tq_segment_free(tq_segment *s) {
   s->d_out_docs.release();
   s->d_out_counts.release();
   s->d_misc.release();
+  s->d_thr.release();
   s->h_stage.release();
   s->h_out.release();
   for (hipEvent_t ev : {s->ev_stage_done, s->ev_t0, s->ev_t1, s->ev_k0, s->ev_k1})
@@ -307,11 +308,11 @@ int tq_term_prepare(tq_segment *s, uint64_t postings_off, uint32_t postings_len,
   const size_t payload = at;
 
   const uint32_t n_blocks = n_full + (n_tail ? 1u : 0u);
-  std::vector<TqdBlock> blocks(n_blocks);
-  std::vector<uint64_t> block_pos(n_blocks + 1, 0);
+  std::vector<uint32_t> b_last(n_blocks), b_meta(n_blocks), b_off(n_blocks);
+  std::vector<uint32_t> block_pos(n_blocks + 1, 0);
   size_t running = 0;
   uint64_t running_pos = 0;
-  uint32_t last_doc = 0, max_tf_code = 0;
+  uint32_t last_doc = 0;
   for (uint32_t i = 0; i < n_full; ++i) {  // skip.rs:205-253,275-302
     const uint8_t *e = skip + entry * i;
     const uint32_t ld = rd32(e);
@@ -329,14 +330,15 @@ int tq_term_prepare(tq_segment *s, uint64_t postings_off, uint32_t postings_len,
     }
     if (tf_bits > 32u) return fail(TQ_ERR_FORMAT, "tf bit width %u > 32", tf_bits);
     if (i && ld <= last_doc) return fail(TQ_ERR_FORMAT, "skip last_doc not increasing");
-    blocks[i].last_doc = ld;
-    blocks[i].bits = doc_bits | (strict << 6) | (tf_bits << 8) | (bm_fn << 16) | (bm_tf << 24);
-    blocks[i].byte_off = abs0 + payload + running;
-    block_pos[i] = running_pos;
+    if (running_pos > 0xFFFFFFFFull)
+      return fail(TQ_ERR_UNSUPPORTED, "term with more than 2^32 positions");
+    b_last[i] = ld;
+    b_meta[i] = doc_bits | (strict << 6) | (tf_bits << 8) | (bm_fn << 16) | (bm_tf << 24);
+    b_off[i] = (uint32_t)running;  // < postings_len, a u32 (term_info.rs:10-17)
+    block_pos[i] = (uint32_t)running_pos;
     running += 16u * (size_t)(doc_bits + tf_bits);
     running_pos += tf_sum;
     last_doc = ld;
-    max_tf_code = std::max(max_tf_code, bm_tf);
   }
   if (payload + running > len) return fail(TQ_ERR_FORMAT, "bitpacked payload exceeds the list");
   std::vector<uint32_t> tail_docs(n_tail), tail_tfs(n_tail, 1u);
@@ -354,17 +356,36 @@ int tq_term_prepare(tq_segment *s, uint64_t postings_off, uint32_t postings_len,
         if (!read_vint32_block(data, len, t, tail_tfs[i]))
           return fail(TQ_ERR_FORMAT, "truncated vint term freqs");
     }
-    blocks[n_full].last_doc = tail_docs[n_tail - 1];
-    blocks[n_full].bits = 0xFFFFFFFFu;
-    blocks[n_full].byte_off = 0;
-    block_pos[n_full] = running_pos;
-    for (uint32_t i = 0; i < n_tail; ++i) running_pos += tail_tfs[i];
+    if (running_pos > 0xFFFFFFFFull)
+      return fail(TQ_ERR_UNSUPPORTED, "term with more than 2^32 positions");
+    b_last[n_full] = tail_docs[n_tail - 1];
+    b_meta[n_full] = 0xFFFFFFFFu;
+    b_off[n_full] = 0;
+    block_pos[n_full] = (uint32_t)running_pos;
+    if (record == TQ_WITH_FREQS_AND_POSITIONS)  // tf sums only index a positions stream
+      for (uint32_t i = 0; i < n_tail; ++i) running_pos += tail_tfs[i];
     last_doc = tail_docs[n_tail - 1];
   }
-  block_pos[n_blocks] = running_pos;
   if (running_pos > 0xFFFFFFFFull)
     return fail(TQ_ERR_UNSUPPORTED, "term with more than 2^32 positions");
+  block_pos[n_blocks] = (uint32_t)running_pos;
   if (last_doc >= TQ_TERMINATED) return fail(TQ_ERR_FORMAT, "doc id >= TERMINATED");
+  if (last_doc >= s->max_doc)
+    return fail(TQ_ERR_FORMAT, "doc id %u >= max_doc %u", last_doc, s->max_doc);
+
+  // coarse[b] = first block j with last_doc[j] >= b << shift, about one block per bucket
+  uint32_t shift = 7;
+  while (shift < 31 && ((uint64_t)(s->max_doc - 1) >> shift) + 1 > 2ull * n_blocks + 2) ++shift;
+  const uint32_t n_buckets = (uint32_t)(((uint64_t)(s->max_doc - 1)) >> shift) + 1;
+  std::vector<uint32_t> coarse(n_buckets + 1);
+  {
+    uint32_t j = 0;
+    for (uint32_t b = 0; b <= n_buckets; ++b) {
+      const uint64_t lo = (uint64_t)b << shift;
+      while (j < n_blocks && (uint64_t)b_last[j] < lo) ++j;
+      coarse[b] = j;
+    }
+  }
 
   // positions stream (positions/reader.rs:43-56,84-101)
   std::vector<uint64_t> pos_block_off;
@@ -403,23 +424,35 @@ int tq_term_prepare(tq_segment *s, uint64_t postings_off, uint32_t postings_len,
                   (unsigned long long)n_pos, (unsigned long long)running_pos);
   }
 
-  // one blob: blocks | tail_docs | tail_tfs | block_pos | pos_block_off | pos_tail | pos_widths
+  // one blob holding every per-term array
   auto align16 = [](size_t x) { return (x + 15) & ~(size_t)15; };
-  const size_t o_blocks = 0;
-  const size_t o_tdocs = align16(o_blocks + sizeof(TqdBlock) * n_blocks);
-  const size_t o_ttfs = align16(o_tdocs + 4 * (size_t)n_tail);
-  const size_t o_bpos = align16(o_ttfs + 4 * (size_t)n_tail);
-  const size_t o_pboff = align16(o_bpos + 8 * (size_t)(n_blocks + 1));
-  const size_t o_ptail = align16(o_pboff + 8 * pos_block_off.size());
-  const size_t o_pw = align16(o_ptail + 4 * pos_tail.size());
-  const size_t total = align16(o_pw + pos_widths.size()) + PAD;
+  size_t total = 0;
+  auto place = [&](size_t bytes) {
+    const size_t o = total;
+    total = align16(total + bytes);
+    return o;
+  };
+  const size_t o_last = place(4 * (size_t)n_blocks);
+  const size_t o_meta = place(4 * (size_t)n_blocks);
+  const size_t o_off = place(4 * (size_t)n_blocks);
+  const size_t o_coarse = place(4 * coarse.size());
+  const size_t o_tdocs = place(4 * (size_t)n_tail);
+  const size_t o_ttfs = place(4 * (size_t)n_tail);
+  const size_t o_bpos = place(4 * (size_t)(n_blocks + 1));
+  const size_t o_pboff = place(8 * pos_block_off.size());
+  const size_t o_ptail = place(4 * pos_tail.size());
+  const size_t o_pw = place(pos_widths.size());
+  total += PAD;
   std::vector<uint8_t> hb(total, 0);
-  memcpy(hb.data() + o_blocks, blocks.data(), sizeof(TqdBlock) * n_blocks);
+  memcpy(hb.data() + o_last, b_last.data(), 4 * (size_t)n_blocks);
+  memcpy(hb.data() + o_meta, b_meta.data(), 4 * (size_t)n_blocks);
+  memcpy(hb.data() + o_off, b_off.data(), 4 * (size_t)n_blocks);
+  memcpy(hb.data() + o_coarse, coarse.data(), 4 * coarse.size());
   if (n_tail) {
     memcpy(hb.data() + o_tdocs, tail_docs.data(), 4 * (size_t)n_tail);
     memcpy(hb.data() + o_ttfs, tail_tfs.data(), 4 * (size_t)n_tail);
   }
-  memcpy(hb.data() + o_bpos, block_pos.data(), 8 * (size_t)(n_blocks + 1));
+  memcpy(hb.data() + o_bpos, block_pos.data(), 4 * (size_t)(n_blocks + 1));
   if (!pos_block_off.empty()) memcpy(hb.data() + o_pboff, pos_block_off.data(), 8 * pos_block_off.size());
   if (!pos_tail.empty()) memcpy(hb.data() + o_ptail, pos_tail.data(), 4 * pos_tail.size());
   if (!pos_widths.empty()) memcpy(hb.data() + o_pw, pos_widths.data(), pos_widths.size());
@@ -431,13 +464,17 @@ int tq_term_prepare(tq_segment *s, uint64_t postings_off, uint32_t postings_len,
     return fail(TQ_ERR_HIP, "term upload: %s", hipGetErrorString(ce));
   }
   TqdTerm dt{};
-  dt.blocks = (const TqdBlock *)(blob + o_blocks);
+  dt.last_doc = (const uint32_t *)(blob + o_last);
+  dt.meta = (const uint32_t *)(blob + o_meta);
+  dt.byte_off = (const uint32_t *)(blob + o_off);
+  dt.coarse = (const uint32_t *)(blob + o_coarse);
   dt.tail_docs = (const uint32_t *)(blob + o_tdocs);
   dt.tail_tfs = (const uint32_t *)(blob + o_ttfs);
-  dt.block_pos = (const uint64_t *)(blob + o_bpos);
+  dt.block_pos = (const uint32_t *)(blob + o_bpos);
   dt.pos_block_off = (const uint64_t *)(blob + o_pboff);
   dt.pos_widths = (const uint8_t *)(blob + o_pw);
   dt.pos_tail = (const uint32_t *)(blob + o_ptail);
+  dt.payload_base = abs0 + payload;
   dt.n_full = n_full;
   dt.n_tail = n_tail;
   dt.n_blocks = n_blocks;
@@ -445,7 +482,7 @@ int tq_term_prepare(tq_segment *s, uint64_t postings_off, uint32_t postings_len,
   dt.n_pos_blocks = (uint32_t)pos_block_off.size();
   dt.n_pos_tail = (uint32_t)pos_tail.size();
   dt.has_freq = has_freq ? 1u : 0u;
-  dt.max_bm_tf_code = max_tf_code;
+  dt.coarse_shift = shift;
 
   TermHost th;
   th.blob = blob;
@@ -522,6 +559,7 @@ int tq_search_batch_device(tq_segment *s, const tq_query *queries, uint32_t n_qu
   groups[2].mode = TQ_MODE_PHRASE;
   std::vector<const float *> caches;
   uint64_t algo_bytes = 0;
+  uint32_t n_thr_rows = 0;
   for (uint32_t qi = 0; qi < n_queries; ++qi) {
     const tq_query &q = queries[qi];
     if (q.n_terms == 0 || q.n_terms > TQ_MAX_TERMS)
@@ -542,6 +580,7 @@ int tq_search_batch_device(tq_segment *s, const tq_query *queries, uint32_t n_qu
     if (cache_idx == caches.size()) caches.push_back(q.tf_cache);
 
     TqdQuery dq{};
+    dq.thr_index = 0xFFFFFFFFu;
     dq.k = q.k;
     dq.cache_idx = cache_idx;
     dq.mode = q.mode;
@@ -573,8 +612,6 @@ int tq_search_batch_device(tq_segment *s, const tq_query *queries, uint32_t n_qu
           dq.term[i] = q.terms[src];
           dq.weight[i] = mode == TQ_MODE_PHRASE ? q.weights[0] : q.weights[src];
           if (mode == TQ_MODE_PHRASE) dq.phrase_off[i] = max_off - q.phrase_offsets[src];
-          if (mode == TQ_MODE_AND && q.n_terms > 2 && !(dq.weight[i] >= 0.0f))
-            return fail(TQ_ERR_UNSUPPORTED, "query %u: negative weight in a 3+ term AND", qi);
           qbytes += s->terms[q.terms[src]].postings_len;
           if (mode == TQ_MODE_PHRASE) {
             if (s->terms[q.terms[src]].positions_len == 0)
@@ -585,9 +622,19 @@ int tq_search_batch_device(tq_segment *s, const tq_query *queries, uint32_t n_qu
         dq.n_terms = q.n_terms;
         if (mode == TQ_MODE_AND && q.n_terms == 1) {
           mode = TQ_MODE_OR;  // TermWeight::for_each_pruning: every doc of the list
+        } else if (mode == TQ_MODE_AND) {
+          const uint32_t lead_blocks = s->terms[dq.term[0]].n_blocks;
+          n_tiles = (lead_blocks + TQD_AND_TILE - 1) / TQD_AND_TILE;
+          bool nonneg = true;
+          for (uint32_t i = 0; i < q.n_terms; ++i) nonneg = nonneg && dq.weight[i] >= 0.0f;
+          if (!s->opt.exhaustive && nonneg) {  // block-max bounds need weights >= 0
+            dq.flags |= TQD_QF_PRUNE;
+            // the shared threshold pays off on long lists only; k-th largest of 64 slots needs k <= 64
+            if (q.k <= TQD_THR_SLOTS && n_tiles >= 2) dq.thr_index = n_thr_rows++;
+          }
         } else {
           const uint32_t drv_blocks = s->terms[dq.term[q.n_terms - 1]].n_blocks;
-          n_tiles = (drv_blocks + TQD_AND_M - 1) / TQD_AND_M;
+          n_tiles = (drv_blocks + TQD_PH_M - 1) / TQD_PH_M;
         }
       }
     }
@@ -699,6 +746,12 @@ int tq_search_batch_device(tq_segment *s, const tq_query *queries, uint32_t n_qu
   HIP_TRY(hipEventRecord(s->ev_stage_done, st));
   s->stage_in_flight = true;
   HIP_TRY(hipMemsetAsync(s->d_match_counter, 0, sizeof(unsigned long long), st));
+  if (n_thr_rows) {
+    const size_t thr_bytes = (size_t)n_thr_rows * TQD_THR_SLOTS * sizeof(uint32_t);
+    rc = s->d_thr.ensure(thr_bytes);
+    if (rc != TQ_OK) return rc;
+    HIP_TRY(hipMemsetAsync(s->d_thr.p, 0, thr_bytes, st));
+  }
 
   // ---- launch
   const uint8_t *ds = (const uint8_t *)s->d_stage.p;
@@ -715,6 +768,7 @@ int tq_search_batch_device(tq_segment *s, const tq_query *queries, uint32_t n_qu
     p.caches = (const float *)(ds + o_caches);
     p.partials = (uint64_t *)((uint8_t *)s->d_partials.p + part_off_bytes[gi]);
     p.match_counter = s->d_match_counter;
+    p.thr_slots = (uint32_t *)s->d_thr.p;
     p.n_queries = (uint32_t)g.queries.size();
     p.total_tiles = g.total_tiles;
     p.tiles_per_chunk = g.tiles_per_chunk;

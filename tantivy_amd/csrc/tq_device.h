@@ -8,33 +8,37 @@
 
 // Tunables of the scan kernels (see DESIGN.md "AND kernel").
 #define TQD_WAVES_PER_WG 4    // independent wavefronts per workgroup
-#define TQD_AND_M 4           // driver-list blocks per tile
-#define TQD_AND_CH 4          // leader-list blocks per hash-table fill
-#define TQD_AND_SLOTS 1024    // hash slots per wavefront (load factor <= 0.5)
+#define TQD_AND_TILE 64       // leader-list blocks per AND tile (one lane each in the pre-filter)
+#define TQD_THR_SLOTS 64      // shared threshold slots per query (pruned mode)
+#define TQD_PH_M 4            // phrase: driver-list blocks per tile
+#define TQD_PH_SLOTS 1024     // phrase: hash slots per wavefront (load factor <= 0.25)
 #define TQD_OR_WINDOW 4096    // docs per OR tile (one workgroup)
 
-// One 128-doc block of a posting list, the skip entry of src/postings/skip.rs:205-253 unrolled
-// from its sequential form (running byte/position offsets made absolute).
-struct TqdBlock {
-  uint32_t last_doc;   // last doc id in the block
-  uint32_t bits;       // doc_bits | strict<<6 | tf_bits<<8 | bm_fieldnorm_id<<16 | bm_tf_code<<24
-                       // 0xFFFFFFFF => the vint tail (pre-decoded in tail_docs/tail_tfs)
-  uint64_t byte_off;   // absolute offset of the bitpacked doc payload inside the .idx sub-file
-};
-
+// A posting list on the device.  The skip list of src/postings/skip.rs:205-253 is unrolled from
+// its sequential form (running byte / position offsets made absolute) into structure-of-arrays
+// tables, so that any block can be located and decoded independently of the others:
+//   last_doc[j]  last doc id in block j (skip.rs `last_doc_in_block`)
+//   meta[j]      doc_bits | strict<<6 | tf_bits<<8 | block-max fieldnorm_id<<16 | block-max tf
+//                code<<24 (skip.rs:16-43,205-253); 0xFFFFFFFF = the vint tail (pre-decoded)
+//   byte_off[j]  offset of the bitpacked doc payload, relative to payload_base
+//   coarse[b]    first j with last_doc[j] >= (b << coarse_shift): O(1) `seek_block`
 struct TqdTerm {
-  const TqdBlock *blocks;     // n_blocks entries (full blocks, then the tail pseudo-block)
+  const uint32_t *last_doc;   // n_blocks
+  const uint32_t *meta;       // n_blocks
+  const uint32_t *byte_off;   // n_blocks
+  const uint32_t *coarse;     // ((max_doc-1) >> coarse_shift) + 2 entries
   const uint32_t *tail_docs;  // n_tail
   const uint32_t *tail_tfs;   // n_tail
-  const uint64_t *block_pos;  // n_blocks+1: index (in positions) of the first position of a block
+  const uint32_t *block_pos;  // n_blocks+1: index (in positions) of the first position of a block
   // positions stream (src/positions/reader.rs): per position-block absolute byte offset / width
   const uint64_t *pos_block_off;  // n_pos_blocks
   const uint8_t *pos_widths;      // n_pos_blocks
   const uint32_t *pos_tail;       // vint tail, pre-decoded deltas
+  uint64_t payload_base;          // absolute offset (inside the .idx sub-file) of block 0's payload
   uint32_t n_full, n_tail, n_blocks, doc_freq;
   uint32_t n_pos_blocks, n_pos_tail;
   uint32_t has_freq;  // 0 => every tf reads as 1
-  uint32_t max_bm_tf_code;
+  uint32_t coarse_shift;
 };
 
 struct TqdQuery {
@@ -49,7 +53,11 @@ struct TqdQuery {
   uint32_t n_tiles;
   uint32_t part_start;  // first partial top-k list of this query
   uint32_t n_parts;
+  uint32_t flags;       // TQD_QF_*
+  uint32_t thr_index;   // row of the shared-threshold table (pruned mode), or 0xFFFFFFFF
 };
+
+#define TQD_QF_PRUNE 1u  // block-max pruning allowed (all weights >= 0, caller asked for it)
 
 struct TqdSegment {
   const uint8_t *idx;        // .idx sub-file (8-byte header included), padded

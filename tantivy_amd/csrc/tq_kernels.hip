@@ -120,73 +120,112 @@ __device__ __forceinline__ uint32_t unpack_one(const uint8_t *p, uint32_t b, uin
 
 // ------------------------------------------------------------------ block decode
 struct TermRef {
-  const TqdBlock *blocks;
+  const uint32_t *last_doc;
+  const uint32_t *meta;
+  const uint32_t *byte_off;
+  const uint32_t *coarse;
   const uint32_t *tail_docs;
   const uint32_t *tail_tfs;
+  uint64_t payload_base;
   uint32_t n_blocks;
   uint32_t n_tail;
   uint32_t has_freq;
+  uint32_t shift;
 };
 __device__ __forceinline__ TermRef load_term(const TqdTerm *terms, uint32_t handle) {
   const TqdTerm *t = uni_ptr(terms + handle);
   TermRef r;
-  r.blocks = uni_ptr(t->blocks);
+  r.last_doc = uni_ptr(t->last_doc);
+  r.meta = uni_ptr(t->meta);
+  r.byte_off = uni_ptr(t->byte_off);
+  r.coarse = uni_ptr(t->coarse);
   r.tail_docs = uni_ptr(t->tail_docs);
   r.tail_tfs = uni_ptr(t->tail_tfs);
+  r.payload_base = uni64(t->payload_base);
   r.n_blocks = uni(t->n_blocks);
   r.n_tail = uni(t->n_tail);
   r.has_freq = uni(t->has_freq);
+  r.shift = uni(t->coarse_shift);
   return r;
 }
 __device__ __forceinline__ uint32_t block_first_possible(const TermRef &t, uint32_t j) {
-  return j ? uni(t.blocks[j - 1].last_doc) + 1u : 0u;
+  return j ? uni(t.last_doc[j - 1]) + 1u : 0u;
 }
 
 struct Dec {
   uint32_t d0, d1;  // doc ids (TQD_TERMINATED padded)
   uint32_t t0, t1;  // term freqs
 };
+constexpr uint32_t META_TAIL = 0xFFFFFFFFu;
+
+// doc ids of block j (wave-uniform j): lane t gets docs 2t, 2t+1
+template <bool USE_DPP>
+__device__ __forceinline__ void decode_docs(const uint8_t *idx, const TermRef &t, uint32_t j,
+                                            uint32_t meta, int lane, uint32_t &d0, uint32_t &d1) {
+  if (meta == META_TAIL) {  // vint tail, pre-decoded at term_prepare
+    const uint32_t i0 = 2u * (uint32_t)lane, i1 = i0 + 1u;
+    d0 = i0 < t.n_tail ? t.tail_docs[i0] : TQD_TERMINATED;
+    d1 = i1 < t.n_tail ? t.tail_docs[i1] : TQD_TERMINATED;
+    return;
+  }
+  const uint8_t *p = idx + t.payload_base + uni(t.byte_off[j]);
+  const uint32_t prev = j ? uni(t.last_doc[j - 1]) : 0u;
+  const uint32_t doc_bits = meta & 31u;
+  const uint32_t strict = (meta >> 6) & 1u;
+  uint32_t x0, x1;
+  unpack2(p, doc_bits, lane, x0, x1);
+  const uint32_t a0 = x0 + strict;
+  const uint32_t a1 = a0 + x1 + strict;
+  const uint32_t incl = wave_inclusive_scan<USE_DPP>(a1, lane);
+  // compression/mod.rs:36-39,112-121: offset 0 <=> None <=> seed u32::MAX (wrapping)
+  const uint32_t base = (strict && prev == 0u) ? 0xFFFFFFFFu : prev;
+  const uint32_t excl = base + (incl - a1);
+  d0 = excl + a0;
+  d1 = excl + a1;
+}
+// term freqs of block j for the same lane layout (padding of the tail reads as tf 0)
+__device__ __forceinline__ void decode_tfs(const uint8_t *idx, const TermRef &t, uint32_t j,
+                                           uint32_t meta, int lane, uint32_t &t0, uint32_t &t1) {
+  if (meta == META_TAIL) {
+    const uint32_t i0 = 2u * (uint32_t)lane, i1 = i0 + 1u;
+    t0 = i0 < t.n_tail ? (t.has_freq ? t.tail_tfs[i0] : 1u) : 0u;
+    t1 = i1 < t.n_tail ? (t.has_freq ? t.tail_tfs[i1] : 1u) : 0u;
+    return;
+  }
+  if (!t.has_freq) {
+    t0 = 1u;
+    t1 = 1u;
+    return;
+  }
+  const uint32_t doc_bits = meta & 31u;
+  const uint32_t strict = (meta >> 6) & 1u;
+  const uint32_t tf_bits = (meta >> 8) & 0xFFu;
+  const uint8_t *p = idx + t.payload_base + uni(t.byte_off[j]) + 16u * doc_bits;
+  unpack2(p, tf_bits, lane, t0, t1);
+  t0 += strict;  // minus-one encoding is tied to the strict flag
+  t1 += strict;  // (block_segment_postings.rs:45-57)
+}
+// term freq of the posting at index i (0..127) of block j; j and meta may differ per lane
+__device__ __forceinline__ uint32_t block_tf_at(const uint8_t *idx, const TermRef &t, uint32_t j,
+                                                uint32_t meta, uint32_t i) {
+  if (!t.has_freq) return 1u;
+  if (meta == META_TAIL) return t.tail_tfs[i];
+  const uint32_t doc_bits = meta & 31u;
+  const uint32_t strict = (meta >> 6) & 1u;
+  const uint32_t tf_bits = (meta >> 8) & 0xFFu;
+  const uint8_t *p = idx + t.payload_base + t.byte_off[j] + 16u * doc_bits;
+  return unpack_one(p, tf_bits, i) + strict;
+}
+
 // WANT_TF_SCAN: also return the exclusive prefix sum of the tfs (position index inside the block)
 template <bool USE_DPP, bool WANT_TF_SCAN>
 __device__ __forceinline__ Dec decode_block(const uint8_t *idx, const TermRef &t, uint32_t j,
                                             int lane, uint32_t *tf_excl0 = nullptr,
                                             uint32_t *tf_excl1 = nullptr) {
   Dec r;
-  const uint32_t bits = uni(t.blocks[j].bits);
-  if (bits == 0xFFFFFFFFu) {  // vint tail, pre-decoded at term_prepare
-    const uint32_t i0 = 2u * (uint32_t)lane, i1 = i0 + 1u;
-    r.d0 = i0 < t.n_tail ? t.tail_docs[i0] : TQD_TERMINATED;
-    r.d1 = i1 < t.n_tail ? t.tail_docs[i1] : TQD_TERMINATED;
-    r.t0 = (t.has_freq && i0 < t.n_tail) ? t.tail_tfs[i0] : 1u;
-    r.t1 = (t.has_freq && i1 < t.n_tail) ? t.tail_tfs[i1] : 1u;
-    if (i0 >= t.n_tail) r.t0 = 0u;  // padding contributes nothing to position offsets
-    if (i1 >= t.n_tail) r.t1 = 0u;
-  } else {
-    const uint64_t off = uni64(t.blocks[j].byte_off);
-    const uint32_t prev = j ? uni(t.blocks[j - 1].last_doc) : 0u;
-    const uint32_t doc_bits = bits & 31u;
-    const uint32_t strict = (bits >> 6) & 1u;
-    const uint32_t tf_bits = (bits >> 8) & 0xFFu;
-    const uint8_t *p = idx + off;
-    uint32_t x0, x1;
-    unpack2(p, doc_bits, lane, x0, x1);
-    const uint32_t a0 = x0 + strict;
-    const uint32_t a1 = a0 + x1 + strict;
-    const uint32_t incl = wave_inclusive_scan<USE_DPP>(a1, lane);
-    // compression/mod.rs:36-39,112-121: offset 0 <=> None <=> seed u32::MAX (wrapping)
-    const uint32_t base = (strict && prev == 0u) ? 0xFFFFFFFFu : prev;
-    const uint32_t excl = base + (incl - a1);
-    r.d0 = excl + a0;
-    r.d1 = excl + a1;
-    if (t.has_freq) {
-      unpack2(p + 16u * doc_bits, tf_bits, lane, r.t0, r.t1);
-      r.t0 += strict;  // minus-one encoding is tied to the strict flag
-      r.t1 += strict;  // (block_segment_postings.rs:45-57)
-    } else {
-      r.t0 = 1u;
-      r.t1 = 1u;
-    }
-  }
+  const uint32_t meta = uni(t.meta[j]);
+  decode_docs<USE_DPP>(idx, t, j, meta, lane, r.d0, r.d1);
+  decode_tfs(idx, t, j, meta, lane, r.t0, r.t1);
   if (WANT_TF_SCAN) {
     const uint32_t s = r.t0 + r.t1;
     const uint32_t incl = wave_inclusive_scan<USE_DPP>(s, lane);
@@ -197,7 +236,7 @@ __device__ __forceinline__ Dec decode_block(const uint8_t *idx, const TermRef &t
 }
 
 // first block index j in [0, n_blocks) with last_doc(j) >= target, else n_blocks.
-// 64-ary cooperative search: 3 rounds for 40k blocks.
+// Wave-uniform target: 64-ary cooperative search, 3 rounds for 40k blocks.
 __device__ __forceinline__ uint32_t lower_bound_block(const TermRef &t, uint32_t target,
                                                       int lane) {
   uint32_t lo = 0, n = t.n_blocks;  // invariant: answer in [lo, lo+n]
@@ -205,7 +244,7 @@ __device__ __forceinline__ uint32_t lower_bound_block(const TermRef &t, uint32_t
     const uint32_t step = (n + 63u) >> 6;
     const uint32_t idx = lo + ((uint32_t)lane + 1u) * step - 1u;
     bool ge = true;
-    if (idx < lo + n) ge = t.blocks[idx].last_doc >= target;
+    if (idx < lo + n) ge = t.last_doc[idx] >= target;
     const uint64_t m = __ballot(ge);
     if (m == 0ull) {  // every probe (the last one sits on lo+n-1) is below the target
       lo += n;
@@ -218,6 +257,20 @@ __device__ __forceinline__ uint32_t lower_bound_block(const TermRef &t, uint32_t
     lo = new_lo;
     lo = uni(lo);
     n = uni(n);
+  }
+  return lo;
+}
+// The same for a per-lane target (BlockSegmentPostings::seek_block, skip.rs:263-273, made O(1)):
+// the coarse table brackets the answer, a short binary search finishes.  doc < max_doc.
+__device__ __forceinline__ uint32_t seek_block(const TermRef &t, uint32_t doc) {
+  const uint32_t b = doc >> t.shift;
+  uint32_t lo = t.coarse[b], hi = t.coarse[b + 1u];
+  while (lo < hi) {
+    const uint32_t mid = (lo + hi) >> 1;
+    if (t.last_doc[mid] >= doc)
+      hi = mid;
+    else
+      lo = mid + 1u;
   }
   return lo;
 }
@@ -295,21 +348,21 @@ struct TopK {
 
 // ------------------------------------------------------------------ per-wave LDS hash table
 struct WaveTable {
-  uint32_t doc[TQD_AND_SLOTS];
-  uint32_t val[TQD_AND_SLOTS];
+  uint32_t doc[TQD_PH_SLOTS];
+  uint32_t val[TQD_PH_SLOTS];
 };
 __device__ __forceinline__ uint32_t ht_insert(WaveTable &tb, uint32_t doc, uint32_t val) {
-  uint32_t h = doc & (TQD_AND_SLOTS - 1u);
+  uint32_t h = doc & (TQD_PH_SLOTS - 1u);
   for (;;) {
     const uint32_t prev = atomicCAS(&tb.doc[h], EMPTY_SLOT, doc);
     if (prev == EMPTY_SLOT) break;
-    h = (h + 1u) & (TQD_AND_SLOTS - 1u);
+    h = (h + 1u) & (TQD_PH_SLOTS - 1u);
   }
   tb.val[h] = val;
   return h;
 }
 __device__ __forceinline__ bool ht_find(const WaveTable &tb, uint32_t doc, uint32_t &slot) {
-  uint32_t h = doc & (TQD_AND_SLOTS - 1u);
+  uint32_t h = doc & (TQD_PH_SLOTS - 1u);
   for (;;) {
     const uint32_t d = tb.doc[h];
     if (d == doc) {
@@ -317,7 +370,7 @@ __device__ __forceinline__ bool ht_find(const WaveTable &tb, uint32_t doc, uint3
       return true;
     }
     if (d == EMPTY_SLOT) return false;
-    h = (h + 1u) & (TQD_AND_SLOTS - 1u);
+    h = (h + 1u) & (TQD_PH_SLOTS - 1u);
   }
 }
 __device__ __forceinline__ void wave_mem_fence() {
@@ -352,18 +405,55 @@ __device__ __forceinline__ void flush_partial(const TopK<KPL> &tk, uint64_t *par
 }
 
 // =================================================================== AND kernel
-// One wavefront = one chunk of consecutive tiles.  Tile = TQD_AND_M blocks of the driver (densest)
-// list, i.e. a doc range; the leader (rarest) list's blocks overlapping that range are hashed
-// into the wave's LDS table in groups of TQD_AND_CH, then every other list streams through the
-// table in ascending doc-freq order (score accumulation order of block_wand_intersection).
+// block_wand_intersection (src/query/boolean_query/block_wand_intersection.rs:19-179) restated for
+// wavefronts.  Terms are ordered by doc freq ascending; term 0 is the leader.  Tile = 64
+// consecutive leader blocks; one wavefront = one chunk of consecutive tiles.
+//   1. pre-filter, one LANE per leader block: O(1) seek_block of the block's doc range in every
+//      other list; drop blocks past the end of a list and (pruned mode) blocks whose block-max sum
+//      cannot reach the threshold (:81-85);
+//   2. per surviving leader block, the whole wave: decode 128 docs + tfs (2 per lane), gather the
+//      fieldnorm bytes, score the leader term (:107-125);
+//   3. per other term, ascending doc freq: per-lane seek_block of every live candidate; pruned
+//      mode drops candidates whose partial score + block-max of that block cannot reach the
+//      threshold (:144-165); the distinct blocks that still hold candidates are decoded once each
+//      (doc ids only) and searched; tfs are fetched individually for the docs found;
+//   4. matches are offered to the wave's register top-k; pruned mode also publishes their score
+//      into the query's 64 threshold slots (atomic max, fire and forget).  The k-th largest slot
+//      is a lower bound of the final k-th best score (every slot holds a distinct real match),
+//      monotone like the callback's threshold in the reference (:141-143,168-174).
+// Candidates equal to the threshold are kept (>=, not >), so ties on the k-th score still resolve
+// by doc id exactly as TopNHeap does; results are identical with and without pruning.
+__device__ __forceinline__ uint32_t sortable(float x) {
+  uint32_t fb = __float_as_uint(x);
+  return fb ^ ((uint32_t)((int32_t)fb >> 31) | 0x80000000u);
+}
+// upper bound of a term's score inside one block (TermScorer::block_max_score,
+// term_scorer.rs:58-75; skip.rs:175-184).  tail / no-freq / unknown block-max => weight itself
+// (tf/(tf+norm) < 1).  Requires weight >= 0.
+__device__ __forceinline__ float block_max_score(uint32_t meta, float w, const float *cache,
+                                                 uint32_t has_freq) {
+  const uint32_t tfc = meta >> 24;
+  if (meta == META_TAIL || !has_freq || tfc == 0u) return w;
+  const uint32_t tf = tfc == 255u ? 0xFFFFFFFFu : tfc;  // skip.rs:31-43
+  return bm25(w, cache[(meta >> 16) & 0xFFu], tf);
+}
+// k-th largest of the 64 per-lane values (0 = empty slot); 0 if fewer than k are set
+__device__ __forceinline__ uint32_t kth_largest64(uint32_t v, uint32_t k) {
+  uint32_t best = 0;
+  for (int i = 0; i < 64; ++i) {
+    const uint32_t x = (uint32_t)__builtin_amdgcn_readlane((int)v, i);
+    const uint32_t c = (uint32_t)__popcll(__ballot(v >= x));
+    if (c >= k && x > best) best = x;
+  }
+  return best;
+}
+
 template <int KPL, bool USE_DPP>
 __global__ __launch_bounds__(TQD_WAVES_PER_WG * 64) void and_kernel(TqkScanParams p) {
-  __shared__ WaveTable tables[TQD_WAVES_PER_WG];
+  __shared__ uint32_t lds_docs[TQD_WAVES_PER_WG][128];
   const int lane = (int)__lane_id();
   const uint32_t wave = uni(threadIdx.x >> 6);
-  WaveTable &tb = tables[wave];
-  for (int i = lane; i < TQD_AND_SLOTS; i += WAVE) tb.doc[i] = EMPTY_SLOT;
-  wave_mem_fence();
+  uint32_t *const blk = lds_docs[wave];
 
   const uint32_t chunk = blockIdx.x * TQD_WAVES_PER_WG + wave;
   if (chunk >= p.n_chunks) return;
@@ -398,119 +488,199 @@ __global__ __launch_bounds__(TQD_WAVES_PER_WG * 64) void and_kernel(TqkScanParam
     const uint32_t nt = uni(Q->n_terms);
     const float *cache = uni_ptr(p.caches + (size_t)uni(Q->cache_idx) * 256u);
     const TermRef lead = load_term(p.terms, uni(Q->term[0]));
-    const TermRef drv = load_term(p.terms, uni(Q->term[nt - 1]));
     const float w_lead = __uint_as_float(uni(__float_as_uint(Q->weight[0])));
-    const float w_drv = __uint_as_float(uni(__float_as_uint(Q->weight[nt - 1])));
+    const bool prune = (uni(Q->flags) & TQD_QF_PRUNE) != 0u;
+    const uint32_t thr_index = uni(Q->thr_index);
+    uint32_t *slots = (prune && thr_index != 0xFFFFFFFFu)
+                          ? p.thr_slots + (size_t)thr_index * TQD_THR_SLOTS
+                          : nullptr;
 
-    const uint32_t tl = t - q_tile_start;
-    const uint32_t j0 = tl * TQD_AND_M;
-    uint32_t j1 = j0 + TQD_AND_M;
-    if (j1 > drv.n_blocks) j1 = drv.n_blocks;
-    const uint32_t lo1 = block_first_possible(drv, j0);      // docs >= lo1
-    const uint32_t hi = uni(drv.blocks[j1 - 1].last_doc);    // docs <= hi
-
-    const uint32_t i0 = lower_bound_block(lead, lo1, lane);
-    if (i0 >= lead.n_blocks) continue;
-    uint32_t iL = lower_bound_block(lead, hi, lane);
-    if (iL >= lead.n_blocks) iL = lead.n_blocks - 1u;
-
-    for (uint32_t ia = i0; ia <= iL; ia += TQD_AND_CH) {
-      uint32_t ib = ia + TQD_AND_CH - 1u;
-      if (ib > iL) ib = iL;
-      uint32_t sub_lo1 = block_first_possible(lead, ia);
-      if (sub_lo1 < lo1) sub_lo1 = lo1;
-      uint32_t sub_hi = hi;
-      if (ib != iL) {
-        const uint32_t l = uni(lead.blocks[ib].last_doc);
-        if (l < sub_hi) sub_hi = l;
+    // threshold (sortable score bits): own k-th key and the k-th largest shared slot
+    uint32_t thr = 0, thr_g = 0;
+    if (prune) {
+      if (slots) {
+        const uint32_t sv = __hip_atomic_load(slots + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        thr_g = kth_largest64(sv, tk.k);
       }
-      // ---- fill: leader postings of (sub_lo1 .. sub_hi]
-      uint32_t my_slot[TQD_AND_CH * 2];
-#pragma unroll
-      for (int c = 0; c < TQD_AND_CH; ++c) {
-        my_slot[2 * c] = EMPTY_SLOT;
-        my_slot[2 * c + 1] = EMPTY_SLOT;
-        if (ia + (uint32_t)c <= ib) {
-          const Dec d = decode_block<USE_DPP, false>(idx, lead, ia + (uint32_t)c, lane);
-          if (d.d0 >= sub_lo1 && d.d0 <= sub_hi) {
-            uint32_t val = d.t0;
-            if (nt > 2) val = __float_as_uint(bm25(w_lead, cache[fieldnorm_id(seg, d.d0)], d.t0));
-            my_slot[2 * c] = ht_insert(tb, d.d0, val);
-          }
-          if (d.d1 >= sub_lo1 && d.d1 <= sub_hi) {
-            uint32_t val = d.t1;
-            if (nt > 2) val = __float_as_uint(bm25(w_lead, cache[fieldnorm_id(seg, d.d1)], d.t1));
-            my_slot[2 * c + 1] = ht_insert(tb, d.d1, val);
-          }
-        }
+      thr = (uint32_t)(tk.thr >> 32);
+      if (thr_g > thr) thr = thr_g;
+    }
+
+    // ---- 1. pre-filter: lane <-> leader block
+    const uint32_t i_base = (t - q_tile_start) * TQD_AND_TILE;
+    const uint32_t i_mine = i_base + (uint32_t)lane;
+    bool surv = i_mine < lead.n_blocks;
+    {
+      uint32_t first = 0, last = 0;
+      float ub = 0.0f;
+      if (surv) {
+        first = i_mine ? lead.last_doc[i_mine - 1u] + 1u : 0u;
+        last = lead.last_doc[i_mine];
+        if (prune) ub = block_max_score(lead.meta[i_mine], w_lead, cache, lead.has_freq);
       }
-      wave_mem_fence();
-      // ---- middle lists (3+ term AND): accumulate leader-first, ascending doc freq.  An entry is
-      // alive after term m iff its sign bit == (m & 1) (scores are >= 0).
-      for (uint32_t m = 1; m + 1 < nt; ++m) {
-        const TermRef mid = load_term(p.terms, uni(Q->term[m]));
-        const float w_mid = __uint_as_float(uni(__float_as_uint(Q->weight[m])));
-        const uint32_t alive_in = ((m - 1u) & 1u) << 31;  // sign expected before this term
-        uint32_t jb = lower_bound_block(mid, sub_lo1, lane);
-        while (jb < mid.n_blocks && block_first_possible(mid, jb) <= sub_hi) {
-          const Dec d = decode_block<USE_DPP, false>(idx, mid, jb, lane);
-#pragma unroll
-          for (int e = 0; e < 2; ++e) {
-            const uint32_t doc = e ? d.d1 : d.d0;
-            const uint32_t tf = e ? d.t1 : d.t0;
-            uint32_t slot;
-            if (doc >= sub_lo1 && doc <= sub_hi && ht_find(tb, doc, slot)) {
-              const uint32_t cur = tb.val[slot];
-              if ((cur & 0x80000000u) == alive_in) {
-                const float acc = __uint_as_float(cur & 0x7FFFFFFFu) +
-                                  bm25(w_mid, cache[fieldnorm_id(seg, doc)], tf);
-                tb.val[slot] = (__float_as_uint(acc) & 0x7FFFFFFFu) | (alive_in ^ 0x80000000u);
+      for (uint32_t m = 1; m < nt; ++m) {
+        const TermRef tr = load_term(p.terms, uni(Q->term[m]));
+        const float w = __uint_as_float(uni(__float_as_uint(Q->weight[m])));
+        if (surv) {
+          const uint32_t j0 = seek_block(tr, first);
+          if (j0 >= tr.n_blocks) {
+            surv = false;  // the list ends before this leader block starts
+          } else if (prune) {
+            uint32_t j1 = seek_block(tr, last);
+            if (j1 >= tr.n_blocks) j1 = tr.n_blocks - 1u;
+            float bound = w;
+            if (j1 - j0 <= 3u) {
+              bound = block_max_score(tr.meta[j0], w, cache, tr.has_freq);
+              for (uint32_t j = j0 + 1u; j <= j1; ++j) {
+                const float b2 = block_max_score(tr.meta[j], w, cache, tr.has_freq);
+                bound = b2 > bound ? b2 : bound;
               }
             }
+            ub = ub + bound;
           }
-          wave_mem_fence();
-          ++jb;
         }
       }
-      const uint32_t alive_last = ((nt - 2u) & 1u) << 31;  // sign after the last middle term
-      // ---- driver blocks of this tile
-      for (uint32_t j = j0; j < j1; ++j) {
-        if (uni(drv.blocks[j].last_doc) < sub_lo1) continue;
-        if (block_first_possible(drv, j) > sub_hi) break;
-        const Dec d = decode_block<USE_DPP, false>(idx, drv, j, lane);
-        bool has[2];
-        uint64_t key[2];
-#pragma unroll
-        for (int e = 0; e < 2; ++e) {
-          const uint32_t doc = e ? d.d1 : d.d0;
-          const uint32_t tf = e ? d.t1 : d.t0;
-          has[e] = false;
-          key[e] = 0;
-          uint32_t slot;
-          if (doc >= sub_lo1 && doc <= sub_hi && ht_find(tb, doc, slot)) {
-            const uint32_t cur = tb.val[slot];
-            const float norm = cache[fieldnorm_id(seg, doc)];
-            if (nt == 2) {
-              const float s = bm25(w_lead, norm, cur) + bm25(w_drv, norm, tf);
-              has[e] = true;
-              key[e] = make_key(s, doc);
-            } else if ((cur & 0x80000000u) == alive_last) {
-              const float s = __uint_as_float(cur & 0x7FFFFFFFu) + bm25(w_drv, norm, tf);
-              has[e] = true;
-              key[e] = make_key(s, doc);
+      if (prune && nt > 2u) ub *= 1.000001f;  // the bound is summed in another order than scores
+      if (prune && surv) surv = sortable(ub) >= thr;
+    }
+    uint64_t todo = __ballot(surv);
+
+    // ---- 2..4: surviving leader blocks, one at a time, whole wave
+    while (todo) {
+      const uint32_t i = i_base + (uint32_t)__builtin_ctzll(todo);
+      todo &= todo - 1ull;
+      const Dec d = decode_block<USE_DPP, false>(idx, lead, i, lane);
+      const uint32_t c0 = d.d0, c1 = d.d1;
+      bool alive0 = c0 != TQD_TERMINATED, alive1 = c1 != TQD_TERMINATED;
+      float norm0 = 0.0f, norm1 = 0.0f, s0 = 0.0f, s1 = 0.0f;
+      if (alive0) {
+        norm0 = cache[fieldnorm_id(seg, c0)];
+        s0 = bm25(w_lead, norm0, d.t0);
+      }
+      if (alive1) {
+        norm1 = cache[fieldnorm_id(seg, c1)];
+        s1 = bm25(w_lead, norm1, d.t1);
+      }
+      // bound of the terms after the current one (3+ terms, pruned mode)
+      float rest = 0.0f;
+      if (prune)
+        for (uint32_t m = 2; m < nt; ++m) rest += __uint_as_float(uni(__float_as_uint(Q->weight[m])));
+
+      for (uint32_t m = 1; m < nt; ++m) {
+        const TermRef tr = load_term(p.terms, uni(Q->term[m]));
+        const float w = __uint_as_float(uni(__float_as_uint(Q->weight[m])));
+        uint32_t jb0 = tr.n_blocks, jb1 = tr.n_blocks;
+        if (alive0) jb0 = seek_block(tr, c0);
+        if (alive1) jb1 = seek_block(tr, c1);
+        alive0 = alive0 && jb0 < tr.n_blocks;
+        alive1 = alive1 && jb1 < tr.n_blocks;
+        uint32_t meta0 = 0, meta1 = 0;
+        if (alive0) meta0 = tr.meta[jb0];
+        if (alive1) meta1 = tr.meta[jb1];
+        if (prune) {
+          if (alive0) {
+            float ub = s0 + block_max_score(meta0, w, cache, tr.has_freq);
+            if (nt > 2u) ub = (ub + rest) * 1.000001f;
+            alive0 = sortable(ub) >= thr;
+          }
+          if (alive1) {
+            float ub = s1 + block_max_score(meta1, w, cache, tr.has_freq);
+            if (nt > 2u) ub = (ub + rest) * 1.000001f;
+            alive1 = sortable(ub) >= thr;
+          }
+          if (m + 1u < nt) rest -= __uint_as_float(uni(__float_as_uint(Q->weight[m + 1u])));
+          if (rest < 0.0f) rest = 0.0f;
+        }
+        // distinct blocks of list m that still hold candidates, ascending
+        uint64_t pend0 = __ballot(alive0), pend1 = __ballot(alive1);
+        uint32_t at0 = 0xFFFFFFFFu, at1 = 0xFFFFFFFFu;  // index of the doc inside its block
+        while (pend0 | pend1) {
+          const uint32_t l0 = pend0 ? (uint32_t)__builtin_ctzll(pend0) : 64u;
+          const uint32_t l1 = pend1 ? (uint32_t)__builtin_ctzll(pend1) : 64u;
+          const uint32_t j = l0 <= l1 ? (uint32_t)__builtin_amdgcn_readlane((int)jb0, (int)l0)
+                                      : (uint32_t)__builtin_amdgcn_readlane((int)jb1, (int)l1);
+          const bool in0 = alive0 && jb0 == j, in1 = alive1 && jb1 == j;
+          uint64_t m0 = __ballot(in0), m1 = __ballot(in1);
+          pend0 &= ~m0;
+          pend1 &= ~m1;
+          const uint32_t meta_j = uni(tr.meta[j]);
+          uint32_t x0, x1;
+          decode_docs<USE_DPP>(idx, tr, j, meta_j, lane, x0, x1);
+          const uint32_t n_in = (uint32_t)__popcll(m0) + (uint32_t)__popcll(m1);
+          if (n_in <= 4u) {  // few candidates: broadcast each, compare against the 128 docs
+            while (m0 | m1) {
+              const bool from0 = m0 != 0ull && (m1 == 0ull || __builtin_ctzll(m0) <= __builtin_ctzll(m1));
+              const uint32_t l = (uint32_t)__builtin_ctzll(from0 ? m0 : m1);
+              if (from0)
+                m0 &= m0 - 1ull;
+              else
+                m1 &= m1 - 1ull;
+              const uint32_t c = (uint32_t)__builtin_amdgcn_readlane((int)(from0 ? c0 : c1), (int)l);
+              const uint64_t h0 = __ballot(x0 == c), h1 = __ballot(x1 == c);
+              uint32_t at = 0xFFFFFFFFu;
+              if (h0)
+                at = 2u * (uint32_t)__builtin_ctzll(h0);
+              else if (h1)
+                at = 2u * (uint32_t)__builtin_ctzll(h1) + 1u;
+              if ((uint32_t)lane == l) {
+                if (from0)
+                  at0 = at;
+                else
+                  at1 = at;
+              }
             }
+          } else {  // many candidates: the block goes to LDS, every candidate binary-searches it
+            *reinterpret_cast<uint2 *>(blk + 2 * lane) = make_uint2(x0, x1);
+            wave_mem_fence();
+            if (in0) {
+              uint32_t pos = 0;
+#pragma unroll
+              for (uint32_t step = 64u; step > 0u; step >>= 1)
+                if (blk[pos + step - 1u] < c0) pos += step;
+              at0 = blk[pos] == c0 ? pos : 0xFFFFFFFFu;
+            }
+            if (in1) {
+              uint32_t pos = 0;
+#pragma unroll
+              for (uint32_t step = 64u; step > 0u; step >>= 1)
+                if (blk[pos + step - 1u] < c1) pos += step;
+              at1 = blk[pos] == c1 ? pos : 0xFFFFFFFFu;
+            }
+            wave_mem_fence();
           }
         }
-        n_matches += (uint32_t)__popcll(__ballot(has[0])) + (uint32_t)__popcll(__ballot(has[1]));
-        tk.offer(has[0], key[0], lane);
-        tk.offer(has[1], key[1], lane);
+        // score the docs found in list m (leader first, then ascending doc freq: :144-165)
+        if (alive0) {
+          if (at0 != 0xFFFFFFFFu)
+            s0 = s0 + bm25(w, norm0, block_tf_at(idx, tr, jb0, meta0, at0));
+          else
+            alive0 = false;
+        }
+        if (alive1) {
+          if (at1 != 0xFFFFFFFFu)
+            s1 = s1 + bm25(w, norm1, block_tf_at(idx, tr, jb1, meta1, at1));
+          else
+            alive1 = false;
+        }
       }
-      // ---- clear the slots this lane filled
-      wave_mem_fence();
-#pragma unroll
-      for (int c = 0; c < TQD_AND_CH * 2; ++c)
-        if (my_slot[c] != EMPTY_SLOT) tb.doc[my_slot[c]] = EMPTY_SLOT;
-      wave_mem_fence();
+      // ---- 4. collect
+      const uint64_t hit0 = __ballot(alive0), hit1 = __ballot(alive1);
+      if (hit0 | hit1) {
+        n_matches += (uint32_t)__popcll(hit0) + (uint32_t)__popcll(hit1);
+        const uint64_t key0 = alive0 ? make_key(s0, c0) : 0ull;
+        const uint64_t key1 = alive1 ? make_key(s1, c1) : 0ull;
+        if (slots) {
+          const uint32_t b0 = (uint32_t)(key0 >> 32), b1 = (uint32_t)(key1 >> 32);
+          if (alive0 && b0 > thr_g) atomicMax(slots + ((c0 * 0x9E3779B1u) >> 26), b0);
+          if (alive1 && b1 > thr_g) atomicMax(slots + ((c1 * 0x9E3779B1u) >> 26), b1);
+        }
+        tk.offer(alive0, key0, lane);
+        tk.offer(alive1, key1, lane);
+        if (prune) {
+          const uint32_t own = (uint32_t)(tk.thr >> 32);
+          if (own > thr) thr = own;
+        }
+      }
     }
   }
   // final flush
@@ -520,6 +690,7 @@ __global__ __launch_bounds__(TQD_WAVES_PER_WG * 64) void and_kernel(TqkScanParam
   }
   if (lane == 0 && n_matches) atomicAdd(p.match_counter, (unsigned long long)n_matches);
 }
+
 
 // =================================================================== OR kernel (exhaustive union)
 // One workgroup = one chunk of consecutive 4096-doc windows.  Per window: f32 accumulators in
@@ -653,7 +824,7 @@ __global__ __launch_bounds__(64) void phrase_kernel(TqkScanParams p) {
   __shared__ PhraseLds L;
   const int lane = (int)__lane_id();
   WaveTable &tb = L.tb;
-  for (int i = lane; i < TQD_AND_SLOTS; i += WAVE) tb.doc[i] = EMPTY_SLOT;
+  for (int i = lane; i < TQD_PH_SLOTS; i += WAVE) tb.doc[i] = EMPTY_SLOT;
   wave_mem_fence();
   const uint32_t chunk = blockIdx.x;
   if (chunk >= p.n_chunks) return;
@@ -690,14 +861,14 @@ __global__ __launch_bounds__(64) void phrase_kernel(TqkScanParams p) {
     const uint32_t h_lead = uni(Q->term[0]), h_drv = uni(Q->term[nt - 1]);
     const TermRef lead = load_term(p.terms, h_lead);
     const TermRef drv = load_term(p.terms, h_drv);
-    const uint64_t *lead_bpos = uni_ptr(p.terms[h_lead].block_pos);
+    const uint32_t *lead_bpos = uni_ptr(p.terms[h_lead].block_pos);
 
     const uint32_t tl = t - q_tile_start;
-    const uint32_t j0 = tl * TQD_AND_M;
-    uint32_t j1 = j0 + TQD_AND_M;
+    const uint32_t j0 = tl * TQD_PH_M;
+    uint32_t j1 = j0 + TQD_PH_M;
     if (j1 > drv.n_blocks) j1 = drv.n_blocks;
     const uint32_t lo1 = block_first_possible(drv, j0);
-    const uint32_t hi = uni(drv.blocks[j1 - 1].last_doc);
+    const uint32_t hi = uni(drv.last_doc[j1 - 1]);
     const uint32_t i0 = lower_bound_block(lead, lo1, lane);
     if (i0 >= lead.n_blocks) continue;
     uint32_t iL = lower_bound_block(lead, hi, lane);
@@ -710,7 +881,7 @@ __global__ __launch_bounds__(64) void phrase_kernel(TqkScanParams p) {
       if (sub_lo1 < lo1) sub_lo1 = lo1;
       uint32_t sub_hi = hi;
       if (ib != iL) {
-        const uint32_t l = uni(lead.blocks[ib].last_doc);
+        const uint32_t l = uni(lead.last_doc[ib]);
         if (l < sub_hi) sub_hi = l;
       }
       // ---- fill from the leader
@@ -725,7 +896,7 @@ __global__ __launch_bounds__(64) void phrase_kernel(TqkScanParams p) {
         if (ia + (uint32_t)c <= ib) {
           uint32_t e0, e1;
           const Dec d = decode_block<USE_DPP, true>(idx, lead, ia + (uint32_t)c, lane, &e0, &e1);
-          const uint32_t bp = (uint32_t)uni64(lead_bpos[ia + (uint32_t)c]);
+          const uint32_t bp = uni(lead_bpos[ia + (uint32_t)c]);
           if (d.d0 >= sub_lo1 && d.d0 <= sub_hi) {
             L.cand_doc[ca] = d.d0;
             L.cand_cnt[ca] = 0u;
@@ -747,7 +918,7 @@ __global__ __launch_bounds__(64) void phrase_kernel(TqkScanParams p) {
       for (uint32_t m = 1; m < nt; ++m) {
         const uint32_t h_m = uni(Q->term[m]);
         const TermRef tr = load_term(p.terms, h_m);
-        const uint64_t *bpos = uni_ptr(p.terms[h_m].block_pos);
+        const uint32_t *bpos = uni_ptr(p.terms[h_m].block_pos);
         uint32_t jb, jend;
         if (m + 1 == nt) {
           jb = j0;
@@ -757,11 +928,11 @@ __global__ __launch_bounds__(64) void phrase_kernel(TqkScanParams p) {
           jend = tr.n_blocks;
         }
         for (uint32_t j = jb; j < jend; ++j) {
-          if (uni(tr.blocks[j].last_doc) < sub_lo1) continue;
+          if (uni(tr.last_doc[j]) < sub_lo1) continue;
           if (block_first_possible(tr, j) > sub_hi) break;
           uint32_t e0, e1;
           const Dec d = decode_block<USE_DPP, true>(idx, tr, j, lane, &e0, &e1);
-          const uint32_t bp = (uint32_t)uni64(bpos[j]);
+          const uint32_t bp = uni(bpos[j]);
 #pragma unroll
           for (int e = 0; e < 2; ++e) {
             const uint32_t doc = e ? d.d1 : d.d0;

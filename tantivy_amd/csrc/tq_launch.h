@@ -13,6 +13,7 @@ struct TqkScanParams {
   const float *caches;          // n_caches x 256
   uint64_t *partials;           // partial top-k lists, KPL*64 keys each
   unsigned long long *match_counter;
+  uint32_t *thr_slots;          // [n_thr_rows][TQD_THR_SLOTS] shared thresholds (pruned mode)
   uint32_t n_queries;
   uint32_t total_tiles;
   uint32_t tiles_per_chunk;

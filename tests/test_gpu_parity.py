@@ -170,6 +170,29 @@ def test_and_three_and_four_terms(synth):
         _assert_hits_equal(g, _oracle_topk(seg, q, O.MODE_AND, 10))
 
 
+@pytest.mark.parametrize("k", [1, 10, 64, 100])
+def test_and_pruned_equals_exhaustive(synth, k):
+    """Block-max pruning (block_wand_intersection.rs:81-85,144-165) never changes the top-k:
+    same docs, same score bits, with the shared threshold (k <= 64) and without (k > 64)."""
+    seg, dev = synth
+    rng = np.random.default_rng(11)
+    qs = [[0, 1], [1, 2], [0, 95], [2, 7, 9], [0, 1, 2, 3], [40, 41], [3, 3]]
+    qs += [rng.choice(96, size=int(rng.integers(2, 5)), replace=False).tolist() for _ in range(60)]
+    batch = [(O.MODE_AND, q) for q in qs]
+    want = _device_topk(dev, batch, k)
+    dev.set_option("exhaustive", 0)
+    try:
+        got = _device_topk(dev, batch, k)
+        got2 = _device_topk(dev, batch, k)
+    finally:
+        dev.set_option("exhaustive", 1)
+    for q, g, g2, w in zip(qs, got, got2, want):
+        assert g == w, q
+        assert g2 == w, q
+    for q, w in list(zip(qs, want))[:12]:
+        _assert_hits_equal(w, _oracle_topk(seg, q, O.MODE_AND, k), exact=len(q) == 2)
+
+
 @pytest.mark.parametrize("k", [1, 10, 100, 300])
 def test_or_union(synth, k):
     seg, dev = synth
@@ -450,6 +473,23 @@ def test_full_size_properties(big):
     for i in (0, 7, 99, 250):
         _assert_hits_equal([(float(sc[i, j]), int(docs[i, j])) for j in range(int(cnt[i]))],
                            _oracle_topk(seg, qid[i].tolist(), O.MODE_AND, 10))
+
+
+def test_full_size_and_pruned(big):
+    """10M docs: pruned == exhaustive on a Zipf query sample, and pruning really skips work."""
+    seg, dev = big
+    qid = O.zipf_queries(300, 2, 256, seed=4321)
+    batch = [(O.MODE_AND, q.tolist()) for q in qid]
+    sc, _, docs, cnt = dev.search(batch, 10)
+    full = dev.last_batch_stats()["matches"]
+    dev.set_option("exhaustive", 0)
+    try:
+        sc2, _, docs2, cnt2 = dev.search(batch, 10)
+        pruned = dev.last_batch_stats()["matches"]
+    finally:
+        dev.set_option("exhaustive", 1)
+    assert np.array_equal(cnt, cnt2) and np.array_equal(docs, docs2) and np.array_equal(sc, sc2)
+    assert pruned < full // 4, (pruned, full)
 
 
 def test_full_size_or_top100(big):
