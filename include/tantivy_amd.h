@@ -157,8 +157,12 @@ typedef struct tq_batch_stats {
   uint32_t chunks;
 } tq_batch_stats;
 int tq_last_batch_stats(tq_segment *seg, tq_batch_stats *out);
-/* knobs: "exhaustive" (0/1, default 1: score every match; 0: block-max pruning),
- *        "timing" (0/1: record HIP events per batch), "count_matches" (0/1) */
+/* knobs: "exhaustive" (0/1, default 1: score every match; 0: block-max pruning as
+ *        block_wand_intersection does — same top-k either way),
+ *        "timing" (0/1: record HIP events per batch),
+ *        "dense" (0/1, default 1: tq_term_prepare also builds a bitmap + rank directory for lists
+ *        with doc_freq >= max_doc/32), "use_dense" (0/1, default 1: the AND kernel may use them),
+ *        "use_dpp" (0/1: DPP or ds_bpermute prefix sums) */
 int tq_set_option(tq_segment *seg, const char *name, int64_t value);
 
 #ifdef __cplusplus

@@ -41,7 +41,7 @@ int fail(int code, const char *fmt, ...) {
                   __FILE__, __LINE__);                                                   \
   } while (0)
 
-constexpr size_t PAD = 64;  // over-read slack after every device byte buffer
+constexpr size_t PAD = 1088;  // over-read slack after every device byte buffer (staged block loads)
 
 // A grow-only device buffer.
 struct DevBuf {
@@ -83,6 +83,7 @@ struct PinnedBuf {
 
 struct TermHost {
   void *blob = nullptr;  // one device allocation holding every per-term array
+  void *dense_blob = nullptr;  // bitmap + rank directory of a dense list
   uint32_t doc_freq = 0, n_blocks = 0, n_full = 0, n_tail = 0;
   uint32_t last_doc = 0;
   uint64_t postings_len = 0, positions_len = 0;
@@ -126,6 +127,8 @@ struct Options {
   int exhaustive = 1;
   int timing = 0;
   int use_dpp = 1;
+  int dense = 1;      // build bitmaps for dense lists at tq_term_prepare
+  int use_dense = 1;  // let the scan kernels use them
 };
 
 }  // namespace
@@ -160,6 +163,57 @@ struct tq_segment {
   tq_batch_stats stats{};
   bool stats_pending = false;
 };
+
+namespace {
+int sync_terms(tq_segment *s, hipStream_t st);
+
+// Dense lists (doc_freq >= max_doc/TQD_DENSE_RATIO) also get a membership bitmap with a rank
+// directory: the list is decoded once on the device (the same kernel as tq_decode_postings),
+// and {32 doc bits, number of postings before them} pairs are uploaded.  A probe of doc d then
+// costs one 8-byte load instead of a block decode; the posting index (=> block, slot, tf) falls
+// out of the rank.  Derived data like the unrolled skip table; the index bytes stay untouched.
+int build_dense(tq_segment *s, uint32_t handle) {
+  int rc = sync_terms(s, s->stream);
+  if (rc != TQ_OK) return rc;
+  TermHost &t = s->terms[handle];
+  const size_t bytes = (size_t)t.doc_freq * sizeof(uint32_t);
+  rc = s->d_misc.ensure(2 * bytes + 64);
+  if (rc != TQ_OK) return rc;
+  uint32_t *dd = (uint32_t *)s->d_misc.p, *dt = dd + t.doc_freq;
+  hipError_t e = tqk_launch_decode_list(s->dseg, s->d_terms, handle, t.n_blocks, dd, dt,
+                                        s->opt.use_dpp != 0, s->stream);
+  if (e != hipSuccess) return fail(TQ_ERR_HIP, "decode launch: %s", hipGetErrorString(e));
+  std::vector<uint32_t> docs(t.doc_freq);
+  HIP_TRY(hipMemcpyAsync(docs.data(), dd, bytes, hipMemcpyDeviceToHost, s->stream));
+  HIP_TRY(hipStreamSynchronize(s->stream));
+  const size_t n_words = ((size_t)s->max_doc + 31) / 32 + 1;
+  std::vector<uint2> tab(n_words, make_uint2(0u, 0u));
+  uint32_t prev = 0;
+  for (uint32_t i = 0; i < t.doc_freq; ++i) {
+    const uint32_t d = docs[i];
+    if (d >= s->max_doc || (i && d <= prev))
+      return fail(TQ_ERR_FORMAT, "posting list not strictly increasing below max_doc");
+    tab[d >> 5].x |= 1u << (d & 31u);
+    prev = d;
+  }
+  uint32_t running = 0;
+  for (size_t w = 0; w < n_words; ++w) {
+    tab[w].y = running;
+    running += (uint32_t)__builtin_popcount(tab[w].x);
+  }
+  void *blob = nullptr;
+  HIP_TRY(hipMalloc(&blob, n_words * sizeof(uint2)));
+  hipError_t ce = hipMemcpy(blob, tab.data(), n_words * sizeof(uint2), hipMemcpyHostToDevice);
+  if (ce != hipSuccess) {
+    (void)hipFree(blob);
+    return fail(TQ_ERR_HIP, "dense upload: %s", hipGetErrorString(ce));
+  }
+  t.dense_blob = blob;
+  s->h_dterms[handle].dense = (const uint2 *)blob;
+  s->d_terms_dirty = true;
+  return TQ_OK;
+}
+}  // namespace
 
 extern "C" {
 
@@ -238,6 +292,12 @@ int tq_segment_upload(tq_ctx *ctx, int device, uint32_t max_doc, const uint8_t *
   s->dseg.fieldnorm = s->d_fn;
   s->dseg.max_doc = max_doc;
   s->dseg.const_fieldnorm_id = 1;  // FieldNormReader::constant(max_doc, 1)
+  s->dseg.min_fieldnorm_id = 1;
+  if (fieldnorm) {
+    uint8_t mn = 255;
+    for (uint32_t d = 0; d < max_doc; ++d) mn = fieldnorm[d] < mn ? fieldnorm[d] : mn;
+    s->dseg.min_fieldnorm_id = max_doc ? mn : 0;
+  }
   *out = s;
   return TQ_OK;
 }
@@ -248,6 +308,8 @@ void tq_segment_free(tq_segment *s) {
   if (s->stream) (void)hipStreamSynchronize(s->stream);
   for (auto &t : s->terms)
     if (t.blob) (void)hipFree(t.blob);
+  for (auto &t : s->terms)
+    if (t.dense_blob) (void)hipFree(t.dense_blob);
   if (s->d_terms) (void)hipFree(s->d_terms);
   if (s->d_idx) (void)hipFree(s->d_idx);
   if (s->d_pos) (void)hipFree(s->d_pos);
@@ -433,8 +495,7 @@ int tq_term_prepare(tq_segment *s, uint64_t postings_off, uint32_t postings_len,
     return o;
   };
   const size_t o_last = place(4 * (size_t)n_blocks);
-  const size_t o_meta = place(4 * (size_t)n_blocks);
-  const size_t o_off = place(4 * (size_t)n_blocks);
+  const size_t o_mo = place(8 * (size_t)n_blocks);
   const size_t o_coarse = place(4 * coarse.size());
   const size_t o_tdocs = place(4 * (size_t)n_tail);
   const size_t o_ttfs = place(4 * (size_t)n_tail);
@@ -445,8 +506,10 @@ int tq_term_prepare(tq_segment *s, uint64_t postings_off, uint32_t postings_len,
   total += PAD;
   std::vector<uint8_t> hb(total, 0);
   memcpy(hb.data() + o_last, b_last.data(), 4 * (size_t)n_blocks);
-  memcpy(hb.data() + o_meta, b_meta.data(), 4 * (size_t)n_blocks);
-  memcpy(hb.data() + o_off, b_off.data(), 4 * (size_t)n_blocks);
+  for (uint32_t i = 0; i < n_blocks; ++i) {
+    memcpy(hb.data() + o_mo + 8 * (size_t)i, &b_meta[i], 4);
+    memcpy(hb.data() + o_mo + 8 * (size_t)i + 4, &b_off[i], 4);
+  }
   memcpy(hb.data() + o_coarse, coarse.data(), 4 * coarse.size());
   if (n_tail) {
     memcpy(hb.data() + o_tdocs, tail_docs.data(), 4 * (size_t)n_tail);
@@ -465,8 +528,7 @@ int tq_term_prepare(tq_segment *s, uint64_t postings_off, uint32_t postings_len,
   }
   TqdTerm dt{};
   dt.last_doc = (const uint32_t *)(blob + o_last);
-  dt.meta = (const uint32_t *)(blob + o_meta);
-  dt.byte_off = (const uint32_t *)(blob + o_off);
+  dt.mo = (const uint2 *)(blob + o_mo);
   dt.coarse = (const uint32_t *)(blob + o_coarse);
   dt.tail_docs = (const uint32_t *)(blob + o_tdocs);
   dt.tail_tfs = (const uint32_t *)(blob + o_ttfs);
@@ -500,6 +562,8 @@ int tq_term_prepare(tq_segment *s, uint64_t postings_off, uint32_t postings_len,
   s->d_terms_dirty = true;
   s->term_by_off.emplace(postings_off, handle);
   *out = handle;
+  if (s->opt.dense && s->max_doc >= 4096u && (uint64_t)doc_freq * TQD_DENSE_RATIO >= s->max_doc)
+    return build_dense(s, handle);
   return TQ_OK;
 }
 
@@ -529,10 +593,12 @@ struct Group {
   std::vector<TqdQuery> queries;
   std::vector<uint32_t> out_index;
   std::vector<uint32_t> tile_starts;
-  uint32_t total_tiles = 0, tiles_per_chunk = 1, n_chunks = 0, max_k = 1;
+  std::vector<uint32_t> chunk_starts;
+  std::vector<uint32_t> tile_cost;  // per query, cost units per tile
+  uint32_t total_tiles = 0, n_chunks = 0, max_k = 1;
   int kpl = 1;
   // offsets inside the staging blob
-  size_t o_queries = 0, o_tiles = 0, o_outidx = 0;
+  size_t o_queries = 0, o_tiles = 0, o_outidx = 0, o_chunks = 0;
 };
 
 int kpl_for(uint32_t k) { return k <= 64 ? 1 : (k <= 128 ? 2 : (k <= 256 ? 4 : 16)); }
@@ -594,7 +660,7 @@ int tq_search_batch_device(tq_segment *s, const tq_query *queries, uint32_t n_qu
         return fail(TQ_ERR_INVALID, "query %u: unknown term handle %u", qi, q.terms[i]);
     }
     int mode = q.mode;
-    uint32_t n_tiles = 0;
+    uint32_t n_tiles = 0, tile_cost = 1;
     uint64_t qbytes = 8ull * q.k;
     if (mode == TQ_MODE_AND || mode == TQ_MODE_PHRASE) {
       if (!any_absent) {
@@ -623,8 +689,18 @@ int tq_search_batch_device(tq_segment *s, const tq_query *queries, uint32_t n_qu
         if (mode == TQ_MODE_AND && q.n_terms == 1) {
           mode = TQ_MODE_OR;  // TermWeight::for_each_pruning: every doc of the list
         } else if (mode == TQ_MODE_AND) {
+          // cost of one leader block: its own decode + the distinct blocks of the non-dense
+          // lists its 128 candidates can fall into (each decoded by the whole wave, serially)
           const uint32_t lead_blocks = s->terms[dq.term[0]].n_blocks;
-          n_tiles = (lead_blocks + TQD_AND_TILE - 1) / TQD_AND_TILE;
+          uint32_t c_lb = 1;
+          for (uint32_t i = 1; i < q.n_terms; ++i) {
+            const TermHost &th = s->terms[dq.term[i]];
+            if (th.dense_blob && s->opt.use_dense) continue;
+            c_lb += 2u * std::min<uint32_t>(128u, (th.n_blocks + lead_blocks - 1) / lead_blocks);
+          }
+          dq.tile_blocks = std::max<uint32_t>(1u, TQD_AND_TILE / c_lb);
+          tile_cost = dq.tile_blocks * c_lb;
+          n_tiles = (lead_blocks + dq.tile_blocks - 1) / dq.tile_blocks;
           bool nonneg = true;
           for (uint32_t i = 0; i < q.n_terms; ++i) nonneg = nonneg && dq.weight[i] >= 0.0f;
           if (!s->opt.exhaustive && nonneg) {  // block-max bounds need weights >= 0
@@ -660,6 +736,7 @@ int tq_search_batch_device(tq_segment *s, const tq_query *queries, uint32_t n_qu
     Group &g = groups[mode];
     dq.mode = (uint32_t)mode;
     g.queries.push_back(dq);
+    g.tile_cost.push_back(tile_cost);
     g.out_index.push_back(qi);
     g.max_k = std::max(g.max_k, q.k);
   }
@@ -679,19 +756,46 @@ int tq_search_batch_device(tq_segment *s, const tq_query *queries, uint32_t n_qu
     }
     g.tile_starts[g.queries.size()] = (uint32_t)acc;
     g.total_tiles = (uint32_t)acc;
-    const uint32_t target = g.mode == TQ_MODE_OR ? 8192u : 20480u;
-    g.tiles_per_chunk = std::max<uint32_t>(1, (g.total_tiles + target - 1) / target);
-    g.n_chunks = (g.total_tiles + g.tiles_per_chunk - 1) / g.tiles_per_chunk;
+    // chunks = runs of consecutive tiles of about equal estimated cost; one chunk is one
+    // wavefront (AND, phrase) or one workgroup (OR) and the hardware dispatcher hands them out
+    // as slots free up, so many small chunks balance the load
+    uint64_t total_cost = 0;
+    for (size_t i = 0; i < g.queries.size(); ++i)
+      total_cost += (uint64_t)g.queries[i].n_tiles * g.tile_cost[i];
+    const uint64_t n_target = g.mode == TQ_MODE_OR ? 8192u : 65536u;
+    const uint64_t cost_target = std::max<uint64_t>(g.mode == TQ_MODE_AND ? 128u : 1u,
+                                                    (total_cost + n_target - 1) / n_target);
+    g.chunk_starts.clear();
+    uint64_t cur_cost = 0;
+    bool open_chunk = false;
     const uint32_t per_chunk = g.mode == TQ_MODE_OR ? TQD_WAVES_PER_WG : 1u;
-    for (TqdQuery &dq : g.queries) {
+    for (size_t i = 0; i < g.queries.size(); ++i) {
+      TqdQuery &dq = g.queries[i];
       dq.part_start = 0;
       dq.n_parts = 0;
-      if (dq.n_tiles) {
-        const uint32_t first = dq.tile_start / g.tiles_per_chunk;
-        const uint32_t last = (dq.tile_start + dq.n_tiles - 1) / g.tiles_per_chunk;
-        dq.n_parts = (last - first + 1) * per_chunk;
+      dq.chunk_first = 0;
+      if (!dq.n_tiles) continue;
+      const uint32_t tc = std::max<uint32_t>(1u, g.tile_cost[i]);
+      uint32_t first_chunk = 0xFFFFFFFFu;
+      for (uint32_t t = 0; t < dq.n_tiles;) {
+        if (!open_chunk || cur_cost >= cost_target) {
+          g.chunk_starts.push_back(dq.tile_start + t);
+          cur_cost = 0;
+          open_chunk = true;
+        }
+        if (first_chunk == 0xFFFFFFFFu) first_chunk = (uint32_t)g.chunk_starts.size() - 1u;
+        // as many tiles of this query as the chunk still takes
+        const uint64_t room = cost_target - cur_cost;
+        uint32_t take = (uint32_t)std::min<uint64_t>(dq.n_tiles - t, (room + tc - 1) / tc);
+        take = std::max<uint32_t>(take, 1u);
+        cur_cost += (uint64_t)take * tc;
+        t += take;
       }
+      dq.chunk_first = first_chunk;
+      dq.n_parts = ((uint32_t)g.chunk_starts.size() - first_chunk) * per_chunk;
     }
+    g.n_chunks = (uint32_t)g.chunk_starts.size();
+    g.chunk_starts.push_back(g.total_tiles);
   }
   // partial lists of all groups share one buffer; its stride is per group (kpl*64 keys)
   size_t part_off_bytes[3] = {0, 0, 0};
@@ -724,6 +828,9 @@ int tq_search_batch_device(tq_segment *s, const tq_query *queries, uint32_t n_qu
     stage = (stage + 15) & ~(size_t)15;
     g.o_outidx = stage;
     stage += g.out_index.size() * sizeof(uint32_t);
+    stage = (stage + 15) & ~(size_t)15;
+    g.o_chunks = stage;
+    stage += g.chunk_starts.size() * sizeof(uint32_t);
   }
   if (s->stage_in_flight) {
     HIP_TRY(hipEventSynchronize(s->ev_stage_done));
@@ -740,6 +847,7 @@ int tq_search_batch_device(tq_segment *s, const tq_query *queries, uint32_t n_qu
     memcpy(hs + g.o_queries, g.queries.data(), g.queries.size() * sizeof(TqdQuery));
     memcpy(hs + g.o_tiles, g.tile_starts.data(), g.tile_starts.size() * sizeof(uint32_t));
     memcpy(hs + g.o_outidx, g.out_index.data(), g.out_index.size() * sizeof(uint32_t));
+    memcpy(hs + g.o_chunks, g.chunk_starts.data(), g.chunk_starts.size() * sizeof(uint32_t));
   }
   if (s->opt.timing) HIP_TRY(hipEventRecord(s->ev_t0, st));
   HIP_TRY(hipMemcpyAsync(s->d_stage.p, hs, stage, hipMemcpyHostToDevice, st));
@@ -771,9 +879,10 @@ int tq_search_batch_device(tq_segment *s, const tq_query *queries, uint32_t n_qu
     p.thr_slots = (uint32_t *)s->d_thr.p;
     p.n_queries = (uint32_t)g.queries.size();
     p.total_tiles = g.total_tiles;
-    p.tiles_per_chunk = g.tiles_per_chunk;
+    p.chunk_starts = (const uint32_t *)(ds + g.o_chunks);
     p.n_chunks = g.n_chunks;
     p.exhaustive = (uint32_t)s->opt.exhaustive;
+    p.use_dense = (uint32_t)s->opt.use_dense;
     tiles_total += g.total_tiles;
     chunks_total += g.n_chunks;
     hipError_t e = hipSuccess;
@@ -866,6 +975,10 @@ int tq_set_option(tq_segment *s, const char *name, int64_t value) {
     s->opt.timing = value != 0;
   else if (!strcmp(name, "use_dpp"))
     s->opt.use_dpp = value != 0;
+  else if (!strcmp(name, "use_dense"))
+    s->opt.use_dense = value != 0;
+  else if (!strcmp(name, "dense"))  // affects terms prepared afterwards
+    s->opt.dense = value != 0;
   else
     return fail(TQ_ERR_INVALID, "unknown option '%s'", name);
   return TQ_OK;

@@ -2,6 +2,7 @@
 // (tq_kernels.hip).  Layouts are fixed (uploaded as raw bytes).
 #pragma once
 #include <stdint.h>
+#include <hip/hip_runtime.h>
 
 #define TQD_TERMINATED 0x7FFFFFFFu
 #define TQD_MAX_TERMS 16
@@ -9,6 +10,7 @@
 // Tunables of the scan kernels (see DESIGN.md "AND kernel").
 #define TQD_WAVES_PER_WG 4    // independent wavefronts per workgroup
 #define TQD_AND_TILE 64       // leader-list blocks per AND tile (one lane each in the pre-filter)
+#define TQD_DENSE_RATIO 32    // lists with doc_freq >= max_doc/32 also get a bitmap + rank directory
 #define TQD_THR_SLOTS 64      // shared threshold slots per query (pruned mode)
 #define TQD_PH_M 4            // phrase: driver-list blocks per tile
 #define TQD_PH_SLOTS 1024     // phrase: hash slots per wavefront (load factor <= 0.25)
@@ -18,27 +20,32 @@
 // its sequential form (running byte / position offsets made absolute) into structure-of-arrays
 // tables, so that any block can be located and decoded independently of the others:
 //   last_doc[j]  last doc id in block j (skip.rs `last_doc_in_block`)
-//   meta[j]      doc_bits | strict<<6 | tf_bits<<8 | block-max fieldnorm_id<<16 | block-max tf
-//                code<<24 (skip.rs:16-43,205-253); 0xFFFFFFFF = the vint tail (pre-decoded)
-//   byte_off[j]  offset of the bitpacked doc payload, relative to payload_base
+//   mo[j].x      meta: doc_bits | strict<<6 | tf_bits<<8 | block-max fieldnorm_id<<16 | block-max
+//                tf code<<24 (skip.rs:16-43,205-253); 0xFFFFFFFF = the vint tail (pre-decoded)
+//   mo[j].y      offset of the bitpacked doc payload, relative to payload_base
 //   coarse[b]    first j with last_doc[j] >= (b << coarse_shift): O(1) `seek_block`
-struct TqdTerm {
+struct TqdTermHead {  // what every kernel needs: fetched with scalar loads
   const uint32_t *last_doc;   // n_blocks
-  const uint32_t *meta;       // n_blocks
-  const uint32_t *byte_off;   // n_blocks
+  const uint2 *mo;            // n_blocks
   const uint32_t *coarse;     // ((max_doc-1) >> coarse_shift) + 2 entries
+  // dense lists only (doc_freq >= max_doc / TQD_DENSE_RATIO), else null: membership bitmap with a
+  // rank directory.  dense[d >> 5] = {bits of docs 32*(d>>5)..+31, number of postings before them}
+  const uint2 *dense;
   const uint32_t *tail_docs;  // n_tail
   const uint32_t *tail_tfs;   // n_tail
+  uint64_t payload_base;      // absolute offset (inside the .idx sub-file) of block 0's payload
+  uint32_t n_blocks, n_tail;
+  uint32_t has_freq;          // 0 => every tf reads as 1
+  uint32_t coarse_shift;
+};
+struct TqdTerm : TqdTermHead {
   const uint32_t *block_pos;  // n_blocks+1: index (in positions) of the first position of a block
   // positions stream (src/positions/reader.rs): per position-block absolute byte offset / width
   const uint64_t *pos_block_off;  // n_pos_blocks
   const uint8_t *pos_widths;      // n_pos_blocks
   const uint32_t *pos_tail;       // vint tail, pre-decoded deltas
-  uint64_t payload_base;          // absolute offset (inside the .idx sub-file) of block 0's payload
-  uint32_t n_full, n_tail, n_blocks, doc_freq;
+  uint32_t n_full, doc_freq;
   uint32_t n_pos_blocks, n_pos_tail;
-  uint32_t has_freq;  // 0 => every tf reads as 1
-  uint32_t coarse_shift;
 };
 
 struct TqdQuery {
@@ -55,6 +62,8 @@ struct TqdQuery {
   uint32_t n_parts;
   uint32_t flags;       // TQD_QF_*
   uint32_t thr_index;   // row of the shared-threshold table (pruned mode), or 0xFFFFFFFF
+  uint32_t chunk_first; // first chunk that holds a tile of this query
+  uint32_t tile_blocks; // AND: leader blocks per tile (1..64, sized so tiles cost about the same)
 };
 
 #define TQD_QF_PRUNE 1u  // block-max pruning allowed (all weights >= 0, caller asked for it)
@@ -65,4 +74,5 @@ struct TqdSegment {
   const uint8_t *fieldnorm;  // max_doc bytes or null
   uint32_t max_doc;
   uint32_t const_fieldnorm_id;
+  uint32_t min_fieldnorm_id;  // smallest fieldnorm id present (lower bound of every doc's norm)
 };

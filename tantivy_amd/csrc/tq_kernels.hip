@@ -119,11 +119,29 @@ __device__ __forceinline__ uint32_t unpack_one(const uint8_t *p, uint32_t b, uin
 }
 
 // ------------------------------------------------------------------ block decode
+// Wave-uniform data (term tables, query descriptors, skip entries of a uniform block index) is
+// read through the constant address space: with a uniform address the compiler emits scalar
+// loads (s_load_*), which leave the vector-memory pipeline — the bottleneck of these kernels —
+// to the per-lane gathers.  The data is written by the host before the launch and never by a
+// kernel.
+#define TQ_AS4 __attribute__((address_space(4)))
+template <typename X>
+__device__ __forceinline__ X sload(const X *p) {
+  static_assert(sizeof(X) % 4 == 0, "dword-sized objects only");
+  const TQ_AS4 uint32_t *q = (const TQ_AS4 uint32_t *)(uintptr_t)p;
+  uint32_t w[sizeof(X) / 4];
+#pragma unroll
+  for (size_t i = 0; i < sizeof(X) / 4; ++i) w[i] = q[i];
+  X x;
+  __builtin_memcpy(&x, w, sizeof(X));
+  return x;
+}
+
 struct TermRef {
   const uint32_t *last_doc;
-  const uint32_t *meta;
-  const uint32_t *byte_off;
+  const uint2 *mo;  // {meta, byte_off}
   const uint32_t *coarse;
+  const uint2 *dense;
   const uint32_t *tail_docs;
   const uint32_t *tail_tfs;
   uint64_t payload_base;
@@ -133,24 +151,29 @@ struct TermRef {
   uint32_t shift;
 };
 __device__ __forceinline__ TermRef load_term(const TqdTerm *terms, uint32_t handle) {
-  const TqdTerm *t = uni_ptr(terms + handle);
+  const TqdTermHead h = sload(reinterpret_cast<const TqdTermHead *>(terms + handle));
   TermRef r;
-  r.last_doc = uni_ptr(t->last_doc);
-  r.meta = uni_ptr(t->meta);
-  r.byte_off = uni_ptr(t->byte_off);
-  r.coarse = uni_ptr(t->coarse);
-  r.tail_docs = uni_ptr(t->tail_docs);
-  r.tail_tfs = uni_ptr(t->tail_tfs);
-  r.payload_base = uni64(t->payload_base);
-  r.n_blocks = uni(t->n_blocks);
-  r.n_tail = uni(t->n_tail);
-  r.has_freq = uni(t->has_freq);
-  r.shift = uni(t->coarse_shift);
+  r.last_doc = h.last_doc;
+  r.mo = h.mo;
+  r.coarse = h.coarse;
+  r.dense = h.dense;
+  r.tail_docs = h.tail_docs;
+  r.tail_tfs = h.tail_tfs;
+  r.payload_base = h.payload_base;
+  r.n_blocks = h.n_blocks;
+  r.n_tail = h.n_tail;
+  r.has_freq = h.has_freq;
+  r.shift = h.coarse_shift;
   return r;
 }
-__device__ __forceinline__ uint32_t block_first_possible(const TermRef &t, uint32_t j) {
-  return j ? uni(t.last_doc[j - 1]) + 1u : 0u;
+// j wave-uniform
+__device__ __forceinline__ uint32_t block_prev_last(const TermRef &t, uint32_t j) {
+  return j ? sload(t.last_doc + (j - 1u)) : 0u;
 }
+__device__ __forceinline__ uint32_t block_first_possible(const TermRef &t, uint32_t j) {
+  return j ? sload(t.last_doc + (j - 1u)) + 1u : 0u;
+}
+__device__ __forceinline__ uint2 uni_mo(const TermRef &t, uint32_t j) { return sload(t.mo + j); }
 
 struct Dec {
   uint32_t d0, d1;  // doc ids (TQD_TERMINATED padded)
@@ -158,22 +181,11 @@ struct Dec {
 };
 constexpr uint32_t META_TAIL = 0xFFFFFFFFu;
 
-// doc ids of block j (wave-uniform j): lane t gets docs 2t, 2t+1
+// doc ids of one block (wave-uniform mo = {meta, byte_off}; prev = last doc of the previous
+// block, 0 for block 0): lane t gets docs 2t, 2t+1
 template <bool USE_DPP>
-__device__ __forceinline__ void decode_docs(const uint8_t *idx, const TermRef &t, uint32_t j,
-                                            uint32_t meta, int lane, uint32_t &d0, uint32_t &d1) {
-  if (meta == META_TAIL) {  // vint tail, pre-decoded at term_prepare
-    const uint32_t i0 = 2u * (uint32_t)lane, i1 = i0 + 1u;
-    d0 = i0 < t.n_tail ? t.tail_docs[i0] : TQD_TERMINATED;
-    d1 = i1 < t.n_tail ? t.tail_docs[i1] : TQD_TERMINATED;
-    return;
-  }
-  const uint8_t *p = idx + t.payload_base + uni(t.byte_off[j]);
-  const uint32_t prev = j ? uni(t.last_doc[j - 1]) : 0u;
-  const uint32_t doc_bits = meta & 31u;
-  const uint32_t strict = (meta >> 6) & 1u;
-  uint32_t x0, x1;
-  unpack2(p, doc_bits, lane, x0, x1);
+__device__ __forceinline__ void finish_docs(uint32_t x0, uint32_t x1, uint32_t strict,
+                                            uint32_t prev, int lane, uint32_t &d0, uint32_t &d1) {
   const uint32_t a0 = x0 + strict;
   const uint32_t a1 = a0 + x1 + strict;
   const uint32_t incl = wave_inclusive_scan<USE_DPP>(a1, lane);
@@ -183,10 +195,24 @@ __device__ __forceinline__ void decode_docs(const uint8_t *idx, const TermRef &t
   d0 = excl + a0;
   d1 = excl + a1;
 }
-// term freqs of block j for the same lane layout (padding of the tail reads as tf 0)
-__device__ __forceinline__ void decode_tfs(const uint8_t *idx, const TermRef &t, uint32_t j,
-                                           uint32_t meta, int lane, uint32_t &t0, uint32_t &t1) {
-  if (meta == META_TAIL) {
+template <bool USE_DPP>
+__device__ __forceinline__ void decode_docs(const uint8_t *idx, const TermRef &t, uint2 mo,
+                                            uint32_t prev, int lane, uint32_t &d0, uint32_t &d1) {
+  if (mo.x == META_TAIL) {  // vint tail, pre-decoded at term_prepare
+    const uint32_t i0 = 2u * (uint32_t)lane, i1 = i0 + 1u;
+    d0 = i0 < t.n_tail ? t.tail_docs[i0] : TQD_TERMINATED;
+    d1 = i1 < t.n_tail ? t.tail_docs[i1] : TQD_TERMINATED;
+    return;
+  }
+  const uint8_t *p = idx + t.payload_base + mo.y;
+  uint32_t x0, x1;
+  unpack2(p, mo.x & 31u, lane, x0, x1);
+  finish_docs<USE_DPP>(x0, x1, (mo.x >> 6) & 1u, prev, lane, d0, d1);
+}
+// term freqs of the same block and lane layout (padding of the tail reads as tf 0)
+__device__ __forceinline__ void decode_tfs(const uint8_t *idx, const TermRef &t, uint2 mo,
+                                           int lane, uint32_t &t0, uint32_t &t1) {
+  if (mo.x == META_TAIL) {
     const uint32_t i0 = 2u * (uint32_t)lane, i1 = i0 + 1u;
     t0 = i0 < t.n_tail ? (t.has_freq ? t.tail_tfs[i0] : 1u) : 0u;
     t1 = i1 < t.n_tail ? (t.has_freq ? t.tail_tfs[i1] : 1u) : 0u;
@@ -197,24 +223,67 @@ __device__ __forceinline__ void decode_tfs(const uint8_t *idx, const TermRef &t,
     t1 = 1u;
     return;
   }
-  const uint32_t doc_bits = meta & 31u;
-  const uint32_t strict = (meta >> 6) & 1u;
-  const uint32_t tf_bits = (meta >> 8) & 0xFFu;
-  const uint8_t *p = idx + t.payload_base + uni(t.byte_off[j]) + 16u * doc_bits;
+  const uint32_t doc_bits = mo.x & 31u;
+  const uint32_t strict = (mo.x >> 6) & 1u;
+  const uint32_t tf_bits = (mo.x >> 8) & 0xFFu;
+  const uint8_t *p = idx + t.payload_base + mo.y + 16u * doc_bits;
   unpack2(p, tf_bits, lane, t0, t1);
   t0 += strict;  // minus-one encoding is tied to the strict flag
   t1 += strict;  // (block_segment_postings.rs:45-57)
 }
-// term freq of the posting at index i (0..127) of block j; j and meta may differ per lane
-__device__ __forceinline__ uint32_t block_tf_at(const uint8_t *idx, const TermRef &t, uint32_t j,
-                                                uint32_t meta, uint32_t i) {
+
+// ---- LDS-staged variant: the block's payload (16*(doc_bits+tf_bits) <= 1008 bytes) is fetched
+// with ONE 16-byte load per lane, parked in LDS, and the 4 interleaved bit streams are unpacked
+// from there (two ds_read_b64 per stream pair instead of two global loads).
+struct __attribute__((packed, aligned(1))) U4Unaligned {
+  uint32_t x, y, z, w;
+};
+__device__ __forceinline__ void stage_payload(uint32_t *pay, const uint8_t *p, uint32_t nbytes,
+                                              int lane) {
+  const uint32_t o = 16u * (uint32_t)lane;
+  if (o < nbytes) {
+    const U4Unaligned v = *reinterpret_cast<const U4Unaligned *>(p + o);
+    *reinterpret_cast<uint4 *>(pay + 4 * lane) = make_uint4(v.x, v.y, v.z, v.w);
+  }
+}
+// pay4 = first 16-byte row of the stream group inside the LDS copy
+__device__ __forceinline__ void unpack2_lds(const uint32_t *pay4, uint32_t b, int lane,
+                                            uint32_t &v0, uint32_t &v1) {
+  if (b == 0) {  // wave-uniform
+    v0 = 0;
+    v1 = 0;
+    return;
+  }
+  const uint32_t k = (uint32_t)lane >> 1;
+  const uint32_t bitpos = k * b;
+  const uint32_t w = bitpos >> 5, s = bitpos & 31u;
+  const uint32_t *q = pay4 + 4u * w + 2u * ((uint32_t)lane & 1u);
+  const uint2 lo = *reinterpret_cast<const uint2 *>(q);
+  const uint2 hi = *reinterpret_cast<const uint2 *>(q + 4);  // row w+1 (stale bytes are masked)
+  const uint32_t mask = (b >= 32u) ? 0xFFFFFFFFu : ((1u << b) - 1u);
+  v0 = __funnelshift_r(lo.x, hi.x, s) & mask;
+  v1 = __funnelshift_r(lo.y, hi.y, s) & mask;
+}
+
+// term freq of the posting at slot i (0..127) of a block; mo and i may differ per lane
+__device__ __forceinline__ uint32_t block_tf_at(const uint8_t *idx, const TermRef &t, uint2 mo,
+                                                uint32_t i) {
   if (!t.has_freq) return 1u;
-  if (meta == META_TAIL) return t.tail_tfs[i];
-  const uint32_t doc_bits = meta & 31u;
-  const uint32_t strict = (meta >> 6) & 1u;
-  const uint32_t tf_bits = (meta >> 8) & 0xFFu;
-  const uint8_t *p = idx + t.payload_base + t.byte_off[j] + 16u * doc_bits;
-  return unpack_one(p, tf_bits, i) + strict;
+  if (mo.x == META_TAIL) return t.tail_tfs[i];
+  const uint32_t doc_bits = mo.x & 31u;
+  const uint32_t strict = (mo.x >> 6) & 1u;
+  const uint32_t tf_bits = (mo.x >> 8) & 0xFFu;
+  if (tf_bits == 0u) return strict;
+  const uint8_t *p = idx + t.payload_base + mo.y + 16u * doc_bits;
+  const uint32_t k = i >> 2, l = i & 3u;
+  const uint32_t bitpos = k * tf_bits;
+  const uint32_t w = bitpos >> 5, sh = bitpos & 31u;
+  const uint8_t *q = p + 16u * w + 4u * l;
+  const uint32_t lo = ld_u1(q);
+  uint32_t hi = 0;
+  if (sh + tf_bits > 32u) hi = ld_u1(q + 16);  // the value straddles two words of its stream
+  const uint32_t mask = (tf_bits >= 32u) ? 0xFFFFFFFFu : ((1u << tf_bits) - 1u);
+  return (__funnelshift_r(lo, hi, sh) & mask) + strict;
 }
 
 // WANT_TF_SCAN: also return the exclusive prefix sum of the tfs (position index inside the block)
@@ -223,9 +292,10 @@ __device__ __forceinline__ Dec decode_block(const uint8_t *idx, const TermRef &t
                                             int lane, uint32_t *tf_excl0 = nullptr,
                                             uint32_t *tf_excl1 = nullptr) {
   Dec r;
-  const uint32_t meta = uni(t.meta[j]);
-  decode_docs<USE_DPP>(idx, t, j, meta, lane, r.d0, r.d1);
-  decode_tfs(idx, t, j, meta, lane, r.t0, r.t1);
+  const uint2 mo = uni_mo(t, j);
+  const uint32_t prev = block_prev_last(t, j);
+  decode_docs<USE_DPP>(idx, t, mo, prev, lane, r.d0, r.d1);
+  decode_tfs(idx, t, mo, lane, r.t0, r.t1);
   if (WANT_TF_SCAN) {
     const uint32_t s = r.t0 + r.t1;
     const uint32_t incl = wave_inclusive_scan<USE_DPP>(s, lane);
@@ -385,7 +455,7 @@ __device__ __forceinline__ uint32_t find_query(const uint32_t *tile_starts, uint
   uint32_t lo = 0, hi = n_queries;  // answer in [lo, hi)
   while (hi - lo > 1u) {
     const uint32_t mid = (lo + hi) >> 1;
-    if (uni(tile_starts[mid]) <= t)
+    if (sload(tile_starts + mid) <= t)
       lo = mid;
     else
       hi = mid;
@@ -407,18 +477,25 @@ __device__ __forceinline__ void flush_partial(const TopK<KPL> &tk, uint64_t *par
 // =================================================================== AND kernel
 // block_wand_intersection (src/query/boolean_query/block_wand_intersection.rs:19-179) restated for
 // wavefronts.  Terms are ordered by doc freq ascending; term 0 is the leader.  Tile = 64
-// consecutive leader blocks; one wavefront = one chunk of consecutive tiles.
-//   1. pre-filter, one LANE per leader block: O(1) seek_block of the block's doc range in every
-//      other list; drop blocks past the end of a list and (pruned mode) blocks whose block-max sum
+// consecutive leader blocks; one wavefront = one chunk of consecutive tiles.  The work of one
+// leader block is cut into three stages joined by per-wave LDS queues, so that every gather runs
+// with (nearly) all 64 lanes carrying a live candidate — vector-memory instructions, not bytes,
+// are what this kernel is short of:
+//   pre-filter (one LANE per leader block): O(1) seek_block of the block's doc range in the other
+//      lists; drop blocks past the end of a list and, pruned mode, blocks whose block-max sum
 //      cannot reach the threshold (:81-85);
-//   2. per surviving leader block, the whole wave: decode 128 docs + tfs (2 per lane), gather the
-//      fieldnorm bytes, score the leader term (:107-125);
-//   3. per other term, ascending doc freq: per-lane seek_block of every live candidate; pruned
-//      mode drops candidates whose partial score + block-max of that block cannot reach the
-//      threshold (:144-165); the distinct blocks that still hold candidates are decoded once each
-//      (doc ids only) and searched; tfs are fetched individually for the docs found;
-//   4. matches are offered to the wave's register top-k; pruned mode also publishes their score
-//      into the query's 64 threshold slots (atomic max, fire and forget).  The k-th largest slot
+//   A  (whole wave, one leader block): ONE 16-byte load per lane stages the bitpacked doc+tf
+//      payload in LDS; unpack + DPP prefix sum; pruned mode keeps the candidates whose tf-only
+//      score bound can reach the threshold; survivors -> queue 1;
+//   B  (64 candidates, one per lane): pruned mode scores the leader term exactly (fieldnorm gather)
+//      and filters (:107-125); locates the candidate in list 1 — dense lists: one bitmap/rank
+//      load gives membership and the posting index; others: O(1) seek_block — and, pruned mode,
+//      filters on the block-max of that block (:144-165); survivors -> queue 2;
+//   C  (64 candidates): verifies membership (non-dense lists: the distinct blocks are decoded once
+//      each and searched), fetches the tfs of the docs found, scores in the reference's order
+//      (leader, then ascending doc freq), runs the remaining lists of a 3+ term query, and offers
+//      the matches to the wave's register top-k.  Pruned mode also publishes each match's score
+//      into the query's 64 threshold slots (atomic max, fire and forget): the k-th largest slot
 //      is a lower bound of the final k-th best score (every slot holds a distinct real match),
 //      monotone like the callback's threshold in the reference (:141-143,168-174).
 // Candidates equal to the threshold are kept (>=, not >), so ties on the k-th score still resolve
@@ -447,80 +524,320 @@ __device__ __forceinline__ uint32_t kth_largest64(uint32_t v, uint32_t k) {
   }
   return best;
 }
+__device__ __forceinline__ uint32_t mbcnt64(uint64_t m) {
+  return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+}
+constexpr uint32_t NOT_FOUND = 0xFFFFFFFFu;
+
+struct AndLds {  // per wavefront
+  uint32_t blk[128];   // doc ids of the block being searched
+  uint32_t pay[272];   // staged bitpacked payload of the block being decoded (+ one spare row)
+  uint32_t q1_doc[192], q1_tf[192], q1_rest[192];
+  uint32_t q2_doc[128], q2_tf[128], q2_loc[128], q2_norm[128];
+  float cache[256];    // Bm25Weight.cache of the current query
+};
+
+// doc ids of block j of `tr` through the LDS staging buffer (one vector load)
+template <bool USE_DPP>
+__device__ __forceinline__ void decode_docs_staged(const uint8_t *idx, const TermRef &tr, uint2 mo,
+                                                   uint32_t prev, uint32_t *pay, int lane,
+                                                   uint32_t &d0, uint32_t &d1) {
+  if (mo.x == META_TAIL) {
+    decode_docs<USE_DPP>(idx, tr, mo, prev, lane, d0, d1);
+    return;
+  }
+  const uint32_t doc_bits = mo.x & 31u;
+  wave_mem_fence();
+  stage_payload(pay, idx + tr.payload_base + mo.y, 16u * doc_bits, lane);
+  wave_mem_fence();
+  uint32_t x0, x1;
+  unpack2_lds(pay, doc_bits, lane, x0, x1);
+  finish_docs<USE_DPP>(x0, x1, (mo.x >> 6) & 1u, prev, lane, d0, d1);
+}
+
+// Where is `doc` inside block jb of list tr?  (lane-private jb/doc; lanes with !alive idle.)
+// The distinct blocks are decoded once each, ascending; few candidates in a block are broadcast
+// and compared, many binary-search the block in LDS (search_block, block_search.rs:38-76).
+template <bool USE_DPP>
+__device__ __forceinline__ uint32_t find_in_blocks(const uint8_t *idx, const TermRef &tr,
+                                                   uint32_t jb, uint32_t doc, bool alive,
+                                                   AndLds &L, int lane) {
+  uint32_t at = NOT_FOUND;
+  uint64_t pend = __ballot(alive);
+  while (pend) {
+    const uint32_t l = (uint32_t)__builtin_ctzll(pend);
+    const uint32_t j = (uint32_t)__builtin_amdgcn_readlane((int)jb, (int)l);
+    const bool in = alive && jb == j;
+    uint64_t m = __ballot(in);
+    pend &= ~m;
+    uint32_t x0, x1;
+    decode_docs_staged<USE_DPP>(idx, tr, uni_mo(tr, j), block_prev_last(tr, j), L.pay, lane, x0, x1);
+    if (__popcll(m) <= 4) {
+      while (m) {
+        const uint32_t lc = (uint32_t)__builtin_ctzll(m);
+        m &= m - 1ull;
+        const uint32_t c = (uint32_t)__builtin_amdgcn_readlane((int)doc, (int)lc);
+        const uint64_t h0 = __ballot(x0 == c), h1 = __ballot(x1 == c);
+        uint32_t a = NOT_FOUND;
+        if (h0)
+          a = 2u * (uint32_t)__builtin_ctzll(h0);
+        else if (h1)
+          a = 2u * (uint32_t)__builtin_ctzll(h1) + 1u;
+        if ((uint32_t)lane == lc) at = a;
+      }
+    } else {
+      wave_mem_fence();
+      *reinterpret_cast<uint2 *>(L.blk + 2 * lane) = make_uint2(x0, x1);
+      wave_mem_fence();
+      if (in) {
+        uint32_t pos = 0;
+#pragma unroll
+        for (uint32_t step = 64u; step > 0u; step >>= 1)
+          if (L.blk[pos + step - 1u] < doc) pos += step;
+        at = L.blk[pos] == doc ? pos : NOT_FOUND;
+      }
+    }
+  }
+  return at;
+}
 
 template <int KPL, bool USE_DPP>
-__global__ __launch_bounds__(TQD_WAVES_PER_WG * 64) void and_kernel(TqkScanParams p) {
-  __shared__ uint32_t lds_docs[TQD_WAVES_PER_WG][128];
+__global__ __launch_bounds__(64) void and_kernel(TqkScanParams p) {
+  __shared__ AndLds L;  // one wavefront per workgroup: finished chunks free their slot at once
   const int lane = (int)__lane_id();
-  const uint32_t wave = uni(threadIdx.x >> 6);
-  uint32_t *const blk = lds_docs[wave];
-
-  const uint32_t chunk = blockIdx.x * TQD_WAVES_PER_WG + wave;
+  const uint32_t chunk = blockIdx.x;
   if (chunk >= p.n_chunks) return;
-  const uint32_t t_begin = chunk * p.tiles_per_chunk;
-  uint32_t t_end = t_begin + p.tiles_per_chunk;
-  if (t_end > p.total_tiles) t_end = p.total_tiles;
+  const uint32_t t_begin = sload(p.chunk_starts + chunk);
+  const uint32_t t_end = sload(p.chunk_starts + chunk + 1u);
 
   const TqdSegment seg = p.seg;
-  const uint8_t *idx = uni_ptr(seg.idx);
+  const uint8_t *idx = seg.idx;
 
-  uint32_t q = find_query(p.tile_starts, p.n_queries, t_begin);
-  uint32_t q_tile_start = uni(p.tile_starts[q]);
-  uint32_t q_tile_end = uni(p.tile_starts[q + 1]);
-  const TqdQuery *Q = uni_ptr(p.queries + q);
+  // ---- per-query state (wave-uniform)
+  uint32_t q = uni(find_query(p.tile_starts, p.n_queries, t_begin));
+  uint32_t q_tile_start = 0, q_tile_end = 0;
+  const TqdQuery *Q = nullptr;
+  uint32_t nt = 0, tile_blocks = TQD_AND_TILE;
+  TermRef lead{}, t1{};
+  float w_lead = 0.0f, w1 = 0.0f, rest_after1 = 0.0f, min_norm = 0.0f;
+  bool prune = false;
+  uint32_t *slots = nullptr;
+  uint32_t thr = 0, thr_g = 0;
+  uint32_t cache_loaded = 0xFFFFFFFFu;
   TopK<KPL> tk;
-  tk.reset(uni(Q->k));
   uint32_t n_matches = 0;
+  uint32_t q1n = 0, q2n = 0;  // queue fill
 
+  auto setup_query = [&]() {
+    q_tile_start = sload(p.tile_starts + q);
+    q_tile_end = sload(p.tile_starts + q + 1u);
+    Q = p.queries + q;
+    nt = sload(&Q->n_terms);
+    tile_blocks = sload(&Q->tile_blocks);
+    lead = load_term(p.terms, sload(&Q->term[0]));
+    t1 = load_term(p.terms, sload(&Q->term[1]));
+    if (!p.use_dense) t1.dense = nullptr;
+    w_lead = sload(&Q->weight[0]);
+    w1 = sload(&Q->weight[1]);
+    rest_after1 = 0.0f;
+    for (uint32_t m = 2; m < nt; ++m) rest_after1 += sload(&Q->weight[m]);
+    prune = (sload(&Q->flags) & TQD_QF_PRUNE) != 0u;
+    const uint32_t thr_index = sload(&Q->thr_index);
+    slots = (prune && thr_index != 0xFFFFFFFFu) ? p.thr_slots + (size_t)thr_index * TQD_THR_SLOTS
+                                                : nullptr;
+    const uint32_t ci = sload(&Q->cache_idx);
+    if (ci != cache_loaded) {
+      const float *cg = p.caches + (size_t)ci * 256u;
+      wave_mem_fence();
+      for (int i = lane; i < 256; i += WAVE) L.cache[i] = cg[i];
+      wave_mem_fence();
+      cache_loaded = ci;
+    }
+    // every doc's norm is >= the norm of the smallest fieldnorm id present (cache is monotone)
+    min_norm = sload(p.caches + (size_t)ci * 256u +
+                     (seg.fieldnorm ? seg.min_fieldnorm_id : seg.const_fieldnorm_id));
+    thr = 0;
+    thr_g = 0;
+    tk.reset(sload(&Q->k));
+  };
+
+  // ---- stage C: verify in list 1, score, remaining lists, collect
+  auto stageC = [&](uint32_t n) {
+    const uint32_t base = q2n - n;
+    q2n = base;
+    bool alive = (uint32_t)lane < n;
+    uint32_t doc = 0, tf = 0, loc = 0;
+    float norm = 0.0f;
+    if (alive) {
+      doc = L.q2_doc[base + lane];
+      tf = L.q2_tf[base + lane];
+      loc = L.q2_loc[base + lane];
+      norm = __uint_as_float(L.q2_norm[base + lane]);
+      if (!prune) norm = L.cache[fieldnorm_id(seg, doc)];
+    }
+    float s = bm25(w_lead, norm, tf);
+    {
+      uint32_t jb = loc, at = NOT_FOUND;
+      uint2 mo = make_uint2(0u, 0u);
+      if (t1.dense) {
+        jb = loc >> 7;
+        at = loc & 127u;
+        if (alive) mo = t1.mo[jb];
+      } else {
+        if (alive) mo = t1.mo[jb];
+        at = find_in_blocks<USE_DPP>(idx, t1, jb, doc, alive, L, lane);
+        alive = alive && at != NOT_FOUND;
+      }
+      // leader first, then ascending doc freq (block_wand_intersection.rs:144-165)
+      if (alive) s = s + bm25(w1, norm, block_tf_at(idx, t1, mo, at));
+    }
+    float rest = rest_after1;
+    for (uint32_t m = 2; m < nt; ++m) {
+      TermRef tr = load_term(p.terms, sload(&Q->term[m]));
+      if (!p.use_dense) tr.dense = nullptr;
+      const float w = sload(&Q->weight[m]);
+      rest -= w;
+      if (rest < 0.0f) rest = 0.0f;
+      uint32_t jb = 0, at = NOT_FOUND;
+      if (tr.dense) {
+        if (alive) {
+          const uint2 wd = tr.dense[doc >> 5];
+          const uint32_t bit = doc & 31u;
+          alive = (wd.x >> bit) & 1u;
+          const uint32_t pi = wd.y + (uint32_t)__popc(wd.x & ((1u << bit) - 1u));
+          jb = pi >> 7;
+          at = pi & 127u;
+        }
+      } else if (alive) {
+        jb = seek_block(tr, doc);
+        alive = jb < tr.n_blocks;
+      }
+      uint2 mo = make_uint2(0u, 0u);
+      if (alive) mo = tr.mo[jb];
+      if (prune && alive) {
+        const float ub = (s + block_max_score(mo.x, w, L.cache, tr.has_freq) + rest) * 1.000001f;
+        alive = sortable(ub) >= thr;
+      }
+      if (!tr.dense) {
+        at = find_in_blocks<USE_DPP>(idx, tr, jb, doc, alive, L, lane);
+        alive = alive && at != NOT_FOUND;
+      }
+      if (alive) s = s + bm25(w, norm, block_tf_at(idx, tr, mo, at));
+    }
+    const uint64_t hit = __ballot(alive);
+    if (hit) {
+      n_matches += (uint32_t)__popcll(hit);
+      const uint64_t key = alive ? make_key(s, doc) : 0ull;
+      if (slots) {
+        const uint32_t sb = (uint32_t)(key >> 32);
+        if (alive && sb > thr_g) atomicMax(slots + ((doc * 0x9E3779B1u) >> 26), sb);
+      }
+      tk.offer(alive, key, lane);
+      if (prune) {
+        const uint32_t own = (uint32_t)(tk.thr >> 32);
+        if (own > thr) thr = own;
+      }
+    }
+  };
+
+  // ---- stage B: exact leader score (pruned), locate in list 1, block-max filter (pruned)
+  auto stageB = [&](uint32_t n) {
+    const uint32_t base = q1n - n;
+    q1n = base;
+    bool alive = (uint32_t)lane < n;
+    uint32_t doc = 0, tf = 0, loc = 0;
+    float norm = 0.0f, s = 0.0f;
+    if (alive) {
+      doc = L.q1_doc[base + lane];
+      tf = L.q1_tf[base + lane];
+    }
+    if (prune && alive) {
+      const float rest_b = __uint_as_float(L.q1_rest[base + lane]);
+      norm = L.cache[fieldnorm_id(seg, doc)];
+      s = bm25(w_lead, norm, tf);
+      alive = sortable(s + rest_b) >= thr;
+    }
+    if (t1.dense) {
+      if (alive) {
+        const uint2 wd = t1.dense[doc >> 5];
+        const uint32_t bit = doc & 31u;
+        alive = (wd.x >> bit) & 1u;
+        loc = wd.y + (uint32_t)__popc(wd.x & ((1u << bit) - 1u));
+      }
+    } else if (alive) {
+      loc = seek_block(t1, doc);
+      alive = loc < t1.n_blocks;
+    }
+    if (prune && alive) {
+      const uint2 mo = t1.mo[t1.dense ? loc >> 7 : loc];
+      float ub = s + block_max_score(mo.x, w1, L.cache, t1.has_freq);
+      if (nt > 2u) ub = (ub + rest_after1) * 1.000001f;
+      alive = sortable(ub) >= thr;
+    }
+    const uint64_t m = __ballot(alive);
+    if (m) {
+      const uint32_t pos = q2n + mbcnt64(m);
+      wave_mem_fence();
+      if (alive) {
+        L.q2_doc[pos] = doc;
+        L.q2_tf[pos] = tf;
+        L.q2_loc[pos] = loc;
+        L.q2_norm[pos] = __float_as_uint(norm);
+      }
+      wave_mem_fence();
+      q2n += (uint32_t)__popcll(m);
+    }
+  };
+
+  auto drain = [&]() {
+    while (q1n) {
+      stageB(q1n < 64u ? q1n : 64u);
+      while (q2n >= 64u) stageC(64u);
+    }
+    while (q2n) stageC(q2n < 64u ? q2n : 64u);
+  };
+
+  setup_query();
   for (uint32_t t = t_begin; t < t_end; ++t) {
     while (t >= q_tile_end) {  // next query (queries with zero tiles are skipped)
       if (q_tile_end > q_tile_start && q_tile_end > t_begin) {  // this chunk touched query q
-        const uint32_t part =
-            uni(Q->part_start) + (chunk - q_tile_start / p.tiles_per_chunk);
+        drain();
+        const uint32_t part = sload(&Q->part_start) + (chunk - sload(&Q->chunk_first));
         flush_partial<KPL>(tk, p.partials, part, lane);
       }
       ++q;
-      q_tile_start = q_tile_end;
-      q_tile_end = uni(p.tile_starts[q + 1]);
-      Q = uni_ptr(p.queries + q);
-      tk.reset(uni(Q->k));
+      setup_query();
     }
-    const uint32_t nt = uni(Q->n_terms);
-    const float *cache = uni_ptr(p.caches + (size_t)uni(Q->cache_idx) * 256u);
-    const TermRef lead = load_term(p.terms, uni(Q->term[0]));
-    const float w_lead = __uint_as_float(uni(__float_as_uint(Q->weight[0])));
-    const bool prune = (uni(Q->flags) & TQD_QF_PRUNE) != 0u;
-    const uint32_t thr_index = uni(Q->thr_index);
-    uint32_t *slots = (prune && thr_index != 0xFFFFFFFFu)
-                          ? p.thr_slots + (size_t)thr_index * TQD_THR_SLOTS
-                          : nullptr;
 
     // threshold (sortable score bits): own k-th key and the k-th largest shared slot
-    uint32_t thr = 0, thr_g = 0;
-    if (prune) {
-      if (slots) {
-        const uint32_t sv = __hip_atomic_load(slots + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        thr_g = kth_largest64(sv, tk.k);
-      }
-      thr = (uint32_t)(tk.thr >> 32);
+    if (slots) {
+      const uint32_t sv =
+          __hip_atomic_load(slots + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      thr_g = kth_largest64(sv, tk.k);
       if (thr_g > thr) thr = thr_g;
     }
 
-    // ---- 1. pre-filter: lane <-> leader block
-    const uint32_t i_base = (t - q_tile_start) * TQD_AND_TILE;
+    // ---- pre-filter: lane <-> leader block
+    const uint32_t i_base = (t - q_tile_start) * tile_blocks;
     const uint32_t i_mine = i_base + (uint32_t)lane;
-    bool surv = i_mine < lead.n_blocks;
+    bool surv = (uint32_t)lane < tile_blocks && i_mine < lead.n_blocks;
+    uint2 mo_mine = make_uint2(0u, 0u);
+    uint32_t prev_mine = 0;
+    float rest_mine = 0.0f;  // bound of the other terms inside this leader block's doc range
     {
       uint32_t first = 0, last = 0;
       float ub = 0.0f;
       if (surv) {
-        first = i_mine ? lead.last_doc[i_mine - 1u] + 1u : 0u;
         last = lead.last_doc[i_mine];
-        if (prune) ub = block_max_score(lead.meta[i_mine], w_lead, cache, lead.has_freq);
+        mo_mine = lead.mo[i_mine];
       }
+      prev_mine = __shfl_up(last, 1, WAVE);
+      if (lane == 0) prev_mine = block_prev_last(lead, i_base);
+      first = i_mine ? prev_mine + 1u : 0u;
+      if (prune && surv) ub = block_max_score(mo_mine.x, w_lead, L.cache, lead.has_freq);
       for (uint32_t m = 1; m < nt; ++m) {
-        const TermRef tr = load_term(p.terms, uni(Q->term[m]));
-        const float w = __uint_as_float(uni(__float_as_uint(Q->weight[m])));
+        const TermRef tr = m == 1u ? t1 : load_term(p.terms, sload(&Q->term[m]));
+        const float w = m == 1u ? w1 : sload(&Q->weight[m]);
         if (surv) {
           const uint32_t j0 = seek_block(tr, first);
           if (j0 >= tr.n_blocks) {
@@ -530,167 +847,93 @@ __global__ __launch_bounds__(TQD_WAVES_PER_WG * 64) void and_kernel(TqkScanParam
             if (j1 >= tr.n_blocks) j1 = tr.n_blocks - 1u;
             float bound = w;
             if (j1 - j0 <= 3u) {
-              bound = block_max_score(tr.meta[j0], w, cache, tr.has_freq);
+              bound = block_max_score(tr.mo[j0].x, w, L.cache, tr.has_freq);
               for (uint32_t j = j0 + 1u; j <= j1; ++j) {
-                const float b2 = block_max_score(tr.meta[j], w, cache, tr.has_freq);
+                const float b2 = block_max_score(tr.mo[j].x, w, L.cache, tr.has_freq);
                 bound = b2 > bound ? b2 : bound;
               }
             }
-            ub = ub + bound;
+            rest_mine = rest_mine + bound;
           }
         }
       }
-      if (prune && nt > 2u) ub *= 1.000001f;  // the bound is summed in another order than scores
-      if (prune && surv) surv = sortable(ub) >= thr;
+      if (prune && nt > 2u) rest_mine *= 1.000001f;  // summed in another order than the scores
+      if (prune && surv) surv = sortable(ub + rest_mine) >= thr;
     }
     uint64_t todo = __ballot(surv);
 
-    // ---- 2..4: surviving leader blocks, one at a time, whole wave
+    // ---- stage A per surviving leader block
     while (todo) {
-      const uint32_t i = i_base + (uint32_t)__builtin_ctzll(todo);
+      const uint32_t b = (uint32_t)__builtin_ctzll(todo);
       todo &= todo - 1ull;
-      const Dec d = decode_block<USE_DPP, false>(idx, lead, i, lane);
-      const uint32_t c0 = d.d0, c1 = d.d1;
+      const uint2 mo_l = make_uint2((uint32_t)__builtin_amdgcn_readlane((int)mo_mine.x, (int)b),
+                                    (uint32_t)__builtin_amdgcn_readlane((int)mo_mine.y, (int)b));
+      const uint32_t prev_l = (uint32_t)__builtin_amdgcn_readlane((int)prev_mine, (int)b);
+      uint32_t c0, c1, t0, t1f;
+      if (mo_l.x == META_TAIL) {
+        decode_docs<USE_DPP>(idx, lead, mo_l, prev_l, lane, c0, c1);
+        decode_tfs(idx, lead, mo_l, lane, t0, t1f);
+      } else {
+        const uint32_t doc_bits = mo_l.x & 31u;
+        const uint32_t strict = (mo_l.x >> 6) & 1u;
+        const uint32_t tf_bits = lead.has_freq ? (mo_l.x >> 8) & 0xFFu : 0u;
+        wave_mem_fence();
+        stage_payload(L.pay, idx + lead.payload_base + mo_l.y, 16u * (doc_bits + tf_bits), lane);
+        wave_mem_fence();
+        uint32_t x0, x1;
+        unpack2_lds(L.pay, doc_bits, lane, x0, x1);
+        finish_docs<USE_DPP>(x0, x1, strict, prev_l, lane, c0, c1);
+        if (lead.has_freq) {
+          unpack2_lds(L.pay + 4u * doc_bits, tf_bits, lane, t0, t1f);
+          t0 += strict;  // minus-one encoding is tied to the strict flag
+          t1f += strict;
+        } else {
+          t0 = 1u;
+          t1f = 1u;
+        }
+      }
       bool alive0 = c0 != TQD_TERMINATED, alive1 = c1 != TQD_TERMINATED;
-      float norm0 = 0.0f, norm1 = 0.0f, s0 = 0.0f, s1 = 0.0f;
+      uint32_t rest_bits = 0;
+      if (prune) {
+        // tf-only bound first: no memory access (block_wand_intersection.rs:112-125 filters on
+        // the exact leader score; this is the same test with the norm replaced by its lower bound)
+        rest_bits = (uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(rest_mine), (int)b);
+        const float rest_b = __uint_as_float(rest_bits);
+        if (alive0) alive0 = sortable(bm25(w_lead, min_norm, t0) + rest_b) >= thr;
+        if (alive1) alive1 = sortable(bm25(w_lead, min_norm, t1f) + rest_b) >= thr;
+      }
+      const uint64_t m0 = __ballot(alive0), m1 = __ballot(alive1);
+      if (!(m0 | m1)) continue;
+      const uint32_t n0 = (uint32_t)__popcll(m0);
+      const uint32_t pos0 = q1n + mbcnt64(m0);
+      const uint32_t pos1 = q1n + n0 + mbcnt64(m1);
+      wave_mem_fence();
       if (alive0) {
-        norm0 = cache[fieldnorm_id(seg, c0)];
-        s0 = bm25(w_lead, norm0, d.t0);
+        L.q1_doc[pos0] = c0;
+        L.q1_tf[pos0] = t0;
+        L.q1_rest[pos0] = rest_bits;
       }
       if (alive1) {
-        norm1 = cache[fieldnorm_id(seg, c1)];
-        s1 = bm25(w_lead, norm1, d.t1);
+        L.q1_doc[pos1] = c1;
+        L.q1_tf[pos1] = t1f;
+        L.q1_rest[pos1] = rest_bits;
       }
-      // bound of the terms after the current one (3+ terms, pruned mode)
-      float rest = 0.0f;
-      if (prune)
-        for (uint32_t m = 2; m < nt; ++m) rest += __uint_as_float(uni(__float_as_uint(Q->weight[m])));
-
-      for (uint32_t m = 1; m < nt; ++m) {
-        const TermRef tr = load_term(p.terms, uni(Q->term[m]));
-        const float w = __uint_as_float(uni(__float_as_uint(Q->weight[m])));
-        uint32_t jb0 = tr.n_blocks, jb1 = tr.n_blocks;
-        if (alive0) jb0 = seek_block(tr, c0);
-        if (alive1) jb1 = seek_block(tr, c1);
-        alive0 = alive0 && jb0 < tr.n_blocks;
-        alive1 = alive1 && jb1 < tr.n_blocks;
-        uint32_t meta0 = 0, meta1 = 0;
-        if (alive0) meta0 = tr.meta[jb0];
-        if (alive1) meta1 = tr.meta[jb1];
-        if (prune) {
-          if (alive0) {
-            float ub = s0 + block_max_score(meta0, w, cache, tr.has_freq);
-            if (nt > 2u) ub = (ub + rest) * 1.000001f;
-            alive0 = sortable(ub) >= thr;
-          }
-          if (alive1) {
-            float ub = s1 + block_max_score(meta1, w, cache, tr.has_freq);
-            if (nt > 2u) ub = (ub + rest) * 1.000001f;
-            alive1 = sortable(ub) >= thr;
-          }
-          if (m + 1u < nt) rest -= __uint_as_float(uni(__float_as_uint(Q->weight[m + 1u])));
-          if (rest < 0.0f) rest = 0.0f;
-        }
-        // distinct blocks of list m that still hold candidates, ascending
-        uint64_t pend0 = __ballot(alive0), pend1 = __ballot(alive1);
-        uint32_t at0 = 0xFFFFFFFFu, at1 = 0xFFFFFFFFu;  // index of the doc inside its block
-        while (pend0 | pend1) {
-          const uint32_t l0 = pend0 ? (uint32_t)__builtin_ctzll(pend0) : 64u;
-          const uint32_t l1 = pend1 ? (uint32_t)__builtin_ctzll(pend1) : 64u;
-          const uint32_t j = l0 <= l1 ? (uint32_t)__builtin_amdgcn_readlane((int)jb0, (int)l0)
-                                      : (uint32_t)__builtin_amdgcn_readlane((int)jb1, (int)l1);
-          const bool in0 = alive0 && jb0 == j, in1 = alive1 && jb1 == j;
-          uint64_t m0 = __ballot(in0), m1 = __ballot(in1);
-          pend0 &= ~m0;
-          pend1 &= ~m1;
-          const uint32_t meta_j = uni(tr.meta[j]);
-          uint32_t x0, x1;
-          decode_docs<USE_DPP>(idx, tr, j, meta_j, lane, x0, x1);
-          const uint32_t n_in = (uint32_t)__popcll(m0) + (uint32_t)__popcll(m1);
-          if (n_in <= 4u) {  // few candidates: broadcast each, compare against the 128 docs
-            while (m0 | m1) {
-              const bool from0 = m0 != 0ull && (m1 == 0ull || __builtin_ctzll(m0) <= __builtin_ctzll(m1));
-              const uint32_t l = (uint32_t)__builtin_ctzll(from0 ? m0 : m1);
-              if (from0)
-                m0 &= m0 - 1ull;
-              else
-                m1 &= m1 - 1ull;
-              const uint32_t c = (uint32_t)__builtin_amdgcn_readlane((int)(from0 ? c0 : c1), (int)l);
-              const uint64_t h0 = __ballot(x0 == c), h1 = __ballot(x1 == c);
-              uint32_t at = 0xFFFFFFFFu;
-              if (h0)
-                at = 2u * (uint32_t)__builtin_ctzll(h0);
-              else if (h1)
-                at = 2u * (uint32_t)__builtin_ctzll(h1) + 1u;
-              if ((uint32_t)lane == l) {
-                if (from0)
-                  at0 = at;
-                else
-                  at1 = at;
-              }
-            }
-          } else {  // many candidates: the block goes to LDS, every candidate binary-searches it
-            *reinterpret_cast<uint2 *>(blk + 2 * lane) = make_uint2(x0, x1);
-            wave_mem_fence();
-            if (in0) {
-              uint32_t pos = 0;
-#pragma unroll
-              for (uint32_t step = 64u; step > 0u; step >>= 1)
-                if (blk[pos + step - 1u] < c0) pos += step;
-              at0 = blk[pos] == c0 ? pos : 0xFFFFFFFFu;
-            }
-            if (in1) {
-              uint32_t pos = 0;
-#pragma unroll
-              for (uint32_t step = 64u; step > 0u; step >>= 1)
-                if (blk[pos + step - 1u] < c1) pos += step;
-              at1 = blk[pos] == c1 ? pos : 0xFFFFFFFFu;
-            }
-            wave_mem_fence();
-          }
-        }
-        // score the docs found in list m (leader first, then ascending doc freq: :144-165)
-        if (alive0) {
-          if (at0 != 0xFFFFFFFFu)
-            s0 = s0 + bm25(w, norm0, block_tf_at(idx, tr, jb0, meta0, at0));
-          else
-            alive0 = false;
-        }
-        if (alive1) {
-          if (at1 != 0xFFFFFFFFu)
-            s1 = s1 + bm25(w, norm1, block_tf_at(idx, tr, jb1, meta1, at1));
-          else
-            alive1 = false;
-        }
-      }
-      // ---- 4. collect
-      const uint64_t hit0 = __ballot(alive0), hit1 = __ballot(alive1);
-      if (hit0 | hit1) {
-        n_matches += (uint32_t)__popcll(hit0) + (uint32_t)__popcll(hit1);
-        const uint64_t key0 = alive0 ? make_key(s0, c0) : 0ull;
-        const uint64_t key1 = alive1 ? make_key(s1, c1) : 0ull;
-        if (slots) {
-          const uint32_t b0 = (uint32_t)(key0 >> 32), b1 = (uint32_t)(key1 >> 32);
-          if (alive0 && b0 > thr_g) atomicMax(slots + ((c0 * 0x9E3779B1u) >> 26), b0);
-          if (alive1 && b1 > thr_g) atomicMax(slots + ((c1 * 0x9E3779B1u) >> 26), b1);
-        }
-        tk.offer(alive0, key0, lane);
-        tk.offer(alive1, key1, lane);
-        if (prune) {
-          const uint32_t own = (uint32_t)(tk.thr >> 32);
-          if (own > thr) thr = own;
-        }
+      wave_mem_fence();
+      q1n += n0 + (uint32_t)__popcll(m1);
+      while (q1n >= 64u) {
+        stageB(64u);
+        while (q2n >= 64u) stageC(64u);
       }
     }
   }
   // final flush
   if (q_tile_end > q_tile_start) {
-    const uint32_t part = uni(Q->part_start) + (chunk - q_tile_start / p.tiles_per_chunk);
+    drain();
+    const uint32_t part = sload(&Q->part_start) + (chunk - sload(&Q->chunk_first));
     flush_partial<KPL>(tk, p.partials, part, lane);
   }
   if (lane == 0 && n_matches) atomicAdd(p.match_counter, (unsigned long long)n_matches);
 }
-
 
 // =================================================================== OR kernel (exhaustive union)
 // One workgroup = one chunk of consecutive 4096-doc windows.  Per window: f32 accumulators in
@@ -705,9 +948,8 @@ __global__ __launch_bounds__(TQD_WAVES_PER_WG * 64) void or_kernel(TqkScanParams
   const uint32_t tid = threadIdx.x;
   const uint32_t chunk = blockIdx.x;
   if (chunk >= p.n_chunks) return;
-  const uint32_t t_begin = chunk * p.tiles_per_chunk;
-  uint32_t t_end = t_begin + p.tiles_per_chunk;
-  if (t_end > p.total_tiles) t_end = p.total_tiles;
+  const uint32_t t_begin = sload(p.chunk_starts + chunk);
+  const uint32_t t_end = sload(p.chunk_starts + chunk + 1u);
 
   const TqdSegment seg = p.seg;
   const uint8_t *idx = uni_ptr(seg.idx);
@@ -723,7 +965,7 @@ __global__ __launch_bounds__(TQD_WAVES_PER_WG * 64) void or_kernel(TqkScanParams
     while (t >= q_tile_end) {
       if (q_tile_end > q_tile_start && q_tile_end > t_begin) {
         const uint32_t part = uni(Q->part_start) +
-                              (chunk - q_tile_start / p.tiles_per_chunk) * TQD_WAVES_PER_WG + wave;
+                              (chunk - sload(&Q->chunk_first)) * TQD_WAVES_PER_WG + wave;
         flush_partial<KPL>(tk, p.partials, part, lane);
       }
       ++q;
@@ -773,7 +1015,7 @@ __global__ __launch_bounds__(TQD_WAVES_PER_WG * 64) void or_kernel(TqkScanParams
   }
   if (q_tile_end > q_tile_start) {
     const uint32_t part = uni(Q->part_start) +
-                          (chunk - q_tile_start / p.tiles_per_chunk) * TQD_WAVES_PER_WG + wave;
+                          (chunk - sload(&Q->chunk_first)) * TQD_WAVES_PER_WG + wave;
     flush_partial<KPL>(tk, p.partials, part, lane);
   }
   if (lane == 0 && n_matches) atomicAdd(p.match_counter, (unsigned long long)n_matches);
@@ -828,9 +1070,8 @@ __global__ __launch_bounds__(64) void phrase_kernel(TqkScanParams p) {
   wave_mem_fence();
   const uint32_t chunk = blockIdx.x;
   if (chunk >= p.n_chunks) return;
-  const uint32_t t_begin = chunk * p.tiles_per_chunk;
-  uint32_t t_end = t_begin + p.tiles_per_chunk;
-  if (t_end > p.total_tiles) t_end = p.total_tiles;
+  const uint32_t t_begin = sload(p.chunk_starts + chunk);
+  const uint32_t t_end = sload(p.chunk_starts + chunk + 1u);
   const TqdSegment seg = p.seg;
   const uint8_t *idx = uni_ptr(seg.idx);
   const uint8_t *pos = uni_ptr(seg.pos);
@@ -846,7 +1087,7 @@ __global__ __launch_bounds__(64) void phrase_kernel(TqkScanParams p) {
   for (uint32_t t = t_begin; t < t_end; ++t) {
     while (t >= q_tile_end) {
       if (q_tile_end > q_tile_start && q_tile_end > t_begin) {
-        const uint32_t part = uni(Q->part_start) + (chunk - q_tile_start / p.tiles_per_chunk);
+        const uint32_t part = uni(Q->part_start) + (chunk - sload(&Q->chunk_first));
         flush_partial<KPL>(tk, p.partials, part, lane);
       }
       ++q;
@@ -868,7 +1109,7 @@ __global__ __launch_bounds__(64) void phrase_kernel(TqkScanParams p) {
     uint32_t j1 = j0 + TQD_PH_M;
     if (j1 > drv.n_blocks) j1 = drv.n_blocks;
     const uint32_t lo1 = block_first_possible(drv, j0);
-    const uint32_t hi = uni(drv.last_doc[j1 - 1]);
+    const uint32_t hi = sload(drv.last_doc + (j1 - 1));
     const uint32_t i0 = lower_bound_block(lead, lo1, lane);
     if (i0 >= lead.n_blocks) continue;
     uint32_t iL = lower_bound_block(lead, hi, lane);
@@ -881,7 +1122,7 @@ __global__ __launch_bounds__(64) void phrase_kernel(TqkScanParams p) {
       if (sub_lo1 < lo1) sub_lo1 = lo1;
       uint32_t sub_hi = hi;
       if (ib != iL) {
-        const uint32_t l = uni(lead.last_doc[ib]);
+        const uint32_t l = sload(lead.last_doc + ib);
         if (l < sub_hi) sub_hi = l;
       }
       // ---- fill from the leader
@@ -928,7 +1169,7 @@ __global__ __launch_bounds__(64) void phrase_kernel(TqkScanParams p) {
           jend = tr.n_blocks;
         }
         for (uint32_t j = jb; j < jend; ++j) {
-          if (uni(tr.last_doc[j]) < sub_lo1) continue;
+          if (sload(tr.last_doc + j) < sub_lo1) continue;
           if (block_first_possible(tr, j) > sub_hi) break;
           uint32_t e0, e1;
           const Dec d = decode_block<USE_DPP, true>(idx, tr, j, lane, &e0, &e1);
@@ -1009,7 +1250,7 @@ __global__ __launch_bounds__(64) void phrase_kernel(TqkScanParams p) {
     }
   }
   if (q_tile_end > q_tile_start) {
-    const uint32_t part = uni(Q->part_start) + (chunk - q_tile_start / p.tiles_per_chunk);
+    const uint32_t part = uni(Q->part_start) + (chunk - sload(&Q->chunk_first));
     flush_partial<KPL>(tk, p.partials, part, lane);
   }
   if (lane == 0 && n_matches) atomicAdd(p.match_counter, (unsigned long long)n_matches);
@@ -1154,8 +1395,8 @@ static void launch_or_t(const TqkScanParams &p, bool dpp, dim3 grid, dim3 block,
 
 hipError_t tqk_launch_and(const TqkScanParams &p, int kpl, bool use_dpp, hipStream_t st) {
   if (p.n_chunks == 0) return hipSuccess;
-  const dim3 grid((p.n_chunks + TQD_WAVES_PER_WG - 1) / TQD_WAVES_PER_WG);
-  const dim3 block(TQD_WAVES_PER_WG * 64);
+  const dim3 grid(p.n_chunks);
+  const dim3 block(64);
   switch (kpl) {
     case 1: launch_and_t<1>(p, use_dpp, grid, block, st); break;
     case 2: launch_and_t<2>(p, use_dpp, grid, block, st); break;

@@ -10,15 +10,16 @@ struct TqkScanParams {
   const TqdTerm *terms;
   const TqdQuery *queries;      // the launch group's queries, contiguous
   const uint32_t *tile_starts;  // n_queries + 1, non-decreasing
+  const uint32_t *chunk_starts; // n_chunks + 1: first tile of every chunk
   const float *caches;          // n_caches x 256
   uint64_t *partials;           // partial top-k lists, KPL*64 keys each
   unsigned long long *match_counter;
   uint32_t *thr_slots;          // [n_thr_rows][TQD_THR_SLOTS] shared thresholds (pruned mode)
   uint32_t n_queries;
   uint32_t total_tiles;
-  uint32_t tiles_per_chunk;
   uint32_t n_chunks;
   uint32_t exhaustive;  // 1: score every match; 0: block-max pruning allowed
+  uint32_t use_dense;   // 0: ignore the dense-list bitmaps (always seek + decode)
 };
 
 struct TqkMergeParams {

@@ -186,9 +186,19 @@ def test_and_pruned_equals_exhaustive(synth, k):
         got2 = _device_topk(dev, batch, k)
     finally:
         dev.set_option("exhaustive", 1)
-    for q, g, g2, w in zip(qs, got, got2, want):
+    dev.set_option("use_dense", 0)   # seek + decode instead of the dense-list bitmaps
+    try:
+        got3 = _device_topk(dev, batch, k)
+        dev.set_option("exhaustive", 0)
+        got4 = _device_topk(dev, batch, k)
+    finally:
+        dev.set_option("exhaustive", 1)
+        dev.set_option("use_dense", 1)
+    for q, g, g2, g3, g4, w in zip(qs, got, got2, got3, got4, want):
         assert g == w, q
         assert g2 == w, q
+        assert g3 == w, q
+        assert g4 == w, q
     for q, w in list(zip(qs, want))[:12]:
         _assert_hits_equal(w, _oracle_topk(seg, q, O.MODE_AND, k), exact=len(q) == 2)
 
