@@ -39,7 +39,10 @@ def parse_args():
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--latency-queries", type=int, default=200)
-    ap.add_argument("--pruned", action="store_true", help="allow block-max pruning on the device")
+    ap.add_argument("--exhaustive", action="store_true",
+                    help="time the exhaustive mode (score every match) instead of the reference's "
+                         "block-max pruned execution; both are always run and compared")
+    ap.add_argument("--pruned", action="store_true", help="(default; kept for old command lines)")
     return ap.parse_args()
 
 
@@ -92,7 +95,7 @@ def main():
     t_gen = time.time() - t0
     dev = tantivy_amd.DeviceIndex([seg], devices=[local_rank])
     dev.set_option("timing", 1)
-    dev.set_option("exhaustive", 0 if args.pruned else 1)
+    pruned_mode = not args.exhaustive
     my_stats = (seg.max_doc, seg.total_num_tokens, [t.doc_freq for t in seg.terms])
     all_stats = [my_stats]
     if world > 1:
@@ -131,6 +134,28 @@ def main():
         torch.cuda.synchronize()
         return dev.last_batch_stats()
 
+    # untimed reference pass in the OTHER mode: every query's top-k must be identical with and
+    # without block-max pruning (full-size parity property), and the exhaustive pass counts the
+    # matches that enter the algorithmic-bytes figure
+    def run_mode(exhaustive, n):
+        dev.set_option("exhaustive", 1 if exhaustive else 0)
+        kms, st = [], None
+        for _ in range(n):
+            st = step()
+            kms.append(st["kernel_ms"])
+        torch.cuda.synchronize()
+        return [h.clone().numpy() for h in h_out], st, kms
+
+    exh_out, exh_st, _ = run_mode(True, 1)
+    _, _, exh_kms = run_mode(True, max(1, min(args.steps, 3)))
+    prn_out, prn_st, _ = run_mode(False, 1)
+    _, _, prn_kms = run_mode(False, max(1, min(args.steps, 3)))
+    mode_parity = all(np.array_equal(a, b) for a, b in zip(exh_out, prn_out))
+    if not mode_parity:
+        raise SystemExit("pruned and exhaustive results differ")
+    full_matches = exh_st["matches"]
+    algo_bytes_full = exh_st["algorithmic_bytes"]  # postings + positions + matches + 8k
+    dev.set_option("exhaustive", 0 if pruned_mode else 1)
     for _ in range(args.warmup):
         step()
     if world > 1:
@@ -141,7 +166,7 @@ def main():
     for _ in range(args.steps):
         st = step()
         kernel_ms.append(st["kernel_ms"])
-        algo_bytes, matches = st["algorithmic_bytes"], st["matches"]
+        algo_bytes, matches = algo_bytes_full, st["matches"]
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -205,6 +230,25 @@ def main():
                          "block_wand (oracle/), not the tantivy binary" % (done, cores, wall_total),
                "p50_latency_ms_1core": round(float(np.median(lat1)) * 1e3, 3)}
 
+    # HBM traffic per launch from the committed rocprofv3 PMC run of this same command
+    traffic, traffic_note = None, "no PMC run recorded"
+    tpath = os.path.join(ROOT, "profiles", "traffic.json")
+    if os.path.exists(tpath):
+        with open(tpath) as f:
+            tj = json.load(f)
+        key = "%s_%s_%d" % (args.workload, "pruned" if pruned_mode else "exhaustive", args.docs)
+        if key in tj:
+            traffic = tj[key]["hbm_bytes_per_launch"]
+            traffic_note = tj[key]["note"]
+
+    def roof(kms):
+        k = float(np.mean(kms))
+        a = algo_bytes_full / (k * 1e-3) / 1e9 if k > 0 else 0.0
+        return {"mode": None, "achieved": round(a, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(a / HBM_PEAK_GBS, 4), "kernel_ms_avg": round(k, 4)}
+
+    other = roof(exh_kms if pruned_mode else prn_kms)
+    other["mode"] = "exhaustive" if pruned_mode else "pruned"
     total_units = n_q * args.steps * world  # one unit = one query evaluated on one segment
     value = total_units / elapsed
     k_ms = float(np.mean(kernel_ms)) if kernel_ms else 0.0
@@ -233,7 +277,8 @@ def main():
                          "all-gathered over RCCL and merged" % (args.docs // 1_000_000),
             "timed_region": "collect_segment (plan + H2D of query descriptors + scan + merge "
                             "kernels) -> all-gather -> merge_top_k -> D2H, synchronised per step",
-            "mode": "pruned" if args.pruned else "exhaustive",
+            "mode": "block-max pruned (block_wand_intersection semantics)" if pruned_mode
+                    else "exhaustive (every match scored)",
             "index_bytes": int(seg.idx_len),
             "index_build_s": round(t_gen, 2),
         },
@@ -243,12 +288,16 @@ def main():
             "peak": HBM_PEAK_GBS,
             "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 4),
-            "traffic": None,
+            "traffic": traffic,
             "kernel": "and_kernel" if args.workload == "and2" else args.workload + " scan kernels",
             "kernel_ms_avg": round(k_ms, 4),
             "algorithmic_bytes_per_launch": int(algo_bytes),
-            "matches_per_launch": int(matches),
+            "docs_scored_per_launch": int(matches),
+            "matches_per_launch": int(full_matches),
+            "traffic_note": traffic_note,
         },
+        "roofline_other_mode": other,
+        "pruned_equals_exhaustive": bool(mode_parity),
         "cpu_baseline": cpu,
         "p50_latency_ms": round(float(np.median(lat)) * 1e3, 4) if lat else None,
         "parity_checked_queries": parity_checked,

@@ -494,28 +494,25 @@ int tq_term_prepare(tq_segment *s, uint64_t postings_off, uint32_t postings_len,
     total = align16(total + bytes);
     return o;
   };
-  const size_t o_last = place(4 * (size_t)n_blocks);
-  const size_t o_mo = place(8 * (size_t)n_blocks);
+  const size_t o_rec = place(16 * (size_t)(n_blocks + 1));
   const size_t o_coarse = place(4 * coarse.size());
   const size_t o_tdocs = place(4 * (size_t)n_tail);
   const size_t o_ttfs = place(4 * (size_t)n_tail);
-  const size_t o_bpos = place(4 * (size_t)(n_blocks + 1));
   const size_t o_pboff = place(8 * pos_block_off.size());
   const size_t o_ptail = place(4 * pos_tail.size());
   const size_t o_pw = place(pos_widths.size());
   total += PAD;
   std::vector<uint8_t> hb(total, 0);
-  memcpy(hb.data() + o_last, b_last.data(), 4 * (size_t)n_blocks);
-  for (uint32_t i = 0; i < n_blocks; ++i) {
-    memcpy(hb.data() + o_mo + 8 * (size_t)i, &b_meta[i], 4);
-    memcpy(hb.data() + o_mo + 8 * (size_t)i + 4, &b_off[i], 4);
+  for (uint32_t i = 0; i <= n_blocks; ++i) {
+    const uint32_t r[4] = {i < n_blocks ? b_last[i] : TQ_TERMINATED, i < n_blocks ? b_meta[i] : 0u,
+                           i < n_blocks ? b_off[i] : 0u, block_pos[i]};
+    memcpy(hb.data() + o_rec + 16 * (size_t)i, r, 16);
   }
   memcpy(hb.data() + o_coarse, coarse.data(), 4 * coarse.size());
   if (n_tail) {
     memcpy(hb.data() + o_tdocs, tail_docs.data(), 4 * (size_t)n_tail);
     memcpy(hb.data() + o_ttfs, tail_tfs.data(), 4 * (size_t)n_tail);
   }
-  memcpy(hb.data() + o_bpos, block_pos.data(), 4 * (size_t)(n_blocks + 1));
   if (!pos_block_off.empty()) memcpy(hb.data() + o_pboff, pos_block_off.data(), 8 * pos_block_off.size());
   if (!pos_tail.empty()) memcpy(hb.data() + o_ptail, pos_tail.data(), 4 * pos_tail.size());
   if (!pos_widths.empty()) memcpy(hb.data() + o_pw, pos_widths.data(), pos_widths.size());
@@ -527,12 +524,10 @@ int tq_term_prepare(tq_segment *s, uint64_t postings_off, uint32_t postings_len,
     return fail(TQ_ERR_HIP, "term upload: %s", hipGetErrorString(ce));
   }
   TqdTerm dt{};
-  dt.last_doc = (const uint32_t *)(blob + o_last);
-  dt.mo = (const uint2 *)(blob + o_mo);
+  dt.rec = (const uint4 *)(blob + o_rec);
   dt.coarse = (const uint32_t *)(blob + o_coarse);
   dt.tail_docs = (const uint32_t *)(blob + o_tdocs);
   dt.tail_tfs = (const uint32_t *)(blob + o_ttfs);
-  dt.block_pos = (const uint32_t *)(blob + o_bpos);
   dt.pos_block_off = (const uint64_t *)(blob + o_pboff);
   dt.pos_widths = (const uint8_t *)(blob + o_pw);
   dt.pos_tail = (const uint32_t *)(blob + o_ptail);

@@ -19,14 +19,15 @@
 // A posting list on the device.  The skip list of src/postings/skip.rs:205-253 is unrolled from
 // its sequential form (running byte / position offsets made absolute) into structure-of-arrays
 // tables, so that any block can be located and decoded independently of the others:
-//   last_doc[j]  last doc id in block j (skip.rs `last_doc_in_block`)
-//   mo[j].x      meta: doc_bits | strict<<6 | tf_bits<<8 | block-max fieldnorm_id<<16 | block-max
+//   rec[j].x     last doc id in block j (skip.rs `last_doc_in_block`)
+//   rec[j].y     meta: doc_bits | strict<<6 | tf_bits<<8 | block-max fieldnorm_id<<16 | block-max
 //                tf code<<24 (skip.rs:16-43,205-253); 0xFFFFFFFF = the vint tail (pre-decoded)
-//   mo[j].y      offset of the bitpacked doc payload, relative to payload_base
+//   rec[j].z     offset of the bitpacked doc payload, relative to payload_base
+//   rec[j].w     index (in the positions stream) of the block's first position
+//                (one 16-byte record: a seek's last probe brings the whole entry)
 //   coarse[b]    first j with last_doc[j] >= (b << coarse_shift): O(1) `seek_block`
 struct TqdTermHead {  // what every kernel needs: fetched with scalar loads
-  const uint32_t *last_doc;   // n_blocks
-  const uint2 *mo;            // n_blocks
+  const uint4 *rec;           // n_blocks + 1 (the extra record carries the total position count)
   const uint32_t *coarse;     // ((max_doc-1) >> coarse_shift) + 2 entries
   // dense lists only (doc_freq >= max_doc / TQD_DENSE_RATIO), else null: membership bitmap with a
   // rank directory.  dense[d >> 5] = {bits of docs 32*(d>>5)..+31, number of postings before them}
@@ -39,7 +40,6 @@ struct TqdTermHead {  // what every kernel needs: fetched with scalar loads
   uint32_t coarse_shift;
 };
 struct TqdTerm : TqdTermHead {
-  const uint32_t *block_pos;  // n_blocks+1: index (in positions) of the first position of a block
   // positions stream (src/positions/reader.rs): per position-block absolute byte offset / width
   const uint64_t *pos_block_off;  // n_pos_blocks
   const uint8_t *pos_widths;      // n_pos_blocks

@@ -138,8 +138,7 @@ __device__ __forceinline__ X sload(const X *p) {
 }
 
 struct TermRef {
-  const uint32_t *last_doc;
-  const uint2 *mo;  // {meta, byte_off}
+  const uint4 *rec;  // {last_doc, meta, byte_off, first position index}
   const uint32_t *coarse;
   const uint2 *dense;
   const uint32_t *tail_docs;
@@ -153,8 +152,7 @@ struct TermRef {
 __device__ __forceinline__ TermRef load_term(const TqdTerm *terms, uint32_t handle) {
   const TqdTermHead h = sload(reinterpret_cast<const TqdTermHead *>(terms + handle));
   TermRef r;
-  r.last_doc = h.last_doc;
-  r.mo = h.mo;
+  r.rec = h.rec;
   r.coarse = h.coarse;
   r.dense = h.dense;
   r.tail_docs = h.tail_docs;
@@ -168,12 +166,16 @@ __device__ __forceinline__ TermRef load_term(const TqdTerm *terms, uint32_t hand
 }
 // j wave-uniform
 __device__ __forceinline__ uint32_t block_prev_last(const TermRef &t, uint32_t j) {
-  return j ? sload(t.last_doc + (j - 1u)) : 0u;
+  return j ? sload(&t.rec[j - 1u].x) : 0u;
 }
 __device__ __forceinline__ uint32_t block_first_possible(const TermRef &t, uint32_t j) {
-  return j ? sload(t.last_doc + (j - 1u)) + 1u : 0u;
+  return j ? sload(&t.rec[j - 1u].x) + 1u : 0u;
 }
-__device__ __forceinline__ uint2 uni_mo(const TermRef &t, uint32_t j) { return sload(t.mo + j); }
+__device__ __forceinline__ uint2 uni_mo(const TermRef &t, uint32_t j) {
+  const uint4 r = sload(t.rec + j);
+  return make_uint2(r.y, r.z);
+}
+__device__ __forceinline__ uint2 rec_mo(const uint4 &r) { return make_uint2(r.y, r.z); }
 
 struct Dec {
   uint32_t d0, d1;  // doc ids (TQD_TERMINATED padded)
@@ -314,7 +316,7 @@ __device__ __forceinline__ uint32_t lower_bound_block(const TermRef &t, uint32_t
     const uint32_t step = (n + 63u) >> 6;
     const uint32_t idx = lo + ((uint32_t)lane + 1u) * step - 1u;
     bool ge = true;
-    if (idx < lo + n) ge = t.last_doc[idx] >= target;
+    if (idx < lo + n) ge = t.rec[idx].x >= target;
     const uint64_t m = __ballot(ge);
     if (m == 0ull) {  // every probe (the last one sits on lo+n-1) is below the target
       lo += n;
@@ -337,7 +339,7 @@ __device__ __forceinline__ uint32_t seek_block(const TermRef &t, uint32_t doc) {
   uint32_t lo = t.coarse[b], hi = t.coarse[b + 1u];
   while (lo < hi) {
     const uint32_t mid = (lo + hi) >> 1;
-    if (t.last_doc[mid] >= doc)
+    if (t.rec[mid].x >= doc)
       hi = mid;
     else
       lo = mid + 1u;
@@ -533,7 +535,7 @@ struct AndLds {  // per wavefront
   uint32_t blk[128];   // doc ids of the block being searched
   uint32_t pay[272];   // staged bitpacked payload of the block being decoded (+ one spare row)
   uint32_t q1_doc[192], q1_tf[192], q1_rest[192];
-  uint32_t q2_doc[128], q2_tf[128], q2_loc[128], q2_norm[128];
+  uint32_t q2_doc[128], q2_tf[128], q2_loc[128];
   float cache[256];    // Bm25Weight.cache of the current query
 };
 
@@ -601,8 +603,9 @@ __device__ __forceinline__ uint32_t find_in_blocks(const uint8_t *idx, const Ter
   return at;
 }
 
-template <int KPL, bool USE_DPP>
+template <int KPL, bool PRUNE>
 __global__ __launch_bounds__(64) void and_kernel(TqkScanParams p) {
+  constexpr bool USE_DPP = true;
   __shared__ AndLds L;  // one wavefront per workgroup: finished chunks free their slot at once
   const int lane = (int)__lane_id();
   const uint32_t chunk = blockIdx.x;
@@ -641,7 +644,7 @@ __global__ __launch_bounds__(64) void and_kernel(TqkScanParams p) {
     w1 = sload(&Q->weight[1]);
     rest_after1 = 0.0f;
     for (uint32_t m = 2; m < nt; ++m) rest_after1 += sload(&Q->weight[m]);
-    prune = (sload(&Q->flags) & TQD_QF_PRUNE) != 0u;
+    prune = PRUNE && (sload(&Q->flags) & TQD_QF_PRUNE) != 0u;
     const uint32_t thr_index = sload(&Q->thr_index);
     slots = (prune && thr_index != 0xFFFFFFFFu) ? p.thr_slots + (size_t)thr_index * TQD_THR_SLOTS
                                                 : nullptr;
@@ -672,8 +675,7 @@ __global__ __launch_bounds__(64) void and_kernel(TqkScanParams p) {
       doc = L.q2_doc[base + lane];
       tf = L.q2_tf[base + lane];
       loc = L.q2_loc[base + lane];
-      norm = __uint_as_float(L.q2_norm[base + lane]);
-      if (!prune) norm = L.cache[fieldnorm_id(seg, doc)];
+      norm = L.cache[fieldnorm_id(seg, doc)];
     }
     float s = bm25(w_lead, norm, tf);
     {
@@ -682,9 +684,14 @@ __global__ __launch_bounds__(64) void and_kernel(TqkScanParams p) {
       if (t1.dense) {
         jb = loc >> 7;
         at = loc & 127u;
-        if (alive) mo = t1.mo[jb];
-      } else {
-        if (alive) mo = t1.mo[jb];
+      }
+      if (alive) mo = rec_mo(t1.rec[jb]);
+      if (prune && alive) {  // block_wand_intersection.rs:144-165
+        float ub = s + block_max_score(mo.x, w1, L.cache, t1.has_freq);
+        if (nt > 2u) ub = (ub + rest_after1) * 1.000001f;
+        alive = sortable(ub) >= thr;
+      }
+      if (!t1.dense) {
         at = find_in_blocks<USE_DPP>(idx, t1, jb, doc, alive, L, lane);
         alive = alive && at != NOT_FOUND;
       }
@@ -713,7 +720,7 @@ __global__ __launch_bounds__(64) void and_kernel(TqkScanParams p) {
         alive = jb < tr.n_blocks;
       }
       uint2 mo = make_uint2(0u, 0u);
-      if (alive) mo = tr.mo[jb];
+      if (alive) mo = rec_mo(tr.rec[jb]);
       if (prune && alive) {
         const float ub = (s + block_max_score(mo.x, w, L.cache, tr.has_freq) + rest) * 1.000001f;
         alive = sortable(ub) >= thr;
@@ -740,22 +747,17 @@ __global__ __launch_bounds__(64) void and_kernel(TqkScanParams p) {
     }
   };
 
-  // ---- stage B: exact leader score (pruned), locate in list 1, block-max filter (pruned)
+  // ---- stage B: locate in list 1.  Dense list: the bitmap answers membership, which is the
+  // strongest filter there is, so nothing else is looked at first.  Other lists: pruned mode
+  // scores the leader exactly (one fieldnorm gather) before paying for the seek.
   auto stageB = [&](uint32_t n) {
     const uint32_t base = q1n - n;
     q1n = base;
     bool alive = (uint32_t)lane < n;
     uint32_t doc = 0, tf = 0, loc = 0;
-    float norm = 0.0f, s = 0.0f;
     if (alive) {
       doc = L.q1_doc[base + lane];
       tf = L.q1_tf[base + lane];
-    }
-    if (prune && alive) {
-      const float rest_b = __uint_as_float(L.q1_rest[base + lane]);
-      norm = L.cache[fieldnorm_id(seg, doc)];
-      s = bm25(w_lead, norm, tf);
-      alive = sortable(s + rest_b) >= thr;
     }
     if (t1.dense) {
       if (alive) {
@@ -764,15 +766,16 @@ __global__ __launch_bounds__(64) void and_kernel(TqkScanParams p) {
         alive = (wd.x >> bit) & 1u;
         loc = wd.y + (uint32_t)__popc(wd.x & ((1u << bit) - 1u));
       }
-    } else if (alive) {
-      loc = seek_block(t1, doc);
-      alive = loc < t1.n_blocks;
-    }
-    if (prune && alive) {
-      const uint2 mo = t1.mo[t1.dense ? loc >> 7 : loc];
-      float ub = s + block_max_score(mo.x, w1, L.cache, t1.has_freq);
-      if (nt > 2u) ub = (ub + rest_after1) * 1.000001f;
-      alive = sortable(ub) >= thr;
+    } else {
+      if (prune && alive) {
+        const float rest_b = __uint_as_float(L.q1_rest[base + lane]);
+        const float s = bm25(w_lead, L.cache[fieldnorm_id(seg, doc)], tf);
+        alive = sortable(s + rest_b) >= thr;
+      }
+      if (alive) {
+        loc = seek_block(t1, doc);
+        alive = loc < t1.n_blocks;
+      }
     }
     const uint64_t m = __ballot(alive);
     if (m) {
@@ -782,7 +785,6 @@ __global__ __launch_bounds__(64) void and_kernel(TqkScanParams p) {
         L.q2_doc[pos] = doc;
         L.q2_tf[pos] = tf;
         L.q2_loc[pos] = loc;
-        L.q2_norm[pos] = __float_as_uint(norm);
       }
       wave_mem_fence();
       q2n += (uint32_t)__popcll(m);
@@ -824,12 +826,14 @@ __global__ __launch_bounds__(64) void and_kernel(TqkScanParams p) {
     uint2 mo_mine = make_uint2(0u, 0u);
     uint32_t prev_mine = 0;
     float rest_mine = 0.0f;  // bound of the other terms inside this leader block's doc range
+    uint32_t tfmin_mine = 1u;  // pruned mode: smallest tf that can still reach the threshold
     {
       uint32_t first = 0, last = 0;
       float ub = 0.0f;
       if (surv) {
-        last = lead.last_doc[i_mine];
-        mo_mine = lead.mo[i_mine];
+        const uint4 r = lead.rec[i_mine];
+        last = r.x;
+        mo_mine = make_uint2(r.y, r.z);
       }
       prev_mine = __shfl_up(last, 1, WAVE);
       if (lane == 0) prev_mine = block_prev_last(lead, i_base);
@@ -843,46 +847,75 @@ __global__ __launch_bounds__(64) void and_kernel(TqkScanParams p) {
           if (j0 >= tr.n_blocks) {
             surv = false;  // the list ends before this leader block starts
           } else if (prune) {
-            uint32_t j1 = seek_block(tr, last);
-            if (j1 >= tr.n_blocks) j1 = tr.n_blocks - 1u;
-            float bound = w;
-            if (j1 - j0 <= 3u) {
-              bound = block_max_score(tr.mo[j0].x, w, L.cache, tr.has_freq);
-              for (uint32_t j = j0 + 1u; j <= j1; ++j) {
-                const float b2 = block_max_score(tr.mo[j].x, w, L.cache, tr.has_freq);
-                bound = b2 > bound ? b2 : bound;
-              }
+            // block-max of list m over this leader block's doc range, if it spans <= 4 blocks
+            // (records j0..j0+3 share a cache line with the seek's last probe)
+            float bound = 0.0f;
+            bool closed = false;
+            for (uint32_t k = 0; k < 4u && !closed; ++k) {
+              const uint32_t j = j0 + k;
+              const uint4 r = tr.rec[j];
+              const float b2 = block_max_score(r.y, w, L.cache, tr.has_freq);
+              bound = b2 > bound ? b2 : bound;
+              closed = r.x >= last || j + 1u >= tr.n_blocks;
             }
+            if (!closed) bound = w;
             rest_mine = rest_mine + bound;
           }
         }
       }
       if (prune && nt > 2u) rest_mine *= 1.000001f;  // summed in another order than the scores
       if (prune && surv) surv = sortable(ub + rest_mine) >= thr;
+      if (prune && surv) {
+        // smallest tf whose tf-only score bound (norm replaced by its lower bound) can reach the
+        // threshold inside this block: stage A then compares integers instead of scoring 128 docs
+        auto pass = [&](uint32_t tfv) {
+          return sortable(bm25(w_lead, min_norm, tfv) + rest_mine) >= thr;
+        };
+        if (!pass(0xFFFFFFFFu)) {
+          surv = false;
+        } else {
+          uint32_t u = thr ^ ((thr >> 31) ? 0x80000000u : 0xFFFFFFFFu);  // sortable^-1
+          const float x = __uint_as_float(u) - rest_mine;
+          float est = 1.0f;
+          if (x > 0.0f) est = x < w_lead ? x * min_norm / (w_lead - x) : 4.0e9f;
+          uint32_t tfm = est >= 4.0e9f ? 0xFFFFFFF0u : (uint32_t)est;
+          if (tfm < 1u) tfm = 1u;
+          for (int it = 0; it < 4 && tfm > 1u && pass(tfm - 1u); ++it) --tfm;
+          if (tfm > 1u && pass(tfm - 1u)) tfm = 1u;  // estimate way off: keep everything
+          for (int it = 0; it < 4 && !pass(tfm); ++it) ++tfm;
+          tfmin_mine = tfm;
+        }
+      }
     }
     uint64_t todo = __ballot(surv);
 
-    // ---- stage A per surviving leader block
-    while (todo) {
-      const uint32_t b = (uint32_t)__builtin_ctzll(todo);
-      todo &= todo - 1ull;
-      const uint2 mo_l = make_uint2((uint32_t)__builtin_amdgcn_readlane((int)mo_mine.x, (int)b),
-                                    (uint32_t)__builtin_amdgcn_readlane((int)mo_mine.y, (int)b));
+    // ---- stage A per surviving leader block.  The payload loads of up to 4 blocks are issued
+    // back to back (one 16-byte load per lane and block) before the first one is unpacked: a
+    // wavefront walks its blocks serially, so memory-level parallelism has to come from here.
+    auto stageA = [&](uint32_t b, uint2 mo_l, const U4Unaligned &v) {
       const uint32_t prev_l = (uint32_t)__builtin_amdgcn_readlane((int)prev_mine, (int)b);
       uint32_t c0, c1, t0, t1f;
+      bool alive0, alive1;
+      uint32_t rest_bits = 0;
       if (mo_l.x == META_TAIL) {
         decode_docs<USE_DPP>(idx, lead, mo_l, prev_l, lane, c0, c1);
         decode_tfs(idx, lead, mo_l, lane, t0, t1f);
+        alive0 = c0 != TQD_TERMINATED;
+        alive1 = c1 != TQD_TERMINATED;
+        if (prune) {
+          rest_bits = (uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(rest_mine), (int)b);
+          const uint32_t tfmin = (uint32_t)__builtin_amdgcn_readlane((int)tfmin_mine, (int)b);
+          alive0 = alive0 && t0 >= tfmin;
+          alive1 = alive1 && t1f >= tfmin;
+        }
       } else {
         const uint32_t doc_bits = mo_l.x & 31u;
         const uint32_t strict = (mo_l.x >> 6) & 1u;
         const uint32_t tf_bits = lead.has_freq ? (mo_l.x >> 8) & 0xFFu : 0u;
         wave_mem_fence();
-        stage_payload(L.pay, idx + lead.payload_base + mo_l.y, 16u * (doc_bits + tf_bits), lane);
+        if (16u * (uint32_t)lane < 16u * (doc_bits + tf_bits))
+          *reinterpret_cast<uint4 *>(L.pay + 4 * lane) = make_uint4(v.x, v.y, v.z, v.w);
         wave_mem_fence();
-        uint32_t x0, x1;
-        unpack2_lds(L.pay, doc_bits, lane, x0, x1);
-        finish_docs<USE_DPP>(x0, x1, strict, prev_l, lane, c0, c1);
         if (lead.has_freq) {
           unpack2_lds(L.pay + 4u * doc_bits, tf_bits, lane, t0, t1f);
           t0 += strict;  // minus-one encoding is tied to the strict flag
@@ -891,19 +924,24 @@ __global__ __launch_bounds__(64) void and_kernel(TqkScanParams p) {
           t0 = 1u;
           t1f = 1u;
         }
-      }
-      bool alive0 = c0 != TQD_TERMINATED, alive1 = c1 != TQD_TERMINATED;
-      uint32_t rest_bits = 0;
-      if (prune) {
-        // tf-only bound first: no memory access (block_wand_intersection.rs:112-125 filters on
-        // the exact leader score; this is the same test with the norm replaced by its lower bound)
-        rest_bits = (uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(rest_mine), (int)b);
-        const float rest_b = __uint_as_float(rest_bits);
-        if (alive0) alive0 = sortable(bm25(w_lead, min_norm, t0) + rest_b) >= thr;
-        if (alive1) alive1 = sortable(bm25(w_lead, min_norm, t1f) + rest_b) >= thr;
+        alive0 = true;  // full blocks have no padding
+        alive1 = true;
+        if (prune) {
+          // tf-only bound first (block_wand_intersection.rs:112-125 filters on the exact leader
+          // score; this is the same test with the norm replaced by its lower bound, folded into
+          // an integer compare by the pre-filter).  Most blocks end here without a prefix sum.
+          rest_bits = (uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(rest_mine), (int)b);
+          const uint32_t tfmin = (uint32_t)__builtin_amdgcn_readlane((int)tfmin_mine, (int)b);
+          alive0 = t0 >= tfmin;
+          alive1 = t1f >= tfmin;
+          if (!(__ballot(alive0) | __ballot(alive1))) return;
+        }
+        uint32_t x0, x1;
+        unpack2_lds(L.pay, doc_bits, lane, x0, x1);
+        finish_docs<USE_DPP>(x0, x1, strict, prev_l, lane, c0, c1);
       }
       const uint64_t m0 = __ballot(alive0), m1 = __ballot(alive1);
-      if (!(m0 | m1)) continue;
+      if (!(m0 | m1)) return;
       const uint32_t n0 = (uint32_t)__popcll(m0);
       const uint32_t pos0 = q1n + mbcnt64(m0);
       const uint32_t pos1 = q1n + n0 + mbcnt64(m1);
@@ -924,6 +962,35 @@ __global__ __launch_bounds__(64) void and_kernel(TqkScanParams p) {
         stageB(64u);
         while (q2n >= 64u) stageC(64u);
       }
+    };
+    auto fetch = [&](uint32_t b, uint2 &mo_l, U4Unaligned &v) {
+      mo_l = make_uint2((uint32_t)__builtin_amdgcn_readlane((int)mo_mine.x, (int)b),
+                        (uint32_t)__builtin_amdgcn_readlane((int)mo_mine.y, (int)b));
+      v = U4Unaligned{0u, 0u, 0u, 0u};
+      if (mo_l.x != META_TAIL) {
+        const uint32_t tf_bits = lead.has_freq ? (mo_l.x >> 8) & 0xFFu : 0u;
+        const uint32_t o = 16u * (uint32_t)lane;
+        if (o < 16u * ((mo_l.x & 31u) + tf_bits))
+          v = *reinterpret_cast<const U4Unaligned *>(idx + lead.payload_base + mo_l.y + o);
+      }
+    };
+    while (todo) {
+      uint32_t bs[4] = {0u, 0u, 0u, 0u};
+      uint2 mos[4];
+      U4Unaligned vs[4];
+      uint32_t nb = 0;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        if (todo) {
+          bs[k] = (uint32_t)__builtin_ctzll(todo);
+          todo &= todo - 1ull;
+          fetch(bs[k], mos[k], vs[k]);
+          nb = (uint32_t)k + 1u;
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+        if ((uint32_t)k < nb) stageA(bs[k], mos[k], vs[k]);
     }
   }
   // final flush
@@ -1102,14 +1169,13 @@ __global__ __launch_bounds__(64) void phrase_kernel(TqkScanParams p) {
     const uint32_t h_lead = uni(Q->term[0]), h_drv = uni(Q->term[nt - 1]);
     const TermRef lead = load_term(p.terms, h_lead);
     const TermRef drv = load_term(p.terms, h_drv);
-    const uint32_t *lead_bpos = uni_ptr(p.terms[h_lead].block_pos);
 
     const uint32_t tl = t - q_tile_start;
     const uint32_t j0 = tl * TQD_PH_M;
     uint32_t j1 = j0 + TQD_PH_M;
     if (j1 > drv.n_blocks) j1 = drv.n_blocks;
     const uint32_t lo1 = block_first_possible(drv, j0);
-    const uint32_t hi = sload(drv.last_doc + (j1 - 1));
+    const uint32_t hi = sload(&drv.rec[j1 - 1].x);
     const uint32_t i0 = lower_bound_block(lead, lo1, lane);
     if (i0 >= lead.n_blocks) continue;
     uint32_t iL = lower_bound_block(lead, hi, lane);
@@ -1122,7 +1188,7 @@ __global__ __launch_bounds__(64) void phrase_kernel(TqkScanParams p) {
       if (sub_lo1 < lo1) sub_lo1 = lo1;
       uint32_t sub_hi = hi;
       if (ib != iL) {
-        const uint32_t l = sload(lead.last_doc + ib);
+        const uint32_t l = sload(&lead.rec[ib].x);
         if (l < sub_hi) sub_hi = l;
       }
       // ---- fill from the leader
@@ -1137,7 +1203,7 @@ __global__ __launch_bounds__(64) void phrase_kernel(TqkScanParams p) {
         if (ia + (uint32_t)c <= ib) {
           uint32_t e0, e1;
           const Dec d = decode_block<USE_DPP, true>(idx, lead, ia + (uint32_t)c, lane, &e0, &e1);
-          const uint32_t bp = uni(lead_bpos[ia + (uint32_t)c]);
+          const uint32_t bp = sload(&lead.rec[ia + (uint32_t)c].w);
           if (d.d0 >= sub_lo1 && d.d0 <= sub_hi) {
             L.cand_doc[ca] = d.d0;
             L.cand_cnt[ca] = 0u;
@@ -1159,7 +1225,6 @@ __global__ __launch_bounds__(64) void phrase_kernel(TqkScanParams p) {
       for (uint32_t m = 1; m < nt; ++m) {
         const uint32_t h_m = uni(Q->term[m]);
         const TermRef tr = load_term(p.terms, h_m);
-        const uint32_t *bpos = uni_ptr(p.terms[h_m].block_pos);
         uint32_t jb, jend;
         if (m + 1 == nt) {
           jb = j0;
@@ -1169,11 +1234,11 @@ __global__ __launch_bounds__(64) void phrase_kernel(TqkScanParams p) {
           jend = tr.n_blocks;
         }
         for (uint32_t j = jb; j < jend; ++j) {
-          if (sload(tr.last_doc + j) < sub_lo1) continue;
+          if (sload(&tr.rec[j].x) < sub_lo1) continue;
           if (block_first_possible(tr, j) > sub_hi) break;
           uint32_t e0, e1;
           const Dec d = decode_block<USE_DPP, true>(idx, tr, j, lane, &e0, &e1);
-          const uint32_t bp = uni(bpos[j]);
+          const uint32_t bp = sload(&tr.rec[j].w);
 #pragma unroll
           for (int e = 0; e < 2; ++e) {
             const uint32_t doc = e ? d.d1 : d.d0;
@@ -1379,11 +1444,11 @@ __global__ __launch_bounds__(64) void merge_segments_kernel(TqkSegMergeParams p)
 
 // =================================================================== launch wrappers
 template <int KPL>
-static void launch_and_t(const TqkScanParams &p, bool dpp, dim3 grid, dim3 block, hipStream_t st) {
-  if (dpp)
+static void launch_and_t(const TqkScanParams &p, dim3 grid, dim3 block, hipStream_t st) {
+  if (p.exhaustive)  // two instantiations: the pruning code costs registers the exhaustive scan
+    and_kernel<KPL, false><<<grid, block, 0, st>>>(p);  // does not need, and the kernel names
+  else                                                   // tell the modes apart in a profile
     and_kernel<KPL, true><<<grid, block, 0, st>>>(p);
-  else
-    and_kernel<KPL, false><<<grid, block, 0, st>>>(p);
 }
 template <int KPL>
 static void launch_or_t(const TqkScanParams &p, bool dpp, dim3 grid, dim3 block, hipStream_t st) {
@@ -1393,15 +1458,15 @@ static void launch_or_t(const TqkScanParams &p, bool dpp, dim3 grid, dim3 block,
     or_kernel<KPL, false><<<grid, block, 0, st>>>(p);
 }
 
-hipError_t tqk_launch_and(const TqkScanParams &p, int kpl, bool use_dpp, hipStream_t st) {
+hipError_t tqk_launch_and(const TqkScanParams &p, int kpl, bool /*use_dpp*/, hipStream_t st) {
   if (p.n_chunks == 0) return hipSuccess;
   const dim3 grid(p.n_chunks);
   const dim3 block(64);
   switch (kpl) {
-    case 1: launch_and_t<1>(p, use_dpp, grid, block, st); break;
-    case 2: launch_and_t<2>(p, use_dpp, grid, block, st); break;
-    case 4: launch_and_t<4>(p, use_dpp, grid, block, st); break;
-    default: launch_and_t<16>(p, use_dpp, grid, block, st); break;
+    case 1: launch_and_t<1>(p, grid, block, st); break;
+    case 2: launch_and_t<2>(p, grid, block, st); break;
+    case 4: launch_and_t<4>(p, grid, block, st); break;
+    default: launch_and_t<16>(p, grid, block, st); break;
   }
   return hipGetLastError();
 }
