@@ -8,6 +8,9 @@ kernel and the CPU restatement of tantivy's own executor timed beside it.
 
 One step = one pass of the hot path over one batch of queries (posting lists resident in HBM;
 query weights prepared outside the timed region, like `query.weight()` in tantivy's benches).
+The timed mode is the reference's own: block-max pruned top-k (block_wand_intersection).  The
+exhaustive mode (every match scored) is run beside it: every query's top-k must be identical in
+both (the run aborts otherwise) and its roofline is reported as `roofline_other_mode`.
 Roles of oracle/ here: (1) workload generator — it serialises the synthetic index into tantivy's
 byte format before anything is timed; (2) the cpu_baseline leg; (3) a post-hoc parity spot check.
 The timed GPU leg runs only tantivy_amd (HIP kernels + C ABI + C++ host mirror).

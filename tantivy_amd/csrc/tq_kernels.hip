@@ -1,10 +1,13 @@
 // tq_kernels.hip — gfx950 (CDNA4, wave64) kernels of the tantivy query-execution path.
 //
-// One wavefront decodes one 128-doc posting block: 64 lanes x 2 values, BitPacker4x funnel-shift
-// unpack, DPP prefix sum for the strict-delta doc ids.  AND = leader list hashed into a per-wave
-// LDS table, denser lists stream through and probe.  OR = 4096-doc window of f32 accumulators in
-// LDS per workgroup.  Top-k = per-wave sorted key registers, flushed as partial lists and merged
-// by a second kernel.  No MFMA: this is integer / byte work bound by HBM + LDS + VALU issue.
+// One wavefront decodes one 128-doc posting block: 64 lanes x 2 values, the bitpacked payload
+// staged in LDS by one 16-byte load per lane, BitPacker4x funnel-shift unpack, DPP prefix sum for
+// the strict-delta doc ids.  AND = leader-block tiles, candidates flowing through per-wave LDS
+// queues (decode -> locate in the other list -> verify + score), dense lists probed through a
+// bitmap + rank directory, block-max pruning against a threshold shared through atomic-max slots.
+// OR = 4096-doc window of f32 accumulators in LDS per workgroup.  Top-k = per-wave sorted key
+// registers, flushed as partial lists and merged by a second kernel.  No MFMA: this is integer /
+// byte work bound by vector-memory issue, LDS and VALU issue.
 //
 // Reference behaviour restated (file:line under the tantivy checkout):
 //   decode      src/postings/compression/mod.rs:105-150, block_segment_postings.rs:343-391
