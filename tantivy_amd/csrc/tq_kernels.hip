@@ -611,8 +611,8 @@ __global__ __launch_bounds__(64) void and_kernel(TqkScanParams p) {
   constexpr bool USE_DPP = true;
   __shared__ AndLds L;  // one wavefront per workgroup: finished chunks free their slot at once
   const int lane = (int)__lane_id();
-  const uint32_t chunk = blockIdx.x;
-  if (chunk >= p.n_chunks) return;
+  if (blockIdx.x >= p.n_chunks) return;
+  const uint32_t chunk = sload(p.chunk_perm + blockIdx.x);
   const uint32_t t_begin = sload(p.chunk_starts + chunk);
   const uint32_t t_end = sload(p.chunk_starts + chunk + 1u);
 

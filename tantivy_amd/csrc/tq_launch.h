@@ -11,6 +11,7 @@ struct TqkScanParams {
   const TqdQuery *queries;      // the launch group's queries, contiguous
   const uint32_t *tile_starts;  // n_queries + 1, non-decreasing
   const uint32_t *chunk_starts; // n_chunks + 1: first tile of every chunk
+  const uint32_t *chunk_perm;   // n_chunks: launch index -> chunk
   const float *caches;          // n_caches x 256
   uint64_t *partials;           // partial top-k lists, KPL*64 keys each
   unsigned long long *match_counter;
