@@ -151,10 +151,11 @@ int tq_decode_position_deltas(tq_segment *seg, tq_term_handle term, uint32_t *ou
 typedef struct tq_batch_stats {
   uint64_t algorithmic_bytes; /* sum len(postings_range) [+positions] + matches + 8k */
   uint64_t matches;           /* docs whose BM25 was evaluated (AND/phrase matches, OR union) */
-  float kernel_ms;            /* HIP-event time of the dominant (scan) kernel, last batch */
-  float total_ms;             /* HIP-event time of the whole batch on the stream */
+  float kernel_ms;            /* HIP-event time of the scan kernel(s), mean over the batches */
+  float total_ms;             /* ... of the whole batch on the stream: launched since the last call */
   uint32_t tiles;
   uint32_t chunks;
+  uint32_t batches_averaged;  /* how many batches kernel_ms / total_ms average (<= 16) */
 } tq_batch_stats;
 int tq_last_batch_stats(tq_segment *seg, tq_batch_stats *out);
 /* knobs: "exhaustive" (0/1, default 1: score every match; 0: block-max pruning as

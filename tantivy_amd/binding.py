@@ -29,7 +29,7 @@ class TqQuery(C.Structure):
 class TqBatchStats(C.Structure):
     _fields_ = [("algorithmic_bytes", C.c_uint64), ("matches", C.c_uint64),
                 ("kernel_ms", C.c_float), ("total_ms", C.c_float), ("tiles", C.c_uint32),
-                ("chunks", C.c_uint32)]
+                ("chunks", C.c_uint32), ("batches_averaged", C.c_uint32)]
 
 
 class TqhTermInfo(C.Structure):
@@ -291,7 +291,7 @@ class DeviceIndex:
         _check(lib().tq_last_batch_stats(self.segment_raw(segment_ord), C.byref(st)))
         return {"algorithmic_bytes": st.algorithmic_bytes, "matches": st.matches,
                 "kernel_ms": st.kernel_ms, "total_ms": st.total_ms, "tiles": st.tiles,
-                "chunks": st.chunks}
+                "chunks": st.chunks, "batches_averaged": st.batches_averaged}
 
     def raw_search(self, queries, weights, cache, k, segment_ord=0, stride=None):
         """Direct tq_search_batch: queries = list of (mode, [term ids], offsets|None);

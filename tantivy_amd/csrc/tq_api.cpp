@@ -9,6 +9,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
@@ -155,8 +156,13 @@ struct tq_segment {
   // batch scratch
   DevBuf d_stage, d_partials, d_out_scores, d_out_docs, d_out_counts, d_misc, d_thr;
   PinnedBuf h_stage, h_out;
-  hipEvent_t ev_stage_done = nullptr, ev_t0 = nullptr, ev_t1 = nullptr, ev_k0 = nullptr,
-             ev_k1 = nullptr;
+  // timing: a ring of event quadruples, one per batch, so that pipelined batches (no host sync
+  // between them) can all be timed; tq_last_batch_stats averages the batches since its last call
+  static constexpr int kTimingRing = 16;
+  hipEvent_t ev_stage_done = nullptr;
+  hipEvent_t ev_t0[kTimingRing] = {}, ev_t1[kTimingRing] = {}, ev_k0[kTimingRing] = {},
+             ev_k1[kTimingRing] = {};
+  uint64_t batches_timed = 0, batches_reported = 0;
   bool stage_in_flight = false;
   unsigned long long *d_match_counter = nullptr;
   Options opt;
@@ -276,10 +282,12 @@ int tq_segment_upload(tq_ctx *ctx, int device, uint32_t max_doc, const uint8_t *
   if (rc == TQ_OK) {
     hipError_t e = hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&s->ev_stage_done, hipEventDisableTiming);
-    if (e == hipSuccess) e = hipEventCreate(&s->ev_t0);
-    if (e == hipSuccess) e = hipEventCreate(&s->ev_t1);
-    if (e == hipSuccess) e = hipEventCreate(&s->ev_k0);
-    if (e == hipSuccess) e = hipEventCreate(&s->ev_k1);
+    for (int i = 0; i < tq_segment::kTimingRing; ++i) {
+      if (e == hipSuccess) e = hipEventCreate(&s->ev_t0[i]);
+      if (e == hipSuccess) e = hipEventCreate(&s->ev_t1[i]);
+      if (e == hipSuccess) e = hipEventCreate(&s->ev_k0[i]);
+      if (e == hipSuccess) e = hipEventCreate(&s->ev_k1[i]);
+    }
     if (e == hipSuccess) e = hipMalloc((void **)&s->d_match_counter, sizeof(unsigned long long));
     if (e != hipSuccess) rc = fail(TQ_ERR_HIP, "segment setup: %s", hipGetErrorString(e));
   }
@@ -324,8 +332,10 @@ void tq_segment_free(tq_segment *s) {
   s->d_thr.release();
   s->h_stage.release();
   s->h_out.release();
-  for (hipEvent_t ev : {s->ev_stage_done, s->ev_t0, s->ev_t1, s->ev_k0, s->ev_k1})
-    if (ev) (void)hipEventDestroy(ev);
+  if (s->ev_stage_done) (void)hipEventDestroy(s->ev_stage_done);
+  for (int i = 0; i < tq_segment::kTimingRing; ++i)
+    for (hipEvent_t ev : {s->ev_t0[i], s->ev_t1[i], s->ev_k0[i], s->ev_k1[i]})
+      if (ev) (void)hipEventDestroy(ev);
   if (s->stream) (void)hipStreamDestroy(s->stream);
   delete s;
 }
@@ -612,6 +622,8 @@ int tq_search_batch_device(tq_segment *s, const tq_query *queries, uint32_t n_qu
   if (!s || (!queries && n_queries) || !d_out_scores || !d_out_docs || !d_out_counts)
     return fail(TQ_ERR_INVALID, "tq_search_batch: null argument");
   if (n_queries == 0) return TQ_OK;
+  static const bool trace = getenv("TQ_TRACE") != nullptr;
+  const auto tr0 = std::chrono::steady_clock::now();
   HIP_TRY(hipSetDevice(s->device));
   hipStream_t st = hip_stream ? (hipStream_t)hip_stream : s->stream;
   int rc = sync_terms(s, st);
@@ -881,6 +893,7 @@ int tq_search_batch_device(tq_segment *s, const tq_query *queries, uint32_t n_qu
     g.o_perm = stage;
     stage += g.chunk_perm.size() * sizeof(uint32_t);
   }
+  const auto tr1 = std::chrono::steady_clock::now();
   if (s->stage_in_flight) {
     HIP_TRY(hipEventSynchronize(s->ev_stage_done));
     s->stage_in_flight = false;
@@ -899,7 +912,9 @@ int tq_search_batch_device(tq_segment *s, const tq_query *queries, uint32_t n_qu
     memcpy(hs + g.o_chunks, g.chunk_starts.data(), g.chunk_starts.size() * sizeof(uint32_t));
     memcpy(hs + g.o_perm, g.chunk_perm.data(), g.chunk_perm.size() * sizeof(uint32_t));
   }
-  if (s->opt.timing) HIP_TRY(hipEventRecord(s->ev_t0, st));
+  const auto tr2 = std::chrono::steady_clock::now();
+  const int slot = (int)(s->batches_timed % tq_segment::kTimingRing);
+  if (s->opt.timing) HIP_TRY(hipEventRecord(s->ev_t0[slot], st));
   HIP_TRY(hipMemcpyAsync(s->d_stage.p, hs, stage, hipMemcpyHostToDevice, st));
   HIP_TRY(hipEventRecord(s->ev_stage_done, st));
   s->stage_in_flight = true;
@@ -913,7 +928,7 @@ int tq_search_batch_device(tq_segment *s, const tq_query *queries, uint32_t n_qu
 
   // ---- launch
   const uint8_t *ds = (const uint8_t *)s->d_stage.p;
-  if (s->opt.timing) HIP_TRY(hipEventRecord(s->ev_k0, st));
+  if (s->opt.timing) HIP_TRY(hipEventRecord(s->ev_k0[slot], st));
   uint32_t tiles_total = 0, chunks_total = 0;
   for (int gi = 0; gi < 3; ++gi) {
     Group &g = groups[gi];
@@ -945,7 +960,7 @@ int tq_search_batch_device(tq_segment *s, const tq_query *queries, uint32_t n_qu
       e = tqk_launch_phrase(p, g.kpl, s->opt.use_dpp != 0, st);
     if (e != hipSuccess) return fail(TQ_ERR_HIP, "scan kernel launch: %s", hipGetErrorString(e));
   }
-  if (s->opt.timing) HIP_TRY(hipEventRecord(s->ev_k1, st));
+  if (s->opt.timing) HIP_TRY(hipEventRecord(s->ev_k1[slot], st));
   for (int gi = 0; gi < 3; ++gi) {
     Group &g = groups[gi];
     if (g.queries.empty()) continue;
@@ -961,7 +976,16 @@ int tq_search_batch_device(tq_segment *s, const tq_query *queries, uint32_t n_qu
     hipError_t e = tqk_launch_merge(m, g.kpl, st);
     if (e != hipSuccess) return fail(TQ_ERR_HIP, "merge kernel launch: %s", hipGetErrorString(e));
   }
-  if (s->opt.timing) HIP_TRY(hipEventRecord(s->ev_t1, st));
+  if (s->opt.timing) {
+    HIP_TRY(hipEventRecord(s->ev_t1[slot], st));
+    ++s->batches_timed;
+  }
+  if (trace) {
+    const auto tr3 = std::chrono::steady_clock::now();
+    auto us = [](auto a, auto b) { return (long)std::chrono::duration_cast<std::chrono::microseconds>(b - a).count(); };
+    fprintf(stderr, "[tq] plan %ld us, stage fill %ld us, enqueue %ld us, stage bytes %zu\n",
+            us(tr0, tr1), us(tr1, tr2), us(tr2, tr3), stage);
+  }
   s->stats.algorithmic_bytes = algo_bytes;
   s->stats.tiles = tiles_total;
   s->stats.chunks = chunks_total;
@@ -1003,14 +1027,36 @@ int tq_last_batch_stats(tq_segment *s, tq_batch_stats *out) {
   HIP_TRY(hipSetDevice(s->device));
   if (s->stats_pending) {
     HIP_TRY(hipStreamSynchronize(s->stream));
+    if (s->opt.timing && s->batches_timed)  // batches may run on a caller's stream
+      HIP_TRY(hipEventSynchronize(
+          s->ev_t1[(s->batches_timed - 1) % tq_segment::kTimingRing]));
     unsigned long long m = 0;
     HIP_TRY(hipMemcpy(&m, s->d_match_counter, sizeof m, hipMemcpyDeviceToHost));
     s->stats.matches = m;
     s->stats.algorithmic_bytes += m;  // 1 fieldnorm byte per scored doc
     if (s->opt.timing) {
       float ms = 0;
-      if (hipEventElapsedTime(&ms, s->ev_k0, s->ev_k1) == hipSuccess) s->stats.kernel_ms = ms;
-      if (hipEventElapsedTime(&ms, s->ev_t0, s->ev_t1) == hipSuccess) s->stats.total_ms = ms;
+      uint64_t first = s->batches_reported;
+      if (s->batches_timed - first > (uint64_t)tq_segment::kTimingRing)
+        first = s->batches_timed - tq_segment::kTimingRing;
+      double k_sum = 0, t_sum = 0;
+      uint32_t n = 0;
+      for (uint64_t b = first; b < s->batches_timed; ++b) {
+        const int i = (int)(b % tq_segment::kTimingRing);
+        float km = 0, tm = 0;
+        if (hipEventElapsedTime(&km, s->ev_k0[i], s->ev_k1[i]) == hipSuccess &&
+            hipEventElapsedTime(&tm, s->ev_t0[i], s->ev_t1[i]) == hipSuccess) {
+          k_sum += km;
+          t_sum += tm;
+          ++n;
+        }
+      }
+      s->batches_reported = s->batches_timed;
+      if (n) {
+        s->stats.kernel_ms = (float)(k_sum / n);
+        s->stats.total_ms = (float)(t_sum / n);
+      }
+      s->stats.batches_averaged = n;
     }
     s->stats_pending = false;
   }
