@@ -630,10 +630,14 @@ int tq_search_batch_device(tq_segment *s, const tq_query *queries, uint32_t n_qu
   if (rc != TQ_OK) return rc;
 
   // ---- plan
-  Group groups[3];
+  // launch groups: AND queries whose non-leader lists all have a bitmap run a leaner kernel
+  // instantiation (no seek / block-search code: fewer registers, less LDS, more waves per CU)
+  constexpr int kGroups = 4, kAndGeneral = 3;
+  Group groups[kGroups];
   groups[0].mode = TQ_MODE_AND;
   groups[1].mode = TQ_MODE_OR;
   groups[2].mode = TQ_MODE_PHRASE;
+  groups[kAndGeneral].mode = TQ_MODE_AND;
   std::vector<const float *> caches;
   uint64_t algo_bytes = 0;
   uint32_t n_thr_rows = 0;
@@ -672,6 +676,7 @@ int tq_search_batch_device(tq_segment *s, const tq_query *queries, uint32_t n_qu
     }
     int mode = q.mode;
     uint32_t n_tiles = 0, tile_cost = 1;
+    bool all_dense = true;
     uint64_t qbytes = 8ull * q.k;
     if (mode == TQ_MODE_AND || mode == TQ_MODE_PHRASE) {
       if (!any_absent) {
@@ -707,6 +712,7 @@ int tq_search_batch_device(tq_segment *s, const tq_query *queries, uint32_t n_qu
           for (uint32_t i = 1; i < q.n_terms; ++i) {
             const TermHost &th = s->terms[dq.term[i]];
             if (th.dense_blob && s->opt.use_dense) continue;
+            all_dense = false;
             c_lb += 2u * std::min<uint32_t>(128u, (th.n_blocks + lead_blocks - 1) / lead_blocks);
           }
           dq.tile_blocks = std::max<uint32_t>(1u, TQD_AND_TILE / c_lb);
@@ -744,7 +750,7 @@ int tq_search_batch_device(tq_segment *s, const tq_query *queries, uint32_t n_qu
     }
     algo_bytes += qbytes;
     dq.n_tiles = n_tiles;
-    Group &g = groups[mode];
+    Group &g = groups[(mode == TQ_MODE_AND && !all_dense) ? kAndGeneral : mode];
     dq.mode = (uint32_t)mode;
     g.queries.push_back(dq);
     g.tile_cost.push_back(tile_cost);
@@ -856,8 +862,8 @@ int tq_search_batch_device(tq_segment *s, const tq_query *queries, uint32_t n_qu
     }
   }
   // partial lists of all groups share one buffer; its stride is per group (kpl*64 keys)
-  size_t part_off_bytes[3] = {0, 0, 0};
-  for (int gi = 0; gi < 3; ++gi) {
+  size_t part_off_bytes[kGroups] = {0, 0, 0, 0};
+  for (int gi = 0; gi < kGroups; ++gi) {
     Group &g = groups[gi];
     part_off_bytes[gi] = partial_bytes;
     uint32_t parts = 0;
@@ -930,7 +936,7 @@ int tq_search_batch_device(tq_segment *s, const tq_query *queries, uint32_t n_qu
   const uint8_t *ds = (const uint8_t *)s->d_stage.p;
   if (s->opt.timing) HIP_TRY(hipEventRecord(s->ev_k0[slot], st));
   uint32_t tiles_total = 0, chunks_total = 0;
-  for (int gi = 0; gi < 3; ++gi) {
+  for (int gi = 0; gi < kGroups; ++gi) {
     Group &g = groups[gi];
     if (g.queries.empty()) continue;
     TqkScanParams p{};
@@ -949,6 +955,7 @@ int tq_search_batch_device(tq_segment *s, const tq_query *queries, uint32_t n_qu
     p.n_chunks = g.n_chunks;
     p.exhaustive = (uint32_t)s->opt.exhaustive;
     p.use_dense = (uint32_t)s->opt.use_dense;
+    p.all_dense = gi == 0 ? 1u : 0u;
     tiles_total += g.total_tiles;
     chunks_total += g.n_chunks;
     hipError_t e = hipSuccess;
@@ -961,7 +968,7 @@ int tq_search_batch_device(tq_segment *s, const tq_query *queries, uint32_t n_qu
     if (e != hipSuccess) return fail(TQ_ERR_HIP, "scan kernel launch: %s", hipGetErrorString(e));
   }
   if (s->opt.timing) HIP_TRY(hipEventRecord(s->ev_k1[slot], st));
-  for (int gi = 0; gi < 3; ++gi) {
+  for (int gi = 0; gi < kGroups; ++gi) {
     Group &g = groups[gi];
     if (g.queries.empty()) continue;
     TqkMergeParams m{};
@@ -1035,7 +1042,6 @@ int tq_last_batch_stats(tq_segment *s, tq_batch_stats *out) {
     s->stats.matches = m;
     s->stats.algorithmic_bytes += m;  // 1 fieldnorm byte per scored doc
     if (s->opt.timing) {
-      float ms = 0;
       uint64_t first = s->batches_reported;
       if (s->batches_timed - first > (uint64_t)tq_segment::kTimingRing)
         first = s->batches_timed - tq_segment::kTimingRing;

@@ -534,82 +534,133 @@ __device__ __forceinline__ uint32_t mbcnt64(uint64_t m) {
 }
 constexpr uint32_t NOT_FOUND = 0xFFFFFFFFu;
 
-struct AndLds {  // per wavefront
-  uint32_t blk[128];   // doc ids of the block being searched
-  uint32_t pay[272];   // staged bitpacked payload of the block being decoded (+ one spare row)
-  uint32_t q1_doc[192], q1_tf[192], q1_rest[192];
-  uint32_t q2_doc[128], q2_tf[128], q2_loc[128];
+template <bool DENSE>
+struct AndLdsT {  // per wavefront
+  // staged bitpacked payload: one leader block (stage A, <= 1008 B) or four 512-byte regions
+  // (find_in_blocks, not needed when every other list has a bitmap), + one spare 16-byte row
+  uint32_t pay[DENSE ? 260 : 516];
+  // queue 1 holds < 64 leftovers + one block (128), queue 2 < 64 leftovers + one batch (64):
+  // sized to the entry so that the lean instantiation fits 32 wavefronts per CU (5120 B each)
+  uint32_t q1_doc[191], q1_tf[191];
+  uint32_t q2_doc[127], q2_tf[127], q2_loc[127];
   float cache[256];    // Bm25Weight.cache of the current query
 };
 
-// doc ids of block j of `tr` through the LDS staging buffer (one vector load)
-template <bool USE_DPP>
-__device__ __forceinline__ void decode_docs_staged(const uint8_t *idx, const TermRef &tr, uint2 mo,
-                                                   uint32_t prev, uint32_t *pay, int lane,
-                                                   uint32_t &d0, uint32_t &d1) {
-  if (mo.x == META_TAIL) {
-    decode_docs<USE_DPP>(idx, tr, mo, prev, lane, d0, d1);
-    return;
-  }
-  const uint32_t doc_bits = mo.x & 31u;
-  wave_mem_fence();
-  stage_payload(pay, idx + tr.payload_base + mo.y, 16u * doc_bits, lane);
-  wave_mem_fence();
-  uint32_t x0, x1;
-  unpack2_lds(pay, doc_bits, lane, x0, x1);
-  finish_docs<USE_DPP>(x0, x1, (mo.x >> 6) & 1u, prev, lane, d0, d1);
-}
-
 // Where is `doc` inside block jb of list tr?  (lane-private jb/doc; lanes with !alive idle.)
-// The distinct blocks are decoded once each, ascending; few candidates in a block are broadcast
-// and compared, many binary-search the block in LDS (search_block, block_search.rs:38-76).
+// Up to FOUR distinct blocks are decoded per step, one per 16-lane row: a lane unpacks 8
+// consecutive values (registers 2r, 2r+1 of all four bit streams: two ds_read_b128 each), sums
+// them locally and the row finishes the prefix sum with 4 DPP row shifts.  The doc ids replace the
+// payload in LDS and every candidate binary-searches its block (search_block,
+// block_search.rs:38-76).  Seeks into sparse lists land in many different blocks; decoding them
+// one per wave-step (as stage A does for the leader, where all 128 docs are wanted) would leave
+// this path with a quarter of the throughput.
 template <bool USE_DPP>
 __device__ __forceinline__ uint32_t find_in_blocks(const uint8_t *idx, const TermRef &tr,
                                                    uint32_t jb, uint32_t doc, bool alive,
-                                                   AndLds &L, int lane) {
+                                                   AndLdsT<false> &L, int lane) {
   uint32_t at = NOT_FOUND;
   uint64_t pend = __ballot(alive);
+  const uint32_t row = (uint32_t)lane >> 4, l16 = (uint32_t)lane & 15u;
+  uint32_t *const P = L.pay;  // 4 regions of 128 words: payload, then the decoded doc ids
   while (pend) {
-    const uint32_t l = (uint32_t)__builtin_ctzll(pend);
-    const uint32_t j = (uint32_t)__builtin_amdgcn_readlane((int)jb, (int)l);
-    const bool in = alive && jb == j;
-    uint64_t m = __ballot(in);
-    pend &= ~m;
-    uint32_t x0, x1;
-    decode_docs_staged<USE_DPP>(idx, tr, uni_mo(tr, j), block_prev_last(tr, j), L.pay, lane, x0, x1);
-    if (__popcll(m) <= 4) {
-      while (m) {
-        const uint32_t lc = (uint32_t)__builtin_ctzll(m);
-        m &= m - 1ull;
-        const uint32_t c = (uint32_t)__builtin_amdgcn_readlane((int)doc, (int)lc);
-        const uint64_t h0 = __ballot(x0 == c), h1 = __ballot(x1 == c);
-        uint32_t a = NOT_FOUND;
-        if (h0)
-          a = 2u * (uint32_t)__builtin_ctzll(h0);
-        else if (h1)
-          a = 2u * (uint32_t)__builtin_ctzll(h1) + 1u;
-        if ((uint32_t)lane == lc) at = a;
-      }
-    } else {
-      wave_mem_fence();
-      *reinterpret_cast<uint2 *>(L.blk + 2 * lane) = make_uint2(x0, x1);
-      wave_mem_fence();
-      if (in) {
-        uint32_t pos = 0;
+    // ---- up to four distinct blocks among the pending candidates
+    uint32_t js[4] = {0u, 0u, 0u, 0u};
+    uint32_t gid = 4u, n_groups = 0;
 #pragma unroll
-        for (uint32_t step = 64u; step > 0u; step >>= 1)
-          if (L.blk[pos + step - 1u] < doc) pos += step;
-        at = L.blk[pos] == doc ? pos : NOT_FOUND;
+    for (uint32_t g = 0; g < 4u; ++g) {
+      if (pend) {
+        const uint32_t l = (uint32_t)__builtin_ctzll(pend);
+        js[g] = (uint32_t)__builtin_amdgcn_readlane((int)jb, (int)l);
+        const bool in = alive && gid == 4u && jb == js[g];
+        if (in) gid = g;
+        pend &= ~__ballot(in);
+        n_groups = g + 1u;
       }
+    }
+    // ---- row r decodes block js[r]
+    const uint32_t my_j = row == 0u ? js[0] : (row == 1u ? js[1] : (row == 2u ? js[2] : js[3]));
+    const bool row_on = row < n_groups;
+    uint4 rec = make_uint4(0u, META_TAIL, 0u, 0u);
+    uint32_t prev = 0;
+    if (row_on) {
+      rec = tr.rec[my_j];
+      if (my_j) prev = tr.rec[my_j - 1u].x;
+    }
+    const bool is_tail = rec.y == META_TAIL;
+    const uint32_t b = is_tail ? 0u : rec.y & 31u;
+    const uint32_t strict = is_tail ? 0u : (rec.y >> 6) & 1u;
+    wave_mem_fence();
+    if (row_on && !is_tail) {
+      const uint8_t *src = idx + tr.payload_base + rec.z + 16u * l16;
+      if (16u * l16 < 16u * b) {
+        const U4Unaligned v = *reinterpret_cast<const U4Unaligned *>(src);
+        *reinterpret_cast<uint4 *>(P + row * 128u + 4u * l16) = make_uint4(v.x, v.y, v.z, v.w);
+      }
+      if (256u + 16u * l16 < 16u * b) {
+        const U4Unaligned v = *reinterpret_cast<const U4Unaligned *>(src + 256);
+        *reinterpret_cast<uint4 *>(P + row * 128u + 64u + 4u * l16) =
+            make_uint4(v.x, v.y, v.z, v.w);
+      }
+    }
+    wave_mem_fence();
+    uint32_t d[8];
+    {
+      const uint32_t mask = (1u << b) - 1u;  // b <= 31 for doc ids (skip.rs:16-22)
+#pragma unroll
+      for (uint32_t kk = 0; kk < 2u; ++kk) {
+        const uint32_t bitpos = (2u * l16 + kk) * b;
+        const uint32_t w = bitpos >> 5, sh = bitpos & 31u;
+        const uint4 lo = *reinterpret_cast<const uint4 *>(P + row * 128u + 4u * w);
+        const uint4 hi = *reinterpret_cast<const uint4 *>(P + row * 128u + 4u * w + 4u);
+        d[4 * kk + 0] = (__funnelshift_r(lo.x, hi.x, sh) & mask) + strict;
+        d[4 * kk + 1] = (__funnelshift_r(lo.y, hi.y, sh) & mask) + strict;
+        d[4 * kk + 2] = (__funnelshift_r(lo.z, hi.z, sh) & mask) + strict;
+        d[4 * kk + 3] = (__funnelshift_r(lo.w, hi.w, sh) & mask) + strict;
+      }
+    }
+#pragma unroll
+    for (int e = 1; e < 8; ++e) d[e] += d[e - 1];
+    uint32_t incl = d[7];
+    incl += dpp_get<0x111, 0xF>(incl);  // row_shr:1 .. 8: inclusive scan inside the 16-lane row
+    incl += dpp_get<0x112, 0xF>(incl);
+    incl += dpp_get<0x114, 0xF>(incl);
+    incl += dpp_get<0x118, 0xF>(incl);
+    // compression/mod.rs:36-39,112-121: offset 0 <=> None <=> seed u32::MAX (wrapping)
+    const uint32_t base = ((strict && prev == 0u) ? 0xFFFFFFFFu : prev) + (incl - d[7]);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) d[e] += base;
+    if (__ballot(row_on && is_tail)) {  // the pre-decoded vint tail of the list
+      if (row_on && is_tail) {
+#pragma unroll
+        for (uint32_t e = 0; e < 8u; ++e) {
+          const uint32_t i = 8u * l16 + e;
+          d[e] = i < tr.n_tail ? tr.tail_docs[i] : TQD_TERMINATED;
+        }
+      }
+    }
+    wave_mem_fence();  // every lane has read its payload words: the doc ids may overwrite them
+    if (row_on) {
+      *reinterpret_cast<uint4 *>(P + row * 128u + 8u * l16) = make_uint4(d[0], d[1], d[2], d[3]);
+      *reinterpret_cast<uint4 *>(P + row * 128u + 8u * l16 + 4u) =
+          make_uint4(d[4], d[5], d[6], d[7]);
+    }
+    wave_mem_fence();
+    if (gid < 4u) {
+      const uint32_t *blk = P + gid * 128u;
+      uint32_t pos = 0;
+#pragma unroll
+      for (uint32_t step = 64u; step > 0u; step >>= 1)
+        if (blk[pos + step - 1u] < doc) pos += step;
+      at = blk[pos] == doc ? pos : NOT_FOUND;
     }
   }
   return at;
 }
 
-template <int KPL, bool PRUNE>
+template <int KPL, bool PRUNE, bool DENSE>
 __global__ __launch_bounds__(64) void and_kernel(TqkScanParams p) {
   constexpr bool USE_DPP = true;
-  __shared__ AndLds L;  // one wavefront per workgroup: finished chunks free their slot at once
+  __shared__ AndLdsT<DENSE> L;  // one wavefront per workgroup: finished chunks free their slot at once
   const int lane = (int)__lane_id();
   if (blockIdx.x >= p.n_chunks) return;
   const uint32_t chunk = sload(p.chunk_perm + blockIdx.x);
@@ -684,7 +735,7 @@ __global__ __launch_bounds__(64) void and_kernel(TqkScanParams p) {
     {
       uint32_t jb = loc, at = NOT_FOUND;
       uint2 mo = make_uint2(0u, 0u);
-      if (t1.dense) {
+      if (DENSE || t1.dense) {
         jb = loc >> 7;
         at = loc & 127u;
       }
@@ -694,9 +745,11 @@ __global__ __launch_bounds__(64) void and_kernel(TqkScanParams p) {
         if (nt > 2u) ub = (ub + rest_after1) * 1.000001f;
         alive = sortable(ub) >= thr;
       }
-      if (!t1.dense) {
-        at = find_in_blocks<USE_DPP>(idx, t1, jb, doc, alive, L, lane);
-        alive = alive && at != NOT_FOUND;
+      if constexpr (!DENSE) {
+        if (!t1.dense) {
+          at = find_in_blocks<USE_DPP>(idx, t1, jb, doc, alive, L, lane);
+          alive = alive && at != NOT_FOUND;
+        }
       }
       // leader first, then ascending doc freq (block_wand_intersection.rs:144-165)
       if (alive) s = s + bm25(w1, norm, block_tf_at(idx, t1, mo, at));
@@ -709,7 +762,7 @@ __global__ __launch_bounds__(64) void and_kernel(TqkScanParams p) {
       rest -= w;
       if (rest < 0.0f) rest = 0.0f;
       uint32_t jb = 0, at = NOT_FOUND;
-      if (tr.dense) {
+      if (DENSE || tr.dense) {
         if (alive) {
           const uint2 wd = tr.dense[doc >> 5];
           const uint32_t bit = doc & 31u;
@@ -728,9 +781,11 @@ __global__ __launch_bounds__(64) void and_kernel(TqkScanParams p) {
         const float ub = (s + block_max_score(mo.x, w, L.cache, tr.has_freq) + rest) * 1.000001f;
         alive = sortable(ub) >= thr;
       }
-      if (!tr.dense) {
-        at = find_in_blocks<USE_DPP>(idx, tr, jb, doc, alive, L, lane);
-        alive = alive && at != NOT_FOUND;
+      if constexpr (!DENSE) {
+        if (!tr.dense) {
+          at = find_in_blocks<USE_DPP>(idx, tr, jb, doc, alive, L, lane);
+          alive = alive && at != NOT_FOUND;
+        }
       }
       if (alive) s = s + bm25(w, norm, block_tf_at(idx, tr, mo, at));
     }
@@ -762,7 +817,7 @@ __global__ __launch_bounds__(64) void and_kernel(TqkScanParams p) {
       doc = L.q1_doc[base + lane];
       tf = L.q1_tf[base + lane];
     }
-    if (t1.dense) {
+    if (DENSE || t1.dense) {
       if (alive) {
         const uint2 wd = t1.dense[doc >> 5];
         const uint32_t bit = doc & 31u;
@@ -770,10 +825,9 @@ __global__ __launch_bounds__(64) void and_kernel(TqkScanParams p) {
         loc = wd.y + (uint32_t)__popc(wd.x & ((1u << bit) - 1u));
       }
     } else {
-      if (prune && alive) {
-        const float rest_b = __uint_as_float(L.q1_rest[base + lane]);
+      if (prune && alive) {  // the other lists can add at most their weights
         const float s = bm25(w_lead, L.cache[fieldnorm_id(seg, doc)], tf);
-        alive = sortable(s + rest_b) >= thr;
+        alive = sortable((s + (w1 + rest_after1)) * 1.000001f) >= thr;
       }
       if (alive) {
         loc = seek_block(t1, doc);
@@ -892,21 +946,19 @@ __global__ __launch_bounds__(64) void and_kernel(TqkScanParams p) {
     }
     uint64_t todo = __ballot(surv);
 
-    // ---- stage A per surviving leader block.  The payload loads of up to 4 blocks are issued
-    // back to back (one 16-byte load per lane and block) before the first one is unpacked: a
-    // wavefront walks its blocks serially, so memory-level parallelism has to come from here.
-    auto stageA = [&](uint32_t b, uint2 mo_l, const U4Unaligned &v) {
+    // ---- stage A per surviving leader block
+    auto stageA = [&](uint32_t b) {
+      const uint2 mo_l = make_uint2((uint32_t)__builtin_amdgcn_readlane((int)mo_mine.x, (int)b),
+                                    (uint32_t)__builtin_amdgcn_readlane((int)mo_mine.y, (int)b));
       const uint32_t prev_l = (uint32_t)__builtin_amdgcn_readlane((int)prev_mine, (int)b);
       uint32_t c0, c1, t0, t1f;
       bool alive0, alive1;
-      uint32_t rest_bits = 0;
       if (mo_l.x == META_TAIL) {
         decode_docs<USE_DPP>(idx, lead, mo_l, prev_l, lane, c0, c1);
         decode_tfs(idx, lead, mo_l, lane, t0, t1f);
         alive0 = c0 != TQD_TERMINATED;
         alive1 = c1 != TQD_TERMINATED;
         if (prune) {
-          rest_bits = (uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(rest_mine), (int)b);
           const uint32_t tfmin = (uint32_t)__builtin_amdgcn_readlane((int)tfmin_mine, (int)b);
           alive0 = alive0 && t0 >= tfmin;
           alive1 = alive1 && t1f >= tfmin;
@@ -916,8 +968,7 @@ __global__ __launch_bounds__(64) void and_kernel(TqkScanParams p) {
         const uint32_t strict = (mo_l.x >> 6) & 1u;
         const uint32_t tf_bits = lead.has_freq ? (mo_l.x >> 8) & 0xFFu : 0u;
         wave_mem_fence();
-        if (16u * (uint32_t)lane < 16u * (doc_bits + tf_bits))
-          *reinterpret_cast<uint4 *>(L.pay + 4 * lane) = make_uint4(v.x, v.y, v.z, v.w);
+        stage_payload(L.pay, idx + lead.payload_base + mo_l.y, 16u * (doc_bits + tf_bits), lane);
         wave_mem_fence();
         if (lead.has_freq) {
           unpack2_lds(L.pay + 4u * doc_bits, tf_bits, lane, t0, t1f);
@@ -933,7 +984,6 @@ __global__ __launch_bounds__(64) void and_kernel(TqkScanParams p) {
           // tf-only bound first (block_wand_intersection.rs:112-125 filters on the exact leader
           // score; this is the same test with the norm replaced by its lower bound, folded into
           // an integer compare by the pre-filter).  Most blocks end here without a prefix sum.
-          rest_bits = (uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(rest_mine), (int)b);
           const uint32_t tfmin = (uint32_t)__builtin_amdgcn_readlane((int)tfmin_mine, (int)b);
           alive0 = t0 >= tfmin;
           alive1 = t1f >= tfmin;
@@ -952,12 +1002,10 @@ __global__ __launch_bounds__(64) void and_kernel(TqkScanParams p) {
       if (alive0) {
         L.q1_doc[pos0] = c0;
         L.q1_tf[pos0] = t0;
-        L.q1_rest[pos0] = rest_bits;
       }
       if (alive1) {
         L.q1_doc[pos1] = c1;
         L.q1_tf[pos1] = t1f;
-        L.q1_rest[pos1] = rest_bits;
       }
       wave_mem_fence();
       q1n += n0 + (uint32_t)__popcll(m1);
@@ -966,34 +1014,10 @@ __global__ __launch_bounds__(64) void and_kernel(TqkScanParams p) {
         while (q2n >= 64u) stageC(64u);
       }
     };
-    auto fetch = [&](uint32_t b, uint2 &mo_l, U4Unaligned &v) {
-      mo_l = make_uint2((uint32_t)__builtin_amdgcn_readlane((int)mo_mine.x, (int)b),
-                        (uint32_t)__builtin_amdgcn_readlane((int)mo_mine.y, (int)b));
-      v = U4Unaligned{0u, 0u, 0u, 0u};
-      if (mo_l.x != META_TAIL) {
-        const uint32_t tf_bits = lead.has_freq ? (mo_l.x >> 8) & 0xFFu : 0u;
-        const uint32_t o = 16u * (uint32_t)lane;
-        if (o < 16u * ((mo_l.x & 31u) + tf_bits))
-          v = *reinterpret_cast<const U4Unaligned *>(idx + lead.payload_base + mo_l.y + o);
-      }
-    };
     while (todo) {
-      uint32_t bs[4] = {0u, 0u, 0u, 0u};
-      uint2 mos[4];
-      U4Unaligned vs[4];
-      uint32_t nb = 0;
-#pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        if (todo) {
-          bs[k] = (uint32_t)__builtin_ctzll(todo);
-          todo &= todo - 1ull;
-          fetch(bs[k], mos[k], vs[k]);
-          nb = (uint32_t)k + 1u;
-        }
-      }
-#pragma unroll
-      for (int k = 0; k < 4; ++k)
-        if ((uint32_t)k < nb) stageA(bs[k], mos[k], vs[k]);
+      const uint32_t b = (uint32_t)__builtin_ctzll(todo);
+      todo &= todo - 1ull;
+      stageA(b);
     }
   }
   // final flush
@@ -1448,10 +1472,20 @@ __global__ __launch_bounds__(64) void merge_segments_kernel(TqkSegMergeParams p)
 // =================================================================== launch wrappers
 template <int KPL>
 static void launch_and_t(const TqkScanParams &p, dim3 grid, dim3 block, hipStream_t st) {
-  if (p.exhaustive)  // two instantiations: the pruning code costs registers the exhaustive scan
-    and_kernel<KPL, false><<<grid, block, 0, st>>>(p);  // does not need, and the kernel names
-  else                                                   // tell the modes apart in a profile
-    and_kernel<KPL, true><<<grid, block, 0, st>>>(p);
+  // instantiations: the pruning code costs registers the exhaustive scan does not need (and the
+  // kernel names tell the modes apart in a profile); launches whose non-leader lists all have
+  // bitmaps drop the seek / block-search code and its LDS
+  if (p.exhaustive) {
+    if (p.all_dense)
+      and_kernel<KPL, false, true><<<grid, block, 0, st>>>(p);
+    else
+      and_kernel<KPL, false, false><<<grid, block, 0, st>>>(p);
+  } else {
+    if (p.all_dense)
+      and_kernel<KPL, true, true><<<grid, block, 0, st>>>(p);
+    else
+      and_kernel<KPL, true, false><<<grid, block, 0, st>>>(p);
+  }
 }
 template <int KPL>
 static void launch_or_t(const TqkScanParams &p, bool dpp, dim3 grid, dim3 block, hipStream_t st) {
