@@ -658,7 +658,7 @@ __device__ __forceinline__ uint32_t find_in_blocks(const uint8_t *idx, const Ter
 }
 
 template <int KPL, bool PRUNE, bool DENSE>
-__global__ __launch_bounds__(64) void and_kernel(TqkScanParams p) {
+__global__ __launch_bounds__(64) __attribute__((amdgpu_num_sgpr(80))) void and_kernel(TqkScanParams p) {
   constexpr bool USE_DPP = true;
   __shared__ AndLdsT<DENSE> L;  // one wavefront per workgroup: finished chunks free their slot at once
   const int lane = (int)__lane_id();
