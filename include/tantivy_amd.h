@@ -162,7 +162,9 @@ int tq_last_batch_stats(tq_segment *seg, tq_batch_stats *out);
  *        block_wand_intersection does — same top-k either way),
  *        "timing" (0/1: record HIP events per batch),
  *        "dense" (0/1, default 1: tq_term_prepare also builds a bitmap + rank directory for lists
- *        with doc_freq >= max_doc/32), "use_dense" (0/1, default 1: the AND kernel may use them),
+ *        with doc_freq >= max_doc/dense_ratio, while all bitmaps stay below 4x the segment's
+ *        bytes), "dense_ratio" (default 64), "use_dense" (0/1, default 1: the AND kernel may use
+ *        them),
  *        "use_dpp" (0/1: DPP or ds_bpermute prefix sums) */
 int tq_set_option(tq_segment *seg, const char *name, int64_t value);
 

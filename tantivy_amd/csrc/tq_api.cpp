@@ -129,6 +129,8 @@ struct Options {
   int timing = 0;
   int use_dpp = 1;
   int dense = 1;      // build bitmaps for dense lists at tq_term_prepare
+  int dense_ratio = TQD_DENSE_RATIO;  // ... for lists with doc_freq >= max_doc / dense_ratio
+  int dense_budget_x = 4;  // ... while all bitmaps stay below this multiple of the segment's bytes
   int use_dense = 1;  // let the scan kernels use them
 };
 
@@ -152,6 +154,7 @@ struct tq_segment {
   TqdTerm *d_terms = nullptr;
   size_t d_terms_cap = 0;
   bool d_terms_dirty = false;
+  size_t dense_bytes_total = 0;
   std::unordered_map<uint64_t, uint32_t> term_by_off;
   // batch scratch
   DevBuf d_stage, d_partials, d_out_scores, d_out_docs, d_out_counts, d_misc, d_thr;
@@ -567,8 +570,16 @@ int tq_term_prepare(tq_segment *s, uint64_t postings_off, uint32_t postings_len,
   s->d_terms_dirty = true;
   s->term_by_off.emplace(postings_off, handle);
   *out = handle;
-  if (s->opt.dense && s->max_doc >= 4096u && (uint64_t)doc_freq * TQD_DENSE_RATIO >= s->max_doc)
+  // 0.25 B/doc per bitmap: worth it for lists whose 128-doc blocks span few docs, and only while
+  // the bitmaps together stay within a fixed multiple of the segment's own size
+  const size_t dense_bytes = (((size_t)s->max_doc + 31) / 32 + 1) * sizeof(uint2);
+  const size_t budget = (size_t)s->opt.dense_budget_x * (s->h_idx.size() + s->h_pos.size() + s->max_doc);
+  if (s->opt.dense && s->max_doc >= 4096u &&
+      (uint64_t)doc_freq * (uint64_t)s->opt.dense_ratio >= s->max_doc &&
+      s->dense_bytes_total + dense_bytes <= budget) {
+    s->dense_bytes_total += dense_bytes;
     return build_dense(s, handle);
+  }
   return TQ_OK;
 }
 
@@ -1080,6 +1091,8 @@ int tq_set_option(tq_segment *s, const char *name, int64_t value) {
     s->opt.use_dpp = value != 0;
   else if (!strcmp(name, "use_dense"))
     s->opt.use_dense = value != 0;
+  else if (!strcmp(name, "dense_ratio") && value >= 1)  // affects terms prepared afterwards
+    s->opt.dense_ratio = (int)value;
   else if (!strcmp(name, "dense"))  // affects terms prepared afterwards
     s->opt.dense = value != 0;
   else

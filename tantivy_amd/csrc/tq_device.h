@@ -10,7 +10,7 @@
 // Tunables of the scan kernels (see DESIGN.md "AND kernel").
 #define TQD_WAVES_PER_WG 4    // independent wavefronts per workgroup
 #define TQD_AND_TILE 64       // leader-list blocks per AND tile (one lane each in the pre-filter)
-#define TQD_DENSE_RATIO 32    // lists with doc_freq >= max_doc/32 also get a bitmap + rank directory
+#define TQD_DENSE_RATIO 64    // default: lists with doc_freq >= max_doc/64 also get a bitmap + rank directory
 #define TQD_THR_SLOTS 64      // shared threshold slots per query (pruned mode)
 #define TQD_PH_M 4            // phrase: driver-list blocks per tile
 #define TQD_PH_SLOTS 1024     // phrase: hash slots per wavefront (load factor <= 0.25)
@@ -29,7 +29,7 @@
 struct TqdTermHead {  // what every kernel needs: fetched with scalar loads
   const uint4 *rec;           // n_blocks + 1 (the extra record carries the total position count)
   const uint32_t *coarse;     // ((max_doc-1) >> coarse_shift) + 2 entries
-  // dense lists only (doc_freq >= max_doc / TQD_DENSE_RATIO), else null: membership bitmap with a
+  // dense lists only (doc_freq >= max_doc / dense_ratio, within the memory budget), else null: membership bitmap with a
   // rank directory.  dense[d >> 5] = {bits of docs 32*(d>>5)..+31, number of postings before them}
   const uint2 *dense;
   const uint32_t *tail_docs;  // n_tail
