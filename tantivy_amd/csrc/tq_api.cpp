@@ -754,6 +754,33 @@ int tq_search_batch_device(tq_segment *s, const tq_query *queries, uint32_t n_qu
         }
         dq.n_terms = n;
       }
+      // terms by weight descending (stable): the score sum order of the union kernel, and what
+      // makes the low-weight (dense) lists the non-essential suffix of MaxScore pruning
+      {
+        uint32_t order[TQ_MAX_TERMS];
+        for (uint32_t i = 0; i < dq.n_terms; ++i) order[i] = i;
+        std::stable_sort(order, order + dq.n_terms,
+                         [&](uint32_t a, uint32_t b) { return dq.weight[a] > dq.weight[b]; });
+        uint32_t t2[TQ_MAX_TERMS];
+        float w2[TQ_MAX_TERMS];
+        for (uint32_t i = 0; i < dq.n_terms; ++i) {
+          t2[i] = dq.term[order[i]];
+          w2[i] = dq.weight[order[i]];
+        }
+        bool nonneg = true;
+        for (uint32_t i = 0; i < dq.n_terms; ++i) {
+          dq.term[i] = t2[i];
+          dq.weight[i] = w2[i];
+          nonneg = nonneg && w2[i] >= 0.0f;
+        }
+        if (!s->opt.exhaustive && nonneg && dq.n_terms) {
+          dq.flags |= TQD_QF_PRUNE;
+          if (q.k <= 2 * TQD_THR_SLOTS) {  // k-th largest of 64 (128) slots needs k <= 64 (128)
+            dq.thr_index = n_thr_rows;
+            n_thr_rows += q.k <= TQD_THR_SLOTS ? 1u : 2u;
+          }
+        }
+      }
       uint32_t max_last = 0;
       for (uint32_t i = 0; i < dq.n_terms; ++i)
         max_last = std::max(max_last, s->terms[dq.term[i]].last_doc);

@@ -335,6 +335,20 @@ __device__ __forceinline__ uint32_t lower_bound_block(const TermRef &t, uint32_t
   }
   return lo;
 }
+// Wave-uniform target through the coarse table, scalar loads only.
+__device__ __forceinline__ uint32_t seek_block_uniform(const TermRef &t, uint32_t doc) {
+  const uint32_t b = doc >> t.shift;
+  const uint2 c = sload(reinterpret_cast<const uint2 *>(t.coarse + b));  // 4-byte aligned pair
+  uint32_t lo = c.x, hi = c.y;
+  while (lo < hi) {
+    const uint32_t mid = (lo + hi) >> 1;
+    if (sload(&t.rec[mid].x) >= doc)
+      hi = mid;
+    else
+      lo = mid + 1u;
+  }
+  return lo;
+}
 // The same for a per-lane target (BlockSegmentPostings::seek_block, skip.rs:263-273, made O(1)):
 // the coarse table brackets the answer, a short binary search finishes.  doc < max_doc.
 __device__ __forceinline__ uint32_t seek_block(const TermRef &t, uint32_t doc) {
@@ -519,15 +533,23 @@ __device__ __forceinline__ float block_max_score(uint32_t meta, float w, const f
   const uint32_t tf = tfc == 255u ? 0xFFFFFFFFu : tfc;  // skip.rs:31-43
   return bm25(w, cache[(meta >> 16) & 0xFFu], tf);
 }
-// k-th largest of the 64 per-lane values (0 = empty slot); 0 if fewer than k are set
-__device__ __forceinline__ uint32_t kth_largest64(uint32_t v, uint32_t k) {
-  uint32_t best = 0;
-  for (int i = 0; i < 64; ++i) {
-    const uint32_t x = (uint32_t)__builtin_amdgcn_readlane((int)v, i);
-    const uint32_t c = (uint32_t)__popcll(__ballot(v >= x));
-    if (c >= k && x > best) best = x;
+// k-th largest of the 64*S per-lane values (0 = empty slot); 0 if fewer than k are set.
+// Radix select: the largest x with |{v >= x}| >= k, one bit per step.
+template <int S>
+__device__ __forceinline__ uint32_t kth_largest_multi(const uint32_t (&v)[S], uint32_t k) {
+  uint32_t ans = 0;
+  for (int bit = 31; bit >= 0; --bit) {
+    const uint32_t trial = ans | (1u << bit);
+    uint32_t c = 0;
+#pragma unroll
+    for (int r = 0; r < S; ++r) c += (uint32_t)__popcll(__ballot(v[r] >= trial));
+    if (c >= k) ans = trial;
   }
-  return best;
+  return ans;
+}
+__device__ __forceinline__ uint32_t kth_largest64(uint32_t v, uint32_t k) {
+  const uint32_t a[1] = {v};
+  return kth_largest_multi<1>(a, k);
 }
 __device__ __forceinline__ uint32_t mbcnt64(uint64_t m) {
   return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
@@ -1029,60 +1051,223 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_num_sgpr(80))) void and_k
   if (lane == 0 && n_matches) atomicAdd(p.match_counter, (unsigned long long)n_matches);
 }
 
-// =================================================================== OR kernel (exhaustive union)
-// One workgroup = one chunk of consecutive 4096-doc windows.  Per window: f32 accumulators in
-// LDS, terms applied one after the other (SumCombiner order = query term order), the 4 waves
-// splitting each term's blocks; then every present doc is offered to the waves' top-k.
-template <int KPL, bool USE_DPP>
+// =================================================================== OR kernel
+// Union with MaxScore pruning, the window-parallel form of block_wand
+// (src/query/boolean_query/block_wand_union.rs:16-265) and BufferedUnionScorer
+// (src/query/union/buffered_union.rs:63-158).  Terms are ordered by weight DESCENDING (the weight
+// bounds a term's score: tf/(tf+norm) < 1).  One workgroup = one chunk of consecutive 4096-doc
+// windows (HORIZON, buffered_union.rs:11-12).  Per window:
+//   * the suffix of terms that are dense (bitmap) and whose weights together stay below the
+//     threshold is NON-ESSENTIAL: a doc found only in those lists cannot reach the top-k, so
+//     their postings are never enumerated (find_pivot_doc's prefix rule, :16-43, with the
+//     reference's per-doc pivot replaced by a per-window one);
+//   * the other (essential) lists are decoded block by block, scored and summed into f32
+//     accumulators in LDS, the 4 waves splitting each list's blocks;
+//   * every present doc whose partial score plus the non-essential weights can reach the
+//     threshold is compacted into a per-wave queue; batches of 64 probe the non-essential lists'
+//     bitmaps in order (one 8-byte load = membership + posting index -> tf), stopping as soon as
+//     the remaining weights cannot lift the score over the threshold (:49-80);
+//   * survivors are offered to the wave's register top-k and published to the query's threshold
+//     slots (same scheme as the AND kernel; 64 slots for k <= 64, 128 for k <= 128).
+// Scores are summed in term order in both modes, so pruned and exhaustive runs are bit-identical;
+// against the reference the sum order of 3+ terms is not canonical (1e-5 relative).
+template <bool PRUNE>
+struct OrLds {
+  float acc[TQD_OR_WINDOW];
+  uint32_t present[TQD_OR_WINDOW / 32];
+  float cache[256];
+  float suffix[TQD_MAX_TERMS + 1];  // suffix[m] = sum of the weights of terms m..
+  uint32_t thr_shared;
+  // first block of every list for 64 consecutive windows (+1): planned lane-parallel once per
+  // 64 windows, so the per-window loops carry no dependent seek
+  uint32_t wj[TQD_MAX_TERMS][65];
+  uint32_t cq_doc[PRUNE ? TQD_WAVES_PER_WG : 1][127];  // per-wave candidate queue
+  uint32_t cq_s[PRUNE ? TQD_WAVES_PER_WG : 1][127];
+};
+
+template <int KPL, bool PRUNE>
 __global__ __launch_bounds__(TQD_WAVES_PER_WG * 64) void or_kernel(TqkScanParams p) {
-  __shared__ float acc[TQD_OR_WINDOW];
-  __shared__ uint32_t present[TQD_OR_WINDOW / 32];
+  constexpr bool USE_DPP = true;
+  __shared__ OrLds<PRUNE> L;
   const int lane = (int)__lane_id();
   const uint32_t wave = uni(threadIdx.x >> 6);
   const uint32_t tid = threadIdx.x;
+  if (blockIdx.x >= p.n_chunks) return;
   const uint32_t chunk = blockIdx.x;
-  if (chunk >= p.n_chunks) return;
   const uint32_t t_begin = sload(p.chunk_starts + chunk);
   const uint32_t t_end = sload(p.chunk_starts + chunk + 1u);
 
   const TqdSegment seg = p.seg;
-  const uint8_t *idx = uni_ptr(seg.idx);
-  uint32_t q = find_query(p.tile_starts, p.n_queries, t_begin);
-  uint32_t q_tile_start = uni(p.tile_starts[q]);
-  uint32_t q_tile_end = uni(p.tile_starts[q + 1]);
-  const TqdQuery *Q = uni_ptr(p.queries + q);
+  const uint8_t *idx = seg.idx;
+  uint32_t q = uni(find_query(p.tile_starts, p.n_queries, t_begin));
+  uint32_t q_tile_start = 0, q_tile_end = 0;
+  const TqdQuery *Q = nullptr;
+  uint32_t nt = 0, dense_mask = 0, n_slot_rows = 0;
+  bool prune = false, query_done = false;
+  uint32_t *slots = nullptr;
+  uint32_t thr = 0, thr_g = 0;
+  uint32_t cache_loaded = 0xFFFFFFFFu;
   TopK<KPL> tk;
-  tk.reset(uni(Q->k));
   uint32_t n_matches = 0;
+  uint32_t cqn = 0;  // this wave's candidate queue fill
+  uint32_t plan_begin = 0xFFFFFFFFu, plan_end = 0;  // windows [plan_begin, plan_end) are planned
 
+  auto setup_query = [&]() {
+    q_tile_start = sload(p.tile_starts + q);
+    q_tile_end = sload(p.tile_starts + q + 1u);
+    Q = p.queries + q;
+    nt = sload(&Q->n_terms);
+    prune = PRUNE && (sload(&Q->flags) & TQD_QF_PRUNE) != 0u;
+    const uint32_t thr_index = sload(&Q->thr_index);
+    const uint32_t k = sload(&Q->k);
+    n_slot_rows = k <= 64u ? 1u : 2u;
+    slots = (prune && thr_index != 0xFFFFFFFFu) ? p.thr_slots + (size_t)thr_index * TQD_THR_SLOTS
+                                                : nullptr;
+    const uint32_t ci = sload(&Q->cache_idx);
+    __syncthreads();  // nobody still reads the previous query's cache / suffix sums
+    if (ci != cache_loaded) {
+      const float *cg = p.caches + (size_t)ci * 256u;
+      for (uint32_t i = tid; i < 256u; i += TQD_WAVES_PER_WG * 64) L.cache[i] = cg[i];
+      cache_loaded = ci;
+    }
+    dense_mask = 0;
+    float suf = 0.0f;
+    if (tid == 0) L.suffix[nt] = 0.0f;
+    for (uint32_t m = nt; m-- > 0u;) {
+      suf += sload(&Q->weight[m]);
+      if (tid == 0) L.suffix[m] = suf;
+      const TermRef tr = load_term(p.terms, sload(&Q->term[m]));
+      if (tr.dense && p.use_dense) dense_mask |= 1u << m;
+    }
+    __syncthreads();
+    thr = 0;
+    thr_g = 0;
+    query_done = false;
+    plan_begin = 0xFFFFFFFFu;
+    plan_end = 0;
+    tk.reset(k);
+  };
+
+  // probe the non-essential lists [E, nt) for a batch of <= 64 candidates (one per lane)
+  auto probe_batch = [&](uint32_t n, uint32_t E) {
+    const uint32_t base = cqn - n;
+    cqn = base;
+    bool alive = (uint32_t)lane < n;
+    uint32_t doc = 0;
+    float s = 0.0f, norm = 0.0f;
+    if (alive) {
+      doc = L.cq_doc[PRUNE ? wave : 0][base + lane];
+      s = __uint_as_float(L.cq_s[PRUNE ? wave : 0][base + lane]);
+      norm = L.cache[fieldnorm_id(seg, doc)];
+    }
+    for (uint32_t m = E; m < nt; ++m) {
+      if (alive) alive = sortable((s + L.suffix[m]) * 1.000001f) >= thr;
+      if (!__ballot(alive)) break;
+      const TermRef tr = load_term(p.terms, sload(&Q->term[m]));
+      const float w = sload(&Q->weight[m]);
+      if (alive) {
+        const uint2 wd = tr.dense[doc >> 5];
+        const uint32_t bit = doc & 31u;
+        if ((wd.x >> bit) & 1u) {
+          const uint32_t pi = wd.y + (uint32_t)__popc(wd.x & ((1u << bit) - 1u));
+          const uint4 r = tr.rec[pi >> 7];
+          s = s + bm25(w, norm, block_tf_at(idx, tr, make_uint2(r.y, r.z), pi & 127u));
+        }
+      }
+    }
+    const uint64_t hit = __ballot(alive);
+    if (hit) {
+      n_matches += (uint32_t)__popcll(hit);
+      const uint64_t key = alive ? make_key(s, doc) : 0ull;
+      if (slots) {
+        const uint32_t sb = (uint32_t)(key >> 32);
+        const uint32_t h = (doc * 0x9E3779B1u) >> (n_slot_rows == 1u ? 26 : 25);
+        if (alive && sb > thr_g) atomicMax(slots + h, sb);
+      }
+      tk.offer(alive, key, lane);
+      const uint32_t own = (uint32_t)(tk.thr >> 32);
+      if (own > thr) thr = own;
+    }
+  };
+
+  setup_query();
   for (uint32_t t = t_begin; t < t_end; ++t) {
     while (t >= q_tile_end) {
       if (q_tile_end > q_tile_start && q_tile_end > t_begin) {
-        const uint32_t part = uni(Q->part_start) +
+        const uint32_t part = sload(&Q->part_start) +
                               (chunk - sload(&Q->chunk_first)) * TQD_WAVES_PER_WG + wave;
         flush_partial<KPL>(tk, p.partials, part, lane);
       }
       ++q;
-      q_tile_start = q_tile_end;
-      q_tile_end = uni(p.tile_starts[q + 1]);
-      Q = uni_ptr(p.queries + q);
-      tk.reset(uni(Q->k));
+      setup_query();
     }
-    const uint32_t nt = uni(Q->n_terms);
-    const float *cache = uni_ptr(p.caches + (size_t)uni(Q->cache_idx) * 256u);
+    if (query_done) continue;  // the weights of all lists together are below the threshold
     const uint32_t base = (t - q_tile_start) * TQD_OR_WINDOW;
     const uint32_t win_hi = base + (TQD_OR_WINDOW - 1u);
+    if (t >= plan_end || t < plan_begin) {  // plan the next 64 windows: one lane per window
+      __syncthreads();
+      plan_begin = t;
+      plan_end = t + 64u;
+      for (uint32_t m = wave; m < nt; m += TQD_WAVES_PER_WG) {
+        const TermRef tr = load_term(p.terms, sload(&Q->term[m]));
+        const uint64_t b0 = (uint64_t)base + (uint64_t)lane * TQD_OR_WINDOW;
+        L.wj[m][lane] = b0 < seg.max_doc ? seek_block(tr, (uint32_t)b0) : tr.n_blocks;
+        if (lane == 0) {
+          const uint64_t b64 = (uint64_t)base + 64ull * TQD_OR_WINDOW;
+          L.wj[m][64] = b64 < seg.max_doc ? seek_block(tr, (uint32_t)b64) : tr.n_blocks;
+        }
+      }
+      __syncthreads();
+    }
+    const uint32_t wl = t - plan_begin;
 
-    for (uint32_t i = tid; i < TQD_OR_WINDOW; i += TQD_WAVES_PER_WG * 64) acc[i] = 0.0f;
-    if (tid < TQD_OR_WINDOW / 32) present[tid] = 0u;
+    // threshold: wave 0 reads the shared slots, everybody takes max(shared, own k-th key)
+    if (slots && wave == 0u) {
+      uint32_t sv[2] = {0u, 0u};
+      sv[0] = __hip_atomic_load(slots + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      uint32_t g;
+      if (n_slot_rows == 2u) {
+        sv[1] = __hip_atomic_load(slots + 64 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        g = kth_largest_multi<2>(sv, tk.k);
+      } else {
+        g = kth_largest64(sv[0], tk.k);
+      }
+      if (lane == 0) L.thr_shared = g;
+    }
+    for (uint32_t i = tid; i < TQD_OR_WINDOW / 4; i += TQD_WAVES_PER_WG * 64)
+      reinterpret_cast<float4 *>(L.acc)[i] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    if (tid < TQD_OR_WINDOW / 32) L.present[tid] = 0u;
     __syncthreads();
+    if (slots) {
+      thr_g = L.thr_shared;
+      if (thr_g > thr) thr = thr_g;
+    }
+    // all 4 waves must agree on E: use the shared threshold only (own thresholds differ)
+    uint32_t E = nt;
+    if (prune) {
+      const uint32_t thr_w = slots ? thr_g : 0u;
+      for (uint32_t m = nt; m-- > 0u;) {
+        if (((dense_mask >> m) & 1u) && sortable(L.suffix[m] * 1.000001f) < thr_w)
+          E = m;
+        else
+          break;
+      }
+      if (E == 0u) {  // no doc of this query can reach the top-k any more
+        query_done = true;
+        __syncthreads();
+        continue;
+      }
+    }
 
-    for (uint32_t m = 0; m < nt; ++m) {
-      const TermRef tr = load_term(p.terms, uni(Q->term[m]));
-      const float w = __uint_as_float(uni(__float_as_uint(Q->weight[m])));
-      const uint32_t jb = lower_bound_block(tr, base, lane);
-      for (uint32_t j = jb + wave; j < tr.n_blocks; j += TQD_WAVES_PER_WG) {
-        if (block_first_possible(tr, j) > win_hi) break;
+    // ---- essential lists: decode, score, accumulate (term order = score sum order)
+    for (uint32_t m = 0; m < E; ++m) {
+      const TermRef tr = load_term(p.terms, sload(&Q->term[m]));
+      const float w = sload(&Q->weight[m]);
+      // blocks [first block reaching into this window, first block reaching into the next one]
+      const uint32_t jb = uni(L.wj[m][wl]);
+      uint32_t je = uni(L.wj[m][wl + 1u]);
+      if (je >= tr.n_blocks) je = tr.n_blocks ? tr.n_blocks - 1u : 0u;
+      for (uint32_t j = jb + wave; j <= je && j < tr.n_blocks; j += TQD_WAVES_PER_WG) {
         const Dec d = decode_block<USE_DPP, false>(idx, tr, j, lane);
 #pragma unroll
         for (int e = 0; e < 2; ++e) {
@@ -1090,25 +1275,56 @@ __global__ __launch_bounds__(TQD_WAVES_PER_WG * 64) void or_kernel(TqkScanParams
           const uint32_t tf = e ? d.t1 : d.t0;
           if (doc >= base && doc <= win_hi) {
             const uint32_t o = doc - base;
-            const float s = bm25(w, cache[fieldnorm_id(seg, doc)], tf);
-            acc[o] = acc[o] + s;  // one posting per (term, doc): no intra-phase conflict
-            atomicOr(&present[o >> 5], 1u << (o & 31u));
+            const float s = bm25(w, L.cache[fieldnorm_id(seg, doc)], tf);
+            L.acc[o] = L.acc[o] + s;  // one posting per (term, doc): no intra-phase conflict
+            atomicOr(&L.present[o >> 5], 1u << (o & 31u));
           }
         }
       }
       __syncthreads();
     }
-    // harvest
+    // ---- harvest
+    const float rest = L.suffix[E];
     for (uint32_t i = tid; i < TQD_OR_WINDOW; i += TQD_WAVES_PER_WG * 64) {
-      const bool has = (present[i >> 5] >> (i & 31u)) & 1u;
-      const uint64_t key = has ? make_key(acc[i], base + i) : 0ull;
-      n_matches += (uint32_t)__popcll(__ballot(has));
-      tk.offer(has, key, lane);
+      bool has = (L.present[i >> 5] >> (i & 31u)) & 1u;
+      const float s = L.acc[i];
+      if (E == nt) {  // every list was enumerated: final score
+        const uint64_t key = has ? make_key(s, base + i) : 0ull;
+        const uint64_t hit = __ballot(has);
+        if (hit) {
+          n_matches += (uint32_t)__popcll(hit);
+          if (slots) {
+            const uint32_t sb = (uint32_t)(key >> 32);
+            const uint32_t h = ((base + i) * 0x9E3779B1u) >> (n_slot_rows == 1u ? 26 : 25);
+            if (has && sb > thr_g) atomicMax(slots + h, sb);
+          }
+          tk.offer(has, key, lane);
+          if (prune) {
+            const uint32_t own = (uint32_t)(tk.thr >> 32);
+            if (own > thr) thr = own;
+          }
+        }
+      } else if (PRUNE) {
+        if (has) has = sortable((s + rest) * 1.000001f) >= thr;
+        const uint64_t m = __ballot(has);
+        if (m) {
+          const uint32_t pos = cqn + mbcnt64(m);
+          wave_mem_fence();
+          if (has) {
+            L.cq_doc[PRUNE ? wave : 0][pos] = base + i;
+            L.cq_s[PRUNE ? wave : 0][pos] = __float_as_uint(s);
+          }
+          wave_mem_fence();
+          cqn += (uint32_t)__popcll(m);
+          if (cqn >= 64u) probe_batch(64u, E);
+        }
+      }
     }
+    if (PRUNE && cqn) probe_batch(cqn, E);
     __syncthreads();
   }
   if (q_tile_end > q_tile_start) {
-    const uint32_t part = uni(Q->part_start) +
+    const uint32_t part = sload(&Q->part_start) +
                           (chunk - sload(&Q->chunk_first)) * TQD_WAVES_PER_WG + wave;
     flush_partial<KPL>(tk, p.partials, part, lane);
   }
@@ -1488,11 +1704,11 @@ static void launch_and_t(const TqkScanParams &p, dim3 grid, dim3 block, hipStrea
   }
 }
 template <int KPL>
-static void launch_or_t(const TqkScanParams &p, bool dpp, dim3 grid, dim3 block, hipStream_t st) {
-  if (dpp)
-    or_kernel<KPL, true><<<grid, block, 0, st>>>(p);
-  else
+static void launch_or_t(const TqkScanParams &p, bool /*dpp*/, dim3 grid, dim3 block, hipStream_t st) {
+  if (p.exhaustive)
     or_kernel<KPL, false><<<grid, block, 0, st>>>(p);
+  else
+    or_kernel<KPL, true><<<grid, block, 0, st>>>(p);
 }
 
 hipError_t tqk_launch_and(const TqkScanParams &p, int kpl, bool /*use_dpp*/, hipStream_t st) {
