@@ -162,7 +162,8 @@ struct tq_segment {
   // timing: a ring of event quadruples, one per batch, so that pipelined batches (no host sync
   // between them) can all be timed; tq_last_batch_stats averages the batches since its last call
   static constexpr int kTimingRing = 16;
-  hipEvent_t ev_stage_done = nullptr;
+  hipEvent_t ev_stage_done = nullptr, ev_fork = nullptr, ev_join = nullptr;
+  hipStream_t side_stream = nullptr;  // the launch groups of one batch run concurrently
   hipEvent_t ev_t0[kTimingRing] = {}, ev_t1[kTimingRing] = {}, ev_k0[kTimingRing] = {},
              ev_k1[kTimingRing] = {};
   uint64_t batches_timed = 0, batches_reported = 0;
@@ -285,6 +286,9 @@ int tq_segment_upload(tq_ctx *ctx, int device, uint32_t max_doc, const uint8_t *
   if (rc == TQ_OK) {
     hipError_t e = hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&s->ev_stage_done, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&s->ev_fork, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&s->ev_join, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&s->side_stream, hipStreamNonBlocking);
     for (int i = 0; i < tq_segment::kTimingRing; ++i) {
       if (e == hipSuccess) e = hipEventCreate(&s->ev_t0[i]);
       if (e == hipSuccess) e = hipEventCreate(&s->ev_t1[i]);
@@ -335,7 +339,10 @@ void tq_segment_free(tq_segment *s) {
   s->d_thr.release();
   s->h_stage.release();
   s->h_out.release();
-  if (s->ev_stage_done) (void)hipEventDestroy(s->ev_stage_done);
+  if (s->side_stream) (void)hipStreamSynchronize(s->side_stream);
+  for (hipEvent_t ev : {s->ev_stage_done, s->ev_fork, s->ev_join})
+    if (ev) (void)hipEventDestroy(ev);
+  if (s->side_stream) (void)hipStreamDestroy(s->side_stream);
   for (int i = 0; i < tq_segment::kTimingRing; ++i)
     for (hipEvent_t ev : {s->ev_t0[i], s->ev_t1[i], s->ev_k0[i], s->ev_k1[i]})
       if (ev) (void)hipEventDestroy(ev);
@@ -974,9 +981,24 @@ int tq_search_batch_device(tq_segment *s, const tq_query *queries, uint32_t n_qu
   const uint8_t *ds = (const uint8_t *)s->d_stage.p;
   if (s->opt.timing) HIP_TRY(hipEventRecord(s->ev_k0[slot], st));
   uint32_t tiles_total = 0, chunks_total = 0;
-  for (int gi = 0; gi < kGroups; ++gi) {
+  // The scan kernels of the different launch groups are independent: all but the first run on
+  // the segment's side stream, forked from and joined back into `st` with events, so that a
+  // small group (e.g. the AND queries over sparse lists) fills the gaps of the big one instead
+  // of adding its own ramp-up and tail.
+  int n_active = 0;
+  for (int gi = 0; gi < kGroups; ++gi) n_active += groups[gi].queries.empty() ? 0 : 1;
+  const bool fork = n_active > 1;
+  if (fork) {
+    HIP_TRY(hipEventRecord(s->ev_fork, st));
+    HIP_TRY(hipStreamWaitEvent(s->side_stream, s->ev_fork, 0));
+  }
+  const int launch_order[kGroups] = {kAndGeneral, 1, 2, 0};  // long serial chains first
+  for (int oi = 0; oi < kGroups; ++oi) {
+    const int gi = launch_order[oi];
     Group &g = groups[gi];
     if (g.queries.empty()) continue;
+    // the big dense-AND group keeps the caller's stream, the others go to the side stream
+    hipStream_t gst = (fork && gi != 0) ? s->side_stream : st;
     TqkScanParams p{};
     p.seg = s->dseg;
     p.terms = s->d_terms;
@@ -998,12 +1020,16 @@ int tq_search_batch_device(tq_segment *s, const tq_query *queries, uint32_t n_qu
     chunks_total += g.n_chunks;
     hipError_t e = hipSuccess;
     if (g.mode == TQ_MODE_AND)
-      e = tqk_launch_and(p, g.kpl, s->opt.use_dpp != 0, st);
+      e = tqk_launch_and(p, g.kpl, s->opt.use_dpp != 0, gst);
     else if (g.mode == TQ_MODE_OR)
-      e = tqk_launch_or(p, g.kpl, s->opt.use_dpp != 0, st);
+      e = tqk_launch_or(p, g.kpl, s->opt.use_dpp != 0, gst);
     else
-      e = tqk_launch_phrase(p, g.kpl, s->opt.use_dpp != 0, st);
+      e = tqk_launch_phrase(p, g.kpl, s->opt.use_dpp != 0, gst);
     if (e != hipSuccess) return fail(TQ_ERR_HIP, "scan kernel launch: %s", hipGetErrorString(e));
+  }
+  if (fork) {
+    HIP_TRY(hipEventRecord(s->ev_join, s->side_stream));
+    HIP_TRY(hipStreamWaitEvent(st, s->ev_join, 0));
   }
   if (s->opt.timing) HIP_TRY(hipEventRecord(s->ev_k1[slot], st));
   for (int gi = 0; gi < kGroups; ++gi) {
