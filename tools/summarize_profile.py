@@ -39,6 +39,7 @@ def main():
              "Command: `python bench.py --steps 3 --warmup 1 --no-cpu-baseline --latency-queries 0` "
              "under `rocprofv3 --pmc ...` (one pass per counter group, tools/profile_bench.sh).", ""]
     traffic = {}
+    fresh = {}
     tpath = os.path.join(out, "traffic.json")
     if os.path.exists(tpath):
         with open(tpath) as f:
@@ -51,17 +52,24 @@ def main():
             v = per[k][c]
             lines.append("| %s | %d | %.6g |" % (c, len(v), sum(v) / len(v)))
         lines.append("")
-        if "and_kernel" in k and "FETCH_SIZE" in per[k]:
-            mode = "pruned" if re.search(r"and_kernel<\d+, true>", k) else "exhaustive"
+        m = re.search(r"and_kernel<\d+, (true|false), (true|false)>", k)
+        if m and "FETCH_SIZE" in per[k]:
+            mode = "pruned" if m.group(1) == "true" else "exhaustive"
             fetch = sum(per[k]["FETCH_SIZE"]) / len(per[k]["FETCH_SIZE"]) * 1024
-            write = sum(per[k].get("WRITE_SIZE", [0])) / max(1, len(per[k].get("WRITE_SIZE", [0]))) * 1024
-            traffic["%s_%s_%d" % (workload, mode, docs)] = {
-                "fetch_bytes_raw": int(fetch), "write_bytes_raw": int(write),
-                "hbm_bytes_per_launch": int(2 * fetch + write),
-                "note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), KiB*1024, "
-                        "FETCH doubled per the gfx950 correction in MI355X_MICROARCH.md; "
-                        "this counts the L2's fabric-side requests, Infinity Cache hits included "
-                        "(the ~150 MB of index + tables fit the 256 MB cache)"}
+            wr = per[k].get("WRITE_SIZE", [0])
+            write = sum(wr) / max(1, len(wr)) * 1024
+            key = "%s_%s_%d" % (workload, mode, docs)
+            if key not in fresh:  # the dense-only and the general instantiation add up
+                fresh[key] = {"fetch_bytes_raw": 0, "write_bytes_raw": 0}
+            fresh[key]["fetch_bytes_raw"] += int(fetch)
+            fresh[key]["write_bytes_raw"] += int(write)
+    for key, v in fresh.items():
+        v["hbm_bytes_per_launch"] = 2 * v["fetch_bytes_raw"] + v["write_bytes_raw"]
+        v["note"] = ("rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), KiB*1024, summed over "
+                     "the batch's two and_kernel launches, FETCH doubled per the gfx950 correction in "
+                     "MI355X_MICROARCH.md; this counts the L2's fabric-side requests, Infinity Cache "
+                     "hits included (the index + tables fit the 256 MB cache)")
+        traffic[key] = v
     with open(os.path.join(out, tag + "_pmc.md"), "w") as f:
         f.write("\n".join(lines) + "\n")
     with open(tpath, "w") as f:
