@@ -33,8 +33,8 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--docs", type=int, default=10_000_000)
     ap.add_argument("--queries", type=int, default=10_000)
     ap.add_argument("--workload", default="and2", choices=["and2", "or5", "phrase3", "mixed"])
