@@ -626,7 +626,13 @@ struct Group {
   size_t o_queries = 0, o_tiles = 0, o_outidx = 0, o_chunks = 0, o_perm = 0;
 };
 
-constexpr uint32_t kSlices = 32;  // doc-range slices of the launch order
+static uint32_t tune_u32(const char *name, uint32_t dflt) {
+  const char *v = getenv(name);
+  return v && *v ? (uint32_t)strtoul(v, nullptr, 10) : dflt;
+}
+// doc-range slices of the launch order / chunks per AND launch (TQ_SLICES, TQ_CHUNKS: tuning only)
+static const uint32_t kSlices = std::min<uint32_t>(256u, std::max<uint32_t>(1u, tune_u32("TQ_SLICES", 32)));
+static const uint32_t kAndChunks = std::max<uint32_t>(256u, tune_u32("TQ_CHUNKS", 65536));
 
 int kpl_for(uint32_t k) { return k <= 64 ? 1 : (k <= 128 ? 2 : (k <= 256 ? 4 : 16)); }
 
@@ -824,7 +830,7 @@ int tq_search_batch_device(tq_segment *s, const tq_query *queries, uint32_t n_qu
     uint64_t total_cost = 0;
     for (size_t i = 0; i < g.queries.size(); ++i)
       total_cost += (uint64_t)g.queries[i].n_tiles * g.tile_cost[i];
-    const uint64_t n_target = g.mode == TQ_MODE_OR ? 8192u : 65536u;
+    const uint64_t n_target = g.mode == TQ_MODE_OR ? 8192u : kAndChunks;
     const uint64_t cost_target = std::max<uint64_t>(g.mode == TQ_MODE_AND ? 128u : 1u,
                                                     (total_cost + n_target - 1) / n_target);
     g.chunk_starts.clear();
