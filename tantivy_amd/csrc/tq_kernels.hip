@@ -335,21 +335,7 @@ __device__ __forceinline__ uint32_t lower_bound_block(const TermRef &t, uint32_t
   }
   return lo;
 }
-// Wave-uniform target through the coarse table, scalar loads only.
-__device__ __forceinline__ uint32_t seek_block_uniform(const TermRef &t, uint32_t doc) {
-  const uint32_t b = doc >> t.shift;
-  const uint2 c = sload(reinterpret_cast<const uint2 *>(t.coarse + b));  // 4-byte aligned pair
-  uint32_t lo = c.x, hi = c.y;
-  while (lo < hi) {
-    const uint32_t mid = (lo + hi) >> 1;
-    if (sload(&t.rec[mid].x) >= doc)
-      hi = mid;
-    else
-      lo = mid + 1u;
-  }
-  return lo;
-}
-// The same for a per-lane target (BlockSegmentPostings::seek_block, skip.rs:263-273, made O(1)):
+// Per-lane target (BlockSegmentPostings::seek_block, skip.rs:263-273, made O(1)):
 // the coarse table brackets the answer, a short binary search finishes.  doc < max_doc.
 __device__ __forceinline__ uint32_t seek_block(const TermRef &t, uint32_t doc) {
   const uint32_t b = doc >> t.shift;
@@ -1132,7 +1118,10 @@ __global__ __launch_bounds__(TQD_WAVES_PER_WG * 64) void or_kernel(TqkScanParams
     }
     dense_mask = 0;
     float suf = 0.0f;
-    if (tid == 0) L.suffix[nt] = 0.0f;
+    if (tid == 0) {
+      L.suffix[nt] = 0.0f;
+      L.thr_shared = 0u;
+    }
     for (uint32_t m = nt; m-- > 0u;) {
       suf += sload(&Q->weight[m]);
       if (tid == 0) L.suffix[m] = suf;
@@ -1239,7 +1228,7 @@ __global__ __launch_bounds__(TQD_WAVES_PER_WG * 64) void or_kernel(TqkScanParams
     if (tid < TQD_OR_WINDOW / 32) L.present[tid] = 0u;
     __syncthreads();
     if (slots) {
-      thr_g = L.thr_shared;
+      thr_g = L.thr_shared;  // (stays from the last refresh in between)
       if (thr_g > thr) thr = thr_g;
     }
     // all 4 waves must agree on E: use the shared threshold only (own thresholds differ)
