@@ -489,7 +489,7 @@ int tq_term_prepare(tq_segment *s, uint64_t postings_off, uint32_t postings_len,
     pos_block_off.resize((size_t)nb);
     for (size_t i = 0; i < nb; ++i) {
       if (pos_widths[i] > 32) return fail(TQ_ERR_FORMAT, "position bit width > 32");
-      pos_block_off[i] = positions_off + pa + prun;
+      pos_block_off[i] = (uint64_t)(positions_off + pa + prun) | ((uint64_t)pos_widths[i] << 56);
       prun += 16u * (size_t)pos_widths[i];
     }
     size_t t = pa + prun;
@@ -520,7 +520,6 @@ int tq_term_prepare(tq_segment *s, uint64_t postings_off, uint32_t postings_len,
   const size_t o_ttfs = place(4 * (size_t)n_tail);
   const size_t o_pboff = place(8 * pos_block_off.size());
   const size_t o_ptail = place(4 * pos_tail.size());
-  const size_t o_pw = place(pos_widths.size());
   total += PAD;
   std::vector<uint8_t> hb(total, 0);
   for (uint32_t i = 0; i <= n_blocks; ++i) {
@@ -535,7 +534,6 @@ int tq_term_prepare(tq_segment *s, uint64_t postings_off, uint32_t postings_len,
   }
   if (!pos_block_off.empty()) memcpy(hb.data() + o_pboff, pos_block_off.data(), 8 * pos_block_off.size());
   if (!pos_tail.empty()) memcpy(hb.data() + o_ptail, pos_tail.data(), 4 * pos_tail.size());
-  if (!pos_widths.empty()) memcpy(hb.data() + o_pw, pos_widths.data(), pos_widths.size());
   uint8_t *blob = nullptr;
   HIP_TRY(hipMalloc((void **)&blob, total));
   hipError_t ce = hipMemcpy(blob, hb.data(), total, hipMemcpyHostToDevice);
@@ -548,8 +546,7 @@ int tq_term_prepare(tq_segment *s, uint64_t postings_off, uint32_t postings_len,
   dt.coarse = (const uint32_t *)(blob + o_coarse);
   dt.tail_docs = (const uint32_t *)(blob + o_tdocs);
   dt.tail_tfs = (const uint32_t *)(blob + o_ttfs);
-  dt.pos_block_off = (const uint64_t *)(blob + o_pboff);
-  dt.pos_widths = (const uint8_t *)(blob + o_pw);
+  dt.pos_blk = (const uint64_t *)(blob + o_pboff);
   dt.pos_tail = (const uint32_t *)(blob + o_ptail);
   dt.payload_base = abs0 + payload;
   dt.n_full = n_full;
@@ -749,9 +746,11 @@ int tq_search_batch_device(tq_segment *s, const tq_query *queries, uint32_t n_qu
             // the shared threshold pays off on long lists only; k-th largest of 64 slots needs k <= 64
             if (q.k <= TQD_THR_SLOTS && n_tiles >= 2) dq.thr_index = n_thr_rows++;
           }
-        } else {
-          const uint32_t drv_blocks = s->terms[dq.term[q.n_terms - 1]].n_blocks;
-          n_tiles = (drv_blocks + TQD_PH_M - 1) / TQD_PH_M;
+        } else {  // phrase: leader-block tiles like AND; every match also walks its positions
+          const uint32_t lead_blocks = s->terms[dq.term[0]].n_blocks;
+          dq.tile_blocks = 16;
+          tile_cost = 64;
+          n_tiles = (lead_blocks + dq.tile_blocks - 1) / dq.tile_blocks;
         }
       }
     }

@@ -12,8 +12,6 @@
 #define TQD_AND_TILE 64       // leader-list blocks per AND tile (one lane each in the pre-filter)
 #define TQD_DENSE_RATIO 64    // default: lists with doc_freq >= max_doc/64 also get a bitmap + rank directory
 #define TQD_THR_SLOTS 64      // shared threshold slots per query (pruned mode)
-#define TQD_PH_M 4            // phrase: driver-list blocks per tile
-#define TQD_PH_SLOTS 1024     // phrase: hash slots per wavefront (load factor <= 0.25)
 #define TQD_OR_WINDOW 4096    // docs per OR tile (one workgroup)
 
 // A posting list on the device.  The skip list of src/postings/skip.rs:205-253 is unrolled from
@@ -41,8 +39,7 @@ struct TqdTermHead {  // what every kernel needs: fetched with scalar loads
 };
 struct TqdTerm : TqdTermHead {
   // positions stream (src/positions/reader.rs): per position-block absolute byte offset / width
-  const uint64_t *pos_block_off;  // n_pos_blocks
-  const uint8_t *pos_widths;      // n_pos_blocks
+  const uint64_t *pos_blk;        // n_pos_blocks: absolute byte offset | bit width << 56
   const uint32_t *pos_tail;       // vint tail, pre-decoded deltas
   uint32_t n_full, doc_freq;
   uint32_t n_pos_blocks, n_pos_tail;

@@ -26,7 +26,6 @@
 
 namespace {
 
-constexpr uint32_t EMPTY_SLOT = 0xFFFFFFFFu;
 constexpr int WAVE = 64;
 
 // ------------------------------------------------------------------ small helpers
@@ -421,33 +420,6 @@ struct TopK {
   }
 };
 
-// ------------------------------------------------------------------ per-wave LDS hash table
-struct WaveTable {
-  uint32_t doc[TQD_PH_SLOTS];
-  uint32_t val[TQD_PH_SLOTS];
-};
-__device__ __forceinline__ uint32_t ht_insert(WaveTable &tb, uint32_t doc, uint32_t val) {
-  uint32_t h = doc & (TQD_PH_SLOTS - 1u);
-  for (;;) {
-    const uint32_t prev = atomicCAS(&tb.doc[h], EMPTY_SLOT, doc);
-    if (prev == EMPTY_SLOT) break;
-    h = (h + 1u) & (TQD_PH_SLOTS - 1u);
-  }
-  tb.val[h] = val;
-  return h;
-}
-__device__ __forceinline__ bool ht_find(const WaveTable &tb, uint32_t doc, uint32_t &slot) {
-  uint32_t h = doc & (TQD_PH_SLOTS - 1u);
-  for (;;) {
-    const uint32_t d = tb.doc[h];
-    if (d == doc) {
-      slot = h;
-      return true;
-    }
-    if (d == EMPTY_SLOT) return false;
-    h = (h + 1u) & (TQD_PH_SLOTS - 1u);
-  }
-}
 __device__ __forceinline__ void wave_mem_fence() {
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
   __builtin_amdgcn_wave_barrier();
@@ -562,14 +534,18 @@ struct AndLdsT {  // per wavefront
 // block_search.rs:38-76).  Seeks into sparse lists land in many different blocks; decoding them
 // one per wave-step (as stage A does for the leader, where all 128 docs are wanted) would leave
 // this path with a quarter of the throughput.
-template <bool USE_DPP>
-__device__ __forceinline__ uint32_t find_in_blocks(const uint8_t *idx, const TermRef &tr,
-                                                   uint32_t jb, uint32_t doc, bool alive,
-                                                   AndLdsT<false> &L, int lane) {
-  uint32_t at = NOT_FOUND;
+// TFS = false: `key` is a doc id, the result is its slot in block jb (or NOT_FOUND).
+// TFS = true (phrase queries): `key` is a slot; the block's term freqs are decoded instead and
+// the result is the posting's tf, with *excl = sum of the tfs before it (its first position's
+// index inside the block, segment_postings.rs:232-254).
+template <bool TFS>
+__device__ __forceinline__ uint32_t lookup_in_blocks(const uint8_t *idx, const TermRef &tr,
+                                                     uint32_t jb, uint32_t key, bool alive,
+                                                     uint32_t *P, int lane, uint32_t *excl) {
+  uint32_t result = NOT_FOUND;
   uint64_t pend = __ballot(alive);
   const uint32_t row = (uint32_t)lane >> 4, l16 = (uint32_t)lane & 15u;
-  uint32_t *const P = L.pay;  // 4 regions of 128 words: payload, then the decoded doc ids
+  // P: 4 regions of 128 words — the payload, then the decoded values
   while (pend) {
     // ---- up to four distinct blocks among the pending candidates
     uint32_t js[4] = {0u, 0u, 0u, 0u};
@@ -592,19 +568,21 @@ __device__ __forceinline__ uint32_t find_in_blocks(const uint8_t *idx, const Ter
     uint32_t prev = 0;
     if (row_on) {
       rec = tr.rec[my_j];
-      if (my_j) prev = tr.rec[my_j - 1u].x;
+      if (!TFS && my_j) prev = tr.rec[my_j - 1u].x;
     }
     const bool is_tail = rec.y == META_TAIL;
-    const uint32_t b = is_tail ? 0u : rec.y & 31u;
+    const uint32_t doc_bits = rec.y & 31u;
+    // width of the stream to unpack: doc deltas (<= 31 bits, skip.rs:16-22) or tfs (<= 32)
+    const uint32_t b = is_tail ? 0u : (TFS ? (tr.has_freq ? (rec.y >> 8) & 0xFFu : 0u) : doc_bits);
     const uint32_t strict = is_tail ? 0u : (rec.y >> 6) & 1u;
     wave_mem_fence();
     if (row_on && !is_tail) {
-      const uint8_t *src = idx + tr.payload_base + rec.z + 16u * l16;
-      if (16u * l16 < 16u * b) {
+      const uint8_t *src = idx + tr.payload_base + rec.z + (TFS ? 16u * doc_bits : 0u) + 16u * l16;
+      if (l16 < b) {
         const U4Unaligned v = *reinterpret_cast<const U4Unaligned *>(src);
         *reinterpret_cast<uint4 *>(P + row * 128u + 4u * l16) = make_uint4(v.x, v.y, v.z, v.w);
       }
-      if (256u + 16u * l16 < 16u * b) {
+      if (16u + l16 < b) {
         const U4Unaligned v = *reinterpret_cast<const U4Unaligned *>(src + 256);
         *reinterpret_cast<uint4 *>(P + row * 128u + 64u + 4u * l16) =
             make_uint4(v.x, v.y, v.z, v.w);
@@ -613,40 +591,51 @@ __device__ __forceinline__ uint32_t find_in_blocks(const uint8_t *idx, const Ter
     wave_mem_fence();
     uint32_t d[8];
     {
-      const uint32_t mask = (1u << b) - 1u;  // b <= 31 for doc ids (skip.rs:16-22)
+      const uint32_t mask = b >= 32u ? 0xFFFFFFFFu : (1u << b) - 1u;
+      // a tf stream without stored bits (or without freqs) reads as tf = strict ? 1 : 0 -> 1
+      const uint32_t add = TFS ? ((tr.has_freq && !is_tail) ? strict : 1u) : strict;
 #pragma unroll
       for (uint32_t kk = 0; kk < 2u; ++kk) {
         const uint32_t bitpos = (2u * l16 + kk) * b;
         const uint32_t w = bitpos >> 5, sh = bitpos & 31u;
         const uint4 lo = *reinterpret_cast<const uint4 *>(P + row * 128u + 4u * w);
         const uint4 hi = *reinterpret_cast<const uint4 *>(P + row * 128u + 4u * w + 4u);
-        d[4 * kk + 0] = (__funnelshift_r(lo.x, hi.x, sh) & mask) + strict;
-        d[4 * kk + 1] = (__funnelshift_r(lo.y, hi.y, sh) & mask) + strict;
-        d[4 * kk + 2] = (__funnelshift_r(lo.z, hi.z, sh) & mask) + strict;
-        d[4 * kk + 3] = (__funnelshift_r(lo.w, hi.w, sh) & mask) + strict;
+        d[4 * kk + 0] = (__funnelshift_r(lo.x, hi.x, sh) & mask) + add;
+        d[4 * kk + 1] = (__funnelshift_r(lo.y, hi.y, sh) & mask) + add;
+        d[4 * kk + 2] = (__funnelshift_r(lo.z, hi.z, sh) & mask) + add;
+        d[4 * kk + 3] = (__funnelshift_r(lo.w, hi.w, sh) & mask) + add;
       }
     }
-#pragma unroll
-    for (int e = 1; e < 8; ++e) d[e] += d[e - 1];
-    uint32_t incl = d[7];
-    incl += dpp_get<0x111, 0xF>(incl);  // row_shr:1 .. 8: inclusive scan inside the 16-lane row
-    incl += dpp_get<0x112, 0xF>(incl);
-    incl += dpp_get<0x114, 0xF>(incl);
-    incl += dpp_get<0x118, 0xF>(incl);
-    // compression/mod.rs:36-39,112-121: offset 0 <=> None <=> seed u32::MAX (wrapping)
-    const uint32_t base = ((strict && prev == 0u) ? 0xFFFFFFFFu : prev) + (incl - d[7]);
-#pragma unroll
-    for (int e = 0; e < 8; ++e) d[e] += base;
     if (__ballot(row_on && is_tail)) {  // the pre-decoded vint tail of the list
       if (row_on && is_tail) {
 #pragma unroll
         for (uint32_t e = 0; e < 8u; ++e) {
           const uint32_t i = 8u * l16 + e;
-          d[e] = i < tr.n_tail ? tr.tail_docs[i] : TQD_TERMINATED;
+          if (TFS)
+            d[e] = i < tr.n_tail ? (tr.has_freq ? tr.tail_tfs[i] : 1u) : 0u;
+          else
+            d[e] = i < tr.n_tail ? tr.tail_docs[i] : TQD_TERMINATED;
         }
       }
     }
-    wave_mem_fence();  // every lane has read its payload words: the doc ids may overwrite them
+    if (TFS || !is_tail) {  // (uniform per 16-lane row)
+      // prefix sum: local, then 4 DPP row shifts inside the 16-lane row
+      uint32_t loc[8];
+      loc[0] = d[0];
+#pragma unroll
+      for (int e = 1; e < 8; ++e) loc[e] = loc[e - 1] + d[e];
+      uint32_t incl = loc[7];
+      incl += dpp_get<0x111, 0xF>(incl);
+      incl += dpp_get<0x112, 0xF>(incl);
+      incl += dpp_get<0x114, 0xF>(incl);
+      incl += dpp_get<0x118, 0xF>(incl);
+      // docs: compression/mod.rs:36-39,112-121: offset 0 <=> None <=> seed u32::MAX (wrapping)
+      const uint32_t base =
+          (TFS ? 0u : ((strict && prev == 0u) ? 0xFFFFFFFFu : prev)) + (incl - loc[7]);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) d[e] = loc[e] + base;
+    }
+    wave_mem_fence();  // every lane has read its payload words: the values may overwrite them
     if (row_on) {
       *reinterpret_cast<uint4 *>(P + row * 128u + 8u * l16) = make_uint4(d[0], d[1], d[2], d[3]);
       *reinterpret_cast<uint4 *>(P + row * 128u + 8u * l16 + 4u) =
@@ -655,14 +644,28 @@ __device__ __forceinline__ uint32_t find_in_blocks(const uint8_t *idx, const Ter
     wave_mem_fence();
     if (gid < 4u) {
       const uint32_t *blk = P + gid * 128u;
-      uint32_t pos = 0;
+      if (TFS) {  // inclusive tf prefix sums: tf = I[at] - I[at-1]
+        const uint32_t hi_v = blk[key];
+        const uint32_t lo_v = key ? blk[key - 1u] : 0u;
+        result = hi_v - lo_v;
+        *excl = lo_v;
+      } else {
+        uint32_t pos = 0;
 #pragma unroll
-      for (uint32_t step = 64u; step > 0u; step >>= 1)
-        if (blk[pos + step - 1u] < doc) pos += step;
-      at = blk[pos] == doc ? pos : NOT_FOUND;
+        for (uint32_t step = 64u; step > 0u; step >>= 1)
+          if (blk[pos + step - 1u] < key) pos += step;
+        result = blk[pos] == key ? pos : NOT_FOUND;
+      }
     }
   }
-  return at;
+  return result;
+}
+template <bool USE_DPP>
+__device__ __forceinline__ uint32_t find_in_blocks(const uint8_t *idx, const TermRef &tr,
+                                                   uint32_t jb, uint32_t doc, bool alive,
+                                                   AndLdsT<false> &L, int lane) {
+  uint32_t unused;
+  return lookup_in_blocks<false>(idx, tr, jb, doc, alive, L.pay, lane, &unused);
 }
 
 template <int KPL, bool PRUNE, bool DENSE>
@@ -1320,31 +1323,51 @@ __global__ __launch_bounds__(TQD_WAVES_PER_WG * 64) void or_kernel(TqkScanParams
   if (lane == 0 && n_matches) atomicAdd(p.match_counter, (unsigned long long)n_matches);
 }
 
-// positions: raw deltas of a whole term (PositionReader::read over everything)
+// positions: raw deltas of a whole term (PositionReader::read over everything).  pos_blk[pb] =
+// absolute byte offset of position block pb | bit width << 56 (positions/reader.rs:84-101).
 __device__ __forceinline__ uint32_t position_delta(const uint8_t *pos, const TqdTerm *t,
                                                    uint64_t i) {
   const uint64_t pb = i >> 7;
-  if (pb < t->n_pos_blocks)
-    return unpack_one(pos + t->pos_block_off[pb], t->pos_widths[pb], (uint32_t)(i & 127u));
+  if (pb < t->n_pos_blocks) {
+    const uint64_t e = t->pos_blk[pb];
+    const uint32_t b = (uint32_t)(e >> 56);
+    if (b == 0u) return 0u;
+    const uint8_t *p = pos + (e & 0x00FFFFFFFFFFFFFFull);
+    const uint32_t v = (uint32_t)(i & 127u);
+    const uint32_t bitpos = (v >> 2) * b;
+    const uint32_t w = bitpos >> 5, sh = bitpos & 31u;
+    const uint8_t *q = p + 16u * w + 4u * (v & 3u);
+    const uint32_t lo = ld_u1(q);
+    uint32_t hi = 0;
+    if (sh + b > 32u) hi = ld_u1(q + 16);  // the value straddles two words of its stream
+    const uint32_t mask = (b >= 32u) ? 0xFFFFFFFFu : ((1u << b) - 1u);
+    return __funnelshift_r(lo, hi, sh) & mask;
+  }
   return t->pos_tail[i - ((uint64_t)t->n_pos_blocks << 7)];
 }
 
 // =================================================================== phrase kernel
-// Exact phrase (slop 0).  One wavefront per workgroup.  Doc candidates come from the same
-// leader-hash / stream-probe intersection as the AND kernel; every (term, candidate) records the
-// index of the doc's first position in the term's position stream and its tf.  Complete
-// candidates are then checked lane-per-candidate with an n-way merge over adjusted positions
-// (position + max_offset - term_offset, phrase_scorer.rs:372-385), fetching single bitpacked
-// deltas by index (positions/reader.rs:84-101).  count = intersection_count (:437-461).
-#define TQD_PH_CH 2
-#define TQD_PH_CAP (TQD_PH_CH * 128)
+// Exact phrase (slop 0), PhraseScorer (src/query/phrase_query/phrase_scorer.rs:82-136,347-507).
+// Built on the AND kernel's stages: terms by doc freq ascending, leader-block tiles, one
+// wavefront per chunk, candidates flowing through LDS queues.  Besides doc and tf every candidate
+// carries the index of its first position in the leader's position stream (block's first position
+// from the block record + exclusive prefix sum of the block's tfs: segment_postings.rs:232-254).
+//   A  decode a leader block: docs, tfs and the tf prefix sum;
+//   B  locate the candidate in list 1 (bitmap, or O(1) seek_block);
+//   C  for every other list: membership (bitmap / find_in_blocks), then tf and position index
+//      through lookup_in_blocks<TFS> (the block's tf stream prefix-summed, 4 blocks per step);
+//      finally one lane per candidate runs the n-way merge over adjusted positions
+//      (position + max_offset - term_offset, :372-385; count = intersection_count, :437-461),
+//      fetching single bitpacked deltas by index, and scores bm25(sum-idf weight, norm, count).
+// The reference runs phrases through the default for_each_pruning_scorer (a threshold filter on
+// finished scores), so there is nothing to prune before the positions are read.
 #define TQD_PH_MAX_TERMS 8
-struct PhraseLds {
-  WaveTable tb;
-  uint32_t cand_doc[TQD_PH_CAP];
-  uint32_t cand_cnt[TQD_PH_CAP];
-  uint32_t pidx[TQD_PH_MAX_TERMS][TQD_PH_CAP];
-  uint32_t ptf[TQD_PH_MAX_TERMS][TQD_PH_CAP];
+struct PhraseLds {  // per wavefront
+  uint32_t pay[516];  // lookup_in_blocks' staging area
+  uint32_t q1_doc[191], q1_tf[191], q1_pi[191];
+  uint32_t q2_doc[127], q2_tf[127], q2_pi[127], q2_loc[127];
+  uint32_t ph_pi[TQD_PH_MAX_TERMS][64], ph_tf[TQD_PH_MAX_TERMS][64];
+  float cache[256];
 };
 
 struct PosCursor {
@@ -1364,190 +1387,263 @@ template <int KPL, bool USE_DPP>
 __global__ __launch_bounds__(64) void phrase_kernel(TqkScanParams p) {
   __shared__ PhraseLds L;
   const int lane = (int)__lane_id();
-  WaveTable &tb = L.tb;
-  for (int i = lane; i < TQD_PH_SLOTS; i += WAVE) tb.doc[i] = EMPTY_SLOT;
-  wave_mem_fence();
-  const uint32_t chunk = blockIdx.x;
-  if (chunk >= p.n_chunks) return;
+  if (blockIdx.x >= p.n_chunks) return;
+  const uint32_t chunk = sload(p.chunk_perm + blockIdx.x);
   const uint32_t t_begin = sload(p.chunk_starts + chunk);
   const uint32_t t_end = sload(p.chunk_starts + chunk + 1u);
   const TqdSegment seg = p.seg;
-  const uint8_t *idx = uni_ptr(seg.idx);
-  const uint8_t *pos = uni_ptr(seg.pos);
+  const uint8_t *idx = seg.idx;
+  const uint8_t *pos = seg.pos;
 
-  uint32_t q = find_query(p.tile_starts, p.n_queries, t_begin);
-  uint32_t q_tile_start = uni(p.tile_starts[q]);
-  uint32_t q_tile_end = uni(p.tile_starts[q + 1]);
-  const TqdQuery *Q = uni_ptr(p.queries + q);
+  uint32_t q = uni(find_query(p.tile_starts, p.n_queries, t_begin));
+  uint32_t q_tile_start = 0, q_tile_end = 0;
+  const TqdQuery *Q = nullptr;
+  uint32_t nt = 0, tile_blocks = TQD_AND_TILE;
+  TermRef lead{}, t1{};
+  float weight = 0.0f;
+  uint32_t cache_loaded = 0xFFFFFFFFu;
   TopK<KPL> tk;
-  tk.reset(uni(Q->k));
   uint32_t n_matches = 0;
+  uint32_t q1n = 0, q2n = 0;
 
+  auto setup_query = [&]() {
+    q_tile_start = sload(p.tile_starts + q);
+    q_tile_end = sload(p.tile_starts + q + 1u);
+    Q = p.queries + q;
+    nt = sload(&Q->n_terms);
+    tile_blocks = sload(&Q->tile_blocks);
+    lead = load_term(p.terms, sload(&Q->term[0]));
+    t1 = load_term(p.terms, sload(&Q->term[1]));
+    if (!p.use_dense) t1.dense = nullptr;
+    weight = sload(&Q->weight[0]);
+    const uint32_t ci = sload(&Q->cache_idx);
+    if (ci != cache_loaded) {
+      const float *cg = p.caches + (size_t)ci * 256u;
+      wave_mem_fence();
+      for (int i = lane; i < 256; i += WAVE) L.cache[i] = cg[i];
+      wave_mem_fence();
+      cache_loaded = ci;
+    }
+    tk.reset(sload(&Q->k));
+  };
+
+  // ---- stage C: the other lists' postings of the candidate, then the positions
+  auto stageC = [&](uint32_t n) {
+    const uint32_t base = q2n - n;
+    q2n = base;
+    bool alive = (uint32_t)lane < n;
+    uint32_t doc = 0, loc = 0;
+    if (alive) {
+      doc = L.q2_doc[base + lane];
+      loc = L.q2_loc[base + lane];
+      L.ph_tf[0][lane] = L.q2_tf[base + lane];
+      L.ph_pi[0][lane] = L.q2_pi[base + lane];
+    }
+    for (uint32_t m = 1; m < nt; ++m) {
+      TermRef tr = m == 1u ? t1 : load_term(p.terms, sload(&Q->term[m]));
+      if (!p.use_dense) tr.dense = nullptr;
+      uint32_t jb = 0, at = NOT_FOUND;
+      if (m == 1u) {
+        if (tr.dense) {
+          jb = loc >> 7;
+          at = loc & 127u;
+        } else {
+          jb = loc;
+        }
+      } else if (tr.dense) {
+        if (alive) {
+          const uint2 wd = tr.dense[doc >> 5];
+          const uint32_t bit = doc & 31u;
+          alive = (wd.x >> bit) & 1u;
+          const uint32_t pi = wd.y + (uint32_t)__popc(wd.x & ((1u << bit) - 1u));
+          jb = pi >> 7;
+          at = pi & 127u;
+        }
+      } else if (alive) {
+        jb = seek_block(tr, doc);
+        alive = jb < tr.n_blocks;
+      }
+      if (!tr.dense) {
+        uint32_t unused;
+        at = lookup_in_blocks<false>(idx, tr, jb, doc, alive, L.pay, lane, &unused);
+        alive = alive && at != NOT_FOUND;
+      }
+      if (!__ballot(alive)) return;
+      uint32_t excl = 0;
+      const uint32_t tf = lookup_in_blocks<true>(idx, tr, jb, at, alive, L.pay, lane, &excl);
+      if (alive) {
+        L.ph_tf[m][lane] = tf;
+        L.ph_pi[m][lane] = tr.rec[jb].w + excl;
+      }
+    }
+    // ---- position check, one lane per candidate
+    bool has = false;
+    uint64_t key = 0;
+    if (alive) {
+      PosCursor cur[TQD_PH_MAX_TERMS];
+#pragma unroll
+      for (int m = 0; m < TQD_PH_MAX_TERMS; ++m) {
+        cur[m].valid = false;
+        cur[m].idx = cur[m].end = cur[m].cur = 0;
+        if ((uint32_t)m < nt) {
+          const uint32_t pi = L.ph_pi[m][lane];
+          cur[m].idx = pi + 1u;
+          cur[m].end = pi + L.ph_tf[m][lane];
+          cur[m].cur = Q->phrase_off[m] + position_delta(pos, p.terms + Q->term[m], pi);
+          cur[m].valid = true;
+        }
+      }
+      uint32_t count = 0;
+      bool done = false;
+      while (cur[0].valid && !done) {
+        const uint32_t a = cur[0].cur;
+        bool ok = true;
+#pragma unroll
+        for (int m = 1; m < TQD_PH_MAX_TERMS; ++m) {
+          if ((uint32_t)m < nt && !done) {
+            while (cur[m].valid && cur[m].cur < a) pos_advance(cur[m], pos, p.terms + Q->term[m]);
+            if (!cur[m].valid)
+              done = true;
+            else if (cur[m].cur != a)
+              ok = false;
+          }
+        }
+        if (done) break;
+        if (ok) {
+          ++count;
+#pragma unroll
+          for (int m = 1; m < TQD_PH_MAX_TERMS; ++m)
+            if ((uint32_t)m < nt) pos_advance(cur[m], pos, p.terms + Q->term[m]);
+        }
+        pos_advance(cur[0], pos, p.terms + Q->term[0]);
+      }
+      if (count > 0) {
+        has = true;
+        key = make_key(bm25(weight, L.cache[fieldnorm_id(seg, doc)], count), doc);
+      }
+    }
+    const uint64_t hit = __ballot(has);
+    if (hit) {
+      n_matches += (uint32_t)__popcll(hit);
+      tk.offer(has, key, lane);
+    }
+  };
+
+  // ---- stage B: locate the candidate in list 1
+  auto stageB = [&](uint32_t n) {
+    const uint32_t base = q1n - n;
+    q1n = base;
+    bool alive = (uint32_t)lane < n;
+    uint32_t doc = 0, tf = 0, pi0 = 0, loc = 0;
+    if (alive) {
+      doc = L.q1_doc[base + lane];
+      tf = L.q1_tf[base + lane];
+      pi0 = L.q1_pi[base + lane];
+    }
+    if (t1.dense) {
+      if (alive) {
+        const uint2 wd = t1.dense[doc >> 5];
+        const uint32_t bit = doc & 31u;
+        alive = (wd.x >> bit) & 1u;
+        loc = wd.y + (uint32_t)__popc(wd.x & ((1u << bit) - 1u));
+      }
+    } else if (alive) {
+      loc = seek_block(t1, doc);
+      alive = loc < t1.n_blocks;
+    }
+    const uint64_t m = __ballot(alive);
+    if (m) {
+      const uint32_t at = q2n + mbcnt64(m);
+      wave_mem_fence();
+      if (alive) {
+        L.q2_doc[at] = doc;
+        L.q2_tf[at] = tf;
+        L.q2_pi[at] = pi0;
+        L.q2_loc[at] = loc;
+      }
+      wave_mem_fence();
+      q2n += (uint32_t)__popcll(m);
+    }
+  };
+
+  auto drain = [&]() {
+    while (q1n) {
+      stageB(q1n < 64u ? q1n : 64u);
+      while (q2n >= 64u) stageC(64u);
+    }
+    while (q2n) stageC(q2n < 64u ? q2n : 64u);
+  };
+
+  setup_query();
   for (uint32_t t = t_begin; t < t_end; ++t) {
     while (t >= q_tile_end) {
       if (q_tile_end > q_tile_start && q_tile_end > t_begin) {
-        const uint32_t part = uni(Q->part_start) + (chunk - sload(&Q->chunk_first));
+        drain();
+        const uint32_t part = sload(&Q->part_start) + (chunk - sload(&Q->chunk_first));
         flush_partial<KPL>(tk, p.partials, part, lane);
       }
       ++q;
-      q_tile_start = q_tile_end;
-      q_tile_end = uni(p.tile_starts[q + 1]);
-      Q = uni_ptr(p.queries + q);
-      tk.reset(uni(Q->k));
+      setup_query();
     }
-    const uint32_t nt = uni(Q->n_terms);
-    const float *cache = uni_ptr(p.caches + (size_t)uni(Q->cache_idx) * 256u);
-    const float weight = __uint_as_float(uni(__float_as_uint(Q->weight[0])));
-    const uint32_t h_lead = uni(Q->term[0]), h_drv = uni(Q->term[nt - 1]);
-    const TermRef lead = load_term(p.terms, h_lead);
-    const TermRef drv = load_term(p.terms, h_drv);
-
-    const uint32_t tl = t - q_tile_start;
-    const uint32_t j0 = tl * TQD_PH_M;
-    uint32_t j1 = j0 + TQD_PH_M;
-    if (j1 > drv.n_blocks) j1 = drv.n_blocks;
-    const uint32_t lo1 = block_first_possible(drv, j0);
-    const uint32_t hi = sload(&drv.rec[j1 - 1].x);
-    const uint32_t i0 = lower_bound_block(lead, lo1, lane);
-    if (i0 >= lead.n_blocks) continue;
-    uint32_t iL = lower_bound_block(lead, hi, lane);
-    if (iL >= lead.n_blocks) iL = lead.n_blocks - 1u;
-
-    for (uint32_t ia = i0; ia <= iL; ia += TQD_PH_CH) {
-      uint32_t ib = ia + TQD_PH_CH - 1u;
-      if (ib > iL) ib = iL;
-      uint32_t sub_lo1 = block_first_possible(lead, ia);
-      if (sub_lo1 < lo1) sub_lo1 = lo1;
-      uint32_t sub_hi = hi;
-      if (ib != iL) {
-        const uint32_t l = sload(&lead.rec[ib].x);
-        if (l < sub_hi) sub_hi = l;
-      }
-      // ---- fill from the leader
-      uint32_t my_slot[TQD_PH_CH * 2];
-#pragma unroll
-      for (int c = 0; c < TQD_PH_CH; ++c) {
-        my_slot[2 * c] = EMPTY_SLOT;
-        my_slot[2 * c + 1] = EMPTY_SLOT;
-        const uint32_t ca = (uint32_t)c * 128u + 2u * (uint32_t)lane;
-        L.cand_cnt[ca] = 0x80000000u;
-        L.cand_cnt[ca + 1u] = 0x80000000u;
-        if (ia + (uint32_t)c <= ib) {
-          uint32_t e0, e1;
-          const Dec d = decode_block<USE_DPP, true>(idx, lead, ia + (uint32_t)c, lane, &e0, &e1);
-          const uint32_t bp = sload(&lead.rec[ia + (uint32_t)c].w);
-          if (d.d0 >= sub_lo1 && d.d0 <= sub_hi) {
-            L.cand_doc[ca] = d.d0;
-            L.cand_cnt[ca] = 0u;
-            L.pidx[0][ca] = bp + e0;
-            L.ptf[0][ca] = d.t0;
-            my_slot[2 * c] = ht_insert(tb, d.d0, ca);
-          }
-          if (d.d1 >= sub_lo1 && d.d1 <= sub_hi) {
-            L.cand_doc[ca + 1u] = d.d1;
-            L.cand_cnt[ca + 1u] = 0u;
-            L.pidx[0][ca + 1u] = bp + e1;
-            L.ptf[0][ca + 1u] = d.t1;
-            my_slot[2 * c + 1] = ht_insert(tb, d.d1, ca + 1u);
-          }
-        }
-      }
-      wave_mem_fence();
-      // ---- every other term (middle lists searched, the driver restricted to the tile)
+    // ---- pre-filter: lane <-> leader block; drop blocks past the end of another list
+    const uint32_t i_base = (t - q_tile_start) * tile_blocks;
+    const uint32_t i_mine = i_base + (uint32_t)lane;
+    bool surv = (uint32_t)lane < tile_blocks && i_mine < lead.n_blocks;
+    uint4 rec_mine = make_uint4(0u, 0u, 0u, 0u);
+    uint32_t prev_mine = 0;
+    {
+      if (surv) rec_mine = lead.rec[i_mine];
+      prev_mine = __shfl_up(rec_mine.x, 1, WAVE);
+      if (lane == 0) prev_mine = block_prev_last(lead, i_base);
+      const uint32_t first = i_mine ? prev_mine + 1u : 0u;
       for (uint32_t m = 1; m < nt; ++m) {
-        const uint32_t h_m = uni(Q->term[m]);
-        const TermRef tr = load_term(p.terms, h_m);
-        uint32_t jb, jend;
-        if (m + 1 == nt) {
-          jb = j0;
-          jend = j1;
-        } else {
-          jb = lower_bound_block(tr, sub_lo1, lane);
-          jend = tr.n_blocks;
-        }
-        for (uint32_t j = jb; j < jend; ++j) {
-          if (sload(&tr.rec[j].x) < sub_lo1) continue;
-          if (block_first_possible(tr, j) > sub_hi) break;
-          uint32_t e0, e1;
-          const Dec d = decode_block<USE_DPP, true>(idx, tr, j, lane, &e0, &e1);
-          const uint32_t bp = sload(&tr.rec[j].w);
-#pragma unroll
-          for (int e = 0; e < 2; ++e) {
-            const uint32_t doc = e ? d.d1 : d.d0;
-            uint32_t slot;
-            if (doc >= sub_lo1 && doc <= sub_hi && ht_find(tb, doc, slot)) {
-              const uint32_t c = tb.val[slot];
-              L.pidx[m][c] = bp + (e ? e1 : e0);
-              L.ptf[m][c] = e ? d.t1 : d.t0;
-              L.cand_cnt[c] = L.cand_cnt[c] + 1u;
-            }
-          }
-          wave_mem_fence();
-        }
+        const TermRef tr = m == 1u ? t1 : load_term(p.terms, sload(&Q->term[m]));
+        if (surv) surv = seek_block(tr, first) < tr.n_blocks;
       }
-      // ---- position check, lane per candidate
-      const uint32_t n_cand = (ib - ia + 1u) * 128u;
-      for (uint32_t c0 = 0; c0 < n_cand; c0 += 64u) {
-        const uint32_t c = c0 + (uint32_t)lane;
-        bool has = false;
-        uint64_t key = 0;
-        if (L.cand_cnt[c] == nt - 1u) {
-          PosCursor cur[TQD_PH_MAX_TERMS];
-#pragma unroll
-          for (int m = 0; m < TQD_PH_MAX_TERMS; ++m) {
-            cur[m].valid = false;
-            cur[m].idx = cur[m].end = cur[m].cur = 0;
-            if ((uint32_t)m < nt) {
-              const uint32_t pi = L.pidx[m][c];
-              cur[m].idx = pi + 1u;
-              cur[m].end = pi + L.ptf[m][c];
-              cur[m].cur = Q->phrase_off[m] + position_delta(pos, p.terms + Q->term[m], pi);
-              cur[m].valid = true;
-            }
-          }
-          uint32_t count = 0;
-          bool done = false;
-          while (cur[0].valid && !done) {
-            const uint32_t a = cur[0].cur;
-            bool ok = true;
-#pragma unroll
-            for (int m = 1; m < TQD_PH_MAX_TERMS; ++m) {
-              if ((uint32_t)m < nt && !done) {
-                while (cur[m].valid && cur[m].cur < a) pos_advance(cur[m], pos, p.terms + Q->term[m]);
-                if (!cur[m].valid)
-                  done = true;
-                else if (cur[m].cur != a)
-                  ok = false;
-              }
-            }
-            if (done) break;
-            if (ok) {
-              ++count;
-#pragma unroll
-              for (int m = 1; m < TQD_PH_MAX_TERMS; ++m)
-                if ((uint32_t)m < nt) pos_advance(cur[m], pos, p.terms + Q->term[m]);
-            }
-            pos_advance(cur[0], pos, p.terms + Q->term[0]);
-          }
-          if (count > 0) {
-            const uint32_t doc = L.cand_doc[c];
-            has = true;
-            key = make_key(bm25(weight, cache[fieldnorm_id(seg, doc)], count), doc);
-          }
-        }
-        n_matches += (uint32_t)__popcll(__ballot(has));
-        tk.offer(has, key, lane);
+    }
+    uint64_t todo = __ballot(surv);
+    // ---- stage A per surviving leader block
+    while (todo) {
+      const uint32_t b = (uint32_t)__builtin_ctzll(todo);
+      todo &= todo - 1ull;
+      const uint2 mo_l = make_uint2((uint32_t)__builtin_amdgcn_readlane((int)rec_mine.y, (int)b),
+                                    (uint32_t)__builtin_amdgcn_readlane((int)rec_mine.z, (int)b));
+      const uint32_t bp = (uint32_t)__builtin_amdgcn_readlane((int)rec_mine.w, (int)b);
+      const uint32_t prev_l = (uint32_t)__builtin_amdgcn_readlane((int)prev_mine, (int)b);
+      uint32_t c0, c1, t0, t1f;
+      decode_docs<USE_DPP>(idx, lead, mo_l, prev_l, lane, c0, c1);
+      decode_tfs(idx, lead, mo_l, lane, t0, t1f);  // tail padding reads as tf 0
+      const uint32_t ssum = t0 + t1f;
+      const uint32_t incl = wave_inclusive_scan<USE_DPP>(ssum, lane);
+      const uint32_t e0 = bp + (incl - ssum), e1 = e0 + t0;
+      const bool alive0 = c0 != TQD_TERMINATED, alive1 = c1 != TQD_TERMINATED;
+      const uint64_t m0 = __ballot(alive0), m1 = __ballot(alive1);
+      if (!(m0 | m1)) continue;
+      const uint32_t n0 = (uint32_t)__popcll(m0);
+      const uint32_t pos0 = q1n + mbcnt64(m0);
+      const uint32_t pos1 = q1n + n0 + mbcnt64(m1);
+      wave_mem_fence();
+      if (alive0) {
+        L.q1_doc[pos0] = c0;
+        L.q1_tf[pos0] = t0;
+        L.q1_pi[pos0] = e0;
       }
-      // ---- clear
+      if (alive1) {
+        L.q1_doc[pos1] = c1;
+        L.q1_tf[pos1] = t1f;
+        L.q1_pi[pos1] = e1;
+      }
       wave_mem_fence();
-#pragma unroll
-      for (int c = 0; c < TQD_PH_CH * 2; ++c)
-        if (my_slot[c] != EMPTY_SLOT) tb.doc[my_slot[c]] = EMPTY_SLOT;
-      wave_mem_fence();
+      q1n += n0 + (uint32_t)__popcll(m1);
+      while (q1n >= 64u) {
+        stageB(64u);
+        while (q2n >= 64u) stageC(64u);
+      }
     }
   }
   if (q_tile_end > q_tile_start) {
-    const uint32_t part = uni(Q->part_start) + (chunk - sload(&Q->chunk_first));
+    drain();
+    const uint32_t part = sload(&Q->part_start) + (chunk - sload(&Q->chunk_first));
     flush_partial<KPL>(tk, p.partials, part, lane);
   }
   if (lane == 0 && n_matches) atomicAdd(p.match_counter, (unsigned long long)n_matches);
