@@ -1021,6 +1021,7 @@ int tq_search_batch_device(tq_segment *s, const tq_query *queries, uint32_t n_qu
     p.exhaustive = (uint32_t)s->opt.exhaustive;
     p.use_dense = (uint32_t)s->opt.use_dense;
     p.all_dense = gi == 0 ? 1u : 0u;
+    p.debug = tune_u32("TQ_DEBUG", 0);
     tiles_total += g.total_tiles;
     chunks_total += g.n_chunks;
     hipError_t e = hipSuccess;

@@ -696,7 +696,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_num_sgpr(80))) void and_k
   uint32_t n_matches = 0;
   uint32_t q1n = 0, q2n = 0;  // queue fill
 
-  auto setup_query = [&]() {
+  auto setup_query = [&]() __attribute__((always_inline)) {
     q_tile_start = sload(p.tile_starts + q);
     q_tile_end = sload(p.tile_starts + q + 1u);
     Q = p.queries + q;
@@ -730,7 +730,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_num_sgpr(80))) void and_k
   };
 
   // ---- stage C: verify in list 1, score, remaining lists, collect
-  auto stageC = [&](uint32_t n) {
+  auto stageC = [&](uint32_t n) __attribute__((always_inline)) {
     const uint32_t base = q2n - n;
     q2n = base;
     bool alive = (uint32_t)lane < n;
@@ -819,7 +819,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_num_sgpr(80))) void and_k
   // ---- stage B: locate in list 1.  Dense list: the bitmap answers membership, which is the
   // strongest filter there is, so nothing else is looked at first.  Other lists: pruned mode
   // scores the leader exactly (one fieldnorm gather) before paying for the seek.
-  auto stageB = [&](uint32_t n) {
+  auto stageB = [&](uint32_t n) __attribute__((always_inline)) {
     const uint32_t base = q1n - n;
     q1n = base;
     bool alive = (uint32_t)lane < n;
@@ -859,7 +859,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_num_sgpr(80))) void and_k
     }
   };
 
-  auto drain = [&]() {
+  auto drain = [&]() __attribute__((always_inline)) {
     while (q1n) {
       stageB(q1n < 64u ? q1n : 64u);
       while (q2n >= 64u) stageC(64u);
@@ -936,7 +936,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_num_sgpr(80))) void and_k
       if (prune && surv) {
         // smallest tf whose tf-only score bound (norm replaced by its lower bound) can reach the
         // threshold inside this block: stage A then compares integers instead of scoring 128 docs
-        auto pass = [&](uint32_t tfv) {
+        auto pass = [&](uint32_t tfv) __attribute__((always_inline)) {
           return sortable(bm25(w_lead, min_norm, tfv) + rest_mine) >= thr;
         };
         if (!pass(0xFFFFFFFFu)) {
@@ -958,7 +958,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_num_sgpr(80))) void and_k
     uint64_t todo = __ballot(surv);
 
     // ---- stage A per surviving leader block
-    auto stageA = [&](uint32_t b) {
+    auto stageA = [&](uint32_t b) __attribute__((always_inline)) {
       const uint2 mo_l = make_uint2((uint32_t)__builtin_amdgcn_readlane((int)mo_mine.x, (int)b),
                                     (uint32_t)__builtin_amdgcn_readlane((int)mo_mine.y, (int)b));
       const uint32_t prev_l = (uint32_t)__builtin_amdgcn_readlane((int)prev_mine, (int)b);
@@ -1101,7 +1101,7 @@ __global__ __launch_bounds__(TQD_WAVES_PER_WG * 64) void or_kernel(TqkScanParams
   uint32_t cqn = 0;  // this wave's candidate queue fill
   uint32_t plan_begin = 0xFFFFFFFFu, plan_end = 0;  // windows [plan_begin, plan_end) are planned
 
-  auto setup_query = [&]() {
+  auto setup_query = [&]() __attribute__((always_inline)) {
     q_tile_start = sload(p.tile_starts + q);
     q_tile_end = sload(p.tile_starts + q + 1u);
     Q = p.queries + q;
@@ -1141,7 +1141,7 @@ __global__ __launch_bounds__(TQD_WAVES_PER_WG * 64) void or_kernel(TqkScanParams
   };
 
   // probe the non-essential lists [E, nt) for a batch of <= 64 candidates (one per lane)
-  auto probe_batch = [&](uint32_t n, uint32_t E) {
+  auto probe_batch = [&](uint32_t n, uint32_t E) __attribute__((always_inline)) {
     const uint32_t base = cqn - n;
     cqn = base;
     bool alive = (uint32_t)lane < n;
@@ -1406,7 +1406,7 @@ __global__ __launch_bounds__(64) void phrase_kernel(TqkScanParams p) {
   uint32_t n_matches = 0;
   uint32_t q1n = 0, q2n = 0;
 
-  auto setup_query = [&]() {
+  auto setup_query = [&]() __attribute__((always_inline)) {
     q_tile_start = sload(p.tile_starts + q);
     q_tile_end = sload(p.tile_starts + q + 1u);
     Q = p.queries + q;
@@ -1428,7 +1428,7 @@ __global__ __launch_bounds__(64) void phrase_kernel(TqkScanParams p) {
   };
 
   // ---- stage C: the other lists' postings of the candidate, then the positions
-  auto stageC = [&](uint32_t n) {
+  auto stageC = [&](uint32_t n) __attribute__((always_inline)) {
     const uint32_t base = q2n - n;
     q2n = base;
     bool alive = (uint32_t)lane < n;
@@ -1470,7 +1470,8 @@ __global__ __launch_bounds__(64) void phrase_kernel(TqkScanParams p) {
       }
       if (!__ballot(alive)) return;
       uint32_t excl = 0;
-      const uint32_t tf = lookup_in_blocks<true>(idx, tr, jb, at, alive, L.pay, lane, &excl);
+      uint32_t tf = 1;
+      if (!(p.debug & 2u)) tf = lookup_in_blocks<true>(idx, tr, jb, at, alive, L.pay, lane, &excl);
       if (alive) {
         L.ph_tf[m][lane] = tf;
         L.ph_pi[m][lane] = tr.rec[jb].w + excl;
@@ -1479,7 +1480,10 @@ __global__ __launch_bounds__(64) void phrase_kernel(TqkScanParams p) {
     // ---- position check, one lane per candidate
     bool has = false;
     uint64_t key = 0;
-    if (alive) {
+    if (alive && (p.debug & 3u)) {
+      has = true;
+      key = make_key(1.0f, doc);
+    } else if (alive) {
       PosCursor cur[TQD_PH_MAX_TERMS];
 #pragma unroll
       for (int m = 0; m < TQD_PH_MAX_TERMS; ++m) {
@@ -1530,7 +1534,7 @@ __global__ __launch_bounds__(64) void phrase_kernel(TqkScanParams p) {
   };
 
   // ---- stage B: locate the candidate in list 1
-  auto stageB = [&](uint32_t n) {
+  auto stageB = [&](uint32_t n) __attribute__((always_inline)) {
     const uint32_t base = q1n - n;
     q1n = base;
     bool alive = (uint32_t)lane < n;
@@ -1566,7 +1570,7 @@ __global__ __launch_bounds__(64) void phrase_kernel(TqkScanParams p) {
     }
   };
 
-  auto drain = [&]() {
+  auto drain = [&]() __attribute__((always_inline)) {
     while (q1n) {
       stageB(q1n < 64u ? q1n : 64u);
       while (q2n >= 64u) stageC(64u);
