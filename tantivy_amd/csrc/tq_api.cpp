@@ -748,8 +748,8 @@ int tq_search_batch_device(tq_segment *s, const tq_query *queries, uint32_t n_qu
           }
         } else {  // phrase: leader-block tiles like AND; every match also walks its positions
           const uint32_t lead_blocks = s->terms[dq.term[0]].n_blocks;
-          dq.tile_blocks = 16;
-          tile_cost = 64;
+          dq.tile_blocks = tune_u32("TQ_PH_TILE", 32);
+          tile_cost = tune_u32("TQ_PH_COST", 64);
           n_tiles = (lead_blocks + dq.tile_blocks - 1) / dq.tile_blocks;
         }
       }

@@ -316,6 +316,68 @@ def test_edge_cases(ta):
         dev.close()
 
 
+@pytest.mark.parametrize("seed", [1, 2, 3, 4, 5, 6])
+def test_fuzz_random_segments(ta, seed):
+    """Random segments (dense and sparse lists, tails, runs of consecutive docs, repeated scores)
+    x random AND / OR / phrase queries x k, in every execution mode (pruned / exhaustive, with and
+    without the dense-list bitmaps): always the oracle's exhaustive top-k."""
+    rng = np.random.default_rng(1000 + seed)
+    md = int(rng.choice([5000, 20000, 70000]))
+    n_terms = 14
+    lists, positions = [], []
+    for t in range(n_terms):
+        kind = rng.integers(0, 5)
+        if kind == 0:      # dense
+            df = int(md * rng.uniform(0.2, 0.9))
+        elif kind == 1:    # mid
+            df = int(md * rng.uniform(0.01, 0.1))
+        elif kind == 2:    # sparse, often below one block
+            df = int(rng.integers(1, 300))
+        elif kind == 3:    # exact block multiples
+            df = int(128 * rng.integers(1, 6))
+        else:              # a consecutive run (zero-width deltas) plus noise
+            df = 0
+        if df:
+            docs = np.sort(rng.choice(md, size=min(df, md), replace=False))
+        else:
+            start = int(rng.integers(0, md // 2))
+            docs = np.unique(np.concatenate([np.arange(start, start + 700),
+                                             rng.choice(md, size=50, replace=False)]))
+        few_tfs = rng.random() < 0.5   # few distinct tf values => many score ties
+        tfs = rng.integers(1, 3 if few_tfs else 12, size=len(docs))
+        lists.append(list(zip(docs.tolist(), tfs.tolist())))
+        pl = []
+        for tf in tfs.tolist():
+            pl.append(np.sort(rng.choice(40, size=tf, replace=False)).tolist())
+        positions.append(pl)
+    fieldnorms = rng.integers(1, 60, size=md).tolist() if seed % 2 else [7] * md
+    seg = O.build_segment(md, lists, fieldnorms, record_option=O.WITH_FREQS_AND_POSITIONS,
+                          positions=positions)
+    queries = []
+    for _ in range(40):
+        mode = int(rng.choice([O.MODE_AND, O.MODE_AND, O.MODE_OR, O.MODE_PHRASE]))
+        n = int(rng.integers(1 if mode == O.MODE_OR else 2, 6))
+        terms = rng.choice(n_terms, size=n, replace=False).tolist()
+        queries.append((mode, terms))
+    dev = ta.DeviceIndex([seg])
+    try:
+        dev.set_option("dense_ratio", 16)  # terms are prepared lazily: set before the first query
+        for k in (1, 10, 100):
+            want = [_oracle_topk(seg, q[1], q[0], k) for q in queries]
+            for ex, ud in ((1, 1), (0, 1), (0, 0), (1, 0)):
+                dev.set_option("exhaustive", ex)
+                dev.set_option("use_dense", ud)
+                got = _device_topk(dev, queries, k)
+                for q, g, w in zip(queries, got, want):
+                    try:
+                        _assert_hits(g, w, q[0], len(q[1]))
+                    except AssertionError:
+                        raise AssertionError("seed %d k %d exhaustive %d use_dense %d query %r\n"
+                                             "got  %r\nwant %r" % (seed, k, ex, ud, q, g[:5], w[:5]))
+    finally:
+        dev.close()
+
+
 def test_ties_prefer_lower_doc(ta):
     md = 1000
     lists = [[(d, 2) for d in range(0, md, 2)], [(d, 2) for d in range(0, md, 3)]]
