@@ -165,6 +165,8 @@ int tq_last_batch_stats(tq_segment *seg, tq_batch_stats *out);
  *        with doc_freq >= max_doc/dense_ratio, while all bitmaps stay below 4x the segment's
  *        bytes), "dense_ratio" (default 64), "use_dense" (0/1, default 1: the AND kernel may use
  *        them),
+ *        "or_windows" (-1/0/1, default -1 = auto: unions run window-parallel when exhaustive and
+ *        candidate-driven when pruning; 0 / 1 force one kernel),
  *        "use_dpp" (0/1: DPP or ds_bpermute prefix sums) */
 int tq_set_option(tq_segment *seg, const char *name, int64_t value);
 

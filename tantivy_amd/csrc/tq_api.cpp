@@ -132,6 +132,8 @@ struct Options {
   int dense_ratio = TQD_DENSE_RATIO;  // ... for lists with doc_freq >= max_doc / dense_ratio
   int dense_budget_x = 4;  // ... while all bitmaps stay below this multiple of the segment's bytes
   int use_dense = 1;  // let the scan kernels use them
+  int or_windows = -1;  // OR: 1 = window-parallel kernel, 0 = candidate-driven kernel, -1 = auto
+                        // (windows for exhaustive scans, candidates when pruning)
 };
 
 }  // namespace
@@ -651,6 +653,7 @@ int tq_search_batch_device(tq_segment *s, const tq_query *queries, uint32_t n_qu
   if (rc != TQ_OK) return rc;
 
   // ---- plan
+  const bool or_windows = s->opt.or_windows < 0 ? s->opt.exhaustive != 0 : s->opt.or_windows != 0;
   // launch groups: AND queries whose non-leader lists all have a bitmap run a leaner kernel
   // instantiation (no seek / block-search code: fewer registers, less LDS, more waves per CU)
   constexpr int kGroups = 4, kAndGeneral = 3;
@@ -793,10 +796,28 @@ int tq_search_batch_device(tq_segment *s, const tq_query *queries, uint32_t n_qu
           }
         }
       }
-      uint32_t max_last = 0;
-      for (uint32_t i = 0; i < dq.n_terms; ++i)
-        max_last = std::max(max_last, s->terms[dq.term[i]].last_doc);
-      if (dq.n_terms) n_tiles = max_last / TQD_OR_WINDOW + 1;
+      if (or_windows) {
+        uint32_t max_last = 0;
+        for (uint32_t i = 0; i < dq.n_terms; ++i)
+          max_last = std::max(max_last, s->terms[dq.term[i]].last_doc);
+        if (dq.n_terms) n_tiles = max_last / TQD_OR_WINDOW + 1;
+      } else if (dq.n_terms) {
+        // candidate-driven: every list leads its own run of tiles; a candidate probes all the
+        // other lists (non-dense ones cost a seek + a block search)
+        uint32_t sparse = 0;
+        for (uint32_t i = 0; i < dq.n_terms; ++i)
+          if (!(s->terms[dq.term[i]].dense_blob && s->opt.use_dense)) ++sparse;
+        const uint32_t c_lb = 1u + dq.n_terms + 8u * sparse;
+        dq.tile_blocks = std::max<uint32_t>(1u, TQD_AND_TILE * 2u / c_lb);
+        tile_cost = dq.tile_blocks * c_lb;
+        uint32_t acc_tiles = 0;
+        for (uint32_t i = 0; i < dq.n_terms; ++i) {
+          dq.lead_tile_start[i] = acc_tiles;
+          acc_tiles += (s->terms[dq.term[i]].n_blocks + dq.tile_blocks - 1) / dq.tile_blocks;
+        }
+        for (uint32_t i = dq.n_terms; i <= TQ_MAX_TERMS; ++i) dq.lead_tile_start[i] = acc_tiles;
+        n_tiles = acc_tiles;
+      }
     }
     algo_bytes += qbytes;
     dq.n_tiles = n_tiles;
@@ -829,14 +850,15 @@ int tq_search_batch_device(tq_segment *s, const tq_query *queries, uint32_t n_qu
     uint64_t total_cost = 0;
     for (size_t i = 0; i < g.queries.size(); ++i)
       total_cost += (uint64_t)g.queries[i].n_tiles * g.tile_cost[i];
-    const uint64_t n_target = g.mode == TQ_MODE_OR ? 8192u : kAndChunks;
-    const uint64_t cost_target = std::max<uint64_t>(g.mode == TQ_MODE_AND ? 128u : 1u,
+    const bool or_win = g.mode == TQ_MODE_OR && or_windows;
+    const uint64_t n_target = or_win ? 8192u : kAndChunks;
+    const uint64_t cost_target = std::max<uint64_t>(or_win ? 1u : 128u,
                                                     (total_cost + n_target - 1) / n_target);
     g.chunk_starts.clear();
     g.chunk_slice.clear();
     uint64_t cur_cost = 0;
     bool open_chunk = false;
-    const uint32_t per_chunk = g.mode == TQ_MODE_OR ? TQD_WAVES_PER_WG : 1u;
+    const uint32_t per_chunk = or_win ? TQD_WAVES_PER_WG : 1u;
     for (size_t i = 0; i < g.queries.size(); ++i) {
       TqdQuery &dq = g.queries[i];
       dq.part_start = 0;
@@ -849,7 +871,17 @@ int tq_search_batch_device(tq_segment *s, const tq_query *queries, uint32_t n_qu
         if (!open_chunk || cur_cost >= cost_target) {
           g.chunk_starts.push_back(dq.tile_start + t);
           // which part of the doc-id space the chunk starts in (lists are spread over it)
-          g.chunk_slice.push_back((uint32_t)(((uint64_t)t * kSlices * 8u) / dq.n_tiles));
+          if (g.mode == TQ_MODE_OR && !or_win) {
+            // candidate-driven OR: high-weight lists first (their matches raise the threshold
+            // that lets the tiles of the dense low-weight lists be skipped), doc order inside
+            uint32_t li = 0;
+            while (li + 1u < dq.n_terms && dq.lead_tile_start[li + 1u] <= t) ++li;
+            const uint32_t span = std::max<uint32_t>(1u, dq.lead_tile_start[li + 1u] - dq.lead_tile_start[li]);
+            const uint32_t sub = (uint32_t)(((uint64_t)(t - dq.lead_tile_start[li]) * 16u) / span);
+            g.chunk_slice.push_back(std::min<uint32_t>(kSlices * 8u - 1u, std::min<uint32_t>(li, 15u) * 16u + sub));
+          } else {
+            g.chunk_slice.push_back((uint32_t)(((uint64_t)t * kSlices * 8u) / dq.n_tiles));
+          }
           cur_cost = 0;
           open_chunk = true;
         }
@@ -1022,6 +1054,7 @@ int tq_search_batch_device(tq_segment *s, const tq_query *queries, uint32_t n_qu
     p.use_dense = (uint32_t)s->opt.use_dense;
     p.all_dense = gi == 0 ? 1u : 0u;
     p.debug = tune_u32("TQ_DEBUG", 0);
+    p.or_windows = or_windows ? 1u : 0u;
     tiles_total += g.total_tiles;
     chunks_total += g.n_chunks;
     hipError_t e = hipSuccess;
@@ -1150,6 +1183,8 @@ int tq_set_option(tq_segment *s, const char *name, int64_t value) {
     s->opt.use_dpp = value != 0;
   else if (!strcmp(name, "use_dense"))
     s->opt.use_dense = value != 0;
+  else if (!strcmp(name, "or_windows"))
+    s->opt.or_windows = value < 0 ? -1 : (value != 0);
   else if (!strcmp(name, "dense_ratio") && value >= 1)  // affects terms prepared afterwards
     s->opt.dense_ratio = (int)value;
   else if (!strcmp(name, "dense"))  // affects terms prepared afterwards

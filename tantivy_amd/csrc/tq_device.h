@@ -61,6 +61,7 @@ struct TqdQuery {
   uint32_t thr_index;   // row of the shared-threshold table (pruned mode), or 0xFFFFFFFF
   uint32_t chunk_first; // first chunk that holds a tile of this query
   uint32_t tile_blocks; // AND: leader blocks per tile (1..64, sized so tiles cost about the same)
+  uint32_t lead_tile_start[TQD_MAX_TERMS + 1];  // candidate-driven OR: first tile led by list i
 };
 
 #define TQD_QF_PRUNE 1u  // block-max pruning allowed (all weights >= 0, caller asked for it)

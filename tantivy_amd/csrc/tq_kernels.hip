@@ -1323,6 +1323,287 @@ __global__ __launch_bounds__(TQD_WAVES_PER_WG * 64) void or_kernel(TqkScanParams
   if (lane == 0 && n_matches) atomicAdd(p.match_counter, (unsigned long long)n_matches);
 }
 
+// =================================================================== union kernel (candidate-driven)
+// The same union, driven by candidates instead of windows — the form that suits the sparse
+// (high-weight) lists MaxScore keeps essential.  Terms by weight descending.  A tile is a run of
+// blocks of ONE list i ("the leader of the tile"); every doc of the union is scored exactly once,
+// by the tile of the FIRST list that holds it:
+//   * tiles of a list that is non-essential by now (the weights of lists i.. together are below
+//     the threshold) are skipped whole; so are leader blocks whose block-max plus the other
+//     lists' weights cannot reach it (block_wand_union.rs:16-43,49-80);
+//   * stage A decodes a leader block (as in the AND kernel, tf_min integer pre-filter included);
+//   * stage B, 64 candidates per step: probe lists 0..i-1 — found there means the doc belongs to
+//     that list's tile and the candidate is dropped — then lists i+1.. in order, adding their
+//     BM25 terms, with the bound "score so far + remaining weights" checked before every probe.
+//     Dense lists are probed through their bitmap, the others by seek_block + find_in_blocks.
+// The sum runs over the lists holding the doc in ascending list index, whichever mode and
+// threshold history: results are bit-identical across modes and runs.  One wavefront per chunk.
+struct UnionLds {  // per wavefront
+  uint32_t pay[516];
+  uint32_t q1_doc[191], q1_tf[191];
+  float cache[256];
+  float suffix[TQD_MAX_TERMS + 1];
+};
+
+template <int KPL, bool PRUNE>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_num_sgpr(96))) void union_kernel(TqkScanParams p) {
+  constexpr bool USE_DPP = true;
+  __shared__ UnionLds L;
+  const int lane = (int)__lane_id();
+  if (blockIdx.x >= p.n_chunks) return;
+  const uint32_t chunk = sload(p.chunk_perm + blockIdx.x);
+  const uint32_t t_begin = sload(p.chunk_starts + chunk);
+  const uint32_t t_end = sload(p.chunk_starts + chunk + 1u);
+  const TqdSegment seg = p.seg;
+  const uint8_t *idx = seg.idx;
+
+  uint32_t q = uni(find_query(p.tile_starts, p.n_queries, t_begin));
+  uint32_t q_tile_start = 0, q_tile_end = 0;
+  const TqdQuery *Q = nullptr;
+  uint32_t nt = 0, tile_blocks = TQD_AND_TILE, n_slot_rows = 1;
+  bool prune = false;
+  uint32_t *slots = nullptr;
+  uint32_t thr = 0, thr_g = 0;
+  uint32_t cache_loaded = 0xFFFFFFFFu;
+  float min_norm = 0.0f;
+  TopK<KPL> tk;
+  uint32_t n_matches = 0;
+  uint32_t q1n = 0;
+  // leader of the current tile
+  uint32_t li = 0, li_end = 0;
+  bool dead = false;
+  TermRef lead{};
+  float w_lead = 0.0f;
+
+  auto setup_query = [&]() __attribute__((always_inline)) {
+    q_tile_start = sload(p.tile_starts + q);
+    q_tile_end = sload(p.tile_starts + q + 1u);
+    Q = p.queries + q;
+    nt = sload(&Q->n_terms);
+    tile_blocks = sload(&Q->tile_blocks);
+    prune = PRUNE && (sload(&Q->flags) & TQD_QF_PRUNE) != 0u;
+    const uint32_t thr_index = sload(&Q->thr_index);
+    const uint32_t k = sload(&Q->k);
+    n_slot_rows = k <= 64u ? 1u : 2u;
+    slots = (prune && thr_index != 0xFFFFFFFFu) ? p.thr_slots + (size_t)thr_index * TQD_THR_SLOTS
+                                                : nullptr;
+    const uint32_t ci = sload(&Q->cache_idx);
+    wave_mem_fence();
+    if (ci != cache_loaded) {
+      const float *cg = p.caches + (size_t)ci * 256u;
+      for (int i = lane; i < 256; i += WAVE) L.cache[i] = cg[i];
+      cache_loaded = ci;
+    }
+    float suf = 0.0f;
+    if (lane == 0) L.suffix[nt] = 0.0f;
+    for (uint32_t m = nt; m-- > 0u;) {
+      suf += sload(&Q->weight[m]);
+      if (lane == 0) L.suffix[m] = suf;
+    }
+    wave_mem_fence();
+    min_norm = sload(p.caches + (size_t)ci * 256u +
+                     (seg.fieldnorm ? seg.min_fieldnorm_id : seg.const_fieldnorm_id));
+    thr = 0;
+    thr_g = 0;
+    li = 0xFFFFFFFFu;
+    li_end = 0;
+    dead = false;
+    tk.reset(k);
+  };
+
+  // ---- stage B: the other lists of <= 64 candidates of leader li
+  auto stageB = [&](uint32_t n) __attribute__((always_inline)) {
+    const uint32_t base = q1n - n;
+    q1n = base;
+    bool alive = (uint32_t)lane < n;
+    uint32_t doc = 0, tf = 0;
+    float norm = 0.0f, s = 0.0f;
+    if (alive) {
+      doc = L.q1_doc[base + lane];
+      tf = L.q1_tf[base + lane];
+      norm = L.cache[fieldnorm_id(seg, doc)];
+      s = bm25(w_lead, norm, tf);
+      if (prune) alive = sortable((s + L.suffix[li + 1u]) * 1.000001f) >= thr;
+    }
+    for (uint32_t m = 0; m < nt; ++m) {
+      if (m == li) continue;
+      const float w = sload(&Q->weight[m]);
+      if (prune && m > li) {
+        // what the lists m.. can still add (lists below li add nothing: found there = dropped)
+        if (alive) alive = sortable((s + L.suffix[m]) * 1.000001f) >= thr;
+      }
+      if (!__ballot(alive)) break;
+      TermRef tr = load_term(p.terms, sload(&Q->term[m]));
+      if (!p.use_dense) tr.dense = nullptr;
+      bool found = false;
+      uint32_t jb = 0, at = NOT_FOUND;
+      if (tr.dense) {
+        if (alive) {
+          const uint2 wd = tr.dense[doc >> 5];
+          const uint32_t bit = doc & 31u;
+          found = (wd.x >> bit) & 1u;
+          const uint32_t pi = wd.y + (uint32_t)__popc(wd.x & ((1u << bit) - 1u));
+          jb = pi >> 7;
+          at = pi & 127u;
+        }
+      } else {
+        bool cand = alive;
+        if (cand) {
+          jb = seek_block(tr, doc);
+          cand = jb < tr.n_blocks;
+        }
+        uint32_t unused;
+        at = lookup_in_blocks<false>(idx, tr, jb, doc, cand, L.pay, lane, &unused);
+        found = cand && at != NOT_FOUND;
+      }
+      if (m < li) {
+        if (found) alive = false;  // this doc is scored by list m's tile
+      } else if (found) {
+        const uint4 r = tr.rec[jb];
+        s = s + bm25(w, norm, block_tf_at(idx, tr, make_uint2(r.y, r.z), at));
+      }
+    }
+    const uint64_t hit = __ballot(alive);
+    if (hit) {
+      n_matches += (uint32_t)__popcll(hit);
+      const uint64_t key = alive ? make_key(s, doc) : 0ull;
+      if (slots) {
+        const uint32_t sb = (uint32_t)(key >> 32);
+        const uint32_t h = (doc * 0x9E3779B1u) >> (n_slot_rows == 1u ? 26 : 25);
+        if (alive && sb > thr_g) atomicMax(slots + h, sb);
+      }
+      tk.offer(alive, key, lane);
+      if (prune) {
+        const uint32_t own = (uint32_t)(tk.thr >> 32);
+        if (own > thr) thr = own;
+      }
+    }
+  };
+
+  setup_query();
+  for (uint32_t t = t_begin; t < t_end; ++t) {
+    while (t >= q_tile_end) {
+      if (q_tile_end > q_tile_start && q_tile_end > t_begin) {
+        while (q1n) stageB(q1n < 64u ? q1n : 64u);
+        const uint32_t part = sload(&Q->part_start) + (chunk - sload(&Q->chunk_first));
+        flush_partial<KPL>(tk, p.partials, part, lane);
+      }
+      ++q;
+      setup_query();
+    }
+    // ---- which list leads this tile (tiles of a chunk come in order: advance, never search)
+    if (dead) {  // lists li.. are non-essential for good (the threshold only rises): nothing
+      t = (q_tile_end < t_end ? q_tile_end : t_end) - 1u;  // left for this query in this chunk
+      continue;
+    }
+    const uint32_t tl = t - q_tile_start;
+    bool new_leader = li == 0xFFFFFFFFu;
+    uint32_t nli = new_leader ? 0u : li;
+    if (new_leader) li_end = sload(&Q->lead_tile_start[1]);
+    while (tl >= li_end && nli + 1u < nt) {
+      ++nli;
+      li_end = sload(&Q->lead_tile_start[nli + 1u]);
+      new_leader = true;
+    }
+    if (new_leader) {
+      while (q1n) stageB(q1n < 64u ? q1n : 64u);  // the queue belongs to the previous leader
+      li = nli;
+      lead = load_term(p.terms, sload(&Q->term[li]));
+      w_lead = sload(&Q->weight[li]);
+    }
+    // threshold: on a new leader and every 8th tile
+    if (slots && (new_leader || (tl & 7u) == 0u)) {
+      uint32_t sv[2] = {0u, 0u};
+      sv[0] = __hip_atomic_load(slots + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (n_slot_rows == 2u) {
+        sv[1] = __hip_atomic_load(slots + 64 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        thr_g = kth_largest_multi<2>(sv, tk.k);
+      } else {
+        thr_g = kth_largest64(sv[0], tk.k);
+      }
+      if (thr_g > thr) thr = thr_g;
+    }
+    // non-essential by now: every doc first seen in list li scores at most the weights of li..
+    if (prune && sortable(L.suffix[li] * 1.000001f) < thr) {
+      while (q1n) stageB(q1n < 64u ? q1n : 64u);
+      dead = true;
+      continue;
+    }
+
+    // ---- pre-filter: lane <-> leader block
+    const uint32_t i_base = (tl - sload(&Q->lead_tile_start[li])) * tile_blocks;
+    const uint32_t i_mine = i_base + (uint32_t)lane;
+    bool surv = (uint32_t)lane < tile_blocks && i_mine < lead.n_blocks;
+    uint4 rec_mine = make_uint4(0u, 0u, 0u, 0u);
+    uint32_t prev_mine = 0, tfmin_mine = 1u;
+    {
+      if (surv) rec_mine = lead.rec[i_mine];
+      prev_mine = __shfl_up(rec_mine.x, 1, WAVE);
+      if (lane == 0) prev_mine = block_prev_last(lead, i_base);
+      if (prune && surv) {
+        const float rest = (L.suffix[li] - w_lead) * 1.000001f;  // the lists after li, at most
+        const float ub = block_max_score(rec_mine.y, w_lead, L.cache, lead.has_freq);
+        surv = sortable((ub + rest) * 1.000001f) >= thr;
+        if (surv) {
+          auto pass = [&](uint32_t tfv) {
+            return sortable((bm25(w_lead, min_norm, tfv) + rest) * 1.000001f) >= thr;
+          };
+          if (!pass(0xFFFFFFFFu)) {
+            surv = false;
+          } else {
+            uint32_t tfm = 1u;
+            while (tfm < 64u && !pass(tfm)) ++tfm;  // tfs are small; beyond 64 keep everything
+            tfmin_mine = tfm < 64u ? tfm : 1u;
+          }
+        }
+      }
+    }
+    uint64_t todo = __ballot(surv);
+    while (todo) {
+      const uint32_t b = (uint32_t)__builtin_ctzll(todo);
+      todo &= todo - 1ull;
+      const uint2 mo_l = make_uint2((uint32_t)__builtin_amdgcn_readlane((int)rec_mine.y, (int)b),
+                                    (uint32_t)__builtin_amdgcn_readlane((int)rec_mine.z, (int)b));
+      const uint32_t prev_l = (uint32_t)__builtin_amdgcn_readlane((int)prev_mine, (int)b);
+      uint32_t c0, c1, t0, t1f;
+      decode_tfs(idx, lead, mo_l, lane, t0, t1f);  // tail padding reads as tf 0
+      bool alive0 = true, alive1 = true;
+      if (prune) {
+        const uint32_t tfmin = (uint32_t)__builtin_amdgcn_readlane((int)tfmin_mine, (int)b);
+        alive0 = t0 >= tfmin;
+        alive1 = t1f >= tfmin;
+        if (!(__ballot(alive0) | __ballot(alive1))) continue;
+      }
+      decode_docs<USE_DPP>(idx, lead, mo_l, prev_l, lane, c0, c1);
+      alive0 = alive0 && c0 != TQD_TERMINATED;
+      alive1 = alive1 && c1 != TQD_TERMINATED;
+      const uint64_t m0 = __ballot(alive0), m1 = __ballot(alive1);
+      if (!(m0 | m1)) continue;
+      const uint32_t n0 = (uint32_t)__popcll(m0);
+      const uint32_t pos0 = q1n + mbcnt64(m0);
+      const uint32_t pos1 = q1n + n0 + mbcnt64(m1);
+      wave_mem_fence();
+      if (alive0) {
+        L.q1_doc[pos0] = c0;
+        L.q1_tf[pos0] = t0;
+      }
+      if (alive1) {
+        L.q1_doc[pos1] = c1;
+        L.q1_tf[pos1] = t1f;
+      }
+      wave_mem_fence();
+      q1n += n0 + (uint32_t)__popcll(m1);
+      while (q1n >= 64u) stageB(64u);
+    }
+  }
+  if (q_tile_end > q_tile_start) {
+    while (q1n) stageB(q1n < 64u ? q1n : 64u);
+    const uint32_t part = sload(&Q->part_start) + (chunk - sload(&Q->chunk_first));
+    flush_partial<KPL>(tk, p.partials, part, lane);
+  }
+  if (lane == 0 && n_matches) atomicAdd(p.match_counter, (unsigned long long)n_matches);
+}
+
 // positions: raw deltas of a whole term (PositionReader::read over everything).  pos_blk[pb] =
 // absolute byte offset of position block pb | bit width << 56 (positions/reader.rs:84-101).
 __device__ __forceinline__ uint32_t position_delta(const uint8_t *pos, const TqdTerm *t,
@@ -1794,10 +2075,17 @@ static void launch_and_t(const TqkScanParams &p, dim3 grid, dim3 block, hipStrea
 }
 template <int KPL>
 static void launch_or_t(const TqkScanParams &p, bool /*dpp*/, dim3 grid, dim3 block, hipStream_t st) {
-  if (p.exhaustive)
-    or_kernel<KPL, false><<<grid, block, 0, st>>>(p);
-  else
-    or_kernel<KPL, true><<<grid, block, 0, st>>>(p);
+  if (p.or_windows) {  // window-parallel form: one workgroup per chunk
+    if (p.exhaustive)
+      or_kernel<KPL, false><<<grid, block, 0, st>>>(p);
+    else
+      or_kernel<KPL, true><<<grid, block, 0, st>>>(p);
+  } else {  // candidate-driven form: one wavefront per chunk
+    if (p.exhaustive)
+      union_kernel<KPL, false><<<grid, dim3(64), 0, st>>>(p);
+    else
+      union_kernel<KPL, true><<<grid, dim3(64), 0, st>>>(p);
+  }
 }
 
 hipError_t tqk_launch_and(const TqkScanParams &p, int kpl, bool /*use_dpp*/, hipStream_t st) {

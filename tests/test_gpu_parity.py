@@ -240,8 +240,12 @@ def test_or_union(synth, k):
             _assert_hits_equal(g, _oracle_topk(seg, q, O.MODE_OR, k))
         else:
             _assert_hits_close(g, _oracle_topk(seg, q, O.MODE_OR, k))
-    # MaxScore pruning (block_wand semantics): identical bits, with and without the bitmaps
-    for opts in ({"exhaustive": 0}, {"exhaustive": 0, "use_dense": 0}, {"use_dense": 0}):
+    # MaxScore pruning (block_wand semantics): identical bits, with and without the bitmaps, in
+    # the candidate-driven (default) and the window-parallel kernel
+    for opts in ({"exhaustive": 0}, {"exhaustive": 0, "use_dense": 0}, {"use_dense": 0},
+                 {"or_windows": 0}, {"or_windows": 1, "exhaustive": 0},
+                 {"or_windows": 1, "exhaustive": 0, "use_dense": 0},
+                 {"or_windows": 0, "use_dense": 0}):
         for name, v in opts.items():
             dev.set_option(name, v)
         try:
@@ -249,6 +253,7 @@ def test_or_union(synth, k):
         finally:
             dev.set_option("exhaustive", 1)
             dev.set_option("use_dense", 1)
+            dev.set_option("or_windows", -1)
         for q, g, g2 in zip(qs, got, got2):
             assert g2 == g, (q, opts)
 
@@ -364,16 +369,19 @@ def test_fuzz_random_segments(ta, seed):
         dev.set_option("dense_ratio", 16)  # terms are prepared lazily: set before the first query
         for k in (1, 10, 100):
             want = [_oracle_topk(seg, q[1], q[0], k) for q in queries]
-            for ex, ud in ((1, 1), (0, 1), (0, 0), (1, 0)):
+            for ex, ud, ow in ((1, 1, 0), (0, 1, 0), (0, 0, 0), (1, 0, 0), (0, 1, 1), (1, 0, 1)):
                 dev.set_option("exhaustive", ex)
                 dev.set_option("use_dense", ud)
+                dev.set_option("or_windows", ow)
                 got = _device_topk(dev, queries, k)
                 for q, g, w in zip(queries, got, want):
                     try:
                         _assert_hits(g, w, q[0], len(q[1]))
                     except AssertionError:
-                        raise AssertionError("seed %d k %d exhaustive %d use_dense %d query %r\n"
-                                             "got  %r\nwant %r" % (seed, k, ex, ud, q, g[:5], w[:5]))
+                        raise AssertionError("seed %d k %d exhaustive %d use_dense %d or_windows %d "
+                                             "query %r\ngot  %r\nwant %r" %
+                                             (seed, k, ex, ud, ow, q, g[:5], w[:5]))
+        dev.set_option("or_windows", -1)
     finally:
         dev.close()
 

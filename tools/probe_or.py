@@ -16,6 +16,12 @@ dev.set_option("timing", 1)
 
 
 def run(name, qs, k=100):
+    for ow in (0, 1):
+        dev.set_option("or_windows", ow)
+        _run(("cand " if ow == 0 else "wind ") + name, qs, k)
+
+
+def _run(name, qs, k=100):
     out = []
     for ex in (1, 0):
         dev.set_option("exhaustive", ex)
