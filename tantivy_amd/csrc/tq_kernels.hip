@@ -906,7 +906,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_num_sgpr(80))) void and_k
       prev_mine = __shfl_up(last, 1, WAVE);
       if (lane == 0) prev_mine = block_prev_last(lead, i_base);
       first = i_mine ? prev_mine + 1u : 0u;
-      if (prune && surv) ub = block_max_score(mo_mine.x, w_lead, L.cache, lead.has_freq);
+      if (prune && surv) {
+        ub = block_max_score(mo_mine.x, w_lead, L.cache, lead.has_freq);
+        // cheapest test first: not even with the other lists at their full weights?  (a rare
+        // leader next to a stop word: most blocks end here, before any seek)
+        surv = sortable((ub + (w1 + rest_after1)) * 1.000001f) >= thr;
+      }
       for (uint32_t m = 1; m < nt; ++m) {
         const TermRef tr = m == 1u ? t1 : load_term(p.terms, sload(&Q->term[m]));
         const float w = m == 1u ? w1 : sload(&Q->weight[m]);
