@@ -22,7 +22,7 @@ HEADERS = [
     os.path.join(os.path.dirname(HERE), "include", "tantivy_amd_host.h"),
 ]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared",
-         "-Wall", "-Wno-unused-function"]
+         "-Wall"]
 
 
 def up_to_date():

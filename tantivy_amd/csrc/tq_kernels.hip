@@ -107,19 +107,6 @@ __device__ __forceinline__ void unpack2(const uint8_t *p, uint32_t b, int lane, 
   v0 = __funnelshift_r(lo.x, hi.x, s) & mask;
   v1 = __funnelshift_r(lo.y, hi.y, s) & mask;
 }
-// Single value at index i of a bitpacked block (positions random access).
-__device__ __forceinline__ uint32_t unpack_one(const uint8_t *p, uint32_t b, uint32_t i) {
-  if (b == 0) return 0;
-  const uint32_t k = i >> 2, l = i & 3u;
-  const uint32_t bitpos = k * b;
-  const uint32_t w = bitpos >> 5, s = bitpos & 31u;
-  const uint8_t *q = p + 16u * w + 4u * l;
-  const uint32_t lo = ld_u1(q);
-  const uint32_t hi = ld_u1(q + 16);
-  const uint32_t mask = (b >= 32u) ? 0xFFFFFFFFu : ((1u << b) - 1u);
-  return __funnelshift_r(lo, hi, s) & mask;
-}
-
 // ------------------------------------------------------------------ block decode
 // Wave-uniform data (term tables, query descriptors, skip entries of a uniform block index) is
 // read through the constant address space: with a uniform address the compiler emits scalar
@@ -169,9 +156,6 @@ __device__ __forceinline__ TermRef load_term(const TqdTerm *terms, uint32_t hand
 // j wave-uniform
 __device__ __forceinline__ uint32_t block_prev_last(const TermRef &t, uint32_t j) {
   return j ? sload(&t.rec[j - 1u].x) : 0u;
-}
-__device__ __forceinline__ uint32_t block_first_possible(const TermRef &t, uint32_t j) {
-  return j ? sload(&t.rec[j - 1u].x) + 1u : 0u;
 }
 __device__ __forceinline__ uint2 uni_mo(const TermRef &t, uint32_t j) {
   const uint4 r = sload(t.rec + j);
@@ -309,32 +293,8 @@ __device__ __forceinline__ Dec decode_block(const uint8_t *idx, const TermRef &t
   return r;
 }
 
-// first block index j in [0, n_blocks) with last_doc(j) >= target, else n_blocks.
-// Wave-uniform target: 64-ary cooperative search, 3 rounds for 40k blocks.
-__device__ __forceinline__ uint32_t lower_bound_block(const TermRef &t, uint32_t target,
-                                                      int lane) {
-  uint32_t lo = 0, n = t.n_blocks;  // invariant: answer in [lo, lo+n]
-  while (n > 0) {
-    const uint32_t step = (n + 63u) >> 6;
-    const uint32_t idx = lo + ((uint32_t)lane + 1u) * step - 1u;
-    bool ge = true;
-    if (idx < lo + n) ge = t.rec[idx].x >= target;
-    const uint64_t m = __ballot(ge);
-    if (m == 0ull) {  // every probe (the last one sits on lo+n-1) is below the target
-      lo += n;
-      break;
-    }
-    const uint32_t first = (uint32_t)__builtin_ctzll(m);
-    const uint32_t new_lo = lo + first * step;
-    const uint32_t rem = n - first * step;
-    n = (step - 1u < rem) ? step - 1u : rem;
-    lo = new_lo;
-    lo = uni(lo);
-    n = uni(n);
-  }
-  return lo;
-}
-// Per-lane target (BlockSegmentPostings::seek_block, skip.rs:263-273, made O(1)):
+// first block index j in [0, n_blocks) with last_doc(j) >= doc, else n_blocks, for a per-lane
+// target (BlockSegmentPostings::seek_block, skip.rs:263-273, made O(1)):
 // the coarse table brackets the answer, a short binary search finishes.  doc < max_doc.
 __device__ __forceinline__ uint32_t seek_block(const TermRef &t, uint32_t doc) {
   const uint32_t b = doc >> t.shift;
