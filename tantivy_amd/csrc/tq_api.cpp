@@ -847,11 +847,43 @@ int tq_search_batch_device(tq_segment *s, const tq_query *queries, uint32_t n_qu
     // chunks = runs of consecutive tiles of about equal estimated cost; one chunk is one
     // wavefront (AND, phrase) or one workgroup (OR) and the hardware dispatcher hands them out
     // as slots free up, so many small chunks balance the load
-    uint64_t total_cost = 0;
-    for (size_t i = 0; i < g.queries.size(); ++i)
-      total_cost += (uint64_t)g.queries[i].n_tiles * g.tile_cost[i];
     const bool or_win = g.mode == TQ_MODE_OR && or_windows;
-    const uint64_t n_target = or_win ? 8192u : kAndChunks;
+    const bool or_cand = g.mode == TQ_MODE_OR && !or_windows;
+    // candidate-driven OR: the tiles of a list that MaxScore will most likely find non-essential
+    // (the weights of lists i.. together below ~3/4 of the query's total weight: top-k docs hold
+    // most of the terms) are skipped whole at run time => weigh them as 1/16 of a live tile, so
+    // that chunks are sized by the work that is really done
+    auto tile_cost_at = [&](size_t qi, uint32_t t) -> uint32_t {
+      const uint32_t tc = std::max<uint32_t>(1u, g.tile_cost[qi]);
+      if (!or_cand) return tc;
+      const TqdQuery &dq = g.queries[qi];
+      uint32_t li = 0;
+      while (li + 1u < dq.n_terms && dq.lead_tile_start[li + 1u] <= t) ++li;
+      float total = 0.0f, suffix = 0.0f;
+      for (uint32_t m = 0; m < dq.n_terms; ++m) {
+        total += dq.weight[m];
+        if (m >= li) suffix += dq.weight[m];
+      }
+      const bool pruning = (dq.flags & TQD_QF_PRUNE) != 0u;
+      return (pruning && suffix < 0.75f * total) ? std::max<uint32_t>(1u, tc / 16u) : tc;
+    };
+    // first tile >= t of query qi where the cost changes (the end of the leader's run)
+    auto cost_run_end = [&](size_t qi, uint32_t t) -> uint32_t {
+      const TqdQuery &dq = g.queries[qi];
+      if (!or_cand) return dq.n_tiles;
+      uint32_t li = 0;
+      while (li + 1u < dq.n_terms && dq.lead_tile_start[li + 1u] <= t) ++li;
+      return std::min<uint32_t>(dq.n_tiles, dq.lead_tile_start[li + 1u]);
+    };
+    uint64_t total_cost = 0;
+    for (size_t i = 0; i < g.queries.size(); ++i) {
+      for (uint32_t t = 0; t < g.queries[i].n_tiles;) {
+        const uint32_t e = std::max<uint32_t>(t + 1u, cost_run_end(i, t));
+        total_cost += (uint64_t)(e - t) * tile_cost_at(i, t);
+        t = e;
+      }
+    }
+    const uint64_t n_target = or_win ? 8192u : (or_cand ? 4u * kAndChunks : kAndChunks);
     const uint64_t cost_target = std::max<uint64_t>(or_win ? 1u : 128u,
                                                     (total_cost + n_target - 1) / n_target);
     g.chunk_starts.clear();
@@ -865,9 +897,10 @@ int tq_search_batch_device(tq_segment *s, const tq_query *queries, uint32_t n_qu
       dq.n_parts = 0;
       dq.chunk_first = 0;
       if (!dq.n_tiles) continue;
-      const uint32_t tc = std::max<uint32_t>(1u, g.tile_cost[i]);
       uint32_t first_chunk = 0xFFFFFFFFu;
       for (uint32_t t = 0; t < dq.n_tiles;) {
+        const uint32_t tc = tile_cost_at(i, t);
+        const uint32_t run_end = std::max<uint32_t>(t + 1u, cost_run_end(i, t));
         if (!open_chunk || cur_cost >= cost_target) {
           g.chunk_starts.push_back(dq.tile_start + t);
           // which part of the doc-id space the chunk starts in (lists are spread over it)
@@ -888,7 +921,7 @@ int tq_search_batch_device(tq_segment *s, const tq_query *queries, uint32_t n_qu
         if (first_chunk == 0xFFFFFFFFu) first_chunk = (uint32_t)g.chunk_starts.size() - 1u;
         // as many tiles of this query as the chunk still takes
         const uint64_t room = cost_target - cur_cost;
-        uint32_t take = (uint32_t)std::min<uint64_t>(dq.n_tiles - t, (room + tc - 1) / tc);
+        uint32_t take = (uint32_t)std::min<uint64_t>(run_end - t, (room + tc - 1) / tc);
         take = std::max<uint32_t>(take, 1u);
         cur_cost += (uint64_t)take * tc;
         t += take;

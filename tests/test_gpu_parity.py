@@ -611,6 +611,22 @@ def test_full_size_and_pruned(big):
     assert pruned < full // 4, (pruned, full)
 
 
+def test_full_size_phrase(ta):
+    """config 4 at BASELINE size: 3-word phrases on a 10M-doc segment with positions."""
+    seg = O.synth_segment(10_000_000, n_terms=64, with_positions=True, phrase_terms=32)
+    dev = ta.DeviceIndex([seg])
+    try:
+        qs = [[0, 1, 2], [5, 6, 7], [13, 14, 15], [29, 30, 31], [1, 0], [31, 2, 17]]
+        got = _device_topk(dev, [(O.MODE_PHRASE, q) for q in qs], 10)
+        for q, g in zip(qs, got):
+            _assert_hits_equal(g, _oracle_topk(seg, q, O.MODE_PHRASE, 10))
+        dev.set_option("use_dense", 0)
+        got2 = _device_topk(dev, [(O.MODE_PHRASE, q) for q in qs], 10)
+        assert got2 == got
+    finally:
+        dev.close()
+
+
 def test_full_size_or_top100(big):
     seg, dev = big
     qs = [[0, 1, 2, 3, 4], [10, 50, 100, 150, 200], [251, 252, 253, 254, 255]]
