@@ -851,7 +851,7 @@ int tq_search_batch_device(tq_segment *s, const tq_query *queries, uint32_t n_qu
     const bool or_cand = g.mode == TQ_MODE_OR && !or_windows;
     // candidate-driven OR: the tiles of a list that MaxScore will most likely find non-essential
     // (the weights of lists i.. together below ~3/4 of the query's total weight: top-k docs hold
-    // most of the terms) are skipped whole at run time => weigh them as 1/16 of a live tile, so
+    // most of the terms) are skipped whole at run time => weigh them as 1/8 of a live tile, so
     // that chunks are sized by the work that is really done
     auto tile_cost_at = [&](size_t qi, uint32_t t) -> uint32_t {
       const uint32_t tc = std::max<uint32_t>(1u, g.tile_cost[qi]);
@@ -865,7 +865,7 @@ int tq_search_batch_device(tq_segment *s, const tq_query *queries, uint32_t n_qu
         if (m >= li) suffix += dq.weight[m];
       }
       const bool pruning = (dq.flags & TQD_QF_PRUNE) != 0u;
-      return (pruning && suffix < 0.75f * total) ? std::max<uint32_t>(1u, tc / 16u) : tc;
+      return (pruning && suffix < 0.01f * (float)tune_u32("TQ_OR_FRAC", 75) * total) ? std::max<uint32_t>(1u, tc / tune_u32("TQ_OR_DIV", 8)) : tc;
     };
     // first tile >= t of query qi where the cost changes (the end of the leader's run)
     auto cost_run_end = [&](size_t qi, uint32_t t) -> uint32_t {
@@ -883,7 +883,7 @@ int tq_search_batch_device(tq_segment *s, const tq_query *queries, uint32_t n_qu
         t = e;
       }
     }
-    const uint64_t n_target = or_win ? 8192u : (or_cand ? 4u * kAndChunks : kAndChunks);
+    const uint64_t n_target = or_win ? 8192u : (or_cand ? tune_u32("TQ_OR_MULT", 4) * kAndChunks : kAndChunks);
     const uint64_t cost_target = std::max<uint64_t>(or_win ? 1u : 128u,
                                                     (total_cost + n_target - 1) / n_target);
     g.chunk_starts.clear();
