@@ -631,6 +631,10 @@ static uint32_t tune_u32(const char *name, uint32_t dflt) {
 }
 // doc-range slices of the launch order / chunks per AND launch (TQ_SLICES, TQ_CHUNKS: tuning only)
 static const uint32_t kSlices = std::min<uint32_t>(256u, std::max<uint32_t>(1u, tune_u32("TQ_SLICES", 32)));
+// candidate-driven OR cost model: lists whose suffix weight is below kOrDeadFrac of the total are
+// expected to be skipped at run time and weigh 1/kOrDeadDiv of a live tile
+static const float kOrDeadFrac = 0.75f;
+static const uint32_t kOrDeadDiv = 8;
 static const uint32_t kAndChunks = std::max<uint32_t>(256u, tune_u32("TQ_CHUNKS", 65536));
 
 int kpl_for(uint32_t k) { return k <= 64 ? 1 : (k <= 128 ? 2 : (k <= 256 ? 4 : 16)); }
@@ -751,8 +755,8 @@ int tq_search_batch_device(tq_segment *s, const tq_query *queries, uint32_t n_qu
           }
         } else {  // phrase: leader-block tiles like AND; every match also walks its positions
           const uint32_t lead_blocks = s->terms[dq.term[0]].n_blocks;
-          dq.tile_blocks = tune_u32("TQ_PH_TILE", 32);
-          tile_cost = tune_u32("TQ_PH_COST", 64);
+          dq.tile_blocks = 32;
+          tile_cost = 64;
           n_tiles = (lead_blocks + dq.tile_blocks - 1) / dq.tile_blocks;
         }
       }
@@ -865,7 +869,7 @@ int tq_search_batch_device(tq_segment *s, const tq_query *queries, uint32_t n_qu
         if (m >= li) suffix += dq.weight[m];
       }
       const bool pruning = (dq.flags & TQD_QF_PRUNE) != 0u;
-      return (pruning && suffix < 0.01f * (float)tune_u32("TQ_OR_FRAC", 75) * total) ? std::max<uint32_t>(1u, tc / tune_u32("TQ_OR_DIV", 8)) : tc;
+      return (pruning && suffix < kOrDeadFrac * total) ? std::max<uint32_t>(1u, tc / kOrDeadDiv) : tc;
     };
     // first tile >= t of query qi where the cost changes (the end of the leader's run)
     auto cost_run_end = [&](size_t qi, uint32_t t) -> uint32_t {
@@ -883,7 +887,7 @@ int tq_search_batch_device(tq_segment *s, const tq_query *queries, uint32_t n_qu
         t = e;
       }
     }
-    const uint64_t n_target = or_win ? 8192u : (or_cand ? tune_u32("TQ_OR_MULT", 4) * kAndChunks : kAndChunks);
+    const uint64_t n_target = or_win ? 8192u : (or_cand ? 4u * kAndChunks : kAndChunks);
     const uint64_t cost_target = std::max<uint64_t>(or_win ? 1u : 128u,
                                                     (total_cost + n_target - 1) / n_target);
     g.chunk_starts.clear();
@@ -1086,7 +1090,8 @@ int tq_search_batch_device(tq_segment *s, const tq_query *queries, uint32_t n_qu
     p.exhaustive = (uint32_t)s->opt.exhaustive;
     p.use_dense = (uint32_t)s->opt.use_dense;
     p.all_dense = gi == 0 ? 1u : 0u;
-    p.debug = tune_u32("TQ_DEBUG", 0);
+    static const uint32_t kDebug = tune_u32("TQ_DEBUG", 0);
+    p.debug = kDebug;
     p.or_windows = or_windows ? 1u : 0u;
     tiles_total += g.total_tiles;
     chunks_total += g.n_chunks;
