@@ -1093,6 +1093,8 @@ int tq_search_batch_device(tq_segment *s, const tq_query *queries, uint32_t n_qu
     static const uint32_t kDebug = tune_u32("TQ_DEBUG", 0);
     p.debug = kDebug;
     p.or_windows = or_windows ? 1u : 0u;
+    p.max_terms = 0;
+    for (const TqdQuery &dq : g.queries) p.max_terms = std::max(p.max_terms, dq.n_terms);
     tiles_total += g.total_tiles;
     chunks_total += g.n_chunks;
     hipError_t e = hipSuccess;

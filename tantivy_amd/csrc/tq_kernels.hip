@@ -1608,11 +1608,12 @@ __device__ __forceinline__ uint32_t position_delta(const uint8_t *pos, const Tqd
 // The reference runs phrases through the default for_each_pruning_scorer (a threshold filter on
 // finished scores), so there is nothing to prune before the positions are read.
 #define TQD_PH_MAX_TERMS 8
+template <int NT_MAX>
 struct PhraseLds {  // per wavefront
   uint32_t pay[516];  // lookup_in_blocks' staging area
   uint32_t q1_doc[191], q1_tf[191], q1_pi[191];
   uint32_t q2_doc[127], q2_tf[127], q2_pi[127], q2_loc[127];
-  uint32_t ph_pi[TQD_PH_MAX_TERMS][64], ph_tf[TQD_PH_MAX_TERMS][64];
+  uint32_t ph_pi[NT_MAX][64], ph_tf[NT_MAX][64];
   float cache[256];
 };
 
@@ -1629,9 +1630,10 @@ __device__ __forceinline__ void pos_advance(PosCursor &c, const uint8_t *pos, co
   }
 }
 
-template <int KPL, bool USE_DPP>
+template <int KPL, int NT_MAX>
 __global__ __launch_bounds__(64) void phrase_kernel(TqkScanParams p) {
-  __shared__ PhraseLds L;
+  constexpr bool USE_DPP = true;
+  __shared__ PhraseLds<NT_MAX> L;
   const int lane = (int)__lane_id();
   if (blockIdx.x >= p.n_chunks) return;
   const uint32_t chunk = sload(p.chunk_perm + blockIdx.x);
@@ -1730,9 +1732,9 @@ __global__ __launch_bounds__(64) void phrase_kernel(TqkScanParams p) {
       has = true;
       key = make_key(1.0f, doc);
     } else if (alive) {
-      PosCursor cur[TQD_PH_MAX_TERMS];
+      PosCursor cur[NT_MAX];
 #pragma unroll
-      for (int m = 0; m < TQD_PH_MAX_TERMS; ++m) {
+      for (int m = 0; m < NT_MAX; ++m) {
         cur[m].valid = false;
         cur[m].idx = cur[m].end = cur[m].cur = 0;
         if ((uint32_t)m < nt) {
@@ -1749,7 +1751,7 @@ __global__ __launch_bounds__(64) void phrase_kernel(TqkScanParams p) {
         const uint32_t a = cur[0].cur;
         bool ok = true;
 #pragma unroll
-        for (int m = 1; m < TQD_PH_MAX_TERMS; ++m) {
+        for (int m = 1; m < NT_MAX; ++m) {
           if ((uint32_t)m < nt && !done) {
             while (cur[m].valid && cur[m].cur < a) pos_advance(cur[m], pos, p.terms + Q->term[m]);
             if (!cur[m].valid)
@@ -1762,7 +1764,7 @@ __global__ __launch_bounds__(64) void phrase_kernel(TqkScanParams p) {
         if (ok) {
           ++count;
 #pragma unroll
-          for (int m = 1; m < TQD_PH_MAX_TERMS; ++m)
+          for (int m = 1; m < NT_MAX; ++m)
             if ((uint32_t)m < nt) pos_advance(cur[m], pos, p.terms + Q->term[m]);
         }
         pos_advance(cur[0], pos, p.terms + Q->term[0]);
@@ -2077,11 +2079,11 @@ hipError_t tqk_launch_or(const TqkScanParams &p, int kpl, bool use_dpp, hipStrea
   return hipGetLastError();
 }
 template <int KPL>
-static void launch_phrase_t(const TqkScanParams &p, bool dpp, dim3 grid, dim3 block, hipStream_t st) {
-  if (dpp)
-    phrase_kernel<KPL, true><<<grid, block, 0, st>>>(p);
+static void launch_phrase_t(const TqkScanParams &p, bool /*dpp*/, dim3 grid, dim3 block, hipStream_t st) {
+  if (p.max_terms <= 4u)  // fewer position cursors and half the per-candidate LDS
+    phrase_kernel<KPL, 4><<<grid, block, 0, st>>>(p);
   else
-    phrase_kernel<KPL, false><<<grid, block, 0, st>>>(p);
+    phrase_kernel<KPL, TQD_PH_MAX_TERMS><<<grid, block, 0, st>>>(p);
 }
 hipError_t tqk_launch_phrase(const TqkScanParams &p, int kpl, bool use_dpp, hipStream_t st) {
   if (p.n_chunks == 0) return hipSuccess;

@@ -21,6 +21,7 @@ struct TqkScanParams {
   uint32_t n_chunks;
   uint32_t exhaustive;  // 1: score every match; 0: block-max pruning allowed
   uint32_t use_dense;   // 0: ignore the dense-list bitmaps (always seek + decode)
+  uint32_t max_terms;   // largest n_terms among the launch's queries
   uint32_t or_windows;  // OR: 1 = window-parallel kernel, 0 = candidate-driven kernel
   uint32_t debug;       // TQ_DEBUG ablation bits (profiling only; results are wrong when set)
   uint32_t all_dense;   // AND: every non-leader list of every query of the launch has a bitmap
