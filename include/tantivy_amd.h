@@ -147,6 +147,23 @@ int tq_decode_postings(tq_segment *seg, tq_term_handle term, uint32_t *docs, uin
 int tq_decode_position_deltas(tq_segment *seg, tq_term_handle term, uint32_t *out, uint64_t cap,
                               uint64_t *n_out);
 
+/* ---- deletes and counting ----
+ * replaces: SegmentReader::alive_bitset + AliveBitSet::is_alive in the collector callback
+ * (src/fastfield/alive_bitset.rs:52-61, src/collector/sort_key/sort_by_score.rs:44-53).  bytes =
+ * the segment's `.del` file body as BitSet::serialize writes it (common/src/bitset.rs:215-223:
+ * u32 LE max_value == max_doc, then 64-bit words); NULL = no deletes.  Deleted docs are skipped
+ * by every search and count on this segment; BM25 statistics still count them, like the
+ * reference (bm25.rs:38-45). */
+int tq_segment_set_alive_bitset(tq_segment *seg, const uint8_t *bytes, size_t len);
+/* replaces: Count collector (src/collector/count_collector.rs:39-80) over the same query shapes:
+ * out_counts[q] = number of alive docs matching query q on this segment (the top-k fields of the
+ * queries are ignored).  Host buffer. */
+int tq_count_batch(tq_segment *seg, const tq_query *queries, uint32_t n_queries,
+                   uint32_t *out_counts);
+/* Number of docs scored per query by the last tq_search_batch* call on this segment (with
+ * "exhaustive" = 1 that is the number of matches, which makes (Count, TopDocs) one pass). */
+int tq_last_batch_match_counts(tq_segment *seg, uint32_t *out, uint32_t n_queries);
+
 /* ---- introspection ---- */
 typedef struct tq_batch_stats {
   uint64_t algorithmic_bytes; /* sum len(postings_range) [+positions] + matches + 8k */

@@ -49,7 +49,8 @@ EXPORTS = [
     "tq_init", "tq_shutdown", "tq_last_error", "tq_segment_upload", "tq_segment_free",
     "tq_term_prepare", "tq_search_batch", "tq_search_batch_device", "tq_merge_topk",
     "tq_merge_topk_device", "tq_decode_postings", "tq_decode_position_deltas",
-    "tq_last_batch_stats", "tq_set_option",
+    "tq_last_batch_stats", "tq_set_option", "tq_segment_set_alive_bitset", "tq_count_batch",
+    "tq_last_batch_match_counts",
     "tqh_last_error", "tqh_searcher_new", "tqh_searcher_free", "tqh_searcher_add_segment",
     "tqh_prepare_batch", "tqh_search_prepared", "tqh_collect_segment_prepared",
     "tqh_collect_segment_prepared_device", "tqh_searcher_add_remote_stats",
@@ -88,6 +89,9 @@ def lib():
                                             C.POINTER(C.c_uint64)]
     L.tq_last_batch_stats.argtypes = [vp, C.POINTER(TqBatchStats)]
     L.tq_set_option.argtypes = [vp, C.c_char_p, C.c_int64]
+    L.tq_segment_set_alive_bitset.argtypes = [vp, vp, C.c_size_t]
+    L.tq_count_batch.argtypes = [vp, C.POINTER(TqQuery), C.c_uint32, u32p]
+    L.tq_last_batch_match_counts.argtypes = [vp, u32p, C.c_uint32]
     L.tqh_searcher_new.argtypes = [vp, C.POINTER(vp)]
     L.tqh_searcher_free.argtypes = [vp]
     L.tqh_searcher_add_segment.argtypes = [vp, C.c_int, C.c_uint32, C.c_uint8, vp, C.c_size_t, vp,
@@ -281,6 +285,20 @@ class DeviceIndex:
                                                C.byref(n)))
         return out[: min(cap, n.value)], n.value
 
+    def set_alive_bitset(self, alive_bytes, segment_ord=0):
+        """alive_bytes: the `.del` body (BitSet::serialize) as bytes / np.uint8, or None."""
+        if alive_bytes is None:
+            _check(lib().tq_segment_set_alive_bitset(self.segment_raw(segment_ord), None, 0))
+            return
+        a = np.ascontiguousarray(np.frombuffer(bytes(alive_bytes), dtype=np.uint8))
+        _check(lib().tq_segment_set_alive_bitset(self.segment_raw(segment_ord), a.ctypes.data,
+                                                 a.size))
+
+    def last_batch_match_counts(self, n, segment_ord=0):
+        out = np.zeros(max(1, n), np.uint32)
+        _check(lib().tq_last_batch_match_counts(self.segment_raw(segment_ord), _u32(out), n))
+        return out[:n]
+
     def set_option(self, name, value, segment_ord=None):
         ords = range(self.n_segments) if segment_ord is None else [segment_ord]
         for o in ords:
@@ -292,6 +310,32 @@ class DeviceIndex:
         return {"algorithmic_bytes": st.algorithmic_bytes, "matches": st.matches,
                 "kernel_ms": st.kernel_ms, "total_ms": st.total_ms, "tiles": st.tiles,
                 "chunks": st.chunks, "batches_averaged": st.batches_averaged}
+
+    def raw_count(self, queries, weights, cache, segment_ord=0):
+        """Direct tq_count_batch (Count collector): alive matches per query."""
+        n = len(queries)
+        qs = (TqQuery * max(1, n))()
+        keep = []
+        cache = np.ascontiguousarray(cache, np.float32)
+        for i, q in enumerate(queries):
+            mode, terms = q[0], q[1]
+            hs = (C.c_uint32 * len(terms))(*[self.term_handle(t, segment_ord) for t in terms])
+            ws = (C.c_float * len(weights[i]))(*weights[i])
+            keep += [hs, ws]
+            qs[i].n_terms = len(terms)
+            qs[i].terms = C.cast(hs, C.POINTER(C.c_uint32))
+            qs[i].weights = C.cast(ws, C.POINTER(C.c_float))
+            qs[i].tf_cache = _f32(cache)
+            qs[i].mode = mode
+            if mode == MODE_PHRASE:
+                oa = (C.c_uint32 * len(terms))(*(q[2] if len(q) > 2 and q[2] is not None
+                                                 else range(len(terms))))
+                keep.append(oa)
+                qs[i].phrase_offsets = C.cast(oa, C.POINTER(C.c_uint32))
+            qs[i].k = 1
+        counts = np.zeros(max(1, n), np.uint32)
+        _check(lib().tq_count_batch(self.segment_raw(segment_ord), qs, n, _u32(counts)))
+        return counts[:n]
 
     def raw_search(self, queries, weights, cache, k, segment_ord=0, stride=None):
         """Direct tq_search_batch: queries = list of (mode, [term ids], offsets|None);

@@ -149,7 +149,7 @@ struct tq_segment {
   uint32_t max_doc = 0;
   uint8_t record_option = 0;
   std::vector<uint8_t> h_idx, h_pos;
-  uint8_t *d_idx = nullptr, *d_pos = nullptr, *d_fn = nullptr;
+  uint8_t *d_idx = nullptr, *d_pos = nullptr, *d_fn = nullptr, *d_alive = nullptr;
   TqdSegment dseg{};
   std::vector<TermHost> terms;
   std::vector<TqdTerm> h_dterms;
@@ -159,7 +159,8 @@ struct tq_segment {
   size_t dense_bytes_total = 0;
   std::unordered_map<uint64_t, uint32_t> term_by_off;
   // batch scratch
-  DevBuf d_stage, d_partials, d_out_scores, d_out_docs, d_out_counts, d_misc, d_thr;
+  DevBuf d_stage, d_partials, d_out_scores, d_out_docs, d_out_counts, d_misc, d_thr, d_qmatches;
+  uint32_t last_batch_queries = 0;
   PinnedBuf h_stage, h_out;
   // timing: a ring of event quadruples, one per batch, so that pipelined batches (no host sync
   // between them) can all be timed; tq_last_batch_stats averages the batches since its last call
@@ -331,6 +332,7 @@ void tq_segment_free(tq_segment *s) {
   if (s->d_idx) (void)hipFree(s->d_idx);
   if (s->d_pos) (void)hipFree(s->d_pos);
   if (s->d_fn) (void)hipFree(s->d_fn);
+  if (s->d_alive) (void)hipFree(s->d_alive);
   if (s->d_match_counter) (void)hipFree(s->d_match_counter);
   s->d_stage.release();
   s->d_partials.release();
@@ -339,6 +341,7 @@ void tq_segment_free(tq_segment *s) {
   s->d_out_counts.release();
   s->d_misc.release();
   s->d_thr.release();
+  s->d_qmatches.release();
   s->h_stage.release();
   s->h_out.release();
   if (s->side_stream) (void)hipStreamSynchronize(s->side_stream);
@@ -622,7 +625,7 @@ struct Group {
   uint32_t total_tiles = 0, n_chunks = 0, max_k = 1;
   int kpl = 1;
   // offsets inside the staging blob
-  size_t o_queries = 0, o_tiles = 0, o_outidx = 0, o_chunks = 0, o_perm = 0;
+  size_t o_queries = 0, o_tiles = 0, o_outidx = 0, o_chunks = 0, o_perm = 0, o_sinks = 0;
 };
 
 static uint32_t tune_u32(const char *name, uint32_t dflt) {
@@ -994,6 +997,7 @@ int tq_search_batch_device(tq_segment *s, const tq_query *queries, uint32_t n_qu
     partial_bytes += (size_t)parts * (size_t)g.kpl * 64u * sizeof(uint64_t);
   }
   rc = s->d_partials.ensure(partial_bytes + 256);
+  if (rc == TQ_OK) rc = s->d_qmatches.ensure((size_t)n_queries * sizeof(uint32_t));
   if (rc != TQ_OK) return rc;
 
   // ---- stage: [caches][per group: queries | tile_starts | out_index]
@@ -1017,6 +1021,9 @@ int tq_search_batch_device(tq_segment *s, const tq_query *queries, uint32_t n_qu
     stage = (stage + 15) & ~(size_t)15;
     g.o_perm = stage;
     stage += g.chunk_perm.size() * sizeof(uint32_t);
+    stage = (stage + 15) & ~(size_t)15;
+    g.o_sinks = stage;
+    stage += sizeof(TqkSinks);
   }
   const auto tr1 = std::chrono::steady_clock::now();
   if (s->stage_in_flight) {
@@ -1037,6 +1044,16 @@ int tq_search_batch_device(tq_segment *s, const tq_query *queries, uint32_t n_qu
     memcpy(hs + g.o_chunks, g.chunk_starts.data(), g.chunk_starts.size() * sizeof(uint32_t));
     memcpy(hs + g.o_perm, g.chunk_perm.data(), g.chunk_perm.size() * sizeof(uint32_t));
   }
+  for (int gi = 0; gi < kGroups; ++gi) {
+    Group &g = groups[gi];
+    if (g.queries.empty()) continue;
+    TqkSinks sk{};
+    sk.partials = (uint64_t *)((uint8_t *)s->d_partials.p + part_off_bytes[gi]);
+    sk.match_counter = s->d_match_counter;
+    sk.query_matches = (uint32_t *)s->d_qmatches.p;
+    sk.out_index = (const uint32_t *)((const uint8_t *)s->d_stage.p + g.o_outidx);
+    memcpy(hs + g.o_sinks, &sk, sizeof sk);
+  }
   const auto tr2 = std::chrono::steady_clock::now();
   const int slot = (int)(s->batches_timed % tq_segment::kTimingRing);
   if (s->opt.timing) HIP_TRY(hipEventRecord(s->ev_t0[slot], st));
@@ -1044,6 +1061,8 @@ int tq_search_batch_device(tq_segment *s, const tq_query *queries, uint32_t n_qu
   HIP_TRY(hipEventRecord(s->ev_stage_done, st));
   s->stage_in_flight = true;
   HIP_TRY(hipMemsetAsync(s->d_match_counter, 0, sizeof(unsigned long long), st));
+  HIP_TRY(hipMemsetAsync(s->d_qmatches.p, 0, (size_t)n_queries * sizeof(uint32_t), st));
+  s->last_batch_queries = n_queries;
   if (n_thr_rows) {
     const size_t thr_bytes = (size_t)n_thr_rows * TQD_THR_SLOTS * sizeof(uint32_t);
     rc = s->d_thr.ensure(thr_bytes);
@@ -1079,8 +1098,7 @@ int tq_search_batch_device(tq_segment *s, const tq_query *queries, uint32_t n_qu
     p.queries = (const TqdQuery *)(ds + g.o_queries);
     p.tile_starts = (const uint32_t *)(ds + g.o_tiles);
     p.caches = (const float *)(ds + o_caches);
-    p.partials = (uint64_t *)((uint8_t *)s->d_partials.p + part_off_bytes[gi]);
-    p.match_counter = s->d_match_counter;
+    p.sinks = (const TqkSinks *)(ds + g.o_sinks);
     p.thr_slots = (uint32_t *)s->d_thr.p;
     p.n_queries = (uint32_t)g.queries.size();
     p.total_tiles = g.total_tiles;
@@ -1170,6 +1188,55 @@ int tq_search_batch(tq_segment *s, const tq_query *queries, uint32_t n_queries,
                          hipMemcpyDeviceToHost, s->stream));
   HIP_TRY(hipStreamSynchronize(s->stream));
   return TQ_OK;
+}
+
+int tq_segment_set_alive_bitset(tq_segment *s, const uint8_t *bytes, size_t len) {
+  if (!s) return fail(TQ_ERR_INVALID, "tq_segment_set_alive_bitset: null segment");
+  HIP_TRY(hipSetDevice(s->device));
+  HIP_TRY(hipStreamSynchronize(s->stream));
+  if (s->d_alive) (void)hipFree(s->d_alive);
+  s->d_alive = nullptr;
+  s->dseg.alive = nullptr;
+  if (!bytes) return TQ_OK;  // no deletes
+  // BitSet::serialize (common/src/bitset.rs:215-223): u32 LE max_value, then 64-bit tiny sets
+  if (len < 4) return fail(TQ_ERR_FORMAT, "alive bitset shorter than its header");
+  const uint32_t max_value = rd32(bytes);
+  const size_t need = ((size_t)s->max_doc + 63) / 64 * 8;
+  if (max_value != s->max_doc || len - 4 < need || (len - 4) % 8 != 0)
+    return fail(TQ_ERR_FORMAT, "alive bitset for %u docs / %zu bytes does not fit max_doc %u",
+                max_value, len - 4, s->max_doc);
+  HIP_TRY(hipMalloc((void **)&s->d_alive, len - 4 + PAD));
+  HIP_TRY(hipMemset(s->d_alive + (len - 4), 0, PAD));
+  HIP_TRY(hipMemcpy(s->d_alive, bytes + 4, len - 4, hipMemcpyHostToDevice));
+  s->dseg.alive = s->d_alive;
+  return TQ_OK;
+}
+
+int tq_last_batch_match_counts(tq_segment *s, uint32_t *out, uint32_t n) {
+  if (!s || !out) return fail(TQ_ERR_INVALID, "tq_last_batch_match_counts: null argument");
+  if (n > s->last_batch_queries) return fail(TQ_ERR_INVALID, "the last batch had %u queries", s->last_batch_queries);
+  HIP_TRY(hipSetDevice(s->device));
+  HIP_TRY(hipStreamSynchronize(s->stream));
+  HIP_TRY(hipMemcpy(out, s->d_qmatches.p, (size_t)n * sizeof(uint32_t), hipMemcpyDeviceToHost));
+  return TQ_OK;
+}
+
+int tq_count_batch(tq_segment *s, const tq_query *queries, uint32_t n_queries,
+                   uint32_t *out_counts) {
+  if (!s || (!queries && n_queries) || !out_counts)
+    return fail(TQ_ERR_INVALID, "tq_count_batch: null argument");
+  if (n_queries == 0) return TQ_OK;
+  // every match has to be visited: exhaustive scan, smallest top-k
+  std::vector<tq_query> qs(queries, queries + n_queries);
+  for (tq_query &q : qs) q.k = 1;
+  std::vector<float> sc(n_queries);
+  std::vector<uint32_t> dc(n_queries), ct(n_queries);
+  const int saved = s->opt.exhaustive;
+  s->opt.exhaustive = 1;
+  int rc = tq_search_batch(s, qs.data(), n_queries, 1, sc.data(), dc.data(), ct.data());
+  s->opt.exhaustive = saved;
+  if (rc != TQ_OK) return rc;
+  return tq_last_batch_match_counts(s, out_counts, n_queries);
 }
 
 int tq_last_batch_stats(tq_segment *s, tq_batch_stats *out) {

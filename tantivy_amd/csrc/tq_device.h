@@ -70,6 +70,7 @@ struct TqdSegment {
   const uint8_t *idx;        // .idx sub-file (8-byte header included), padded
   const uint8_t *pos;        // .pos sub-file or null
   const uint8_t *fieldnorm;  // max_doc bytes or null
+  const uint8_t *alive;      // AliveBitSet bits (bit d of byte d>>3) or null = no deletes
   uint32_t max_doc;
   uint32_t const_fieldnorm_id;
   uint32_t min_fieldnorm_id;  // smallest fieldnorm id present (lower bound of every doc's norm)

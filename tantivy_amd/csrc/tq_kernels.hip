@@ -313,6 +313,12 @@ __device__ __forceinline__ uint32_t seek_block(const TermRef &t, uint32_t doc) {
 __device__ __forceinline__ uint32_t fieldnorm_id(const TqdSegment &seg, uint32_t doc) {
   return seg.fieldnorm ? (uint32_t)seg.fieldnorm[doc] : seg.const_fieldnorm_id;
 }
+// AliveBitSet::is_alive (src/fastfield/alive_bitset.rs:58-61; ReadOnlyBitSet::contains,
+// common/src/bitset.rs:305-311): deleted docs never reach the collector
+// (sort_by_score.rs:44-53); statistics and block-max metadata still include them.
+__device__ __forceinline__ bool doc_is_alive(const TqdSegment &seg, uint32_t doc) {
+  return !seg.alive || ((seg.alive[doc >> 3] >> (doc & 7u)) & 1u);
+}
 __device__ __forceinline__ float bm25(float weight, float norm, uint32_t tf) {
   const float f = (float)tf;
   return weight * (f / (f + norm));  // bm25.rs:179-193; compiled with -ffp-contract=off
@@ -653,7 +659,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_num_sgpr(80))) void and_k
   uint32_t thr = 0, thr_g = 0;
   uint32_t cache_loaded = 0xFFFFFFFFu;
   TopK<KPL> tk;
-  uint32_t n_matches = 0;
+  uint32_t n_matches = 0, n_q = 0;  // docs scored: whole chunk / current query
   uint32_t q1n = 0, q2n = 0;  // queue fill
 
   auto setup_query = [&]() __attribute__((always_inline)) {
@@ -760,9 +766,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_num_sgpr(80))) void and_k
       }
       if (alive) s = s + bm25(w, norm, block_tf_at(idx, tr, mo, at));
     }
+    if (alive) alive = doc_is_alive(seg, doc);
     const uint64_t hit = __ballot(alive);
     if (hit) {
       n_matches += (uint32_t)__popcll(hit);
+      n_q += (uint32_t)__popcll(hit);
       const uint64_t key = alive ? make_key(s, doc) : 0ull;
       if (slots) {
         const uint32_t sb = (uint32_t)(key >> 32);
@@ -833,7 +841,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_num_sgpr(80))) void and_k
       if (q_tile_end > q_tile_start && q_tile_end > t_begin) {  // this chunk touched query q
         drain();
         const uint32_t part = sload(&Q->part_start) + (chunk - sload(&Q->chunk_first));
-        flush_partial<KPL>(tk, p.partials, part, lane);
+        flush_partial<KPL>(tk, sload(&p.sinks->partials), part, lane);
+        if (lane == 0 && n_q) atomicAdd(sload(&p.sinks->query_matches) + sload(sload(&p.sinks->out_index) + q), n_q);
+        n_q = 0;
       }
       ++q;
       setup_query();
@@ -1000,9 +1010,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_num_sgpr(80))) void and_k
   if (q_tile_end > q_tile_start) {
     drain();
     const uint32_t part = sload(&Q->part_start) + (chunk - sload(&Q->chunk_first));
-    flush_partial<KPL>(tk, p.partials, part, lane);
+    flush_partial<KPL>(tk, sload(&p.sinks->partials), part, lane);
+        if (lane == 0 && n_q) atomicAdd(sload(&p.sinks->query_matches) + sload(sload(&p.sinks->out_index) + q), n_q);
+        n_q = 0;
   }
-  if (lane == 0 && n_matches) atomicAdd(p.match_counter, (unsigned long long)n_matches);
+  if (lane == 0 && n_matches) atomicAdd(sload(&p.sinks->match_counter), (unsigned long long)n_matches);
 }
 
 // =================================================================== OR kernel
@@ -1062,7 +1074,7 @@ __global__ __launch_bounds__(TQD_WAVES_PER_WG * 64) void or_kernel(TqkScanParams
   uint32_t thr = 0, thr_g = 0;
   uint32_t cache_loaded = 0xFFFFFFFFu;
   TopK<KPL> tk;
-  uint32_t n_matches = 0;
+  uint32_t n_matches = 0, n_q = 0;  // docs scored: whole chunk / current query
   uint32_t cqn = 0;  // this wave's candidate queue fill
   uint32_t plan_begin = 0xFFFFFFFFu, plan_end = 0;  // windows [plan_begin, plan_end) are planned
 
@@ -1132,9 +1144,11 @@ __global__ __launch_bounds__(TQD_WAVES_PER_WG * 64) void or_kernel(TqkScanParams
         }
       }
     }
+    if (alive) alive = doc_is_alive(seg, doc);
     const uint64_t hit = __ballot(alive);
     if (hit) {
       n_matches += (uint32_t)__popcll(hit);
+      n_q += (uint32_t)__popcll(hit);
       const uint64_t key = alive ? make_key(s, doc) : 0ull;
       if (slots) {
         const uint32_t sb = (uint32_t)(key >> 32);
@@ -1153,7 +1167,9 @@ __global__ __launch_bounds__(TQD_WAVES_PER_WG * 64) void or_kernel(TqkScanParams
       if (q_tile_end > q_tile_start && q_tile_end > t_begin) {
         const uint32_t part = sload(&Q->part_start) +
                               (chunk - sload(&Q->chunk_first)) * TQD_WAVES_PER_WG + wave;
-        flush_partial<KPL>(tk, p.partials, part, lane);
+        flush_partial<KPL>(tk, sload(&p.sinks->partials), part, lane);
+        if (lane == 0 && n_q) atomicAdd(sload(&p.sinks->query_matches) + sload(sload(&p.sinks->out_index) + q), n_q);
+        n_q = 0;
       }
       ++q;
       setup_query();
@@ -1244,12 +1260,14 @@ __global__ __launch_bounds__(TQD_WAVES_PER_WG * 64) void or_kernel(TqkScanParams
     const float rest = L.suffix[E];
     for (uint32_t i = tid; i < TQD_OR_WINDOW; i += TQD_WAVES_PER_WG * 64) {
       bool has = (L.present[i >> 5] >> (i & 31u)) & 1u;
+      if (has) has = doc_is_alive(seg, base + i);
       const float s = L.acc[i];
       if (E == nt) {  // every list was enumerated: final score
         const uint64_t key = has ? make_key(s, base + i) : 0ull;
         const uint64_t hit = __ballot(has);
         if (hit) {
           n_matches += (uint32_t)__popcll(hit);
+          n_q += (uint32_t)__popcll(hit);
           if (slots) {
             const uint32_t sb = (uint32_t)(key >> 32);
             const uint32_t h = ((base + i) * 0x9E3779B1u) >> (n_slot_rows == 1u ? 26 : 25);
@@ -1283,9 +1301,11 @@ __global__ __launch_bounds__(TQD_WAVES_PER_WG * 64) void or_kernel(TqkScanParams
   if (q_tile_end > q_tile_start) {
     const uint32_t part = sload(&Q->part_start) +
                           (chunk - sload(&Q->chunk_first)) * TQD_WAVES_PER_WG + wave;
-    flush_partial<KPL>(tk, p.partials, part, lane);
+    flush_partial<KPL>(tk, sload(&p.sinks->partials), part, lane);
+        if (lane == 0 && n_q) atomicAdd(sload(&p.sinks->query_matches) + sload(sload(&p.sinks->out_index) + q), n_q);
+        n_q = 0;
   }
-  if (lane == 0 && n_matches) atomicAdd(p.match_counter, (unsigned long long)n_matches);
+  if (lane == 0 && n_matches) atomicAdd(sload(&p.sinks->match_counter), (unsigned long long)n_matches);
 }
 
 // =================================================================== union kernel (candidate-driven)
@@ -1332,7 +1352,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_num_sgpr(96))) void union
   uint32_t cache_loaded = 0xFFFFFFFFu;
   float min_norm = 0.0f;
   TopK<KPL> tk;
-  uint32_t n_matches = 0;
+  uint32_t n_matches = 0, n_q = 0;  // docs scored: whole chunk / current query
   uint32_t q1n = 0;
   // leader of the current tile
   uint32_t li = 0, li_end = 0;
@@ -1428,9 +1448,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_num_sgpr(96))) void union
         s = s + bm25(w, norm, block_tf_at(idx, tr, make_uint2(r.y, r.z), at));
       }
     }
+    if (alive) alive = doc_is_alive(seg, doc);
     const uint64_t hit = __ballot(alive);
     if (hit) {
       n_matches += (uint32_t)__popcll(hit);
+      n_q += (uint32_t)__popcll(hit);
       const uint64_t key = alive ? make_key(s, doc) : 0ull;
       if (slots) {
         const uint32_t sb = (uint32_t)(key >> 32);
@@ -1451,7 +1473,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_num_sgpr(96))) void union
       if (q_tile_end > q_tile_start && q_tile_end > t_begin) {
         while (q1n) stageB(q1n < 64u ? q1n : 64u);
         const uint32_t part = sload(&Q->part_start) + (chunk - sload(&Q->chunk_first));
-        flush_partial<KPL>(tk, p.partials, part, lane);
+        flush_partial<KPL>(tk, sload(&p.sinks->partials), part, lane);
+        if (lane == 0 && n_q) atomicAdd(sload(&p.sinks->query_matches) + sload(sload(&p.sinks->out_index) + q), n_q);
+        n_q = 0;
       }
       ++q;
       setup_query();
@@ -1564,9 +1588,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_num_sgpr(96))) void union
   if (q_tile_end > q_tile_start) {
     while (q1n) stageB(q1n < 64u ? q1n : 64u);
     const uint32_t part = sload(&Q->part_start) + (chunk - sload(&Q->chunk_first));
-    flush_partial<KPL>(tk, p.partials, part, lane);
+    flush_partial<KPL>(tk, sload(&p.sinks->partials), part, lane);
+        if (lane == 0 && n_q) atomicAdd(sload(&p.sinks->query_matches) + sload(sload(&p.sinks->out_index) + q), n_q);
+        n_q = 0;
   }
-  if (lane == 0 && n_matches) atomicAdd(p.match_counter, (unsigned long long)n_matches);
+  if (lane == 0 && n_matches) atomicAdd(sload(&p.sinks->match_counter), (unsigned long long)n_matches);
 }
 
 // positions: raw deltas of a whole term (PositionReader::read over everything).  pos_blk[pb] =
@@ -1651,7 +1677,7 @@ __global__ __launch_bounds__(64) void phrase_kernel(TqkScanParams p) {
   float weight = 0.0f;
   uint32_t cache_loaded = 0xFFFFFFFFu;
   TopK<KPL> tk;
-  uint32_t n_matches = 0;
+  uint32_t n_matches = 0, n_q = 0;  // docs scored: whole chunk / current query
   uint32_t q1n = 0, q2n = 0;
 
   auto setup_query = [&]() __attribute__((always_inline)) {
@@ -1769,7 +1795,7 @@ __global__ __launch_bounds__(64) void phrase_kernel(TqkScanParams p) {
         }
         pos_advance(cur[0], pos, p.terms + Q->term[0]);
       }
-      if (count > 0) {
+      if (count > 0 && doc_is_alive(seg, doc)) {
         has = true;
         key = make_key(bm25(weight, L.cache[fieldnorm_id(seg, doc)], count), doc);
       }
@@ -1777,6 +1803,7 @@ __global__ __launch_bounds__(64) void phrase_kernel(TqkScanParams p) {
     const uint64_t hit = __ballot(has);
     if (hit) {
       n_matches += (uint32_t)__popcll(hit);
+      n_q += (uint32_t)__popcll(hit);
       tk.offer(has, key, lane);
     }
   };
@@ -1832,7 +1859,9 @@ __global__ __launch_bounds__(64) void phrase_kernel(TqkScanParams p) {
       if (q_tile_end > q_tile_start && q_tile_end > t_begin) {
         drain();
         const uint32_t part = sload(&Q->part_start) + (chunk - sload(&Q->chunk_first));
-        flush_partial<KPL>(tk, p.partials, part, lane);
+        flush_partial<KPL>(tk, sload(&p.sinks->partials), part, lane);
+        if (lane == 0 && n_q) atomicAdd(sload(&p.sinks->query_matches) + sload(sload(&p.sinks->out_index) + q), n_q);
+        n_q = 0;
       }
       ++q;
       setup_query();
@@ -1896,9 +1925,11 @@ __global__ __launch_bounds__(64) void phrase_kernel(TqkScanParams p) {
   if (q_tile_end > q_tile_start) {
     drain();
     const uint32_t part = sload(&Q->part_start) + (chunk - sload(&Q->chunk_first));
-    flush_partial<KPL>(tk, p.partials, part, lane);
+    flush_partial<KPL>(tk, sload(&p.sinks->partials), part, lane);
+        if (lane == 0 && n_q) atomicAdd(sload(&p.sinks->query_matches) + sload(sload(&p.sinks->out_index) + q), n_q);
+        n_q = 0;
   }
-  if (lane == 0 && n_matches) atomicAdd(p.match_counter, (unsigned long long)n_matches);
+  if (lane == 0 && n_matches) atomicAdd(sload(&p.sinks->match_counter), (unsigned long long)n_matches);
 }
 
 // =================================================================== merge kernel

@@ -5,6 +5,16 @@
 
 #include "tq_device.h"
 
+// Output locations of a scan launch.  Kept in device memory behind ONE kernel-argument pointer:
+// they are touched once per (chunk, query), and as kernel arguments they would pin 8 SGPRs of a
+// kernel that is already spilling scalar registers.
+struct TqkSinks {
+  uint64_t *partials;                 // partial top-k lists, KPL*64 keys each
+  unsigned long long *match_counter;  // docs scored by the whole launch
+  uint32_t *query_matches;            // per query of the BATCH (through out_index): docs scored
+  const uint32_t *out_index;          // launch-group query -> batch query
+};
+
 struct TqkScanParams {
   TqdSegment seg;
   const TqdTerm *terms;
@@ -13,8 +23,7 @@ struct TqkScanParams {
   const uint32_t *chunk_starts; // n_chunks + 1: first tile of every chunk
   const uint32_t *chunk_perm;   // n_chunks: launch index -> chunk
   const float *caches;          // n_caches x 256
-  uint64_t *partials;           // partial top-k lists, KPL*64 keys each
-  unsigned long long *match_counter;
+  const TqkSinks *sinks;        // where results go (read at flush time only)
   uint32_t *thr_slots;          // [n_thr_rows][TQD_THR_SLOTS] shared thresholds (pruned mode)
   uint32_t n_queries;
   uint32_t total_tiles;

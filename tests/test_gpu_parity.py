@@ -386,6 +386,72 @@ def test_fuzz_random_segments(ta, seed):
         dev.close()
 
 
+def _alive_bytes(max_doc, deleted):
+    """BitSet::serialize (common/src/bitset.rs:215-223) of the alive set."""
+    bits = np.ones(((max_doc + 63) // 64) * 64, dtype=np.uint8)
+    bits[max_doc:] = 0
+    bits[np.asarray(sorted(deleted), dtype=np.int64)] = 0
+    return np.uint32(max_doc).tobytes() + np.packbits(bits, bitorder="little").tobytes()
+
+
+def test_deletes_and_counts(ta):
+    """AliveBitSet filter (sort_by_score.rs:44-53) and per-query match counts (Count collector),
+    every query shape, pruned and exhaustive."""
+    seg = O.synth_segment(120_000, n_terms=48, with_positions=True, phrase_terms=12)
+    rng = np.random.default_rng(77)
+    deleted = set(rng.choice(seg.max_doc, size=seg.max_doc // 3, replace=False).tolist())
+    queries = [(O.MODE_AND, [0, 1]), (O.MODE_AND, [2, 30]), (O.MODE_AND, [40, 41, 3]),
+               (O.MODE_OR, [0, 5, 9]), (O.MODE_OR, [44]), (O.MODE_OR, [1, 2, 3, 20, 47]),
+               (O.MODE_PHRASE, [0, 1, 2]), (O.MODE_PHRASE, [4, 5])]
+    dev = ta.DeviceIndex([seg])
+    try:
+        # counts without deletes == oracle match counts
+        dev.search(queries, 10)
+        counts = dev.last_batch_match_counts(len(queries))
+        for (mode, terms), c in zip(queries, counts.tolist()):
+            d, _ = O.match_all(seg, terms, mode)
+            assert c == len(d), (mode, terms)
+        dev.set_alive_bitset(_alive_bytes(seg.max_doc, deleted))
+        for k in (5, 100):
+            want = []
+            for mode, terms in queries:
+                d, s = O.match_all(seg, terms, mode)
+                hits = [(float(sc), int(doc)) for doc, sc in zip(d.tolist(), s.tolist())
+                        if doc not in deleted]
+                hits.sort(key=lambda h: (-h[0], h[1]))
+                want.append(hits)
+            for ex in (1, 0):
+                dev.set_option("exhaustive", ex)
+                got = _device_topk(dev, queries, k)
+                if ex:
+                    counts = dev.last_batch_match_counts(len(queries))
+                for i, ((mode, terms), g, w) in enumerate(zip(queries, got, want)):
+                    assert all(doc not in deleted for _, doc in g)
+                    _assert_hits(g, w[:k], mode, len(terms))
+                    if ex:
+                        assert counts[i] == len(w), (mode, terms)
+        dev.set_option("exhaustive", 1)
+        # Count collector through the C ABI (tq_count_batch), deletes applied, mode untouched
+        dev.set_option("exhaustive", 0)
+        w1, cache = ta.bm25_for_terms([seg.terms[0].doc_freq], seg.max_doc, seg.total_num_tokens)
+        cnt = dev.raw_count([(O.MODE_AND, [0, 1]), (O.MODE_OR, [0, 5, 9]), (O.MODE_PHRASE, [0, 1, 2])],
+                            [[w1, w1], [w1, w1, w1], [w1]], cache)
+        for (mode, terms), c in zip([queries[0], queries[3], queries[6]], cnt.tolist()):
+            d, _ = O.match_all(seg, terms, mode)
+            assert c == sum(1 for doc in d.tolist() if doc not in deleted), (mode, terms)
+        dev.set_option("exhaustive", 1)
+        # clearing the bitset restores the plain results
+        dev.set_alive_bitset(None)
+        got = _device_topk(dev, queries[:2], 10)
+        for (mode, terms), g in zip(queries[:2], got):
+            _assert_hits_equal(g, _oracle_topk(seg, terms, mode, 10))
+        # malformed bitsets are refused
+        with pytest.raises(ta.TantivyAmdError):
+            dev.set_alive_bitset(np.uint32(seg.max_doc + 1).tobytes() + bytes(8 * ((seg.max_doc + 63) // 64)))
+    finally:
+        dev.close()
+
+
 def test_ties_prefer_lower_doc(ta):
     md = 1000
     lists = [[(d, 2) for d in range(0, md, 2)], [(d, 2) for d in range(0, md, 3)]]
