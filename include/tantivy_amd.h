@@ -48,7 +48,14 @@ enum tq_record_option { TQ_BASIC = 0, TQ_WITH_FREQS = 1, TQ_WITH_FREQS_AND_POSIT
  * AND    = all-Must term clauses   -> block_wand_intersection
  * OR     = all-Should term clauses -> block_wand / BufferedUnionScorer
  * PHRASE = PhraseQuery (slop 0)    -> PhraseScorer */
-enum tq_mode { TQ_MODE_AND = 0, TQ_MODE_OR = 1, TQ_MODE_PHRASE = 2 };
+enum tq_mode { TQ_MODE_AND = 0, TQ_MODE_OR = 1, TQ_MODE_PHRASE = 2, TQ_MODE_BOOL = 3 };
+/* TQ_MODE_BOOL = flat BooleanQuery of term clauses with mixed occurs (`+a b -c`), the
+ * RequiredOptionalScorer / Exclude part of BooleanWeight::complex_scorer
+ * (boolean_weight.rs:347-431, reqopt_scorer.rs:85-98, exclude.rs): docs = AND of the Must terms
+ * (or OR of the Should terms when there is no Must) minus the MustNot terms; score = sum of the
+ * Must terms' scores + sum of the matching Should terms' scores.  Values of tq_query.occurs
+ * follow src/query/occur.rs. */
+enum tq_occur { TQ_SHOULD = 0, TQ_MUST = 1, TQ_MUST_NOT = 2 };
 
 typedef struct tq_ctx tq_ctx;
 typedef struct tq_segment tq_segment;
@@ -67,6 +74,7 @@ typedef struct tq_query {
   uint8_t mode;                  /* enum tq_mode */
   const uint32_t *phrase_offsets; /* PHRASE: term offsets inside the phrase; else NULL */
   uint32_t k;                    /* TopDocs offset+limit, 1..TQ_MAX_K */
+  const uint8_t *occurs;         /* TQ_MODE_BOOL: n_terms x enum tq_occur; else NULL */
 } tq_query;
 
 /* ---- lifecycle ---- */

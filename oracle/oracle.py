@@ -494,6 +494,71 @@ def match_all(seg, term_ids, mode, weights=None, phrase_offsets=None, cap=None):
     return docs[:n], scores[:n]
 
 
+SHOULD, MUST, MUST_NOT = 0, 1, 2  # src/query/occur.rs
+
+
+def bool_match_all(seg, term_ids, occurs):
+    """Flat BooleanQuery of term clauses with mixed occurs, restated from
+    BooleanWeight::complex_scorer (src/query/boolean_query/boolean_weight.rs:236-431):
+      - Must terms intersect, cheapest first; Intersection::score = left + right + sum(others)
+        (src/query/intersection.rs:93, :325-329);
+      - Should terms are optional when there is a Must (RequiredOptionalScorer::score =
+        req + opt, src/query/reqopt_scorer.rs:85-98) and form the union otherwise; the union's
+        SumCombiner adds in clause order (the reference's own order depends on scorer removal,
+        so 2+ Should terms compare within 1e-5);
+      - MustNot terms exclude (src/query/exclude.rs); MustNot clauses alone match nothing.
+    Every term scores with its own Bm25Weight (TermQuery::specialized_weight).
+    Returns (docs ascending, f32 scores)."""
+    per = {}
+    for t in set(term_ids):
+        d, sc = match_all(seg, [t], MODE_OR)
+        per[t] = (d.astype(np.int64), sc.astype(np.float32))
+    must = [t for t, o in zip(term_ids, occurs) if o == MUST]
+    should = [t for t, o in zip(term_ids, occurs) if o == SHOULD]
+    mustnot = [t for t, o in zip(term_ids, occurs) if o == MUST_NOT]
+    md = seg.max_doc
+
+    def dense(t):
+        sc = np.zeros(md, np.float32)
+        hit = np.zeros(md, bool)
+        sc[per[t][0]] = per[t][1]
+        hit[per[t][0]] = True
+        return hit, sc
+
+    opt = np.zeros(md, np.float32)
+    any_should = np.zeros(md, bool)
+    for t in should:
+        hit, sc = dense(t)
+        opt = (opt + sc).astype(np.float32)
+        any_should |= hit
+    if must:
+        must = sorted(must, key=lambda t: seg.terms[t].doc_freq)  # stable, like sort_by_key
+        match = np.ones(md, bool)
+        parts = []
+        for t in must:
+            hit, sc = dense(t)
+            match &= hit
+            parts.append(sc)
+        score = parts[0]
+        if len(parts) > 1:
+            score = (score + parts[1]).astype(np.float32)
+        if len(parts) > 2:
+            oth = np.zeros(md, np.float32)
+            for sc in parts[2:]:
+                oth = (oth + sc).astype(np.float32)
+            score = (score + oth).astype(np.float32)
+        if should:
+            score = (score + opt).astype(np.float32)
+    elif should:
+        match, score = any_should, opt
+    else:
+        match, score = np.zeros(md, bool), opt
+    for t in mustnot:
+        match &= ~dense(t)[0]
+    docs = np.nonzero(match)[0]
+    return docs.astype(np.uint32), score[docs]
+
+
 def decode_postings(seg, term_id):
     t = seg.terms[term_id]
     docs = np.zeros(max(1, t.doc_freq), np.uint32)

@@ -3,4 +3,4 @@ BM25, top-k) behind a C ABI (include/tantivy_amd.h).  This package is only the P
 that library; there is no CPU fallback: importing `binding` without the built HIP library raises.
 """
 from .binding import (DeviceIndex, TantivyAmdError, lib, bm25_for_terms, MODE_AND, MODE_OR,  # noqa: F401
-                      MODE_PHRASE, MODE_TERM, TERMINATED)
+                      MODE_PHRASE, MODE_TERM, MODE_BOOL, SHOULD, MUST, MUST_NOT, TERMINATED)

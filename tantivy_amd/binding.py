@@ -9,7 +9,8 @@ LIB_PATH = os.path.join(_HERE, "lib", "libtantivy_amd.so")
 
 TERMINATED = 0x7FFFFFFF
 TERM_ABSENT = 0xFFFFFFFF
-MODE_AND, MODE_OR, MODE_PHRASE, MODE_TERM = 0, 1, 2, 3
+MODE_AND, MODE_OR, MODE_PHRASE, MODE_TERM, MODE_BOOL = 0, 1, 2, 3, 4
+SHOULD, MUST, MUST_NOT = 0, 1, 2  # src/query/occur.rs
 BASIC, WITH_FREQS, WITH_FREQS_AND_POSITIONS = 0, 1, 2
 
 
@@ -23,7 +24,7 @@ class TqQuery(C.Structure):
     _fields_ = [("n_terms", C.c_uint32), ("terms", C.POINTER(C.c_uint32)),
                 ("weights", C.POINTER(C.c_float)), ("tf_cache", C.POINTER(C.c_float)),
                 ("mode", C.c_uint8), ("phrase_offsets", C.POINTER(C.c_uint32)),
-                ("k", C.c_uint32)]
+                ("k", C.c_uint32), ("occurs", C.POINTER(C.c_uint8))]
 
 
 class TqBatchStats(C.Structure):
@@ -40,7 +41,7 @@ class TqhTermInfo(C.Structure):
 
 class TqhQuery(C.Structure):
     _fields_ = [("mode", C.c_uint8), ("n_terms", C.c_uint32), ("terms", C.POINTER(C.c_uint32)),
-                ("phrase_offsets", C.POINTER(C.c_uint32))]
+                ("phrase_offsets", C.POINTER(C.c_uint32)), ("occurs", C.POINTER(C.c_uint8))]
 
 
 _lib = None
@@ -209,7 +210,8 @@ class DeviceIndex:
 
     # ---- host-mirror path (Query::weight + Searcher::search)
     def prepare(self, queries):
-        """queries: list of (mode, [term ids]) or (MODE_PHRASE, [term ids], [offsets])."""
+        """queries: list of (mode, [term ids]), (MODE_PHRASE, [term ids], [offsets]) or
+        (MODE_BOOL, [term ids], [occurs]) with occurs in {SHOULD, MUST, MUST_NOT}."""
         n = len(queries)
         qs = (TqhQuery * max(1, n))()
         keep = []
@@ -220,7 +222,11 @@ class DeviceIndex:
             qs[i].mode = mode
             qs[i].n_terms = len(terms)
             qs[i].terms = C.cast(ta, C.POINTER(C.c_uint32))
-            if len(q) > 2 and q[2] is not None:
+            if mode == MODE_BOOL:
+                oc = (C.c_uint8 * len(terms))(*[int(o) for o in q[2]])
+                keep.append(oc)
+                qs[i].occurs = C.cast(oc, C.POINTER(C.c_uint8))
+            elif len(q) > 2 and q[2] is not None:
                 oa = (C.c_uint32 * len(terms))(*[int(o) for o in q[2]])
                 keep.append(oa)
                 qs[i].phrase_offsets = C.cast(oa, C.POINTER(C.c_uint32))
@@ -359,6 +365,10 @@ class DeviceIndex:
                 oa = (C.c_uint32 * len(terms))(*q[2])
                 keep.append(oa)
                 qs[i].phrase_offsets = C.cast(oa, C.POINTER(C.c_uint32))
+            if len(q) > 3 and q[3] is not None:  # TQ_MODE_BOOL (= 3 at this level): enum tq_occur
+                oc = (C.c_uint8 * len(terms))(*q[3])
+                keep.append(oc)
+                qs[i].occurs = C.cast(oc, C.POINTER(C.c_uint8))
             qs[i].k = k
         scores = np.zeros((n, stride), np.float32)
         docs = np.zeros((n, stride), np.uint32)

@@ -660,7 +660,11 @@ int tq_search_batch_device(tq_segment *s, const tq_query *queries, uint32_t n_qu
   if (rc != TQ_OK) return rc;
 
   // ---- plan
-  const bool or_windows = s->opt.or_windows < 0 ? s->opt.exhaustive != 0 : s->opt.or_windows != 0;
+  // queries with Must / MustNot roles only run on the candidate-driven union kernel
+  bool any_bool = false;
+  for (uint32_t qi = 0; qi < n_queries; ++qi) any_bool = any_bool || queries[qi].mode == TQ_MODE_BOOL;
+  const bool or_windows =
+      !any_bool && (s->opt.or_windows < 0 ? s->opt.exhaustive != 0 : s->opt.or_windows != 0);
   // launch groups: AND queries whose non-leader lists all have a bitmap run a leaner kernel
   // instantiation (no seek / block-search code: fewer registers, less LDS, more waves per CU)
   constexpr int kGroups = 4, kAndGeneral = 3;
@@ -681,7 +685,9 @@ int tq_search_batch_device(tq_segment *s, const tq_query *queries, uint32_t n_qu
                   TQ_MAX_K, out_stride);
     if (!q.terms || !q.weights || !q.tf_cache)
       return fail(TQ_ERR_INVALID, "query %u: null terms/weights/tf_cache", qi);
-    if (q.mode > TQ_MODE_PHRASE) return fail(TQ_ERR_INVALID, "query %u: bad mode", qi);
+    if (q.mode > TQ_MODE_BOOL) return fail(TQ_ERR_INVALID, "query %u: bad mode", qi);
+    if (q.mode == TQ_MODE_BOOL && !q.occurs)
+      return fail(TQ_ERR_INVALID, "query %u: TQ_MODE_BOOL needs occurs", qi);
     if (q.mode == TQ_MODE_PHRASE && (q.n_terms < 2 || !q.phrase_offsets))
       return fail(TQ_ERR_INVALID, "query %u: a phrase needs >= 2 terms and offsets", qi);
     if (q.mode == TQ_MODE_PHRASE && q.n_terms > 8)
@@ -764,7 +770,85 @@ int tq_search_batch_device(tq_segment *s, const tq_query *queries, uint32_t n_qu
         }
       }
     }
-    if (mode == TQ_MODE_OR) {
+    bool bool_done = false;
+    if (q.mode == TQ_MODE_BOOL) {
+      // flat BooleanQuery with mixed occurs (boolean_weight.rs:236-431): absent Should / MustNot
+      // terms drop out, an absent Must term empties the query (EmptyScorer, :249-251)
+      uint32_t must[TQ_MAX_TERMS], should[TQ_MAX_TERMS], mustnot[TQ_MAX_TERMS];
+      uint32_t n_must = 0, n_should = 0, n_not = 0;
+      bool empty = false;
+      for (uint32_t i = 0; i < q.n_terms; ++i) {
+        if (q.occurs[i] > TQ_MUST_NOT) return fail(TQ_ERR_INVALID, "query %u: bad occur", qi);
+        const bool absent = q.terms[i] == TQ_TERM_ABSENT;
+        if (q.occurs[i] == TQ_MUST) {
+          if (absent) empty = true;
+          must[n_must++] = i;
+        } else if (!absent) {
+          if (q.occurs[i] == TQ_SHOULD)
+            should[n_should++] = i;
+          else
+            mustnot[n_not++] = i;
+        }
+      }
+      // MustNot clauses only: no include scorer, EmptyScorer (boolean_weight.rs:340-349)
+      if (n_must == 0 && n_should == 0) empty = true;
+      mode = TQ_MODE_OR;  // runs in the union launch group
+      bool_done = true;
+      if (!empty) {
+        auto df = [&](uint32_t i) { return s->terms[q.terms[i]].doc_freq; };
+        uint32_t n = 0;
+        auto put = [&](uint32_t i, uint32_t role) {
+          dq.term[n] = q.terms[i];
+          dq.weight[n] = role == TQD_ROLE_MUST_NOT ? 0.0f : q.weights[i];
+          dq.roles |= role << (2u * n);
+          qbytes += s->terms[q.terms[i]].postings_len;
+          ++n;
+        };
+        uint32_t n_leaders;
+        if (n_must) {
+          // Must terms by doc freq ascending (intersect_scorers sorts by cost), MustNot terms
+          // next (they only exclude: densest first), Should terms last in clause order
+          std::stable_sort(must, must + n_must, [&](uint32_t a, uint32_t b) { return df(a) < df(b); });
+          std::stable_sort(mustnot, mustnot + n_not, [&](uint32_t a, uint32_t b) { return df(a) > df(b); });
+          for (uint32_t i = 0; i < n_must; ++i) put(must[i], TQD_ROLE_MUST);
+          for (uint32_t i = 0; i < n_not; ++i) put(mustnot[i], TQD_ROLE_MUST_NOT);
+          for (uint32_t i = 0; i < n_should; ++i) put(should[i], TQD_ROLE_SHOULD);
+          n_leaders = 1;
+        } else {
+          // no Must: the Should terms form the union (by weight descending), MustNot exclude
+          std::stable_sort(should, should + n_should,
+                           [&](uint32_t a, uint32_t b) { return q.weights[a] > q.weights[b]; });
+          for (uint32_t i = 0; i < n_should; ++i) put(should[i], TQD_ROLE_SHOULD);
+          for (uint32_t i = 0; i < n_not; ++i) put(mustnot[i], TQD_ROLE_MUST_NOT);
+          n_leaders = n_should;
+        }
+        dq.n_terms = n;
+        bool nonneg = true;
+        uint32_t sparse = 0;
+        for (uint32_t i = 0; i < n; ++i) {
+          nonneg = nonneg && dq.weight[i] >= 0.0f;
+          if (!(s->terms[dq.term[i]].dense_blob && s->opt.use_dense)) ++sparse;
+        }
+        if (!s->opt.exhaustive && nonneg) {
+          dq.flags |= TQD_QF_PRUNE;
+          if (q.k <= 2 * TQD_THR_SLOTS) {
+            dq.thr_index = n_thr_rows;
+            n_thr_rows += q.k <= TQD_THR_SLOTS ? 1u : 2u;
+          }
+        }
+        const uint32_t c_lb = 1u + n + 8u * sparse;
+        dq.tile_blocks = std::max<uint32_t>(1u, TQD_AND_TILE * 2u / c_lb);
+        tile_cost = dq.tile_blocks * c_lb;
+        uint32_t acc_tiles = 0;
+        for (uint32_t i = 0; i <= TQ_MAX_TERMS; ++i) {
+          dq.lead_tile_start[i] = acc_tiles;
+          if (i < n_leaders)
+            acc_tiles += (s->terms[dq.term[i]].n_blocks + dq.tile_blocks - 1) / dq.tile_blocks;
+        }
+        n_tiles = acc_tiles;
+      }
+    }
+    if (mode == TQ_MODE_OR && !bool_done) {
       if (q.mode == TQ_MODE_OR) {
         uint32_t n = 0;
         for (uint32_t i = 0; i < q.n_terms; ++i) {

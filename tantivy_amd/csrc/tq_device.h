@@ -62,7 +62,12 @@ struct TqdQuery {
   uint32_t chunk_first; // first chunk that holds a tile of this query
   uint32_t tile_blocks; // AND: leader blocks per tile (1..64, sized so tiles cost about the same)
   uint32_t lead_tile_start[TQD_MAX_TERMS + 1];  // candidate-driven OR: first tile led by list i
+  uint32_t roles;       // union kernel: 2 bits per term, TQD_ROLE_*
 };
+
+#define TQD_ROLE_SHOULD 0u
+#define TQD_ROLE_MUST 1u
+#define TQD_ROLE_MUST_NOT 2u
 
 #define TQD_QF_PRUNE 1u  // block-max pruning allowed (all weights >= 0, caller asked for it)
 

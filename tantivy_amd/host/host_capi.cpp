@@ -46,12 +46,14 @@ struct tqh_term_info {
   uint32_t doc_freq;
   uint64_t postings_start, postings_end, positions_start, positions_end;
 };
-// mode: 0 AND (all Must), 1 OR (all Should), 2 PHRASE (offsets 0..n or explicit), 3 single term
+// mode: 0 AND (all Must), 1 OR (all Should), 2 PHRASE (offsets 0..n or explicit), 3 single term,
+//       4 BooleanQuery of term clauses with the given occurs (src/query/occur.rs order)
 struct tqh_query {
   uint8_t mode;
   uint32_t n_terms;
   const uint32_t *terms;
   const uint32_t *phrase_offsets;  // may be null
+  const uint8_t *occurs;           // mode 4: 0 Should, 1 Must, 2 MustNot
 };
 
 const char *tqh_last_error(void) { return g_err.c_str(); }
@@ -111,7 +113,17 @@ int tqh_prepare_batch(tqh_searcher *s, const tqh_query *queries, uint32_t n) {
     for (uint32_t i = 0; i < n; ++i) {
       const tqh_query &q = queries[i];
       Query query;
-      if (q.mode == 3 || (q.n_terms == 1 && q.mode != 2)) {
+      if (q.mode == 4) {
+        if (!q.occurs) throw TantivyError(TantivyError::InvalidArgument, "mode 4 needs occurs");
+        std::vector<std::pair<Occur, Query>> clauses;
+        for (uint32_t t = 0; t < q.n_terms; ++t) {
+          if (q.occurs[t] > 2) throw TantivyError(TantivyError::InvalidArgument, "bad occur");
+          const Occur oc = q.occurs[t] == 1 ? Occur::Must
+                                            : (q.occurs[t] == 2 ? Occur::MustNot : Occur::Should);
+          clauses.emplace_back(oc, Query::term_query(q.terms[t]));
+        }
+        query = Query::boolean(std::move(clauses));
+      } else if (q.mode == 3 || (q.n_terms == 1 && q.mode != 2)) {
         query = Query::term_query(q.terms[0]);
       } else if (q.mode == 2) {
         std::vector<std::pair<uint32_t, uint32_t>> pt;

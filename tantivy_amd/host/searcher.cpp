@@ -119,8 +119,9 @@ Weight Searcher::weight(const Query &query) const {
       return w;
     }
     case Query::Boolean: {
-      // BooleanWeight::complex_scorer specialisations (boolean_weight.rs:287-330):
-      // all clauses are term queries and either all Must or all Should.
+      // BooleanWeight::complex_scorer (boolean_weight.rs:236-431) over term clauses: all Must ->
+      // TermIntersection (block_wand_intersection), all Should -> TermUnion (block_wand), mixed
+      // occurs -> RequiredOptionalScorer / Exclude, which the union kernel runs with roles.
       bool all_must = true, all_should = true;
       for (auto &c : query.clauses) {
         if (c.second.kind != Query::Term)
@@ -129,13 +130,17 @@ Weight Searcher::weight(const Query &query) const {
         all_must &= c.first == Occur::Must;
         all_should &= c.first == Occur::Should;
       }
-      if (query.clauses.empty() || !(all_must || all_should))
-        throw TantivyError(TantivyError::Unsupported,
-                           "mixed Must/Should/MustNot clauses stay on the CPU scorer path");
-      w.mode = all_must ? TQ_MODE_AND : TQ_MODE_OR;
+      if (query.clauses.empty())
+        throw TantivyError(TantivyError::Unsupported, "empty boolean query");
+      w.mode = all_must ? TQ_MODE_AND : (all_should ? TQ_MODE_OR : TQ_MODE_BOOL);
       for (auto &c : query.clauses) {
         w.terms.push_back(c.second.term);
         w.weights.push_back(term_weight(c.second.term));
+        if (w.mode == TQ_MODE_BOOL)
+          w.occurs.push_back(c.first == Occur::Must
+                                 ? (uint8_t)TQ_MUST
+                                 : (c.first == Occur::MustNot ? (uint8_t)TQ_MUST_NOT
+                                                              : (uint8_t)TQ_SHOULD));
       }
       return w;
     }
@@ -167,6 +172,7 @@ struct SegmentBatch {
       q.mode = w.mode;
       q.phrase_offsets = w.phrase_offsets.empty() ? nullptr : w.phrase_offsets.data();
       q.k = k;
+      q.occurs = w.occurs.empty() ? nullptr : w.occurs.data();
     }
   }
 };

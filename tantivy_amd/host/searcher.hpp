@@ -144,6 +144,7 @@ struct Weight {
   std::vector<uint32_t> terms;           // term ids in query order
   std::vector<Score> weights;            // per term (AND/OR) or one (phrase)
   std::vector<uint32_t> phrase_offsets;  // phrase
+  std::vector<uint8_t> occurs;           // TQ_MODE_BOOL: enum tq_occur per term
   std::shared_ptr<Bm25Weight> bm25;      // holds the shared tf cache
 };
 

@@ -452,6 +452,101 @@ def test_deletes_and_counts(ta):
         dev.close()
 
 
+def _bool_want(seg, terms, occurs, deleted=()):
+    d, sc = O.bool_match_all(seg, terms, occurs)
+    hits = [(float(x), int(doc)) for doc, x in zip(d.tolist(), sc.tolist()) if doc not in deleted]
+    hits.sort(key=lambda h: (-h[0], h[1]))
+    return hits
+
+
+def _assert_bool_hits(got, want_all, k, occurs):
+    """bit-exact unless 2+ Should terms sum (union order, see O.bool_match_all)"""
+    want = want_all[:k]
+    if sum(1 for o in occurs if o == O.SHOULD) >= 2:
+        if len(want_all) > k:  # near-ties across the k-th rank
+            _assert_hits_close(got, want)
+        else:
+            assert sorted(d for _, d in got) == sorted(d for _, d in want)
+            _assert_hits_close(got, want)
+    else:
+        _assert_hits_equal(got, want)
+
+
+@pytest.mark.parametrize("seed", [11, 12, 13])
+def test_boolean_mixed_occurs(ta, seed):
+    """Flat BooleanQuery with Must / Should / MustNot term clauses (RequiredOptionalScorer,
+    Exclude; boolean_weight.rs:236-431) against the oracle's restatement: pruned and exhaustive,
+    with and without bitmaps, with deletes, and the match counts."""
+    rng = np.random.default_rng(seed)
+    seg = O.synth_segment(60_000 + 7000 * seed, n_terms=40, with_positions=False)
+    shapes = [([O.MUST, O.SHOULD]), ([O.MUST, O.MUST_NOT]), ([O.SHOULD, O.MUST_NOT]),
+              ([O.MUST, O.MUST, O.SHOULD]), ([O.MUST, O.SHOULD, O.SHOULD]),
+              ([O.SHOULD, O.SHOULD, O.MUST_NOT]), ([O.MUST, O.MUST, O.MUST, O.MUST_NOT]),
+              ([O.MUST, O.SHOULD, O.MUST_NOT, O.SHOULD, O.MUST]),
+              ([O.MUST, O.MUST, O.MUST, O.MUST, O.SHOULD]), ([O.MUST_NOT, O.SHOULD]),
+              ([O.MUST_NOT, O.MUST_NOT, O.MUST]), ([O.MUST_NOT])]
+    queries = []
+    for occ in shapes * 3:
+        terms = rng.choice(40, size=len(occ), replace=False).tolist()
+        queries.append((ta.MODE_BOOL, terms, list(occ)))
+    deleted = set(rng.choice(seg.max_doc, size=seg.max_doc // 5, replace=False).tolist())
+    dev = ta.DeviceIndex([seg])
+    try:
+        dev.set_option("dense_ratio", 16)
+        for dels in ((), deleted):
+            dev.set_alive_bitset(_alive_bytes(seg.max_doc, dels) if dels else None)
+            want = [_bool_want(seg, q[1], q[2], dels) for q in queries]
+            for k in (1, 10, 100):
+                for ex, ud in ((1, 1), (0, 1), (0, 0), (1, 0)):
+                    dev.set_option("exhaustive", ex)
+                    dev.set_option("use_dense", ud)
+                    got = _device_topk(dev, queries, k)
+                    counts = dev.last_batch_match_counts(len(queries)) if ex else None
+                    for i, (q, g, w) in enumerate(zip(queries, got, want)):
+                        try:
+                            _assert_bool_hits(g, w, k, q[2])
+                            if ex:
+                                assert counts[i] == len(w)
+                        except AssertionError:
+                            raise AssertionError("seed %d k %d exhaustive %d use_dense %d deletes %d "
+                                                 "query %r\ngot  %r\nwant %r" %
+                                                 (seed, k, ex, ud, bool(dels), q, g[:5], w[:5]))
+        dev.set_option("exhaustive", 1)
+        dev.set_option("use_dense", 1)
+    finally:
+        dev.close()
+
+
+def test_boolean_degenerate_shapes(ta):
+    """An absent Must term or MustNot clauses alone match nothing (EmptyScorer); absent Should /
+    MustNot terms drop out; all-Must / all-Should boolean queries equal the AND / OR modes."""
+    rng = np.random.default_rng(5)
+    md = 30_000
+    lists = [random_postings(rng, md, int(df)) for df in (9000, 400, 6000, 2500, 7000, 3000, 800)]
+    lists.append([])  # 7: absent term
+    seg = O.build_segment(md, lists, rng.integers(1, 300, size=md).tolist())
+    dev = ta.DeviceIndex([seg])
+    try:
+        absent = 7
+        qs = [(ta.MODE_BOOL, [0, absent], [O.MUST, O.MUST]),
+              (ta.MODE_BOOL, [3], [O.MUST_NOT]),
+              (ta.MODE_BOOL, [0, absent, 2], [O.MUST, O.SHOULD, O.MUST_NOT]),
+              (ta.MODE_BOOL, [0, absent], [O.MUST, O.MUST_NOT]),
+              (ta.MODE_BOOL, [4, 5, 6], [O.MUST, O.MUST, O.MUST]),
+              (ta.MODE_BOOL, [4, 5], [O.SHOULD, O.SHOULD])]
+        for ex in (1, 0):
+            dev.set_option("exhaustive", ex)
+            got = _device_topk(dev, qs, 10)
+            assert got[0] == [] and got[1] == []
+            _assert_hits_equal(got[2], _bool_want(seg, [0, 2], [O.MUST, O.MUST_NOT])[:10])
+            _assert_hits_equal(got[3], _oracle_topk(seg, [0], O.MODE_OR, 10))
+            _assert_hits_equal(got[4], _oracle_topk(seg, [4, 5, 6], O.MODE_AND, 10))
+            _assert_hits_equal(got[5], _oracle_topk(seg, [4, 5], O.MODE_OR, 10))
+        dev.set_option("exhaustive", 1)
+    finally:
+        dev.close()
+
+
 def test_ties_prefer_lower_doc(ta):
     md = 1000
     lists = [[(d, 2) for d in range(0, md, 2)], [(d, 2) for d in range(0, md, 3)]]

@@ -641,3 +641,29 @@ def test_synth_segment_shapes():
     assert len(d) > 0
     seg2 = O.synth_segment(20_000, n_terms=64, with_positions=True)
     assert np.array_equal(seg.idx, seg2.idx) and np.array_equal(seg.pos, seg2.pos)
+
+
+def test_bool_match_all_consistency():
+    """The boolean restatement against the C oracle's own AND / OR paths and by brute force."""
+    seg = O.synth_segment(30_000, n_terms=20, with_positions=False)
+    d, sc = O.bool_match_all(seg, [1, 2, 3], [O.MUST] * 3)
+    d2, sc2 = O.match_all(seg, [1, 2, 3], O.MODE_AND)
+    order = np.argsort(d2)
+    assert np.array_equal(d, d2[order]) and np.array_equal(sc, sc2[order])
+    d, sc = O.bool_match_all(seg, [4, 5], [O.SHOULD] * 2)
+    d2, sc2 = O.match_all(seg, [4, 5], O.MODE_OR)
+    order = np.argsort(d2)
+    assert np.array_equal(d, d2[order]) and np.array_equal(sc, sc2[order])
+    # Must + Should + MustNot by sets
+    d, sc = O.bool_match_all(seg, [1, 6, 7], [O.MUST, O.SHOULD, O.MUST_NOT])
+    d1, s1 = O.match_all(seg, [1], O.MODE_OR)
+    d6, s6 = O.match_all(seg, [6], O.MODE_OR)
+    d7, _ = O.match_all(seg, [7], O.MODE_OR)
+    keep = sorted(set(d1.tolist()) - set(d7.tolist()))
+    assert d.tolist() == keep
+    m1 = dict(zip(d1.tolist(), s1.tolist()))
+    m6 = dict(zip(d6.tolist(), s6.tolist()))
+    for doc, x in zip(d.tolist(), sc.tolist()):
+        want = np.float32(m1[doc]) + np.float32(m6[doc]) if doc in m6 else np.float32(m1[doc])
+        assert np.float32(x) == np.float32(want)
+    assert len(O.bool_match_all(seg, [3], [O.MUST_NOT])[0]) == 0
