@@ -49,12 +49,15 @@ enum tq_record_option { TQ_BASIC = 0, TQ_WITH_FREQS = 1, TQ_WITH_FREQS_AND_POSIT
  * OR     = all-Should term clauses -> block_wand / BufferedUnionScorer
  * PHRASE = PhraseQuery (slop 0)    -> PhraseScorer */
 enum tq_mode { TQ_MODE_AND = 0, TQ_MODE_OR = 1, TQ_MODE_PHRASE = 2, TQ_MODE_BOOL = 3 };
-/* TQ_MODE_BOOL = flat BooleanQuery of term clauses with mixed occurs (`+a b -c`), the
- * RequiredOptionalScorer / Exclude part of BooleanWeight::complex_scorer
- * (boolean_weight.rs:347-431, reqopt_scorer.rs:85-98, exclude.rs): docs = AND of the Must terms
- * (or OR of the Should terms when there is no Must) minus the MustNot terms; score = sum of the
- * Must terms' scores + sum of the matching Should terms' scores.  Values of tq_query.occurs
- * follow src/query/occur.rs. */
+/* TQ_MODE_BOOL = BooleanQuery whose clauses are terms or unions of terms, with mixed occurs
+ * (`+a b -c`, `+a +(b OR c)`, `+(a OR b) +(c OR d)`) and minimum_number_should_match: the
+ * Intersection / RequiredOptionalScorer / Exclude / Disjunction part of
+ * BooleanWeight::complex_scorer (boolean_weight.rs:236-431, intersection.rs:20-56,
+ * reqopt_scorer.rs:85-98, exclude.rs, disjunction.rs): docs = AND of the Must clauses (or OR of
+ * the Should clauses when there is no Must), with at least min_should_match Should clauses
+ * matching, minus the MustNot clauses; score = Must clauses summed cheapest first
+ * (left + right + sum(others)) + the matching Should terms.  Values of tq_query.occurs follow
+ * src/query/occur.rs. */
 enum tq_occur { TQ_SHOULD = 0, TQ_MUST = 1, TQ_MUST_NOT = 2 };
 
 typedef struct tq_ctx tq_ctx;
@@ -75,6 +78,10 @@ typedef struct tq_query {
   const uint32_t *phrase_offsets; /* PHRASE: term offsets inside the phrase; else NULL */
   uint32_t k;                    /* TopDocs offset+limit, 1..TQ_MAX_K */
   const uint8_t *occurs;         /* TQ_MODE_BOOL: n_terms x enum tq_occur; else NULL */
+  const uint8_t *clause_of;      /* TQ_MODE_BOOL: clause index per term (terms sharing a value form
+                                    one nested all-Should BooleanQuery, `+a +(b OR c)`); NULL =
+                                    every term is its own clause */
+  uint32_t min_should_match;     /* TQ_MODE_BOOL: BooleanQuery::minimum_number_should_match */
 } tq_query;
 
 /* ---- lifecycle ---- */

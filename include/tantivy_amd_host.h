@@ -24,13 +24,17 @@ typedef struct tqh_term_info {
 
 /* mode: 0 = BooleanQuery of Must term clauses, 1 = BooleanQuery of Should term clauses,
  *       2 = PhraseQuery (offsets 0..n unless phrase_offsets given), 3 = TermQuery,
- *       4 = BooleanQuery of term clauses with per-clause occurs (0 Should, 1 Must, 2 MustNot) */
+ *       4 = BooleanQuery with per-term occurs (0 Should, 1 Must, 2 MustNot); terms sharing a
+ *           clause_of value form one nested union (`+a +(b OR c)`); min_should_match as
+ *           BooleanQuery::set_minimum_number_should_match */
 typedef struct tqh_query {
   uint8_t mode;
   uint32_t n_terms;
   const uint32_t *terms;
   const uint32_t *phrase_offsets;
   const uint8_t *occurs;
+  const uint8_t *clause_of;
+  uint32_t min_should_match;
 } tqh_query;
 
 const char *tqh_last_error(void);

@@ -497,64 +497,94 @@ def match_all(seg, term_ids, mode, weights=None, phrase_offsets=None, cap=None):
 SHOULD, MUST, MUST_NOT = 0, 1, 2  # src/query/occur.rs
 
 
-def bool_match_all(seg, term_ids, occurs):
-    """Flat BooleanQuery of term clauses with mixed occurs, restated from
-    BooleanWeight::complex_scorer (src/query/boolean_query/boolean_weight.rs:236-431):
-      - Must terms intersect, cheapest first; Intersection::score = left + right + sum(others)
-        (src/query/intersection.rs:93, :325-329);
-      - Should terms are optional when there is a Must (RequiredOptionalScorer::score =
-        req + opt, src/query/reqopt_scorer.rs:85-98) and form the union otherwise; the union's
-        SumCombiner adds in clause order (the reference's own order depends on scorer removal,
-        so 2+ Should terms compare within 1e-5);
-      - MustNot terms exclude (src/query/exclude.rs); MustNot clauses alone match nothing.
+def bool_match_all(seg, term_ids, occurs, clause_of=None, min_should_match=0):
+    """BooleanQuery whose clauses are terms or unions of terms (terms sharing a clause_of value),
+    restated from BooleanWeight::complex_scorer (src/query/boolean_query/boolean_weight.rs:236-431):
+      - a union clause scores the sum of its matching terms in clause order (SumCombiner; the
+        reference's own order depends on scorer removal, so sums of 3+ terms compare within
+        1e-5) and costs the sum of its terms' doc freqs (BufferedUnionScorer::cost,
+        src/query/union/buffered_union.rs:326-328);
+      - Must clauses intersect, cheapest first (intersect_scorers, src/query/intersection.rs:31);
+        Intersection::score = left + right + sum(others) (:325-329);
+      - minimum_number_should_match (:272-305): > number of Should clauses matches nothing;
+        == all of them (>= 2) turns them into Must clauses; 1 makes the union required
+        (intersected with the Must part); else scorer_disjunction;
+      - Should clauses are optional when there is a Must (RequiredOptionalScorer::score =
+        req + opt, src/query/reqopt_scorer.rs:85-98) and form the union otherwise;
+      - MustNot clauses exclude (src/query/exclude.rs); MustNot clauses alone match nothing.
     Every term scores with its own Bm25Weight (TermQuery::specialized_weight).
     Returns (docs ascending, f32 scores)."""
+    md = seg.max_doc
     per = {}
     for t in set(term_ids):
+        if seg.terms[t].doc_freq == 0:
+            per[t] = (np.zeros(0, np.int64), np.zeros(0, np.float32))
+            continue
         d, sc = match_all(seg, [t], MODE_OR)
         per[t] = (d.astype(np.int64), sc.astype(np.float32))
-    must = [t for t, o in zip(term_ids, occurs) if o == MUST]
-    should = [t for t, o in zip(term_ids, occurs) if o == SHOULD]
-    mustnot = [t for t, o in zip(term_ids, occurs) if o == MUST_NOT]
-    md = seg.max_doc
+    if clause_of is None:
+        clause_of = list(range(len(term_ids)))
+    clauses = []  # [occur, [terms]] in order of first appearance
+    ids = []
+    for t, o, c in zip(term_ids, occurs, clause_of):
+        if c not in ids:
+            ids.append(c)
+            clauses.append([o, []])
+        assert clauses[ids.index(c)][0] == o
+        clauses[ids.index(c)][1].append(t)
 
-    def dense(t):
-        sc = np.zeros(md, np.float32)
+    def clause_eval(terms):
         hit = np.zeros(md, bool)
-        sc[per[t][0]] = per[t][1]
-        hit[per[t][0]] = True
-        return hit, sc
+        sc = np.zeros(md, np.float32)
+        for t in terms:
+            one = np.zeros(md, np.float32)
+            one[per[t][0]] = per[t][1]
+            hit[per[t][0]] = True
+            sc = (sc + one).astype(np.float32)
+        cost = sum(seg.terms[t].doc_freq for t in terms)
+        return hit, sc, cost
 
+    none = (np.zeros(0, np.uint32), np.zeros(0, np.float32))
+    must = [clause_eval(ts) for o, ts in clauses if o == MUST]
+    if any(not h.any() for h, _, _ in must):
+        return none
+    should = [clause_eval(ts) for o, ts in clauses if o == SHOULD]
+    should = [c for c in should if c[0].any()]          # EmptyScorers are removed (:255-257)
+    mustnot = [clause_eval(ts) for o, ts in clauses if o == MUST_NOT]
+    msm = min_should_match
+    if msm > len(should):
+        return none
+    if msm >= 2 and msm == len(should):
+        must += should
+        should, msm = [], 0
+    n_hit = np.zeros(md, np.int32)
     opt = np.zeros(md, np.float32)
-    any_should = np.zeros(md, bool)
-    for t in should:
-        hit, sc = dense(t)
+    for hit, sc, _ in should:
         opt = (opt + sc).astype(np.float32)
-        any_should |= hit
+        n_hit += hit
     if must:
-        must = sorted(must, key=lambda t: seg.terms[t].doc_freq)  # stable, like sort_by_key
+        must.sort(key=lambda c: c[2])   # stable, like sort_by_key(cost)
         match = np.ones(md, bool)
-        parts = []
-        for t in must:
-            hit, sc = dense(t)
+        for hit, _, _ in must:
             match &= hit
-            parts.append(sc)
-        score = parts[0]
-        if len(parts) > 1:
-            score = (score + parts[1]).astype(np.float32)
-        if len(parts) > 2:
+        score = must[0][1]
+        if len(must) > 1:
+            score = (score + must[1][1]).astype(np.float32)
+        if len(must) > 2:
             oth = np.zeros(md, np.float32)
-            for sc in parts[2:]:
+            for _, sc, _ in must[2:]:
                 oth = (oth + sc).astype(np.float32)
             score = (score + oth).astype(np.float32)
         if should:
             score = (score + opt).astype(np.float32)
+            if msm:
+                match &= n_hit >= msm
     elif should:
-        match, score = any_should, opt
+        match, score = n_hit >= max(1, msm), opt
     else:
-        match, score = np.zeros(md, bool), opt
-    for t in mustnot:
-        match &= ~dense(t)[0]
+        return none
+    for hit, _, _ in mustnot:
+        match &= ~hit
     docs = np.nonzero(match)[0]
     return docs.astype(np.uint32), score[docs]
 

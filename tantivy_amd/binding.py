@@ -24,7 +24,8 @@ class TqQuery(C.Structure):
     _fields_ = [("n_terms", C.c_uint32), ("terms", C.POINTER(C.c_uint32)),
                 ("weights", C.POINTER(C.c_float)), ("tf_cache", C.POINTER(C.c_float)),
                 ("mode", C.c_uint8), ("phrase_offsets", C.POINTER(C.c_uint32)),
-                ("k", C.c_uint32), ("occurs", C.POINTER(C.c_uint8))]
+                ("k", C.c_uint32), ("occurs", C.POINTER(C.c_uint8)),
+                ("clause_of", C.POINTER(C.c_uint8)), ("min_should_match", C.c_uint32)]
 
 
 class TqBatchStats(C.Structure):
@@ -41,7 +42,8 @@ class TqhTermInfo(C.Structure):
 
 class TqhQuery(C.Structure):
     _fields_ = [("mode", C.c_uint8), ("n_terms", C.c_uint32), ("terms", C.POINTER(C.c_uint32)),
-                ("phrase_offsets", C.POINTER(C.c_uint32)), ("occurs", C.POINTER(C.c_uint8))]
+                ("phrase_offsets", C.POINTER(C.c_uint32)), ("occurs", C.POINTER(C.c_uint8)),
+                ("clause_of", C.POINTER(C.c_uint8)), ("min_should_match", C.c_uint32)]
 
 
 _lib = None
@@ -211,7 +213,8 @@ class DeviceIndex:
     # ---- host-mirror path (Query::weight + Searcher::search)
     def prepare(self, queries):
         """queries: list of (mode, [term ids]), (MODE_PHRASE, [term ids], [offsets]) or
-        (MODE_BOOL, [term ids], [occurs]) with occurs in {SHOULD, MUST, MUST_NOT}."""
+        (MODE_BOOL, [term ids], [occurs][, clause_of | None[, min_should_match]]) with occurs in
+        {SHOULD, MUST, MUST_NOT}; terms sharing a clause_of value form one nested union."""
         n = len(queries)
         qs = (TqhQuery * max(1, n))()
         keep = []
@@ -226,6 +229,12 @@ class DeviceIndex:
                 oc = (C.c_uint8 * len(terms))(*[int(o) for o in q[2]])
                 keep.append(oc)
                 qs[i].occurs = C.cast(oc, C.POINTER(C.c_uint8))
+                if len(q) > 3 and q[3] is not None:
+                    co = (C.c_uint8 * len(terms))(*[int(o) for o in q[3]])
+                    keep.append(co)
+                    qs[i].clause_of = C.cast(co, C.POINTER(C.c_uint8))
+                if len(q) > 4:
+                    qs[i].min_should_match = int(q[4])
             elif len(q) > 2 and q[2] is not None:
                 oa = (C.c_uint32 * len(terms))(*[int(o) for o in q[2]])
                 keep.append(oa)
@@ -369,6 +378,12 @@ class DeviceIndex:
                 oc = (C.c_uint8 * len(terms))(*q[3])
                 keep.append(oc)
                 qs[i].occurs = C.cast(oc, C.POINTER(C.c_uint8))
+            if len(q) > 4 and q[4] is not None:
+                co = (C.c_uint8 * len(terms))(*q[4])
+                keep.append(co)
+                qs[i].clause_of = C.cast(co, C.POINTER(C.c_uint8))
+            if len(q) > 5:
+                qs[i].min_should_match = int(q[5])
             qs[i].k = k
         scores = np.zeros((n, stride), np.float32)
         docs = np.zeros((n, stride), np.uint32)

@@ -62,7 +62,12 @@ struct TqdQuery {
   uint32_t chunk_first; // first chunk that holds a tile of this query
   uint32_t tile_blocks; // AND: leader blocks per tile (1..64, sized so tiles cost about the same)
   uint32_t lead_tile_start[TQD_MAX_TERMS + 1];  // candidate-driven OR: first tile led by list i
-  uint32_t roles;       // union kernel: 2 bits per term, TQD_ROLE_*
+  // union kernel, boolean queries: terms are laid out [leader clause | other Must clauses |
+  // MustNot terms | optional Should terms]
+  uint32_t roles;       // 2 bits per term, TQD_ROLE_*
+  uint32_t clause_end;  // bit m: term m is the last term of its Must clause (a union of terms)
+  uint32_t n_lead;      // terms of the leader clause: each leads its own run of tiles
+  uint32_t min_should;  // Should terms that have to match (minimum_number_should_match)
 };
 
 #define TQD_ROLE_SHOULD 0u

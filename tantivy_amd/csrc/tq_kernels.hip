@@ -1345,9 +1345,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_num_sgpr(96))) void union
   uint32_t q = uni(find_query(p.tile_starts, p.n_queries, t_begin));
   uint32_t q_tile_start = 0, q_tile_end = 0;
   const TqdQuery *Q = nullptr;
-  uint32_t nt = 0, tile_blocks = TQD_AND_TILE, n_slot_rows = 1, roles = 0;
-  bool prune = false, has_must = false;
-  float others_bool = 0.0f;  // has_must: what the non-leader Must and Should lists can add
+  uint32_t nt = 0, tile_blocks = TQD_AND_TILE, n_slot_rows = 1;
+  uint32_t roles = 0, clause_end = 0, n_lead = 0, min_should = 0;
+  bool prune = false;
   uint32_t *slots = nullptr;
   uint32_t thr = 0, thr_g = 0;
   uint32_t cache_loaded = 0xFFFFFFFFu;
@@ -1381,17 +1381,15 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_num_sgpr(96))) void union
       cache_loaded = ci;
     }
     roles = sload(&Q->roles);
-    has_must = false;
-    others_bool = 0.0f;
+    clause_end = sload(&Q->clause_end);
+    n_lead = sload(&Q->n_lead);
+    min_should = sload(&Q->min_should);
+    // suffix[m]: what the lists m.. can add at most (MustNot lists carry weight 0)
     float suf = 0.0f;
     if (lane == 0) L.suffix[nt] = 0.0f;
     for (uint32_t m = nt; m-- > 0u;) {
-      const uint32_t r = (roles >> (2u * m)) & 3u;
-      const float w = r == TQD_ROLE_MUST_NOT ? 0.0f : sload(&Q->weight[m]);
-      suf += w;
+      suf += sload(&Q->weight[m]);
       if (lane == 0) L.suffix[m] = suf;
-      has_must = has_must || r == TQD_ROLE_MUST;
-      if (m) others_bool += w;
     }
     wave_mem_fence();
     min_norm = sload(p.caches + (size_t)ci * 256u +
@@ -1416,29 +1414,25 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_num_sgpr(96))) void union
       tf = L.q1_tf[base + lane];
       norm = L.cache[fieldnorm_id(seg, doc)];
       s = bm25(w_lead, norm, tf);
-      if (prune)
-        alive = sortable((s + (has_must ? others_bool : L.suffix[li + 1u])) * 1.000001f) >= thr;
+      if (prune) alive = sortable((s + L.suffix[li + 1u]) * 1.000001f) >= thr;
     }
-    // has_must (TQ_MODE_BOOL with Must clauses): the Must terms come first, by ascending doc freq,
-    // and sum as Intersection::score does (intersection.rs:325-329: left + right + sum(others));
-    // opt sums the matching Should terms in clause order (RequiredOptionalScorer::score,
-    // reqopt_scorer.rs:85-98); MustNot terms exclude.
-    float opt = 0.0f, oth = 0.0f, rest_bool = others_bool;
-    uint32_t musts = 1u;
+    // The leader clause is a union of n_lead lists (a pure union: all the Should terms; with Must
+    // clauses: the cheapest one): a doc is scored by the tile of the first list of the clause that
+    // holds it.  Then come the other Must clauses (each a union of terms; cheapest first, summed
+    // as Intersection::score does: left + right + sum(others), intersection.rs:325-329), the
+    // MustNot terms (Exclude, exclude.rs) and the optional Should terms
+    // (RequiredOptionalScorer::score = req + opt, reqopt_scorer.rs:85-98).
+    float opt = 0.0f, oth = 0.0f, csum = 0.0f;
+    bool cfound = false;
+    uint32_t clause = 1u;
+    uint32_t n_should = ((roles >> (2u * li)) & 3u) == TQD_ROLE_SHOULD ? 1u : 0u;
     for (uint32_t m = 0; m < nt; ++m) {
       if (m == li) continue;
       const uint32_t role = (roles >> (2u * m)) & 3u;
       const float w = sload(&Q->weight[m]);
-      if (prune) {
-        if (has_must) {
-          if (alive) alive = sortable((((s + oth) + opt) + rest_bool) * 1.000001f) >= thr;
-          if (role != TQD_ROLE_MUST_NOT) rest_bool -= w;
-          if (rest_bool < 0.0f) rest_bool = 0.0f;
-        } else if (m > li) {
-          // what the lists m.. can still add (lists below li add nothing: found there = dropped)
-          if (alive) alive = sortable((s + L.suffix[m]) * 1.000001f) >= thr;
-        }
-      }
+      // what the lists m.. can still add (lists below li add nothing: found there = dropped)
+      if (prune && m > li && alive)
+        alive = sortable((((s + oth) + (csum + opt)) + L.suffix[m]) * 1.000001f) >= thr;
       if (!__ballot(alive)) break;
       TermRef tr = load_term(p.terms, sload(&Q->term[m]));
       if (!p.use_dense) tr.dense = nullptr;
@@ -1463,32 +1457,39 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_num_sgpr(96))) void union
         at = lookup_in_blocks<false>(idx, tr, jb, doc, cand, L.pay, lane, &unused);
         found = cand && at != NOT_FOUND;
       }
-      if (role == TQD_ROLE_MUST_NOT) {
-        if (found) alive = false;  // Exclude (src/query/exclude.rs)
-      } else if (role == TQD_ROLE_MUST) {
-        if (!found) {
-          alive = false;
-        } else if (alive) {
-          const uint4 r = tr.rec[jb];
-          const float sc = bm25(w, norm, block_tf_at(idx, tr, make_uint2(r.y, r.z), at));
-          if (musts == 1u)
-            s = s + sc;
-          else
-            oth = oth + sc;
-        }
-        ++musts;
-      } else if (!has_must && m < li) {
-        if (found) alive = false;  // this doc is scored by list m's tile
-      } else if (found && alive) {
+      float sc = 0.0f;
+      if (found && alive && role != TQD_ROLE_MUST_NOT && !(m < li && m < n_lead)) {
         const uint4 r = tr.rec[jb];
-        const float sc = bm25(w, norm, block_tf_at(idx, tr, make_uint2(r.y, r.z), at));
-        if (has_must)
-          opt = opt + sc;
-        else
+        sc = bm25(w, norm, block_tf_at(idx, tr, make_uint2(r.y, r.z), at));
+      }
+      if (role == TQD_ROLE_MUST_NOT) {
+        if (found) alive = false;
+      } else if (m < n_lead) {
+        if (found) {
+          if (m < li) alive = false;  // this doc is scored by list m's tile
           s = s + sc;
+          if (role == TQD_ROLE_SHOULD) ++n_should;
+        }
+      } else if (role == TQD_ROLE_MUST) {
+        cfound = cfound || found;
+        if (found) csum = csum + sc;
+        if ((clause_end >> m) & 1u) {
+          if (!cfound) alive = false;
+          if (clause == 1u)
+            s = s + csum;
+          else
+            oth = oth + csum;
+          ++clause;
+          csum = 0.0f;
+          cfound = false;
+        }
+      } else if (found) {
+        opt = opt + sc;
+        ++n_should;
       }
     }
-    if (has_must) s = (s + oth) + opt;
+    s = (s + oth) + opt;
+    if (n_should < min_should) alive = false;
     if (alive) alive = doc_is_alive(seg, doc);
     const uint64_t hit = __ballot(alive);
     if (hit) {
@@ -1554,7 +1555,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_num_sgpr(96))) void union
       if (thr_g > thr) thr = thr_g;
     }
     // non-essential by now: every doc first seen in list li scores at most the weights of li..
-    if (prune && !has_must && sortable(L.suffix[li] * 1.000001f) < thr) {
+    if (prune && sortable(L.suffix[li] * 1.000001f) < thr) {
       while (q1n) stageB(q1n < 64u ? q1n : 64u);
       dead = true;
       continue;
@@ -1571,8 +1572,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_num_sgpr(96))) void union
       prev_mine = __shfl_up(rec_mine.x, 1, WAVE);
       if (lane == 0) prev_mine = block_prev_last(lead, i_base);
       if (prune && surv) {
-        // the other lists, at most: pure union = the lists after li; with Must = all the others
-        const float rest = (has_must ? others_bool : L.suffix[li] - w_lead) * 1.000001f;
+        // the lists after li, at most (the lists before li hold none of this tile's docs)
+        const float rest = L.suffix[li + 1u] * 1.000001f;
         const float ub = block_max_score(rec_mine.y, w_lead, L.cache, lead.has_freq);
         surv = sortable((ub + rest) * 1.000001f) >= thr;
         if (surv) {

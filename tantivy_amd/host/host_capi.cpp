@@ -54,6 +54,8 @@ struct tqh_query {
   const uint32_t *terms;
   const uint32_t *phrase_offsets;  // may be null
   const uint8_t *occurs;           // mode 4: 0 Should, 1 Must, 2 MustNot
+  const uint8_t *clause_of;        // mode 4: terms sharing a value form one nested union; or null
+  uint32_t min_should_match;       // mode 4
 };
 
 const char *tqh_last_error(void) { return g_err.c_str(); }
@@ -116,13 +118,29 @@ int tqh_prepare_batch(tqh_searcher *s, const tqh_query *queries, uint32_t n) {
       if (q.mode == 4) {
         if (!q.occurs) throw TantivyError(TantivyError::InvalidArgument, "mode 4 needs occurs");
         std::vector<std::pair<Occur, Query>> clauses;
+        std::vector<int> ids;  // clause_of value of every clause built so far
         for (uint32_t t = 0; t < q.n_terms; ++t) {
           if (q.occurs[t] > 2) throw TantivyError(TantivyError::InvalidArgument, "bad occur");
           const Occur oc = q.occurs[t] == 1 ? Occur::Must
                                             : (q.occurs[t] == 2 ? Occur::MustNot : Occur::Should);
-          clauses.emplace_back(oc, Query::term_query(q.terms[t]));
+          const int id = q.clause_of ? (int)q.clause_of[t] : -1;
+          size_t c = ids.size();
+          if (id >= 0)
+            for (c = 0; c < ids.size() && ids[c] != id; ++c) {}
+          if (c == ids.size()) {
+            ids.push_back(id);
+            clauses.emplace_back(oc, Query::term_query(q.terms[t]));
+            continue;
+          }
+          if (clauses[c].first != oc)
+            throw TantivyError(TantivyError::InvalidArgument, "a clause mixes occurs");
+          Query &sub = clauses[c].second;
+          if (sub.kind == Query::Term)  // second term of the clause: it becomes a nested union
+            sub = Query::boolean({{Occur::Should, Query::term_query(sub.term)}});
+          sub.clauses.emplace_back(Occur::Should, Query::term_query(q.terms[t]));
         }
         query = Query::boolean(std::move(clauses));
+        query.set_minimum_number_should_match(q.min_should_match);
       } else if (q.mode == 3 || (q.n_terms == 1 && q.mode != 2)) {
         query = Query::term_query(q.terms[0]);
       } else if (q.mode == 2) {

@@ -119,29 +119,61 @@ Weight Searcher::weight(const Query &query) const {
       return w;
     }
     case Query::Boolean: {
-      // BooleanWeight::complex_scorer (boolean_weight.rs:236-431) over term clauses: all Must ->
-      // TermIntersection (block_wand_intersection), all Should -> TermUnion (block_wand), mixed
-      // occurs -> RequiredOptionalScorer / Exclude, which the union kernel runs with roles.
-      bool all_must = true, all_should = true;
+      // BooleanWeight::complex_scorer (boolean_weight.rs:236-431).  Clauses are terms or nested
+      // BooleanQuerys of Should terms (`+a +(b OR c)`): all Must terms -> TermIntersection
+      // (block_wand_intersection), all Should terms -> TermUnion (block_wand), anything else ->
+      // Intersection / RequiredOptionalScorer / Exclude / Disjunction on the union kernel.
+      if (query.clauses.empty())
+        throw TantivyError(TantivyError::Unsupported, "empty boolean query");
+      bool all_must = true, all_should = true, flat = true;
+      auto is_term_union = [](const Query &q) {
+        if (q.kind != Query::Boolean || q.clauses.empty() || q.minimum_number_should_match > 1)
+          return false;
+        for (auto &c : q.clauses)
+          if (c.first != Occur::Should || c.second.kind != Query::Term) return false;
+        return true;
+      };
       for (auto &c : query.clauses) {
-        if (c.second.kind != Query::Term)
-          throw TantivyError(TantivyError::Unsupported,
-                             "nested boolean trees stay on the CPU scorer path");
+        if (c.second.kind != Query::Term) {
+          if (!is_term_union(c.second))
+            throw TantivyError(TantivyError::Unsupported,
+                               "nested boolean trees other than unions of terms stay on the CPU "
+                               "scorer path");
+          flat = false;
+        }
         all_must &= c.first == Occur::Must;
         all_should &= c.first == Occur::Should;
       }
-      if (query.clauses.empty())
-        throw TantivyError(TantivyError::Unsupported, "empty boolean query");
-      w.mode = all_must ? TQ_MODE_AND : (all_should ? TQ_MODE_OR : TQ_MODE_BOOL);
+      const size_t msm = query.minimum_number_should_match;
+      if (flat && all_must && msm == 0)
+        w.mode = TQ_MODE_AND;
+      else if (flat && all_should && msm <= 1)
+        w.mode = TQ_MODE_OR;
+      else
+        w.mode = TQ_MODE_BOOL;
+      uint8_t clause = 0;
       for (auto &c : query.clauses) {
-        w.terms.push_back(c.second.term);
-        w.weights.push_back(term_weight(c.second.term));
-        if (w.mode == TQ_MODE_BOOL)
-          w.occurs.push_back(c.first == Occur::Must
-                                 ? (uint8_t)TQ_MUST
-                                 : (c.first == Occur::MustNot ? (uint8_t)TQ_MUST_NOT
-                                                              : (uint8_t)TQ_SHOULD));
+        const uint8_t oc = c.first == Occur::Must
+                               ? (uint8_t)TQ_MUST
+                               : (c.first == Occur::MustNot ? (uint8_t)TQ_MUST_NOT
+                                                            : (uint8_t)TQ_SHOULD);
+        auto add = [&](uint32_t term) {
+          w.terms.push_back(term);
+          w.weights.push_back(term_weight(term));
+          if (w.mode == TQ_MODE_BOOL) {
+            w.occurs.push_back(oc);
+            w.clause_of.push_back(clause);
+          }
+        };
+        if (c.second.kind == Query::Term)
+          add(c.second.term);
+        else
+          for (auto &sub : c.second.clauses) add(sub.second.term);
+        ++clause;
       }
+      if (w.terms.size() > TQ_MAX_TERMS)
+        throw TantivyError(TantivyError::Unsupported, "more than 16 terms stay on the CPU");
+      w.min_should_match = (uint32_t)std::min<size_t>(msm, 0xFFFFu);
       return w;
     }
   }
@@ -173,6 +205,8 @@ struct SegmentBatch {
       q.phrase_offsets = w.phrase_offsets.empty() ? nullptr : w.phrase_offsets.data();
       q.k = k;
       q.occurs = w.occurs.empty() ? nullptr : w.occurs.data();
+      q.clause_of = w.clause_of.empty() ? nullptr : w.clause_of.data();
+      q.min_should_match = w.min_should_match;
     }
   }
 };

@@ -83,6 +83,7 @@ struct Query {
   uint32_t term = 0;
   // Boolean: clauses of (Occur, sub query)
   std::vector<std::pair<Occur, Query>> clauses;
+  size_t minimum_number_should_match = 0;  // boolean_query.rs:146-150
   // Phrase: (offset, term), slop 0 (phrase_query.rs:28-63)
   std::vector<std::pair<uint32_t, uint32_t>> phrase_terms;
 
@@ -97,6 +98,11 @@ struct Query {
     q.kind = Boolean;
     q.clauses = std::move(clauses);
     return q;
+  }
+  // BooleanQuery::set_minimum_number_should_match
+  Query &set_minimum_number_should_match(size_t n) {
+    minimum_number_should_match = n;
+    return *this;
   }
   // PhraseQuery::new(terms): offsets 0..n
   static Query phrase(const std::vector<uint32_t> &terms) {
@@ -145,6 +151,8 @@ struct Weight {
   std::vector<Score> weights;            // per term (AND/OR) or one (phrase)
   std::vector<uint32_t> phrase_offsets;  // phrase
   std::vector<uint8_t> occurs;           // TQ_MODE_BOOL: enum tq_occur per term
+  std::vector<uint8_t> clause_of;        // TQ_MODE_BOOL: clause index per term
+  uint32_t min_should_match = 0;         // TQ_MODE_BOOL
   std::shared_ptr<Bm25Weight> bm25;      // holds the shared tf cache
 };
 

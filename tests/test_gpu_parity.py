@@ -452,17 +452,19 @@ def test_deletes_and_counts(ta):
         dev.close()
 
 
-def _bool_want(seg, terms, occurs, deleted=()):
-    d, sc = O.bool_match_all(seg, terms, occurs)
+def _bool_want(seg, terms, occurs, deleted=(), clause_of=None, msm=0):
+    d, sc = O.bool_match_all(seg, terms, occurs, clause_of, msm)
     hits = [(float(x), int(doc)) for doc, x in zip(d.tolist(), sc.tolist()) if doc not in deleted]
     hits.sort(key=lambda h: (-h[0], h[1]))
     return hits
 
 
-def _assert_bool_hits(got, want_all, k, occurs):
-    """bit-exact unless 2+ Should terms sum (union order, see O.bool_match_all)"""
+def _assert_bool_hits(got, want_all, k, occurs, clause_of=None):
+    """bit-exact unless a union sums 3+ terms (union order, see O.bool_match_all)"""
     want = want_all[:k]
-    if sum(1 for o in occurs if o == O.SHOULD) >= 2:
+    n_should = sum(1 for o in occurs if o == O.SHOULD)
+    widest = max(clause_of.count(c) for c in clause_of) if clause_of else 1
+    if n_should >= 3 or widest >= 3 or (n_should == 2 and O.MUST in occurs and widest > 1):
         if len(want_all) > k:  # near-ties across the k-th rank
             _assert_hits_close(got, want)
         else:
@@ -485,17 +487,30 @@ def test_boolean_mixed_occurs(ta, seed):
               ([O.MUST, O.SHOULD, O.MUST_NOT, O.SHOULD, O.MUST]),
               ([O.MUST, O.MUST, O.MUST, O.MUST, O.SHOULD]), ([O.MUST_NOT, O.SHOULD]),
               ([O.MUST_NOT, O.MUST_NOT, O.MUST]), ([O.MUST_NOT])]
+    M, S, N = O.MUST, O.SHOULD, O.MUST_NOT
+    # (occurs, clause_of, minimum_number_should_match): nested unions and required Should parts
+    # (benches/and_or_queries.rs:150-153: `+c +(b OR d)`, `+(c OR b) +(d OR e)`)
+    nested = [([M, M, M], [0, 1, 1], 0), ([M, M, M, M], [0, 0, 1, 1], 0),
+              ([M, M, M, S], [0, 1, 1, 2], 0), ([M, M, M, N], [0, 0, 1, 2], 0),
+              ([M, M, M, M, M], [0, 1, 1, 2, 2], 0), ([M, M, M, M], [0, 1, 1, 1], 0),
+              ([M, S, S], None, 1), ([M, S, S, S], None, 2), ([S, S, S], None, 2),
+              ([S, S, S], None, 3), ([S, S, N], None, 2), ([M, S], None, 1), ([M, S], None, 2),
+              ([M, M], None, 1), ([S, S, S, S, N], None, 3), ([M, S, S, N], [0, 1, 1, 2], 1),
+              ([N, N, S, S], [0, 0, 1, 2], 0)]
     queries = []
     for occ in shapes * 3:
         terms = rng.choice(40, size=len(occ), replace=False).tolist()
-        queries.append((ta.MODE_BOOL, terms, list(occ)))
+        queries.append((ta.MODE_BOOL, terms, list(occ), None, 0))
+    for occ, cof, msm in nested * 2:
+        terms = rng.choice(40, size=len(occ), replace=False).tolist()
+        queries.append((ta.MODE_BOOL, terms, list(occ), cof, msm))
     deleted = set(rng.choice(seg.max_doc, size=seg.max_doc // 5, replace=False).tolist())
     dev = ta.DeviceIndex([seg])
     try:
         dev.set_option("dense_ratio", 16)
         for dels in ((), deleted):
             dev.set_alive_bitset(_alive_bytes(seg.max_doc, dels) if dels else None)
-            want = [_bool_want(seg, q[1], q[2], dels) for q in queries]
+            want = [_bool_want(seg, q[1], q[2], dels, q[3], q[4]) for q in queries]
             for k in (1, 10, 100):
                 for ex, ud in ((1, 1), (0, 1), (0, 0), (1, 0)):
                     dev.set_option("exhaustive", ex)
@@ -504,7 +519,7 @@ def test_boolean_mixed_occurs(ta, seed):
                     counts = dev.last_batch_match_counts(len(queries)) if ex else None
                     for i, (q, g, w) in enumerate(zip(queries, got, want)):
                         try:
-                            _assert_bool_hits(g, w, k, q[2])
+                            _assert_bool_hits(g, w, k, q[2], q[3])
                             if ex:
                                 assert counts[i] == len(w)
                         except AssertionError:
