@@ -37,7 +37,7 @@ def parse_args():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--docs", type=int, default=10_000_000)
     ap.add_argument("--queries", type=int, default=10_000)
-    ap.add_argument("--workload", default="and2", choices=["and2", "or5", "phrase3", "mixed"])
+    ap.add_argument("--workload", default="and2", choices=["and2", "or5", "phrase3", "mixed", "bool"])
     ap.add_argument("--k", type=int, default=None)
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -60,6 +60,19 @@ def build_queries(O, workload, n, k):
         rng = np.random.default_rng(20260923)
         starts = rng.integers(0, 30, size=n)
         return [(O.MODE_PHRASE, [int(s), int(s) + 1, int(s) + 2]) for s in starts], k or 10
+    if workload == "bool":
+        # the shapes of the reference's union_intersection group (benches/and_or_queries.rs:150-153):
+        # `+c +(b OR d)`, `+e +(c OR a)`, `+(c OR b) +(d OR e)`, plus `+a b -c`
+        import tantivy_amd as T
+        ids = O.zipf_queries(n, 4, 256, seed=20260924)
+        M, S, N = T.MUST, T.SHOULD, T.MUST_NOT
+        shapes = [(3, [M, M, M], [0, 1, 1]), (4, [M, M, M, M], [0, 0, 1, 1]),
+                  (3, [M, S, N], None), (3, [M, M, M], [0, 0, 1])]
+        qs = []
+        for i, q in enumerate(ids):
+            nt, occ, cof = shapes[i % len(shapes)]
+            qs.append((T.MODE_BOOL, q.tolist()[:nt], occ, cof, 0))
+        return qs, k or 10
     a = O.zipf_queries(n // 2, 2, 256, seed=20260921)
     o = O.zipf_queries(n - n // 2, 5, 256, seed=20260922)
     qs = []
@@ -206,7 +219,12 @@ def main():
     if world == 1:
         for i in list(range(0, n_q, max(1, n_q // 16)))[:16]:
             mode, terms = queries[i][0], queries[i][1]
-            want = O.search(seg, terms, mode, k, pruned=False)
+            if args.workload == "bool":
+                d, sc = O.bool_match_all(seg, terms, queries[i][2], queries[i][3], queries[i][4])
+                want = sorted(((float(x), int(doc)) for doc, x in zip(d.tolist(), sc.tolist())),
+                              key=lambda h: (-h[0], h[1]))[:k]
+            else:
+                want = O.search(seg, terms, mode, k, pruned=False)
             got = [(float(final[0][i, j]), int(final[2][i, j])) for j in range(int(final[3][i]))]
             assert len(got) == len(want), (i, got, want)
             for (gs, gd), (ws, wd) in zip(got, want):
@@ -215,7 +233,7 @@ def main():
 
     # ---- CPU baseline: the oracle's restatement of tantivy's block-WAND executors
     cpu = None
-    if world == 1 and not args.no_cpu_baseline:
+    if world == 1 and not args.no_cpu_baseline and args.workload != "bool":
         cores = os.cpu_count() or 1
         specs, done, wall_total = [], 0, 0.0
         chunk = max(64, cores * 16)

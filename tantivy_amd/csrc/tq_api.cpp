@@ -660,15 +660,13 @@ int tq_search_batch_device(tq_segment *s, const tq_query *queries, uint32_t n_qu
   if (rc != TQ_OK) return rc;
 
   // ---- plan
-  // queries with Must / MustNot roles only run on the candidate-driven union kernel
-  bool any_bool = false;
-  for (uint32_t qi = 0; qi < n_queries; ++qi) any_bool = any_bool || queries[qi].mode == TQ_MODE_BOOL;
-  const bool or_windows =
-      !any_bool && (s->opt.or_windows < 0 ? s->opt.exhaustive != 0 : s->opt.or_windows != 0);
+  const bool or_windows_opt = s->opt.or_windows < 0 ? s->opt.exhaustive != 0 : s->opt.or_windows != 0;
   // launch groups: AND queries whose non-leader lists all have a bitmap run a leaner kernel
   // instantiation (no seek / block-search code: fewer registers, less LDS, more waves per CU)
-  constexpr int kGroups = 4, kAndGeneral = 3;
+  // boolean queries (clauses with roles) run the candidate-driven union kernel's BOOL instantiation
+  constexpr int kGroups = 5, kAndGeneral = 3, kBool = 4;
   Group groups[kGroups];
+  groups[kBool].mode = TQ_MODE_OR;
   groups[0].mode = TQ_MODE_AND;
   groups[1].mode = TQ_MODE_OR;
   groups[2].mode = TQ_MODE_PHRASE;
@@ -943,7 +941,7 @@ int tq_search_batch_device(tq_segment *s, const tq_query *queries, uint32_t n_qu
           }
         }
       }
-      if (or_windows) {
+      if (or_windows_opt) {
         uint32_t max_last = 0;
         for (uint32_t i = 0; i < dq.n_terms; ++i)
           max_last = std::max(max_last, s->terms[dq.term[i]].last_doc);
@@ -969,7 +967,7 @@ int tq_search_batch_device(tq_segment *s, const tq_query *queries, uint32_t n_qu
     }
     algo_bytes += qbytes;
     dq.n_tiles = n_tiles;
-    Group &g = groups[(mode == TQ_MODE_AND && !all_dense) ? kAndGeneral : mode];
+    Group &g = groups[bool_done ? kBool : ((mode == TQ_MODE_AND && !all_dense) ? kAndGeneral : mode)];
     dq.mode = (uint32_t)mode;
     g.queries.push_back(dq);
     g.tile_cost.push_back(tile_cost);
@@ -995,6 +993,7 @@ int tq_search_batch_device(tq_segment *s, const tq_query *queries, uint32_t n_qu
     // chunks = runs of consecutive tiles of about equal estimated cost; one chunk is one
     // wavefront (AND, phrase) or one workgroup (OR) and the hardware dispatcher hands them out
     // as slots free up, so many small chunks balance the load
+    const bool or_windows = or_windows_opt && &g != &groups[kBool];
     const bool or_win = g.mode == TQ_MODE_OR && or_windows;
     const bool or_cand = g.mode == TQ_MODE_OR && !or_windows;
     // candidate-driven OR: the tiles of a list that MaxScore will most likely find non-essential
@@ -1125,7 +1124,7 @@ int tq_search_batch_device(tq_segment *s, const tq_query *queries, uint32_t n_qu
     }
   }
   // partial lists of all groups share one buffer; its stride is per group (kpl*64 keys)
-  size_t part_off_bytes[kGroups] = {0, 0, 0, 0};
+  size_t part_off_bytes[kGroups] = {0, 0, 0, 0, 0};
   for (int gi = 0; gi < kGroups; ++gi) {
     Group &g = groups[gi];
     part_off_bytes[gi] = partial_bytes;
@@ -1226,7 +1225,7 @@ int tq_search_batch_device(tq_segment *s, const tq_query *queries, uint32_t n_qu
     HIP_TRY(hipEventRecord(s->ev_fork, st));
     HIP_TRY(hipStreamWaitEvent(s->side_stream, s->ev_fork, 0));
   }
-  const int launch_order[kGroups] = {kAndGeneral, 1, 2, 0};  // long serial chains first
+  const int launch_order[kGroups] = {kAndGeneral, kBool, 1, 2, 0};  // long serial chains first
   for (int oi = 0; oi < kGroups; ++oi) {
     const int gi = launch_order[oi];
     Group &g = groups[gi];
@@ -1251,7 +1250,8 @@ int tq_search_batch_device(tq_segment *s, const tq_query *queries, uint32_t n_qu
     p.all_dense = gi == 0 ? 1u : 0u;
     static const uint32_t kDebug = tune_u32("TQ_DEBUG", 0);
     p.debug = kDebug;
-    p.or_windows = or_windows ? 1u : 0u;
+    p.or_windows = (or_windows_opt && gi != kBool) ? 1u : 0u;
+    p.boolean = gi == kBool ? 1u : 0u;
     p.max_terms = 0;
     for (const TqdQuery &dq : g.queries) p.max_terms = std::max(p.max_terms, dq.n_terms);
     tiles_total += g.total_tiles;

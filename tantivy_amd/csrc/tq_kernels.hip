@@ -1330,7 +1330,7 @@ struct UnionLds {  // per wavefront
   float suffix[TQD_MAX_TERMS + 1];
 };
 
-template <int KPL, bool PRUNE>
+template <int KPL, bool PRUNE, bool BOOL>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_num_sgpr(96))) void union_kernel(TqkScanParams p) {
   constexpr bool USE_DPP = true;
   __shared__ UnionLds L;
@@ -1380,10 +1380,14 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_num_sgpr(96))) void union
       for (int i = lane; i < 256; i += WAVE) L.cache[i] = cg[i];
       cache_loaded = ci;
     }
-    roles = sload(&Q->roles);
-    clause_end = sload(&Q->clause_end);
-    n_lead = sload(&Q->n_lead);
-    min_should = sload(&Q->min_should);
+    if (BOOL) {
+      roles = sload(&Q->roles);
+      clause_end = sload(&Q->clause_end);
+      n_lead = sload(&Q->n_lead);
+      min_should = sload(&Q->min_should);
+    } else {  // pure union: one leading clause of Should terms
+      n_lead = nt;
+    }
     // suffix[m]: what the lists m.. can add at most (MustNot lists carry weight 0)
     float suf = 0.0f;
     if (lane == 0) L.suffix[nt] = 0.0f;
@@ -1428,7 +1432,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_num_sgpr(96))) void union
     uint32_t n_should = ((roles >> (2u * li)) & 3u) == TQD_ROLE_SHOULD ? 1u : 0u;
     for (uint32_t m = 0; m < nt; ++m) {
       if (m == li) continue;
-      const uint32_t role = (roles >> (2u * m)) & 3u;
+      const uint32_t role = BOOL ? (roles >> (2u * m)) & 3u : TQD_ROLE_SHOULD;
       const float w = sload(&Q->weight[m]);
       // what the lists m.. can still add (lists below li add nothing: found there = dropped)
       if (prune && m > li && alive)
@@ -1458,13 +1462,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_num_sgpr(96))) void union
         found = cand && at != NOT_FOUND;
       }
       float sc = 0.0f;
-      if (found && alive && role != TQD_ROLE_MUST_NOT && !(m < li && m < n_lead)) {
+      if (found && alive && role != TQD_ROLE_MUST_NOT && !(m < li && (!BOOL || m < n_lead))) {
         const uint4 r = tr.rec[jb];
         sc = bm25(w, norm, block_tf_at(idx, tr, make_uint2(r.y, r.z), at));
       }
       if (role == TQD_ROLE_MUST_NOT) {
         if (found) alive = false;
-      } else if (m < n_lead) {
+      } else if (!BOOL || m < n_lead) {
         if (found) {
           if (m < li) alive = false;  // this doc is scored by list m's tile
           s = s + sc;
@@ -1488,8 +1492,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_num_sgpr(96))) void union
         ++n_should;
       }
     }
-    s = (s + oth) + opt;
-    if (n_should < min_should) alive = false;
+    if (BOOL) {
+      s = (s + oth) + opt;
+      if (n_should < min_should) alive = false;
+    }
     if (alive) alive = doc_is_alive(seg, doc);
     const uint64_t hit = __ballot(alive);
     if (hit) {
@@ -1571,14 +1577,53 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_num_sgpr(96))) void union
       if (surv) rec_mine = lead.rec[i_mine];
       prev_mine = __shfl_up(rec_mine.x, 1, WAVE);
       if (lane == 0) prev_mine = block_prev_last(lead, i_base);
-      if (prune && surv) {
-        // the lists after li, at most (the lists before li hold none of this tile's docs)
-        const float rest = L.suffix[li + 1u] * 1.000001f;
-        const float ub = block_max_score(rec_mine.y, w_lead, L.cache, lead.has_freq);
-        surv = sortable((ub + rest) * 1.000001f) >= thr;
+      if (prune) {
+        // what the lists after li can add inside this leader block's doc range (the lists before
+        // li hold none of this tile's docs): block-max over the <= 4 blocks the range spans,
+        // else the weight; a single-term Must clause that ends before the range drops the block
+        const uint32_t first = i_mine ? prev_mine + 1u : 0u;
+        const uint32_t last = rec_mine.x;
+        float ub = 0.0f, rest_mine = 0.0f;
         if (surv) {
-          auto pass = [&](uint32_t tfv) {
-            return sortable((bm25(w_lead, min_norm, tfv) + rest) * 1.000001f) >= thr;
+          ub = block_max_score(rec_mine.y, w_lead, L.cache, lead.has_freq);
+          surv = sortable((ub + L.suffix[li + 1u] * 1.000001f) * 1.000001f) >= thr;
+        }
+        // (pure unions: their dense lists span far more than 4 blocks, the seeks do not pay)
+        const bool block_bounds = BOOL && n_lead < nt;
+        if (!block_bounds) rest_mine = L.suffix[li + 1u];
+        if (block_bounds && __ballot(surv)) {
+          for (uint32_t m = li + 1u; m < nt; ++m) {
+            const uint32_t role = (roles >> (2u * m)) & 3u;
+            if (role == TQD_ROLE_MUST_NOT) continue;
+            const bool single = role == TQD_ROLE_MUST && m >= n_lead && ((clause_end >> m) & 1u) &&
+                                (m == n_lead || ((clause_end >> (m - 1u)) & 1u));
+            const TermRef tr = load_term(p.terms, sload(&Q->term[m]));
+            const float w = sload(&Q->weight[m]);
+            if (surv) {
+              const uint32_t j0 = seek_block(tr, first);
+              if (j0 >= tr.n_blocks) {
+                if (single) surv = false;
+              } else {
+                float bound = 0.0f;
+                bool closed = false;
+                for (uint32_t k = 0; k < 4u && !closed; ++k) {
+                  const uint32_t j = j0 + k;
+                  const uint4 r = tr.rec[j];
+                  const float b2 = block_max_score(r.y, w, L.cache, tr.has_freq);
+                  bound = b2 > bound ? b2 : bound;
+                  closed = r.x >= last || j + 1u >= tr.n_blocks;
+                }
+                if (!closed) bound = w;
+                rest_mine = rest_mine + bound;
+              }
+            }
+          }
+        }
+        rest_mine *= 1.000001f;
+        if (surv) surv = sortable((ub + rest_mine) * 1.000001f) >= thr;
+        if (surv) {
+          auto pass = [&](uint32_t tfv) __attribute__((always_inline)) {
+            return sortable((bm25(w_lead, min_norm, tfv) + rest_mine) * 1.000001f) >= thr;
           };
           if (!pass(0xFFFFFFFFu)) {
             surv = false;
@@ -2122,10 +2167,16 @@ static void launch_or_t(const TqkScanParams &p, bool /*dpp*/, dim3 grid, dim3 bl
     else
       or_kernel<KPL, true><<<grid, block, 0, st>>>(p);
   } else {  // candidate-driven form: one wavefront per chunk
-    if (p.exhaustive)
-      union_kernel<KPL, false><<<grid, dim3(64), 0, st>>>(p);
-    else
-      union_kernel<KPL, true><<<grid, dim3(64), 0, st>>>(p);
+    if (p.boolean) {
+      if (p.exhaustive)
+        union_kernel<KPL, false, true><<<grid, dim3(64), 0, st>>>(p);
+      else
+        union_kernel<KPL, true, true><<<grid, dim3(64), 0, st>>>(p);
+    } else if (p.exhaustive) {
+      union_kernel<KPL, false, false><<<grid, dim3(64), 0, st>>>(p);
+    } else {
+      union_kernel<KPL, true, false><<<grid, dim3(64), 0, st>>>(p);
+    }
   }
 }
 

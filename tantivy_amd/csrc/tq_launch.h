@@ -34,6 +34,7 @@ struct TqkScanParams {
   uint32_t or_windows;  // OR: 1 = window-parallel kernel, 0 = candidate-driven kernel
   uint32_t debug;       // TQ_DEBUG ablation bits (profiling only; results are wrong when set)
   uint32_t all_dense;   // AND: every non-leader list of every query of the launch has a bitmap
+  uint32_t boolean;     // union kernel: queries carry roles / clauses / min_should (TQ_MODE_BOOL)
 };
 
 struct TqkMergeParams {
