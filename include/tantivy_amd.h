@@ -162,6 +162,46 @@ int tq_decode_postings(tq_segment *seg, tq_term_handle term, uint32_t *docs, uin
 int tq_decode_position_deltas(tq_segment *seg, tq_term_handle term, uint32_t *out, uint64_t cap,
                               uint64_t *n_out);
 
+/* ---- codec writers (segment finalisation / merges on the device) ----
+ * replaces: PostingsSerializer::{new_term, write_doc, close_term} (src/postings/serializer.rs:
+ * 342-481; skip entries src/postings/skip.rs:55-88; block-max selection serializer.rs:404-428)
+ * for a batch of terms.  Term t owns docs/tfs[term_starts[t] .. term_starts[t+1]) (doc ids
+ * strictly increasing, tfs >= 1; tfs ignored / may be NULL with TQ_BASIC).  fieldnorm_ids =
+ * num_docs bytes of the field's fieldnorm sub-file or NULL (then no block-max metadata, as when
+ * the serializer has no FieldNormReader); avg_fieldnorm = total_num_tokens / num_docs
+ * (serializer.rs:130-135).  Writes the posting lists back to back, exactly the bytes the
+ * reference writes after the 8-byte total_num_tokens header of the field's .idx sub-file;
+ * out_term_starts[t] .. [t+1] is TermInfo::postings_range relative to that point;
+ * *out_len = bytes needed (valid also when TQ_ERR_INVALID reports out_cap too small). */
+typedef struct tq_encoder tq_encoder;
+int tq_encoder_create(tq_ctx *ctx, int device, tq_encoder **out);
+void tq_encoder_free(tq_encoder *enc);
+int tq_encode_postings(tq_encoder *enc, uint32_t n_terms, const uint64_t *term_starts,
+                       const uint32_t *docs, const uint32_t *tfs, const uint8_t *fieldnorm_ids,
+                       uint32_t num_docs, float avg_fieldnorm, uint8_t record_option, uint8_t *out,
+                       uint64_t out_cap, uint64_t *out_term_starts, uint64_t *out_len);
+/* replaces: PositionSerializer::{write_positions_delta, close_term} (src/positions/serializer.rs:
+ * 46-91) for a batch of terms: term t owns position_deltas[term_starts[t] .. term_starts[t+1])
+ * (the within-document deltas of all its docs, concatenated); output = the terms' .pos bytes back
+ * to back, out_term_starts = TermInfo::positions_range. */
+int tq_encode_positions(tq_encoder *enc, uint32_t n_terms, const uint64_t *term_starts,
+                        const uint32_t *position_deltas, uint8_t *out, uint64_t out_cap,
+                        uint64_t *out_term_starts, uint64_t *out_len);
+/* Same with inputs and outputs resident in device memory (d_*); term_starts is needed on both
+ * sides (host copy: block planning).  Only the 8-byte total crosses back to the host. */
+int tq_encode_postings_device(tq_encoder *enc, uint32_t n_terms, const uint64_t *term_starts,
+                              const uint64_t *d_term_starts, const uint32_t *d_docs,
+                              const uint32_t *d_tfs, const uint8_t *d_fieldnorm_ids,
+                              uint32_t num_docs, float avg_fieldnorm, uint8_t record_option,
+                              uint8_t *d_out, uint64_t out_cap, uint64_t *d_out_term_starts,
+                              uint64_t *out_len, void *hip_stream);
+int tq_encode_positions_device(tq_encoder *enc, uint32_t n_terms, const uint64_t *term_starts,
+                               const uint64_t *d_term_starts, const uint32_t *d_position_deltas,
+                               uint8_t *d_out, uint64_t out_cap, uint64_t *d_out_term_starts,
+                               uint64_t *out_len, void *hip_stream);
+/* HIP-event time of the last call's kernels (measure + scan + write), milliseconds. */
+int tq_encoder_last_kernel_ms(tq_encoder *enc, float *ms);
+
 /* ---- deletes and counting ----
  * replaces: SegmentReader::alive_bitset + AliveBitSet::is_alive in the collector callback
  * (src/fastfield/alive_bitset.rs:52-61, src/collector/sort_key/sort_by_score.rs:44-53).  bytes =

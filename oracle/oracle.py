@@ -165,6 +165,11 @@ def lib():
     L.to_position_serializer_free.argtypes = [C.c_void_p]
     L.to_position_serializer_write_positions_delta.argtypes = [C.c_void_p, u32p, C.c_size_t]
     L.to_position_serializer_close_term.argtypes = [C.c_void_p]
+    L.to_serialize_postings_batch.argtypes = [C.c_float, C.c_int, C.c_void_p, C.c_uint32, C.c_uint32,
+                                              C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(Buf),
+                                              C.c_void_p]
+    L.to_serialize_positions_batch.argtypes = [C.c_uint32, C.c_void_p, C.c_void_p, C.POINTER(Buf),
+                                               C.c_void_p]
     L.to_search_pruned.restype = C.c_size_t
     L.to_search_pruned.argtypes = [C.POINTER(SegmentView), C.POINTER(Query), C.POINTER(Hit)]
     L.to_search_exhaustive.restype = C.c_size_t
@@ -422,6 +427,41 @@ def build_segment(max_doc, postings, fieldnorms=None, record_option=WITH_FREQS, 
     L.to_buf_free(C.byref(posbuf))
     idx = np.concatenate([hdr, body])
     return Segment(max_doc, record_option, idx, pos, fn_ids, terms, total_num_tokens)
+
+
+def serialize_postings_batch(term_starts, docs, tfs, fieldnorm_ids, num_docs, avg_fieldnorm,
+                             record_option):
+    """PostingsSerializer over flat arrays (term t = docs/tfs[term_starts[t]:term_starts[t+1]]):
+    (bytes, u64 term starts in them)."""
+    ts = np.ascontiguousarray(term_starts, np.uint64)
+    docs = np.ascontiguousarray(docs, np.uint32)
+    tfs = None if tfs is None else np.ascontiguousarray(tfs, np.uint32)
+    fn = None if fieldnorm_ids is None else np.ascontiguousarray(fieldnorm_ids, np.uint8)
+    out = Buf()
+    lib().to_buf_init(C.byref(out))
+    ots = np.zeros(len(ts), np.uint64)
+    lib().to_serialize_postings_batch(C.c_float(avg_fieldnorm), record_option,
+                                      None if fn is None else fn.ctypes.data, num_docs, len(ts) - 1,
+                                      ts.ctypes.data, docs.ctypes.data,
+                                      None if tfs is None else tfs.ctypes.data, C.byref(out),
+                                      ots.ctypes.data)
+    body = np.ctypeslib.as_array(out.data, shape=(out.len,)).copy() if out.len else np.zeros(0, np.uint8)
+    lib().to_buf_free(C.byref(out))
+    return body, ots
+
+
+def serialize_positions_batch(term_starts, deltas):
+    """PositionSerializer over flat arrays of within-document position deltas."""
+    ts = np.ascontiguousarray(term_starts, np.uint64)
+    deltas = np.ascontiguousarray(deltas, np.uint32)
+    out = Buf()
+    lib().to_buf_init(C.byref(out))
+    ots = np.zeros(len(ts), np.uint64)
+    lib().to_serialize_positions_batch(len(ts) - 1, ts.ctypes.data, deltas.ctypes.data,
+                                       C.byref(out), ots.ctypes.data)
+    body = np.ctypeslib.as_array(out.data, shape=(out.len,)).copy() if out.len else np.zeros(0, np.uint8)
+    lib().to_buf_free(C.byref(out))
+    return body, ots
 
 
 # ----------------------------------------------------------------------------- queries

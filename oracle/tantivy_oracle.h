@@ -158,6 +158,12 @@ void to_position_serializer_free(to_position_serializer *s);
 void to_position_serializer_write_positions_delta(to_position_serializer *s, const uint32_t *d,
                                                   size_t n);
 void to_position_serializer_close_term(to_position_serializer *s);
+void to_serialize_postings_batch(float avg_fieldnorm, int mode, const uint8_t *fieldnorm_ids,
+                                 uint32_t num_docs, uint32_t n_terms, const uint64_t *term_starts,
+                                 const uint32_t *docs, const uint32_t *tfs, to_buf *out,
+                                 uint64_t *out_term_starts);
+void to_serialize_positions_batch(uint32_t n_terms, const uint64_t *term_starts,
+                                  const uint32_t *deltas, to_buf *out, uint64_t *out_term_starts);
 
 typedef struct {
   const uint8_t *bit_widths;

@@ -214,6 +214,25 @@ void to_postings_serializer_close_term(to_postings_serializer *s, uint32_t doc_f
   s->has_bm25 = 0;
 }
 
+/* FieldSerializer's loop over the terms of a field (serializer.rs:186-260: new_term, write_doc
+ * per posting, close_term) for lists given as flat arrays; out_term_starts = postings_range. */
+void to_serialize_postings_batch(float avg_fieldnorm, int mode, const uint8_t *fieldnorm_ids,
+                                 uint32_t num_docs, uint32_t n_terms, const uint64_t *term_starts,
+                                 const uint32_t *docs, const uint32_t *tfs, to_buf *out,
+                                 uint64_t *out_term_starts) {
+  to_postings_serializer *s = to_postings_serializer_new(avg_fieldnorm, mode, fieldnorm_ids, num_docs);
+  for (uint32_t t = 0; t < n_terms; t++) {
+    const uint64_t lo = term_starts[t], hi = term_starts[t + 1];
+    out_term_starts[t] = out->len;
+    to_postings_serializer_new_term(s, (uint32_t)(hi - lo), 1);
+    for (uint64_t i = lo; i < hi; i++)
+      to_postings_serializer_write_doc(s, docs[i], tfs ? tfs[i] : 1u);
+    to_postings_serializer_close_term(s, (uint32_t)(hi - lo), out);
+  }
+  out_term_starts[n_terms] = out->len;
+  to_postings_serializer_free(s);
+}
+
 /* ------------------------------------------------------------------ PositionSerializer
  * src/positions/serializer.rs:12-93 */
 struct to_position_serializer {
@@ -527,4 +546,18 @@ size_t to_skip_walk(const uint8_t *data, size_t len, uint32_t doc_freq, int skip
     if (i < n_advances) to_skip_reader_advance(&r);
   }
   return n_advances + 1;
+}
+
+/* the same for the positions of a field: write_positions_delta + close_term per term */
+void to_serialize_positions_batch(uint32_t n_terms, const uint64_t *term_starts,
+                                  const uint32_t *deltas, to_buf *out, uint64_t *out_term_starts) {
+  to_position_serializer *s = to_position_serializer_new(out);
+  for (uint32_t t = 0; t < n_terms; t++) {
+    out_term_starts[t] = out->len;
+    to_position_serializer_write_positions_delta(s, deltas + term_starts[t],
+                                                 (size_t)(term_starts[t + 1] - term_starts[t]));
+    to_position_serializer_close_term(s);
+  }
+  out_term_starts[n_terms] = out->len;
+  to_position_serializer_free(s);
 }

@@ -53,7 +53,9 @@ EXPORTS = [
     "tq_term_prepare", "tq_search_batch", "tq_search_batch_device", "tq_merge_topk",
     "tq_merge_topk_device", "tq_decode_postings", "tq_decode_position_deltas",
     "tq_last_batch_stats", "tq_set_option", "tq_segment_set_alive_bitset", "tq_count_batch",
-    "tq_last_batch_match_counts",
+    "tq_last_batch_match_counts", "tq_encoder_create", "tq_encoder_free", "tq_encode_postings",
+    "tq_encode_positions", "tq_encode_postings_device", "tq_encode_positions_device",
+    "tq_encoder_last_kernel_ms",
     "tqh_last_error", "tqh_searcher_new", "tqh_searcher_free", "tqh_searcher_add_segment",
     "tqh_prepare_batch", "tqh_search_prepared", "tqh_collect_segment_prepared",
     "tqh_collect_segment_prepared_device", "tqh_searcher_add_remote_stats",
@@ -95,6 +97,18 @@ def lib():
     L.tq_segment_set_alive_bitset.argtypes = [vp, vp, C.c_size_t]
     L.tq_count_batch.argtypes = [vp, C.POINTER(TqQuery), C.c_uint32, u32p]
     L.tq_last_batch_match_counts.argtypes = [vp, u32p, C.c_uint32]
+    u64p = C.POINTER(C.c_uint64)
+    L.tq_encoder_create.argtypes = [vp, C.c_int, C.POINTER(vp)]
+    L.tq_encoder_free.argtypes = [vp]
+    L.tq_encoder_free.restype = None
+    L.tq_encode_postings.argtypes = [vp, C.c_uint32, vp, vp, vp, vp, C.c_uint32, C.c_float,
+                                     C.c_uint8, vp, C.c_uint64, vp, u64p]
+    L.tq_encode_positions.argtypes = [vp, C.c_uint32, vp, vp, vp, C.c_uint64, vp, u64p]
+    L.tq_encode_postings_device.argtypes = [vp, C.c_uint32, vp, vp, vp, vp, vp, C.c_uint32,
+                                            C.c_float, C.c_uint8, vp, C.c_uint64, vp, u64p, vp]
+    L.tq_encode_positions_device.argtypes = [vp, C.c_uint32, vp, vp, vp, vp, C.c_uint64, vp, u64p,
+                                             vp]
+    L.tq_encoder_last_kernel_ms.argtypes = [vp, C.POINTER(C.c_float)]
     L.tqh_searcher_new.argtypes = [vp, C.POINTER(vp)]
     L.tqh_searcher_free.argtypes = [vp]
     L.tqh_searcher_add_segment.argtypes = [vp, C.c_int, C.c_uint32, C.c_uint8, vp, C.c_size_t, vp,
@@ -140,6 +154,74 @@ def bm25_for_terms(doc_freqs, total_num_docs, total_num_tokens, boost=1.0):
     _check(lib().tqh_bm25_for_terms(dfs, len(doc_freqs), int(total_num_docs), int(total_num_tokens),
                                     C.c_float(boost), C.byref(w), _f32(cache)), host=True)
     return float(w.value), cache
+
+
+class Encoder:
+    """Device-side PostingsSerializer / PositionSerializer (tq_encode_*), host buffers in and out."""
+
+    def __init__(self, device=0):
+        self._ctx = C.c_void_p()
+        arr = (C.c_int * 1)(device)
+        _check(lib().tq_init(arr, 1, C.byref(self._ctx)))
+        self._e = C.c_void_p()
+        _check(lib().tq_encoder_create(self._ctx, device, C.byref(self._e)))
+
+    def close(self):
+        if self._e:
+            lib().tq_encoder_free(self._e)
+            self._e = None
+        if self._ctx:
+            lib().tq_shutdown(self._ctx)
+            self._ctx = None
+
+    def _run(self, call, n_terms, est):
+        out = np.zeros(max(16, est), np.uint8)
+        ots = np.zeros(n_terms + 1, np.uint64)
+        need = C.c_uint64()
+        rc = call(out, ots, need)
+        if rc != 0 and need.value > out.size:  # too small: the call reported the size
+            out = np.zeros(need.value, np.uint8)
+            rc = call(out, ots, need)
+        _check(rc)
+        return out[: need.value].copy(), ots
+
+    def encode_postings(self, term_starts, docs, tfs, fieldnorm_ids, num_docs, avg_fieldnorm,
+                        record_option, out_cap=None):
+        ts = np.ascontiguousarray(term_starts, np.uint64)
+        docs = np.ascontiguousarray(docs, np.uint32)
+        tfs = None if tfs is None else np.ascontiguousarray(tfs, np.uint32)
+        fn = None if fieldnorm_ids is None else np.ascontiguousarray(fieldnorm_ids, np.uint8)
+
+        def call(out, ots, need):
+            return lib().tq_encode_postings(
+                self._e, len(ts) - 1, ts.ctypes.data, docs.ctypes.data,
+                None if tfs is None else tfs.ctypes.data, None if fn is None else fn.ctypes.data,
+                int(num_docs), C.c_float(avg_fieldnorm), int(record_option), out.ctypes.data,
+                out.size, ots.ctypes.data, C.byref(need))
+
+        est = out_cap if out_cap is not None else int(docs.size) * 3 + 64 * len(ts)
+        return self._run(call, len(ts) - 1, est)
+
+    def encode_positions(self, term_starts, deltas, out_cap=None):
+        ts = np.ascontiguousarray(term_starts, np.uint64)
+        deltas = np.ascontiguousarray(deltas, np.uint32)
+
+        def call(out, ots, need):
+            return lib().tq_encode_positions(self._e, len(ts) - 1, ts.ctypes.data,
+                                             deltas.ctypes.data, out.ctypes.data, out.size,
+                                             ots.ctypes.data, C.byref(need))
+
+        est = out_cap if out_cap is not None else int(deltas.size) * 2 + 64 * len(ts)
+        return self._run(call, len(ts) - 1, est)
+
+    def last_kernel_ms(self):
+        ms = C.c_float()
+        _check(lib().tq_encoder_last_kernel_ms(self._e, C.byref(ms)))
+        return float(ms.value)
+
+    @property
+    def raw(self):
+        return self._e
 
 
 class DeviceIndex:

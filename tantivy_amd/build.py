@@ -9,6 +9,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB = os.path.join(HERE, "lib", "libtantivy_amd.so")
 SOURCES = [
     os.path.join(HERE, "csrc", "tq_kernels.hip"),
+    os.path.join(HERE, "csrc", "tq_encode.hip"),
     os.path.join(HERE, "csrc", "tq_api.cpp"),
     os.path.join(HERE, "host", "searcher.cpp"),
     os.path.join(HERE, "host", "host_capi.cpp"),

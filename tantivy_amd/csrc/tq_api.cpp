@@ -142,6 +142,13 @@ struct tq_ctx {
   std::vector<int> devices;
 };
 
+int tq_internal_fail(int code, const char *where, const char *what) {
+  return fail(code, "%s: %s", where, what);
+}
+bool tq_internal_ctx_has_device(const tq_ctx *ctx, int device) {
+  return std::find(ctx->devices.begin(), ctx->devices.end(), device) != ctx->devices.end();
+}
+
 struct tq_segment {
   tq_ctx *ctx = nullptr;
   int device = 0;

@@ -70,3 +70,8 @@ hipError_t tqk_launch_decode_list(const TqdSegment &seg, const TqdTerm *terms, u
 hipError_t tqk_launch_decode_positions(const TqdSegment &seg, const TqdTerm *terms,
                                        uint32_t handle, uint32_t *out, uint64_t n, hipStream_t st);
 hipError_t tqk_launch_merge_segments(const TqkSegMergeParams &p, hipStream_t st);
+
+// ---- shared with tq_encode.hip: the C ABI's error slot and context checks live in tq_api.cpp
+struct tq_ctx;
+int tq_internal_fail(int code, const char *where, const char *what);
+bool tq_internal_ctx_has_device(const tq_ctx *ctx, int device);
