@@ -18,6 +18,7 @@
 
 #include <algorithm>
 #include <cstdint>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -29,10 +30,17 @@ namespace {
 constexpr int WAVE = 64;
 constexpr int ENC_WAVES = 4;  // wavefronts per workgroup
 
+// where block b lives: its term (| first block of the term << 31), its index inside the term and
+// the index of its first value
+struct BlkInfo {
+  uint32_t term_first, j;
+  uint64_t base;
+};
+
 struct EncParams {
   const uint64_t *term_starts;  // n_terms + 1, into values / tfs
   const uint32_t *blk_first;    // n_terms + 1: number of full blocks before term t
-  const uint32_t *blk_term;     // n_blocks: term of block b
+  BlkInfo *blk_info;            // n_blocks, written by enc_plan_kernel
   const uint32_t *values;       // doc ids (postings) or position deltas (positions)
   const uint32_t *tfs;          // postings with freqs, else null
   const uint8_t *fieldnorm_ids; // postings: block-max needs them, else null
@@ -47,29 +55,52 @@ struct EncParams {
   uint32_t has_freq, has_pos, has_bm25, positions_file;
 };
 
+// wave-wide reductions on the DPP network (row_shr 1/2/4/8, row_bcast 15/31: six VALU ops, no LDS
+// round trips); lanes without a source read the identity 0; the total lands in lane 63
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ uint32_t dpp0(uint32_t x) {
+  return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, CTRL, ROW_MASK, 0xF, false);
+}
+__device__ __forceinline__ uint32_t last_lane(uint32_t v) {
+  return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+}
 __device__ __forceinline__ uint32_t wave_or(uint32_t v) {
-  for (int o = 32; o; o >>= 1) v |= __shfl_xor(v, o, WAVE);
+  v |= dpp0<0x111, 0xF>(v);
+  v |= dpp0<0x112, 0xF>(v);
+  v |= dpp0<0x114, 0xF>(v);
+  v |= dpp0<0x118, 0xF>(v);
+  v |= dpp0<0x142, 0xA>(v);
+  v |= dpp0<0x143, 0xC>(v);
+  return last_lane(v);
+}
+__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v, int /*lane*/) {
+  v += dpp0<0x111, 0xF>(v);
+  v += dpp0<0x112, 0xF>(v);
+  v += dpp0<0x114, 0xF>(v);
+  v += dpp0<0x118, 0xF>(v);
+  v += dpp0<0x142, 0xA>(v);
+  v += dpp0<0x143, 0xC>(v);
   return v;
 }
-__device__ __forceinline__ uint32_t wave_add(uint32_t v) {
-  for (int o = 32; o; o >>= 1) v += __shfl_xor(v, o, WAVE);
-  return v;
-}
+__device__ __forceinline__ uint32_t wave_add(uint32_t v) { return last_lane(wave_incl_scan(v, 0)); }
+// max of (hi, lo) pairs compared as one 64-bit key
 __device__ __forceinline__ uint64_t wave_max64(uint64_t v) {
-  for (int o = 32; o; o >>= 1) {
-    const uint32_t lo = __shfl_xor((uint32_t)v, o, WAVE);
-    const uint32_t hi = __shfl_xor((uint32_t)(v >> 32), o, WAVE);
-    const uint64_t w = ((uint64_t)hi << 32) | lo;
-    v = w > v ? w : v;
+  uint32_t hi = (uint32_t)(v >> 32), lo = (uint32_t)v;
+#define TQ_MAX_STEP(CTRL, MASK)                                       \
+  {                                                                   \
+    const uint32_t h2 = dpp0<CTRL, MASK>(hi), l2 = dpp0<CTRL, MASK>(lo); \
+    const bool take = h2 > hi || (h2 == hi && l2 > lo);               \
+    hi = take ? h2 : hi;                                              \
+    lo = take ? l2 : lo;                                              \
   }
-  return v;
-}
-__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v, int lane) {
-  for (int o = 1; o < WAVE; o <<= 1) {
-    const uint32_t u = __shfl_up(v, o, WAVE);
-    if (lane >= o) v += u;
-  }
-  return v;
+  TQ_MAX_STEP(0x111, 0xF)
+  TQ_MAX_STEP(0x112, 0xF)
+  TQ_MAX_STEP(0x114, 0xF)
+  TQ_MAX_STEP(0x118, 0xF)
+  TQ_MAX_STEP(0x142, 0xA)
+  TQ_MAX_STEP(0x143, 0xC)
+#undef TQ_MAX_STEP
+  return ((uint64_t)last_lane(hi) << 32) | last_lane(lo);
 }
 __device__ __forceinline__ uint32_t bit_len(uint32_t v) { return v ? 32u - (uint32_t)__clz(v) : 0u; }
 __device__ __forceinline__ uint32_t vint_len(uint32_t v) {  // compression/vint.rs: 7 bits a byte
@@ -101,12 +132,41 @@ struct BlockVals {
   uint32_t d0, d1;  // what gets bit-packed
   uint32_t t0, t1;  // tfs
 };
-__device__ __forceinline__ void load_block(const EncParams &p, uint32_t t, uint32_t j, int lane,
-                                           BlockVals &x) {
-  const uint64_t base = p.term_starts[t] + (uint64_t)j * 128u;
-  x.v0 = p.values[base + lane];
-  x.v1 = p.values[base + 64 + lane];
-  x.t0 = x.t1 = 1u;
+// Both passes are latency-bound if a wavefront walks "block record -> values -> fieldnorms ->
+// results" one block at a time (3.3 us per block measured).  So a wavefront takes ENC_CHUNK
+// consecutive blocks: lane i loads block i's record once (coalesced), the per-block loop gets it
+// through v_readlane, the values of block i+2 and the fieldnorm gather of block i+1 are in flight
+// while block i is reduced, and the per-block results leave through lane i at the end.
+constexpr uint32_t ENC_CHUNK = 32;
+struct RawBlock {
+  uint32_t v0, v1, t0, t1, prev, term;  // term: | first << 31
+};
+__device__ __forceinline__ uint32_t rl(uint32_t v, uint32_t i) {
+  return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)i);
+}
+__device__ __forceinline__ RawBlock load_raw(const EncParams &p, const BlkInfo &mine, uint32_t i,
+                                             int lane) {
+  RawBlock r;
+  r.term = rl(mine.term_first, i);
+  const uint64_t base = ((uint64_t)rl((uint32_t)(mine.base >> 32), i) << 32) | rl((uint32_t)mine.base, i);
+  // every load is issued unconditionally (clamped addresses, dummy sources): conditional loads in
+  // the pipelined loops make the compiler fall back to s_waitcnt vmcnt(0)
+  const uint32_t *tfp = p.has_freq ? p.tfs : p.values;
+  r.v0 = p.values[base + lane];
+  r.v1 = p.values[base + 64 + lane];
+  r.prev = p.values[base ? base - 1 : 0];
+  r.t0 = tfp[base + lane];
+  r.t1 = tfp[base + 64 + lane];
+  if (!p.has_freq) r.t0 = r.t1 = 1u;
+  if (r.term >> 31) r.prev = 0u;
+  return r;
+}
+__device__ __forceinline__ void finish_block(const EncParams &p, const RawBlock &r, int lane,
+                                             BlockVals &x) {
+  x.v0 = r.v0;
+  x.v1 = r.v1;
+  x.t0 = r.t0;
+  x.t1 = r.t1;
   if (p.positions_file) {
     x.d0 = x.v0;
     x.d1 = x.v1;
@@ -116,18 +176,34 @@ __device__ __forceinline__ void load_block(const EncParams &p, uint32_t t, uint3
   // (offset 0 <-> None) stores its first doc raw (compression/mod.rs:36-45)
   uint32_t p0 = __shfl_up(x.v0, 1, WAVE);
   uint32_t p1 = __shfl_up(x.v1, 1, WAVE);
-  const uint32_t v0_last = __shfl(x.v0, 63, WAVE);
+  const uint32_t v0_last = last_lane(x.v0);
   if (lane == 0) {
     p1 = v0_last;
-    p0 = j ? p.values[base - 1] : 0u;
+    p0 = r.prev;
   }
   x.d0 = x.v0 - p0 - 1u;
-  if (lane == 0 && (j == 0 || p0 == 0u)) x.d0 = x.v0;
+  if (lane == 0 && (r.term >> 31)) x.d0 = x.v0;
   x.d1 = x.v1 - p1 - 1u;
-  if (p.has_freq) {
-    x.t0 = p.tfs[base + lane];
-    x.t1 = p.tfs[base + 64 + lane];
+}
+
+// block b -> its term (largest t with blk_first[t] <= b), one thread per block
+__global__ __launch_bounds__(256) void enc_plan_kernel(EncParams p) {
+  const uint32_t b = blockIdx.x * 256u + threadIdx.x;
+  if (b >= p.n_blocks) return;
+  uint32_t lo = 0, hi = p.n_terms;
+  while (hi - lo > 1u) {
+    const uint32_t mid = (lo + hi) >> 1;
+    if (p.blk_first[mid] <= b)
+      lo = mid;
+    else
+      hi = mid;
   }
+  const uint32_t j = b - p.blk_first[lo];
+  BlkInfo o;
+  o.term_first = lo | (j == 0u ? 0x80000000u : 0u);
+  o.j = j;
+  o.base = p.term_starts[lo] + 128ull * j;
+  p.blk_info[b] = o;
 }
 
 __global__ __launch_bounds__(WAVE *ENC_WAVES) void enc_measure_kernel(EncParams p) {
@@ -139,36 +215,58 @@ __global__ __launch_bounds__(WAVE *ENC_WAVES) void enc_measure_kernel(EncParams 
     cache[threadIdx.x] = p.cache[threadIdx.x];
     __syncthreads();
   }
-  for (uint32_t b = wave; b < p.n_blocks; b += n_waves) {
-    const uint32_t t = p.blk_term[b];
-    const uint32_t j = b - p.blk_first[t];
-    BlockVals x;
-    load_block(p, t, j, lane, x);
-    const uint32_t doc_bits = bit_len(wave_or(x.d0 | x.d1));
-    uint32_t tf_bits = 0, bw_fn = 0, bw_tf = 0, tfsum = 0;
-    if (p.has_freq) {
-      tf_bits = bit_len(wave_or((x.t0 - 1u) | (x.t1 - 1u)));  // minus-one encoded (mod.rs:54-75)
-      if (p.has_pos) tfsum = wave_add(x.t0 + x.t1);
-      if (p.has_bm25) {
-        const uint32_t f0 = p.fieldnorm_ids[x.v0], f1 = p.fieldnorm_ids[x.v1];
-        const float tf0 = (float)x.t0, tf1 = (float)x.t1;
-        const float s0 = tf0 / (tf0 + cache[f0]), s1 = tf1 / (tf1 + cache[f1]);
-        // non-negative floats order like their bits; the index breaks ties towards the last
-        const uint64_t k0 = ((uint64_t)__float_as_uint(s0) << 32) | (uint32_t)lane;
-        const uint64_t k1 = ((uint64_t)__float_as_uint(s1) << 32) | (uint32_t)(lane + 64);
-        const uint64_t best = wave_max64(k0 > k1 ? k0 : k1);
-        const uint32_t bi = (uint32_t)best & 127u;
-        const uint32_t fa = __shfl(f0, (int)(bi & 63u), WAVE), fb = __shfl(f1, (int)(bi & 63u), WAVE);
-        const uint32_t ta = __shfl(x.t0, (int)(bi & 63u), WAVE), tb = __shfl(x.t1, (int)(bi & 63u), WAVE);
-        bw_fn = bi < 64u ? fa : fb;
-        bw_tf = bi < 64u ? ta : tb;
-        bw_tf = bw_tf > 255u ? 255u : bw_tf;  // encode_block_wand_max_tf (skip.rs:31-34)
+  const uint8_t *fnp = p.has_bm25 ? p.fieldnorm_ids : reinterpret_cast<const uint8_t *>(p.values);
+  const uint32_t fn_mask = p.has_bm25 ? 0xFFFFFFFFu : 0u;  // no fieldnorms: every lane reads byte 0
+  auto gather = [&](const RawBlock &r, uint32_t &f0, uint32_t &f1) __attribute__((always_inline)) {
+    f0 = fnp[r.v0 & fn_mask];
+    f1 = fnp[r.v1 & fn_mask];
+  };
+  for (uint32_t b0 = wave * ENC_CHUNK; b0 < p.n_blocks; b0 += n_waves * ENC_CHUNK) {
+    const uint32_t nb = p.n_blocks - b0 < ENC_CHUNK ? p.n_blocks - b0 : ENC_CHUNK;
+    BlkInfo mine{};
+    if ((uint32_t)lane < nb) mine = p.blk_info[b0 + lane];
+    uint32_t meta_mine = 0, tfsum_mine = 0;
+    RawBlock r0 = load_raw(p, mine, 0, lane);
+    RawBlock r1 = nb > 1u ? load_raw(p, mine, 1, lane) : r0;
+    uint32_t nf0, nf1;
+    gather(r0, nf0, nf1);
+    for (uint32_t i = 0; i < nb; ++i) {
+      const RawBlock cur = r0;
+      const uint32_t f0 = nf0, f1 = nf1;
+      r0 = r1;
+      r1 = load_raw(p, mine, i + 2u < nb ? i + 2u : nb - 1u, lane);
+      gather(r0, nf0, nf1);
+      BlockVals x;
+      finish_block(p, cur, lane, x);
+      const uint32_t doc_bits = bit_len(wave_or(x.d0 | x.d1));
+      uint32_t tf_bits = 0, bw_fn = 0, bw_tf = 0, tfsum = 0;
+      if (p.has_freq) {
+        tf_bits = bit_len(wave_or((x.t0 - 1u) | (x.t1 - 1u)));  // minus-one encoded (mod.rs:54-75)
+        if (p.has_pos) tfsum = wave_add(x.t0 + x.t1);
+        if (p.has_bm25) {
+          const float tf0 = (float)x.t0, tf1 = (float)x.t1;
+          const float s0 = tf0 / (tf0 + cache[f0]), s1 = tf1 / (tf1 + cache[f1]);
+          // non-negative floats order like their bits; the index breaks ties towards the last
+          const uint64_t k0 = ((uint64_t)__float_as_uint(s0) << 32) | (uint32_t)lane;
+          const uint64_t k1 = ((uint64_t)__float_as_uint(s1) << 32) | (uint32_t)(lane + 64);
+          const uint64_t best = wave_max64(k0 > k1 ? k0 : k1);
+          const uint32_t bi = (uint32_t)best & 127u;
+          const uint32_t bl = bi & 63u;  // wave-uniform (came through readlane)
+          bw_fn = bi < 64u ? rl(f0, bl) : rl(f1, bl);
+          bw_tf = bi < 64u ? rl(x.t0, bl) : rl(x.t1, bl);
+          bw_tf = bw_tf > 255u ? 255u : bw_tf;  // encode_block_wand_max_tf (skip.rs:31-34)
+        }
+      }
+      if ((uint32_t)lane == i) {
+        meta_mine = doc_bits | (tf_bits << 8) | (bw_fn << 16) | (bw_tf << 24);
+        tfsum_mine = tfsum;
       }
     }
-    if (lane == 0) {
-      p.blk_meta[b] = doc_bits | (tf_bits << 8) | (bw_fn << 16) | (bw_tf << 24);
-      if (p.has_pos) p.blk_tfsum[b] = tfsum;
-      p.item_size[b + 2u * t + 1u] = 16u * (doc_bits + tf_bits);
+    if ((uint32_t)lane < nb) {
+      const uint32_t b = b0 + (uint32_t)lane, t = mine.term_first & 0x7FFFFFFFu;
+      p.blk_meta[b] = meta_mine;
+      if (p.has_pos) p.blk_tfsum[b] = tfsum_mine;
+      p.item_size[b + 2u * t + 1u] = 16u * ((meta_mine & 255u) + ((meta_mine >> 8) & 255u));
     }
   }
   // headers and tails: one wavefront per term
@@ -298,57 +396,71 @@ __global__ __launch_bounds__(WAVE *ENC_WAVES) void enc_write_kernel(EncParams p)
   const uint32_t wave = blockIdx.x * ENC_WAVES + wslot;
   const uint32_t n_waves = gridDim.x * ENC_WAVES;
   const uint32_t entry = skip_entry_size(p);
-  for (uint32_t b = wave; b < p.n_blocks; b += n_waves) {
-    const uint32_t t = p.blk_term[b];
-    const uint32_t j = b - p.blk_first[t];
-    BlockVals x;
-    load_block(p, t, j, lane, x);
-    const uint32_t meta = p.blk_meta[b];
-    const uint32_t doc_bits = meta & 255u, tf_bits = (meta >> 8) & 255u;
-    const uint32_t n_words = 4u * (doc_bits + tf_bits);
-    for (uint32_t i = (uint32_t)lane; i < n_words + 1u; i += WAVE) pk[i] = 0u;
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    pack_value(pk, (uint32_t)lane, doc_bits, x.d0);
-    pack_value(pk, (uint32_t)lane + 64u, doc_bits, x.d1);
-    if (p.has_freq) {
-      pack_value(pk + 4u * doc_bits, (uint32_t)lane, tf_bits, x.t0 - 1u);
-      pack_value(pk + 4u * doc_bits, (uint32_t)lane + 64u, tf_bits, x.t1 - 1u);
+  for (uint32_t b0 = wave * ENC_CHUNK; b0 < p.n_blocks; b0 += n_waves * ENC_CHUNK) {
+    const uint32_t nb = p.n_blocks - b0 < ENC_CHUNK ? p.n_blocks - b0 : ENC_CHUNK;
+    BlkInfo mine{};
+    uint32_t meta_mine = 0;
+    uint64_t off_mine = 0;
+    if ((uint32_t)lane < nb) {
+      mine = p.blk_info[b0 + lane];
+      meta_mine = p.blk_meta[b0 + lane];
+      off_mine = p.item_off[b0 + (uint32_t)lane + 2u * (mine.term_first & 0x7FFFFFFFu) + 1u];
     }
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    // payload -> out[off, off + n): dword stores where a dword lies inside, bytes at the edges
-    const uint64_t off = p.item_off[b + 2u * t + 1u];
-    const uint32_t n = 4u * n_words;
-    const uint64_t a0 = off & ~3ull;
-    const uint32_t lead = (uint32_t)(off - a0);  // bytes of the first dword that are not ours
-    const uint32_t n_dw = (lead + n + 3u) >> 2;
-    for (uint32_t k = (uint32_t)lane; k < n_dw; k += WAVE) {
-      const int32_t s = (int32_t)(4u * k) - (int32_t)lead;  // source byte of this dword
-      if (s >= 0 && (uint32_t)s + 4u <= n) {
-        const uint32_t wi = (uint32_t)s >> 2, sh = ((uint32_t)s & 3u) * 8u;
-        const uint32_t lo = pk[wi], hi = pk[wi + 1u];
-        const uint32_t v = sh ? (lo >> sh) | (hi << (32u - sh)) : lo;
-        *reinterpret_cast<uint32_t *>(p.out + a0 + 4ull * k) = v;
-      } else {
-        for (int q = 0; q < 4; ++q) {
-          const int32_t sb = s + q;
-          if (sb >= 0 && (uint32_t)sb < n)
-            p.out[a0 + 4ull * k + (uint32_t)q] = (uint8_t)(pk[(uint32_t)sb >> 2] >> (((uint32_t)sb & 3u) * 8u));
+    RawBlock r0 = load_raw(p, mine, 0, lane);
+    for (uint32_t i = 0; i < nb; ++i) {
+      const RawBlock cur = r0;
+      r0 = load_raw(p, mine, i + 1u < nb ? i + 1u : nb - 1u, lane);
+      BlockVals x;
+      finish_block(p, cur, lane, x);
+      const uint32_t meta = rl(meta_mine, i);
+      const uint32_t doc_bits = meta & 255u, tf_bits = (meta >> 8) & 255u;
+      const uint32_t n_words = 4u * (doc_bits + tf_bits);
+      for (uint32_t k = (uint32_t)lane; k < n_words + 1u; k += WAVE) pk[k] = 0u;
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      pack_value(pk, (uint32_t)lane, doc_bits, x.d0);
+      pack_value(pk, (uint32_t)lane + 64u, doc_bits, x.d1);
+      if (p.has_freq) {
+        pack_value(pk + 4u * doc_bits, (uint32_t)lane, tf_bits, x.t0 - 1u);
+        pack_value(pk + 4u * doc_bits, (uint32_t)lane + 64u, tf_bits, x.t1 - 1u);
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      // payload -> out[off, off + n): dword stores where a dword lies inside, bytes at the edges
+      const uint64_t off = ((uint64_t)rl((uint32_t)(off_mine >> 32), i) << 32) | rl((uint32_t)off_mine, i);
+      const uint32_t n = 4u * n_words;
+      const uint64_t a0 = off & ~3ull;
+      const uint32_t lead = (uint32_t)(off - a0);  // bytes of the first dword that are not ours
+      const uint32_t n_dw = (lead + n + 3u) >> 2;
+      for (uint32_t k = (uint32_t)lane; k < n_dw; k += WAVE) {
+        const int32_t s = (int32_t)(4u * k) - (int32_t)lead;  // source byte of this dword
+        if (s >= 0 && (uint32_t)s + 4u <= n) {
+          const uint32_t wi = (uint32_t)s >> 2, sh = ((uint32_t)s & 3u) * 8u;
+          const uint32_t lo = pk[wi], hi = pk[wi + 1u];
+          const uint32_t v = sh ? (lo >> sh) | (hi << (32u - sh)) : lo;
+          *reinterpret_cast<uint32_t *>(p.out + a0 + 4ull * k) = v;
+        } else {
+          for (int q = 0; q < 4; ++q) {
+            const int32_t sb = s + q;
+            if (sb >= 0 && (uint32_t)sb < n)
+              p.out[a0 + 4ull * k + (uint32_t)q] =
+                  (uint8_t)(pk[(uint32_t)sb >> 2] >> (((uint32_t)sb & 3u) * 8u));
+          }
         }
       }
+      __builtin_amdgcn_wave_barrier();
     }
-    // skip entry (skip.rs:55-88) / width byte into the term's header
-    const uint32_t last_doc = __shfl(x.v1, 63, WAVE);
-    if (lane == 0) {
-      const uint64_t lo = p.term_starts[t], hi = p.term_starts[t + 1u];
-      const uint32_t n_full = (uint32_t)((hi - lo) >> 7);
-      const uint64_t hoff = p.item_off[p.blk_first[t] + 2u * t];
+    // skip entries (skip.rs:55-88) / width bytes into the terms' headers: lane i writes block i's
+    if ((uint32_t)lane < nb) {
+      const uint32_t b = b0 + (uint32_t)lane, t = mine.term_first & 0x7FFFFFFFu, j = mine.j;
+      const uint32_t bf = p.blk_first[t], n_full = p.blk_first[t + 1u] - bf;
+      const uint64_t hoff = p.item_off[bf + 2u * t];
+      const uint32_t doc_bits = meta_mine & 255u, tf_bits = (meta_mine >> 8) & 255u;
       if (p.positions_file) {
         p.out[hoff + vint_len64(n_full) + j] = (uint8_t)doc_bits;
       } else {
         uint8_t *e = p.out + hoff + vint_len64((uint64_t)n_full * entry) + (uint64_t)j * entry;
-        put_bytes(e, last_doc, 4);
+        put_bytes(e, p.values[mine.base + 127u], 4);
         e[4] = (uint8_t)(doc_bits | 0x40u);  // strict-delta flag, always set (skip.rs:64-67)
         if (p.has_freq) {
           e[5] = (uint8_t)tf_bits;
@@ -357,12 +469,11 @@ __global__ __launch_bounds__(WAVE *ENC_WAVES) void enc_write_kernel(EncParams p)
             put_bytes(e + at, p.blk_tfsum[b], 4);
             at += 4;
           }
-          e[at] = (uint8_t)(meta >> 16);
-          e[at + 1] = (uint8_t)(meta >> 24);
+          e[at] = (uint8_t)(meta_mine >> 16);
+          e[at + 1] = (uint8_t)(meta_mine >> 24);
         }
       }
     }
-    __builtin_amdgcn_wave_barrier();
   }
   // headers' length prefixes and the vint tails: one wavefront per term
   for (uint32_t t = wave; t < p.n_terms; t += n_waves) {
@@ -397,9 +508,9 @@ __global__ __launch_bounds__(WAVE *ENC_WAVES) void enc_write_kernel(EncParams p)
         }
       }
     }
-    const uint32_t sv0 = wave_incl_scan(lv[0], lane), tv0 = __shfl(sv0, 63, WAVE);
-    const uint32_t sv1 = wave_incl_scan(lv[1], lane), tv1 = __shfl(sv1, 63, WAVE);
-    const uint32_t sf0 = wave_incl_scan(lf[0], lane), tf0 = __shfl(sf0, 63, WAVE);
+    const uint32_t sv0 = wave_incl_scan(lv[0], lane), tv0 = last_lane(sv0);
+    const uint32_t sv1 = wave_incl_scan(lv[1], lane), tv1 = last_lane(sv1);
+    const uint32_t sf0 = wave_incl_scan(lf[0], lane), tf0 = last_lane(sf0);
     const uint32_t sf1 = wave_incl_scan(lf[1], lane);
     const uint32_t docs_total = tv0 + tv1;
     if (lv[0]) put_vint(dst + (sv0 - lv[0]), v[0]);
@@ -474,9 +585,6 @@ int encode_device(tq_encoder *enc, bool positions_file, uint32_t n_terms,
   }
   blk_first[n_terms] = (uint32_t)nb;
   const uint32_t n_blocks = (uint32_t)nb;
-  std::vector<uint32_t> blk_term(n_blocks);
-  for (uint32_t t = 0; t < n_terms; ++t)
-    for (uint32_t b = blk_first[t]; b < blk_first[t + 1]; ++b) blk_term[b] = t;
   const uint32_t n_items = n_blocks + 2u * n_terms;
   const uint32_t n_partials = (n_items + 1u + SCAN_TILE - 1) / SCAN_TILE;  // + the total's slot
 
@@ -486,7 +594,7 @@ int encode_device(tq_encoder *enc, bool positions_file, uint32_t n_terms,
     o = align256(o + n);
     return at;
   };
-  const size_t o_first = take(4ull * (n_terms + 1)), o_term = take(4ull * n_blocks);
+  const size_t o_first = take(4ull * (n_terms + 1)), o_info = take(16ull * n_blocks);
   const size_t o_meta = take(4ull * n_blocks), o_tfsum = take(4ull * n_blocks);
   const size_t o_size = take(4ull * n_items), o_off = take(8ull * (n_items + 1));
   const size_t o_part = take(8ull * (n_partials + 1)), o_cache = take(1024);
@@ -498,14 +606,12 @@ int encode_device(tq_encoder *enc, bool positions_file, uint32_t n_terms,
   const bool has_bm25 = has_freq && d_fieldnorm_ids && num_docs > 0;  // serializer.rs:353-377
   if (has_bm25) tf_cache(avg_fieldnorm, cache);
   ENC_TRY(hipMemcpyAsync(sc + o_first, blk_first.data(), 4ull * (n_terms + 1), hipMemcpyHostToDevice, st));
-  if (n_blocks)
-    ENC_TRY(hipMemcpyAsync(sc + o_term, blk_term.data(), 4ull * n_blocks, hipMemcpyHostToDevice, st));
   if (has_bm25) ENC_TRY(hipMemcpyAsync(sc + o_cache, cache, 1024, hipMemcpyHostToDevice, st));
 
   EncParams p{};
   p.term_starts = d_term_starts;
   p.blk_first = (const uint32_t *)(sc + o_first);
-  p.blk_term = (const uint32_t *)(sc + o_term);
+  p.blk_info = (BlkInfo *)(sc + o_info);
   p.values = d_values;
   p.tfs = has_freq ? d_tfs : nullptr;
   p.fieldnorm_ids = d_fieldnorm_ids;
@@ -523,9 +629,15 @@ int encode_device(tq_encoder *enc, bool positions_file, uint32_t n_terms,
   p.has_bm25 = has_bm25;
   p.positions_file = positions_file;
 
-  const uint32_t work = std::max(n_blocks, n_terms);
-  const uint32_t grid = std::max<uint32_t>(1u, std::min<uint32_t>((work + ENC_WAVES - 1) / ENC_WAVES, 256u * 32u));
+  const uint32_t work = std::max((n_blocks + ENC_CHUNK - 1) / ENC_CHUNK, n_terms);
+  // grid cap (the loops are grid-stride over chunks of ENC_CHUNK blocks)
+  static const uint32_t kMaxWgs = [] {
+    const char *e = getenv("TQ_ENC_WGS");
+    return e ? (uint32_t)atoi(e) : 8192u;
+  }();
+  const uint32_t grid = std::max<uint32_t>(1u, std::min<uint32_t>((work + ENC_WAVES - 1) / ENC_WAVES, kMaxWgs));
   ENC_TRY(hipEventRecord(enc->ev0, st));
+  if (n_blocks) enc_plan_kernel<<<(n_blocks + 255) / 256, 256, 0, st>>>(p);
   enc_measure_kernel<<<grid, WAVE * ENC_WAVES, 0, st>>>(p);
   scan_partials_kernel<<<n_partials, SCAN_WG, 0, st>>>(p.item_size, (uint64_t *)(sc + o_part), n_items);
   scan_top_kernel<<<1, SCAN_WG, 0, st>>>((uint64_t *)(sc + o_part), n_partials);

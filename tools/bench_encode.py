@@ -1,8 +1,8 @@
 #!/usr/bin/env python
 """Device-side PostingsSerializer throughput: tq_encode_postings_device over the
 postings of the bench's synthetic 10M-doc segment, inputs and output resident in HBM.  One JSON
-line: postings/s, the roofline of the measure+scan+write kernels (algorithmic bytes = 8 B per
-posting read + the bytes written) and the oracle's serializer timed on one host core.
+line: postings/s, the roofline of the measure+scan+write kernels (algorithmic bytes = 9 B per
+posting read — doc id, tf, fieldnorm id — + the bytes written) and the oracle's serializer timed on one host core.
 The output is checked byte for byte against the segment the oracle serialised."""
 import argparse
 import ctypes as C
@@ -92,7 +92,7 @@ def main():
                "sample": "the same %d posting lists through the oracle's PostingsSerializer "
                          "restatement, one thread, %.2f s" % (sub, wall)}
     k = float(np.mean(kms))
-    algo = 8 * n_post + int(want.size)
+    algo = 9 * n_post + int(want.size)  # doc + tf + fieldnorm id read per posting, bytes written
     print(json.dumps({
         "metric": "postings_encoded_per_sec", "value": round(n_post * args.steps / elapsed, 1),
         "unit": "postings/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
