@@ -70,6 +70,34 @@ int tqh_bm25_for_terms(const uint64_t *term_doc_freqs, uint32_t n_terms, uint64_
 tq_segment *tqh_segment_raw(tqh_searcher *s, uint32_t segment_ord);
 uint32_t tqh_term_handle(tqh_searcher *s, uint32_t segment_ord, uint32_t term_id);
 
+/* ---- term dictionary values ----
+ * replaces: TermInfoStore::{open, get} and TermInfoStoreWriter (src/termdict/fst_termdict/
+ * term_info_store.rs:130-163, :166-290).  The FST (term bytes -> ordinal) stays with tantivy-fst;
+ * everything after the ordinal is here, so a query batch crosses the boundary as ordinals.
+ * tqh_term_dictionary_values: where the store sits inside a field's term dictionary file
+ * (TermDictionary::open, termdict.rs:123-140 inside the wrapper of src/termdict/mod.rs:82-98:
+ * fst | store | u64 store_len | u32 fst version | u32 dictionary type). */
+typedef struct tqh_term_info_store tqh_term_info_store;
+int tqh_term_dictionary_values(const uint8_t *file, size_t len, uint64_t *store_off,
+                               uint64_t *store_len);
+int tqh_term_info_store_open(const uint8_t *bytes, size_t len, tqh_term_info_store **out);
+void tqh_term_info_store_free(tqh_term_info_store *s);
+uint64_t tqh_term_info_store_num_terms(const tqh_term_info_store *s);
+/* out[i] = TermInfo of term_ords[i] (term_id = the ordinal) */
+int tqh_term_info_store_get(const tqh_term_info_store *s, const uint64_t *term_ords, uint32_t n,
+                            tqh_term_info *out);
+/* TermInfoStoreWriter::{write_term_info*, serialize} over infos in ordinal order; *out_len =
+ * bytes needed (also when the buffer was too small). */
+int tqh_term_info_store_write(const tqh_term_info *infos, uint32_t n, uint8_t *out,
+                              uint64_t out_cap, uint64_t *out_len);
+/* tqh_searcher_add_segment with the segment's TermInfoStore instead of a TermInfo array: term
+ * ids are term ordinals and TermInfos are decoded on first use. */
+int tqh_searcher_add_segment_with_store(tqh_searcher *s, int device, uint32_t max_doc,
+                                        uint8_t record_option, const uint8_t *idx, size_t idx_len,
+                                        const uint8_t *pos, size_t pos_len,
+                                        const uint8_t *fieldnorm, size_t fn_len,
+                                        const uint8_t *store, size_t store_len);
+
 #ifdef __cplusplus
 }
 #endif

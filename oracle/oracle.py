@@ -464,6 +464,155 @@ def serialize_positions_batch(term_starts, deltas):
     return body, ots
 
 
+# ----------------------------------------------------------------------------- files & term dictionary
+# Pure-Python restatements (small inputs only) of the file framing around the hot path and of the
+# TermInfoStore, pinned by the reference's compat fixture (tests/golden/compat_index.json).
+def _vint(data, at):
+    """common/src/vint.rs:180-196: 7-bit groups, stop bit 0x80 on the LAST byte."""
+    r, shift = 0, 0
+    while True:
+        b = data[at]
+        at += 1
+        r |= (b & 127) << shift
+        if b & 128:
+            return r, at
+        shift += 7
+
+
+def strip_footer(data):
+    """src/directory/footer.rs:17-47: body | json | u32 json_len | u32 magic 1337."""
+    data = bytes(data)
+    assert int.from_bytes(data[-4:], "little") == 1337
+    n = int.from_bytes(data[-8:-4], "little")
+    return data[: len(data) - 8 - n], data[len(data) - 8 - n: len(data) - 8]
+
+
+def composite_fields(body):
+    """src/directory/composite_file.rs:68-84,109-150: {(field, idx): bytes}."""
+    body = bytes(body)
+    flen = int.from_bytes(body[-4:], "little")
+    start = len(body) - 4 - flen
+    n, at = _vint(body, start)
+    addrs, offs, off = [], [], 0
+    for _ in range(n):
+        d, at = _vint(body, at)
+        off += d
+        field = int.from_bytes(body[at:at + 4], "little")
+        idx, at = _vint(body, at + 4)
+        addrs.append((field, idx))
+        offs.append(off)
+    offs.append(start)
+    return {a: body[offs[i]:offs[i + 1]] for i, a in enumerate(addrs)}
+
+
+def term_dictionary_parts(field_bytes):
+    """TermDictionary::open: the wrapper strips a u32 dictionary type (1 = Fst,
+    src/termdict/mod.rs:82-98), the fst dictionary is fst | term info store | u64 store_len |
+    u32 fst version (src/termdict/fst_termdict/termdict.rs:123-140).
+    Returns (fst bytes, store bytes)."""
+    b = bytes(field_bytes)
+    assert int.from_bytes(b[-4:], "little") == 1, "not an fst term dictionary"
+    assert int.from_bytes(b[-8:-4], "little") == 1, "fst dictionary version"
+    store_len = int.from_bytes(b[-16:-8], "little")
+    main = b[:-16]
+    return main[: len(main) - store_len], main[len(main) - store_len:]
+
+
+def compute_num_bits(n):
+    """bitpacker/src/lib.rs: bit length, but 64 once it exceeds 56."""
+    a = int(n).bit_length()
+    return a if a <= 56 else 64
+
+
+TERM_INFO_BLOCK_LEN = 256
+_BLOCK_META_SIZE = 8 + 28 + 3  # term_info_store.rs:51-53, term_info.rs:37
+
+
+def _extract_bits(data, addr_bits, num_bits):
+    """term_info_store.rs:108-128"""
+    assert num_bits <= 56
+    a = addr_bits // 8
+    v = int.from_bytes(data[a:a + 8].ljust(8, b"\0"), "little")
+    return (v >> (addr_bits % 8)) & ((1 << num_bits) - 1)
+
+
+def term_info_store_num_terms(store):
+    return int.from_bytes(bytes(store[8:16]), "little")
+
+
+def term_info_store_get(store, term_ord):
+    """TermInfoStore::open + get (term_info_store.rs:130-163, :64-101):
+    (doc_freq, postings_start, postings_end, positions_start, positions_end)."""
+    store = bytes(store)
+    meta_len = int.from_bytes(store[0:8], "little")
+    metas, infos = store[16:16 + meta_len], store[16 + meta_len:]
+    m = metas[(term_ord // TERM_INFO_BLOCK_LEN) * _BLOCK_META_SIZE:][:_BLOCK_META_SIZE]
+    offset = int.from_bytes(m[0:8], "little")
+    df = int.from_bytes(m[8:12], "little")
+    ps = int.from_bytes(m[12:20], "little")
+    pn = int.from_bytes(m[20:24], "little")
+    qs = int.from_bytes(m[24:32], "little")
+    qn = int.from_bytes(m[32:36], "little")
+    df_bits, post_bits, pos_bits = m[36], m[37], m[38]
+    inner = term_ord % TERM_INFO_BLOCK_LEN
+    if inner == 0:
+        return (df, ps, ps + pn, qs, qs + qn)
+    data = infos[offset:]
+    nb = df_bits + post_bits + pos_bits
+    a = nb * (inner - 1)
+    p0 = ps + _extract_bits(data, a, post_bits)
+    p1 = ps + _extract_bits(data, a + nb, post_bits)
+    q0 = qs + _extract_bits(data, a + post_bits, pos_bits)
+    q1 = qs + _extract_bits(data, a + post_bits + nb, pos_bits)
+    d = _extract_bits(data, a + post_bits + pos_bits, df_bits)
+    return (d, p0, p1, q0, q1)
+
+
+def term_info_store_serialize(term_infos):
+    """TermInfoStoreWriter (term_info_store.rs:171-290) over (doc_freq, postings_start,
+    postings_end, positions_start, positions_end) tuples in term-ordinal order."""
+    metas, infos = bytearray(), bytearray()
+
+    class _BP:  # bitpacker/src/bitpacker.rs:24-58
+        def __init__(self):
+            self.buf, self.n = 0, 0
+
+        def write(self, val, bits, out):
+            self.buf |= (val & ((1 << 64) - 1)) << self.n
+            self.n += bits
+            while self.n >= 64:
+                out += (self.buf & ((1 << 64) - 1)).to_bytes(8, "little")
+                self.buf >>= 64
+                self.n -= 64
+
+        def flush(self, out):
+            if self.n:
+                out += (self.buf & ((1 << 64) - 1)).to_bytes(8, "little")[: (self.n + 7) // 8]
+            self.buf, self.n = 0, 0
+
+    for b0 in range(0, len(term_infos), TERM_INFO_BLOCK_LEN):
+        blk = term_infos[b0:b0 + TERM_INFO_BLOCK_LEN]
+        ref, last = blk[0], blk[-1]
+        post_end = last[2] - ref[1]
+        pos_end = last[4] - ref[3]
+        df_bits = compute_num_bits(max([t[0] for t in blk[1:]], default=0))
+        post_bits, pos_bits = compute_num_bits(post_end), compute_num_bits(pos_end)
+        metas += len(infos).to_bytes(8, "little")
+        metas += ref[0].to_bytes(4, "little") + ref[1].to_bytes(8, "little")
+        metas += (ref[2] - ref[1]).to_bytes(4, "little") + ref[3].to_bytes(8, "little")
+        metas += (ref[4] - ref[3]).to_bytes(4, "little") + bytes([df_bits, post_bits, pos_bits])
+        bp = _BP()
+        for t in blk[1:]:
+            bp.write(t[1] - ref[1], post_bits, infos)
+            bp.write(t[3] - ref[3], pos_bits, infos)
+            bp.write(t[0], df_bits, infos)
+        bp.write(post_end, post_bits, infos)
+        bp.write(pos_end, pos_bits, infos)
+        bp.flush(infos)
+    return (len(metas).to_bytes(8, "little") + len(term_infos).to_bytes(8, "little")
+            + bytes(metas) + bytes(infos))
+
+
 # ----------------------------------------------------------------------------- queries
 class QuerySpec:
     """Keeps the ctypes arrays alive for one to_query."""

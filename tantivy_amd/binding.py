@@ -59,7 +59,9 @@ EXPORTS = [
     "tqh_last_error", "tqh_searcher_new", "tqh_searcher_free", "tqh_searcher_add_segment",
     "tqh_prepare_batch", "tqh_search_prepared", "tqh_collect_segment_prepared",
     "tqh_collect_segment_prepared_device", "tqh_searcher_add_remote_stats",
-    "tqh_bm25_for_terms", "tqh_segment_raw", "tqh_term_handle",
+    "tqh_bm25_for_terms", "tqh_segment_raw", "tqh_term_handle", "tqh_term_dictionary_values",
+    "tqh_term_info_store_open", "tqh_term_info_store_free", "tqh_term_info_store_num_terms",
+    "tqh_term_info_store_get", "tqh_term_info_store_write", "tqh_searcher_add_segment_with_store",
 ]
 
 
@@ -125,6 +127,17 @@ def lib():
     L.tqh_segment_raw.argtypes = [vp, C.c_uint32]
     L.tqh_term_handle.restype = C.c_uint32
     L.tqh_term_handle.argtypes = [vp, C.c_uint32, C.c_uint32]
+    L.tqh_term_dictionary_values.argtypes = [vp, C.c_size_t, u64p, u64p]
+    L.tqh_term_info_store_open.argtypes = [vp, C.c_size_t, C.POINTER(vp)]
+    L.tqh_term_info_store_free.argtypes = [vp]
+    L.tqh_term_info_store_free.restype = None
+    L.tqh_term_info_store_num_terms.argtypes = [vp]
+    L.tqh_term_info_store_num_terms.restype = C.c_uint64
+    L.tqh_term_info_store_get.argtypes = [vp, vp, C.c_uint32, C.POINTER(TqhTermInfo)]
+    L.tqh_term_info_store_write.argtypes = [C.POINTER(TqhTermInfo), C.c_uint32, vp, C.c_uint64, u64p]
+    L.tqh_searcher_add_segment_with_store.argtypes = [vp, C.c_int, C.c_uint32, C.c_uint8, vp,
+                                                      C.c_size_t, vp, C.c_size_t, vp, C.c_size_t,
+                                                      vp, C.c_size_t]
     _lib = L
     return L
 
@@ -154,6 +167,55 @@ def bm25_for_terms(doc_freqs, total_num_docs, total_num_tokens, boost=1.0):
     _check(lib().tqh_bm25_for_terms(dfs, len(doc_freqs), int(total_num_docs), int(total_num_tokens),
                                     C.c_float(boost), C.byref(w), _f32(cache)), host=True)
     return float(w.value), cache
+
+
+def term_dictionary_values(field_file):
+    """(offset, length) of the TermInfoStore inside a field's term dictionary file."""
+    b = np.frombuffer(bytes(field_file), dtype=np.uint8)
+    off, ln = C.c_uint64(), C.c_uint64()
+    _check(lib().tqh_term_dictionary_values(b.ctypes.data, b.size, C.byref(off), C.byref(ln)), host=True)
+    return int(off.value), int(ln.value)
+
+
+class TermInfoStore:
+    """Host-side TermInfoStore (tantivy_amd/host/term_info_store.hpp)."""
+
+    def __init__(self, store_bytes):
+        b = np.frombuffer(bytes(store_bytes), dtype=np.uint8)
+        self._h = C.c_void_p()
+        _check(lib().tqh_term_info_store_open(b.ctypes.data, b.size, C.byref(self._h)), host=True)
+
+    def num_terms(self):
+        return int(lib().tqh_term_info_store_num_terms(self._h))
+
+    def get(self, ords):
+        """[(doc_freq, postings_start, postings_end, positions_start, positions_end), ...]"""
+        o = np.ascontiguousarray(ords, np.uint64)
+        out = (TqhTermInfo * max(1, o.size))()
+        _check(lib().tqh_term_info_store_get(self._h, o.ctypes.data, o.size, out), host=True)
+        return [(t.doc_freq, t.postings_start, t.postings_end, t.positions_start, t.positions_end)
+                for t in out[: o.size]]
+
+    def close(self):
+        if self._h:
+            lib().tqh_term_info_store_free(self._h)
+            self._h = None
+
+    @staticmethod
+    def serialize(term_infos):
+        """TermInfoStoreWriter over (doc_freq, ps, pe, qs, qe) tuples in ordinal order."""
+        n = len(term_infos)
+        tis = (TqhTermInfo * max(1, n))()
+        for i, t in enumerate(term_infos):
+            tis[i] = TqhTermInfo(i, *[int(x) for x in t])
+        need = C.c_uint64()
+        out = np.zeros(64 + 48 * n, np.uint8)
+        rc = lib().tqh_term_info_store_write(tis, n, out.ctypes.data, out.size, C.byref(need))
+        if rc != 0 and need.value > out.size:
+            out = np.zeros(need.value, np.uint8)
+            rc = lib().tqh_term_info_store_write(tis, n, out.ctypes.data, out.size, C.byref(need))
+        _check(rc, host=True)
+        return out[: need.value].tobytes()
 
 
 class Encoder:
@@ -247,13 +309,24 @@ class DeviceIndex:
         for i, seg in enumerate(segments):
             self.add_segment(seg, devs[i % len(devs)])
 
-    def add_segment(self, seg, device=0):
+    def add_segment(self, seg, device=0, term_info_store=None):
+        """term_info_store: the bytes of the segment's TermInfoStore; then term ids are term
+        ordinals and seg.terms is not consulted (TermInfos are decoded by the library)."""
         L = lib()
         idx = np.ascontiguousarray(seg.idx[: seg.idx_len] if hasattr(seg, "idx_len") else seg.idx,
                                    dtype=np.uint8)
         pos_len = getattr(seg, "pos_len", len(seg.pos) if seg.pos is not None else 0)
         pos = np.ascontiguousarray(seg.pos[:pos_len], dtype=np.uint8) if pos_len else None
         fn = None if seg.fieldnorm is None else np.ascontiguousarray(seg.fieldnorm, dtype=np.uint8)
+        if term_info_store is not None:
+            st = np.frombuffer(bytes(term_info_store), dtype=np.uint8)
+            _check(L.tqh_searcher_add_segment_with_store(
+                self._s, int(device), int(seg.max_doc), int(seg.record_option),
+                idx.ctypes.data, idx.size, pos.ctypes.data if pos is not None else None,
+                pos.size if pos is not None else 0, fn.ctypes.data if fn is not None else None,
+                fn.size if fn is not None else 0, st.ctypes.data, st.size), host=True)
+            self.n_segments += 1
+            return
         n = len(seg.terms)
         tis = (TqhTermInfo * max(1, n))()
         for i, t in enumerate(seg.terms):

@@ -13,12 +13,14 @@ SOURCES = [
     os.path.join(HERE, "csrc", "tq_api.cpp"),
     os.path.join(HERE, "host", "searcher.cpp"),
     os.path.join(HERE, "host", "host_capi.cpp"),
+    os.path.join(HERE, "host", "term_info_store.cpp"),
 ]
 HEADERS = [
     os.path.join(HERE, "csrc", "tq_device.h"),
     os.path.join(HERE, "csrc", "tq_launch.h"),
     os.path.join(HERE, "host", "searcher.hpp"),
     os.path.join(HERE, "host", "bm25.hpp"),
+    os.path.join(HERE, "host", "term_info_store.hpp"),
     os.path.join(os.path.dirname(HERE), "include", "tantivy_amd.h"),
     os.path.join(os.path.dirname(HERE), "include", "tantivy_amd_host.h"),
 ]

@@ -7,6 +7,7 @@
 #include <vector>
 
 #include "searcher.hpp"
+#include "term_info_store.hpp"
 
 using namespace tantivy_amd;
 
@@ -88,6 +89,25 @@ int tqh_searcher_add_segment(tqh_searcher *s, int device, uint32_t max_doc, uint
       ti.positions_end = terms[i].positions_end;
       seg->add_term(terms[i].term_id, ti);
     }
+    s->segments.push_back(seg);
+    s->searcher.reset(new Searcher(s->segments));
+  });
+}
+
+// A segment whose term ids are the term ordinals of its TermInfoStore (the value half of the
+// field's term dictionary file): no per-term TermInfo crosses the boundary.
+int tqh_searcher_add_segment_with_store(tqh_searcher *s, int device, uint32_t max_doc,
+                                        uint8_t record_option, const uint8_t *idx, size_t idx_len,
+                                        const uint8_t *pos, size_t pos_len,
+                                        const uint8_t *fieldnorm, size_t fn_len,
+                                        const uint8_t *store, size_t store_len) {
+  return guard([&] {
+    if (!s) throw TantivyError(TantivyError::InvalidArgument, "null searcher");
+    auto st = std::make_shared<TermInfoStore>(TermInfoStore::open(store, store_len));
+    auto seg = std::make_shared<SegmentReader>(s->ctx, device, (uint32_t)s->segments.size(),
+                                               max_doc, record_option, idx, idx_len, pos, pos_len,
+                                               fieldnorm, fn_len);
+    seg->set_term_info_store(st);
     s->segments.push_back(seg);
     s->searcher.reset(new Searcher(s->segments));
   });
@@ -229,6 +249,70 @@ uint32_t tqh_term_handle(tqh_searcher *s, uint32_t segment_ord, uint32_t term_id
   uint32_t h = TQ_TERM_ABSENT;
   guard([&] { h = s->segments[segment_ord]->term_handle(term_id); });
   return h;
+}
+
+// ---- TermInfoStore (src/termdict/fst_termdict/term_info_store.rs)
+struct tqh_term_info_store {
+  TermInfoStore store;
+};
+int tqh_term_dictionary_values(const uint8_t *file, size_t len, uint64_t *store_off,
+                               uint64_t *store_len) {
+  return guard([&] {
+    if (!store_off || !store_len) throw TantivyError(TantivyError::InvalidArgument, "null argument");
+    size_t o = 0, l = 0;
+    term_dictionary_values(file, len, &o, &l);
+    *store_off = o;
+    *store_len = l;
+  });
+}
+int tqh_term_info_store_open(const uint8_t *bytes, size_t len, tqh_term_info_store **out) {
+  return guard([&] {
+    if (!out) throw TantivyError(TantivyError::InvalidArgument, "null argument");
+    *out = new tqh_term_info_store{TermInfoStore::open(bytes, len)};
+  });
+}
+void tqh_term_info_store_free(tqh_term_info_store *s) { delete s; }
+uint64_t tqh_term_info_store_num_terms(const tqh_term_info_store *s) {
+  return s ? s->store.num_terms() : 0;
+}
+int tqh_term_info_store_get(const tqh_term_info_store *s, const uint64_t *term_ords, uint32_t n,
+                            tqh_term_info *out) {
+  return guard([&] {
+    if (!s || (n && (!term_ords || !out))) throw TantivyError(TantivyError::InvalidArgument, "null argument");
+    for (uint32_t i = 0; i < n; ++i) {
+      const TermInfo ti = s->store.get(term_ords[i]);
+      out[i].term_id = (uint32_t)term_ords[i];
+      out[i].doc_freq = ti.doc_freq;
+      out[i].postings_start = ti.postings_start;
+      out[i].postings_end = ti.postings_end;
+      out[i].positions_start = ti.positions_start;
+      out[i].positions_end = ti.positions_end;
+    }
+  });
+}
+// TermInfoStoreWriter over term infos in ordinal order; *out_len = bytes needed
+int tqh_term_info_store_write(const tqh_term_info *infos, uint32_t n, uint8_t *out, uint64_t out_cap,
+                              uint64_t *out_len) {
+  return guard([&] {
+    if (!out_len || (n && !infos)) throw TantivyError(TantivyError::InvalidArgument, "null argument");
+    TermInfoStoreWriter w;
+    for (uint32_t i = 0; i < n; ++i) {
+      TermInfo ti;
+      ti.doc_freq = infos[i].doc_freq;
+      ti.postings_start = infos[i].postings_start;
+      ti.postings_end = infos[i].postings_end;
+      ti.positions_start = infos[i].positions_start;
+      ti.positions_end = infos[i].positions_end;
+      if (ti.postings_end < ti.postings_start || ti.positions_end < ti.positions_start)
+        throw TantivyError(TantivyError::InvalidArgument, "term info range ends before it starts");
+      w.write_term_info(ti);
+    }
+    std::vector<uint8_t> bytes;
+    w.serialize(bytes);
+    *out_len = bytes.size();
+    if (bytes.size() > out_cap) throw TantivyError(TantivyError::InvalidArgument, "output buffer too small");
+    if (!bytes.empty()) std::memcpy(out, bytes.data(), bytes.size());
+  });
 }
 
 }  // extern "C"

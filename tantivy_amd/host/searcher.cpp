@@ -1,6 +1,8 @@
 // searcher.cpp — see searcher.hpp.
 #include "searcher.hpp"
 
+#include "term_info_store.hpp"
+
 #include <algorithm>
 #include <cstring>
 
@@ -33,8 +35,13 @@ SegmentReader::SegmentReader(tq_ctx *ctx, int device, uint32_t segment_ord, uint
 SegmentReader::~SegmentReader() { tq_segment_free(seg_); }
 
 void SegmentReader::add_term(uint32_t term_id, const TermInfo &info) { terms_[term_id] = info; }
+void SegmentReader::set_term_info_store(std::shared_ptr<const TermInfoStore> store) {
+  store_ = std::move(store);
+}
 const TermInfo *SegmentReader::get_term_info(uint32_t term_id) const {
   auto it = terms_.find(term_id);
+  if (it == terms_.end() && store_ && term_id < store_->num_terms())
+    it = terms_.emplace(term_id, store_->get(term_id)).first;
   if (it == terms_.end() || it->second.doc_freq == 0) return nullptr;
   return &it->second;
 }

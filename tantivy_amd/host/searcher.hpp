@@ -55,6 +55,9 @@ class SegmentReader {
   SegmentReader &operator=(const SegmentReader &) = delete;
 
   void add_term(uint32_t term_id, const TermInfo &info);  // TermDictionary substitute
+  // the segment's TermInfoStore: term ids are term ordinals, TermInfos are decoded on first use
+  // (TermDictionary::term_info_from_ord, termdict.rs:185-188)
+  void set_term_info_store(std::shared_ptr<const class TermInfoStore> store);
   const TermInfo *get_term_info(uint32_t term_id) const;  // None => nullptr
   tq_term_handle term_handle(uint32_t term_id);            // prepares on first use
   uint32_t max_doc() const { return max_doc_; }
@@ -68,8 +71,9 @@ class SegmentReader {
   uint32_t segment_ord_, max_doc_;
   uint8_t record_option_;
   uint64_t total_num_tokens_ = 0;
-  std::unordered_map<uint32_t, TermInfo> terms_;
+  mutable std::unordered_map<uint32_t, TermInfo> terms_;
   std::unordered_map<uint32_t, tq_term_handle> handles_;
+  std::shared_ptr<const class TermInfoStore> store_;
 };
 
 enum class Occur { Should, Must, MustNot };  // src/query/occur.rs

@@ -54,6 +54,31 @@ def main():
         print(k, [len(l) for l in v["posting_lists"]], len(v["fieldnorms"]))
     dst = os.path.join(os.path.dirname(os.path.abspath(__file__)), "block_wand_regressions.json")
     json.dump(out, open(dst, "w"))
+    compat_index()
+
+
+def compat_index():
+    """The reference's backward-compatibility fixtures (tests/compat_tests_data/index_v6, index_v7:
+    one-document indexes written by released tantivy versions): file bytes as hex, a few hundred
+    bytes each.  They pin the file framing, the TermInfoStore layout and real BitPacker/vint
+    posting bytes for the oracle (tests/test_oracle_kat.py)."""
+    out = {}
+    for ver in ("index_v6", "index_v7"):
+        d = os.path.join(REF, "tests", "compat_tests_data", ver)
+        meta = json.load(open(os.path.join(d, "meta.json")))
+        seg = meta["segments"][0]["segment_id"].replace("-", "")
+        files = {}
+        for ext in ("idx", "pos", "term", "fieldnorm"):
+            files[ext] = open(os.path.join(d, seg + "." + ext), "rb").read().hex()
+        out[ver] = {"max_doc": meta["segments"][0]["max_doc"],
+                    "schema": [{"name": f["name"], "type": f["type"],
+                                "record": f["options"].get("indexing", {}).get("record")
+                                if isinstance(f["options"].get("indexing"), dict) else None}
+                               for f in meta["schema"]],
+                    "files": files}
+    dst = os.path.join(os.path.dirname(os.path.abspath(__file__)), "compat_index.json")
+    json.dump(out, open(dst, "w"), indent=1)
+    print("compat_index:", {k: {e: len(v) // 2 for e, v in o["files"].items()} for k, o in out.items()})
 
 
 if __name__ == "__main__":

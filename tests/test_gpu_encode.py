@@ -131,3 +131,57 @@ def test_encode_errors(ta, enc):
     body, _ = enc.encode_postings(ts, docs, None, None, 0, 0.0, O.BASIC, out_cap=16)
     want, _ = O.serialize_postings_batch(ts, docs, None, None, 0, 0.0, O.BASIC)
     assert np.array_equal(body, want)
+
+
+def test_segment_built_on_the_device_and_opened_by_ordinal(ta, enc):
+    """Segment finalisation without the CPU serializer: postings + positions encoded on the
+    device, their TermInfo ranges written by the product's TermInfoStoreWriter, the segment opened
+    through that store (term id = term ordinal) — and it answers like the oracle's segment."""
+    seg = O.synth_segment(60_000, n_terms=20, with_positions=True, phrase_terms=8)
+    starts, docs, tfs, pstarts, deltas = [0], [], [], [0], []
+    for t in range(len(seg.terms)):
+        d, f = O.decode_postings(seg, t)
+        docs.append(d)
+        tfs.append(f)
+        starts.append(starts[-1] + len(d))
+        ps, _ = O.decode_positions(seg, t, int(f.sum()))
+        dl = np.diff(ps.astype(np.int64), prepend=0)
+        first = np.cumsum(f.astype(np.int64)) - f
+        dl[first] = ps[first]
+        deltas.append(dl.astype(np.uint32))
+        pstarts.append(pstarts[-1] + len(dl))
+    avg = float(np.float32(seg.total_num_tokens) / np.float32(seg.max_doc))
+    body, ots = enc.encode_postings(np.array(starts, np.uint64), np.concatenate(docs),
+                                    np.concatenate(tfs), seg.fieldnorm, seg.max_doc, avg,
+                                    O.WITH_FREQS_AND_POSITIONS)
+    pos, pts = enc.encode_positions(np.array(pstarts, np.uint64), np.concatenate(deltas))
+    infos = [(len(docs[t]), int(ots[t]), int(ots[t + 1]), int(pts[t]), int(pts[t + 1]))
+             for t in range(len(seg.terms))]
+    store = ta.TermInfoStore.serialize(infos)
+    assert store == O.term_info_store_serialize(infos)
+
+    class Built:
+        max_doc = seg.max_doc
+        record_option = O.WITH_FREQS_AND_POSITIONS
+        idx = np.concatenate([np.frombuffer(int(seg.total_num_tokens).to_bytes(8, "little"), np.uint8), body])
+        fieldnorm = seg.fieldnorm
+        terms = []
+
+    Built.pos = pos
+    dev = ta.DeviceIndex([])
+    try:
+        dev.add_segment(Built, 0, term_info_store=store)
+        queries = [(O.MODE_AND, [0, 1]), (O.MODE_AND, [3, 7, 11]), (O.MODE_OR, [2, 5, 19]),
+                   (O.MODE_PHRASE, [0, 1, 2]), (O.MODE_OR, [17]), (O.MODE_AND, [4, 25])]  # 25: no such ordinal
+        scores, _, dd, counts = dev.search(queries, 10)
+        for i, (mode, terms) in enumerate(queries):
+            if 25 in terms:
+                assert counts[i] == 0
+                continue
+            want = O.search(seg, terms, mode, 10, pruned=False)
+            got = [(float(scores[i, j]), int(dd[i, j])) for j in range(int(counts[i]))]
+            assert [d for _, d in got] == [d for _, d in want]
+            for (gs, _), (ws, _) in zip(got, want):
+                assert abs(gs - ws) <= 1e-5 * abs(ws)
+    finally:
+        dev.close()
