@@ -111,6 +111,9 @@ def main():
     t_gen = time.time() - t0
     dev = tantivy_amd.DeviceIndex([seg], devices=[local_rank])
     dev.set_option("timing", 1)
+    for name in ("dense_ratio", "dense_budget_x"):  # experiments: TQ_OPT_dense_ratio=...
+        if os.environ.get("TQ_OPT_" + name):
+            dev.set_option(name, int(os.environ["TQ_OPT_" + name]))
     pruned_mode = not args.exhaustive
     my_stats = (seg.max_doc, seg.total_num_tokens, [t.doc_freq for t in seg.terms])
     all_stats = [my_stats]

@@ -1442,6 +1442,8 @@ int tq_set_option(tq_segment *s, const char *name, int64_t value) {
     s->opt.or_windows = value < 0 ? -1 : (value != 0);
   else if (!strcmp(name, "dense_ratio") && value >= 1)  // affects terms prepared afterwards
     s->opt.dense_ratio = (int)value;
+  else if (!strcmp(name, "dense_budget_x") && value >= 0)
+    s->opt.dense_budget_x = (int)value;
   else if (!strcmp(name, "dense"))  // affects terms prepared afterwards
     s->opt.dense = value != 0;
   else
