@@ -235,7 +235,7 @@ int tq_last_batch_stats(tq_segment *seg, tq_batch_stats *out);
  *        "timing" (0/1: record HIP events per batch),
  *        "dense" (0/1, default 1: tq_term_prepare also builds a bitmap + rank directory for lists
  *        with doc_freq >= max_doc/dense_ratio, while all bitmaps stay below 4x the segment's
- *        bytes), "dense_ratio" (default 64), "use_dense" (0/1, default 1: the AND kernel may use
+ *        bytes), "dense_ratio" (default 128), "use_dense" (0/1, default 1: the AND kernel may use
  *        them),
  *        "or_windows" (-1/0/1, default -1 = auto: unions run window-parallel when exhaustive and
  *        candidate-driven when pruning; 0 / 1 force one kernel),

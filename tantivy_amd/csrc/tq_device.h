@@ -10,7 +10,7 @@
 // Tunables of the scan kernels (see DESIGN.md "AND kernel").
 #define TQD_WAVES_PER_WG 4    // independent wavefronts per workgroup
 #define TQD_AND_TILE 64       // leader-list blocks per AND tile (one lane each in the pre-filter)
-#define TQD_DENSE_RATIO 64    // default: lists with doc_freq >= max_doc/64 also get a bitmap + rank directory
+#define TQD_DENSE_RATIO 128   // default: lists with doc_freq >= max_doc/128 also get a bitmap + rank directory
 #define TQD_THR_SLOTS 64      // shared threshold slots per query (pruned mode)
 #define TQD_OR_WINDOW 4096    // docs per OR tile (one workgroup)
 

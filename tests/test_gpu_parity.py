@@ -819,3 +819,33 @@ def test_full_size_or_top100(big):
         dev.set_option("exhaustive", 1)
     assert got2 == got
     assert pruned < full, (pruned, full)
+
+
+def test_full_size_boolean(ta, big):
+    """The reference's union_intersection shapes (benches/and_or_queries.rs:150-153) and a mixed
+    `+a b -c` on the 10M-doc segment: against the oracle's restatement for a few queries, and
+    pruned == exhaustive on a Zipf stream."""
+    seg, dev = big
+    M, S, N = O.MUST, O.SHOULD, O.MUST_NOT
+    qs = [([40, 3, 9], [M, M, M], [0, 1, 1], 0), ([2, 30, 7, 100], [M, M, M, M], [0, 0, 1, 1], 0),
+          ([5, 60, 1], [M, S, N], None, 0), ([200, 201, 0], [M, S, S], None, 1),
+          ([12, 13, 14], [S, S, S], None, 2)]
+    queries = [(ta.MODE_BOOL, t, o, c, m) for t, o, c, m in qs]
+    for ex in (1, 0):
+        dev.set_option("exhaustive", ex)
+        got = _device_topk(dev, queries, 10)
+        for (t, o, c, m), g in zip(qs, got):
+            _assert_bool_hits(g, _bool_want(seg, t, o, (), c, m), 10, o, c)
+    ids = O.zipf_queries(200, 4, 256, seed=99)
+    shapes = [(3, [M, M, M], [0, 1, 1]), (4, [M, M, M, M], [0, 0, 1, 1]), (3, [M, S, N], None)]
+    stream = []
+    for i, q in enumerate(ids):
+        nt, occ, cof = shapes[i % 3]
+        stream.append((ta.MODE_BOOL, q.tolist()[:nt], occ, cof, 0))
+    dev.set_option("exhaustive", 1)
+    a = dev.search(stream, 10)
+    dev.set_option("exhaustive", 0)
+    b = dev.search(stream, 10)
+    dev.set_option("exhaustive", 1)
+    for x, y in zip(a, b):
+        assert np.array_equal(x, y)
