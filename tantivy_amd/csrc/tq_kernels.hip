@@ -1331,7 +1331,7 @@ struct UnionLds {  // per wavefront
 };
 
 template <int KPL, bool PRUNE, bool BOOL>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_num_sgpr(96))) void union_kernel(TqkScanParams p) {
+__device__ __forceinline__ void union_body(const TqkScanParams &p) {
   constexpr bool USE_DPP = true;
   __shared__ UnionLds L;
   const int lane = (int)__lane_id();
@@ -1681,6 +1681,17 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_num_sgpr(96))) void union
         n_q = 0;
   }
   if (lane == 0 && n_matches) atomicAdd(sload(&p.sinks->match_counter), (unsigned long long)n_matches);
+}
+
+// k <= 128 (KPL <= 2) instantiations are compiled for 6 waves/SIMD (<= 84 registers) instead of 4
+template <int KPL, bool PRUNE, bool BOOL>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_num_sgpr(96))) void union_kernel(TqkScanParams p) {
+  union_body<KPL, PRUNE, BOOL>(p);
+}
+template <int KPL, bool PRUNE, bool BOOL>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_num_sgpr(96), amdgpu_waves_per_eu(6, 8))) void
+union_kernel_small(TqkScanParams p) {
+  union_body<KPL, PRUNE, BOOL>(p);
 }
 
 // positions: raw deltas of a whole term (PositionReader::read over everything).  pos_blk[pb] =
@@ -2167,16 +2178,24 @@ static void launch_or_t(const TqkScanParams &p, bool /*dpp*/, dim3 grid, dim3 bl
     else
       or_kernel<KPL, true><<<grid, block, 0, st>>>(p);
   } else {  // candidate-driven form: one wavefront per chunk
+#define TQ_UNION(PR, BO)                                                  \
+  do {                                                                    \
+    if (KPL <= 2)                                                         \
+      union_kernel_small<KPL, PR, BO><<<grid, dim3(64), 0, st>>>(p);      \
+    else                                                                  \
+      union_kernel<KPL, PR, BO><<<grid, dim3(64), 0, st>>>(p);            \
+  } while (0)
     if (p.boolean) {
       if (p.exhaustive)
-        union_kernel<KPL, false, true><<<grid, dim3(64), 0, st>>>(p);
+        TQ_UNION(false, true);
       else
-        union_kernel<KPL, true, true><<<grid, dim3(64), 0, st>>>(p);
+        TQ_UNION(true, true);
     } else if (p.exhaustive) {
-      union_kernel<KPL, false, false><<<grid, dim3(64), 0, st>>>(p);
+      TQ_UNION(false, false);
     } else {
-      union_kernel<KPL, true, false><<<grid, dim3(64), 0, st>>>(p);
+      TQ_UNION(true, false);
     }
+#undef TQ_UNION
   }
 }
 
