@@ -223,9 +223,7 @@ def main():
         for i in list(range(0, n_q, max(1, n_q // 16)))[:16]:
             mode, terms = queries[i][0], queries[i][1]
             if args.workload == "bool":
-                d, sc = O.bool_match_all(seg, terms, queries[i][2], queries[i][3], queries[i][4])
-                want = sorted(((float(x), int(doc)) for doc, x in zip(d.tolist(), sc.tolist())),
-                              key=lambda h: (-h[0], h[1]))[:k]
+                want = O.bool_search(seg, terms, queries[i][2], k, queries[i][3], queries[i][4])
             else:
                 want = O.search(seg, terms, mode, k, pruned=False)
             got = [(float(final[0][i, j]), int(final[2][i, j])) for j in range(int(final[3][i]))]
@@ -236,27 +234,33 @@ def main():
 
     # ---- CPU baseline: the oracle's restatement of tantivy's block-WAND executors
     cpu = None
-    if world == 1 and not args.no_cpu_baseline and args.workload != "bool":
+    if world == 1 and not args.no_cpu_baseline:
         cores = os.cpu_count() or 1
         specs, done, wall_total = [], 0, 0.0
         chunk = max(64, cores * 16)
+        def spec_of(q):
+            if args.workload == "bool":  # the restated generic scorer tree (no block-max executor)
+                return O.bool_spec(seg, q[1], q[2], q[3], q[4], k)
+            return O.QuerySpec(seg, q[1], O.default_weights(seg, q[1], q[0]), q[0], k,
+                               list(range(len(q[1]))) if q[0] == O.MODE_PHRASE else None)
+
         while wall_total < args.cpu_seconds and done < n_q:
             part = queries[done:done + chunk]
-            sp = [O.QuerySpec(seg, q[1], O.default_weights(seg, q[1], q[0]), q[0], k,
-                              list(range(len(q[1]))) if q[0] == O.MODE_PHRASE else None)
-                  for q in part]
+            sp = [spec_of(q) for q in part]
             wall, _, _ = O.baseline_run(seg, sp, cores)
             wall_total += wall
             done += len(part)
-        sp1 = [O.QuerySpec(seg, q[1], O.default_weights(seg, q[1], q[0]), q[0], k,
-                           list(range(len(q[1]))) if q[0] == O.MODE_PHRASE else None)
-               for q in queries[:48]]
+        sp1 = [spec_of(q) for q in queries[:48]]
         _, lat1, _ = O.baseline_run(seg, sp1, 1)
         cpu = {"value": round(done / wall_total, 2), "unit": "queries/s", "cores": cores,
                "kind": "port",
                "sample": "first %d queries of the same stream, query-level parallelism on %d "
-                         "threads, %.1f s; C restatement of tantivy's block_wand_intersection/"
-                         "block_wand (oracle/), not the tantivy binary" % (done, cores, wall_total),
+                         "threads, %.1f s; C restatement of tantivy's %s (oracle/), not the tantivy "
+                         "binary" % (done, cores, wall_total,
+                                     "generic scorer tree (Intersection / BufferedUnionScorer / "
+                                     "RequiredOptionalScorer / Exclude under for_each_pruning_scorer)"
+                                     if args.workload == "bool" else
+                                     "block_wand_intersection/block_wand"),
                "p50_latency_ms_1core": round(float(np.median(lat1)) * 1e3, 3)}
 
     # HBM traffic per launch from the committed rocprofv3 PMC run of this same command

@@ -15,7 +15,7 @@ _LIB_PATH = os.path.join(_HERE, "liboracle.so")
 TERMINATED = 0x7FFFFFFF
 BLOCK_LEN = 128
 BASIC, WITH_FREQS, WITH_FREQS_AND_POSITIONS = 0, 1, 2
-MODE_AND, MODE_OR, MODE_PHRASE = 0, 1, 2
+MODE_AND, MODE_OR, MODE_PHRASE, MODE_BOOL = 0, 1, 2, 3
 
 
 def build(force=False):
@@ -67,6 +67,9 @@ class Query(C.Structure):
         ("phrase_offsets", C.POINTER(C.c_uint32)),
         ("mode", C.c_int),
         ("k", C.c_uint32),
+        ("occurs", C.POINTER(C.c_uint8)),
+        ("clause_of", C.POINTER(C.c_uint8)),
+        ("min_should_match", C.c_uint32),
     ]
 
 
@@ -617,7 +620,8 @@ def term_info_store_serialize(term_infos):
 class QuerySpec:
     """Keeps the ctypes arrays alive for one to_query."""
 
-    def __init__(self, seg, term_ids, weights, mode, k, phrase_offsets=None):
+    def __init__(self, seg, term_ids, weights, mode, k, phrase_offsets=None, occurs=None,
+                 clause_of=None, min_should_match=0):
         n = len(term_ids)
         self.terms = (TermInfo * n)(*[seg.terms[t] for t in term_ids])
         self.weights = (Bm25 * len(weights))(*weights)
@@ -631,6 +635,13 @@ class QuerySpec:
             q.phrase_offsets = C.cast(self.offsets, C.POINTER(C.c_uint32))
         q.mode = mode
         q.k = k
+        if occurs is not None:  # MODE_BOOL
+            self.occurs = (C.c_uint8 * n)(*[int(o) for o in occurs])
+            q.occurs = C.cast(self.occurs, C.POINTER(C.c_uint8))
+            if clause_of is not None:
+                self.clause_of = (C.c_uint8 * n)(*[int(c) for c in clause_of])
+                q.clause_of = C.cast(self.clause_of, C.POINTER(C.c_uint8))
+            q.min_should_match = int(min_should_match)
         self.q = q
 
 
@@ -776,6 +787,33 @@ def bool_match_all(seg, term_ids, occurs, clause_of=None, min_should_match=0):
         match &= ~hit
     docs = np.nonzero(match)[0]
     return docs.astype(np.uint32), score[docs]
+
+
+def bool_spec(seg, term_ids, occurs, clause_of=None, min_should_match=0, k=1):
+    """QuerySpec of a boolean query for the C executor restatement (generic scorer tree)."""
+    ws = default_weights(seg, term_ids, MODE_OR)
+    return QuerySpec(seg, term_ids, ws, MODE_BOOL, k, None, occurs, clause_of, min_should_match)
+
+
+def bool_search(seg, term_ids, occurs, k, clause_of=None, min_should_match=0):
+    """Top-k through the restated scorer tree (Intersection / BufferedUnionScorer / Disjunction /
+    RequiredOptionalScorer / Exclude under for_each_pruning_scorer): [(score, doc)] sorted."""
+    spec = bool_spec(seg, term_ids, occurs, clause_of, min_should_match, k)
+    out = (Hit * max(1, k))()
+    n = lib().to_search_exhaustive(C.byref(seg.view), C.byref(spec.q), out)
+    lib().to_sort_hits(out, n)
+    return _hits(out, n)
+
+
+def bool_match_all_c(seg, term_ids, occurs, clause_of=None, min_should_match=0):
+    """Every match of the restated scorer tree: (docs ascending, f32 scores)."""
+    spec = bool_spec(seg, term_ids, occurs, clause_of, min_should_match)
+    cap = max(1, seg.max_doc)
+    docs = np.zeros(cap, np.uint32)
+    scores = np.zeros(cap, np.float32)
+    n = lib().to_match_all(C.byref(seg.view), C.byref(spec.q), _u32(docs),
+                           scores.ctypes.data_as(C.POINTER(C.c_float)), cap)
+    return docs[:n], scores[:n]
 
 
 def decode_postings(seg, term_id):

@@ -268,7 +268,7 @@ typedef struct {
   uint64_t total_num_tokens;
 } to_segment_view;
 
-enum { TO_MODE_AND = 0, TO_MODE_OR = 1, TO_MODE_PHRASE = 2 };
+enum { TO_MODE_AND = 0, TO_MODE_OR = 1, TO_MODE_PHRASE = 2, TO_MODE_BOOL = 3 };
 
 /* A query against one segment.  weights[i]/tf cache follow Bm25Weight semantics; for a phrase
  * there is a single weight (weights[0]) built with idf summed over the terms. */
@@ -279,6 +279,11 @@ typedef struct {
   const uint32_t *phrase_offsets; /* phrase only */
   int mode;
   uint32_t k;
+  /* TO_MODE_BOOL: Occur per term (0 Should, 1 Must, 2 MustNot), clause index per term (terms
+   * sharing one form a nested union; NULL = one clause per term), minimum_number_should_match */
+  const uint8_t *occurs;
+  const uint8_t *clause_of;
+  uint32_t min_should_match;
 } to_query;
 
 /* Faithful executors (what the reference runs for TopDocs order_by_score):

@@ -636,8 +636,13 @@ static int open_scorers(const to_segment_view *seg, const to_query *q, term_scor
   }
   return 0;
 }
+static void run_bool(const to_segment_view *seg, const to_query *q, match_fn fn, void *ctx);
 static void run_exhaustive(const to_segment_view *seg, const to_query *q, match_fn fn,
                            void *ctx) {
+  if (q->mode == TO_MODE_BOOL) {
+    run_bool(seg, q, fn, ctx);
+    return;
+  }
   term_scorer *store = (term_scorer *)malloc(sizeof(term_scorer) * (q->n_terms ? q->n_terms : 1));
   term_scorer *ptrs[TO_MAX_TERMS];
   if (q->mode == TO_MODE_AND) {
@@ -696,6 +701,8 @@ size_t to_match_all(const to_segment_view *seg, const to_query *q, uint32_t *doc
   return c.n;
 }
 size_t to_search_pruned(const to_segment_view *seg, const to_query *q, to_hit *out) {
+  /* the generic scorer tree has no block-max executor: for_each_pruning_scorer scores every doc */
+  if (q->mode == TO_MODE_BOOL) return to_search_exhaustive(seg, q, out);
   to_topn_heap heap;
   to_topn_init(&heap, q->k);
   pruning_cb cb = {&heap};
@@ -794,3 +801,583 @@ float to_ts_score(void *t) { return ts_score((term_scorer *)t); }
 float to_ts_block_max_score(void *t) { return ts_block_max_score((term_scorer *)t); }
 float to_ts_max_score(void *t) { return ((term_scorer *)t)->max_score; }
 uint32_t to_ts_last_doc_in_block(void *t) { return ts_last_doc_in_block((term_scorer *)t); }
+
+/* ================================================================== generic scorer tree
+ * What BooleanWeight::complex_scorer builds when the query is not a plain term intersection /
+ * union (boolean_weight.rs:236-431): Intersection (intersection.rs:20-56,120-234),
+ * BufferedUnionScorer with SumCombiner (union/buffered_union.rs:63-316), Disjunction
+ * (disjunction.rs:85-170), RequiredOptionalScorer (reqopt_scorer.rs:36-99), Exclude
+ * (exclude.rs:31-115), driven by for_each_pruning_scorer (weight.rs:47-60).  Clauses are terms or
+ * unions of terms (the shapes the device path takes, include/tantivy_amd.h TQ_MODE_BOOL). */
+typedef struct gscorer gscorer;
+enum { GS_TERM, GS_UNION, GS_INTER, GS_REQOPT, GS_EXCLUDE, GS_DISJ, GS_EMPTY };
+#define GS_HORIZON 4096u
+struct gscorer {
+  int kind;
+  term_scorer *term;           /* GS_TERM */
+  gscorer **kids;              /* UNION: active docsets; INTER: left,right,others; DISJ: heap */
+  size_t n_kids;
+  /* union window */
+  uint64_t *bits;              /* 64 words */
+  float *acc;                  /* 4096 sums (SumCombiner) */
+  size_t bucket_idx;
+  uint32_t window_start, doc;
+  float score;
+  /* reqopt / exclude */
+  gscorer *req, *opt;
+  gscorer **excl;
+  size_t n_excl;
+  int has_cache;
+  float cache;
+  /* disjunction */
+  size_t min_match;
+  uint32_t *heap_doc;          /* ScorerWrapper::current_doc per kid */
+};
+static uint32_t gs_doc(gscorer *s);
+static uint32_t gs_advance(gscorer *s);
+static uint32_t gs_seek(gscorer *s, uint32_t target);
+static float gs_score(gscorer *s);
+/* SeekDangerResult: returns 1 = Found, else 0 with *lower = SeekLowerBound */
+static int gs_seek_danger(gscorer *s, uint32_t target, uint32_t *lower);
+
+static uint64_t gs_cost(gscorer *s) {
+  switch (s->kind) {
+    case GS_TERM: return s->term->sp.bp.doc_freq; /* SegmentPostings::size_hint = doc_freq */
+    case GS_UNION: { /* buffered_union.rs:326-328 */
+      uint64_t c = 0;
+      for (size_t i = 0; i < s->n_kids; i++) c += gs_cost(s->kids[i]);
+      return c;
+    }
+    case GS_INTER: return gs_cost(s->kids[0]); /* intersection.rs:227-232 */
+    case GS_REQOPT: return gs_cost(s->req);
+    case GS_EXCLUDE: return gs_cost(s->req); /* DocSet::cost default = size_hint of underlying */
+    case GS_DISJ: { /* disjunction.rs:149-155 */
+      uint64_t c = 0;
+      for (size_t i = 0; i < s->n_kids; i++) {
+        uint64_t k = gs_cost(s->kids[i]);
+        if (k > c) c = k;
+      }
+      return c;
+    }
+    default: return 0;
+  }
+}
+static int default_seek_danger(gscorer *s, uint32_t target, uint32_t *lower) {
+  /* docset.rs:90-111 */
+  if (target >= TO_TERMINATED) {
+    *lower = target;
+    return 0;
+  }
+  uint32_t doc = gs_doc(s);
+  if (doc < target) doc = gs_seek(s, target);
+  if (doc == target) return 1;
+  *lower = doc;
+  return 0;
+}
+static uint32_t default_seek(gscorer *s, uint32_t target) {
+  /* docset.rs: advance until >= target */
+  uint32_t doc = gs_doc(s);
+  while (doc < target) doc = gs_advance(s);
+  return doc;
+}
+
+/* ---- union */
+static void union_drain_refill(gscorer *u, uint32_t min_doc) {
+  /* refill() helper, buffered_union.rs:63-87, with unordered_drain_filter's swap_remove */
+  size_t i = 0;
+  while (i < u->n_kids) {
+    gscorer *sc = u->kids[i];
+    const uint32_t horizon = min_doc + GS_HORIZON;
+    int consumed = 0;
+    for (;;) {
+      uint32_t doc = gs_doc(sc);
+      if (doc >= horizon) break;
+      uint32_t delta = doc - min_doc;
+      u->bits[delta / 64] |= 1ull << (delta % 64);
+      u->acc[delta] += gs_score(sc);
+      if (gs_advance(sc) == TO_TERMINATED) {
+        consumed = 1;
+        break;
+      }
+    }
+    if (consumed) {
+      u->kids[i] = u->kids[u->n_kids - 1];
+      u->n_kids--;
+    } else {
+      i++;
+    }
+  }
+}
+static int union_refill(gscorer *u) { /* :118-137 */
+  if (u->n_kids == 0) return 0;
+  uint32_t min_doc = TO_TERMINATED;
+  for (size_t i = 0; i < u->n_kids; i++) {
+    uint32_t d = gs_doc(u->kids[i]);
+    if (d < min_doc) min_doc = d;
+  }
+  u->window_start = min_doc;
+  u->bucket_idx = 0;
+  u->doc = min_doc;
+  union_drain_refill(u, min_doc);
+  return 1;
+}
+static int union_advance_buffered(gscorer *u) { /* :139-155 */
+  while (u->bucket_idx < 64) {
+    uint64_t w = u->bits[u->bucket_idx];
+    if (w) {
+      uint32_t val = (uint32_t)__builtin_ctzll(w);
+      u->bits[u->bucket_idx] = w & (w - 1);
+      uint32_t delta = val + (uint32_t)u->bucket_idx * 64u;
+      u->doc = u->window_start + delta;
+      u->score = u->acc[delta];
+      u->acc[delta] = 0.0f;
+      return 1;
+    }
+    u->bucket_idx++;
+  }
+  return 0;
+}
+static uint32_t union_advance(gscorer *u) { /* :170-182 */
+  if (union_advance_buffered(u)) return u->doc;
+  if (!union_refill(u)) {
+    u->doc = TO_TERMINATED;
+    return TO_TERMINATED;
+  }
+  if (!union_advance_buffered(u)) return TO_TERMINATED;
+  return u->doc;
+}
+static uint32_t union_seek(gscorer *u, uint32_t target) { /* :226-275 */
+  if (u->doc >= target) return u->doc;
+  uint32_t gap = target - u->window_start;
+  if (gap < GS_HORIZON) {
+    size_t nb = gap / 64;
+    for (size_t b = u->bucket_idx; b < nb; b++) u->bits[b] = 0;
+    for (size_t k = u->bucket_idx * 64; k < nb * 64; k++) u->acc[k] = 0.0f;
+    u->bucket_idx = nb;
+    uint32_t doc = u->doc;
+    while (doc < target) doc = union_advance(u);
+    return doc;
+  }
+  memset(u->bits, 0, 64 * sizeof(uint64_t));
+  memset(u->acc, 0, GS_HORIZON * sizeof(float));
+  size_t i = 0;
+  while (i < u->n_kids) {
+    gscorer *sc = u->kids[i];
+    if (gs_doc(sc) < target) gs_seek(sc, target);
+    if (gs_doc(sc) == TO_TERMINATED) {
+      u->kids[i] = u->kids[u->n_kids - 1];
+      u->n_kids--;
+    } else {
+      i++;
+    }
+  }
+  if (!union_refill(u)) {
+    u->doc = TO_TERMINATED;
+    return TO_TERMINATED;
+  }
+  return union_advance(u);
+}
+static int union_seek_danger(gscorer *u, uint32_t target, uint32_t *lower) { /* :277-321 */
+  if (target >= TO_TERMINATED) {
+    *lower = TO_TERMINATED;
+    return 0;
+  }
+  if ((uint32_t)(target - u->window_start) < GS_HORIZON) {
+    uint32_t d = union_seek(u, target);
+    if (d == target) return 1;
+    *lower = d;
+    return 0;
+  }
+  int hit = 0;
+  uint32_t min_new = TO_TERMINATED;
+  for (size_t i = 0; i < u->n_kids; i++) {
+    uint32_t lb;
+    if (gs_seek_danger(u->kids[i], target, &lb)) {
+      hit = 1;
+      break;
+    }
+    if (lb < min_new) min_new = lb;
+  }
+  if (hit) {
+    union_seek(u, target);
+    return 1;
+  }
+  *lower = min_new;
+  return 0;
+}
+
+/* ---- intersection */
+static uint32_t go_to_first_doc(gscorer **ds, size_t n) { /* intersection.rs:66-79 */
+  uint32_t candidate = 0;
+  for (size_t i = 0; i < n; i++) {
+    uint32_t d = gs_doc(ds[i]);
+    if (d > candidate) candidate = d;
+  }
+  for (;;) {
+    int again = 0;
+    for (size_t i = 0; i < n; i++) {
+      uint32_t sd = gs_seek(ds[i], candidate);
+      if (sd > candidate) {
+        candidate = gs_doc(ds[i]);
+        again = 1;
+        break;
+      }
+    }
+    if (!again) return candidate;
+  }
+}
+static uint32_t inter_advance(gscorer *s) { /* :120-175 */
+  gscorer *left = s->kids[0], *right = s->kids[1];
+  uint32_t candidate = gs_doc(left) + 1;
+  while (candidate < TO_TERMINATED) {
+    candidate = gs_seek(left, candidate);
+    uint32_t lb;
+    if (!gs_seek_danger(right, candidate, &lb)) {
+      candidate = lb;
+      continue;
+    }
+    int restart = 0;
+    for (size_t i = 2; i < s->n_kids; i++) {
+      if (!gs_seek_danger(s->kids[i], candidate, &lb)) {
+        candidate = lb;
+        restart = 1;
+        break;
+      }
+    }
+    if (restart) continue;
+    return candidate;
+  }
+  gs_seek(left, TO_TERMINATED);
+  return TO_TERMINATED;
+}
+
+/* ---- disjunction: a binary heap on ScorerWrapper::current_doc (min first) */
+static void disj_sift_down(gscorer *s, size_t i) {
+  size_t n = s->n_kids;
+  for (;;) {
+    size_t l = 2 * i + 1, r = l + 1, m = i;
+    if (l < n && s->heap_doc[l] < s->heap_doc[m]) m = l;
+    if (r < n && s->heap_doc[r] < s->heap_doc[m]) m = r;
+    if (m == i) return;
+    gscorer *t = s->kids[i];
+    s->kids[i] = s->kids[m];
+    s->kids[m] = t;
+    uint32_t d = s->heap_doc[i];
+    s->heap_doc[i] = s->heap_doc[m];
+    s->heap_doc[m] = d;
+    i = m;
+  }
+}
+static uint32_t disj_advance(gscorer *s) { /* disjunction.rs:113-139 */
+  size_t matches = 0;
+  float sum = 0.0f;
+  /* the reference pops / pushes; here the root is updated in place (same visiting order up to
+   * ties, whose order the reference's BinaryHeap leaves unspecified) */
+  while (s->n_kids) {
+    uint32_t next = s->heap_doc[0];
+    if (next == TO_TERMINATED) { /* drop exhausted chains */
+      s->kids[0] = s->kids[s->n_kids - 1];
+      s->heap_doc[0] = s->heap_doc[s->n_kids - 1];
+      s->n_kids--;
+      if (s->n_kids) disj_sift_down(s, 0);
+      continue;
+    }
+    if (s->doc != next) {
+      if (matches >= s->min_match) {
+        s->score = sum;
+        return s->doc;
+      }
+      matches = 0;
+      s->doc = next;
+      sum = 0.0f;
+    }
+    matches++;
+    sum += gs_score(s->kids[0]);
+    s->heap_doc[0] = gs_advance(s->kids[0]);
+    disj_sift_down(s, 0);
+  }
+  if (matches < s->min_match) s->doc = TO_TERMINATED;
+  s->score = sum;
+  return s->doc;
+}
+
+/* ---- exclude */
+static int excl_contains(gscorer *s, uint32_t doc) { /* exclude.rs:9-27 */
+  for (size_t i = 0; i < s->n_excl; i++) {
+    uint32_t lb;
+    if (gs_seek_danger(s->excl[i], doc, &lb)) return 1;
+  }
+  return 0;
+}
+static uint32_t excl_advance(gscorer *s) { /* :63-73 */
+  for (;;) {
+    uint32_t c = gs_advance(s->req);
+    if (c == TO_TERMINATED) return TO_TERMINATED;
+    if (!excl_contains(s, c)) return c;
+  }
+}
+
+static uint32_t gs_doc(gscorer *s) {
+  switch (s->kind) {
+    case GS_TERM: return ts_doc(s->term);
+    case GS_UNION: case GS_DISJ: return s->doc;
+    case GS_INTER: return gs_doc(s->kids[0]);
+    case GS_REQOPT: case GS_EXCLUDE: return gs_doc(s->req);
+    default: return TO_TERMINATED;
+  }
+}
+static uint32_t gs_advance(gscorer *s) {
+  switch (s->kind) {
+    case GS_TERM: return to_sp_advance(&s->term->sp);
+    case GS_UNION: return union_advance(s);
+    case GS_INTER: return inter_advance(s);
+    case GS_REQOPT: s->has_cache = 0; return gs_advance(s->req);
+    case GS_EXCLUDE: return excl_advance(s);
+    case GS_DISJ: return disj_advance(s);
+    default: return TO_TERMINATED;
+  }
+}
+static uint32_t gs_seek(gscorer *s, uint32_t target) {
+  switch (s->kind) {
+    case GS_TERM: return to_sp_seek(&s->term->sp, target);
+    case GS_UNION: return union_seek(s, target);
+    case GS_INTER: { /* :177-187 */
+      gs_seek(s->kids[0], target);
+      return go_to_first_doc(s->kids, s->n_kids);
+    }
+    case GS_REQOPT: s->has_cache = 0; return gs_seek(s->req, target);
+    case GS_EXCLUDE: { /* :75-84 */
+      uint32_t c = gs_seek(s->req, target);
+      if (c == TO_TERMINATED) return TO_TERMINATED;
+      if (!excl_contains(s, c)) return c;
+      return excl_advance(s);
+    }
+    case GS_DISJ: return default_seek(s, target);
+    default: return TO_TERMINATED;
+  }
+}
+static int gs_seek_danger(gscorer *s, uint32_t target, uint32_t *lower) {
+  switch (s->kind) {
+    case GS_UNION: return union_seek_danger(s, target, lower);
+    case GS_INTER: { /* :193-210 */
+      for (size_t i = 0; i < s->n_kids; i++)
+        if (!gs_seek_danger(s->kids[i], target, lower)) return 0;
+      return 1;
+    }
+    case GS_REQOPT: s->has_cache = 0; return gs_seek_danger(s->req, target, lower);
+    case GS_EMPTY: *lower = TO_TERMINATED; return 0;
+    default: return default_seek_danger(s, target, lower);
+  }
+}
+static float gs_score(gscorer *s) {
+  switch (s->kind) {
+    case GS_TERM: return ts_score(s->term);
+    case GS_UNION: case GS_DISJ: return s->score;
+    case GS_INTER: { /* :325-329: left + right + sum(others) */
+      float oth = 0.0f;
+      for (size_t i = 2; i < s->n_kids; i++) oth += gs_score(s->kids[i]);
+      return gs_score(s->kids[0]) + gs_score(s->kids[1]) + oth;
+    }
+    case GS_REQOPT: { /* reqopt_scorer.rs:85-98 */
+      if (s->has_cache) return s->cache;
+      uint32_t doc = gs_doc(s->req);
+      float sc = 0.0f;
+      sc += gs_score(s->req);
+      if (gs_doc(s->opt) <= doc && gs_seek(s->opt, doc) == doc) sc += gs_score(s->opt);
+      s->cache = sc;
+      s->has_cache = 1;
+      return sc;
+    }
+    case GS_EXCLUDE: return gs_score(s->req);
+    default: return 0.0f;
+  }
+}
+
+/* arena of nodes for one query */
+typedef struct {
+  gscorer nodes[4 * TO_MAX_TERMS + 8];
+  size_t n_nodes;
+  gscorer *ptrs[8 * TO_MAX_TERMS + 16];
+  size_t n_ptrs;
+  uint64_t *bits;
+  float *acc;
+  size_t n_windows;
+  uint32_t heap_docs[TO_MAX_TERMS];
+} gs_arena;
+static gscorer *gs_new(gs_arena *a, int kind) {
+  gscorer *s = &a->nodes[a->n_nodes++];
+  memset(s, 0, sizeof *s);
+  s->kind = kind;
+  return s;
+}
+static gscorer **gs_ptrs(gs_arena *a, size_t n) {
+  gscorer **p = &a->ptrs[a->n_ptrs];
+  a->n_ptrs += n;
+  return p;
+}
+static void sort_by_cost(gscorer **v, size_t n) { /* stable insertion sort = sort_by_key(cost) */
+  for (size_t i = 1; i < n; i++) {
+    gscorer *x = v[i];
+    uint64_t c = gs_cost(x);
+    size_t j = i;
+    while (j > 0 && gs_cost(v[j - 1]) > c) {
+      v[j] = v[j - 1];
+      j--;
+    }
+    v[j] = x;
+  }
+}
+/* BufferedUnionScorer::build (:92-116); a single scorer stays itself (into_box_scorer :94-101) */
+static gscorer *gs_make_union(gs_arena *a, gscorer **kids, size_t n) {
+  if (n == 1) return kids[0];
+  gscorer *u = gs_new(a, GS_UNION);
+  u->kids = gs_ptrs(a, n);
+  for (size_t i = 0; i < n; i++)
+    if (gs_doc(kids[i]) != TO_TERMINATED) u->kids[u->n_kids++] = kids[i];
+  u->bits = a->bits + 64 * a->n_windows;
+  u->acc = a->acc + GS_HORIZON * a->n_windows;
+  a->n_windows++;
+  memset(u->bits, 0, 64 * sizeof(uint64_t));
+  memset(u->acc, 0, GS_HORIZON * sizeof(float));
+  u->bucket_idx = 64;
+  if (union_refill(u))
+    union_advance(u);
+  else
+    u->doc = TO_TERMINATED;
+  return u;
+}
+/* intersect_scorers (intersection.rs:20-56) */
+static gscorer *gs_make_inter(gs_arena *a, gscorer **kids, size_t n) {
+  if (n == 0) return gs_new(a, GS_EMPTY);
+  if (n == 1) return kids[0];
+  gscorer *s = gs_new(a, GS_INTER);
+  s->kids = gs_ptrs(a, n);
+  memcpy(s->kids, kids, n * sizeof(gscorer *));
+  s->n_kids = n;
+  sort_by_cost(s->kids, n);
+  if (go_to_first_doc(s->kids, n) == TO_TERMINATED) return gs_new(a, GS_EMPTY);
+  return s;
+}
+
+/* BooleanWeight::complex_scorer for clauses that are terms or unions of terms.  Returns NULL for
+ * an empty result. */
+static gscorer *gs_build(gs_arena *a, const to_segment_view *seg, const to_query *q,
+                         term_scorer *store) {
+  gscorer *clause[TO_MAX_TERMS];
+  uint8_t clause_occ[TO_MAX_TERMS];
+  uint32_t clause_id[TO_MAX_TERMS];
+  gscorer *members[TO_MAX_TERMS][TO_MAX_TERMS > 16 ? 16 : TO_MAX_TERMS];
+  size_t n_members[TO_MAX_TERMS];
+  size_t n_clauses = 0;
+  if (q->n_terms > 16) return NULL;
+  for (uint32_t i = 0; i < q->n_terms; i++) {
+    uint32_t id = q->clause_of ? q->clause_of[i] : i;
+    size_t c = 0;
+    while (c < n_clauses && clause_id[c] != id) c++;
+    if (c == n_clauses) {
+      clause_id[c] = id;
+      clause_occ[c] = q->occurs[i];
+      n_members[c] = 0;
+      n_clauses++;
+    }
+    if (q->terms[i].doc_freq == 0) continue; /* EmptyScorer: drops out of its union */
+    if (ts_open(&store[i], seg, &q->terms[i], &q->weights[i], TO_WITH_FREQS)) return NULL;
+    gscorer *t = gs_new(a, GS_TERM);
+    t->term = &store[i];
+    members[c][n_members[c]++] = t;
+  }
+  gscorer *must[TO_MAX_TERMS], *should[TO_MAX_TERMS], *excl[TO_MAX_TERMS];
+  size_t n_must = 0, n_should = 0, n_excl = 0;
+  for (size_t c = 0; c < n_clauses; c++) {
+    if (n_members[c] == 0) { /* the clause's scorer is an EmptyScorer */
+      if (clause_occ[c] == 1) return NULL; /* boolean_weight.rs:249-251 */
+      continue;                            /* removed from should / exclude (:253-262) */
+    }
+    clause[c] = gs_make_union(a, members[c], n_members[c]);
+    if (clause_occ[c] == 1) must[n_must++] = clause[c];
+    else if (clause_occ[c] == 0) should[n_should++] = clause[c];
+    else excl[n_excl++] = clause[c];
+  }
+  size_t msm = q->min_should_match;
+  if (msm > n_should) return NULL; /* :275-279 */
+  gscorer *should_sc = NULL;
+  int should_required = 0;
+  if (n_should == 0) {
+    /* Ignored */
+  } else if (msm == 0 || msm == 1) {
+    /* scorer_union over the clause scorers: all terms -> one BufferedUnionScorer over the terms;
+     * otherwise a union over the clause scorers (:44-86) */
+    should_sc = gs_make_union(a, should, n_should);
+    should_required = msm == 1;
+  } else if (msm == n_should) {
+    for (size_t i = 0; i < n_should; i++) must[n_must++] = should[i]; /* :293-298 */
+    n_should = 0;
+  } else {
+    gscorer *d = gs_new(a, GS_DISJ); /* scorer_disjunction :23-41 */
+    d->kids = gs_ptrs(a, n_should);
+    d->heap_doc = a->heap_docs;
+    d->n_kids = n_should;
+    for (size_t i = 0; i < n_should; i++) d->kids[i] = should[i];
+    /* heapify on the scorers' current docs */
+    for (size_t i = 0; i < n_should; i++) d->heap_doc[i] = gs_doc(d->kids[i]);
+    for (size_t i = n_should; i-- > 0;) disj_sift_down(d, i);
+    d->min_match = msm;
+    d->doc = TO_TERMINATED;
+    disj_advance(d);
+    should_sc = d;
+    should_required = 1;
+  }
+  gscorer *include = NULL;
+  if (!should_sc) {
+    if (n_must == 0) return NULL; /* no include scorer: EmptyScorer */
+    include = gs_make_inter(a, must, n_must);
+  } else if (!should_required) {
+    if (n_must == 0) {
+      include = should_sc; /* promoted to required (:361-372) */
+    } else {
+      gscorer *m = gs_make_inter(a, must, n_must);
+      gscorer *r = gs_new(a, GS_REQOPT); /* :373-388 */
+      r->req = m;
+      r->opt = should_sc;
+      include = r;
+    }
+  } else {
+    if (n_must == 0) {
+      include = should_sc;
+    } else {
+      gscorer *pair[2];
+      pair[0] = gs_make_inter(a, must, n_must);
+      pair[1] = should_sc;
+      include = gs_make_inter(a, pair, 2); /* :401-409 */
+    }
+  }
+  if (include->kind == GS_EMPTY) return NULL;
+  if (n_excl == 0) return include;
+  gscorer *e = gs_new(a, GS_EXCLUDE); /* :416-431; Exclude::new skips excluded heads (:38-52) */
+  e->req = include;
+  e->excl = gs_ptrs(a, n_excl);
+  memcpy(e->excl, excl, n_excl * sizeof(gscorer *));
+  e->n_excl = n_excl;
+  while (gs_doc(include) != TO_TERMINATED) {
+    if (!excl_contains(e, gs_doc(include))) break;
+    gs_advance(include);
+  }
+  return e;
+}
+
+static void run_bool(const to_segment_view *seg, const to_query *q, match_fn fn, void *ctx) {
+  term_scorer *store = (term_scorer *)malloc(sizeof(term_scorer) * (q->n_terms ? q->n_terms : 1));
+  gs_arena *a = (gs_arena *)malloc(sizeof(gs_arena));
+  a->n_nodes = a->n_ptrs = a->n_windows = 0;
+  a->bits = (uint64_t *)malloc((size_t)(q->n_terms + 2) * 64 * sizeof(uint64_t));
+  a->acc = (float *)malloc((size_t)(q->n_terms + 2) * GS_HORIZON * sizeof(float));
+  gscorer *s = gs_build(a, seg, q, store);
+  if (s) {
+    /* for_each_pruning_scorer (weight.rs:47-60); fn applies the threshold */
+    for (uint32_t d = gs_doc(s); d != TO_TERMINATED; d = gs_advance(s)) fn(ctx, d, gs_score(s));
+  }
+  free(a->bits);
+  free(a->acc);
+  free(a);
+  free(store);
+}

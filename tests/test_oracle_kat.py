@@ -667,3 +667,44 @@ def test_bool_match_all_consistency():
         want = np.float32(m1[doc]) + np.float32(m6[doc]) if doc in m6 else np.float32(m1[doc])
         assert np.float32(x) == np.float32(want)
     assert len(O.bool_match_all(seg, [3], [O.MUST_NOT])[0]) == 0
+
+
+def test_scorer_tree_restatement_against_the_semantic_one():
+    """The C restatement of the generic scorer tree (Intersection / BufferedUnionScorer /
+    Disjunction / RequiredOptionalScorer / Exclude, what the bench's cpu_baseline times for
+    boolean queries) and the dense numpy restatement of the same semantics agree."""
+    seg = O.synth_segment(40_000, n_terms=30, with_positions=False)
+    rng = np.random.default_rng(3)
+    M, S, N = O.MUST, O.SHOULD, O.MUST_NOT
+    shapes = [([M, S], None, 0), ([M, N], None, 0), ([S, S, N], None, 0), ([M, M, M, N], None, 0),
+              ([M, S, N, S, M], None, 0), ([N], None, 0), ([M, M, M], [0, 1, 1], 0),
+              ([M, M, M, M], [0, 0, 1, 1], 0), ([M, S, S], None, 1), ([M, S, S, S], None, 2),
+              ([S, S, S], None, 2), ([S, S, S], None, 3), ([M, S], None, 2),
+              ([M, S, S, N], [0, 1, 1, 2], 1), ([M, M, M, M, M], [0, 1, 1, 2, 2], 0)]
+    for occ, cof, msm in shapes * 2:
+        terms = rng.choice(30, size=len(occ), replace=False).tolist()
+        d1, s1 = O.bool_match_all(seg, terms, occ, cof, msm)
+        d2, s2 = O.bool_match_all_c(seg, terms, occ, cof, msm)
+        assert np.array_equal(d1, d2), (occ, cof, msm, terms)
+        assert np.allclose(s1, s2, rtol=1e-5, atol=0), (occ, cof, msm, terms)
+        top = O.bool_search(seg, terms, occ, 10, cof, msm)
+        want = sorted(zip(s2.tolist(), d2.tolist()), key=lambda h: (-h[0], h[1]))[:10]
+        assert [d for _, d in top] == [d for _, d in want]
+
+
+def test_scorer_tree_reference_unit_cases():
+    """exclude.rs:104-117 (test_exclude), disjunction.rs tests (docs matched by >= pass_line of the
+    lists), reqopt_scorer.rs tests (the required side decides the doc set)."""
+    a = [1, 2, 5, 8, 10, 15, 24]
+    b = [1, 2, 3, 10, 16, 24]
+    c = [2, 5, 9, 10, 24, 30]
+    seg = O.build_segment(64, [[(d, 1) for d in l] for l in (a, b, c)], [3] * 64)
+    M, S, N = O.MUST, O.SHOULD, O.MUST_NOT
+    d, _ = O.bool_match_all_c(seg, [0, 1], [M, N])
+    assert d.tolist() == [5, 8, 15]
+    d, _ = O.bool_match_all_c(seg, [0, 1, 2], [S, S, S], None, 2)
+    assert d.tolist() == sorted(x for x in set(a + b + c) if (x in a) + (x in b) + (x in c) >= 2)
+    d, sc = O.bool_match_all_c(seg, [0, 1], [M, S])
+    assert d.tolist() == a
+    one = sc[a.index(5)]                       # only the required term matches doc 5
+    assert all((s > one) == (doc in b) for doc, s in zip(a, sc.tolist()))
