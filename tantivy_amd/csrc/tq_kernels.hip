@@ -1738,8 +1738,7 @@ struct PhraseLds {  // per wavefront
   uint32_t pay[516];  // lookup_in_blocks' staging area
   uint32_t q1_doc[191], q1_tf[191], q1_pi[191];
   uint32_t q2_doc[127], q2_tf[127], q2_pi[127], q2_loc[127];
-  uint32_t ph_pi[NT_MAX][64], ph_tf[NT_MAX][64];
-  float cache[256];
+  uint32_t ph_pi[NT_MAX - 1][64], ph_tf[NT_MAX - 1][64];  // lists 1.. (the leader's stay in q2)
 };
 
 struct PosCursor {
@@ -1774,7 +1773,7 @@ __global__ __launch_bounds__(64) void phrase_kernel(TqkScanParams p) {
   uint32_t nt = 0, tile_blocks = TQD_AND_TILE;
   TermRef lead{}, t1{};
   float weight = 0.0f;
-  uint32_t cache_loaded = 0xFFFFFFFFu;
+  const float *cache_g = nullptr;  // tf cache of the current query (global memory)
   TopK<KPL> tk;
   uint32_t n_matches = 0, n_q = 0;  // docs scored: whole chunk / current query
   uint32_t q1n = 0, q2n = 0;
@@ -1789,14 +1788,9 @@ __global__ __launch_bounds__(64) void phrase_kernel(TqkScanParams p) {
     t1 = load_term(p.terms, sload(&Q->term[1]));
     if (!p.use_dense) t1.dense = nullptr;
     weight = sload(&Q->weight[0]);
-    const uint32_t ci = sload(&Q->cache_idx);
-    if (ci != cache_loaded) {
-      const float *cg = p.caches + (size_t)ci * 256u;
-      wave_mem_fence();
-      for (int i = lane; i < 256; i += WAVE) L.cache[i] = cg[i];
-      wave_mem_fence();
-      cache_loaded = ci;
-    }
+    // the tf cache stays in global memory: only phrase matches are scored (7.9 KB of LDS per
+    // wavefront instead of 9.5 KB: 5 waves/SIMD)
+    cache_g = p.caches + (size_t)sload(&Q->cache_idx) * 256u;
     tk.reset(sload(&Q->k));
   };
 
@@ -1805,12 +1799,12 @@ __global__ __launch_bounds__(64) void phrase_kernel(TqkScanParams p) {
     const uint32_t base = q2n - n;
     q2n = base;
     bool alive = (uint32_t)lane < n;
-    uint32_t doc = 0, loc = 0;
+    uint32_t doc = 0, loc = 0, lead_tf = 0, lead_pi = 0;
     if (alive) {
       doc = L.q2_doc[base + lane];
       loc = L.q2_loc[base + lane];
-      L.ph_tf[0][lane] = L.q2_tf[base + lane];
-      L.ph_pi[0][lane] = L.q2_pi[base + lane];
+      lead_tf = L.q2_tf[base + lane];
+      lead_pi = L.q2_pi[base + lane];
     }
     for (uint32_t m = 1; m < nt; ++m) {
       TermRef tr = m == 1u ? t1 : load_term(p.terms, sload(&Q->term[m]));
@@ -1846,8 +1840,8 @@ __global__ __launch_bounds__(64) void phrase_kernel(TqkScanParams p) {
       uint32_t tf = 1;
       if (!(p.debug & 2u)) tf = lookup_in_blocks<true>(idx, tr, jb, at, alive, L.pay, lane, &excl);
       if (alive) {
-        L.ph_tf[m][lane] = tf;
-        L.ph_pi[m][lane] = tr.rec[jb].w + excl;
+        L.ph_tf[m - 1u][lane] = tf;
+        L.ph_pi[m - 1u][lane] = tr.rec[jb].w + excl;
       }
     }
     // ---- position check, one lane per candidate
@@ -1863,9 +1857,9 @@ __global__ __launch_bounds__(64) void phrase_kernel(TqkScanParams p) {
         cur[m].valid = false;
         cur[m].idx = cur[m].end = cur[m].cur = 0;
         if ((uint32_t)m < nt) {
-          const uint32_t pi = L.ph_pi[m][lane];
+          const uint32_t pi = m ? L.ph_pi[m ? m - 1 : 0][lane] : lead_pi;
           cur[m].idx = pi + 1u;
-          cur[m].end = pi + L.ph_tf[m][lane];
+          cur[m].end = pi + (m ? L.ph_tf[m ? m - 1 : 0][lane] : lead_tf);
           cur[m].cur = Q->phrase_off[m] + position_delta(pos, p.terms + Q->term[m], pi);
           cur[m].valid = true;
         }
@@ -1896,7 +1890,7 @@ __global__ __launch_bounds__(64) void phrase_kernel(TqkScanParams p) {
       }
       if (count > 0 && doc_is_alive(seg, doc)) {
         has = true;
-        key = make_key(bm25(weight, L.cache[fieldnorm_id(seg, doc)], count), doc);
+        key = make_key(bm25(weight, cache_g[fieldnorm_id(seg, doc)], count), doc);
       }
     }
     const uint64_t hit = __ballot(has);
