@@ -1410,6 +1410,7 @@ __device__ __forceinline__ void union_body(const TqkScanParams &p) {
   auto stageB = [&](uint32_t n) __attribute__((always_inline)) {
     const uint32_t base = q1n - n;
     q1n = base;
+    if (p.debug & 64u) n_matches += n;  // COUNTERS
     bool alive = (uint32_t)lane < n;
     uint32_t doc = 0, tf = 0;
     float norm = 0.0f, s = 0.0f;
@@ -1430,8 +1431,12 @@ __device__ __forceinline__ void union_body(const TqkScanParams &p) {
     bool cfound = false;
     uint32_t clause = 1u;
     uint32_t n_should = ((roles >> (2u * li)) & 3u) == TQD_ROLE_SHOULD ? 1u : 0u;
-    for (uint32_t m = 0; m < nt; ++m) {
-      if (m == li) continue;
+    // lists after the leader first (they add to the score and tighten the bound), the lists
+    // before it last: those only decide whether another tile owns the doc, and most candidates
+    // are gone by then without the (sparse, expensive) probes into the high-weight lists
+    for (uint32_t mm = 1; mm < nt; ++mm) {
+      uint32_t m = li + mm;
+      if (m >= nt) m -= nt;
       const uint32_t role = BOOL ? (roles >> (2u * m)) & 3u : TQD_ROLE_SHOULD;
       const float w = sload(&Q->weight[m]);
       // what the lists m.. can still add (lists below li add nothing: found there = dropped)
@@ -1499,7 +1504,7 @@ __device__ __forceinline__ void union_body(const TqkScanParams &p) {
     if (alive) alive = doc_is_alive(seg, doc);
     const uint64_t hit = __ballot(alive);
     if (hit) {
-      n_matches += (uint32_t)__popcll(hit);
+      if (!(p.debug & 224u)) n_matches += (uint32_t)__popcll(hit);  // COUNTERS
       n_q += (uint32_t)__popcll(hit);
       const uint64_t key = alive ? make_key(s, doc) : 0ull;
       if (slots) {
@@ -1636,6 +1641,8 @@ __device__ __forceinline__ void union_body(const TqkScanParams &p) {
       }
     }
     uint64_t todo = __ballot(surv);
+    if (p.debug & 32u) n_matches += (uint32_t)__popcll(todo);  // COUNTERS
+    if (p.debug & 128u) n_matches += 1u;  // COUNTERS
     while (todo) {
       const uint32_t b = (uint32_t)__builtin_ctzll(todo);
       todo &= todo - 1ull;
