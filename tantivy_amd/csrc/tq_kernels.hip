@@ -699,6 +699,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_num_sgpr(80))) void and_k
   auto stageC = [&](uint32_t n) __attribute__((always_inline)) {
     const uint32_t base = q2n - n;
     q2n = base;
+    if (p.debug & 128u) n_matches += n;  // COUNTERS
     bool alive = (uint32_t)lane < n;
     uint32_t doc = 0, tf = 0, loc = 0;
     float norm = 0.0f;
@@ -769,7 +770,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_num_sgpr(80))) void and_k
     if (alive) alive = doc_is_alive(seg, doc);
     const uint64_t hit = __ballot(alive);
     if (hit) {
-      n_matches += (uint32_t)__popcll(hit);
+      if (!(p.debug & 224u)) n_matches += (uint32_t)__popcll(hit);  // COUNTERS
       n_q += (uint32_t)__popcll(hit);
       const uint64_t key = alive ? make_key(s, doc) : 0ull;
       if (slots) {
@@ -790,6 +791,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_num_sgpr(80))) void and_k
   auto stageB = [&](uint32_t n) __attribute__((always_inline)) {
     const uint32_t base = q1n - n;
     q1n = base;
+    if (p.debug & 64u) n_matches += n;  // COUNTERS
     bool alive = (uint32_t)lane < n;
     uint32_t doc = 0, tf = 0, loc = 0;
     if (alive) {
@@ -931,6 +933,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_num_sgpr(80))) void and_k
       }
     }
     uint64_t todo = __ballot(surv);
+    if (p.debug & 32u) n_matches += (uint32_t)__popcll(todo);  // COUNTERS
 
     // ---- stage A per surviving leader block
     auto stageA = [&](uint32_t b) __attribute__((always_inline)) {
