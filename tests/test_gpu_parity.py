@@ -321,14 +321,9 @@ def test_edge_cases(ta):
         dev.close()
 
 
-@pytest.mark.parametrize("seed", [1, 2, 3, 4, 5, 6])
-def test_fuzz_random_segments(ta, seed):
-    """Random segments (dense and sparse lists, tails, runs of consecutive docs, repeated scores)
-    x random AND / OR / phrase queries x k, in every execution mode (pruned / exhaustive, with and
-    without the dense-list bitmaps): always the oracle's exhaustive top-k."""
-    rng = np.random.default_rng(1000 + seed)
+def _fuzz_segment(rng, seed, n_terms=14):
+    """Random segment: dense and sparse lists, tails, runs of consecutive docs, repeated scores."""
     md = int(rng.choice([5000, 20000, 70000]))
-    n_terms = 14
     lists, positions = [], []
     for t in range(n_terms):
         kind = rng.integers(0, 5)
@@ -356,8 +351,18 @@ def test_fuzz_random_segments(ta, seed):
             pl.append(np.sort(rng.choice(40, size=tf, replace=False)).tolist())
         positions.append(pl)
     fieldnorms = rng.integers(1, 60, size=md).tolist() if seed % 2 else [7] * md
-    seg = O.build_segment(md, lists, fieldnorms, record_option=O.WITH_FREQS_AND_POSITIONS,
-                          positions=positions)
+    return O.build_segment(md, lists, fieldnorms, record_option=O.WITH_FREQS_AND_POSITIONS,
+                           positions=positions)
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3, 4, 5, 6])
+def test_fuzz_random_segments(ta, seed):
+    """Random segments (dense and sparse lists, tails, runs of consecutive docs, repeated scores)
+    x random AND / OR / phrase queries x k, in every execution mode (pruned / exhaustive, with and
+    without the dense-list bitmaps): always the oracle's exhaustive top-k."""
+    rng = np.random.default_rng(1000 + seed)
+    n_terms = 14
+    seg = _fuzz_segment(rng, seed, n_terms)
     queries = []
     for _ in range(40):
         mode = int(rng.choice([O.MODE_AND, O.MODE_AND, O.MODE_OR, O.MODE_PHRASE]))
@@ -382,6 +387,57 @@ def test_fuzz_random_segments(ta, seed):
                                              "query %r\ngot  %r\nwant %r" %
                                              (seed, k, ex, ud, ow, q, g[:5], w[:5]))
         dev.set_option("or_windows", -1)
+    finally:
+        dev.close()
+
+
+@pytest.mark.parametrize("seed", [21, 22, 23, 24])
+def test_fuzz_random_segments_boolean(ta, seed):
+    """The same random segments under random boolean queries (occurs, nested unions,
+    minimum_number_should_match), pruned / exhaustive, with and without bitmaps: the top-k and the
+    match counts of the oracle's restatements (dense numpy semantics == C scorer tree)."""
+    rng = np.random.default_rng(seed)
+    n_terms = 14
+    seg = _fuzz_segment(rng, seed, n_terms)
+    queries = []
+    for _ in range(48):
+        n = int(rng.integers(1, 6))
+        terms = rng.choice(n_terms, size=n, replace=False).tolist()
+        n_cl = int(rng.integers(1, n + 1))
+        cof = sorted(rng.integers(0, n_cl, size=n).tolist())
+        occ_of = rng.choice([O.MUST, O.MUST, O.SHOULD, O.SHOULD, O.MUST_NOT], size=n_cl).tolist()
+        occ = [int(occ_of[c]) for c in cof]
+        n_should_cl = len({c for c, o in zip(cof, occ) if o == O.SHOULD})
+        widest_should = max([cof.count(c) for c, o in zip(cof, occ) if o == O.SHOULD], default=1)
+        msm = int(rng.integers(0, n_should_cl + 2)) if rng.random() < 0.4 else 0
+        if msm >= 2 and widest_should > 1 and msm != n_should_cl:
+            msm = 1  # min_should_match > 1 over nested unions stays on the CPU (Unsupported)
+        queries.append((ta.MODE_BOOL, terms, occ, cof, msm))
+    want_all = []
+    for q in queries:
+        w = _bool_want(seg, q[1], q[2], (), q[3], q[4])
+        dc, _ = O.bool_match_all_c(seg, q[1], q[2], q[3], q[4])
+        assert sorted(d for _, d in w) == dc.tolist(), q   # the two restatements agree
+        want_all.append(w)
+    dev = ta.DeviceIndex([seg])
+    try:
+        dev.set_option("dense_ratio", 16)
+        for k in (1, 10, 100):
+            for ex, ud in ((1, 1), (0, 1), (0, 0), (1, 0)):
+                dev.set_option("exhaustive", ex)
+                dev.set_option("use_dense", ud)
+                got = _device_topk(dev, queries, k)
+                counts = dev.last_batch_match_counts(len(queries)) if ex else None
+                for i, (q, g, w) in enumerate(zip(queries, got, want_all)):
+                    try:
+                        _assert_hits_close(g, w[:k]) if len(w) > k else _assert_bool_hits(g, w, k, q[2], q[3])
+                        if ex:
+                            assert counts[i] == len(w)
+                    except AssertionError:
+                        raise AssertionError("seed %d k %d exhaustive %d use_dense %d query %r\ngot  %r\n"
+                                             "want %r" % (seed, k, ex, ud, q, g[:5], w[:5]))
+        dev.set_option("exhaustive", 1)
+        dev.set_option("use_dense", 1)
     finally:
         dev.close()
 
