@@ -894,7 +894,7 @@ int tq_search_batch_device(tq_segment *s, const tq_query *queries, uint32_t n_qu
           dq.flags |= TQD_QF_PRUNE;
           if (q.k <= 2 * TQD_THR_SLOTS) {
             dq.thr_index = n_thr_rows;
-            n_thr_rows += q.k <= TQD_THR_SLOTS ? 1u : 2u;
+            n_thr_rows += 4u;  // union kernel: 64 slots for k <= 16, 256 above; the window kernel 64 / 128
           }
         }
         const uint32_t c_lb = 1u + n + 8u * sparse;
@@ -944,7 +944,7 @@ int tq_search_batch_device(tq_segment *s, const tq_query *queries, uint32_t n_qu
           dq.flags |= TQD_QF_PRUNE;
           if (q.k <= 2 * TQD_THR_SLOTS) {  // k-th largest of 64 (128) slots needs k <= 64 (128)
             dq.thr_index = n_thr_rows;
-            n_thr_rows += q.k <= TQD_THR_SLOTS ? 1u : 2u;
+            n_thr_rows += 4u;  // union kernel: 64 slots for k <= 16, 256 above; the window kernel 64 / 128
           }
         }
       }

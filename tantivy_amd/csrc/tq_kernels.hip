@@ -1373,7 +1373,9 @@ __device__ __forceinline__ void union_body(const TqkScanParams &p) {
     prune = PRUNE && (sload(&Q->flags) & TQD_QF_PRUNE) != 0u;
     const uint32_t thr_index = sload(&Q->thr_index);
     const uint32_t k = sload(&Q->k);
-    n_slot_rows = k <= 64u ? 1u : 2u;
+    // 64 slots hold the top 16 well; beyond that the k-th largest slot is loose (the top k docs
+    // collide): 256 slots (128: still loose at k = 100; 512: no better)
+    n_slot_rows = k <= 16u ? 1u : 4u;
     slots = (prune && thr_index != 0xFFFFFFFFu) ? p.thr_slots + (size_t)thr_index * TQD_THR_SLOTS
                                                 : nullptr;
     const uint32_t ci = sload(&Q->cache_idx);
@@ -1512,7 +1514,7 @@ __device__ __forceinline__ void union_body(const TqkScanParams &p) {
       const uint64_t key = alive ? make_key(s, doc) : 0ull;
       if (slots) {
         const uint32_t sb = (uint32_t)(key >> 32);
-        const uint32_t h = (doc * 0x9E3779B1u) >> (n_slot_rows == 1u ? 26 : 25);
+        const uint32_t h = (doc * 0x9E3779B1u) >> (n_slot_rows == 1u ? 26 : 24);
         if (alive && sb > thr_g) atomicMax(slots + h, sb);
       }
       tk.offer(alive, key, lane);
@@ -1558,11 +1560,13 @@ __device__ __forceinline__ void union_body(const TqkScanParams &p) {
     }
     // threshold: on a new leader and every 8th tile
     if (slots && (new_leader || (tl & 7u) == 0u)) {
-      uint32_t sv[2] = {0u, 0u};
+      uint32_t sv[4] = {0u, 0u, 0u, 0u};
       sv[0] = __hip_atomic_load(slots + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if (n_slot_rows == 2u) {
-        sv[1] = __hip_atomic_load(slots + 64 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        thr_g = kth_largest_multi<2>(sv, tk.k);
+      if (n_slot_rows == 4u) {
+#pragma unroll
+        for (int r = 1; r < 4; ++r)
+          sv[r] = __hip_atomic_load(slots + 64 * r + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        thr_g = kth_largest_multi<4>(sv, tk.k);
       } else {
         thr_g = kth_largest64(sv[0], tk.k);
       }
