@@ -2051,12 +2051,37 @@ __global__ __launch_bounds__(64) void merge_kernel(TqkMergeParams p) {
   const uint32_t part_start = uni(Q->part_start), n_parts = uni(Q->n_parts);
   TopK<KPL> tk;
   tk.reset(k);
-  for (uint32_t pi = 0; pi < n_parts; ++pi) {
-    const uint64_t *src = p.partials + (uint64_t)(part_start + pi) * (uint64_t)(KPL * 64);
+  // a full partial list's k-th key is a lower bound of the final k-th key: the largest of them
+  // (one 8-byte load per list, 64 lists at a time) keeps almost every other key out of the
+  // serial insertions below
+  uint64_t floor_key = 0;
+  for (uint32_t pi = (uint32_t)lane; pi < n_parts; pi += WAVE) {
+    const uint64_t kth = p.partials[(uint64_t)(part_start + pi) * (uint64_t)(KPL * 64) + (k - 1u)];
+    floor_key = kth > floor_key ? kth : floor_key;
+  }
+  for (int o = 32; o; o >>= 1) {
+    const uint64_t other = ((uint64_t)(uint32_t)__shfl_xor((int)(floor_key >> 32), o, WAVE) << 32) |
+                           (uint32_t)__shfl_xor((int)(uint32_t)floor_key, o, WAVE);
+    floor_key = other > floor_key ? other : floor_key;
+  }
+  // the loads of a group of lists are issued together (one wavefront walks hundreds of lists:
+  // one round trip per list was the whole cost of this kernel)
+  constexpr uint32_t GROUP = KPL <= 2 ? 8u : (KPL <= 4 ? 4u : 1u);
+  for (uint32_t pi0 = 0; pi0 < n_parts; pi0 += GROUP) {
+    uint64_t keys[GROUP][KPL];
 #pragma unroll
-    for (int r = 0; r < KPL; ++r) {
-      const uint64_t key = src[(uint32_t)r * 64u + (uint32_t)lane];
-      tk.offer(key != 0ull, key, lane);
+    for (uint32_t g = 0; g < GROUP; ++g) {
+      const uint32_t pi = pi0 + g < n_parts ? pi0 + g : n_parts - 1u;  // clamped: unconditional loads
+      const uint64_t *src = p.partials + (uint64_t)(part_start + pi) * (uint64_t)(KPL * 64);
+#pragma unroll
+      for (int r = 0; r < KPL; ++r) keys[g][r] = src[(uint32_t)r * 64u + (uint32_t)lane];
+    }
+#pragma unroll
+    for (uint32_t g = 0; g < GROUP; ++g) {
+      if (pi0 + g >= n_parts) break;
+#pragma unroll
+      for (int r = 0; r < KPL; ++r)
+        tk.offer(keys[g][r] != 0ull && keys[g][r] >= floor_key, keys[g][r], lane);
     }
   }
   const uint32_t out_q = p.out_index ? p.out_index[q] : q;
