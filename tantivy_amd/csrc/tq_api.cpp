@@ -645,7 +645,7 @@ static const uint32_t kSlices = std::min<uint32_t>(256u, std::max<uint32_t>(1u, 
 // expected to be skipped at run time and weigh 1/kOrDeadDiv of a live tile
 static const float kOrDeadFrac = 0.75f;
 static const uint32_t kOrDeadDiv = 8;
-static const uint32_t kAndChunks = std::max<uint32_t>(256u, tune_u32("TQ_CHUNKS", 65536));
+static const uint32_t kAndChunks = std::max<uint32_t>(256u, tune_u32("TQ_CHUNKS", 131072));
 
 int kpl_for(uint32_t k) { return k <= 64 ? 1 : (k <= 128 ? 2 : (k <= 256 ? 4 : 16)); }
 
@@ -1037,7 +1037,7 @@ int tq_search_batch_device(tq_segment *s, const tq_query *queries, uint32_t n_qu
         t = e;
       }
     }
-    const uint64_t n_target = or_win ? 8192u : (or_cand ? 4u * kAndChunks : kAndChunks);
+    const uint64_t n_target = or_win ? 8192u : (or_cand ? 8u * kAndChunks : kAndChunks);
     const uint64_t cost_target = std::max<uint64_t>(or_win ? 1u : 128u,
                                                     (total_cost + n_target - 1) / n_target);
     g.chunk_starts.clear();
