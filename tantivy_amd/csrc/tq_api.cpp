@@ -640,7 +640,7 @@ static uint32_t tune_u32(const char *name, uint32_t dflt) {
   return v && *v ? (uint32_t)strtoul(v, nullptr, 10) : dflt;
 }
 // doc-range slices of the launch order / chunks per AND launch (TQ_SLICES, TQ_CHUNKS: tuning only)
-static const uint32_t kSlices = std::min<uint32_t>(256u, std::max<uint32_t>(1u, tune_u32("TQ_SLICES", 32)));
+static const uint32_t kSlices = std::min<uint32_t>(256u, std::max<uint32_t>(1u, tune_u32("TQ_SLICES", 128)));
 // candidate-driven OR cost model: lists whose suffix weight is below kOrDeadFrac of the total are
 // expected to be skipped at run time and weigh 1/kOrDeadDiv of a live tile
 static const float kOrDeadFrac = 0.75f;
