@@ -52,6 +52,7 @@ struct EncParams {
   uint8_t *out;
   uint64_t *out_term_starts;    // n_terms + 1
   uint32_t n_terms, n_blocks;
+  uint32_t fn_limit;            // num_docs - 1: doc ids are clamped for the fieldnorm gather
   uint32_t has_freq, has_pos, has_bm25, positions_file;
 };
 
@@ -218,8 +219,10 @@ __global__ __launch_bounds__(WAVE *ENC_WAVES) void enc_measure_kernel(EncParams 
   const uint8_t *fnp = p.has_bm25 ? p.fieldnorm_ids : reinterpret_cast<const uint8_t *>(p.values);
   const uint32_t fn_mask = p.has_bm25 ? 0xFFFFFFFFu : 0u;  // no fieldnorms: every lane reads byte 0
   auto gather = [&](const RawBlock &r, uint32_t &f0, uint32_t &f1) __attribute__((always_inline)) {
-    f0 = fnp[r.v0 & fn_mask];
-    f1 = fnp[r.v1 & fn_mask];
+    // (a doc id >= num_docs is the caller's bug; it must not become an out-of-bounds read)
+    const uint32_t a0 = r.v0 & fn_mask, a1 = r.v1 & fn_mask;
+    f0 = fnp[a0 < p.fn_limit ? a0 : p.fn_limit];
+    f1 = fnp[a1 < p.fn_limit ? a1 : p.fn_limit];
   };
   for (uint32_t b0 = wave * ENC_CHUNK; b0 < p.n_blocks; b0 += n_waves * ENC_CHUNK) {
     const uint32_t nb = p.n_blocks - b0 < ENC_CHUNK ? p.n_blocks - b0 : ENC_CHUNK;
@@ -573,6 +576,15 @@ int encode_device(tq_encoder *enc, bool positions_file, uint32_t n_terms,
                   uint32_t num_docs, float avg_fieldnorm, uint8_t record_option, uint8_t *d_out,
                   uint64_t out_cap, uint64_t *d_out_term_starts, uint64_t *total_out,
                   hipStream_t st) {
+  if (n_terms == 0) {  // nothing to write
+    const uint64_t zero = 0;
+    ENC_TRY(hipMemcpyAsync(d_out_term_starts, &zero, 8, hipMemcpyHostToDevice, st));
+    ENC_TRY(hipEventRecord(enc->ev0, st));
+    ENC_TRY(hipEventRecord(enc->ev1, st));
+    ENC_TRY(hipStreamSynchronize(st));
+    *total_out = 0;
+    return TQ_OK;
+  }
   // full blocks per term (host: O(n_terms + n_blocks))
   std::vector<uint32_t> blk_first(n_terms + 1);
   uint64_t nb = 0;
@@ -624,6 +636,7 @@ int encode_device(tq_encoder *enc, bool positions_file, uint32_t n_terms,
   p.out_term_starts = d_out_term_starts;
   p.n_terms = n_terms;
   p.n_blocks = n_blocks;
+  p.fn_limit = has_bm25 ? num_docs - 1u : 0u;
   p.has_freq = has_freq;
   p.has_pos = !positions_file && record_option == TQ_WITH_FREQS_AND_POSITIONS;
   p.has_bm25 = has_bm25;

@@ -122,6 +122,14 @@ def test_encode_then_search_round_trip(ta, enc):
         assert (int(pts[t]), int(pts[t + 1])) == (ti.positions_start, ti.positions_end)
 
 
+def test_encode_nothing(enc):
+    body, ots = enc.encode_postings(np.zeros(1, np.uint64), np.zeros(0, np.uint32), None, None, 0, 0.0,
+                                    O.BASIC)
+    assert body.size == 0 and ots.tolist() == [0]
+    body, ots = enc.encode_positions(np.zeros(1, np.uint64), np.zeros(0, np.uint32))
+    assert body.size == 0 and ots.tolist() == [0]
+
+
 def test_encode_errors(ta, enc):
     ts = np.array([0, 200], np.uint64)
     docs = np.arange(200, dtype=np.uint32)
