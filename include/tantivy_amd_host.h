@@ -56,6 +56,9 @@ int tqh_prepare_batch(tqh_searcher *s, const tqh_query *queries, uint32_t n);
  * outputs [n][limit], (score desc, segment_ord asc, doc asc). */
 int tqh_search_prepared(tqh_searcher *s, uint32_t offset, uint32_t limit, float *scores,
                         uint32_t *segment_ords, uint32_t *docs, uint32_t *counts);
+/* Searcher::search(&query, &Count) of the prepared batch (src/collector/count_collector.rs:39-80):
+ * counts[q] = alive matching docs summed over the segments. */
+int tqh_count_prepared(tqh_searcher *s, uint64_t *counts);
 /* Collector::collect_segment of the prepared batch on one segment: [n][k] sorted. */
 int tqh_collect_segment_prepared(tqh_searcher *s, uint32_t segment_ord, uint32_t k, float *scores,
                                  uint32_t *docs, uint32_t *counts);

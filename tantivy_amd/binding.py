@@ -62,6 +62,7 @@ EXPORTS = [
     "tqh_bm25_for_terms", "tqh_segment_raw", "tqh_term_handle", "tqh_term_dictionary_values",
     "tqh_term_info_store_open", "tqh_term_info_store_free", "tqh_term_info_store_num_terms",
     "tqh_term_info_store_get", "tqh_term_info_store_write", "tqh_searcher_add_segment_with_store",
+    "tqh_count_prepared",
 ]
 
 
@@ -128,6 +129,7 @@ def lib():
     L.tqh_term_handle.restype = C.c_uint32
     L.tqh_term_handle.argtypes = [vp, C.c_uint32, C.c_uint32]
     L.tqh_term_dictionary_values.argtypes = [vp, C.c_size_t, u64p, u64p]
+    L.tqh_count_prepared.argtypes = [vp, u64p]
     L.tqh_term_info_store_open.argtypes = [vp, C.c_size_t, C.POINTER(vp)]
     L.tqh_term_info_store_free.argtypes = [vp]
     L.tqh_term_info_store_free.restype = None
@@ -430,6 +432,13 @@ class DeviceIndex:
     def search(self, queries, limit, offset=0):
         self.prepare(queries)
         return self.search_prepared(limit, offset)
+
+    def count(self, queries):
+        """Searcher::search(&query, &Count) for a batch: alive matching docs over all segments."""
+        self.prepare(queries)
+        out = np.zeros(max(1, len(queries)), np.uint64)
+        _check(lib().tqh_count_prepared(self._s, out.ctypes.data_as(C.POINTER(C.c_uint64))), host=True)
+        return out[: len(queries)]
 
     # ---- raw C ABI access (parity tests)
     def segment_raw(self, segment_ord=0):

@@ -251,6 +251,16 @@ uint32_t tqh_term_handle(tqh_searcher *s, uint32_t segment_ord, uint32_t term_id
   return h;
 }
 
+// Searcher::search(&query, &Count) of the prepared batch: counts[q] = alive matching docs over
+// all segments.
+int tqh_count_prepared(tqh_searcher *s, uint64_t *counts) {
+  return guard([&] {
+    if (!s || !s->searcher || !counts) throw TantivyError(TantivyError::InvalidArgument, "null argument");
+    const std::vector<uint64_t> c = s->searcher->count_batch(s->prepared);
+    if (!c.empty()) std::memcpy(counts, c.data(), c.size() * sizeof(uint64_t));
+  });
+}
+
 // ---- TermInfoStore (src/termdict/fst_termdict/term_info_store.rs)
 struct tqh_term_info_store {
   TermInfoStore store;

@@ -233,6 +233,18 @@ void Searcher::collect_segment_batch(size_t segment_ord, const std::vector<Weigh
   if (rc != TQ_OK) throw_tq(rc);
 }
 
+std::vector<uint64_t> Searcher::count_batch(const std::vector<Weight> &weights) {
+  std::vector<uint64_t> total(weights.size(), 0);
+  std::vector<uint32_t> per(weights.size());
+  for (auto &seg : segments_) {
+    SegmentBatch b(*seg, weights, 1);
+    const int rc = tq_count_batch(seg->raw(), b.qs.data(), (uint32_t)weights.size(), per.data());
+    if (rc != TQ_OK) throw_tq(rc);
+    for (size_t i = 0; i < per.size(); ++i) total[i] += per[i];
+  }
+  return total;
+}
+
 void Searcher::collect_segment_batch_device(size_t segment_ord, const std::vector<Weight> &weights,
                                             uint32_t k, float *d_scores, uint32_t *d_docs,
                                             uint32_t *d_counts, void *hip_stream) {

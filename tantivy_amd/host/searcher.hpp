@@ -179,6 +179,9 @@ class Searcher {
   // Searcher::search (searcher.rs:180-238) for one query / a batch of queries
   Fruit search(const Query &query, const TopDocs &collector);
   std::vector<Fruit> search_batch(const std::vector<Weight> &weights, const TopDocs &collector);
+  // Searcher::search(&query, &Count) for a batch (count_collector.rs:39-80: per-segment counts of
+  // alive matching docs, summed by merge_fruits)
+  std::vector<uint64_t> count_batch(const std::vector<Weight> &weights);
   // collect_segment for a batch on one segment: per-segment top-(offset+limit), sorted
   void collect_segment_batch(size_t segment_ord, const std::vector<Weight> &weights, uint32_t k,
                              std::vector<float> &scores, std::vector<uint32_t> &docs,

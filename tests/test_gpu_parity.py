@@ -496,6 +496,11 @@ def test_deletes_and_counts(ta):
             d, _ = O.match_all(seg, terms, mode)
             assert c == sum(1 for doc in d.tolist() if doc not in deleted), (mode, terms)
         dev.set_option("exhaustive", 1)
+        # the Count collector through the host mirror (Searcher::search(&query, &Count))
+        got_counts = dev.count(queries)
+        for (mode, terms), c in zip(queries, got_counts.tolist()):
+            d, _ = O.match_all(seg, terms, mode)
+            assert c == sum(1 for doc in d.tolist() if doc not in deleted), (mode, terms)
         # clearing the bitset restores the plain results
         dev.set_alive_bitset(None)
         got = _device_topk(dev, queries[:2], 10)
