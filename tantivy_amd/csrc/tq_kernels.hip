@@ -324,6 +324,13 @@ __device__ __forceinline__ float bm25(float weight, float norm, uint32_t tf) {
   return weight * (f / (f + norm));  // bm25.rs:179-193; compiled with -ffp-contract=off
 }
 
+// The same quantity for threshold tests only: v_rcp_f32 (1 ulp) instead of the IEEE division
+// sequence.  Three roundings of <= 1 ulp each: callers widen the bound by 1.000002 (> 16 ulp).
+__device__ __forceinline__ float bm25_bound(float weight, float norm, uint32_t tf) {
+  const float f = (float)tf;
+  return weight * (f * __builtin_amdgcn_rcpf(f + norm));
+}
+
 // ------------------------------------------------------------------ top-k keys
 // key = sortable(score) << 32 | ~doc : larger key == (higher score, then lower doc)
 __device__ __forceinline__ uint64_t make_key(float score, uint32_t doc) {
@@ -456,6 +463,14 @@ __device__ __forceinline__ float block_max_score(uint32_t meta, float w, const f
   if (meta == META_TAIL || !has_freq || tfc == 0u) return w;
   const uint32_t tf = tfc == 255u ? 0xFFFFFFFFu : tfc;  // skip.rs:31-43
   return bm25(w, cache[(meta >> 16) & 0xFFu], tf);
+}
+// block_max_score for threshold tests (see bm25_bound)
+__device__ __forceinline__ float block_max_bound(uint32_t meta, float w, const float *cache,
+                                                 uint32_t has_freq) {
+  const uint32_t tfc = meta >> 24;
+  if (meta == META_TAIL || !has_freq || tfc == 0u) return w;
+  const uint32_t tf = tfc == 255u ? 0xFFFFFFFFu : tfc;
+  return bm25_bound(w, cache[(meta >> 16) & 0xFFu], tf);
 }
 // k-th largest of the 64*S per-lane values (0 = empty slot); 0 if fewer than k are set.
 // Radix select: the largest x with |{v >= x}| >= k, one bit per step.
@@ -709,7 +724,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_num_sgpr(80))) void and_k
       loc = L.q2_loc[base + lane];
       norm = L.cache[fieldnorm_id(seg, doc)];
     }
-    float s = bm25(w_lead, norm, tf);
+    float s = 0.0f;
     {
       uint32_t jb = loc, at = NOT_FOUND;
       uint2 mo = make_uint2(0u, 0u);
@@ -719,10 +734,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_num_sgpr(80))) void and_k
       }
       if (alive) mo = rec_mo(t1.rec[jb]);
       if (prune && alive) {  // block_wand_intersection.rs:144-165
-        float ub = s + block_max_score(mo.x, w1, L.cache, t1.has_freq);
-        if (nt > 2u) ub = (ub + rest_after1) * 1.000001f;
-        alive = sortable(ub) >= thr;
+        // 96 % of the candidates end here: the test runs on reciprocal-based bounds, the exact
+        // (IEEE-divided) leader score is only computed for the survivors
+        float ub = bm25_bound(w_lead, norm, tf) + block_max_bound(mo.x, w1, L.cache, t1.has_freq);
+        if (nt > 2u) ub = ub + rest_after1;
+        alive = sortable(ub * 1.000002f) >= thr;
       }
+      s = bm25(w_lead, norm, tf);
       if constexpr (!DENSE) {
         if (!t1.dense) {
           at = find_in_blocks<USE_DPP>(idx, t1, jb, doc, alive, L, lane);
