@@ -186,9 +186,15 @@ def main():
     torch.cuda.synchronize()
     t_start = time.perf_counter()
     dev.last_batch_stats()  # start a fresh timing window
+    trace = [] if os.environ.get("BENCH_TRACE") else None
     for _ in range(args.steps):
         enqueue()  # steps are pipelined: one synchronisation closes the timed region
+        if trace is not None:
+            trace.append(time.perf_counter() - t_start)
     torch.cuda.synchronize()
+    if trace is not None:
+        trace.append(time.perf_counter() - t_start)
+        print("enqueue returns / final sync (ms):", [round(x * 1e3, 2) for x in trace], file=sys.stderr)
     if world > 1:
         dist.barrier()
     elapsed = time.perf_counter() - t_start
