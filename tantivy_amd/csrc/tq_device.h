@@ -66,7 +66,9 @@ struct TqdQuery {
   // MustNot terms | optional Should terms]
   uint32_t roles;       // 2 bits per term, TQD_ROLE_*
   uint32_t clause_end;  // bit m: term m is the last term of its Must clause (a union of terms)
-  uint32_t n_lead;      // terms of the leader clause: each leads its own run of tiles
+  uint32_t n_lead;      // terms of the leader set: each leads its own run of tiles
+  uint32_t n_opt_lead;  // the first n_opt_lead leaders are optional Should lists; the rest of
+                        // the leader set is the cheapest Must clause (0: the set is one clause)
   uint32_t min_should;  // Should terms that have to match (minimum_number_should_match)
 };
 

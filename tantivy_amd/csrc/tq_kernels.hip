@@ -1367,7 +1367,7 @@ __device__ __forceinline__ void union_body(const TqkScanParams &p) {
   uint32_t q_tile_start = 0, q_tile_end = 0;
   const TqdQuery *Q = nullptr;
   uint32_t nt = 0, tile_blocks = TQD_AND_TILE, n_slot_rows = 1;
-  uint32_t roles = 0, clause_end = 0, n_lead = 0, min_should = 0;
+  uint32_t roles = 0, clause_end = 0, n_lead = 0, n_opt_lead = 0, min_should = 0;
   bool prune = false;
   uint32_t *slots = nullptr;
   uint32_t thr = 0, thr_g = 0;
@@ -1407,6 +1407,7 @@ __device__ __forceinline__ void union_body(const TqkScanParams &p) {
       roles = sload(&Q->roles);
       clause_end = sload(&Q->clause_end);
       n_lead = sload(&Q->n_lead);
+      n_opt_lead = sload(&Q->n_opt_lead);
       min_should = sload(&Q->min_should);
     } else {  // pure union: one leading clause of Should terms
       n_lead = nt;
@@ -1444,14 +1445,23 @@ __device__ __forceinline__ void union_body(const TqkScanParams &p) {
       s = bm25(w_lead, norm, tf);
       if (prune) alive = sortable((s + L.suffix[li + 1u]) * 1.000001f) >= thr;
     }
-    // The leader clause is a union of n_lead lists (a pure union: all the Should terms; with Must
-    // clauses: the cheapest one): a doc is scored by the tile of the first list of the clause that
-    // holds it.  Then come the other Must clauses (each a union of terms; cheapest first, summed
-    // as Intersection::score does: left + right + sum(others), intersection.rs:325-329), the
-    // MustNot terms (Exclude, exclude.rs) and the optional Should terms
+    // The leader set is a union of n_lead lists: a doc is scored by the tile of the first list of
+    // the set that holds it.  Pure unions: all the Should terms.  With Must clauses: the cheapest
+    // Must clause, preceded (n_opt_lead) by the optional Should lists in weight order — MaxScore
+    // for RequiredOptionalScorer: a Should list drives the docs it holds (which must also be in the
+    // Must clause), the Must clause drives the rest with a bound that no longer carries the
+    // Should weights, and its tiles die once the threshold passes what the Must part alone can
+    // score.  Then come the other Must clauses (each a union of terms; cheapest first, summed as
+    // Intersection::score does: left + right + sum(others), intersection.rs:325-329), the MustNot
+    // terms (Exclude, exclude.rs) and the remaining optional Should terms
     // (RequiredOptionalScorer::score = req + opt, reqopt_scorer.rs:85-98).
     float opt = 0.0f, oth = 0.0f, csum = 0.0f;
     bool cfound = false;
+    bool lcfound = !BOOL || li >= n_opt_lead;  // the lead Must clause holds the doc
+    if (BOOL && li < n_opt_lead) {             // an optional list leads: its score is optional
+      opt = s;
+      s = 0.0f;
+    }
     uint32_t clause = 1u;
     uint32_t n_should = ((roles >> (2u * li)) & 3u) == TQD_ROLE_SHOULD ? 1u : 0u;
     // lists after the leader first (they add to the score and tighten the bound), the lists
@@ -1498,10 +1508,18 @@ __device__ __forceinline__ void union_body(const TqkScanParams &p) {
         if (found) alive = false;
       } else if (!BOOL || m < n_lead) {
         if (found) {
-          if (m < li) alive = false;  // this doc is scored by list m's tile
-          s = s + sc;
-          if (role == TQD_ROLE_SHOULD) ++n_should;
+          if (m < li) {
+            alive = false;  // this doc is scored by list m's tile
+          } else if (BOOL && m < n_opt_lead) {
+            opt = opt + sc;
+            ++n_should;
+          } else {
+            s = s + sc;
+            lcfound = true;
+            if (role == TQD_ROLE_SHOULD) ++n_should;
+          }
         }
+        if (BOOL && m + 1u == n_lead && !lcfound) alive = false;  // not in the lead Must clause
       } else if (role == TQD_ROLE_MUST) {
         cfound = cfound || found;
         if (found) csum = csum + sc;
