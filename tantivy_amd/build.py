@@ -8,7 +8,10 @@ import subprocess
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB = os.path.join(HERE, "lib", "libtantivy_amd.so")
 SOURCES = [
-    os.path.join(HERE, "csrc", "tq_kernels.hip"),
+    os.path.join(HERE, "csrc", "tq_and.hip"),
+    os.path.join(HERE, "csrc", "tq_union.hip"),
+    os.path.join(HERE, "csrc", "tq_phrase.hip"),
+    os.path.join(HERE, "csrc", "tq_misc.hip"),
     os.path.join(HERE, "csrc", "tq_encode.hip"),
     os.path.join(HERE, "csrc", "tq_api.cpp"),
     os.path.join(HERE, "host", "searcher.cpp"),
@@ -16,6 +19,7 @@ SOURCES = [
     os.path.join(HERE, "host", "term_info_store.cpp"),
 ]
 HEADERS = [
+    os.path.join(HERE, "csrc", "tq_common.hpp"),
     os.path.join(HERE, "csrc", "tq_device.h"),
     os.path.join(HERE, "csrc", "tq_launch.h"),
     os.path.join(HERE, "host", "searcher.hpp"),
@@ -24,8 +28,8 @@ HEADERS = [
     os.path.join(os.path.dirname(HERE), "include", "tantivy_amd.h"),
     os.path.join(os.path.dirname(HERE), "include", "tantivy_amd_host.h"),
 ]
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared",
-         "-Wall"]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-Wall"]
+OBJ_DIR = os.path.join(HERE, "lib", "obj")
 
 
 def up_to_date():
@@ -36,13 +40,28 @@ def up_to_date():
 
 
 def build(force=False, verbose=False):
+    """One hipcc -c per translation unit, in parallel (the kernel families dominate: ~45 s each),
+    then one link."""
     if not force and up_to_date():
         return LIB
+    from concurrent.futures import ThreadPoolExecutor
+
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     if not os.path.exists(hipcc):
         hipcc = "hipcc"
-    os.makedirs(os.path.dirname(LIB), exist_ok=True)
-    cmd = [hipcc] + FLAGS + ["-o", LIB] + SOURCES
+    os.makedirs(OBJ_DIR, exist_ok=True)
+    objs = [os.path.join(OBJ_DIR, os.path.basename(src) + ".o") for src in SOURCES]
+
+    def compile_one(pair):
+        src, obj = pair
+        cmd = [hipcc] + FLAGS + ["-c", src, "-o", obj]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
+
+    with ThreadPoolExecutor(max_workers=min(len(SOURCES), os.cpu_count() or 1)) as pool:
+        list(pool.map(compile_one, zip(SOURCES, objs)))
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)

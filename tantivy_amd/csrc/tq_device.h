@@ -1,5 +1,5 @@
 // tq_device.h — structures shared by the host planner (tq_api.cpp) and the gfx950 kernels
-// (tq_kernels.hip).  Layouts are fixed (uploaded as raw bytes).
+// (tq_common.hpp and the kernel files).  Layouts are fixed (uploaded as raw bytes).
 #pragma once
 #include <stdint.h>
 #include <hip/hip_runtime.h>

@@ -1,4 +1,4 @@
-// tq_launch.h — kernel parameter blocks and launch entry points (tq_kernels.hip <-> tq_api.cpp)
+// tq_launch.h — kernel parameter blocks and launch entry points (tq_*.hip <-> tq_api.cpp)
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>

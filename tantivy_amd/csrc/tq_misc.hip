@@ -1,0 +1,188 @@
+// tq_misc.hip — top-k merge kernels and whole-list decode (codec parity, bitmap construction).
+// Shared device helpers: tq_common.hpp.
+#include "tq_common.hpp"
+
+namespace {
+
+// =================================================================== merge kernel
+// One wavefront per query: reduce its partial lists to the final top-k, sorted.
+template <int KPL>
+__global__ __launch_bounds__(64) void merge_kernel(TqkMergeParams p) {
+  const int lane = (int)__lane_id();
+  const uint32_t q = blockIdx.x;
+  if (q >= p.n_queries) return;
+  const TqdQuery *Q = uni_ptr(p.queries + q);
+  const uint32_t k = uni(Q->k);
+  const uint32_t part_start = uni(Q->part_start), n_parts = uni(Q->n_parts);
+  TopK<KPL> tk;
+  tk.reset(k);
+  // a full partial list's k-th key is a lower bound of the final k-th key: the largest of them
+  // (one 8-byte load per list, 64 lists at a time) keeps almost every other key out of the
+  // serial insertions below
+  uint64_t floor_key = 0;
+  for (uint32_t pi = (uint32_t)lane; pi < n_parts; pi += WAVE) {
+    const uint64_t kth = p.partials[(uint64_t)(part_start + pi) * (uint64_t)(KPL * 64) + (k - 1u)];
+    floor_key = kth > floor_key ? kth : floor_key;
+  }
+  for (int o = 32; o; o >>= 1) {
+    const uint64_t other = ((uint64_t)(uint32_t)__shfl_xor((int)(floor_key >> 32), o, WAVE) << 32) |
+                           (uint32_t)__shfl_xor((int)(uint32_t)floor_key, o, WAVE);
+    floor_key = other > floor_key ? other : floor_key;
+  }
+  // the loads of a group of lists are issued together (one wavefront walks hundreds of lists:
+  // one round trip per list was the whole cost of this kernel)
+  constexpr uint32_t GROUP = KPL <= 2 ? 8u : (KPL <= 4 ? 4u : 1u);
+  for (uint32_t pi0 = 0; pi0 < n_parts; pi0 += GROUP) {
+    uint64_t keys[GROUP][KPL];
+#pragma unroll
+    for (uint32_t g = 0; g < GROUP; ++g) {
+      const uint32_t pi = pi0 + g < n_parts ? pi0 + g : n_parts - 1u;  // clamped: unconditional loads
+      const uint64_t *src = p.partials + (uint64_t)(part_start + pi) * (uint64_t)(KPL * 64);
+#pragma unroll
+      for (int r = 0; r < KPL; ++r) keys[g][r] = src[(uint32_t)r * 64u + (uint32_t)lane];
+    }
+#pragma unroll
+    for (uint32_t g = 0; g < GROUP; ++g) {
+      if (pi0 + g >= n_parts) break;
+#pragma unroll
+      for (int r = 0; r < KPL; ++r)
+        tk.offer(keys[g][r] != 0ull && keys[g][r] >= floor_key, keys[g][r], lane);
+    }
+  }
+  const uint32_t out_q = p.out_index ? p.out_index[q] : q;
+  uint32_t count = 0;
+#pragma unroll
+  for (int r = 0; r < KPL; ++r) {
+    const uint32_t rank = (uint32_t)r * 64u + (uint32_t)lane;
+    const bool real = rank < k && tk.v[r] != 0ull;
+    count += (uint32_t)__popcll(__ballot(real));
+    if (rank < p.out_stride) {
+      p.out_scores[(uint64_t)out_q * p.out_stride + rank] = real ? key_score(tk.v[r]) : 0.0f;
+      p.out_docs[(uint64_t)out_q * p.out_stride + rank] = real ? key_doc(tk.v[r]) : TQD_TERMINATED;
+    }
+  }
+  for (uint32_t rank = (uint32_t)(KPL * 64) + (uint32_t)lane; rank < p.out_stride; rank += 64u) {
+    p.out_scores[(uint64_t)out_q * p.out_stride + rank] = 0.0f;
+    p.out_docs[(uint64_t)out_q * p.out_stride + rank] = TQD_TERMINATED;
+  }
+  if (lane == 0) p.out_counts[out_q] = count;
+}
+
+// =================================================================== whole-list decode (codec parity)
+template <bool USE_DPP>
+__global__ __launch_bounds__(256) void decode_list_kernel(TqdSegment seg, const TqdTerm *terms,
+                                                          uint32_t handle, uint32_t *docs,
+                                                          uint32_t *tfs) {
+  const int lane = (int)__lane_id();
+  const uint32_t wave = uni(threadIdx.x >> 6);
+  const TermRef t = load_term(terms, handle);
+  const uint32_t j = blockIdx.x * 4u + wave;
+  if (j >= t.n_blocks) return;
+  const Dec d = decode_block<USE_DPP, false>(uni_ptr(seg.idx), t, j, lane);
+  const uint32_t i0 = j * 128u + 2u * (uint32_t)lane;
+  const uint32_t df = uni(terms[handle].doc_freq);
+  if (i0 < df) {
+    docs[i0] = d.d0;
+    tfs[i0] = d.t0;
+  }
+  if (i0 + 1u < df) {
+    docs[i0 + 1u] = d.d1;
+    tfs[i0 + 1u] = d.t1;
+  }
+}
+
+__global__ void decode_positions_kernel(TqdSegment seg, const TqdTerm *terms, uint32_t handle,
+                                        uint32_t *out, uint64_t n) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  out[i] = position_delta(seg.pos, terms + handle, i);
+}
+
+// =================================================================== cross-segment merge
+// merge_top_k (sort_key_top_collector.rs:76-95): key = (score desc, segment_ord asc, doc asc).
+// One wavefront per query; S*stride candidates; selection by repeated max (k <= 1024, tiny).
+__global__ __launch_bounds__(64) void merge_segments_kernel(TqkSegMergeParams p) {
+  const int lane = (int)__lane_id();
+  const uint32_t q = blockIdx.x;
+  if (q >= p.n_queries) return;
+  const uint32_t total = p.n_segments * p.stride;
+  const uint32_t want = p.offset + p.limit;
+  // Each output rank r: the candidate with exactly r candidates ordered before it.
+  // O(total^2 / 64) compares per query; total is S*k (e.g. 8*10).
+  uint32_t n_valid = 0;
+  for (uint32_t s = 0; s < p.n_segments; ++s) n_valid += p.counts[(uint64_t)s * p.n_queries + q];
+  for (uint32_t c = (uint32_t)lane; c < total; c += 64u) {
+    const uint32_t s = c / p.stride, i = c % p.stride;
+    const uint32_t cnt = p.counts[(uint64_t)s * p.n_queries + q];
+    if (i >= cnt) continue;
+    const uint64_t at = ((uint64_t)s * p.n_queries + q) * p.stride + i;
+    const float sc = p.scores[at];
+    const uint32_t dc = p.docs[at];
+    const uint32_t so = p.segment_ords ? p.segment_ords[s] : s;
+    uint32_t before = 0;
+    for (uint32_t s2 = 0; s2 < p.n_segments; ++s2) {
+      const uint32_t cnt2 = p.counts[(uint64_t)s2 * p.n_queries + q];
+      const uint32_t so2 = p.segment_ords ? p.segment_ords[s2] : s2;
+      const uint64_t b2 = ((uint64_t)s2 * p.n_queries + q) * p.stride;
+      for (uint32_t i2 = 0; i2 < cnt2; ++i2) {
+        const float sc2 = p.scores[b2 + i2];
+        const uint32_t dc2 = p.docs[b2 + i2];
+        const bool lt = (sc2 > sc) || (sc2 == sc && (so2 < so || (so2 == so && dc2 < dc)));
+        before += lt ? 1u : 0u;
+      }
+    }
+    if (before >= p.offset && before < want) {
+      const uint64_t o = (uint64_t)q * p.limit + (before - p.offset);
+      p.out_scores[o] = sc;
+      p.out_segment_ords[o] = so;
+      p.out_docs[o] = dc;
+    }
+  }
+  const uint32_t got = n_valid > p.offset ? (n_valid - p.offset < p.limit ? n_valid - p.offset : p.limit) : 0u;
+  for (uint32_t r = got + (uint32_t)lane; r < p.limit; r += 64u) {
+    const uint64_t o = (uint64_t)q * p.limit + r;
+    p.out_scores[o] = 0.0f;
+    p.out_segment_ords[o] = 0xFFFFFFFFu;
+    p.out_docs[o] = TQD_TERMINATED;
+  }
+  if (lane == 0) p.out_counts[q] = got;
+}
+
+}  // namespace
+
+// =================================================================== launch wrappers
+hipError_t tqk_launch_merge(const TqkMergeParams &p, int kpl, hipStream_t st) {
+  if (p.n_queries == 0) return hipSuccess;
+  const dim3 grid(p.n_queries), block(64);
+  switch (kpl) {
+    case 1: merge_kernel<1><<<grid, block, 0, st>>>(p); break;
+    case 2: merge_kernel<2><<<grid, block, 0, st>>>(p); break;
+    case 4: merge_kernel<4><<<grid, block, 0, st>>>(p); break;
+    default: merge_kernel<16><<<grid, block, 0, st>>>(p); break;
+  }
+  return hipGetLastError();
+}
+hipError_t tqk_launch_decode_list(const TqdSegment &seg, const TqdTerm *terms, uint32_t handle,
+                                  uint32_t n_blocks, uint32_t *docs, uint32_t *tfs, bool use_dpp,
+                                  hipStream_t st) {
+  if (n_blocks == 0) return hipSuccess;
+  const dim3 grid((n_blocks + 3) / 4), block(256);
+  if (use_dpp)
+    hipLaunchKernelGGL((decode_list_kernel<true>), grid, block, 0, st, seg, terms, handle, docs, tfs);
+  else
+    hipLaunchKernelGGL((decode_list_kernel<false>), grid, block, 0, st, seg, terms, handle, docs, tfs);
+  return hipGetLastError();
+}
+hipError_t tqk_launch_decode_positions(const TqdSegment &seg, const TqdTerm *terms,
+                                       uint32_t handle, uint32_t *out, uint64_t n,
+                                       hipStream_t st) {
+  if (n == 0) return hipSuccess;
+  hipLaunchKernelGGL(decode_positions_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st,
+                     seg, terms, handle, out, n);
+  return hipGetLastError();
+}
+hipError_t tqk_launch_merge_segments(const TqkSegMergeParams &p, hipStream_t st) {
+  if (p.n_queries == 0) return hipSuccess;
+  hipLaunchKernelGGL(merge_segments_kernel, dim3(p.n_queries), dim3(64), 0, st, p);
+  return hipGetLastError();
+}

@@ -1,0 +1,755 @@
+// tq_union.hip — unions and boolean queries: or_kernel (4096-doc windows) and union_kernel (candidate-driven).
+// Shared device helpers: tq_common.hpp.
+#include "tq_common.hpp"
+
+namespace {
+
+// =================================================================== OR kernel
+// Union with MaxScore pruning, the window-parallel form of block_wand
+// (src/query/boolean_query/block_wand_union.rs:16-265) and BufferedUnionScorer
+// (src/query/union/buffered_union.rs:63-158).  Terms are ordered by weight DESCENDING (the weight
+// bounds a term's score: tf/(tf+norm) < 1).  One workgroup = one chunk of consecutive 4096-doc
+// windows (HORIZON, buffered_union.rs:11-12).  Per window:
+//   * the suffix of terms that are dense (bitmap) and whose weights together stay below the
+//     threshold is NON-ESSENTIAL: a doc found only in those lists cannot reach the top-k, so
+//     their postings are never enumerated (find_pivot_doc's prefix rule, :16-43, with the
+//     reference's per-doc pivot replaced by a per-window one);
+//   * the other (essential) lists are decoded block by block, scored and summed into f32
+//     accumulators in LDS, the 4 waves splitting each list's blocks;
+//   * every present doc whose partial score plus the non-essential weights can reach the
+//     threshold is compacted into a per-wave queue; batches of 64 probe the non-essential lists'
+//     bitmaps in order (one 8-byte load = membership + posting index -> tf), stopping as soon as
+//     the remaining weights cannot lift the score over the threshold (:49-80);
+//   * survivors are offered to the wave's register top-k and published to the query's threshold
+//     slots (same scheme as the AND kernel; 64 slots for k <= 64, 128 for k <= 128).
+// Scores are summed in term order in both modes, so pruned and exhaustive runs are bit-identical;
+// against the reference the sum order of 3+ terms is not canonical (1e-5 relative).
+template <bool PRUNE>
+struct OrLds {
+  float acc[TQD_OR_WINDOW];
+  uint32_t present[TQD_OR_WINDOW / 32];
+  float cache[256];
+  float suffix[TQD_MAX_TERMS + 1];  // suffix[m] = sum of the weights of terms m..
+  uint32_t thr_shared;
+  // first block of every list for 64 consecutive windows (+1): planned lane-parallel once per
+  // 64 windows, so the per-window loops carry no dependent seek
+  uint32_t wj[TQD_MAX_TERMS][65];
+  uint32_t cq_doc[PRUNE ? TQD_WAVES_PER_WG : 1][127];  // per-wave candidate queue
+  uint32_t cq_s[PRUNE ? TQD_WAVES_PER_WG : 1][127];
+};
+
+template <int KPL, bool PRUNE>
+__global__ __launch_bounds__(TQD_WAVES_PER_WG * 64) void or_kernel(TqkScanParams p) {
+  constexpr bool USE_DPP = true;
+  __shared__ OrLds<PRUNE> L;
+  const int lane = (int)__lane_id();
+  const uint32_t wave = uni(threadIdx.x >> 6);
+  const uint32_t tid = threadIdx.x;
+  if (blockIdx.x >= p.n_chunks) return;
+  const uint32_t chunk = blockIdx.x;
+  const uint32_t t_begin = sload(p.chunk_starts + chunk);
+  const uint32_t t_end = sload(p.chunk_starts + chunk + 1u);
+
+  const TqdSegment seg = p.seg;
+  const uint8_t *idx = seg.idx;
+  uint32_t q = uni(find_query(p.tile_starts, p.n_queries, t_begin));
+  uint32_t q_tile_start = 0, q_tile_end = 0;
+  const TqdQuery *Q = nullptr;
+  uint32_t nt = 0, dense_mask = 0, n_slot_rows = 0;
+  bool prune = false, query_done = false;
+  uint32_t *slots = nullptr;
+  uint32_t thr = 0, thr_g = 0;
+  uint32_t cache_loaded = 0xFFFFFFFFu;
+  TopK<KPL> tk;
+  uint32_t n_matches = 0, n_q = 0;  // docs scored: whole chunk / current query
+  uint32_t cqn = 0;  // this wave's candidate queue fill
+  uint32_t plan_begin = 0xFFFFFFFFu, plan_end = 0;  // windows [plan_begin, plan_end) are planned
+
+  auto setup_query = [&]() __attribute__((always_inline)) {
+    q_tile_start = sload(p.tile_starts + q);
+    q_tile_end = sload(p.tile_starts + q + 1u);
+    Q = p.queries + q;
+    nt = sload(&Q->n_terms);
+    prune = PRUNE && (sload(&Q->flags) & TQD_QF_PRUNE) != 0u;
+    const uint32_t thr_index = sload(&Q->thr_index);
+    const uint32_t k = sload(&Q->k);
+    n_slot_rows = k <= 64u ? 1u : 2u;
+    slots = (prune && thr_index != 0xFFFFFFFFu) ? p.thr_slots + (size_t)thr_index * TQD_THR_SLOTS
+                                                : nullptr;
+    const uint32_t ci = sload(&Q->cache_idx);
+    __syncthreads();  // nobody still reads the previous query's cache / suffix sums
+    if (ci != cache_loaded) {
+      const float *cg = p.caches + (size_t)ci * 256u;
+      for (uint32_t i = tid; i < 256u; i += TQD_WAVES_PER_WG * 64) L.cache[i] = cg[i];
+      cache_loaded = ci;
+    }
+    dense_mask = 0;
+    float suf = 0.0f;
+    if (tid == 0) {
+      L.suffix[nt] = 0.0f;
+      L.thr_shared = 0u;
+    }
+    for (uint32_t m = nt; m-- > 0u;) {
+      suf += sload(&Q->weight[m]);
+      if (tid == 0) L.suffix[m] = suf;
+      const TermRef tr = load_term(p.terms, sload(&Q->term[m]));
+      if (tr.dense && p.use_dense) dense_mask |= 1u << m;
+    }
+    __syncthreads();
+    thr = 0;
+    thr_g = 0;
+    query_done = false;
+    plan_begin = 0xFFFFFFFFu;
+    plan_end = 0;
+    tk.reset(k);
+  };
+
+  // probe the non-essential lists [E, nt) for a batch of <= 64 candidates (one per lane)
+  auto probe_batch = [&](uint32_t n, uint32_t E) __attribute__((always_inline)) {
+    const uint32_t base = cqn - n;
+    cqn = base;
+    bool alive = (uint32_t)lane < n;
+    uint32_t doc = 0;
+    float s = 0.0f, norm = 0.0f;
+    if (alive) {
+      doc = L.cq_doc[PRUNE ? wave : 0][base + lane];
+      s = __uint_as_float(L.cq_s[PRUNE ? wave : 0][base + lane]);
+      norm = L.cache[fieldnorm_id(seg, doc)];
+    }
+    for (uint32_t m = E; m < nt; ++m) {
+      if (alive) alive = sortable((s + L.suffix[m]) * 1.000001f) >= thr;
+      if (!__ballot(alive)) break;
+      const TermRef tr = load_term(p.terms, sload(&Q->term[m]));
+      const float w = sload(&Q->weight[m]);
+      if (alive) {
+        const uint2 wd = tr.dense[doc >> 5];
+        const uint32_t bit = doc & 31u;
+        if ((wd.x >> bit) & 1u) {
+          const uint32_t pi = wd.y + (uint32_t)__popc(wd.x & ((1u << bit) - 1u));
+          const uint4 r = tr.rec[pi >> 7];
+          s = s + bm25(w, norm, block_tf_at(idx, tr, make_uint2(r.y, r.z), pi & 127u));
+        }
+      }
+    }
+    if (alive) alive = doc_is_alive(seg, doc);
+    const uint64_t hit = __ballot(alive);
+    if (hit) {
+      n_matches += (uint32_t)__popcll(hit);
+      n_q += (uint32_t)__popcll(hit);
+      const uint64_t key = alive ? make_key(s, doc) : 0ull;
+      if (slots) {
+        const uint32_t sb = (uint32_t)(key >> 32);
+        const uint32_t h = (doc * 0x9E3779B1u) >> (n_slot_rows == 1u ? 26 : 25);
+        if (alive && sb > thr_g) atomicMax(slots + h, sb);
+      }
+      tk.offer(alive, key, lane);
+      const uint32_t own = (uint32_t)(tk.thr >> 32);
+      if (own > thr) thr = own;
+    }
+  };
+
+  setup_query();
+  for (uint32_t t = t_begin; t < t_end; ++t) {
+    while (t >= q_tile_end) {
+      if (q_tile_end > q_tile_start && q_tile_end > t_begin) {
+        const uint32_t part = sload(&Q->part_start) +
+                              (chunk - sload(&Q->chunk_first)) * TQD_WAVES_PER_WG + wave;
+        flush_partial<KPL>(tk, sload(&p.sinks->partials), part, lane);
+        if (lane == 0 && n_q) atomicAdd(sload(&p.sinks->query_matches) + sload(sload(&p.sinks->out_index) + q), n_q);
+        n_q = 0;
+      }
+      ++q;
+      setup_query();
+    }
+    if (query_done) continue;  // the weights of all lists together are below the threshold
+    const uint32_t base = (t - q_tile_start) * TQD_OR_WINDOW;
+    const uint32_t win_hi = base + (TQD_OR_WINDOW - 1u);
+    if (t >= plan_end || t < plan_begin) {  // plan the next 64 windows: one lane per window
+      __syncthreads();
+      plan_begin = t;
+      plan_end = t + 64u;
+      for (uint32_t m = wave; m < nt; m += TQD_WAVES_PER_WG) {
+        const TermRef tr = load_term(p.terms, sload(&Q->term[m]));
+        const uint64_t b0 = (uint64_t)base + (uint64_t)lane * TQD_OR_WINDOW;
+        L.wj[m][lane] = b0 < seg.max_doc ? seek_block(tr, (uint32_t)b0) : tr.n_blocks;
+        if (lane == 0) {
+          const uint64_t b64 = (uint64_t)base + 64ull * TQD_OR_WINDOW;
+          L.wj[m][64] = b64 < seg.max_doc ? seek_block(tr, (uint32_t)b64) : tr.n_blocks;
+        }
+      }
+      __syncthreads();
+    }
+    const uint32_t wl = t - plan_begin;
+
+    // threshold: wave 0 reads the shared slots, everybody takes max(shared, own k-th key)
+    if (slots && wave == 0u) {
+      uint32_t sv[2] = {0u, 0u};
+      sv[0] = __hip_atomic_load(slots + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      uint32_t g;
+      if (n_slot_rows == 2u) {
+        sv[1] = __hip_atomic_load(slots + 64 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        g = kth_largest_multi<2>(sv, tk.k);
+      } else {
+        g = kth_largest64(sv[0], tk.k);
+      }
+      if (lane == 0) L.thr_shared = g;
+    }
+    for (uint32_t i = tid; i < TQD_OR_WINDOW / 4; i += TQD_WAVES_PER_WG * 64)
+      reinterpret_cast<float4 *>(L.acc)[i] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    if (tid < TQD_OR_WINDOW / 32) L.present[tid] = 0u;
+    __syncthreads();
+    if (slots) {
+      thr_g = L.thr_shared;  // (stays from the last refresh in between)
+      if (thr_g > thr) thr = thr_g;
+    }
+    // all 4 waves must agree on E: use the shared threshold only (own thresholds differ)
+    uint32_t E = nt;
+    if (prune) {
+      const uint32_t thr_w = slots ? thr_g : 0u;
+      for (uint32_t m = nt; m-- > 0u;) {
+        if (((dense_mask >> m) & 1u) && sortable(L.suffix[m] * 1.000001f) < thr_w)
+          E = m;
+        else
+          break;
+      }
+      if (E == 0u) {  // no doc of this query can reach the top-k any more
+        query_done = true;
+        __syncthreads();
+        continue;
+      }
+    }
+
+    // ---- essential lists: decode, score, accumulate (term order = score sum order)
+    for (uint32_t m = 0; m < E; ++m) {
+      const TermRef tr = load_term(p.terms, sload(&Q->term[m]));
+      const float w = sload(&Q->weight[m]);
+      // blocks [first block reaching into this window, first block reaching into the next one]
+      const uint32_t jb = uni(L.wj[m][wl]);
+      uint32_t je = uni(L.wj[m][wl + 1u]);
+      if (je >= tr.n_blocks) je = tr.n_blocks ? tr.n_blocks - 1u : 0u;
+      for (uint32_t j = jb + wave; j <= je && j < tr.n_blocks; j += TQD_WAVES_PER_WG) {
+        const Dec d = decode_block<USE_DPP, false>(idx, tr, j, lane);
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+          const uint32_t doc = e ? d.d1 : d.d0;
+          const uint32_t tf = e ? d.t1 : d.t0;
+          if (doc >= base && doc <= win_hi) {
+            const uint32_t o = doc - base;
+            const float s = bm25(w, L.cache[fieldnorm_id(seg, doc)], tf);
+            L.acc[o] = L.acc[o] + s;  // one posting per (term, doc): no intra-phase conflict
+            atomicOr(&L.present[o >> 5], 1u << (o & 31u));
+          }
+        }
+      }
+      __syncthreads();
+    }
+    // ---- harvest
+    const float rest = L.suffix[E];
+    for (uint32_t i = tid; i < TQD_OR_WINDOW; i += TQD_WAVES_PER_WG * 64) {
+      bool has = (L.present[i >> 5] >> (i & 31u)) & 1u;
+      if (has) has = doc_is_alive(seg, base + i);
+      const float s = L.acc[i];
+      if (E == nt) {  // every list was enumerated: final score
+        const uint64_t key = has ? make_key(s, base + i) : 0ull;
+        const uint64_t hit = __ballot(has);
+        if (hit) {
+          n_matches += (uint32_t)__popcll(hit);
+          n_q += (uint32_t)__popcll(hit);
+          if (slots) {
+            const uint32_t sb = (uint32_t)(key >> 32);
+            const uint32_t h = ((base + i) * 0x9E3779B1u) >> (n_slot_rows == 1u ? 26 : 25);
+            if (has && sb > thr_g) atomicMax(slots + h, sb);
+          }
+          tk.offer(has, key, lane);
+          if (prune) {
+            const uint32_t own = (uint32_t)(tk.thr >> 32);
+            if (own > thr) thr = own;
+          }
+        }
+      } else if (PRUNE) {
+        if (has) has = sortable((s + rest) * 1.000001f) >= thr;
+        const uint64_t m = __ballot(has);
+        if (m) {
+          const uint32_t pos = cqn + mbcnt64(m);
+          wave_mem_fence();
+          if (has) {
+            L.cq_doc[PRUNE ? wave : 0][pos] = base + i;
+            L.cq_s[PRUNE ? wave : 0][pos] = __float_as_uint(s);
+          }
+          wave_mem_fence();
+          cqn += (uint32_t)__popcll(m);
+          if (cqn >= 64u) probe_batch(64u, E);
+        }
+      }
+    }
+    if (PRUNE && cqn) probe_batch(cqn, E);
+    __syncthreads();
+  }
+  if (q_tile_end > q_tile_start) {
+    const uint32_t part = sload(&Q->part_start) +
+                          (chunk - sload(&Q->chunk_first)) * TQD_WAVES_PER_WG + wave;
+    flush_partial<KPL>(tk, sload(&p.sinks->partials), part, lane);
+        if (lane == 0 && n_q) atomicAdd(sload(&p.sinks->query_matches) + sload(sload(&p.sinks->out_index) + q), n_q);
+        n_q = 0;
+  }
+  if (lane == 0 && n_matches) atomicAdd(sload(&p.sinks->match_counter), (unsigned long long)n_matches);
+}
+
+// =================================================================== union kernel (candidate-driven)
+// The same union, driven by candidates instead of windows — the form that suits the sparse
+// (high-weight) lists MaxScore keeps essential.  Terms by weight descending.  A tile is a run of
+// blocks of ONE list i ("the leader of the tile"); every doc of the union is scored exactly once,
+// by the tile of the FIRST list that holds it:
+//   * tiles of a list that is non-essential by now (the weights of lists i.. together are below
+//     the threshold) are skipped whole; so are leader blocks whose block-max plus the other
+//     lists' weights cannot reach it (block_wand_union.rs:16-43,49-80);
+//   * stage A decodes a leader block (as in the AND kernel, tf_min integer pre-filter included);
+//   * stage B, 64 candidates per step: probe lists 0..i-1 — found there means the doc belongs to
+//     that list's tile and the candidate is dropped — then lists i+1.. in order, adding their
+//     BM25 terms, with the bound "score so far + remaining weights" checked before every probe.
+//     Dense lists are probed through their bitmap, the others by seek_block + find_in_blocks.
+// The sum runs over the lists holding the doc in ascending list index, whichever mode and
+// threshold history: results are bit-identical across modes and runs.  One wavefront per chunk.
+struct UnionLds {  // per wavefront
+  uint32_t pay[516];
+  uint32_t q1_doc[191], q1_tf[191];
+  float cache[256];
+  float suffix[TQD_MAX_TERMS + 1];
+};
+
+template <int KPL, bool PRUNE, bool BOOL>
+__device__ __forceinline__ void union_body(const TqkScanParams &p) {
+  constexpr bool USE_DPP = true;
+  __shared__ UnionLds L;
+  const int lane = (int)__lane_id();
+  if (blockIdx.x >= p.n_chunks) return;
+  const uint32_t chunk = sload(p.chunk_perm + blockIdx.x);
+  const uint32_t t_begin = sload(p.chunk_starts + chunk);
+  const uint32_t t_end = sload(p.chunk_starts + chunk + 1u);
+  const TqdSegment seg = p.seg;
+  const uint8_t *idx = seg.idx;
+
+  uint32_t q = uni(find_query(p.tile_starts, p.n_queries, t_begin));
+  uint32_t q_tile_start = 0, q_tile_end = 0;
+  const TqdQuery *Q = nullptr;
+  uint32_t nt = 0, tile_blocks = TQD_AND_TILE, n_slot_rows = 1;
+  uint32_t roles = 0, clause_end = 0, n_lead = 0, n_opt_lead = 0, min_should = 0;
+  bool prune = false;
+  uint32_t *slots = nullptr;
+  uint32_t thr = 0, thr_g = 0;
+  uint32_t cache_loaded = 0xFFFFFFFFu;
+  float min_norm = 0.0f;
+  TopK<KPL> tk;
+  uint32_t n_matches = 0, n_q = 0;  // docs scored: whole chunk / current query
+  uint32_t q1n = 0;
+  // leader of the current tile
+  uint32_t li = 0, li_end = 0;
+  bool dead = false;
+  TermRef lead{};
+  float w_lead = 0.0f;
+
+  auto setup_query = [&]() __attribute__((always_inline)) {
+    q_tile_start = sload(p.tile_starts + q);
+    q_tile_end = sload(p.tile_starts + q + 1u);
+    Q = p.queries + q;
+    nt = sload(&Q->n_terms);
+    tile_blocks = sload(&Q->tile_blocks);
+    prune = PRUNE && (sload(&Q->flags) & TQD_QF_PRUNE) != 0u;
+    const uint32_t thr_index = sload(&Q->thr_index);
+    const uint32_t k = sload(&Q->k);
+    // 64 slots hold the top 16 well; beyond that the k-th largest slot is loose (the top k docs
+    // collide): 256 slots (128: still loose at k = 100; 512: no better)
+    n_slot_rows = k <= 16u ? 1u : 4u;
+    slots = (prune && thr_index != 0xFFFFFFFFu) ? p.thr_slots + (size_t)thr_index * TQD_THR_SLOTS
+                                                : nullptr;
+    const uint32_t ci = sload(&Q->cache_idx);
+    wave_mem_fence();
+    if (ci != cache_loaded) {
+      const float *cg = p.caches + (size_t)ci * 256u;
+      for (int i = lane; i < 256; i += WAVE) L.cache[i] = cg[i];
+      cache_loaded = ci;
+    }
+    if (BOOL) {
+      roles = sload(&Q->roles);
+      clause_end = sload(&Q->clause_end);
+      n_lead = sload(&Q->n_lead);
+      n_opt_lead = sload(&Q->n_opt_lead);
+      min_should = sload(&Q->min_should);
+    } else {  // pure union: one leading clause of Should terms
+      n_lead = nt;
+    }
+    // suffix[m]: what the lists m.. can add at most (MustNot lists carry weight 0)
+    float suf = 0.0f;
+    if (lane == 0) L.suffix[nt] = 0.0f;
+    for (uint32_t m = nt; m-- > 0u;) {
+      suf += sload(&Q->weight[m]);
+      if (lane == 0) L.suffix[m] = suf;
+    }
+    wave_mem_fence();
+    min_norm = sload(p.caches + (size_t)ci * 256u +
+                     (seg.fieldnorm ? seg.min_fieldnorm_id : seg.const_fieldnorm_id));
+    thr = 0;
+    thr_g = 0;
+    li = 0xFFFFFFFFu;
+    li_end = 0;
+    dead = false;
+    tk.reset(k);
+  };
+
+  // ---- stage B: the other lists of <= 64 candidates of leader li
+  auto stageB = [&](uint32_t n) __attribute__((always_inline)) {
+    const uint32_t base = q1n - n;
+    q1n = base;
+    if (p.debug & 64u) n_matches += n;  // COUNTERS
+    bool alive = (uint32_t)lane < n;
+    uint32_t doc = 0, tf = 0;
+    float norm = 0.0f, s = 0.0f;
+    if (alive) {
+      doc = L.q1_doc[base + lane];
+      tf = L.q1_tf[base + lane];
+      norm = L.cache[fieldnorm_id(seg, doc)];
+      s = bm25(w_lead, norm, tf);
+      if (prune) alive = sortable((s + L.suffix[li + 1u]) * 1.000001f) >= thr;
+    }
+    // The leader set is a union of n_lead lists: a doc is scored by the tile of the first list of
+    // the set that holds it.  Pure unions: all the Should terms.  With Must clauses: the cheapest
+    // Must clause, preceded (n_opt_lead) by the optional Should lists in weight order — MaxScore
+    // for RequiredOptionalScorer: a Should list drives the docs it holds (which must also be in the
+    // Must clause), the Must clause drives the rest with a bound that no longer carries the
+    // Should weights, and its tiles die once the threshold passes what the Must part alone can
+    // score.  Then come the other Must clauses (each a union of terms; cheapest first, summed as
+    // Intersection::score does: left + right + sum(others), intersection.rs:325-329), the MustNot
+    // terms (Exclude, exclude.rs) and the remaining optional Should terms
+    // (RequiredOptionalScorer::score = req + opt, reqopt_scorer.rs:85-98).
+    float opt = 0.0f, oth = 0.0f, csum = 0.0f;
+    bool cfound = false;
+    bool lcfound = !BOOL || li >= n_opt_lead;  // the lead Must clause holds the doc
+    if (BOOL && li < n_opt_lead) {             // an optional list leads: its score is optional
+      opt = s;
+      s = 0.0f;
+    }
+    uint32_t clause = 1u;
+    uint32_t n_should = ((roles >> (2u * li)) & 3u) == TQD_ROLE_SHOULD ? 1u : 0u;
+    // lists after the leader first (they add to the score and tighten the bound), the lists
+    // before it last: those only decide whether another tile owns the doc, and most candidates
+    // are gone by then without the (sparse, expensive) probes into the high-weight lists
+    for (uint32_t mm = 1; mm < nt; ++mm) {
+      uint32_t m = li + mm;
+      if (m >= nt) m -= nt;
+      const uint32_t role = BOOL ? (roles >> (2u * m)) & 3u : TQD_ROLE_SHOULD;
+      const float w = sload(&Q->weight[m]);
+      // what the lists m.. can still add (lists below li add nothing: found there = dropped)
+      if (prune && m > li && alive)
+        alive = sortable((((s + oth) + (csum + opt)) + L.suffix[m]) * 1.000001f) >= thr;
+      if (!__ballot(alive)) break;
+      TermRef tr = load_term(p.terms, sload(&Q->term[m]));
+      if (!p.use_dense) tr.dense = nullptr;
+      bool found = false;
+      uint32_t jb = 0, at = NOT_FOUND;
+      if (tr.dense) {
+        if (alive) {
+          const uint2 wd = tr.dense[doc >> 5];
+          const uint32_t bit = doc & 31u;
+          found = (wd.x >> bit) & 1u;
+          const uint32_t pi = wd.y + (uint32_t)__popc(wd.x & ((1u << bit) - 1u));
+          jb = pi >> 7;
+          at = pi & 127u;
+        }
+      } else {
+        bool cand = alive;
+        if (cand) {
+          jb = seek_block(tr, doc);
+          cand = jb < tr.n_blocks;
+        }
+        uint32_t unused;
+        at = lookup_in_blocks<false>(idx, tr, jb, doc, cand, L.pay, lane, &unused);
+        found = cand && at != NOT_FOUND;
+      }
+      float sc = 0.0f;
+      if (found && alive && role != TQD_ROLE_MUST_NOT && !(m < li && (!BOOL || m < n_lead))) {
+        const uint4 r = tr.rec[jb];
+        sc = bm25(w, norm, block_tf_at(idx, tr, make_uint2(r.y, r.z), at));
+      }
+      if (role == TQD_ROLE_MUST_NOT) {
+        if (found) alive = false;
+      } else if (!BOOL || m < n_lead) {
+        if (found) {
+          if (m < li) {
+            alive = false;  // this doc is scored by list m's tile
+          } else if (BOOL && m < n_opt_lead) {
+            opt = opt + sc;
+            ++n_should;
+          } else {
+            s = s + sc;
+            lcfound = true;
+            if (role == TQD_ROLE_SHOULD) ++n_should;
+          }
+        }
+        if (BOOL && m + 1u == n_lead && !lcfound) alive = false;  // not in the lead Must clause
+      } else if (role == TQD_ROLE_MUST) {
+        cfound = cfound || found;
+        if (found) csum = csum + sc;
+        if ((clause_end >> m) & 1u) {
+          if (!cfound) alive = false;
+          if (clause == 1u)
+            s = s + csum;
+          else
+            oth = oth + csum;
+          ++clause;
+          csum = 0.0f;
+          cfound = false;
+        }
+      } else if (found) {
+        opt = opt + sc;
+        ++n_should;
+      }
+    }
+    if (BOOL) {
+      s = (s + oth) + opt;
+      if (n_should < min_should) alive = false;
+    }
+    if (alive) alive = doc_is_alive(seg, doc);
+    const uint64_t hit = __ballot(alive);
+    if (hit) {
+      if (!(p.debug & 224u)) n_matches += (uint32_t)__popcll(hit);  // COUNTERS
+      n_q += (uint32_t)__popcll(hit);
+      const uint64_t key = alive ? make_key(s, doc) : 0ull;
+      if (slots) {
+        const uint32_t sb = (uint32_t)(key >> 32);
+        const uint32_t h = (doc * 0x9E3779B1u) >> (n_slot_rows == 1u ? 26 : 24);
+        if (alive && sb > thr_g) atomicMax(slots + h, sb);
+      }
+      tk.offer(alive, key, lane);
+      if (prune) {
+        const uint32_t own = (uint32_t)(tk.thr >> 32);
+        if (own > thr) thr = own;
+      }
+    }
+  };
+
+  setup_query();
+  for (uint32_t t = t_begin; t < t_end; ++t) {
+    while (t >= q_tile_end) {
+      if (q_tile_end > q_tile_start && q_tile_end > t_begin) {
+        while (q1n) stageB(q1n < 64u ? q1n : 64u);
+        const uint32_t part = sload(&Q->part_start) + (chunk - sload(&Q->chunk_first));
+        flush_partial<KPL>(tk, sload(&p.sinks->partials), part, lane);
+        if (lane == 0 && n_q) atomicAdd(sload(&p.sinks->query_matches) + sload(sload(&p.sinks->out_index) + q), n_q);
+        n_q = 0;
+      }
+      ++q;
+      setup_query();
+    }
+    // ---- which list leads this tile (tiles of a chunk come in order: advance, never search)
+    if (dead) {  // lists li.. are non-essential for good (the threshold only rises): nothing
+      t = (q_tile_end < t_end ? q_tile_end : t_end) - 1u;  // left for this query in this chunk
+      continue;
+    }
+    const uint32_t tl = t - q_tile_start;
+    bool new_leader = li == 0xFFFFFFFFu;
+    uint32_t nli = new_leader ? 0u : li;
+    if (new_leader) li_end = sload(&Q->lead_tile_start[1]);
+    while (tl >= li_end && nli + 1u < nt) {
+      ++nli;
+      li_end = sload(&Q->lead_tile_start[nli + 1u]);
+      new_leader = true;
+    }
+    if (new_leader) {
+      while (q1n) stageB(q1n < 64u ? q1n : 64u);  // the queue belongs to the previous leader
+      li = nli;
+      lead = load_term(p.terms, sload(&Q->term[li]));
+      w_lead = sload(&Q->weight[li]);
+    }
+    // threshold: on a new leader and every 8th tile
+    if (slots && (new_leader || (tl & 7u) == 0u)) {
+      uint32_t sv[4] = {0u, 0u, 0u, 0u};
+      sv[0] = __hip_atomic_load(slots + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (n_slot_rows == 4u) {
+#pragma unroll
+        for (int r = 1; r < 4; ++r)
+          sv[r] = __hip_atomic_load(slots + 64 * r + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        thr_g = kth_largest_multi<4>(sv, tk.k);
+      } else {
+        thr_g = kth_largest64(sv[0], tk.k);
+      }
+      if (thr_g > thr) thr = thr_g;
+    }
+    // non-essential by now: every doc first seen in list li scores at most the weights of li..
+    if (prune && sortable(L.suffix[li] * 1.000001f) < thr) {
+      while (q1n) stageB(q1n < 64u ? q1n : 64u);
+      dead = true;
+      continue;
+    }
+
+    // ---- pre-filter: lane <-> leader block
+    const uint32_t i_base = (tl - sload(&Q->lead_tile_start[li])) * tile_blocks;
+    const uint32_t i_mine = i_base + (uint32_t)lane;
+    bool surv = (uint32_t)lane < tile_blocks && i_mine < lead.n_blocks;
+    uint4 rec_mine = make_uint4(0u, 0u, 0u, 0u);
+    uint32_t prev_mine = 0, tfmin_mine = 1u;
+    {
+      if (surv) rec_mine = lead.rec[i_mine];
+      prev_mine = __shfl_up(rec_mine.x, 1, WAVE);
+      if (lane == 0) prev_mine = block_prev_last(lead, i_base);
+      if (prune) {
+        // what the lists after li can add inside this leader block's doc range (the lists before
+        // li hold none of this tile's docs): block-max over the <= 4 blocks the range spans,
+        // else the weight; a single-term Must clause that ends before the range drops the block
+        const uint32_t first = i_mine ? prev_mine + 1u : 0u;
+        const uint32_t last = rec_mine.x;
+        float ub = 0.0f, rest_mine = 0.0f;
+        if (surv) {
+          ub = block_max_score(rec_mine.y, w_lead, L.cache, lead.has_freq);
+          surv = sortable((ub + L.suffix[li + 1u] * 1.000001f) * 1.000001f) >= thr;
+        }
+        // (pure unions: their dense lists span far more than 4 blocks, the seeks do not pay)
+        const bool block_bounds = BOOL && n_lead < nt;
+        if (!block_bounds) rest_mine = L.suffix[li + 1u];
+        if (block_bounds && __ballot(surv)) {
+          for (uint32_t m = li + 1u; m < nt; ++m) {
+            const uint32_t role = (roles >> (2u * m)) & 3u;
+            if (role == TQD_ROLE_MUST_NOT) continue;
+            const bool single = role == TQD_ROLE_MUST && m >= n_lead && ((clause_end >> m) & 1u) &&
+                                (m == n_lead || ((clause_end >> (m - 1u)) & 1u));
+            const TermRef tr = load_term(p.terms, sload(&Q->term[m]));
+            const float w = sload(&Q->weight[m]);
+            if (surv) {
+              const uint32_t j0 = seek_block(tr, first);
+              if (j0 >= tr.n_blocks) {
+                if (single) surv = false;
+              } else {
+                float bound = 0.0f;
+                bool closed = false;
+                for (uint32_t k = 0; k < 4u && !closed; ++k) {
+                  const uint32_t j = j0 + k;
+                  const uint4 r = tr.rec[j];
+                  const float b2 = block_max_score(r.y, w, L.cache, tr.has_freq);
+                  bound = b2 > bound ? b2 : bound;
+                  closed = r.x >= last || j + 1u >= tr.n_blocks;
+                }
+                if (!closed) bound = w;
+                rest_mine = rest_mine + bound;
+              }
+            }
+          }
+        }
+        rest_mine *= 1.000001f;
+        if (surv) surv = sortable((ub + rest_mine) * 1.000001f) >= thr;
+        if (surv) {
+          auto pass = [&](uint32_t tfv) __attribute__((always_inline)) {
+            return sortable((bm25(w_lead, min_norm, tfv) + rest_mine) * 1.000001f) >= thr;
+          };
+          if (!pass(0xFFFFFFFFu)) {
+            surv = false;
+          } else {
+            uint32_t tfm = 1u;
+            while (tfm < 64u && !pass(tfm)) ++tfm;  // tfs are small; beyond 64 keep everything
+            tfmin_mine = tfm < 64u ? tfm : 1u;
+          }
+        }
+      }
+    }
+    uint64_t todo = __ballot(surv);
+    if (p.debug & 32u) n_matches += (uint32_t)__popcll(todo);  // COUNTERS
+    if (p.debug & 128u) n_matches += 1u;  // COUNTERS
+    while (todo) {
+      const uint32_t b = (uint32_t)__builtin_ctzll(todo);
+      todo &= todo - 1ull;
+      const uint2 mo_l = make_uint2((uint32_t)__builtin_amdgcn_readlane((int)rec_mine.y, (int)b),
+                                    (uint32_t)__builtin_amdgcn_readlane((int)rec_mine.z, (int)b));
+      const uint32_t prev_l = (uint32_t)__builtin_amdgcn_readlane((int)prev_mine, (int)b);
+      uint32_t c0, c1, t0, t1f;
+      decode_tfs(idx, lead, mo_l, lane, t0, t1f);  // tail padding reads as tf 0
+      bool alive0 = true, alive1 = true;
+      if (prune) {
+        const uint32_t tfmin = (uint32_t)__builtin_amdgcn_readlane((int)tfmin_mine, (int)b);
+        alive0 = t0 >= tfmin;
+        alive1 = t1f >= tfmin;
+        if (!(__ballot(alive0) | __ballot(alive1))) continue;
+      }
+      decode_docs<USE_DPP>(idx, lead, mo_l, prev_l, lane, c0, c1);
+      alive0 = alive0 && c0 != TQD_TERMINATED;
+      alive1 = alive1 && c1 != TQD_TERMINATED;
+      const uint64_t m0 = __ballot(alive0), m1 = __ballot(alive1);
+      if (!(m0 | m1)) continue;
+      const uint32_t n0 = (uint32_t)__popcll(m0);
+      const uint32_t pos0 = q1n + mbcnt64(m0);
+      const uint32_t pos1 = q1n + n0 + mbcnt64(m1);
+      wave_mem_fence();
+      if (alive0) {
+        L.q1_doc[pos0] = c0;
+        L.q1_tf[pos0] = t0;
+      }
+      if (alive1) {
+        L.q1_doc[pos1] = c1;
+        L.q1_tf[pos1] = t1f;
+      }
+      wave_mem_fence();
+      q1n += n0 + (uint32_t)__popcll(m1);
+      while (q1n >= 64u) stageB(64u);
+    }
+  }
+  if (q_tile_end > q_tile_start) {
+    while (q1n) stageB(q1n < 64u ? q1n : 64u);
+    const uint32_t part = sload(&Q->part_start) + (chunk - sload(&Q->chunk_first));
+    flush_partial<KPL>(tk, sload(&p.sinks->partials), part, lane);
+        if (lane == 0 && n_q) atomicAdd(sload(&p.sinks->query_matches) + sload(sload(&p.sinks->out_index) + q), n_q);
+        n_q = 0;
+  }
+  if (lane == 0 && n_matches) atomicAdd(sload(&p.sinks->match_counter), (unsigned long long)n_matches);
+}
+
+// k <= 128 (KPL <= 2) instantiations are compiled for 6 waves/SIMD (<= 84 registers) instead of 4
+template <int KPL, bool PRUNE, bool BOOL>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_num_sgpr(96))) void union_kernel(TqkScanParams p) {
+  union_body<KPL, PRUNE, BOOL>(p);
+}
+template <int KPL, bool PRUNE, bool BOOL>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_num_sgpr(96), amdgpu_waves_per_eu(6, 8))) void
+union_kernel_small(TqkScanParams p) {
+  union_body<KPL, PRUNE, BOOL>(p);
+}
+
+}  // namespace
+
+// =================================================================== launch wrappers
+template <int KPL>
+static void launch_or_t(const TqkScanParams &p, bool /*dpp*/, dim3 grid, dim3 block, hipStream_t st) {
+  if (p.or_windows) {  // window-parallel form: one workgroup per chunk
+    if (p.exhaustive)
+      or_kernel<KPL, false><<<grid, block, 0, st>>>(p);
+    else
+      or_kernel<KPL, true><<<grid, block, 0, st>>>(p);
+  } else {  // candidate-driven form: one wavefront per chunk
+#define TQ_UNION(PR, BO)                                                  \
+  do {                                                                    \
+    if (KPL <= 2)                                                         \
+      union_kernel_small<KPL, PR, BO><<<grid, dim3(64), 0, st>>>(p);      \
+    else                                                                  \
+      union_kernel<KPL, PR, BO><<<grid, dim3(64), 0, st>>>(p);            \
+  } while (0)
+    if (p.boolean) {
+      if (p.exhaustive)
+        TQ_UNION(false, true);
+      else
+        TQ_UNION(true, true);
+    } else if (p.exhaustive) {
+      TQ_UNION(false, false);
+    } else {
+      TQ_UNION(true, false);
+    }
+#undef TQ_UNION
+  }
+}
+
+hipError_t tqk_launch_or(const TqkScanParams &p, int kpl, bool use_dpp, hipStream_t st) {
+  if (p.n_chunks == 0) return hipSuccess;
+  const dim3 grid(p.n_chunks), block(TQD_WAVES_PER_WG * 64);
+  switch (kpl) {
+    case 1: launch_or_t<1>(p, use_dpp, grid, block, st); break;
+    case 2: launch_or_t<2>(p, use_dpp, grid, block, st); break;
+    case 4: launch_or_t<4>(p, use_dpp, grid, block, st); break;
+    default: launch_or_t<16>(p, use_dpp, grid, block, st); break;
+  }
+  return hipGetLastError();
+}
