@@ -649,6 +649,156 @@ static const uint32_t kAndChunks = std::max<uint32_t>(256u, tune_u32("TQ_CHUNKS"
 
 int kpl_for(uint32_t k) { return k <= 64 ? 1 : (k <= 128 ? 2 : (k <= 256 ? 4 : 16)); }
 
+// tiles -> chunks of one launch group: runs of consecutive tiles of about equal estimated cost,
+// their launch order (doc-range slices) and the number of partial lists per query
+int build_group_chunks(Group &g, bool or_windows) {
+  g.kpl = kpl_for(g.max_k);
+  g.tile_starts.resize(g.queries.size() + 1);
+  uint64_t acc = 0;
+  for (size_t i = 0; i < g.queries.size(); ++i) {
+    g.tile_starts[i] = (uint32_t)acc;
+    g.queries[i].tile_start = (uint32_t)acc;
+    acc += g.queries[i].n_tiles;
+    if (acc > 0x7FFFFFFFull) return fail(TQ_ERR_UNSUPPORTED, "batch too large (tiles)");
+  }
+  g.tile_starts[g.queries.size()] = (uint32_t)acc;
+  g.total_tiles = (uint32_t)acc;
+  // chunks = runs of consecutive tiles of about equal estimated cost; one chunk is one
+  // wavefront (AND, phrase) or one workgroup (OR) and the hardware dispatcher hands them out
+  // as slots free up, so many small chunks balance the load
+  // doc-range slices of the launch order (phrase batches: 128 was 5 % slower than 32)
+  const uint32_t n_slices = g.mode == TQ_MODE_PHRASE ? std::min<uint32_t>(kSlices, 32u) : kSlices;
+  const bool or_win = g.mode == TQ_MODE_OR && or_windows;
+  const bool or_cand = g.mode == TQ_MODE_OR && !or_windows;
+  // candidate-driven OR: the tiles of a list that MaxScore will most likely find non-essential
+  // (the weights of lists i.. together below ~3/4 of the query's total weight: top-k docs hold
+  // most of the terms) are skipped whole at run time => weigh them as 1/8 of a live tile, so
+  // that chunks are sized by the work that is really done
+  auto tile_cost_at = [&](size_t qi, uint32_t t) -> uint32_t {
+    const uint32_t tc = std::max<uint32_t>(1u, g.tile_cost[qi]);
+    if (!or_cand) return tc;
+    const TqdQuery &dq = g.queries[qi];
+    uint32_t li = 0;
+    while (li + 1u < dq.n_terms && dq.lead_tile_start[li + 1u] <= t) ++li;
+    float total = 0.0f, suffix = 0.0f;
+    for (uint32_t m = 0; m < dq.n_terms; ++m) {
+      total += dq.weight[m];
+      if (m >= li) suffix += dq.weight[m];
+    }
+    const bool pruning = (dq.flags & TQD_QF_PRUNE) != 0u;
+    return (pruning && suffix < kOrDeadFrac * total) ? std::max<uint32_t>(1u, tc / kOrDeadDiv) : tc;
+  };
+  // first tile >= t of query qi where the cost changes (the end of the leader's run)
+  auto cost_run_end = [&](size_t qi, uint32_t t) -> uint32_t {
+    const TqdQuery &dq = g.queries[qi];
+    if (!or_cand) return dq.n_tiles;
+    uint32_t li = 0;
+    while (li + 1u < dq.n_terms && dq.lead_tile_start[li + 1u] <= t) ++li;
+    return std::min<uint32_t>(dq.n_tiles, dq.lead_tile_start[li + 1u]);
+  };
+  uint64_t total_cost = 0;
+  for (size_t i = 0; i < g.queries.size(); ++i) {
+    for (uint32_t t = 0; t < g.queries[i].n_tiles;) {
+      const uint32_t e = std::max<uint32_t>(t + 1u, cost_run_end(i, t));
+      total_cost += (uint64_t)(e - t) * tile_cost_at(i, t);
+      t = e;
+    }
+  }
+  const uint64_t n_target = or_win ? 8192u : (or_cand ? 8u * kAndChunks : kAndChunks);
+  const uint64_t cost_target = std::max<uint64_t>(or_win ? 1u : 128u,
+                                                  (total_cost + n_target - 1) / n_target);
+  g.chunk_starts.clear();
+  g.chunk_slice.clear();
+  uint64_t cur_cost = 0;
+  bool open_chunk = false;
+  const uint32_t per_chunk = or_win ? TQD_WAVES_PER_WG : 1u;
+  for (size_t i = 0; i < g.queries.size(); ++i) {
+    TqdQuery &dq = g.queries[i];
+    dq.part_start = 0;
+    dq.n_parts = 0;
+    dq.chunk_first = 0;
+    if (!dq.n_tiles) continue;
+    uint32_t first_chunk = 0xFFFFFFFFu;
+    for (uint32_t t = 0; t < dq.n_tiles;) {
+      const uint32_t tc = tile_cost_at(i, t);
+      const uint32_t run_end = std::max<uint32_t>(t + 1u, cost_run_end(i, t));
+      if (!open_chunk || cur_cost >= cost_target) {
+        g.chunk_starts.push_back(dq.tile_start + t);
+        // which part of the doc-id space the chunk starts in (lists are spread over it)
+        if (g.mode == TQ_MODE_OR && !or_win) {
+          // candidate-driven OR: high-weight lists first (their matches raise the threshold
+          // that lets the tiles of the dense low-weight lists be skipped), doc order inside
+          uint32_t li = 0;
+          while (li + 1u < dq.n_terms && dq.lead_tile_start[li + 1u] <= t) ++li;
+          const uint32_t span = std::max<uint32_t>(1u, dq.lead_tile_start[li + 1u] - dq.lead_tile_start[li]);
+          const uint32_t sub = (uint32_t)(((uint64_t)(t - dq.lead_tile_start[li]) * 16u) / span);
+          g.chunk_slice.push_back(std::min<uint32_t>(n_slices * 8u - 1u, std::min<uint32_t>(li, 15u) * 16u + sub));
+        } else {
+          g.chunk_slice.push_back((uint32_t)(((uint64_t)t * n_slices * 8u) / dq.n_tiles));
+        }
+        cur_cost = 0;
+        open_chunk = true;
+      }
+      if (first_chunk == 0xFFFFFFFFu) first_chunk = (uint32_t)g.chunk_starts.size() - 1u;
+      // as many tiles of this query as the chunk still takes
+      const uint64_t room = cost_target - cur_cost;
+      uint32_t take = (uint32_t)std::min<uint64_t>(run_end - t, (room + tc - 1) / tc);
+      take = std::max<uint32_t>(take, 1u);
+      cur_cost += (uint64_t)take * tc;
+      t += take;
+    }
+    dq.chunk_first = first_chunk;
+    dq.n_parts = ((uint32_t)g.chunk_starts.size() - first_chunk) * per_chunk;
+  }
+  g.n_chunks = (uint32_t)g.chunk_starts.size();
+  g.chunk_starts.push_back(g.total_tiles);
+  // Launch order: all chunks of doc-range slice 0 (of every query), then slice 1, ...  The
+  // dispatcher hands out workgroups in index order, so at any moment the whole chip works on
+  // the same ~1/128 of the doc-id space: the fieldnorm bytes, bitmap words and hot posting
+  // blocks of that slice stay in the 4 MB L2s across queries instead of being re-fetched.
+  // Inside a slice the chunks are dealt round-robin from its 8 sub-slices: workgroup i runs
+  // on XCD i % 8 (observed placement, MI355X_MICROARCH.md), so each XCD's L2 sees one eighth
+  // of the slice.  Placement is a speed-up only; nothing depends on it.
+  g.chunk_perm.resize(g.n_chunks);
+  {
+    const uint32_t nb = n_slices * 8u;
+    std::vector<uint32_t> start(nb + 1, 0);
+    for (uint32_t c = 0; c < g.n_chunks; ++c) ++start[g.chunk_slice[c] + 1];
+    for (uint32_t i = 0; i < nb; ++i) start[i + 1] += start[i];
+    std::vector<uint32_t> sorted(g.n_chunks), fill(start.begin(), start.end() - 1);
+    for (uint32_t c = 0; c < g.n_chunks; ++c) sorted[fill[g.chunk_slice[c]]++] = c;
+    uint32_t out = 0;
+    for (uint32_t sl = 0; sl < n_slices; ++sl) {
+      uint32_t at[8], end[8], left = 0;
+      for (uint32_t x = 0; x < 8; ++x) {
+        at[x] = start[sl * 8 + x];
+        end[x] = start[sl * 8 + x + 1];
+        left += end[x] - at[x];
+      }
+      while (left) {
+        for (uint32_t x = 0; x < 8; ++x) {
+          if (at[x] < end[x]) {
+            g.chunk_perm[out++] = sorted[at[x]++];
+            --left;
+          } else if (left) {  // keep the i % 8 alignment: borrow from the fullest sub-slice
+            uint32_t best = 8, most = 0;
+            for (uint32_t y = 0; y < 8; ++y)
+              if (end[y] - at[y] > most) {
+                most = end[y] - at[y];
+                best = y;
+              }
+            if (best < 8) {
+              g.chunk_perm[out++] = sorted[--end[best]];
+              --left;
+            }
+          }
+        }
+      }
+    }
+  }
+  return TQ_OK;
+}
+
 // Planning of one TQ_MODE_BOOL query: clause layout of the union kernel (tq_union.hip), pruning
 // flags, tile sizes.  An empty result leaves dq.n_terms == 0 and n_tiles == 0.
 int plan_bool_query(tq_segment *s, const tq_query &q, uint32_t qi, TqdQuery &dq, uint64_t &qbytes,
@@ -1007,151 +1157,8 @@ int tq_search_batch_device(tq_segment *s, const tq_query *queries, uint32_t n_qu
   size_t partial_bytes = 0;
   for (Group &g : groups) {
     if (g.queries.empty()) continue;
-    g.kpl = kpl_for(g.max_k);
-    g.tile_starts.resize(g.queries.size() + 1);
-    uint64_t acc = 0;
-    for (size_t i = 0; i < g.queries.size(); ++i) {
-      g.tile_starts[i] = (uint32_t)acc;
-      g.queries[i].tile_start = (uint32_t)acc;
-      acc += g.queries[i].n_tiles;
-      if (acc > 0x7FFFFFFFull) return fail(TQ_ERR_UNSUPPORTED, "batch too large (tiles)");
-    }
-    g.tile_starts[g.queries.size()] = (uint32_t)acc;
-    g.total_tiles = (uint32_t)acc;
-    // chunks = runs of consecutive tiles of about equal estimated cost; one chunk is one
-    // wavefront (AND, phrase) or one workgroup (OR) and the hardware dispatcher hands them out
-    // as slots free up, so many small chunks balance the load
-    const bool or_windows = or_windows_opt && &g != &groups[kBool];
-    // doc-range slices of the launch order (phrase batches: 128 was 5 % slower than 32)
-    const uint32_t n_slices = g.mode == TQ_MODE_PHRASE ? std::min<uint32_t>(kSlices, 32u) : kSlices;
-    const bool or_win = g.mode == TQ_MODE_OR && or_windows;
-    const bool or_cand = g.mode == TQ_MODE_OR && !or_windows;
-    // candidate-driven OR: the tiles of a list that MaxScore will most likely find non-essential
-    // (the weights of lists i.. together below ~3/4 of the query's total weight: top-k docs hold
-    // most of the terms) are skipped whole at run time => weigh them as 1/8 of a live tile, so
-    // that chunks are sized by the work that is really done
-    auto tile_cost_at = [&](size_t qi, uint32_t t) -> uint32_t {
-      const uint32_t tc = std::max<uint32_t>(1u, g.tile_cost[qi]);
-      if (!or_cand) return tc;
-      const TqdQuery &dq = g.queries[qi];
-      uint32_t li = 0;
-      while (li + 1u < dq.n_terms && dq.lead_tile_start[li + 1u] <= t) ++li;
-      float total = 0.0f, suffix = 0.0f;
-      for (uint32_t m = 0; m < dq.n_terms; ++m) {
-        total += dq.weight[m];
-        if (m >= li) suffix += dq.weight[m];
-      }
-      const bool pruning = (dq.flags & TQD_QF_PRUNE) != 0u;
-      return (pruning && suffix < kOrDeadFrac * total) ? std::max<uint32_t>(1u, tc / kOrDeadDiv) : tc;
-    };
-    // first tile >= t of query qi where the cost changes (the end of the leader's run)
-    auto cost_run_end = [&](size_t qi, uint32_t t) -> uint32_t {
-      const TqdQuery &dq = g.queries[qi];
-      if (!or_cand) return dq.n_tiles;
-      uint32_t li = 0;
-      while (li + 1u < dq.n_terms && dq.lead_tile_start[li + 1u] <= t) ++li;
-      return std::min<uint32_t>(dq.n_tiles, dq.lead_tile_start[li + 1u]);
-    };
-    uint64_t total_cost = 0;
-    for (size_t i = 0; i < g.queries.size(); ++i) {
-      for (uint32_t t = 0; t < g.queries[i].n_tiles;) {
-        const uint32_t e = std::max<uint32_t>(t + 1u, cost_run_end(i, t));
-        total_cost += (uint64_t)(e - t) * tile_cost_at(i, t);
-        t = e;
-      }
-    }
-    const uint64_t n_target = or_win ? 8192u : (or_cand ? 8u * kAndChunks : kAndChunks);
-    const uint64_t cost_target = std::max<uint64_t>(or_win ? 1u : 128u,
-                                                    (total_cost + n_target - 1) / n_target);
-    g.chunk_starts.clear();
-    g.chunk_slice.clear();
-    uint64_t cur_cost = 0;
-    bool open_chunk = false;
-    const uint32_t per_chunk = or_win ? TQD_WAVES_PER_WG : 1u;
-    for (size_t i = 0; i < g.queries.size(); ++i) {
-      TqdQuery &dq = g.queries[i];
-      dq.part_start = 0;
-      dq.n_parts = 0;
-      dq.chunk_first = 0;
-      if (!dq.n_tiles) continue;
-      uint32_t first_chunk = 0xFFFFFFFFu;
-      for (uint32_t t = 0; t < dq.n_tiles;) {
-        const uint32_t tc = tile_cost_at(i, t);
-        const uint32_t run_end = std::max<uint32_t>(t + 1u, cost_run_end(i, t));
-        if (!open_chunk || cur_cost >= cost_target) {
-          g.chunk_starts.push_back(dq.tile_start + t);
-          // which part of the doc-id space the chunk starts in (lists are spread over it)
-          if (g.mode == TQ_MODE_OR && !or_win) {
-            // candidate-driven OR: high-weight lists first (their matches raise the threshold
-            // that lets the tiles of the dense low-weight lists be skipped), doc order inside
-            uint32_t li = 0;
-            while (li + 1u < dq.n_terms && dq.lead_tile_start[li + 1u] <= t) ++li;
-            const uint32_t span = std::max<uint32_t>(1u, dq.lead_tile_start[li + 1u] - dq.lead_tile_start[li]);
-            const uint32_t sub = (uint32_t)(((uint64_t)(t - dq.lead_tile_start[li]) * 16u) / span);
-            g.chunk_slice.push_back(std::min<uint32_t>(n_slices * 8u - 1u, std::min<uint32_t>(li, 15u) * 16u + sub));
-          } else {
-            g.chunk_slice.push_back((uint32_t)(((uint64_t)t * n_slices * 8u) / dq.n_tiles));
-          }
-          cur_cost = 0;
-          open_chunk = true;
-        }
-        if (first_chunk == 0xFFFFFFFFu) first_chunk = (uint32_t)g.chunk_starts.size() - 1u;
-        // as many tiles of this query as the chunk still takes
-        const uint64_t room = cost_target - cur_cost;
-        uint32_t take = (uint32_t)std::min<uint64_t>(run_end - t, (room + tc - 1) / tc);
-        take = std::max<uint32_t>(take, 1u);
-        cur_cost += (uint64_t)take * tc;
-        t += take;
-      }
-      dq.chunk_first = first_chunk;
-      dq.n_parts = ((uint32_t)g.chunk_starts.size() - first_chunk) * per_chunk;
-    }
-    g.n_chunks = (uint32_t)g.chunk_starts.size();
-    g.chunk_starts.push_back(g.total_tiles);
-    // Launch order: all chunks of doc-range slice 0 (of every query), then slice 1, ...  The
-    // dispatcher hands out workgroups in index order, so at any moment the whole chip works on
-    // the same ~1/128 of the doc-id space: the fieldnorm bytes, bitmap words and hot posting
-    // blocks of that slice stay in the 4 MB L2s across queries instead of being re-fetched.
-    // Inside a slice the chunks are dealt round-robin from its 8 sub-slices: workgroup i runs
-    // on XCD i % 8 (observed placement, MI355X_MICROARCH.md), so each XCD's L2 sees one eighth
-    // of the slice.  Placement is a speed-up only; nothing depends on it.
-    g.chunk_perm.resize(g.n_chunks);
-    {
-      const uint32_t nb = n_slices * 8u;
-      std::vector<uint32_t> start(nb + 1, 0);
-      for (uint32_t c = 0; c < g.n_chunks; ++c) ++start[g.chunk_slice[c] + 1];
-      for (uint32_t i = 0; i < nb; ++i) start[i + 1] += start[i];
-      std::vector<uint32_t> sorted(g.n_chunks), fill(start.begin(), start.end() - 1);
-      for (uint32_t c = 0; c < g.n_chunks; ++c) sorted[fill[g.chunk_slice[c]]++] = c;
-      uint32_t out = 0;
-      for (uint32_t sl = 0; sl < n_slices; ++sl) {
-        uint32_t at[8], end[8], left = 0;
-        for (uint32_t x = 0; x < 8; ++x) {
-          at[x] = start[sl * 8 + x];
-          end[x] = start[sl * 8 + x + 1];
-          left += end[x] - at[x];
-        }
-        while (left) {
-          for (uint32_t x = 0; x < 8; ++x) {
-            if (at[x] < end[x]) {
-              g.chunk_perm[out++] = sorted[at[x]++];
-              --left;
-            } else if (left) {  // keep the i % 8 alignment: borrow from the fullest sub-slice
-              uint32_t best = 8, most = 0;
-              for (uint32_t y = 0; y < 8; ++y)
-                if (end[y] - at[y] > most) {
-                  most = end[y] - at[y];
-                  best = y;
-                }
-              if (best < 8) {
-                g.chunk_perm[out++] = sorted[--end[best]];
-                --left;
-              }
-            }
-          }
-        }
-      }
-    }
+    const int crc = build_group_chunks(g, or_windows_opt && &g != &groups[kBool]);
+    if (crc != TQ_OK) return crc;
   }
   // partial lists of all groups share one buffer; its stride is per group (kpl*64 keys)
   size_t part_off_bytes[kGroups] = {0, 0, 0, 0, 0};
