@@ -9,10 +9,18 @@
  * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may
  * link or call this library.  The product path (tantivy_amd/) never does.
  *
+ * Also restated: the generic scorer tree behind boolean queries (Intersection,
+ * BufferedUnionScorer, Disjunction, RequiredOptionalScorer, Exclude; to_query.c),
+ * PostingsSerializer / PositionSerializer (to_postings.c: the checker of the device-side
+ * codec writers) and, in oracle.py, the file framing and the TermInfoStore.
+ *
  * PARITY PINNING:
  *   - everything above the 128-int codec (decoded ints, skip entries, doc ids,
  *     BM25 scores, top-k ordering) is pinned by the reference's own known-answer
  *     tests (see tests/test_oracle_kat.py and SURVEY.md §8c);
+ *   - file framing, TermInfoStore and vint posting / position bytes are pinned by the
+ *     reference's compat fixtures (tests/golden/compat_index.json: files written by
+ *     released tantivy versions);
  *   - the *byte layout* of a BitPacker4x block comes from the third-party crate
  *     `bitpacking = 0.9.3` (Cargo.toml:42), whose source is not in the reference
  *     tree and for which the tree holds no golden bytes  =>  "parity unpinned"
