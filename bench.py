@@ -100,6 +100,13 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
+    from tantivy_amd import build as product_build
+
+    if not os.path.exists(product_build.LIB):  # normally prebuilt (__graft_entry__.build())
+        if rank == 0:
+            product_build.build()
+        if dist is not None:
+            dist.barrier()
     from oracle import oracle as O  # workload generator + cpu baseline + spot check only
     import tantivy_amd
     from tantivy_amd import distributed as D
