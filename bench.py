@@ -182,7 +182,8 @@ def main():
     _, _, prn_kms = run_mode(False, max(1, min(args.steps, 3)))
     mode_parity = all(np.array_equal(a, b) for a, b in zip(exh_out, prn_out))
     if not mode_parity:
-        raise SystemExit("pruned and exhaustive results differ")
+        n_diff = int(np.sum(np.any(exh_out[2] != prn_out[2], axis=1)))
+        raise SystemExit("pruned and exhaustive results differ on %d queries" % n_diff)
     full_matches = exh_st["matches"]
     algo_bytes_full = exh_st["algorithmic_bytes"]  # postings + positions + matches + 8k
     dev.set_option("exhaustive", 0 if pruned_mode else 1)

@@ -239,6 +239,12 @@ int tq_last_batch_stats(tq_segment *seg, tq_batch_stats *out);
  *        them),
  *        "or_windows" (-1/0/1, default -1 = auto: unions run window-parallel when exhaustive and
  *        candidate-driven when pruning; 0 / 1 force one kernel),
+ *        "bound_slack_ppm" (default 0): block-max bounds are widened by (1 + ppm * 1e-6).  The
+ *        block-max pairs were selected under the segment's own average fieldnorm
+ *        (serializer.rs:130-135); a caller whose Bm25Weights use global statistics passes
+ *        ((1 + d)^2 - 1) * 1e6 with d = relative difference of the two averages and pruning
+ *        stays exact (the reference accepts the approximation, term_scorer.rs:58-70),
+ *        "dense_budget_x" (default 4: bitmaps together stay below this multiple of the segment),
  *        "use_dpp" (0/1: DPP or ds_bpermute prefix sums) */
 int tq_set_option(tq_segment *seg, const char *name, int64_t value);
 

@@ -117,7 +117,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_num_sgpr(80))) void and_k
       if (prune && alive) {  // block_wand_intersection.rs:144-165
         // 96 % of the candidates end here: the test runs on reciprocal-based bounds, the exact
         // (IEEE-divided) leader score is only computed for the survivors
-        float ub = bm25_bound(w_lead, norm, tf) + block_max_bound(mo.x, w1, L.cache, t1.has_freq);
+        float ub = bm25_bound(w_lead, norm, tf) + block_max_bound(mo.x, w1, L.cache, t1.has_freq, p.bound_slack);
         if (nt > 2u) ub = ub + rest_after1;
         alive = sortable(ub * 1.000002f) >= thr;
       }
@@ -155,7 +155,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_num_sgpr(80))) void and_k
       uint2 mo = make_uint2(0u, 0u);
       if (alive) mo = rec_mo(tr.rec[jb]);
       if (prune && alive) {
-        const float ub = (s + block_max_score(mo.x, w, L.cache, tr.has_freq) + rest) * 1.000001f;
+        const float ub = (s + block_max_score(mo.x, w, L.cache, tr.has_freq, p.bound_slack) + rest) * 1.000001f;
         alive = sortable(ub) >= thr;
       }
       if constexpr (!DENSE) {
@@ -278,7 +278,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_num_sgpr(80))) void and_k
       if (lane == 0) prev_mine = block_prev_last(lead, i_base);
       first = i_mine ? prev_mine + 1u : 0u;
       if (prune && surv) {
-        ub = block_max_score(mo_mine.x, w_lead, L.cache, lead.has_freq);
+        ub = block_max_score(mo_mine.x, w_lead, L.cache, lead.has_freq, p.bound_slack);
         // cheapest test first: not even with the other lists at their full weights?  (a rare
         // leader next to a stop word: most blocks end here, before any seek)
         surv = sortable((ub + (w1 + rest_after1)) * 1.000001f) >= thr;
@@ -298,7 +298,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_num_sgpr(80))) void and_k
             for (uint32_t k = 0; k < 4u && !closed; ++k) {
               const uint32_t j = j0 + k;
               const uint4 r = tr.rec[j];
-              const float b2 = block_max_score(r.y, w, L.cache, tr.has_freq);
+              const float b2 = block_max_score(r.y, w, L.cache, tr.has_freq, p.bound_slack);
               bound = b2 > bound ? b2 : bound;
               closed = r.x >= last || j + 1u >= tr.n_blocks;
             }

@@ -133,6 +133,7 @@ struct Options {
   int dense_budget_x = 4;  // ... while all bitmaps stay below this multiple of the segment's bytes
   int use_dense = 1;  // let the scan kernels use them
   int or_windows = -1;  // OR: 1 = window-parallel kernel, 0 = candidate-driven kernel, -1 = auto
+  int bound_slack_ppm = 0;  // block-max bounds are widened by (1 + ppm * 1e-6), see block_max_score
                         // (windows for exhaustive scans, candidates when pruning)
 };
 
@@ -1289,6 +1290,7 @@ int tq_search_batch_device(tq_segment *s, const tq_query *queries, uint32_t n_qu
     p.debug = kDebug;
     p.or_windows = (or_windows_opt && gi != kBool) ? 1u : 0u;
     p.boolean = gi == kBool ? 1u : 0u;
+    p.bound_slack = 1.0f + (float)s->opt.bound_slack_ppm * 1e-6f;
     p.max_terms = 0;
     for (const TqdQuery &dq : g.queries) p.max_terms = std::max(p.max_terms, dq.n_terms);
     tiles_total += g.total_tiles;
@@ -1474,6 +1476,8 @@ int tq_set_option(tq_segment *s, const char *name, int64_t value) {
     s->opt.dense_ratio = (int)value;
   else if (!strcmp(name, "dense_budget_x") && value >= 0)
     s->opt.dense_budget_x = (int)value;
+  else if (!strcmp(name, "bound_slack_ppm") && value >= 0 && value <= 1000000)
+    s->opt.bound_slack_ppm = (int)value;
   else if (!strcmp(name, "dense"))  // affects terms prepared afterwards
     s->opt.dense = value != 0;
   else

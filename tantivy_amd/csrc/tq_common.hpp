@@ -434,20 +434,25 @@ __device__ __forceinline__ uint32_t sortable(float x) {
 // upper bound of a term's score inside one block (TermScorer::block_max_score,
 // term_scorer.rs:58-75; skip.rs:175-184).  tail / no-freq / unknown block-max => weight itself
 // (tf/(tf+norm) < 1).  Requires weight >= 0.
+// `slack` (>= 1): the stored (fieldnorm id, tf) pair is the block's best under the SEGMENT's own
+// average fieldnorm (serializer.rs:130-135,404-428); under the query's global average another doc
+// of the block may score up to (1 + d)^2 higher, d = relative difference of the two averages
+// (tf/(tf+norm) moves by at most d when the average does).  The reference accepts that risk
+// (term_scorer.rs:58-70); here the host passes slack = (1 + d)^2 and pruning stays exact.
 __device__ __forceinline__ float block_max_score(uint32_t meta, float w, const float *cache,
-                                                 uint32_t has_freq) {
+                                                 uint32_t has_freq, float slack) {
   const uint32_t tfc = meta >> 24;
   if (meta == META_TAIL || !has_freq || tfc == 0u) return w;
   const uint32_t tf = tfc == 255u ? 0xFFFFFFFFu : tfc;  // skip.rs:31-43
-  return bm25(w, cache[(meta >> 16) & 0xFFu], tf);
+  return bm25(w, cache[(meta >> 16) & 0xFFu], tf) * slack;
 }
 // block_max_score for threshold tests (see bm25_bound)
 __device__ __forceinline__ float block_max_bound(uint32_t meta, float w, const float *cache,
-                                                 uint32_t has_freq) {
+                                                 uint32_t has_freq, float slack) {
   const uint32_t tfc = meta >> 24;
   if (meta == META_TAIL || !has_freq || tfc == 0u) return w;
   const uint32_t tf = tfc == 255u ? 0xFFFFFFFFu : tfc;
-  return bm25_bound(w, cache[(meta >> 16) & 0xFFu], tf);
+  return bm25_bound(w, cache[(meta >> 16) & 0xFFu], tf) * slack;
 }
 // k-th largest of the 64*S per-lane values (0 = empty slot); 0 if fewer than k are set.
 // Radix select: the largest x with |{v >= x}| >= k, one bit per step.

@@ -599,7 +599,7 @@ __device__ __forceinline__ void union_body(const TqkScanParams &p) {
         const uint32_t last = rec_mine.x;
         float ub = 0.0f, rest_mine = 0.0f;
         if (surv) {
-          ub = block_max_score(rec_mine.y, w_lead, L.cache, lead.has_freq);
+          ub = block_max_score(rec_mine.y, w_lead, L.cache, lead.has_freq, p.bound_slack);
           surv = sortable((ub + L.suffix[li + 1u] * 1.000001f) * 1.000001f) >= thr;
         }
         // (pure unions: their dense lists span far more than 4 blocks, the seeks do not pay)
@@ -623,7 +623,7 @@ __device__ __forceinline__ void union_body(const TqkScanParams &p) {
                 for (uint32_t k = 0; k < 4u && !closed; ++k) {
                   const uint32_t j = j0 + k;
                   const uint4 r = tr.rec[j];
-                  const float b2 = block_max_score(r.y, w, L.cache, tr.has_freq);
+                  const float b2 = block_max_score(r.y, w, L.cache, tr.has_freq, p.bound_slack);
                   bound = b2 > bound ? b2 : bound;
                   closed = r.x >= last || j + 1u >= tr.n_blocks;
                 }

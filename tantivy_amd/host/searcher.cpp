@@ -4,6 +4,7 @@
 #include "term_info_store.hpp"
 
 #include <algorithm>
+#include <cmath>
 #include <cstring>
 
 namespace tantivy_amd {
@@ -219,11 +220,24 @@ struct SegmentBatch {
 };
 }  // namespace
 
+void Searcher::apply_bound_slack(SegmentReader &seg) const {
+  const double global = (double)total_num_tokens() / (double)total_num_docs();
+  const double local = seg.max_doc() ? (double)seg.total_num_tokens() / (double)seg.max_doc() : global;
+  double ppm = 0.0;
+  if (global > 0.0 && local > 0.0 && global != local) {
+    const double d = std::abs(global - local) / std::min(global, local);
+    ppm = std::ceil(((1.0 + d) * (1.0 + d) - 1.0) * 1e6) + 2.0;  // + f32 rounding of the averages
+  }
+  const int rc = tq_set_option(seg.raw(), "bound_slack_ppm", (int64_t)std::min(ppm, 1e6));
+  if (rc != TQ_OK) throw_tq(rc);
+}
+
 void Searcher::collect_segment_batch(size_t segment_ord, const std::vector<Weight> &weights,
                                      uint32_t k, std::vector<float> &scores,
                                      std::vector<uint32_t> &docs, std::vector<uint32_t> &counts) {
   SegmentReader &seg = *segments_[segment_ord];
   const size_t n = weights.size();
+  apply_bound_slack(seg);
   SegmentBatch b(seg, weights, k);
   scores.assign(n * k, 0.0f);
   docs.assign(n * k, TERMINATED);
@@ -249,6 +263,7 @@ void Searcher::collect_segment_batch_device(size_t segment_ord, const std::vecto
                                             uint32_t k, float *d_scores, uint32_t *d_docs,
                                             uint32_t *d_counts, void *hip_stream) {
   SegmentReader &seg = *segments_[segment_ord];
+  apply_bound_slack(seg);
   SegmentBatch b(seg, weights, k);
   const int rc = tq_search_batch_device(seg.raw(), b.qs.data(), (uint32_t)weights.size(), k,
                                         d_scores, d_docs, d_counts, hip_stream);

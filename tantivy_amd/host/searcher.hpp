@@ -193,6 +193,9 @@ class Searcher {
                                     uint32_t *d_counts, void *hip_stream);
 
  private:
+  // block-max metadata was selected under the segment's own average fieldnorm; with global
+  // statistics the device widens those bounds by (1 + d)^2 (tq_common.hpp: block_max_score)
+  void apply_bound_slack(SegmentReader &seg) const;
   std::vector<std::shared_ptr<SegmentReader>> segments_;
   mutable std::shared_ptr<Bm25Weight> shared_cache_;  // one tf cache per field (avg fieldnorm)
   uint64_t remote_docs_ = 0, remote_tokens_ = 0;

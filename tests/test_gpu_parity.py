@@ -742,6 +742,38 @@ def test_two_segments_global_stats_and_merge(ta):
         dev.close()
 
 
+def test_pruning_is_exact_under_global_statistics(ta):
+    """Block-max pairs are selected under each segment's own average fieldnorm; with the global
+    statistics of a multi-segment index the device widens those bounds by (1 + d)^2
+    ("bound_slack_ppm", set by the host mirror): pruned == exhaustive on every query, also when
+    the segments' averages differ a lot."""
+    rng = np.random.default_rng(12)
+    md = 40_000
+    segs = []
+    for avg_len in (6, 60):  # very different average fieldnorms
+        lists = [random_postings(rng, md, int(df), max_tf=6) for df in
+                 (20000, 9000, 4000, 15000, 700, 12000, 2500, 30000)]
+        fieldnorms = rng.integers(1, 2 * avg_len, size=md).tolist()
+        segs.append(O.build_segment(md, lists, fieldnorms))
+    dev = ta.DeviceIndex(segs)
+    try:
+        dev.set_option("dense_ratio", 16)
+        qs = [(O.MODE_AND, rng.choice(8, size=2, replace=False).tolist()) for _ in range(60)]
+        qs += [(O.MODE_OR, rng.choice(8, size=3, replace=False).tolist()) for _ in range(30)]
+        qs += [(ta.MODE_BOOL, rng.choice(8, size=3, replace=False).tolist(), [O.MUST, O.SHOULD, O.MUST_NOT],
+                None, 0) for _ in range(30)]
+        for k in (1, 10):
+            dev.set_option("exhaustive", 1)
+            a = dev.search(qs, k)
+            dev.set_option("exhaustive", 0)
+            b = dev.search(qs, k)
+            for x, y in zip(a, b):
+                assert np.array_equal(x, y)
+        dev.set_option("exhaustive", 1)
+    finally:
+        dev.close()
+
+
 def test_device_merge_kernel_matches_host(ta):
     import ctypes as C
 
