@@ -1476,7 +1476,7 @@ int tq_set_option(tq_segment *s, const char *name, int64_t value) {
     s->opt.dense_ratio = (int)value;
   else if (!strcmp(name, "dense_budget_x") && value >= 0)
     s->opt.dense_budget_x = (int)value;
-  else if (!strcmp(name, "bound_slack_ppm") && value >= 0 && value <= 1000000)
+  else if (!strcmp(name, "bound_slack_ppm") && value >= 0 && value <= 1000000000)
     s->opt.bound_slack_ppm = (int)value;
   else if (!strcmp(name, "dense"))  // affects terms prepared afterwards
     s->opt.dense = value != 0;

@@ -228,7 +228,7 @@ void Searcher::apply_bound_slack(SegmentReader &seg) const {
     const double d = std::abs(global - local) / std::min(global, local);
     ppm = std::ceil(((1.0 + d) * (1.0 + d) - 1.0) * 1e6) + 2.0;  // + f32 rounding of the averages
   }
-  const int rc = tq_set_option(seg.raw(), "bound_slack_ppm", (int64_t)std::min(ppm, 1e6));
+  const int rc = tq_set_option(seg.raw(), "bound_slack_ppm", (int64_t)std::min(ppm, 1e9));
   if (rc != TQ_OK) throw_tq(rc);
 }
 
