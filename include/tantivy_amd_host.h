@@ -35,6 +35,7 @@ typedef struct tqh_query {
   const uint8_t *occurs;
   const uint8_t *clause_of;
   uint32_t min_should_match;
+  const float *boosts; /* per term: the TermQuery is wrapped in BoostQuery(boost) (boost_query.rs); NULL = 1 */
 } tqh_query;
 
 const char *tqh_last_error(void);

@@ -645,15 +645,20 @@ class QuerySpec:
         self.q = q
 
 
-def default_weights(seg, term_ids, mode, total_num_docs=None, total_num_tokens=None, dfs=None):
-    """Bm25Weight per term from (possibly global) statistics, as Searcher supplies them."""
+def default_weights(seg, term_ids, mode, total_num_docs=None, total_num_tokens=None, dfs=None,
+                    boosts=None):
+    """Bm25Weight per term from (possibly global) statistics, as Searcher supplies them; boosts =
+    the factors handed down by BoostWeight::scorer (boost_query.rs:70-72), applied with
+    Bm25Weight::boost_by."""
     nd = seg.max_doc if total_num_docs is None else total_num_docs
     nt = seg.total_num_tokens if total_num_tokens is None else total_num_tokens
     avg = float(np.float32(nt) / np.float32(nd))
     dfl = [seg.terms[t].doc_freq for t in term_ids] if dfs is None else dfs
     if mode == MODE_PHRASE:
         return [bm25_for_terms(dfl, nd, avg)]
-    return [bm25_for_one_term(df, nd, avg) for df in dfl]
+    if boosts is None:
+        boosts = [1.0] * len(dfl)
+    return [bm25_for_one_term(df, nd, avg, float(np.float32(b))) for df, b in zip(dfl, boosts)]
 
 
 def _hits(arr, n):
@@ -789,16 +794,16 @@ def bool_match_all(seg, term_ids, occurs, clause_of=None, min_should_match=0):
     return docs.astype(np.uint32), score[docs]
 
 
-def bool_spec(seg, term_ids, occurs, clause_of=None, min_should_match=0, k=1):
+def bool_spec(seg, term_ids, occurs, clause_of=None, min_should_match=0, k=1, boosts=None):
     """QuerySpec of a boolean query for the C executor restatement (generic scorer tree)."""
-    ws = default_weights(seg, term_ids, MODE_OR)
+    ws = default_weights(seg, term_ids, MODE_OR, boosts=boosts)
     return QuerySpec(seg, term_ids, ws, MODE_BOOL, k, None, occurs, clause_of, min_should_match)
 
 
-def bool_search(seg, term_ids, occurs, k, clause_of=None, min_should_match=0):
+def bool_search(seg, term_ids, occurs, k, clause_of=None, min_should_match=0, boosts=None):
     """Top-k through the restated scorer tree (Intersection / BufferedUnionScorer / Disjunction /
     RequiredOptionalScorer / Exclude under for_each_pruning_scorer): [(score, doc)] sorted."""
-    spec = bool_spec(seg, term_ids, occurs, clause_of, min_should_match, k)
+    spec = bool_spec(seg, term_ids, occurs, clause_of, min_should_match, k, boosts)
     out = (Hit * max(1, k))()
     n = lib().to_search_exhaustive(C.byref(seg.view), C.byref(spec.q), out)
     lib().to_sort_hits(out, n)

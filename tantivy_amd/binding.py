@@ -43,7 +43,8 @@ class TqhTermInfo(C.Structure):
 class TqhQuery(C.Structure):
     _fields_ = [("mode", C.c_uint8), ("n_terms", C.c_uint32), ("terms", C.POINTER(C.c_uint32)),
                 ("phrase_offsets", C.POINTER(C.c_uint32)), ("occurs", C.POINTER(C.c_uint8)),
-                ("clause_of", C.POINTER(C.c_uint8)), ("min_should_match", C.c_uint32)]
+                ("clause_of", C.POINTER(C.c_uint8)), ("min_should_match", C.c_uint32),
+                ("boosts", C.POINTER(C.c_float))]
 
 
 _lib = None
@@ -371,12 +372,20 @@ class DeviceIndex:
     def prepare(self, queries):
         """queries: list of (mode, [term ids]), (MODE_PHRASE, [term ids], [offsets]) or
         (MODE_BOOL, [term ids], [occurs][, clause_of | None[, min_should_match]]) with occurs in
-        {SHOULD, MUST, MUST_NOT}; terms sharing a clause_of value form one nested union."""
+        {SHOULD, MUST, MUST_NOT}; terms sharing a clause_of value form one nested union.  A trailing
+        dict {"boosts": [...]} wraps every term query in BoostQuery(boost)."""
         n = len(queries)
         qs = (TqhQuery * max(1, n))()
         keep = []
         for i, q in enumerate(queries):
+            extra = q[-1] if isinstance(q[-1], dict) else None
+            if extra is not None:
+                q = q[:-1]
             mode, terms = q[0], q[1]
+            if extra and extra.get("boosts") is not None:
+                ba = (C.c_float * len(terms))(*[float(b) for b in extra["boosts"]])
+                keep.append(ba)
+                qs[i].boosts = C.cast(ba, C.POINTER(C.c_float))
             ta = (C.c_uint32 * len(terms))(*[int(t) for t in terms])
             keep.append(ta)
             qs[i].mode = mode

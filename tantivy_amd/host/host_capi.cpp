@@ -57,6 +57,7 @@ struct tqh_query {
   const uint8_t *occurs;           // mode 4: 0 Should, 1 Must, 2 MustNot
   const uint8_t *clause_of;        // mode 4: terms sharing a value form one nested union; or null
   uint32_t min_should_match;       // mode 4
+  const float *boosts;             // modes 0, 1, 3, 4: BoostQuery factor per term query; or null
 };
 
 const char *tqh_last_error(void) { return g_err.c_str(); }
@@ -149,20 +150,23 @@ int tqh_prepare_batch(tqh_searcher *s, const tqh_query *queries, uint32_t n) {
             for (c = 0; c < ids.size() && ids[c] != id; ++c) {}
           if (c == ids.size()) {
             ids.push_back(id);
-            clauses.emplace_back(oc, Query::term_query(q.terms[t]));
+            clauses.emplace_back(oc, Query::term_query(q.terms[t]).boosted(q.boosts ? q.boosts[t] : 1.0f));
             continue;
           }
           if (clauses[c].first != oc)
             throw TantivyError(TantivyError::InvalidArgument, "a clause mixes occurs");
           Query &sub = clauses[c].second;
-          if (sub.kind == Query::Term)  // second term of the clause: it becomes a nested union
-            sub = Query::boolean({{Occur::Should, Query::term_query(sub.term)}});
-          sub.clauses.emplace_back(Occur::Should, Query::term_query(q.terms[t]));
+          if (sub.kind == Query::Term) {  // second term of the clause: it becomes a nested union
+            const Query first = sub;
+            sub = Query::boolean({{Occur::Should, first}});
+          }
+          sub.clauses.emplace_back(Occur::Should,
+                                   Query::term_query(q.terms[t]).boosted(q.boosts ? q.boosts[t] : 1.0f));
         }
         query = Query::boolean(std::move(clauses));
         query.set_minimum_number_should_match(q.min_should_match);
       } else if (q.mode == 3 || (q.n_terms == 1 && q.mode != 2)) {
-        query = Query::term_query(q.terms[0]);
+        query = Query::term_query(q.terms[0]).boosted(q.boosts ? q.boosts[0] : 1.0f);
       } else if (q.mode == 2) {
         std::vector<std::pair<uint32_t, uint32_t>> pt;
         for (uint32_t t = 0; t < q.n_terms; ++t)
@@ -172,7 +176,7 @@ int tqh_prepare_batch(tqh_searcher *s, const tqh_query *queries, uint32_t n) {
         std::vector<std::pair<Occur, Query>> clauses;
         for (uint32_t t = 0; t < q.n_terms; ++t)
           clauses.emplace_back(q.mode == 0 ? Occur::Must : Occur::Should,
-                               Query::term_query(q.terms[t]));
+                               Query::term_query(q.terms[t]).boosted(q.boosts ? q.boosts[t] : 1.0f));
         query = Query::boolean(std::move(clauses));
       }
       s->prepared.push_back(s->searcher->weight(query));

@@ -101,16 +101,20 @@ Weight Searcher::weight(const Query &query) const {
   }
   Weight w;
   w.bm25 = shared_cache_;
-  auto term_weight = [&](uint32_t term) {
+  // Weight::scorer(reader, boost) starts at 1.0; every BoostWeight multiplies its own factor in
+  // (boost_query.rs:70-72) and the leaf applies Bm25Weight::boost_by(boost) (bm25.rs:82-92)
+  auto boost_by = [](Score weight, Score boost) { return boost == 1.0f ? weight : weight * boost; };
+  const Score b0 = 1.0f * query.boost;
+  auto term_weight = [&](uint32_t term, Score boost) {
     // TermQuery::specialized_weight -> Bm25Weight::for_terms(statistics, [term])
-    return idf(doc_freq(term), nd) * (1.0f + K1);
+    return boost_by(idf(doc_freq(term), nd) * (1.0f + K1), boost);
   };
   switch (query.kind) {
     case Query::Term:
       // TermWeight::for_each_pruning == one-scorer block-WAND == every doc of the list
       w.mode = TQ_MODE_OR;
       w.terms = {query.term};
-      w.weights = {term_weight(query.term)};
+      w.weights = {term_weight(query.term, b0)};
       return w;
     case Query::Phrase: {
       if (query.phrase_terms.size() < 2)
@@ -123,7 +127,7 @@ Weight Searcher::weight(const Query &query) const {
         w.terms.push_back(ot.second);
         idf_sum += idf(doc_freq(ot.second), nd);
       }
-      w.weights = {idf_sum * (1.0f + K1)};
+      w.weights = {boost_by(idf_sum * (1.0f + K1), b0)};
       return w;
     }
     case Query::Boolean: {
@@ -165,18 +169,19 @@ Weight Searcher::weight(const Query &query) const {
                                ? (uint8_t)TQ_MUST
                                : (c.first == Occur::MustNot ? (uint8_t)TQ_MUST_NOT
                                                             : (uint8_t)TQ_SHOULD);
-        auto add = [&](uint32_t term) {
+        const Score bc = b0 * c.second.boost;  // the clause's own BoostQuery wrapper, if any
+        auto add = [&](uint32_t term, Score boost) {
           w.terms.push_back(term);
-          w.weights.push_back(term_weight(term));
+          w.weights.push_back(term_weight(term, boost));
           if (w.mode == TQ_MODE_BOOL) {
             w.occurs.push_back(oc);
             w.clause_of.push_back(clause);
           }
         };
         if (c.second.kind == Query::Term)
-          add(c.second.term);
+          add(c.second.term, bc);
         else
-          for (auto &sub : c.second.clauses) add(sub.second.term);
+          for (auto &sub : c.second.clauses) add(sub.second.term, bc * sub.second.boost);
         ++clause;
       }
       if (w.terms.size() > TQ_MAX_TERMS)

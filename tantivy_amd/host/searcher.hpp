@@ -88,6 +88,9 @@ struct Query {
   // Boolean: clauses of (Occur, sub query)
   std::vector<std::pair<Occur, Query>> clauses;
   size_t minimum_number_should_match = 0;  // boolean_query.rs:146-150
+  // BoostQuery::new(this, boost) (boost_query.rs:14-31): BoostWeight::scorer hands
+  // `boost * self.boost` down the tree (:70-72) and the leaves apply Bm25Weight::boost_by
+  Score boost = 1.0f;
   // Phrase: (offset, term), slop 0 (phrase_query.rs:28-63)
   std::vector<std::pair<uint32_t, uint32_t>> phrase_terms;
 
@@ -102,6 +105,10 @@ struct Query {
     q.kind = Boolean;
     q.clauses = std::move(clauses);
     return q;
+  }
+  Query &boosted(Score b) {  // one BoostQuery wrapper per node
+    boost = b;
+    return *this;
   }
   // BooleanQuery::set_minimum_number_should_match
   Query &set_minimum_number_should_match(size_t n) {

@@ -942,3 +942,26 @@ def test_full_size_boolean(ta, big):
     dev.set_option("exhaustive", 1)
     for x, y in zip(a, b):
         assert np.array_equal(x, y)
+
+
+def test_boosted_term_queries(synth, ta):
+    """BoostQuery around term queries (boost_query.rs: the boost reaches the leaf through
+    Weight::scorer(reader, boost) and Bm25Weight::boost_by), in AND / OR / boolean queries —
+    negative boosts included (they switch the block-max pruning off)."""
+    seg, dev = synth
+    cases = [((O.MODE_AND, [0, 1]), [2.0, 0.5]), ((O.MODE_AND, [3, 20, 7]), [1.0, 3.25, 0.125]),
+             ((O.MODE_OR, [2, 9]), [0.75, 4.0]), ((O.MODE_OR, [5]), [7.0]),
+             ((O.MODE_AND, [4, 6]), [-1.0, 2.0])]
+    for ex in (1, 0):
+        dev.set_option("exhaustive", ex)
+        got = _device_topk(dev, [q + ({"boosts": b},) for q, b in cases], 10)
+        for (q, b), g in zip(cases, got):
+            w = O.default_weights(seg, q[1], q[0], boosts=b)
+            _assert_hits_equal(g, O.search(seg, q[1], q[0], 10, weights=w, pruned=False))
+        M, S, N = O.MUST, O.SHOULD, O.MUST_NOT
+        bq = [((ta.MODE_BOOL, [0, 5, 9], [M, S, N], None, 0), [1.5, 2.0, 1.0]),
+              ((ta.MODE_BOOL, [10, 3, 4], [M, M, M], [0, 1, 1], 0), [0.5, 2.0, 3.0])]
+        got = _device_topk(dev, [q + ({"boosts": b},) for q, b in bq], 10)
+        for (q, b), g in zip(bq, got):
+            _assert_hits_equal(g, O.bool_search(seg, q[1], q[2], 10, q[3], q[4], boosts=b))
+    dev.set_option("exhaustive", 1)
