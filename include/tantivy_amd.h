@@ -16,6 +16,10 @@
  * Thread-safety: one tq_segment may be searched from one thread at a time (it owns one HIP
  * stream and its scratch buffers); different segments may be searched concurrently — that is
  * tantivy's own "one task per segment" executor model (src/core/executor.rs:44-106).
+ * Streams: consecutive batches on one segment share its scratch buffers.  A batch enqueued on
+ * another stream than the previous one first waits (stream-side, no host block) for that batch;
+ * the host paths (tq_search_batch, tq_count_batch, tq_decode_*, tq_segment_set_alive_bitset,
+ * tq_last_batch_*) wait for whatever the segment still has in flight on any stream.
  */
 #ifndef TANTIVY_AMD_H
 #define TANTIVY_AMD_H
@@ -134,6 +138,31 @@ int tq_search_batch(tq_segment *seg, const tq_query *queries, uint32_t n_queries
 int tq_search_batch_device(tq_segment *seg, const tq_query *queries, uint32_t n_queries,
                            uint32_t out_stride, float *d_out_scores, uint32_t *d_out_docs,
                            uint32_t *d_out_counts, void *hip_stream);
+
+/* Per-call execution options: everything a call needs that is not part of the queries.  Carried
+ * per call (not as segment state) so that two Searchers / threads sharing the statistics of
+ * different indexes never race on a segment's options.
+ *   exhaustive       -1 = the segment's "exhaustive" option (tq_set_option), 0 = block-max pruning
+ *                    as block_wand / block_wand_intersection do, 1 = score every match
+ *   bound_slack_ppm  TQ_OPT_DEFAULT = the segment's option; else block-max bounds are widened by
+ *                    (1 + ppm * 1e-6) for THIS call.  Callers whose Bm25Weights come from global
+ *                    (cross-segment) statistics MUST pass ((1 + d)^2 - 1) * 1e6 with d = the
+ *                    relative difference between the global and this segment's average
+ *                    fieldnorm, or pruning is only as exact as the reference's own
+ *                    (term_scorer.rs:58-70); the host mirror (Searcher) does. */
+#define TQ_OPT_DEFAULT 0xFFFFFFFFu
+typedef struct tq_search_opts {
+  int32_t exhaustive;
+  uint32_t bound_slack_ppm;
+} tq_search_opts;
+/* tq_search_batch / tq_search_batch_device with per-call options (opts == NULL: segment defaults). */
+int tq_search_batch_opts(tq_segment *seg, const tq_query *queries, uint32_t n_queries,
+                         uint32_t out_stride, float *out_scores, uint32_t *out_docs,
+                         uint32_t *out_counts, const tq_search_opts *opts);
+int tq_search_batch_device_opts(tq_segment *seg, const tq_query *queries, uint32_t n_queries,
+                                uint32_t out_stride, float *d_out_scores, uint32_t *d_out_docs,
+                                uint32_t *d_out_counts, const tq_search_opts *opts,
+                                void *hip_stream);
 
 /* replaces: TopBySortKeyCollector::merge_fruits -> merge_top_k
  * (src/collector/sort_key_top_collector.rs:54-95; ordering top_score_collector.rs:590-600):

@@ -22,11 +22,14 @@ typedef struct tqh_term_info {
   uint64_t postings_start, postings_end, positions_start, positions_end;
 } tqh_term_info;
 
-/* mode: 0 = BooleanQuery of Must term clauses, 1 = BooleanQuery of Should term clauses,
- *       2 = PhraseQuery (offsets 0..n unless phrase_offsets given), 3 = TermQuery,
- *       4 = BooleanQuery with per-term occurs (0 Should, 1 Must, 2 MustNot); terms sharing a
- *           clause_of value form one nested union (`+a +(b OR c)`); min_should_match as
- *           BooleanQuery::set_minimum_number_should_match */
+/* mode: the values of enum tq_mode (tantivy_amd.h) —
+ *       TQ_MODE_AND (0) = BooleanQuery of Must term clauses, TQ_MODE_OR (1) = BooleanQuery of
+ *       Should term clauses, TQ_MODE_PHRASE (2) = PhraseQuery (offsets 0..n unless phrase_offsets
+ *       given), TQ_MODE_BOOL (3) = BooleanQuery with per-term occurs (0 Should, 1 Must,
+ *       2 MustNot); terms sharing a clause_of value form one nested union (`+a +(b OR c)`);
+ *       min_should_match as BooleanQuery::set_minimum_number_should_match —
+ *       plus TQH_MODE_TERM (4) = TermQuery.  Anything else: TQ_ERR_INVALID. */
+#define TQH_MODE_TERM 4
 typedef struct tqh_query {
   uint8_t mode;
   uint32_t n_terms;
@@ -35,7 +38,8 @@ typedef struct tqh_query {
   const uint8_t *occurs;
   const uint8_t *clause_of;
   uint32_t min_should_match;
-  const float *boosts; /* per term: the TermQuery is wrapped in BoostQuery(boost) (boost_query.rs); NULL = 1 */
+  const float *boosts; /* per term: the TermQuery is wrapped in BoostQuery(boost) (boost_query.rs);
+                          PHRASE: boosts[0] wraps the PhraseQuery; NULL = 1 */
 } tqh_query;
 
 const char *tqh_last_error(void);

@@ -9,7 +9,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libtantivy_amd.so")
 
 TERMINATED = 0x7FFFFFFF
 TERM_ABSENT = 0xFFFFFFFF
-MODE_AND, MODE_OR, MODE_PHRASE, MODE_TERM, MODE_BOOL = 0, 1, 2, 3, 4
+MODE_AND, MODE_OR, MODE_PHRASE, MODE_BOOL, MODE_TERM = 0, 1, 2, 3, 4  # enum tq_mode + TQH_MODE_TERM
 SHOULD, MUST, MUST_NOT = 0, 1, 2  # src/query/occur.rs
 BASIC, WITH_FREQS, WITH_FREQS_AND_POSITIONS = 0, 1, 2
 
@@ -26,6 +26,13 @@ class TqQuery(C.Structure):
                 ("mode", C.c_uint8), ("phrase_offsets", C.POINTER(C.c_uint32)),
                 ("k", C.c_uint32), ("occurs", C.POINTER(C.c_uint8)),
                 ("clause_of", C.POINTER(C.c_uint8)), ("min_should_match", C.c_uint32)]
+
+
+class TqSearchOpts(C.Structure):
+    _fields_ = [("exhaustive", C.c_int32), ("bound_slack_ppm", C.c_uint32)]
+
+
+OPT_DEFAULT = 0xFFFFFFFF
 
 
 class TqBatchStats(C.Structure):
@@ -51,7 +58,8 @@ _lib = None
 
 EXPORTS = [
     "tq_init", "tq_shutdown", "tq_last_error", "tq_segment_upload", "tq_segment_free",
-    "tq_term_prepare", "tq_search_batch", "tq_search_batch_device", "tq_merge_topk",
+    "tq_term_prepare", "tq_search_batch", "tq_search_batch_device", "tq_search_batch_opts",
+    "tq_search_batch_device_opts", "tq_merge_topk",
     "tq_merge_topk_device", "tq_decode_postings", "tq_decode_position_deltas",
     "tq_last_batch_stats", "tq_set_option", "tq_segment_set_alive_bitset", "tq_count_batch",
     "tq_last_batch_match_counts", "tq_encoder_create", "tq_encoder_free", "tq_encode_postings",
@@ -89,6 +97,10 @@ def lib():
     L.tq_search_batch.argtypes = [vp, C.POINTER(TqQuery), C.c_uint32, C.c_uint32, f32p, u32p, u32p]
     L.tq_search_batch_device.argtypes = [vp, C.POINTER(TqQuery), C.c_uint32, C.c_uint32, vp, vp,
                                          vp, vp]
+    L.tq_search_batch_opts.argtypes = [vp, C.POINTER(TqQuery), C.c_uint32, C.c_uint32, f32p, u32p,
+                                       u32p, C.POINTER(TqSearchOpts)]
+    L.tq_search_batch_device_opts.argtypes = [vp, C.POINTER(TqQuery), C.c_uint32, C.c_uint32, vp,
+                                              vp, vp, C.POINTER(TqSearchOpts), vp]
     L.tq_merge_topk.argtypes = [f32p, u32p, u32p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
                                 C.c_uint32, f32p, u32p, u32p, u32p]
     L.tq_merge_topk_device.argtypes = [vp, C.c_int, vp, vp, vp, vp, C.c_uint32, C.c_uint32,
@@ -525,9 +537,10 @@ class DeviceIndex:
         _check(lib().tq_count_batch(self.segment_raw(segment_ord), qs, n, _u32(counts)))
         return counts[:n]
 
-    def raw_search(self, queries, weights, cache, k, segment_ord=0, stride=None):
-        """Direct tq_search_batch: queries = list of (mode, [term ids], offsets|None);
-        weights = list of per-query float lists; cache = np.float32[256]."""
+    def raw_search(self, queries, weights, cache, k, segment_ord=0, stride=None, opts=None):
+        """Direct tq_search_batch[_opts]: queries = list of (mode, [term ids], offsets|None);
+        weights = list of per-query float lists; cache = np.float32[256]; opts = (exhaustive,
+        bound_slack_ppm) for this call only (tq_search_opts) or None."""
         n = len(queries)
         stride = k if stride is None else stride
         qs = (TqQuery * max(1, n))()
@@ -547,7 +560,7 @@ class DeviceIndex:
                 oa = (C.c_uint32 * len(terms))(*q[2])
                 keep.append(oa)
                 qs[i].phrase_offsets = C.cast(oa, C.POINTER(C.c_uint32))
-            if len(q) > 3 and q[3] is not None:  # TQ_MODE_BOOL (= 3 at this level): enum tq_occur
+            if len(q) > 3 and q[3] is not None:  # TQ_MODE_BOOL: enum tq_occur
                 oc = (C.c_uint8 * len(terms))(*q[3])
                 keep.append(oc)
                 qs[i].occurs = C.cast(oc, C.POINTER(C.c_uint8))
@@ -561,6 +574,11 @@ class DeviceIndex:
         scores = np.zeros((n, stride), np.float32)
         docs = np.zeros((n, stride), np.uint32)
         counts = np.zeros(n, np.uint32)
-        _check(lib().tq_search_batch(self.segment_raw(segment_ord), qs, n, stride, _f32(scores),
-                                     _u32(docs), _u32(counts)))
+        if opts is not None:
+            o = TqSearchOpts(int(opts[0]), int(opts[1]))
+            _check(lib().tq_search_batch_opts(self.segment_raw(segment_ord), qs, n, stride,
+                                              _f32(scores), _u32(docs), _u32(counts), C.byref(o)))
+        else:
+            _check(lib().tq_search_batch(self.segment_raw(segment_ord), qs, n, stride, _f32(scores),
+                                         _u32(docs), _u32(counts)))
         return scores, docs, counts

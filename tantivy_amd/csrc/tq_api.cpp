@@ -10,6 +10,7 @@
 
 #include <algorithm>
 #include <chrono>
+#include <cmath>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
@@ -174,6 +175,12 @@ struct tq_segment {
   // between them) can all be timed; tq_last_batch_stats averages the batches since its last call
   static constexpr int kTimingRing = 16;
   hipEvent_t ev_stage_done = nullptr, ev_fork = nullptr, ev_join = nullptr;
+  // The per-segment scratch (query descriptors, partial lists, threshold slots, counters, the
+  // side stream) is shared by consecutive batches: work enqueued on another stream than the
+  // previous batch's must first wait for that batch (ev_batch_done, recorded at its end).
+  hipEvent_t ev_batch_done = nullptr;
+  hipStream_t last_stream = nullptr;
+  bool batch_in_flight = false;
   hipStream_t side_stream = nullptr;  // the launch groups of one batch run concurrently
   hipEvent_t ev_t0[kTimingRing] = {}, ev_t1[kTimingRing] = {}, ev_k0[kTimingRing] = {},
              ev_k1[kTimingRing] = {};
@@ -187,6 +194,23 @@ struct tq_segment {
 
 namespace {
 int sync_terms(tq_segment *s, hipStream_t st);
+
+// Orders work about to be enqueued on `st` after the segment's previous batch, whatever stream
+// that batch ran on (no-op when it is the same stream: stream order already holds).
+int order_after_last_batch(tq_segment *s, hipStream_t st) {
+  if (s->batch_in_flight && s->last_stream != st)
+    HIP_TRY(hipStreamWaitEvent(st, s->ev_batch_done, 0));
+  return TQ_OK;
+}
+// Host-side wait for everything the segment has in flight (its own stream and the last batch).
+int wait_segment_idle(tq_segment *s) {
+  HIP_TRY(hipStreamSynchronize(s->stream));
+  if (s->batch_in_flight) {
+    HIP_TRY(hipEventSynchronize(s->ev_batch_done));
+    s->batch_in_flight = false;
+  }
+  return TQ_OK;
+}
 
 // Dense lists (doc_freq >= max_doc/TQD_DENSE_RATIO) also get a membership bitmap with a rank
 // directory: the list is decoded once on the device (the same kernel as tq_decode_postings),
@@ -299,6 +323,7 @@ int tq_segment_upload(tq_ctx *ctx, int device, uint32_t max_doc, const uint8_t *
     if (e == hipSuccess) e = hipEventCreateWithFlags(&s->ev_stage_done, hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&s->ev_fork, hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&s->ev_join, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&s->ev_batch_done, hipEventDisableTiming);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&s->side_stream, hipStreamNonBlocking);
     for (int i = 0; i < tq_segment::kTimingRing; ++i) {
       if (e == hipSuccess) e = hipEventCreate(&s->ev_t0[i]);
@@ -332,6 +357,7 @@ void tq_segment_free(tq_segment *s) {
   if (!s) return;
   (void)hipSetDevice(s->device);
   if (s->stream) (void)hipStreamSynchronize(s->stream);
+  if (s->batch_in_flight && s->ev_batch_done) (void)hipEventSynchronize(s->ev_batch_done);
   for (auto &t : s->terms)
     if (t.blob) (void)hipFree(t.blob);
   for (auto &t : s->terms)
@@ -353,7 +379,7 @@ void tq_segment_free(tq_segment *s) {
   s->h_stage.release();
   s->h_out.release();
   if (s->side_stream) (void)hipStreamSynchronize(s->side_stream);
-  for (hipEvent_t ev : {s->ev_stage_done, s->ev_fork, s->ev_join})
+  for (hipEvent_t ev : {s->ev_stage_done, s->ev_fork, s->ev_join, s->ev_batch_done})
     if (ev) (void)hipEventDestroy(ev);
   if (s->side_stream) (void)hipStreamDestroy(s->side_stream);
   for (int i = 0; i < tq_segment::kTimingRing; ++i)
@@ -607,8 +633,12 @@ namespace {
 int sync_terms(tq_segment *s, hipStream_t st) {
   if (!s->d_terms_dirty) return TQ_OK;
   const size_t n = s->h_dterms.size();
+  // nothing in flight may still read the table while it is rewritten (terms are prepared rarely)
+  {
+    const int wrc = wait_segment_idle(s);
+    if (wrc != TQ_OK) return wrc;
+  }
   if (n > s->d_terms_cap) {
-    // make sure nothing in flight still reads the old table
     HIP_TRY(hipStreamSynchronize(st));
     if (s->d_terms) (void)hipFree(s->d_terms);
     s->d_terms = nullptr;
@@ -803,7 +833,7 @@ int build_group_chunks(Group &g, bool or_windows) {
 // Planning of one TQ_MODE_BOOL query: clause layout of the union kernel (tq_union.hip), pruning
 // flags, tile sizes.  An empty result leaves dq.n_terms == 0 and n_tiles == 0.
 int plan_bool_query(tq_segment *s, const tq_query &q, uint32_t qi, TqdQuery &dq, uint64_t &qbytes,
-                    uint32_t &n_tiles, uint32_t &tile_cost, uint32_t &n_thr_rows) {
+                    uint32_t &n_tiles, uint32_t &tile_cost, uint32_t &n_thr_rows, bool exhaustive) {
   // BooleanQuery whose clauses are terms or unions of terms (`+a b -c`, `+a +(b OR c)`),
   // BooleanWeight::complex_scorer (boolean_weight.rs:236-431).  A clause = the terms sharing
   // one clause_of value.  Absent terms are EmptyScorers: they drop out of unions, an empty
@@ -884,7 +914,7 @@ int plan_bool_query(tq_segment *s, const tq_query &q, uint32_t qi, TqdQuery &dq,
                        [&](uint32_t a, uint32_t b) { return cl[a].cost < cl[b].cost; });
       // optional Should lists lead too (MaxScore for RequiredOptionalScorer, see union_body)
       // (only when pruning: with every match scored the extra ownership probes cost 60 %)
-      const bool opt_lead = n_should > 0 && msm == 0 && !s->opt.exhaustive;
+      const bool opt_lead = n_should > 0 && msm == 0 && !exhaustive;
       if (opt_lead) {
         for (uint32_t c = 0; c < n_should; ++c)
           for (uint32_t i = 0; i < cl[should[c]].n; ++i) flat[n_flat++] = cl[should[c]].terms[i];
@@ -926,7 +956,7 @@ int plan_bool_query(tq_segment *s, const tq_query &q, uint32_t qi, TqdQuery &dq,
       nonneg = nonneg && dq.weight[i] >= 0.0f;
       if (!(s->terms[dq.term[i]].dense_blob && s->opt.use_dense)) ++sparse;
     }
-    if (!s->opt.exhaustive && nonneg) {
+    if (!exhaustive && nonneg) {
       dq.flags |= TQD_QF_PRUNE;
       if (q.k <= 2 * TQD_THR_SLOTS) {
         dq.thr_index = n_thr_rows;
@@ -950,11 +980,18 @@ int plan_bool_query(tq_segment *s, const tq_query &q, uint32_t qi, TqdQuery &dq,
 
 }  // namespace
 
-extern "C" {
+namespace {
 
-int tq_search_batch_device(tq_segment *s, const tq_query *queries, uint32_t n_queries,
-                           uint32_t out_stride, float *d_out_scores, uint32_t *d_out_docs,
-                           uint32_t *d_out_counts, void *hip_stream) {
+// Per-call execution options (tq_search_opts resolved against the segment's defaults): nothing
+// a call needs is read from mutable segment state after this point.
+struct CallOpts {
+  bool exhaustive;
+  float bound_slack;
+};
+
+int search_batch_impl(tq_segment *s, const tq_query *queries, uint32_t n_queries,
+                      uint32_t out_stride, float *d_out_scores, uint32_t *d_out_docs,
+                      uint32_t *d_out_counts, void *hip_stream, const CallOpts &co) {
   if (!s || (!queries && n_queries) || !d_out_scores || !d_out_docs || !d_out_counts)
     return fail(TQ_ERR_INVALID, "tq_search_batch: null argument");
   if (n_queries == 0) return TQ_OK;
@@ -964,9 +1001,10 @@ int tq_search_batch_device(tq_segment *s, const tq_query *queries, uint32_t n_qu
   hipStream_t st = hip_stream ? (hipStream_t)hip_stream : s->stream;
   int rc = sync_terms(s, st);
   if (rc != TQ_OK) return rc;
+  const int opt_exhaustive = co.exhaustive ? 1 : 0;
 
   // ---- plan
-  const bool or_windows_opt = s->opt.or_windows < 0 ? s->opt.exhaustive != 0 : s->opt.or_windows != 0;
+  const bool or_windows_opt = s->opt.or_windows < 0 ? opt_exhaustive != 0 : s->opt.or_windows != 0;
   // launch groups: AND queries whose non-leader lists all have a bitmap run a leaner kernel
   // instantiation (no seek / block-search code: fewer registers, less LDS, more waves per CU)
   // boolean queries (clauses with roles) run the candidate-driven union kernel's BOOL instantiation
@@ -996,6 +1034,10 @@ int tq_search_batch_device(tq_segment *s, const tq_query *queries, uint32_t n_qu
       return fail(TQ_ERR_INVALID, "query %u: a phrase needs >= 2 terms and offsets", qi);
     if (q.mode == TQ_MODE_PHRASE && q.n_terms > 8)
       return fail(TQ_ERR_UNSUPPORTED, "query %u: device phrases take at most 8 terms", qi);
+    // NaN / inf weights (boosts) would break the total order of the top-k keys and of merge_top_k
+    for (uint32_t i = 0; i < (q.mode == TQ_MODE_PHRASE ? 1u : q.n_terms); ++i)
+      if (!std::isfinite(q.weights[i]))
+        return fail(TQ_ERR_INVALID, "query %u: weight %u is not finite", qi, i);
     uint32_t cache_idx = 0;
     for (; cache_idx < caches.size(); ++cache_idx)
       if (caches[cache_idx] == q.tf_cache) break;
@@ -1061,7 +1103,7 @@ int tq_search_batch_device(tq_segment *s, const tq_query *queries, uint32_t n_qu
           n_tiles = (lead_blocks + dq.tile_blocks - 1) / dq.tile_blocks;
           bool nonneg = true;
           for (uint32_t i = 0; i < q.n_terms; ++i) nonneg = nonneg && dq.weight[i] >= 0.0f;
-          if (!s->opt.exhaustive && nonneg) {  // block-max bounds need weights >= 0
+          if (!opt_exhaustive && nonneg) {  // block-max bounds need weights >= 0
             dq.flags |= TQD_QF_PRUNE;
             // the shared threshold pays off on long lists only; k-th largest of 64 slots needs k <= 64
             if (q.k <= TQD_THR_SLOTS && n_tiles >= 2) dq.thr_index = n_thr_rows++;
@@ -1076,7 +1118,7 @@ int tq_search_batch_device(tq_segment *s, const tq_query *queries, uint32_t n_qu
     }
     bool bool_done = false;
     if (q.mode == TQ_MODE_BOOL) {
-      const int rc = plan_bool_query(s, q, qi, dq, qbytes, n_tiles, tile_cost, n_thr_rows);
+      const int rc = plan_bool_query(s, q, qi, dq, qbytes, n_tiles, tile_cost, n_thr_rows, opt_exhaustive != 0);
       if (rc != TQ_OK) return rc;
       mode = TQ_MODE_OR;  // runs in the union launch group
       bool_done = true;
@@ -1112,7 +1154,7 @@ int tq_search_batch_device(tq_segment *s, const tq_query *queries, uint32_t n_qu
           dq.weight[i] = w2[i];
           nonneg = nonneg && w2[i] >= 0.0f;
         }
-        if (!s->opt.exhaustive && nonneg && dq.n_terms) {
+        if (!opt_exhaustive && nonneg && dq.n_terms) {
           dq.flags |= TQD_QF_PRUNE;
           if (q.k <= 2 * TQD_THR_SLOTS) {  // k-th largest of 64 (128) slots needs k <= 64 (128)
             dq.thr_index = n_thr_rows;
@@ -1234,6 +1276,9 @@ int tq_search_batch_device(tq_segment *s, const tq_query *queries, uint32_t n_qu
   }
   const auto tr2 = std::chrono::steady_clock::now();
   const int slot = (int)(s->batches_timed % tq_segment::kTimingRing);
+  // the scratch below is shared with the previous batch: wait for it if it ran on another stream
+  rc = order_after_last_batch(s, st);
+  if (rc != TQ_OK) return rc;
   if (s->opt.timing) HIP_TRY(hipEventRecord(s->ev_t0[slot], st));
   HIP_TRY(hipMemcpyAsync(s->d_stage.p, hs, stage, hipMemcpyHostToDevice, st));
   HIP_TRY(hipEventRecord(s->ev_stage_done, st));
@@ -1283,14 +1328,14 @@ int tq_search_batch_device(tq_segment *s, const tq_query *queries, uint32_t n_qu
     p.chunk_starts = (const uint32_t *)(ds + g.o_chunks);
     p.chunk_perm = (const uint32_t *)(ds + g.o_perm);
     p.n_chunks = g.n_chunks;
-    p.exhaustive = (uint32_t)s->opt.exhaustive;
+    p.exhaustive = (uint32_t)opt_exhaustive;
     p.use_dense = (uint32_t)s->opt.use_dense;
     p.all_dense = gi == 0 ? 1u : 0u;
     static const uint32_t kDebug = tune_u32("TQ_DEBUG", 0);
     p.debug = kDebug;
     p.or_windows = (or_windows_opt && gi != kBool) ? 1u : 0u;
     p.boolean = gi == kBool ? 1u : 0u;
-    p.bound_slack = 1.0f + (float)s->opt.bound_slack_ppm * 1e-6f;
+    p.bound_slack = co.bound_slack;
     p.max_terms = 0;
     for (const TqdQuery &dq : g.queries) p.max_terms = std::max(p.max_terms, dq.n_terms);
     tiles_total += g.total_tiles;
@@ -1328,6 +1373,9 @@ int tq_search_batch_device(tq_segment *s, const tq_query *queries, uint32_t n_qu
     HIP_TRY(hipEventRecord(s->ev_t1[slot], st));
     ++s->batches_timed;
   }
+  HIP_TRY(hipEventRecord(s->ev_batch_done, st));
+  s->last_stream = st;
+  s->batch_in_flight = true;
   if (trace) {
     const auto tr3 = std::chrono::steady_clock::now();
     auto us = [](auto a, auto b) { return (long)std::chrono::duration_cast<std::chrono::microseconds>(b - a).count(); };
@@ -1345,9 +1393,71 @@ int tq_search_batch_device(tq_segment *s, const tq_query *queries, uint32_t n_qu
   return TQ_OK;
 }
 
+int resolve_opts(const tq_segment *s, const tq_search_opts *o, CallOpts &co) {
+  co.exhaustive = s->opt.exhaustive != 0;
+  uint32_t ppm = (uint32_t)s->opt.bound_slack_ppm;
+  if (o) {
+    if (o->exhaustive == 0 || o->exhaustive == 1)
+      co.exhaustive = o->exhaustive != 0;
+    else if (o->exhaustive != -1)
+      return fail(TQ_ERR_INVALID, "tq_search_opts.exhaustive must be -1, 0 or 1");
+    if (o->bound_slack_ppm != TQ_OPT_DEFAULT) ppm = o->bound_slack_ppm;
+    if (ppm > 1000000000u) return fail(TQ_ERR_INVALID, "bound_slack_ppm above 1e9");
+  }
+  co.bound_slack = 1.0f + (float)ppm * 1e-6f;
+  return TQ_OK;
+}
+
+int search_batch_host(tq_segment *s, const tq_query *queries, uint32_t n_queries,
+                      uint32_t out_stride, float *out_scores, uint32_t *out_docs,
+                      uint32_t *out_counts, const CallOpts &co);
+
+}  // namespace
+
+extern "C" {
+
+int tq_search_batch_device(tq_segment *s, const tq_query *queries, uint32_t n_queries,
+                           uint32_t out_stride, float *d_out_scores, uint32_t *d_out_docs,
+                           uint32_t *d_out_counts, void *hip_stream) {
+  return tq_search_batch_device_opts(s, queries, n_queries, out_stride, d_out_scores, d_out_docs,
+                                     d_out_counts, nullptr, hip_stream);
+}
+
+int tq_search_batch_device_opts(tq_segment *s, const tq_query *queries, uint32_t n_queries,
+                                uint32_t out_stride, float *d_out_scores, uint32_t *d_out_docs,
+                                uint32_t *d_out_counts, const tq_search_opts *opts,
+                                void *hip_stream) {
+  if (!s) return fail(TQ_ERR_INVALID, "tq_search_batch: null segment");
+  CallOpts co;
+  const int rc = resolve_opts(s, opts, co);
+  if (rc != TQ_OK) return rc;
+  return search_batch_impl(s, queries, n_queries, out_stride, d_out_scores, d_out_docs,
+                           d_out_counts, hip_stream, co);
+}
+
 int tq_search_batch(tq_segment *s, const tq_query *queries, uint32_t n_queries,
                     uint32_t out_stride, float *out_scores, uint32_t *out_docs,
                     uint32_t *out_counts) {
+  return tq_search_batch_opts(s, queries, n_queries, out_stride, out_scores, out_docs, out_counts,
+                              nullptr);
+}
+
+int tq_search_batch_opts(tq_segment *s, const tq_query *queries, uint32_t n_queries,
+                         uint32_t out_stride, float *out_scores, uint32_t *out_docs,
+                         uint32_t *out_counts, const tq_search_opts *opts) {
+  if (!s) return fail(TQ_ERR_INVALID, "tq_search_batch: null segment");
+  CallOpts co;
+  const int rc = resolve_opts(s, opts, co);
+  if (rc != TQ_OK) return rc;
+  return search_batch_host(s, queries, n_queries, out_stride, out_scores, out_docs, out_counts, co);
+}
+
+}  // extern "C"
+
+namespace {
+int search_batch_host(tq_segment *s, const tq_query *queries, uint32_t n_queries,
+                      uint32_t out_stride, float *out_scores, uint32_t *out_docs,
+                      uint32_t *out_counts, const CallOpts &co) {
   if (!s || !out_scores || !out_docs || !out_counts)
     return fail(TQ_ERR_INVALID, "tq_search_batch: null argument");
   if (n_queries == 0) return TQ_OK;
@@ -1357,8 +1467,8 @@ int tq_search_batch(tq_segment *s, const tq_query *queries, uint32_t n_queries,
   if (rc == TQ_OK) rc = s->d_out_docs.ensure(n * sizeof(uint32_t));
   if (rc == TQ_OK) rc = s->d_out_counts.ensure((size_t)n_queries * sizeof(uint32_t));
   if (rc != TQ_OK) return rc;
-  rc = tq_search_batch_device(s, queries, n_queries, out_stride, (float *)s->d_out_scores.p,
-                              (uint32_t *)s->d_out_docs.p, (uint32_t *)s->d_out_counts.p, nullptr);
+  rc = search_batch_impl(s, queries, n_queries, out_stride, (float *)s->d_out_scores.p,
+                         (uint32_t *)s->d_out_docs.p, (uint32_t *)s->d_out_counts.p, nullptr, co);
   if (rc != TQ_OK) return rc;
   HIP_TRY(hipMemcpyAsync(out_scores, s->d_out_scores.p, n * sizeof(float), hipMemcpyDeviceToHost,
                          s->stream));
@@ -1369,11 +1479,17 @@ int tq_search_batch(tq_segment *s, const tq_query *queries, uint32_t n_queries,
   HIP_TRY(hipStreamSynchronize(s->stream));
   return TQ_OK;
 }
+}  // namespace
+
+extern "C" {
 
 int tq_segment_set_alive_bitset(tq_segment *s, const uint8_t *bytes, size_t len) {
   if (!s) return fail(TQ_ERR_INVALID, "tq_segment_set_alive_bitset: null segment");
   HIP_TRY(hipSetDevice(s->device));
-  HIP_TRY(hipStreamSynchronize(s->stream));
+  {
+    const int wrc = wait_segment_idle(s);  // batches may run on a caller's stream
+    if (wrc != TQ_OK) return wrc;
+  }
   if (s->d_alive) (void)hipFree(s->d_alive);
   s->d_alive = nullptr;
   s->dseg.alive = nullptr;
@@ -1396,7 +1512,10 @@ int tq_last_batch_match_counts(tq_segment *s, uint32_t *out, uint32_t n) {
   if (!s || !out) return fail(TQ_ERR_INVALID, "tq_last_batch_match_counts: null argument");
   if (n > s->last_batch_queries) return fail(TQ_ERR_INVALID, "the last batch had %u queries", s->last_batch_queries);
   HIP_TRY(hipSetDevice(s->device));
-  HIP_TRY(hipStreamSynchronize(s->stream));
+  {
+    const int wrc = wait_segment_idle(s);
+    if (wrc != TQ_OK) return wrc;
+  }
   HIP_TRY(hipMemcpy(out, s->d_qmatches.p, (size_t)n * sizeof(uint32_t), hipMemcpyDeviceToHost));
   return TQ_OK;
 }
@@ -1411,10 +1530,11 @@ int tq_count_batch(tq_segment *s, const tq_query *queries, uint32_t n_queries,
   for (tq_query &q : qs) q.k = 1;
   std::vector<float> sc(n_queries);
   std::vector<uint32_t> dc(n_queries), ct(n_queries);
-  const int saved = s->opt.exhaustive;
-  s->opt.exhaustive = 1;
-  int rc = tq_search_batch(s, qs.data(), n_queries, 1, sc.data(), dc.data(), ct.data());
-  s->opt.exhaustive = saved;
+  CallOpts co;
+  int rc = resolve_opts(s, nullptr, co);
+  if (rc != TQ_OK) return rc;
+  co.exhaustive = true;  // per call: the segment's options are not touched
+  rc = search_batch_host(s, qs.data(), n_queries, 1, sc.data(), dc.data(), ct.data(), co);
   if (rc != TQ_OK) return rc;
   return tq_last_batch_match_counts(s, out_counts, n_queries);
 }
@@ -1423,10 +1543,10 @@ int tq_last_batch_stats(tq_segment *s, tq_batch_stats *out) {
   if (!s || !out) return fail(TQ_ERR_INVALID, "tq_last_batch_stats: null argument");
   HIP_TRY(hipSetDevice(s->device));
   if (s->stats_pending) {
-    HIP_TRY(hipStreamSynchronize(s->stream));
-    if (s->opt.timing && s->batches_timed)  // batches may run on a caller's stream
-      HIP_TRY(hipEventSynchronize(
-          s->ev_t1[(s->batches_timed - 1) % tq_segment::kTimingRing]));
+    {
+      const int wrc = wait_segment_idle(s);  // batches may run on a caller's stream
+      if (wrc != TQ_OK) return wrc;
+    }
     unsigned long long m = 0;
     HIP_TRY(hipMemcpy(&m, s->d_match_counter, sizeof m, hipMemcpyDeviceToHost));
     s->stats.matches = m;
@@ -1546,9 +1666,18 @@ int tq_merge_topk(const float *scores, const uint32_t *docs, const uint32_t *cou
       const size_t b = ((size_t)sg * n_queries + q) * stride;
       for (uint32_t i = 0; i < c; ++i) all.push_back({scores[b + i], sg, docs[b + i]});
     }
-    // top_score_collector.rs:590-600: sort key desc, then DocAddress asc
-    std::sort(all.begin(), all.end(), [](const H &a, const H &b) {
-      if (a.s != b.s) return a.s > b.s;
+    // top_score_collector.rs:590-600: sort key desc, then DocAddress asc.  Scores are compared
+    // through the order-preserving u32 transform the device keys use (a strict weak order even
+    // for NaN inputs, which partial_cmp().unwrap_or(Equal) in the reference is not)
+    auto sortable = [](float x) {
+      uint32_t u;
+      memcpy(&u, &x, 4);
+      if ((u & 0x7FFFFFFFu) == 0u) u = 0u;  // -0.0 == +0.0
+      return u ^ ((uint32_t)((int32_t)u >> 31) | 0x80000000u);
+    };
+    std::sort(all.begin(), all.end(), [&](const H &a, const H &b) {
+      const uint32_t ka = sortable(a.s), kb = sortable(b.s);
+      if (ka != kb) return ka > kb;
       if (a.o != b.o) return a.o < b.o;
       return a.d < b.d;
     });

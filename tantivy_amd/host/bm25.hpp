@@ -4,6 +4,7 @@
 #pragma once
 #include <cmath>
 #include <cstdint>
+#include <stdexcept>
 #include <vector>
 
 namespace tantivy_amd {
@@ -40,6 +41,9 @@ constexpr Score B = 0.75f;
 
 // bm25.rs:52-56
 inline Score idf(uint64_t doc_freq, uint64_t doc_count) {
+  // the reference asserts doc_count >= doc_freq (bm25.rs:53); inconsistent (e.g. remote)
+  // statistics must not wrap the subtraction
+  if (doc_freq > doc_count) throw std::invalid_argument("idf: doc_freq > doc_count");
   const Score x = ((Score)(doc_count - doc_freq) + 0.5f) / ((Score)doc_freq + 0.5f);
   return std::log(1.0f + x);  // f32 ln, as Rust's f32::ln
 }

@@ -47,17 +47,18 @@ struct tqh_term_info {
   uint32_t doc_freq;
   uint64_t postings_start, postings_end, positions_start, positions_end;
 };
-// mode: 0 AND (all Must), 1 OR (all Should), 2 PHRASE (offsets 0..n or explicit), 3 single term,
-//       4 BooleanQuery of term clauses with the given occurs (src/query/occur.rs order)
+// mode: enum tq_mode (0 AND / all Must, 1 OR / all Should, 2 PHRASE, 3 BOOL = term clauses with
+//       the given occurs, src/query/occur.rs order) + TQH_MODE_TERM (4) = TermQuery
+#define TQH_MODE_TERM 4
 struct tqh_query {
   uint8_t mode;
   uint32_t n_terms;
   const uint32_t *terms;
   const uint32_t *phrase_offsets;  // may be null
-  const uint8_t *occurs;           // mode 4: 0 Should, 1 Must, 2 MustNot
-  const uint8_t *clause_of;        // mode 4: terms sharing a value form one nested union; or null
-  uint32_t min_should_match;       // mode 4
-  const float *boosts;             // modes 0, 1, 3, 4: BoostQuery factor per term query; or null
+  const uint8_t *occurs;           // TQ_MODE_BOOL: 0 Should, 1 Must, 2 MustNot
+  const uint8_t *clause_of;        // TQ_MODE_BOOL: terms sharing a value form one nested union; or null
+  uint32_t min_should_match;       // TQ_MODE_BOOL
+  const float *boosts;             // BoostQuery factor per term query (PHRASE: boosts[0] = the phrase's); or null
 };
 
 const char *tqh_last_error(void) { return g_err.c_str(); }
@@ -136,8 +137,11 @@ int tqh_prepare_batch(tqh_searcher *s, const tqh_query *queries, uint32_t n) {
     for (uint32_t i = 0; i < n; ++i) {
       const tqh_query &q = queries[i];
       Query query;
-      if (q.mode == 4) {
-        if (!q.occurs) throw TantivyError(TantivyError::InvalidArgument, "mode 4 needs occurs");
+      if (q.mode > TQH_MODE_TERM)
+        throw TantivyError(TantivyError::InvalidArgument, "unknown query mode");
+      if (q.n_terms == 0) throw TantivyError(TantivyError::InvalidArgument, "query without terms");
+      if (q.mode == TQ_MODE_BOOL) {
+        if (!q.occurs) throw TantivyError(TantivyError::InvalidArgument, "TQ_MODE_BOOL needs occurs");
         std::vector<std::pair<Occur, Query>> clauses;
         std::vector<int> ids;  // clause_of value of every clause built so far
         for (uint32_t t = 0; t < q.n_terms; ++t) {
@@ -165,17 +169,20 @@ int tqh_prepare_batch(tqh_searcher *s, const tqh_query *queries, uint32_t n) {
         }
         query = Query::boolean(std::move(clauses));
         query.set_minimum_number_should_match(q.min_should_match);
-      } else if (q.mode == 3 || (q.n_terms == 1 && q.mode != 2)) {
+      } else if (q.mode == TQH_MODE_TERM || (q.n_terms == 1 && q.mode != TQ_MODE_PHRASE)) {
         query = Query::term_query(q.terms[0]).boosted(q.boosts ? q.boosts[0] : 1.0f);
-      } else if (q.mode == 2) {
+      } else if (q.mode == TQ_MODE_PHRASE) {
         std::vector<std::pair<uint32_t, uint32_t>> pt;
         for (uint32_t t = 0; t < q.n_terms; ++t)
           pt.emplace_back(q.phrase_offsets ? q.phrase_offsets[t] : t, q.terms[t]);
         query = Query::phrase_with_offsets(std::move(pt));
+        // BoostQuery around the PhraseQuery: PhraseWeight applies it with boost_by
+        // (phrase_weight.rs:42-69); boosts[0] is the factor of the whole phrase
+        if (q.boosts) query.boosted(q.boosts[0]);
       } else {
         std::vector<std::pair<Occur, Query>> clauses;
         for (uint32_t t = 0; t < q.n_terms; ++t)
-          clauses.emplace_back(q.mode == 0 ? Occur::Must : Occur::Should,
+          clauses.emplace_back(q.mode == TQ_MODE_AND ? Occur::Must : Occur::Should,
                                Query::term_query(q.terms[t]).boosted(q.boosts ? q.boosts[t] : 1.0f));
         query = Query::boolean(std::move(clauses));
       }

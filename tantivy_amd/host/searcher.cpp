@@ -95,6 +95,8 @@ uint64_t Searcher::doc_freq(uint32_t term) const {
 
 Weight Searcher::weight(const Query &query) const {
   const uint64_t nd = total_num_docs(), nt = total_num_tokens();
+  if (nd == 0)
+    throw TantivyError(TantivyError::InvalidArgument, "no documents: BM25 statistics undefined");
   if (!shared_cache_) {
     const Score avg = (Score)nt / (Score)nd;
     shared_cache_ = std::make_shared<Bm25Weight>(Bm25Weight::from_idf(0.0f, avg));
@@ -225,7 +227,7 @@ struct SegmentBatch {
 };
 }  // namespace
 
-void Searcher::apply_bound_slack(SegmentReader &seg) const {
+uint32_t Searcher::bound_slack_ppm(const SegmentReader &seg) const {
   const double global = (double)total_num_tokens() / (double)total_num_docs();
   const double local = seg.max_doc() ? (double)seg.total_num_tokens() / (double)seg.max_doc() : global;
   double ppm = 0.0;
@@ -233,8 +235,7 @@ void Searcher::apply_bound_slack(SegmentReader &seg) const {
     const double d = std::abs(global - local) / std::min(global, local);
     ppm = std::ceil(((1.0 + d) * (1.0 + d) - 1.0) * 1e6) + 2.0;  // + f32 rounding of the averages
   }
-  const int rc = tq_set_option(seg.raw(), "bound_slack_ppm", (int64_t)std::min(ppm, 1e9));
-  if (rc != TQ_OK) throw_tq(rc);
+  return (uint32_t)std::min(ppm, 1e9);
 }
 
 void Searcher::collect_segment_batch(size_t segment_ord, const std::vector<Weight> &weights,
@@ -242,13 +243,14 @@ void Searcher::collect_segment_batch(size_t segment_ord, const std::vector<Weigh
                                      std::vector<uint32_t> &docs, std::vector<uint32_t> &counts) {
   SegmentReader &seg = *segments_[segment_ord];
   const size_t n = weights.size();
-  apply_bound_slack(seg);
   SegmentBatch b(seg, weights, k);
   scores.assign(n * k, 0.0f);
   docs.assign(n * k, TERMINATED);
   counts.assign(n, 0);
-  const int rc = tq_search_batch(seg.raw(), b.qs.data(), (uint32_t)n, k, scores.data(),
-                                 docs.data(), counts.data());
+  // the slack travels with the call: segments shared by several Searchers never race on it
+  const tq_search_opts opts{-1, bound_slack_ppm(seg)};
+  const int rc = tq_search_batch_opts(seg.raw(), b.qs.data(), (uint32_t)n, k, scores.data(),
+                                      docs.data(), counts.data(), &opts);
   if (rc != TQ_OK) throw_tq(rc);
 }
 
@@ -268,10 +270,10 @@ void Searcher::collect_segment_batch_device(size_t segment_ord, const std::vecto
                                             uint32_t k, float *d_scores, uint32_t *d_docs,
                                             uint32_t *d_counts, void *hip_stream) {
   SegmentReader &seg = *segments_[segment_ord];
-  apply_bound_slack(seg);
   SegmentBatch b(seg, weights, k);
-  const int rc = tq_search_batch_device(seg.raw(), b.qs.data(), (uint32_t)weights.size(), k,
-                                        d_scores, d_docs, d_counts, hip_stream);
+  const tq_search_opts opts{-1, bound_slack_ppm(seg)};
+  const int rc = tq_search_batch_device_opts(seg.raw(), b.qs.data(), (uint32_t)weights.size(), k,
+                                             d_scores, d_docs, d_counts, &opts, hip_stream);
   if (rc != TQ_OK) throw_tq(rc);
 }
 

@@ -106,8 +106,8 @@ struct Query {
     q.clauses = std::move(clauses);
     return q;
   }
-  Query &boosted(Score b) {  // one BoostQuery wrapper per node
-    boost = b;
+  Query &boosted(Score b) {  // BoostQuery::new(self, b): nested wrappers multiply (:70-72)
+    boost *= b;
     return *this;
   }
   // BooleanQuery::set_minimum_number_should_match
@@ -201,8 +201,9 @@ class Searcher {
 
  private:
   // block-max metadata was selected under the segment's own average fieldnorm; with global
-  // statistics the device widens those bounds by (1 + d)^2 (tq_common.hpp: block_max_score)
-  void apply_bound_slack(SegmentReader &seg) const;
+  // statistics the device widens those bounds by (1 + d)^2 (tq_common.hpp: block_max_score);
+  // passed with every call (tq_search_opts)
+  uint32_t bound_slack_ppm(const SegmentReader &seg) const;
   std::vector<std::shared_ptr<SegmentReader>> segments_;
   mutable std::shared_ptr<Bm25Weight> shared_cache_;  // one tf cache per field (avg fieldnorm)
   uint64_t remote_docs_ = 0, remote_tokens_ = 0;

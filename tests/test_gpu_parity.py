@@ -880,6 +880,25 @@ def test_full_size_and_pruned(big):
     assert pruned < full // 4, (pruned, full)
 
 
+@pytest.mark.parametrize("k", [65, 256, 1024])
+def test_full_size_and_pruned_large_k(big, k):
+    """10M docs, k above the 64 shared threshold slots (pruning then runs on each wave's own k-th
+    key only, tq_api.cpp): pruned == exhaustive bits, and a sample against the oracle."""
+    seg, dev = big
+    qid = O.zipf_queries(60, 2, 256, seed=700 + k)
+    batch = [(O.MODE_AND, q.tolist()) for q in qid] + [(O.MODE_AND, [0, 1]), (O.MODE_AND, [3, 200, 17])]
+    sc, _, docs, cnt = dev.search(batch, k)
+    dev.set_option("exhaustive", 0)
+    try:
+        sc2, _, docs2, cnt2 = dev.search(batch, k)
+    finally:
+        dev.set_option("exhaustive", 1)
+    assert np.array_equal(cnt, cnt2) and np.array_equal(docs, docs2) and np.array_equal(sc, sc2)
+    for i in (0, 31, 60):
+        want = _oracle_topk(seg, batch[i][1], O.MODE_AND, k)
+        _assert_hits_equal([(float(sc2[i, j]), int(docs2[i, j])) for j in range(int(cnt2[i]))], want)
+
+
 def test_full_size_phrase(ta):
     """config 4 at BASELINE size: 3-word phrases on a 10M-doc segment with positions."""
     seg = O.synth_segment(10_000_000, n_terms=64, with_positions=True, phrase_terms=32)

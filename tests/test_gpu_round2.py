@@ -1,0 +1,275 @@
+"""GPU tests closing the holes the round-1 review named: bytes written by released tantivy versions
+searched on the device, segments without fieldnorms, legacy (non-strict-delta) blocks, the stream
+contract of consecutive batches, two segments searched from two host threads, per-call options."""
+import json
+import os
+import threading
+
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+from tests.helpers import legacy_posting_list, random_postings
+
+pytestmark = pytest.mark.gpu
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "compat_index.json")
+
+
+@pytest.fixture(scope="module")
+def ta():
+    import tantivy_amd
+
+    return tantivy_amd
+
+
+def _hits(scores, docs, counts, i):
+    return [(float(scores[i, j]), int(docs[i, j])) for j in range(int(counts[i]))]
+
+
+# ------------------------------------------------------------------ real tantivy bytes
+@pytest.mark.parametrize("ver", ["index_v6", "index_v7"])
+def test_compat_fixture_searched_on_device(ta, ver):
+    """compat_tests.rs:39-57 opens tests/compat_tests_data/index_v6|v7 (written by released
+    tantivy versions) and finds the one document with the term query `dateformat`
+    (TopDocs::with_limit(1)).  Here the fixture's field sub-files go through tq_segment_upload
+    byte for byte, the segment is opened by its TermInfoStore (term ordinal 0) and the same
+    query runs on the GPU; the score is the oracle's on the same bytes."""
+    with open(GOLD) as f:
+        j = json.load(f)[ver]
+    files = {k: bytes.fromhex(v) for k, v in j["files"].items()}
+    term = O.composite_fields(O.strip_footer(files["term"])[0])
+    idx = O.composite_fields(O.strip_footer(files["idx"])[0])
+    pos = O.composite_fields(O.strip_footer(files["pos"])[0])
+    fnorm = O.composite_fields(O.strip_footer(files["fieldnorm"])[0])
+    for key, record in (((0, 0), O.WITH_FREQS_AND_POSITIONS), ((1, 0), O.BASIC)):
+        _, store = O.term_dictionary_parts(term[key])
+        df, ps, pe, qs, qe = O.term_info_store_get(store, 0)
+        body = idx[key]
+        fn = np.frombuffer(fnorm[key], np.uint8) if key in fnorm else None
+        seg = O.Segment(j["max_doc"], record, np.frombuffer(body, np.uint8),
+                        np.frombuffer(pos.get(key, b""), np.uint8), fn,
+                        [O.TermInfo(df, ps, pe, qs, qe)], int.from_bytes(body[:8], "little"))
+        dev = ta.DeviceIndex([])
+        try:
+            dev.add_segment(seg, 0, term_info_store=store)  # term id = term ordinal
+            for exhaustive in (1, 0):
+                dev.set_option("exhaustive", exhaustive)
+                sc, ords, docs, cnt = dev.search([(ta.MODE_TERM, [0])], 1)
+                want = O.search(seg, [0], O.MODE_OR, 1, pruned=False)
+                assert int(cnt[0]) == 1 and _hits(sc, docs, cnt, 0) == want
+                assert int(docs[0, 0]) == 0 and int(ords[0, 0]) == 0
+                if record != O.BASIC:  # a Must clause over the same term: block_wand_intersection
+                    sc2, _, docs2, cnt2 = dev.search([(ta.MODE_AND, [0, 0])], 1)
+                    assert _hits(sc2, docs2, cnt2, 0) == O.search(seg, [0, 0], O.MODE_AND, 1, pruned=False)
+            gd, gt = dev.decode_postings(0, df)
+            assert gd.tolist() == [0] and gt.tolist() == [1]
+            if record == O.WITH_FREQS_AND_POSITIONS:
+                deltas, n = dev.decode_position_deltas(0, 4)
+                assert n == 1 and deltas.tolist() == [0]
+        finally:
+            dev.close()
+
+
+# ------------------------------------------------------------------ fieldnorm == NULL
+def test_search_without_fieldnorms(ta):
+    """FieldNormReader::constant(max_doc, 1) (term_weight.rs:209-219): every kernel takes the
+    constant-id branch of fieldnorm_id()."""
+    rng = np.random.default_rng(77)
+    md = 60_000
+    dfs = [30_000, 9_000, 2_500, 700, 129, 128, 5, 20_000]
+    lists = [random_postings(rng, md, df, max_tf=6) for df in dfs]
+    positions = [[sorted(rng.choice(40, size=tf, replace=False).tolist()) for _, tf in pl] for pl in lists]
+    seg = O.build_segment(md, lists, None, record_option=O.WITH_FREQS_AND_POSITIONS,
+                          positions=positions, total_num_tokens=md * 7, avg_fieldnorm=7.0)
+    assert seg.fieldnorm is None
+    dev = ta.DeviceIndex([seg])
+    try:
+        qs = [(O.MODE_AND, [0, 1]), (O.MODE_AND, [7, 0]), (O.MODE_AND, [2, 3]), (O.MODE_AND, [0, 1, 7]),
+              (O.MODE_OR, [0, 3]), (O.MODE_OR, [1, 2, 3, 4, 6]), (O.MODE_OR, [5]),
+              (O.MODE_PHRASE, [0, 7]), (O.MODE_PHRASE, [1, 0, 7])]
+        for exhaustive in (1, 0):
+            for use_dense in (1, 0):
+                dev.set_option("exhaustive", exhaustive)
+                dev.set_option("use_dense", use_dense)
+                for k in (1, 10, 100):
+                    sc, _, docs, cnt = dev.search(qs, k)
+                    for i, q in enumerate(qs):
+                        want = O.search(seg, q[1], q[0], k, pruned=False)
+                        got = _hits(sc, docs, cnt, i)
+                        assert [d for _, d in got] == [d for _, d in want], (q, k, exhaustive)
+                        for (gs, _), (ws, _) in zip(got, want):
+                            if q[0] == O.MODE_OR and len(q[1]) > 2:
+                                assert abs(gs - ws) <= 1e-5 * abs(ws)
+                            else:
+                                assert np.float32(gs) == np.float32(ws), (q, gs, ws)
+    finally:
+        dev.close()
+
+
+# ------------------------------------------------------------------ legacy blocks (flag 0)
+def test_legacy_non_strict_blocks_on_device(ta):
+    """Blocks written before strict deltas (width byte without bit 6: D1 deltas seeded with the
+    previous block's last doc, raw tfs) — compression/mod.rs:124-125.  The oracle's serializer
+    never writes them, so the list is packed by hand (tests/helpers.py)."""
+    rng = np.random.default_rng(31)
+    md = 200_000
+    old = random_postings(rng, md, 128 * 9 + 57, max_tf=9)
+    old[0] = (0, 3)                      # doc 0 first: delta 0 from the seed 0 is legal only here
+    old = sorted(dict(old).items())
+    new = random_postings(rng, md, 40_000, max_tf=5)
+    ref = O.build_segment(md, [old, new], rng.integers(1, 300, size=md).tolist())
+    legacy = legacy_posting_list(old)
+    t_new = ref.terms[1]
+    new_bytes = bytes(ref.idx[8 + t_new.postings_start: 8 + t_new.postings_end])
+    body = bytes(ref.idx[:8]) + legacy + new_bytes
+    terms = [O.TermInfo(len(old), 0, len(legacy), 0, 0),
+             O.TermInfo(len(new), len(legacy), len(legacy) + len(new_bytes), 0, 0)]
+    seg = O.Segment(md, O.WITH_FREQS, np.frombuffer(body, np.uint8), np.zeros(0, np.uint8),
+                    ref.fieldnorm, terms, ref.total_num_tokens)
+    od, ot = O.decode_postings(seg, 0)      # the oracle reads the flag (to_postings.c)
+    assert od.tolist() == [d for d, _ in old] and ot.tolist() == [t for _, t in old]
+    dev = ta.DeviceIndex([seg])
+    try:
+        for use_dpp in (1, 0):
+            dev.set_option("use_dpp", use_dpp)
+            gd, gt = dev.decode_postings(0, len(old))
+            assert gd.tolist() == [d for d, _ in old] and gt.tolist() == [t for _, t in old]
+        dev.set_option("use_dpp", 1)
+        qs = [(O.MODE_AND, [0, 1]), (O.MODE_OR, [0, 1]), (O.MODE_OR, [0])]
+        for exhaustive in (1, 0):
+            for use_dense in (1, 0):  # legacy list as leader (stage A) and as probed list (find_in_blocks)
+                dev.set_option("exhaustive", exhaustive)
+                dev.set_option("use_dense", use_dense)
+                sc, _, docs, cnt = dev.search(qs, 20)
+                for i, q in enumerate(qs):
+                    # block-max bytes are 0 (= unknown) in these entries: scores must still be exact
+                    assert _hits(sc, docs, cnt, i) == O.search(ref, q[1], q[0], 20, pruned=False)
+    finally:
+        dev.close()
+
+
+# ------------------------------------------------------------------ streams and threads
+def test_consecutive_batches_on_different_streams(ta):
+    """The per-segment scratch is shared by consecutive batches: a batch enqueued on another
+    stream must wait for the previous one (tq_api.cpp order_after_last_batch)."""
+    import torch
+
+    seg = O.synth_segment(2_000_000, n_terms=64)
+    dev = ta.DeviceIndex([seg])
+    try:
+        qa = [(O.MODE_AND, q.tolist()) for q in O.zipf_queries(3000, 2, 64, seed=1)]
+        qb = [(O.MODE_OR, q.tolist()) for q in O.zipf_queries(300, 3, 64, seed=2)]
+        k = 10
+        want = {}
+        for name, qs in (("a", qa), ("b", qb)):
+            sc, _, dc, ct = dev.search(qs, k)
+            want[name] = (sc.copy(), dc.copy(), ct.copy())
+        streams = [torch.cuda.Stream(), torch.cuda.Stream(), None]
+        outs = []
+        for it in range(6):
+            name, qs = ("a", qa) if it % 2 == 0 else ("b", qb)
+            st = streams[it % 3]
+            d_sc = torch.empty((len(qs), k), dtype=torch.float32, device="cuda")
+            d_dc = torch.empty((len(qs), k), dtype=torch.int32, device="cuda")
+            d_ct = torch.empty(len(qs), dtype=torch.int32, device="cuda")
+            dev.prepare(qs)
+            dev.collect_segment_prepared_device(0, k, d_sc, d_dc, d_ct,
+                                                st.cuda_stream if st is not None else None)
+            outs.append((name, d_sc, d_dc, d_ct))  # no synchronisation between the batches
+        dev.last_batch_stats()  # waits for whatever the segment has in flight, on any stream
+        torch.cuda.synchronize()
+        for name, d_sc, d_dc, d_ct in outs:
+            sc, dc, ct = want[name]
+            assert np.array_equal(d_ct.cpu().numpy().view(np.uint32), ct)
+            assert np.array_equal(d_dc.cpu().numpy().view(np.uint32), dc)
+            assert np.array_equal(d_sc.cpu().numpy(), sc)
+    finally:
+        dev.close()
+
+
+def test_two_segments_from_two_threads(ta):
+    """include/tantivy_amd.h: different segments may be searched concurrently (tantivy's one
+    task per segment, executor.rs:61-104)."""
+    segs = [O.synth_segment(1_500_000, n_terms=48, segment_ord=o) for o in range(2)]
+    devs = [ta.DeviceIndex([s]) for s in segs]
+    try:
+        qs = [(O.MODE_AND, q.tolist()) for q in O.zipf_queries(1500, 2, 48, seed=9)]
+        qs += [(O.MODE_OR, q.tolist()) for q in O.zipf_queries(200, 4, 48, seed=10)]
+        want = [d.search(qs, 10) for d in devs]
+        got = [[None] * 8, [None] * 8]
+        errs = []
+
+        def run(i):
+            try:
+                for it in range(8):
+                    got[i][it] = devs[i].search(qs, 10)
+            except Exception as e:  # pragma: no cover
+                errs.append(e)
+
+        th = [threading.Thread(target=run, args=(i,)) for i in range(2)]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+        assert not errs, errs
+        for i in range(2):
+            for it in range(8):
+                for a, b in zip(got[i][it], want[i]):
+                    assert np.array_equal(a, b)
+        # spot check against the oracle
+        for i in range(2):
+            sc, _, dc, ct = want[i]
+            for qi in (0, 500, 1499, 1600):
+                w = O.search(segs[i], qs[qi][1], qs[qi][0], 10, pruned=False)
+                g = _hits(sc, dc, ct, qi)
+                assert [d for _, d in g] == [d for _, d in w]
+    finally:
+        for d in devs:
+            d.close()
+
+
+# ------------------------------------------------------------------ per-call options, argument checks
+def test_per_call_options_and_argument_checks(ta):
+    import ctypes as C
+
+    from tantivy_amd import binding as B
+
+    seg = O.synth_segment(300_000, n_terms=32)
+    dev = ta.DeviceIndex([seg])
+    try:
+        assert ta.MODE_BOOL == O.MODE_BOOL == 3 and ta.MODE_TERM == 4
+        with pytest.raises(ta.TantivyAmdError):
+            dev.prepare([(7, [0, 1])])  # unknown mode
+        qs = [(O.MODE_AND, [0, 1]), (O.MODE_AND, [2, 9])]
+        ws = [O.default_weights(seg, q[1], q[0]) for q in qs]
+        _, cache = ta.bm25_for_terms([seg.terms[0].doc_freq], seg.max_doc, seg.total_num_tokens)
+        base = dev.raw_search(qs, ws, cache, 10)
+        # exhaustive / pruned per call give the same top-k and leave the segment option alone
+        for exh in (0, 1, -1):
+            got = dev.raw_search(qs, ws, cache, 10, opts=(exh, 0 if exh == 0 else B.OPT_DEFAULT))
+            for a, b in zip(got, base):
+                assert np.array_equal(a, b)
+        counts = dev.raw_count(qs, ws, cache)   # exhaustive for this call only
+        n0 = len(O.match_all(seg, [0, 1], O.MODE_AND)[0])
+        assert int(counts[0]) == n0
+        with pytest.raises(ta.TantivyAmdError):
+            dev.raw_search(qs, ws, cache, 10, opts=(5, 0))
+        with pytest.raises(ta.TantivyAmdError):   # NaN / inf weights are rejected
+            dev.raw_search(qs, [[float("nan"), 1.0], ws[1]], cache, 10)
+        with pytest.raises(ta.TantivyAmdError):
+            dev.raw_search(qs, [[float("inf"), 1.0], ws[1]], cache, 10)
+        # BoostQuery around a PhraseQuery scales its score
+        segp = O.synth_segment(100_000, n_terms=16, with_positions=True, phrase_terms=8)
+        devp = ta.DeviceIndex([segp])
+        try:
+            s1, _, d1, c1 = devp.search([(O.MODE_PHRASE, [0, 1])], 5)
+            s2, _, d2, c2 = devp.search([(O.MODE_PHRASE, [0, 1], None, {"boosts": [2.5]})], 5)
+            assert int(c1[0]) > 0 and np.array_equal(d1, d2)
+            w = np.float32(s1[0, 0])
+            assert np.all(np.abs(s2[0, :int(c2[0])] - s1[0, :int(c1[0])] * np.float32(2.5)) <=
+                          1e-6 * np.abs(s2[0, :int(c2[0])])) and w > 0
+        finally:
+            devp.close()
+    finally:
+        dev.close()
