@@ -242,7 +242,7 @@ def test_per_call_options_and_argument_checks(ta):
         with pytest.raises(ta.TantivyAmdError):
             dev.prepare([(7, [0, 1])])  # unknown mode
         qs = [(O.MODE_AND, [0, 1]), (O.MODE_AND, [2, 9])]
-        ws = [O.default_weights(seg, q[1], q[0]) for q in qs]
+        ws = [[float(w.weight) for w in O.default_weights(seg, q[1], q[0])] for q in qs]
         _, cache = ta.bm25_for_terms([seg.terms[0].doc_freq], seg.max_doc, seg.total_num_tokens)
         base = dev.raw_search(qs, ws, cache, 10)
         # exhaustive / pruned per call give the same top-k and leave the segment option alone
