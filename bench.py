@@ -1,23 +1,28 @@
 #!/usr/bin/env python
 """bench.py — headline benchmark: 2-term AND + BM25 top-10 QPS on a 10M-doc synthetic Zipf
 segment per GPU (BASELINE.json configs[1]), with the HBM roofline of the scan
-kernel and the CPU restatement of tantivy's own executor timed beside it.
+kernel and the CPU restatement of tantivy's own executor timed beside it; in the same run the
+other BASELINE configs (5-term OR top-100, 3-word phrase, mixed AND/OR stream) and the
+8-segment index of config 5 sharded over the GPUs of the run (strong scaling).
 
-    python bench.py --gpus 1 --steps K --warmup W
-    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+    python bench.py --gpus N --steps K --warmup W        # N > 1: spawns the N ranks itself
+    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...   # also fine
 
 One step = one pass of the hot path over one batch of queries (posting lists resident in HBM;
 query weights prepared outside the timed region, like `query.weight()` in tantivy's benches).
-The timed mode is the reference's own: block-max pruned top-k (block_wand_intersection).  The
-exhaustive mode (every match scored) is run beside it: every query's top-k must be identical in
-both (the run aborts otherwise) and its roofline is reported as `roofline_other_mode`.
+The timed mode is the reference's own: block-max pruned top-k (block_wand_intersection /
+block_wand).  The exhaustive mode (every match scored) is run beside it: every query's top-k must
+be identical in both (the run aborts otherwise).
 Roles of oracle/ here: (1) workload generator — it serialises the synthetic index into tantivy's
-byte format before anything is timed; (2) the cpu_baseline leg; (3) a post-hoc parity spot check.
-The timed GPU leg runs only tantivy_amd (HIP kernels + C ABI + C++ host mirror).
+byte format before anything is timed; (2) the cpu_baseline legs; (3) a post-hoc parity spot check.
+The timed GPU legs run only tantivy_amd (HIP kernels + C ABI + C++ host mirror).
 """
 import argparse
 import json
+import math
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -28,25 +33,81 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+N_SEGMENTS_STRONG = 8  # BASELINE.json configs[4]: 80M docs in 8 segments
 
 
-def parse_args():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--docs", type=int, default=10_000_000)
-    ap.add_argument("--queries", type=int, default=10_000)
+    ap.add_argument("--queries", type=int, default=None,
+                    help="queries per batch (default: 10000 for and2 / mixed, 1000 for or5 / phrase3 / bool)")
     ap.add_argument("--workload", default="and2", choices=["and2", "or5", "phrase3", "mixed", "bool"])
     ap.add_argument("--k", type=int, default=None)
-    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--cpu-seconds", type=float, default=10.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--latency-queries", type=int, default=200)
     ap.add_argument("--exhaustive", action="store_true",
                     help="time the exhaustive mode (score every match) instead of the reference's "
                          "block-max pruned execution; both are always run and compared")
     ap.add_argument("--pruned", action="store_true", help="(default; kept for old command lines)")
-    return ap.parse_args()
+    ap.add_argument("--no-side", action="store_true",
+                    help="only the main workload (profiling runs): skip other_workloads and strong_scaling")
+    ap.add_argument("--side-steps", type=int, default=5)
+    ap.add_argument("--selftest-launcher", action="store_true",
+                    help="CPU plumbing check of the rank launcher (gloo, no GPU work, no timing)")
+    return ap.parse_args(argv)
+
+
+# ----------------------------------------------------------------------------- launcher
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def relaunch_ranks(args):
+    """`python bench.py --gpus N` without a launcher: re-exec under torch.distributed.run, one
+    rank per GPU (Executor::MultiThread's role, executor.rs:61-104, with processes for threads)."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1",
+           "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.call(cmd, env=env)
+
+
+def selftest_launcher(rank, world):
+    """World-size-N gloo run of the exchange plumbing with synthetic per-rank results (no GPU)."""
+    import torch
+    import torch.distributed as dist
+
+    from tantivy_amd import distributed as D
+
+    dist.init_process_group("gloo")
+    n, k = 5, 4
+    scores = torch.arange(n * k, dtype=torch.float32).reshape(n, k).flip(1) + 100.0 * rank
+    docs = (torch.arange(n * k, dtype=torch.int32).reshape(n, k) + 7 * rank)
+    counts = torch.full((n,), k, dtype=torch.int32)
+    g = D.allgather_topk(scores, docs, counts)
+    out_s, out_o, out_d, out_c = D.merge_gathered_host(*g, 0, k)
+    ok = bool(np.all(out_o == world - 1) and np.all(out_c == k) and
+              np.array_equal(out_s, scores.numpy() - 100.0 * rank + 100.0 * (world - 1)))
+    flags = [None] * world
+    dist.all_gather_object(flags, ok)
+    if rank == 0:
+        print(json.dumps({"selftest": "launcher", "n_gpus": world, "ok": all(flags)}))
+    dist.barrier()
+    dist.destroy_process_group()
+    return 0 if ok else 1
+
+
+# ----------------------------------------------------------------------------- workloads
+DEFAULT_QUERIES = {"and2": 10_000, "mixed": 10_000, "or5": 1_000, "phrase3": 1_000, "bool": 2_000}
 
 
 def build_queries(O, workload, n, k):
@@ -81,225 +142,398 @@ def build_queries(O, workload, n, k):
     return qs, k or 10
 
 
+def usable_cpus():
+    """Threads this process may really use: affinity mask bounded by the cgroup CPU quota
+    (os.cpu_count() ignores both: round 1 reported 256 'cores' on a 16-CPU lease)."""
+    n = len(os.sched_getaffinity(0))
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            with open(path) as f:
+                parts = f.read().split()
+            if path.endswith("cpu.max"):
+                if parts[0] != "max":
+                    n = min(n, max(1, math.ceil(int(parts[0]) / int(parts[1]))))
+            else:
+                quota = int(parts[0])
+                with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as f:
+                    period = int(f.read())
+                if quota > 0:
+                    n = min(n, max(1, math.ceil(quota / period)))
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    return max(1, n)
+
+
+def cpu_baseline(O, seg, workload, queries, k, seconds, sweep):
+    """The oracle's C restatement of tantivy's executors, query-level parallelism over host
+    threads (tantivy runs one query per thread per segment), on a bounded sample."""
+    cores = usable_cpus()
+
+    def spec_of(q):
+        if workload == "bool":  # the restated generic scorer tree (no block-max executor)
+            return O.bool_spec(seg, q[1], q[2], q[3], q[4], k)
+        return O.QuerySpec(seg, q[1], O.default_weights(seg, q[1], q[0]), q[0], k,
+                           list(range(len(q[1]))) if q[0] == O.MODE_PHRASE else None)
+
+    def run(threads, budget):
+        done, wall_total = 0, 0.0
+        chunk = max(32, threads * 8)
+        while wall_total < budget and done < len(queries):
+            part = queries[done:done + chunk]
+            wall, _, _ = O.baseline_run(seg, [spec_of(q) for q in part], threads)
+            wall_total += wall
+            done += len(part)
+        return done / wall_total, done, wall_total
+
+    qps, done, wall = run(cores, seconds)
+    out = {"value": round(qps, 2), "unit": "queries/s", "cores": cores, "kind": "port",
+           "sample": "first %d queries of the same stream, query-level parallelism on %d threads "
+                     "(sched_getaffinity bounded by the cgroup CPU quota; os.cpu_count() = %d), "
+                     "%.1f s; C restatement of tantivy's %s (oracle/), scalar code, not the tantivy "
+                     "binary" % (done, cores, os.cpu_count() or 0, wall,
+                                 "generic scorer tree (Intersection / BufferedUnionScorer / "
+                                 "RequiredOptionalScorer / Exclude under for_each_pruning_scorer)"
+                                 if workload == "bool" else
+                                 "block_wand_intersection / block_wand / PhraseScorer")}
+    if sweep:
+        by_threads = {}
+        for t in sorted({1, 8, 32, cores}):
+            if t > cores:
+                continue
+            by_threads[str(t)] = round(run(t, seconds / 5.0)[0], 1) if t != cores else out["value"]
+        out["qps_by_threads"] = by_threads
+        _, lat1, _ = O.baseline_run(seg, [spec_of(q) for q in queries[:48]], 1)
+        out["p50_latency_ms_1core"] = round(float(np.median(lat1)) * 1e3, 3)
+    return out
+
+
+# ----------------------------------------------------------------------------- measurement
+class Cluster:
+    """Rank plumbing of one bench process: control plane over gloo (statistics, the RCCL id,
+    timing), data plane over the C ABI's RCCL communicator."""
+
+    def __init__(self):
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        self.dist = None
+        self.comm = None
+        self.torch_group = None
+        self.exchange_note = "single rank: no exchange"
+
+    def init(self, torch):
+        if self.world > 1:
+            import torch.distributed as dist
+
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            dist.init_process_group("gloo")
+            self.dist = dist
+
+    def all_gather_object(self, obj):
+        if self.world == 1:
+            return [obj]
+        out = [None] * self.world
+        self.dist.all_gather_object(out, obj)
+        return out
+
+    def barrier(self):
+        if self.world > 1:
+            self.dist.barrier()
+
+    def max_over_ranks(self, x):
+        if self.world == 1:
+            return x
+        import torch
+
+        t = torch.tensor([x], dtype=torch.float64)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def make_comm(self, ctx):
+        """tq_comm_init over all ranks; falls back to torch.distributed's RCCL group when the
+        C-ABI communicator cannot be built (the fallback is still RCCL over xGMI)."""
+        if self.world == 1:
+            return
+        from tantivy_amd import distributed as D
+
+        def exchange(raw):
+            box = [raw]
+            self.dist.broadcast_object_list(box, src=0)
+            return box[0]
+
+        err = None
+        try:
+            self.comm = D.Comm(ctx, self.local_rank, self.rank, self.world, exchange)
+        except Exception as e:  # noqa: BLE001
+            err = repr(e)
+        errs = self.all_gather_object(err)
+        if any(errs):
+            if self.comm is not None:
+                self.comm.close()
+                self.comm = None
+            if self.rank == 0:
+                print("tq_comm_init failed (%s): falling back to torch.distributed RCCL" %
+                      [e for e in errs if e][0], file=sys.stderr)
+            self.torch_group = self.dist.new_group(backend="nccl")
+            self.exchange_note = "torch.distributed all_gather_into_tensor (RCCL), tq_comm_init failed"
+        else:
+            self.exchange_note = ("tq_allgather_topk: one grouped ncclAllGather per step through the "
+                                  "C ABI (%s)" % self.comm.library)
+
+
+def measure(cl, runner, torch, queries, k, steps, warmup, time_exhaustive=False):
+    """Both modes once (parity + algorithmic bytes), then W warm-up and K timed steps of the
+    chosen mode, pipelined, bracketed by barrier + synchronize; max over ranks."""
+    runner.prepare(queries, k)
+
+    def one(exhaustive, n):
+        runner.set_option("exhaustive", 1 if exhaustive else 0)
+        st = None
+        for _ in range(n):
+            runner.enqueue()
+            runner.synchronize()
+            st = runner.batch_stats()
+        return runner.results(), st
+
+    exh_out, exh_st = one(True, 1)
+    _, exh_st2 = one(True, 2)
+    prn_out, prn_st = one(False, 1)
+    _, prn_st2 = one(False, 2)
+    same = all(np.array_equal(a, b) for a, b in zip(exh_out, prn_out))
+    runner.set_option("exhaustive", 1 if time_exhaustive else 0)
+    for _ in range(warmup):
+        runner.enqueue()
+        runner.synchronize()
+    runner.batch_stats()  # start a fresh timing window
+    cl.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        runner.enqueue()  # steps are pipelined: one synchronisation closes the timed region
+    runner.synchronize()
+    torch.cuda.synchronize()
+    cl.barrier()
+    elapsed = cl.max_over_ranks(time.perf_counter() - t0)
+    st = runner.batch_stats()  # HIP-event kernel time, mean over the timed steps (<= last 16)
+    return {"elapsed": elapsed, "stats": st, "final": runner.results(), "mode_parity": same,
+            "n_diff": int(np.sum(np.any(exh_out[2] != prn_out[2], axis=1))),
+            "exh_stats": exh_st2, "prn_stats": prn_st2,
+            "algo_bytes_full": exh_st["algorithmic_bytes"], "full_matches": exh_st["matches"]}
+
+
+def frac_of(algo_bytes, kernel_ms):
+    a = algo_bytes / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
+    return round(a, 1), round(a / HBM_PEAK_GBS, 4)
+
+
+def load_traffic(key):
+    tpath = os.path.join(ROOT, "profiles", "traffic.json")
+    if os.path.exists(tpath):
+        with open(tpath) as f:
+            tj = json.load(f)
+        return tj.get(key)
+    return None
+
+
+def spot_check(O, seg, workload, queries, k, final, n_check=16):
+    n_q = len(queries)
+    checked = 0
+    for i in list(range(0, n_q, max(1, n_q // n_check)))[:n_check]:
+        mode, terms = queries[i][0], queries[i][1]
+        if workload == "bool":
+            want = O.bool_search(seg, terms, queries[i][2], k, queries[i][3], queries[i][4])
+        else:
+            want = O.search(seg, terms, mode, k, pruned=False)
+        got = [(float(final[0][i, j]), int(final[2][i, j])) for j in range(int(final[3][i]))]
+        assert len(got) == len(want), (i, got, want)
+        for (gs, gd), (ws, wd) in zip(got, want):
+            assert gd == wd and abs(gs - ws) <= 1e-5 * abs(ws), (i, got, want)
+        checked += 1
+    return checked
+
+
 def main():
     args = parse_args()
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
-        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        raise SystemExit(relaunch_ranks(args))
+    cl = Cluster()
+    if cl.world != args.gpus and cl.world > 1:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, cl.world))
+    if args.selftest_launcher:
+        raise SystemExit(selftest_launcher(cl.rank, cl.world))
     import torch
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (no CPU fallback exists for the product path)")
-    torch.cuda.set_device(local_rank)
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    if torch.cuda.device_count() <= cl.local_rank:
+        raise SystemExit("rank %d has no GPU (%d visible)" % (cl.local_rank, torch.cuda.device_count()))
+    torch.cuda.set_device(cl.local_rank)
+    cl.init(torch)
 
     from tantivy_amd import build as product_build
 
     if not os.path.exists(product_build.LIB):  # normally prebuilt (__graft_entry__.build())
-        if rank == 0:
+        if cl.rank == 0:
             product_build.build()
-        if dist is not None:
-            dist.barrier()
+        cl.barrier()
     from oracle import oracle as O  # workload generator + cpu baseline + spot check only
-    import tantivy_amd
     from tantivy_amd import distributed as D
 
+    rank, world = cl.rank, cl.world
+    pruned_mode = not args.exhaustive
+    n_main = args.queries or DEFAULT_QUERIES[args.workload]
+
+    def stats_of(seg):
+        return (seg.max_doc, seg.total_num_tokens, [t.doc_freq for t in seg.terms])
+
+    # ---------------------------------------------------------------- main workload (weak)
     with_pos = args.workload == "phrase3"
     t0 = time.time()
     seg = O.synth_segment(args.docs, n_terms=256, segment_ord=rank, with_positions=with_pos,
                           phrase_terms=32)
     t_gen = time.time() - t0
-    dev = tantivy_amd.DeviceIndex([seg], devices=[local_rank])
-    dev.set_option("timing", 1)
+    all_stats = cl.all_gather_object(stats_of(seg))
+    runner = D.ShardRunner([seg], cl.local_rank, rank, world,
+                           [st for r, st in enumerate(all_stats) if r != rank])
+    cl.make_comm(runner.dev.ctx)
+    runner.comm, runner.torch_group = cl.comm, cl.torch_group
+    runner.set_option("timing", 1)
     for name in ("dense_ratio", "dense_budget_x"):  # experiments: TQ_OPT_dense_ratio=...
         if os.environ.get("TQ_OPT_" + name):
-            dev.set_option(name, int(os.environ["TQ_OPT_" + name]))
-    pruned_mode = not args.exhaustive
-    my_stats = (seg.max_doc, seg.total_num_tokens, [t.doc_freq for t in seg.terms])
-    all_stats = [my_stats]
-    if world > 1:
-        all_stats = [None] * world
-        dist.all_gather_object(all_stats, my_stats)
-        for r, st in enumerate(all_stats):
-            if r != rank:
-                dev.add_remote_stats(*st)
-    queries, k = build_queries(O, args.workload, args.queries, args.k)
+            runner.set_option(name, int(os.environ["TQ_OPT_" + name]))
+    queries, k = build_queries(O, args.workload, n_main, args.k)
     n_q = len(queries)
-    dev.prepare(queries)  # Query::weight: global BM25 statistics, executor choice
-
-    # a non-default stream: the library's kernels, the RCCL all-gather and the merge kernel are
-    # all ordered on it (the legacy null stream would not order against the library's own stream)
-    ts = torch.cuda.Stream()
-    torch.cuda.set_stream(ts)
-    stream = ts.cuda_stream
-    d_scores = torch.empty((n_q, k), dtype=torch.float32, device="cuda")
-    d_docs = torch.empty((n_q, k), dtype=torch.int32, device="cuda")
-    d_counts = torch.empty(n_q, dtype=torch.int32, device="cuda")
-    h_out = [torch.empty((n_q, k), dtype=torch.float32).pin_memory(),
-             torch.empty((n_q, k), dtype=torch.int32).pin_memory(),
-             torch.empty((n_q, k), dtype=torch.int32).pin_memory(),
-             torch.empty(n_q, dtype=torch.int32).pin_memory()]
-
-    def enqueue():
-        """collect_segment on this rank's segment -> (all-gather) -> merge_top_k -> host copies.
-        Nothing here waits for the GPU: the host plans batch i+1 while batch i runs."""
-        dev.collect_segment_prepared_device(0, k, d_scores, d_docs, d_counts, stream)
-        if world > 1:
-            g = D.allgather_topk(d_scores, d_docs, d_counts)
-        else:
-            g = (d_scores.unsqueeze(0), d_docs.unsqueeze(0), d_counts.unsqueeze(0))
-        m = D.merge_gathered_device(dev.ctx, local_rank, g[0], g[1], g[2], 0, k, stream)
-        for h, t in zip(h_out, m):
-            h.copy_(t, non_blocking=True)
-
-    def step():
-        enqueue()
-        torch.cuda.synchronize()
-        return dev.last_batch_stats()
-
-    # untimed reference pass in the OTHER mode: every query's top-k must be identical with and
-    # without block-max pruning (full-size parity property), and the exhaustive pass counts the
-    # matches that enter the algorithmic-bytes figure (SURVEY.md §8d)
-    def run_mode(exhaustive, n):
-        dev.set_option("exhaustive", 1 if exhaustive else 0)
-        kms, st = [], None
-        for _ in range(n):
-            st = step()
-            kms.append(st["kernel_ms"])
-        torch.cuda.synchronize()
-        return [h.clone().numpy() for h in h_out], st, kms
-
-    exh_out, exh_st, _ = run_mode(True, 1)
-    _, _, exh_kms = run_mode(True, max(1, min(args.steps, 3)))
-    prn_out, prn_st, _ = run_mode(False, 1)
-    _, _, prn_kms = run_mode(False, max(1, min(args.steps, 3)))
-    mode_parity = all(np.array_equal(a, b) for a, b in zip(exh_out, prn_out))
-    if not mode_parity:
-        n_diff = int(np.sum(np.any(exh_out[2] != prn_out[2], axis=1)))
-        raise SystemExit("pruned and exhaustive results differ on %d queries" % n_diff)
-    full_matches = exh_st["matches"]
-    algo_bytes_full = exh_st["algorithmic_bytes"]  # postings + positions + matches + 8k
-    dev.set_option("exhaustive", 0 if pruned_mode else 1)
-    for _ in range(args.warmup):
-        step()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t_start = time.perf_counter()
-    dev.last_batch_stats()  # start a fresh timing window
-    trace = [] if os.environ.get("BENCH_TRACE") else None
-    for _ in range(args.steps):
-        enqueue()  # steps are pipelined: one synchronisation closes the timed region
-        if trace is not None:
-            trace.append(time.perf_counter() - t_start)
-    torch.cuda.synchronize()
-    if trace is not None:
-        trace.append(time.perf_counter() - t_start)
-        print("enqueue returns / final sync (ms):", [round(x * 1e3, 2) for x in trace], file=sys.stderr)
-    if world > 1:
-        dist.barrier()
-    elapsed = time.perf_counter() - t_start
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-    final = [h.clone().numpy() for h in h_out]
-    st = dev.last_batch_stats()  # HIP-event kernel time, mean over the timed steps (<= last 16)
-    kernel_ms = [st["kernel_ms"]]
-    algo_bytes, matches = algo_bytes_full, st["matches"]
+    m = measure(cl, runner, torch, queries, k, args.steps, args.warmup, args.exhaustive)
+    if not m["mode_parity"]:
+        raise SystemExit("pruned and exhaustive results differ on %d queries" % m["n_diff"])
 
     # ---- single-query latency (p50), outside the timed region
     lat = []
-    if rank == 0 and args.latency_queries > 0:
+    if rank == 0 and world == 1 and args.latency_queries > 0:
         for i in range(min(args.latency_queries, n_q)):
-            dev.prepare([queries[i]])
+            runner.dev.prepare([queries[i]])
             t1 = time.perf_counter()
-            dev.search_prepared(k)
+            runner.dev.search_prepared(k)
             lat.append(time.perf_counter() - t1)
-        dev.prepare(queries)
 
-    if rank != 0:
-        if world > 1:
-            dist.barrier()
-            dist.destroy_process_group()
-        return
-
-    # ---- post-hoc parity spot check against the oracle (N=1 only: local stats == global)
-    parity_checked = 0
-    if world == 1:
-        for i in list(range(0, n_q, max(1, n_q // 16)))[:16]:
-            mode, terms = queries[i][0], queries[i][1]
-            if args.workload == "bool":
-                want = O.bool_search(seg, terms, queries[i][2], k, queries[i][3], queries[i][4])
-            else:
-                want = O.search(seg, terms, mode, k, pruned=False)
-            got = [(float(final[0][i, j]), int(final[2][i, j])) for j in range(int(final[3][i]))]
-            assert len(got) == len(want), (i, got, want)
-            for (gs, gd), (ws, wd) in zip(got, want):
-                assert gd == wd and abs(gs - ws) <= 1e-5 * abs(ws), (i, got, want)
-            parity_checked += 1
-
-    # ---- CPU baseline: the oracle's restatement of tantivy's block-WAND executors
+    parity_checked = spot_check(O, seg, args.workload, queries, k, m["final"]) if world == 1 else 0
     cpu = None
     if world == 1 and not args.no_cpu_baseline:
-        cores = os.cpu_count() or 1
-        specs, done, wall_total = [], 0, 0.0
-        chunk = max(64, cores * 16)
-        def spec_of(q):
-            if args.workload == "bool":  # the restated generic scorer tree (no block-max executor)
-                return O.bool_spec(seg, q[1], q[2], q[3], q[4], k)
-            return O.QuerySpec(seg, q[1], O.default_weights(seg, q[1], q[0]), q[0], k,
-                               list(range(len(q[1]))) if q[0] == O.MODE_PHRASE else None)
+        cpu = cpu_baseline(O, seg, args.workload, queries, k, args.cpu_seconds, sweep=True)
 
-        while wall_total < args.cpu_seconds and done < n_q:
-            part = queries[done:done + chunk]
-            sp = [spec_of(q) for q in part]
-            wall, _, _ = O.baseline_run(seg, sp, cores)
-            wall_total += wall
-            done += len(part)
-        sp1 = [spec_of(q) for q in queries[:48]]
-        _, lat1, _ = O.baseline_run(seg, sp1, 1)
-        cpu = {"value": round(done / wall_total, 2), "unit": "queries/s", "cores": cores,
-               "kind": "port",
-               "sample": "first %d queries of the same stream, query-level parallelism on %d "
-                         "threads, %.1f s; C restatement of tantivy's %s (oracle/), not the tantivy "
-                         "binary" % (done, cores, wall_total,
-                                     "generic scorer tree (Intersection / BufferedUnionScorer / "
-                                     "RequiredOptionalScorer / Exclude under for_each_pruning_scorer)"
-                                     if args.workload == "bool" else
-                                     "block_wand_intersection/block_wand"),
-               "p50_latency_ms_1core": round(float(np.median(lat1)) * 1e3, 3)}
+    # ---------------------------------------------------------------- other BASELINE configs (N=1)
+    side = {}
+    if world == 1 and not args.no_side:
+        for wl in ("or5", "phrase3", "mixed"):
+            if wl == args.workload:
+                continue
+            s_seg, s_runner = seg, runner
+            if (wl == "phrase3") != with_pos:
+                s_seg = O.synth_segment(args.docs, n_terms=256, segment_ord=rank,
+                                        with_positions=wl == "phrase3", phrase_terms=32)
+                s_runner = D.ShardRunner([s_seg], cl.local_rank)
+                s_runner.set_option("timing", 1)
+            qs, kk = build_queries(O, wl, DEFAULT_QUERIES[wl], None)
+            sm = measure(cl, s_runner, torch, qs, kk, args.side_steps, 1)
+            if not sm["mode_parity"]:
+                raise SystemExit("%s: pruned and exhaustive results differ on %d queries" % (wl, sm["n_diff"]))
+            checked = spot_check(O, s_seg, wl, qs, kk, sm["final"], 6)
+            k_ms = sm["stats"]["kernel_ms"]
+            ach, fr = frac_of(sm["algo_bytes_full"], k_ms)
+            ach_e, fr_e = frac_of(sm["algo_bytes_full"], sm["exh_stats"]["kernel_ms"])
+            side[wl] = {
+                "config": "%s: %d queries/batch, k=%d, same %dM-doc segment%s" %
+                          (wl, len(qs), kk, args.docs // 1_000_000,
+                           " (with positions)" if wl == "phrase3" else ""),
+                "qps": round(len(qs) * args.side_steps / sm["elapsed"], 1),
+                "ms_per_step": round(sm["elapsed"] / args.side_steps * 1e3, 3),
+                "kernel_ms_avg": round(k_ms, 4),
+                "roofline_achieved_GBps": ach, "roofline_frac": fr,
+                "exhaustive_kernel_ms": round(sm["exh_stats"]["kernel_ms"], 4),
+                "exhaustive_roofline_frac": fr_e,
+                "algorithmic_bytes_per_launch": int(sm["algo_bytes_full"]),
+                "docs_scored_per_launch": int(sm["stats"]["matches"]),
+                "pruned_equals_exhaustive": True, "parity_checked_queries": checked,
+                "traffic": (load_traffic("%s_pruned_%d" % (wl, args.docs)) or {}).get("hbm_bytes_per_launch"),
+            }
+            if not args.no_cpu_baseline:
+                c = cpu_baseline(O, s_seg, wl, qs, kk, max(2.0, args.cpu_seconds / 3), sweep=False)
+                side[wl]["cpu_baseline"] = {key: c[key] for key in ("value", "unit", "cores", "kind")}
+            if s_runner is not runner:
+                s_runner.close()
+    runner.close()
+    if cl.comm is not None:
+        cl.comm.close()
+        cl.comm = None
 
-    # HBM traffic per launch from the committed rocprofv3 PMC run of this same command
-    traffic, traffic_note = None, "no PMC run recorded"
-    tpath = os.path.join(ROOT, "profiles", "traffic.json")
-    if os.path.exists(tpath):
-        with open(tpath) as f:
-            tj = json.load(f)
-        key = "%s_%s_%d" % (args.workload, "pruned" if pruned_mode else "exhaustive", args.docs)
-        if key in tj:
-            traffic = tj[key]["hbm_bytes_per_launch"]
-            traffic_note = tj[key]["note"]
+    # ---------------------------------------------------------------- config 5: 8 segments, strong
+    strong = None
+    if not args.no_side and N_SEGMENTS_STRONG % world == 0:
+        s_local = N_SEGMENTS_STRONG // world
+        ords = list(range(rank * s_local, (rank + 1) * s_local))
+        t0 = time.time()
+        segs = [O.synth_segment(args.docs, n_terms=256, segment_ord=o) for o in ords]
+        t_gen8 = time.time() - t0
+        mine = [stats_of(s) for s in segs]
+        everyone = cl.all_gather_object(mine)
+        remote = [st for r, lst in enumerate(everyone) if r != rank for st in lst]
+        srun = D.ShardRunner(segs, cl.local_rank, rank, world, remote)
+        cl.make_comm(srun.dev.ctx)
+        srun.comm, srun.torch_group = cl.comm, cl.torch_group
+        srun.set_option("timing", 1)
+        qs, kk = build_queries(O, "mixed", DEFAULT_QUERIES["mixed"], None)
+        sm = measure(cl, srun, torch, qs, kk, args.side_steps, 1)
+        if not sm["mode_parity"]:
+            raise SystemExit("strong: pruned and exhaustive results differ on %d queries" % sm["n_diff"])
+        k_ms = sm["stats"]["kernel_ms"]
+        ach, fr = frac_of(sm["algo_bytes_full"], k_ms)
+        resident = sum(int(s.idx_len) + s.max_doc for s in segs)
+        strong = {
+            "config": "BASELINE configs[4]: %d x %dM-doc segments (%dM docs), mixed 50%% 2-term AND / "
+                      "50%% 5-term OR stream, %d queries/batch, k=%d, global BM25 statistics; %d "
+                      "segment(s) per GPU, all-gather of the per-segment top-k + merge_top_k" %
+                      (N_SEGMENTS_STRONG, args.docs // 1_000_000,
+                       N_SEGMENTS_STRONG * args.docs // 1_000_000, len(qs), kk, s_local),
+            "scaling": "strong", "unit": "queries/s over the whole %d-segment index" % N_SEGMENTS_STRONG,
+            "n_gpus": world, "segments_per_gpu": s_local,
+            "qps": round(len(qs) * args.side_steps / sm["elapsed"], 1),
+            "ms_per_step": round(sm["elapsed"] / args.side_steps * 1e3, 3),
+            "kernel_ms_per_gpu": round(k_ms, 4),
+            "roofline_achieved_GBps_per_gpu": ach, "roofline_frac_per_gpu": fr,
+            "algorithmic_bytes_per_step_per_gpu": int(sm["algo_bytes_full"]),
+            "index_plus_fieldnorm_bytes_per_gpu": resident,
+            "hbm_resident_note": "index + fieldnorms + bitmaps + skip tables of %d segments ~ %.1f GB per "
+                                 "GPU: %s the 256 MB Infinity Cache" %
+                                 (s_local, s_local * 0.14, "beyond" if s_local >= 2 else "within"),
+            "exchange": cl.exchange_note, "pruned_equals_exhaustive": True,
+            "index_build_s": round(t_gen8, 2),
+        }
+        srun.close()
+        if cl.comm is not None:
+            cl.comm.close()
 
-    def roof(kms):
-        k = float(np.mean(kms))
-        a = algo_bytes_full / (k * 1e-3) / 1e9 if k > 0 else 0.0
-        return {"mode": None, "achieved": round(a, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(a / HBM_PEAK_GBS, 4), "kernel_ms_avg": round(k, 4)}
+    if rank != 0:
+        cl.barrier()
+        if cl.dist is not None:
+            cl.dist.destroy_process_group()
+        return
 
-    other = roof(exh_kms if pruned_mode else prn_kms)
-    other["mode"] = "exhaustive" if pruned_mode else "pruned"
+    st = m["stats"]
+    k_ms = st["kernel_ms"]
+    algo_bytes = m["algo_bytes_full"]
+    achieved, frac = frac_of(algo_bytes, k_ms)
+    other_st = m["exh_stats"] if pruned_mode else m["prn_stats"]
+    o_ach, o_frac = frac_of(algo_bytes, other_st["kernel_ms"])
+    traffic, traffic_note, physical = None, "no PMC run recorded", None
+    tj = load_traffic("%s_%s_%d" % (args.workload, "pruned" if pruned_mode else "exhaustive", args.docs))
+    if tj:
+        traffic = tj["hbm_bytes_per_launch"]
+        traffic_note = tj["note"]
+        if k_ms > 0:
+            physical = round(traffic / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
     total_units = n_q * args.steps * world  # one unit = one query evaluated on one segment
-    value = total_units / elapsed
-    k_ms = float(np.mean(kernel_ms)) if kernel_ms else 0.0
-    achieved = (algo_bytes / (k_ms * 1e-3) / 1e9) if k_ms > 0 else 0.0
+    value = total_units / m["elapsed"]
     out = {
         "metric": "queries_per_sec_2term_AND_bm25_top10" if args.workload == "and2"
         else "queries_per_sec_" + args.workload,
@@ -308,7 +542,7 @@ def main():
         "n_gpus": world,
         "steps": args.steps,
         "warmup": args.warmup,
-        "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+        "ms_per_step": round(m["elapsed"] / args.steps * 1e3, 3),
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
@@ -319,42 +553,56 @@ def main():
                         "df_r=0.5N/r, WithFreqs%s); term ranks ~ Zipf(1)" %
                         (args.workload, n_q, k, args.docs // 1_000_000,
                          "AndPositions" if with_pos else ""),
-            "unit_note": "one unit = one query evaluated on one segment; at N GPUs every query "
-                         "runs on N segments (N x %dM docs) and the per-segment top-k are "
-                         "all-gathered over RCCL and merged" % (args.docs // 1_000_000),
+            "unit_note": "weak scaling: one unit = one query evaluated on one segment; at N GPUs every "
+                         "query runs on N segments (N x %dM docs), the per-segment top-k are "
+                         "all-gathered over RCCL and merged.  The same 8-segment index at every N "
+                         "(strong scaling, config 5) is reported under strong_scaling" %
+                         (args.docs // 1_000_000),
             "timed_region": "K x [collect_segment (plan + H2D of query descriptors + scan + merge "
                             "kernels) -> all-gather -> merge_top_k -> D2H], enqueued back to back "
                             "(host planning of step i+1 overlaps the GPU work of step i), one "
                             "synchronisation at each end",
             "mode": "block-max pruned (block_wand_intersection semantics)" if pruned_mode
                     else "exhaustive (every match scored)",
+            "exchange": cl.exchange_note,
             "index_bytes": int(seg.idx_len),
             "index_build_s": round(t_gen, 2),
         },
         "roofline": {
             "bound": "hbm",
-            "achieved": round(achieved, 1),
+            "achieved": achieved,
             "peak": HBM_PEAK_GBS,
             "unit": "GB/s",
-            "frac": round(achieved / HBM_PEAK_GBS, 4),
+            "frac": frac,
             "traffic": traffic,
+            "physical_frac": physical,
             "kernel": "and_kernel" if args.workload == "and2" else args.workload + " scan kernels",
             "kernel_ms_avg": round(k_ms, 4),
             "algorithmic_bytes_per_launch": int(algo_bytes),
-            "docs_scored_per_launch": int(matches),
-            "matches_per_launch": int(full_matches),
+            "docs_scored_per_launch": int(st["matches"]),
+            "matches_per_launch": int(m["full_matches"]),
             "traffic_note": traffic_note,
+            "frac_note": "frac = algorithmic bytes (SURVEY.md §8d: postings ranges + 1 B per match + 8k; "
+                         "what a full scan would read) / kernel time / 8 TB/s — the pruned kernel skips "
+                         "most of them, so this is work-equivalent bandwidth, not achieved HBM bandwidth; "
+                         "physical_frac = rocprofv3 fabric bytes (committed PMC run, calibrated per "
+                         "DESIGN.md §3.0) / kernel time / 8 TB/s",
         },
-        "roofline_other_mode": other,
-        "pruned_equals_exhaustive": bool(mode_parity),
+        "roofline_other_mode": {"mode": "exhaustive" if pruned_mode else "pruned", "achieved": o_ach,
+                                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": o_frac,
+                                "kernel_ms_avg": round(other_st["kernel_ms"], 4)},
+        "pruned_equals_exhaustive": bool(m["mode_parity"]),
         "cpu_baseline": cpu,
         "p50_latency_ms": round(float(np.median(lat)) * 1e3, 4) if lat else None,
         "parity_checked_queries": parity_checked,
+        "other_workloads": side or None,
+        "strong_scaling": strong,
     }
     print(json.dumps(out))
-    if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
+    sys.stdout.flush()
+    cl.barrier()
+    if cl.dist is not None:
+        cl.dist.destroy_process_group()
 
 
 if __name__ == "__main__":

@@ -182,6 +182,37 @@ int tq_merge_topk_device(tq_ctx *ctx, int device, const float *d_scores, const u
                          uint32_t *d_out_segment_ords, uint32_t *d_out_docs,
                          uint32_t *d_out_counts, void *hip_stream);
 
+/* ---- cross-GPU exchange (one segment set per GPU) ----
+ * replaces: the fan-in of Searcher::search_with_executor (src/core/searcher.rs:230-235: the
+ * executor maps collect_segment over the segments, src/core/executor.rs:61-104, and hands the
+ * fruits to merge_fruits, src/collector/sort_key_top_collector.rs:54-95) when the segments live
+ * on different GPUs, one process per GPU.  The only collective of the path: an RCCL all-gather of
+ * the per-segment top-k lists over xGMI.  BM25 statistics need none (sums known to the host
+ * before dispatch, src/query/bm25.rs:27-50).
+ *
+ * tq_comm_unique_id : ncclGetUniqueId on ONE rank; the host sends the 128 bytes to the others
+ *                     (any channel: the Rust host's own control plane).
+ * tq_comm_init      : ncclCommInitRank(world, id, rank) on `device`; collective over all ranks.
+ * tq_allgather_topk : every rank passes the [n_rows][stride] result slabs of its local segments
+ *                     (n_rows = local segments x queries; scores / docs, and [n_rows] counts) as
+ *                     written by tq_search_batch_device, and receives all ranks' slabs as
+ *                     [world][n_rows][stride] / [world][n_rows] — with rank r holding segments
+ *                     r*S..r*S+S-1 that is the [segment][query][stride] input of
+ *                     tq_merge_topk_device.  Device pointers; enqueued on hip_stream (stream
+ *                     ordered after the searches, no host synchronisation); one grouped RCCL
+ *                     launch.  librccl is opened at run time (TQ_RCCL_LIB overrides the path);
+ *                     TQ_ERR_UNSUPPORTED if it cannot be loaded. */
+#define TQ_COMM_ID_BYTES 128
+typedef struct tq_comm tq_comm;
+int tq_comm_unique_id(uint8_t *id_out /* TQ_COMM_ID_BYTES */);
+int tq_comm_init(tq_ctx *ctx, int device, const uint8_t *id, int rank, int world, tq_comm **out);
+void tq_comm_free(tq_comm *comm);
+int tq_comm_info(const tq_comm *comm, int *rank, int *world, const char **library);
+int tq_allgather_topk(tq_comm *comm, const float *d_scores, const uint32_t *d_docs,
+                      const uint32_t *d_counts, uint32_t n_rows, uint32_t stride,
+                      float *d_all_scores, uint32_t *d_all_docs, uint32_t *d_all_counts,
+                      void *hip_stream);
+
 /* ---- codec access (parity tests / tooling) ----
  * replaces: BlockSegmentPostings::load_block over a whole list (block_segment_postings.rs:343-391;
  * BitPacker4x decode + strict-delta prefix sum + vint tail).  docs/tfs: doc_freq u32 each (host). */

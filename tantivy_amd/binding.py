@@ -64,7 +64,8 @@ EXPORTS = [
     "tq_last_batch_stats", "tq_set_option", "tq_segment_set_alive_bitset", "tq_count_batch",
     "tq_last_batch_match_counts", "tq_encoder_create", "tq_encoder_free", "tq_encode_postings",
     "tq_encode_positions", "tq_encode_postings_device", "tq_encode_positions_device",
-    "tq_encoder_last_kernel_ms",
+    "tq_encoder_last_kernel_ms", "tq_comm_unique_id", "tq_comm_init", "tq_comm_free",
+    "tq_comm_info", "tq_allgather_topk",
     "tqh_last_error", "tqh_searcher_new", "tqh_searcher_free", "tqh_searcher_add_segment",
     "tqh_prepare_batch", "tqh_search_prepared", "tqh_collect_segment_prepared",
     "tqh_collect_segment_prepared_device", "tqh_searcher_add_remote_stats",
@@ -125,6 +126,12 @@ def lib():
     L.tq_encode_positions_device.argtypes = [vp, C.c_uint32, vp, vp, vp, vp, C.c_uint64, vp, u64p,
                                              vp]
     L.tq_encoder_last_kernel_ms.argtypes = [vp, C.POINTER(C.c_float)]
+    L.tq_comm_unique_id.argtypes = [vp]
+    L.tq_comm_init.argtypes = [vp, C.c_int, vp, C.c_int, C.c_int, C.POINTER(vp)]
+    L.tq_comm_free.argtypes = [vp]
+    L.tq_comm_free.restype = None
+    L.tq_comm_info.argtypes = [vp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_char_p)]
+    L.tq_allgather_topk.argtypes = [vp, vp, vp, vp, C.c_uint32, C.c_uint32, vp, vp, vp, vp]
     L.tqh_searcher_new.argtypes = [vp, C.POINTER(vp)]
     L.tqh_searcher_free.argtypes = [vp]
     L.tqh_searcher_add_segment.argtypes = [vp, C.c_int, C.c_uint32, C.c_uint8, vp, C.c_size_t, vp,

@@ -14,6 +14,7 @@ SOURCES = [
     os.path.join(HERE, "csrc", "tq_misc.hip"),
     os.path.join(HERE, "csrc", "tq_encode.hip"),
     os.path.join(HERE, "csrc", "tq_api.cpp"),
+    os.path.join(HERE, "csrc", "tq_comm.cpp"),
     os.path.join(HERE, "host", "searcher.cpp"),
     os.path.join(HERE, "host", "host_capi.cpp"),
     os.path.join(HERE, "host", "term_info_store.cpp"),
@@ -61,7 +62,7 @@ def build(force=False, verbose=False):
 
     with ThreadPoolExecutor(max_workers=min(len(SOURCES), os.cpu_count() or 1)) as pool:
         list(pool.map(compile_one, zip(SOURCES, objs)))
-    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs + ["-ldl"]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)

@@ -1,6 +1,7 @@
-"""Segment-per-rank execution: every rank holds one segment, all ranks run the
-same query batch with the same global BM25 statistics, and the per-segment top-k lists are
-exchanged with ONE all-gather (RCCL over xGMI on GPUs, gloo on CPU) before `merge_top_k`
+"""Segments sharded over GPUs, one process per GPU: every rank holds a contiguous
+run of the index's segments, all ranks run the same query batch with the same global BM25
+statistics, and the per-segment top-k lists are exchanged with ONE all-gather (RCCL over xGMI
+through the C ABI's tq_allgather_topk; gloo on CPU in the tests) before `merge_top_k`
 (src/collector/sort_key_top_collector.rs:76-95) picks the global top-(offset+limit) by
 (score desc, segment_ord asc, doc asc).  No other collective exists on this path: BM25
 statistics are sums of per-segment counters known to the host before dispatch (bm25.rs:27-50).
@@ -13,8 +14,9 @@ from . import binding as B
 
 
 def allgather_topk(scores, docs, counts, group=None):
-    """scores/docs: [n_queries, k] tensors, counts: [n_queries] (any device).  Returns the
-    gathered [world, n_queries, k] / [world, n_queries] tensors (rank r == segment_ord r)."""
+    """torch.distributed version (gloo in the CPU tests; RCCL fallback when the C-ABI communicator
+    is unavailable).  scores/docs: [rows, k] tensors, counts: [rows].  Returns the gathered
+    [world, rows, k] / [world, rows] tensors (rank order == segment order)."""
     import torch
     import torch.distributed as dist
 
@@ -49,19 +51,149 @@ def merge_gathered_host(g_scores, g_docs, g_counts, offset, limit):
     return out_s, out_o, out_d, out_c
 
 
-def merge_gathered_device(ctx, device, g_scores, g_docs, g_counts, offset, limit, stream=None):
+def merge_gathered_device(ctx, device, g_scores, g_docs, g_counts, offset, limit, stream=None,
+                          out=None):
     """merge_top_k on the device (tq_merge_topk_device); tensors stay on the GPU."""
     import torch
 
     S, n, k = g_scores.shape
     dev = g_scores.device
-    out_s = torch.empty((n, limit), dtype=torch.float32, device=dev)
-    out_o = torch.empty((n, limit), dtype=torch.int32, device=dev)
-    out_d = torch.empty((n, limit), dtype=torch.int32, device=dev)
-    out_c = torch.empty(n, dtype=torch.int32, device=dev)
+    if out is None:
+        out = (torch.empty((n, limit), dtype=torch.float32, device=dev),
+               torch.empty((n, limit), dtype=torch.int32, device=dev),
+               torch.empty((n, limit), dtype=torch.int32, device=dev),
+               torch.empty(n, dtype=torch.int32, device=dev))
+    out_s, out_o, out_d, out_c = out
     st = stream if stream is not None else torch.cuda.current_stream(dev).cuda_stream
     B._check(B.lib().tq_merge_topk_device(
         ctx, int(device), g_scores.data_ptr(), g_docs.data_ptr(), g_counts.data_ptr(), None, S, n, k,
         int(offset), int(limit), out_s.data_ptr(), out_o.data_ptr(), out_d.data_ptr(),
         out_c.data_ptr(), C.c_void_p(st)))
     return out_s, out_o, out_d, out_c
+
+
+class Comm:
+    """RCCL communicator behind the C ABI (tq_comm_*): what a Rust host would hold.  `exchange`
+    sends rank 0's 128-byte id to every rank (any control-plane channel; here the caller's)."""
+
+    def __init__(self, ctx, device, rank, world, exchange):
+        L = B.lib()
+        ident = (C.c_uint8 * 128)()
+        if rank == 0:
+            B._check(L.tq_comm_unique_id(ident))
+        raw = exchange(bytes(ident) if rank == 0 else None)
+        ident = (C.c_uint8 * 128).from_buffer_copy(raw)
+        self._c = C.c_void_p()
+        B._check(L.tq_comm_init(ctx, int(device), ident, int(rank), int(world), C.byref(self._c)))
+        self.rank, self.world = rank, world
+        lib_name = C.c_char_p()
+        B._check(L.tq_comm_info(self._c, None, None, C.byref(lib_name)))
+        self.library = (lib_name.value or b"").decode()
+
+    def allgather_topk(self, scores, docs, counts, out, stream):
+        """scores/docs [rows, k], counts [rows] -> out = ([world, rows, k] x2, [world, rows])."""
+        rows, k = scores.shape
+        B._check(B.lib().tq_allgather_topk(
+            self._c, scores.data_ptr(), docs.data_ptr(), counts.data_ptr(), rows, k,
+            out[0].data_ptr(), out[1].data_ptr(), out[2].data_ptr(), C.c_void_p(stream)))
+
+    def close(self):
+        if self._c:
+            B.lib().tq_comm_free(self._c)
+            self._c = C.c_void_p()
+
+
+class ShardRunner:
+    """One rank's share of a sharded index: `segments` (its contiguous run, in global segment
+    order) resident on `device`, the global statistics of the others added as remote statistics.
+    enqueue() = for every local segment collect_segment (tq_search_batch_device) into its slab,
+    one all-gather of the slabs, merge_top_k on the device, asynchronous copies to pinned host
+    memory — all on one HIP stream, nothing waits for the GPU."""
+
+    def __init__(self, segments, device, rank=0, world=1, remote_stats=(), comm=None,
+                 torch_group=None):
+        import torch
+
+        from . import DeviceIndex
+
+        self.torch = torch
+        self.dev = DeviceIndex(segments, devices=[device] * max(1, len(segments)))
+        self.n_local = len(segments)
+        self.device, self.rank, self.world = device, rank, world
+        for st in remote_stats:
+            self.dev.add_remote_stats(*st)
+        self.comm, self.torch_group = comm, torch_group
+        self.stream_obj = torch.cuda.Stream(device=device)
+        self.stream = self.stream_obj.cuda_stream
+        self.n = self.k = 0
+
+    def set_option(self, name, value):
+        self.dev.set_option(name, value)
+
+    def prepare(self, queries, k):
+        torch = self.torch
+        self.dev.prepare(queries)
+        n, S, W = len(queries), self.n_local, self.world
+        if (n, k) == (self.n, self.k):
+            return
+        self.n, self.k = n, k
+        cuda = torch.device("cuda", self.device)
+        self.local = (torch.empty((S * n, k), dtype=torch.float32, device=cuda),
+                      torch.empty((S * n, k), dtype=torch.int32, device=cuda),
+                      torch.empty(S * n, dtype=torch.int32, device=cuda))
+        if W > 1:
+            self.gathered = (torch.empty((W, S * n, k), dtype=torch.float32, device=cuda),
+                             torch.empty((W, S * n, k), dtype=torch.int32, device=cuda),
+                             torch.empty((W, S * n), dtype=torch.int32, device=cuda))
+        self.merged = (torch.empty((n, k), dtype=torch.float32, device=cuda),
+                       torch.empty((n, k), dtype=torch.int32, device=cuda),
+                       torch.empty((n, k), dtype=torch.int32, device=cuda),
+                       torch.empty(n, dtype=torch.int32, device=cuda))
+        self.host = [torch.empty(t.shape, dtype=t.dtype).pin_memory() for t in self.merged]
+
+    def enqueue(self):
+        torch = self.torch
+        n, k, S, W = self.n, self.k, self.n_local, self.world
+        sc, dc, ct = self.local
+        with torch.cuda.stream(self.stream_obj):
+            for s in range(S):
+                self.dev.collect_segment_prepared_device(
+                    s, k, sc[s * n:(s + 1) * n], dc[s * n:(s + 1) * n], ct[s * n:(s + 1) * n],
+                    self.stream)
+            if W > 1:
+                if self.comm is not None:
+                    self.comm.allgather_topk(sc, dc, ct, self.gathered, self.stream)
+                    g = self.gathered
+                else:  # RCCL through torch.distributed (same wire, torch's communicator)
+                    g = allgather_topk(sc, dc, ct, group=self.torch_group)
+            else:
+                g = (sc.unsqueeze(0), dc.unsqueeze(0), ct.unsqueeze(0))
+            # [world][S*n][k] == [world*S segments][n][k]: rank order is segment order
+            merge_gathered_device(self.dev.ctx, self.device, g[0].reshape(W * S, n, k),
+                                  g[1].reshape(W * S, n, k), g[2].reshape(W * S, n), 0, k,
+                                  self.stream, out=self.merged)
+            for h, t in zip(self.host, self.merged):
+                h.copy_(t, non_blocking=True)
+
+    def synchronize(self):
+        self.stream_obj.synchronize()
+
+    def results(self):
+        """(scores, segment_ords, docs, counts) of the last finished step (host copies)."""
+        return [h.clone().numpy() for h in self.host]
+
+    def batch_stats(self):
+        """Per-step statistics summed over the local segments (kernel_ms: the segments' scan
+        kernels run back to back on one stream)."""
+        out = None
+        for s in range(self.n_local):
+            st = self.dev.last_batch_stats(s)
+            if out is None:
+                out = dict(st)
+            else:
+                for key in ("algorithmic_bytes", "matches", "kernel_ms", "total_ms", "tiles", "chunks"):
+                    out[key] += st[key]
+        return out
+
+    def close(self):
+        self.dev.close()

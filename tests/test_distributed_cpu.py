@@ -79,3 +79,22 @@ def test_allgather_merge_world2():
         p.join(180)
     assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
     assert ret.get(0) and ret.get(1)
+
+
+def test_bench_launcher_spawns_ranks():
+    """`python bench.py --gpus 2` without a launcher must spawn its two ranks itself and print ONE
+    JSON line with n_gpus == 2 (it used to run one rank).  --selftest-launcher runs
+    the exchange plumbing over gloo with synthetic per-rank results instead of GPU work."""
+    import json
+    import subprocess
+
+    env = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2",
+                        "--selftest-launcher"], capture_output=True, text=True, timeout=300, env=env)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout
+    j = json.loads(lines[0])
+    assert j == {"selftest": "launcher", "n_gpus": 2, "ok": True}
