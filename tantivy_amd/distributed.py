@@ -111,7 +111,7 @@ class ShardRunner:
     memory — all on one HIP stream, nothing waits for the GPU."""
 
     def __init__(self, segments, device, rank=0, world=1, remote_stats=(), comm=None,
-                 torch_group=None):
+                 torch_group=None, force_exchange=False):
         import torch
 
         from . import DeviceIndex
@@ -123,6 +123,7 @@ class ShardRunner:
         for st in remote_stats:
             self.dev.add_remote_stats(*st)
         self.comm, self.torch_group = comm, torch_group
+        self.force_exchange = force_exchange  # tests: run the all-gather even with one rank
         self.stream_obj = torch.cuda.Stream(device=device)
         self.stream = self.stream_obj.cuda_stream
         self.n = self.k = 0
@@ -141,7 +142,7 @@ class ShardRunner:
         self.local = (torch.empty((S * n, k), dtype=torch.float32, device=cuda),
                       torch.empty((S * n, k), dtype=torch.int32, device=cuda),
                       torch.empty(S * n, dtype=torch.int32, device=cuda))
-        if W > 1:
+        if W > 1 or self.force_exchange:
             self.gathered = (torch.empty((W, S * n, k), dtype=torch.float32, device=cuda),
                              torch.empty((W, S * n, k), dtype=torch.int32, device=cuda),
                              torch.empty((W, S * n), dtype=torch.int32, device=cuda))
@@ -160,7 +161,7 @@ class ShardRunner:
                 self.dev.collect_segment_prepared_device(
                     s, k, sc[s * n:(s + 1) * n], dc[s * n:(s + 1) * n], ct[s * n:(s + 1) * n],
                     self.stream)
-            if W > 1:
+            if W > 1 or self.force_exchange:
                 if self.comm is not None:
                     self.comm.allgather_topk(sc, dc, ct, self.gathered, self.stream)
                     g = self.gathered

@@ -273,3 +273,46 @@ def test_per_call_options_and_argument_checks(ta):
             devp.close()
     finally:
         dev.close()
+
+
+# ------------------------------------------------------------------ RCCL behind the C ABI
+def test_rccl_allgather_through_the_c_abi(ta):
+    """tq_comm_unique_id / tq_comm_init / tq_allgather_topk on a one-rank communicator (the GPU
+    box has one GPU): the gathered slabs equal the inputs, and a ShardRunner that is forced
+    through the exchange (collect_segment x 2 local segments -> all-gather -> merge_top_k, one
+    stream) returns what Searcher::search over the same two segments returns."""
+    import torch
+
+    from tantivy_amd import distributed as D
+
+    segs = [O.synth_segment(400_000, n_terms=32, segment_ord=o) for o in range(2)]
+    ref = ta.DeviceIndex(segs, devices=[0])
+    qs = [(O.MODE_AND, q.tolist()) for q in O.zipf_queries(500, 2, 32, seed=3)]
+    qs += [(O.MODE_OR, q.tolist()) for q in O.zipf_queries(100, 3, 32, seed=4)]
+    want = ref.search(qs, 10)
+    ref.close()
+    run = D.ShardRunner(segs, 0, 0, 1, force_exchange=True)
+    comm = D.Comm(run.dev.ctx, 0, 0, 1, lambda raw: raw)
+    try:
+        assert comm.library
+        run.comm = comm
+        run.prepare(qs, 10)
+        for _ in range(3):
+            run.enqueue()
+        run.synchronize()
+        got = run.results()
+        for a, b in zip(got, want):
+            assert np.array_equal(a.view(np.uint32) if a.dtype != np.float32 else a,
+                                  b.view(np.uint32) if b.dtype != np.float32 else b)
+        # raw call: [rows][k] slabs in, [1][rows][k] out
+        sc = torch.rand((7, 5), device="cuda")
+        dc = torch.randint(0, 1000, (7, 5), dtype=torch.int32, device="cuda")
+        ct = torch.randint(0, 6, (7,), dtype=torch.int32, device="cuda")
+        out = (torch.zeros((1, 7, 5), device="cuda"), torch.zeros((1, 7, 5), dtype=torch.int32, device="cuda"),
+               torch.zeros((1, 7), dtype=torch.int32, device="cuda"))
+        comm.allgather_topk(sc, dc, ct, out, torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        assert torch.equal(out[0][0], sc) and torch.equal(out[1][0], dc) and torch.equal(out[2][0], ct)
+    finally:
+        comm.close()
+        run.close()
