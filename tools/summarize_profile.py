@@ -1,12 +1,17 @@
 #!/usr/bin/env python
-"""Turns the rocprofv3 CSVs of tools/profile_bench.sh (gpurun_out/prof_r01/) into the committed
-summaries under profiles/:  <tag>_kernel_stats.csv (verbatim --stats output), <tag>_pmc.md
-(per-kernel counter averages per launch) and traffic.json (HBM bytes per launch, used by
-bench.py's roofline.traffic).
+"""Turns the rocprofv3 CSVs of tools/profile_workload.sh (gpurun_out/prof_<tag>/) into the
+committed summaries under profiles/:  <tag>_kernel_stats.csv (verbatim --stats output),
+<tag>_pmc.md (per-kernel counter averages per launch) and traffic.json (fabric bytes per batch,
+used by bench.py's roofline.traffic / physical_frac).
 
-FETCH_SIZE / WRITE_SIZE are in KiB.  MI355X_MICROARCH.md §HBM: on gfx950 FETCH_SIZE reports
-exactly half the bytes of a wide (16 B/lane) coalesced streaming read, other access widths are
-uncalibrated; both the raw and the doubled figure are recorded, the doubled one is reported."""
+    python tools/summarize_profile.py <prof dir> <tag> <workload> [docs]
+
+FETCH_SIZE / WRITE_SIZE are in KiB.  MI355X_MICROARCH.md §HBM: on gfx950 FETCH_SIZE reports half
+the bytes of a wide (16 B/lane) coalesced streaming read and is uncalibrated for other access
+widths.  profiles/fetch_calibration.json (tools/calibrate_fetch.py: micro-kernels reading a known
+byte count with this path's access patterns) holds the measured bytes-per-reported-byte factors;
+the factor of the pattern that dominates a kernel is applied and recorded next to the raw figure.
+Both counters are taken at the L2's fabric side: Infinity-Cache hits are included."""
 import csv
 import json
 import os
@@ -17,10 +22,23 @@ from collections import defaultdict
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
+SCAN = re.compile(r"(and_kernel|union_kernel_small|union_kernel|or_kernel|phrase_kernel)<([^>]*)>")
+
+
+def classify(name):
+    """-> (family, mode) with mode in {pruned, exhaustive, both} for the scan kernels, else None"""
+    m = SCAN.search(name)
+    if not m:
+        return None
+    fam, args = m.group(1), [a.strip() for a in m.group(2).split(",")]
+    if fam == "phrase_kernel":
+        return fam, "both"  # the reference prunes nothing before positions are read
+    return fam, ("pruned" if args[1] == "true" else "exhaustive")
+
 
 def main():
-    src = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "gpurun_out", "prof_r01")
-    tag = sys.argv[2] if len(sys.argv) > 2 else "r01_and2"
+    src = sys.argv[1]
+    tag = sys.argv[2]
     workload = sys.argv[3] if len(sys.argv) > 3 else "and2"
     docs = int(sys.argv[4]) if len(sys.argv) > 4 else 10_000_000
     out = os.path.join(ROOT, "profiles")
@@ -35,15 +53,27 @@ def main():
         with open(f) as fh:
             for r in csv.DictReader(fh):
                 per[r["Kernel_Name"]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    cmd = ""
+    if os.path.exists(os.path.join(src, "command.txt")):
+        cmd = open(os.path.join(src, "command.txt")).read().strip()
+    cal = {}
+    cpath = os.path.join(out, "fetch_calibration.json")
+    if os.path.exists(cpath):
+        cal = json.load(open(cpath))
+    # factor applied to FETCH_SIZE: the gather pattern of this path if calibrated, else the
+    # guide's x2 for wide streaming reads
+    factor = cal.get("factor_used", {}).get("value", 2.0)
+    factor_note = cal.get("factor_used", {}).get(
+        "note", "x2: MI355X_MICROARCH.md gfx950 correction for 16 B/lane streaming reads (uncalibrated "
+                "for this kernel's 1/8/16-byte gathers)")
     lines = ["# rocprofv3 PMC counters, average per launch (%s)" % tag, "",
-             "Command: `python bench.py --steps 3 --warmup 1 --no-cpu-baseline --latency-queries 0` "
-             "under `rocprofv3 --pmc ...` (one pass per counter group, tools/profile_bench.sh).", ""]
+             "Command: `%s` under `rocprofv3 --pmc ...` (one pass per counter group, "
+             "tools/profile_workload.sh)." % cmd, ""]
     traffic = {}
-    fresh = {}
     tpath = os.path.join(out, "traffic.json")
     if os.path.exists(tpath):
-        with open(tpath) as f:
-            traffic = json.load(f)
+        traffic = json.load(open(tpath))
+    fresh = {}
     for k in sorted(per):
         if "rocclr" in k:
             continue
@@ -51,31 +81,37 @@ def main():
         for c in sorted(per[k]):
             v = per[k][c]
             lines.append("| %s | %d | %.6g |" % (c, len(v), sum(v) / len(v)))
+        if "TCC_HIT_sum" in per[k] and "TCC_MISS_sum" in per[k]:
+            h = sum(per[k]["TCC_HIT_sum"])
+            ms = sum(per[k]["TCC_MISS_sum"])
+            if h + ms > 0:
+                lines.append("| L2 hit rate (TCC_HIT / (HIT + MISS)) | | %.3f |" % (h / (h + ms)))
         lines.append("")
-        m = re.search(r"and_kernel<\d+, (true|false), (true|false)>", k)
-        if m and "FETCH_SIZE" in per[k]:
-            mode = "pruned" if m.group(1) == "true" else "exhaustive"
+        cl = classify(k)
+        if cl and "FETCH_SIZE" in per[k]:
             fetch = sum(per[k]["FETCH_SIZE"]) / len(per[k]["FETCH_SIZE"]) * 1024
             wr = per[k].get("WRITE_SIZE", [0])
             write = sum(wr) / max(1, len(wr)) * 1024
-            key = "%s_%s_%d" % (workload, mode, docs)
-            if key not in fresh:  # the dense-only and the general instantiation add up
-                fresh[key] = {"fetch_bytes_raw": 0, "write_bytes_raw": 0}
-            fresh[key]["fetch_bytes_raw"] += int(fetch)
-            fresh[key]["write_bytes_raw"] += int(write)
+            for mode in (("pruned", "exhaustive") if cl[1] == "both" else (cl[1],)):
+                key = "%s_%s_%d" % (workload, mode, docs)
+                e = fresh.setdefault(key, {"fetch_bytes_raw": 0, "write_bytes_raw": 0, "kernels": []})
+                e["fetch_bytes_raw"] += int(fetch)  # the launch groups of one batch add up
+                e["write_bytes_raw"] += int(write)
+                e["kernels"].append(k)
     for key, v in fresh.items():
-        v["hbm_bytes_per_launch"] = 2 * v["fetch_bytes_raw"] + v["write_bytes_raw"]
-        v["note"] = ("rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), KiB*1024, summed over "
-                     "the batch's two and_kernel launches, FETCH doubled per the gfx950 correction in "
-                     "MI355X_MICROARCH.md; this counts the L2's fabric-side requests, Infinity Cache "
-                     "hits included (the index + tables fit the 256 MB cache)")
+        v["fetch_factor"] = factor
+        v["hbm_bytes_per_launch"] = int(factor * v["fetch_bytes_raw"] + v["write_bytes_raw"])
+        v["profile"] = tag
+        v["note"] = ("rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, %s), KiB*1024, summed over "
+                     "the batch's scan kernels; FETCH x %.2f (%s); fabric-side counters: Infinity-Cache "
+                     "hits are included" % (tag, factor, factor_note))
         traffic[key] = v
     with open(os.path.join(out, tag + "_pmc.md"), "w") as f:
         f.write("\n".join(lines) + "\n")
     with open(tpath, "w") as f:
         json.dump(traffic, f, indent=1, sort_keys=True)
-    print(open(os.path.join(out, tag + "_kernel_stats.csv")).read())
-    print(json.dumps(traffic, indent=1))
+    print(open(os.path.join(out, tag + "_kernel_stats.csv")).read()[:3000])
+    print(json.dumps({k: traffic[k] for k in fresh}, indent=1))
 
 
 if __name__ == "__main__":
