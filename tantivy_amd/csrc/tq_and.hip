@@ -36,15 +36,14 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_num_sgpr(80))) void and_k
   __shared__ AndLdsT<DENSE> L;  // one wavefront per workgroup: finished chunks free their slot at once
   const int lane = (int)__lane_id();
   if (blockIdx.x >= p.n_chunks) return;
-  const uint32_t chunk = sload(p.chunk_perm + blockIdx.x);
-  const uint32_t t_begin = sload(p.chunk_starts + chunk);
-  const uint32_t t_end = sload(p.chunk_starts + chunk + 1u);
+  const uint4 crec = sload(p.chunk_recs + blockIdx.x);
+  const uint32_t chunk = crec.w, t_begin = crec.x, t_end = crec.y;
 
   const TqdSegment seg = p.seg;
   const uint8_t *idx = seg.idx;
 
   // ---- per-query state (wave-uniform)
-  uint32_t q = uni(find_query(p.tile_starts, p.n_queries, t_begin));
+  uint32_t q = crec.z;
   uint32_t q_tile_start = 0, q_tile_end = 0;
   const TqdQuery *Q = nullptr;
   uint32_t nt = 0, tile_blocks = TQD_AND_TILE;

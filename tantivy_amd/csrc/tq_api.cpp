@@ -131,8 +131,9 @@ struct Options {
   int use_dpp = 1;
   int dense = 1;      // build bitmaps for dense lists at tq_term_prepare
   int dense_ratio = TQD_DENSE_RATIO;  // ... for lists with doc_freq >= max_doc / dense_ratio
-  int dense_budget_x = 4;  // ... while all bitmaps stay below this multiple of the segment's bytes
+  int dense_budget_x = 6;  // ... while bitmaps + doc matrix stay below this multiple of the segment's bytes
   int use_dense = 1;  // let the scan kernels use them
+  int docmat = 1;     // also build the doc-major matrix of the dense lists
   int or_windows = -1;  // OR: 1 = window-parallel kernel, 0 = candidate-driven kernel, -1 = auto
   int bound_slack_ppm = 0;  // block-max bounds are widened by (1 + ppm * 1e-6), see block_max_score
                         // (windows for exhaustive scans, candidates when pruning)
@@ -159,6 +160,8 @@ struct tq_segment {
   uint8_t record_option = 0;
   std::vector<uint8_t> h_idx, h_pos;
   uint8_t *d_idx = nullptr, *d_pos = nullptr, *d_fn = nullptr, *d_alive = nullptr;
+  uint64_t *d_docmat = nullptr;  // doc-major matrix of the dense lists (TqdSegment::docmat)
+  uint32_t n_mat_slots = 0;
   TqdSegment dseg{};
   std::vector<TermHost> terms;
   std::vector<TqdTerm> h_dterms;
@@ -188,6 +191,9 @@ struct tq_segment {
   bool stage_in_flight = false;
   unsigned long long *d_match_counter = nullptr;
   Options opt;
+  size_t dense_budget() const {
+    return (size_t)opt.dense_budget_x * (h_idx.size() + h_pos.size() + max_doc);
+  }
   tq_batch_stats stats{};
   bool stats_pending = false;
 };
@@ -228,6 +234,25 @@ int build_dense(tq_segment *s, uint32_t handle) {
   hipError_t e = tqk_launch_decode_list(s->dseg, s->d_terms, handle, t.n_blocks, dd, dt,
                                         s->opt.use_dpp != 0, s->stream);
   if (e != hipSuccess) return fail(TQ_ERR_HIP, "decode launch: %s", hipGetErrorString(e));
+  // the list's column of the doc matrix (first TQD_MAT_SLOTS dense lists of the segment, while
+  // the matrix fits the same memory budget as the bitmaps)
+  if (s->n_mat_slots < TQD_MAT_SLOTS && s->opt.docmat) {
+    const size_t mat_bytes = (size_t)s->max_doc * sizeof(uint64_t);
+    if (!s->d_docmat && s->dense_bytes_total + mat_bytes <= s->dense_budget()) {
+      HIP_TRY(hipMalloc((void **)&s->d_docmat, mat_bytes + PAD));
+      HIP_TRY(hipMemsetAsync((uint8_t *)s->d_docmat + mat_bytes, 0, PAD, s->stream));
+      e = tqk_launch_docmat_init(s->d_docmat, s->d_fn, s->dseg.const_fieldnorm_id, s->max_doc, s->stream);
+      if (e != hipSuccess) return fail(TQ_ERR_HIP, "docmat init: %s", hipGetErrorString(e));
+      s->dense_bytes_total += mat_bytes;
+      s->dseg.docmat = s->d_docmat;
+    }
+    if (s->d_docmat) {
+      const uint32_t slot = s->n_mat_slots++;
+      e = tqk_launch_docmat_set(s->d_docmat, dd, t.doc_freq, slot, s->stream);
+      if (e != hipSuccess) return fail(TQ_ERR_HIP, "docmat set: %s", hipGetErrorString(e));
+      s->h_dterms[handle].has_freq |= (slot + 1u) << 8;
+    }
+  }
   std::vector<uint32_t> docs(t.doc_freq);
   HIP_TRY(hipMemcpyAsync(docs.data(), dd, bytes, hipMemcpyDeviceToHost, s->stream));
   HIP_TRY(hipStreamSynchronize(s->stream));
@@ -367,6 +392,7 @@ void tq_segment_free(tq_segment *s) {
   if (s->d_pos) (void)hipFree(s->d_pos);
   if (s->d_fn) (void)hipFree(s->d_fn);
   if (s->d_alive) (void)hipFree(s->d_alive);
+  if (s->d_docmat) (void)hipFree(s->d_docmat);
   if (s->d_match_counter) (void)hipFree(s->d_match_counter);
   s->d_stage.release();
   s->d_partials.release();
@@ -616,7 +642,7 @@ int tq_term_prepare(tq_segment *s, uint64_t postings_off, uint32_t postings_len,
   // 0.25 B/doc per bitmap: worth it for lists whose 128-doc blocks span few docs, and only while
   // the bitmaps together stay within a fixed multiple of the segment's own size
   const size_t dense_bytes = (((size_t)s->max_doc + 31) / 32 + 1) * sizeof(uint2);
-  const size_t budget = (size_t)s->opt.dense_budget_x * (s->h_idx.size() + s->h_pos.size() + s->max_doc);
+  const size_t budget = s->dense_budget();
   if (s->opt.dense && s->max_doc >= 4096u &&
       (uint64_t)doc_freq * (uint64_t)s->opt.dense_ratio >= s->max_doc &&
       s->dense_bytes_total + dense_bytes <= budget) {
@@ -658,6 +684,8 @@ struct Group {
   std::vector<uint32_t> tile_starts;
   std::vector<uint32_t> chunk_starts;
   std::vector<uint32_t> chunk_perm;   // launch order -> chunk (doc-range slices, see planner)
+  std::vector<uint32_t> chunk_query;  // query of the chunk's first tile
+  std::vector<uint4> chunk_recs;      // launch order: {first tile, end tile, first query, chunk}
   std::vector<uint32_t> chunk_slice;
   std::vector<uint32_t> tile_cost;  // per query, cost units per tile
   uint32_t total_tiles = 0, n_chunks = 0, max_k = 1;
@@ -740,6 +768,7 @@ int build_group_chunks(Group &g, bool or_windows) {
                                                   (total_cost + n_target - 1) / n_target);
   g.chunk_starts.clear();
   g.chunk_slice.clear();
+  g.chunk_query.clear();
   uint64_t cur_cost = 0;
   bool open_chunk = false;
   const uint32_t per_chunk = or_win ? TQD_WAVES_PER_WG : 1u;
@@ -755,6 +784,7 @@ int build_group_chunks(Group &g, bool or_windows) {
       const uint32_t run_end = std::max<uint32_t>(t + 1u, cost_run_end(i, t));
       if (!open_chunk || cur_cost >= cost_target) {
         g.chunk_starts.push_back(dq.tile_start + t);
+        g.chunk_query.push_back((uint32_t)i);
         // which part of the doc-id space the chunk starts in (lists are spread over it)
         if (g.mode == TQ_MODE_OR && !or_win) {
           // candidate-driven OR: high-weight lists first (their matches raise the threshold
@@ -826,6 +856,11 @@ int build_group_chunks(Group &g, bool or_windows) {
         }
       }
     }
+  }
+  g.chunk_recs.resize(g.n_chunks);
+  for (uint32_t b = 0; b < g.n_chunks; ++b) {
+    const uint32_t c = or_win ? b : g.chunk_perm[b];  // the window kernel runs in chunk order
+    g.chunk_recs[b] = make_uint4(g.chunk_starts[c], g.chunk_starts[c + 1], g.chunk_query[c], c);
   }
   return TQ_OK;
 }
@@ -1237,10 +1272,7 @@ int search_batch_impl(tq_segment *s, const tq_query *queries, uint32_t n_queries
     stage += g.out_index.size() * sizeof(uint32_t);
     stage = (stage + 15) & ~(size_t)15;
     g.o_chunks = stage;
-    stage += g.chunk_starts.size() * sizeof(uint32_t);
-    stage = (stage + 15) & ~(size_t)15;
-    g.o_perm = stage;
-    stage += g.chunk_perm.size() * sizeof(uint32_t);
+    stage += g.chunk_recs.size() * sizeof(uint4);
     stage = (stage + 15) & ~(size_t)15;
     g.o_sinks = stage;
     stage += sizeof(TqkSinks);
@@ -1261,8 +1293,7 @@ int search_batch_impl(tq_segment *s, const tq_query *queries, uint32_t n_queries
     memcpy(hs + g.o_queries, g.queries.data(), g.queries.size() * sizeof(TqdQuery));
     memcpy(hs + g.o_tiles, g.tile_starts.data(), g.tile_starts.size() * sizeof(uint32_t));
     memcpy(hs + g.o_outidx, g.out_index.data(), g.out_index.size() * sizeof(uint32_t));
-    memcpy(hs + g.o_chunks, g.chunk_starts.data(), g.chunk_starts.size() * sizeof(uint32_t));
-    memcpy(hs + g.o_perm, g.chunk_perm.data(), g.chunk_perm.size() * sizeof(uint32_t));
+    memcpy(hs + g.o_chunks, g.chunk_recs.data(), g.chunk_recs.size() * sizeof(uint4));
   }
   for (int gi = 0; gi < kGroups; ++gi) {
     Group &g = groups[gi];
@@ -1317,6 +1348,7 @@ int search_batch_impl(tq_segment *s, const tq_query *queries, uint32_t n_queries
     hipStream_t gst = (fork && gi != 0) ? s->side_stream : st;
     TqkScanParams p{};
     p.seg = s->dseg;
+    if (!s->opt.use_dense) p.seg.docmat = nullptr;
     p.terms = s->d_terms;
     p.queries = (const TqdQuery *)(ds + g.o_queries);
     p.tile_starts = (const uint32_t *)(ds + g.o_tiles);
@@ -1325,8 +1357,7 @@ int search_batch_impl(tq_segment *s, const tq_query *queries, uint32_t n_queries
     p.thr_slots = (uint32_t *)s->d_thr.p;
     p.n_queries = (uint32_t)g.queries.size();
     p.total_tiles = g.total_tiles;
-    p.chunk_starts = (const uint32_t *)(ds + g.o_chunks);
-    p.chunk_perm = (const uint32_t *)(ds + g.o_perm);
+    p.chunk_recs = (const uint4 *)(ds + g.o_chunks);
     p.n_chunks = g.n_chunks;
     p.exhaustive = (uint32_t)opt_exhaustive;
     p.use_dense = (uint32_t)s->opt.use_dense;
@@ -1600,6 +1631,8 @@ int tq_set_option(tq_segment *s, const char *name, int64_t value) {
     s->opt.bound_slack_ppm = (int)value;
   else if (!strcmp(name, "dense"))  // affects terms prepared afterwards
     s->opt.dense = value != 0;
+  else if (!strcmp(name, "docmat"))  // affects terms prepared afterwards
+    s->opt.docmat = value != 0;
   else
     return fail(TQ_ERR_INVALID, "unknown option '%s'", name);
   return TQ_OK;

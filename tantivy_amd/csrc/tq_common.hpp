@@ -140,6 +140,7 @@ struct TermRef {
   uint32_t n_tail;
   uint32_t has_freq;
   uint32_t shift;
+  uint32_t mat_slot;  // column of the list in TqdSegment::docmat, or >= TQD_MAT_SLOTS
 };
 __device__ __forceinline__ TermRef load_term(const TqdTerm *terms, uint32_t handle) {
   const TqdTermHead h = sload(reinterpret_cast<const TqdTermHead *>(terms + handle));
@@ -152,7 +153,8 @@ __device__ __forceinline__ TermRef load_term(const TqdTerm *terms, uint32_t hand
   r.payload_base = h.payload_base;
   r.n_blocks = h.n_blocks;
   r.n_tail = h.n_tail;
-  r.has_freq = h.has_freq;
+  r.has_freq = h.has_freq & 1u;
+  r.mat_slot = ((h.has_freq >> 8) & 0xFFu) - 1u;  // 0 => 0xFFFFFFFF
   r.shift = h.coarse_shift;
   return r;
 }
@@ -460,6 +462,20 @@ template <int S>
 __device__ __forceinline__ uint32_t kth_largest_multi(const uint32_t (&v)[S], uint32_t k) {
   uint32_t ans = 0;
   for (int bit = 31; bit >= 0; --bit) {
+    const uint32_t trial = ans | (1u << bit);
+    uint32_t c = 0;
+#pragma unroll
+    for (int r = 0; r < S; ++r) c += (uint32_t)__popcll(__ballot(v[r] >= trial));
+    if (c >= k) ans = trial;
+  }
+  return ans;
+}
+// The same on the upper 16 bits only (first S registers of v): the result, low bits zero, still
+// has at least k values at or above it — a slightly lower, equally valid bound at half the steps.
+template <int S>
+__device__ __forceinline__ uint32_t kth_largest_hi16(const uint32_t (&v)[4], uint32_t k) {
+  uint32_t ans = 0;
+  for (int bit = 31; bit >= 16; --bit) {
     const uint32_t trial = ans | (1u << bit);
     uint32_t c = 0;
 #pragma unroll

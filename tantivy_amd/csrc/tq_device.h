@@ -13,6 +13,7 @@
 #define TQD_DENSE_RATIO 128   // default: lists with doc_freq >= max_doc/128 also get a bitmap + rank directory
 #define TQD_THR_SLOTS 64      // shared threshold slots per query (pruned mode)
 #define TQD_OR_WINDOW 4096    // docs per OR tile (one workgroup)
+#define TQD_MAT_SLOTS 56      // dense lists per segment with a column in the doc matrix
 
 // A posting list on the device.  The skip list of src/postings/skip.rs:205-253 is unrolled from
 // its sequential form (running byte / position offsets made absolute) into structure-of-arrays
@@ -34,7 +35,7 @@ struct TqdTermHead {  // what every kernel needs: fetched with scalar loads
   const uint32_t *tail_tfs;   // n_tail
   uint64_t payload_base;      // absolute offset (inside the .idx sub-file) of block 0's payload
   uint32_t n_blocks, n_tail;
-  uint32_t has_freq;          // 0 => every tf reads as 1
+  uint32_t has_freq;          // bit 0: 0 => every tf reads as 1; bits 8..15: doc-matrix slot + 1 (0 = none)
   uint32_t coarse_shift;
 };
 struct TqdTerm : TqdTermHead {
@@ -83,6 +84,12 @@ struct TqdSegment {
   const uint8_t *pos;        // .pos sub-file or null
   const uint8_t *fieldnorm;  // max_doc bytes or null
   const uint8_t *alive;      // AliveBitSet bits (bit d of byte d>>3) or null = no deletes
+  // doc-major matrix of the segment's dense lists, or null: docmat[d] = fieldnorm id of doc d
+  // (bits 0..7) | bit (8 + slot) set iff d is in the dense list that owns matrix slot `slot`
+  // (TQD_MAT_SLOTS lists per segment).  ONE 8-byte gather gives a candidate's BM25 norm and its
+  // membership in every dense list of the query — the scan kernels are bound by the number of
+  // divergent gathers, not by bytes.  Derived data, built at tq_term_prepare like the bitmaps.
+  const uint64_t *docmat;
   uint32_t max_doc;
   uint32_t const_fieldnorm_id;
   uint32_t min_fieldnorm_id;  // smallest fieldnorm id present (lower bound of every doc's norm)

@@ -20,8 +20,10 @@ struct TqkScanParams {
   const TqdTerm *terms;
   const TqdQuery *queries;      // the launch group's queries, contiguous
   const uint32_t *tile_starts;  // n_queries + 1, non-decreasing
-  const uint32_t *chunk_starts; // n_chunks + 1: first tile of every chunk
-  const uint32_t *chunk_perm;   // n_chunks: launch index -> chunk
+  // one record per chunk, IN LAUNCH ORDER: {first tile, end tile, query of the first tile, chunk
+  // id} — one 16-byte scalar load where a permutation lookup, two neighbouring starts and a
+  // binary search over the queries' tile ranges (~14 dependent loads) used to be
+  const uint4 *chunk_recs;
   const float *caches;          // n_caches x 256
   const TqkSinks *sinks;        // where results go (read at flush time only)
   uint32_t *thr_slots;          // [n_thr_rows][TQD_THR_SLOTS] shared thresholds (pruned mode)
@@ -71,6 +73,11 @@ hipError_t tqk_launch_decode_list(const TqdSegment &seg, const TqdTerm *terms, u
 hipError_t tqk_launch_decode_positions(const TqdSegment &seg, const TqdTerm *terms,
                                        uint32_t handle, uint32_t *out, uint64_t n, hipStream_t st);
 hipError_t tqk_launch_merge_segments(const TqkSegMergeParams &p, hipStream_t st);
+// doc matrix (TqdSegment::docmat): fill with the fieldnorm ids / set one list's column
+hipError_t tqk_launch_docmat_init(uint64_t *mat, const uint8_t *fieldnorm, uint32_t const_id,
+                                  uint32_t max_doc, hipStream_t st);
+hipError_t tqk_launch_docmat_set(uint64_t *mat, const uint32_t *docs, uint32_t n, uint32_t slot,
+                                 hipStream_t st);
 
 // ---- shared with tq_encode.hip: the C ABI's error slot and context checks live in tq_api.cpp
 struct tq_ctx;

@@ -148,9 +148,33 @@ __global__ __launch_bounds__(64) void merge_segments_kernel(TqkSegMergeParams p)
   if (lane == 0) p.out_counts[q] = got;
 }
 
+// =================================================================== doc matrix
+__global__ void docmat_init_kernel(uint64_t *mat, const uint8_t *fieldnorm, uint32_t const_id,
+                                   uint32_t max_doc) {
+  const uint32_t d = blockIdx.x * blockDim.x + threadIdx.x;
+  if (d < max_doc) mat[d] = fieldnorm ? (uint64_t)fieldnorm[d] : (uint64_t)const_id;
+}
+__global__ void docmat_set_kernel(uint64_t *mat, const uint32_t *docs, uint32_t n, uint32_t slot) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) atomicOr((unsigned long long *)(mat + docs[i]), 1ull << (8u + slot));
+}
+
 }  // namespace
 
 // =================================================================== launch wrappers
+hipError_t tqk_launch_docmat_init(uint64_t *mat, const uint8_t *fieldnorm, uint32_t const_id,
+                                  uint32_t max_doc, hipStream_t st) {
+  if (max_doc == 0) return hipSuccess;
+  hipLaunchKernelGGL(docmat_init_kernel, dim3((max_doc + 255) / 256), dim3(256), 0, st, mat,
+                     fieldnorm, const_id, max_doc);
+  return hipGetLastError();
+}
+hipError_t tqk_launch_docmat_set(uint64_t *mat, const uint32_t *docs, uint32_t n, uint32_t slot,
+                                 hipStream_t st) {
+  if (n == 0) return hipSuccess;
+  hipLaunchKernelGGL(docmat_set_kernel, dim3((n + 255) / 256), dim3(256), 0, st, mat, docs, n, slot);
+  return hipGetLastError();
+}
 hipError_t tqk_launch_merge(const TqkMergeParams &p, int kpl, hipStream_t st) {
   if (p.n_queries == 0) return hipSuccess;
   const dim3 grid(p.n_queries), block(64);

@@ -46,13 +46,12 @@ __global__ __launch_bounds__(TQD_WAVES_PER_WG * 64) void or_kernel(TqkScanParams
   const uint32_t wave = uni(threadIdx.x >> 6);
   const uint32_t tid = threadIdx.x;
   if (blockIdx.x >= p.n_chunks) return;
-  const uint32_t chunk = blockIdx.x;
-  const uint32_t t_begin = sload(p.chunk_starts + chunk);
-  const uint32_t t_end = sload(p.chunk_starts + chunk + 1u);
+  const uint4 crec = sload(p.chunk_recs + blockIdx.x);
+  const uint32_t chunk = crec.w, t_begin = crec.x, t_end = crec.y;
 
   const TqdSegment seg = p.seg;
   const uint8_t *idx = seg.idx;
-  uint32_t q = uni(find_query(p.tile_starts, p.n_queries, t_begin));
+  uint32_t q = crec.z;
   uint32_t q_tile_start = 0, q_tile_end = 0;
   const TqdQuery *Q = nullptr;
   uint32_t nt = 0, dense_mask = 0, n_slot_rows = 0;
@@ -310,26 +309,33 @@ __global__ __launch_bounds__(TQD_WAVES_PER_WG * 64) void or_kernel(TqkScanParams
 //     Dense lists are probed through their bitmap, the others by seek_block + find_in_blocks.
 // The sum runs over the lists holding the doc in ascending list index, whichever mode and
 // threshold history: results are bit-identical across modes and runs.  One wavefront per chunk.
+template <bool BOOL>
 struct UnionLds {  // per wavefront
   uint32_t pay[516];
   uint32_t q1_doc[191], q1_tf[191];
   float cache[256];
   float suffix[TQD_MAX_TERMS + 1];
+  // pure unions: survivors of the membership stage (doc, tf, membership bits | fieldnorm id << 16,
+  // what the lists after the leader can still add) and per-query tables read by broadcast
+  uint32_t q2_doc[BOOL ? 1 : 127], q2_tf[BOOL ? 1 : 127], q2_mx[BOOL ? 1 : 127];
+  float q2_rest[BOOL ? 1 : 127];
+  float wgt[TQD_MAX_TERMS];
+  const uint2 *dptr[TQD_MAX_TERMS];
+  uint32_t mshift[TQD_MAX_TERMS];  // bit of the list's column in a doc-matrix word
 };
 
 template <int KPL, bool PRUNE, bool BOOL>
 __device__ __forceinline__ void union_body(const TqkScanParams &p) {
   constexpr bool USE_DPP = true;
-  __shared__ UnionLds L;
+  __shared__ UnionLds<BOOL> L;
   const int lane = (int)__lane_id();
   if (blockIdx.x >= p.n_chunks) return;
-  const uint32_t chunk = sload(p.chunk_perm + blockIdx.x);
-  const uint32_t t_begin = sload(p.chunk_starts + chunk);
-  const uint32_t t_end = sload(p.chunk_starts + chunk + 1u);
+  const uint4 crec = sload(p.chunk_recs + blockIdx.x);
+  const uint32_t chunk = crec.w, t_begin = crec.x, t_end = crec.y;
   const TqdSegment seg = p.seg;
   const uint8_t *idx = seg.idx;
 
-  uint32_t q = uni(find_query(p.tile_starts, p.n_queries, t_begin));
+  uint32_t q = crec.z;
   uint32_t q_tile_start = 0, q_tile_end = 0;
   const TqdQuery *Q = nullptr;
   uint32_t nt = 0, tile_blocks = TQD_AND_TILE, n_slot_rows = 1;
@@ -341,12 +347,28 @@ __device__ __forceinline__ void union_body(const TqkScanParams &p) {
   float min_norm = 0.0f;
   TopK<KPL> tk;
   uint32_t n_matches = 0, n_q = 0;  // docs scored: whole chunk / current query
-  uint32_t q1n = 0;
+  uint32_t q1n = 0, q2n = 0;
+  uint32_t dense_mask = 0, sparse_mask = 0;  // pure unions: lists with / without a bitmap
+  uint32_t mat_mask = 0;                     // ... with a column in the doc matrix
+  uint32_t slots_sum = 0;  // checksum of the threshold slots at the last radix select
+  float slack_abs = 0.0f;
   // leader of the current tile
   uint32_t li = 0, li_end = 0;
   bool dead = false;
   TermRef lead{};
   float w_lead = 0.0f;
+  // PROFILING (TQ_DEBUG bits 16..19 = phase): wave cycles spent in one phase, summed into the
+  // match counter.  1 chunk start + query setup + flush, 2 tile bookkeeping + threshold,
+  // 3 pre-filter, 4 stage A, 5 stage B, 6 stage C
+  const uint32_t tphase = (p.debug >> 16) & 15u;
+  uint64_t tacc = 0, tlast = tphase ? __builtin_readcyclecounter() : 0ull;
+  auto tick = [&](uint32_t done) __attribute__((always_inline)) {
+    if (tphase) {
+      const uint64_t now = __builtin_readcyclecounter();
+      if (done == tphase) tacc += now - tlast;
+      tlast = now;
+    }
+  };
 
   auto setup_query = [&]() __attribute__((always_inline)) {
     q_tile_start = sload(p.tile_starts + q);
@@ -385,11 +407,28 @@ __device__ __forceinline__ void union_body(const TqkScanParams &p) {
       suf += sload(&Q->weight[m]);
       if (lane == 0) L.suffix[m] = suf;
     }
+    if constexpr (!BOOL) {  // per-list tables of the membership stage, one list per lane
+      const uint2 *dp = nullptr;
+      uint32_t slot = 0xFFFFFFFFu;
+      if ((uint32_t)lane < nt) {
+        const TqdTerm *tt = p.terms + Q->term[lane];
+        dp = p.use_dense ? tt->dense : nullptr;
+        if (dp && seg.docmat) slot = ((tt->has_freq >> 8) & 0xFFu) - 1u;
+        L.dptr[lane] = dp;
+        L.wgt[lane] = Q->weight[lane];
+        L.mshift[lane] = 8u + slot;
+      }
+      dense_mask = (uint32_t)__ballot(dp != nullptr);
+      mat_mask = (uint32_t)__ballot(slot < TQD_MAT_SLOTS);
+      sparse_mask = ((1u << nt) - 1u) & ~dense_mask;
+      slack_abs = suf * 4.0e-6f;  // bounds summed by add-then-subtract: absolute slack
+    }
     wave_mem_fence();
     min_norm = sload(p.caches + (size_t)ci * 256u +
                      (seg.fieldnorm ? seg.min_fieldnorm_id : seg.const_fieldnorm_id));
     thr = 0;
     thr_g = 0;
+    slots_sum = 0;
     li = 0xFFFFFFFFu;
     li_end = 0;
     dead = false;
@@ -438,9 +477,15 @@ __device__ __forceinline__ void union_body(const TqkScanParams &p) {
       if (m >= nt) m -= nt;
       const uint32_t role = BOOL ? (roles >> (2u * m)) & 3u : TQD_ROLE_SHOULD;
       const float w = sload(&Q->weight[m]);
-      // what the lists m.. can still add (lists below li add nothing: found there = dropped)
-      if (prune && m > li && alive)
-        alive = sortable((((s + oth) + (csum + opt)) + L.suffix[m]) * 1.000001f) >= thr;
+      // what the lists m.. can still add.  Lists below li add nothing (found there = dropped:
+      // that list's tile scores the doc), so once the walk wraps around to them the score is
+      // final unless the doc is dropped: below the threshold it is dead either way, before
+      // the (sparse, expensive) ownership probes
+      if (prune && alive) {
+        const float rest = m > li ? L.suffix[m] : 0.0f;
+        if (m > li || !BOOL)
+          alive = sortable((((s + oth) + (csum + opt)) + rest) * 1.000001f) >= thr;
+      }
       if (!__ballot(alive)) break;
       TermRef tr = load_term(p.terms, sload(&Q->term[m]));
       if (!p.use_dense) tr.dense = nullptr;
@@ -511,7 +556,7 @@ __device__ __forceinline__ void union_body(const TqkScanParams &p) {
     if (alive) alive = doc_is_alive(seg, doc);
     const uint64_t hit = __ballot(alive);
     if (hit) {
-      if (!(p.debug & 224u)) n_matches += (uint32_t)__popcll(hit);  // COUNTERS
+      if (!(p.debug & 480u)) n_matches += (uint32_t)__popcll(hit);  // COUNTERS
       n_q += (uint32_t)__popcll(hit);
       const uint64_t key = alive ? make_key(s, doc) : 0ull;
       if (slots) {
@@ -527,11 +572,195 @@ __device__ __forceinline__ void union_body(const TqkScanParams &p) {
     }
   };
 
+  // ================================================================ pure unions: two stages
+  // C (64 survivors): the exact score.  Dense lists after the leader that hold the doc: rank
+  // from the bitmap word -> block record -> tf; lists without a bitmap: seek + block search;
+  // then the ownership probes into the sparse lists BEFORE the leader (found = dropped).  The
+  // sum runs leader first, then ascending list index: the same bits as every other mode.
+  auto stageC = [&](uint32_t n) __attribute__((always_inline)) {
+    tick(5u);
+    const uint32_t base = q2n - n;
+    q2n = base;
+    if (p.debug & 128u) n_matches += n;  // COUNTERS
+    bool alive = (uint32_t)lane < n;
+    uint32_t doc = 0, tf = 0, mx = 0;
+    float rest = 0.0f;
+    if (alive) {
+      doc = L.q2_doc[base + lane];
+      tf = L.q2_tf[base + lane];
+      mx = L.q2_mx[base + lane];
+      rest = L.q2_rest[base + lane];
+    }
+    const float norm = L.cache[mx >> 16];
+    float s = bm25(w_lead, norm, tf);
+    for (uint32_t mm = 1; mm < nt; ++mm) {
+      uint32_t m = li + mm;
+      if (m >= nt) m -= nt;
+      const bool after = m > li;
+      const bool is_dense = (dense_mask >> m) & 1u;
+      if (!after && is_dense) continue;  // ownership by a dense list was settled in stage B
+      const bool mine = (mx >> m) & 1u;
+      if (is_dense) {
+        if (__ballot(alive && mine)) {
+          const TermRef tr = load_term(p.terms, sload(&Q->term[m]));
+          const float w = L.wgt[m];
+          if (alive && mine) {
+            const uint2 wd = tr.dense[doc >> 5];
+            const uint32_t pi = wd.y + (uint32_t)__popc(wd.x & ((1u << (doc & 31u)) - 1u));
+            const uint4 r = tr.rec[pi >> 7];
+            s = s + bm25(w, norm, block_tf_at(idx, tr, make_uint2(r.y, r.z), pi & 127u));
+            rest -= w;
+          }
+        }
+        continue;
+      }
+      // no bitmap: the exact (expensive) probe, only for candidates that can still make it
+      if (prune && alive) {
+        const float r0 = after ? (rest > 0.0f ? rest : 0.0f) : 0.0f;
+        alive = sortable((s + r0) * 1.000002f + slack_abs) >= thr;
+      }
+      if (!__ballot(alive)) break;
+      const TermRef tr = load_term(p.terms, sload(&Q->term[m]));
+      bool cand = alive;
+      uint32_t jb = 0;
+      if (cand) {
+        jb = seek_block(tr, doc);
+        cand = jb < tr.n_blocks;
+      }
+      uint32_t unused;
+      const uint32_t at = lookup_in_blocks<false>(idx, tr, jb, doc, cand, L.pay, lane, &unused);
+      const bool found = cand && at != NOT_FOUND;
+      if (after) {
+        const float w = L.wgt[m];
+        if (found) {
+          const uint4 r = tr.rec[jb];
+          s = s + bm25(w, norm, block_tf_at(idx, tr, make_uint2(r.y, r.z), at));
+        }
+        rest -= w;
+      } else if (found) {
+        alive = false;  // list m's tile scores this doc
+      }
+    }
+    if (alive) alive = doc_is_alive(seg, doc);
+    const uint64_t hit = __ballot(alive);
+    if (hit) {
+      if (!(p.debug & 480u)) n_matches += (uint32_t)__popcll(hit);  // COUNTERS
+      n_q += (uint32_t)__popcll(hit);
+      const uint64_t key = alive ? make_key(s, doc) : 0ull;
+      if (slots) {
+        const uint32_t sb = (uint32_t)(key >> 32);
+        const uint32_t h = (doc * 0x9E3779B1u) >> (n_slot_rows == 1u ? 26 : 24);
+        if (alive && sb > thr_g) atomicMax(slots + h, sb);
+      }
+      tk.offer(alive, key, lane);
+      if (prune) {
+        const uint32_t own = (uint32_t)(tk.thr >> 32);
+        if (own > thr) thr = own;
+      }
+    }
+    tick(6u);
+  };
+  // B (64 candidates of leader li): membership only.  One fieldnorm byte and one bitmap word per
+  // dense list, all independent gathers; a doc held by a list before the leader belongs to that
+  // list's tile; the others keep "leader score + the weights of the later lists that hold the
+  // doc (bitmap) or may hold it (no bitmap)" as their bound (block_wand_union.rs:16-80 with the
+  // pivot test made per doc) and most of them end here, before any tf is fetched.
+  auto stageB_pure = [&](uint32_t n) __attribute__((always_inline)) {
+    tick(4u);
+    const uint32_t base = q1n - n;
+    q1n = base;
+    if (p.debug & 64u) n_matches += n;  // COUNTERS
+    bool alive = (uint32_t)lane < n;
+    uint32_t doc = 0, tf = 0;
+    if (alive) {
+      doc = L.q1_doc[base + lane];
+      tf = L.q1_tf[base + lane];
+    }
+    uint32_t nid = 0, mask = 0;
+    uint32_t dm = dense_mask & ~(1u << li);
+    if (seg.docmat) {  // one gather: the fieldnorm id and the membership in every matrix list
+      const uint64_t mw = alive ? seg.docmat[doc] : 0ull;
+      nid = (uint32_t)mw & 0xFFu;
+      uint32_t mm = mat_mask & ~(1u << li);
+      dm &= ~mat_mask;
+      while (mm) {
+        const uint32_t m = (uint32_t)__builtin_ctz(mm);
+        mm &= mm - 1u;
+        mask |= ((uint32_t)(mw >> L.mshift[m]) & 1u) << m;
+      }
+    } else if (alive) {
+      nid = fieldnorm_id(seg, doc);
+    }
+    const uint32_t word = doc >> 5, bit = doc & 31u;
+    while (dm) {  // four lists per round: the gathers of a round are in flight together
+      uint32_t ms[4] = {0u, 0u, 0u, 0u}, bits[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        if (dm) {
+          ms[u] = (uint32_t)__builtin_ctz(dm);
+          dm &= dm - 1u;
+          const uint2 *dp = L.dptr[ms[u]];
+          if (alive) bits[u] = dp[word].x;
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) mask |= ((bits[u] >> bit) & 1u) << ms[u];
+    }
+    if (mask & ((1u << li) - 1u)) alive = false;  // an earlier list's tile scores this doc
+    float rest = 0.0f;
+    {
+      const uint32_t may = mask | sparse_mask;
+      for (uint32_t m = nt; m-- > li + 1u;) rest += ((may >> m) & 1u) ? L.wgt[m] : 0.0f;
+    }
+    if (prune && alive) {
+      const float s = bm25(w_lead, L.cache[nid], tf);
+      if (p.debug & 256u)  // COUNTERS: the bound without membership knowledge
+        n_matches += (uint32_t)__popcll(__ballot(sortable((s + L.suffix[li + 1u]) * 1.000002f + slack_abs) >= thr));
+      alive = sortable((s + rest) * 1.000002f + slack_abs) >= thr;
+    }
+    if (p.debug & 2048u) alive = false;  // ABLATION: no stage C
+    const uint64_t mk = __ballot(alive);
+    if (mk) {
+      const uint32_t pos = q2n + mbcnt64(mk);
+      wave_mem_fence();
+      if (alive) {
+        L.q2_doc[pos] = doc;
+        L.q2_tf[pos] = tf;
+        L.q2_mx[pos] = mask | (nid << 16);
+        L.q2_rest[pos] = rest;
+      }
+      wave_mem_fence();
+      q2n += (uint32_t)__popcll(mk);
+    }
+    tick(5u);
+  };
+  auto step64 = [&]() __attribute__((always_inline)) {  // q1 holds >= 64 candidates
+    if constexpr (BOOL) {
+      stageB(64u);
+    } else {
+      stageB_pure(64u);
+      while (q2n >= 64u) stageC(64u);
+    }
+  };
+  auto drain = [&]() __attribute__((always_inline)) {
+    if constexpr (BOOL) {
+      while (q1n) stageB(q1n < 64u ? q1n : 64u);
+    } else {
+      while (q1n) {
+        stageB_pure(q1n < 64u ? q1n : 64u);
+        while (q2n >= 64u) stageC(64u);
+      }
+      while (q2n) stageC(q2n < 64u ? q2n : 64u);
+    }
+  };
+
   setup_query();
+  tick(1u);
   for (uint32_t t = t_begin; t < t_end; ++t) {
+    tick(4u);
     while (t >= q_tile_end) {
       if (q_tile_end > q_tile_start && q_tile_end > t_begin) {
-        while (q1n) stageB(q1n < 64u ? q1n : 64u);
+        drain();
         const uint32_t part = sload(&Q->part_start) + (chunk - sload(&Q->chunk_first));
         flush_partial<KPL>(tk, sload(&p.sinks->partials), part, lane);
         if (lane == 0 && n_q) atomicAdd(sload(&p.sinks->query_matches) + sload(sload(&p.sinks->out_index) + q), n_q);
@@ -539,6 +768,7 @@ __device__ __forceinline__ void union_body(const TqkScanParams &p) {
       }
       ++q;
       setup_query();
+      tick(1u);
     }
     // ---- which list leads this tile (tiles of a chunk come in order: advance, never search)
     if (dead) {  // lists li.. are non-essential for good (the threshold only rises): nothing
@@ -555,12 +785,15 @@ __device__ __forceinline__ void union_body(const TqkScanParams &p) {
       new_leader = true;
     }
     if (new_leader) {
-      while (q1n) stageB(q1n < 64u ? q1n : 64u);  // the queue belongs to the previous leader
+      drain();  // the queue belongs to the previous leader
       li = nli;
       lead = load_term(p.terms, sload(&Q->term[li]));
       w_lead = sload(&Q->weight[li]);
     }
-    // threshold: on a new leader and every 8th tile
+    // threshold: on a new leader and every 8th tile.  The radix select over the slots (the bulk of
+    // this kernel's scalar work when it ran at every refresh) only runs when the slots changed
+    // since the wave last looked (checksum), and on the upper 16 bits only: any v with
+    // |{slots >= v}| >= k is a valid bound, the low bits of the k-th largest cost 0.8 % of it.
     if (slots && (new_leader || (tl & 7u) == 0u)) {
       uint32_t sv[4] = {0u, 0u, 0u, 0u};
       sv[0] = __hip_atomic_load(slots + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -568,19 +801,31 @@ __device__ __forceinline__ void union_body(const TqkScanParams &p) {
 #pragma unroll
         for (int r = 1; r < 4; ++r)
           sv[r] = __hip_atomic_load(slots + 64 * r + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        thr_g = kth_largest_multi<4>(sv, tk.k);
-      } else {
-        thr_g = kth_largest64(sv[0], tk.k);
+      }
+      uint32_t sum = (sv[0] + sv[1]) + (sv[2] + sv[3]);
+      sum += dpp_get<0x111, 0xF>(sum);
+      sum += dpp_get<0x112, 0xF>(sum);
+      sum += dpp_get<0x114, 0xF>(sum);
+      sum += dpp_get<0x118, 0xF>(sum);
+      sum += dpp_get<0x142, 0xA>(sum);
+      sum += dpp_get<0x143, 0xC>(sum);
+      sum = (uint32_t)__builtin_amdgcn_readlane((int)sum, 63);
+      if (sum != slots_sum) {
+        slots_sum = sum;
+        const uint32_t g = n_slot_rows == 4u ? kth_largest_hi16<4>(sv, tk.k) : kth_largest_hi16<1>(sv, tk.k);
+        if (g > thr_g) thr_g = g;
       }
       if (thr_g > thr) thr = thr_g;
     }
     // non-essential by now: every doc first seen in list li scores at most the weights of li..
     if (prune && sortable(L.suffix[li] * 1.000001f) < thr) {
-      while (q1n) stageB(q1n < 64u ? q1n : 64u);
+      drain();
       dead = true;
       continue;
     }
 
+    if (p.debug & 4096u) continue;  // ABLATION: tile bookkeeping only
+    tick(2u);
     // ---- pre-filter: lane <-> leader block
     const uint32_t i_base = (tl - sload(&Q->lead_tile_start[li])) * tile_blocks;
     const uint32_t i_mine = i_base + (uint32_t)lane;
@@ -651,7 +896,7 @@ __device__ __forceinline__ void union_body(const TqkScanParams &p) {
     }
     uint64_t todo = __ballot(surv);
     if (p.debug & 32u) n_matches += (uint32_t)__popcll(todo);  // COUNTERS
-    if (p.debug & 128u) n_matches += 1u;  // COUNTERS
+    tick(3u);
     while (todo) {
       const uint32_t b = (uint32_t)__builtin_ctzll(todo);
       todo &= todo - 1ull;
@@ -659,19 +904,48 @@ __device__ __forceinline__ void union_body(const TqkScanParams &p) {
                                     (uint32_t)__builtin_amdgcn_readlane((int)rec_mine.z, (int)b));
       const uint32_t prev_l = (uint32_t)__builtin_amdgcn_readlane((int)prev_mine, (int)b);
       uint32_t c0, c1, t0, t1f;
-      decode_tfs(idx, lead, mo_l, lane, t0, t1f);  // tail padding reads as tf 0
       bool alive0 = true, alive1 = true;
-      if (prune) {
-        const uint32_t tfmin = (uint32_t)__builtin_amdgcn_readlane((int)tfmin_mine, (int)b);
-        alive0 = t0 >= tfmin;
-        alive1 = t1f >= tfmin;
-        if (!(__ballot(alive0) | __ballot(alive1))) continue;
+      if (mo_l.x == META_TAIL) {
+        decode_tfs(idx, lead, mo_l, lane, t0, t1f);  // tail padding reads as tf 0
+        if (prune) {
+          const uint32_t tfmin = (uint32_t)__builtin_amdgcn_readlane((int)tfmin_mine, (int)b);
+          alive0 = t0 >= tfmin;
+          alive1 = t1f >= tfmin;
+          if (!(__ballot(alive0) | __ballot(alive1))) continue;
+        }
+        decode_docs<USE_DPP>(idx, lead, mo_l, prev_l, lane, c0, c1);
+      } else {
+        // ONE 16-byte load per lane brings the block's doc + tf payload (<= 1008 B) into LDS:
+        // one memory round trip per leader block instead of two dependent ones
+        const uint32_t doc_bits = mo_l.x & 31u;
+        const uint32_t strict = (mo_l.x >> 6) & 1u;
+        const uint32_t tf_bits = lead.has_freq ? (mo_l.x >> 8) & 0xFFu : 0u;
+        wave_mem_fence();
+        stage_payload(L.pay, idx + lead.payload_base + mo_l.y, 16u * (doc_bits + tf_bits), lane);
+        wave_mem_fence();
+        if (lead.has_freq) {
+          unpack2_lds(L.pay + 4u * doc_bits, tf_bits, lane, t0, t1f);
+          t0 += strict;  // minus-one encoding is tied to the strict flag
+          t1f += strict;
+        } else {
+          t0 = 1u;
+          t1f = 1u;
+        }
+        if (prune) {
+          const uint32_t tfmin = (uint32_t)__builtin_amdgcn_readlane((int)tfmin_mine, (int)b);
+          alive0 = t0 >= tfmin;
+          alive1 = t1f >= tfmin;
+          if (!(__ballot(alive0) | __ballot(alive1))) continue;
+        }
+        uint32_t x0, x1;
+        unpack2_lds(L.pay, doc_bits, lane, x0, x1);
+        finish_docs<USE_DPP>(x0, x1, strict, prev_l, lane, c0, c1);
       }
-      decode_docs<USE_DPP>(idx, lead, mo_l, prev_l, lane, c0, c1);
       alive0 = alive0 && c0 != TQD_TERMINATED;
       alive1 = alive1 && c1 != TQD_TERMINATED;
       const uint64_t m0 = __ballot(alive0), m1 = __ballot(alive1);
       if (!(m0 | m1)) continue;
+      if (p.debug & 1024u) continue;  // ABLATION: no stage B / C
       const uint32_t n0 = (uint32_t)__popcll(m0);
       const uint32_t pos0 = q1n + mbcnt64(m0);
       const uint32_t pos1 = q1n + n0 + mbcnt64(m1);
@@ -686,16 +960,18 @@ __device__ __forceinline__ void union_body(const TqkScanParams &p) {
       }
       wave_mem_fence();
       q1n += n0 + (uint32_t)__popcll(m1);
-      while (q1n >= 64u) stageB(64u);
+      while (q1n >= 64u) step64();
     }
   }
   if (q_tile_end > q_tile_start) {
-    while (q1n) stageB(q1n < 64u ? q1n : 64u);
+    drain();
     const uint32_t part = sload(&Q->part_start) + (chunk - sload(&Q->chunk_first));
     flush_partial<KPL>(tk, sload(&p.sinks->partials), part, lane);
         if (lane == 0 && n_q) atomicAdd(sload(&p.sinks->query_matches) + sload(sload(&p.sinks->out_index) + q), n_q);
         n_q = 0;
   }
+  tick(1u);
+  if (tphase) n_matches = (uint32_t)(tacc >> 4);
   if (lane == 0 && n_matches) atomicAdd(sload(&p.sinks->match_counter), (unsigned long long)n_matches);
 }
 
