@@ -86,6 +86,7 @@ struct PinnedBuf {
 struct TermHost {
   void *blob = nullptr;  // one device allocation holding every per-term array
   void *dense_blob = nullptr;  // bitmap + rank directory of a dense list
+  void *posdir_blob = nullptr; // position directory of a dense list with positions
   uint32_t doc_freq = 0, n_blocks = 0, n_full = 0, n_tail = 0;
   uint32_t last_doc = 0;
   uint64_t postings_len = 0, positions_len = 0;
@@ -248,13 +249,18 @@ int build_dense(tq_segment *s, uint32_t handle) {
     }
     if (s->d_docmat) {
       const uint32_t slot = s->n_mat_slots++;
-      e = tqk_launch_docmat_set(s->d_docmat, dd, t.doc_freq, slot, s->stream);
+      e = tqk_launch_docmat_set(s->d_docmat, dd, t.doc_freq, slot, s->max_doc, s->stream);
       if (e != hipSuccess) return fail(TQ_ERR_HIP, "docmat set: %s", hipGetErrorString(e));
       s->h_dterms[handle].has_freq |= (slot + 1u) << 8;
     }
   }
-  std::vector<uint32_t> docs(t.doc_freq);
+  std::vector<uint32_t> docs(t.doc_freq), tfs;
   HIP_TRY(hipMemcpyAsync(docs.data(), dd, bytes, hipMemcpyDeviceToHost, s->stream));
+  const bool want_dir = t.positions_len > 0;
+  if (want_dir) {
+    tfs.resize(t.doc_freq);
+    HIP_TRY(hipMemcpyAsync(tfs.data(), dt, bytes, hipMemcpyDeviceToHost, s->stream));
+  }
   HIP_TRY(hipStreamSynchronize(s->stream));
   const size_t n_words = ((size_t)s->max_doc + 31) / 32 + 1;
   std::vector<uint2> tab(n_words, make_uint2(0u, 0u));
@@ -281,6 +287,29 @@ int build_dense(tq_segment *s, uint32_t handle) {
   t.dense_blob = blob;
   s->h_dterms[handle].dense = (const uint2 *)blob;
   s->d_terms_dirty = true;
+  if (want_dir) {  // position directory: positions before every fourth posting
+    const size_t n_dir = ((size_t)t.doc_freq + 3) / 4 + 1;
+    std::vector<uint32_t> dir(n_dir);
+    uint64_t run = 0;
+    for (uint32_t i = 0; i < t.doc_freq; ++i) {
+      if ((i & 3u) == 0u) dir[i >> 2] = (uint32_t)run;
+      run += tfs[i];
+    }
+    dir[n_dir - 1] = (uint32_t)run;
+    if (run != t.n_positions)
+      return fail(TQ_ERR_FORMAT, "term freqs sum to %llu positions, the stream holds %llu",
+                  (unsigned long long)run, (unsigned long long)t.n_positions);
+    void *db = nullptr;
+    HIP_TRY(hipMalloc(&db, n_dir * sizeof(uint32_t) + PAD));
+    hipError_t de = hipMemcpy(db, dir.data(), n_dir * sizeof(uint32_t), hipMemcpyHostToDevice);
+    if (de != hipSuccess) {
+      (void)hipFree(db);
+      return fail(TQ_ERR_HIP, "position directory upload: %s", hipGetErrorString(de));
+    }
+    t.posdir_blob = db;
+    s->h_dterms[handle].pos_dir = (const uint32_t *)db;
+    s->dense_bytes_total += n_dir * sizeof(uint32_t);
+  }
   return TQ_OK;
 }
 }  // namespace
@@ -387,6 +416,8 @@ void tq_segment_free(tq_segment *s) {
     if (t.blob) (void)hipFree(t.blob);
   for (auto &t : s->terms)
     if (t.dense_blob) (void)hipFree(t.dense_blob);
+  for (auto &t : s->terms)
+    if (t.posdir_blob) (void)hipFree(t.posdir_blob);
   if (s->d_terms) (void)hipFree(s->d_terms);
   if (s->d_idx) (void)hipFree(s->d_idx);
   if (s->d_pos) (void)hipFree(s->d_pos);
@@ -1053,6 +1084,7 @@ int search_batch_impl(tq_segment *s, const tq_query *queries, uint32_t n_queries
   std::vector<const float *> caches;
   uint64_t algo_bytes = 0;
   uint32_t n_thr_rows = 0;
+  bool phrase_all_dense = true;
   for (uint32_t qi = 0; qi < n_queries; ++qi) {
     const tq_query &q = queries[qi];
     if (q.n_terms == 0 || q.n_terms > TQ_MAX_TERMS)
@@ -1145,6 +1177,14 @@ int search_batch_impl(tq_segment *s, const tq_query *queries, uint32_t n_queries
           }
         } else {  // phrase: leader-block tiles like AND; every match also walks its positions
           const uint32_t lead_blocks = s->terms[dq.term[0]].n_blocks;
+          // the lean instantiation needs a bitmap, a doc-matrix column and a position directory
+          // for every non-leader list
+          for (uint32_t i = 1; i < q.n_terms; ++i) {
+            const TermHost &th = s->terms[dq.term[i]];
+            const bool col = ((s->h_dterms[dq.term[i]].has_freq >> 8) & 0xFFu) != 0u;
+            if (!(th.dense_blob && th.posdir_blob && col && s->opt.use_dense && s->d_docmat))
+              phrase_all_dense = false;
+          }
           dq.tile_blocks = 32;
           tile_cost = 64;
           n_tiles = (lead_blocks + dq.tile_blocks - 1) / dq.tile_blocks;
@@ -1361,7 +1401,7 @@ int search_batch_impl(tq_segment *s, const tq_query *queries, uint32_t n_queries
     p.n_chunks = g.n_chunks;
     p.exhaustive = (uint32_t)opt_exhaustive;
     p.use_dense = (uint32_t)s->opt.use_dense;
-    p.all_dense = gi == 0 ? 1u : 0u;
+    p.all_dense = (gi == 0 || (gi == 2 && phrase_all_dense)) ? 1u : 0u;
     static const uint32_t kDebug = tune_u32("TQ_DEBUG", 0);
     p.debug = kDebug;
     p.or_windows = (or_windows_opt && gi != kBool) ? 1u : 0u;

@@ -44,6 +44,11 @@ struct TqdTerm : TqdTermHead {
   const uint32_t *pos_tail;       // vint tail, pre-decoded deltas
   uint32_t n_full, doc_freq;
   uint32_t n_pos_blocks, n_pos_tail;
+  // dense lists with positions: pos_dir[j] = number of positions before posting 4*j.  With the
+  // posting index from the bitmap's rank, a posting's first position index is pos_dir[i >> 2] +
+  // the term freqs of the <= 3 postings before it in its group of four — which share one
+  // 16-byte row of the bitpacked tf stream — instead of a prefix sum over its whole block.
+  const uint32_t *pos_dir;
 };
 
 struct TqdQuery {

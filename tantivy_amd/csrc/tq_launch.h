@@ -77,7 +77,7 @@ hipError_t tqk_launch_merge_segments(const TqkSegMergeParams &p, hipStream_t st)
 hipError_t tqk_launch_docmat_init(uint64_t *mat, const uint8_t *fieldnorm, uint32_t const_id,
                                   uint32_t max_doc, hipStream_t st);
 hipError_t tqk_launch_docmat_set(uint64_t *mat, const uint32_t *docs, uint32_t n, uint32_t slot,
-                                 hipStream_t st);
+                                 uint32_t max_doc, hipStream_t st);
 
 // ---- shared with tq_encode.hip: the C ABI's error slot and context checks live in tq_api.cpp
 struct tq_ctx;

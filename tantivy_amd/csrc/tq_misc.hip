@@ -154,9 +154,11 @@ __global__ void docmat_init_kernel(uint64_t *mat, const uint8_t *fieldnorm, uint
   const uint32_t d = blockIdx.x * blockDim.x + threadIdx.x;
   if (d < max_doc) mat[d] = fieldnorm ? (uint64_t)fieldnorm[d] : (uint64_t)const_id;
 }
-__global__ void docmat_set_kernel(uint64_t *mat, const uint32_t *docs, uint32_t n, uint32_t slot) {
+__global__ void docmat_set_kernel(uint64_t *mat, const uint32_t *docs, uint32_t n, uint32_t slot,
+                                  uint32_t max_doc) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) atomicOr((unsigned long long *)(mat + docs[i]), 1ull << (8u + slot));
+  if (i < n && docs[i] < max_doc)  // (a malformed list is rejected by the host right after)
+    atomicOr((unsigned long long *)(mat + docs[i]), 1ull << (8u + slot));
 }
 
 }  // namespace
@@ -170,9 +172,10 @@ hipError_t tqk_launch_docmat_init(uint64_t *mat, const uint8_t *fieldnorm, uint3
   return hipGetLastError();
 }
 hipError_t tqk_launch_docmat_set(uint64_t *mat, const uint32_t *docs, uint32_t n, uint32_t slot,
-                                 hipStream_t st) {
+                                 uint32_t max_doc, hipStream_t st) {
   if (n == 0) return hipSuccess;
-  hipLaunchKernelGGL(docmat_set_kernel, dim3((n + 255) / 256), dim3(256), 0, st, mat, docs, n, slot);
+  hipLaunchKernelGGL(docmat_set_kernel, dim3((n + 255) / 256), dim3(256), 0, st, mat, docs, n, slot,
+                     max_doc);
   return hipGetLastError();
 }
 hipError_t tqk_launch_merge(const TqkMergeParams &p, int kpl, hipStream_t st) {

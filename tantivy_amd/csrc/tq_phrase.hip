@@ -20,12 +20,18 @@ namespace {
 // The reference runs phrases through the default for_each_pruning_scorer (a threshold filter on
 // finished scores), so there is nothing to prune before the positions are read.
 #define TQD_PH_MAX_TERMS 8
-template <int NT_MAX>
+// DENSE: every non-leader list of every query of the launch has a bitmap, a doc-matrix column and
+// a position directory (the planner checks): no seek / block-search code, half the staging area
+template <int NT_MAX, bool DENSE>
 struct PhraseLds {  // per wavefront
-  uint32_t pay[516];  // lookup_in_blocks' staging area
+  uint32_t pay[DENSE ? 260 : 516];  // stage A's payload / lookup_in_blocks' staging area
   uint32_t q1_doc[191], q1_tf[191], q1_pi[191];
-  uint32_t q2_doc[127], q2_tf[127], q2_pi[127], q2_loc[127];
+  uint32_t q2_doc[127], q2_tf[127], q2_pi[127], q2_loc[DENSE ? 1 : 127];
   uint32_t ph_pi[NT_MAX - 1][64], ph_tf[NT_MAX - 1][64];  // lists 1.. (the leader's stay in q2)
+  // per-term position stream tables of the current query, read by broadcast
+  const uint64_t *pt_blk[NT_MAX];
+  const uint32_t *pt_tail[NT_MAX];
+  uint32_t pt_nblk[NT_MAX], pt_off[NT_MAX];
 };
 
 struct PosCursor {
@@ -41,10 +47,88 @@ __device__ __forceinline__ void pos_advance(PosCursor &c, const uint8_t *pos, co
   }
 }
 
-template <int KPL, int NT_MAX>
-__global__ __launch_bounds__(64) void phrase_kernel(TqkScanParams p) {
+
+// Term freq of posting `at` of a block and the sum of the term freqs of the <= 3 postings before
+// it in its group of four (slots 4g..4g+3 are value g of the four bit streams: they share one
+// 16-byte row of the tf payload, or two when the value straddles a word).  rec = the block's
+// record; per-lane arguments.
+__device__ __forceinline__ void group_tfs(const uint8_t *idx, const TermRef &t, const uint4 rec,
+                                          uint32_t at, uint32_t &tf, uint32_t &excl) {
+  uint32_t v[4];
+  if (rec.y == META_TAIL) {
+    const uint32_t g0 = at & ~3u;
+#pragma unroll
+    for (uint32_t l = 0; l < 4u; ++l) v[l] = g0 + l < t.n_tail ? t.tail_tfs[g0 + l] : 0u;
+  } else {
+    const uint32_t doc_bits = rec.y & 31u;
+    const uint32_t strict = (rec.y >> 6) & 1u;
+    const uint32_t b = (rec.y >> 8) & 0xFFu;
+    const uint32_t bitpos = (at >> 2) * b;
+    const uint32_t w = bitpos >> 5, sh = bitpos & 31u;
+    const uint8_t *q = idx + t.payload_base + rec.z + 16u * doc_bits + 16u * w;
+    U4Unaligned r0 = {0u, 0u, 0u, 0u}, r1 = {0u, 0u, 0u, 0u};
+    if (b) {  // (b == 0: every tf of the block is `strict`)
+      r0 = *reinterpret_cast<const U4Unaligned *>(q);
+      r1 = *reinterpret_cast<const U4Unaligned *>(q + 16);  // may over-read: buffers are padded
+    }
+    const uint32_t mask = b >= 32u ? 0xFFFFFFFFu : ((1u << b) - 1u);
+    v[0] = (__funnelshift_r(r0.x, r1.x, sh) & mask) + strict;
+    v[1] = (__funnelshift_r(r0.y, r1.y, sh) & mask) + strict;
+    v[2] = (__funnelshift_r(r0.z, r1.z, sh) & mask) + strict;
+    v[3] = (__funnelshift_r(r0.w, r1.w, sh) & mask) + strict;
+  }
+  const uint32_t l0 = at & 3u;
+  tf = l0 == 0u ? v[0] : (l0 == 1u ? v[1] : (l0 == 2u ? v[2] : v[3]));
+  excl = (l0 > 0u ? v[0] : 0u) + (l0 > 1u ? v[1] : 0u) + (l0 > 2u ? v[2] : 0u);
+}
+
+// The position deltas [i, i + n), n <= 8, of a term, fetched with independent loads: they lie in
+// position block i >> 7 and possibly the next one, each either a bitpacked block (pos_blk record:
+// byte offset | width << 56, positions/reader.rs:84-101) or the pre-decoded vint tail.
+struct PosRun {
+  const uint8_t *base[2];  // block payload, or the tail array
+  uint32_t b[2];           // bit width; 0xFFFFFFFF = tail (plain u32 values)
+  uint32_t v0;             // index of delta 0 inside block 0 (tail: inside the tail array)
+};
+__device__ __forceinline__ PosRun pos_run(const uint8_t *pos, const uint64_t *pos_blk,
+                                          const uint32_t *pos_tail, uint32_t n_pb, uint32_t i) {
+  PosRun r;
+  const uint32_t pb = i >> 7;
+  // both records are loaded unconditionally (clamped): independent loads
+  const uint64_t e0 = pos_blk[pb < n_pb ? pb : 0u];
+  const uint64_t e1 = pos_blk[pb + 1u < n_pb ? pb + 1u : 0u];
+  const bool t0 = pb >= n_pb, t1 = pb + 1u >= n_pb;
+  r.base[0] = t0 ? reinterpret_cast<const uint8_t *>(pos_tail) : pos + (e0 & 0x00FFFFFFFFFFFFFFull);
+  r.b[0] = t0 ? 0xFFFFFFFFu : (uint32_t)(e0 >> 56);
+  r.v0 = t0 ? i - (n_pb << 7) : (i & 127u);
+  // block 1 is indexed from v0 as well: index v of block 0 is index v - 128 of block 1; as a tail
+  // it starts at element 0 of the tail array
+  r.base[1] = t1 ? reinterpret_cast<const uint8_t *>(pos_tail) : pos + (e1 & 0x00FFFFFFFFFFFFFFull);
+  r.b[1] = t1 ? 0xFFFFFFFFu : (uint32_t)(e1 >> 56);
+  return r;
+}
+// delta k of the run (k clamped by the caller): two independent 4-byte loads
+__device__ __forceinline__ uint32_t pos_run_delta(const PosRun &r, uint32_t k) {
+  uint32_t v = r.v0 + k;
+  const bool second = r.b[0] != 0xFFFFFFFFu && v >= 128u;  // (a tail never overflows)
+  if (second) v -= 128u;
+  const uint8_t *base = second ? r.base[1] : r.base[0];
+  const uint32_t b = second ? r.b[1] : r.b[0];
+  const bool tail = b == 0xFFFFFFFFu;
+  const uint32_t bb = tail ? 32u : b;
+  const uint32_t bitpos = tail ? 0u : (v >> 2) * bb;
+  const uint32_t w = bitpos >> 5, sh = bitpos & 31u;
+  const uint8_t *q = tail ? base + 4u * v : base + 16u * w + 4u * (v & 3u);
+  const uint32_t lo = ld_u1(q), hi = ld_u1(q + 16);  // hi may over-read: buffers are padded
+  const uint32_t mask = bb >= 32u ? 0xFFFFFFFFu : ((1u << bb) - 1u);
+  return bb ? (__funnelshift_r(lo, tail ? 0u : hi, sh) & mask) : 0u;
+}
+
+// (5 waves per SIMD: what the 8 KB of LDS per wavefront admit)
+template <int KPL, int NT_MAX, bool DENSE>
+__global__ __launch_bounds__(64, DENSE ? 6 : 5) void phrase_kernel(TqkScanParams p) {
   constexpr bool USE_DPP = true;
-  __shared__ PhraseLds<NT_MAX> L;
+  __shared__ PhraseLds<NT_MAX, DENSE> L;
   const int lane = (int)__lane_id();
   if (blockIdx.x >= p.n_chunks) return;
   const uint4 crec = sload(p.chunk_recs + blockIdx.x);
@@ -63,6 +147,19 @@ __global__ __launch_bounds__(64) void phrase_kernel(TqkScanParams p) {
   TopK<KPL> tk;
   uint32_t n_matches = 0, n_q = 0;  // docs scored: whole chunk / current query
   uint32_t q1n = 0, q2n = 0;
+  uint64_t mat_need = 0;  // != 0: stage B tests every non-leader list with one doc-matrix word
+  // PROFILING (TQ_DEBUG bits 16..19 = phase): wave cycles of one phase, summed into the match
+  // counter.  1 setup + flush, 2 pre-filter, 3 stage A, 4 stage B, 5 stage C lists, 6 positions,
+  // 7 collector
+  const uint32_t tphase = (p.debug >> 16) & 15u;
+  uint64_t tacc = 0, tlast = tphase ? __builtin_readcyclecounter() : 0ull;
+  auto tick = [&](uint32_t done) __attribute__((always_inline)) {
+    if (tphase) {
+      const uint64_t now = __builtin_readcyclecounter();
+      if (done == tphase) tacc += now - tlast;
+      tlast = now;
+    }
+  };
 
   auto setup_query = [&]() __attribute__((always_inline)) {
     q_tile_start = sload(p.tile_starts + q);
@@ -78,17 +175,39 @@ __global__ __launch_bounds__(64) void phrase_kernel(TqkScanParams p) {
     // wavefront instead of 9.5 KB: 5 waves/SIMD)
     cache_g = p.caches + (size_t)sload(&Q->cache_idx) * 256u;
     tk.reset(sload(&Q->k));
+    // per-term tables (one term per lane) and the doc-matrix columns of the non-leader lists
+    wave_mem_fence();
+    uint32_t slot = 0xFFFFFFFFu;
+    if ((uint32_t)lane < nt) {
+      const TqdTerm *tt = p.terms + Q->term[lane];
+      L.pt_blk[lane] = tt->pos_blk;
+      L.pt_tail[lane] = tt->pos_tail;
+      L.pt_nblk[lane] = tt->n_pos_blocks;
+      L.pt_off[lane] = Q->phrase_off[lane];
+      if (lane && seg.docmat && tt->dense) slot = ((tt->has_freq >> 8) & 0xFFu) - 1u;
+    }
+    wave_mem_fence();
+    const uint64_t have = __ballot(slot < TQD_MAT_SLOTS);
+    mat_need = 0;
+    if (seg.docmat && have == (((1ull << nt) - 1ull) & ~1ull)) {  // every non-leader list has a column
+      uint64_t need = slot < TQD_MAT_SLOTS ? 1ull << (8u + slot) : 0ull;
+      for (int o = 32; o; o >>= 1)
+        need |= ((uint64_t)(uint32_t)__shfl_xor((int)(need >> 32), o, WAVE) << 32) |
+                (uint32_t)__shfl_xor((int)(uint32_t)need, o, WAVE);
+      mat_need = uni64(need);
+    }
   };
 
   // ---- stage C: the other lists' postings of the candidate, then the positions
   auto stageC = [&](uint32_t n) __attribute__((always_inline)) {
+    tick(4u);
     const uint32_t base = q2n - n;
     q2n = base;
     bool alive = (uint32_t)lane < n;
     uint32_t doc = 0, loc = 0, lead_tf = 0, lead_pi = 0;
     if (alive) {
       doc = L.q2_doc[base + lane];
-      loc = L.q2_loc[base + lane];
+      if constexpr (!DENSE) loc = L.q2_loc[base + lane];
       lead_tf = L.q2_tf[base + lane];
       lead_pi = L.q2_pi[base + lane];
     }
@@ -96,14 +215,14 @@ __global__ __launch_bounds__(64) void phrase_kernel(TqkScanParams p) {
       TermRef tr = m == 1u ? t1 : load_term(p.terms, sload(&Q->term[m]));
       if (!p.use_dense) tr.dense = nullptr;
       uint32_t jb = 0, at = NOT_FOUND;
-      if (m == 1u) {
+      if (!DENSE && m == 1u && !mat_need) {
         if (tr.dense) {
           jb = loc >> 7;
           at = loc & 127u;
         } else {
           jb = loc;
         }
-      } else if (tr.dense) {
+      } else if (DENSE || tr.dense) {
         if (alive) {
           const uint2 wd = tr.dense[doc >> 5];
           const uint32_t bit = doc & 31u;
@@ -116,27 +235,44 @@ __global__ __launch_bounds__(64) void phrase_kernel(TqkScanParams p) {
         jb = seek_block(tr, doc);
         alive = jb < tr.n_blocks;
       }
-      if (!tr.dense) {
-        uint32_t unused;
-        at = lookup_in_blocks<false>(idx, tr, jb, doc, alive, L.pay, lane, &unused);
-        alive = alive && at != NOT_FOUND;
+      if constexpr (!DENSE) {
+        if (!tr.dense) {
+          uint32_t unused;
+          at = lookup_in_blocks<false>(idx, tr, jb, doc, alive, L.pay, lane, &unused);
+          alive = alive && at != NOT_FOUND;
+        }
       }
-      if (!__ballot(alive)) return;
+      if (!__ballot(alive)) {
+        tick(5u);
+        return;
+      }
       uint32_t excl = 0;
       uint32_t tf = 1;
-      if (!(p.debug & 2u)) tf = lookup_in_blocks<true>(idx, tr, jb, at, alive, L.pay, lane, &excl);
-      if (alive) {
-        L.ph_tf[m - 1u][lane] = tf;
-        L.ph_pi[m - 1u][lane] = tr.rec[jb].w + excl;
+      const uint32_t *pdir =
+          (DENSE || tr.dense) ? sload(&(p.terms + sload(&Q->term[m]))->pos_dir) : nullptr;
+      if (DENSE || pdir) {
+        // dense list: posting index = 128 * jb + at (from the bitmap's rank); its first position
+        // index = directory entry of its group of four + the term freqs before it in the group
+        if (alive) {
+          const uint4 r = tr.rec[jb];
+          const uint32_t dirv = pdir[(jb << 5) + (at >> 2)];
+          uint32_t ex;
+          group_tfs(idx, tr, r, at, tf, ex);
+          L.ph_tf[m - 1u][lane] = tf;
+          L.ph_pi[m - 1u][lane] = dirv + ex;
+        }
+      } else if constexpr (!DENSE) {
+        if (!(p.debug & 2u)) tf = lookup_in_blocks<true>(idx, tr, jb, at, alive, L.pay, lane, &excl);
+        if (alive) {
+          L.ph_tf[m - 1u][lane] = tf;
+          L.ph_pi[m - 1u][lane] = tr.rec[jb].w + excl;
+        }
       }
     }
-    // ---- position check, one lane per candidate
-    bool has = false;
-    uint64_t key = 0;
-    if (alive && (p.debug & 3u)) {
-      has = true;
-      key = make_key(1.0f, doc);
-    } else if (alive) {
+    // the n-way cursor merge over adjusted positions (phrase_scorer.rs:372-385,437-461), one
+    // position fetched at a time: candidates with a long position list or a run that crosses a
+    // position block
+    auto phrase_count_serial = [&]() __attribute__((always_inline)) -> uint32_t {
       PosCursor cur[NT_MAX];
 #pragma unroll
       for (int m = 0; m < NT_MAX; ++m) {
@@ -174,21 +310,86 @@ __global__ __launch_bounds__(64) void phrase_kernel(TqkScanParams p) {
         }
         pos_advance(cur[0], pos, p.terms + Q->term[0]);
       }
+      return count;
+    };
+    tick(5u);
+    // ---- position check, one lane per candidate
+    bool has = false;
+    uint64_t key = 0;
+    if (alive && (p.debug & 3u)) {
+      has = true;
+      key = make_key(1.0f, doc);
+    } else if (NT_MAX <= 4 && alive) {
+      // Fast path (every term's tf <= 8 — all but 2e-4 of the candidates): the deltas of a term
+      // are fetched with independent loads (one round trip per term instead of one per position)
+      // and the adjusted positions intersected in registers.
+      // Everything else takes the cursor merge below.
+      constexpr uint32_t TM = 8;
+      bool fast = lead_tf <= TM;
+      for (uint32_t m = 1; m < nt; ++m) fast = fast && L.ph_tf[m - 1u][lane] <= TM;
+      uint32_t count = 0xFFFFFFFFu;  // = resolved by the cursor merge
+      if (fast) {
+        // adjusted positions of the leader term, then one term at a time: bit i of `ok` stays set
+        // while every term seen so far has a position equal to the leader's i-th
+        uint32_t a[TM], d[TM];
+        {
+          const PosRun run = pos_run(pos, L.pt_blk[0], L.pt_tail[0], L.pt_nblk[0], lead_pi);
+#pragma unroll
+          for (uint32_t k = 0; k < TM; ++k)  // clamped: unconditional, independent loads
+            d[k] = pos_run_delta(run, k < lead_tf ? k : lead_tf - 1u);
+          uint32_t c = L.pt_off[0];
+#pragma unroll
+          for (uint32_t k = 0; k < TM; ++k) {
+            c += d[k];
+            a[k] = c;
+          }
+        }
+        uint32_t ok = (1u << lead_tf) - 1u;
+        for (uint32_t m = 1; m < nt; ++m) {
+          const uint32_t tfm = L.ph_tf[m - 1u][lane];
+          const PosRun run = pos_run(pos, L.pt_blk[m], L.pt_tail[m], L.pt_nblk[m], L.ph_pi[m - 1u][lane]);
+#pragma unroll
+          for (uint32_t k = 0; k < TM; ++k) d[k] = pos_run_delta(run, k < tfm ? k : tfm - 1u);
+          uint32_t c = L.pt_off[m], hit = 0;
+#pragma unroll
+          for (uint32_t k = 0; k < TM; ++k) {
+            c += d[k];  // (k >= tfm repeats the last delta; those sums are masked out below)
+            uint32_t eq = 0;
+#pragma unroll
+            for (uint32_t i = 0; i < TM; ++i) eq |= (a[i] == c ? 1u : 0u) << i;
+            hit |= k < tfm ? eq : 0u;
+          }
+          ok &= hit;
+        }
+        count = (uint32_t)__popc(ok);
+      }
+      if (__ballot(count == 0xFFFFFFFFu)) {
+        if (count == 0xFFFFFFFFu) count = phrase_count_serial();
+      }
+      if (count > 0 && doc_is_alive(seg, doc)) {
+        has = true;
+        key = make_key(bm25(weight, cache_g[fieldnorm_id(seg, doc)], count), doc);
+      }
+    } else if (alive) {
+      const uint32_t count = phrase_count_serial();
       if (count > 0 && doc_is_alive(seg, doc)) {
         has = true;
         key = make_key(bm25(weight, cache_g[fieldnorm_id(seg, doc)], count), doc);
       }
     }
+    tick(6u);
     const uint64_t hit = __ballot(has);
     if (hit) {
       n_matches += (uint32_t)__popcll(hit);
       n_q += (uint32_t)__popcll(hit);
       tk.offer(has, key, lane);
     }
+    tick(7u);
   };
 
   // ---- stage B: locate the candidate in list 1
   auto stageB = [&](uint32_t n) __attribute__((always_inline)) {
+    tick(3u);
     const uint32_t base = q1n - n;
     q1n = base;
     bool alive = (uint32_t)lane < n;
@@ -198,7 +399,9 @@ __global__ __launch_bounds__(64) void phrase_kernel(TqkScanParams p) {
       tf = L.q1_tf[base + lane];
       pi0 = L.q1_pi[base + lane];
     }
-    if (t1.dense) {
+    if (DENSE || mat_need) {  // one gather answers every other list (all have bitmaps + columns)
+      if (alive) alive = (seg.docmat[doc] & mat_need) == mat_need;
+    } else if (t1.dense) {
       if (alive) {
         const uint2 wd = t1.dense[doc >> 5];
         const uint32_t bit = doc & 31u;
@@ -217,11 +420,12 @@ __global__ __launch_bounds__(64) void phrase_kernel(TqkScanParams p) {
         L.q2_doc[at] = doc;
         L.q2_tf[at] = tf;
         L.q2_pi[at] = pi0;
-        L.q2_loc[at] = loc;
+        if constexpr (!DENSE) L.q2_loc[at] = loc;
       }
       wave_mem_fence();
       q2n += (uint32_t)__popcll(m);
     }
+    tick(4u);
   };
 
   auto drain = [&]() __attribute__((always_inline)) {
@@ -233,7 +437,9 @@ __global__ __launch_bounds__(64) void phrase_kernel(TqkScanParams p) {
   };
 
   setup_query();
+  tick(1u);
   for (uint32_t t = t_begin; t < t_end; ++t) {
+    tick(3u);
     while (t >= q_tile_end) {
       if (q_tile_end > q_tile_start && q_tile_end > t_begin) {
         drain();
@@ -262,6 +468,7 @@ __global__ __launch_bounds__(64) void phrase_kernel(TqkScanParams p) {
       }
     }
     uint64_t todo = __ballot(surv);
+    tick(2u);
     // ---- stage A per surviving leader block
     while (todo) {
       const uint32_t b = (uint32_t)__builtin_ctzll(todo);
@@ -271,8 +478,29 @@ __global__ __launch_bounds__(64) void phrase_kernel(TqkScanParams p) {
       const uint32_t bp = (uint32_t)__builtin_amdgcn_readlane((int)rec_mine.w, (int)b);
       const uint32_t prev_l = (uint32_t)__builtin_amdgcn_readlane((int)prev_mine, (int)b);
       uint32_t c0, c1, t0, t1f;
-      decode_docs<USE_DPP>(idx, lead, mo_l, prev_l, lane, c0, c1);
-      decode_tfs(idx, lead, mo_l, lane, t0, t1f);  // tail padding reads as tf 0
+      if (mo_l.x == META_TAIL) {
+        decode_docs<USE_DPP>(idx, lead, mo_l, prev_l, lane, c0, c1);
+        decode_tfs(idx, lead, mo_l, lane, t0, t1f);  // tail padding reads as tf 0
+      } else {
+        // one 16-byte load per lane brings the whole doc + tf payload (<= 1008 B) into LDS
+        const uint32_t doc_bits = mo_l.x & 31u;
+        const uint32_t strict = (mo_l.x >> 6) & 1u;
+        const uint32_t tf_bits = lead.has_freq ? (mo_l.x >> 8) & 0xFFu : 0u;
+        wave_mem_fence();
+        stage_payload(L.pay, idx + lead.payload_base + mo_l.y, 16u * (doc_bits + tf_bits), lane);
+        wave_mem_fence();
+        uint32_t x0, x1;
+        unpack2_lds(L.pay, doc_bits, lane, x0, x1);
+        finish_docs<USE_DPP>(x0, x1, strict, prev_l, lane, c0, c1);
+        if (lead.has_freq) {
+          unpack2_lds(L.pay + 4u * doc_bits, tf_bits, lane, t0, t1f);
+          t0 += strict;  // minus-one encoding is tied to the strict flag
+          t1f += strict;
+        } else {
+          t0 = 1u;
+          t1f = 1u;
+        }
+      }
       const uint32_t ssum = t0 + t1f;
       const uint32_t incl = wave_inclusive_scan<USE_DPP>(ssum, lane);
       const uint32_t e0 = bp + (incl - ssum), e1 = e0 + t0;
@@ -308,6 +536,8 @@ __global__ __launch_bounds__(64) void phrase_kernel(TqkScanParams p) {
         if (lane == 0 && n_q) atomicAdd(sload(&p.sinks->query_matches) + sload(sload(&p.sinks->out_index) + q), n_q);
         n_q = 0;
   }
+  tick(1u);
+  if (tphase) n_matches = (uint32_t)(tacc >> 4);
   if (lane == 0 && n_matches) atomicAdd(sload(&p.sinks->match_counter), (unsigned long long)n_matches);
 }
 
@@ -316,10 +546,14 @@ __global__ __launch_bounds__(64) void phrase_kernel(TqkScanParams p) {
 // =================================================================== launch wrappers
 template <int KPL>
 static void launch_phrase_t(const TqkScanParams &p, bool /*dpp*/, dim3 grid, dim3 block, hipStream_t st) {
-  if (p.max_terms <= 4u)  // fewer position cursors and half the per-candidate LDS
-    phrase_kernel<KPL, 4><<<grid, block, 0, st>>>(p);
-  else
-    phrase_kernel<KPL, TQD_PH_MAX_TERMS><<<grid, block, 0, st>>>(p);
+  if (p.max_terms <= 4u) {  // fewer position cursors and half the per-candidate LDS
+    if (p.all_dense)
+      phrase_kernel<KPL, 4, true><<<grid, block, 0, st>>>(p);
+    else
+      phrase_kernel<KPL, 4, false><<<grid, block, 0, st>>>(p);
+  } else {
+    phrase_kernel<KPL, TQD_PH_MAX_TERMS, false><<<grid, block, 0, st>>>(p);
+  }
 }
 hipError_t tqk_launch_phrase(const TqkScanParams &p, int kpl, bool use_dpp, hipStream_t st) {
   if (p.n_chunks == 0) return hipSuccess;

@@ -1,0 +1,43 @@
+#!/usr/bin/env python
+"""In-kernel phase timers (TQ_DEBUG bits 16..19, union and phrase kernels): wave cycles per phase.
+usage: python tools/probe_phases.py <or5|phrase3> ; runs once per phase (the debug word is read at
+library load)."""
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+if len(sys.argv) > 2:  # child: one phase
+    from oracle import oracle as O
+    import numpy as np
+    import tantivy_amd
+
+    wl = sys.argv[1]
+    seg = O.synth_segment(10_000_000, n_terms=256, with_positions=wl == "phrase3", phrase_terms=32)
+    dev = tantivy_amd.DeviceIndex([seg], devices=[0])
+    dev.set_option("timing", 1)
+    dev.set_option("exhaustive", 0)
+    if wl == "or5":
+        qs = [(O.MODE_OR, q.tolist()) for q in O.zipf_queries(1000, 5, 256, seed=20260922)]
+        k = 100
+    elif wl == "and2":
+        qs = [(O.MODE_AND, q.tolist()) for q in O.zipf_queries(10000, 2, 256, seed=20260921)]
+        k = 10
+    else:
+        starts = np.random.default_rng(20260923).integers(0, 30, size=1000)
+        qs = [(O.MODE_PHRASE, [int(s), int(s) + 1, int(s) + 2]) for s in starts]
+        k = 10
+    dev.prepare(qs)
+    for _ in range(2):
+        dev.search_prepared(k)
+        st = dev.last_batch_stats()
+    print("phase %s kernel %.3f ms wave-cycles %.4g" % (sys.argv[2], st["kernel_ms"], st["matches"] * 16.0))
+    dev.close()
+else:
+    for ph in range(1, 8):
+        env = dict(os.environ, TQ_DEBUG=str(ph << 16))
+        out = subprocess.run([sys.executable, __file__, sys.argv[1], str(ph)], env=env,
+                             capture_output=True, text=True).stdout
+        print(out.strip().splitlines()[-1] if out.strip() else "phase %d: no output" % ph)
