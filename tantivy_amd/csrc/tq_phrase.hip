@@ -25,8 +25,9 @@ namespace {
 template <int NT_MAX, bool DENSE>
 struct PhraseLds {  // per wavefront
   uint32_t pay[DENSE ? 260 : 516];  // stage A's payload / lookup_in_blocks' staging area
-  uint32_t q1_doc[191], q1_tf[191], q1_pi[191];
-  uint32_t q2_doc[127], q2_tf[127], q2_pi[127], q2_loc[DENSE ? 1 : 127];
+  uint32_t q1_doc[DENSE ? 1 : 191], q1_tf[DENSE ? 1 : 191], q1_pi[DENSE ? 1 : 191];
+  // (DENSE: stage A tests its 128 docs against the doc matrix itself and feeds queue 2 directly)
+  uint32_t q2_doc[DENSE ? 191 : 127], q2_tf[DENSE ? 191 : 127], q2_pi[DENSE ? 191 : 127], q2_loc[DENSE ? 1 : 127];
   uint32_t ph_pi[NT_MAX - 1][64], ph_tf[NT_MAX - 1][64];  // lists 1.. (the leader's stay in q2)
   // per-term position stream tables of the current query, read by broadcast
   const uint64_t *pt_blk[NT_MAX];
@@ -504,7 +505,35 @@ __global__ __launch_bounds__(64, DENSE ? 6 : 5) void phrase_kernel(TqkScanParams
       const uint32_t ssum = t0 + t1f;
       const uint32_t incl = wave_inclusive_scan<USE_DPP>(ssum, lane);
       const uint32_t e0 = bp + (incl - ssum), e1 = e0 + t0;
-      const bool alive0 = c0 != TQD_TERMINATED, alive1 = c1 != TQD_TERMINATED;
+      bool alive0 = c0 != TQD_TERMINATED, alive1 = c1 != TQD_TERMINATED;
+      if constexpr (DENSE) {
+        // every doc of the block is a candidate and one doc-matrix word answers all the other
+        // lists: the two gathers run with all lanes live, no queue in between
+        const uint64_t w0 = alive0 ? seg.docmat[c0] : 0ull;
+        const uint64_t w1 = alive1 ? seg.docmat[c1] : 0ull;
+        alive0 = alive0 && (w0 & mat_need) == mat_need;
+        alive1 = alive1 && (w1 & mat_need) == mat_need;
+        const uint64_t k0 = __ballot(alive0), k1 = __ballot(alive1);
+        if (!(k0 | k1)) continue;
+        const uint32_t n0 = (uint32_t)__popcll(k0);
+        const uint32_t pos0 = q2n + mbcnt64(k0);
+        const uint32_t pos1 = q2n + n0 + mbcnt64(k1);
+        wave_mem_fence();
+        if (alive0) {
+          L.q2_doc[pos0] = c0;
+          L.q2_tf[pos0] = t0;
+          L.q2_pi[pos0] = e0;
+        }
+        if (alive1) {
+          L.q2_doc[pos1] = c1;
+          L.q2_tf[pos1] = t1f;
+          L.q2_pi[pos1] = e1;
+        }
+        wave_mem_fence();
+        q2n += n0 + (uint32_t)__popcll(k1);
+        while (q2n >= 64u) stageC(64u);
+        continue;
+      }
       const uint64_t m0 = __ballot(alive0), m1 = __ballot(alive1);
       if (!(m0 | m1)) continue;
       const uint32_t n0 = (uint32_t)__popcll(m0);
