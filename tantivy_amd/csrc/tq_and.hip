@@ -56,6 +56,17 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_num_sgpr(80))) void and_k
   TopK<KPL> tk;
   uint32_t n_matches = 0, n_q = 0;  // docs scored: whole chunk / current query
   uint32_t q1n = 0, q2n = 0;  // queue fill
+  // PROFILING (TQ_DEBUG bits 16..19 = phase): wave cycles of one phase, summed into the match
+  // counter.  1 setup + flush, 2 threshold + pre-filter, 3 stage A, 4 stage B, 5 stage C
+  const uint32_t tphase = (p.debug >> 16) & 15u;
+  uint64_t tacc = 0, tlast = tphase ? __builtin_readcyclecounter() : 0ull;
+  auto tick = [&](uint32_t done) __attribute__((always_inline)) {
+    if (tphase) {
+      const uint64_t now = __builtin_readcyclecounter();
+      if (done == tphase) tacc += now - tlast;
+      tlast = now;
+    }
+  };
 
   auto setup_query = [&]() __attribute__((always_inline)) {
     q_tile_start = sload(p.tile_starts + q);
@@ -92,6 +103,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_num_sgpr(80))) void and_k
 
   // ---- stage C: verify in list 1, score, remaining lists, collect
   auto stageC = [&](uint32_t n) __attribute__((always_inline)) {
+    tick(4u);
     const uint32_t base = q2n - n;
     q2n = base;
     if (p.debug & 128u) n_matches += n;  // COUNTERS
@@ -181,12 +193,14 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_num_sgpr(80))) void and_k
         if (own > thr) thr = own;
       }
     }
+    tick(5u);
   };
 
   // ---- stage B: locate in list 1.  Dense list: the bitmap answers membership, which is the
   // strongest filter there is, so nothing else is looked at first.  Other lists: pruned mode
   // scores the leader exactly (one fieldnorm gather) before paying for the seek.
   auto stageB = [&](uint32_t n) __attribute__((always_inline)) {
+    tick(3u);
     const uint32_t base = q1n - n;
     q1n = base;
     if (p.debug & 64u) n_matches += n;  // COUNTERS
@@ -225,6 +239,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_num_sgpr(80))) void and_k
       wave_mem_fence();
       q2n += (uint32_t)__popcll(m);
     }
+    tick(4u);
   };
 
   auto drain = [&]() __attribute__((always_inline)) {
@@ -236,7 +251,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_num_sgpr(80))) void and_k
   };
 
   setup_query();
+  tick(1u);
   for (uint32_t t = t_begin; t < t_end; ++t) {
+    tick(3u);
     while (t >= q_tile_end) {  // next query (queries with zero tiles are skipped)
       if (q_tile_end > q_tile_start && q_tile_end > t_begin) {  // this chunk touched query q
         drain();
@@ -247,6 +264,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_num_sgpr(80))) void and_k
       }
       ++q;
       setup_query();
+      tick(1u);
     }
 
     // threshold (sortable score bits): own k-th key and the k-th largest shared slot
@@ -332,6 +350,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_num_sgpr(80))) void and_k
     }
     uint64_t todo = __ballot(surv);
     if (p.debug & 32u) n_matches += (uint32_t)__popcll(todo);  // COUNTERS
+    tick(2u);
 
     // ---- stage A per surviving leader block
     auto stageA = [&](uint32_t b) __attribute__((always_inline)) {
@@ -415,6 +434,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_num_sgpr(80))) void and_k
         if (lane == 0 && n_q) atomicAdd(sload(&p.sinks->query_matches) + sload(sload(&p.sinks->out_index) + q), n_q);
         n_q = 0;
   }
+  tick(1u);
+  if (tphase) n_matches = (uint32_t)(tacc >> 4);
   if (lane == 0 && n_matches) atomicAdd(sload(&p.sinks->match_counter), (unsigned long long)n_matches);
 }
 

@@ -764,27 +764,39 @@ int build_group_chunks(Group &g, bool or_windows) {
   // (the weights of lists i.. together below ~3/4 of the query's total weight: top-k docs hold
   // most of the terms) are skipped whole at run time => weigh them as 1/8 of a live tile, so
   // that chunks are sized by the work that is really done
-  auto tile_cost_at = [&](size_t qi, uint32_t t) -> uint32_t {
-    const uint32_t tc = std::max<uint32_t>(1u, g.tile_cost[qi]);
-    if (!or_cand) return tc;
-    const TqdQuery &dq = g.queries[qi];
+  // per query: cost per tile of every leader's run (computed once: the chunk loops below ask
+  // per chunk)
+  std::vector<uint32_t> lead_cost;  // [query][TQ_MAX_TERMS]
+  if (or_cand) {
+    lead_cost.resize(g.queries.size() * TQ_MAX_TERMS);
+    for (size_t qi = 0; qi < g.queries.size(); ++qi) {
+      const TqdQuery &dq = g.queries[qi];
+      const uint32_t tc = std::max<uint32_t>(1u, g.tile_cost[qi]);
+      const bool pruning = (dq.flags & TQD_QF_PRUNE) != 0u;
+      float total = 0.0f;
+      for (uint32_t m = 0; m < dq.n_terms; ++m) total += dq.weight[m];
+      float suffix = total;
+      for (uint32_t li = 0; li < dq.n_terms; ++li) {
+        lead_cost[qi * TQ_MAX_TERMS + li] =
+            (pruning && suffix < kOrDeadFrac * total) ? std::max<uint32_t>(1u, tc / kOrDeadDiv) : tc;
+        suffix -= dq.weight[li];
+      }
+    }
+  }
+  auto leader_of = [&](const TqdQuery &dq, uint32_t t) -> uint32_t {
     uint32_t li = 0;
     while (li + 1u < dq.n_terms && dq.lead_tile_start[li + 1u] <= t) ++li;
-    float total = 0.0f, suffix = 0.0f;
-    for (uint32_t m = 0; m < dq.n_terms; ++m) {
-      total += dq.weight[m];
-      if (m >= li) suffix += dq.weight[m];
-    }
-    const bool pruning = (dq.flags & TQD_QF_PRUNE) != 0u;
-    return (pruning && suffix < kOrDeadFrac * total) ? std::max<uint32_t>(1u, tc / kOrDeadDiv) : tc;
+    return li;
+  };
+  auto tile_cost_at = [&](size_t qi, uint32_t t) -> uint32_t {
+    if (!or_cand) return std::max<uint32_t>(1u, g.tile_cost[qi]);
+    return lead_cost[qi * TQ_MAX_TERMS + leader_of(g.queries[qi], t)];
   };
   // first tile >= t of query qi where the cost changes (the end of the leader's run)
   auto cost_run_end = [&](size_t qi, uint32_t t) -> uint32_t {
     const TqdQuery &dq = g.queries[qi];
     if (!or_cand) return dq.n_tiles;
-    uint32_t li = 0;
-    while (li + 1u < dq.n_terms && dq.lead_tile_start[li + 1u] <= t) ++li;
-    return std::min<uint32_t>(dq.n_tiles, dq.lead_tile_start[li + 1u]);
+    return std::min<uint32_t>(dq.n_tiles, dq.lead_tile_start[leader_of(dq, t) + 1u]);
   };
   uint64_t total_cost = 0;
   for (size_t i = 0; i < g.queries.size(); ++i) {
@@ -794,7 +806,11 @@ int build_group_chunks(Group &g, bool or_windows) {
       t = e;
     }
   }
-  const uint64_t n_target = or_win ? 8192u : (or_cand ? 8u * kAndChunks : kAndChunks);
+  // candidate unions: smaller chunks balance better (the work per tile swings with the
+  // threshold); with large k the partial lists (1 KB per chunk and query) and the host's
+  // planning time per chunk weigh more
+  const uint64_t n_target =
+      or_win ? 8192u : (or_cand ? (g.max_k <= 16u ? 8u : 4u) * kAndChunks : kAndChunks);
   const uint64_t cost_target = std::max<uint64_t>(or_win ? 1u : 128u,
                                                   (total_cost + n_target - 1) / n_target);
   g.chunk_starts.clear();

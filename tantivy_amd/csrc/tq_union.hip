@@ -641,6 +641,9 @@ __device__ __forceinline__ void union_body(const TqkScanParams &p) {
         alive = false;  // list m's tile scores this doc
       }
     }
+    // the score is final: below the threshold it cannot enter the top-k (equal scores stay: ties
+    // resolve by doc id in the collector)
+    if (prune && alive) alive = sortable(s) >= thr;
     if (alive) alive = doc_is_alive(seg, doc);
     const uint64_t hit = __ballot(alive);
     if (hit) {
