@@ -106,6 +106,16 @@ int tq_segment_upload(tq_ctx *ctx, int device, uint32_t max_doc, const uint8_t *
                       size_t idx_len, const uint8_t *pos, size_t pos_len,
                       const uint8_t *fieldnorm, size_t fn_len, uint8_t record_option,
                       tq_segment **out);
+/* The same for sub-files that are ALREADY in device memory on `device` (written by
+ * tq_encode_postings_device / tq_encode_positions_device, or copied there by the caller): the
+ * bytes are copied device to device and the library keeps no host copy — tq_term_prepare then
+ * walks skip lists and positions headers in HBM (tq_prepare.hip) and builds the dense-list
+ * tables with device scans; only a few dozen bytes of facts per term cross back to the host.
+ * d_idx includes the 8-byte total_num_tokens header like idx above. */
+int tq_segment_upload_device(tq_ctx *ctx, int device, uint32_t max_doc, const uint8_t *d_idx,
+                             size_t idx_len, const uint8_t *d_pos, size_t pos_len,
+                             const uint8_t *d_fieldnorm, size_t fn_len, uint8_t record_option,
+                             tq_segment **out);
 void tq_segment_free(tq_segment *seg);
 
 /* replaces: InvertedIndexReader::read_postings_from_terminfo + BlockSegmentPostings::open +
@@ -304,7 +314,12 @@ int tq_last_batch_stats(tq_segment *seg, tq_batch_stats *out);
  *        (serializer.rs:130-135); a caller whose Bm25Weights use global statistics passes
  *        ((1 + d)^2 - 1) * 1e6 with d = relative difference of the two averages and pruning
  *        stays exact (the reference accepts the approximation, term_scorer.rs:58-70),
- *        "dense_budget_x" (default 4: bitmaps together stay below this multiple of the segment),
+ *        "dense_budget_x" (default 6: bitmaps + doc matrix + position directories together stay
+ *        below this multiple of the segment), "docmat" (0/1, default 1: the first 56 dense lists
+ *        also get a column in a doc-major matrix: one 8-byte word per doc = fieldnorm id + the
+ *        doc's membership in those lists), "device_prepare" (0/1, default 0: tq_term_prepare
+ *        works on the device copy even when a host copy exists; always so for segments from
+ *        tq_segment_upload_device),
  *        "use_dpp" (0/1: DPP or ds_bpermute prefix sums) */
 int tq_set_option(tq_segment *seg, const char *name, int64_t value);
 

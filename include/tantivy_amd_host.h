@@ -106,6 +106,15 @@ int tqh_searcher_add_segment_with_store(tqh_searcher *s, int device, uint32_t ma
                                         const uint8_t *fieldnorm, size_t fn_len,
                                         const uint8_t *store, size_t store_len);
 
+/* The same for sub-files that are resident on `device` (tq_segment_upload_device): device
+ * pointers; total_num_tokens = the value of the .idx sub-file's 8-byte header. */
+int tqh_searcher_add_segment_device_with_store(tqh_searcher *s, int device, uint32_t max_doc,
+                                               uint8_t record_option, const uint8_t *d_idx,
+                                               size_t idx_len, const uint8_t *d_pos, size_t pos_len,
+                                               const uint8_t *d_fieldnorm, size_t fn_len,
+                                               uint64_t total_num_tokens, const uint8_t *store,
+                                               size_t store_len);
+
 #ifdef __cplusplus
 }
 #endif

@@ -57,7 +57,8 @@ class TqhQuery(C.Structure):
 _lib = None
 
 EXPORTS = [
-    "tq_init", "tq_shutdown", "tq_last_error", "tq_segment_upload", "tq_segment_free",
+    "tq_init", "tq_shutdown", "tq_last_error", "tq_segment_upload", "tq_segment_upload_device",
+    "tq_segment_free",
     "tq_term_prepare", "tq_search_batch", "tq_search_batch_device", "tq_search_batch_opts",
     "tq_search_batch_device_opts", "tq_merge_topk",
     "tq_merge_topk_device", "tq_decode_postings", "tq_decode_position_deltas",
@@ -72,7 +73,7 @@ EXPORTS = [
     "tqh_bm25_for_terms", "tqh_segment_raw", "tqh_term_handle", "tqh_term_dictionary_values",
     "tqh_term_info_store_open", "tqh_term_info_store_free", "tqh_term_info_store_num_terms",
     "tqh_term_info_store_get", "tqh_term_info_store_write", "tqh_searcher_add_segment_with_store",
-    "tqh_count_prepared",
+    "tqh_count_prepared", "tqh_searcher_add_segment_device_with_store",
 ]
 
 
@@ -92,6 +93,8 @@ def lib():
     L.tq_shutdown.argtypes = [vp]
     L.tq_segment_upload.argtypes = [vp, C.c_int, C.c_uint32, vp, C.c_size_t, vp, C.c_size_t, vp,
                                     C.c_size_t, C.c_uint8, C.POINTER(vp)]
+    L.tq_segment_upload_device.argtypes = [vp, C.c_int, C.c_uint32, vp, C.c_size_t, vp, C.c_size_t, vp,
+                                           C.c_size_t, C.c_uint8, C.POINTER(vp)]
     L.tq_segment_free.argtypes = [vp]
     L.tq_term_prepare.argtypes = [vp, C.c_uint64, C.c_uint32, C.c_uint64, C.c_uint32, C.c_uint32,
                                   u32p]
@@ -160,6 +163,9 @@ def lib():
     L.tqh_searcher_add_segment_with_store.argtypes = [vp, C.c_int, C.c_uint32, C.c_uint8, vp,
                                                       C.c_size_t, vp, C.c_size_t, vp, C.c_size_t,
                                                       vp, C.c_size_t]
+    L.tqh_searcher_add_segment_device_with_store.argtypes = [
+        vp, C.c_int, C.c_uint32, C.c_uint8, vp, C.c_size_t, vp, C.c_size_t, vp, C.c_size_t,
+        C.c_uint64, vp, C.c_size_t]
     _lib = L
     return L
 
@@ -363,6 +369,20 @@ class DeviceIndex:
             idx.ctypes.data, idx.size, pos.ctypes.data if pos is not None else None,
             pos.size if pos is not None else 0, fn.ctypes.data if fn is not None else None,
             fn.size if fn is not None else 0, tis, n), host=True)
+        self.n_segments += 1
+
+    def add_segment_device(self, max_doc, record_option, d_idx, d_pos, d_fieldnorm,
+                           total_num_tokens, term_info_store, device=0):
+        """Segment whose sub-files are torch uint8 tensors on the GPU (d_idx with the 8-byte
+        header; d_pos / d_fieldnorm may be None); term ids = ordinals of term_info_store."""
+        st = np.frombuffer(bytes(term_info_store), dtype=np.uint8)
+        _check(lib().tqh_searcher_add_segment_device_with_store(
+            self._s, int(device), int(max_doc), int(record_option), d_idx.data_ptr(), d_idx.numel(),
+            d_pos.data_ptr() if d_pos is not None else None,
+            d_pos.numel() if d_pos is not None else 0,
+            d_fieldnorm.data_ptr() if d_fieldnorm is not None else None,
+            d_fieldnorm.numel() if d_fieldnorm is not None else 0, int(total_num_tokens),
+            st.ctypes.data, st.size), host=True)
         self.n_segments += 1
 
     def add_remote_stats(self, max_doc, total_num_tokens, doc_freqs):

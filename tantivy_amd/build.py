@@ -13,6 +13,7 @@ SOURCES = [
     os.path.join(HERE, "csrc", "tq_phrase.hip"),
     os.path.join(HERE, "csrc", "tq_misc.hip"),
     os.path.join(HERE, "csrc", "tq_encode.hip"),
+    os.path.join(HERE, "csrc", "tq_prepare.hip"),
     os.path.join(HERE, "csrc", "tq_api.cpp"),
     os.path.join(HERE, "csrc", "tq_comm.cpp"),
     os.path.join(HERE, "host", "searcher.cpp"),
@@ -23,6 +24,7 @@ HEADERS = [
     os.path.join(HERE, "csrc", "tq_common.hpp"),
     os.path.join(HERE, "csrc", "tq_device.h"),
     os.path.join(HERE, "csrc", "tq_launch.h"),
+    os.path.join(HERE, "csrc", "tq_prepare.h"),
     os.path.join(HERE, "host", "searcher.hpp"),
     os.path.join(HERE, "host", "bm25.hpp"),
     os.path.join(HERE, "host", "term_info_store.hpp"),

@@ -21,6 +21,7 @@
 #include "../../include/tantivy_amd.h"
 #include "tq_device.h"
 #include "tq_launch.h"
+#include "tq_prepare.h"
 
 namespace {
 
@@ -87,6 +88,7 @@ struct TermHost {
   void *blob = nullptr;  // one device allocation holding every per-term array
   void *dense_blob = nullptr;  // bitmap + rank directory of a dense list
   void *posdir_blob = nullptr; // position directory of a dense list with positions
+  void *pos_blob = nullptr;    // device-side prepare: positions tables (sized after the walk)
   uint32_t doc_freq = 0, n_blocks = 0, n_full = 0, n_tail = 0;
   uint32_t last_doc = 0;
   uint64_t postings_len = 0, positions_len = 0;
@@ -135,6 +137,7 @@ struct Options {
   int dense_budget_x = 6;  // ... while bitmaps + doc matrix stay below this multiple of the segment's bytes
   int use_dense = 1;  // let the scan kernels use them
   int docmat = 1;     // also build the doc-major matrix of the dense lists
+  int device_prepare = 0;  // walk skip lists / build dense tables on the device even with a host copy
   int or_windows = -1;  // OR: 1 = window-parallel kernel, 0 = candidate-driven kernel, -1 = auto
   int bound_slack_ppm = 0;  // block-max bounds are widened by (1 + ppm * 1e-6), see block_max_score
                         // (windows for exhaustive scans, candidates when pruning)
@@ -159,7 +162,9 @@ struct tq_segment {
   hipStream_t stream = nullptr;
   uint32_t max_doc = 0;
   uint8_t record_option = 0;
-  std::vector<uint8_t> h_idx, h_pos;
+  std::vector<uint8_t> h_idx, h_pos;  // host copies (empty for a device-resident upload)
+  size_t idx_len = 0, pos_len = 0;    // sizes of the sub-files in HBM
+  TqpInfo *d_tp_info = nullptr;       // device-side prepare: result slots (info + positions result)
   uint8_t *d_idx = nullptr, *d_pos = nullptr, *d_fn = nullptr, *d_alive = nullptr;
   uint64_t *d_docmat = nullptr;  // doc-major matrix of the dense lists (TqdSegment::docmat)
   uint32_t n_mat_slots = 0;
@@ -192,15 +197,20 @@ struct tq_segment {
   bool stage_in_flight = false;
   unsigned long long *d_match_counter = nullptr;
   Options opt;
-  size_t dense_budget() const {
-    return (size_t)opt.dense_budget_x * (h_idx.size() + h_pos.size() + max_doc);
-  }
+  size_t dense_budget() const { return (size_t)opt.dense_budget_x * (idx_len + pos_len + max_doc); }
+  bool device_prepare() const { return h_idx.empty() || opt.device_prepare != 0; }
   tq_batch_stats stats{};
   bool stats_pending = false;
 };
 
 namespace {
 int sync_terms(tq_segment *s, hipStream_t st);
+int term_prepare_device(tq_segment *s, uint64_t postings_off, uint32_t postings_len,
+                        uint64_t positions_off, uint32_t positions_len, uint32_t doc_freq,
+                        tq_term_handle *out);
+int build_dense_device(tq_segment *s, uint32_t handle);
+int register_term(tq_segment *s, const TqdTerm &dt, const TermHost &th, uint64_t postings_off,
+                  tq_term_handle *out);
 
 // Orders work about to be enqueued on `st` after the segment's previous batch, whatever stream
 // that batch ran on (no-op when it is the same stream: stream order already holds).
@@ -344,9 +354,10 @@ int tq_init(const int *device_ids, int n_devices, tq_ctx **out) {
 
 void tq_shutdown(tq_ctx *ctx) { delete ctx; }
 
-int tq_segment_upload(tq_ctx *ctx, int device, uint32_t max_doc, const uint8_t *idx,
-                      size_t idx_len, const uint8_t *pos, size_t pos_len, const uint8_t *fieldnorm,
-                      size_t fn_len, uint8_t record_option, tq_segment **out) {
+static int segment_upload_common(tq_ctx *ctx, int device, uint32_t max_doc, const uint8_t *idx,
+                                 size_t idx_len, const uint8_t *pos, size_t pos_len,
+                                 const uint8_t *fieldnorm, size_t fn_len, uint8_t record_option,
+                                 bool from_device, tq_segment **out) {
   if (!ctx || !out || !idx) return fail(TQ_ERR_INVALID, "tq_segment_upload: null argument");
   if (idx_len < 8) return fail(TQ_ERR_FORMAT, "idx sub-file shorter than its 8-byte header");
   if (record_option > TQ_WITH_FREQS_AND_POSITIONS)
@@ -361,12 +372,17 @@ int tq_segment_upload(tq_ctx *ctx, int device, uint32_t max_doc, const uint8_t *
   s->device = device;
   s->max_doc = max_doc;
   s->record_option = record_option;
-  s->h_idx.assign(idx, idx + idx_len);
-  if (pos && pos_len) s->h_pos.assign(pos, pos + pos_len);
+  s->idx_len = idx_len;
+  s->pos_len = (pos && pos_len) ? pos_len : 0;
+  if (!from_device) {
+    s->h_idx.assign(idx, idx + idx_len);
+    if (pos && pos_len) s->h_pos.assign(pos, pos + pos_len);
+  }
+  const hipMemcpyKind kind = from_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
   auto up = [&](uint8_t **dst, const uint8_t *src, size_t n) -> int {
     HIP_TRY(hipMalloc((void **)dst, n + PAD));
     HIP_TRY(hipMemset(*dst + n, 0, PAD));
-    HIP_TRY(hipMemcpy(*dst, src, n, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(*dst, src, n, kind));
     return TQ_OK;
   };
   int rc = up(&s->d_idx, idx, idx_len);
@@ -386,6 +402,7 @@ int tq_segment_upload(tq_ctx *ctx, int device, uint32_t max_doc, const uint8_t *
       if (e == hipSuccess) e = hipEventCreate(&s->ev_k1[i]);
     }
     if (e == hipSuccess) e = hipMalloc((void **)&s->d_match_counter, sizeof(unsigned long long));
+    if (e == hipSuccess) e = hipMalloc((void **)&s->d_tp_info, 2 * sizeof(TqpInfo));
     if (e != hipSuccess) rc = fail(TQ_ERR_HIP, "segment setup: %s", hipGetErrorString(e));
   }
   if (rc != TQ_OK) {
@@ -398,13 +415,40 @@ int tq_segment_upload(tq_ctx *ctx, int device, uint32_t max_doc, const uint8_t *
   s->dseg.max_doc = max_doc;
   s->dseg.const_fieldnorm_id = 1;  // FieldNormReader::constant(max_doc, 1)
   s->dseg.min_fieldnorm_id = 1;
-  if (fieldnorm) {
+  if (fieldnorm && !from_device) {
     uint8_t mn = 255;
     for (uint32_t d = 0; d < max_doc; ++d) mn = fieldnorm[d] < mn ? fieldnorm[d] : mn;
+    s->dseg.min_fieldnorm_id = max_doc ? mn : 0;
+  } else if (fieldnorm) {  // smallest fieldnorm id present: a device reduction, 4 bytes back
+    uint32_t *slot = (uint32_t *)s->d_tp_info;
+    uint32_t mn = 255;
+    hipError_t e = hipMemcpy(slot, &mn, 4, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = tqp_launch_min_fieldnorm(s->d_fn, max_doc, slot, s->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(&mn, slot, 4, hipMemcpyDeviceToHost, s->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(s->stream);
+    if (e != hipSuccess) {
+      tq_segment_free(s);
+      return fail(TQ_ERR_HIP, "fieldnorm scan: %s", hipGetErrorString(e));
+    }
     s->dseg.min_fieldnorm_id = max_doc ? mn : 0;
   }
   *out = s;
   return TQ_OK;
+}
+
+int tq_segment_upload(tq_ctx *ctx, int device, uint32_t max_doc, const uint8_t *idx,
+                      size_t idx_len, const uint8_t *pos, size_t pos_len, const uint8_t *fieldnorm,
+                      size_t fn_len, uint8_t record_option, tq_segment **out) {
+  return segment_upload_common(ctx, device, max_doc, idx, idx_len, pos, pos_len, fieldnorm, fn_len,
+                               record_option, false, out);
+}
+
+int tq_segment_upload_device(tq_ctx *ctx, int device, uint32_t max_doc, const uint8_t *d_idx,
+                             size_t idx_len, const uint8_t *d_pos, size_t pos_len,
+                             const uint8_t *d_fieldnorm, size_t fn_len, uint8_t record_option,
+                             tq_segment **out) {
+  return segment_upload_common(ctx, device, max_doc, d_idx, idx_len, d_pos, pos_len, d_fieldnorm,
+                               fn_len, record_option, true, out);
 }
 
 void tq_segment_free(tq_segment *s) {
@@ -418,12 +462,15 @@ void tq_segment_free(tq_segment *s) {
     if (t.dense_blob) (void)hipFree(t.dense_blob);
   for (auto &t : s->terms)
     if (t.posdir_blob) (void)hipFree(t.posdir_blob);
+  for (auto &t : s->terms)
+    if (t.pos_blob) (void)hipFree(t.pos_blob);
   if (s->d_terms) (void)hipFree(s->d_terms);
   if (s->d_idx) (void)hipFree(s->d_idx);
   if (s->d_pos) (void)hipFree(s->d_pos);
   if (s->d_fn) (void)hipFree(s->d_fn);
   if (s->d_alive) (void)hipFree(s->d_alive);
   if (s->d_docmat) (void)hipFree(s->d_docmat);
+  if (s->d_tp_info) (void)hipFree(s->d_tp_info);
   if (s->d_match_counter) (void)hipFree(s->d_match_counter);
   s->d_stage.release();
   s->d_partials.release();
@@ -456,11 +503,14 @@ int tq_term_prepare(tq_segment *s, uint64_t postings_off, uint32_t postings_len,
     return TQ_OK;
   }
   if (doc_freq == 0) return fail(TQ_ERR_INVALID, "tq_term_prepare: doc_freq 0 (term absent)");
-  const size_t body_len = s->h_idx.size() - 8;
+  const size_t body_len = s->idx_len - 8;
   if (postings_off > body_len || (uint64_t)postings_len > body_len - postings_off)
     return fail(TQ_ERR_FORMAT, "postings_range [%llu,+%u) outside the idx body (%zu)",
                 (unsigned long long)postings_off, postings_len, body_len);
   HIP_TRY(hipSetDevice(s->device));
+  if (s->device_prepare())
+    return term_prepare_device(s, postings_off, postings_len, positions_off, positions_len, doc_freq,
+                               out);
   const uint8_t *data = s->h_idx.data() + 8 + postings_off;
   const size_t len = postings_len;
   const uint64_t abs0 = 8 + postings_off;  // offset of `data` inside the uploaded sub-file
@@ -664,6 +714,34 @@ int tq_term_prepare(tq_segment *s, uint64_t postings_off, uint32_t postings_len,
   th.postings_len = postings_len;
   th.positions_len = want_pos ? positions_len : 0;
   th.n_positions = want_pos ? running_pos : 0;
+  return register_term(s, dt, th, postings_off, out);
+}
+
+}  // extern "C"
+
+namespace {
+
+const char *tqp_message(uint32_t st) {
+  switch (st) {
+    case TQP_BAD_SKIP_LEN: return "bad skip_len";
+    case TQP_SKIP_TOO_SHORT: return "skip data too short";
+    case TQP_NOT_INCREASING: return "skip last_doc not increasing";
+    case TQP_BAD_TF_WIDTH: return "tf bit width > 32";
+    case TQP_TOO_MANY_POSITIONS: return "term with more than 2^32 positions";
+    case TQP_PAYLOAD_TOO_LONG: return "bitpacked payload exceeds the list";
+    case TQP_TRUNCATED_TAIL: return "truncated vint tail";
+    case TQP_DOC_OUT_OF_RANGE: return "doc id >= max_doc / TERMINATED";
+    case TQP_BAD_POS_HEADER: return "bad positions header";
+    case TQP_POS_COUNT_MISMATCH: return "positions stream and postings disagree on the number of positions";
+    case TQP_BAD_POS_WIDTH: return "position bit width > 32";
+    case TQP_POS_PAYLOAD_TOO_LONG: return "bitpacked positions exceed the range";
+    default: return "unknown";
+  }
+}
+
+// the part of tq_term_prepare both paths share: the handle, and the dense-list structures
+int register_term(tq_segment *s, const TqdTerm &dt, const TermHost &th, uint64_t postings_off,
+                  tq_term_handle *out) {
   const uint32_t handle = (uint32_t)s->terms.size();
   s->terms.push_back(th);
   s->h_dterms.push_back(dt);
@@ -675,15 +753,217 @@ int tq_term_prepare(tq_segment *s, uint64_t postings_off, uint32_t postings_len,
   const size_t dense_bytes = (((size_t)s->max_doc + 31) / 32 + 1) * sizeof(uint2);
   const size_t budget = s->dense_budget();
   if (s->opt.dense && s->max_doc >= 4096u &&
-      (uint64_t)doc_freq * (uint64_t)s->opt.dense_ratio >= s->max_doc &&
+      (uint64_t)th.doc_freq * (uint64_t)s->opt.dense_ratio >= s->max_doc &&
       s->dense_bytes_total + dense_bytes <= budget) {
     s->dense_bytes_total += dense_bytes;
-    return build_dense(s, handle);
+    return s->device_prepare() ? build_dense_device(s, handle) : build_dense(s, handle);
   }
   return TQ_OK;
 }
 
-}  // extern "C"
+// tq_term_prepare without a host copy of the index: two small kernels walk the list's skip data
+// and positions header where they lie in HBM (tq_prepare.hip); the host sizes the tables from
+// TermInfo, and reads back 48 bytes of facts in between (no index bytes).
+int term_prepare_device(tq_segment *s, uint64_t postings_off, uint32_t postings_len,
+                        uint64_t positions_off, uint32_t positions_len, uint32_t doc_freq,
+                        tq_term_handle *out) {
+  const uint32_t n_full = doc_freq / 128u, n_tail = doc_freq % 128u;
+  const uint32_t n_blocks = n_full + (n_tail ? 1u : 0u);
+  uint32_t shift = 7;
+  while (shift < 31 && ((uint64_t)(s->max_doc - 1) >> shift) + 1 > 2ull * n_blocks + 2) ++shift;
+  const uint32_t n_buckets = (uint32_t)(((uint64_t)(s->max_doc - 1)) >> shift) + 1;
+  const bool maybe_pos = s->record_option == TQ_WITH_FREQS_AND_POSITIONS && s->d_pos != nullptr;
+  if (maybe_pos && (positions_off > s->pos_len || (uint64_t)positions_len > s->pos_len - positions_off))
+    return fail(TQ_ERR_FORMAT, "positions_range outside the pos file");
+  auto align16 = [](size_t x) { return (x + 15) & ~(size_t)15; };
+  size_t total = 0;
+  auto place = [&](size_t bytes) {
+    const size_t o = total;
+    total = align16(total + bytes);
+    return o;
+  };
+  const size_t o_rec = place(16 * (size_t)(n_blocks + 1));
+  const size_t o_coarse = place(4 * (size_t)(n_buckets + 1));
+  const size_t o_tdocs = place(4 * (size_t)n_tail);
+  const size_t o_ttfs = place(4 * (size_t)n_tail);
+  total += PAD;
+  uint8_t *blob = nullptr;
+  HIP_TRY(hipMalloc((void **)&blob, total));
+  auto bail = [&](int rc) {
+    (void)hipFree(blob);
+    return rc;
+  };
+  hipError_t e = hipMemsetAsync(blob, 0, total, s->stream);
+  TqpPostingsParams pp{};
+  pp.idx = s->d_idx;
+  pp.pos = s->d_pos;
+  pp.postings_off = postings_off;
+  pp.positions_off = positions_off;
+  pp.postings_len = postings_len;
+  pp.positions_len = positions_len;
+  pp.doc_freq = doc_freq;
+  pp.record_option = s->record_option;
+  pp.max_doc = s->max_doc;
+  pp.want_pos = maybe_pos ? 1u : 0u;
+  pp.rec = (uint4 *)(blob + o_rec);
+  pp.tail_docs = (uint32_t *)(blob + o_tdocs);
+  pp.tail_tfs = (uint32_t *)(blob + o_ttfs);
+  pp.info = s->d_tp_info;
+  if (e == hipSuccess) e = tqp_launch_postings(pp, s->stream);
+  TqpInfo info{};
+  if (e == hipSuccess) e = hipMemcpyAsync(&info, s->d_tp_info, sizeof info, hipMemcpyDeviceToHost, s->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(s->stream);
+  if (e != hipSuccess) return bail(fail(TQ_ERR_HIP, "device term prepare: %s", hipGetErrorString(e)));
+  if (info.status != TQP_OK)
+    return bail(fail(info.status == TQP_TOO_MANY_POSITIONS ? TQ_ERR_UNSUPPORTED : TQ_ERR_FORMAT,
+                     "term at %llu: %s", (unsigned long long)postings_off, tqp_message(info.status)));
+  e = tqp_launch_coarse((const uint4 *)(blob + o_rec), n_blocks, shift, n_buckets,
+                        (uint32_t *)(blob + o_coarse), s->stream);
+  if (e != hipSuccess) return bail(fail(TQ_ERR_HIP, "coarse table: %s", hipGetErrorString(e)));
+  // positions tables, sized from the walk
+  const bool want_pos = maybe_pos && info.record == TQ_WITH_FREQS_AND_POSITIONS;
+  uint8_t *pblob = nullptr;
+  uint32_t n_pos_tail = 0;
+  size_t o_pboff = 0, o_ptail = 0;
+  if (want_pos) {
+    const uint64_t tail_cap = info.n_positions - info.n_pos_blocks * 128ull;
+    if (tail_cap > 127ull)
+      return bail(fail(TQ_ERR_FORMAT, "positions stream and postings disagree on the number of positions"));
+    size_t ptotal = 0;
+    o_pboff = 0;
+    ptotal = align16(8 * (size_t)info.n_pos_blocks);
+    o_ptail = ptotal;
+    ptotal = align16(ptotal + 4 * (size_t)tail_cap) + PAD;
+    e = hipMalloc((void **)&pblob, ptotal);
+    if (e == hipSuccess) e = hipMemsetAsync(pblob, 0, ptotal, s->stream);
+    TqpPositionsParams qp{};
+    qp.pos = s->d_pos;
+    qp.positions_off = positions_off;
+    qp.pos_hdr = info.pos_hdr;
+    qp.n_pos_blocks = info.n_pos_blocks;
+    qp.n_positions = info.n_positions;
+    qp.positions_len = positions_len;
+    qp.pos_tail_cap = (uint32_t)tail_cap;
+    qp.pos_blk = (uint64_t *)(pblob + o_pboff);
+    qp.pos_tail = (uint32_t *)(pblob + o_ptail);
+    qp.result = (uint32_t *)(s->d_tp_info + 1);
+    uint32_t res[2] = {0, 0};
+    if (e == hipSuccess) e = tqp_launch_positions(qp, s->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(res, s->d_tp_info + 1, sizeof res, hipMemcpyDeviceToHost, s->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(s->stream);
+    if (e != hipSuccess || res[0] != TQP_OK) {
+      if (pblob) (void)hipFree(pblob);
+      return bail(e != hipSuccess ? fail(TQ_ERR_HIP, "device positions prepare: %s", hipGetErrorString(e))
+                                  : fail(TQ_ERR_FORMAT, "term at %llu: %s", (unsigned long long)postings_off,
+                                         tqp_message(res[0])));
+    }
+    n_pos_tail = res[1];
+  } else {
+    HIP_TRY(hipStreamSynchronize(s->stream));
+  }
+  TqdTerm dt{};
+  dt.rec = (const uint4 *)(blob + o_rec);
+  dt.coarse = (const uint32_t *)(blob + o_coarse);
+  dt.tail_docs = (const uint32_t *)(blob + o_tdocs);
+  dt.tail_tfs = (const uint32_t *)(blob + o_ttfs);
+  dt.pos_blk = (const uint64_t *)(pblob ? pblob + o_pboff : blob + o_rec);
+  dt.pos_tail = (const uint32_t *)(pblob ? pblob + o_ptail : blob + o_rec);
+  dt.payload_base = 8 + postings_off + info.payload;
+  dt.n_full = n_full;
+  dt.n_tail = n_tail;
+  dt.n_blocks = n_blocks;
+  dt.doc_freq = doc_freq;
+  dt.n_pos_blocks = want_pos ? (uint32_t)info.n_pos_blocks : 0u;
+  dt.n_pos_tail = n_pos_tail;
+  dt.has_freq = info.record != TQ_BASIC ? 1u : 0u;
+  dt.coarse_shift = shift;
+  TermHost th;
+  th.blob = blob;
+  th.pos_blob = pblob;
+  th.doc_freq = doc_freq;
+  th.n_blocks = n_blocks;
+  th.n_full = n_full;
+  th.n_tail = n_tail;
+  th.last_doc = info.last_doc;
+  th.postings_len = postings_len;
+  th.positions_len = want_pos ? positions_len : 0;
+  th.n_positions = want_pos ? info.n_positions : 0;
+  return register_term(s, dt, th, postings_off, out);
+}
+
+// build_dense without the host: bitmap bits by atomic OR, rank directory and position directory
+// by device scans; 4 bytes (the validity flag) come back.
+int build_dense_device(tq_segment *s, uint32_t handle) {
+  int rc = sync_terms(s, s->stream);
+  if (rc != TQ_OK) return rc;
+  TermHost &t = s->terms[handle];
+  const size_t bytes = (size_t)t.doc_freq * sizeof(uint32_t);
+  rc = s->d_misc.ensure(2 * bytes + 64);
+  if (rc != TQ_OK) return rc;
+  uint32_t *dd = (uint32_t *)s->d_misc.p, *dt = dd + t.doc_freq;
+  hipError_t e = tqk_launch_decode_list(s->dseg, s->d_terms, handle, t.n_blocks, dd, dt,
+                                        s->opt.use_dpp != 0, s->stream);
+  if (e != hipSuccess) return fail(TQ_ERR_HIP, "decode launch: %s", hipGetErrorString(e));
+  const size_t n_words = ((size_t)s->max_doc + 31) / 32 + 1;
+  void *blob = nullptr;
+  HIP_TRY(hipMalloc(&blob, n_words * sizeof(uint2)));
+  uint32_t *bad = (uint32_t *)s->d_tp_info;
+  e = hipMemsetAsync(blob, 0, n_words * sizeof(uint2), s->stream);
+  if (e == hipSuccess) e = hipMemsetAsync(bad, 0, 4, s->stream);
+  if (e == hipSuccess)
+    e = tqp_launch_dense(dd, t.doc_freq, s->max_doc, (uint2 *)blob, (uint32_t)n_words, bad, s->stream);
+  uint32_t h_bad = 0;
+  if (e == hipSuccess) e = hipMemcpyAsync(&h_bad, bad, 4, hipMemcpyDeviceToHost, s->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(s->stream);
+  if (e != hipSuccess || h_bad) {
+    (void)hipFree(blob);
+    return e != hipSuccess ? fail(TQ_ERR_HIP, "dense tables: %s", hipGetErrorString(e))
+                           : fail(TQ_ERR_FORMAT, "posting list not strictly increasing below max_doc");
+  }
+  t.dense_blob = blob;
+  s->h_dterms[handle].dense = (const uint2 *)blob;
+  s->d_terms_dirty = true;
+  if (s->n_mat_slots < TQD_MAT_SLOTS && s->opt.docmat) {  // the list's column of the doc matrix
+    const size_t mat_bytes = (size_t)s->max_doc * sizeof(uint64_t);
+    if (!s->d_docmat && s->dense_bytes_total + mat_bytes <= s->dense_budget()) {
+      HIP_TRY(hipMalloc((void **)&s->d_docmat, mat_bytes + PAD));
+      HIP_TRY(hipMemsetAsync((uint8_t *)s->d_docmat + mat_bytes, 0, PAD, s->stream));
+      e = tqk_launch_docmat_init(s->d_docmat, s->d_fn, s->dseg.const_fieldnorm_id, s->max_doc, s->stream);
+      if (e != hipSuccess) return fail(TQ_ERR_HIP, "docmat init: %s", hipGetErrorString(e));
+      s->dense_bytes_total += mat_bytes;
+      s->dseg.docmat = s->d_docmat;
+    }
+    if (s->d_docmat) {
+      const uint32_t slot = s->n_mat_slots++;
+      e = tqk_launch_docmat_set(s->d_docmat, dd, t.doc_freq, slot, s->max_doc, s->stream);
+      if (e != hipSuccess) return fail(TQ_ERR_HIP, "docmat set: %s", hipGetErrorString(e));
+      s->h_dterms[handle].has_freq |= (slot + 1u) << 8;
+    }
+  }
+  if (t.positions_len > 0) {  // position directory: positions before every fourth posting
+    const size_t n_dir = ((size_t)t.doc_freq + 3) / 4 + 1;
+    void *db = nullptr;
+    HIP_TRY(hipMalloc(&db, n_dir * sizeof(uint32_t) + PAD));
+    e = tqp_launch_posdir(dt, t.doc_freq, (uint32_t *)db, (uint32_t)n_dir, s->stream);
+    uint32_t total = 0;
+    if (e == hipSuccess)
+      e = hipMemcpyAsync(&total, (uint32_t *)db + (n_dir - 1), 4, hipMemcpyDeviceToHost, s->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(s->stream);
+    if (e != hipSuccess || total != (uint32_t)t.n_positions) {
+      (void)hipFree(db);
+      return e != hipSuccess ? fail(TQ_ERR_HIP, "position directory: %s", hipGetErrorString(e))
+                             : fail(TQ_ERR_FORMAT, "term freqs sum to %u positions, the stream holds %llu",
+                                    total, (unsigned long long)t.n_positions);
+    }
+    t.posdir_blob = db;
+    s->h_dterms[handle].pos_dir = (const uint32_t *)db;
+    s->dense_bytes_total += n_dir * sizeof(uint32_t);
+  }
+  HIP_TRY(hipStreamSynchronize(s->stream));
+  return TQ_OK;
+}
+
+}  // namespace
 
 namespace {
 
@@ -1689,6 +1969,8 @@ int tq_set_option(tq_segment *s, const char *name, int64_t value) {
     s->opt.dense = value != 0;
   else if (!strcmp(name, "docmat"))  // affects terms prepared afterwards
     s->opt.docmat = value != 0;
+  else if (!strcmp(name, "device_prepare"))  // affects terms prepared afterwards
+    s->opt.device_prepare = value != 0;
   else
     return fail(TQ_ERR_INVALID, "unknown option '%s'", name);
   return TQ_OK;

@@ -115,6 +115,26 @@ int tqh_searcher_add_segment_with_store(tqh_searcher *s, int device, uint32_t ma
   });
 }
 
+// The same for a segment whose sub-files are device-resident (tq_segment_upload_device).
+int tqh_searcher_add_segment_device_with_store(tqh_searcher *s, int device, uint32_t max_doc,
+                                               uint8_t record_option, const uint8_t *d_idx,
+                                               size_t idx_len, const uint8_t *d_pos, size_t pos_len,
+                                               const uint8_t *d_fieldnorm, size_t fn_len,
+                                               uint64_t total_num_tokens, const uint8_t *store,
+                                               size_t store_len) {
+  return guard([&] {
+    if (!s) throw TantivyError(TantivyError::InvalidArgument, "null searcher");
+    auto st = std::make_shared<TermInfoStore>(TermInfoStore::open(store, store_len));
+    auto seg = std::make_shared<SegmentReader>(SegmentReader::DeviceResident{}, s->ctx, device,
+                                               (uint32_t)s->segments.size(), max_doc, record_option,
+                                               d_idx, idx_len, d_pos, pos_len, d_fieldnorm, fn_len,
+                                               total_num_tokens);
+    seg->set_term_info_store(st);
+    s->segments.push_back(seg);
+    s->searcher.reset(new Searcher(s->segments));
+  });
+}
+
 // Bm25 statistics of a segment that lives on another rank (one segment per GPU).
 int tqh_searcher_add_remote_stats(tqh_searcher *s, uint64_t max_doc, uint64_t total_num_tokens,
                                   const uint32_t *term_ids, const uint32_t *doc_freqs,

@@ -33,6 +33,16 @@ SegmentReader::SegmentReader(tq_ctx *ctx, int device, uint32_t segment_ord, uint
   for (int i = 0; i < 8; ++i) t |= (uint64_t)idx[i] << (8 * i);
   total_num_tokens_ = t;
 }
+SegmentReader::SegmentReader(DeviceResident, tq_ctx *ctx, int device, uint32_t segment_ord,
+                             uint32_t max_doc, uint8_t record_option, const uint8_t *d_idx,
+                             size_t idx_len, const uint8_t *d_pos, size_t pos_len,
+                             const uint8_t *d_fieldnorm, size_t fn_len, uint64_t total_num_tokens)
+    : segment_ord_(segment_ord), max_doc_(max_doc), record_option_(record_option),
+      total_num_tokens_(total_num_tokens) {
+  const int rc = tq_segment_upload_device(ctx, device, max_doc, d_idx, idx_len, d_pos, pos_len,
+                                          d_fieldnorm, fn_len, record_option, &seg_);
+  if (rc != TQ_OK) throw_tq(rc);
+}
 SegmentReader::~SegmentReader() { tq_segment_free(seg_); }
 
 void SegmentReader::add_term(uint32_t term_id, const TermInfo &info) { terms_[term_id] = info; }

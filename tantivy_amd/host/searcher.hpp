@@ -50,6 +50,12 @@ class SegmentReader {
   SegmentReader(tq_ctx *ctx, int device, uint32_t segment_ord, uint32_t max_doc,
                 uint8_t record_option, const uint8_t *idx, size_t idx_len, const uint8_t *pos,
                 size_t pos_len, const uint8_t *fieldnorm, size_t fn_len);
+  // sub-files already resident on `device` (e.g. written by the device codec writers): copied
+  // device to device, no host copy kept; total_num_tokens = the 8-byte header of the .idx sub-file
+  struct DeviceResident {};
+  SegmentReader(DeviceResident, tq_ctx *ctx, int device, uint32_t segment_ord, uint32_t max_doc,
+                uint8_t record_option, const uint8_t *d_idx, size_t idx_len, const uint8_t *d_pos,
+                size_t pos_len, const uint8_t *d_fieldnorm, size_t fn_len, uint64_t total_num_tokens);
   ~SegmentReader();
   SegmentReader(const SegmentReader &) = delete;
   SegmentReader &operator=(const SegmentReader &) = delete;

@@ -316,3 +316,149 @@ def test_rccl_allgather_through_the_c_abi(ta):
     finally:
         comm.close()
         run.close()
+
+
+# ------------------------------------------------------------------ tq_term_prepare on the device
+def _search_all(dev, qs, k):
+    sc, _, dc, ct = dev.search(qs, k)
+    return [(sc[i, :int(ct[i])].tolist(), dc[i, :int(ct[i])].tolist()) for i in range(len(qs))]
+
+
+def test_device_side_term_prepare_equals_host_walk(ta):
+    """option "device_prepare": the skip lists / positions headers are walked by tq_prepare.hip in
+    HBM and the dense-list tables built by device scans; everything a search or a decode returns
+    must equal the host walk's (and the oracle's), list shapes of the edge-case test included."""
+    rng = np.random.default_rng(123)
+    md = 300_000
+    dfs = [100, 127, 128, 129, 255, 256, 257, 1, 5000, 40_000, 150_000, 64 * 128, 64 * 128 + 1, 65 * 128 + 77]
+    lists = [random_postings(rng, md, df, max_tf=7) for df in dfs]
+    lists[7] = [(md - 1, 3)]
+    positions = [[sorted(rng.choice(60, size=tf, replace=False).tolist()) for _, tf in pl] for pl in lists]
+    fieldnorms = rng.integers(1, 500, size=md).tolist()
+    for record, pos in ((O.WITH_FREQS_AND_POSITIONS, positions), (O.WITH_FREQS, None), (O.BASIC, None)):
+        pls = lists if record != O.BASIC else [[(d, 1) for d, _ in pl] for pl in lists]
+        seg = O.build_segment(md, pls, fieldnorms, record_option=record, positions=pos)
+        qs = [(O.MODE_AND, [9, 10]), (O.MODE_AND, [8, 10]), (O.MODE_AND, [4, 5, 10]), (O.MODE_OR, [0, 1, 2, 3]),
+              (O.MODE_OR, [7, 8, 9]), (O.MODE_AND, [11, 12]), (O.MODE_OR, [13, 6]), (O.MODE_AND, [13, 9])]
+        if record == O.WITH_FREQS_AND_POSITIONS:
+            qs += [(O.MODE_PHRASE, [9, 10]), (O.MODE_PHRASE, [10, 9, 8]), (O.MODE_PHRASE, [8, 13])]
+        results = []
+        for device_prepare in (0, 1):
+            dev = ta.DeviceIndex([seg])
+            try:
+                dev.set_option("device_prepare", device_prepare)
+                got = {ex: _search_all(dev, qs, 10) for ex in (1, 0) if not dev.set_option("exhaustive", ex)}
+                dec = [tuple(a.tolist() for a in dev.decode_postings(t, len(pls[t]))) for t in range(len(pls))]
+                pd = None
+                if record == O.WITH_FREQS_AND_POSITIONS:
+                    pd = [dev.decode_position_deltas(t, sum(tf for _, tf in pls[t]))[0].tolist()
+                          for t in range(len(pls))]
+                results.append((got, dec, pd))
+            finally:
+                dev.close()
+        assert results[0] == results[1]
+        for i, q in enumerate(qs):  # and the oracle
+            want = O.search(seg, q[1], q[0], 10, pruned=False)
+            assert results[1][0][1][i][1] == [d for _, d in want], q
+        for t, pl in enumerate(pls):
+            assert results[1][1][t][0] == [d for d, _ in pl]
+
+
+def test_device_side_prepare_reports_corrupt_lists(ta):
+    """the device walk maps malformed bytes to TQ_ERR_FORMAT like the host walk"""
+    rng = np.random.default_rng(5)
+    seg = O.build_segment(50_000, [random_postings(rng, 50_000, 3000, max_tf=5)], rng.integers(1, 50, size=50_000).tolist())
+    bad = O.Segment(seg.max_doc, seg.record_option, seg.idx[: seg.idx_len].copy(), np.zeros(0, np.uint8),
+                    seg.fieldnorm, seg.terms, seg.total_num_tokens)
+    bad.idx[8 + 3 + 8 * 5:8 + 3 + 8 * 5 + 4] = 0  # last_doc of skip entry 5 := 0 (not increasing)
+    for device_prepare in (0, 1):
+        dev = ta.DeviceIndex([bad])
+        try:
+            dev.set_option("device_prepare", device_prepare)
+            with pytest.raises(ta.TantivyAmdError):
+                dev.search([(O.MODE_OR, [0])], 5)
+        finally:
+            dev.close()
+
+
+def test_segment_encoded_and_opened_on_the_device(ta):
+    """Segment finalisation with the index bytes never leaving the GPU: postings + positions
+    encoded by tq_encode_*_device into device buffers, adopted with tq_segment_upload_device
+    (device-to-device), terms prepared by the device walk; only TermInfo ranges (the term
+    dictionary's values) and 48-byte fact records cross to the host.  Answers like the oracle."""
+    import ctypes as C
+
+    import torch
+
+    from tantivy_amd import binding as B
+
+    seg = O.synth_segment(120_000, n_terms=24, with_positions=True, phrase_terms=8)
+    starts, docs, tfs, pstarts, deltas = [0], [], [], [0], []
+    for t in range(len(seg.terms)):
+        d, f = O.decode_postings(seg, t)
+        docs.append(d)
+        tfs.append(f)
+        starts.append(starts[-1] + len(d))
+        ps, _ = O.decode_positions(seg, t, int(f.sum()))
+        dl = np.diff(ps.astype(np.int64), prepend=0)
+        first = np.cumsum(f.astype(np.int64)) - f
+        dl[first] = ps[first]
+        deltas.append(dl.astype(np.uint32))
+        pstarts.append(pstarts[-1] + len(dl))
+    n = len(seg.terms)
+    avg = float(np.float32(seg.total_num_tokens) / np.float32(seg.max_doc))
+    L = B.lib()
+    dev = ta.DeviceIndex([])
+    enc = ta.Encoder(0)
+    try:
+        cuda = torch.device("cuda", 0)
+        h_starts = np.array(starts, np.uint64)
+        h_pstarts = np.array(pstarts, np.uint64)
+        d_starts = torch.from_numpy(h_starts.view(np.int64)).to(cuda)
+        d_pstarts = torch.from_numpy(h_pstarts.view(np.int64)).to(cuda)
+        d_docs = torch.from_numpy(np.concatenate(docs).view(np.int32)).to(cuda)
+        d_tfs = torch.from_numpy(np.concatenate(tfs).view(np.int32)).to(cuda)
+        d_deltas = torch.from_numpy(np.concatenate(deltas).view(np.int32)).to(cuda)
+        d_fn = torch.from_numpy(seg.fieldnorm).to(cuda)
+        cap = 8 * int(starts[-1]) + 4096
+        d_idx = torch.zeros(8 + cap, dtype=torch.uint8, device=cuda)
+        d_idx[:8] = torch.from_numpy(np.frombuffer(int(seg.total_num_tokens).to_bytes(8, "little"), np.uint8).copy()).to(cuda)
+        d_ots = torch.zeros(n + 1, dtype=torch.int64, device=cuda)
+        out_len = C.c_uint64()
+        B._check(L.tq_encode_postings_device(enc.raw, n, h_starts.ctypes.data, d_starts.data_ptr(),
+                                             d_docs.data_ptr(), d_tfs.data_ptr(), d_fn.data_ptr(),
+                                             seg.max_doc, C.c_float(avg), O.WITH_FREQS_AND_POSITIONS,
+                                             d_idx.data_ptr() + 8, cap, d_ots.data_ptr(),
+                                             C.byref(out_len), None))
+        idx_len = 8 + out_len.value
+        pcap = 8 * int(pstarts[-1]) + 4096
+        d_pos = torch.zeros(pcap, dtype=torch.uint8, device=cuda)
+        d_pts = torch.zeros(n + 1, dtype=torch.int64, device=cuda)
+        plen = C.c_uint64()
+        B._check(L.tq_encode_positions_device(enc.raw, n, h_pstarts.ctypes.data, d_pstarts.data_ptr(),
+                                              d_deltas.data_ptr(), d_pos.data_ptr(), pcap,
+                                              d_pts.data_ptr(), C.byref(plen), None))
+        torch.cuda.synchronize()
+        # the device bytes equal the oracle's serializer output (checked once; not needed to search)
+        assert bytes(d_idx[:idx_len].cpu().numpy()) == bytes(seg.idx[: seg.idx_len])
+        assert bytes(d_pos[:plen.value].cpu().numpy()) == bytes(seg.pos[: seg.pos_len])
+        ots = d_ots.cpu().numpy().view(np.uint64)   # TermInfo ranges: the term dictionary's values
+        pts = d_pts.cpu().numpy().view(np.uint64)
+        infos = [(len(docs[t]), int(ots[t]), int(ots[t + 1]), int(pts[t]), int(pts[t + 1])) for t in range(n)]
+        store = ta.TermInfoStore.serialize(infos)
+        dev.add_segment_device(seg.max_doc, O.WITH_FREQS_AND_POSITIONS, d_idx[:idx_len], d_pos[:plen.value],
+                               d_fn, seg.total_num_tokens, store)
+        queries = [(O.MODE_AND, [0, 1]), (O.MODE_AND, [3, 7, 11]), (O.MODE_OR, [2, 5, 19]),
+                   (O.MODE_PHRASE, [0, 1, 2]), (O.MODE_OR, [17]), (O.MODE_PHRASE, [6, 7]), (O.MODE_AND, [20, 23])]
+        for exhaustive in (1, 0):
+            dev.set_option("exhaustive", exhaustive)
+            scores, _, dd, counts = dev.search(queries, 10)
+            for i, (mode, terms) in enumerate(queries):
+                want = O.search(seg, terms, mode, 10, pruned=False)
+                got = _hits(scores, dd, counts, i)
+                assert [d for _, d in got] == [d for _, d in want], (mode, terms)
+                for (gs, _), (ws, _) in zip(got, want):
+                    assert abs(gs - ws) <= 1e-5 * abs(ws)
+    finally:
+        enc.close()
+        dev.close()
