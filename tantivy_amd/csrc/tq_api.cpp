@@ -1702,6 +1702,7 @@ int search_batch_impl(tq_segment *s, const tq_query *queries, uint32_t n_queries
     p.debug = kDebug;
     p.or_windows = (or_windows_opt && gi != kBool) ? 1u : 0u;
     p.boolean = gi == kBool ? 1u : 0u;
+    p.small_k = g.max_k <= 16u ? 1u : 0u;
     p.bound_slack = co.bound_slack;
     p.max_terms = 0;
     for (const TqdQuery &dq : g.queries) p.max_terms = std::max(p.max_terms, dq.n_terms);

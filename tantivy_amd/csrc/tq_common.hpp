@@ -472,10 +472,13 @@ __device__ __forceinline__ uint32_t kth_largest_multi(const uint32_t (&v)[S], ui
 }
 // The same on the upper 16 bits only (first S registers of v): the result, low bits zero, still
 // has at least k values at or above it — a slightly lower, equally valid bound at half the steps.
+#ifndef TQ_KTH_LOW_BIT
+#define TQ_KTH_LOW_BIT 8
+#endif
 template <int S>
 __device__ __forceinline__ uint32_t kth_largest_hi16(const uint32_t (&v)[4], uint32_t k) {
   uint32_t ans = 0;
-  for (int bit = 31; bit >= 16; --bit) {
+  for (int bit = 31; bit >= TQ_KTH_LOW_BIT; --bit) {
     const uint32_t trial = ans | (1u << bit);
     uint32_t c = 0;
 #pragma unroll

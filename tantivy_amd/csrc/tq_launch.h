@@ -37,6 +37,7 @@ struct TqkScanParams {
   uint32_t debug;       // TQ_DEBUG ablation bits (profiling only; results are wrong when set)
   uint32_t all_dense;   // AND: every non-leader list of every query of the launch has a bitmap
   uint32_t boolean;     // union kernel: queries carry roles / clauses / min_should (TQ_MODE_BOOL)
+  uint32_t small_k;     // every query of the launch has k <= 16
   float bound_slack;    // >= 1: widens block-max bounds when the BM25 statistics are not the segment's own
 };
 

@@ -908,42 +908,14 @@ __device__ __forceinline__ void union_body(const TqkScanParams &p) {
       const uint32_t prev_l = (uint32_t)__builtin_amdgcn_readlane((int)prev_mine, (int)b);
       uint32_t c0, c1, t0, t1f;
       bool alive0 = true, alive1 = true;
-      if (mo_l.x == META_TAIL) {
-        decode_tfs(idx, lead, mo_l, lane, t0, t1f);  // tail padding reads as tf 0
-        if (prune) {
-          const uint32_t tfmin = (uint32_t)__builtin_amdgcn_readlane((int)tfmin_mine, (int)b);
-          alive0 = t0 >= tfmin;
-          alive1 = t1f >= tfmin;
-          if (!(__ballot(alive0) | __ballot(alive1))) continue;
-        }
-        decode_docs<USE_DPP>(idx, lead, mo_l, prev_l, lane, c0, c1);
-      } else {
-        // ONE 16-byte load per lane brings the block's doc + tf payload (<= 1008 B) into LDS:
-        // one memory round trip per leader block instead of two dependent ones
-        const uint32_t doc_bits = mo_l.x & 31u;
-        const uint32_t strict = (mo_l.x >> 6) & 1u;
-        const uint32_t tf_bits = lead.has_freq ? (mo_l.x >> 8) & 0xFFu : 0u;
-        wave_mem_fence();
-        stage_payload(L.pay, idx + lead.payload_base + mo_l.y, 16u * (doc_bits + tf_bits), lane);
-        wave_mem_fence();
-        if (lead.has_freq) {
-          unpack2_lds(L.pay + 4u * doc_bits, tf_bits, lane, t0, t1f);
-          t0 += strict;  // minus-one encoding is tied to the strict flag
-          t1f += strict;
-        } else {
-          t0 = 1u;
-          t1f = 1u;
-        }
-        if (prune) {
-          const uint32_t tfmin = (uint32_t)__builtin_amdgcn_readlane((int)tfmin_mine, (int)b);
-          alive0 = t0 >= tfmin;
-          alive1 = t1f >= tfmin;
-          if (!(__ballot(alive0) | __ballot(alive1))) continue;
-        }
-        uint32_t x0, x1;
-        unpack2_lds(L.pay, doc_bits, lane, x0, x1);
-        finish_docs<USE_DPP>(x0, x1, strict, prev_l, lane, c0, c1);
+      decode_tfs(idx, lead, mo_l, lane, t0, t1f);  // tail padding reads as tf 0
+      if (prune) {
+        const uint32_t tfmin = (uint32_t)__builtin_amdgcn_readlane((int)tfmin_mine, (int)b);
+        alive0 = t0 >= tfmin;
+        alive1 = t1f >= tfmin;
+        if (!(__ballot(alive0) | __ballot(alive1))) continue;
       }
+      decode_docs<USE_DPP>(idx, lead, mo_l, prev_l, lane, c0, c1);
       alive0 = alive0 && c0 != TQD_TERMINATED;
       alive1 = alive1 && c1 != TQD_TERMINATED;
       const uint64_t m0 = __ballot(alive0), m1 = __ballot(alive1);
@@ -1007,7 +979,12 @@ static void launch_or_t(const TqkScanParams &p, bool /*dpp*/, dim3 grid, dim3 bl
     else                                                                  \
       union_kernel<KPL, PR, BO><<<grid, dim3(64), 0, st>>>(p);            \
   } while (0)
-    if (p.boolean) {
+    // Pure unions with small k run the single-stage walk too (every list after the leader probed
+    // in turn, the bound re-tested with the exact partial sums): with a high threshold most
+    // candidates die on the first test, which needs the fieldnorm byte only, and the two-stage
+    // form's doc-matrix gather (8 B/doc: one 128-byte line per candidate) costs more than it
+    // saves.  A pure union is a boolean query whose leading clause holds all its terms.
+    if (p.boolean || (p.small_k && !p.exhaustive)) {
       if (p.exhaustive)
         TQ_UNION(false, true);
       else
