@@ -6,6 +6,8 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libtantivy_amd.so")
+if os.environ.get("TQ_LIB_PATH"):  # experiments: a variant build (tools/build_variant.py)
+    LIB_PATH = os.environ["TQ_LIB_PATH"]
 
 TERMINATED = 0x7FFFFFFF
 TERM_ABSENT = 0xFFFFFFFF

@@ -55,8 +55,14 @@ def build(force=False, verbose=False):
     os.makedirs(OBJ_DIR, exist_ok=True)
     objs = [os.path.join(OBJ_DIR, os.path.basename(src) + ".o") for src in SOURCES]
 
+    newest_header = max(os.path.getmtime(h) for h in HEADERS)
+
     def compile_one(pair):
         src, obj = pair
+        # incremental: an object newer than its source and every header is kept
+        if not force and os.path.exists(obj) and \
+                os.path.getmtime(obj) >= max(os.path.getmtime(src), newest_header):
+            return
         cmd = [hipcc] + FLAGS + ["-c", src, "-o", obj]
         if verbose:
             print(" ".join(cmd))

@@ -1545,7 +1545,9 @@ int search_batch_impl(tq_segment *s, const tq_query *queries, uint32_t n_queries
         for (uint32_t i = 0; i < dq.n_terms; ++i)
           if (!(s->terms[dq.term[i]].dense_blob && s->opt.use_dense)) ++sparse;
         const uint32_t c_lb = 1u + dq.n_terms + 8u * sparse;
-        dq.tile_blocks = std::max<uint32_t>(1u, TQD_AND_TILE * 2u / c_lb);
+        static const uint32_t kOrTileBlocks = tune_u32("TQ_OR_TILE_BLOCKS", 0);
+        dq.tile_blocks = kOrTileBlocks ? std::min<uint32_t>(kOrTileBlocks, TQD_AND_TILE)
+                                       : std::max<uint32_t>(1u, TQD_AND_TILE * 2u / c_lb);
         tile_cost = dq.tile_blocks * c_lb;
         uint32_t acc_tiles = 0;
         for (uint32_t i = 0; i < dq.n_terms; ++i) {
@@ -1657,7 +1659,12 @@ int search_batch_impl(tq_segment *s, const tq_query *queries, uint32_t n_queries
     const size_t thr_bytes = (size_t)n_thr_rows * TQD_THR_SLOTS * sizeof(uint32_t);
     rc = s->d_thr.ensure(thr_bytes);
     if (rc != TQ_OK) return rc;
-    HIP_TRY(hipMemsetAsync(s->d_thr.p, 0, thr_bytes, st));
+    // TQ_KEEP_THR=1 (experiments only): the slots keep the previous batch's final values, i.e. the
+    // same batch run again starts from its final thresholds (what perfect threshold knowledge buys)
+    static const bool kKeepThr = tune_u32("TQ_KEEP_THR", 0) != 0;
+    static bool thr_seeded = false;
+    if (!kKeepThr || !thr_seeded) HIP_TRY(hipMemsetAsync(s->d_thr.p, 0, thr_bytes, st));
+    thr_seeded = true;
   }
 
   // ---- launch

@@ -2,6 +2,27 @@
 // Shared device helpers: tq_common.hpp.
 #include "tq_common.hpp"
 
+// experiment switches of the union kernel (tools/build_variant.py): payload read-ahead in the
+// decode path, threshold slots read one refresh ahead, doc + tf streams requested together
+#ifndef TQ_U_PF
+#define TQ_U_PF 0
+#endif
+#ifndef TQ_U_SVPF
+#define TQ_U_SVPF 0
+#endif
+#ifndef TQ_U_JOINT
+#define TQ_U_JOINT 1
+#endif
+#ifndef TQ_U_TIMERS
+#define TQ_U_TIMERS 0  // region timers cost 2 %: tools/probe_phases.py builds a variant with them
+#endif
+#ifndef TQ_U_LANESUF
+#define TQ_U_LANESUF 1
+#endif
+#ifndef TQ_U_SWEEP_RATIO
+#define TQ_U_SWEEP_RATIO 32u
+#endif
+
 namespace {
 
 // =================================================================== OR kernel
@@ -351,26 +372,40 @@ __device__ __forceinline__ void union_body(const TqkScanParams &p) {
   uint32_t dense_mask = 0, sparse_mask = 0;  // pure unions: lists with / without a bitmap
   uint32_t mat_mask = 0;                     // ... with a column in the doc matrix
   uint32_t slots_sum = 0;  // checksum of the threshold slots at the last radix select
+  // threshold slots, read ahead: the values a refresh uses were requested at the previous refresh
+  // (or during query setup), so the read's latency is off the critical path; a stale threshold is
+  // a valid threshold (it only rises)
+  uint32_t sv_pf[4] = {0u, 0u, 0u, 0u};
+  uint32_t pf_anchor = 0, pf_junk = 0;  // payload read-ahead of the decode path (see stage A)
   float slack_abs = 0.0f;
   // leader of the current tile
   uint32_t li = 0, li_end = 0;
   bool dead = false;
   TermRef lead{};
   float w_lead = 0.0f;
-  // PROFILING (TQ_DEBUG bits 16..19 = phase): wave cycles spent in one phase, summed into the
-  // match counter.  1 chunk start + query setup + flush, 2 tile bookkeeping + threshold,
-  // 3 pre-filter, 4 stage A, 5 stage B, 6 stage C
-  const uint32_t tphase = (p.debug >> 16) & 15u;
-  uint64_t tacc = 0, tlast = tphase ? __builtin_readcyclecounter() : 0ull;
-  auto tick = [&](uint32_t done) __attribute__((always_inline)) {
-    if (tphase) {
-      const uint64_t now = __builtin_readcyclecounter();
-      if (done == tphase) tacc += now - tlast;
-      tlast = now;
-    }
+  // bitmap sweep of a dense leader's tiles (pure unions, pruned): see the main loop
+  const uint2 *sw_lead = nullptr;  // the leader's bitmap + rank directory, or null = no sweep
+  uint32_t sw_after = 0, sw_before = 0, sw_n = 0;  // dense lists after / before the leader
+  float sw_ssum = 0.0f;          // lane j < 2^sw_n: weights of the subset j of the lists after
+  float sw_sparse_after = 0.0f;  // weights of the lists after the leader without a bitmap
+  bool q1_is_pi = false;         // queue 1 carries posting indices instead of term freqs
+  // PROFILING (TQ_DEBUG bits 16..19 = region): wave cycles spent inside ONE region per run (the
+  // counter is only read at the edges of that region), summed into the match counter.
+  // 1 whole chunk, 2 query setup, 3 flush, 4 tile bookkeeping + threshold, 5 pre-filter,
+  // 6 bitmap sweep (stages B / C inside included), 7 decode path (B / C included), 8 stage B,
+  // 9 stage C
+  const uint32_t tphase = TQ_U_TIMERS ? (p.debug >> 16) & 15u : 0u;
+  uint64_t tacc = 0, tlast = 0;
+  auto tb = [&](uint32_t ph) __attribute__((always_inline)) {
+    if (TQ_U_TIMERS && tphase == ph) tlast = __builtin_readcyclecounter();
   };
+  auto te = [&](uint32_t ph) __attribute__((always_inline)) {
+    if (TQ_U_TIMERS && tphase == ph) tacc += __builtin_readcyclecounter() - tlast;
+  };
+  tb(1u);
 
   auto setup_query = [&]() __attribute__((always_inline)) {
+    tb(2u);
     q_tile_start = sload(p.tile_starts + q);
     q_tile_end = sload(p.tile_starts + q + 1u);
     Q = p.queries + q;
@@ -384,6 +419,16 @@ __device__ __forceinline__ void union_body(const TqkScanParams &p) {
     n_slot_rows = k <= 16u ? 1u : 4u;
     slots = (prune && thr_index != 0xFFFFFFFFu) ? p.thr_slots + (size_t)thr_index * TQD_THR_SLOTS
                                                 : nullptr;
+#if TQ_U_SVPF
+    if (slots) {
+      sv_pf[0] = __hip_atomic_load(slots + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (n_slot_rows == 4u) {
+#pragma unroll
+        for (int r = 1; r < 4; ++r)
+          sv_pf[r] = __hip_atomic_load(slots + 64 * r + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+#endif
     const uint32_t ci = sload(&Q->cache_idx);
     wave_mem_fence();
     if (ci != cache_loaded) {
@@ -401,12 +446,26 @@ __device__ __forceinline__ void union_body(const TqkScanParams &p) {
       n_lead = nt;
     }
     // suffix[m]: what the lists m.. can add at most (MustNot lists carry weight 0)
+    // (the weights come in with ONE vector load, lane m <-> list m; the sums run over registers
+    // in the order nt-1 .. m, the order every bound was derived with)
     float suf = 0.0f;
+#if !TQ_U_LANESUF
     if (lane == 0) L.suffix[nt] = 0.0f;
     for (uint32_t m = nt; m-- > 0u;) {
       suf += sload(&Q->weight[m]);
       if (lane == 0) L.suffix[m] = suf;
     }
+#else
+    {
+      const float wv = (uint32_t)lane < nt ? Q->weight[lane] : 0.0f;
+      float mine = 0.0f;
+      for (uint32_t m = nt; m-- > 0u;) {
+        suf += __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(wv), (int)m));
+        if ((uint32_t)lane == m) mine = suf;
+      }
+      if ((uint32_t)lane <= nt) L.suffix[lane] = mine;  // suffix[nt] = 0
+    }
+#endif
     if constexpr (!BOOL) {  // per-list tables of the membership stage, one list per lane
       const uint2 *dp = nullptr;
       uint32_t slot = 0xFFFFFFFFu;
@@ -433,6 +492,7 @@ __device__ __forceinline__ void union_body(const TqkScanParams &p) {
     li_end = 0;
     dead = false;
     tk.reset(k);
+    te(2u);
   };
 
   // ---- stage B: the other lists of <= 64 candidates of leader li
@@ -578,7 +638,7 @@ __device__ __forceinline__ void union_body(const TqkScanParams &p) {
   // then the ownership probes into the sparse lists BEFORE the leader (found = dropped).  The
   // sum runs leader first, then ascending list index: the same bits as every other mode.
   auto stageC = [&](uint32_t n) __attribute__((always_inline)) {
-    tick(5u);
+    tb(9u);
     const uint32_t base = q2n - n;
     q2n = base;
     if (p.debug & 128u) n_matches += n;  // COUNTERS
@@ -661,7 +721,7 @@ __device__ __forceinline__ void union_body(const TqkScanParams &p) {
         if (own > thr) thr = own;
       }
     }
-    tick(6u);
+    te(9u);
   };
   // B (64 candidates of leader li): membership only.  One fieldnorm byte and one bitmap word per
   // dense list, all independent gathers; a doc held by a list before the leader belongs to that
@@ -669,7 +729,7 @@ __device__ __forceinline__ void union_body(const TqkScanParams &p) {
   // doc (bitmap) or may hold it (no bitmap)" as their bound (block_wand_union.rs:16-80 with the
   // pivot test made per doc) and most of them end here, before any tf is fetched.
   auto stageB_pure = [&](uint32_t n) __attribute__((always_inline)) {
-    tick(4u);
+    tb(8u);
     const uint32_t base = q1n - n;
     q1n = base;
     if (p.debug & 64u) n_matches += n;  // COUNTERS
@@ -678,6 +738,12 @@ __device__ __forceinline__ void union_body(const TqkScanParams &p) {
     if (alive) {
       doc = L.q1_doc[base + lane];
       tf = L.q1_tf[base + lane];
+    }
+    if (q1_is_pi) {  // swept tiles: the queue carries the posting index (bitmap rank), not the tf
+      if (alive) {
+        const uint4 r = lead.rec[tf >> 7];
+        tf = block_tf_at(idx, lead, make_uint2(r.y, r.z), tf & 127u);
+      }
     }
     uint32_t nid = 0, mask = 0;
     uint32_t dm = dense_mask & ~(1u << li);
@@ -735,7 +801,7 @@ __device__ __forceinline__ void union_body(const TqkScanParams &p) {
       wave_mem_fence();
       q2n += (uint32_t)__popcll(mk);
     }
-    tick(5u);
+    te(8u);
   };
   auto step64 = [&]() __attribute__((always_inline)) {  // q1 holds >= 64 candidates
     if constexpr (BOOL) {
@@ -758,24 +824,25 @@ __device__ __forceinline__ void union_body(const TqkScanParams &p) {
   };
 
   setup_query();
-  tick(1u);
   for (uint32_t t = t_begin; t < t_end; ++t) {
-    tick(4u);
     while (t >= q_tile_end) {
       if (q_tile_end > q_tile_start && q_tile_end > t_begin) {
         drain();
+        tb(3u);
         const uint32_t part = sload(&Q->part_start) + (chunk - sload(&Q->chunk_first));
         flush_partial<KPL>(tk, sload(&p.sinks->partials), part, lane);
         if (lane == 0 && n_q) atomicAdd(sload(&p.sinks->query_matches) + sload(sload(&p.sinks->out_index) + q), n_q);
         n_q = 0;
+        te(3u);
       }
       ++q;
       setup_query();
-      tick(1u);
     }
     // ---- which list leads this tile (tiles of a chunk come in order: advance, never search)
+    tb(4u);
     if (dead) {  // lists li.. are non-essential for good (the threshold only rises): nothing
       t = (q_tile_end < t_end ? q_tile_end : t_end) - 1u;  // left for this query in this chunk
+      te(4u);
       continue;
     }
     const uint32_t tl = t - q_tile_start;
@@ -788,22 +855,59 @@ __device__ __forceinline__ void union_body(const TqkScanParams &p) {
       new_leader = true;
     }
     if (new_leader) {
+      te(4u);
       drain();  // the queue belongs to the previous leader
+      tb(4u);
       li = nli;
       lead = load_term(p.terms, sload(&Q->term[li]));
       w_lead = sload(&Q->weight[li]);
+      if constexpr (!BOOL && PRUNE) {
+        q1_is_pi = false;
+        sw_after = dense_mask & ~((2u << li) - 1u);
+        sw_before = dense_mask & ((1u << li) - 1u);
+        sw_n = (uint32_t)__popc(sw_after);
+        sw_lead = nullptr;
+        // only where a 32-doc word holds several postings of the leader: below that the decode
+        // path spends fewer instructions per candidate than the sweep spends per word
+        const uint32_t sw_ratio = ((p.debug >> 24) & 63u) ? ((p.debug >> 24) & 63u) : TQ_U_SWEEP_RATIO;
+        if (((dense_mask >> li) & 1u) && sw_n >= 1u && sw_n <= 5u && !(p.debug & 8192u) &&
+            (uint64_t)lead.n_blocks * 128ull * sw_ratio >= seg.max_doc) {
+          sw_lead = uni_ptr(L.dptr[li]);
+          sw_ssum = 0.0f;
+          uint32_t am = sw_after, b = 0;
+          while (am) {
+            const uint32_t m = (uint32_t)__builtin_ctz(am);
+            am &= am - 1u;
+            if (((uint32_t)lane >> b) & 1u) sw_ssum += L.wgt[m];
+            ++b;
+          }
+          sw_sparse_after = 0.0f;
+          uint32_t sm = sparse_mask & ~((2u << li) - 1u);
+          while (sm) {
+            const uint32_t m = (uint32_t)__builtin_ctz(sm);
+            sm &= sm - 1u;
+            sw_sparse_after += L.wgt[m];
+          }
+        }
+      }
     }
     // threshold: on a new leader and every 8th tile.  The radix select over the slots (the bulk of
     // this kernel's scalar work when it ran at every refresh) only runs when the slots changed
     // since the wave last looked (checksum), and on the upper 16 bits only: any v with
     // |{slots >= v}| >= k is a valid bound, the low bits of the k-th largest cost 0.8 % of it.
     if (slots && (new_leader || (tl & 7u) == 0u)) {
+#if TQ_U_SVPF
+      uint32_t sv[4] = {sv_pf[0], sv_pf[1], sv_pf[2], sv_pf[3]};
+      uint32_t (&svn)[4] = sv_pf;
+#else
       uint32_t sv[4] = {0u, 0u, 0u, 0u};
-      sv[0] = __hip_atomic_load(slots + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      uint32_t (&svn)[4] = sv;
+#endif
+      svn[0] = __hip_atomic_load(slots + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       if (n_slot_rows == 4u) {
 #pragma unroll
         for (int r = 1; r < 4; ++r)
-          sv[r] = __hip_atomic_load(slots + 64 * r + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          svn[r] = __hip_atomic_load(slots + 64 * r + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
       uint32_t sum = (sv[0] + sv[1]) + (sv[2] + sv[3]);
       sum += dpp_get<0x111, 0xF>(sum);
@@ -821,6 +925,7 @@ __device__ __forceinline__ void union_body(const TqkScanParams &p) {
       if (thr_g > thr) thr = thr_g;
     }
     // non-essential by now: every doc first seen in list li scores at most the weights of li..
+    te(4u);
     if (prune && sortable(L.suffix[li] * 1.000001f) < thr) {
       drain();
       dead = true;
@@ -828,13 +933,14 @@ __device__ __forceinline__ void union_body(const TqkScanParams &p) {
     }
 
     if (p.debug & 4096u) continue;  // ABLATION: tile bookkeeping only
-    tick(2u);
+    tb(5u);
     // ---- pre-filter: lane <-> leader block
     const uint32_t i_base = (tl - sload(&Q->lead_tile_start[li])) * tile_blocks;
     const uint32_t i_mine = i_base + (uint32_t)lane;
     bool surv = (uint32_t)lane < tile_blocks && i_mine < lead.n_blocks;
     uint4 rec_mine = make_uint4(0u, 0u, 0u, 0u);
     uint32_t prev_mine = 0, tfmin_mine = 1u;
+    float ub_mine = 0.0f;  // block-max score of the lane's leader block (valid lanes)
     {
       if (surv) rec_mine = lead.rec[i_mine];
       prev_mine = __shfl_up(rec_mine.x, 1, WAVE);
@@ -848,6 +954,7 @@ __device__ __forceinline__ void union_body(const TqkScanParams &p) {
         float ub = 0.0f, rest_mine = 0.0f;
         if (surv) {
           ub = block_max_score(rec_mine.y, w_lead, L.cache, lead.has_freq, p.bound_slack);
+          ub_mine = ub;
           surv = sortable((ub + L.suffix[li + 1u] * 1.000001f) * 1.000001f) >= thr;
         }
         // (pure unions: their dense lists span far more than 4 blocks, the seeks do not pay)
@@ -899,7 +1006,121 @@ __device__ __forceinline__ void union_body(const TqkScanParams &p) {
     }
     uint64_t todo = __ballot(surv);
     if (p.debug & 32u) n_matches += (uint32_t)__popcll(todo);  // COUNTERS
-    tick(3u);
+    te(5u);
+    tb(6u);
+    // ---- bitmap sweep (pure unions, pruned, the leader has a bitmap and 1..5 of the lists after
+    // it do): the membership test of stage B moved in front of the decode and made word-parallel.
+    // A doc of this tile can only reach the threshold if the lists after the leader that hold it
+    // carry enough weight: "block-max of the tile + the weights of a subset S of those lists >=
+    // threshold" is a monotone function of S, evaluated once per tile for all <= 32 subsets (one
+    // per lane); its minimal passing subsets S_1.. turn the per-doc test into
+    //   survivors = leader bits & ~(bits of the dense lists before) & OR_i AND_{m in S_i} bits_m
+    // over coalesced 32-doc bitmap words — no leader block is decoded and no candidate gathers
+    // anything until it has passed.  Survivors enter queue 1 with their posting index (rank
+    // directory), stage B fetches the tf.  block_wand_union.rs:16-80 with the pivot test made
+    // per 32 docs.  When the leader alone can reach the threshold the tile takes the decode path.
+    if constexpr (!BOOL && PRUNE) {
+      bool swept = false;
+      if (sw_lead && todo && thr != 0u) {
+        const uint32_t lo_l = (uint32_t)__builtin_ctzll(todo), hi_l = 63u - (uint32_t)__builtin_clzll(todo);
+        uint32_t ubv = ((uint32_t)lane >= lo_l && (uint32_t)lane <= hi_l) ? __float_as_uint(ub_mine) : 0u;
+        {  // wave max (scores are >= 0: their bits order like integers)
+          uint32_t o;
+          o = dpp_get<0x111, 0xF>(ubv); ubv = o > ubv ? o : ubv;
+          o = dpp_get<0x112, 0xF>(ubv); ubv = o > ubv ? o : ubv;
+          o = dpp_get<0x114, 0xF>(ubv); ubv = o > ubv ? o : ubv;
+          o = dpp_get<0x118, 0xF>(ubv); ubv = o > ubv ? o : ubv;
+          o = dpp_get<0x142, 0xA>(ubv); ubv = o > ubv ? o : ubv;
+          o = dpp_get<0x143, 0xC>(ubv); ubv = o > ubv ? o : ubv;
+          ubv = (uint32_t)__builtin_amdgcn_readlane((int)ubv, 63);
+        }
+        const float base_ub = __uint_as_float(ubv) + sw_sparse_after;
+        const bool pj = (uint32_t)lane < (1u << sw_n) &&
+                        sortable((base_ub + sw_ssum) * 1.000002f + slack_abs) >= thr;
+        const uint32_t tt = (uint32_t)__ballot(pj);
+        if (!(tt & 1u)) {  // the leader alone cannot make it: sweep
+          swept = true;
+          bool minimal = pj;
+          for (uint32_t b = 0; b < sw_n; ++b)
+            if ((((uint32_t)lane >> b) & 1u) && ((tt >> ((uint32_t)lane & ~(1u << b))) & 1u)) minimal = false;
+          uint32_t mins = (uint32_t)__ballot(minimal);
+          if (mins) {
+            if (!q1_is_pi) {
+              drain();
+              q1_is_pi = true;
+            }
+            const uint32_t prev_lo = (uint32_t)__builtin_amdgcn_readlane((int)prev_mine, (int)lo_l);
+            const uint32_t first = (i_base + lo_l) ? prev_lo + 1u : 0u;
+            const uint32_t last = (uint32_t)__builtin_amdgcn_readlane((int)rec_mine.x, (int)hi_l);
+            const uint32_t w_lo = first >> 5, w_hi = last >> 5;
+            uint32_t used = 0;  // lists after the leader that some minimal subset needs
+            for (uint32_t mm = mins; mm; mm &= mm - 1u) used |= (uint32_t)__builtin_ctz(mm);
+            // pointers of the lists after the leader, by subset bit
+            const uint2 *ap[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+            {
+              uint32_t am = sw_after;
+#pragma unroll
+              for (int b = 0; b < 5; ++b) {
+                if (am) {
+                  ap[b] = uni_ptr(L.dptr[__builtin_ctz(am)]);
+                  am &= am - 1u;
+                }
+              }
+            }
+            for (uint32_t wb = w_lo; wb <= w_hi; wb += 64u) {
+              const uint32_t w = wb + (uint32_t)lane;
+              const bool on = w <= w_hi;
+              uint2 wl = make_uint2(0u, 0u);
+              if (on) wl = sw_lead[w];
+              uint32_t before = 0;
+              for (uint32_t bm = sw_before; bm; bm &= bm - 1u) {
+                const uint2 *dp = uni_ptr(L.dptr[__builtin_ctz(bm)]);
+                if (on) before |= dp[w].x;
+              }
+              uint32_t W[5] = {0u, 0u, 0u, 0u, 0u};
+#pragma unroll
+              for (int b = 0; b < 5; ++b)
+                if (((used >> b) & 1u) && on) W[b] = ap[b][w].x;
+              uint32_t cand = wl.x & ~before;
+              if (w == w_lo) cand &= 0xFFFFFFFFu << (first & 31u);
+              if (w == w_hi) cand &= 0xFFFFFFFFu >> (31u - (last & 31u));
+              uint32_t pass = 0;
+              for (uint32_t mm = mins; mm; mm &= mm - 1u) {
+                const uint32_t j = (uint32_t)__builtin_ctz(mm);
+                uint32_t acc = 0xFFFFFFFFu;
+#pragma unroll
+                for (int b = 0; b < 5; ++b)
+                  if ((j >> b) & 1u) acc &= W[b];
+                pass |= acc;
+              }
+              uint32_t sv = cand & pass;
+              while (__ballot(sv != 0u)) {
+                const bool has = sv != 0u;
+                const uint32_t bit = has ? (uint32_t)__builtin_ctz(sv) : 0u;
+                sv &= sv - 1u;
+                const uint64_t mk = __ballot(has);
+                const uint32_t pos = q1n + mbcnt64(mk);
+                wave_mem_fence();
+                if (has) {
+                  L.q1_doc[pos] = (w << 5) + bit;
+                  L.q1_tf[pos] = wl.y + (uint32_t)__popc(wl.x & ((1u << bit) - 1u));
+                }
+                wave_mem_fence();
+                q1n += (uint32_t)__popcll(mk);
+                while (q1n >= 64u) step64();
+              }
+            }
+          }
+        }
+      }
+      te(6u);
+      if (swept) continue;
+      if (q1_is_pi) {  // back on the decode path (never happens while the threshold only rises
+        drain();       // for one leader, but a fresh chunk starts below its predecessor's)
+        q1_is_pi = false;
+      }
+    }
+    tb(7u);
     while (todo) {
       const uint32_t b = (uint32_t)__builtin_ctzll(todo);
       todo &= todo - 1ull;
@@ -908,14 +1129,31 @@ __device__ __forceinline__ void union_body(const TqkScanParams &p) {
       const uint32_t prev_l = (uint32_t)__builtin_amdgcn_readlane((int)prev_mine, (int)b);
       uint32_t c0, c1, t0, t1f;
       bool alive0 = true, alive1 = true;
+      // the doc and tf streams are requested together (one round trip, not two), and the first
+      // dword of every 128-byte line of the NEXT surviving block's payload right behind them: that
+      // load is only waited for one block later, when the lines it pulled in are about to be used
+      const bool packed = TQ_U_JOINT && mo_l.x != META_TAIL;
+      uint32_t x0 = 0, x1 = 0;
+      if (packed) unpack2(idx + lead.payload_base + mo_l.y, mo_l.x & 31u, lane, x0, x1);
       decode_tfs(idx, lead, mo_l, lane, t0, t1f);  // tail padding reads as tf 0
+      if (TQ_U_PF) pf_junk |= pf_anchor;
+      if (TQ_U_PF && todo) {
+        const uint32_t nb = (uint32_t)__builtin_ctzll(todo);
+        const uint32_t nmeta = (uint32_t)__builtin_amdgcn_readlane((int)rec_mine.y, (int)nb);
+        const uint32_t noff = (uint32_t)__builtin_amdgcn_readlane((int)rec_mine.z, (int)nb);
+        const uint32_t nbytes = nmeta == META_TAIL ? 0u : 16u * ((nmeta & 31u) + ((nmeta >> 8) & 0xFFu));
+        if (128u * (uint32_t)lane < nbytes) pf_anchor = ld_u1(idx + lead.payload_base + noff + 128u * (uint32_t)lane);
+      }
       if (prune) {
         const uint32_t tfmin = (uint32_t)__builtin_amdgcn_readlane((int)tfmin_mine, (int)b);
         alive0 = t0 >= tfmin;
         alive1 = t1f >= tfmin;
         if (!(__ballot(alive0) | __ballot(alive1))) continue;
       }
-      decode_docs<USE_DPP>(idx, lead, mo_l, prev_l, lane, c0, c1);
+      if (packed)
+        finish_docs<USE_DPP>(x0, x1, (mo_l.x >> 6) & 1u, prev_l, lane, c0, c1);
+      else
+        decode_docs<USE_DPP>(idx, lead, mo_l, prev_l, lane, c0, c1);
       alive0 = alive0 && c0 != TQD_TERMINATED;
       alive1 = alive1 && c1 != TQD_TERMINATED;
       const uint64_t m0 = __ballot(alive0), m1 = __ballot(alive1);
@@ -937,15 +1175,19 @@ __device__ __forceinline__ void union_body(const TqkScanParams &p) {
       q1n += n0 + (uint32_t)__popcll(m1);
       while (q1n >= 64u) step64();
     }
+    te(7u);
   }
   if (q_tile_end > q_tile_start) {
     drain();
+    tb(3u);
     const uint32_t part = sload(&Q->part_start) + (chunk - sload(&Q->chunk_first));
     flush_partial<KPL>(tk, sload(&p.sinks->partials), part, lane);
         if (lane == 0 && n_q) atomicAdd(sload(&p.sinks->query_matches) + sload(sload(&p.sinks->out_index) + q), n_q);
         n_q = 0;
+    te(3u);
   }
-  tick(1u);
+  te(1u);
+  if (pf_junk == 0x9E3779B1u && p.debug == 0xFFFFFFFFu) n_matches += 1u;  // (keeps the read-ahead loads)
   if (tphase) n_matches = (uint32_t)(tacc >> 4);
   if (lane == 0 && n_matches) atomicAdd(sload(&p.sinks->match_counter), (unsigned long long)n_matches);
 }
@@ -984,7 +1226,7 @@ static void launch_or_t(const TqkScanParams &p, bool /*dpp*/, dim3 grid, dim3 bl
     // candidates die on the first test, which needs the fieldnorm byte only, and the two-stage
     // form's doc-matrix gather (8 B/doc: one 128-byte line per candidate) costs more than it
     // saves.  A pure union is a boolean query whose leading clause holds all its terms.
-    if (p.boolean || (p.small_k && !p.exhaustive)) {
+    if (p.boolean || (p.small_k && !p.exhaustive && !(p.debug & 16384u))) {
       if (p.exhaustive)
         TQ_UNION(false, true);
       else

@@ -462,3 +462,40 @@ def test_segment_encoded_and_opened_on_the_device(ta):
     finally:
         enc.close()
         dev.close()
+
+
+# ------------------------------------------------------------------ union kernel: bitmap sweep
+@pytest.mark.parametrize("k", [17, 64, 100, 128])
+def test_union_bitmap_sweep_matches_exhaustive_and_oracle(ta, k):
+    """Pure unions whose leaders are dense enough to take the bitmap sweep of tq_union.hip (a
+    leader with a bitmap and 1..5 dense lists after it, k > 16): pruned == exhaustive bit for bit,
+    with and without deletes, and equal to the oracle's union (block_wand_union.rs semantics;
+    3+ term sums within 1e-5).  The sparse terms 40.. make tiles of both kinds meet in one query."""
+    from tests.test_gpu_parity import _assert_hits_close, _alive_bytes
+
+    seg = O.synth_segment(300_000, n_terms=64)
+    rng = np.random.default_rng(1000 + k)
+    qs = [[0, 1, 2, 3, 4], [1, 2, 3, 5, 8], [0, 2, 4, 6, 7, 9], [3, 5, 7, 40, 50], [2, 6, 45, 55, 63],
+          [0, 1], [4, 9, 60]]
+    qs += [sorted(rng.choice(12, size=5, replace=False).tolist()) for _ in range(6)]
+    batch = [(O.MODE_OR, q) for q in qs]
+    dev = ta.DeviceIndex([seg])
+    try:
+        for deleted in (None, set(rng.choice(seg.max_doc, size=seg.max_doc // 4, replace=False).tolist())):
+            if deleted is not None:
+                dev.set_alive_bitset(_alive_bytes(seg.max_doc, deleted))
+            dev.set_option("exhaustive", 1)
+            s, _, d, c = dev.search(batch, k)
+            full = [_hits(s, d, c, i) for i in range(len(qs))]
+            dev.set_option("exhaustive", 0)
+            s, _, d, c = dev.search(batch, k)
+            pruned = [_hits(s, d, c, i) for i in range(len(qs))]
+            assert pruned == full
+            for q, got in zip(qs, full):
+                docs, scores = O.match_all(seg, q, O.MODE_OR)
+                hits = [(float(sc), int(doc)) for doc, sc in zip(docs.tolist(), scores.tolist())
+                        if deleted is None or doc not in deleted]
+                hits.sort(key=lambda h: (-h[0], h[1]))
+                _assert_hits_close(got, hits[:k])
+    finally:
+        dev.close()

@@ -1,5 +1,8 @@
 #!/usr/bin/env python
-"""In-kernel phase timers (TQ_DEBUG bits 16..19, union and phrase kernels): wave cycles per phase.
+"""In-kernel region timers (TQ_DEBUG bits 16..19, union and phrase kernels): wave cycles per region.
+Union kernel regions: 1 whole chunk, 2 query setup, 3 flush, 4 tile bookkeeping + threshold,
+5 pre-filter, 6 bitmap sweep (B / C inside included), 7 decode path (B / C included), 8 stage B,
+9 stage C.
 usage: python tools/probe_phases.py <or5|phrase3> ; runs once per phase (the debug word is read at
 library load)."""
 import os
@@ -36,8 +39,12 @@ if len(sys.argv) > 2:  # child: one phase
     print("phase %s kernel %.3f ms wave-cycles %.4g" % (sys.argv[2], st["kernel_ms"], st["matches"] * 16.0))
     dev.close()
 else:
-    for ph in range(1, 8):
-        env = dict(os.environ, TQ_DEBUG=str(ph << 16))
+    if sys.argv[1] == "or5" and not os.environ.get("TQ_LIB_PATH"):  # the union kernel's timers are compiled out by default
+        lib = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "build_variant.py"), "timers",
+                              "tq_union.hip", "-DTQ_U_TIMERS=1"], capture_output=True, text=True).stdout.strip().splitlines()[-1]
+        os.environ["TQ_LIB_PATH"] = lib
+    for ph in range(1, 10):
+        env = dict(os.environ, TQ_DEBUG=str((ph << 16) | int(os.environ.get("TQ_DEBUG_BASE", "0"))))
         out = subprocess.run([sys.executable, __file__, sys.argv[1], str(ph)], env=env,
                              capture_output=True, text=True).stdout
         print(out.strip().splitlines()[-1] if out.strip() else "phase %d: no output" % ph)
