@@ -42,6 +42,15 @@ def parse_args(argv=None):
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--docs", type=int, default=10_000_000)
+    ap.add_argument("--terms", type=int, default=256,
+                    help="vocabulary of the synthetic segment and of the query stream (df_r = 0.5 N / r, "
+                         "ranks ~ Zipf(1)).  256 = SURVEY.md section 8d; larger vocabularies (4096, 65536) give the "
+                         "HBM-resident data point: few repeated queries, most lists without a bitmap "
+                         "(implies --no-side)")
+    ap.add_argument("--segments", type=int, default=1,
+                    help="segments per GPU of the MAIN workload (global BM25 statistics, merge_top_k over "
+                         "them): 8 puts ~1.1 GB of index + side tables behind the scan kernels, well "
+                         "beyond the 256 MB Infinity Cache (implies --no-side, --no-cpu-baseline)")
     ap.add_argument("--queries", type=int, default=None,
                     help="queries per batch (default: 10000 for and2 / mixed, 1000 for or5 / phrase3 / bool)")
     ap.add_argument("--workload", default="and2", choices=["and2", "or5", "phrase3", "mixed", "bool"])
@@ -110,12 +119,12 @@ def selftest_launcher(rank, world):
 DEFAULT_QUERIES = {"and2": 10_000, "mixed": 10_000, "or5": 1_000, "phrase3": 1_000, "bool": 2_000}
 
 
-def build_queries(O, workload, n, k):
+def build_queries(O, workload, n, k, terms=256):
     if workload == "and2":
-        ids = O.zipf_queries(n, 2, 256, seed=20260921)
+        ids = O.zipf_queries(n, 2, terms, seed=20260921)
         return [(O.MODE_AND, q.tolist()) for q in ids], k or 10
     if workload == "or5":
-        ids = O.zipf_queries(n, 5, 256, seed=20260922)
+        ids = O.zipf_queries(n, 5, terms, seed=20260922)
         return [(O.MODE_OR, q.tolist()) for q in ids], k or 100
     if workload == "phrase3":
         rng = np.random.default_rng(20260923)
@@ -134,8 +143,8 @@ def build_queries(O, workload, n, k):
             nt, occ, cof = shapes[i % len(shapes)]
             qs.append((T.MODE_BOOL, q.tolist()[:nt], occ, cof, 0))
         return qs, k or 10
-    a = O.zipf_queries(n // 2, 2, 256, seed=20260921)
-    o = O.zipf_queries(n - n // 2, 5, 256, seed=20260922)
+    a = O.zipf_queries(n // 2, 2, terms, seed=20260921)
+    o = O.zipf_queries(n - n // 2, 5, terms, seed=20260922)
     qs = []
     for i in range(n):
         qs.append((O.MODE_AND, a[i // 2].tolist()) if i % 2 == 0 else (O.MODE_OR, o[i // 2].tolist()))
@@ -390,20 +399,28 @@ def main():
     # ---------------------------------------------------------------- main workload (weak)
     with_pos = args.workload == "phrase3"
     t0 = time.time()
-    seg = O.synth_segment(args.docs, n_terms=256, segment_ord=rank, with_positions=with_pos,
-                          phrase_terms=32)
+    if args.terms != 256 or args.segments != 1:
+        args.no_side = True
+    S_main = max(1, args.segments)
+    if S_main > 1:
+        args.no_cpu_baseline = True
+        args.latency_queries = 0
+    main_segs = [O.synth_segment(args.docs, n_terms=args.terms, segment_ord=rank * S_main + j,
+                                 with_positions=with_pos, phrase_terms=32) for j in range(S_main)]
+    seg = main_segs[0]
     t_gen = time.time() - t0
-    all_stats = cl.all_gather_object(stats_of(seg))
-    runner = D.ShardRunner([seg], cl.local_rank, rank, world,
-                           [st for r, st in enumerate(all_stats) if r != rank])
+    all_stats = cl.all_gather_object([stats_of(x) for x in main_segs])
+    runner = D.ShardRunner(main_segs, cl.local_rank, rank, world,
+                           [st for r, lst in enumerate(all_stats) if r != rank for st in lst])
     cl.make_comm(runner.dev.ctx)
     runner.comm, runner.torch_group = cl.comm, cl.torch_group
     runner.set_option("timing", 1)
     for name in ("dense_ratio", "dense_budget_x", "docmat", "device_prepare"):  # experiments: TQ_OPT_dense_ratio=...
         if os.environ.get("TQ_OPT_" + name):
             runner.set_option(name, int(os.environ["TQ_OPT_" + name]))
-    queries, k = build_queries(O, args.workload, n_main, args.k)
+    queries, k = build_queries(O, args.workload, n_main, args.k, args.terms)
     n_q = len(queries)
+    n_distinct = len({(q[0], tuple(sorted(q[1]))) for q in queries})
     m = measure(cl, runner, torch, queries, k, args.steps, args.warmup, args.exhaustive)
     if not m["mode_parity"]:
         raise SystemExit("pruned and exhaustive results differ on %d queries" % m["n_diff"])
@@ -417,7 +434,8 @@ def main():
             runner.dev.search_prepared(k)
             lat.append(time.perf_counter() - t1)
 
-    parity_checked = spot_check(O, seg, args.workload, queries, k, m["final"]) if world == 1 else 0
+    parity_checked = (spot_check(O, seg, args.workload, queries, k, m["final"])
+                      if world == 1 and S_main == 1 else 0)
     cpu = None
     if world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(O, seg, args.workload, queries, k, args.cpu_seconds, sweep=True)
@@ -526,9 +544,14 @@ def main():
     other_st = m["exh_stats"] if pruned_mode else m["prn_stats"]
     o_ach, o_frac = frac_of(algo_bytes, other_st["kernel_ms"])
     traffic, traffic_note, physical = None, "no PMC run recorded", None
-    tj = load_traffic("%s_%s_%d" % (args.workload, "pruned" if pruned_mode else "exhaustive", args.docs))
+    tkey = "%s_%s_%d" % (args.workload, "pruned" if pruned_mode else "exhaustive", args.docs)
+    if args.terms != 256:
+        tkey += "_t%d" % args.terms
+    if S_main != 1:
+        tkey += "_s%d" % S_main
+    tj = load_traffic(tkey)
     if tj:
-        traffic = tj["hbm_bytes_per_launch"]
+        traffic = tj["hbm_bytes_per_launch"] * S_main  # per step: one scan launch per local segment
         traffic_note = tj["note"]
         if k_ms > 0:
             physical = round(traffic / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
@@ -549,10 +572,11 @@ def main():
         "dtype": "u32+f32",
         "data": "synthetic",
         "config": {
-            "workload": "%s: %d queries/batch, k=%d, one %dM-doc Zipf segment per GPU (256 terms, "
+            "workload": "%s: %d queries/batch, k=%d, one %dM-doc Zipf segment per GPU (%d terms, "
                         "df_r=0.5N/r, WithFreqs%s); term ranks ~ Zipf(1)" %
-                        (args.workload, n_q, k, args.docs // 1_000_000,
+                        (args.workload, n_q, k, args.docs // 1_000_000, args.terms,
                          "AndPositions" if with_pos else ""),
+            "distinct_queries": n_distinct,
             "unit_note": "weak scaling: one unit = one query evaluated on one segment; at N GPUs every "
                          "query runs on N segments (N x %dM docs), the per-segment top-k are "
                          "all-gathered over RCCL and merged.  The same 8-segment index at every N "
@@ -565,7 +589,8 @@ def main():
             "mode": "block-max pruned (block_wand_intersection semantics)" if pruned_mode
                     else "exhaustive (every match scored)",
             "exchange": cl.exchange_note,
-            "index_bytes": int(seg.idx_len),
+            "segments_per_gpu": S_main,
+            "index_bytes": int(sum(x.idx_len for x in main_segs)),
             "index_build_s": round(t_gen, 2),
         },
         "roofline": {
@@ -576,6 +601,7 @@ def main():
             "frac": frac,
             "traffic": traffic,
             "physical_frac": physical,
+            "l2_hit_rate": (tj or {}).get("l2_hit_rate"),
             "kernel": "and_kernel" if args.workload == "and2" else args.workload + " scan kernels",
             "kernel_ms_avg": round(k_ms, 4),
             "algorithmic_bytes_per_launch": int(algo_bytes),

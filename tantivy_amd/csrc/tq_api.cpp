@@ -201,7 +201,12 @@ struct tq_segment {
   bool device_prepare() const { return h_idx.empty() || opt.device_prepare != 0; }
   tq_batch_stats stats{};
   bool stats_pending = false;
+  // host planner scratch (launch groups, chunk tables): kept between batches so that planning a
+  // batch does not start by page-faulting tens of megabytes of fresh vectors
+  struct PlanScratch *plan = nullptr;
 };
+
+void tq_free_plan_scratch(PlanScratch *p);  // (defined next to the planner)
 
 namespace {
 int sync_terms(tq_segment *s, hipStream_t st);
@@ -479,6 +484,8 @@ void tq_segment_free(tq_segment *s) {
   s->d_out_counts.release();
   s->d_misc.release();
   s->d_thr.release();
+  tq_free_plan_scratch(s->plan);
+  s->plan = nullptr;
   s->d_qmatches.release();
   s->h_stage.release();
   s->h_out.release();
@@ -1003,7 +1010,33 @@ struct Group {
   int kpl = 1;
   // offsets inside the staging blob
   size_t o_queries = 0, o_tiles = 0, o_outidx = 0, o_chunks = 0, o_perm = 0, o_sinks = 0;
+  void reset() {  // keeps the vectors' capacity
+    queries.clear();
+    out_index.clear();
+    tile_starts.clear();
+    chunk_starts.clear();
+    chunk_perm.clear();
+    chunk_query.clear();
+    chunk_recs.clear();
+    chunk_slice.clear();
+    tile_cost.clear();
+    total_tiles = 0;
+    n_chunks = 0;
+    max_k = 1;
+    kpl = 1;
+    o_queries = o_tiles = o_outidx = o_chunks = o_perm = o_sinks = 0;
+  }
 };
+
+}  // namespace
+
+struct PlanScratch {
+  Group groups[5];
+  std::vector<uint32_t> lead_cost, sort_start, sort_sorted, sort_fill;
+};
+void tq_free_plan_scratch(PlanScratch *p) { delete p; }
+
+namespace {
 
 static uint32_t tune_u32(const char *name, uint32_t dflt) {
   const char *v = getenv(name);
@@ -1016,12 +1049,15 @@ static const uint32_t kSlices = std::min<uint32_t>(256u, std::max<uint32_t>(1u, 
 static const float kOrDeadFrac = 0.75f;
 static const uint32_t kOrDeadDiv = 8;
 static const uint32_t kAndChunks = std::max<uint32_t>(256u, tune_u32("TQ_CHUNKS", 131072));
+// candidate unions: chunks per launch as a multiple of kAndChunks (k > 16 / k <= 16)
+static const uint32_t kOrChunkMul = std::max<uint32_t>(1u, tune_u32("TQ_OR_CHUNK_MUL", 4));
+static const uint32_t kOrChunkMulSmallK = std::max<uint32_t>(1u, tune_u32("TQ_OR_CHUNK_MUL_SMALLK", 8));
 
 int kpl_for(uint32_t k) { return k <= 64 ? 1 : (k <= 128 ? 2 : (k <= 256 ? 4 : 16)); }
 
 // tiles -> chunks of one launch group: runs of consecutive tiles of about equal estimated cost,
 // their launch order (doc-range slices) and the number of partial lists per query
-int build_group_chunks(Group &g, bool or_windows) {
+int build_group_chunks(Group &g, bool or_windows, PlanScratch &ps) {
   g.kpl = kpl_for(g.max_k);
   g.tile_starts.resize(g.queries.size() + 1);
   uint64_t acc = 0;
@@ -1043,10 +1079,10 @@ int build_group_chunks(Group &g, bool or_windows) {
   // candidate-driven OR: the tiles of a list that MaxScore will most likely find non-essential
   // (the weights of lists i.. together below ~3/4 of the query's total weight: top-k docs hold
   // most of the terms) are skipped whole at run time => weigh them as 1/8 of a live tile, so
-  // that chunks are sized by the work that is really done
-  // per query: cost per tile of every leader's run (computed once: the chunk loops below ask
-  // per chunk)
-  std::vector<uint32_t> lead_cost;  // [query][TQ_MAX_TERMS]
+  // that chunks are sized by the work that is really done.  A query's tiles form runs of equal
+  // cost: one per leader (candidate unions) or one for the whole query; every loop below walks
+  // runs, never single tiles.
+  std::vector<uint32_t> &lead_cost = ps.lead_cost;  // [query][TQ_MAX_TERMS]
   if (or_cand) {
     lead_cost.resize(g.queries.size() * TQ_MAX_TERMS);
     for (size_t qi = 0; qi < g.queries.size(); ++qi) {
@@ -1063,26 +1099,25 @@ int build_group_chunks(Group &g, bool or_windows) {
       }
     }
   }
-  auto leader_of = [&](const TqdQuery &dq, uint32_t t) -> uint32_t {
-    uint32_t li = 0;
-    while (li + 1u < dq.n_terms && dq.lead_tile_start[li + 1u] <= t) ++li;
-    return li;
-  };
-  auto tile_cost_at = [&](size_t qi, uint32_t t) -> uint32_t {
-    if (!or_cand) return std::max<uint32_t>(1u, g.tile_cost[qi]);
-    return lead_cost[qi * TQ_MAX_TERMS + leader_of(g.queries[qi], t)];
-  };
-  // first tile >= t of query qi where the cost changes (the end of the leader's run)
-  auto cost_run_end = [&](size_t qi, uint32_t t) -> uint32_t {
+  // run of equal cost that holds tile t of query qi (li = leader of the run, advanced by the
+  // caller's cursor: tiles are visited in order)
+  auto run_of = [&](size_t qi, uint32_t t, uint32_t &li, uint32_t &run_end) -> uint32_t {
     const TqdQuery &dq = g.queries[qi];
-    if (!or_cand) return dq.n_tiles;
-    return std::min<uint32_t>(dq.n_tiles, dq.lead_tile_start[leader_of(dq, t) + 1u]);
+    if (!or_cand) {
+      run_end = dq.n_tiles;
+      return std::max<uint32_t>(1u, g.tile_cost[qi]);
+    }
+    while (li + 1u < dq.n_terms && dq.lead_tile_start[li + 1u] <= t) ++li;
+    run_end = std::max<uint32_t>(t + 1u, std::min<uint32_t>(dq.n_tiles, dq.lead_tile_start[li + 1u]));
+    return lead_cost[qi * TQ_MAX_TERMS + li];
   };
   uint64_t total_cost = 0;
   for (size_t i = 0; i < g.queries.size(); ++i) {
+    uint32_t li = 0;
     for (uint32_t t = 0; t < g.queries[i].n_tiles;) {
-      const uint32_t e = std::max<uint32_t>(t + 1u, cost_run_end(i, t));
-      total_cost += (uint64_t)(e - t) * tile_cost_at(i, t);
+      uint32_t e;
+      const uint32_t tc = run_of(i, t, li, e);
+      total_cost += (uint64_t)(e - t) * tc;
       t = e;
     }
   }
@@ -1090,7 +1125,7 @@ int build_group_chunks(Group &g, bool or_windows) {
   // threshold); with large k the partial lists (1 KB per chunk and query) and the host's
   // planning time per chunk weigh more
   const uint64_t n_target =
-      or_win ? 8192u : (or_cand ? (g.max_k <= 16u ? 8u : 4u) * kAndChunks : kAndChunks);
+      or_win ? 8192u : (or_cand ? (g.max_k <= 16u ? kOrChunkMulSmallK : kOrChunkMul) * kAndChunks : kAndChunks);
   const uint64_t cost_target = std::max<uint64_t>(or_win ? 1u : 128u,
                                                   (total_cost + n_target - 1) / n_target);
   g.chunk_starts.clear();
@@ -1106,18 +1141,17 @@ int build_group_chunks(Group &g, bool or_windows) {
     dq.chunk_first = 0;
     if (!dq.n_tiles) continue;
     uint32_t first_chunk = 0xFFFFFFFFu;
+    uint32_t li = 0;
     for (uint32_t t = 0; t < dq.n_tiles;) {
-      const uint32_t tc = tile_cost_at(i, t);
-      const uint32_t run_end = std::max<uint32_t>(t + 1u, cost_run_end(i, t));
+      uint32_t run_end;
+      const uint32_t tc = run_of(i, t, li, run_end);
       if (!open_chunk || cur_cost >= cost_target) {
         g.chunk_starts.push_back(dq.tile_start + t);
         g.chunk_query.push_back((uint32_t)i);
         // which part of the doc-id space the chunk starts in (lists are spread over it)
-        if (g.mode == TQ_MODE_OR && !or_win) {
+        if (or_cand) {
           // candidate-driven OR: high-weight lists first (their matches raise the threshold
           // that lets the tiles of the dense low-weight lists be skipped), doc order inside
-          uint32_t li = 0;
-          while (li + 1u < dq.n_terms && dq.lead_tile_start[li + 1u] <= t) ++li;
           const uint32_t span = std::max<uint32_t>(1u, dq.lead_tile_start[li + 1u] - dq.lead_tile_start[li]);
           const uint32_t sub = (uint32_t)(((uint64_t)(t - dq.lead_tile_start[li]) * 16u) / span);
           g.chunk_slice.push_back(std::min<uint32_t>(n_slices * 8u - 1u, std::min<uint32_t>(li, 15u) * 16u + sub));
@@ -1150,10 +1184,12 @@ int build_group_chunks(Group &g, bool or_windows) {
   g.chunk_perm.resize(g.n_chunks);
   {
     const uint32_t nb = n_slices * 8u;
-    std::vector<uint32_t> start(nb + 1, 0);
+    std::vector<uint32_t> &start = ps.sort_start, &sorted = ps.sort_sorted, &fill = ps.sort_fill;
+    start.assign(nb + 1, 0);
     for (uint32_t c = 0; c < g.n_chunks; ++c) ++start[g.chunk_slice[c] + 1];
     for (uint32_t i = 0; i < nb; ++i) start[i + 1] += start[i];
-    std::vector<uint32_t> sorted(g.n_chunks), fill(start.begin(), start.end() - 1);
+    sorted.resize(g.n_chunks);
+    fill.assign(start.begin(), start.end() - 1);
     for (uint32_t c = 0; c < g.n_chunks; ++c) sorted[fill[g.chunk_slice[c]]++] = c;
     uint32_t out = 0;
     for (uint32_t sl = 0; sl < n_slices; ++sl) {
@@ -1371,7 +1407,9 @@ int search_batch_impl(tq_segment *s, const tq_query *queries, uint32_t n_queries
   // instantiation (no seek / block-search code: fewer registers, less LDS, more waves per CU)
   // boolean queries (clauses with roles) run the candidate-driven union kernel's BOOL instantiation
   constexpr int kGroups = 5, kAndGeneral = 3, kBool = 4;
-  Group groups[kGroups];
+  if (!s->plan) s->plan = new PlanScratch();
+  Group(&groups)[kGroups] = s->plan->groups;
+  for (Group &g : groups) g.reset();
   groups[kBool].mode = TQ_MODE_OR;
   groups[0].mode = TQ_MODE_AND;
   groups[1].mode = TQ_MODE_OR;
@@ -1568,12 +1606,13 @@ int search_batch_impl(tq_segment *s, const tq_query *queries, uint32_t n_queries
     g.out_index.push_back(qi);
     g.max_k = std::max(g.max_k, q.k);
   }
+  const auto tr0b = std::chrono::steady_clock::now();
   // tiles -> chunks -> partial lists
   uint32_t total_parts = 0;
   size_t partial_bytes = 0;
   for (Group &g : groups) {
     if (g.queries.empty()) continue;
-    const int crc = build_group_chunks(g, or_windows_opt && &g != &groups[kBool]);
+    const int crc = build_group_chunks(g, or_windows_opt && &g != &groups[kBool], *s->plan);
     if (crc != TQ_OK) return crc;
   }
   // partial lists of all groups share one buffer; its stride is per group (kpl*64 keys)
@@ -1754,8 +1793,8 @@ int search_batch_impl(tq_segment *s, const tq_query *queries, uint32_t n_queries
   if (trace) {
     const auto tr3 = std::chrono::steady_clock::now();
     auto us = [](auto a, auto b) { return (long)std::chrono::duration_cast<std::chrono::microseconds>(b - a).count(); };
-    fprintf(stderr, "[tq] plan %ld us, stage fill %ld us, enqueue %ld us, stage bytes %zu\n",
-            us(tr0, tr1), us(tr1, tr2), us(tr2, tr3), stage);
+    fprintf(stderr, "[tq] plan %ld us (queries %ld us, chunks %ld us), stage fill %ld us, enqueue %ld us, stage bytes %zu\n",
+            us(tr0, tr1), us(tr0, tr0b), us(tr0b, tr1), us(tr1, tr2), us(tr2, tr3), stage);
   }
   s->stats.algorithmic_bytes = algo_bytes;
   s->stats.tiles = tiles_total;

@@ -1221,12 +1221,10 @@ static void launch_or_t(const TqkScanParams &p, bool /*dpp*/, dim3 grid, dim3 bl
     else                                                                  \
       union_kernel<KPL, PR, BO><<<grid, dim3(64), 0, st>>>(p);            \
   } while (0)
-    // Pure unions with small k run the single-stage walk too (every list after the leader probed
-    // in turn, the bound re-tested with the exact partial sums): with a high threshold most
-    // candidates die on the first test, which needs the fieldnorm byte only, and the two-stage
-    // form's doc-matrix gather (8 B/doc: one 128-byte line per candidate) costs more than it
-    // saves.  A pure union is a boolean query whose leading clause holds all its terms.
-    if (p.boolean || (p.small_k && !p.exhaustive && !(p.debug & 16384u))) {
+    // Pure unions run the two-stage form (membership, then exact scores) at every k: with the
+    // bitmap sweep in front of it, it beats the single-stage walk of the boolean instantiation also
+    // for k <= 16 (4.03 vs 4.55 ms per 1000 5-term queries at k = 10; TQ_DEBUG bit 14 = walk).
+    if (p.boolean || (p.small_k && !p.exhaustive && (p.debug & 16384u))) {
       if (p.exhaustive)
         TQ_UNION(false, true);
       else

@@ -20,4 +20,4 @@ rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/p3 -o p3 -- $B > $OUT/p3.
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/p4 -o p4 -- $B > $OUT/p4.log 2>&1
 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum --output-format csv -d $OUT/p5 -o p5 -- $B > $OUT/p5.log 2>&1
 tail -1 $OUT/kt.log | cut -c1-300
-python $R/tools/summarize_profile.py $OUT $TAG $W
+python $R/tools/summarize_profile.py $OUT $TAG $W 10000000 "$KEY_SUFFIX"

@@ -41,6 +41,7 @@ def main():
     tag = sys.argv[2]
     workload = sys.argv[3] if len(sys.argv) > 3 else "and2"
     docs = int(sys.argv[4]) if len(sys.argv) > 4 else 10_000_000
+    key_suffix = sys.argv[5] if len(sys.argv) > 5 else ""  # e.g. _t4096: bench.py --terms 4096
     out = os.path.join(ROOT, "profiles")
     os.makedirs(out, exist_ok=True)
     shutil.copy(os.path.join(src, "kt", "kt_kernel_stats.csv"),
@@ -93,8 +94,12 @@ def main():
             wr = per[k].get("WRITE_SIZE", [0])
             write = sum(wr) / max(1, len(wr)) * 1024
             for mode in (("pruned", "exhaustive") if cl[1] == "both" else (cl[1],)):
-                key = "%s_%s_%d" % (workload, mode, docs)
-                e = fresh.setdefault(key, {"fetch_bytes_raw": 0, "write_bytes_raw": 0, "kernels": []})
+                key = "%s_%s_%d%s" % (workload, mode, docs, key_suffix)
+                e = fresh.setdefault(key, {"fetch_bytes_raw": 0, "write_bytes_raw": 0, "kernels": [],
+                                           "tcc_hit": 0, "tcc_miss": 0})
+                if "TCC_HIT_sum" in per[k] and "TCC_MISS_sum" in per[k]:
+                    e["tcc_hit"] += int(sum(per[k]["TCC_HIT_sum"]) / len(per[k]["TCC_HIT_sum"]))
+                    e["tcc_miss"] += int(sum(per[k]["TCC_MISS_sum"]) / len(per[k]["TCC_MISS_sum"]))
                 e["fetch_bytes_raw"] += int(fetch)  # the launch groups of one batch add up
                 e["write_bytes_raw"] += int(write)
                 e["kernels"].append(k)
@@ -102,6 +107,8 @@ def main():
         v["fetch_factor"] = factor
         v["hbm_bytes_per_launch"] = int(factor * v["fetch_bytes_raw"] + v["write_bytes_raw"])
         v["profile"] = tag
+        if v["tcc_hit"] + v["tcc_miss"]:
+            v["l2_hit_rate"] = round(v["tcc_hit"] / (v["tcc_hit"] + v["tcc_miss"]), 3)
         v["note"] = ("rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, %s), KiB*1024, summed over "
                      "the batch's scan kernels; FETCH x %.2f (%s); fabric-side counters: Infinity-Cache "
                      "hits are included" % (tag, factor, factor_note))
