@@ -19,6 +19,12 @@
 #ifndef TQ_U_LANESUF
 #define TQ_U_LANESUF 1
 #endif
+#ifndef TQ_U_PERSIST
+#define TQ_U_PERSIST 0  // 1: persistent wavefronts pulling tiles from per-query cursors (measured slower: DESIGN.md section 3.2)
+#endif
+#ifndef TQ_U_REFRESH_ALL
+#define TQ_U_REFRESH_ALL TQ_U_PERSIST
+#endif
 #ifndef TQ_U_SWEEP_RATIO
 #define TQ_U_SWEEP_RATIO 32u
 #endif
@@ -351,12 +357,16 @@ __device__ __forceinline__ void union_body(const TqkScanParams &p) {
   __shared__ UnionLds<BOOL> L;
   const int lane = (int)__lane_id();
   if (blockIdx.x >= p.n_chunks) return;
+#if TQ_U_PERSIST
+  uint32_t q = sload(p.wave_start + blockIdx.x);
+  uint32_t n_tiles_q = 0, my_slot = 0;
+#else
   const uint4 crec = sload(p.chunk_recs + blockIdx.x);
   const uint32_t chunk = crec.w, t_begin = crec.x, t_end = crec.y;
+  uint32_t q = crec.z;
+#endif
   const TqdSegment seg = p.seg;
   const uint8_t *idx = seg.idx;
-
-  uint32_t q = crec.z;
   uint32_t q_tile_start = 0, q_tile_end = 0;
   const TqdQuery *Q = nullptr;
   uint32_t nt = 0, tile_blocks = TQD_AND_TILE, n_slot_rows = 1;
@@ -406,9 +416,13 @@ __device__ __forceinline__ void union_body(const TqkScanParams &p) {
 
   auto setup_query = [&]() __attribute__((always_inline)) {
     tb(2u);
+    Q = p.queries + q;
+#if TQ_U_PERSIST
+    n_tiles_q = sload(&Q->n_tiles);
+#else
     q_tile_start = sload(p.tile_starts + q);
     q_tile_end = sload(p.tile_starts + q + 1u);
-    Q = p.queries + q;
+#endif
     nt = sload(&Q->n_terms);
     tile_blocks = sload(&Q->tile_blocks);
     prune = PRUNE && (sload(&Q->flags) & TQD_QF_PRUNE) != 0u;
@@ -823,6 +837,57 @@ __device__ __forceinline__ void union_body(const TqkScanParams &p) {
     }
   };
 
+#if TQ_U_PERSIST
+  // ================================================================ persistent scheduling
+  // The launch is ~one resident wavefront per slot of the chip, not one per chunk.  Every query
+  // has a tile cursor and a count of partial-list slots handed out (qstate, zeroed per batch).  A
+  // wavefront looks for a query that still has tiles and a free slot (starting where the host's
+  // cost estimate put it), sets the query up ONCE, then pulls tile after tile from the cursor
+  // until none is left or the leader it reaches is non-essential (then it closes the cursor for
+  // everybody), flushes its partial top-k into its slot and moves on.  Heavy queries end up with
+  // many wavefronts, light ones with one: the balance the host used to approximate with ~10^6
+  // cost-estimated chunks per batch (and ~13 ms of planning) comes from the cursors, and the
+  // per-query setup chains are paid once per (wavefront, query) instead of once per chunk.
+  const uint32_t nq = p.n_queries;
+  uint32_t *const qstate = p.qstate;
+  for (;;) {
+    // ---- an active query with a free slot, scanning 64 queries per step from q on
+    uint32_t found = 0xFFFFFFFFu;
+    for (uint32_t base = 0; base < nq && found == 0xFFFFFFFFu; base += 64u) {
+      uint32_t qq = q + base + (uint32_t)lane;
+      while (qq >= nq) qq -= nq;
+      bool act = base + (uint32_t)lane < nq;
+      if (act) {
+        const uint32_t cur = __hip_atomic_load(qstate + 2u * qq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const uint32_t used = __hip_atomic_load(qstate + 2u * qq + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        act = cur < p.queries[qq].n_tiles && used < p.queries[qq].n_parts;
+      }
+      uint64_t m = __ballot(act);
+      while (m && found == 0xFFFFFFFFu) {
+        const uint32_t l = (uint32_t)__builtin_ctzll(m);
+        m &= m - 1ull;
+        const uint32_t qc = (uint32_t)__builtin_amdgcn_readlane((int)qq, (int)l);
+        uint32_t s = 0;
+        if (lane == 0) s = atomicAdd(qstate + 2u * qc + 1u, 1u);
+        s = uni(s);
+        if (s < sload(&p.queries[qc].n_parts)) {
+          found = qc;
+          my_slot = s;
+        }
+      }
+    }
+    if (found == 0xFFFFFFFFu) break;  // nothing left anywhere
+    q = found;
+    setup_query();
+    for (;;) {
+      // (the pull is synchronous: a read-ahead kept in one lane's register across the tile body was
+      // lost when that register was spilled under a partial exec mask)
+      uint32_t nxt = 0;
+      if (lane == 0) nxt = atomicAdd(qstate + 2u * q, 1u);
+      const uint32_t tl = uni(nxt);
+      if (tl >= n_tiles_q) break;
+      tb(4u);
+#else
   setup_query();
   for (uint32_t t = t_begin; t < t_end; ++t) {
     while (t >= q_tile_end) {
@@ -846,6 +911,7 @@ __device__ __forceinline__ void union_body(const TqkScanParams &p) {
       continue;
     }
     const uint32_t tl = t - q_tile_start;
+#endif
     bool new_leader = li == 0xFFFFFFFFu;
     uint32_t nli = new_leader ? 0u : li;
     if (new_leader) li_end = sload(&Q->lead_tile_start[1]);
@@ -895,7 +961,7 @@ __device__ __forceinline__ void union_body(const TqkScanParams &p) {
     // this kernel's scalar work when it ran at every refresh) only runs when the slots changed
     // since the wave last looked (checksum), and on the upper 16 bits only: any v with
     // |{slots >= v}| >= k is a valid bound, the low bits of the k-th largest cost 0.8 % of it.
-    if (slots && (new_leader || (tl & 7u) == 0u)) {
+    if (slots && (TQ_U_REFRESH_ALL || new_leader || (tl & 7u) == 0u)) {
 #if TQ_U_SVPF
       uint32_t sv[4] = {sv_pf[0], sv_pf[1], sv_pf[2], sv_pf[3]};
       uint32_t (&svn)[4] = sv_pf;
@@ -929,7 +995,13 @@ __device__ __forceinline__ void union_body(const TqkScanParams &p) {
     if (prune && sortable(L.suffix[li] * 1.000001f) < thr) {
       drain();
       dead = true;
+#if TQ_U_PERSIST
+      // tiles come in leader order: everything from here on is dead for every wavefront
+      if (lane == 0) atomicMax(qstate + 2u * q, n_tiles_q);
+      break;
+#else
       continue;
+#endif
     }
 
     if (p.debug & 4096u) continue;  // ABLATION: tile bookkeeping only
@@ -1177,6 +1249,16 @@ __device__ __forceinline__ void union_body(const TqkScanParams &p) {
     }
     te(7u);
   }
+#if TQ_U_PERSIST
+    drain();
+    tb(3u);
+    flush_partial<KPL>(tk, sload(&p.sinks->partials), sload(&Q->part_start) + my_slot, lane);
+    if (lane == 0 && n_q) atomicAdd(sload(&p.sinks->query_matches) + sload(sload(&p.sinks->out_index) + q), n_q);
+    n_q = 0;
+    te(3u);
+    q = q + 1u < nq ? q + 1u : 0u;
+  }
+#else
   if (q_tile_end > q_tile_start) {
     drain();
     tb(3u);
@@ -1186,6 +1268,7 @@ __device__ __forceinline__ void union_body(const TqkScanParams &p) {
         n_q = 0;
     te(3u);
   }
+#endif
   te(1u);
   if (pf_junk == 0x9E3779B1u && p.debug == 0xFFFFFFFFu) n_matches += 1u;  // (keeps the read-ahead loads)
   if (tphase) n_matches = (uint32_t)(tacc >> 4);
@@ -1206,6 +1289,8 @@ union_kernel_small(TqkScanParams p) {
 }  // namespace
 
 // =================================================================== launch wrappers
+int tqk_union_persistent() { return TQ_U_PERSIST; }
+
 template <int KPL>
 static void launch_or_t(const TqkScanParams &p, bool /*dpp*/, dim3 grid, dim3 block, hipStream_t st) {
   if (p.or_windows) {  // window-parallel form: one workgroup per chunk
