@@ -177,8 +177,7 @@ struct tq_segment {
   size_t dense_bytes_total = 0;
   std::unordered_map<uint64_t, uint32_t> term_by_off;
   // batch scratch
-  DevBuf d_stage, d_partials, d_out_scores, d_out_docs, d_out_counts, d_misc, d_thr, d_qmatches, d_qstate;
-  uint32_t max_resident_waves = 256 * 24;  // CUs x wavefronts the union kernel keeps resident per CU
+  DevBuf d_stage, d_partials, d_out_scores, d_out_docs, d_out_counts, d_misc, d_thr, d_qmatches;
   uint32_t last_batch_queries = 0;
   PinnedBuf h_stage, h_out;
   // timing: a ring of event quadruples, one per batch, so that pipelined batches (no host sync
@@ -395,9 +394,6 @@ static int segment_upload_common(tq_ctx *ctx, int device, uint32_t max_doc, cons
   if (rc == TQ_OK && pos && pos_len) rc = up(&s->d_pos, pos, pos_len);
   if (rc == TQ_OK && fieldnorm) rc = up(&s->d_fn, fieldnorm, max_doc);
   if (rc == TQ_OK) {
-    int cus = 0;
-    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cus > 0)
-      s->max_resident_waves = (uint32_t)cus * 24u;
     hipError_t e = hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&s->ev_stage_done, hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&s->ev_fork, hipEventDisableTiming);
@@ -488,7 +484,6 @@ void tq_segment_free(tq_segment *s) {
   s->d_out_counts.release();
   s->d_misc.release();
   s->d_thr.release();
-  s->d_qstate.release();
   tq_free_plan_scratch(s->plan);
   s->plan = nullptr;
   s->d_qmatches.release();
@@ -1013,8 +1008,6 @@ struct Group {
   std::vector<uint32_t> tile_cost;  // per query, cost units per tile
   uint32_t total_tiles = 0, n_chunks = 0, max_k = 1;
   int kpl = 1;
-  bool persistent = false;  // union kernel schedules itself: chunk_perm = first query per wavefront
-  size_t o_qstate = 0;      // offset of the group's {cursor, slots used} pairs in d_qstate
   // offsets inside the staging blob
   size_t o_queries = 0, o_tiles = 0, o_outidx = 0, o_chunks = 0, o_perm = 0, o_sinks = 0;
   void reset() {  // keeps the vectors' capacity
@@ -1031,8 +1024,6 @@ struct Group {
     n_chunks = 0;
     max_k = 1;
     kpl = 1;
-    persistent = false;
-    o_qstate = 0;
     o_queries = o_tiles = o_outidx = o_chunks = o_perm = o_sinks = 0;
   }
 };
@@ -1059,8 +1050,6 @@ static const float kOrDeadFrac = 0.75f;
 static const uint32_t kOrDeadDiv = 8;
 static const uint32_t kAndChunks = std::max<uint32_t>(256u, tune_u32("TQ_CHUNKS", 131072));
 // candidate unions: chunks per launch as a multiple of kAndChunks (k > 16 / k <= 16)
-// persistent unions: partial-list slots per query (wavefronts that may ever join one query)
-static const uint32_t kPersistSlots = std::max<uint32_t>(1u, tune_u32("TQ_PERSIST_SLOTS", 64));
 static const uint32_t kOrChunkMul = std::max<uint32_t>(1u, tune_u32("TQ_OR_CHUNK_MUL", 4));
 static const uint32_t kOrChunkMulSmallK = std::max<uint32_t>(1u, tune_u32("TQ_OR_CHUNK_MUL_SMALLK", 8));
 
@@ -1239,61 +1228,6 @@ int build_group_chunks(Group &g, bool or_windows, PlanScratch &ps) {
   return TQ_OK;
 }
 
-// Candidate-driven unions / boolean queries under persistent scheduling (tq_union.hip): no chunks.
-// Per query the number of partial-list slots (= wavefronts that may ever work on it), and for
-// every wavefront of the launch the query it looks at first — wavefronts are dealt over the queries
-// in proportion to the same cost estimate the chunk builder uses, so that the launch starts
-// balanced; from there on the cursors balance it.
-int build_group_persistent(Group &g, PlanScratch &ps, uint32_t max_waves) {
-  g.kpl = kpl_for(g.max_k);
-  g.tile_starts.clear();
-  g.chunk_starts.clear();
-  g.chunk_recs.clear();
-  const size_t nq = g.queries.size();
-  std::vector<uint32_t> &wave_start = g.chunk_perm;
-  std::vector<uint32_t> &cost = ps.lead_cost;  // per query (prefix sums below need 64 bits)
-  cost.resize(nq);
-  uint64_t total_cost = 0, total_tiles = 0, total_parts = 0;
-  for (size_t qi = 0; qi < nq; ++qi) {
-    TqdQuery &dq = g.queries[qi];
-    dq.tile_start = 0;
-    dq.chunk_first = 0;
-    dq.part_start = 0;
-    dq.n_parts = std::min<uint32_t>(dq.n_tiles, kPersistSlots);
-    const uint32_t tc = std::max<uint32_t>(1u, g.tile_cost[qi]);
-    const bool pruning = (dq.flags & TQD_QF_PRUNE) != 0u;
-    float total = 0.0f;
-    for (uint32_t m = 0; m < dq.n_terms; ++m) total += dq.weight[m];
-    float suffix = total;
-    uint64_t c = 0;
-    const uint32_t n_lead = dq.n_lead ? dq.n_lead : dq.n_terms;
-    for (uint32_t li = 0; li < n_lead; ++li) {
-      const uint32_t tiles = dq.lead_tile_start[li + 1u] - dq.lead_tile_start[li];
-      const uint32_t per = (pruning && suffix < kOrDeadFrac * total) ? std::max<uint32_t>(1u, tc / kOrDeadDiv) : tc;
-      c += (uint64_t)tiles * per;
-      suffix -= dq.weight[li];
-    }
-    cost[qi] = (uint32_t)std::min<uint64_t>(c, 0xFFFFFFFFull);
-    total_cost += cost[qi];
-    total_tiles += dq.n_tiles;
-    total_parts += dq.n_parts;
-    if (total_tiles > 0x7FFFFFFFull) return fail(TQ_ERR_UNSUPPORTED, "batch too large (tiles)");
-  }
-  g.total_tiles = (uint32_t)total_tiles;
-  const uint32_t n_waves = (uint32_t)std::min<uint64_t>(max_waves, total_parts);
-  g.n_chunks = n_waves;
-  wave_start.resize(n_waves);
-  // wave w starts at the query holding cost quantile (w + 1/2) / n_waves
-  size_t qi = 0;
-  uint64_t acc = nq ? cost[0] : 0;
-  for (uint32_t w = 0; w < n_waves; ++w) {
-    const uint64_t target = (uint64_t)(((2ull * w + 1ull) * total_cost) / (2ull * n_waves));
-    while (qi + 1 < nq && acc <= target) acc += cost[++qi];
-    wave_start[w] = (uint32_t)qi;
-  }
-  return TQ_OK;
-}
-
 // Planning of one TQ_MODE_BOOL query: clause layout of the union kernel (tq_union.hip), pruning
 // flags, tile sizes.  An empty result leaves dq.n_terms == 0 and n_tiles == 0.
 int plan_bool_query(tq_segment *s, const tq_query &q, uint32_t qi, TqdQuery &dq, uint64_t &qbytes,
@@ -1428,9 +1362,7 @@ int plan_bool_query(tq_segment *s, const tq_query &q, uint32_t qi, TqdQuery &dq,
       }
     }
     const uint32_t c_lb = 1u + n + 8u * sparse;
-    // (persistent scheduling pulls single tiles from a cursor: full 64-block tiles, one leader
-    // block per lane of the pre-filter; host-built chunks want tiles of about equal cost)
-    dq.tile_blocks = tqk_union_persistent() ? TQD_AND_TILE : std::max<uint32_t>(1u, TQD_AND_TILE * 2u / c_lb);
+    dq.tile_blocks = std::max<uint32_t>(1u, TQD_AND_TILE * 2u / c_lb);
     tile_cost = dq.tile_blocks * c_lb;
     uint32_t acc_tiles = 0;
     for (uint32_t i = 0; i <= TQ_MAX_TERMS; ++i) {
@@ -1475,7 +1407,6 @@ int search_batch_impl(tq_segment *s, const tq_query *queries, uint32_t n_queries
   // instantiation (no seek / block-search code: fewer registers, less LDS, more waves per CU)
   // boolean queries (clauses with roles) run the candidate-driven union kernel's BOOL instantiation
   constexpr int kGroups = 5, kAndGeneral = 3, kBool = 4;
-  static const bool kUnionPersist = tqk_union_persistent() != 0 && tune_u32("TQ_PERSIST", 1) != 0;
   if (!s->plan) s->plan = new PlanScratch();
   Group(&groups)[kGroups] = s->plan->groups;
   for (Group &g : groups) g.reset();
@@ -1654,8 +1585,7 @@ int search_batch_impl(tq_segment *s, const tq_query *queries, uint32_t n_queries
         const uint32_t c_lb = 1u + dq.n_terms + 8u * sparse;
         static const uint32_t kOrTileBlocks = tune_u32("TQ_OR_TILE_BLOCKS", 0);
         dq.tile_blocks = kOrTileBlocks ? std::min<uint32_t>(kOrTileBlocks, TQD_AND_TILE)
-                         : tqk_union_persistent() ? TQD_AND_TILE
-                                                  : std::max<uint32_t>(1u, TQD_AND_TILE * 2u / c_lb);
+                                       : std::max<uint32_t>(1u, TQD_AND_TILE * 2u / c_lb);
         tile_cost = dq.tile_blocks * c_lb;
         uint32_t acc_tiles = 0;
         for (uint32_t i = 0; i < dq.n_terms; ++i) {
@@ -1682,10 +1612,7 @@ int search_batch_impl(tq_segment *s, const tq_query *queries, uint32_t n_queries
   size_t partial_bytes = 0;
   for (Group &g : groups) {
     if (g.queries.empty()) continue;
-    const bool windows = or_windows_opt && &g != &groups[kBool];
-    g.persistent = kUnionPersist && g.mode == TQ_MODE_OR && !windows;
-    const int crc = g.persistent ? build_group_persistent(g, *s->plan, s->max_resident_waves)
-                                 : build_group_chunks(g, windows, *s->plan);
+    const int crc = build_group_chunks(g, or_windows_opt && &g != &groups[kBool], *s->plan);
     if (crc != TQ_OK) return crc;
   }
   // partial lists of all groups share one buffer; its stride is per group (kpl*64 keys)
@@ -1726,21 +1653,6 @@ int search_batch_impl(tq_segment *s, const tq_query *queries, uint32_t n_queries
     stage = (stage + 15) & ~(size_t)15;
     g.o_sinks = stage;
     stage += sizeof(TqkSinks);
-    if (g.persistent) {
-      stage = (stage + 15) & ~(size_t)15;
-      g.o_perm = stage;
-      stage += g.chunk_perm.size() * sizeof(uint32_t);
-    }
-  }
-  size_t qstate_bytes = 0;
-  for (Group &g : groups) {
-    if (!g.persistent || g.queries.empty()) continue;
-    g.o_qstate = qstate_bytes;
-    qstate_bytes += g.queries.size() * 2 * sizeof(uint32_t);
-  }
-  if (qstate_bytes) {
-    rc = s->d_qstate.ensure(qstate_bytes);
-    if (rc != TQ_OK) return rc;
   }
   const auto tr1 = std::chrono::steady_clock::now();
   if (s->stage_in_flight) {
@@ -1759,7 +1671,6 @@ int search_batch_impl(tq_segment *s, const tq_query *queries, uint32_t n_queries
     memcpy(hs + g.o_tiles, g.tile_starts.data(), g.tile_starts.size() * sizeof(uint32_t));
     memcpy(hs + g.o_outidx, g.out_index.data(), g.out_index.size() * sizeof(uint32_t));
     memcpy(hs + g.o_chunks, g.chunk_recs.data(), g.chunk_recs.size() * sizeof(uint4));
-    if (g.persistent) memcpy(hs + g.o_perm, g.chunk_perm.data(), g.chunk_perm.size() * sizeof(uint32_t));
   }
   for (int gi = 0; gi < kGroups; ++gi) {
     Group &g = groups[gi];
@@ -1782,7 +1693,6 @@ int search_batch_impl(tq_segment *s, const tq_query *queries, uint32_t n_queries
   s->stage_in_flight = true;
   HIP_TRY(hipMemsetAsync(s->d_match_counter, 0, sizeof(unsigned long long), st));
   HIP_TRY(hipMemsetAsync(s->d_qmatches.p, 0, (size_t)n_queries * sizeof(uint32_t), st));
-  if (qstate_bytes) HIP_TRY(hipMemsetAsync(s->d_qstate.p, 0, qstate_bytes, st));
   s->last_batch_queries = n_queries;
   if (n_thr_rows) {
     const size_t thr_bytes = (size_t)n_thr_rows * TQD_THR_SLOTS * sizeof(uint32_t);
@@ -1840,10 +1750,6 @@ int search_batch_impl(tq_segment *s, const tq_query *queries, uint32_t n_queries
     p.boolean = gi == kBool ? 1u : 0u;
     p.small_k = g.max_k <= 16u ? 1u : 0u;
     p.bound_slack = co.bound_slack;
-    if (g.persistent) {
-      p.qstate = (uint32_t *)((uint8_t *)s->d_qstate.p + g.o_qstate);
-      p.wave_start = (const uint32_t *)(ds + g.o_perm);
-    }
     p.max_terms = 0;
     for (const TqdQuery &dq : g.queries) p.max_terms = std::max(p.max_terms, dq.n_terms);
     tiles_total += g.total_tiles;
@@ -1869,7 +1775,6 @@ int search_batch_impl(tq_segment *s, const tq_query *queries, uint32_t n_queries
     m.queries = (const TqdQuery *)(ds + g.o_queries);
     m.partials = (const uint64_t *)((const uint8_t *)s->d_partials.p + part_off_bytes[gi]);
     m.out_index = (const uint32_t *)(ds + g.o_outidx);
-    m.parts_used = g.persistent ? (const uint32_t *)((const uint8_t *)s->d_qstate.p + g.o_qstate) : nullptr;
     m.out_scores = d_out_scores;
     m.out_docs = d_out_docs;
     m.out_counts = d_out_counts;

@@ -39,18 +39,12 @@ struct TqkScanParams {
   uint32_t boolean;     // union kernel: queries carry roles / clauses / min_should (TQ_MODE_BOOL)
   uint32_t small_k;     // every query of the launch has k <= 16
   float bound_slack;    // >= 1: widens block-max bounds when the BM25 statistics are not the segment's own
-  // union kernel, persistent scheduling (n_chunks = wavefronts launched): per query of the launch
-  // group {tile cursor, partial-list slots handed out}, zeroed per batch; wave -> first query
-  uint32_t *qstate;
-  const uint32_t *wave_start;
 };
 
 struct TqkMergeParams {
   const TqdQuery *queries;
   const uint64_t *partials;
   const uint32_t *out_index;  // query -> output row (null = identity)
-  // persistent union launches: qstate (above); query q merges min(n_parts, qstate[2q+1]) lists
-  const uint32_t *parts_used;
   float *out_scores;
   uint32_t *out_docs;
   uint32_t *out_counts;
@@ -72,7 +66,6 @@ struct TqkSegMergeParams {
 
 hipError_t tqk_launch_and(const TqkScanParams &p, int kpl, bool use_dpp, hipStream_t st);
 hipError_t tqk_launch_or(const TqkScanParams &p, int kpl, bool use_dpp, hipStream_t st);
-int tqk_union_persistent();  // 1: the candidate-driven union kernel schedules itself (qstate / wave_start)
 hipError_t tqk_launch_phrase(const TqkScanParams &p, int kpl, bool use_dpp, hipStream_t st);
 hipError_t tqk_launch_merge(const TqkMergeParams &p, int kpl, hipStream_t st);
 hipError_t tqk_launch_decode_list(const TqdSegment &seg, const TqdTerm *terms, uint32_t handle,

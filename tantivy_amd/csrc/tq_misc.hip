@@ -13,12 +13,7 @@ __global__ __launch_bounds__(64) void merge_kernel(TqkMergeParams p) {
   if (q >= p.n_queries) return;
   const TqdQuery *Q = uni_ptr(p.queries + q);
   const uint32_t k = uni(Q->k);
-  const uint32_t part_start = uni(Q->part_start);
-  uint32_t n_parts = uni(Q->n_parts);
-  if (p.parts_used) {  // persistent union launch: the slots that were handed out
-    const uint32_t used = uni(p.parts_used[2u * q + 1u]);
-    n_parts = used < n_parts ? used : n_parts;
-  }
+  const uint32_t part_start = uni(Q->part_start), n_parts = uni(Q->n_parts);
   TopK<KPL> tk;
   tk.reset(k);
   // a full partial list's k-th key is a lower bound of the final k-th key: the largest of them

@@ -2,28 +2,9 @@
 // Shared device helpers: tq_common.hpp.
 #include "tq_common.hpp"
 
-// experiment switches of the union kernel (tools/build_variant.py): payload read-ahead in the
-// decode path, threshold slots read one refresh ahead, doc + tf streams requested together
-#ifndef TQ_U_PF
-#define TQ_U_PF 0
-#endif
-#ifndef TQ_U_SVPF
-#define TQ_U_SVPF 0
-#endif
-#ifndef TQ_U_JOINT
-#define TQ_U_JOINT 1
-#endif
+// build switches of the union kernel (tools/build_variant.py makes A/B libraries from them)
 #ifndef TQ_U_TIMERS
 #define TQ_U_TIMERS 0  // region timers cost 2 %: tools/probe_phases.py builds a variant with them
-#endif
-#ifndef TQ_U_LANESUF
-#define TQ_U_LANESUF 1
-#endif
-#ifndef TQ_U_PERSIST
-#define TQ_U_PERSIST 0  // 1: persistent wavefronts pulling tiles from per-query cursors (measured slower: DESIGN.md section 3.2)
-#endif
-#ifndef TQ_U_REFRESH_ALL
-#define TQ_U_REFRESH_ALL TQ_U_PERSIST
 #endif
 #ifndef TQ_U_SWEEP_RATIO
 #define TQ_U_SWEEP_RATIO 32u
@@ -357,14 +338,9 @@ __device__ __forceinline__ void union_body(const TqkScanParams &p) {
   __shared__ UnionLds<BOOL> L;
   const int lane = (int)__lane_id();
   if (blockIdx.x >= p.n_chunks) return;
-#if TQ_U_PERSIST
-  uint32_t q = sload(p.wave_start + blockIdx.x);
-  uint32_t n_tiles_q = 0, my_slot = 0;
-#else
   const uint4 crec = sload(p.chunk_recs + blockIdx.x);
   const uint32_t chunk = crec.w, t_begin = crec.x, t_end = crec.y;
   uint32_t q = crec.z;
-#endif
   const TqdSegment seg = p.seg;
   const uint8_t *idx = seg.idx;
   uint32_t q_tile_start = 0, q_tile_end = 0;
@@ -382,11 +358,6 @@ __device__ __forceinline__ void union_body(const TqkScanParams &p) {
   uint32_t dense_mask = 0, sparse_mask = 0;  // pure unions: lists with / without a bitmap
   uint32_t mat_mask = 0;                     // ... with a column in the doc matrix
   uint32_t slots_sum = 0;  // checksum of the threshold slots at the last radix select
-  // threshold slots, read ahead: the values a refresh uses were requested at the previous refresh
-  // (or during query setup), so the read's latency is off the critical path; a stale threshold is
-  // a valid threshold (it only rises)
-  uint32_t sv_pf[4] = {0u, 0u, 0u, 0u};
-  uint32_t pf_anchor = 0, pf_junk = 0;  // payload read-ahead of the decode path (see stage A)
   float slack_abs = 0.0f;
   // leader of the current tile
   uint32_t li = 0, li_end = 0;
@@ -417,12 +388,8 @@ __device__ __forceinline__ void union_body(const TqkScanParams &p) {
   auto setup_query = [&]() __attribute__((always_inline)) {
     tb(2u);
     Q = p.queries + q;
-#if TQ_U_PERSIST
-    n_tiles_q = sload(&Q->n_tiles);
-#else
     q_tile_start = sload(p.tile_starts + q);
     q_tile_end = sload(p.tile_starts + q + 1u);
-#endif
     nt = sload(&Q->n_terms);
     tile_blocks = sload(&Q->tile_blocks);
     prune = PRUNE && (sload(&Q->flags) & TQD_QF_PRUNE) != 0u;
@@ -433,16 +400,6 @@ __device__ __forceinline__ void union_body(const TqkScanParams &p) {
     n_slot_rows = k <= 16u ? 1u : 4u;
     slots = (prune && thr_index != 0xFFFFFFFFu) ? p.thr_slots + (size_t)thr_index * TQD_THR_SLOTS
                                                 : nullptr;
-#if TQ_U_SVPF
-    if (slots) {
-      sv_pf[0] = __hip_atomic_load(slots + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if (n_slot_rows == 4u) {
-#pragma unroll
-        for (int r = 1; r < 4; ++r)
-          sv_pf[r] = __hip_atomic_load(slots + 64 * r + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      }
-    }
-#endif
     const uint32_t ci = sload(&Q->cache_idx);
     wave_mem_fence();
     if (ci != cache_loaded) {
@@ -463,13 +420,6 @@ __device__ __forceinline__ void union_body(const TqkScanParams &p) {
     // (the weights come in with ONE vector load, lane m <-> list m; the sums run over registers
     // in the order nt-1 .. m, the order every bound was derived with)
     float suf = 0.0f;
-#if !TQ_U_LANESUF
-    if (lane == 0) L.suffix[nt] = 0.0f;
-    for (uint32_t m = nt; m-- > 0u;) {
-      suf += sload(&Q->weight[m]);
-      if (lane == 0) L.suffix[m] = suf;
-    }
-#else
     {
       const float wv = (uint32_t)lane < nt ? Q->weight[lane] : 0.0f;
       float mine = 0.0f;
@@ -479,7 +429,6 @@ __device__ __forceinline__ void union_body(const TqkScanParams &p) {
       }
       if ((uint32_t)lane <= nt) L.suffix[lane] = mine;  // suffix[nt] = 0
     }
-#endif
     if constexpr (!BOOL) {  // per-list tables of the membership stage, one list per lane
       const uint2 *dp = nullptr;
       uint32_t slot = 0xFFFFFFFFu;
@@ -837,57 +786,6 @@ __device__ __forceinline__ void union_body(const TqkScanParams &p) {
     }
   };
 
-#if TQ_U_PERSIST
-  // ================================================================ persistent scheduling
-  // The launch is ~one resident wavefront per slot of the chip, not one per chunk.  Every query
-  // has a tile cursor and a count of partial-list slots handed out (qstate, zeroed per batch).  A
-  // wavefront looks for a query that still has tiles and a free slot (starting where the host's
-  // cost estimate put it), sets the query up ONCE, then pulls tile after tile from the cursor
-  // until none is left or the leader it reaches is non-essential (then it closes the cursor for
-  // everybody), flushes its partial top-k into its slot and moves on.  Heavy queries end up with
-  // many wavefronts, light ones with one: the balance the host used to approximate with ~10^6
-  // cost-estimated chunks per batch (and ~13 ms of planning) comes from the cursors, and the
-  // per-query setup chains are paid once per (wavefront, query) instead of once per chunk.
-  const uint32_t nq = p.n_queries;
-  uint32_t *const qstate = p.qstate;
-  for (;;) {
-    // ---- an active query with a free slot, scanning 64 queries per step from q on
-    uint32_t found = 0xFFFFFFFFu;
-    for (uint32_t base = 0; base < nq && found == 0xFFFFFFFFu; base += 64u) {
-      uint32_t qq = q + base + (uint32_t)lane;
-      while (qq >= nq) qq -= nq;
-      bool act = base + (uint32_t)lane < nq;
-      if (act) {
-        const uint32_t cur = __hip_atomic_load(qstate + 2u * qq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const uint32_t used = __hip_atomic_load(qstate + 2u * qq + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        act = cur < p.queries[qq].n_tiles && used < p.queries[qq].n_parts;
-      }
-      uint64_t m = __ballot(act);
-      while (m && found == 0xFFFFFFFFu) {
-        const uint32_t l = (uint32_t)__builtin_ctzll(m);
-        m &= m - 1ull;
-        const uint32_t qc = (uint32_t)__builtin_amdgcn_readlane((int)qq, (int)l);
-        uint32_t s = 0;
-        if (lane == 0) s = atomicAdd(qstate + 2u * qc + 1u, 1u);
-        s = uni(s);
-        if (s < sload(&p.queries[qc].n_parts)) {
-          found = qc;
-          my_slot = s;
-        }
-      }
-    }
-    if (found == 0xFFFFFFFFu) break;  // nothing left anywhere
-    q = found;
-    setup_query();
-    for (;;) {
-      // (the pull is synchronous: a read-ahead kept in one lane's register across the tile body was
-      // lost when that register was spilled under a partial exec mask)
-      uint32_t nxt = 0;
-      if (lane == 0) nxt = atomicAdd(qstate + 2u * q, 1u);
-      const uint32_t tl = uni(nxt);
-      if (tl >= n_tiles_q) break;
-      tb(4u);
-#else
   setup_query();
   for (uint32_t t = t_begin; t < t_end; ++t) {
     while (t >= q_tile_end) {
@@ -911,7 +809,6 @@ __device__ __forceinline__ void union_body(const TqkScanParams &p) {
       continue;
     }
     const uint32_t tl = t - q_tile_start;
-#endif
     bool new_leader = li == 0xFFFFFFFFu;
     uint32_t nli = new_leader ? 0u : li;
     if (new_leader) li_end = sload(&Q->lead_tile_start[1]);
@@ -961,19 +858,13 @@ __device__ __forceinline__ void union_body(const TqkScanParams &p) {
     // this kernel's scalar work when it ran at every refresh) only runs when the slots changed
     // since the wave last looked (checksum), and on the upper 16 bits only: any v with
     // |{slots >= v}| >= k is a valid bound, the low bits of the k-th largest cost 0.8 % of it.
-    if (slots && (TQ_U_REFRESH_ALL || new_leader || (tl & 7u) == 0u)) {
-#if TQ_U_SVPF
-      uint32_t sv[4] = {sv_pf[0], sv_pf[1], sv_pf[2], sv_pf[3]};
-      uint32_t (&svn)[4] = sv_pf;
-#else
+    if (slots && (new_leader || (tl & 7u) == 0u)) {
       uint32_t sv[4] = {0u, 0u, 0u, 0u};
-      uint32_t (&svn)[4] = sv;
-#endif
-      svn[0] = __hip_atomic_load(slots + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      sv[0] = __hip_atomic_load(slots + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       if (n_slot_rows == 4u) {
 #pragma unroll
         for (int r = 1; r < 4; ++r)
-          svn[r] = __hip_atomic_load(slots + 64 * r + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          sv[r] = __hip_atomic_load(slots + 64 * r + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
       uint32_t sum = (sv[0] + sv[1]) + (sv[2] + sv[3]);
       sum += dpp_get<0x111, 0xF>(sum);
@@ -995,13 +886,7 @@ __device__ __forceinline__ void union_body(const TqkScanParams &p) {
     if (prune && sortable(L.suffix[li] * 1.000001f) < thr) {
       drain();
       dead = true;
-#if TQ_U_PERSIST
-      // tiles come in leader order: everything from here on is dead for every wavefront
-      if (lane == 0) atomicMax(qstate + 2u * q, n_tiles_q);
-      break;
-#else
       continue;
-#endif
     }
 
     if (p.debug & 4096u) continue;  // ABLATION: tile bookkeeping only
@@ -1201,21 +1086,11 @@ __device__ __forceinline__ void union_body(const TqkScanParams &p) {
       const uint32_t prev_l = (uint32_t)__builtin_amdgcn_readlane((int)prev_mine, (int)b);
       uint32_t c0, c1, t0, t1f;
       bool alive0 = true, alive1 = true;
-      // the doc and tf streams are requested together (one round trip, not two), and the first
-      // dword of every 128-byte line of the NEXT surviving block's payload right behind them: that
-      // load is only waited for one block later, when the lines it pulled in are about to be used
-      const bool packed = TQ_U_JOINT && mo_l.x != META_TAIL;
+      // the doc and tf streams are requested together (the prefix sum still waits for the tf test)
+      const bool packed = mo_l.x != META_TAIL;
       uint32_t x0 = 0, x1 = 0;
       if (packed) unpack2(idx + lead.payload_base + mo_l.y, mo_l.x & 31u, lane, x0, x1);
       decode_tfs(idx, lead, mo_l, lane, t0, t1f);  // tail padding reads as tf 0
-      if (TQ_U_PF) pf_junk |= pf_anchor;
-      if (TQ_U_PF && todo) {
-        const uint32_t nb = (uint32_t)__builtin_ctzll(todo);
-        const uint32_t nmeta = (uint32_t)__builtin_amdgcn_readlane((int)rec_mine.y, (int)nb);
-        const uint32_t noff = (uint32_t)__builtin_amdgcn_readlane((int)rec_mine.z, (int)nb);
-        const uint32_t nbytes = nmeta == META_TAIL ? 0u : 16u * ((nmeta & 31u) + ((nmeta >> 8) & 0xFFu));
-        if (128u * (uint32_t)lane < nbytes) pf_anchor = ld_u1(idx + lead.payload_base + noff + 128u * (uint32_t)lane);
-      }
       if (prune) {
         const uint32_t tfmin = (uint32_t)__builtin_amdgcn_readlane((int)tfmin_mine, (int)b);
         alive0 = t0 >= tfmin;
@@ -1249,16 +1124,6 @@ __device__ __forceinline__ void union_body(const TqkScanParams &p) {
     }
     te(7u);
   }
-#if TQ_U_PERSIST
-    drain();
-    tb(3u);
-    flush_partial<KPL>(tk, sload(&p.sinks->partials), sload(&Q->part_start) + my_slot, lane);
-    if (lane == 0 && n_q) atomicAdd(sload(&p.sinks->query_matches) + sload(sload(&p.sinks->out_index) + q), n_q);
-    n_q = 0;
-    te(3u);
-    q = q + 1u < nq ? q + 1u : 0u;
-  }
-#else
   if (q_tile_end > q_tile_start) {
     drain();
     tb(3u);
@@ -1268,9 +1133,7 @@ __device__ __forceinline__ void union_body(const TqkScanParams &p) {
         n_q = 0;
     te(3u);
   }
-#endif
   te(1u);
-  if (pf_junk == 0x9E3779B1u && p.debug == 0xFFFFFFFFu) n_matches += 1u;  // (keeps the read-ahead loads)
   if (tphase) n_matches = (uint32_t)(tacc >> 4);
   if (lane == 0 && n_matches) atomicAdd(sload(&p.sinks->match_counter), (unsigned long long)n_matches);
 }
@@ -1289,8 +1152,6 @@ union_kernel_small(TqkScanParams p) {
 }  // namespace
 
 // =================================================================== launch wrappers
-int tqk_union_persistent() { return TQ_U_PERSIST; }
-
 template <int KPL>
 static void launch_or_t(const TqkScanParams &p, bool /*dpp*/, dim3 grid, dim3 block, hipStream_t st) {
   if (p.or_windows) {  // window-parallel form: one workgroup per chunk
