@@ -26,7 +26,13 @@ typedef struct tqh_term_info {
  *       TQ_MODE_AND (0) = BooleanQuery of Must term clauses, TQ_MODE_OR (1) = BooleanQuery of
  *       Should term clauses, TQ_MODE_PHRASE (2) = PhraseQuery (offsets 0..n unless phrase_offsets
  *       given), TQ_MODE_BOOL (3) = BooleanQuery with per-term occurs (0 Should, 1 Must,
- *       2 MustNot); terms sharing a clause_of value form one nested union (`+a +(b OR c)`);
+ *       2 MustNot); terms sharing a clause_of value form one nested query: a union of its terms
+ *       (`+a +(b OR c)`) or, with nested_occurs, a BooleanQuery with an occur per term
+ *       (`+a +(+b -c)`: clause_of {0,1,1}, occurs {1,1,1}, nested_occurs {255,1,2}; 255 / NULL =
+ *       Should).  A Must clause holding a nested query with a Must term is hoisted into its
+ *       parent (boolean_weight.rs:308-431: same docs, same score terms); other nestings
+ *       (an intersection inside a union or under MustNot) are TQ_ERR_UNSUPPORTED and stay on
+ *       tantivy's CPU scorer;
  *       min_should_match as BooleanQuery::set_minimum_number_should_match —
  *       plus TQH_MODE_TERM (4) = TermQuery.  Anything else: TQ_ERR_INVALID. */
 #define TQH_MODE_TERM 4
@@ -40,6 +46,8 @@ typedef struct tqh_query {
   uint32_t min_should_match;
   const float *boosts; /* per term: the TermQuery is wrapped in BoostQuery(boost) (boost_query.rs);
                           PHRASE: boosts[0] wraps the PhraseQuery; NULL = 1 */
+  const uint8_t *nested_occurs; /* TQ_MODE_BOOL: occur of a term inside its clause_of group (read for
+                                   groups of >= 2 terms); NULL = unions */
 } tqh_query;
 
 const char *tqh_last_error(void);

@@ -53,7 +53,7 @@ class TqhQuery(C.Structure):
     _fields_ = [("mode", C.c_uint8), ("n_terms", C.c_uint32), ("terms", C.POINTER(C.c_uint32)),
                 ("phrase_offsets", C.POINTER(C.c_uint32)), ("occurs", C.POINTER(C.c_uint8)),
                 ("clause_of", C.POINTER(C.c_uint8)), ("min_should_match", C.c_uint32),
-                ("boosts", C.POINTER(C.c_float))]
+                ("boosts", C.POINTER(C.c_float)), ("nested_occurs", C.POINTER(C.c_uint8))]
 
 
 _lib = None
@@ -414,7 +414,9 @@ class DeviceIndex:
         """queries: list of (mode, [term ids]), (MODE_PHRASE, [term ids], [offsets]) or
         (MODE_BOOL, [term ids], [occurs][, clause_of | None[, min_should_match]]) with occurs in
         {SHOULD, MUST, MUST_NOT}; terms sharing a clause_of value form one nested union.  A trailing
-        dict {"boosts": [...]} wraps every term query in BoostQuery(boost)."""
+        dict {"boosts": [...]} wraps every term query in BoostQuery(boost); {"nested_occurs": [...]}
+        gives the occur of every term INSIDE its clause_of group (255 = Should: a nested union), e.g.
+        `+a +(+b -c)` = (MODE_BOOL, [a, b, c], [MUST]*3, [0, 1, 1], 0, {"nested_occurs": [255, 1, 2]})."""
         n = len(queries)
         qs = (TqhQuery * max(1, n))()
         keep = []
@@ -427,6 +429,10 @@ class DeviceIndex:
                 ba = (C.c_float * len(terms))(*[float(b) for b in extra["boosts"]])
                 keep.append(ba)
                 qs[i].boosts = C.cast(ba, C.POINTER(C.c_float))
+            if extra and extra.get("nested_occurs") is not None:
+                na = (C.c_uint8 * len(terms))(*[int(o) for o in extra["nested_occurs"]])
+                keep.append(na)
+                qs[i].nested_occurs = C.cast(na, C.POINTER(C.c_uint8))
             ta = (C.c_uint32 * len(terms))(*[int(t) for t in terms])
             keep.append(ta)
             qs[i].mode = mode

@@ -59,6 +59,7 @@ struct tqh_query {
   const uint8_t *clause_of;        // TQ_MODE_BOOL: terms sharing a value form one nested union; or null
   uint32_t min_should_match;       // TQ_MODE_BOOL
   const float *boosts;             // BoostQuery factor per term query (PHRASE: boosts[0] = the phrase's); or null
+  const uint8_t *nested_occurs;    // TQ_MODE_BOOL, or null: see tantivy_amd_host.h
 };
 
 const char *tqh_last_error(void) { return g_err.c_str(); }
@@ -164,6 +165,7 @@ int tqh_prepare_batch(tqh_searcher *s, const tqh_query *queries, uint32_t n) {
         if (!q.occurs) throw TantivyError(TantivyError::InvalidArgument, "TQ_MODE_BOOL needs occurs");
         std::vector<std::pair<Occur, Query>> clauses;
         std::vector<int> ids;  // clause_of value of every clause built so far
+        std::vector<uint32_t> first_term_of;  // index (in q.terms) of the clause's first term
         for (uint32_t t = 0; t < q.n_terms; ++t) {
           if (q.occurs[t] > 2) throw TantivyError(TantivyError::InvalidArgument, "bad occur");
           const Occur oc = q.occurs[t] == 1 ? Occur::Must
@@ -174,17 +176,25 @@ int tqh_prepare_batch(tqh_searcher *s, const tqh_query *queries, uint32_t n) {
             for (c = 0; c < ids.size() && ids[c] != id; ++c) {}
           if (c == ids.size()) {
             ids.push_back(id);
+            first_term_of.push_back(t);
             clauses.emplace_back(oc, Query::term_query(q.terms[t]).boosted(q.boosts ? q.boosts[t] : 1.0f));
             continue;
           }
           if (clauses[c].first != oc)
             throw TantivyError(TantivyError::InvalidArgument, "a clause mixes occurs");
           Query &sub = clauses[c].second;
-          if (sub.kind == Query::Term) {  // second term of the clause: it becomes a nested union
+          // occur of a term INSIDE its clause: Should (a nested union) unless nested_occurs says
+          // otherwise (`+a +(+b -c)`: clause_of {0,1,1}, occurs {1,1,1}, nested_occurs {255,1,2})
+          auto inner = [&](uint32_t tt) {
+            const uint8_t v = q.nested_occurs ? q.nested_occurs[tt] : 255;
+            if (v != 255 && v > 2) throw TantivyError(TantivyError::InvalidArgument, "bad nested occur");
+            return v == 1 ? Occur::Must : (v == 2 ? Occur::MustNot : Occur::Should);
+          };
+          if (sub.kind == Query::Term) {  // second term of the clause: it becomes a nested query
             const Query first = sub;
-            sub = Query::boolean({{Occur::Should, first}});
+            sub = Query::boolean({{inner(first_term_of[c]), first}});
           }
-          sub.clauses.emplace_back(Occur::Should,
+          sub.clauses.emplace_back(inner(t),
                                    Query::term_query(q.terms[t]).boosted(q.boosts ? q.boosts[t] : 1.0f));
         }
         query = Query::boolean(std::move(clauses));

@@ -149,6 +149,46 @@ Weight Searcher::weight(const Query &query) const {
       // Intersection / RequiredOptionalScorer / Exclude / Disjunction on the union kernel.
       if (query.clauses.empty())
         throw TantivyError(TantivyError::Unsupported, "empty boolean query");
+      // A Must clause that is itself a BooleanQuery with at least one Must term (`+a +(+b +c)`,
+      // `+a +(+b -c)`, `+a +(+b c)`) is an Intersection of the parent's required scorers with the
+      // nested query's scorer (boolean_weight.rs:308-431): the same doc set and the same score
+      // terms as the nested clauses hoisted into the parent — required stays required, excluded
+      // stays excluded, and the nested optional clauses stay optional because the parent has a Must.
+      // Only the association of the f32 sum differs (a + (b + c) against a + b + c): within the
+      // 1e-5 the reference's own cursor-order sums already move by.  Hoisting needs
+      // minimum_number_should_match == 0 on both levels (its count is per BooleanQuery).
+      std::vector<std::pair<Occur, Query>> hoisted;
+      const std::vector<std::pair<Occur, Query>> *clauses_p = &query.clauses;
+      {
+        auto hoistable = [](const std::pair<Occur, Query> &c) {
+          if (c.first != Occur::Must || c.second.kind != Query::Boolean ||
+              c.second.minimum_number_should_match != 0 || c.second.clauses.empty())
+            return false;
+          bool has_must = false;
+          for (auto &sc : c.second.clauses) {
+            if (sc.second.kind != Query::Term) return false;
+            has_must |= sc.first == Occur::Must;
+          }
+          return has_must;
+        };
+        bool any = false;
+        for (auto &c : query.clauses) any |= hoistable(c);
+        if (any && query.minimum_number_should_match == 0) {
+          for (auto &c : query.clauses) {
+            if (!hoistable(c)) {
+              hoisted.push_back(c);
+              continue;
+            }
+            for (auto &sc : c.second.clauses) {
+              Query t = sc.second;
+              t.boost *= c.second.boost;  // BoostQuery around the nested query reaches its leaves
+              hoisted.emplace_back(sc.first, std::move(t));
+            }
+          }
+          clauses_p = &hoisted;
+        }
+      }
+      const std::vector<std::pair<Occur, Query>> &clauses = *clauses_p;
       bool all_must = true, all_should = true, flat = true;
       auto is_term_union = [](const Query &q) {
         if (q.kind != Query::Boolean || q.clauses.empty() || q.minimum_number_should_match > 1)
@@ -157,7 +197,7 @@ Weight Searcher::weight(const Query &query) const {
           if (c.first != Occur::Should || c.second.kind != Query::Term) return false;
         return true;
       };
-      for (auto &c : query.clauses) {
+      for (auto &c : clauses) {
         if (c.second.kind != Query::Term) {
           if (!is_term_union(c.second))
             throw TantivyError(TantivyError::Unsupported,
@@ -176,7 +216,7 @@ Weight Searcher::weight(const Query &query) const {
       else
         w.mode = TQ_MODE_BOOL;
       uint8_t clause = 0;
-      for (auto &c : query.clauses) {
+      for (auto &c : clauses) {
         const uint8_t oc = c.first == Occur::Must
                                ? (uint8_t)TQ_MUST
                                : (c.first == Occur::MustNot ? (uint8_t)TQ_MUST_NOT

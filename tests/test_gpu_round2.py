@@ -499,3 +499,57 @@ def test_union_bitmap_sweep_matches_exhaustive_and_oracle(ta, k):
                 _assert_hits_close(got, hits[:k])
     finally:
         dev.close()
+
+
+# ------------------------------------------------------------------ nested boolean queries that flatten
+def test_nested_must_queries_are_hoisted(ta):
+    """`+a +(+b +c)`, `+a +(+b -c)`, `+a +(+b c)`, `+(+a +b) +(c OR d)`: a Must clause holding a
+    BooleanQuery with a Must term is an Intersection with that query's scorer
+    (boolean_weight.rs:308-431) — the docs and score terms of the flat query with the nested
+    clauses hoisted; only the association of the f32 sum differs (1e-5).  An intersection inside a
+    union / under MustNot stays Unsupported (the caller keeps tantivy's CPU scorer)."""
+    from tests.test_gpu_parity import _assert_hits_close
+
+    M, S, N = ta.MUST, ta.SHOULD, ta.MUST_NOT
+    seg = O.synth_segment(150_000, n_terms=40)
+    nested = [
+        (ta.MODE_BOOL, [3, 5, 9], [M, M, M], [0, 1, 1], 0, {"nested_occurs": [255, 1, 1]}),
+        (ta.MODE_BOOL, [2, 6, 1], [M, M, M], [0, 1, 1], 0, {"nested_occurs": [255, 1, 2]}),
+        (ta.MODE_BOOL, [4, 7, 0], [M, M, M], [0, 1, 1], 0, {"nested_occurs": [255, 1, 0]}),
+        (ta.MODE_BOOL, [8, 3, 20, 30], [M, M, M, M], [0, 0, 1, 1], 0, {"nested_occurs": [1, 1, 255, 255]}),
+        (ta.MODE_BOOL, [1, 10, 12, 2], [M, M, M, S], [0, 1, 1, 2], 0, {"nested_occurs": [255, 1, 1, 255]}),
+    ]
+    flat = [
+        (ta.MODE_BOOL, [3, 5, 9], [M, M, M], None, 0),
+        (ta.MODE_BOOL, [2, 6, 1], [M, M, N], None, 0),
+        (ta.MODE_BOOL, [4, 7, 0], [M, M, S], None, 0),
+        (ta.MODE_BOOL, [8, 3, 20, 30], [M, M, M, M], [0, 1, 2, 2], 0),
+        (ta.MODE_BOOL, [1, 10, 12, 2], [M, M, M, S], None, 0),
+    ]
+    dev = ta.DeviceIndex([seg])
+    try:
+        for k in (10, 100):
+            for ex in (1, 0):
+                dev.set_option("exhaustive", ex)
+                s, _, d, c = dev.search(nested, k)
+                got = [_hits(s, d, c, i) for i in range(len(nested))]
+                s, _, d, c = dev.search(flat, k)
+                want = [_hits(s, d, c, i) for i in range(len(flat))]
+                for g, w, q in zip(got, want, nested):
+                    assert len(g) > 0, q
+                    _assert_hits_close(g, w)
+        # against the oracle's scorer tree on the flat forms
+        dev.set_option("exhaustive", 1)
+        s, _, d, c = dev.search(nested, 10)
+        for i, q in enumerate(flat):
+            want = O.bool_search(seg, q[1], q[2], 10, q[3], q[4])
+            _assert_hits_close(_hits(s, d, c, i), want)
+        # not hoistable: an intersection inside a union, under MustNot, or with msm on either level
+        for bad in [(ta.MODE_BOOL, [1, 2, 3], [S, S, S], [0, 1, 1], 0, {"nested_occurs": [255, 1, 1]}),
+                    (ta.MODE_BOOL, [1, 2, 3], [M, N, N], [0, 1, 1], 0, {"nested_occurs": [255, 1, 1]}),
+                    (ta.MODE_BOOL, [1, 2, 3, 4], [M, M, M, S], [0, 1, 1, 2], 1, {"nested_occurs": [255, 1, 1, 255]})]:
+            with pytest.raises(ta.TantivyAmdError) as e:
+                dev.search([bad], 10)
+            assert e.value.code == 4, e.value  # TQ_ERR_UNSUPPORTED
+    finally:
+        dev.close()
