@@ -1050,6 +1050,10 @@ static const float kOrDeadFrac = 0.75f;
 static const uint32_t kOrDeadDiv = 8;
 static const uint32_t kAndChunks = std::max<uint32_t>(256u, tune_u32("TQ_CHUNKS", 131072));
 // candidate unions: chunks per launch as a multiple of kAndChunks (k > 16 / k <= 16)
+// candidate unions: doc-range sub-slices per leader list in the launch order
+static const uint32_t kOrSubSlices = std::min<uint32_t>(256u, std::max<uint32_t>(1u, tune_u32("TQ_OR_SUBSLICES", 64)));
+static const bool kOrSubMajor = tune_u32("TQ_OR_SUBMAJOR", 0) != 0;
+static const bool kOrSortQueries = tune_u32("TQ_OR_SORT", 1) != 0;
 static const uint32_t kOrChunkMul = std::max<uint32_t>(1u, tune_u32("TQ_OR_CHUNK_MUL", 4));
 static const uint32_t kOrChunkMulSmallK = std::max<uint32_t>(1u, tune_u32("TQ_OR_CHUNK_MUL_SMALLK", 8));
 
@@ -1059,6 +1063,33 @@ int kpl_for(uint32_t k) { return k <= 64 ? 1 : (k <= 128 ? 2 : (k <= 256 ? 4 : 1
 // their launch order (doc-range slices) and the number of partial lists per query
 int build_group_chunks(Group &g, bool or_windows, PlanScratch &ps) {
   g.kpl = kpl_for(g.max_k);
+  // Candidate unions: queries that lead with the same lists gather the same doc-matrix rows and
+  // decode the same blocks.  Inside a (leader, doc sub-slice) bucket of the launch order the chunks
+  // follow the query order, so the queries are put in the order of their leading terms: chunks
+  // of one term run next to each other in time and find each other's lines in the L2.  (Results
+  // go to their rows through out_index; the order of a group's queries is nobody's business.)
+  if (g.mode == TQ_MODE_OR && !or_windows && kOrSortQueries && g.queries.size() > 1) {
+    const size_t n = g.queries.size();
+    std::vector<uint32_t> &perm = ps.sort_fill;
+    perm.resize(n);
+    for (size_t i = 0; i < n; ++i) perm[i] = (uint32_t)i;
+    auto key = [&](uint32_t i) {
+      const TqdQuery &q = g.queries[i];
+      return ((uint64_t)q.term[0] << 40) | ((uint64_t)(q.n_terms > 1 ? q.term[1] & 0xFFFFFu : 0u) << 20) |
+             (uint64_t)(q.n_terms > 2 ? q.term[2] & 0xFFFFFu : 0u);
+    };
+    std::stable_sort(perm.begin(), perm.end(), [&](uint32_t a, uint32_t b) { return key(a) < key(b); });
+    std::vector<TqdQuery> q2(n);
+    std::vector<uint32_t> o2(n), c2(n);
+    for (size_t i = 0; i < n; ++i) {
+      q2[i] = g.queries[perm[i]];
+      o2[i] = g.out_index[perm[i]];
+      c2[i] = g.tile_cost[perm[i]];
+    }
+    g.queries.swap(q2);
+    g.out_index.swap(o2);
+    g.tile_cost.swap(c2);
+  }
   g.tile_starts.resize(g.queries.size() + 1);
   uint64_t acc = 0;
   for (size_t i = 0; i < g.queries.size(); ++i) {
@@ -1153,8 +1184,11 @@ int build_group_chunks(Group &g, bool or_windows, PlanScratch &ps) {
           // candidate-driven OR: high-weight lists first (their matches raise the threshold
           // that lets the tiles of the dense low-weight lists be skipped), doc order inside
           const uint32_t span = std::max<uint32_t>(1u, dq.lead_tile_start[li + 1u] - dq.lead_tile_start[li]);
-          const uint32_t sub = (uint32_t)(((uint64_t)(t - dq.lead_tile_start[li]) * 16u) / span);
-          g.chunk_slice.push_back(std::min<uint32_t>(n_slices * 8u - 1u, std::min<uint32_t>(li, 15u) * 16u + sub));
+          const uint32_t sub = (uint32_t)(((uint64_t)(t - dq.lead_tile_start[li]) * kOrSubSlices) / span);
+          const uint32_t li_cap = n_slices * 8u / kOrSubSlices - 1u;
+          const uint32_t lic = std::min<uint32_t>(li, li_cap);
+          g.chunk_slice.push_back(std::min<uint32_t>(
+              n_slices * 8u - 1u, kOrSubMajor ? sub * (li_cap + 1u) + lic : lic * kOrSubSlices + sub));
         } else {
           g.chunk_slice.push_back((uint32_t)(((uint64_t)t * n_slices * 8u) / dq.n_tiles));
         }
