@@ -20,6 +20,10 @@ namespace {
 // The reference runs phrases through the default for_each_pruning_scorer (a threshold filter on
 // finished scores), so there is nothing to prune before the positions are read.
 #define TQD_PH_MAX_TERMS 8
+#ifndef TQ_PH_WAVES_DENSE
+#define TQ_PH_WAVES_DENSE 5  // occupancy target of the all-dense instantiation (waves per SIMD): 96 VGPRs
+                             // without scratch beat 80 with 12 B of it by 2 %
+#endif
 // DENSE: every non-leader list of every query of the launch has a bitmap, a doc-matrix column and
 // a position directory (the planner checks): no seek / block-search code, half the staging area
 template <int NT_MAX, bool DENSE>
@@ -127,7 +131,7 @@ __device__ __forceinline__ uint32_t pos_run_delta(const PosRun &r, uint32_t k) {
 
 // (5 waves per SIMD: what the 8 KB of LDS per wavefront admit)
 template <int KPL, int NT_MAX, bool DENSE>
-__global__ __launch_bounds__(64, DENSE ? 6 : 5) void phrase_kernel(TqkScanParams p) {
+__global__ __launch_bounds__(64, DENSE ? TQ_PH_WAVES_DENSE : 5) void phrase_kernel(TqkScanParams p) {
   constexpr bool USE_DPP = true;
   __shared__ PhraseLds<NT_MAX, DENSE> L;
   const int lane = (int)__lane_id();

@@ -6,6 +6,11 @@
 #ifndef TQ_U_TIMERS
 #define TQ_U_TIMERS 0  // region timers cost 2 %: tools/probe_phases.py builds a variant with them
 #endif
+#ifndef TQ_U_WAVES
+#define TQ_U_WAVES 5  // occupancy target of the k <= 128 instantiations: 96 VGPRs, (almost) no scratch.
+                      // At 6 (80 VGPRs) a third of the vector-memory instructions were spills: +10..13 % time;
+                      // LDS (6.9 KB per wavefront) caps the CU at 22 wavefronts anyway
+#endif
 #ifndef TQ_U_SWEEP_RATIO
 #define TQ_U_SWEEP_RATIO 32u
 #endif
@@ -1144,7 +1149,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_num_sgpr(96))) void union
   union_body<KPL, PRUNE, BOOL>(p);
 }
 template <int KPL, bool PRUNE, bool BOOL>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_num_sgpr(96), amdgpu_waves_per_eu(6, 8))) void
+__global__ __launch_bounds__(64) __attribute__((amdgpu_num_sgpr(96), amdgpu_waves_per_eu(TQ_U_WAVES, 8))) void
 union_kernel_small(TqkScanParams p) {
   union_body<KPL, PRUNE, BOOL>(p);
 }
