@@ -16,6 +16,7 @@
 #include <cstring>
 #include <string>
 #include <unordered_map>
+#include <thread>
 #include <vector>
 
 #include "../../include/tantivy_amd.h"
@@ -1000,11 +1001,7 @@ struct Group {
   std::vector<TqdQuery> queries;
   std::vector<uint32_t> out_index;
   std::vector<uint32_t> tile_starts;
-  std::vector<uint32_t> chunk_starts;
-  std::vector<uint32_t> chunk_perm;   // launch order -> chunk (doc-range slices, see planner)
-  std::vector<uint32_t> chunk_query;  // query of the chunk's first tile
   std::vector<uint4> chunk_recs;      // launch order: {first tile, end tile, first query, chunk}
-  std::vector<uint32_t> chunk_slice;
   std::vector<uint32_t> tile_cost;  // per query, cost units per tile
   uint32_t total_tiles = 0, n_chunks = 0, max_k = 1;
   int kpl = 1;
@@ -1014,11 +1011,7 @@ struct Group {
     queries.clear();
     out_index.clear();
     tile_starts.clear();
-    chunk_starts.clear();
-    chunk_perm.clear();
-    chunk_query.clear();
     chunk_recs.clear();
-    chunk_slice.clear();
     tile_cost.clear();
     total_tiles = 0;
     n_chunks = 0;
@@ -1030,13 +1023,39 @@ struct Group {
 
 }  // namespace
 
+struct alignas(128) PlanSlab {  // chunk tables of one slab of queries (build_group_chunks); its own
+                                // cache lines: the slabs' vector ends are bumped by different threads
+  size_t q0 = 0, q1 = 0;
+  std::vector<uint32_t> starts, slice, query;
+};
 struct PlanScratch {
   Group groups[5];
-  std::vector<uint32_t> lead_cost, sort_start, sort_sorted, sort_fill;
+  std::vector<uint32_t> lead_cost, sort_start;
+  std::vector<PlanSlab> slabs;
+  std::vector<std::pair<uint64_t, uint32_t>> keyed;
+  std::vector<TqdQuery> q_tmp;
+  std::vector<uint32_t> o_tmp, c_tmp, hist;
+  std::vector<uint4> sorted_recs;
 };
 void tq_free_plan_scratch(PlanScratch *p) { delete p; }
 
 namespace {
+
+// Planner threads (TQ_PLAN_THREADS, default 4, 1 = off): the chunk tables of a large batch are
+// built in slabs of queries / slices / records by a handful of short-lived threads.
+static uint32_t plan_threads();
+template <typename F>
+static void parallel_slabs(uint32_t n_slabs, F &&fn) {  // fn(slab) for slab in [0, n_slabs)
+  if (n_slabs <= 1) {
+    if (n_slabs) fn(0u);
+    return;
+  }
+  std::vector<std::thread> th;
+  th.reserve(n_slabs - 1);
+  for (uint32_t i = 1; i < n_slabs; ++i) th.emplace_back([&fn, i] { fn(i); });
+  fn(0u);
+  for (std::thread &t : th) t.join();
+}
 
 static uint32_t tune_u32(const char *name, uint32_t dflt) {
   const char *v = getenv(name);
@@ -1054,6 +1073,10 @@ static const uint32_t kAndChunks = std::max<uint32_t>(256u, tune_u32("TQ_CHUNKS"
 static const uint32_t kOrSubSlices = std::min<uint32_t>(256u, std::max<uint32_t>(1u, tune_u32("TQ_OR_SUBSLICES", 64)));
 static const bool kOrSubMajor = tune_u32("TQ_OR_SUBMAJOR", 0) != 0;
 static const bool kOrSortQueries = tune_u32("TQ_OR_SORT", 1) != 0;
+static uint32_t plan_threads() {
+  static const uint32_t n = std::min<uint32_t>(16u, std::max<uint32_t>(1u, tune_u32("TQ_PLAN_THREADS", 4)));
+  return n;
+}
 static const uint32_t kOrChunkMul = std::max<uint32_t>(1u, tune_u32("TQ_OR_CHUNK_MUL", 4));
 static const uint32_t kOrChunkMulSmallK = std::max<uint32_t>(1u, tune_u32("TQ_OR_CHUNK_MUL_SMALLK", 8));
 
@@ -1062,6 +1085,14 @@ int kpl_for(uint32_t k) { return k <= 64 ? 1 : (k <= 128 ? 2 : (k <= 256 ? 4 : 1
 // tiles -> chunks of one launch group: runs of consecutive tiles of about equal estimated cost,
 // their launch order (doc-range slices) and the number of partial lists per query
 int build_group_chunks(Group &g, bool or_windows, PlanScratch &ps) {
+  static const bool ptrace = getenv("TQ_PLAN_TRACE") != nullptr;  // phase times of the planner
+  auto pt_last = std::chrono::steady_clock::now();
+  auto pt = [&](const char *what) {
+    if (!ptrace) return;
+    const auto now = std::chrono::steady_clock::now();
+    fprintf(stderr, "[tq plan] %-12s %7.2f ms\n", what, std::chrono::duration<double, std::milli>(now - pt_last).count());
+    pt_last = now;
+  };
   g.kpl = kpl_for(g.max_k);
   // Candidate unions: queries that lead with the same lists gather the same doc-matrix rows and
   // decode the same blocks.  Inside a (leader, doc sub-slice) bucket of the launch order the chunks
@@ -1070,26 +1101,30 @@ int build_group_chunks(Group &g, bool or_windows, PlanScratch &ps) {
   // go to their rows through out_index; the order of a group's queries is nobody's business.)
   if (g.mode == TQ_MODE_OR && !or_windows && kOrSortQueries && g.queries.size() > 1) {
     const size_t n = g.queries.size();
-    std::vector<uint32_t> &perm = ps.sort_fill;
-    perm.resize(n);
-    for (size_t i = 0; i < n; ++i) perm[i] = (uint32_t)i;
-    auto key = [&](uint32_t i) {
-      const TqdQuery &q = g.queries[i];
-      return ((uint64_t)q.term[0] << 40) | ((uint64_t)(q.n_terms > 1 ? q.term[1] & 0xFFFFFu : 0u) << 20) |
-             (uint64_t)(q.n_terms > 2 ? q.term[2] & 0xFFFFFu : 0u);
-    };
-    std::stable_sort(perm.begin(), perm.end(), [&](uint32_t a, uint32_t b) { return key(a) < key(b); });
-    std::vector<TqdQuery> q2(n);
-    std::vector<uint32_t> o2(n), c2(n);
+    std::vector<std::pair<uint64_t, uint32_t>> &keyed = ps.keyed;  // (leading terms, query)
+    keyed.resize(n);
     for (size_t i = 0; i < n; ++i) {
-      q2[i] = g.queries[perm[i]];
-      o2[i] = g.out_index[perm[i]];
-      c2[i] = g.tile_cost[perm[i]];
+      const TqdQuery &q = g.queries[i];
+      keyed[i] = {((uint64_t)q.term[0] << 40) | ((uint64_t)(q.n_terms > 1 ? q.term[1] & 0xFFFFFu : 0u) << 20) |
+                      (uint64_t)(q.n_terms > 2 ? q.term[2] & 0xFFFFFu : 0u),
+                  (uint32_t)i};
+    }
+    std::sort(keyed.begin(), keyed.end());  // (ties fall back to the query index: stable)
+    std::vector<TqdQuery> &q2 = ps.q_tmp;
+    std::vector<uint32_t> &o2 = ps.o_tmp, &c2 = ps.c_tmp;
+    q2.resize(n);
+    o2.resize(n);
+    c2.resize(n);
+    for (size_t i = 0; i < n; ++i) {
+      q2[i] = g.queries[keyed[i].second];
+      o2[i] = g.out_index[keyed[i].second];
+      c2[i] = g.tile_cost[keyed[i].second];
     }
     g.queries.swap(q2);
     g.out_index.swap(o2);
     g.tile_cost.swap(c2);
   }
+  pt("sort queries");
   g.tile_starts.resize(g.queries.size() + 1);
   uint64_t acc = 0;
   for (size_t i = 0; i < g.queries.size(); ++i) {
@@ -1159,55 +1194,129 @@ int build_group_chunks(Group &g, bool or_windows, PlanScratch &ps) {
       or_win ? 8192u : (or_cand ? (g.max_k <= 16u ? kOrChunkMulSmallK : kOrChunkMul) * kAndChunks : kAndChunks);
   const uint64_t cost_target = std::max<uint64_t>(or_win ? 1u : 128u,
                                                   (total_cost + n_target - 1) / n_target);
-  g.chunk_starts.clear();
-  g.chunk_slice.clear();
-  g.chunk_query.clear();
-  uint64_t cur_cost = 0;
-  bool open_chunk = false;
+  pt("costs");
   const uint32_t per_chunk = or_win ? TQD_WAVES_PER_WG : 1u;
-  for (size_t i = 0; i < g.queries.size(); ++i) {
-    TqdQuery &dq = g.queries[i];
-    dq.part_start = 0;
-    dq.n_parts = 0;
-    dq.chunk_first = 0;
-    if (!dq.n_tiles) continue;
-    uint32_t first_chunk = 0xFFFFFFFFu;
-    uint32_t li = 0;
-    for (uint32_t t = 0; t < dq.n_tiles;) {
-      uint32_t run_end;
-      const uint32_t tc = run_of(i, t, li, run_end);
-      if (!open_chunk || cur_cost >= cost_target) {
-        g.chunk_starts.push_back(dq.tile_start + t);
-        g.chunk_query.push_back((uint32_t)i);
-        // which part of the doc-id space the chunk starts in (lists are spread over it)
-        if (or_cand) {
-          // candidate-driven OR: high-weight lists first (their matches raise the threshold
-          // that lets the tiles of the dense low-weight lists be skipped), doc order inside
-          const uint32_t span = std::max<uint32_t>(1u, dq.lead_tile_start[li + 1u] - dq.lead_tile_start[li]);
-          const uint32_t sub = (uint32_t)(((uint64_t)(t - dq.lead_tile_start[li]) * kOrSubSlices) / span);
-          const uint32_t li_cap = n_slices * 8u / kOrSubSlices - 1u;
-          const uint32_t lic = std::min<uint32_t>(li, li_cap);
-          g.chunk_slice.push_back(std::min<uint32_t>(
-              n_slices * 8u - 1u, kOrSubMajor ? sub * (li_cap + 1u) + lic : lic * kOrSubSlices + sub));
-        } else {
-          g.chunk_slice.push_back((uint32_t)(((uint64_t)t * n_slices * 8u) / dq.n_tiles));
+  const uint32_t li_cap = n_slices * 8u / kOrSubSlices - 1u;
+  // The queries are cut into slabs of about equal cost; every slab builds its chunks on its own
+  // (a chunk never spans two slabs) and the tables are concatenated afterwards.
+  const size_t nq = g.queries.size();
+  const uint32_t n_slabs = (uint32_t)std::max<size_t>(1, std::min<size_t>(total_cost / cost_target >= 65536 ? plan_threads() : 1u, nq));
+  using Slab = PlanSlab;
+  std::vector<Slab> &slabs = ps.slabs;
+  if (slabs.size() < n_slabs) slabs.resize(n_slabs);
+  {
+    size_t qi = 0;
+    uint64_t acc_cost = 0;
+    for (uint32_t sb = 0; sb < n_slabs; ++sb) {
+      slabs[sb].q0 = qi;
+      const uint64_t upto = total_cost * (sb + 1) / n_slabs;
+      while (qi < nq && (acc_cost < upto || sb + 1 == n_slabs)) {
+        uint32_t li = 0;
+        for (uint32_t t = 0; t < g.queries[qi].n_tiles;) {
+          uint32_t e;
+          const uint32_t tc = run_of(qi, t, li, e);
+          acc_cost += (uint64_t)(e - t) * tc;
+          t = e;
         }
-        cur_cost = 0;
-        open_chunk = true;
+        ++qi;
       }
-      if (first_chunk == 0xFFFFFFFFu) first_chunk = (uint32_t)g.chunk_starts.size() - 1u;
-      // as many tiles of this query as the chunk still takes
-      const uint64_t room = cost_target - cur_cost;
-      uint32_t take = (uint32_t)std::min<uint64_t>(run_end - t, (room + tc - 1) / tc);
-      take = std::max<uint32_t>(take, 1u);
-      cur_cost += (uint64_t)take * tc;
-      t += take;
+      slabs[sb].q1 = qi;
     }
-    dq.chunk_first = first_chunk;
-    dq.n_parts = ((uint32_t)g.chunk_starts.size() - first_chunk) * per_chunk;
+    slabs[n_slabs - 1].q1 = nq;
   }
-  g.n_chunks = (uint32_t)g.chunk_starts.size();
-  g.chunk_starts.push_back(g.total_tiles);
+  pt("slabs");
+  parallel_slabs(n_slabs, [&](uint32_t sb) {
+    Slab &S = slabs[sb];
+    S.starts.clear();
+    S.slice.clear();
+    S.query.clear();
+    uint64_t cur_cost = 0;
+    bool open_chunk = false;
+    uint32_t tc_seen = 0, per_fresh = 1;
+    for (size_t i = S.q0; i < S.q1; ++i) {
+      TqdQuery &dq = g.queries[i];
+      dq.part_start = 0;
+      dq.n_parts = 0;
+      dq.chunk_first = 0;
+      if (!dq.n_tiles) continue;
+      uint32_t first_chunk = 0xFFFFFFFFu;
+      uint32_t li = 0, li_seen = 0xFFFFFFFFu;
+      double sub_scale = 0.0;  // sub-slices per tile of the current leader's run
+      const double slice_scale = (double)(n_slices * 8u) / (double)dq.n_tiles;
+      for (uint32_t t = 0; t < dq.n_tiles;) {
+        uint32_t run_end;
+        const uint32_t tc = run_of(i, t, li, run_end);
+        if (!open_chunk || cur_cost >= cost_target) {
+          S.starts.push_back(dq.tile_start + t);
+          S.query.push_back((uint32_t)i);
+          // which part of the doc-id space the chunk starts in (lists are spread over it)
+          if (or_cand) {
+            // candidate-driven OR: high-weight lists first (their matches raise the threshold
+            // that lets the tiles of the dense low-weight lists be skipped), doc order inside
+            if (li != li_seen) {
+              li_seen = li;
+              const uint32_t span = std::max<uint32_t>(1u, dq.lead_tile_start[li + 1u] - dq.lead_tile_start[li]);
+              sub_scale = (double)kOrSubSlices / (double)span;
+            }
+            const uint32_t sub = std::min<uint32_t>(kOrSubSlices - 1u, (uint32_t)((double)(t - dq.lead_tile_start[li]) * sub_scale));
+            const uint32_t lic = std::min<uint32_t>(li, li_cap);
+            S.slice.push_back(std::min<uint32_t>(
+                n_slices * 8u - 1u, kOrSubMajor ? sub * (li_cap + 1u) + lic : lic * kOrSubSlices + sub));
+          } else {
+            S.slice.push_back(std::min<uint32_t>(n_slices * 8u - 1u, (uint32_t)((double)t * slice_scale)));
+          }
+          cur_cost = 0;
+          open_chunk = true;
+        }
+        if (first_chunk == 0xFFFFFFFFu) first_chunk = (uint32_t)S.starts.size() - 1u;
+        // as many tiles of this query as the chunk still takes (a fresh chunk takes the same
+        // number of tiles all along a run: the division is per run, not per chunk)
+        if (tc != tc_seen) {
+          tc_seen = tc;
+          per_fresh = (uint32_t)std::min<uint64_t>(0xFFFFFFFFull, (cost_target + tc - 1) / tc);
+        }
+        const uint64_t room = cost_target - cur_cost;
+        uint32_t take = cur_cost == 0 ? per_fresh
+                                      : (uint32_t)std::min<uint64_t>(0xFFFFFFFFull, (room + tc - 1) / tc);
+        take = std::min<uint32_t>(take, run_end - t);
+        take = std::max<uint32_t>(take, 1u);
+        cur_cost += (uint64_t)take * tc;
+        t += take;
+      }
+      dq.chunk_first = first_chunk;  // slab-local: rebased below
+      dq.n_parts = ((uint32_t)S.starts.size() - first_chunk) * per_chunk;
+    }
+  });
+  pt("chunk loop");
+  // The slabs' tables stay where they are: chunk c = offs[slab] + index in the slab.  Records
+  // {first tile, end tile, first query, chunk} are built slab by slab (sequential reads) and
+  // scattered straight to their launch positions' buckets.
+  std::vector<size_t> offs(n_slabs + 1, 0);
+  for (uint32_t sb = 0; sb < n_slabs; ++sb) offs[sb + 1] = offs[sb] + slabs[sb].starts.size();
+  g.n_chunks = (uint32_t)offs[n_slabs];
+  for (uint32_t sb = 1; sb < n_slabs; ++sb)
+    if (offs[sb])
+      for (size_t i = slabs[sb].q0; i < slabs[sb].q1; ++i)
+        if (g.queries[i].n_tiles) g.queries[i].chunk_first += (uint32_t)offs[sb];
+  auto end_tile_after = [&](uint32_t sb) -> uint32_t {  // first tile of the next non-empty slab
+    for (uint32_t nx = sb + 1; nx < n_slabs; ++nx)
+      if (!slabs[nx].starts.empty()) return slabs[nx].starts[0];
+    return g.total_tiles;
+  };
+  auto record_of = [&](const Slab &S, uint32_t sb, size_t j, uint32_t slab_end) {
+    return make_uint4(S.starts[j], j + 1 < S.starts.size() ? S.starts[j + 1] : slab_end, S.query[j],
+                      (uint32_t)(offs[sb] + j));
+  };
+  g.chunk_recs.resize(g.n_chunks);
+  if (or_win) {  // the window kernel runs in chunk order
+    for (uint32_t sb = 0; sb < n_slabs; ++sb) {
+      const uint32_t slab_end = end_tile_after(sb);
+      for (size_t j = 0; j < slabs[sb].starts.size(); ++j)
+        g.chunk_recs[offs[sb] + j] = record_of(slabs[sb], sb, j, slab_end);
+    }
+    pt("records");
+    return TQ_OK;
+  }
   // Launch order: all chunks of doc-range slice 0 (of every query), then slice 1, ...  The
   // dispatcher hands out workgroups in index order, so at any moment the whole chip works on
   // the same ~1/128 of the doc-id space: the fieldnorm bytes, bitmap words and hot posting
@@ -1215,50 +1324,76 @@ int build_group_chunks(Group &g, bool or_windows, PlanScratch &ps) {
   // Inside a slice the chunks are dealt round-robin from its 8 sub-slices: workgroup i runs
   // on XCD i % 8 (observed placement, MI355X_MICROARCH.md), so each XCD's L2 sees one eighth
   // of the slice.  Placement is a speed-up only; nothing depends on it.
-  g.chunk_perm.resize(g.n_chunks);
   {
     const uint32_t nb = n_slices * 8u;
-    std::vector<uint32_t> &start = ps.sort_start, &sorted = ps.sort_sorted, &fill = ps.sort_fill;
+    std::vector<uint32_t> &start = ps.sort_start;
+    // stable counting sort by slice: every slab counts its own histogram, the (slice, slab)
+    // prefix sums give every slab its own output positions
+    std::vector<uint32_t> &hist = ps.hist;  // [slab][nb]
+    hist.assign((size_t)n_slabs * nb, 0);
+    parallel_slabs(n_slabs, [&](uint32_t sb) {
+      uint32_t *h = hist.data() + (size_t)sb * nb;
+      for (uint32_t sl : slabs[sb].slice) ++h[sl];
+    });
     start.assign(nb + 1, 0);
-    for (uint32_t c = 0; c < g.n_chunks; ++c) ++start[g.chunk_slice[c] + 1];
-    for (uint32_t i = 0; i < nb; ++i) start[i + 1] += start[i];
-    sorted.resize(g.n_chunks);
-    fill.assign(start.begin(), start.end() - 1);
-    for (uint32_t c = 0; c < g.n_chunks; ++c) sorted[fill[g.chunk_slice[c]]++] = c;
-    uint32_t out = 0;
-    for (uint32_t sl = 0; sl < n_slices; ++sl) {
-      uint32_t at[8], end[8], left = 0;
-      for (uint32_t x = 0; x < 8; ++x) {
-        at[x] = start[sl * 8 + x];
-        end[x] = start[sl * 8 + x + 1];
-        left += end[x] - at[x];
+    {
+      uint32_t run = 0;
+      for (uint32_t i = 0; i < nb; ++i) {
+        start[i] = run;
+        for (uint32_t sb = 0; sb < n_slabs; ++sb) {
+          const uint32_t n = hist[(size_t)sb * nb + i];
+          hist[(size_t)sb * nb + i] = run;  // becomes the slab's write position in slice i
+          run += n;
+        }
       }
-      while (left) {
+      start[nb] = run;
+    }
+    std::vector<uint4> &sorted_recs = ps.sorted_recs;
+    sorted_recs.resize(g.n_chunks);
+    parallel_slabs(n_slabs, [&](uint32_t sb) {
+      const Slab &S = slabs[sb];
+      const uint32_t slab_end = end_tile_after(sb);
+      uint32_t *h = hist.data() + (size_t)sb * nb;
+      for (size_t j = 0; j < S.starts.size(); ++j) sorted_recs[h[S.slice[j]]++] = record_of(S, sb, j, slab_end);
+    });
+    pt("count sort");
+    // slice sl writes chunk_recs[start[8 sl] .. start[8 sl + 8)): slices are independent
+    const uint32_t deal_slabs = g.n_chunks >= 65536u ? std::min<uint32_t>(plan_threads(), n_slices) : 1u;
+    parallel_slabs(deal_slabs, [&](uint32_t sb) {
+      const uint32_t sl0 = (uint32_t)((uint64_t)n_slices * sb / deal_slabs);
+      const uint32_t sl1 = (uint32_t)((uint64_t)n_slices * (sb + 1) / deal_slabs);
+      for (uint32_t sl = sl0; sl < sl1; ++sl) {
+        uint32_t out = start[sl * 8];
+        uint32_t at[8], end[8], left = 0;
         for (uint32_t x = 0; x < 8; ++x) {
-          if (at[x] < end[x]) {
-            g.chunk_perm[out++] = sorted[at[x]++];
-            --left;
-          } else if (left) {  // keep the i % 8 alignment: borrow from the fullest sub-slice
-            uint32_t best = 8, most = 0;
-            for (uint32_t y = 0; y < 8; ++y)
-              if (end[y] - at[y] > most) {
-                most = end[y] - at[y];
-                best = y;
-              }
-            if (best < 8) {
-              g.chunk_perm[out++] = sorted[--end[best]];
+          at[x] = start[sl * 8 + x];
+          end[x] = start[sl * 8 + x + 1];
+          left += end[x] - at[x];
+        }
+        while (left) {
+          for (uint32_t x = 0; x < 8; ++x) {
+            if (at[x] < end[x]) {
+              g.chunk_recs[out++] = sorted_recs[at[x]++];
               --left;
+            } else if (left) {  // keep the i % 8 alignment: borrow from the fullest sub-slice
+              uint32_t best = 8, most = 0;
+              for (uint32_t y = 0; y < 8; ++y)
+                if (end[y] - at[y] > most) {
+                  most = end[y] - at[y];
+                  best = y;
+                }
+              if (best < 8) {
+                g.chunk_recs[out++] = sorted_recs[--end[best]];
+                --left;
+              }
             }
           }
         }
       }
-    }
+    });
   }
-  g.chunk_recs.resize(g.n_chunks);
-  for (uint32_t b = 0; b < g.n_chunks; ++b) {
-    const uint32_t c = or_win ? b : g.chunk_perm[b];  // the window kernel runs in chunk order
-    g.chunk_recs[b] = make_uint4(g.chunk_starts[c], g.chunk_starts[c + 1], g.chunk_query[c], c);
-  }
+  pt("deal");
+  pt("records");
   return TQ_OK;
 }
 

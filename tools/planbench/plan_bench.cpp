@@ -1,0 +1,73 @@
+// Host-only timing of the chunk planner (build_group_chunks of tq_api.cpp) on a synthetic launch
+// group shaped like the union half of the mixed bench stream: 5000 5-term candidate unions over a
+// 256-term Zipf vocabulary, 10M docs.  No GPU needed: the planner is plain host code.
+//   hipcc -O3 -std=c++17 -I tantivy_amd/csrc tools/planbench/plan_bench.cpp -o /tmp/plan_bench
+#include "../../tantivy_amd/csrc/tq_api.cpp"
+
+#include <chrono>
+#include <random>
+
+int main(int argc, char **argv) {
+  const int n_queries = argc > 1 ? atoi(argv[1]) : 5000;
+  const int reps = argc > 2 ? atoi(argv[2]) : 5;
+  const uint32_t max_doc = 10000000u, n_terms = 256;
+  std::vector<uint32_t> n_blocks(n_terms);
+  for (uint32_t r = 0; r < n_terms; ++r) n_blocks[r] = (max_doc / 2 / (r + 1) + 127) / 128;
+  std::mt19937 rng(7);
+  std::vector<double> cdf(n_terms);
+  double acc = 0;
+  for (uint32_t r = 0; r < n_terms; ++r) cdf[r] = (acc += 1.0 / (r + 1));
+  PlanScratch ps;
+  double best = 1e9;
+  uint32_t chunks = 0;
+  for (int rep = 0; rep < reps; ++rep) {
+    Group &g = ps.groups[1];
+    g.reset();
+    g.mode = TQ_MODE_OR;
+    rng.seed(7);
+    for (int q = 0; q < n_queries; ++q) {
+      TqdQuery dq{};
+      uint32_t picked[5], n = 0;
+      while (n < 5) {
+        const double u = std::uniform_real_distribution<double>(0, acc)(rng);
+        const uint32_t r = (uint32_t)(std::lower_bound(cdf.begin(), cdf.end(), u) - cdf.begin());
+        bool dup = false;
+        for (uint32_t i = 0; i < n; ++i) dup |= picked[i] == r;
+        if (!dup) picked[n++] = r;
+      }
+      std::sort(picked, picked + 5, [](uint32_t a, uint32_t b) { return a > b; });  // rare (heavy) first
+      dq.n_terms = 5;
+      dq.k = 10;
+      dq.flags = TQD_QF_PRUNE;
+      uint32_t sparse = 0;
+      for (uint32_t i = 0; i < 5; ++i) {
+        dq.term[i] = picked[i];
+        dq.weight[i] = 2.2f * logf(1.0f + (max_doc - max_doc / 2.0f / (picked[i] + 1)) / (max_doc / 2.0f / (picked[i] + 1)));
+        if (picked[i] >= 64) ++sparse;
+      }
+      const uint32_t c_lb = 1u + 5u + 8u * sparse;
+      dq.tile_blocks = std::max<uint32_t>(1u, TQD_AND_TILE * 2u / c_lb);
+      uint32_t at = 0;
+      for (uint32_t i = 0; i < 5; ++i) {
+        dq.lead_tile_start[i] = at;
+        at += (n_blocks[picked[i]] + dq.tile_blocks - 1) / dq.tile_blocks;
+      }
+      for (uint32_t i = 5; i <= TQ_MAX_TERMS; ++i) dq.lead_tile_start[i] = at;
+      dq.n_lead = 5;
+      dq.n_tiles = at;
+      g.queries.push_back(dq);
+      g.tile_cost.push_back(dq.tile_blocks * c_lb);
+      g.out_index.push_back((uint32_t)q);
+      g.max_k = 10;
+    }
+    const auto t0 = std::chrono::steady_clock::now();
+    const int rc = build_group_chunks(g, false, ps);
+    const auto t1 = std::chrono::steady_clock::now();
+    if (rc != TQ_OK) return 1;
+    best = std::min(best, std::chrono::duration<double, std::milli>(t1 - t0).count());
+    chunks = g.n_chunks;
+  }
+  printf("queries %d chunks %u tiles %u: build_group_chunks %.2f ms (best of %d)\n", n_queries, chunks,
+         ps.groups[1].total_tiles, best, reps);
+  return 0;
+}
