@@ -1077,6 +1077,8 @@ static uint32_t plan_threads() {
   static const uint32_t n = std::min<uint32_t>(16u, std::max<uint32_t>(1u, tune_u32("TQ_PLAN_THREADS", 4)));
   return n;
 }
+// batches below this many chunks are planned by the calling thread alone (TQ_PLAN_PAR_MIN: tests)
+static const uint32_t kPlanParMin = tune_u32("TQ_PLAN_PAR_MIN", 65536);
 static const uint32_t kOrChunkMul = std::max<uint32_t>(1u, tune_u32("TQ_OR_CHUNK_MUL", 4));
 static const uint32_t kOrChunkMulSmallK = std::max<uint32_t>(1u, tune_u32("TQ_OR_CHUNK_MUL_SMALLK", 8));
 
@@ -1200,7 +1202,7 @@ int build_group_chunks(Group &g, bool or_windows, PlanScratch &ps) {
   // The queries are cut into slabs of about equal cost; every slab builds its chunks on its own
   // (a chunk never spans two slabs) and the tables are concatenated afterwards.
   const size_t nq = g.queries.size();
-  const uint32_t n_slabs = (uint32_t)std::max<size_t>(1, std::min<size_t>(total_cost / cost_target >= 65536 ? plan_threads() : 1u, nq));
+  const uint32_t n_slabs = (uint32_t)std::max<size_t>(1, std::min<size_t>(total_cost / cost_target >= kPlanParMin ? plan_threads() : 1u, nq));
   using Slab = PlanSlab;
   std::vector<Slab> &slabs = ps.slabs;
   if (slabs.size() < n_slabs) slabs.resize(n_slabs);
@@ -1358,7 +1360,7 @@ int build_group_chunks(Group &g, bool or_windows, PlanScratch &ps) {
     });
     pt("count sort");
     // slice sl writes chunk_recs[start[8 sl] .. start[8 sl + 8)): slices are independent
-    const uint32_t deal_slabs = g.n_chunks >= 65536u ? std::min<uint32_t>(plan_threads(), n_slices) : 1u;
+    const uint32_t deal_slabs = g.n_chunks >= kPlanParMin ? std::min<uint32_t>(plan_threads(), n_slices) : 1u;
     parallel_slabs(deal_slabs, [&](uint32_t sb) {
       const uint32_t sl0 = (uint32_t)((uint64_t)n_slices * sb / deal_slabs);
       const uint32_t sl1 = (uint32_t)((uint64_t)n_slices * (sb + 1) / deal_slabs);

@@ -1,0 +1,39 @@
+"""Host planner (tq_api.cpp: build_group_chunks) without a GPU: tools/planbench/plan_check.cpp
+includes the planner's translation unit, plans synthetic launch groups (candidate unions with a
+run of tiles per leader, AND-style groups, window unions) and checks that the chunks tile the
+tile range exactly once, that every chunk is launched exactly once and that the per-query chunk
+ranges are consistent — with the calling thread alone and with the planner's worker threads."""
+import os
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+
+
+@pytest.fixture(scope="module")
+def plan_check(tmp_path_factory):
+    from tantivy_amd import build as B
+
+    B.build()  # the kernel objects the planner's translation unit links against
+    out = tmp_path_factory.mktemp("plan") / "plan_check"
+    obj = str(out) + ".o"
+    src = os.path.join(ROOT, "tools", "planbench", "plan_check.cpp")
+    subprocess.check_call([HIPCC, "-O1", "-std=c++17", "-Wno-unused-function", "-fPIC", "-c", src, "-o", obj],
+                          cwd=str(out.parent))
+    objs = [os.path.join(B.OBJ_DIR, os.path.basename(s) + ".o") for s in B.SOURCES
+            if os.path.basename(s).endswith(".hip") or os.path.basename(s) == "tq_comm.cpp"]
+    subprocess.check_call([HIPCC, "--offload-arch=gfx950", "-o", str(out), obj] + objs + ["-ldl", "-lpthread"],
+                          cwd=str(out.parent))
+    return str(out)
+
+
+@pytest.mark.parametrize("threads", [1, 4])
+@pytest.mark.parametrize("chunks", [512, 131072])
+def test_chunk_tables_cover_every_tile_once(plan_check, threads, chunks):
+    for seed in (1, 2, 3):
+        env = dict(os.environ, TQ_PLAN_THREADS=str(threads), TQ_CHUNKS=str(chunks), TQ_PLAN_PAR_MIN="1")
+        r = subprocess.run([plan_check, str(seed)], env=env, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr + r.stdout
+        assert r.stdout.count("ok") == 3, r.stdout
