@@ -6,8 +6,8 @@ R=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$R/gpurun_out/prof_extra_$W
 rm -rf $OUT; mkdir -p $OUT
 B="python $R/bench.py --workload $W --steps 3 --warmup 1 --no-cpu-baseline --latency-queries 0 --no-side"
-rocprofv3 --pmc SQ_INSTS_VMEM_WR SQ_INSTS_VMEM_RD SQ_INSTS_FLAT SQ_INSTS_LDS SQ_INSTS_SMEM --output-format csv -d $OUT/e1 -o e1 -- $B > $OUT/e1.log 2>&1
-rocprofv3 --pmc TCC_REQ_sum TCC_READ_sum TCC_WRITE_sum TCC_ATOMIC_sum TCC_EA0_RDREQ_sum TCC_EA0_WRREQ_sum --output-format csv -d $OUT/e2 -o e2 -- $B > $OUT/e2.log 2>&1
+timeout 120 rocprofv3 --pmc SQ_INSTS_VMEM_WR SQ_INSTS_VMEM_RD SQ_INSTS_FLAT SQ_INSTS_LDS SQ_INSTS_SMEM --output-format csv -d $OUT/e1 -o e1 -- $B > $OUT/e1.log 2>&1
+timeout 120 rocprofv3 --pmc TCC_REQ_sum TCC_READ_sum TCC_WRITE_sum --output-format csv -d $OUT/e2 -o e2 -- $B > $OUT/e2.log 2>&1
 python - <<PY
 import csv, collections
 for e in ("e1","e2"):
