@@ -1690,8 +1690,10 @@ int search_batch_impl(tq_segment *s, const tq_query *queries, uint32_t n_queries
             if (!(th.dense_blob && th.posdir_blob && col && s->opt.use_dense && s->d_docmat))
               phrase_all_dense = false;
           }
-          dq.tile_blocks = 32;
-          tile_cost = 64;
+          // (64-block tiles: one leader block per lane of the pre-filter; 32 was 10 % slower)
+          static const uint32_t kPhTile = std::min<uint32_t>(TQD_AND_TILE, std::max<uint32_t>(1u, tune_u32("TQ_PH_TILE_BLOCKS", 64)));
+          dq.tile_blocks = kPhTile;
+          tile_cost = 2u * kPhTile;
           n_tiles = (lead_blocks + dq.tile_blocks - 1) / dq.tile_blocks;
         }
       }
