@@ -1533,7 +1533,8 @@ int plan_bool_query(tq_segment *s, const tq_query &q, uint32_t qi, TqdQuery &dq,
       }
     }
     const uint32_t c_lb = 1u + n + 8u * sparse;
-    dq.tile_blocks = std::max<uint32_t>(1u, TQD_AND_TILE * 2u / c_lb);
+    static const uint32_t kBoolTileNum = std::max<uint32_t>(1u, tune_u32("TQ_BOOL_TILE_NUM", TQD_AND_TILE * 2u));
+    dq.tile_blocks = std::min<uint32_t>(TQD_AND_TILE, std::max<uint32_t>(1u, kBoolTileNum / c_lb));
     tile_cost = dq.tile_blocks * c_lb;
     uint32_t acc_tiles = 0;
     for (uint32_t i = 0; i <= TQ_MAX_TERMS; ++i) {
@@ -1670,7 +1671,8 @@ int search_batch_impl(tq_segment *s, const tq_query *queries, uint32_t n_queries
             all_dense = false;
             c_lb += 2u * std::min<uint32_t>(128u, (th.n_blocks + lead_blocks - 1) / lead_blocks);
           }
-          dq.tile_blocks = std::max<uint32_t>(1u, TQD_AND_TILE / c_lb);
+          static const uint32_t kAndTileNum = std::max<uint32_t>(1u, tune_u32("TQ_AND_TILE_NUM", TQD_AND_TILE));
+          dq.tile_blocks = std::min<uint32_t>(TQD_AND_TILE, std::max<uint32_t>(1u, kAndTileNum / c_lb));
           tile_cost = dq.tile_blocks * c_lb;
           n_tiles = (lead_blocks + dq.tile_blocks - 1) / dq.tile_blocks;
           bool nonneg = true;
@@ -1757,8 +1759,9 @@ int search_batch_impl(tq_segment *s, const tq_query *queries, uint32_t n_queries
           if (!(s->terms[dq.term[i]].dense_blob && s->opt.use_dense)) ++sparse;
         const uint32_t c_lb = 1u + dq.n_terms + 8u * sparse;
         static const uint32_t kOrTileBlocks = tune_u32("TQ_OR_TILE_BLOCKS", 0);
+        static const uint32_t kOrTileNum = std::max<uint32_t>(1u, tune_u32("TQ_OR_TILE_NUM", TQD_AND_TILE * 2u));
         dq.tile_blocks = kOrTileBlocks ? std::min<uint32_t>(kOrTileBlocks, TQD_AND_TILE)
-                                       : std::max<uint32_t>(1u, TQD_AND_TILE * 2u / c_lb);
+                                       : std::min<uint32_t>(TQD_AND_TILE, std::max<uint32_t>(1u, kOrTileNum / c_lb));
         tile_cost = dq.tile_blocks * c_lb;
         uint32_t acc_tiles = 0;
         for (uint32_t i = 0; i < dq.n_terms; ++i) {
