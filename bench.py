@@ -436,9 +436,12 @@ def main():
 
     parity_checked = (spot_check(O, seg, args.workload, queries, k, m["final"])
                       if world == 1 and S_main == 1 else 0)
-    cpu = None
+    # The CPU baselines run AFTER every GPU measurement of the run: 10 s of all granted host cores
+    # exhaust the cgroup's CPU quota, and the host planner of the next GPU measurement pays for it
+    # (one run had the or5 step at 8.1 ms right after the baseline, 5.2 ms without).
+    cpu_jobs = []  # (key, segment, workload, queries, k, seconds, sweep)
     if world == 1 and not args.no_cpu_baseline:
-        cpu = cpu_baseline(O, seg, args.workload, queries, k, args.cpu_seconds, sweep=True)
+        cpu_jobs.append(("main", seg, args.workload, queries, k, args.cpu_seconds, True))
 
     # ---------------------------------------------------------------- other BASELINE configs (N=1)
     side = {}
@@ -476,8 +479,7 @@ def main():
                 "traffic": (load_traffic("%s_pruned_%d" % (wl, args.docs)) or {}).get("hbm_bytes_per_launch"),
             }
             if not args.no_cpu_baseline:
-                c = cpu_baseline(O, s_seg, wl, qs, kk, max(2.0, args.cpu_seconds / 3), sweep=False)
-                side[wl]["cpu_baseline"] = {key: c[key] for key in ("value", "unit", "cores", "kind")}
+                cpu_jobs.append((wl, s_seg, wl, qs, kk, max(2.0, args.cpu_seconds / 3), False))
             if s_runner is not runner:
                 s_runner.close()
     runner.close()
@@ -536,6 +538,14 @@ def main():
         if cl.dist is not None:
             cl.dist.destroy_process_group()
         return
+
+    cpu = None
+    for key, c_seg, c_wl, c_qs, c_k, c_sec, c_sweep in cpu_jobs:
+        c = cpu_baseline(O, c_seg, c_wl, c_qs, c_k, c_sec, sweep=c_sweep)
+        if key == "main":
+            cpu = c
+        else:
+            side[key]["cpu_baseline"] = {kk2: c[kk2] for kk2 in ("value", "unit", "cores", "kind")}
 
     st = m["stats"]
     k_ms = st["kernel_ms"]
