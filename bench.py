@@ -174,45 +174,78 @@ def usable_cpus():
     return max(1, n)
 
 
-def cpu_baseline(O, seg, workload, queries, k, seconds, sweep):
-    """The oracle's C restatement of tantivy's executors, query-level parallelism over host
-    threads (tantivy runs one query per thread per segment), on a bounded sample."""
+def global_stats(all_stats):
+    """(total docs, total tokens, doc freq per term id) over every segment of every rank
+    (Bm25Weight::for_terms statistics, bm25.rs:27-50,95-129)."""
+    flat = [st for lst in all_stats for st in lst]
+    nd = sum(st[0] for st in flat)
+    nt = sum(st[1] for st in flat)
+    dfs = np.sum(np.array([st[2] for st in flat], dtype=np.int64), axis=0)
+    return nd, nt, dfs
+
+
+def oracle_spec(O, seg, workload, q, k, gstats):
+    """QuerySpec of one query on one segment with the index-wide Bm25Weights."""
+    if q[0] not in (O.MODE_AND, O.MODE_OR, O.MODE_PHRASE):  # boolean shapes: the generic scorer tree
+        return O.bool_spec(seg, q[1], q[2], q[3], q[4], k)
+    nd, nt, dfs = gstats if gstats is not None else (None, None, None)
+    w = O.default_weights(seg, q[1], q[0], nd, nt, None if dfs is None else [int(dfs[t]) for t in q[1]])
+    return O.QuerySpec(seg, q[1], w, q[0], k,
+                       list(range(len(q[1]))) if q[0] == O.MODE_PHRASE else None)
+
+
+def cpu_baseline(O, segs, workload, queries, k, seconds, sweep, gstats=None):
+    """The oracle's C restatement of tantivy's executors on the host cores, on a bounded sample:
+    every query runs on every segment of `segs` (one task per query and segment, all granted
+    threads busy — Executor::MultiThread's map over segment readers, executor.rs:61-104), with the
+    index-wide Bm25Weights when there are several.  Timed twice: with the SSE2 BitPacker4x decode
+    (oracle/to_simd.c — the reference's decoder is SIMD code; this is `value`) and with the
+    scalar decode (`qps_scalar`)."""
     cores = usable_cpus()
+    many = len(segs) > 1
 
-    def spec_of(q):
-        if workload == "bool":  # the restated generic scorer tree (no block-max executor)
-            return O.bool_spec(seg, q[1], q[2], q[3], q[4], k)
-        return O.QuerySpec(seg, q[1], O.default_weights(seg, q[1], q[0]), q[0], k,
-                           list(range(len(q[1]))) if q[0] == O.MODE_PHRASE else None)
+    def run(threads, budget, simd):
+        prev = O.set_simd(simd)
+        try:
+            done, wall_total = 0, 0.0
+            chunk = max(32, threads * 8)
+            while wall_total < budget and done < len(queries):
+                part = queries[done:done + chunk]
+                for seg in segs:
+                    specs = [oracle_spec(O, seg, workload, q, k, gstats if many else None) for q in part]
+                    wall, _, _ = O.baseline_run(seg, specs, threads)
+                    wall_total += wall
+                done += len(part)
+            return done / wall_total, done, wall_total
+        finally:
+            O.set_simd(prev)
 
-    def run(threads, budget):
-        done, wall_total = 0, 0.0
-        chunk = max(32, threads * 8)
-        while wall_total < budget and done < len(queries):
-            part = queries[done:done + chunk]
-            wall, _, _ = O.baseline_run(seg, [spec_of(q) for q in part], threads)
-            wall_total += wall
-            done += len(part)
-        return done / wall_total, done, wall_total
-
-    qps, done, wall = run(cores, seconds)
+    qps, done, wall = run(cores, seconds, True)
+    qps_scalar = run(cores, max(1.0, seconds / 3.0), False)[0]
+    what = ("generic scorer tree (Intersection / BufferedUnionScorer / RequiredOptionalScorer / "
+            "Exclude under for_each_pruning_scorer)" if workload == "bool" else
+            "block_wand_intersection / block_wand / PhraseScorer")
     out = {"value": round(qps, 2), "unit": "queries/s", "cores": cores, "kind": "port",
-           "sample": "first %d queries of the same stream, query-level parallelism on %d threads "
+           "qps_simd": round(qps, 2), "qps_scalar": round(qps_scalar, 2),
+           "sample": "first %d queries of the same stream%s, query-level parallelism on %d threads "
                      "(sched_getaffinity bounded by the cgroup CPU quota; os.cpu_count() = %d), "
-                     "%.1f s; C restatement of tantivy's %s (oracle/), scalar code, not the tantivy "
-                     "binary" % (done, cores, os.cpu_count() or 0, wall,
-                                 "generic scorer tree (Intersection / BufferedUnionScorer / "
-                                 "RequiredOptionalScorer / Exclude under for_each_pruning_scorer)"
-                                 if workload == "bool" else
-                                 "block_wand_intersection / block_wand / PhraseScorer")}
+                     "%.1f s; C restatement of tantivy's %s (oracle/) with an SSE2 BitPacker4x decode "
+                     "(qps_scalar: the scalar decode), -O3 -march=x86-64-v3; not the tantivy binary" %
+                     (done, " on each of the %d segments (global statistics)" % len(segs) if many else "",
+                      cores, os.cpu_count() or 0, wall, what)}
     if sweep:
         by_threads = {}
         for t in sorted({1, 8, 32, cores}):
             if t > cores:
                 continue
-            by_threads[str(t)] = round(run(t, seconds / 5.0)[0], 1) if t != cores else out["value"]
+            by_threads[str(t)] = round(run(t, seconds / 5.0, True)[0], 1) if t != cores else out["value"]
         out["qps_by_threads"] = by_threads
-        _, lat1, _ = O.baseline_run(seg, [spec_of(q) for q in queries[:48]], 1)
+        prev = O.set_simd(True)
+        try:
+            _, lat1, _ = O.baseline_run(segs[0], [oracle_spec(O, segs[0], workload, q, k, None)
+                                                  for q in queries[:48]], 1)
+        finally:
+            O.set_simd(prev)
         out["p50_latency_ms_1core"] = round(float(np.median(lat1)) * 1e3, 3)
     return out
 
@@ -345,21 +378,77 @@ def load_traffic(key):
     return None
 
 
-def spot_check(O, seg, workload, queries, k, final, n_check=16):
+def traffic_fields(tj, launches, kernel_ms):
+    """roofline.traffic & co. from a committed PMC run (profiles/traffic.json), only while that
+    run measured THIS tree's kernels: entries carry the hash of tantivy_amd/csrc they were taken
+    on (tools/summarize_profile.py); with another hash the figures are withheld, not re-printed."""
+    from tantivy_amd import build as product_build
+
+    out = {"traffic": None, "physical_frac": None, "l2_hit_rate": None, "traffic_from_commit": None,
+           "traffic_matches_this_build": None, "traffic_note": "no PMC run recorded"}
+    if not tj:
+        return out
+    out["traffic_from_commit"] = tj.get("measured_on_commit")
+    same = tj.get("csrc_hash") == product_build.csrc_hash()
+    out["traffic_matches_this_build"] = same
+    if not same:
+        out["traffic_note"] = ("the committed PMC run (%s) measured other kernel sources (csrc hash %s, this "
+                               "tree %s): traffic / physical_frac withheld" %
+                               (tj.get("profile"), tj.get("csrc_hash"), product_build.csrc_hash()))
+        return out
+    out["traffic"] = tj["hbm_bytes_per_launch"] * launches
+    out["traffic_note"] = tj["note"]
+    out["l2_hit_rate"] = tj.get("l2_hit_rate")
+    if kernel_ms > 0:
+        out["physical_frac"] = round(out["traffic"] / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+    return out
+
+
+def spot_check(O, cl, segs, first_ord, gstats, workload, queries, k, final, n_check=64):
+    """A sample of the batch against the oracle, at the run's own size: every rank runs the oracle's
+    exhaustive executor on each of its local segments with the index-wide Bm25Weights, the hits
+    are gathered over the control plane (gloo), merged by the oracle's merge_top_k (score desc,
+    segment_ord asc, doc asc) and compared with the merged device result: doc addresses equal,
+    scores within 1e-5 relative (BASELINE.json).  Returns the number of queries checked."""
+    import ctypes as C
+    from concurrent.futures import ThreadPoolExecutor
+
     n_q = len(queries)
-    checked = 0
-    for i in list(range(0, n_q, max(1, n_q // n_check)))[:n_check]:
-        mode, terms = queries[i][0], queries[i][1]
-        if workload == "bool":
-            want = O.bool_search(seg, terms, queries[i][2], k, queries[i][3], queries[i][4])
-        else:
-            want = O.search(seg, terms, mode, k, pruned=False)
-        got = [(float(final[0][i, j]), int(final[2][i, j])) for j in range(int(final[3][i]))]
-        assert len(got) == len(want), (i, got, want)
-        for (gs, gd), (ws, wd) in zip(got, want):
-            assert gd == wd and abs(gs - ws) <= 1e-5 * abs(ws), (i, got, want)
-        checked += 1
-    return checked
+    if workload == "bool" and (len(segs) > 1 or cl.world > 1):
+        return 0  # (the restated scorer tree takes segment-local weights only)
+    many = len(segs) > 1 or cl.world > 1
+    sample = sorted(set(int(x) for x in np.linspace(0, n_q - 1, min(n_check, n_q))))
+
+    def local_hits(i):
+        hits = []
+        for j, seg in enumerate(segs):
+            spec = oracle_spec(O, seg, workload, queries[i], k, gstats if many else None)
+            out = (O.Hit * max(1, k))()
+            n = O.lib().to_search_exhaustive(C.byref(seg.view), C.byref(spec.q), out)
+            hits += [(float(out[x].score), first_ord + j, int(out[x].doc)) for x in range(n)]
+        return hits
+
+    with ThreadPoolExecutor(max_workers=max(1, min(16, usable_cpus()))) as pool:
+        mine = list(pool.map(local_hits, sample))  # (ctypes calls release the GIL)
+    everyone = cl.all_gather_object(mine)
+    for si, i in enumerate(sample):
+        want = O.merge_top_k([h for r in everyone for h in r[si]], 0, k)
+        got = [(float(final[0][i, j]), int(final[1][i, j]), int(final[2][i, j]))
+               for j in range(int(final[3][i]))]
+        assert len(got) == len(want), (workload, i, got, want)
+        for (gs, go, gd), (ws, wo, wd) in zip(got, want):
+            assert (go, gd) == (wo, wd) and abs(gs - ws) <= 1e-5 * abs(ws), (workload, i, got, want)
+    return len(sample)
+
+
+def resident_bytes(runner):
+    """Bytes the local segments keep in HBM, by kind, from the library (tq_segment_get_stats)."""
+    tot = {}
+    for s in range(runner.n_local):
+        for key, v in runner.dev.segment_stats(s).items():
+            if key.endswith("_bytes"):
+                tot[key] = tot.get(key, 0) + v
+    return tot
 
 
 def main():
@@ -367,6 +456,10 @@ def main():
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         raise SystemExit(relaunch_ranks(args))
     cl = Cluster()
+    # planner worker threads per process: the granted CPUs are shared by the ranks of the node
+    # (8 ranks x 4 threads on a 16-CPU cgroup would make the host planner the bottleneck)
+    local_world = int(os.environ.get("LOCAL_WORLD_SIZE", cl.world))
+    os.environ.setdefault("TQ_PLAN_THREADS", str(max(1, min(4, usable_cpus() // max(1, local_world)))))
     if cl.world != args.gpus and cl.world > 1:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, cl.world))
     if args.selftest_launcher:
@@ -415,7 +508,7 @@ def main():
     cl.make_comm(runner.dev.ctx)
     runner.comm, runner.torch_group = cl.comm, cl.torch_group
     runner.set_option("timing", 1)
-    for name in ("dense_ratio", "dense_budget_x", "docmat", "device_prepare"):  # experiments: TQ_OPT_dense_ratio=...
+    for name in ("dense_ratio", "dense_budget_x", "docmat", "device_prepare", "or_windows"):  # experiments: TQ_OPT_dense_ratio=...
         if os.environ.get("TQ_OPT_" + name):
             runner.set_option(name, int(os.environ["TQ_OPT_" + name]))
     queries, k = build_queries(O, args.workload, n_main, args.k, args.terms)
@@ -434,19 +527,22 @@ def main():
             runner.dev.search_prepared(k)
             lat.append(time.perf_counter() - t1)
 
-    parity_checked = (spot_check(O, seg, args.workload, queries, k, m["final"])
-                      if world == 1 and S_main == 1 else 0)
+    gstats_main = global_stats(all_stats)
+    parity_checked = spot_check(O, cl, main_segs, rank * S_main, gstats_main, args.workload, queries, k,
+                                m["final"], 64)
+    main_resident = resident_bytes(runner)
+    main_exchange_ms = runner.exchange_ms()
     # The CPU baselines run AFTER every GPU measurement of the run: 10 s of all granted host cores
     # exhaust the cgroup's CPU quota, and the host planner of the next GPU measurement pays for it
     # (one run had the or5 step at 8.1 ms right after the baseline, 5.2 ms without).
     cpu_jobs = []  # (key, segment, workload, queries, k, seconds, sweep)
     if world == 1 and not args.no_cpu_baseline:
-        cpu_jobs.append(("main", seg, args.workload, queries, k, args.cpu_seconds, True))
+        cpu_jobs.append(("main", [seg], args.workload, queries, k, args.cpu_seconds, True, None))
 
     # ---------------------------------------------------------------- other BASELINE configs (N=1)
     side = {}
     if world == 1 and not args.no_side:
-        for wl in ("or5", "phrase3", "mixed"):
+        for wl in ("or5", "phrase3", "mixed", "bool"):
             if wl == args.workload:
                 continue
             s_seg, s_runner = seg, runner
@@ -459,7 +555,7 @@ def main():
             sm = measure(cl, s_runner, torch, qs, kk, args.side_steps, 1)
             if not sm["mode_parity"]:
                 raise SystemExit("%s: pruned and exhaustive results differ on %d queries" % (wl, sm["n_diff"]))
-            checked = spot_check(O, s_seg, wl, qs, kk, sm["final"], 6)
+            checked = spot_check(O, cl, [s_seg], rank, None, wl, qs, kk, sm["final"], 64)
             k_ms = sm["stats"]["kernel_ms"]
             ach, fr = frac_of(sm["algo_bytes_full"], k_ms)
             ach_e, fr_e = frac_of(sm["algo_bytes_full"], sm["exh_stats"]["kernel_ms"])
@@ -475,11 +571,12 @@ def main():
                 "exhaustive_roofline_frac": fr_e,
                 "algorithmic_bytes_per_launch": int(sm["algo_bytes_full"]),
                 "docs_scored_per_launch": int(sm["stats"]["matches"]),
+                "host_plan_ms": round(sm["stats"]["host_plan_ms"], 3),
                 "pruned_equals_exhaustive": True, "parity_checked_queries": checked,
-                "traffic": (load_traffic("%s_pruned_%d" % (wl, args.docs)) or {}).get("hbm_bytes_per_launch"),
             }
+            side[wl].update(traffic_fields(load_traffic("%s_pruned_%d" % (wl, args.docs)), 1, k_ms))
             if not args.no_cpu_baseline:
-                cpu_jobs.append((wl, s_seg, wl, qs, kk, max(2.0, args.cpu_seconds / 3), False))
+                cpu_jobs.append((wl, [s_seg], wl, qs, kk, max(2.0, args.cpu_seconds / 3), False, None))
             if s_runner is not runner:
                 s_runner.close()
     runner.close()
@@ -508,7 +605,9 @@ def main():
             raise SystemExit("strong: pruned and exhaustive results differ on %d queries" % sm["n_diff"])
         k_ms = sm["stats"]["kernel_ms"]
         ach, fr = frac_of(sm["algo_bytes_full"], k_ms)
-        resident = sum(int(s.idx_len) + s.max_doc for s in segs)
+        gstats8 = global_stats(everyone)
+        checked8 = spot_check(O, cl, segs, ords[0], gstats8, "mixed", qs, kk, sm["final"], 64)
+        res8 = resident_bytes(srun)
         strong = {
             "config": "BASELINE configs[4]: %d x %dM-doc segments (%dM docs), mixed 50%% 2-term AND / "
                       "50%% 5-term OR stream, %d queries/batch, k=%d, global BM25 statistics; %d "
@@ -522,13 +621,27 @@ def main():
             "kernel_ms_per_gpu": round(k_ms, 4),
             "roofline_achieved_GBps_per_gpu": ach, "roofline_frac_per_gpu": fr,
             "algorithmic_bytes_per_step_per_gpu": int(sm["algo_bytes_full"]),
-            "index_plus_fieldnorm_bytes_per_gpu": resident,
-            "hbm_resident_note": "index + fieldnorms + bitmaps + skip tables of %d segments ~ %.1f GB per "
-                                 "GPU: %s the 256 MB Infinity Cache" %
-                                 (s_local, s_local * 0.14, "beyond" if s_local >= 2 else "within"),
+            "resident_bytes_per_gpu": res8,
+            "hbm_resident_note": "tantivy's bytes %.3f GB + derived side tables %.3f GB resident per GPU "
+                                 "(tq_segment_get_stats): %s the 256 MB Infinity Cache" %
+                                 (res8.get("tantivy_bytes", 0) / 1e9, res8.get("derived_bytes", 0) / 1e9,
+                                  "beyond" if res8.get("tantivy_bytes", 0) + res8.get("derived_bytes", 0) > 256e6
+                                  else "within"),
+            "host_plan_ms_per_gpu": round(sm["stats"]["host_plan_ms"], 3),
+            "exchange_ms": round(srun.exchange_ms(), 4),
+            "time_note": "per step and GPU: host_plan_ms = host time inside collect_segment over the "
+                         "local segments (validate + plan + stage + enqueue; overlaps the previous step's "
+                         "kernels while it stays below them), kernel_ms = scan kernels (HIP events), "
+                         "exchange_ms = all-gather + merge_top_k (stream events)",
+            "plan_threads": int(os.environ.get("TQ_PLAN_THREADS", "4")),
             "exchange": cl.exchange_note, "pruned_equals_exhaustive": True,
+            "parity_checked_queries": checked8,
+            "parity_note": "oracle (exhaustive executor per segment, global Bm25Weights) -> gathered over "
+                           "the control plane -> oracle merge_top_k, against the merged device result",
             "index_build_s": round(t_gen8, 2),
         }
+        if world == 1 and not args.no_cpu_baseline:
+            cpu_jobs.append(("strong", segs, "mixed", qs, kk, args.cpu_seconds, False, gstats8))
         srun.close()
         if cl.comm is not None:
             cl.comm.close()
@@ -540,12 +653,15 @@ def main():
         return
 
     cpu = None
-    for key, c_seg, c_wl, c_qs, c_k, c_sec, c_sweep in cpu_jobs:
-        c = cpu_baseline(O, c_seg, c_wl, c_qs, c_k, c_sec, sweep=c_sweep)
+    for key, c_segs, c_wl, c_qs, c_k, c_sec, c_sweep, c_gs in cpu_jobs:
+        c = cpu_baseline(O, c_segs, c_wl, c_qs, c_k, c_sec, sweep=c_sweep, gstats=c_gs)
         if key == "main":
             cpu = c
+        elif key == "strong":
+            strong["cpu_baseline"] = c
         else:
-            side[key]["cpu_baseline"] = {kk2: c[kk2] for kk2 in ("value", "unit", "cores", "kind")}
+            side[key]["cpu_baseline"] = {kk2: c[kk2] for kk2 in ("value", "unit", "cores", "kind",
+                                                                 "qps_simd", "qps_scalar")}
 
     st = m["stats"]
     k_ms = st["kernel_ms"]
@@ -553,18 +669,12 @@ def main():
     achieved, frac = frac_of(algo_bytes, k_ms)
     other_st = m["exh_stats"] if pruned_mode else m["prn_stats"]
     o_ach, o_frac = frac_of(algo_bytes, other_st["kernel_ms"])
-    traffic, traffic_note, physical = None, "no PMC run recorded", None
     tkey = "%s_%s_%d" % (args.workload, "pruned" if pruned_mode else "exhaustive", args.docs)
     if args.terms != 256:
         tkey += "_t%d" % args.terms
     if S_main != 1:
         tkey += "_s%d" % S_main
-    tj = load_traffic(tkey)
-    if tj:
-        traffic = tj["hbm_bytes_per_launch"] * S_main  # per step: one scan launch per local segment
-        traffic_note = tj["note"]
-        if k_ms > 0:
-            physical = round(traffic / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+    tf = traffic_fields(load_traffic(tkey), S_main, k_ms)  # per step: one scan launch per local segment
     total_units = n_q * args.steps * world  # one unit = one query evaluated on one segment
     value = total_units / m["elapsed"]
     out = {
@@ -609,15 +719,20 @@ def main():
             "peak": HBM_PEAK_GBS,
             "unit": "GB/s",
             "frac": frac,
-            "traffic": traffic,
-            "physical_frac": physical,
-            "l2_hit_rate": (tj or {}).get("l2_hit_rate"),
+            "traffic": tf["traffic"],
+            "physical_frac": tf["physical_frac"],
+            "l2_hit_rate": tf["l2_hit_rate"],
+            "traffic_from_commit": tf["traffic_from_commit"],
+            "traffic_matches_this_build": tf["traffic_matches_this_build"],
             "kernel": "and_kernel" if args.workload == "and2" else args.workload + " scan kernels",
             "kernel_ms_avg": round(k_ms, 4),
             "algorithmic_bytes_per_launch": int(algo_bytes),
             "docs_scored_per_launch": int(st["matches"]),
             "matches_per_launch": int(m["full_matches"]),
-            "traffic_note": traffic_note,
+            "traffic_note": tf["traffic_note"],
+            "host_plan_ms": round(st["host_plan_ms"], 3),
+            "exchange_ms": round(main_exchange_ms, 4),
+            "resident_bytes": main_resident,
             "frac_note": "frac = algorithmic bytes (SURVEY.md §8d: postings ranges + 1 B per match + 8k; "
                          "what a full scan would read) / kernel time / 8 TB/s — the pruned kernel skips "
                          "most of them, so this is work-equivalent bandwidth, not achieved HBM bandwidth; "

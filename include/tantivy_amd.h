@@ -301,14 +301,30 @@ typedef struct tq_batch_stats {
   uint32_t tiles;
   uint32_t chunks;
   uint32_t batches_averaged;  /* how many batches kernel_ms / total_ms average (<= 16) */
+  float host_plan_ms;         /* host time inside tq_search_batch_device (validate + plan + stage +
+                                 enqueue), mean over the calls since the last tq_last_batch_stats */
 } tq_batch_stats;
 int tq_last_batch_stats(tq_segment *seg, tq_batch_stats *out);
-/* knobs: "exhaustive" (0/1, default 1: score every match; 0: block-max pruning as
- *        block_wand_intersection does — same top-k either way),
+/* Bytes the segment keeps resident in HBM, by kind: the reference's own sub-files (copied
+ * verbatim) and the derived side tables of DESIGN.md section 2 — term tables (unrolled skip
+ * records, coarse seek tables, decoded vint tails, position-block tables: what SkipReader /
+ * PositionReader hold per open term in the reference), bitmaps + rank directories of the dense
+ * lists, the doc matrix, position directories — plus the per-batch scratch. */
+typedef struct tq_segment_stats {
+  uint64_t index_bytes, positions_bytes, fieldnorm_bytes, alive_bytes; /* tantivy's bytes */
+  uint64_t term_table_bytes, bitmap_bytes, docmat_bytes, posdir_bytes; /* derived */
+  uint64_t scratch_bytes;       /* staging, partial lists, threshold slots, result slabs */
+  uint64_t dense_budget_bytes;  /* cap on bitmap + docmat + posdir bytes ("dense_budget_x") */
+  uint32_t n_terms, n_dense_lists, n_docmat_columns;
+} tq_segment_stats;
+int tq_segment_get_stats(tq_segment *seg, tq_segment_stats *out);
+/* knobs: "exhaustive" (0/1, default 0: block-max pruning as block_wand / block_wand_intersection
+ *        do — the reference's execution; 1: score every match — same top-k either way, and
+ *        tq_last_batch_match_counts then returns match counts),
  *        "timing" (0/1: record HIP events per batch),
  *        "dense" (0/1, default 1: tq_term_prepare also builds a bitmap + rank directory for lists
- *        with doc_freq >= max_doc/dense_ratio, while all bitmaps stay below 4x the segment's
- *        bytes), "dense_ratio" (default 128), "use_dense" (0/1, default 1: the AND kernel may use
+ *        with doc_freq >= max_doc/dense_ratio, while bitmaps + doc matrix + position directories
+ *        stay below "dense_budget_x" times the segment's bytes), "dense_ratio" (default 128), "use_dense" (0/1, default 1: the AND kernel may use
  *        them),
  *        "or_windows" (-1/0/1, default -1 = auto: unions run window-parallel when exhaustive and
  *        candidate-driven when pruning; 0 / 1 force one kernel),

@@ -19,7 +19,7 @@ MODE_AND, MODE_OR, MODE_PHRASE, MODE_BOOL = 0, 1, 2, 3
 
 
 def build(force=False):
-    srcs = ["to_codec.c", "to_postings.c", "to_query.c", "to_gen.c", "tantivy_oracle.h", "Makefile"]
+    srcs = ["to_codec.c", "to_simd.c", "to_postings.c", "to_query.c", "to_gen.c", "tantivy_oracle.h", "Makefile"]
     if not force and os.path.exists(_LIB_PATH):
         so_m = os.path.getmtime(_LIB_PATH)
         if all(os.path.getmtime(os.path.join(_HERE, s)) <= so_m for s in srcs):
@@ -213,6 +213,15 @@ def _u32(a):
 
 
 # ----------------------------------------------------------------------------- codec helpers
+def set_simd(on):
+    """Baseline runs: decode posting blocks with the SSE2 unpack of to_simd.c (the reference's
+    BitPacker4x is SIMD code) instead of the scalar loops.  Returns the previous setting."""
+    L = lib()
+    prev = bool(L.to_get_simd())
+    L.to_set_simd(1 if on else 0)
+    return prev
+
+
 def compress_block_sorted(vals, offset):
     v = np.ascontiguousarray(vals, dtype=np.uint32)
     assert v.size == BLOCK_LEN

@@ -78,6 +78,13 @@ uint8_t to_bp4_num_bits_strictly_sorted(int has_initial, uint32_t initial, const
 uint8_t to_bp4_num_bits_sorted(uint32_t initial, const uint32_t *v);
 size_t to_bp4_compress(const uint32_t *v, uint8_t *out, uint8_t num_bits);
 size_t to_bp4_decompress(const uint8_t *in, uint32_t *out, uint8_t num_bits);
+/* to_simd.c: the same decode with SSE2 registers (the CPU baseline's decoder; to_set_simd(1) routes
+ * to_bp4_decompress* through it; tests cross-check it against the scalar loops) */
+size_t to_simd_bp4_decompress(const uint8_t *in, uint32_t *out, uint8_t num_bits);
+size_t to_simd_bp4_decompress_delta(uint32_t seed, uint32_t add, const uint8_t *in, uint32_t *out,
+                                    uint8_t num_bits);
+void to_set_simd(int on);
+int to_get_simd(void);
 size_t to_bp4_compress_strictly_sorted(int has_initial, uint32_t initial, const uint32_t *v,
                                        uint8_t *out, uint8_t num_bits);
 size_t to_bp4_decompress_strictly_sorted(int has_initial, uint32_t initial, const uint8_t *in,

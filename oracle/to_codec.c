@@ -246,7 +246,13 @@ size_t to_bp4_compress(const uint32_t *v, uint8_t *out, uint8_t b) {
     for (int l = 0; l < 4; l++) wr32(out + 16u * w + 4u * (uint32_t)l, W[w][l]);
   return nbytes;
 }
+/* baseline runs only: the SSE2 decode of to_simd.c instead of the scalar loops below */
+static int g_simd = 0;
+void to_set_simd(int on) { g_simd = on != 0; }
+int to_get_simd(void) { return g_simd; }
+
 size_t to_bp4_decompress(const uint8_t *in, uint32_t *out, uint8_t b) {
+  if (g_simd) return to_simd_bp4_decompress(in, out, b);
   if (b == 0) {
     memset(out, 0, TO_BLOCK_LEN * sizeof(uint32_t));
     return 0;
@@ -273,6 +279,7 @@ size_t to_bp4_compress_strictly_sorted(int has_initial, uint32_t initial, const 
 }
 size_t to_bp4_decompress_strictly_sorted(int has_initial, uint32_t initial, const uint8_t *in,
                                          uint32_t *out, uint8_t b) {
+  if (g_simd) return to_simd_bp4_decompress_delta(has_initial ? initial : 0xFFFFFFFFu, 1u, in, out, b);
   size_t n = to_bp4_decompress(in, out, b);
   uint32_t prev = has_initial ? initial : 0xFFFFFFFFu;
   for (int i = 0; i < TO_BLOCK_LEN; i++) {
@@ -291,6 +298,7 @@ size_t to_bp4_compress_sorted(uint32_t initial, const uint32_t *v, uint8_t *out,
   return to_bp4_compress(d, out, b);
 }
 size_t to_bp4_decompress_sorted(uint32_t initial, const uint8_t *in, uint32_t *out, uint8_t b) {
+  if (g_simd) return to_simd_bp4_decompress_delta(initial, 0u, in, out, b);
   size_t n = to_bp4_decompress(in, out, b);
   uint32_t prev = initial;
   for (int i = 0; i < TO_BLOCK_LEN; i++) {

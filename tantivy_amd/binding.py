@@ -40,7 +40,15 @@ OPT_DEFAULT = 0xFFFFFFFF
 class TqBatchStats(C.Structure):
     _fields_ = [("algorithmic_bytes", C.c_uint64), ("matches", C.c_uint64),
                 ("kernel_ms", C.c_float), ("total_ms", C.c_float), ("tiles", C.c_uint32),
-                ("chunks", C.c_uint32), ("batches_averaged", C.c_uint32)]
+                ("chunks", C.c_uint32), ("batches_averaged", C.c_uint32),
+                ("host_plan_ms", C.c_float)]
+
+
+class TqSegmentStats(C.Structure):
+    _fields_ = [(n, C.c_uint64) for n in (
+        "index_bytes", "positions_bytes", "fieldnorm_bytes", "alive_bytes", "term_table_bytes",
+        "bitmap_bytes", "docmat_bytes", "posdir_bytes", "scratch_bytes", "dense_budget_bytes")] + [
+        (n, C.c_uint32) for n in ("n_terms", "n_dense_lists", "n_docmat_columns")]
 
 
 class TqhTermInfo(C.Structure):
@@ -64,7 +72,7 @@ EXPORTS = [
     "tq_term_prepare", "tq_search_batch", "tq_search_batch_device", "tq_search_batch_opts",
     "tq_search_batch_device_opts", "tq_merge_topk",
     "tq_merge_topk_device", "tq_decode_postings", "tq_decode_position_deltas",
-    "tq_last_batch_stats", "tq_set_option", "tq_segment_set_alive_bitset", "tq_count_batch",
+    "tq_last_batch_stats", "tq_segment_get_stats", "tq_set_option", "tq_segment_set_alive_bitset", "tq_count_batch",
     "tq_last_batch_match_counts", "tq_encoder_create", "tq_encoder_free", "tq_encode_postings",
     "tq_encode_positions", "tq_encode_postings_device", "tq_encode_positions_device",
     "tq_encoder_last_kernel_ms", "tq_comm_unique_id", "tq_comm_init", "tq_comm_free",
@@ -115,6 +123,7 @@ def lib():
     L.tq_decode_position_deltas.argtypes = [vp, C.c_uint32, u32p, C.c_uint64,
                                             C.POINTER(C.c_uint64)]
     L.tq_last_batch_stats.argtypes = [vp, C.POINTER(TqBatchStats)]
+    L.tq_segment_get_stats.argtypes = [vp, C.POINTER(TqSegmentStats)]
     L.tq_set_option.argtypes = [vp, C.c_char_p, C.c_int64]
     L.tq_segment_set_alive_bitset.argtypes = [vp, vp, C.c_size_t]
     L.tq_count_batch.argtypes = [vp, C.POINTER(TqQuery), C.c_uint32, u32p]
@@ -544,7 +553,19 @@ class DeviceIndex:
         _check(lib().tq_last_batch_stats(self.segment_raw(segment_ord), C.byref(st)))
         return {"algorithmic_bytes": st.algorithmic_bytes, "matches": st.matches,
                 "kernel_ms": st.kernel_ms, "total_ms": st.total_ms, "tiles": st.tiles,
-                "chunks": st.chunks, "batches_averaged": st.batches_averaged}
+                "chunks": st.chunks, "batches_averaged": st.batches_averaged,
+                "host_plan_ms": st.host_plan_ms}
+
+    def segment_stats(self, segment_ord=0):
+        """Resident HBM bytes of one segment by kind (tq_segment_get_stats)."""
+        st = TqSegmentStats()
+        _check(lib().tq_segment_get_stats(self.segment_raw(segment_ord), C.byref(st)))
+        out = {n: int(getattr(st, n)) for n, _ in TqSegmentStats._fields_}
+        out["derived_bytes"] = (out["term_table_bytes"] + out["bitmap_bytes"] + out["docmat_bytes"]
+                                + out["posdir_bytes"])
+        out["tantivy_bytes"] = (out["index_bytes"] + out["positions_bytes"] + out["fieldnorm_bytes"]
+                                + out["alive_bytes"])
+        return out
 
     def raw_count(self, queries, weights, cache, segment_ord=0):
         """Direct tq_count_batch (Count collector): alive matches per query."""

@@ -35,6 +35,21 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fP
 OBJ_DIR = os.path.join(HERE, "lib", "obj")
 
 
+def csrc_hash():
+    """sha256 over the kernel / C-ABI sources: ties a profile (profiles/traffic.json entries carry
+    the hash of the tree they were measured on) to the code bench.py is running."""
+    import hashlib
+
+    h = hashlib.sha256()
+    d = os.path.join(HERE, "csrc")
+    for name in sorted(os.listdir(d)):
+        if name.endswith((".hip", ".hpp", ".h", ".cpp")):
+            h.update(name.encode())
+            with open(os.path.join(d, name), "rb") as f:
+                h.update(f.read())
+    return h.hexdigest()[:16]
+
+
 def up_to_date():
     if not os.path.exists(LIB):
         return False

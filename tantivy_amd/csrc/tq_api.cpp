@@ -130,7 +130,7 @@ bool read_vint32_block(const uint8_t *d, size_t len, size_t &at, uint32_t &out) 
 }
 
 struct Options {
-  int exhaustive = 1;
+  int exhaustive = 0;  // 0 = block-max pruned top-k (what the reference executes), 1 = score every match
   int timing = 0;
   int use_dpp = 1;
   int dense = 1;      // build bitmaps for dense lists at tq_term_prepare
@@ -176,6 +176,9 @@ struct tq_segment {
   size_t d_terms_cap = 0;
   bool d_terms_dirty = false;
   size_t dense_bytes_total = 0;
+  // resident bytes by kind (tq_segment_get_stats)
+  size_t bytes_term_tables = 0, bytes_bitmaps = 0, bytes_docmat = 0, bytes_posdir = 0, bytes_alive = 0;
+  uint32_t n_dense_lists = 0;
   std::unordered_map<uint64_t, uint32_t> term_by_off;
   // batch scratch
   DevBuf d_stage, d_partials, d_out_scores, d_out_docs, d_out_counts, d_misc, d_thr, d_qmatches;
@@ -205,6 +208,9 @@ struct tq_segment {
              ev_k1[kTimingRing] = {};
   uint64_t batches_timed = 0, batches_reported = 0;
   bool stage_in_flight = false;
+  bool thr_seeded = false;  // (TQ_KEEP_THR experiments: the slots were zeroed once)
+  double host_ms_sum = 0;   // host time inside tq_search_batch_device since the last stats call
+  uint32_t host_ms_n = 0;
   unsigned long long *d_match_counter = nullptr;
   Options opt;
   size_t dense_budget() const { return (size_t)opt.dense_budget_x * (idx_len + pos_len + max_doc); }
@@ -270,6 +276,7 @@ int build_dense(tq_segment *s, uint32_t handle) {
       e = tqk_launch_docmat_init(s->d_docmat, s->d_fn, s->dseg.const_fieldnorm_id, s->max_doc, s->stream);
       if (e != hipSuccess) return fail(TQ_ERR_HIP, "docmat init: %s", hipGetErrorString(e));
       s->dense_bytes_total += mat_bytes;
+      s->bytes_docmat = mat_bytes;
       s->dseg.docmat = s->d_docmat;
     }
     if (s->d_docmat) {
@@ -304,6 +311,8 @@ int build_dense(tq_segment *s, uint32_t handle) {
   }
   void *blob = nullptr;
   HIP_TRY(hipMalloc(&blob, n_words * sizeof(uint2)));
+  s->bytes_bitmaps += n_words * sizeof(uint2);
+  ++s->n_dense_lists;
   hipError_t ce = hipMemcpy(blob, tab.data(), n_words * sizeof(uint2), hipMemcpyHostToDevice);
   if (ce != hipSuccess) {
     (void)hipFree(blob);
@@ -334,6 +343,7 @@ int build_dense(tq_segment *s, uint32_t handle) {
     t.posdir_blob = db;
     s->h_dterms[handle].pos_dir = (const uint32_t *)db;
     s->dense_bytes_total += n_dir * sizeof(uint32_t);
+    s->bytes_posdir += n_dir * sizeof(uint32_t);
   }
   return TQ_OK;
 }
@@ -708,6 +718,7 @@ int tq_term_prepare(tq_segment *s, uint64_t postings_off, uint32_t postings_len,
   if (!pos_tail.empty()) memcpy(hb.data() + o_ptail, pos_tail.data(), 4 * pos_tail.size());
   uint8_t *blob = nullptr;
   HIP_TRY(hipMalloc((void **)&blob, total));
+  s->bytes_term_tables += total;
   hipError_t ce = hipMemcpy(blob, hb.data(), total, hipMemcpyHostToDevice);
   if (ce != hipSuccess) {
     (void)hipFree(blob);
@@ -815,6 +826,7 @@ int term_prepare_device(tq_segment *s, uint64_t postings_off, uint32_t postings_
   total += PAD;
   uint8_t *blob = nullptr;
   HIP_TRY(hipMalloc((void **)&blob, total));
+  s->bytes_term_tables += total;
   auto bail = [&](int rc) {
     (void)hipFree(blob);
     return rc;
@@ -861,6 +873,7 @@ int term_prepare_device(tq_segment *s, uint64_t postings_off, uint32_t postings_
     o_ptail = ptotal;
     ptotal = align16(ptotal + 4 * (size_t)tail_cap) + PAD;
     e = hipMalloc((void **)&pblob, ptotal);
+    if (e == hipSuccess) s->bytes_term_tables += ptotal;
     if (e == hipSuccess) e = hipMemsetAsync(pblob, 0, ptotal, s->stream);
     TqpPositionsParams qp{};
     qp.pos = s->d_pos;
@@ -933,6 +946,8 @@ int build_dense_device(tq_segment *s, uint32_t handle) {
   const size_t n_words = ((size_t)s->max_doc + 31) / 32 + 1;
   void *blob = nullptr;
   HIP_TRY(hipMalloc(&blob, n_words * sizeof(uint2)));
+  s->bytes_bitmaps += n_words * sizeof(uint2);
+  ++s->n_dense_lists;
   uint32_t *bad = (uint32_t *)s->d_tp_info;
   e = hipMemsetAsync(blob, 0, n_words * sizeof(uint2), s->stream);
   if (e == hipSuccess) e = hipMemsetAsync(bad, 0, 4, s->stream);
@@ -957,6 +972,7 @@ int build_dense_device(tq_segment *s, uint32_t handle) {
       e = tqk_launch_docmat_init(s->d_docmat, s->d_fn, s->dseg.const_fieldnorm_id, s->max_doc, s->stream);
       if (e != hipSuccess) return fail(TQ_ERR_HIP, "docmat init: %s", hipGetErrorString(e));
       s->dense_bytes_total += mat_bytes;
+      s->bytes_docmat = mat_bytes;
       s->dseg.docmat = s->d_docmat;
     }
     if (s->d_docmat) {
@@ -984,6 +1000,7 @@ int build_dense_device(tq_segment *s, uint32_t handle) {
     t.posdir_blob = db;
     s->h_dterms[handle].pos_dir = (const uint32_t *)db;
     s->dense_bytes_total += n_dir * sizeof(uint32_t);
+    s->bytes_posdir += n_dir * sizeof(uint32_t);
   }
   HIP_TRY(hipStreamSynchronize(s->stream));
   return TQ_OK;
@@ -1068,10 +1085,17 @@ static void parallel_slabs(uint32_t n_slabs, F &&fn) {  // fn(slab) for slab in 
     if (n_slabs) fn(0u);
     return;
   }
+  // (std::thread's constructor throws std::system_error under a thread limit: this runs inside an
+  // extern "C" call, so the slabs that got no thread are planned by the calling thread instead)
   std::vector<std::thread> th;
-  th.reserve(n_slabs - 1);
-  for (uint32_t i = 1; i < n_slabs; ++i) th.emplace_back([&fn, i] { fn(i); });
+  uint32_t spawned = 1;
+  try {
+    th.reserve(n_slabs - 1);
+    for (; spawned < n_slabs; ++spawned) th.emplace_back([&fn, spawned] { fn(spawned); });
+  } catch (...) {
+  }
   fn(0u);
+  for (uint32_t i = spawned; i < n_slabs; ++i) fn(i);
   for (std::thread &t : th) t.join();
 }
 
@@ -1892,6 +1916,20 @@ int search_batch_impl(tq_segment *s, const tq_query *queries, uint32_t n_queries
   rc = order_after_last_batch(s, st);
   if (rc != TQ_OK) return rc;
   if (s->opt.timing) HIP_TRY(hipEventRecord(s->ev_t0[slot], st));
+  // From here on work is in flight that reads the staging buffer: a failure below must not let the
+  // next call overwrite it under kernels that were already launched (the events that order the
+  // buffers are only recorded at the end), so every error return first drains the streams.
+  struct DrainOnError {
+    tq_segment *s;
+    hipStream_t st;
+    bool armed = true;
+    ~DrainOnError() {
+      if (!armed) return;
+      if (s->copy_stream) (void)hipStreamSynchronize(s->copy_stream);
+      if (s->side_stream) (void)hipStreamSynchronize(s->side_stream);
+      (void)hipStreamSynchronize(st);
+    }
+  } drain_on_error{s, st};
   if (kCopyStream) {
     // buffer bx was last read by the batch before the previous one: the copy waits for that
     // batch's end (recorded on its stream), the kernels below wait for the copy
@@ -1915,9 +1953,8 @@ int search_batch_impl(tq_segment *s, const tq_query *queries, uint32_t n_queries
     // TQ_KEEP_THR=1 (experiments only): the slots keep the previous batch's final values, i.e. the
     // same batch run again starts from its final thresholds (what perfect threshold knowledge buys)
     static const bool kKeepThr = tune_u32("TQ_KEEP_THR", 0) != 0;
-    static bool thr_seeded = false;
-    if (!kKeepThr || !thr_seeded) HIP_TRY(hipMemsetAsync(s->d_thr.p, 0, thr_bytes, st));
-    thr_seeded = true;
+    if (!kKeepThr || !s->thr_seeded) HIP_TRY(hipMemsetAsync(s->d_thr.p, 0, thr_bytes, st));
+    s->thr_seeded = true;
   }
 
   // ---- launch
@@ -2021,8 +2058,12 @@ int search_batch_impl(tq_segment *s, const tq_query *queries, uint32_t n_queries
   s->stats.matches = 0;
   s->stats.kernel_ms = 0;
   s->stats.total_ms = 0;
+  s->stats.host_plan_ms = 0;
   s->stats_pending = true;
   (void)total_parts;
+  drain_on_error.armed = false;
+  s->host_ms_sum += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tr0).count();
+  ++s->host_ms_n;
   return TQ_OK;
 }
 
@@ -2125,6 +2166,7 @@ int tq_segment_set_alive_bitset(tq_segment *s, const uint8_t *bytes, size_t len)
   }
   if (s->d_alive) (void)hipFree(s->d_alive);
   s->d_alive = nullptr;
+  s->bytes_alive = 0;
   s->dseg.alive = nullptr;
   if (!bytes) return TQ_OK;  // no deletes
   // BitSet::serialize (common/src/bitset.rs:215-223): u32 LE max_value, then 64-bit tiny sets
@@ -2137,6 +2179,7 @@ int tq_segment_set_alive_bitset(tq_segment *s, const uint8_t *bytes, size_t len)
   HIP_TRY(hipMalloc((void **)&s->d_alive, len - 4 + PAD));
   HIP_TRY(hipMemset(s->d_alive + (len - 4), 0, PAD));
   HIP_TRY(hipMemcpy(s->d_alive, bytes + 4, len - 4, hipMemcpyHostToDevice));
+  s->bytes_alive = len - 4;
   s->dseg.alive = s->d_alive;
   return TQ_OK;
 }
@@ -2207,9 +2250,34 @@ int tq_last_batch_stats(tq_segment *s, tq_batch_stats *out) {
       }
       s->stats.batches_averaged = n;
     }
+    s->stats.host_plan_ms = s->host_ms_n ? (float)(s->host_ms_sum / s->host_ms_n) : 0.0f;
+    s->host_ms_sum = 0;
+    s->host_ms_n = 0;
     s->stats_pending = false;
   }
   *out = s->stats;
+  return TQ_OK;
+}
+
+int tq_segment_get_stats(tq_segment *s, tq_segment_stats *out) {
+  if (!s || !out) return fail(TQ_ERR_INVALID, "tq_segment_get_stats: null argument");
+  tq_segment_stats r{};
+  r.index_bytes = s->idx_len;
+  r.positions_bytes = s->pos_len;
+  r.fieldnorm_bytes = s->d_fn ? s->max_doc : 0;
+  r.alive_bytes = s->bytes_alive;
+  r.term_table_bytes = s->bytes_term_tables + s->d_terms_cap * sizeof(TqdTerm);
+  r.bitmap_bytes = s->bytes_bitmaps;
+  r.docmat_bytes = s->bytes_docmat;
+  r.posdir_bytes = s->bytes_posdir;
+  r.scratch_bytes = s->d_stage.cap + s->d_stage_alt.cap + s->d_partials.cap + s->d_out_scores.cap +
+                    s->d_out_docs.cap + s->d_out_counts.cap + s->d_misc.cap + s->d_thr.cap +
+                    s->d_qmatches.cap;
+  r.n_terms = (uint32_t)s->terms.size();
+  r.n_dense_lists = s->n_dense_lists;
+  r.n_docmat_columns = s->n_mat_slots;
+  r.dense_budget_bytes = s->dense_budget();
+  *out = r;
   return TQ_OK;
 }
 

@@ -13,7 +13,19 @@
 // go multi-GPU do not need the library at all.
 #include <dlfcn.h>
 #include <hip/hip_runtime.h>
+#if __has_include(<rccl/rccl.h>)
 #include <rccl/rccl.h>
+#else
+// Hosts without the RCCL development headers still build the library (it only dlopen()s librccl):
+// the handful of types the seven entry points use, as rccl.h / nccl.h declare them.
+#define NCCL_UNIQUE_ID_BYTES 128
+typedef struct {
+  char internal[NCCL_UNIQUE_ID_BYTES];
+} ncclUniqueId;
+typedef struct ncclComm *ncclComm_t;
+typedef enum { ncclSuccess = 0 } ncclResult_t;
+typedef enum { ncclInt8 = 0, ncclUint8 = 1, ncclInt32 = 2, ncclUint32 = 3, ncclFloat32 = 7 } ncclDataType_t;
+#endif
 
 #include <cstdio>
 #include <cstdlib>

@@ -288,7 +288,7 @@ __global__ __launch_bounds__(64, DENSE ? TQ_PH_WAVES_DENSE : 5) void phrase_kern
           cur[m].idx = pi + 1u;
           cur[m].end = pi + (m ? L.ph_tf[m ? m - 1 : 0][lane] : lead_tf);
           cur[m].cur = Q->phrase_off[m] + position_delta(pos, p.terms + Q->term[m], pi);
-          cur[m].valid = true;
+          cur[m].valid = cur[m].end >= cur[m].idx;  // tf >= 1 (0 only in a corrupt index: no position)
         }
       }
       uint32_t count = 0;
@@ -330,8 +330,10 @@ __global__ __launch_bounds__(64, DENSE ? TQ_PH_WAVES_DENSE : 5) void phrase_kern
       // and the adjusted positions intersected in registers.
       // Everything else takes the cursor merge below.
       constexpr uint32_t TM = 8;
-      bool fast = lead_tf <= TM;
-      for (uint32_t m = 1; m < nt; ++m) fast = fast && L.ph_tf[m - 1u][lane] <= TM;
+      // (tf - 1 < TM: a term freq of 0 — only a corrupt index has one — must not reach the clamped
+      // `tf - 1` delta index below; it takes the cursor merge, which finds no position)
+      bool fast = lead_tf - 1u < TM;
+      for (uint32_t m = 1; m < nt; ++m) fast = fast && L.ph_tf[m - 1u][lane] - 1u < TM;
       uint32_t count = 0xFFFFFFFFu;  // = resolved by the cursor merge
       if (fast) {
         // adjusted positions of the leader term, then one term at a time: bit i of `ok` stays set

@@ -127,6 +127,24 @@ class ShardRunner:
         self.stream_obj = torch.cuda.Stream(device=device)
         self.stream = self.stream_obj.cuda_stream
         self.n = self.k = 0
+        self._ex_events = []  # (start, end) torch events around exchange + merge, last 16 steps
+        self._agree("local segments per rank", self.n_local)
+
+    def _agree(self, what, value):
+        """The equal-count all-gather and the [world * S, n, k] reshape need every rank to hold the
+        same number of local segments and to run the same (n, k): mismatched ranks would hang the
+        collective or merge garbage, so the control plane (torch.distributed's default group) checks
+        it where one exists."""
+        if self.world <= 1:
+            return
+        import torch.distributed as dist
+
+        if not (dist.is_available() and dist.is_initialized()):
+            return
+        seen = [None] * dist.get_world_size()
+        dist.all_gather_object(seen, value)
+        if any(v != value for v in seen):
+            raise ValueError("ShardRunner: ranks disagree on %s: %r" % (what, seen))
 
     def set_option(self, name, value):
         self.dev.set_option(name, value)
@@ -135,6 +153,7 @@ class ShardRunner:
         torch = self.torch
         self.dev.prepare(queries)
         n, S, W = len(queries), self.n_local, self.world
+        self._agree("(queries per batch, k)", (n, k))  # (before the early return: every rank calls it)
         if (n, k) == (self.n, self.k):
             return
         self.n, self.k = n, k
@@ -161,6 +180,8 @@ class ShardRunner:
                 self.dev.collect_segment_prepared_device(
                     s, k, sc[s * n:(s + 1) * n], dc[s * n:(s + 1) * n], ct[s * n:(s + 1) * n],
                     self.stream)
+            ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            ev[0].record(self.stream_obj)
             if W > 1 or self.force_exchange:
                 if self.comm is not None:
                     self.comm.allgather_topk(sc, dc, ct, self.gathered, self.stream)
@@ -173,6 +194,8 @@ class ShardRunner:
             merge_gathered_device(self.dev.ctx, self.device, g[0].reshape(W * S, n, k),
                                   g[1].reshape(W * S, n, k), g[2].reshape(W * S, n), 0, k,
                                   self.stream, out=self.merged)
+            ev[1].record(self.stream_obj)
+            self._ex_events = (self._ex_events + [ev])[-16:]
             for h, t in zip(self.host, self.merged):
                 h.copy_(t, non_blocking=True)
 
@@ -192,9 +215,19 @@ class ShardRunner:
             if out is None:
                 out = dict(st)
             else:
-                for key in ("algorithmic_bytes", "matches", "kernel_ms", "total_ms", "tiles", "chunks"):
+                for key in ("algorithmic_bytes", "matches", "kernel_ms", "total_ms", "tiles", "chunks",
+                            "host_plan_ms"):
                     out[key] += st[key]
         return out
+
+    def exchange_ms(self):
+        """Mean GPU time of [all-gather + merge_top_k] over the last (<= 16) finished steps."""
+        if not self._ex_events:
+            return 0.0
+        self.stream_obj.synchronize()
+        ms = [a.elapsed_time(b) for a, b in self._ex_events]
+        self._ex_events = []
+        return float(sum(ms) / len(ms))
 
     def close(self):
         self.dev.close()

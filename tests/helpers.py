@@ -106,3 +106,25 @@ def legacy_posting_list(postings):
         tail += vint_stop_last(t)
     head = (vint_stop_last(len(skip)) + bytes(skip)) if len(docs) >= 128 else b""
     return head + bytes(payload) + bytes(tail)
+
+
+def exhaustive_by_default(module):
+    """The library executes the reference's way by default: block-max pruned top-k ("exhaustive" =
+    0).  The parity tests assert match counts and full match sets next to the top-k, which only
+    the exhaustive scan reports, so their DeviceIndex starts every segment with "exhaustive" = 1;
+    the tests of the pruned mode switch it off explicitly.  Returns a namespace with the module's
+    names and that DeviceIndex."""
+    import types
+
+    class DeviceIndex(module.DeviceIndex):
+        def add_segment(self, *a, **kw):
+            super().add_segment(*a, **kw)
+            self.set_option("exhaustive", 1, self.n_segments - 1)
+
+        def add_segment_device(self, *a, **kw):
+            super().add_segment_device(*a, **kw)
+            self.set_option("exhaustive", 1, self.n_segments - 1)
+
+    ns = types.SimpleNamespace(**{k: getattr(module, k) for k in dir(module) if not k.startswith("__")})
+    ns.DeviceIndex = DeviceIndex
+    return ns

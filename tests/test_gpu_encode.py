@@ -13,7 +13,9 @@ pytestmark = pytest.mark.gpu
 def ta():
     import tantivy_amd
 
-    return tantivy_amd
+    from tests.helpers import exhaustive_by_default
+
+    return exhaustive_by_default(tantivy_amd)
 
 
 @pytest.fixture(scope="module")

@@ -18,7 +18,9 @@ MODE_NAMES = {O.MODE_AND: "AND", O.MODE_OR: "OR", O.MODE_PHRASE: "PHRASE"}
 def ta():
     import tantivy_amd
 
-    return tantivy_amd
+    from tests.helpers import exhaustive_by_default
+
+    return exhaustive_by_default(tantivy_amd)
 
 
 @pytest.fixture(scope="module")

@@ -20,7 +20,9 @@ GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "compa
 def ta():
     import tantivy_amd
 
-    return tantivy_amd
+    from tests.helpers import exhaustive_by_default
+
+    return exhaustive_by_default(tantivy_amd)
 
 
 def _hits(scores, docs, counts, i):

@@ -708,3 +708,62 @@ def test_scorer_tree_reference_unit_cases():
     assert d.tolist() == a
     one = sc[a.index(5)]                       # only the required term matches doc 5
     assert all((s > one) == (doc in b) for doc, s in zip(a, sc.tolist()))
+
+
+# ------------------------------------------------------------------ SSE2 decode of the CPU baseline
+def test_simd_decode_equals_scalar_decode():
+    """oracle/to_simd.c (the BitPacker4x decode the CPU baseline times, written with SSE2 registers
+    as the reference's `bitpacking` crate is) against the scalar restatement: every bit width
+    0..32, plain / minus-one tf blocks, strict and legacy doc deltas, with and without a seed."""
+    rng = np.random.default_rng(20260923)
+    try:
+        for b in range(0, 33):
+            for trial in range(8):
+                hi = 1 << b
+                vals = (rng.integers(0, hi, size=128, dtype=np.uint64).astype(np.uint32)
+                        if b else np.zeros(128, np.uint32))
+                if b:
+                    vals[int(rng.integers(0, 128))] = hi - 1
+                for minus_one in (False, True):
+                    src = vals if not minus_one else (vals.astype(np.uint64) + 1).clip(1, 0xFFFFFFFF).astype(np.uint32)
+                    nb, data = O.compress_block_unsorted(src, minus_one)
+                    O.set_simd(False)
+                    n0, a = O.uncompress_block_unsorted(data, nb, minus_one)
+                    O.set_simd(True)
+                    n1, c = O.uncompress_block_unsorted(data, nb, minus_one)
+                    assert n0 == n1 == 16 * nb
+                    assert np.array_equal(a, c) and np.array_equal(a, src), (b, minus_one)
+        for trial in range(200):
+            gaps = rng.integers(1, 1 << int(rng.integers(1, 20)), size=128)
+            off = int(rng.integers(1, 1000)) if trial % 3 else 0
+            docs = (off + np.cumsum(gaps)).astype(np.uint32)
+            nb, data = O.compress_block_sorted(docs, off)
+            O.set_simd(False)
+            _, a = O.uncompress_block_sorted(data, off, nb, True)
+            O.set_simd(True)
+            _, c = O.uncompress_block_sorted(data, off, nb, True)
+            assert np.array_equal(a, c) and np.array_equal(a, docs)
+            # legacy (non-strict) deltas decode the same bytes as v[i] = v[i-1] + d[i]
+            O.set_simd(False)
+            _, a = O.uncompress_block_sorted(data, off, nb, False)
+            O.set_simd(True)
+            _, c = O.uncompress_block_sorted(data, off, nb, False)
+            assert np.array_equal(a, c)
+    finally:
+        O.set_simd(False)
+
+
+def test_simd_baseline_returns_the_scalar_top_k():
+    """The executors give the same hits whichever decoder is switched in."""
+    seg = O.synth_segment(150_000, n_terms=48, with_positions=True, phrase_terms=8)
+    qs = [(O.MODE_AND, [0, 3]), (O.MODE_AND, [5, 40]), (O.MODE_OR, [1, 7, 9, 30, 44]),
+          (O.MODE_PHRASE, [0, 1, 2])]
+    try:
+        for mode, terms in qs:
+            O.set_simd(False)
+            a = O.search(seg, terms, mode, 10, pruned=True)
+            O.set_simd(True)
+            b = O.search(seg, terms, mode, 10, pruned=True)
+            assert a == b
+    finally:
+        O.set_simd(False)

@@ -103,7 +103,17 @@ def main():
                 e["fetch_bytes_raw"] += int(fetch)  # the launch groups of one batch add up
                 e["write_bytes_raw"] += int(write)
                 e["kernels"].append(k)
+    sys.path.insert(0, ROOT)
+    from tantivy_amd import build as product_build
+
+    commit = os.environ.get("GIT_COMMIT", "")
+    stamp = os.path.join(ROOT, ".git_commit_stamp")  # written by tools/stamp_commit.sh before gpurun
+    if not commit and os.path.exists(stamp):
+        commit = open(stamp).read().strip()
     for key, v in fresh.items():
+        # which tree was measured: bench.py drops physical_frac when its kernels differ from these
+        v["csrc_hash"] = product_build.csrc_hash()
+        v["measured_on_commit"] = commit or "unknown (no .git on the GPU box and no stamp)"
         v["fetch_factor"] = factor
         v["hbm_bytes_per_launch"] = int(factor * v["fetch_bytes_raw"] + v["write_bytes_raw"])
         v["profile"] = tag
