@@ -10,6 +10,7 @@ LIB = os.path.join(HERE, "lib", "libtantivy_amd.so")
 SOURCES = [
     os.path.join(HERE, "csrc", "tq_and.hip"),
     os.path.join(HERE, "csrc", "tq_union.hip"),
+    os.path.join(HERE, "csrc", "tq_ushare.hip"),
     os.path.join(HERE, "csrc", "tq_phrase.hip"),
     os.path.join(HERE, "csrc", "tq_misc.hip"),
     os.path.join(HERE, "csrc", "tq_encode.hip"),

@@ -182,6 +182,7 @@ struct tq_segment {
   std::unordered_map<uint64_t, uint32_t> term_by_off;
   // batch scratch
   DevBuf d_stage, d_partials, d_out_scores, d_out_docs, d_out_counts, d_misc, d_thr, d_qmatches;
+  DevBuf d_share_words, d_share_stage;  // shared-union launch: per-query words, staging lists
   uint32_t last_batch_queries = 0;
   PinnedBuf h_stage, h_out;
   // timing: a ring of event quadruples, one per batch, so that pipelined batches (no host sync
@@ -512,6 +513,8 @@ void tq_segment_free(tq_segment *s) {
   tq_free_plan_scratch(s->plan);
   s->plan = nullptr;
   s->d_qmatches.release();
+  s->d_share_words.release();
+  s->d_share_stage.release();
   s->h_stage.release();
   s->h_out.release();
   if (s->side_stream) (void)hipStreamSynchronize(s->side_stream);
@@ -1042,6 +1045,7 @@ struct Group {
   int kpl = 1;
   // offsets inside the staging blob
   size_t o_queries = 0, o_tiles = 0, o_outidx = 0, o_chunks = 0, o_perm = 0, o_sinks = 0;
+  size_t o_leads = 0, o_tasks = 0;  // shared-union group
   void reset() {  // keeps the vectors' capacity
     queries.clear();
     out_index.clear();
@@ -1053,6 +1057,7 @@ struct Group {
     max_k = 1;
     kpl = 1;
     o_queries = o_tiles = o_outidx = o_chunks = o_perm = o_sinks = 0;
+    o_leads = o_tasks = 0;
   }
 };
 
@@ -1063,8 +1068,17 @@ struct alignas(128) PlanSlab {  // chunk tables of one slab of queries (build_gr
   size_t q0 = 0, q1 = 0;
   std::vector<uint32_t> starts, slice, query;
 };
+struct ShareKey {  // one (query, list) pair of the shared-union group, sorted by term
+  uint64_t key;    // blocks of the term (rare terms first) << 40 | cache << 32 | term handle
+  uint32_t q, i;
+};
 struct PlanScratch {
-  Group groups[5];
+  Group groups[6];
+  // shared-union group (tq_ushare.hip): leads grouped by term, tasks in launch order
+  std::vector<ShareKey> share_keys;
+  std::vector<TqdLead> leads;
+  std::vector<uint4> tasks;
+  std::vector<uint32_t> share_pairs;  // per query: (task, lead) pairs = result-list appends at most
   std::vector<uint32_t> lead_cost, sort_start;
   std::vector<PlanSlab> slabs;
   std::vector<std::pair<uint64_t, uint32_t>> keyed;
@@ -1445,6 +1459,112 @@ int build_group_chunks(Group &g, bool or_windows, PlanScratch &ps) {
   return TQ_OK;
 }
 
+// The shared-union launch (tq_ushare.hip): the (query, list) pairs of the group's pure unions are
+// sorted by term, cut into groups of <= TQD_US_GROUP leads, and every group gets one task per run of
+// blocks of its term.  Rare (high-weight) terms come first in the task order: their matches raise
+// the thresholds that let the tasks of the dense terms end at their first look at them.
+int build_share_plan(tq_segment *s, Group &g, PlanScratch &ps) {
+  static const uint32_t kTaskCost = std::max<uint32_t>(64u, tune_u32("TQ_US_TASK_COST", 4096));
+  static const uint32_t kTaskBlocksMax = std::max<uint32_t>(TQD_US_TILE, tune_u32("TQ_US_TASK_BLOCKS", 512));
+  const size_t nq = g.queries.size();
+  g.kpl = kpl_for(g.max_k);
+  std::vector<ShareKey> &keys = ps.share_keys;
+  keys.clear();
+  for (size_t q = 0; q < nq; ++q) {
+    const TqdQuery &dq = g.queries[q];
+    for (uint32_t i = 0; i < dq.n_terms; ++i) {
+      const uint64_t nb = std::min<uint64_t>(0xFFFFFFu, s->terms[dq.term[i]].n_blocks);
+      keys.push_back({(nb << 40) | ((uint64_t)(dq.cache_idx & 0xFFu) << 32) | dq.term[i], (uint32_t)q, i});
+    }
+  }
+  std::sort(keys.begin(), keys.end(), [](const ShareKey &a, const ShareKey &b) {
+    if (a.key != b.key) return a.key < b.key;
+    if (a.q != b.q) return a.q < b.q;
+    return a.i < b.i;
+  });
+  std::vector<TqdLead> &leads = ps.leads;
+  std::vector<uint4> &tasks = ps.tasks;
+  std::vector<uint32_t> &pairs = ps.share_pairs;
+  leads.resize(keys.size());
+  tasks.clear();
+  pairs.assign(nq, 0u);
+  auto column_of = [&](uint32_t handle) -> uint32_t {  // doc-matrix bit of the list, or 0
+    const uint32_t slot1 = (s->h_dterms[handle].has_freq >> 8) & 0xFFu;
+    return slot1 ? 8u + (slot1 - 1u) : 0u;
+  };
+  for (size_t at = 0; at < keys.size(); ++at) {
+    const ShareKey &k = keys[at];
+    const TqdQuery &dq = g.queries[k.q];
+    TqdLead ld{};
+    ld.query = k.q;
+    ld.w = dq.weight[k.i];
+    uint32_t ncols = 0, nocol = 0;
+    float suffix = 0.0f, sparse_after = 0.0f;
+    for (uint32_t m = dq.n_terms; m-- > k.i;) suffix += dq.weight[m];
+    for (uint32_t m = 0; m < dq.n_terms; ++m) {
+      const uint32_t col = column_of(dq.term[m]);
+      if (!col) nocol |= 1u << m;
+      if (m < k.i) {
+        if (col) ld.before_mask |= 1ull << col;
+      } else if (m > k.i) {
+        if (col) {
+          if (ncols < 4u)
+            ld.cols_lo |= col << (8u * ncols);
+          else
+            ld.cols_hi |= col << (8u * (ncols - 4u));
+          ld.aw[ncols] = dq.weight[m];
+          ++ncols;
+        } else {
+          sparse_after += dq.weight[m];
+        }
+      }
+    }
+    ld.suffix = suffix;
+    ld.sparse_after = sparse_after;
+    ld.info = k.i | (ncols << 4) | (dq.n_terms << 8) | (nocol << 16);
+    leads[at] = ld;
+  }
+  // runs of one (term, cache): groups of leads x runs of blocks
+  for (size_t r0 = 0; r0 < keys.size();) {
+    size_t r1 = r0;
+    while (r1 < keys.size() && keys[r1].key == keys[r0].key) ++r1;
+    const uint32_t term = (uint32_t)keys[r0].key, cache = (uint32_t)(keys[r0].key >> 32) & 0xFFu;
+    const uint32_t n_blocks = s->terms[term].n_blocks;
+    const uint32_t n_run = (uint32_t)(r1 - r0);
+    const uint32_t n_groups = (n_run + TQD_US_GROUP - 1) / TQD_US_GROUP;
+    // blocks per task: about equal cost (a block costs its decode + one test per lead)
+    const uint32_t per_group = (n_run + n_groups - 1) / n_groups;
+    uint32_t bpt = kTaskCost / (4u + per_group);
+    bpt = std::min<uint32_t>(kTaskBlocksMax, std::max<uint32_t>(TQD_US_TILE, bpt / TQD_US_TILE * TQD_US_TILE));
+    for (uint32_t j0 = 0; j0 < n_blocks; j0 += bpt) {
+      const uint32_t nb = std::min<uint32_t>(bpt, n_blocks - j0);
+      for (uint32_t gr = 0; gr < n_groups; ++gr) {
+        const uint32_t l0 = gr * per_group, l1 = std::min<uint32_t>(n_run, l0 + per_group);
+        if (l0 >= l1) continue;
+        tasks.push_back(make_uint4(term, j0, nb | ((l1 - l0) << 16) | (cache << 24), (uint32_t)r0 + l0));
+      }
+    }
+    const uint32_t n_runs = (n_blocks + bpt - 1) / bpt;
+    for (size_t a = r0; a < r1; ++a) pairs[keys[a].q] += n_runs;
+    r0 = r1;
+  }
+  if (tasks.size() > 0x7FFFFFFFull) return fail(TQ_ERR_UNSUPPORTED, "batch too large (tasks)");
+  // result lists: every (task, lead) pair appends at most k entries
+  uint64_t entries = 0;
+  for (size_t q = 0; q < nq; ++q) {
+    TqdQuery &dq = g.queries[q];
+    const uint64_t cap = (uint64_t)pairs[q] * dq.k;
+    if (entries + cap > 0xFFFFFFFFull) return fail(TQ_ERR_UNSUPPORTED, "batch too large (result lists)");
+    dq.part_start = (uint32_t)entries;
+    dq.n_parts = (uint32_t)cap;
+    dq.chunk_first = 0;
+    entries += cap;
+  }
+  g.total_tiles = (uint32_t)tasks.size();
+  g.n_chunks = (uint32_t)tasks.size();
+  return TQ_OK;
+}
+
 // Planning of one TQ_MODE_BOOL query: clause layout of the union kernel (tq_union.hip), pruning
 // flags, tile sizes.  An empty result leaves dq.n_terms == 0 and n_tiles == 0.
 int plan_bool_query(tq_segment *s, const tq_query &q, uint32_t qi, TqdQuery &dq, uint64_t &qbytes,
@@ -1624,11 +1744,15 @@ int search_batch_impl(tq_segment *s, const tq_query *queries, uint32_t n_queries
   // launch groups: AND queries whose non-leader lists all have a bitmap run a leaner kernel
   // instantiation (no seek / block-search code: fewer registers, less LDS, more waves per CU)
   // boolean queries (clauses with roles) run the candidate-driven union kernel's BOOL instantiation
-  constexpr int kGroups = 5, kAndGeneral = 3, kBool = 4;
+  constexpr int kGroups = 6, kAndGeneral = 3, kBool = 4, kShare = 5;
+  // pure unions, pruned, k <= 128, <= 8 terms, on a segment with a doc matrix: the shared-union
+  // launch (term-major, tq_ushare.hip); everything else keeps the per-query union kernels
+  static const bool kUseShare = tune_u32("TQ_USHARE", 1) != 0;
   if (!s->plan) s->plan = new PlanScratch();
   Group(&groups)[kGroups] = s->plan->groups;
   for (Group &g : groups) g.reset();
   groups[kBool].mode = TQ_MODE_OR;
+  groups[kShare].mode = TQ_MODE_OR;
   groups[0].mode = TQ_MODE_AND;
   groups[1].mode = TQ_MODE_OR;
   groups[2].mode = TQ_MODE_PHRASE;
@@ -1746,7 +1870,7 @@ int search_batch_impl(tq_segment *s, const tq_query *queries, uint32_t n_queries
         }
       }
     }
-    bool bool_done = false;
+    bool bool_done = false, share = false;
     if (q.mode == TQ_MODE_BOOL) {
       const int rc = plan_bool_query(s, q, qi, dq, qbytes, n_tiles, tile_cost, n_thr_rows, opt_exhaustive != 0);
       if (rc != TQ_OK) return rc;
@@ -1792,7 +1916,12 @@ int search_batch_impl(tq_segment *s, const tq_query *queries, uint32_t n_queries
           }
         }
       }
-      if (or_windows_opt) {
+      share = kUseShare && !or_windows_opt && (dq.flags & TQD_QF_PRUNE) && dq.thr_index != 0xFFFFFFFFu &&
+              dq.n_terms >= 1 && dq.n_terms <= TQD_US_MAX_TERMS && s->d_docmat && s->opt.use_dense &&
+              cache_idx < 256u;
+      if (share) {
+        // (planned per term, not per query: build_share_plan)
+      } else if (or_windows_opt) {
         uint32_t max_last = 0;
         for (uint32_t i = 0; i < dq.n_terms; ++i)
           max_last = std::max(max_last, s->terms[dq.term[i]].last_doc);
@@ -1821,7 +1950,7 @@ int search_batch_impl(tq_segment *s, const tq_query *queries, uint32_t n_queries
     }
     algo_bytes += qbytes;
     dq.n_tiles = n_tiles;
-    Group &g = groups[bool_done ? kBool : ((mode == TQ_MODE_AND && !all_dense) ? kAndGeneral : mode)];
+    Group &g = groups[bool_done ? kBool : (share ? kShare : ((mode == TQ_MODE_AND && !all_dense) ? kAndGeneral : mode))];
     dq.mode = (uint32_t)mode;
     g.queries.push_back(dq);
     g.tile_cost.push_back(tile_cost);
@@ -1834,14 +1963,20 @@ int search_batch_impl(tq_segment *s, const tq_query *queries, uint32_t n_queries
   size_t partial_bytes = 0;
   for (Group &g : groups) {
     if (g.queries.empty()) continue;
-    const int crc = build_group_chunks(g, or_windows_opt && &g != &groups[kBool], *s->plan);
+    const int crc = &g == &groups[kShare] ? build_share_plan(s, g, *s->plan)
+                                          : build_group_chunks(g, or_windows_opt && &g != &groups[kBool], *s->plan);
     if (crc != TQ_OK) return crc;
   }
   // partial lists of all groups share one buffer; its stride is per group (kpl*64 keys)
-  size_t part_off_bytes[kGroups] = {0, 0, 0, 0, 0};
+  size_t part_off_bytes[kGroups] = {0, 0, 0, 0, 0, 0};
   for (int gi = 0; gi < kGroups; ++gi) {
     Group &g = groups[gi];
     part_off_bytes[gi] = partial_bytes;
+    if (gi == kShare) {  // result lists: part_start / n_parts count 8-byte entries (build_share_plan)
+      if (!g.queries.empty())
+        partial_bytes += ((size_t)g.queries.back().part_start + g.queries.back().n_parts) * sizeof(uint64_t);
+      continue;
+    }
     uint32_t parts = 0;
     for (TqdQuery &dq : g.queries) {
       dq.part_start = parts;
@@ -1875,6 +2010,14 @@ int search_batch_impl(tq_segment *s, const tq_query *queries, uint32_t n_queries
     stage = (stage + 15) & ~(size_t)15;
     g.o_sinks = stage;
     stage += sizeof(TqkSinks);
+    if (&g == &groups[kShare]) {
+      stage = (stage + 63) & ~(size_t)63;
+      g.o_leads = stage;
+      stage += s->plan->leads.size() * sizeof(TqdLead);
+      stage = (stage + 15) & ~(size_t)15;
+      g.o_tasks = stage;
+      stage += s->plan->tasks.size() * sizeof(uint4);
+    }
   }
   const auto tr1 = std::chrono::steady_clock::now();
   if (s->stage_in_flight) {
@@ -1899,6 +2042,10 @@ int search_batch_impl(tq_segment *s, const tq_query *queries, uint32_t n_queries
     memcpy(hs + g.o_tiles, g.tile_starts.data(), g.tile_starts.size() * sizeof(uint32_t));
     memcpy(hs + g.o_outidx, g.out_index.data(), g.out_index.size() * sizeof(uint32_t));
     memcpy(hs + g.o_chunks, g.chunk_recs.data(), g.chunk_recs.size() * sizeof(uint4));
+    if (&g == &groups[kShare]) {
+      memcpy(hs + g.o_leads, s->plan->leads.data(), s->plan->leads.size() * sizeof(TqdLead));
+      memcpy(hs + g.o_tasks, s->plan->tasks.data(), s->plan->tasks.size() * sizeof(uint4));
+    }
   }
   for (int gi = 0; gi < kGroups; ++gi) {
     Group &g = groups[gi];
@@ -1957,6 +2104,24 @@ int search_batch_impl(tq_segment *s, const tq_query *queries, uint32_t n_queries
     s->thr_seeded = true;
   }
 
+  // shared-union launch: thr_val | list_count per query, then the task counter (zeroed per batch);
+  // staging lists of the persistent grid
+  uint32_t share_grid = 0;
+  const size_t n_share = groups[kShare].queries.size();
+  if (n_share) {
+    static const uint32_t kGridMul = std::max<uint32_t>(1u, tune_u32("TQ_US_GRID_MUL", 20));
+    int cus = 256;
+    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, s->device);
+    share_grid = (uint32_t)std::min<uint64_t>(groups[kShare].n_chunks, (uint64_t)std::max(1, cus) * kGridMul);
+    const size_t words = 2 * n_share + 16;
+    rc = s->d_share_words.ensure(words * sizeof(uint32_t));
+    if (rc == TQ_OK)
+      rc = s->d_share_stage.ensure((size_t)share_grid * TQD_US_GROUP * tqk_share_capl(groups[kShare].kpl) *
+                                   sizeof(uint64_t));
+    if (rc != TQ_OK) return rc;
+    HIP_TRY(hipMemsetAsync(s->d_share_words.p, 0, words * sizeof(uint32_t), st));
+  }
+
   // ---- launch
   const uint8_t *ds = (const uint8_t *)dstage.p;
   if (s->opt.timing) HIP_TRY(hipEventRecord(s->ev_k0[slot], st));
@@ -1972,13 +2137,40 @@ int search_batch_impl(tq_segment *s, const tq_query *queries, uint32_t n_queries
     HIP_TRY(hipEventRecord(s->ev_fork, st));
     HIP_TRY(hipStreamWaitEvent(s->side_stream, s->ev_fork, 0));
   }
-  const int launch_order[kGroups] = {kAndGeneral, kBool, 1, 2, 0};  // long serial chains first
+  const int launch_order[kGroups] = {kAndGeneral, kBool, kShare, 1, 2, 0};  // long serial chains first
   for (int oi = 0; oi < kGroups; ++oi) {
     const int gi = launch_order[oi];
     Group &g = groups[gi];
     if (g.queries.empty()) continue;
     // the big dense-AND group keeps the caller's stream, the others go to the side stream
     hipStream_t gst = (fork && gi != 0) ? s->side_stream : st;
+    if (gi == kShare) {
+      TqkShareParams sp{};
+      sp.seg = s->dseg;
+      sp.terms = s->d_terms;
+      sp.queries = (const TqdQuery *)(ds + g.o_queries);
+      sp.caches = (const float *)(ds + o_caches);
+      sp.leads = (const TqdLead *)(ds + g.o_leads);
+      sp.tasks = (const uint4 *)(ds + g.o_tasks);
+      sp.sinks = (const TqkSinks *)(ds + g.o_sinks);
+      sp.thr_slots = (uint32_t *)s->d_thr.p;
+      sp.thr_val = (uint32_t *)s->d_share_words.p;
+      sp.list_count = sp.thr_val + n_share;
+      sp.task_counter = sp.thr_val + 2 * n_share;
+      sp.stage = (uint64_t *)s->d_share_stage.p;
+      sp.lists = (uint64_t *)((uint8_t *)s->d_partials.p + part_off_bytes[gi]);
+      sp.n_tasks = g.n_chunks;
+      sp.n_queries = (uint32_t)n_share;
+      sp.grid = share_grid;
+      static const uint32_t kDebugS = tune_u32("TQ_DEBUG", 0);
+      sp.debug = kDebugS;
+      sp.bound_slack = co.bound_slack;
+      tiles_total += g.total_tiles;
+      chunks_total += g.n_chunks;
+      const hipError_t e = tqk_launch_share(sp, g.kpl, gst);
+      if (e != hipSuccess) return fail(TQ_ERR_HIP, "shared-union launch: %s", hipGetErrorString(e));
+      continue;
+    }
     TqkScanParams p{};
     p.seg = s->dseg;
     if (!s->opt.use_dense) p.seg.docmat = nullptr;
@@ -2031,7 +2223,9 @@ int search_batch_impl(tq_segment *s, const tq_query *queries, uint32_t n_queries
     m.out_counts = d_out_counts;
     m.n_queries = (uint32_t)g.queries.size();
     m.out_stride = out_stride;
-    hipError_t e = tqk_launch_merge(m, g.kpl, st);
+    hipError_t e = gi == kShare
+                       ? tqk_launch_merge_lists(m, (const uint32_t *)s->d_share_words.p + n_share, g.kpl, st)
+                       : tqk_launch_merge(m, g.kpl, st);
     if (e != hipSuccess) return fail(TQ_ERR_HIP, "merge kernel launch: %s", hipGetErrorString(e));
   }
   if (s->opt.timing) {
@@ -2272,7 +2466,7 @@ int tq_segment_get_stats(tq_segment *s, tq_segment_stats *out) {
   r.posdir_bytes = s->bytes_posdir;
   r.scratch_bytes = s->d_stage.cap + s->d_stage_alt.cap + s->d_partials.cap + s->d_out_scores.cap +
                     s->d_out_docs.cap + s->d_out_counts.cap + s->d_misc.cap + s->d_thr.cap +
-                    s->d_qmatches.cap;
+                    s->d_qmatches.cap + s->d_share_words.cap + s->d_share_stage.cap;
   r.n_terms = (uint32_t)s->terms.size();
   r.n_dense_lists = s->n_dense_lists;
   r.n_docmat_columns = s->n_mat_slots;

@@ -78,6 +78,27 @@ struct TqdQuery {
   uint32_t min_should;  // Should terms that have to match (minimum_number_should_match)
 };
 
+// ---- shared-union launch (tq_ushare.hip): the pure unions of a batch, driven term by term.
+// A LEAD is one (query, list) pair: list i of query q leading the docs it is the first list to
+// hold.  The leads of one term are cut into groups of <= TQD_US_GROUP; a TASK is a run of blocks of
+// that term for one group: the blocks are decoded and their doc-matrix words gathered ONCE, every
+// lead of the group tests them on registers.
+#define TQD_US_GROUP 32      // leads per group (one lane each at task setup)
+#define TQD_US_MAX_TERMS 8   // unions with more terms keep the per-query kernel
+#define TQD_US_TILE 64       // blocks per pre-filter step (one lane each)
+struct TqdLead {             // 64 bytes, written by the host planner
+  uint32_t query;            // launch-group query index
+  uint32_t info;             // i (bits 0-3) | lists after i with a doc-matrix column (4-7) | n_terms
+                             // (8-11) | bit 16+m: list m of the query has NO column
+  float w;                   // weight of the leading term in this query
+  float suffix;              // weights of lists i.. : the most a doc first seen in list i can score
+  float sparse_after;        // weights of the lists after i without a column
+  uint32_t cols_lo, cols_hi; // doc-matrix bit positions (8 + slot) of the after-column lists 0-3 / 4-6
+  float aw[7];               // their weights, in list order
+  uint64_t before_mask;      // doc-matrix bits of the lists before i that have a column
+};
+static_assert(sizeof(TqdLead) == 64, "TqdLead is uploaded as raw bytes");
+
 #define TQD_ROLE_SHOULD 0u
 #define TQD_ROLE_MUST 1u
 #define TQD_ROLE_MUST_NOT 2u

@@ -41,6 +41,28 @@ struct TqkScanParams {
   float bound_slack;    // >= 1: widens block-max bounds when the BM25 statistics are not the segment's own
 };
 
+// shared-union launch: a persistent grid of single-wave workgroups pulling tasks
+struct TqkShareParams {
+  TqdSegment seg;
+  const TqdTerm *terms;
+  const TqdQuery *queries;      // the launch group's queries (part_start / n_parts count list ENTRIES)
+  const float *caches;
+  const TqdLead *leads;
+  const uint4 *tasks;           // {term handle, first block, n_blocks | n_leads << 16 | cache << 24, first lead}
+  const TqkSinks *sinks;
+  uint32_t *thr_slots;          // hashed score slots per query (as the other pruned kernels use)
+  uint32_t *thr_val;            // [n_queries] current lower bound of each query's k-th best score
+  uint32_t *task_counter;       // next task to hand out (zeroed per batch)
+  uint64_t *stage;              // [grid][TQD_US_GROUP][capl] per-wave staging lists
+  uint64_t *lists;              // per-query result lists (query q: entries part_start .. + n_parts)
+  uint32_t *list_count;         // [n_queries] entries written so far
+  uint32_t n_tasks;
+  uint32_t n_queries;
+  uint32_t grid;
+  uint32_t debug;
+  float bound_slack;
+};
+
 struct TqkMergeParams {
   const TqdQuery *queries;
   const uint64_t *partials;
@@ -68,6 +90,11 @@ hipError_t tqk_launch_and(const TqkScanParams &p, int kpl, bool use_dpp, hipStre
 hipError_t tqk_launch_or(const TqkScanParams &p, int kpl, bool use_dpp, hipStream_t st);
 hipError_t tqk_launch_phrase(const TqkScanParams &p, int kpl, bool use_dpp, hipStream_t st);
 hipError_t tqk_launch_merge(const TqkMergeParams &p, int kpl, hipStream_t st);
+hipError_t tqk_launch_share(const TqkShareParams &p, int kpl, hipStream_t st);
+// merge of the shared-union launch's per-query lists (m.partials = lists, list_count per query)
+hipError_t tqk_launch_merge_lists(const TqkMergeParams &m, const uint32_t *list_count, int kpl,
+                                  hipStream_t st);
+uint32_t tqk_share_capl(int kpl);  // staging entries per lead slot
 hipError_t tqk_launch_decode_list(const TqdSegment &seg, const TqdTerm *terms, uint32_t handle,
                                   uint32_t n_blocks, uint32_t *docs, uint32_t *tfs, bool use_dpp,
                                   hipStream_t st);

@@ -1,0 +1,712 @@
+// tq_ushare.hip — the pure unions of a batch, driven TERM BY TERM instead of query by query.
+// Shared device helpers: tq_common.hpp.
+//
+// block_wand (src/query/boolean_query/block_wand_union.rs:16-80,158-214) in its MaxScore set form,
+// as union_kernel (tq_union.hip) runs it per query: terms by weight descending, every list leads
+// the docs it is the FIRST list to hold, a doc first seen in list i can score at most the weights
+// of lists i.. ("suffix"), lists whose suffix is below the threshold are never enumerated.
+//
+// What changes is the loop order.  In a batch many queries lead with the same term (nine per term
+// in the 1000-query or5 batch, 45 in the mixed one): each of them used to decode the same blocks
+// and gather the same doc-matrix rows.  Here a TASK is a run of blocks of ONE term for a GROUP of
+// up to 32 LEADS — (query, list) pairs whose list is that term:
+//   pre-filter, lane <-> block: the block's record, its block-max tf/(tf+norm), and for every live
+//      lead "block-max score + weights of the later lists >= threshold" -> a lead mask per block;
+//   A  per surviving block: ONE staged load + unpack + prefix sum, ONE 8-byte doc-matrix gather
+//      per doc (fieldnorm id + membership in every dense list of the segment);
+//   F  per (block, lead in the block's mask): the lead's constants come from lane g's registers
+//      (readlane -> scalar operands); two docs per lane test "another list before i holds the doc"
+//      (owned elsewhere) and "leader score + weights of the later lists that HOLD it (column bits)
+//      or MAY hold it (no column) >= threshold" on registers; survivors -> LDS queue, tagged g;
+//   C  64 survivors, each lane with its own query: exact BM25 of the leader and of the later
+//      lists (bitmap rank -> block record -> tf bits; lists without a bitmap: seek + block search,
+//      up to four distinct (list, block) pairs per step), ownership probes into the earlier lists
+//      without a column, then the collector step.
+// Scores are summed leader first, then ascending list index: the bits of every other union
+// kernel and mode.
+//
+// Collector: a wave works for up to 32 queries at once, so the top-k cannot live in registers.
+// Every lead slot has a staging list in global memory private to the wave (k + 64.. entries);
+// a list that fills up is cut back to its k best (64-bit radix select) — which also yields a
+// threshold: k real docs score at least that.  At the end of a task the lists are appended to
+// their queries' result lists (one atomic per list), which merge_lists_kernel reduces.
+// Thresholds: the hashed atomic-max slots of the other pruned kernels, plus thr_val[query], the
+// k-th largest slot as last computed by a wave that changed a slot — tasks read ONE word per
+// lead instead of selecting over 256 slots.  Both only ever rise and every value is the score of
+// k distinct real matches, so pruning stays exact: the top-k equals the exhaustive run's bits.
+#include "tq_common.hpp"
+
+#ifndef TQ_US_WAVES
+#define TQ_US_WAVES 5
+#endif
+
+namespace {
+
+constexpr uint32_t US_GROUP = TQD_US_GROUP;
+
+struct ShareLds {  // per wavefront
+  uint32_t pay[516];  // staged payload of the leader block / four 512-byte regions of the block search
+  float cache[256];   // Bm25Weight.cache of the task's queries
+  uint32_t q_doc[127], q_tf[127], q_tag[127];  // survivors: doc, leader tf, g | fieldnorm id << 8 | column bits << 16
+  uint32_t cnt[US_GROUP];      // entries in the lead slots' staging lists
+  uint32_t scored[US_GROUP];   // docs scored per lead slot (Count / statistics)
+};
+
+// per-lane view of a posting list (fields of TqdTermHead fetched with vector loads)
+__device__ __forceinline__ TermRef load_term_lane(const TqdTerm *terms, uint32_t handle) {
+  const TqdTermHead *h = terms + handle;
+  TermRef r;
+  r.rec = h->rec;
+  r.coarse = h->coarse;
+  r.dense = h->dense;
+  r.tail_docs = h->tail_docs;
+  r.tail_tfs = h->tail_tfs;
+  r.payload_base = h->payload_base;
+  r.n_blocks = h->n_blocks;
+  r.n_tail = h->n_tail;
+  const uint32_t hf = h->has_freq;
+  r.has_freq = hf & 1u;
+  r.mat_slot = ((hf >> 8) & 0xFFu) - 1u;
+  r.shift = h->coarse_shift;
+  return r;
+}
+
+// lookup_in_blocks<false> (tq_common.hpp) for candidates whose LISTS differ per lane: where is
+// `doc` inside block jb of list t?  Up to four distinct (list, block) pairs are decoded per step,
+// one per 16-lane row; then every candidate binary-searches its block (block_search.rs:38-76).
+__device__ __forceinline__ uint32_t lookup_docs_multi(const uint8_t *idx, const TermRef &t,
+                                                      uint32_t jb, uint32_t doc, bool alive,
+                                                      uint32_t *P, int lane) {
+  uint32_t result = NOT_FOUND;
+  uint64_t pend = __ballot(alive);
+  const uint32_t row = (uint32_t)lane >> 4, l16 = (uint32_t)lane & 15u;
+  while (pend) {
+    uint32_t gid = 4u, n_groups = 0;
+    // the row's block: record pointer, block index, payload base, vint tail of its list
+    uint64_t my_rec = 0, my_pb = 0, my_td = 0;
+    uint32_t my_j = 0, my_nt = 0;
+#pragma unroll
+    for (uint32_t g = 0; g < 4u; ++g) {
+      if (pend) {
+        const uint32_t l = (uint32_t)__builtin_ctzll(pend);
+        const uint32_t j = (uint32_t)__builtin_amdgcn_readlane((int)jb, (int)l);
+        const uint64_t rp = readlane64((uint64_t)t.rec, l);
+        const uint64_t pb = readlane64(t.payload_base, l);
+        const uint64_t td = readlane64((uint64_t)t.tail_docs, l);
+        const uint32_t nt = (uint32_t)__builtin_amdgcn_readlane((int)t.n_tail, (int)l);
+        const bool in = alive && gid == 4u && jb == j && (uint64_t)t.rec == rp;
+        if (in) gid = g;
+        pend &= ~__ballot(in);
+        if (row == g) {
+          my_rec = rp;
+          my_pb = pb;
+          my_td = td;
+          my_j = j;
+          my_nt = nt;
+        }
+        n_groups = g + 1u;
+      }
+    }
+    const bool row_on = row < n_groups;
+    uint4 rec = make_uint4(0u, META_TAIL, 0u, 0u);
+    uint32_t prev = 0;
+    if (row_on) {
+      const uint4 *rp = (const uint4 *)my_rec;
+      rec = rp[my_j];
+      if (my_j) prev = rp[my_j - 1u].x;
+    }
+    const bool is_tail = rec.y == META_TAIL;
+    const uint32_t b = is_tail ? 0u : (rec.y & 31u);
+    const uint32_t strict = is_tail ? 0u : (rec.y >> 6) & 1u;
+    wave_mem_fence();
+    if (row_on && !is_tail) {
+      const uint8_t *src = idx + my_pb + rec.z + 16u * l16;
+      if (l16 < b) {
+        const U4Unaligned v = *reinterpret_cast<const U4Unaligned *>(src);
+        *reinterpret_cast<uint4 *>(P + row * 128u + 4u * l16) = make_uint4(v.x, v.y, v.z, v.w);
+      }
+      if (16u + l16 < b) {
+        const U4Unaligned v = *reinterpret_cast<const U4Unaligned *>(src + 256);
+        *reinterpret_cast<uint4 *>(P + row * 128u + 64u + 4u * l16) = make_uint4(v.x, v.y, v.z, v.w);
+      }
+    }
+    wave_mem_fence();
+    uint32_t d[8];
+    {
+      const uint32_t mask = b >= 32u ? 0xFFFFFFFFu : (1u << b) - 1u;
+#pragma unroll
+      for (uint32_t kk = 0; kk < 2u; ++kk) {
+        const uint32_t bitpos = (2u * l16 + kk) * b;
+        const uint32_t w = bitpos >> 5, sh = bitpos & 31u;
+        const uint4 lo = *reinterpret_cast<const uint4 *>(P + row * 128u + 4u * w);
+        const uint4 hi = *reinterpret_cast<const uint4 *>(P + row * 128u + 4u * w + 4u);
+        d[4 * kk + 0] = (__funnelshift_r(lo.x, hi.x, sh) & mask) + strict;
+        d[4 * kk + 1] = (__funnelshift_r(lo.y, hi.y, sh) & mask) + strict;
+        d[4 * kk + 2] = (__funnelshift_r(lo.z, hi.z, sh) & mask) + strict;
+        d[4 * kk + 3] = (__funnelshift_r(lo.w, hi.w, sh) & mask) + strict;
+      }
+    }
+    if (__ballot(row_on && is_tail)) {  // the pre-decoded vint tail of the list
+      if (row_on && is_tail) {
+        const uint32_t *td = (const uint32_t *)my_td;
+#pragma unroll
+        for (uint32_t e = 0; e < 8u; ++e) {
+          const uint32_t i = 8u * l16 + e;
+          d[e] = i < my_nt ? td[i] : TQD_TERMINATED;
+        }
+      }
+    }
+    if (!is_tail) {  // (uniform per 16-lane row)
+      uint32_t loc[8];
+      loc[0] = d[0];
+#pragma unroll
+      for (int e = 1; e < 8; ++e) loc[e] = loc[e - 1] + d[e];
+      uint32_t incl = loc[7];
+      incl += dpp_get<0x111, 0xF>(incl);
+      incl += dpp_get<0x112, 0xF>(incl);
+      incl += dpp_get<0x114, 0xF>(incl);
+      incl += dpp_get<0x118, 0xF>(incl);
+      // compression/mod.rs:36-39,112-121: offset 0 <=> None <=> seed u32::MAX (wrapping)
+      const uint32_t base = ((strict && prev == 0u) ? 0xFFFFFFFFu : prev) + (incl - loc[7]);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) d[e] = loc[e] + base;
+    }
+    wave_mem_fence();
+    if (row_on) {
+      *reinterpret_cast<uint4 *>(P + row * 128u + 8u * l16) = make_uint4(d[0], d[1], d[2], d[3]);
+      *reinterpret_cast<uint4 *>(P + row * 128u + 8u * l16 + 4u) = make_uint4(d[4], d[5], d[6], d[7]);
+    }
+    wave_mem_fence();
+    if (gid < 4u) {
+      const uint32_t *blk = P + gid * 128u;
+      uint32_t pos = 0;
+#pragma unroll
+      for (uint32_t step = 64u; step > 0u; step >>= 1)
+        if (blk[pos + step - 1u] < doc) pos += step;
+      result = blk[pos] == doc ? pos : NOT_FOUND;
+    }
+  }
+  return result;
+}
+
+// k-th largest of the n (<= 64 R) keys held R per lane (0 = empty); n >= k
+template <int R>
+__device__ __forceinline__ uint64_t kth_largest_key(const uint64_t (&v)[R], uint32_t k) {
+  uint64_t ans = 0;
+  for (int bit = 63; bit >= 0; --bit) {
+    const uint64_t trial = ans | (1ull << bit);
+    uint32_t c = 0;
+#pragma unroll
+    for (int r = 0; r < R; ++r) c += (uint32_t)__popcll(__ballot(v[r] >= trial));
+    if (c >= k) ans = trial;
+  }
+  return ans;
+}
+
+template <int KPL>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_num_sgpr(96), amdgpu_waves_per_eu(TQ_US_WAVES, 8))) void
+ushare_kernel(TqkShareParams p) {
+  constexpr bool USE_DPP = true;
+  constexpr int R = KPL + 1;                    // staging registers per lane
+  constexpr uint32_t CAPL = (uint32_t)R * 64u;  // staging entries per lead slot
+  __shared__ ShareLds L;
+  const int lane = (int)__lane_id();
+  const TqdSegment seg = p.seg;
+  const uint8_t *idx = seg.idx;
+  uint64_t *const my_stage = p.stage + (size_t)blockIdx.x * (size_t)(US_GROUP * CAPL);
+  uint32_t cache_loaded = 0xFFFFFFFFu;
+  uint32_t qn = 0;        // survivor queue fill
+  uint32_t n_scored = 0;  // docs scored by this wave (all tasks)
+
+  // ---- state of the current task (lane g < n_leads <-> lead g)
+  TqdLead mine{};
+  uint32_t thr_mine = 0xFFFFFFFFu, k_mine = 1, thr_row_mine = 0;
+  uint32_t n_leads = 0;
+
+  // a staging list is cut back to its k best; returns the k-th key (the list held n > k entries)
+  auto compact_slot = [&](uint32_t g, uint32_t n, uint32_t k) __attribute__((always_inline)) -> uint64_t {
+    uint64_t *sl = my_stage + (size_t)g * CAPL;
+    uint64_t v[R];
+    wave_mem_fence();
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const uint32_t i = (uint32_t)r * 64u + (uint32_t)lane;
+      v[r] = i < n ? sl[i] : 0ull;
+    }
+    const uint64_t kth = kth_largest_key<R>(v, k);
+    uint32_t base = 0;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const bool keep = v[r] >= kth && v[r] != 0ull;
+      const uint64_t m = __ballot(keep);
+      if (keep) sl[base + mbcnt64(m)] = v[r];
+      base += (uint32_t)__popcll(m);
+    }
+    wave_mem_fence();
+    return kth;
+  };
+
+  // ---- stage C: 64 survivors, every lane with its own query
+  auto stageC = [&](uint32_t n) __attribute__((always_inline)) {
+    const uint32_t base = qn - n;
+    qn = base;
+    bool alive = (uint32_t)lane < n;
+    uint32_t doc = 0, tf = 0, tag = 0;
+    if (alive) {
+      doc = L.q_doc[base + lane];
+      tf = L.q_tf[base + lane];
+      tag = L.q_tag[base + lane];
+    }
+    const uint32_t g = tag & 31u;
+    const float norm = L.cache[(tag >> 8) & 0xFFu];
+    const uint32_t bits = tag >> 16;
+    // the lead's constants from lane g's registers
+    const uint32_t q = (uint32_t)__shfl((int)mine.query, (int)g, WAVE);
+    const uint32_t info = (uint32_t)__shfl((int)mine.info, (int)g, WAVE);
+    const float w_lead = __shfl(mine.w, (int)g, WAVE);
+    const float suffix = __shfl(mine.suffix, (int)g, WAVE);
+    const uint32_t thr = (uint32_t)__shfl((int)thr_mine, (int)g, WAVE);
+    const uint32_t k = (uint32_t)__shfl((int)k_mine, (int)g, WAVE);
+    const uint32_t thr_row = (uint32_t)__shfl((int)thr_row_mine, (int)g, WAVE);
+    const uint32_t li = info & 15u, nt = (info >> 8) & 15u, nocol = info >> 16;
+    const TqdQuery *Q = p.queries + q;
+    const float slack_abs = suffix * 4.0e-6f;
+    float s = bm25(w_lead, norm, tf);
+    float rest = suffix - w_lead;  // what the lists after the current one can still add
+    uint32_t c = 0;                // column counter of the lists after the leader
+    uint32_t max_after = 0, max_before = 0;
+    {
+      uint32_t a = alive ? nt - 1u - li : 0u, b = alive ? li : 0u;
+      for (int o = 32; o; o >>= 1) {
+        const uint32_t a2 = (uint32_t)__shfl_xor((int)a, o, WAVE), b2 = (uint32_t)__shfl_xor((int)b, o, WAVE);
+        a = a2 > a ? a2 : a;
+        b = b2 > b ? b2 : b;
+      }
+      max_after = uni(a);
+      max_before = uni(b);
+    }
+    // lists after the leader, ascending: they add to the score
+    for (uint32_t a = 1; a <= max_after; ++a) {
+      const uint32_t m = li + a;
+      const bool on = alive && m < nt;
+      if (!__ballot(on)) break;
+      float w = 0.0f;
+      uint32_t h = 0;
+      if (on) {
+        w = Q->weight[m];
+        h = Q->term[m];
+      }
+      const bool has_col = on && !((nocol >> m) & 1u);
+      bool member = false;
+      if (has_col) {
+        member = (bits >> c) & 1u;
+        ++c;
+      }
+      bool probe = on && !has_col;  // no column: the exact probe, only while the doc can still make it
+      if (probe) {
+        const float r0 = rest > 0.0f ? rest : 0.0f;
+        if (!(sortable((s + r0) * 1.000002f + slack_abs) >= thr)) {
+          alive = false;
+          probe = false;
+        }
+      }
+      if (__ballot(member || probe)) {
+        TermRef tr{};
+        if (member || probe) tr = load_term_lane(p.terms, h);
+        uint32_t jb = 0, at = NOT_FOUND;
+        bool found = false;
+        const bool bitmap = (member || probe) && tr.dense != nullptr;
+        if (bitmap) {
+          const uint2 wd = tr.dense[doc >> 5];
+          const uint32_t bit = doc & 31u;
+          found = (wd.x >> bit) & 1u;
+          const uint32_t pi = wd.y + (uint32_t)__popc(wd.x & ((1u << bit) - 1u));
+          jb = pi >> 7;
+          at = pi & 127u;
+        }
+        bool cand = probe && !bitmap;
+        if (__ballot(cand)) {
+          if (cand) {
+            jb = seek_block(tr, doc);
+            cand = jb < tr.n_blocks;
+          }
+          const uint32_t a2 = lookup_docs_multi(idx, tr, jb, doc, cand, L.pay, lane);
+          if (cand && a2 != NOT_FOUND) {
+            found = true;
+            at = a2;
+          }
+        }
+        if (found) {
+          const uint4 r = tr.rec[jb];
+          s = s + bm25(w, norm, block_tf_at(idx, tr, make_uint2(r.y, r.z), at));
+        }
+      }
+      if (on) rest -= w;
+    }
+    // lists before the leader without a column: found there = that list's tasks score the doc
+    for (uint32_t m = 0; m < max_before; ++m) {
+      bool probe = alive && m < li && ((nocol >> m) & 1u);
+      if (probe && !(sortable(s * 1.000002f + slack_abs) >= thr)) {  // the score is final: dead either way
+        alive = false;
+        probe = false;
+      }
+      if (!__ballot(probe)) continue;
+      TermRef tr{};
+      if (probe) tr = load_term_lane(p.terms, Q->term[m]);
+      const bool bitmap = probe && tr.dense != nullptr;
+      bool found = false;
+      if (bitmap) found = (tr.dense[doc >> 5].x >> (doc & 31u)) & 1u;
+      bool cand = probe && !bitmap;
+      if (__ballot(cand)) {
+        uint32_t jb = 0;
+        if (cand) {
+          jb = seek_block(tr, doc);
+          cand = jb < tr.n_blocks;
+        }
+        const uint32_t a2 = lookup_docs_multi(idx, tr, jb, doc, cand, L.pay, lane);
+        if (cand && a2 != NOT_FOUND) found = true;
+      }
+      if (found) alive = false;
+    }
+    // the score is final: below the threshold it cannot enter the top-k (equal scores stay: ties
+    // resolve by doc id in the collector)
+    if (alive) alive = sortable(s) >= thr;
+    if (alive) alive = doc_is_alive(seg, doc);
+    const uint64_t hit = __ballot(alive);
+    if (!hit) return;
+    n_scored += (uint32_t)__popcll(hit);
+    const uint64_t key = alive ? make_key(s, doc) : 0ull;
+    const uint32_t sb = (uint32_t)(key >> 32);
+    bool changed = false;
+    if (alive) {
+      atomicAdd(&L.scored[g], 1u);
+      const uint32_t hsh = (doc * 0x9E3779B1u) >> (k <= 16u ? 26 : 24);
+      const uint32_t old = atomicMax(p.thr_slots + (size_t)thr_row * TQD_THR_SLOTS + hsh, sb);
+      changed = old < sb;
+      const uint32_t pos = atomicAdd(&L.cnt[g], 1u);  // (a list never overflows: see the cut below)
+      my_stage[(size_t)g * CAPL + pos] = key;
+    }
+    // queries whose slots changed: their k-th largest slot is the new shared threshold
+    uint64_t chg = __ballot(changed);
+    while (chg) {
+      const uint32_t l = (uint32_t)__builtin_ctzll(chg);
+      const uint32_t qs = (uint32_t)__builtin_amdgcn_readlane((int)q, (int)l);
+      const uint32_t ks = (uint32_t)__builtin_amdgcn_readlane((int)k, (int)l);
+      const uint32_t rs = (uint32_t)__builtin_amdgcn_readlane((int)thr_row, (int)l);
+      chg &= ~__ballot(changed && q == qs);
+      const uint32_t *slots = p.thr_slots + (size_t)rs * TQD_THR_SLOTS;
+      uint32_t sv[4] = {0u, 0u, 0u, 0u};
+      sv[0] = __hip_atomic_load(slots + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      uint32_t gth;
+      if (ks > 16u) {
+#pragma unroll
+        for (int r = 1; r < 4; ++r)
+          sv[r] = __hip_atomic_load(slots + 64 * r + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        gth = kth_largest_hi16<4>(sv, ks);
+      } else {
+        gth = kth_largest_hi16<1>(sv, ks);
+      }
+      if (gth) {
+        if (lane == 0) atomicMax(p.thr_val + qs, gth);
+        if ((uint32_t)lane < n_leads && mine.query == qs && gth > thr_mine) thr_mine = gth;
+      }
+    }
+    // staging lists that could overflow with the next batch are cut back to their k best now
+    wave_mem_fence();
+    const uint32_t cn = (uint32_t)lane < US_GROUP ? L.cnt[lane] : 0u;
+    uint64_t full = __ballot(cn > CAPL - 64u);
+    while (full) {
+      const uint32_t gs = (uint32_t)__builtin_ctzll(full);
+      full &= full - 1ull;
+      const uint32_t ns = (uint32_t)__builtin_amdgcn_readlane((int)cn, (int)gs);
+      const uint32_t ks = (uint32_t)__builtin_amdgcn_readlane((int)k_mine, (int)gs);
+      const uint64_t kth = compact_slot(gs, ns, ks);
+      const uint32_t t = (uint32_t)(kth >> 32);
+      if ((uint32_t)lane == gs) {
+        L.cnt[gs] = ks;
+        if (t > thr_mine) thr_mine = t;
+        atomicMax(p.thr_val + mine.query, t);  // k distinct docs of this query score >= t
+      }
+    }
+    wave_mem_fence();
+  };
+
+  for (;;) {
+    uint32_t task = 0;
+    if (lane == 0) task = atomicAdd(p.task_counter, 1u);
+    task = uni(task);
+    if (task >= p.n_tasks) break;
+    const uint4 trec = sload(p.tasks + task);
+    const uint32_t j0 = trec.y, nb_task = trec.z & 0xFFFFu, ci = trec.z >> 24, lead0 = trec.w;
+    n_leads = (trec.z >> 16) & 0xFFu;
+    const TermRef lead = load_term(p.terms, trec.x);
+    if (ci != cache_loaded) {
+      const float *cg = p.caches + (size_t)ci * 256u;
+      wave_mem_fence();
+      for (int i = lane; i < 256; i += WAVE) L.cache[i] = cg[i];
+      wave_mem_fence();
+      cache_loaded = ci;
+    }
+    // ---- the group's leads, one per lane
+    thr_mine = 0xFFFFFFFFu;
+    mine.suffix = 0.0f;
+    if ((uint32_t)lane < n_leads) {
+      mine = p.leads[lead0 + lane];
+      const TqdQuery *Q = p.queries + mine.query;
+      k_mine = Q->k;
+      thr_row_mine = Q->thr_index;
+      thr_mine = __hip_atomic_load(p.thr_val + mine.query, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    wave_mem_fence();
+    if ((uint32_t)lane < US_GROUP) {
+      L.cnt[lane] = 0u;
+      L.scored[lane] = 0u;
+    }
+    wave_mem_fence();
+    auto lead_alive = [&]() __attribute__((always_inline)) {
+      return (uint32_t)lane < n_leads && sortable(mine.suffix * 1.000001f) >= thr_mine;
+    };
+    uint32_t live = (uint32_t)__ballot(lead_alive());
+
+    for (uint32_t jt = 0; jt < nb_task && live; jt += TQD_US_TILE) {
+      // thresholds may have risen since the last step (one word per lead)
+      if (jt) {
+        if ((uint32_t)lane < n_leads) {
+          const uint32_t t = __hip_atomic_load(p.thr_val + mine.query, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if (t > thr_mine) thr_mine = t;
+        }
+        live = (uint32_t)__ballot(lead_alive());
+        if (!live) break;
+      }
+      // ---- pre-filter: lane <-> block
+      const uint32_t nb = nb_task - jt < TQD_US_TILE ? nb_task - jt : TQD_US_TILE;
+      const uint32_t i_base = j0 + jt;
+      const uint32_t i_mine = i_base + (uint32_t)lane;
+      const bool in_tile = (uint32_t)lane < nb && i_mine < lead.n_blocks;
+      uint4 rec_mine = make_uint4(0u, 0u, 0u, 0u);
+      if (in_tile) rec_mine = lead.rec[i_mine];
+      uint32_t prev_mine = __shfl_up(rec_mine.x, 1, WAVE);
+      if (lane == 0) prev_mine = block_prev_last(lead, i_base);
+      // block-max of tf/(tf+norm), the weight-free part of block_max_score (term_scorer.rs:58-75)
+      float tfn_max = 1.0f;
+      {
+        const uint32_t tfc = rec_mine.y >> 24;
+        if (!(rec_mine.y == META_TAIL || !lead.has_freq || tfc == 0u)) {
+          const float f = (float)(tfc == 255u ? 0xFFFFFFFFu : tfc);
+          tfn_max = f * __builtin_amdgcn_rcpf(f + L.cache[(rec_mine.y >> 16) & 0xFFu]);
+        }
+      }
+      uint32_t pass_mask = 0;  // leads that still want this block
+      for (uint32_t lm = live; lm; lm &= lm - 1u) {
+        const uint32_t g = (uint32_t)__builtin_ctz(lm);
+        const float w = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(mine.w), (int)g));
+        const float suf = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(mine.suffix), (int)g));
+        const uint32_t thr = (uint32_t)__builtin_amdgcn_readlane((int)thr_mine, (int)g);
+        const float ub = w * tfn_max * p.bound_slack;
+        if (in_tile && sortable((ub + (suf - w)) * 1.000004f + suf * 4.0e-6f) >= thr) pass_mask |= 1u << g;
+      }
+      uint64_t todo = __ballot(pass_mask != 0u);
+      while (todo) {
+        const uint32_t b = (uint32_t)__builtin_ctzll(todo);
+        todo &= todo - 1ull;
+        uint32_t lm = (uint32_t)__builtin_amdgcn_readlane((int)pass_mask, (int)b);
+        const uint2 mo_l = make_uint2((uint32_t)__builtin_amdgcn_readlane((int)rec_mine.y, (int)b),
+                                      (uint32_t)__builtin_amdgcn_readlane((int)rec_mine.z, (int)b));
+        const uint32_t prev_l = (uint32_t)__builtin_amdgcn_readlane((int)prev_mine, (int)b);
+        // ---- stage A: decode the block once
+        uint32_t c0, c1, t0, t1;
+        if (mo_l.x == META_TAIL) {
+          decode_docs<USE_DPP>(idx, lead, mo_l, prev_l, lane, c0, c1);
+          decode_tfs(idx, lead, mo_l, lane, t0, t1);
+        } else {
+          const uint32_t doc_bits = mo_l.x & 31u;
+          const uint32_t strict = (mo_l.x >> 6) & 1u;
+          const uint32_t tf_bits = lead.has_freq ? (mo_l.x >> 8) & 0xFFu : 0u;
+          wave_mem_fence();
+          stage_payload(L.pay, idx + lead.payload_base + mo_l.y, 16u * (doc_bits + tf_bits), lane);
+          wave_mem_fence();
+          if (lead.has_freq) {
+            unpack2_lds(L.pay + 4u * doc_bits, tf_bits, lane, t0, t1);
+            t0 += strict;
+            t1 += strict;
+          } else {
+            t0 = 1u;
+            t1 = 1u;
+          }
+          uint32_t x0, x1;
+          unpack2_lds(L.pay, doc_bits, lane, x0, x1);
+          finish_docs<USE_DPP>(x0, x1, strict, prev_l, lane, c0, c1);
+        }
+        const bool v0 = c0 != TQD_TERMINATED, v1 = c1 != TQD_TERMINATED;
+        // ONE gather per doc: fieldnorm id + membership in every dense list of the segment
+        const uint64_t mw0 = v0 ? seg.docmat[c0] : 0ull;
+        const uint64_t mw1 = v1 ? seg.docmat[c1] : 0ull;
+        const uint32_t nid0 = (uint32_t)mw0 & 0xFFu, nid1 = (uint32_t)mw1 & 0xFFu;
+        const float f0 = (float)t0, f1 = (float)t1;
+        const float tfn0 = f0 * __builtin_amdgcn_rcpf(f0 + L.cache[nid0]);
+        const float tfn1 = f1 * __builtin_amdgcn_rcpf(f1 + L.cache[nid1]);
+        // ---- stage F: every lead that wants the block
+        for (; lm; lm &= lm - 1u) {
+          const uint32_t g = (uint32_t)__builtin_ctz(lm);
+          auto rl = [&](uint32_t x) __attribute__((always_inline)) {
+            return (uint32_t)__builtin_amdgcn_readlane((int)x, (int)g);
+          };
+          const uint32_t thr = rl(thr_mine);
+          const float w = __uint_as_float(rl(__float_as_uint(mine.w)));
+          const float suf = __uint_as_float(rl(__float_as_uint(mine.suffix)));
+          const float sp = __uint_as_float(rl(__float_as_uint(mine.sparse_after)));
+          const uint32_t ncols = (rl(mine.info) >> 4) & 15u;
+          const uint64_t before = ((uint64_t)rl((uint32_t)(mine.before_mask >> 32)) << 32) | rl((uint32_t)mine.before_mask);
+          const uint32_t cols_lo = rl(mine.cols_lo), cols_hi = rl(mine.cols_hi);
+          float rest0 = sp, rest1 = sp;
+          uint32_t bits0 = 0, bits1 = 0;
+#pragma unroll
+          for (uint32_t c = 0; c < 7u; ++c) {
+            if (c < ncols) {  // (wave-uniform)
+              const uint32_t col = ((c < 4u ? cols_lo >> (8u * c) : cols_hi >> (8u * (c - 4u)))) & 0xFFu;
+              const float aw = __uint_as_float(rl(__float_as_uint(mine.aw[c])));
+              const uint32_t m0 = (uint32_t)(mw0 >> col) & 1u, m1 = (uint32_t)(mw1 >> col) & 1u;
+              rest0 += m0 ? aw : 0.0f;
+              rest1 += m1 ? aw : 0.0f;
+              bits0 |= m0 << c;
+              bits1 |= m1 << c;
+            }
+          }
+          const float sl = suf * 4.0e-6f;
+          const bool a0 = v0 && !(mw0 & before) && sortable((w * tfn0 + rest0) * 1.000004f + sl) >= thr;
+          const bool a1 = v1 && !(mw1 & before) && sortable((w * tfn1 + rest1) * 1.000004f + sl) >= thr;
+          const uint64_t m0 = __ballot(a0), m1 = __ballot(a1);
+          if (!(m0 | m1)) continue;
+          const uint32_t n0 = (uint32_t)__popcll(m0);
+          const uint32_t pos0 = qn + mbcnt64(m0);
+          const uint32_t pos1 = qn + n0 + mbcnt64(m1);
+          wave_mem_fence();
+          if (a0) {
+            L.q_doc[pos0] = c0;
+            L.q_tf[pos0] = t0;
+            L.q_tag[pos0] = g | (nid0 << 8) | (bits0 << 16);
+          }
+          if (a1) {
+            L.q_doc[pos1] = c1;
+            L.q_tf[pos1] = t1;
+            L.q_tag[pos1] = g | (nid1 << 8) | (bits1 << 16);
+          }
+          wave_mem_fence();
+          qn += n0 + (uint32_t)__popcll(m1);
+          // (the queue holds < 64 leftovers + <= 128 of this step: drained to < 64 before the next)
+          while (qn >= 64u) stageC(64u);
+        }
+      }
+    }
+    while (qn) stageC(qn < 64u ? qn : 64u);
+
+    // ---- flush: the staging lists go to their queries' result lists
+    wave_mem_fence();
+    const uint32_t cn = (uint32_t)lane < US_GROUP ? L.cnt[lane] : 0u;
+    const uint32_t sc = (uint32_t)lane < US_GROUP ? L.scored[lane] : 0u;
+    if (sc) atomicAdd(sload(&p.sinks->query_matches) + sload(&p.sinks->out_index)[mine.query], sc);
+    uint64_t have = __ballot(cn != 0u);
+    while (have) {
+      const uint32_t gs = (uint32_t)__builtin_ctzll(have);
+      have &= have - 1ull;
+      uint32_t ns = (uint32_t)__builtin_amdgcn_readlane((int)cn, (int)gs);
+      const uint32_t ks = (uint32_t)__builtin_amdgcn_readlane((int)k_mine, (int)gs);
+      const uint32_t qs = (uint32_t)__builtin_amdgcn_readlane((int)mine.query, (int)gs);
+      if (ns > ks) {
+        (void)compact_slot(gs, ns, ks);
+        ns = ks;
+      }
+      const uint32_t thr_now = __hip_atomic_load(p.thr_val + qs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const uint64_t *sl = my_stage + (size_t)gs * CAPL;
+      uint64_t v[R];
+      uint32_t keep_n = 0;
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        const uint32_t i = (uint32_t)r * 64u + (uint32_t)lane;
+        v[r] = i < ns ? sl[i] : 0ull;
+        if ((uint32_t)(v[r] >> 32) < thr_now) v[r] = 0ull;  // k docs of the query score higher by now
+        keep_n += (uint32_t)__popcll(__ballot(v[r] != 0ull));
+      }
+      if (!keep_n) continue;
+      uint32_t at = 0;
+      if (lane == 0) at = atomicAdd(p.list_count + qs, keep_n);
+      at = uni(at);
+      uint64_t *dst = p.lists + (size_t)sload(&p.queries[qs].part_start) + at;
+      uint32_t base = 0;
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        const uint64_t m = __ballot(v[r] != 0ull);
+        if (v[r] != 0ull) dst[base + mbcnt64(m)] = v[r];
+        base += (uint32_t)__popcll(m);
+      }
+    }
+  }
+  if (lane == 0 && n_scored) atomicAdd(sload(&p.sinks->match_counter), (unsigned long long)n_scored);
+}
+
+// One wavefront per query: the query's result list (list_count entries) -> sorted top-k.
+template <int KPL>
+__global__ __launch_bounds__(64) void merge_lists_kernel(TqkMergeParams p, const uint32_t *list_count) {
+  const int lane = (int)__lane_id();
+  const uint32_t q = blockIdx.x;
+  if (q >= p.n_queries) return;
+  const TqdQuery *Q = uni_ptr(p.queries + q);
+  const uint32_t k = uni(Q->k);
+  const uint32_t n = uni(list_count[q]);
+  const uint64_t *src = p.partials + (size_t)uni(Q->part_start);
+  TopK<KPL> tk;
+  tk.reset(k);
+  for (uint32_t i0 = 0; i0 < n; i0 += 256u) {  // four loads in flight per step
+    uint64_t keys[4];
+#pragma unroll
+    for (uint32_t u = 0; u < 4u; ++u) {
+      const uint32_t i = i0 + 64u * u + (uint32_t)lane;
+      keys[u] = i < n ? src[i] : 0ull;
+    }
+#pragma unroll
+    for (uint32_t u = 0; u < 4u; ++u) tk.offer(keys[u] != 0ull, keys[u], lane);
+  }
+  const uint32_t out_q = p.out_index ? p.out_index[q] : q;
+  uint32_t count = 0;
+#pragma unroll
+  for (int r = 0; r < KPL; ++r) {
+    const uint32_t rank = (uint32_t)r * 64u + (uint32_t)lane;
+    const bool real = rank < k && tk.v[r] != 0ull;
+    count += (uint32_t)__popcll(__ballot(real));
+    if (rank < p.out_stride) {
+      p.out_scores[(uint64_t)out_q * p.out_stride + rank] = real ? key_score(tk.v[r]) : 0.0f;
+      p.out_docs[(uint64_t)out_q * p.out_stride + rank] = real ? key_doc(tk.v[r]) : TQD_TERMINATED;
+    }
+  }
+  for (uint32_t rank = (uint32_t)(KPL * 64) + (uint32_t)lane; rank < p.out_stride; rank += 64u) {
+    p.out_scores[(uint64_t)out_q * p.out_stride + rank] = 0.0f;
+    p.out_docs[(uint64_t)out_q * p.out_stride + rank] = TQD_TERMINATED;
+  }
+  if (lane == 0) p.out_counts[out_q] = count;
+}
+
+}  // namespace
+
+// =================================================================== launch wrappers
+uint32_t tqk_share_capl(int kpl) { return (uint32_t)(kpl + 1) * 64u; }
+
+hipError_t tqk_launch_share(const TqkShareParams &p, int kpl, hipStream_t st) {
+  if (p.n_tasks == 0) return hipSuccess;
+  const dim3 grid(p.grid), block(64);
+  switch (kpl) {
+    case 1: ushare_kernel<1><<<grid, block, 0, st>>>(p); break;
+    default: ushare_kernel<2><<<grid, block, 0, st>>>(p); break;
+  }
+  return hipGetLastError();
+}
+
+hipError_t tqk_launch_merge_lists(const TqkMergeParams &m, const uint32_t *list_count, int kpl,
+                                  hipStream_t st) {
+  if (m.n_queries == 0) return hipSuccess;
+  const dim3 grid(m.n_queries), block(64);
+  switch (kpl) {
+    case 1: merge_lists_kernel<1><<<grid, block, 0, st>>>(m, list_count); break;
+    default: merge_lists_kernel<2><<<grid, block, 0, st>>>(m, list_count); break;
+  }
+  return hipGetLastError();
+}
