@@ -138,6 +138,7 @@ struct Options {
   int dense_budget_x = 6;  // ... while bitmaps + doc matrix stay below this multiple of the segment's bytes
   int use_dense = 1;  // let the scan kernels use them
   int docmat = 1;     // also build the doc-major matrix of the dense lists
+  int docsig = 1;     // ... and the per-doc signature word of the lists without a column
   int device_prepare = 0;  // walk skip lists / build dense tables on the device even with a host copy
   int or_windows = -1;  // OR: 1 = window-parallel kernel, 0 = candidate-driven kernel, -1 = auto
   int bound_slack_ppm = 0;  // block-max bounds are widened by (1 + ppm * 1e-6), see block_max_score
@@ -168,6 +169,7 @@ struct tq_segment {
   TqpInfo *d_tp_info = nullptr;       // device-side prepare: result slots (info + positions result)
   uint8_t *d_idx = nullptr, *d_pos = nullptr, *d_fn = nullptr, *d_alive = nullptr;
   uint64_t *d_docmat = nullptr;  // doc-major matrix of the dense lists (TqdSegment::docmat)
+  uint64_t *d_docsig = nullptr;  // per-doc signature of the prepared lists WITHOUT a column (TqdSegment::docsig)
   uint32_t n_mat_slots = 0;
   TqdSegment dseg{};
   std::vector<TermHost> terms;
@@ -178,6 +180,7 @@ struct tq_segment {
   size_t dense_bytes_total = 0;
   // resident bytes by kind (tq_segment_get_stats)
   size_t bytes_term_tables = 0, bytes_bitmaps = 0, bytes_docmat = 0, bytes_posdir = 0, bytes_alive = 0;
+  size_t bytes_docsig = 0;
   uint32_t n_dense_lists = 0;
   std::unordered_map<uint64_t, uint32_t> term_by_off;
   // batch scratch
@@ -233,6 +236,7 @@ int term_prepare_device(tq_segment *s, uint64_t postings_off, uint32_t postings_
 int build_dense_device(tq_segment *s, uint32_t handle);
 int register_term(tq_segment *s, const TqdTerm &dt, const TermHost &th, uint64_t postings_off,
                   tq_term_handle *out);
+int add_to_doc_signatures(tq_segment *s, uint32_t handle);
 
 // Orders work about to be enqueued on `st` after the segment's previous batch, whatever stream
 // that batch ran on (no-op when it is the same stream: stream order already holds).
@@ -248,6 +252,44 @@ int wait_segment_idle(tq_segment *s) {
     HIP_TRY(hipEventSynchronize(s->ev_batch_done));
     s->batch_in_flight = false;
   }
+  return TQ_OK;
+}
+
+// Lists WITHOUT a column in the doc matrix (the sparse, high-weight lists; dense lists beyond the
+// 56 columns) share one more 64-bit word per doc: every such list sets bit hash(handle) of the docs
+// it holds.  A clear bit proves "not in the list"; a set bit means "maybe" (another list with the
+// same bit, or this one).  The union kernels test it where they used to assume the list holds
+// every candidate — a rare list holds a fraction of a percent of them, and each wrong guess cost a
+// seek and a block search.  Only prepared (queried) lists set bits; derived data like the doc
+// matrix, within the same memory budget (8 B per doc), built by one decode of the list.
+int add_to_doc_signatures(tq_segment *s, uint32_t handle) {
+  if (!s->opt.docsig || !s->opt.docmat || !s->opt.dense || s->max_doc < 4096u) return TQ_OK;
+  if ((s->h_dterms[handle].has_freq >> 8) & 0xFFu) return TQ_OK;  // the list has a column
+  TermHost &t = s->terms[handle];
+  if (t.doc_freq == 0) return TQ_OK;
+  const size_t sig_bytes = (size_t)s->max_doc * sizeof(uint64_t);
+  if (!s->d_docsig) {
+    if (s->dense_bytes_total + sig_bytes > s->dense_budget()) return TQ_OK;
+    HIP_TRY(hipMalloc((void **)&s->d_docsig, sig_bytes + PAD));
+    HIP_TRY(hipMemsetAsync(s->d_docsig, 0, sig_bytes + PAD, s->stream));
+    s->dense_bytes_total += sig_bytes;
+    s->bytes_docsig = sig_bytes;
+    s->dseg.docsig = s->d_docsig;
+  }
+  int rc = sync_terms(s, s->stream);
+  if (rc != TQ_OK) return rc;
+  const size_t bytes = (size_t)t.doc_freq * sizeof(uint32_t);
+  rc = s->d_misc.ensure(2 * bytes + 64);
+  if (rc != TQ_OK) return rc;
+  uint32_t *dd = (uint32_t *)s->d_misc.p, *dt = dd + t.doc_freq;
+  hipError_t e = tqk_launch_decode_list(s->dseg, s->d_terms, handle, t.n_blocks, dd, dt,
+                                        s->opt.use_dpp != 0, s->stream);
+  if (e != hipSuccess) return fail(TQ_ERR_HIP, "decode launch: %s", hipGetErrorString(e));
+  const uint32_t bit = (handle * 0x9E3779B1u) >> 26;
+  e = tqk_launch_docsig_set(s->d_docsig, dd, t.doc_freq, bit, s->max_doc, s->stream);
+  if (e != hipSuccess) return fail(TQ_ERR_HIP, "docsig set: %s", hipGetErrorString(e));
+  s->h_dterms[handle].has_freq |= (bit + 1u) << 16;
+  s->d_terms_dirty = true;
   return TQ_OK;
 }
 
@@ -501,6 +543,7 @@ void tq_segment_free(tq_segment *s) {
   if (s->d_fn) (void)hipFree(s->d_fn);
   if (s->d_alive) (void)hipFree(s->d_alive);
   if (s->d_docmat) (void)hipFree(s->d_docmat);
+  if (s->d_docsig) (void)hipFree(s->d_docsig);
   if (s->d_tp_info) (void)hipFree(s->d_tp_info);
   if (s->d_match_counter) (void)hipFree(s->d_match_counter);
   s->d_stage.release();
@@ -796,9 +839,10 @@ int register_term(tq_segment *s, const TqdTerm &dt, const TermHost &th, uint64_t
       (uint64_t)th.doc_freq * (uint64_t)s->opt.dense_ratio >= s->max_doc &&
       s->dense_bytes_total + dense_bytes <= budget) {
     s->dense_bytes_total += dense_bytes;
-    return s->device_prepare() ? build_dense_device(s, handle) : build_dense(s, handle);
+    const int rc = s->device_prepare() ? build_dense_device(s, handle) : build_dense(s, handle);
+    if (rc != TQ_OK) return rc;
   }
-  return TQ_OK;
+  return add_to_doc_signatures(s, handle);
 }
 
 // tq_term_prepare without a host copy of the index: two small kernels walk the list's skip data
@@ -1068,9 +1112,9 @@ struct alignas(128) PlanSlab {  // chunk tables of one slab of queries (build_gr
   size_t q0 = 0, q1 = 0;
   std::vector<uint32_t> starts, slice, query;
 };
-struct ShareKey {  // one (query, list) pair of the shared-union group, sorted by term
-  uint64_t key;    // blocks of the term (rare terms first) << 40 | cache << 32 | term handle
-  uint32_t q, i;
+struct ShareKey {  // one (query, list) pair of the shared-union group
+  uint64_t key;    // list position i << 56 | blocks of the term (rare terms first) << 32 | cache
+  uint32_t term, q;
 };
 struct PlanScratch {
   Group groups[6];
@@ -1079,6 +1123,7 @@ struct PlanScratch {
   std::vector<TqdLead> leads;
   std::vector<uint4> tasks;
   std::vector<uint32_t> share_pairs;  // per query: (task, lead) pairs = result-list appends at most
+  uint32_t share_phase_first[TQD_US_MAX_TERMS + 1];  // tasks of list position i: [first[i], first[i+1])
   std::vector<uint32_t> lead_cost, sort_start;
   std::vector<PlanSlab> slabs;
   std::vector<std::pair<uint64_t, uint32_t>> keyed;
@@ -1464,23 +1509,27 @@ int build_group_chunks(Group &g, bool or_windows, PlanScratch &ps) {
 // blocks of its term.  Rare (high-weight) terms come first in the task order: their matches raise
 // the thresholds that let the tasks of the dense terms end at their first look at them.
 int build_share_plan(tq_segment *s, Group &g, PlanScratch &ps) {
-  static const uint32_t kTaskCost = std::max<uint32_t>(64u, tune_u32("TQ_US_TASK_COST", 4096));
-  static const uint32_t kTaskBlocksMax = std::max<uint32_t>(TQD_US_TILE, tune_u32("TQ_US_TASK_BLOCKS", 512));
+  static const uint32_t kTaskCost = std::max<uint32_t>(64u, tune_u32("TQ_US_TASK_COST", 2048));
+  static const uint32_t kTaskBlocksMax = std::max<uint32_t>(1u, tune_u32("TQ_US_TASK_BLOCKS", 64));
+  static const uint32_t kGroupMax = std::min<uint32_t>(TQD_US_GROUP, std::max<uint32_t>(1u, tune_u32("TQ_US_GROUP", TQD_US_GROUP)));
   const size_t nq = g.queries.size();
   g.kpl = kpl_for(g.max_k);
+  // Leads by list position first: position 0 is every query's highest-weight list, and its docs
+  // settle the query's threshold — all tasks of position i are launched (and done) before those of
+  // position i + 1 (one launch per position).  Inside a position: by term, rare terms first.
   std::vector<ShareKey> &keys = ps.share_keys;
   keys.clear();
   for (size_t q = 0; q < nq; ++q) {
     const TqdQuery &dq = g.queries[q];
     for (uint32_t i = 0; i < dq.n_terms; ++i) {
       const uint64_t nb = std::min<uint64_t>(0xFFFFFFu, s->terms[dq.term[i]].n_blocks);
-      keys.push_back({(nb << 40) | ((uint64_t)(dq.cache_idx & 0xFFu) << 32) | dq.term[i], (uint32_t)q, i});
+      keys.push_back({((uint64_t)i << 56) | (nb << 32) | (uint64_t)(dq.cache_idx & 0xFFu), dq.term[i], (uint32_t)q});
     }
   }
   std::sort(keys.begin(), keys.end(), [](const ShareKey &a, const ShareKey &b) {
     if (a.key != b.key) return a.key < b.key;
-    if (a.q != b.q) return a.q < b.q;
-    return a.i < b.i;
+    if (a.term != b.term) return a.term < b.term;
+    return a.q < b.q;
   });
   std::vector<TqdLead> &leads = ps.leads;
   std::vector<uint4> &tasks = ps.tasks;
@@ -1494,24 +1543,31 @@ int build_share_plan(tq_segment *s, Group &g, PlanScratch &ps) {
   };
   for (size_t at = 0; at < keys.size(); ++at) {
     const ShareKey &k = keys[at];
+    const uint32_t li = (uint32_t)(k.key >> 56);
     const TqdQuery &dq = g.queries[k.q];
     TqdLead ld{};
     ld.query = k.q;
-    ld.w = dq.weight[k.i];
-    uint32_t ncols = 0, nocol = 0;
+    ld.w = dq.weight[li];
+    uint32_t ncols = 0, nocol = 0, nopc = 0, uses_sig = 0;
     float suffix = 0.0f, sparse_after = 0.0f;
-    for (uint32_t m = dq.n_terms; m-- > k.i;) suffix += dq.weight[m];
+    for (uint32_t m = dq.n_terms; m-- > li;) suffix += dq.weight[m];
     for (uint32_t m = 0; m < dq.n_terms; ++m) {
       const uint32_t col = column_of(dq.term[m]);
+      // lists without a column: their signature bit (docsig), if the segment keeps signatures
+      const uint32_t sig1 = (!col && s->d_docsig) ? (s->h_dterms[dq.term[m]].has_freq >> 16) & 0xFFu : 0u;
+      ld.sig[m] = (uint8_t)sig1;
       if (!col) nocol |= 1u << m;
-      if (m < k.i) {
+      if (!col && !sig1) nopc |= 1u << m;
+      if (sig1 && m != li) uses_sig = 1;
+      if (m < li) {
         if (col) ld.before_mask |= 1ull << col;
-      } else if (m > k.i) {
-        if (col) {
+      } else if (m > li) {
+        const uint32_t bitpos = col ? col : (sig1 ? 64u + (sig1 - 1u) : 0u);
+        if (bitpos) {
           if (ncols < 4u)
-            ld.cols_lo |= col << (8u * ncols);
+            ld.cols_lo |= bitpos << (8u * ncols);
           else
-            ld.cols_hi |= col << (8u * (ncols - 4u));
+            ld.cols_hi |= bitpos << (8u * (ncols - 4u));
           ld.aw[ncols] = dq.weight[m];
           ++ncols;
         } else {
@@ -1521,21 +1577,40 @@ int build_share_plan(tq_segment *s, Group &g, PlanScratch &ps) {
     }
     ld.suffix = suffix;
     ld.sparse_after = sparse_after;
-    ld.info = k.i | (ncols << 4) | (dq.n_terms << 8) | (nocol << 16);
+    ld.info = li | (ncols << 4) | (dq.n_terms << 8) | (uses_sig << 12) | (nocol << 16) | (nopc << 24);
     leads[at] = ld;
   }
-  // runs of one (term, cache): groups of leads x runs of blocks
+  // cost of every position's tasks together (a block costs its decode + one test per lead): a
+  // position with little work is cut into smaller tasks, so that it still fills the chip and its
+  // launch does not end on a few long tasks
+  static const uint32_t kPhaseTasks = std::max<uint32_t>(1u, tune_u32("TQ_US_PHASE_TASKS", 8192));
+  uint64_t phase_cost[TQD_US_MAX_TERMS] = {};
   for (size_t r0 = 0; r0 < keys.size();) {
     size_t r1 = r0;
-    while (r1 < keys.size() && keys[r1].key == keys[r0].key) ++r1;
-    const uint32_t term = (uint32_t)keys[r0].key, cache = (uint32_t)(keys[r0].key >> 32) & 0xFFu;
+    while (r1 < keys.size() && keys[r1].key == keys[r0].key && keys[r1].term == keys[r0].term) ++r1;
+    const uint32_t n_run = (uint32_t)(r1 - r0);
+    const uint32_t n_groups = (n_run + kGroupMax - 1) / kGroupMax;
+    phase_cost[keys[r0].key >> 56] += (uint64_t)s->terms[keys[r0].term].n_blocks * (4u * n_groups + n_run);
+    r0 = r1;
+  }
+  // runs of one (position, term, cache): groups of leads x runs of blocks
+  for (uint32_t i = 0; i <= TQD_US_MAX_TERMS; ++i) ps.share_phase_first[i] = 0;
+  uint32_t phase = 0;
+  for (size_t r0 = 0; r0 < keys.size();) {
+    size_t r1 = r0;
+    while (r1 < keys.size() && keys[r1].key == keys[r0].key && keys[r1].term == keys[r0].term) ++r1;
+    const uint32_t li = (uint32_t)(keys[r0].key >> 56);
+    const uint32_t task_cost = (uint32_t)std::min<uint64_t>(kTaskCost, std::max<uint64_t>(36u, phase_cost[li] / kPhaseTasks));
+    while (phase < li) ps.share_phase_first[++phase] = (uint32_t)tasks.size();
+    const uint32_t term = keys[r0].term, cache = (uint32_t)keys[r0].key & 0xFFu;
     const uint32_t n_blocks = s->terms[term].n_blocks;
     const uint32_t n_run = (uint32_t)(r1 - r0);
-    const uint32_t n_groups = (n_run + TQD_US_GROUP - 1) / TQD_US_GROUP;
-    // blocks per task: about equal cost (a block costs its decode + one test per lead)
+    const uint32_t n_groups = (n_run + kGroupMax - 1) / kGroupMax;
     const uint32_t per_group = (n_run + n_groups - 1) / n_groups;
-    uint32_t bpt = kTaskCost / (4u + per_group);
-    bpt = std::min<uint32_t>(kTaskBlocksMax, std::max<uint32_t>(TQD_US_TILE, bpt / TQD_US_TILE * TQD_US_TILE));
+    // blocks per task: about equal cost (a block costs its decode + one test per lead); small
+    // tasks keep the share of the batch that is in flight before thresholds exist small
+    uint32_t bpt = task_cost / (4u + per_group);
+    bpt = std::min<uint32_t>(kTaskBlocksMax, std::max<uint32_t>(1u, bpt));
     for (uint32_t j0 = 0; j0 < n_blocks; j0 += bpt) {
       const uint32_t nb = std::min<uint32_t>(bpt, n_blocks - j0);
       for (uint32_t gr = 0; gr < n_groups; ++gr) {
@@ -1548,6 +1623,7 @@ int build_share_plan(tq_segment *s, Group &g, PlanScratch &ps) {
     for (size_t a = r0; a < r1; ++a) pairs[keys[a].q] += n_runs;
     r0 = r1;
   }
+  while (phase < TQD_US_MAX_TERMS) ps.share_phase_first[++phase] = (uint32_t)tasks.size();
   if (tasks.size() > 0x7FFFFFFFull) return fail(TQ_ERR_UNSUPPORTED, "batch too large (tasks)");
   // result lists: every (task, lead) pair appends at most k entries
   uint64_t entries = 0;
@@ -2109,7 +2185,7 @@ int search_batch_impl(tq_segment *s, const tq_query *queries, uint32_t n_queries
   uint32_t share_grid = 0;
   const size_t n_share = groups[kShare].queries.size();
   if (n_share) {
-    static const uint32_t kGridMul = std::max<uint32_t>(1u, tune_u32("TQ_US_GRID_MUL", 20));
+    static const uint32_t kGridMul = std::max<uint32_t>(1u, tune_u32("TQ_US_GRID_MUL", 16));
     int cus = 256;
     (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, s->device);
     share_grid = (uint32_t)std::min<uint64_t>(groups[kShare].n_chunks, (uint64_t)std::max(1, cus) * kGridMul);
@@ -2156,19 +2232,30 @@ int search_batch_impl(tq_segment *s, const tq_query *queries, uint32_t n_queries
       sp.thr_slots = (uint32_t *)s->d_thr.p;
       sp.thr_val = (uint32_t *)s->d_share_words.p;
       sp.list_count = sp.thr_val + n_share;
-      sp.task_counter = sp.thr_val + 2 * n_share;
+      uint32_t *const counters = sp.thr_val + 2 * n_share;  // one task counter per launch
       sp.stage = (uint64_t *)s->d_share_stage.p;
       sp.lists = (uint64_t *)((uint8_t *)s->d_partials.p + part_off_bytes[gi]);
-      sp.n_tasks = g.n_chunks;
       sp.n_queries = (uint32_t)n_share;
-      sp.grid = share_grid;
       static const uint32_t kDebugS = tune_u32("TQ_DEBUG", 0);
       sp.debug = kDebugS;
       sp.bound_slack = co.bound_slack;
       tiles_total += g.total_tiles;
       chunks_total += g.n_chunks;
-      const hipError_t e = tqk_launch_share(sp, g.kpl, gst);
-      if (e != hipSuccess) return fail(TQ_ERR_HIP, "shared-union launch: %s", hipGetErrorString(e));
+      // one launch per list position (stream order = the barrier between positions)
+      static const uint32_t kPhases = tune_u32("TQ_US_PHASES", 0);
+      for (uint32_t ph = 0; ph < TQD_US_MAX_TERMS; ++ph) {
+        sp.task_begin = s->plan->share_phase_first[ph];
+        sp.n_tasks = s->plan->share_phase_first[ph + 1];
+        if (!kPhases) {  // (experiments) one launch, tasks still in position order
+          if (ph) break;
+          sp.n_tasks = g.n_chunks;
+        }
+        if (sp.n_tasks <= sp.task_begin) continue;
+        sp.task_counter = counters + ph;
+        sp.grid = std::min<uint32_t>(share_grid, sp.n_tasks - sp.task_begin);
+        const hipError_t e = tqk_launch_share(sp, g.kpl, gst);
+        if (e != hipSuccess) return fail(TQ_ERR_HIP, "shared-union launch: %s", hipGetErrorString(e));
+      }
       continue;
     }
     TqkScanParams p{};
@@ -2462,7 +2549,7 @@ int tq_segment_get_stats(tq_segment *s, tq_segment_stats *out) {
   r.alive_bytes = s->bytes_alive;
   r.term_table_bytes = s->bytes_term_tables + s->d_terms_cap * sizeof(TqdTerm);
   r.bitmap_bytes = s->bytes_bitmaps;
-  r.docmat_bytes = s->bytes_docmat;
+  r.docmat_bytes = s->bytes_docmat + s->bytes_docsig;
   r.posdir_bytes = s->bytes_posdir;
   r.scratch_bytes = s->d_stage.cap + s->d_stage_alt.cap + s->d_partials.cap + s->d_out_scores.cap +
                     s->d_out_docs.cap + s->d_out_counts.cap + s->d_misc.cap + s->d_thr.cap +
@@ -2497,6 +2584,8 @@ int tq_set_option(tq_segment *s, const char *name, int64_t value) {
     s->opt.dense = value != 0;
   else if (!strcmp(name, "docmat"))  // affects terms prepared afterwards
     s->opt.docmat = value != 0;
+  else if (!strcmp(name, "docsig"))  // affects terms prepared afterwards
+    s->opt.docsig = value != 0;
   else if (!strcmp(name, "device_prepare"))  // affects terms prepared afterwards
     s->opt.device_prepare = value != 0;
   else

@@ -35,7 +35,8 @@ struct TqdTermHead {  // what every kernel needs: fetched with scalar loads
   const uint32_t *tail_tfs;   // n_tail
   uint64_t payload_base;      // absolute offset (inside the .idx sub-file) of block 0's payload
   uint32_t n_blocks, n_tail;
-  uint32_t has_freq;          // bit 0: 0 => every tf reads as 1; bits 8..15: doc-matrix slot + 1 (0 = none)
+  uint32_t has_freq;          // bit 0: 0 => every tf reads as 1; bits 8..15: doc-matrix slot + 1 (0 = none);
+                              // bits 16..23: signature bit + 1 of a list without a column (0 = none)
   uint32_t coarse_shift;
 };
 struct TqdTerm : TqdTermHead {
@@ -86,18 +87,21 @@ struct TqdQuery {
 #define TQD_US_GROUP 32      // leads per group (one lane each at task setup)
 #define TQD_US_MAX_TERMS 8   // unions with more terms keep the per-query kernel
 #define TQD_US_TILE 64       // blocks per pre-filter step (one lane each)
-struct TqdLead {             // 64 bytes, written by the host planner
+struct TqdLead {             // 72 bytes, written by the host planner
   uint32_t query;            // launch-group query index
-  uint32_t info;             // i (bits 0-3) | lists after i with a doc-matrix column (4-7) | n_terms
-                             // (8-11) | bit 16+m: list m of the query has NO column
+  uint32_t info;             // i (bits 0-3) | lists after i with a membership bit (4-7) | n_terms
+                             // (8-11) | bit 12: some list uses the signature word | bit 16+m: list m
+                             // has NO doc-matrix column | bit 24+m: ... and no signature bit either
   float w;                   // weight of the leading term in this query
   float suffix;              // weights of lists i.. : the most a doc first seen in list i can score
-  float sparse_after;        // weights of the lists after i without a column
-  uint32_t cols_lo, cols_hi; // doc-matrix bit positions (8 + slot) of the after-column lists 0-3 / 4-6
+  float sparse_after;        // weights of the lists after i with neither column nor signature bit
+  uint32_t cols_lo, cols_hi; // membership bits of the after-lists that have one, in list order (0-3 / 4-6):
+                             // 8 + slot = doc-matrix column (exact), 64 + b = signature bit b (maybe)
   float aw[7];               // their weights, in list order
   uint64_t before_mask;      // doc-matrix bits of the lists before i that have a column
+  uint8_t sig[8];            // per list of the query: signature bit + 1 (0 = none)
 };
-static_assert(sizeof(TqdLead) == 64, "TqdLead is uploaded as raw bytes");
+static_assert(sizeof(TqdLead) == 72, "TqdLead is uploaded as raw bytes");
 
 #define TQD_ROLE_SHOULD 0u
 #define TQD_ROLE_MUST 1u
@@ -116,6 +120,10 @@ struct TqdSegment {
   // membership in every dense list of the query — the scan kernels are bound by the number of
   // divergent gathers, not by bytes.  Derived data, built at tq_term_prepare like the bitmaps.
   const uint64_t *docmat;
+  // signature word of the lists WITHOUT a column (or null): docsig[d] bit b set iff d is in some
+  // prepared column-less list whose signature bit is b (TqdTermHead::has_freq bits 16..23 = b + 1).
+  // Clear bit = not in the list; set bit = maybe.
+  const uint64_t *docsig;
   uint32_t max_doc;
   uint32_t const_fieldnorm_id;
   uint32_t min_fieldnorm_id;  // smallest fieldnorm id present (lower bound of every doc's norm)

@@ -56,7 +56,7 @@ struct TqkShareParams {
   uint64_t *stage;              // [grid][TQD_US_GROUP][capl] per-wave staging lists
   uint64_t *lists;              // per-query result lists (query q: entries part_start .. + n_parts)
   uint32_t *list_count;         // [n_queries] entries written so far
-  uint32_t n_tasks;
+  uint32_t task_begin, n_tasks; // this launch hands out tasks [task_begin, n_tasks)
   uint32_t n_queries;
   uint32_t grid;
   uint32_t debug;
@@ -105,6 +105,9 @@ hipError_t tqk_launch_merge_segments(const TqkSegMergeParams &p, hipStream_t st)
 hipError_t tqk_launch_docmat_init(uint64_t *mat, const uint8_t *fieldnorm, uint32_t const_id,
                                   uint32_t max_doc, hipStream_t st);
 hipError_t tqk_launch_docmat_set(uint64_t *mat, const uint32_t *docs, uint32_t n, uint32_t slot,
+                                 uint32_t max_doc, hipStream_t st);
+// doc signatures (TqdSegment::docsig): set bit `bit` of the list's docs
+hipError_t tqk_launch_docsig_set(uint64_t *sig, const uint32_t *docs, uint32_t n, uint32_t bit,
                                  uint32_t max_doc, hipStream_t st);
 
 // ---- shared with tq_encode.hip: the C ABI's error slot and context checks live in tq_api.cpp

@@ -161,9 +161,22 @@ __global__ void docmat_set_kernel(uint64_t *mat, const uint32_t *docs, uint32_t 
     atomicOr((unsigned long long *)(mat + docs[i]), 1ull << (8u + slot));
 }
 
+__global__ void docsig_set_kernel(uint64_t *sig, const uint32_t *docs, uint32_t n, uint32_t bit,
+                                  uint32_t max_doc) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n && docs[i] < max_doc) atomicOr((unsigned long long *)(sig + docs[i]), 1ull << bit);
+}
+
 }  // namespace
 
 // =================================================================== launch wrappers
+hipError_t tqk_launch_docsig_set(uint64_t *sig, const uint32_t *docs, uint32_t n, uint32_t bit,
+                                 uint32_t max_doc, hipStream_t st) {
+  if (n == 0) return hipSuccess;
+  hipLaunchKernelGGL(docsig_set_kernel, dim3((n + 255) / 256), dim3(256), 0, st, sig, docs, n, bit,
+                     max_doc);
+  return hipGetLastError();
+}
 hipError_t tqk_launch_docmat_init(uint64_t *mat, const uint8_t *fieldnorm, uint32_t const_id,
                                   uint32_t max_doc, hipStream_t st) {
   if (max_doc == 0) return hipSuccess;

@@ -36,8 +36,11 @@
 // k distinct real matches, so pruning stays exact: the top-k equals the exhaustive run's bits.
 #include "tq_common.hpp"
 
+#ifndef TQ_US_TIMERS
+#define TQ_US_TIMERS 0  // region timers (tools/probe_ushare.sh builds a variant with them)
+#endif
 #ifndef TQ_US_WAVES
-#define TQ_US_WAVES 5
+#define TQ_US_WAVES 4
 #endif
 
 namespace {
@@ -48,6 +51,15 @@ struct ShareLds {  // per wavefront
   uint32_t pay[516];  // staged payload of the leader block / four 512-byte regions of the block search
   float cache[256];   // Bm25Weight.cache of the task's queries
   uint32_t q_doc[127], q_tf[127], q_tag[127];  // survivors: doc, leader tf, g | fieldnorm id << 8 | column bits << 16
+  // The leads of the task, one per slot: kept in LDS, not in lane g's registers — stage C needs
+  // its registers for four lists' worth of loads in flight, and 20 live lead registers across it
+  // ended in scratch (3 spill reloads per (block, lead) pair: 7000 cycles each, measured)
+  TqdLead lead[US_GROUP];
+  uint32_t lthr[US_GROUP];     // the lead's threshold (sortable score bits); only ever rises
+  uint32_t lk[US_GROUP];       // k of its query
+  uint32_t lrow[US_GROUP];     // its query's row of threshold slots
+  uint32_t lh[US_GROUP][8];    // term handles / weights of the lead slots' queries (all lists)
+  float lw[US_GROUP][8];
   uint32_t cnt[US_GROUP];      // entries in the lead slots' staging lists
   uint32_t scored[US_GROUP];   // docs scored per lead slot (Count / statistics)
 };
@@ -219,9 +231,20 @@ ushare_kernel(TqkShareParams p) {
   uint32_t n_scored = 0;  // docs scored by this wave (all tasks)
 
   // ---- state of the current task (lane g < n_leads <-> lead g)
-  TqdLead mine{};
-  uint32_t thr_mine = 0xFFFFFFFFu, k_mine = 1, thr_row_mine = 0;
   uint32_t n_leads = 0;
+  // PROFILING (TQ_DEBUG bits 16..19 = region): wave cycles spent inside ONE region per run, summed
+  // into the match counter.  1 everything, 2 task fetch + setup, 3 pre-filter, 4 stage A (decode +
+  // doc-matrix gather), 5 stage F, 6 stage C, 7 stage C: lists after the leader, 8 stage C: ownership
+  // probes, 9 stage C: collector (slots, select, staging), 10 staging cuts, 11 flush
+  const uint32_t tphase = TQ_US_TIMERS ? (p.debug >> 16) & 15u : 0u;
+  uint64_t tacc = 0, tlast = 0;
+  auto tb = [&](uint32_t ph) __attribute__((always_inline)) {
+    if (TQ_US_TIMERS && tphase == ph) tlast = __builtin_readcyclecounter();
+  };
+  auto te = [&](uint32_t ph) __attribute__((always_inline)) {
+    if (TQ_US_TIMERS && tphase == ph) tacc += __builtin_readcyclecounter() - tlast;
+  };
+  tb(1u);
 
   // a staging list is cut back to its k best; returns the k-th key (the list held n > k entries)
   auto compact_slot = [&](uint32_t g, uint32_t n, uint32_t k) __attribute__((always_inline)) -> uint64_t {
@@ -248,8 +271,12 @@ ushare_kernel(TqkShareParams p) {
 
   // ---- stage C: 64 survivors, every lane with its own query
   auto stageC = [&](uint32_t n) __attribute__((always_inline)) {
+    te(5u);
+    tb(6u);
+    tb(7u);
     const uint32_t base = qn - n;
     qn = base;
+    if (p.debug & 64u) n_scored += n;  // COUNTERS
     bool alive = (uint32_t)lane < n;
     uint32_t doc = 0, tf = 0, tag = 0;
     if (alive) {
@@ -258,101 +285,180 @@ ushare_kernel(TqkShareParams p) {
       tag = L.q_tag[base + lane];
     }
     const uint32_t g = tag & 31u;
-    const float norm = L.cache[(tag >> 8) & 0xFFu];
-    const uint32_t bits = tag >> 16;
+    // fieldnorm id + membership in the dense lists: the doc-matrix word again (a gather for the
+    // survivors only; stage F does not carry it through the queue)
+    const uint64_t mw = alive ? seg.docmat[doc] : 0ull;
+    const uint64_t sg = (alive && seg.docsig) ? seg.docsig[doc] : 0ull;
+    const float norm = L.cache[(uint32_t)mw & 0xFFu];
+    uint32_t bits = 0;
+    {
+      const uint32_t cl = L.lead[g].cols_lo, ch = L.lead[g].cols_hi;
+#pragma unroll
+      for (uint32_t c = 0; c < 7u; ++c) {
+        const uint32_t col = ((c < 4u ? cl >> (8u * c) : ch >> (8u * (c - 4u)))) & 0xFFu;
+        const uint64_t src = col >= 64u ? sg : mw;
+        bits |= (col ? (uint32_t)(src >> (col & 63u)) & 1u : 0u) << c;
+      }
+    }
     // the lead's constants from lane g's registers
-    const uint32_t q = (uint32_t)__shfl((int)mine.query, (int)g, WAVE);
-    const uint32_t info = (uint32_t)__shfl((int)mine.info, (int)g, WAVE);
-    const float w_lead = __shfl(mine.w, (int)g, WAVE);
-    const float suffix = __shfl(mine.suffix, (int)g, WAVE);
-    const uint32_t thr = (uint32_t)__shfl((int)thr_mine, (int)g, WAVE);
-    const uint32_t k = (uint32_t)__shfl((int)k_mine, (int)g, WAVE);
-    const uint32_t thr_row = (uint32_t)__shfl((int)thr_row_mine, (int)g, WAVE);
-    const uint32_t li = info & 15u, nt = (info >> 8) & 15u, nocol = info >> 16;
-    const TqdQuery *Q = p.queries + q;
+    const uint32_t q = L.lead[g].query;
+    const uint32_t info = L.lead[g].info;
+    const float w_lead = L.lead[g].w;
+    const float suffix = L.lead[g].suffix;
+    const uint32_t thr = L.lthr[g];
+    const uint32_t k = L.lk[g];
+    const uint32_t thr_row = L.lrow[g];
+    const uint32_t li = info & 15u, nt = (info >> 8) & 15u, nocol = (info >> 16) & 0xFFu, nopc = info >> 24;
     const float slack_abs = suffix * 4.0e-6f;
     float s = bm25(w_lead, norm, tf);
     float rest = suffix - w_lead;  // what the lists after the current one can still add
     uint32_t c = 0;                // column counter of the lists after the leader
     uint32_t max_after = 0, max_before = 0;
     {
-      uint32_t a = alive ? nt - 1u - li : 0u, b = alive ? li : 0u;
-      for (int o = 32; o; o >>= 1) {
-        const uint32_t a2 = (uint32_t)__shfl_xor((int)a, o, WAVE), b2 = (uint32_t)__shfl_xor((int)b, o, WAVE);
-        a = a2 > a ? a2 : a;
-        b = b2 > b ? b2 : b;
+      const uint32_t na = alive ? nt - 1u - li : 0u, nbf = alive ? li : 0u;
+#pragma unroll
+      for (uint32_t x = 1; x < TQD_US_MAX_TERMS; ++x) {  // (independent ballots, no shuffle chain)
+        if (__ballot(na >= x)) max_after = x;
+        if (__ballot(nbf >= x)) max_before = x;
       }
-      max_after = uni(a);
-      max_before = uni(b);
     }
-    // lists after the leader, ascending: they add to the score
-    for (uint32_t a = 1; a <= max_after; ++a) {
-      const uint32_t m = li + a;
-      const bool on = alive && m < nt;
-      if (!__ballot(on)) break;
-      float w = 0.0f;
-      uint32_t h = 0;
-      if (on) {
-        w = Q->weight[m];
-        h = Q->term[m];
+    // Lists after the leader, ascending: they add to the score.  Four lists at a time, and every
+    // level of the chain (term table -> bitmap word -> block record -> tf bits) is issued for all
+    // four before the next one is awaited: a candidate costs four dependent round trips per group
+    // of lists, not four per list.  The adds then run in list order.
+    for (uint32_t a0 = 1; a0 <= max_after; a0 += 4u) {
+      bool on[4], probe_sparse[4], found[4];
+      float w[4];
+      uint32_t h[4], tfv[4], pi[4];
+      const uint2 *dptr[4];
+      const uint4 *rptr[4];
+      const uint32_t *ttf[4];
+      uint64_t pbase[4];
+      uint32_t hfreq[4];
+#pragma unroll
+      for (uint32_t u = 0; u < 4u; ++u) {
+        const uint32_t m = li + a0 + u;
+        on[u] = alive && m < nt;
+        w[u] = 0.0f;
+        h[u] = 0;
+        if (on[u]) {
+          w[u] = L.lw[g][m & 7u];
+          h[u] = L.lh[g][m & 7u];
+        }
+        // a list with a membership bit: exact (doc-matrix column) or "maybe" (signature bit)
+        const bool has_bit = on[u] && !((nopc >> m) & 1u);
+        const bool exact = on[u] && !((nocol >> m) & 1u);
+        bool set = false;
+        if (has_bit) {
+          set = (bits >> c) & 1u;
+          ++c;
+        }
+        // no column: bitmap or seek (decided by the term table) unless the signature says "not in it"
+        probe_sparse[u] = on[u] && !exact && (set || !has_bit);
+        found[u] = exact && set;  // (column lists: membership is known already)
+        tfv[u] = 0;
+        pi[u] = 0;
       }
-      const bool has_col = on && !((nocol >> m) & 1u);
-      bool member = false;
-      if (has_col) {
-        member = (bits >> c) & 1u;
-        ++c;
-      }
-      bool probe = on && !has_col;  // no column: the exact probe, only while the doc can still make it
-      if (probe) {
-        const float r0 = rest > 0.0f ? rest : 0.0f;
-        if (!(sortable((s + r0) * 1.000002f + slack_abs) >= thr)) {
-          alive = false;
-          probe = false;
+      // level 1: the lists' tables
+#pragma unroll
+      for (uint32_t u = 0; u < 4u; ++u) {
+        dptr[u] = nullptr;
+        rptr[u] = nullptr;
+        ttf[u] = nullptr;
+        pbase[u] = 0;
+        hfreq[u] = 0;
+        if (found[u] || probe_sparse[u]) {
+          const TqdTermHead *th = p.terms + h[u];
+          dptr[u] = th->dense;
+          rptr[u] = th->rec;
+          ttf[u] = th->tail_tfs;
+          pbase[u] = th->payload_base;
+          hfreq[u] = th->has_freq & 1u;
         }
       }
-      if (__ballot(member || probe)) {
-        TermRef tr{};
-        if (member || probe) tr = load_term_lane(p.terms, h);
-        uint32_t jb = 0, at = NOT_FOUND;
-        bool found = false;
-        const bool bitmap = (member || probe) && tr.dense != nullptr;
-        if (bitmap) {
-          const uint2 wd = tr.dense[doc >> 5];
-          const uint32_t bit = doc & 31u;
-          found = (wd.x >> bit) & 1u;
-          const uint32_t pi = wd.y + (uint32_t)__popc(wd.x & ((1u << bit) - 1u));
-          jb = pi >> 7;
-          at = pi & 127u;
+      // level 2: bitmap word + rank (membership of the column-less lists that have a bitmap)
+      uint2 wd[4];
+#pragma unroll
+      for (uint32_t u = 0; u < 4u; ++u) {
+        wd[u] = make_uint2(0u, 0u);
+        if ((found[u] || probe_sparse[u]) && dptr[u]) wd[u] = dptr[u][doc >> 5];
+      }
+#pragma unroll
+      for (uint32_t u = 0; u < 4u; ++u) {
+        const uint32_t bit = doc & 31u;
+        if (probe_sparse[u] && dptr[u]) {
+          found[u] = (wd[u].x >> bit) & 1u;
+          probe_sparse[u] = false;
         }
-        bool cand = probe && !bitmap;
-        if (__ballot(cand)) {
+        pi[u] = wd[u].y + (uint32_t)__popc(wd[u].x & ((1u << bit) - 1u));
+      }
+      // level 3: block records; level 4: tf bits
+      uint2 mo[4];
+#pragma unroll
+      for (uint32_t u = 0; u < 4u; ++u) {
+        mo[u] = make_uint2(0u, 0u);
+        if (found[u]) mo[u] = rec_mo(rptr[u][pi[u] >> 7]);
+      }
+#pragma unroll
+      for (uint32_t u = 0; u < 4u; ++u) {
+        if (found[u]) {
+          TermRef tr{};
+          tr.has_freq = hfreq[u];
+          tr.tail_tfs = ttf[u];
+          tr.payload_base = pbase[u];
+          tfv[u] = block_tf_at(idx, tr, mo[u], pi[u] & 127u);
+        }
+      }
+      // in list order: lists without a bitmap are searched (only while the doc can still make it),
+      // scores are added
+#pragma unroll
+      for (uint32_t u = 0; u < 4u; ++u) {
+        if (__ballot(probe_sparse[u])) {
+          bool cand = probe_sparse[u] && alive;
           if (cand) {
-            jb = seek_block(tr, doc);
-            cand = jb < tr.n_blocks;
+            const float r0 = rest > 0.0f ? rest : 0.0f;
+            if (!(sortable((s + r0) * 1.000002f + slack_abs) >= thr)) {
+              alive = false;
+              cand = false;
+            }
           }
-          const uint32_t a2 = lookup_docs_multi(idx, tr, jb, doc, cand, L.pay, lane);
-          if (cand && a2 != NOT_FOUND) {
-            found = true;
-            at = a2;
+          if (__ballot(cand)) {
+            TermRef tr{};
+            uint32_t jb = 0;
+            if (cand) {
+              tr = load_term_lane(p.terms, h[u]);
+              jb = seek_block(tr, doc);
+              cand = jb < tr.n_blocks;
+            }
+            if (p.debug & 128u) n_scored += (uint32_t)__popcll(__ballot(cand));  // COUNTERS
+            const uint32_t at = lookup_docs_multi(idx, tr, jb, doc, cand, L.pay, lane);
+            if (cand && at != NOT_FOUND) {
+              const uint4 r = tr.rec[jb];
+              tfv[u] = block_tf_at(idx, tr, make_uint2(r.y, r.z), at);
+              found[u] = true;
+            }
           }
         }
-        if (found) {
-          const uint4 r = tr.rec[jb];
-          s = s + bm25(w, norm, block_tf_at(idx, tr, make_uint2(r.y, r.z), at));
-        }
+        if (found[u] && alive) s = s + bm25(w[u], norm, tfv[u]);
+        if (on[u]) rest -= w[u];
       }
-      if (on) rest -= w;
     }
+    te(7u);
+    tb(8u);
     // lists before the leader without a column: found there = that list's tasks score the doc
     for (uint32_t m = 0; m < max_before; ++m) {
       bool probe = alive && m < li && ((nocol >> m) & 1u);
+      if (probe) {  // the signature word may already say "not in that list"
+        const uint32_t sb1 = L.lead[g].sig[m & 7u];
+        if (sb1 && !((sg >> (sb1 - 1u)) & 1u)) probe = false;
+      }
       if (probe && !(sortable(s * 1.000002f + slack_abs) >= thr)) {  // the score is final: dead either way
         alive = false;
         probe = false;
       }
       if (!__ballot(probe)) continue;
       TermRef tr{};
-      if (probe) tr = load_term_lane(p.terms, Q->term[m]);
+      if (probe) tr = load_term_lane(p.terms, L.lh[g][m & 7u]);
       const bool bitmap = probe && tr.dense != nullptr;
       bool found = false;
       if (bitmap) found = (tr.dense[doc >> 5].x >> (doc & 31u)) & 1u;
@@ -363,6 +469,7 @@ ushare_kernel(TqkShareParams p) {
           jb = seek_block(tr, doc);
           cand = jb < tr.n_blocks;
         }
+        if (p.debug & 128u) n_scored += (uint32_t)__popcll(__ballot(cand));  // COUNTERS
         const uint32_t a2 = lookup_docs_multi(idx, tr, jb, doc, cand, L.pay, lane);
         if (cand && a2 != NOT_FOUND) found = true;
       }
@@ -370,12 +477,18 @@ ushare_kernel(TqkShareParams p) {
     }
     // the score is final: below the threshold it cannot enter the top-k (equal scores stay: ties
     // resolve by doc id in the collector)
+    te(8u);
     if (alive) alive = sortable(s) >= thr;
     if (alive) alive = doc_is_alive(seg, doc);
     const uint64_t hit = __ballot(alive);
-    if (!hit) return;
-    n_scored += (uint32_t)__popcll(hit);
-    const uint64_t key = alive ? make_key(s, doc) : 0ull;
+    if (!hit) {
+      te(6u);
+      tb(5u);
+      return;
+    }
+    tb(9u);
+    if (!(p.debug & 480u)) n_scored += (uint32_t)__popcll(hit);  // COUNTERS (TQ_DEBUG): 32 (block, lead) pairs,
+    const uint64_t key = alive ? make_key(s, doc) : 0ull;        // 64 stage-C candidates, 128 block searches, 256 blocks decoded
     const uint32_t sb = (uint32_t)(key >> 32);
     bool changed = false;
     if (alive) {
@@ -408,9 +521,11 @@ ushare_kernel(TqkShareParams p) {
       }
       if (gth) {
         if (lane == 0) atomicMax(p.thr_val + qs, gth);
-        if ((uint32_t)lane < n_leads && mine.query == qs && gth > thr_mine) thr_mine = gth;
+        if ((uint32_t)lane < n_leads && L.lead[lane].query == qs && gth > L.lthr[lane]) L.lthr[lane] = gth;
       }
     }
+    te(9u);
+    tb(10u);
     // staging lists that could overflow with the next batch are cut back to their k best now
     wave_mem_fence();
     const uint32_t cn = (uint32_t)lane < US_GROUP ? L.cnt[lane] : 0u;
@@ -419,22 +534,26 @@ ushare_kernel(TqkShareParams p) {
       const uint32_t gs = (uint32_t)__builtin_ctzll(full);
       full &= full - 1ull;
       const uint32_t ns = (uint32_t)__builtin_amdgcn_readlane((int)cn, (int)gs);
-      const uint32_t ks = (uint32_t)__builtin_amdgcn_readlane((int)k_mine, (int)gs);
+      const uint32_t ks = uni(L.lk[gs]);
       const uint64_t kth = compact_slot(gs, ns, ks);
       const uint32_t t = (uint32_t)(kth >> 32);
       if ((uint32_t)lane == gs) {
         L.cnt[gs] = ks;
-        if (t > thr_mine) thr_mine = t;
-        atomicMax(p.thr_val + mine.query, t);  // k distinct docs of this query score >= t
+        if (t > L.lthr[gs]) L.lthr[gs] = t;
+        atomicMax(p.thr_val + L.lead[gs].query, t);  // k distinct docs of this query score >= t
       }
     }
     wave_mem_fence();
+    te(10u);
+    te(6u);
+    tb(5u);
   };
 
   for (;;) {
+    tb(2u);
     uint32_t task = 0;
     if (lane == 0) task = atomicAdd(p.task_counter, 1u);
-    task = uni(task);
+    task = uni(task) + p.task_begin;
     if (task >= p.n_tasks) break;
     const uint4 trec = sload(p.tasks + task);
     const uint32_t j0 = trec.y, nb_task = trec.z & 0xFFFFu, ci = trec.z >> 24, lead0 = trec.w;
@@ -448,14 +567,22 @@ ushare_kernel(TqkShareParams p) {
       cache_loaded = ci;
     }
     // ---- the group's leads, one per lane
-    thr_mine = 0xFFFFFFFFu;
-    mine.suffix = 0.0f;
+    wave_mem_fence();
     if ((uint32_t)lane < n_leads) {
-      mine = p.leads[lead0 + lane];
+      const TqdLead mine = p.leads[lead0 + lane];
+      L.lead[lane] = mine;
       const TqdQuery *Q = p.queries + mine.query;
-      k_mine = Q->k;
-      thr_row_mine = Q->thr_index;
-      thr_mine = __hip_atomic_load(p.thr_val + mine.query, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      L.lk[lane] = Q->k;
+      L.lrow[lane] = Q->thr_index;
+      // (a TqdQuery is dword-aligned only: unaligned 16-byte loads)
+      const U4Unaligned *qt = reinterpret_cast<const U4Unaligned *>(Q->term);
+      const U4Unaligned *qw = reinterpret_cast<const U4Unaligned *>(Q->weight);
+      const U4Unaligned t0 = qt[0], t1 = qt[1], w0 = qw[0], w1 = qw[1];
+      *reinterpret_cast<uint4 *>(&L.lh[lane][0]) = make_uint4(t0.x, t0.y, t0.z, t0.w);
+      *reinterpret_cast<uint4 *>(&L.lh[lane][4]) = make_uint4(t1.x, t1.y, t1.z, t1.w);
+      *reinterpret_cast<uint4 *>(&L.lw[lane][0]) = make_uint4(w0.x, w0.y, w0.z, w0.w);
+      *reinterpret_cast<uint4 *>(&L.lw[lane][4]) = make_uint4(w1.x, w1.y, w1.z, w1.w);
+      L.lthr[lane] = __hip_atomic_load(p.thr_val + mine.query, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     wave_mem_fence();
     if ((uint32_t)lane < US_GROUP) {
@@ -464,20 +591,25 @@ ushare_kernel(TqkShareParams p) {
     }
     wave_mem_fence();
     auto lead_alive = [&]() __attribute__((always_inline)) {
-      return (uint32_t)lane < n_leads && sortable(mine.suffix * 1.000001f) >= thr_mine;
+      return (uint32_t)lane < n_leads && sortable(L.lead[lane].suffix * 1.000001f) >= L.lthr[lane];
     };
     uint32_t live = (uint32_t)__ballot(lead_alive());
+    const bool task_sig = seg.docsig != nullptr &&
+                          __ballot((uint32_t)lane < n_leads && ((L.lead[lane].info >> 12) & 1u)) != 0ull;
+    te(2u);
 
     for (uint32_t jt = 0; jt < nb_task && live; jt += TQD_US_TILE) {
       // thresholds may have risen since the last step (one word per lead)
       if (jt) {
         if ((uint32_t)lane < n_leads) {
-          const uint32_t t = __hip_atomic_load(p.thr_val + mine.query, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          if (t > thr_mine) thr_mine = t;
+          const uint32_t t = __hip_atomic_load(p.thr_val + L.lead[lane].query, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if (t > L.lthr[lane]) L.lthr[lane] = t;
         }
+        wave_mem_fence();
         live = (uint32_t)__ballot(lead_alive());
         if (!live) break;
       }
+      tb(3u);
       // ---- pre-filter: lane <-> block
       const uint32_t nb = nb_task - jt < TQD_US_TILE ? nb_task - jt : TQD_US_TILE;
       const uint32_t i_base = j0 + jt;
@@ -499,20 +631,34 @@ ushare_kernel(TqkShareParams p) {
       uint32_t pass_mask = 0;  // leads that still want this block
       for (uint32_t lm = live; lm; lm &= lm - 1u) {
         const uint32_t g = (uint32_t)__builtin_ctz(lm);
-        const float w = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(mine.w), (int)g));
-        const float suf = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(mine.suffix), (int)g));
-        const uint32_t thr = (uint32_t)__builtin_amdgcn_readlane((int)thr_mine, (int)g);
+        const float w = L.lead[g].w, suf = L.lead[g].suffix;  // (uniform address: LDS broadcast)
+        const uint32_t thr = L.lthr[g];
         const float ub = w * tfn_max * p.bound_slack;
         if (in_tile && sortable((ub + (suf - w)) * 1.000004f + suf * 4.0e-6f) >= thr) pass_mask |= 1u << g;
       }
       uint64_t todo = __ballot(pass_mask != 0u);
+      te(3u);
+      uint32_t since_refresh = 0;
       while (todo) {
         const uint32_t b = (uint32_t)__builtin_ctzll(todo);
         todo &= todo - 1ull;
-        uint32_t lm = (uint32_t)__builtin_amdgcn_readlane((int)pass_mask, (int)b);
+        if (++since_refresh == 8u) {  // thresholds rise while the tile is walked: one word per lead
+          since_refresh = 0;
+          if ((uint32_t)lane < n_leads) {
+            const uint32_t t = __hip_atomic_load(p.thr_val + L.lead[lane].query, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (t > L.lthr[lane]) L.lthr[lane] = t;
+          }
+          wave_mem_fence();
+          live = (uint32_t)__ballot(lead_alive());
+          if (!live) break;
+        }
+        uint32_t lm = (uint32_t)__builtin_amdgcn_readlane((int)pass_mask, (int)b) & live;
+        if (!lm) continue;
         const uint2 mo_l = make_uint2((uint32_t)__builtin_amdgcn_readlane((int)rec_mine.y, (int)b),
                                       (uint32_t)__builtin_amdgcn_readlane((int)rec_mine.z, (int)b));
         const uint32_t prev_l = (uint32_t)__builtin_amdgcn_readlane((int)prev_mine, (int)b);
+        tb(4u);
+        if (p.debug & 256u) ++n_scored;  // COUNTERS
         // ---- stage A: decode the block once
         uint32_t c0, c1, t0, t1;
         if (mo_l.x == META_TAIL) {
@@ -541,77 +687,87 @@ ushare_kernel(TqkShareParams p) {
         // ONE gather per doc: fieldnorm id + membership in every dense list of the segment
         const uint64_t mw0 = v0 ? seg.docmat[c0] : 0ull;
         const uint64_t mw1 = v1 ? seg.docmat[c1] : 0ull;
+        uint64_t sg0 = 0, sg1 = 0;  // signature words, when a lead of the task tests them
+        if (task_sig) {
+          sg0 = v0 ? seg.docsig[c0] : 0ull;
+          sg1 = v1 ? seg.docsig[c1] : 0ull;
+        }
         const uint32_t nid0 = (uint32_t)mw0 & 0xFFu, nid1 = (uint32_t)mw1 & 0xFFu;
         const float f0 = (float)t0, f1 = (float)t1;
         const float tfn0 = f0 * __builtin_amdgcn_rcpf(f0 + L.cache[nid0]);
         const float tfn1 = f1 * __builtin_amdgcn_rcpf(f1 + L.cache[nid1]);
+        te(4u);
+        tb(5u);
         // ---- stage F: every lead that wants the block
         for (; lm; lm &= lm - 1u) {
           const uint32_t g = (uint32_t)__builtin_ctz(lm);
-          auto rl = [&](uint32_t x) __attribute__((always_inline)) {
-            return (uint32_t)__builtin_amdgcn_readlane((int)x, (int)g);
-          };
-          const uint32_t thr = rl(thr_mine);
-          const float w = __uint_as_float(rl(__float_as_uint(mine.w)));
-          const float suf = __uint_as_float(rl(__float_as_uint(mine.suffix)));
-          const float sp = __uint_as_float(rl(__float_as_uint(mine.sparse_after)));
-          const uint32_t ncols = (rl(mine.info) >> 4) & 15u;
-          const uint64_t before = ((uint64_t)rl((uint32_t)(mine.before_mask >> 32)) << 32) | rl((uint32_t)mine.before_mask);
-          const uint32_t cols_lo = rl(mine.cols_lo), cols_hi = rl(mine.cols_hi);
+          if (p.debug & 32u) ++n_scored;  // COUNTERS
+          // the lead's constants: LDS reads at a uniform address (broadcast), used as vector operands
+          const TqdLead &ld = L.lead[g];
+          const uint32_t thr = uni(L.lthr[g]);
+          const float w = ld.w, suf = ld.suffix, sp = ld.sparse_after;
+          const uint32_t ncols = uni((ld.info >> 4) & 15u);
+          const uint32_t b_lo = (uint32_t)ld.before_mask, b_hi = (uint32_t)(ld.before_mask >> 32);
+          const uint32_t cols_lo = uni(ld.cols_lo), cols_hi = uni(ld.cols_hi);
+          // "leader score + weights of the later lists that hold / may hold the doc >= threshold" as
+          // one fused multiply-add and one float compare per doc: scores are >= 0, so the float
+          // order is the order of the sortable bits; the slack that the reciprocal-based tfn and the
+          // different summation order need is folded into the threshold once per (block, lead)
+          const float thr_f = thr ? __uint_as_float(thr ^ ((thr >> 31) ? 0x80000000u : 0xFFFFFFFFu)) : -1.0f;
+          const float need = (thr_f - suf * 4.0e-6f) * 0.999995f;
           float rest0 = sp, rest1 = sp;
-          uint32_t bits0 = 0, bits1 = 0;
 #pragma unroll
           for (uint32_t c = 0; c < 7u; ++c) {
             if (c < ncols) {  // (wave-uniform)
               const uint32_t col = ((c < 4u ? cols_lo >> (8u * c) : cols_hi >> (8u * (c - 4u)))) & 0xFFu;
-              const float aw = __uint_as_float(rl(__float_as_uint(mine.aw[c])));
-              const uint32_t m0 = (uint32_t)(mw0 >> col) & 1u, m1 = (uint32_t)(mw1 >> col) & 1u;
-              rest0 += m0 ? aw : 0.0f;
-              rest1 += m1 ? aw : 0.0f;
-              bits0 |= m0 << c;
-              bits1 |= m1 << c;
+              const float aw = ld.aw[c];
+              const uint64_t s0 = col >= 64u ? sg0 : mw0, s1 = col >= 64u ? sg1 : mw1;  // (uniform select)
+              rest0 = fmaf((float)((uint32_t)(s0 >> (col & 63u)) & 1u), aw, rest0);
+              rest1 = fmaf((float)((uint32_t)(s1 >> (col & 63u)) & 1u), aw, rest1);
             }
           }
-          const float sl = suf * 4.0e-6f;
-          const bool a0 = v0 && !(mw0 & before) && sortable((w * tfn0 + rest0) * 1.000004f + sl) >= thr;
-          const bool a1 = v1 && !(mw1 & before) && sortable((w * tfn1 + rest1) * 1.000004f + sl) >= thr;
-          const uint64_t m0 = __ballot(a0), m1 = __ballot(a1);
-          if (!(m0 | m1)) continue;
-          const uint32_t n0 = (uint32_t)__popcll(m0);
-          const uint32_t pos0 = qn + mbcnt64(m0);
-          const uint32_t pos1 = qn + n0 + mbcnt64(m1);
-          wave_mem_fence();
-          if (a0) {
-            L.q_doc[pos0] = c0;
-            L.q_tf[pos0] = t0;
-            L.q_tag[pos0] = g | (nid0 << 8) | (bits0 << 16);
+          const bool a0 = v0 && !(((uint32_t)mw0 & b_lo) | ((uint32_t)(mw0 >> 32) & b_hi)) && fmaf(w, tfn0, rest0) >= need;
+          const bool a1 = v1 && !(((uint32_t)mw1 & b_lo) | ((uint32_t)(mw1 >> 32) & b_hi)) && fmaf(w, tfn1, rest1) >= need;
+          if (!(__ballot(a0) | __ballot(a1))) continue;
+          // the two docs of a lane are queued one after the other: the queue holds < 64 leftovers
+          // plus <= 64 new entries and is drained below 64 before the next push
+#pragma unroll 1
+          for (uint32_t e = 0; e < 2u; ++e) {
+            const bool a = e ? a1 : a0;
+            const uint64_t m = __ballot(a);
+            if (!m) continue;
+            const uint32_t pos = qn + mbcnt64(m);
+            wave_mem_fence();
+            if (a) {
+              L.q_doc[pos] = e ? c1 : c0;
+              L.q_tf[pos] = e ? t1 : t0;
+              L.q_tag[pos] = g;
+            }
+            wave_mem_fence();
+            qn += (uint32_t)__popcll(m);
+            while (qn >= 64u) stageC(64u);
           }
-          if (a1) {
-            L.q_doc[pos1] = c1;
-            L.q_tf[pos1] = t1;
-            L.q_tag[pos1] = g | (nid1 << 8) | (bits1 << 16);
-          }
-          wave_mem_fence();
-          qn += n0 + (uint32_t)__popcll(m1);
-          // (the queue holds < 64 leftovers + <= 128 of this step: drained to < 64 before the next)
-          while (qn >= 64u) stageC(64u);
         }
+        te(5u);
       }
     }
+    tb(5u);
     while (qn) stageC(qn < 64u ? qn : 64u);
+    te(5u);
+    tb(11u);
 
     // ---- flush: the staging lists go to their queries' result lists
     wave_mem_fence();
     const uint32_t cn = (uint32_t)lane < US_GROUP ? L.cnt[lane] : 0u;
     const uint32_t sc = (uint32_t)lane < US_GROUP ? L.scored[lane] : 0u;
-    if (sc) atomicAdd(sload(&p.sinks->query_matches) + sload(&p.sinks->out_index)[mine.query], sc);
+    if (sc) atomicAdd(sload(&p.sinks->query_matches) + sload(&p.sinks->out_index)[L.lead[lane].query], sc);
     uint64_t have = __ballot(cn != 0u);
     while (have) {
       const uint32_t gs = (uint32_t)__builtin_ctzll(have);
       have &= have - 1ull;
       uint32_t ns = (uint32_t)__builtin_amdgcn_readlane((int)cn, (int)gs);
-      const uint32_t ks = (uint32_t)__builtin_amdgcn_readlane((int)k_mine, (int)gs);
-      const uint32_t qs = (uint32_t)__builtin_amdgcn_readlane((int)mine.query, (int)gs);
+      const uint32_t ks = uni(L.lk[gs]);
+      const uint32_t qs = uni(L.lead[gs].query);
       if (ns > ks) {
         (void)compact_slot(gs, ns, ks);
         ns = ks;
@@ -640,7 +796,10 @@ ushare_kernel(TqkShareParams p) {
         base += (uint32_t)__popcll(m);
       }
     }
+    te(11u);
   }
+  te(1u);
+  if (tphase) n_scored = (uint32_t)(tacc >> 6);
   if (lane == 0 && n_scored) atomicAdd(sload(&p.sinks->match_counter), (unsigned long long)n_scored);
 }
 
@@ -691,7 +850,7 @@ __global__ __launch_bounds__(64) void merge_lists_kernel(TqkMergeParams p, const
 uint32_t tqk_share_capl(int kpl) { return (uint32_t)(kpl + 1) * 64u; }
 
 hipError_t tqk_launch_share(const TqkShareParams &p, int kpl, hipStream_t st) {
-  if (p.n_tasks == 0) return hipSuccess;
+  if (p.n_tasks <= p.task_begin || p.grid == 0) return hipSuccess;
   const dim3 grid(p.grid), block(64);
   switch (kpl) {
     case 1: ushare_kernel<1><<<grid, block, 0, st>>>(p); break;

@@ -22,7 +22,7 @@ from collections import defaultdict
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
-SCAN = re.compile(r"(and_kernel|union_kernel_small|union_kernel|or_kernel|phrase_kernel)<([^>]*)>")
+SCAN = re.compile(r"(and_kernel|union_kernel_small|union_kernel|ushare_kernel|or_kernel|phrase_kernel)<([^>]*)>")
 
 
 def classify(name):
@@ -33,6 +33,8 @@ def classify(name):
     fam, args = m.group(1), [a.strip() for a in m.group(2).split(",")]
     if fam == "phrase_kernel":
         return fam, "both"  # the reference prunes nothing before positions are read
+    if fam == "ushare_kernel":
+        return fam, "pruned"  # the shared-union launch only exists in the pruned mode
     return fam, ("pruned" if args[1] == "true" else "exhaustive")
 
 
