@@ -89,6 +89,7 @@ struct TermHost {
   void *blob = nullptr;  // one device allocation holding every per-term array
   void *dense_blob = nullptr;  // bitmap + rank directory of a dense list
   void *posdir_blob = nullptr; // position directory of a dense list with positions
+  void *tf8_blob = nullptr;    // term freqs of a dense list as bytes (posting index -> min(tf, 255))
   void *pos_blob = nullptr;    // device-side prepare: positions tables (sized after the walk)
   uint32_t doc_freq = 0, n_blocks = 0, n_full = 0, n_tail = 0;
   uint32_t last_doc = 0;
@@ -238,6 +239,29 @@ int register_term(tq_segment *s, const TqdTerm &dt, const TermHost &th, uint64_t
                   tq_term_handle *out);
 int add_to_doc_signatures(tq_segment *s, uint32_t handle);
 
+// Dense lists also get their term freqs as one byte per posting (255 = "255 or more: read the
+// packed value"): with the posting index from the bitmap's rank the tf of a candidate is ONE load,
+// where block record -> packed tf bits are two dependent ones (the shared-union kernel's scoring
+// stage is a chain of dependent gathers, 1.6 us each under load).  d_tfs = the decoded tfs.
+int build_tf8(tq_segment *s, uint32_t handle, const uint32_t *d_tfs) {
+  TermHost &t = s->terms[handle];
+  const size_t bytes = ((size_t)t.doc_freq + 7) & ~(size_t)7;
+  if (s->dense_bytes_total + bytes > s->dense_budget()) return TQ_OK;
+  void *blob = nullptr;
+  HIP_TRY(hipMalloc(&blob, bytes + PAD));
+  hipError_t e = tqk_launch_tf8_pack(d_tfs, t.doc_freq, (uint8_t *)blob, s->stream);
+  if (e != hipSuccess) {
+    (void)hipFree(blob);
+    return fail(TQ_ERR_HIP, "tf8 pack: %s", hipGetErrorString(e));
+  }
+  t.tf8_blob = blob;
+  s->h_dterms[handle].tf8 = (const uint8_t *)blob;
+  s->dense_bytes_total += bytes;
+  s->bytes_bitmaps += bytes;
+  s->d_terms_dirty = true;
+  return TQ_OK;
+}
+
 // Orders work about to be enqueued on `st` after the segment's previous batch, whatever stream
 // that batch ran on (no-op when it is the same stream: stream order already holds).
 int order_after_last_batch(tq_segment *s, hipStream_t st) {
@@ -309,6 +333,8 @@ int build_dense(tq_segment *s, uint32_t handle) {
   hipError_t e = tqk_launch_decode_list(s->dseg, s->d_terms, handle, t.n_blocks, dd, dt,
                                         s->opt.use_dpp != 0, s->stream);
   if (e != hipSuccess) return fail(TQ_ERR_HIP, "decode launch: %s", hipGetErrorString(e));
+  rc = build_tf8(s, handle, dt);
+  if (rc != TQ_OK) return rc;
   // the list's column of the doc matrix (first TQD_MAT_SLOTS dense lists of the segment, while
   // the matrix fits the same memory budget as the bitmaps)
   if (s->n_mat_slots < TQD_MAT_SLOTS && s->opt.docmat) {
@@ -535,6 +561,8 @@ void tq_segment_free(tq_segment *s) {
     if (t.dense_blob) (void)hipFree(t.dense_blob);
   for (auto &t : s->terms)
     if (t.posdir_blob) (void)hipFree(t.posdir_blob);
+  for (auto &t : s->terms)
+    if (t.tf8_blob) (void)hipFree(t.tf8_blob);
   for (auto &t : s->terms)
     if (t.pos_blob) (void)hipFree(t.pos_blob);
   if (s->d_terms) (void)hipFree(s->d_terms);
@@ -990,6 +1018,8 @@ int build_dense_device(tq_segment *s, uint32_t handle) {
   hipError_t e = tqk_launch_decode_list(s->dseg, s->d_terms, handle, t.n_blocks, dd, dt,
                                         s->opt.use_dpp != 0, s->stream);
   if (e != hipSuccess) return fail(TQ_ERR_HIP, "decode launch: %s", hipGetErrorString(e));
+  rc = build_tf8(s, handle, dt);
+  if (rc != TQ_OK) return rc;
   const size_t n_words = ((size_t)s->max_doc + 31) / 32 + 1;
   void *blob = nullptr;
   HIP_TRY(hipMalloc(&blob, n_words * sizeof(uint2)));
@@ -1124,6 +1154,7 @@ struct PlanScratch {
   std::vector<uint4> tasks;
   std::vector<uint32_t> share_pairs;  // per query: (task, lead) pairs = result-list appends at most
   uint32_t share_phase_first[TQD_US_MAX_TERMS + 1];  // tasks of list position i: [first[i], first[i+1])
+  uint64_t share_table_base = 0;  // TqdLead::dense_off / tf8_off are relative to this device address
   std::vector<uint32_t> lead_cost, sort_start;
   std::vector<PlanSlab> slabs;
   std::vector<std::pair<uint64_t, uint32_t>> keyed;
@@ -1537,6 +1568,24 @@ int build_share_plan(tq_segment *s, Group &g, PlanScratch &ps) {
   leads.resize(keys.size());
   tasks.clear();
   pairs.assign(nq, 0u);
+  // bitmaps and byte-wide tfs are addressed as 32-bit offsets (8-byte units) from one base: the
+  // lowest table address among the batch's lists (32 GB of span; beyond it the batch is refused)
+  uint64_t lo = ~0ull, hi = 0;
+  for (const ShareKey &k : keys) {
+    const TermHost &th = s->terms[k.term];
+    for (const void *ptr : {th.dense_blob, th.tf8_blob})
+      if (ptr) {
+        lo = std::min<uint64_t>(lo, (uint64_t)ptr);
+        hi = std::max<uint64_t>(hi, (uint64_t)ptr);
+      }
+  }
+  if (lo == ~0ull) lo = 8;
+  ps.share_table_base = lo - 8;
+  if (hi - ps.share_table_base >= (8ull << 32))
+    return fail(TQ_ERR_UNSUPPORTED, "dense-list tables span more than 32 GB of device addresses");
+  auto off_of = [&](const void *ptr) -> uint32_t {
+    return ptr ? (uint32_t)(((uint64_t)ptr - ps.share_table_base) >> 3) : 0u;
+  };
   auto column_of = [&](uint32_t handle) -> uint32_t {  // doc-matrix bit of the list, or 0
     const uint32_t slot1 = (s->h_dterms[handle].has_freq >> 8) & 0xFFu;
     return slot1 ? 8u + (slot1 - 1u) : 0u;
@@ -1562,6 +1611,8 @@ int build_share_plan(tq_segment *s, Group &g, PlanScratch &ps) {
       if (m < li) {
         if (col) ld.before_mask |= 1ull << col;
       } else if (m > li) {
+        ld.dense_off[m - li - 1u] = off_of(s->opt.use_dense ? s->terms[dq.term[m]].dense_blob : nullptr);
+        ld.tf8_off[m - li - 1u] = off_of(s->terms[dq.term[m]].tf8_blob);
         const uint32_t bitpos = col ? col : (sig1 ? 64u + (sig1 - 1u) : 0u);
         if (bitpos) {
           if (ncols < 4u)
@@ -1995,6 +2046,8 @@ int search_batch_impl(tq_segment *s, const tq_query *queries, uint32_t n_queries
       share = kUseShare && !or_windows_opt && (dq.flags & TQD_QF_PRUNE) && dq.thr_index != 0xFFFFFFFFu &&
               dq.n_terms >= 1 && dq.n_terms <= TQD_US_MAX_TERMS && s->d_docmat && s->opt.use_dense &&
               cache_idx < 256u;
+      for (uint32_t i = 0; share && i < dq.n_terms; ++i)  // (lists with a bitmap carry byte-wide tfs)
+        if (s->terms[dq.term[i]].dense_blob && !s->terms[dq.term[i]].tf8_blob) share = false;
       if (share) {
         // (planned per term, not per query: build_share_plan)
       } else if (or_windows_opt) {
@@ -2252,6 +2305,7 @@ int search_batch_impl(tq_segment *s, const tq_query *queries, uint32_t n_queries
         }
         if (sp.n_tasks <= sp.task_begin) continue;
         sp.task_counter = counters + ph;
+        sp.table_base = (const uint8_t *)s->plan->share_table_base;
         sp.grid = std::min<uint32_t>(share_grid, sp.n_tasks - sp.task_begin);
         const hipError_t e = tqk_launch_share(sp, g.kpl, gst);
         if (e != hipSuccess) return fail(TQ_ERR_HIP, "shared-union launch: %s", hipGetErrorString(e));

@@ -50,6 +50,8 @@ struct TqdTerm : TqdTermHead {
   // the term freqs of the <= 3 postings before it in its group of four — which share one
   // 16-byte row of the bitpacked tf stream — instead of a prefix sum over its whole block.
   const uint32_t *pos_dir;
+  // dense lists: min(tf, 255) per posting, indexed by the posting index (bitmap rank), or null
+  const uint8_t *tf8;
 };
 
 struct TqdQuery {
@@ -100,8 +102,12 @@ struct TqdLead {             // 72 bytes, written by the host planner
   float aw[7];               // their weights, in list order
   uint64_t before_mask;      // doc-matrix bits of the lists before i that have a column
   uint8_t sig[8];            // per list of the query: signature bit + 1 (0 = none)
+  // the lists after i (a = 1.. <-> list i + a): bitmap + rank directory and byte-wide term freqs
+  // as offsets from TqkShareParams::table_base in 8-byte units (0 = the list has no bitmap)
+  uint32_t dense_off[7];
+  uint32_t tf8_off[7];
 };
-static_assert(sizeof(TqdLead) == 72, "TqdLead is uploaded as raw bytes");
+static_assert(sizeof(TqdLead) == 128, "TqdLead is uploaded as raw bytes");
 
 #define TQD_ROLE_SHOULD 0u
 #define TQD_ROLE_MUST 1u

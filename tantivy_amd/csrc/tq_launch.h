@@ -53,6 +53,7 @@ struct TqkShareParams {
   uint32_t *thr_slots;          // hashed score slots per query (as the other pruned kernels use)
   uint32_t *thr_val;            // [n_queries] current lower bound of each query's k-th best score
   uint32_t *task_counter;       // next task to hand out (zeroed per batch)
+  const uint8_t *table_base;    // TqdLead::dense_off / tf8_off count 8-byte units from here
   uint64_t *stage;              // [grid][TQD_US_GROUP][capl] per-wave staging lists
   uint64_t *lists;              // per-query result lists (query q: entries part_start .. + n_parts)
   uint32_t *list_count;         // [n_queries] entries written so far
@@ -106,6 +107,8 @@ hipError_t tqk_launch_docmat_init(uint64_t *mat, const uint8_t *fieldnorm, uint3
                                   uint32_t max_doc, hipStream_t st);
 hipError_t tqk_launch_docmat_set(uint64_t *mat, const uint32_t *docs, uint32_t n, uint32_t slot,
                                  uint32_t max_doc, hipStream_t st);
+// term freqs of a decoded list as bytes (TqdTerm::tf8)
+hipError_t tqk_launch_tf8_pack(const uint32_t *tfs, uint32_t n, uint8_t *out, hipStream_t st);
 // doc signatures (TqdSegment::docsig): set bit `bit` of the list's docs
 hipError_t tqk_launch_docsig_set(uint64_t *sig, const uint32_t *docs, uint32_t n, uint32_t bit,
                                  uint32_t max_doc, hipStream_t st);

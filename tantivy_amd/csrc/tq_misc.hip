@@ -161,6 +161,10 @@ __global__ void docmat_set_kernel(uint64_t *mat, const uint32_t *docs, uint32_t 
     atomicOr((unsigned long long *)(mat + docs[i]), 1ull << (8u + slot));
 }
 
+__global__ void tf8_pack_kernel(const uint32_t *tfs, uint32_t n, uint8_t *out) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = (uint8_t)(tfs[i] < 255u ? tfs[i] : 255u);
+}
 __global__ void docsig_set_kernel(uint64_t *sig, const uint32_t *docs, uint32_t n, uint32_t bit,
                                   uint32_t max_doc) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -170,6 +174,11 @@ __global__ void docsig_set_kernel(uint64_t *sig, const uint32_t *docs, uint32_t 
 }  // namespace
 
 // =================================================================== launch wrappers
+hipError_t tqk_launch_tf8_pack(const uint32_t *tfs, uint32_t n, uint8_t *out, hipStream_t st) {
+  if (n == 0) return hipSuccess;
+  hipLaunchKernelGGL(tf8_pack_kernel, dim3((n + 255) / 256), dim3(256), 0, st, tfs, n, out);
+  return hipGetLastError();
+}
 hipError_t tqk_launch_docsig_set(uint64_t *sig, const uint32_t *docs, uint32_t n, uint32_t bit,
                                  uint32_t max_doc, hipStream_t st) {
   if (n == 0) return hipSuccess;

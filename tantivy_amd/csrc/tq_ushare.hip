@@ -39,6 +39,9 @@
 #ifndef TQ_US_TIMERS
 #define TQ_US_TIMERS 0  // region timers (tools/probe_ushare.sh builds a variant with them)
 #endif
+#ifndef TQ_US_CHUNK
+#define TQ_US_CHUNK 2  // lists after the leader resolved together in the scoring stage (4 spills more than it hides)
+#endif
 #ifndef TQ_US_WAVES
 #define TQ_US_WAVES 4
 #endif
@@ -46,6 +49,7 @@
 namespace {
 
 constexpr uint32_t US_GROUP = TQD_US_GROUP;
+constexpr uint32_t CH = TQ_US_CHUNK;
 
 struct ShareLds {  // per wavefront
   uint32_t pay[516];  // staged payload of the leader block / four 512-byte regions of the block search
@@ -56,12 +60,14 @@ struct ShareLds {  // per wavefront
   // ended in scratch (3 spill reloads per (block, lead) pair: 7000 cycles each, measured)
   TqdLead lead[US_GROUP];
   uint32_t lthr[US_GROUP];     // the lead's threshold (sortable score bits); only ever rises
-  uint32_t lk[US_GROUP];       // k of its query
-  uint32_t lrow[US_GROUP];     // its query's row of threshold slots
-  uint32_t lh[US_GROUP][8];    // term handles / weights of the lead slots' queries (all lists)
-  float lw[US_GROUP][8];
-  uint32_t cnt[US_GROUP];      // entries in the lead slots' staging lists
-  uint32_t scored[US_GROUP];   // docs scored per lead slot (Count / statistics)
+  uint32_t lk[US_GROUP];       // k of its query (bits 0..7: k <= 128) | its row of threshold slots << 8
+  // per block of the current tile: the leads that still want it; per doc of the current block:
+  // tf/(tf+norm).  (In LDS because the scoring stage needs the registers: what the compiler spilled
+  // instead cost a scratch round trip per (block, lead) pair.)
+  uint32_t pmask[64];
+  float tfn[2][64];
+  uint32_t cnt[US_GROUP];      // bits 0..15: entries in the lead slot's staging list; bits 16..31: docs
+                               // scored for the slot by this task (Count / statistics)
 };
 
 // per-lane view of a posting list (fields of TqdTermHead fetched with vector loads)
@@ -277,6 +283,7 @@ ushare_kernel(TqkShareParams p) {
     const uint32_t base = qn - n;
     qn = base;
     if (p.debug & 64u) n_scored += n;  // COUNTERS
+    if (p.debug & 512u) ++n_scored;
     bool alive = (uint32_t)lane < n;
     uint32_t doc = 0, tf = 0, tag = 0;
     if (alive) {
@@ -306,8 +313,8 @@ ushare_kernel(TqkShareParams p) {
     const float w_lead = L.lead[g].w;
     const float suffix = L.lead[g].suffix;
     const uint32_t thr = L.lthr[g];
-    const uint32_t k = L.lk[g];
-    const uint32_t thr_row = L.lrow[g];
+    const uint32_t k = L.lk[g] & 0xFFu;
+    const uint32_t thr_row = L.lk[g] >> 8;
     const uint32_t li = info & 15u, nt = (info >> 8) & 15u, nocol = (info >> 16) & 0xFFu, nopc = info >> 24;
     const float slack_abs = suffix * 4.0e-6f;
     float s = bm25(w_lead, norm, tf);
@@ -322,97 +329,86 @@ ushare_kernel(TqkShareParams p) {
         if (__ballot(nbf >= x)) max_before = x;
       }
     }
-    // Lists after the leader, ascending: they add to the score.  Four lists at a time, and every
-    // level of the chain (term table -> bitmap word -> block record -> tf bits) is issued for all
-    // four before the next one is awaited: a candidate costs four dependent round trips per group
-    // of lists, not four per list.  The adds then run in list order.
-    for (uint32_t a0 = 1; a0 <= max_after; a0 += 4u) {
-      bool on[4], probe_sparse[4], found[4];
-      float w[4];
-      uint32_t h[4], tfv[4], pi[4];
-      const uint2 *dptr[4];
-      const uint4 *rptr[4];
-      const uint32_t *ttf[4];
-      uint64_t pbase[4];
-      uint32_t hfreq[4];
+    // Lists after the leader, ascending: they add to the score.  CH lists at a time, and every
+    // level of the chain is issued for all of them before the next one is awaited: bitmap word
+    // (membership of the lists without a column + the posting index) -> the tf byte at that index.
+    // The tables' addresses come from the lead record in LDS: two dependent round trips per group
+    // of lists (it was four per list: term table -> bitmap word -> block record -> packed tf).
+    // The adds then run in list order.
+    const uint8_t *const tbase = p.table_base;
+    for (uint32_t a0 = 1; a0 <= max_after; a0 += CH) {
+      bool on[CH], probe_sparse[CH], found[CH], has_w[CH];
+      float w[CH];
+      uint32_t tfv[CH], pi[CH], doff[CH], toff[CH];
 #pragma unroll
-      for (uint32_t u = 0; u < 4u; ++u) {
+      for (uint32_t u = 0; u < CH; ++u) {
         const uint32_t m = li + a0 + u;
         on[u] = alive && m < nt;
-        w[u] = 0.0f;
-        h[u] = 0;
-        if (on[u]) {
-          w[u] = L.lw[g][m & 7u];
-          h[u] = L.lh[g][m & 7u];
-        }
         // a list with a membership bit: exact (doc-matrix column) or "maybe" (signature bit)
         const bool has_bit = on[u] && !((nopc >> m) & 1u);
         const bool exact = on[u] && !((nocol >> m) & 1u);
         bool set = false;
+        w[u] = 0.0f;
+        has_w[u] = has_bit;
         if (has_bit) {
           set = (bits >> c) & 1u;
+          w[u] = L.lead[g].aw[c < 7u ? c : 6u];
           ++c;
         }
-        // no column: bitmap or seek (decided by the term table) unless the signature says "not in it"
+        doff[u] = 0;
+        toff[u] = 0;
+        if (on[u] && (a0 + u) <= 7u) {
+          doff[u] = L.lead[g].dense_off[a0 + u - 1u];
+          toff[u] = L.lead[g].tf8_off[a0 + u - 1u];
+        }
+        found[u] = exact && set;  // (column lists: membership is known already; the rank is not)
+        // no column: bitmap or seek — unless the signature says "not in it"
         probe_sparse[u] = on[u] && !exact && (set || !has_bit);
-        found[u] = exact && set;  // (column lists: membership is known already)
         tfv[u] = 0;
         pi[u] = 0;
       }
-      // level 1: the lists' tables
+      tb(12u);
+      // level 1: bitmap word + rank
+      uint2 wd[CH];
 #pragma unroll
-      for (uint32_t u = 0; u < 4u; ++u) {
-        dptr[u] = nullptr;
-        rptr[u] = nullptr;
-        ttf[u] = nullptr;
-        pbase[u] = 0;
-        hfreq[u] = 0;
-        if (found[u] || probe_sparse[u]) {
-          const TqdTermHead *th = p.terms + h[u];
-          dptr[u] = th->dense;
-          rptr[u] = th->rec;
-          ttf[u] = th->tail_tfs;
-          pbase[u] = th->payload_base;
-          hfreq[u] = th->has_freq & 1u;
-        }
-      }
-      // level 2: bitmap word + rank (membership of the column-less lists that have a bitmap)
-      uint2 wd[4];
-#pragma unroll
-      for (uint32_t u = 0; u < 4u; ++u) {
+      for (uint32_t u = 0; u < CH; ++u) {
         wd[u] = make_uint2(0u, 0u);
-        if ((found[u] || probe_sparse[u]) && dptr[u]) wd[u] = dptr[u][doc >> 5];
+        if ((found[u] || probe_sparse[u]) && doff[u])
+          wd[u] = reinterpret_cast<const uint2 *>(tbase + ((uint64_t)doff[u] << 3))[doc >> 5];
       }
 #pragma unroll
-      for (uint32_t u = 0; u < 4u; ++u) {
+      for (uint32_t u = 0; u < CH; ++u) {
         const uint32_t bit = doc & 31u;
-        if (probe_sparse[u] && dptr[u]) {
+        if (probe_sparse[u] && doff[u]) {
           found[u] = (wd[u].x >> bit) & 1u;
           probe_sparse[u] = false;
         }
         pi[u] = wd[u].y + (uint32_t)__popc(wd[u].x & ((1u << bit) - 1u));
       }
-      // level 3: block records; level 4: tf bits
-      uint2 mo[4];
+      // level 2: the tf byte
 #pragma unroll
-      for (uint32_t u = 0; u < 4u; ++u) {
-        mo[u] = make_uint2(0u, 0u);
-        if (found[u]) mo[u] = rec_mo(rptr[u][pi[u] >> 7]);
+      for (uint32_t u = 0; u < CH; ++u)
+        if (found[u]) tfv[u] = (tbase + ((uint64_t)toff[u] << 3))[pi[u]];
+      if (TQ_US_TIMERS && tphase == 12u) {  // (the loads have to land inside the timed region)
+        uint32_t acc = 0;
+#pragma unroll
+        for (uint32_t u = 0; u < CH; ++u) acc += tfv[u];
+        if (acc == 0xFFFFFFFFu) ++n_scored;
       }
+      te(12u);
+      tb(13u);
+      // in list order: saturated tf bytes are read exactly, lists without a bitmap are searched
+      // (only while the doc can still make it), scores are added
 #pragma unroll
-      for (uint32_t u = 0; u < 4u; ++u) {
-        if (found[u]) {
-          TermRef tr{};
-          tr.has_freq = hfreq[u];
-          tr.tail_tfs = ttf[u];
-          tr.payload_base = pbase[u];
-          tfv[u] = block_tf_at(idx, tr, mo[u], pi[u] & 127u);
+      for (uint32_t u = 0; u < CH; ++u) {
+        const uint32_t m = li + a0 + u;
+        if (__ballot(found[u] && tfv[u] == 255u)) {  // tf >= 255: block record -> packed tf
+          if (found[u] && tfv[u] == 255u) {
+            const TermRef tr = load_term_lane(p.terms, p.queries[q].term[m]);
+            const uint4 r = tr.rec[pi[u] >> 7];
+            tfv[u] = block_tf_at(idx, tr, make_uint2(r.y, r.z), pi[u] & 127u);
+          }
         }
-      }
-      // in list order: lists without a bitmap are searched (only while the doc can still make it),
-      // scores are added
-#pragma unroll
-      for (uint32_t u = 0; u < 4u; ++u) {
         if (__ballot(probe_sparse[u])) {
           bool cand = probe_sparse[u] && alive;
           if (cand) {
@@ -426,7 +422,7 @@ ushare_kernel(TqkShareParams p) {
             TermRef tr{};
             uint32_t jb = 0;
             if (cand) {
-              tr = load_term_lane(p.terms, h[u]);
+              tr = load_term_lane(p.terms, p.queries[q].term[m]);
               jb = seek_block(tr, doc);
               cand = jb < tr.n_blocks;
             }
@@ -439,9 +435,11 @@ ushare_kernel(TqkShareParams p) {
             }
           }
         }
+        if (on[u] && !has_w[u]) w[u] = p.queries[q].weight[m];  // (a list with neither column nor signature bit)
         if (found[u] && alive) s = s + bm25(w[u], norm, tfv[u]);
         if (on[u]) rest -= w[u];
       }
+      te(13u);
     }
     te(7u);
     tb(8u);
@@ -458,7 +456,7 @@ ushare_kernel(TqkShareParams p) {
       }
       if (!__ballot(probe)) continue;
       TermRef tr{};
-      if (probe) tr = load_term_lane(p.terms, L.lh[g][m & 7u]);
+      if (probe) tr = load_term_lane(p.terms, p.queries[q].term[m]);
       const bool bitmap = probe && tr.dense != nullptr;
       bool found = false;
       if (bitmap) found = (tr.dense[doc >> 5].x >> (doc & 31u)) & 1u;
@@ -487,16 +485,16 @@ ushare_kernel(TqkShareParams p) {
       return;
     }
     tb(9u);
-    if (!(p.debug & 480u)) n_scored += (uint32_t)__popcll(hit);  // COUNTERS (TQ_DEBUG): 32 (block, lead) pairs,
+    if (!(p.debug & 992u)) n_scored += (uint32_t)__popcll(hit);  // COUNTERS (TQ_DEBUG): 32 (block, lead) pairs,
     const uint64_t key = alive ? make_key(s, doc) : 0ull;        // 64 stage-C candidates, 128 block searches, 256 blocks decoded
     const uint32_t sb = (uint32_t)(key >> 32);
     bool changed = false;
     if (alive) {
-      atomicAdd(&L.scored[g], 1u);
+
       const uint32_t hsh = (doc * 0x9E3779B1u) >> (k <= 16u ? 26 : 24);
       const uint32_t old = atomicMax(p.thr_slots + (size_t)thr_row * TQD_THR_SLOTS + hsh, sb);
       changed = old < sb;
-      const uint32_t pos = atomicAdd(&L.cnt[g], 1u);  // (a list never overflows: see the cut below)
+      const uint32_t pos = atomicAdd(&L.cnt[g], 0x10001u) & 0xFFFFu;  // (a list never overflows: see the cut below)
       my_stage[(size_t)g * CAPL + pos] = key;
     }
     // queries whose slots changed: their k-th largest slot is the new shared threshold
@@ -528,17 +526,17 @@ ushare_kernel(TqkShareParams p) {
     tb(10u);
     // staging lists that could overflow with the next batch are cut back to their k best now
     wave_mem_fence();
-    const uint32_t cn = (uint32_t)lane < US_GROUP ? L.cnt[lane] : 0u;
+    const uint32_t cn = (uint32_t)lane < US_GROUP ? L.cnt[lane] & 0xFFFFu : 0u;
     uint64_t full = __ballot(cn > CAPL - 64u);
     while (full) {
       const uint32_t gs = (uint32_t)__builtin_ctzll(full);
       full &= full - 1ull;
       const uint32_t ns = (uint32_t)__builtin_amdgcn_readlane((int)cn, (int)gs);
-      const uint32_t ks = uni(L.lk[gs]);
+      const uint32_t ks = uni(L.lk[gs]) & 0xFFu;
       const uint64_t kth = compact_slot(gs, ns, ks);
       const uint32_t t = (uint32_t)(kth >> 32);
       if ((uint32_t)lane == gs) {
-        L.cnt[gs] = ks;
+        L.cnt[gs] = (L.cnt[gs] & 0xFFFF0000u) | ks;
         if (t > L.lthr[gs]) L.lthr[gs] = t;
         atomicMax(p.thr_val + L.lead[gs].query, t);  // k distinct docs of this query score >= t
       }
@@ -572,23 +570,11 @@ ushare_kernel(TqkShareParams p) {
       const TqdLead mine = p.leads[lead0 + lane];
       L.lead[lane] = mine;
       const TqdQuery *Q = p.queries + mine.query;
-      L.lk[lane] = Q->k;
-      L.lrow[lane] = Q->thr_index;
-      // (a TqdQuery is dword-aligned only: unaligned 16-byte loads)
-      const U4Unaligned *qt = reinterpret_cast<const U4Unaligned *>(Q->term);
-      const U4Unaligned *qw = reinterpret_cast<const U4Unaligned *>(Q->weight);
-      const U4Unaligned t0 = qt[0], t1 = qt[1], w0 = qw[0], w1 = qw[1];
-      *reinterpret_cast<uint4 *>(&L.lh[lane][0]) = make_uint4(t0.x, t0.y, t0.z, t0.w);
-      *reinterpret_cast<uint4 *>(&L.lh[lane][4]) = make_uint4(t1.x, t1.y, t1.z, t1.w);
-      *reinterpret_cast<uint4 *>(&L.lw[lane][0]) = make_uint4(w0.x, w0.y, w0.z, w0.w);
-      *reinterpret_cast<uint4 *>(&L.lw[lane][4]) = make_uint4(w1.x, w1.y, w1.z, w1.w);
+      L.lk[lane] = Q->k | (Q->thr_index << 8);
       L.lthr[lane] = __hip_atomic_load(p.thr_val + mine.query, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     wave_mem_fence();
-    if ((uint32_t)lane < US_GROUP) {
-      L.cnt[lane] = 0u;
-      L.scored[lane] = 0u;
-    }
+    if ((uint32_t)lane < US_GROUP) L.cnt[lane] = 0u;
     wave_mem_fence();
     auto lead_alive = [&]() __attribute__((always_inline)) {
       return (uint32_t)lane < n_leads && sortable(L.lead[lane].suffix * 1.000001f) >= L.lthr[lane];
@@ -617,8 +603,6 @@ ushare_kernel(TqkShareParams p) {
       const bool in_tile = (uint32_t)lane < nb && i_mine < lead.n_blocks;
       uint4 rec_mine = make_uint4(0u, 0u, 0u, 0u);
       if (in_tile) rec_mine = lead.rec[i_mine];
-      uint32_t prev_mine = __shfl_up(rec_mine.x, 1, WAVE);
-      if (lane == 0) prev_mine = block_prev_last(lead, i_base);
       // block-max of tf/(tf+norm), the weight-free part of block_max_score (term_scorer.rs:58-75)
       float tfn_max = 1.0f;
       {
@@ -637,8 +621,14 @@ ushare_kernel(TqkShareParams p) {
         if (in_tile && sortable((ub + (suf - w)) * 1.000004f + suf * 4.0e-6f) >= thr) pass_mask |= 1u << g;
       }
       uint64_t todo = __ballot(pass_mask != 0u);
+      wave_mem_fence();
+      L.pmask[lane] = pass_mask;
+      wave_mem_fence();
       te(3u);
       uint32_t since_refresh = 0;
+      // (Tried: software-pipelining the walk — the next wanted block's record and payload requested
+      // under the current block's doc-matrix gathers.  The four registers of the payload in flight
+      // cost more in spills than the two hidden round trips won: 2.79..2.98 against 2.81 ms.)
       while (todo) {
         const uint32_t b = (uint32_t)__builtin_ctzll(todo);
         todo &= todo - 1ull;
@@ -652,11 +642,12 @@ ushare_kernel(TqkShareParams p) {
           live = (uint32_t)__ballot(lead_alive());
           if (!live) break;
         }
-        uint32_t lm = (uint32_t)__builtin_amdgcn_readlane((int)pass_mask, (int)b) & live;
+        uint32_t lm = uni(L.pmask[b]) & live;
         if (!lm) continue;
-        const uint2 mo_l = make_uint2((uint32_t)__builtin_amdgcn_readlane((int)rec_mine.y, (int)b),
-                                      (uint32_t)__builtin_amdgcn_readlane((int)rec_mine.z, (int)b));
-        const uint32_t prev_l = (uint32_t)__builtin_amdgcn_readlane((int)prev_mine, (int)b);
+        // the block's record again, by scalar loads (the 64 records of the tile are not kept in registers)
+        const uint4 rec_b = sload(lead.rec + (i_base + b));
+        const uint32_t prev_l = block_prev_last(lead, i_base + b);
+        const uint2 mo_l = make_uint2(rec_b.y, rec_b.z);
         tb(4u);
         if (p.debug & 256u) ++n_scored;  // COUNTERS
         // ---- stage A: decode the block once
@@ -694,8 +685,10 @@ ushare_kernel(TqkShareParams p) {
         }
         const uint32_t nid0 = (uint32_t)mw0 & 0xFFu, nid1 = (uint32_t)mw1 & 0xFFu;
         const float f0 = (float)t0, f1 = (float)t1;
-        const float tfn0 = f0 * __builtin_amdgcn_rcpf(f0 + L.cache[nid0]);
-        const float tfn1 = f1 * __builtin_amdgcn_rcpf(f1 + L.cache[nid1]);
+        wave_mem_fence();
+        L.tfn[0][lane] = f0 * __builtin_amdgcn_rcpf(f0 + L.cache[nid0]);
+        L.tfn[1][lane] = f1 * __builtin_amdgcn_rcpf(f1 + L.cache[nid1]);
+        wave_mem_fence();
         te(4u);
         tb(5u);
         // ---- stage F: every lead that wants the block
@@ -726,8 +719,8 @@ ushare_kernel(TqkShareParams p) {
               rest1 = fmaf((float)((uint32_t)(s1 >> (col & 63u)) & 1u), aw, rest1);
             }
           }
-          const bool a0 = v0 && !(((uint32_t)mw0 & b_lo) | ((uint32_t)(mw0 >> 32) & b_hi)) && fmaf(w, tfn0, rest0) >= need;
-          const bool a1 = v1 && !(((uint32_t)mw1 & b_lo) | ((uint32_t)(mw1 >> 32) & b_hi)) && fmaf(w, tfn1, rest1) >= need;
+          const bool a0 = v0 && !(((uint32_t)mw0 & b_lo) | ((uint32_t)(mw0 >> 32) & b_hi)) && fmaf(w, L.tfn[0][lane], rest0) >= need;
+          const bool a1 = v1 && !(((uint32_t)mw1 & b_lo) | ((uint32_t)(mw1 >> 32) & b_hi)) && fmaf(w, L.tfn[1][lane], rest1) >= need;
           if (!(__ballot(a0) | __ballot(a1))) continue;
           // the two docs of a lane are queued one after the other: the queue holds < 64 leftovers
           // plus <= 64 new entries and is drained below 64 before the next push
@@ -758,15 +751,15 @@ ushare_kernel(TqkShareParams p) {
 
     // ---- flush: the staging lists go to their queries' result lists
     wave_mem_fence();
-    const uint32_t cn = (uint32_t)lane < US_GROUP ? L.cnt[lane] : 0u;
-    const uint32_t sc = (uint32_t)lane < US_GROUP ? L.scored[lane] : 0u;
+    const uint32_t cw = (uint32_t)lane < US_GROUP ? L.cnt[lane] : 0u;
+    const uint32_t cn = cw & 0xFFFFu, sc = cw >> 16;
     if (sc) atomicAdd(sload(&p.sinks->query_matches) + sload(&p.sinks->out_index)[L.lead[lane].query], sc);
     uint64_t have = __ballot(cn != 0u);
     while (have) {
       const uint32_t gs = (uint32_t)__builtin_ctzll(have);
       have &= have - 1ull;
       uint32_t ns = (uint32_t)__builtin_amdgcn_readlane((int)cn, (int)gs);
-      const uint32_t ks = uni(L.lk[gs]);
+      const uint32_t ks = uni(L.lk[gs]) & 0xFFu;
       const uint32_t qs = uni(L.lead[gs].query);
       if (ns > ks) {
         (void)compact_slot(gs, ns, ks);

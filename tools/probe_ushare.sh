@@ -3,7 +3,7 @@
 R=${GRAFT_REPO_ROOT:-/root/repo}; cd $R
 export TQ_LIB_PATH=$R/tantivy_amd/lib/variants/libtantivy_amd_ust.so
 W=${1:-or5}; shift
-for ph in 1 2 3 4 5 6 7 8 9 10 11; do
+for ph in ${PHASES_LIST:-1 2 3 4 5 6 7 8 9 10 11 12 13}; do
   echo -n "region $ph: "
   TQ_DEBUG=$((ph<<16)) python bench.py --workload $W --no-side --no-cpu-baseline --latency-queries 0 --steps 2 --warmup 1 "$@" 2>/dev/null | tail -1 | python -c '
 import json,sys
