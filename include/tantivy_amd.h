@@ -301,8 +301,9 @@ typedef struct tq_batch_stats {
   uint32_t tiles;
   uint32_t chunks;
   uint32_t batches_averaged;  /* how many batches kernel_ms / total_ms average (<= 16) */
-  float host_plan_ms;         /* host time inside tq_search_batch_device (validate + plan + stage +
-                                 enqueue), mean over the calls since the last tq_last_batch_stats */
+  float host_plan_ms;         /* host CPU time inside tq_search_batch_device (validate + plan + stage +
+                                 enqueue; waiting for the previous batch's staging copy excluded),
+                                 mean over the calls since the last tq_last_batch_stats */
 } tq_batch_stats;
 int tq_last_batch_stats(tq_segment *seg, tq_batch_stats *out);
 /* Bytes the segment keeps resident in HBM, by kind: the reference's own sub-files (copied
@@ -333,10 +334,12 @@ int tq_segment_get_stats(tq_segment *seg, tq_segment_stats *out);
  *        (serializer.rs:130-135); a caller whose Bm25Weights use global statistics passes
  *        ((1 + d)^2 - 1) * 1e6 with d = relative difference of the two averages and pruning
  *        stays exact (the reference accepts the approximation, term_scorer.rs:58-70),
- *        "dense_budget_x" (default 6: bitmaps + doc matrix + position directories together stay
- *        below this multiple of the segment), "docmat" (0/1, default 1: the first 56 dense lists
- *        also get a column in a doc-major matrix: one 8-byte word per doc = fieldnorm id + the
- *        doc's membership in those lists), "device_prepare" (0/1, default 0: tq_term_prepare
+ *        "dense_budget_x" (default 8: bitmaps + byte-wide term freqs of the dense lists + doc matrix
+ *        + doc signatures + position directories together stay below this multiple of the
+ *        segment), "docmat" (0/1, default 1: the first 56 dense lists also get a column in a
+ *        doc-major matrix: one 8-byte word per doc = fieldnorm id + the doc's membership in those
+ *        lists), "docsig" (0/1, default 1: one more 8-byte word per doc, a 64-bit signature of the
+ *        prepared lists WITHOUT a column: a clear bit proves the doc is not in the list), "device_prepare" (0/1, default 0: tq_term_prepare
  *        works on the device copy even when a host copy exists; always so for segments from
  *        tq_segment_upload_device),
  *        "use_dpp" (0/1: DPP or ds_bpermute prefix sums) */

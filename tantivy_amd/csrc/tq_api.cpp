@@ -136,7 +136,8 @@ struct Options {
   int use_dpp = 1;
   int dense = 1;      // build bitmaps for dense lists at tq_term_prepare
   int dense_ratio = TQD_DENSE_RATIO;  // ... for lists with doc_freq >= max_doc / dense_ratio
-  int dense_budget_x = 6;  // ... while bitmaps + doc matrix stay below this multiple of the segment's bytes
+  int dense_budget_x = 8;  // ... while bitmaps + byte-wide tfs + doc matrix + signatures + position directories
+                           // stay below this multiple of the segment's bytes
   int use_dense = 1;  // let the scan kernels use them
   int docmat = 1;     // also build the doc-major matrix of the dense lists
   int docsig = 1;     // ... and the per-doc signature word of the lists without a column
@@ -298,7 +299,6 @@ int add_to_doc_signatures(tq_segment *s, uint32_t handle) {
     HIP_TRY(hipMemsetAsync(s->d_docsig, 0, sig_bytes + PAD, s->stream));
     s->dense_bytes_total += sig_bytes;
     s->bytes_docsig = sig_bytes;
-    s->dseg.docsig = s->d_docsig;
   }
   int rc = sync_terms(s, s->stream);
   if (rc != TQ_OK) return rc;
@@ -1634,7 +1634,11 @@ int build_share_plan(tq_segment *s, Group &g, PlanScratch &ps) {
   // cost of every position's tasks together (a block costs its decode + one test per lead): a
   // position with little work is cut into smaller tasks, so that it still fills the chip and its
   // launch does not end on a few long tasks
-  static const uint32_t kPhaseTasks = std::max<uint32_t>(1u, tune_u32("TQ_US_PHASE_TASKS", 8192));
+  // (measured: or5 at k = 100 wants ~8192 tasks per position — 4096: +10 % time, 12288: +13 % — the
+  // mixed stream at k = 10 ~4096: its thresholds settle after a few docs, and longer tasks keep the
+  // feedback inside one wave: 8.85 against 9.7 ms)
+  static const uint32_t kPhaseTasksEnv = tune_u32("TQ_US_PHASE_TASKS", 0);
+  const uint32_t kPhaseTasks = kPhaseTasksEnv ? kPhaseTasksEnv : (g.max_k <= 16u ? 4096u : 8192u);
   uint64_t phase_cost[TQD_US_MAX_TERMS] = {};
   for (size_t r0 = 0; r0 < keys.size();) {
     size_t r1 = r0;
@@ -2149,10 +2153,11 @@ int search_batch_impl(tq_segment *s, const tq_query *queries, uint32_t n_queries
     }
   }
   const auto tr1 = std::chrono::steady_clock::now();
-  if (s->stage_in_flight) {
+  if (s->stage_in_flight) {  // (the pinned staging buffer is reused: the previous batch's copy must have left it)
     HIP_TRY(hipEventSynchronize(s->ev_stage_done));
     s->stage_in_flight = false;
   }
+  const auto tr1w = std::chrono::steady_clock::now();  // time spent waiting for the GPU is not planning time
   static const bool kCopyStream = tune_u32("TQ_COPY_STREAM", 1) != 0;
   const int bx = kCopyStream ? (int)(s->batches_enqueued & 1u) : 0;
   DevBuf &dstage = bx ? s->d_stage_alt : s->d_stage;
@@ -2306,6 +2311,7 @@ int search_batch_impl(tq_segment *s, const tq_query *queries, uint32_t n_queries
         if (sp.n_tasks <= sp.task_begin) continue;
         sp.task_counter = counters + ph;
         sp.table_base = (const uint8_t *)s->plan->share_table_base;
+        sp.docsig = s->d_docsig;
         sp.grid = std::min<uint32_t>(share_grid, sp.n_tasks - sp.task_begin);
         const hipError_t e = tqk_launch_share(sp, g.kpl, gst);
         if (e != hipSuccess) return fail(TQ_ERR_HIP, "shared-union launch: %s", hipGetErrorString(e));
@@ -2397,7 +2403,7 @@ int search_batch_impl(tq_segment *s, const tq_query *queries, uint32_t n_queries
   s->stats_pending = true;
   (void)total_parts;
   drain_on_error.armed = false;
-  s->host_ms_sum += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tr0).count();
+  s->host_ms_sum += std::chrono::duration<double, std::milli>((std::chrono::steady_clock::now() - tr0) - (tr1w - tr1)).count();
   ++s->host_ms_n;
   return TQ_OK;
 }

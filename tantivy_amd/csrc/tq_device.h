@@ -126,10 +126,6 @@ struct TqdSegment {
   // membership in every dense list of the query — the scan kernels are bound by the number of
   // divergent gathers, not by bytes.  Derived data, built at tq_term_prepare like the bitmaps.
   const uint64_t *docmat;
-  // signature word of the lists WITHOUT a column (or null): docsig[d] bit b set iff d is in some
-  // prepared column-less list whose signature bit is b (TqdTermHead::has_freq bits 16..23 = b + 1).
-  // Clear bit = not in the list; set bit = maybe.
-  const uint64_t *docsig;
   uint32_t max_doc;
   uint32_t const_fieldnorm_id;
   uint32_t min_fieldnorm_id;  // smallest fieldnorm id present (lower bound of every doc's norm)

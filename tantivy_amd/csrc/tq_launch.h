@@ -54,6 +54,11 @@ struct TqkShareParams {
   uint32_t *thr_val;            // [n_queries] current lower bound of each query's k-th best score
   uint32_t *task_counter;       // next task to hand out (zeroed per batch)
   const uint8_t *table_base;    // TqdLead::dense_off / tf8_off count 8-byte units from here
+  // signature word of the lists WITHOUT a column (or null): docsig[d] bit b set iff d is in some
+  // prepared column-less list whose signature bit is b (TqdTermHead::has_freq bits 16..23 = b + 1).
+  // Clear bit = not in the list; set bit = maybe.  (Not in TqdSegment: the other scan kernels do
+  // not use it, and two more scalar registers cost the AND kernel 7 % under its SGPR cap.)
+  const uint64_t *docsig;
   uint64_t *stage;              // [grid][TQD_US_GROUP][capl] per-wave staging lists
   uint64_t *lists;              // per-query result lists (query q: entries part_start .. + n_parts)
   uint32_t *list_count;         // [n_queries] entries written so far

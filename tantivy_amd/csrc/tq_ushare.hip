@@ -295,7 +295,7 @@ ushare_kernel(TqkShareParams p) {
     // fieldnorm id + membership in the dense lists: the doc-matrix word again (a gather for the
     // survivors only; stage F does not carry it through the queue)
     const uint64_t mw = alive ? seg.docmat[doc] : 0ull;
-    const uint64_t sg = (alive && seg.docsig) ? seg.docsig[doc] : 0ull;
+    const uint64_t sg = (alive && p.docsig) ? p.docsig[doc] : 0ull;
     const float norm = L.cache[(uint32_t)mw & 0xFFu];
     uint32_t bits = 0;
     {
@@ -580,7 +580,7 @@ ushare_kernel(TqkShareParams p) {
       return (uint32_t)lane < n_leads && sortable(L.lead[lane].suffix * 1.000001f) >= L.lthr[lane];
     };
     uint32_t live = (uint32_t)__ballot(lead_alive());
-    const bool task_sig = seg.docsig != nullptr &&
+    const bool task_sig = p.docsig != nullptr &&
                           __ballot((uint32_t)lane < n_leads && ((L.lead[lane].info >> 12) & 1u)) != 0ull;
     te(2u);
 
@@ -680,8 +680,8 @@ ushare_kernel(TqkShareParams p) {
         const uint64_t mw1 = v1 ? seg.docmat[c1] : 0ull;
         uint64_t sg0 = 0, sg1 = 0;  // signature words, when a lead of the task tests them
         if (task_sig) {
-          sg0 = v0 ? seg.docsig[c0] : 0ull;
-          sg1 = v1 ? seg.docsig[c1] : 0ull;
+          sg0 = v0 ? p.docsig[c0] : 0ull;
+          sg1 = v1 ? p.docsig[c1] : 0ull;
         }
         const uint32_t nid0 = (uint32_t)mw0 & 0xFFu, nid1 = (uint32_t)mw1 & 0xFFu;
         const float f0 = (float)t0, f1 = (float)t1;
