@@ -2189,6 +2189,7 @@ int search_batch_impl(tq_segment *s, const tq_query *queries, uint32_t n_queries
     sk.match_counter = s->d_match_counter;
     sk.query_matches = (uint32_t *)s->d_qmatches.p;
     sk.out_index = (const uint32_t *)((const uint8_t *)dstage.p + g.o_outidx);
+    sk.docsig = s->opt.use_dense ? s->d_docsig : nullptr;
     memcpy(hs + g.o_sinks, &sk, sizeof sk);
   }
   const auto tr2 = std::chrono::steady_clock::now();

@@ -13,6 +13,7 @@ struct TqkSinks {
   unsigned long long *match_counter;  // docs scored by the whole launch
   uint32_t *query_matches;            // per query of the BATCH (through out_index): docs scored
   const uint32_t *out_index;          // launch-group query -> batch query
+  const uint64_t *docsig;             // signature words of the lists without a column, or null (see TqkShareParams)
 };
 
 struct TqkScanParams {

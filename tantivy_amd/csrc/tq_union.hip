@@ -330,8 +330,14 @@ struct UnionLds {  // per wavefront
   float suffix[TQD_MAX_TERMS + 1];
   // pure unions: survivors of the membership stage (doc, tf, membership bits | fieldnorm id << 16,
   // what the lists after the leader can still add) and per-query tables read by broadcast
-  uint32_t q2_doc[BOOL ? 1 : 127], q2_tf[BOOL ? 1 : 127], q2_mx[BOOL ? 1 : 127];
+  // (boolean queries: survivors of the doc-matrix pre-stage, doc and tf only)
+  uint32_t q2_doc[127], q2_tf[127], q2_mx[BOOL ? 1 : 127];
   float q2_rest[BOOL ? 1 : 127];
+  // boolean queries: doc-matrix bits of every Must clause after the leader set whose terms all
+  // have a column (a doc with none of them cannot match), and of the MustNot terms with a column
+  uint64_t cmask[BOOL ? TQD_MAX_TERMS : 1], csig[BOOL ? TQD_MAX_TERMS : 1];  // (columns / signature bits)
+  uint64_t bmask[BOOL ? 3 : 1];  // [0] MustNot columns, [1] / [2] columns / signature bits of the lead Must
+                                 // clause (optional leaders; 0 = no test)
   float wgt[TQD_MAX_TERMS];
   const uint2 *dptr[TQD_MAX_TERMS];
   uint32_t mshift[TQD_MAX_TERMS];  // bit of the list's column in a doc-matrix word
@@ -362,6 +368,11 @@ __device__ __forceinline__ void union_body(const TqkScanParams &p) {
   uint32_t q1n = 0, q2n = 0;
   uint32_t dense_mask = 0, sparse_mask = 0;  // pure unions: lists with / without a bitmap
   uint32_t mat_mask = 0;                     // ... with a column in the doc matrix
+  uint32_t n_cmask = 0;                      // boolean queries: testable Must clauses after the leader set
+  uint32_t sig_mask = 0;                     // ... lists with a signature bit instead of a column
+  bool lead_test = false;                    // ... the lead Must clause is testable (optional leaders)
+  const uint64_t *docsig = nullptr;          // ... the segment's signature words
+  const bool use_sig = BOOL && !(p.debug & 65536u);
   uint32_t slots_sum = 0;  // checksum of the threshold slots at the last radix select
   float slack_abs = 0.0f;
   // leader of the current tile
@@ -449,6 +460,64 @@ __device__ __forceinline__ void union_body(const TqkScanParams &p) {
       mat_mask = (uint32_t)__ballot(slot < TQD_MAT_SLOTS);
       sparse_mask = ((1u << nt) - 1u) & ~dense_mask;
       slack_abs = suf * 4.0e-6f;  // bounds summed by add-then-subtract: absolute slack
+    } else {
+      // boolean queries: the doc-matrix pre-stage (stageB0) needs every list's column and weight,
+      // the column masks of the all-column Must clauses and of the MustNot terms
+      // a list's membership bit: its doc-matrix column (exact), else its signature bit (a clear
+      // bit proves absence, a set one means "maybe"), else none: mshift < 64 / 64..127 / >= 128
+      docsig = use_sig ? sload(&p.sinks->docsig) : nullptr;
+      uint32_t slot = 0xFFFFFFFFu, sbit = 0xFFFFFFFFu;
+      if ((uint32_t)lane < nt) {
+        const TqdTerm *tt = p.terms + Q->term[lane];
+        if (p.use_dense && tt->dense && seg.docmat) slot = ((tt->has_freq >> 8) & 0xFFu) - 1u;
+        if (slot >= TQD_MAT_SLOTS && docsig) sbit = ((tt->has_freq >> 16) & 0xFFu) - 1u;
+        L.wgt[lane] = Q->weight[lane];
+        L.mshift[lane] = slot < TQD_MAT_SLOTS ? 8u + slot : (sbit < 64u ? 64u + sbit : 128u);
+      }
+      mat_mask = (uint32_t)__ballot(slot < TQD_MAT_SLOTS);
+      sig_mask = (uint32_t)__ballot(sbit < 64u);
+      slack_abs = suf * 4.0e-6f;
+      uint64_t notm = 0, leadm = 0, leads = 0, cm = 0, cs = 0;
+      bool call = true;  // every term of the current clause has a column or a signature bit
+      n_cmask = 0;
+      bool lead_all = true;
+      for (uint32_t m = 0; m < nt; ++m) {
+        const uint32_t role = (roles >> (2u * m)) & 3u;
+        const bool has = (mat_mask >> m) & 1u, hsig = (sig_mask >> m) & 1u;
+        const uint64_t bit = has ? 1ull << (8u + (uint32_t)__builtin_amdgcn_readlane((int)slot, (int)m)) : 0ull;
+        const uint64_t sgb = hsig ? 1ull << (uint32_t)__builtin_amdgcn_readlane((int)sbit, (int)m) : 0ull;
+        if (role == TQD_ROLE_MUST_NOT) {
+          notm |= bit;  // (only an exact bit may exclude)
+        } else if (m < n_lead) {
+          if (m >= n_opt_lead) {  // the lead Must clause (when optional lists lead in front of it)
+            leadm |= bit;
+            leads |= sgb;
+            lead_all = lead_all && (has || hsig);
+          }
+        } else if (role == TQD_ROLE_MUST) {
+          cm |= bit;
+          cs |= sgb;
+          call = call && (has || hsig);
+          if ((clause_end >> m) & 1u) {
+            if (call && n_cmask < TQD_MAX_TERMS) {
+              if (lane == 0) {
+                L.cmask[n_cmask] = cm;
+                L.csig[n_cmask] = cs;
+              }
+              ++n_cmask;
+            }
+            cm = 0;
+            cs = 0;
+            call = true;
+          }
+        }
+      }
+      if (lane == 0) {
+        L.bmask[0] = notm;
+        L.bmask[1] = (n_opt_lead && lead_all) ? leadm : 0ull;
+        L.bmask[2] = (n_opt_lead && lead_all) ? leads : 0ull;
+      }
+      lead_test = n_opt_lead && lead_all;
     }
     wave_mem_fence();
     min_norm = sload(p.caches + (size_t)ci * 256u +
@@ -464,16 +533,19 @@ __device__ __forceinline__ void union_body(const TqkScanParams &p) {
   };
 
   // ---- stage B: the other lists of <= 64 candidates of leader li
-  auto stageB = [&](uint32_t n) __attribute__((always_inline)) {
-    const uint32_t base = q1n - n;
-    q1n = base;
-    if (p.debug & 64u) n_matches += n;  // COUNTERS
+  auto stageB = [&](uint32_t n, bool from_q2) __attribute__((always_inline)) {
+    const uint32_t base = (from_q2 ? q2n : q1n) - n;
+    if (from_q2)
+      q2n = base;
+    else
+      q1n = base;
+    if (p.debug & (from_q2 ? 128u : 64u)) n_matches += n;  // COUNTERS
     bool alive = (uint32_t)lane < n;
     uint32_t doc = 0, tf = 0;
     float norm = 0.0f, s = 0.0f;
     if (alive) {
-      doc = L.q1_doc[base + lane];
-      tf = L.q1_tf[base + lane];
+      doc = from_q2 ? L.q2_doc[base + lane] : L.q1_doc[base + lane];
+      tf = from_q2 ? L.q2_tf[base + lane] : L.q1_tf[base + lane];
       norm = L.cache[fieldnorm_id(seg, doc)];
       s = bm25(w_lead, norm, tf);
       if (prune) alive = sortable((s + L.suffix[li + 1u]) * 1.000001f) >= thr;
@@ -771,9 +843,66 @@ __device__ __forceinline__ void union_body(const TqkScanParams &p) {
     }
     te(8u);
   };
+  // Boolean queries, stage B0 (64 candidates of leader li): ONE doc-matrix gather — fieldnorm id
+  // and the membership in every list with a column — settles most candidates on registers, before
+  // the leader is scored and before any list is probed: a doc held by an earlier list of the leader
+  // set belongs to that list's tile; a MustNot term holds it; a Must clause whose terms all have
+  // columns holds it in none of them (intersection.rs:120-179 / exclude.rs with the seeks replaced
+  // by bit tests); or "leader score + weights of the other lists that hold or may hold it" cannot
+  // reach the threshold.  Survivors (11..20 % on the bench shapes) take the exact walk of stage B.
+  auto stageB0 = [&](uint32_t n) __attribute__((always_inline)) {
+    const uint32_t base = q1n - n;
+    q1n = base;
+    if (p.debug & 64u) n_matches += n;  // COUNTERS
+    bool alive = (uint32_t)lane < n;
+    uint32_t doc = 0, tf = 0;
+    if (alive) {
+      doc = L.q1_doc[base + lane];
+      tf = L.q1_tf[base + lane];
+    }
+    const uint64_t mw = alive ? seg.docmat[doc] : 0ull;
+    const uint64_t sg = (alive && docsig) ? docsig[doc] : 0ull;
+    // ownership: lists of the leader set before li
+    uint64_t own = 0;
+    for (uint32_t mm = mat_mask & ((1u << (li < n_lead ? li : n_lead)) - 1u); mm; mm &= mm - 1u)
+      own |= 1ull << L.mshift[__builtin_ctz(mm)];
+    if (mw & (own | L.bmask[0])) alive = false;
+    if (li < n_opt_lead && lead_test && !((mw & L.bmask[1]) | (sg & L.bmask[2]))) alive = false;
+    for (uint32_t c = 0; c < n_cmask; ++c)
+      if (!((mw & L.cmask[c]) | (sg & L.csig[c]))) alive = false;
+    if (prune && alive) {
+      float rest = 0.0f;
+      for (uint32_t m = 0; m < nt; ++m) {
+        if (m == li) continue;
+        const float w = L.wgt[m];  // (0 for MustNot terms)
+        const uint32_t sh = L.mshift[m];
+        const uint64_t src = sh < 64u ? mw : sg;
+        rest += sh < 128u ? (((src >> (sh & 63u)) & 1ull) ? w : 0.0f) : w;
+      }
+      const float sl = bm25_bound(w_lead, L.cache[(uint32_t)mw & 0xFFu], tf);
+      alive = sortable((sl + rest) * 1.000004f + slack_abs) >= thr;
+    }
+    const uint64_t mk = __ballot(alive);
+    if (mk) {
+      const uint32_t pos = q2n + mbcnt64(mk);
+      wave_mem_fence();
+      if (alive) {
+        L.q2_doc[pos] = doc;
+        L.q2_tf[pos] = tf;
+      }
+      wave_mem_fence();
+      q2n += (uint32_t)__popcll(mk);
+    }
+  };
+  const bool use_b0 = BOOL && PRUNE && seg.docmat != nullptr && !(p.debug & 32768u);
   auto step64 = [&]() __attribute__((always_inline)) {  // q1 holds >= 64 candidates
     if constexpr (BOOL) {
-      stageB(64u);
+      if (use_b0 && prune) {
+        stageB0(64u);
+        while (q2n >= 64u) stageB(64u, true);
+      } else {
+        stageB(64u, false);
+      }
     } else {
       stageB_pure(64u);
       while (q2n >= 64u) stageC(64u);
@@ -781,7 +910,15 @@ __device__ __forceinline__ void union_body(const TqkScanParams &p) {
   };
   auto drain = [&]() __attribute__((always_inline)) {
     if constexpr (BOOL) {
-      while (q1n) stageB(q1n < 64u ? q1n : 64u);
+      if (use_b0 && prune) {
+        while (q1n) {
+          stageB0(q1n < 64u ? q1n : 64u);
+          while (q2n >= 64u) stageB(64u, true);
+        }
+        while (q2n) stageB(q2n < 64u ? q2n : 64u, true);
+      } else {
+        while (q1n) stageB(q1n < 64u ? q1n : 64u, false);
+      }
     } else {
       while (q1n) {
         stageB_pure(q1n < 64u ? q1n : 64u);
