@@ -1147,7 +1147,7 @@ struct ShareKey {  // one (query, list) pair of the shared-union group
   uint32_t term, q;
 };
 struct PlanScratch {
-  Group groups[6];
+  Group groups[7];
   // shared-union group (tq_ushare.hip): leads grouped by term, tasks in launch order
   std::vector<ShareKey> share_keys;
   std::vector<TqdLead> leads;
@@ -1875,7 +1875,10 @@ int search_batch_impl(tq_segment *s, const tq_query *queries, uint32_t n_queries
   // launch groups: AND queries whose non-leader lists all have a bitmap run a leaner kernel
   // instantiation (no seek / block-search code: fewer registers, less LDS, more waves per CU)
   // boolean queries (clauses with roles) run the candidate-driven union kernel's BOOL instantiation
-  constexpr int kGroups = 6, kAndGeneral = 3, kBool = 4, kShare = 5;
+  constexpr int kGroups = 7, kAndGeneral = 3, kBool = 4, kShare = 5, kPhSweep = 6;
+  // phrases whose lists ALL have a bitmap, byte-wide tfs and a position directory, the rarest one
+  // still about a posting per bitmap word: the bitmap-AND sweep (phrase_sweep_kernel)
+  static const uint32_t kPhSweepRatio = tune_u32("TQ_PH_SWEEP_RATIO", 64);  // 0 = never
   // pure unions, pruned, k <= 128, <= 8 terms, on a segment with a doc matrix: the shared-union
   // launch (term-major, tq_ushare.hip); everything else keeps the per-query union kernels
   static const bool kUseShare = tune_u32("TQ_USHARE", 1) != 0;
@@ -1884,6 +1887,7 @@ int search_batch_impl(tq_segment *s, const tq_query *queries, uint32_t n_queries
   for (Group &g : groups) g.reset();
   groups[kBool].mode = TQ_MODE_OR;
   groups[kShare].mode = TQ_MODE_OR;
+  groups[kPhSweep].mode = TQ_MODE_PHRASE;
   groups[0].mode = TQ_MODE_AND;
   groups[1].mode = TQ_MODE_OR;
   groups[2].mode = TQ_MODE_PHRASE;
@@ -1932,6 +1936,7 @@ int search_batch_impl(tq_segment *s, const tq_query *queries, uint32_t n_queries
         return fail(TQ_ERR_INVALID, "query %u: unknown term handle %u", qi, q.terms[i]);
     }
     int mode = q.mode;
+    bool ph_sweep = false;
     uint32_t n_tiles = 0, tile_cost = 1;
     bool all_dense = true;
     uint64_t qbytes = 8ull * q.k;
@@ -1985,12 +1990,18 @@ int search_batch_impl(tq_segment *s, const tq_query *queries, uint32_t n_queries
           }
         } else {  // phrase: leader-block tiles like AND; every match also walks its positions
           const uint32_t lead_blocks = s->terms[dq.term[0]].n_blocks;
+          ph_sweep = kPhSweepRatio && q.n_terms <= 4u && s->opt.use_dense &&
+                     (uint64_t)s->terms[dq.term[0]].doc_freq * kPhSweepRatio >= s->max_doc;
+          for (uint32_t i = 0; ph_sweep && i < q.n_terms; ++i) {
+            const TermHost &th = s->terms[dq.term[i]];
+            if (!(th.dense_blob && th.tf8_blob && th.posdir_blob)) ph_sweep = false;
+          }
           // the lean instantiation needs a bitmap, a doc-matrix column and a position directory
           // for every non-leader list
-          for (uint32_t i = 1; i < q.n_terms; ++i) {
+          for (uint32_t i = 1; !ph_sweep && i < q.n_terms; ++i) {
             const TermHost &th = s->terms[dq.term[i]];
             const bool col = ((s->h_dterms[dq.term[i]].has_freq >> 8) & 0xFFu) != 0u;
-            if (!(th.dense_blob && th.posdir_blob && col && s->opt.use_dense && s->d_docmat))
+            if (!(th.dense_blob && th.posdir_blob && th.tf8_blob && col && s->opt.use_dense && s->d_docmat))
               phrase_all_dense = false;
           }
           // (64-block tiles: one leader block per lane of the pre-filter; 32 was 10 % slower)
@@ -1998,6 +2009,11 @@ int search_batch_impl(tq_segment *s, const tq_query *queries, uint32_t n_queries
           dq.tile_blocks = kPhTile;
           tile_cost = 2u * kPhTile;
           n_tiles = (lead_blocks + dq.tile_blocks - 1) / dq.tile_blocks;
+          if (ph_sweep) {  // tiles are runs of 2048 bitmap words (phrase_sweep_kernel's SWEEP_WORDS)
+            const uint32_t n_words = (s->max_doc + 31u) / 32u;
+            n_tiles = (n_words + 2047u) / 2048u;
+            tile_cost = 64u;
+          }
         }
       }
     }
@@ -2083,7 +2099,7 @@ int search_batch_impl(tq_segment *s, const tq_query *queries, uint32_t n_queries
     }
     algo_bytes += qbytes;
     dq.n_tiles = n_tiles;
-    Group &g = groups[bool_done ? kBool : (share ? kShare : ((mode == TQ_MODE_AND && !all_dense) ? kAndGeneral : mode))];
+    Group &g = groups[bool_done ? kBool : (share ? kShare : (ph_sweep ? kPhSweep : ((mode == TQ_MODE_AND && !all_dense) ? kAndGeneral : mode)))];
     dq.mode = (uint32_t)mode;
     g.queries.push_back(dq);
     g.tile_cost.push_back(tile_cost);
@@ -2101,7 +2117,7 @@ int search_batch_impl(tq_segment *s, const tq_query *queries, uint32_t n_queries
     if (crc != TQ_OK) return crc;
   }
   // partial lists of all groups share one buffer; its stride is per group (kpl*64 keys)
-  size_t part_off_bytes[kGroups] = {0, 0, 0, 0, 0, 0};
+  size_t part_off_bytes[kGroups] = {0, 0, 0, 0, 0, 0, 0};
   for (int gi = 0; gi < kGroups; ++gi) {
     Group &g = groups[gi];
     part_off_bytes[gi] = partial_bytes;
@@ -2272,7 +2288,7 @@ int search_batch_impl(tq_segment *s, const tq_query *queries, uint32_t n_queries
     HIP_TRY(hipEventRecord(s->ev_fork, st));
     HIP_TRY(hipStreamWaitEvent(s->side_stream, s->ev_fork, 0));
   }
-  const int launch_order[kGroups] = {kAndGeneral, kBool, kShare, 1, 2, 0};  // long serial chains first
+  const int launch_order[kGroups] = {kAndGeneral, kBool, kShare, 1, 2, kPhSweep, 0};  // long serial chains first
   for (int oi = 0; oi < kGroups; ++oi) {
     const int gi = launch_order[oi];
     Group &g = groups[gi];
@@ -2337,7 +2353,7 @@ int search_batch_impl(tq_segment *s, const tq_query *queries, uint32_t n_queries
     p.all_dense = (gi == 0 || (gi == 2 && phrase_all_dense)) ? 1u : 0u;
     static const uint32_t kDebug = tune_u32("TQ_DEBUG", 0);
     p.debug = kDebug;
-    p.or_windows = (or_windows_opt && gi != kBool) ? 1u : 0u;
+    p.or_windows = gi == kPhSweep ? 2u : ((or_windows_opt && gi != kBool) ? 1u : 0u);  // (2 = phrase sweep)
     p.boolean = gi == kBool ? 1u : 0u;
     p.small_k = g.max_k <= 16u ? 1u : 0u;
     p.bound_slack = co.bound_slack;

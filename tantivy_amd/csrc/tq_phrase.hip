@@ -20,8 +20,13 @@ namespace {
 // The reference runs phrases through the default for_each_pruning_scorer (a threshold filter on
 // finished scores), so there is nothing to prune before the positions are read.
 #define TQD_PH_MAX_TERMS 8
+#ifndef TQ_PH_HOIST
+#define TQ_PH_HOIST 0  // 1: the block records of every term's position run are loaded together (one round
+                       // trip instead of one per term; 16 more live registers: spills at 96 VGPRs)
+#endif
 #ifndef TQ_PH_WAVES_DENSE
-#define TQ_PH_WAVES_DENSE 5  // occupancy target of the all-dense instantiation (waves per SIMD): 96 VGPRs
+#define TQ_PH_WAVES_DENSE 4  // occupancy target of the all-dense instantiation (waves per SIMD): the level-parallel
+                             // list stage needs ~100 VGPRs (5 waves: 56..84 B of scratch, 2.2..2.5 ms against 1.85)
                              // without scratch beat 80 with 12 B of it by 2 %
 #endif
 // DENSE: every non-leader list of every query of the launch has a bitmap, a doc-matrix column and
@@ -37,6 +42,10 @@ struct PhraseLds {  // per wavefront
   const uint64_t *pt_blk[NT_MAX];
   const uint32_t *pt_tail[NT_MAX];
   uint32_t pt_nblk[NT_MAX], pt_off[NT_MAX];
+  // DENSE: bitmap + rank directory, byte-wide tfs and position directory of every list
+  const uint2 *pt_dense[DENSE ? NT_MAX : 1];
+  const uint8_t *pt_tf8[DENSE ? NT_MAX : 1];
+  const uint32_t *pt_dir[DENSE ? NT_MAX : 1];
 };
 
 struct PosCursor {
@@ -95,13 +104,17 @@ struct PosRun {
   uint32_t b[2];           // bit width; 0xFFFFFFFF = tail (plain u32 values)
   uint32_t v0;             // index of delta 0 inside block 0 (tail: inside the tail array)
 };
-__device__ __forceinline__ PosRun pos_run(const uint8_t *pos, const uint64_t *pos_blk,
-                                          const uint32_t *pos_tail, uint32_t n_pb, uint32_t i) {
+// the two block records of a run (loaded unconditionally, clamped: independent loads)
+__device__ __forceinline__ void pos_run_records(const uint64_t *pos_blk, uint32_t n_pb, uint32_t i,
+                                                uint64_t &e0, uint64_t &e1) {
+  const uint32_t pb = i >> 7;
+  e0 = pos_blk[pb < n_pb ? pb : 0u];
+  e1 = pos_blk[pb + 1u < n_pb ? pb + 1u : 0u];
+}
+__device__ __forceinline__ PosRun pos_run_of(const uint8_t *pos, uint64_t e0, uint64_t e1,
+                                             const uint32_t *pos_tail, uint32_t n_pb, uint32_t i) {
   PosRun r;
   const uint32_t pb = i >> 7;
-  // both records are loaded unconditionally (clamped): independent loads
-  const uint64_t e0 = pos_blk[pb < n_pb ? pb : 0u];
-  const uint64_t e1 = pos_blk[pb + 1u < n_pb ? pb + 1u : 0u];
   const bool t0 = pb >= n_pb, t1 = pb + 1u >= n_pb;
   r.base[0] = t0 ? reinterpret_cast<const uint8_t *>(pos_tail) : pos + (e0 & 0x00FFFFFFFFFFFFFFull);
   r.b[0] = t0 ? 0xFFFFFFFFu : (uint32_t)(e0 >> 56);
@@ -111,6 +124,12 @@ __device__ __forceinline__ PosRun pos_run(const uint8_t *pos, const uint64_t *po
   r.base[1] = t1 ? reinterpret_cast<const uint8_t *>(pos_tail) : pos + (e1 & 0x00FFFFFFFFFFFFFFull);
   r.b[1] = t1 ? 0xFFFFFFFFu : (uint32_t)(e1 >> 56);
   return r;
+}
+__device__ __forceinline__ PosRun pos_run(const uint8_t *pos, const uint64_t *pos_blk,
+                                          const uint32_t *pos_tail, uint32_t n_pb, uint32_t i) {
+  uint64_t e0, e1;
+  pos_run_records(pos_blk, n_pb, i, e0, e1);
+  return pos_run_of(pos, e0, e1, pos_tail, n_pb, i);
 }
 // delta k of the run (k clamped by the caller): two independent 4-byte loads
 __device__ __forceinline__ uint32_t pos_run_delta(const PosRun &r, uint32_t k) {
@@ -189,6 +208,11 @@ __global__ __launch_bounds__(64, DENSE ? TQ_PH_WAVES_DENSE : 5) void phrase_kern
       L.pt_tail[lane] = tt->pos_tail;
       L.pt_nblk[lane] = tt->n_pos_blocks;
       L.pt_off[lane] = Q->phrase_off[lane];
+      if constexpr (DENSE) {
+        L.pt_dense[lane] = tt->dense;
+        L.pt_tf8[lane] = tt->tf8;
+        L.pt_dir[lane] = tt->pos_dir;
+      }
       if (lane && seg.docmat && tt->dense) slot = ((tt->has_freq >> 8) & 0xFFu) - 1u;
     }
     wave_mem_fence();
@@ -216,7 +240,60 @@ __global__ __launch_bounds__(64, DENSE ? TQ_PH_WAVES_DENSE : 5) void phrase_kern
       lead_tf = L.q2_tf[base + lane];
       lead_pi = L.q2_pi[base + lane];
     }
-    for (uint32_t m = 1; m < nt; ++m) {
+    if constexpr (DENSE) {
+      // Every other list has a bitmap, byte-wide tfs and a position directory: the chain per list
+      // is bitmap word (posting index) -> {the four tf bytes of its group, the group's directory
+      // entry}, and the levels of ALL lists are in flight together: two dependent round trips for
+      // the whole candidate (it was bitmap word -> block record -> packed tf row, list after list).
+      uint2 wd[NT_MAX - 1];
+#pragma unroll
+      for (int m = 1; m < NT_MAX; ++m) {
+        wd[m - 1] = make_uint2(0u, 0u);
+        if ((uint32_t)m < nt && alive) wd[m - 1] = L.pt_dense[m][doc >> 5];
+      }
+      uint32_t piv[NT_MAX - 1], tw[NT_MAX - 1], dv[NT_MAX - 1];
+#pragma unroll
+      for (int m = 1; m < NT_MAX; ++m) {
+        const uint32_t bit = doc & 31u;
+        if ((uint32_t)m < nt) alive = alive && ((wd[m - 1].x >> bit) & 1u);
+        piv[m - 1] = wd[m - 1].y + (uint32_t)__popc(wd[m - 1].x & ((1u << bit) - 1u));
+      }
+#pragma unroll
+      for (int m = 1; m < NT_MAX; ++m) {
+        tw[m - 1] = 0;
+        dv[m - 1] = 0;
+        if ((uint32_t)m < nt && alive) {
+          tw[m - 1] = *reinterpret_cast<const uint32_t *>(L.pt_tf8[m] + (piv[m - 1] & ~3u));
+          dv[m - 1] = L.pt_dir[m][piv[m - 1] >> 2];
+        }
+      }
+      if (!__ballot(alive)) {
+        tick(5u);
+        return;
+      }
+#pragma unroll
+      for (int m = 1; m < NT_MAX; ++m) {
+        if ((uint32_t)m < nt) {
+          const uint32_t l0 = piv[m - 1] & 3u;
+          const uint32_t b0 = tw[m - 1] & 0xFFu, b1 = (tw[m - 1] >> 8) & 0xFFu, b2 = (tw[m - 1] >> 16) & 0xFFu,
+                         b3 = tw[m - 1] >> 24;
+          uint32_t tf = l0 == 0u ? b0 : (l0 == 1u ? b1 : (l0 == 2u ? b2 : b3));
+          uint32_t ex = (l0 > 0u ? b0 : 0u) + (l0 > 1u ? b1 : 0u) + (l0 > 2u ? b2 : 0u);
+          // a saturated byte (tf >= 255) among the ones used: the packed values are read instead
+          const bool sat = alive && (tf == 255u || (l0 > 0u && b0 == 255u) || (l0 > 1u && b1 == 255u) ||
+                                     (l0 > 2u && b2 == 255u));
+          if (__ballot(sat)) {
+            const TermRef tr = load_term(p.terms, sload(&Q->term[m]));
+            if (sat) group_tfs(idx, tr, tr.rec[piv[m - 1] >> 7], piv[m - 1] & 127u, tf, ex);
+          }
+          if (alive) {
+            L.ph_tf[m - 1][lane] = tf;
+            L.ph_pi[m - 1][lane] = dv[m - 1] + ex;
+          }
+        }
+      }
+    }
+    for (uint32_t m = 1; !DENSE && m < nt; ++m) {
       TermRef tr = m == 1u ? t1 : load_term(p.terms, sload(&Q->term[m]));
       if (!p.use_dense) tr.dense = nullptr;
       uint32_t jb = 0, at = NOT_FOUND;
@@ -339,8 +416,22 @@ __global__ __launch_bounds__(64, DENSE ? TQ_PH_WAVES_DENSE : 5) void phrase_kern
         // adjusted positions of the leader term, then one term at a time: bit i of `ok` stays set
         // while every term seen so far has a position equal to the leader's i-th
         uint32_t a[TM], d[TM];
+        // the block records of every term's run first (one round trip for all of them)
+        uint64_t e0[NT_MAX], e1[NT_MAX];
+        uint32_t pis[NT_MAX];
+#pragma unroll
+        for (int m = 0; m < NT_MAX; ++m) {
+          pis[m] = 0;
+          e0[m] = 0;
+          e1[m] = 0;
+          if ((uint32_t)m < nt) {
+            pis[m] = m ? L.ph_pi[m ? m - 1 : 0][lane] : lead_pi;
+            if (TQ_PH_HOIST) pos_run_records(L.pt_blk[m], L.pt_nblk[m], pis[m], e0[m], e1[m]);
+          }
+        }
         {
-          const PosRun run = pos_run(pos, L.pt_blk[0], L.pt_tail[0], L.pt_nblk[0], lead_pi);
+          if (!TQ_PH_HOIST) pos_run_records(L.pt_blk[0], L.pt_nblk[0], lead_pi, e0[0], e1[0]);
+          const PosRun run = pos_run_of(pos, e0[0], e1[0], L.pt_tail[0], L.pt_nblk[0], lead_pi);
 #pragma unroll
           for (uint32_t k = 0; k < TM; ++k)  // clamped: unconditional, independent loads
             d[k] = pos_run_delta(run, k < lead_tf ? k : lead_tf - 1u);
@@ -352,9 +443,12 @@ __global__ __launch_bounds__(64, DENSE ? TQ_PH_WAVES_DENSE : 5) void phrase_kern
           }
         }
         uint32_t ok = (1u << lead_tf) - 1u;
-        for (uint32_t m = 1; m < nt; ++m) {
-          const uint32_t tfm = L.ph_tf[m - 1u][lane];
-          const PosRun run = pos_run(pos, L.pt_blk[m], L.pt_tail[m], L.pt_nblk[m], L.ph_pi[m - 1u][lane]);
+#pragma unroll
+        for (int m = 1; m < NT_MAX; ++m) {
+          if ((uint32_t)m >= nt) break;
+          const uint32_t tfm = L.ph_tf[m - 1][lane];
+          if (!TQ_PH_HOIST) pos_run_records(L.pt_blk[m], L.pt_nblk[m], pis[m], e0[m], e1[m]);
+          const PosRun run = pos_run_of(pos, e0[m], e1[m], L.pt_tail[m], L.pt_nblk[m], pis[m]);
 #pragma unroll
           for (uint32_t k = 0; k < TM; ++k) d[k] = pos_run_delta(run, k < tfm ? k : tfm - 1u);
           uint32_t c = L.pt_off[m], hit = 0;
@@ -576,6 +670,285 @@ __global__ __launch_bounds__(64, DENSE ? TQ_PH_WAVES_DENSE : 5) void phrase_kern
   if (lane == 0 && n_matches) atomicAdd(sload(&p.sinks->match_counter), (unsigned long long)n_matches);
 }
 
+
+// =================================================================== phrase sweep (all lists dense)
+// Exact phrases whose lists ALL have a bitmap + rank directory, byte-wide term freqs and a position
+// directory, and whose rarest list still holds about a posting per bitmap word: the doc set of
+// PhraseScorer's intersection (phrase_scorer.rs:82-136) is the AND of the lists' bitmaps, read as
+// coalesced 8-byte words — 32 docs per load and list — instead of one doc-matrix gather per leader
+// posting (the block-driven kernel above spends 61 % of its time there: 427 M gathers per
+// 1000-query batch).  No posting block is decoded at all: a surviving doc's posting index in
+// every list falls out of the rank directory, its tf and the index of its first position out of
+// the tf bytes of its group of four and the position directory.  Tile = SWEEP_WORDS bitmap words.
+// Stage C (64 docs, one per lane): {four tf bytes, directory entry} of every list in flight
+// together, then the position runs (block records of all terms together, deltas term by term)
+// and the n-way intersection of adjusted positions over registers (phrase_scorer.rs:437-507);
+// long runs take the cursor merge.
+constexpr uint32_t SWEEP_NT = 4;       // terms per phrase in this kernel
+constexpr uint32_t SWEEP_WORDS = 2048; // bitmap words per tile (65536 docs)
+#ifndef TQ_PH_SWEEP_UNROLL
+#define TQ_PH_SWEEP_UNROLL 2  // (4 and 8: the word arrays end in scratch, 3.9 ms; 1: 1.67 ms; 2: 1.53 ms)
+#endif
+#ifndef TQ_PH_SWEEP_WAVES
+#define TQ_PH_SWEEP_WAVES 5
+#endif
+constexpr uint32_t SWEEP_UNROLL = TQ_PH_SWEEP_UNROLL;  // 64-word steps whose loads are in flight together
+struct SweepLds {  // per wavefront
+  uint32_t q_doc[127];
+  uint32_t q_pi[SWEEP_NT][127];  // posting index of the doc in every list
+  const uint2 *dense[SWEEP_NT];
+  const uint8_t *tf8[SWEEP_NT];
+  const uint32_t *dir[SWEEP_NT];
+  const uint64_t *blk[SWEEP_NT];
+  const uint32_t *tail[SWEEP_NT];
+  uint32_t nblk[SWEEP_NT], off[SWEEP_NT];
+};
+
+template <int KPL>
+__global__ __launch_bounds__(64, TQ_PH_SWEEP_WAVES) void phrase_sweep_kernel(TqkScanParams p) {
+  __shared__ SweepLds L;
+  const int lane = (int)__lane_id();
+  if (blockIdx.x >= p.n_chunks) return;
+  const uint4 crec = sload(p.chunk_recs + blockIdx.x);
+  const uint32_t chunk = crec.w, t_begin = crec.x, t_end = crec.y;
+  const TqdSegment seg = p.seg;
+  const uint8_t *idx = seg.idx;
+  const uint8_t *pos = seg.pos;
+  const uint32_t n_words = (seg.max_doc + 31u) >> 5;
+  uint32_t q = crec.z;
+  uint32_t q_tile_start = 0, q_tile_end = 0;
+  const TqdQuery *Q = nullptr;
+  uint32_t nt = 0;
+  float weight = 0.0f;
+  const float *cache_g = nullptr;
+  TopK<KPL> tk;
+  uint32_t n_matches = 0, n_q = 0, qn = 0;
+
+  auto setup_query = [&]() __attribute__((always_inline)) {
+    q_tile_start = sload(p.tile_starts + q);
+    q_tile_end = sload(p.tile_starts + q + 1u);
+    Q = p.queries + q;
+    nt = sload(&Q->n_terms);
+    weight = sload(&Q->weight[0]);
+    cache_g = p.caches + (size_t)sload(&Q->cache_idx) * 256u;
+    tk.reset(sload(&Q->k));
+    wave_mem_fence();
+    if ((uint32_t)lane < nt) {
+      const TqdTerm *tt = p.terms + Q->term[lane];
+      L.dense[lane] = tt->dense;
+      L.tf8[lane] = tt->tf8;
+      L.dir[lane] = tt->pos_dir;
+      L.blk[lane] = tt->pos_blk;
+      L.tail[lane] = tt->pos_tail;
+      L.nblk[lane] = tt->n_pos_blocks;
+      L.off[lane] = Q->phrase_off[lane];
+    }
+    wave_mem_fence();
+  };
+
+  auto stageC = [&](uint32_t n) __attribute__((always_inline)) {
+    const uint32_t base = qn - n;
+    qn = base;
+    const bool alive = (uint32_t)lane < n;
+    uint32_t doc = 0;
+    uint32_t pi[SWEEP_NT] = {0u, 0u, 0u, 0u};
+    if (alive) {
+      doc = L.q_doc[base + lane];
+#pragma unroll
+      for (uint32_t m = 0; m < SWEEP_NT; ++m)
+        if (m < nt) pi[m] = L.q_pi[m][base + lane];
+    }
+    // level 1: the four tf bytes of the posting's group + the group's directory entry, every list
+    uint32_t tw[SWEEP_NT], dv[SWEEP_NT];
+#pragma unroll
+    for (uint32_t m = 0; m < SWEEP_NT; ++m) {
+      tw[m] = 0;
+      dv[m] = 0;
+      if (m < nt && alive) {
+        tw[m] = *reinterpret_cast<const uint32_t *>(L.tf8[m] + (pi[m] & ~3u));
+        dv[m] = L.dir[m][pi[m] >> 2];
+      }
+    }
+    uint32_t tf[SWEEP_NT], fp[SWEEP_NT];  // term freq, index of the first position
+    constexpr uint32_t TM = 8;
+    bool fast = alive;
+#pragma unroll
+    for (uint32_t m = 0; m < SWEEP_NT; ++m) {
+      tf[m] = 1;
+      fp[m] = 0;
+      if (m < nt) {
+        const uint32_t l0 = pi[m] & 3u;
+        const uint32_t b0 = tw[m] & 0xFFu, b1 = (tw[m] >> 8) & 0xFFu, b2 = (tw[m] >> 16) & 0xFFu, b3 = tw[m] >> 24;
+        uint32_t t = l0 == 0u ? b0 : (l0 == 1u ? b1 : (l0 == 2u ? b2 : b3));
+        uint32_t ex = (l0 > 0u ? b0 : 0u) + (l0 > 1u ? b1 : 0u) + (l0 > 2u ? b2 : 0u);
+        // a saturated byte (tf >= 255) among the ones used: the packed values are read instead
+        const bool sat = alive && (t == 255u || (l0 > 0u && b0 == 255u) || (l0 > 1u && b1 == 255u) ||
+                                   (l0 > 2u && b2 == 255u));
+        if (__ballot(sat)) {
+          const TermRef tr = load_term(p.terms, sload(&Q->term[m]));
+          if (sat) group_tfs(idx, tr, tr.rec[pi[m] >> 7], pi[m] & 127u, t, ex);
+        }
+        tf[m] = t;
+        fp[m] = dv[m] + ex;
+        fast = fast && t - 1u < TM;  // (tf 0 — a corrupt index — takes the cursor merge: no position)
+      }
+    }
+    uint32_t count = 0xFFFFFFFFu;  // = resolved by the cursor merge
+    if (fast) {
+      // level 2: the block records of every term's run; then the deltas, term by term
+      uint64_t e0[SWEEP_NT], e1[SWEEP_NT];
+#pragma unroll
+      for (uint32_t m = 0; m < SWEEP_NT; ++m) {
+        e0[m] = 0;
+        e1[m] = 0;
+        if (m < nt) pos_run_records(L.blk[m], L.nblk[m], fp[m], e0[m], e1[m]);
+      }
+      uint32_t a[TM], d[TM];
+      {
+        const PosRun run = pos_run_of(pos, e0[0], e1[0], L.tail[0], L.nblk[0], fp[0]);
+#pragma unroll
+        for (uint32_t k = 0; k < TM; ++k) d[k] = pos_run_delta(run, k < tf[0] ? k : tf[0] - 1u);
+        uint32_t c = L.off[0];
+#pragma unroll
+        for (uint32_t k = 0; k < TM; ++k) {
+          c += d[k];
+          a[k] = c;
+        }
+      }
+      uint32_t ok = (1u << tf[0]) - 1u;
+#pragma unroll
+      for (uint32_t m = 1; m < SWEEP_NT; ++m) {
+        if (m >= nt) break;
+        const PosRun run = pos_run_of(pos, e0[m], e1[m], L.tail[m], L.nblk[m], fp[m]);
+#pragma unroll
+        for (uint32_t k = 0; k < TM; ++k) d[k] = pos_run_delta(run, k < tf[m] ? k : tf[m] - 1u);
+        uint32_t c = L.off[m], hit = 0;
+#pragma unroll
+        for (uint32_t k = 0; k < TM; ++k) {
+          c += d[k];  // (k >= tf repeats the last delta; those sums are masked out below)
+          uint32_t eq = 0;
+#pragma unroll
+          for (uint32_t i = 0; i < TM; ++i) eq |= (a[i] == c ? 1u : 0u) << i;
+          hit |= k < tf[m] ? eq : 0u;
+        }
+        ok &= hit;
+      }
+      count = (uint32_t)__popc(ok);
+    }
+    if (__ballot(alive && count == 0xFFFFFFFFu)) {
+      if (alive && count == 0xFFFFFFFFu) {  // the n-way cursor merge, one position at a time
+        PosCursor cur[SWEEP_NT];
+#pragma unroll
+        for (uint32_t m = 0; m < SWEEP_NT; ++m) {
+          cur[m].valid = false;
+          cur[m].idx = cur[m].end = cur[m].cur = 0;
+          if (m < nt) {
+            cur[m].idx = fp[m] + 1u;
+            cur[m].end = fp[m] + tf[m];
+            cur[m].cur = L.off[m] + position_delta(pos, p.terms + Q->term[m], fp[m]);
+            cur[m].valid = cur[m].end >= cur[m].idx;
+          }
+        }
+        uint32_t cnt = 0;
+        bool done = false;
+        while (cur[0].valid && !done) {
+          const uint32_t av = cur[0].cur;
+          bool okv = true;
+#pragma unroll
+          for (uint32_t m = 1; m < SWEEP_NT; ++m) {
+            if (m < nt && !done) {
+              while (cur[m].valid && cur[m].cur < av) pos_advance(cur[m], pos, p.terms + Q->term[m]);
+              if (!cur[m].valid)
+                done = true;
+              else if (cur[m].cur != av)
+                okv = false;
+            }
+          }
+          if (done) break;
+          if (okv) {
+            ++cnt;
+#pragma unroll
+            for (uint32_t m = 1; m < SWEEP_NT; ++m)
+              if (m < nt) pos_advance(cur[m], pos, p.terms + Q->term[m]);
+          }
+          pos_advance(cur[0], pos, p.terms + Q->term[0]);
+        }
+        count = cnt;
+      }
+    }
+    bool has = false;
+    uint64_t key = 0;
+    if (alive && count > 0u && doc_is_alive(seg, doc)) {
+      has = true;
+      key = make_key(bm25(weight, cache_g[fieldnorm_id(seg, doc)], count), doc);
+    }
+    const uint64_t hit = __ballot(has);
+    if (hit) {
+      n_matches += (uint32_t)__popcll(hit);
+      n_q += (uint32_t)__popcll(hit);
+      tk.offer(has, key, lane);
+    }
+  };
+
+  auto flush_query = [&]() __attribute__((always_inline)) {
+    while (qn) stageC(qn < 64u ? qn : 64u);
+    const uint32_t part = sload(&Q->part_start) + (chunk - sload(&Q->chunk_first));
+    flush_partial<KPL>(tk, sload(&p.sinks->partials), part, lane);
+    if (lane == 0 && n_q) atomicAdd(sload(&p.sinks->query_matches) + sload(sload(&p.sinks->out_index) + q), n_q);
+    n_q = 0;
+  };
+
+  setup_query();
+  for (uint32_t t = t_begin; t < t_end; ++t) {
+    while (t >= q_tile_end) {
+      if (q_tile_end > q_tile_start && q_tile_end > t_begin) flush_query();
+      ++q;
+      setup_query();
+    }
+    const uint32_t w_begin = (t - q_tile_start) * SWEEP_WORDS;
+    const uint32_t w_end = w_begin + SWEEP_WORDS < n_words ? w_begin + SWEEP_WORDS : n_words;
+    // (the words of SWEEP_UNROLL steps are requested together: a step is a chain of one round trip)
+    for (uint32_t wb0 = w_begin; wb0 < w_end; wb0 += 64u * SWEEP_UNROLL) {
+     uint2 wdu[SWEEP_UNROLL][SWEEP_NT];
+#pragma unroll
+     for (uint32_t u = 0; u < SWEEP_UNROLL; ++u) {
+       const uint32_t w = wb0 + 64u * u + (uint32_t)lane;
+#pragma unroll
+       for (uint32_t m = 0; m < SWEEP_NT; ++m) {
+         wdu[u][m] = make_uint2(m < nt ? 0u : 0xFFFFFFFFu, 0u);
+         if (m < nt && w < w_end) wdu[u][m] = L.dense[m][w];
+       }
+     }
+#pragma unroll
+     for (uint32_t u = 0; u < SWEEP_UNROLL; ++u) {
+      const uint32_t w = wb0 + 64u * u + (uint32_t)lane;
+      const uint2 (&wd)[SWEEP_NT] = wdu[u];
+      uint32_t cand = wd[0].x & wd[1].x & wd[2].x & wd[3].x;
+      while (__ballot(cand != 0u)) {
+        const bool has = cand != 0u;
+        const uint32_t bit = has ? (uint32_t)__builtin_ctz(cand) : 0u;
+        cand &= cand - 1u;
+        const uint64_t mk = __ballot(has);
+        const uint32_t at = qn + mbcnt64(mk);
+        wave_mem_fence();
+        if (has) {
+          const uint32_t below = (1u << bit) - 1u;
+          L.q_doc[at] = (w << 5) + bit;
+#pragma unroll
+          for (uint32_t m = 0; m < SWEEP_NT; ++m)
+            if (m < nt) L.q_pi[m][at] = wd[m].y + (uint32_t)__popc(wd[m].x & below);
+        }
+        wave_mem_fence();
+        qn += (uint32_t)__popcll(mk);
+        while (qn >= 64u) stageC(64u);
+      }
+     }
+    }
+  }
+  if (q_tile_end > q_tile_start) flush_query();
+  if (lane == 0 && n_matches) atomicAdd(sload(&p.sinks->match_counter), (unsigned long long)n_matches);
+}
+
 }  // namespace
 
 // =================================================================== launch wrappers
@@ -593,6 +966,15 @@ static void launch_phrase_t(const TqkScanParams &p, bool /*dpp*/, dim3 grid, dim
 hipError_t tqk_launch_phrase(const TqkScanParams &p, int kpl, bool use_dpp, hipStream_t st) {
   if (p.n_chunks == 0) return hipSuccess;
   const dim3 grid(p.n_chunks), block(64);
+  if (p.or_windows == 2u) {  // (the planner's "phrase sweep" launch group: tiles are bitmap-word ranges)
+    switch (kpl) {
+      case 1: phrase_sweep_kernel<1><<<grid, block, 0, st>>>(p); break;
+      case 2: phrase_sweep_kernel<2><<<grid, block, 0, st>>>(p); break;
+      case 4: phrase_sweep_kernel<4><<<grid, block, 0, st>>>(p); break;
+      default: phrase_sweep_kernel<16><<<grid, block, 0, st>>>(p); break;
+    }
+    return hipGetLastError();
+  }
   switch (kpl) {
     case 1: launch_phrase_t<1>(p, use_dpp, grid, block, st); break;
     case 2: launch_phrase_t<2>(p, use_dpp, grid, block, st); break;
