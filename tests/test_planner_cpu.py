@@ -37,3 +37,14 @@ def test_chunk_tables_cover_every_tile_once(plan_check, threads, chunks):
         r = subprocess.run([plan_check, str(seed)], env=env, capture_output=True, text=True, timeout=300)
         assert r.returncode == 0, r.stderr + r.stdout
         assert r.stdout.count("ok") == 3, r.stdout
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3, 4])
+def test_share_plan_invariants(plan_check, seed):
+    """build_share_plan (the shared-union launch's planner): leads, lead records, tasks and result
+    regions against a host-side restatement of their definitions."""
+    for env_extra in ({}, {"TQ_US_TASK_COST": "256", "TQ_US_GROUP": "8"}, {"TQ_US_TASK_BLOCKS": "16"}):
+        r = subprocess.run([plan_check, str(seed), "share"], env=dict(os.environ, **env_extra),
+                           capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr + r.stdout
+        assert "ok" in r.stdout

@@ -52,8 +52,149 @@ static int check(Group &g, bool or_win) {
   return 0;
 }
 
+// The shared-union planner (build_share_plan): every (query, list) pair is exactly one lead; the
+// tasks of a (position, term) run cover the term's blocks exactly once per lead group, in position
+// order; every lead record describes its query (columns, signature bits, weights); the result-list
+// regions are disjoint and hold k entries per (task, lead) pair.
+static int check_share(int seed) {
+  std::mt19937 rng(seed + 100);
+  auto uni = [&](uint32_t lo, uint32_t hi) { return std::uniform_int_distribution<uint32_t>(lo, hi)(rng); };
+  tq_segment seg;
+  const uint32_t n_terms = 300;
+  static uint8_t arena[1 << 20];
+  for (uint32_t t = 0; t < n_terms; ++t) {
+    TermHost th;
+    th.n_blocks = uni(1, 3000);
+    th.doc_freq = th.n_blocks * 128u;
+    TqdTerm dt{};
+    dt.has_freq = 1u;
+    if (t < 80) {  // dense: bitmap + tf8 at fake (distinct, 8-aligned) addresses; the first 56 have columns
+      th.dense_blob = arena + 4096u * t + 8u;
+      th.tf8_blob = arena + 4096u * t + 2048u;
+      if (t < 56) dt.has_freq |= (t + 1u) << 8;
+    }
+    if (t >= 56 && t % 3) dt.has_freq |= ((t * 7u) % 64u + 1u) << 16;  // signature bits for some
+    seg.terms.push_back(th);
+    seg.h_dterms.push_back(dt);
+  }
+  seg.d_docsig = (uint64_t *)arena;  // (only tested against null)
+  seg.max_doc = 10000000u;
+  PlanScratch ps;
+  Group &g = ps.groups[5];
+  g.reset();
+  g.mode = TQ_MODE_OR;
+  const uint32_t nq = 700;
+  for (uint32_t q = 0; q < nq; ++q) {
+    TqdQuery dq{};
+    dq.n_terms = uni(1, TQD_US_MAX_TERMS);
+    dq.k = uni(1, 128);
+    dq.flags = TQD_QF_PRUNE;
+    dq.cache_idx = uni(0, 2);
+    dq.thr_index = 4u * q;
+    uint32_t used[TQD_US_MAX_TERMS];
+    for (uint32_t i = 0; i < dq.n_terms; ++i) {
+      uint32_t t;
+      bool dup;
+      do {
+        t = uni(0, n_terms - 1);
+        dup = false;
+        for (uint32_t j = 0; j < i; ++j) dup |= used[j] == t;
+      } while (dup);
+      used[i] = t;
+      dq.term[i] = t;
+      dq.weight[i] = 30.0f / (float)(i + 1);  // descending
+    }
+    g.queries.push_back(dq);
+    g.tile_cost.push_back(1);
+    g.out_index.push_back(q);
+    g.max_k = std::max(g.max_k, dq.k);
+  }
+  if (build_share_plan(&seg, g, ps) != TQ_OK) {
+    seg.d_docsig = nullptr;
+    return fail_msg("build_share_plan failed");
+  }
+  seg.d_docsig = nullptr;  // (not ours to free)
+  size_t n_leads = 0;
+  for (const TqdQuery &q : g.queries) n_leads += q.n_terms;
+  if (ps.leads.size() != n_leads) return fail_msg("lead count", (long)ps.leads.size(), (long)n_leads);
+  std::vector<uint8_t> seen(nq * TQD_US_MAX_TERMS, 0);
+  for (const TqdLead &ld : ps.leads) {
+    const uint32_t li = ld.info & 15u, nt = (ld.info >> 8) & 15u;
+    if (ld.query >= nq || li >= g.queries[ld.query].n_terms) return fail_msg("lead out of range", ld.query, li);
+    const TqdQuery &q = g.queries[ld.query];
+    if (nt != q.n_terms || seen[ld.query * TQD_US_MAX_TERMS + li]++) return fail_msg("lead twice / n_terms", ld.query, li);
+    if (ld.w != q.weight[li]) return fail_msg("lead weight", ld.query, li);
+    float suffix = 0;
+    for (uint32_t m = q.n_terms; m-- > li;) suffix += q.weight[m];
+    if (ld.suffix != suffix) return fail_msg("lead suffix", ld.query, li);
+    uint32_t c = 0;
+    float sparse = 0;
+    for (uint32_t m = 0; m < q.n_terms; ++m) {
+      const uint32_t hf = seg.h_dterms[q.term[m]].has_freq;
+      const uint32_t col = (hf >> 8) & 0xFFu ? 8u + ((hf >> 8) & 0xFFu) - 1u : 0u;
+      const uint32_t sig1 = col ? 0u : (hf >> 16) & 0xFFu;
+      if (((ld.info >> (16 + m)) & 1u) != (col ? 0u : 1u)) return fail_msg("nocol bit", ld.query, m);
+      if (((ld.info >> (24 + m)) & 1u) != ((col || sig1) ? 0u : 1u)) return fail_msg("nopc bit", ld.query, m);
+      if (ld.sig[m] != sig1) return fail_msg("sig byte", ld.query, m);
+      if (m < li && col && !((ld.before_mask >> col) & 1ull)) return fail_msg("before_mask", ld.query, m);
+      if (m > li) {
+        const uint32_t want = col ? col : (sig1 ? 64u + sig1 - 1u : 0u);
+        if (want) {
+          const uint32_t got = ((c < 4 ? ld.cols_lo >> (8 * c) : ld.cols_hi >> (8 * (c - 4)))) & 0xFFu;
+          if (got != want || ld.aw[c] != q.weight[m]) return fail_msg("column entry", ld.query, m);
+          ++c;
+        } else {
+          sparse += q.weight[m];
+        }
+        const TermHost &th = seg.terms[q.term[m]];
+        const uint64_t d = th.dense_blob ? (uint64_t)th.dense_blob - ps.share_table_base : 0;
+        if ((uint64_t)ld.dense_off[m - li - 1] * 8u != d) return fail_msg("dense_off", ld.query, m);
+      }
+    }
+    if (((ld.info >> 4) & 15u) != c || ld.sparse_after != sparse) return fail_msg("ncols / sparse_after", ld.query, li);
+  }
+  // tasks: per (lead group) the runs of blocks tile the term's list; positions ascend
+  std::vector<uint32_t> pairs(nq, 0);
+  std::unordered_map<uint64_t, uint32_t> next_block;  // (first lead << 8 | n_leads) -> next expected block
+  uint32_t last_pos = 0;
+  for (size_t ti = 0; ti < ps.tasks.size(); ++ti) {
+    const uint4 t = ps.tasks[ti];
+    const uint32_t nb = t.z & 0xFFFFu, nl = (t.z >> 16) & 0xFFu, cache = t.z >> 24;
+    if (!nb || !nl || nl > TQD_US_GROUP || t.w + nl > ps.leads.size()) return fail_msg("task shape", (long)ti);
+    uint32_t pos = 0;
+    for (uint32_t l = 0; l < nl; ++l) {
+      const TqdLead &ld = ps.leads[t.w + l];
+      const TqdQuery &q = g.queries[ld.query];
+      if (q.term[ld.info & 15u] != t.x || q.cache_idx != cache) return fail_msg("task lead of another term", (long)ti, l);
+      pos = ld.info & 15u;
+      ++pairs[ld.query];
+    }
+    if (pos < last_pos) return fail_msg("positions not ascending", (long)ti);
+    last_pos = pos;
+    if ((uint32_t)ti < ps.share_phase_first[pos] || (uint32_t)ti >= ps.share_phase_first[pos + 1])
+      return fail_msg("phase bounds", (long)ti, pos);
+    uint32_t &nx = next_block[((uint64_t)t.w << 8) | nl];
+    if (t.y != nx) return fail_msg("runs do not tile the list", (long)ti, t.y);
+    nx += nb;
+    if (nx > seg.terms[t.x].n_blocks) return fail_msg("run past the list", (long)ti);
+  }
+  for (auto &kv : next_block) {
+    const TqdLead &ld = ps.leads[kv.first >> 8];
+    if (kv.second != seg.terms[g.queries[ld.query].term[ld.info & 15u]].n_blocks) return fail_msg("list not covered");
+  }
+  uint64_t at = 0;
+  for (uint32_t q = 0; q < nq; ++q) {
+    if (g.queries[q].part_start != at) return fail_msg("result regions overlap", q);
+    if (g.queries[q].n_parts != pairs[q] * g.queries[q].k) return fail_msg("result region size", q);
+    at += g.queries[q].n_parts;
+  }
+  printf("share: %u queries, %zu leads, %zu tasks ok\n", nq, ps.leads.size(), ps.tasks.size());
+  return 0;
+}
+
 int main(int argc, char **argv) {
   const int seed = argc > 1 ? atoi(argv[1]) : 1;
+  if (argc > 2 && !strcmp(argv[2], "share")) return check_share(seed);
   std::mt19937 rng(seed);
   auto uni = [&](uint32_t lo, uint32_t hi) { return std::uniform_int_distribution<uint32_t>(lo, hi)(rng); };
   PlanScratch ps;
