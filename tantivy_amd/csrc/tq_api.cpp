@@ -171,7 +171,6 @@ struct tq_segment {
   TqpInfo *d_tp_info = nullptr;       // device-side prepare: result slots (info + positions result)
   uint8_t *d_idx = nullptr, *d_pos = nullptr, *d_fn = nullptr, *d_alive = nullptr;
   uint64_t *d_docmat = nullptr;  // doc-major matrix of the dense lists (TqdSegment::docmat)
-  uint64_t *d_docsig = nullptr;  // per-doc signature of the prepared lists WITHOUT a column (TqdSegment::docsig)
   uint32_t n_mat_slots = 0;
   TqdSegment dseg{};
   std::vector<TermHost> terms;
@@ -182,7 +181,6 @@ struct tq_segment {
   size_t dense_bytes_total = 0;
   // resident bytes by kind (tq_segment_get_stats)
   size_t bytes_term_tables = 0, bytes_bitmaps = 0, bytes_docmat = 0, bytes_posdir = 0, bytes_alive = 0;
-  size_t bytes_docsig = 0;
   uint32_t n_dense_lists = 0;
   std::unordered_map<uint64_t, uint32_t> term_by_off;
   // batch scratch
@@ -239,6 +237,7 @@ int build_dense_device(tq_segment *s, uint32_t handle);
 int register_term(tq_segment *s, const TqdTerm &dt, const TermHost &th, uint64_t postings_off,
                   tq_term_handle *out);
 int add_to_doc_signatures(tq_segment *s, uint32_t handle);
+int ensure_docmat(tq_segment *s);
 
 // Dense lists also get their term freqs as one byte per posting (255 = "255 or more: read the
 // packed value"): with the posting index from the bitmap's rank the tf of a candidate is ONE load,
@@ -280,27 +279,38 @@ int wait_segment_idle(tq_segment *s) {
   return TQ_OK;
 }
 
+// The doc matrix (TqdSegment::docmat): allocated with the first list that needs it.
+int ensure_docmat(tq_segment *s) {
+  if (s->d_docmat) return TQ_OK;
+  const size_t mat_bytes = (size_t)s->max_doc * sizeof(uint64_t);
+  if (s->dense_bytes_total + mat_bytes > s->dense_budget()) return TQ_OK;  // (stays null: over budget)
+  HIP_TRY(hipMalloc((void **)&s->d_docmat, mat_bytes + PAD));
+  HIP_TRY(hipMemsetAsync((uint8_t *)s->d_docmat + mat_bytes, 0, PAD, s->stream));
+  const hipError_t e = tqk_launch_docmat_init(s->d_docmat, s->d_fn, s->dseg.const_fieldnorm_id, s->max_doc, s->stream);
+  if (e != hipSuccess) return fail(TQ_ERR_HIP, "docmat init: %s", hipGetErrorString(e));
+  s->dense_bytes_total += mat_bytes;
+  s->bytes_docmat = mat_bytes;
+  s->dseg.docmat = s->d_docmat;
+  return TQ_OK;
+}
+
 // Lists WITHOUT a column in the doc matrix (the sparse, high-weight lists; dense lists beyond the
-// 56 columns) share one more 64-bit word per doc: every such list sets bit hash(handle) of the docs
-// it holds.  A clear bit proves "not in the list"; a set bit means "maybe" (another list with the
-// same bit, or this one).  The union kernels test it where they used to assume the list holds
-// every candidate — a rare list holds a fraction of a percent of them, and each wrong guess cost a
-// seek and a block search.  Only prepared (queried) lists set bits; derived data like the doc
-// matrix, within the same memory budget (8 B per doc), built by one decode of the list.
+// 40 columns) share the top 16 bits of the doc-matrix words: every such list sets bit
+// 48 + hash(handle) of the docs it holds.  A clear bit proves "not in the list"; a set bit means
+// "maybe" (another list with the same bit, or this one).  The union kernels test it where they
+// used to assume the list holds every candidate — a rare list holds a fraction of a percent of
+// them, and each wrong guess cost a seek and a block search.  The same gather that brings a
+// candidate's fieldnorm id and column bits brings its signature.  Only prepared (queried) lists
+// set bits; built by one decode of the list.
 int add_to_doc_signatures(tq_segment *s, uint32_t handle) {
   if (!s->opt.docsig || !s->opt.docmat || !s->opt.dense || s->max_doc < 4096u) return TQ_OK;
   if ((s->h_dterms[handle].has_freq >> 8) & 0xFFu) return TQ_OK;  // the list has a column
   TermHost &t = s->terms[handle];
   if (t.doc_freq == 0) return TQ_OK;
-  const size_t sig_bytes = (size_t)s->max_doc * sizeof(uint64_t);
-  if (!s->d_docsig) {
-    if (s->dense_bytes_total + sig_bytes > s->dense_budget()) return TQ_OK;
-    HIP_TRY(hipMalloc((void **)&s->d_docsig, sig_bytes + PAD));
-    HIP_TRY(hipMemsetAsync(s->d_docsig, 0, sig_bytes + PAD, s->stream));
-    s->dense_bytes_total += sig_bytes;
-    s->bytes_docsig = sig_bytes;
-  }
-  int rc = sync_terms(s, s->stream);
+  int rc = ensure_docmat(s);
+  if (rc != TQ_OK) return rc;
+  if (!s->d_docmat) return TQ_OK;
+  rc = sync_terms(s, s->stream);
   if (rc != TQ_OK) return rc;
   const size_t bytes = (size_t)t.doc_freq * sizeof(uint32_t);
   rc = s->d_misc.ensure(2 * bytes + 64);
@@ -309,9 +319,9 @@ int add_to_doc_signatures(tq_segment *s, uint32_t handle) {
   hipError_t e = tqk_launch_decode_list(s->dseg, s->d_terms, handle, t.n_blocks, dd, dt,
                                         s->opt.use_dpp != 0, s->stream);
   if (e != hipSuccess) return fail(TQ_ERR_HIP, "decode launch: %s", hipGetErrorString(e));
-  const uint32_t bit = (handle * 0x9E3779B1u) >> 26;
-  e = tqk_launch_docsig_set(s->d_docsig, dd, t.doc_freq, bit, s->max_doc, s->stream);
-  if (e != hipSuccess) return fail(TQ_ERR_HIP, "docsig set: %s", hipGetErrorString(e));
+  const uint32_t bit = (handle * 0x9E3779B1u) >> (32 - 4);  // 0 .. TQD_SIG_BITS - 1
+  e = tqk_launch_docmat_set(s->d_docmat, dd, t.doc_freq, (TQD_SIG_SHIFT - 8u) + bit, s->max_doc, s->stream);
+  if (e != hipSuccess) return fail(TQ_ERR_HIP, "docmat signature: %s", hipGetErrorString(e));
   s->h_dterms[handle].has_freq |= (bit + 1u) << 16;
   s->d_terms_dirty = true;
   return TQ_OK;
@@ -338,15 +348,9 @@ int build_dense(tq_segment *s, uint32_t handle) {
   // the list's column of the doc matrix (first TQD_MAT_SLOTS dense lists of the segment, while
   // the matrix fits the same memory budget as the bitmaps)
   if (s->n_mat_slots < TQD_MAT_SLOTS && s->opt.docmat) {
-    const size_t mat_bytes = (size_t)s->max_doc * sizeof(uint64_t);
-    if (!s->d_docmat && s->dense_bytes_total + mat_bytes <= s->dense_budget()) {
-      HIP_TRY(hipMalloc((void **)&s->d_docmat, mat_bytes + PAD));
-      HIP_TRY(hipMemsetAsync((uint8_t *)s->d_docmat + mat_bytes, 0, PAD, s->stream));
-      e = tqk_launch_docmat_init(s->d_docmat, s->d_fn, s->dseg.const_fieldnorm_id, s->max_doc, s->stream);
-      if (e != hipSuccess) return fail(TQ_ERR_HIP, "docmat init: %s", hipGetErrorString(e));
-      s->dense_bytes_total += mat_bytes;
-      s->bytes_docmat = mat_bytes;
-      s->dseg.docmat = s->d_docmat;
+    {
+      const int mrc = ensure_docmat(s);
+      if (mrc != TQ_OK) return mrc;
     }
     if (s->d_docmat) {
       const uint32_t slot = s->n_mat_slots++;
@@ -571,7 +575,6 @@ void tq_segment_free(tq_segment *s) {
   if (s->d_fn) (void)hipFree(s->d_fn);
   if (s->d_alive) (void)hipFree(s->d_alive);
   if (s->d_docmat) (void)hipFree(s->d_docmat);
-  if (s->d_docsig) (void)hipFree(s->d_docsig);
   if (s->d_tp_info) (void)hipFree(s->d_tp_info);
   if (s->d_match_counter) (void)hipFree(s->d_match_counter);
   s->d_stage.release();
@@ -1042,15 +1045,9 @@ int build_dense_device(tq_segment *s, uint32_t handle) {
   s->h_dterms[handle].dense = (const uint2 *)blob;
   s->d_terms_dirty = true;
   if (s->n_mat_slots < TQD_MAT_SLOTS && s->opt.docmat) {  // the list's column of the doc matrix
-    const size_t mat_bytes = (size_t)s->max_doc * sizeof(uint64_t);
-    if (!s->d_docmat && s->dense_bytes_total + mat_bytes <= s->dense_budget()) {
-      HIP_TRY(hipMalloc((void **)&s->d_docmat, mat_bytes + PAD));
-      HIP_TRY(hipMemsetAsync((uint8_t *)s->d_docmat + mat_bytes, 0, PAD, s->stream));
-      e = tqk_launch_docmat_init(s->d_docmat, s->d_fn, s->dseg.const_fieldnorm_id, s->max_doc, s->stream);
-      if (e != hipSuccess) return fail(TQ_ERR_HIP, "docmat init: %s", hipGetErrorString(e));
-      s->dense_bytes_total += mat_bytes;
-      s->bytes_docmat = mat_bytes;
-      s->dseg.docmat = s->d_docmat;
+    {
+      const int mrc = ensure_docmat(s);
+      if (mrc != TQ_OK) return mrc;
     }
     if (s->d_docmat) {
       const uint32_t slot = s->n_mat_slots++;
@@ -1603,7 +1600,7 @@ int build_share_plan(tq_segment *s, Group &g, PlanScratch &ps) {
     for (uint32_t m = 0; m < dq.n_terms; ++m) {
       const uint32_t col = column_of(dq.term[m]);
       // lists without a column: their signature bit (docsig), if the segment keeps signatures
-      const uint32_t sig1 = (!col && s->d_docsig) ? (s->h_dterms[dq.term[m]].has_freq >> 16) & 0xFFu : 0u;
+      const uint32_t sig1 = !col ? (s->h_dterms[dq.term[m]].has_freq >> 16) & 0xFFu : 0u;
       ld.sig[m] = (uint8_t)sig1;
       if (!col) nocol |= 1u << m;
       if (!col && !sig1) nopc |= 1u << m;
@@ -1613,7 +1610,7 @@ int build_share_plan(tq_segment *s, Group &g, PlanScratch &ps) {
       } else if (m > li) {
         ld.dense_off[m - li - 1u] = off_of(s->opt.use_dense ? s->terms[dq.term[m]].dense_blob : nullptr);
         ld.tf8_off[m - li - 1u] = off_of(s->terms[dq.term[m]].tf8_blob);
-        const uint32_t bitpos = col ? col : (sig1 ? 64u + (sig1 - 1u) : 0u);
+        const uint32_t bitpos = col ? col : (sig1 ? TQD_SIG_SHIFT + (sig1 - 1u) : 0u);
         if (bitpos) {
           if (ncols < 4u)
             ld.cols_lo |= bitpos << (8u * ncols);
@@ -2205,7 +2202,6 @@ int search_batch_impl(tq_segment *s, const tq_query *queries, uint32_t n_queries
     sk.match_counter = s->d_match_counter;
     sk.query_matches = (uint32_t *)s->d_qmatches.p;
     sk.out_index = (const uint32_t *)((const uint8_t *)dstage.p + g.o_outidx);
-    sk.docsig = s->opt.use_dense ? s->d_docsig : nullptr;
     memcpy(hs + g.o_sinks, &sk, sizeof sk);
   }
   const auto tr2 = std::chrono::steady_clock::now();
@@ -2328,7 +2324,6 @@ int search_batch_impl(tq_segment *s, const tq_query *queries, uint32_t n_queries
         if (sp.n_tasks <= sp.task_begin) continue;
         sp.task_counter = counters + ph;
         sp.table_base = (const uint8_t *)s->plan->share_table_base;
-        sp.docsig = s->d_docsig;
         sp.grid = std::min<uint32_t>(share_grid, sp.n_tasks - sp.task_begin);
         const hipError_t e = tqk_launch_share(sp, g.kpl, gst);
         if (e != hipSuccess) return fail(TQ_ERR_HIP, "shared-union launch: %s", hipGetErrorString(e));
@@ -2626,7 +2621,7 @@ int tq_segment_get_stats(tq_segment *s, tq_segment_stats *out) {
   r.alive_bytes = s->bytes_alive;
   r.term_table_bytes = s->bytes_term_tables + s->d_terms_cap * sizeof(TqdTerm);
   r.bitmap_bytes = s->bytes_bitmaps;
-  r.docmat_bytes = s->bytes_docmat + s->bytes_docsig;
+  r.docmat_bytes = s->bytes_docmat;
   r.posdir_bytes = s->bytes_posdir;
   r.scratch_bytes = s->d_stage.cap + s->d_stage_alt.cap + s->d_partials.cap + s->d_out_scores.cap +
                     s->d_out_docs.cap + s->d_out_counts.cap + s->d_misc.cap + s->d_thr.cap +

@@ -13,7 +13,9 @@
 #define TQD_DENSE_RATIO 128   // default: lists with doc_freq >= max_doc/128 also get a bitmap + rank directory
 #define TQD_THR_SLOTS 64      // shared threshold slots per query (pruned mode)
 #define TQD_OR_WINDOW 4096    // docs per OR tile (one workgroup)
-#define TQD_MAT_SLOTS 56      // dense lists per segment with a column in the doc matrix
+#define TQD_MAT_SLOTS 40      // dense lists per segment with a column in the doc matrix (bits 8..47 of a word)
+#define TQD_SIG_SHIFT 48      // bits 48..63 of a doc-matrix word: the signature of the lists WITHOUT a column
+#define TQD_SIG_BITS 16
 
 // A posting list on the device.  The skip list of src/postings/skip.rs:205-253 is unrolled from
 // its sequential form (running byte / position offsets made absolute) into structure-of-arrays
@@ -36,7 +38,7 @@ struct TqdTermHead {  // what every kernel needs: fetched with scalar loads
   uint64_t payload_base;      // absolute offset (inside the .idx sub-file) of block 0's payload
   uint32_t n_blocks, n_tail;
   uint32_t has_freq;          // bit 0: 0 => every tf reads as 1; bits 8..15: doc-matrix slot + 1 (0 = none);
-                              // bits 16..23: signature bit + 1 of a list without a column (0 = none)
+                              // bits 16..23: signature bit (0..15) + 1 of a list without a column (0 = none)
   uint32_t coarse_shift;
 };
 struct TqdTerm : TqdTermHead {
@@ -98,7 +100,8 @@ struct TqdLead {             // 72 bytes, written by the host planner
   float suffix;              // weights of lists i.. : the most a doc first seen in list i can score
   float sparse_after;        // weights of the lists after i with neither column nor signature bit
   uint32_t cols_lo, cols_hi; // membership bits of the after-lists that have one, in list order (0-3 / 4-6):
-                             // 8 + slot = doc-matrix column (exact), 64 + b = signature bit b (maybe)
+                             // bit positions in the doc-matrix word: 8 + slot = the list's column (exact),
+                             // 48 + b = signature bit b (a clear bit proves absence, a set one means maybe)
   float aw[7];               // their weights, in list order
   uint64_t before_mask;      // doc-matrix bits of the lists before i that have a column
   uint8_t sig[8];            // per list of the query: signature bit + 1 (0 = none)

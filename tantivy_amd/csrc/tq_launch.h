@@ -13,7 +13,6 @@ struct TqkSinks {
   unsigned long long *match_counter;  // docs scored by the whole launch
   uint32_t *query_matches;            // per query of the BATCH (through out_index): docs scored
   const uint32_t *out_index;          // launch-group query -> batch query
-  const uint64_t *docsig;             // signature words of the lists without a column, or null (see TqkShareParams)
 };
 
 struct TqkScanParams {
@@ -55,11 +54,6 @@ struct TqkShareParams {
   uint32_t *thr_val;            // [n_queries] current lower bound of each query's k-th best score
   uint32_t *task_counter;       // next task to hand out (zeroed per batch)
   const uint8_t *table_base;    // TqdLead::dense_off / tf8_off count 8-byte units from here
-  // signature word of the lists WITHOUT a column (or null): docsig[d] bit b set iff d is in some
-  // prepared column-less list whose signature bit is b (TqdTermHead::has_freq bits 16..23 = b + 1).
-  // Clear bit = not in the list; set bit = maybe.  (Not in TqdSegment: the other scan kernels do
-  // not use it, and two more scalar registers cost the AND kernel 7 % under its SGPR cap.)
-  const uint64_t *docsig;
   uint64_t *stage;              // [grid][TQD_US_GROUP][capl] per-wave staging lists
   uint64_t *lists;              // per-query result lists (query q: entries part_start .. + n_parts)
   uint32_t *list_count;         // [n_queries] entries written so far
@@ -115,9 +109,7 @@ hipError_t tqk_launch_docmat_set(uint64_t *mat, const uint32_t *docs, uint32_t n
                                  uint32_t max_doc, hipStream_t st);
 // term freqs of a decoded list as bytes (TqdTerm::tf8)
 hipError_t tqk_launch_tf8_pack(const uint32_t *tfs, uint32_t n, uint8_t *out, hipStream_t st);
-// doc signatures (TqdSegment::docsig): set bit `bit` of the list's docs
-hipError_t tqk_launch_docsig_set(uint64_t *sig, const uint32_t *docs, uint32_t n, uint32_t bit,
-                                 uint32_t max_doc, hipStream_t st);
+
 
 // ---- shared with tq_encode.hip: the C ABI's error slot and context checks live in tq_api.cpp
 struct tq_ctx;

@@ -165,11 +165,6 @@ __global__ void tf8_pack_kernel(const uint32_t *tfs, uint32_t n, uint8_t *out) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) out[i] = (uint8_t)(tfs[i] < 255u ? tfs[i] : 255u);
 }
-__global__ void docsig_set_kernel(uint64_t *sig, const uint32_t *docs, uint32_t n, uint32_t bit,
-                                  uint32_t max_doc) {
-  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n && docs[i] < max_doc) atomicOr((unsigned long long *)(sig + docs[i]), 1ull << bit);
-}
 
 }  // namespace
 
@@ -177,13 +172,6 @@ __global__ void docsig_set_kernel(uint64_t *sig, const uint32_t *docs, uint32_t 
 hipError_t tqk_launch_tf8_pack(const uint32_t *tfs, uint32_t n, uint8_t *out, hipStream_t st) {
   if (n == 0) return hipSuccess;
   hipLaunchKernelGGL(tf8_pack_kernel, dim3((n + 255) / 256), dim3(256), 0, st, tfs, n, out);
-  return hipGetLastError();
-}
-hipError_t tqk_launch_docsig_set(uint64_t *sig, const uint32_t *docs, uint32_t n, uint32_t bit,
-                                 uint32_t max_doc, hipStream_t st) {
-  if (n == 0) return hipSuccess;
-  hipLaunchKernelGGL(docsig_set_kernel, dim3((n + 255) / 256), dim3(256), 0, st, sig, docs, n, bit,
-                     max_doc);
   return hipGetLastError();
 }
 hipError_t tqk_launch_docmat_init(uint64_t *mat, const uint8_t *fieldnorm, uint32_t const_id,

@@ -371,7 +371,6 @@ __device__ __forceinline__ void union_body(const TqkScanParams &p) {
   uint32_t n_cmask = 0;                      // boolean queries: testable Must clauses after the leader set
   uint32_t sig_mask = 0;                     // ... lists with a signature bit instead of a column
   bool lead_test = false;                    // ... the lead Must clause is testable (optional leaders)
-  const uint64_t *docsig = nullptr;          // ... the segment's signature words
   const bool use_sig = BOOL && !(p.debug & 65536u);
   uint32_t slots_sum = 0;  // checksum of the threshold slots at the last radix select
   float slack_abs = 0.0f;
@@ -465,17 +464,16 @@ __device__ __forceinline__ void union_body(const TqkScanParams &p) {
       // the column masks of the all-column Must clauses and of the MustNot terms
       // a list's membership bit: its doc-matrix column (exact), else its signature bit (a clear
       // bit proves absence, a set one means "maybe"), else none: mshift < 64 / 64..127 / >= 128
-      docsig = use_sig ? sload(&p.sinks->docsig) : nullptr;
       uint32_t slot = 0xFFFFFFFFu, sbit = 0xFFFFFFFFu;
       if ((uint32_t)lane < nt) {
         const TqdTerm *tt = p.terms + Q->term[lane];
         if (p.use_dense && tt->dense && seg.docmat) slot = ((tt->has_freq >> 8) & 0xFFu) - 1u;
-        if (slot >= TQD_MAT_SLOTS && docsig) sbit = ((tt->has_freq >> 16) & 0xFFu) - 1u;
+        if (slot >= TQD_MAT_SLOTS && use_sig && seg.docmat) sbit = ((tt->has_freq >> 16) & 0xFFu) - 1u;
         L.wgt[lane] = Q->weight[lane];
-        L.mshift[lane] = slot < TQD_MAT_SLOTS ? 8u + slot : (sbit < 64u ? 64u + sbit : 128u);
+        L.mshift[lane] = slot < TQD_MAT_SLOTS ? 8u + slot : (sbit < TQD_SIG_BITS ? TQD_SIG_SHIFT + sbit : 128u);
       }
       mat_mask = (uint32_t)__ballot(slot < TQD_MAT_SLOTS);
-      sig_mask = (uint32_t)__ballot(sbit < 64u);
+      sig_mask = (uint32_t)__ballot(sbit < TQD_SIG_BITS);
       slack_abs = suf * 4.0e-6f;
       uint64_t notm = 0, leadm = 0, leads = 0, cm = 0, cs = 0;
       bool call = true;  // every term of the current clause has a column or a signature bit
@@ -485,7 +483,7 @@ __device__ __forceinline__ void union_body(const TqkScanParams &p) {
         const uint32_t role = (roles >> (2u * m)) & 3u;
         const bool has = (mat_mask >> m) & 1u, hsig = (sig_mask >> m) & 1u;
         const uint64_t bit = has ? 1ull << (8u + (uint32_t)__builtin_amdgcn_readlane((int)slot, (int)m)) : 0ull;
-        const uint64_t sgb = hsig ? 1ull << (uint32_t)__builtin_amdgcn_readlane((int)sbit, (int)m) : 0ull;
+        const uint64_t sgb = hsig ? 1ull << (TQD_SIG_SHIFT + (uint32_t)__builtin_amdgcn_readlane((int)sbit, (int)m)) : 0ull;
         if (role == TQD_ROLE_MUST_NOT) {
           notm |= bit;  // (only an exact bit may exclude)
         } else if (m < n_lead) {
@@ -860,24 +858,22 @@ __device__ __forceinline__ void union_body(const TqkScanParams &p) {
       doc = L.q1_doc[base + lane];
       tf = L.q1_tf[base + lane];
     }
-    const uint64_t mw = alive ? seg.docmat[doc] : 0ull;
-    const uint64_t sg = (alive && docsig) ? docsig[doc] : 0ull;
+    const uint64_t mw = alive ? seg.docmat[doc] : 0ull;  // (column bits, signature bits, fieldnorm id)
     // ownership: lists of the leader set before li
     uint64_t own = 0;
     for (uint32_t mm = mat_mask & ((1u << (li < n_lead ? li : n_lead)) - 1u); mm; mm &= mm - 1u)
       own |= 1ull << L.mshift[__builtin_ctz(mm)];
     if (mw & (own | L.bmask[0])) alive = false;
-    if (li < n_opt_lead && lead_test && !((mw & L.bmask[1]) | (sg & L.bmask[2]))) alive = false;
+    if (li < n_opt_lead && lead_test && !(mw & (L.bmask[1] | L.bmask[2]))) alive = false;
     for (uint32_t c = 0; c < n_cmask; ++c)
-      if (!((mw & L.cmask[c]) | (sg & L.csig[c]))) alive = false;
+      if (!(mw & (L.cmask[c] | L.csig[c]))) alive = false;
     if (prune && alive) {
       float rest = 0.0f;
       for (uint32_t m = 0; m < nt; ++m) {
         if (m == li) continue;
         const float w = L.wgt[m];  // (0 for MustNot terms)
         const uint32_t sh = L.mshift[m];
-        const uint64_t src = sh < 64u ? mw : sg;
-        rest += sh < 128u ? (((src >> (sh & 63u)) & 1ull) ? w : 0.0f) : w;
+        rest += sh < 64u ? (((mw >> sh) & 1ull) ? w : 0.0f) : w;
       }
       const float sl = bm25_bound(w_lead, L.cache[(uint32_t)mw & 0xFFu], tf);
       alive = sortable((sl + rest) * 1.000004f + slack_abs) >= thr;

@@ -295,7 +295,6 @@ ushare_kernel(TqkShareParams p) {
     // fieldnorm id + membership in the dense lists: the doc-matrix word again (a gather for the
     // survivors only; stage F does not carry it through the queue)
     const uint64_t mw = alive ? seg.docmat[doc] : 0ull;
-    const uint64_t sg = (alive && p.docsig) ? p.docsig[doc] : 0ull;
     const float norm = L.cache[(uint32_t)mw & 0xFFu];
     uint32_t bits = 0;
     {
@@ -303,8 +302,7 @@ ushare_kernel(TqkShareParams p) {
 #pragma unroll
       for (uint32_t c = 0; c < 7u; ++c) {
         const uint32_t col = ((c < 4u ? cl >> (8u * c) : ch >> (8u * (c - 4u)))) & 0xFFu;
-        const uint64_t src = col >= 64u ? sg : mw;
-        bits |= (col ? (uint32_t)(src >> (col & 63u)) & 1u : 0u) << c;
+        bits |= (col ? (uint32_t)(mw >> col) & 1u : 0u) << c;
       }
     }
     // the lead's constants from lane g's registers
@@ -448,7 +446,7 @@ ushare_kernel(TqkShareParams p) {
       bool probe = alive && m < li && ((nocol >> m) & 1u);
       if (probe) {  // the signature word may already say "not in that list"
         const uint32_t sb1 = L.lead[g].sig[m & 7u];
-        if (sb1 && !((sg >> (sb1 - 1u)) & 1u)) probe = false;
+        if (sb1 && !((mw >> (TQD_SIG_SHIFT + sb1 - 1u)) & 1u)) probe = false;
       }
       if (probe && !(sortable(s * 1.000002f + slack_abs) >= thr)) {  // the score is final: dead either way
         alive = false;
@@ -580,8 +578,6 @@ ushare_kernel(TqkShareParams p) {
       return (uint32_t)lane < n_leads && sortable(L.lead[lane].suffix * 1.000001f) >= L.lthr[lane];
     };
     uint32_t live = (uint32_t)__ballot(lead_alive());
-    const bool task_sig = p.docsig != nullptr &&
-                          __ballot((uint32_t)lane < n_leads && ((L.lead[lane].info >> 12) & 1u)) != 0ull;
     te(2u);
 
     for (uint32_t jt = 0; jt < nb_task && live; jt += TQD_US_TILE) {
@@ -678,11 +674,6 @@ ushare_kernel(TqkShareParams p) {
         // ONE gather per doc: fieldnorm id + membership in every dense list of the segment
         const uint64_t mw0 = v0 ? seg.docmat[c0] : 0ull;
         const uint64_t mw1 = v1 ? seg.docmat[c1] : 0ull;
-        uint64_t sg0 = 0, sg1 = 0;  // signature words, when a lead of the task tests them
-        if (task_sig) {
-          sg0 = v0 ? p.docsig[c0] : 0ull;
-          sg1 = v1 ? p.docsig[c1] : 0ull;
-        }
         const uint32_t nid0 = (uint32_t)mw0 & 0xFFu, nid1 = (uint32_t)mw1 & 0xFFu;
         const float f0 = (float)t0, f1 = (float)t1;
         wave_mem_fence();
@@ -714,9 +705,8 @@ ushare_kernel(TqkShareParams p) {
             if (c < ncols) {  // (wave-uniform)
               const uint32_t col = ((c < 4u ? cols_lo >> (8u * c) : cols_hi >> (8u * (c - 4u)))) & 0xFFu;
               const float aw = ld.aw[c];
-              const uint64_t s0 = col >= 64u ? sg0 : mw0, s1 = col >= 64u ? sg1 : mw1;  // (uniform select)
-              rest0 = fmaf((float)((uint32_t)(s0 >> (col & 63u)) & 1u), aw, rest0);
-              rest1 = fmaf((float)((uint32_t)(s1 >> (col & 63u)) & 1u), aw, rest1);
+              rest0 = fmaf((float)((uint32_t)(mw0 >> col) & 1u), aw, rest0);
+              rest1 = fmaf((float)((uint32_t)(mw1 >> col) & 1u), aw, rest1);
             }
           }
           const bool a0 = v0 && !(((uint32_t)mw0 & b_lo) | ((uint32_t)(mw0 >> 32) & b_hi)) && fmaf(w, L.tfn[0][lane], rest0) >= need;

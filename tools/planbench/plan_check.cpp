@@ -68,16 +68,15 @@ static int check_share(int seed) {
     th.doc_freq = th.n_blocks * 128u;
     TqdTerm dt{};
     dt.has_freq = 1u;
-    if (t < 80) {  // dense: bitmap + tf8 at fake (distinct, 8-aligned) addresses; the first 56 have columns
+    if (t < 80) {  // dense: bitmap + tf8 at fake (distinct, 8-aligned) addresses; the first 40 have columns
       th.dense_blob = arena + 4096u * t + 8u;
       th.tf8_blob = arena + 4096u * t + 2048u;
-      if (t < 56) dt.has_freq |= (t + 1u) << 8;
+      if (t < TQD_MAT_SLOTS) dt.has_freq |= (t + 1u) << 8;
     }
-    if (t >= 56 && t % 3) dt.has_freq |= ((t * 7u) % 64u + 1u) << 16;  // signature bits for some
+    if (t >= TQD_MAT_SLOTS && t % 3) dt.has_freq |= ((t * 7u) % TQD_SIG_BITS + 1u) << 16;  // signature bits for some
     seg.terms.push_back(th);
     seg.h_dterms.push_back(dt);
   }
-  seg.d_docsig = (uint64_t *)arena;  // (only tested against null)
   seg.max_doc = 10000000u;
   PlanScratch ps;
   Group &g = ps.groups[5];
@@ -109,11 +108,7 @@ static int check_share(int seed) {
     g.out_index.push_back(q);
     g.max_k = std::max(g.max_k, dq.k);
   }
-  if (build_share_plan(&seg, g, ps) != TQ_OK) {
-    seg.d_docsig = nullptr;
-    return fail_msg("build_share_plan failed");
-  }
-  seg.d_docsig = nullptr;  // (not ours to free)
+  if (build_share_plan(&seg, g, ps) != TQ_OK) return fail_msg("build_share_plan failed");
   size_t n_leads = 0;
   for (const TqdQuery &q : g.queries) n_leads += q.n_terms;
   if (ps.leads.size() != n_leads) return fail_msg("lead count", (long)ps.leads.size(), (long)n_leads);
@@ -138,7 +133,7 @@ static int check_share(int seed) {
       if (ld.sig[m] != sig1) return fail_msg("sig byte", ld.query, m);
       if (m < li && col && !((ld.before_mask >> col) & 1ull)) return fail_msg("before_mask", ld.query, m);
       if (m > li) {
-        const uint32_t want = col ? col : (sig1 ? 64u + sig1 - 1u : 0u);
+        const uint32_t want = col ? col : (sig1 ? TQD_SIG_SHIFT + sig1 - 1u : 0u);
         if (want) {
           const uint32_t got = ((c < 4 ? ld.cols_lo >> (8 * c) : ld.cols_hi >> (8 * (c - 4)))) & 0xFFu;
           if (got != want || ld.aw[c] != q.weight[m]) return fail_msg("column entry", ld.query, m);
