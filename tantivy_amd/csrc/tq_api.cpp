@@ -1631,11 +1631,12 @@ int build_share_plan(tq_segment *s, Group &g, PlanScratch &ps) {
   // cost of every position's tasks together (a block costs its decode + one test per lead): a
   // position with little work is cut into smaller tasks, so that it still fills the chip and its
   // launch does not end on a few long tasks
-  // (measured: or5 at k = 100 wants ~8192 tasks per position — 4096: +10 % time, 12288: +13 % — the
-  // mixed stream at k = 10 ~4096: its thresholds settle after a few docs, and longer tasks keep the
-  // feedback inside one wave: 8.85 against 9.7 ms)
+  // (measured, kernel ms: or5 at k = 100 wants ~6144 tasks per position — 3072: 2.65, 4096: 2.54, 5120:
+  // 2.44, 6144: 2.36, 7168: 2.51, 10240: 2.83 — the mixed stream at k = 10 ~4096: 3072: 9.75, 4096: 9.02,
+  // 5120: 9.19, 6144: 9.54: its thresholds settle after a few docs, and longer tasks keep the
+  // feedback inside one wave)
   static const uint32_t kPhaseTasksEnv = tune_u32("TQ_US_PHASE_TASKS", 0);
-  const uint32_t kPhaseTasks = kPhaseTasksEnv ? kPhaseTasksEnv : (g.max_k <= 16u ? 4096u : 8192u);
+  const uint32_t kPhaseTasks = kPhaseTasksEnv ? kPhaseTasksEnv : (g.max_k <= 16u ? 4096u : 6144u);
   uint64_t phase_cost[TQD_US_MAX_TERMS] = {};
   for (size_t r0 = 0; r0 < keys.size();) {
     size_t r1 = r0;
