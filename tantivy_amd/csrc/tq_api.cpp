@@ -186,6 +186,11 @@ struct tq_segment {
   // batch scratch
   DevBuf d_stage, d_partials, d_out_scores, d_out_docs, d_out_counts, d_misc, d_thr, d_qmatches;
   DevBuf d_share_words, d_share_stage;  // shared-union launch: per-query words, staging lists
+  // the shared-union launch addresses bitmaps / byte-wide tfs as 32-bit offsets (8-byte units) from
+  // the lowest such table: usable while all of them lie within 32 GB of device addresses
+  size_t share_span_terms = 0;  // number of terms the span was computed over
+  uint64_t share_table_lo = 0;
+  bool share_span_ok = true;
   uint32_t last_batch_queries = 0;
   PinnedBuf h_stage, h_out;
   // timing: a ring of event quadruples, one per batch, so that pipelined batches (no host sync
@@ -1566,20 +1571,9 @@ int build_share_plan(tq_segment *s, Group &g, PlanScratch &ps) {
   tasks.clear();
   pairs.assign(nq, 0u);
   // bitmaps and byte-wide tfs are addressed as 32-bit offsets (8-byte units) from one base: the
-  // lowest table address among the batch's lists (32 GB of span; beyond it the batch is refused)
-  uint64_t lo = ~0ull, hi = 0;
-  for (const ShareKey &k : keys) {
-    const TermHost &th = s->terms[k.term];
-    for (const void *ptr : {th.dense_blob, th.tf8_blob})
-      if (ptr) {
-        lo = std::min<uint64_t>(lo, (uint64_t)ptr);
-        hi = std::max<uint64_t>(hi, (uint64_t)ptr);
-      }
-  }
-  if (lo == ~0ull) lo = 8;
-  ps.share_table_base = lo - 8;
-  if (hi - ps.share_table_base >= (8ull << 32))
-    return fail(TQ_ERR_UNSUPPORTED, "dense-list tables span more than 32 GB of device addresses");
+  // lowest table address of the segment (the caller checked that they span less than 32 GB:
+  // otherwise the unions keep the per-query kernel)
+  ps.share_table_base = s->share_table_lo;
   auto off_of = [&](const void *ptr) -> uint32_t {
     return ptr ? (uint32_t)(((uint64_t)ptr - ps.share_table_base) >> 3) : 0u;
   };
@@ -1880,6 +1874,19 @@ int search_batch_impl(tq_segment *s, const tq_query *queries, uint32_t n_queries
   // pure unions, pruned, k <= 128, <= 8 terms, on a segment with a doc matrix: the shared-union
   // launch (term-major, tq_ushare.hip); everything else keeps the per-query union kernels
   static const bool kUseShare = tune_u32("TQ_USHARE", 1) != 0;
+  if (s->share_span_terms != s->terms.size()) {  // (terms are prepared rarely)
+    uint64_t lo = ~0ull, hi = 0;
+    for (const TermHost &th : s->terms)
+      for (const void *ptr : {th.dense_blob, th.tf8_blob})
+        if (ptr) {
+          lo = std::min<uint64_t>(lo, (uint64_t)ptr);
+          hi = std::max<uint64_t>(hi, (uint64_t)ptr);
+        }
+    if (lo == ~0ull) lo = hi = 8;
+    s->share_table_lo = lo - 8;
+    s->share_span_ok = hi - s->share_table_lo < (8ull << 32);
+    s->share_span_terms = s->terms.size();
+  }
   if (!s->plan) s->plan = new PlanScratch();
   Group(&groups)[kGroups] = s->plan->groups;
   for (Group &g : groups) g.reset();
@@ -2061,7 +2068,7 @@ int search_batch_impl(tq_segment *s, const tq_query *queries, uint32_t n_queries
           }
         }
       }
-      share = kUseShare && !or_windows_opt && (dq.flags & TQD_QF_PRUNE) && dq.thr_index != 0xFFFFFFFFu &&
+      share = kUseShare && s->share_span_ok && !or_windows_opt && (dq.flags & TQD_QF_PRUNE) && dq.thr_index != 0xFFFFFFFFu &&
               dq.n_terms >= 1 && dq.n_terms <= TQD_US_MAX_TERMS && s->d_docmat && s->opt.use_dense &&
               cache_idx < 256u;
       for (uint32_t i = 0; share && i < dq.n_terms; ++i)  // (lists with a bitmap carry byte-wide tfs)

@@ -108,6 +108,7 @@ static int check_share(int seed) {
     g.out_index.push_back(q);
     g.max_k = std::max(g.max_k, dq.k);
   }
+  seg.share_table_lo = (uint64_t)arena;  // (what search_batch_impl computes over the segment's terms)
   if (build_share_plan(&seg, g, ps) != TQ_OK) return fail_msg("build_share_plan failed");
   size_t n_leads = 0;
   for (const TqdQuery &q : g.queries) n_leads += q.n_terms;
