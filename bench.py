@@ -64,7 +64,7 @@ def parse_args(argv=None):
     ap.add_argument("--pruned", action="store_true", help="(default; kept for old command lines)")
     ap.add_argument("--no-side", action="store_true",
                     help="only the main workload (profiling runs): skip other_workloads and strong_scaling")
-    ap.add_argument("--side-steps", type=int, default=5)
+    ap.add_argument("--side-steps", type=int, default=10)
     ap.add_argument("--selftest-launcher", action="store_true",
                     help="CPU plumbing check of the rank launcher (gloo, no GPU work, no timing)")
     return ap.parse_args(argv)
@@ -552,7 +552,7 @@ def main():
                 s_runner = D.ShardRunner([s_seg], cl.local_rank)
                 s_runner.set_option("timing", 1)
             qs, kk = build_queries(O, wl, DEFAULT_QUERIES[wl], None)
-            sm = measure(cl, s_runner, torch, qs, kk, args.side_steps, 1)
+            sm = measure(cl, s_runner, torch, qs, kk, args.side_steps, 2)
             if not sm["mode_parity"]:
                 raise SystemExit("%s: pruned and exhaustive results differ on %d queries" % (wl, sm["n_diff"]))
             checked = spot_check(O, cl, [s_seg], rank, None, wl, qs, kk, sm["final"], 64)
@@ -600,7 +600,8 @@ def main():
         srun.comm, srun.torch_group = cl.comm, cl.torch_group
         srun.set_option("timing", 1)
         qs, kk = build_queries(O, "mixed", DEFAULT_QUERIES["mixed"], None)
-        sm = measure(cl, srun, torch, qs, kk, args.side_steps, 1)
+        strong_steps = max(3, args.side_steps // 2)
+        sm = measure(cl, srun, torch, qs, kk, strong_steps, 1)
         if not sm["mode_parity"]:
             raise SystemExit("strong: pruned and exhaustive results differ on %d queries" % sm["n_diff"])
         k_ms = sm["stats"]["kernel_ms"]
@@ -616,8 +617,8 @@ def main():
                        N_SEGMENTS_STRONG * args.docs // 1_000_000, len(qs), kk, s_local),
             "scaling": "strong", "unit": "queries/s over the whole %d-segment index" % N_SEGMENTS_STRONG,
             "n_gpus": world, "segments_per_gpu": s_local,
-            "qps": round(len(qs) * args.side_steps / sm["elapsed"], 1),
-            "ms_per_step": round(sm["elapsed"] / args.side_steps * 1e3, 3),
+            "qps": round(len(qs) * strong_steps / sm["elapsed"], 1),
+            "ms_per_step": round(sm["elapsed"] / strong_steps * 1e3, 3),
             "kernel_ms_per_gpu": round(k_ms, 4),
             "roofline_achieved_GBps_per_gpu": ach, "roofline_frac_per_gpu": fr,
             "algorithmic_bytes_per_step_per_gpu": int(sm["algo_bytes_full"]),

@@ -22,7 +22,7 @@ from collections import defaultdict
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
-SCAN = re.compile(r"(and_kernel|union_kernel_small|union_kernel|ushare_kernel|or_kernel|phrase_kernel)<([^>]*)>")
+SCAN = re.compile(r"(and_kernel|union_kernel_small|union_kernel|ushare_kernel|or_kernel|phrase_sweep_kernel|phrase_kernel)<([^>]*)>")
 
 
 def classify(name):
@@ -31,7 +31,7 @@ def classify(name):
     if not m:
         return None
     fam, args = m.group(1), [a.strip() for a in m.group(2).split(",")]
-    if fam == "phrase_kernel":
+    if fam in ("phrase_kernel", "phrase_sweep_kernel"):
         return fam, "both"  # the reference prunes nothing before positions are read
     if fam == "ushare_kernel":
         return fam, "pruned"  # the shared-union launch only exists in the pruned mode
