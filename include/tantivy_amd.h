@@ -313,9 +313,9 @@ int tq_last_batch_stats(tq_segment *seg, tq_batch_stats *out);
  * lists, the doc matrix, position directories — plus the per-batch scratch. */
 typedef struct tq_segment_stats {
   uint64_t index_bytes, positions_bytes, fieldnorm_bytes, alive_bytes; /* tantivy's bytes */
-  uint64_t term_table_bytes, bitmap_bytes, docmat_bytes, posdir_bytes; /* derived */
+  uint64_t term_table_bytes, bitmap_bytes /* + byte-wide tfs */, docmat_bytes, posdir_bytes; /* derived */
   uint64_t scratch_bytes;       /* staging, partial lists, threshold slots, result slabs */
-  uint64_t dense_budget_bytes;  /* cap on bitmap + docmat + posdir bytes ("dense_budget_x") */
+  uint64_t dense_budget_bytes;  /* cap on bitmap (+ byte-wide tf) + docmat + posdir bytes ("dense_budget_x") */
   uint32_t n_terms, n_dense_lists, n_docmat_columns;
 } tq_segment_stats;
 int tq_segment_get_stats(tq_segment *seg, tq_segment_stats *out);
@@ -336,10 +336,10 @@ int tq_segment_get_stats(tq_segment *seg, tq_segment_stats *out);
  *        stays exact (the reference accepts the approximation, term_scorer.rs:58-70),
  *        "dense_budget_x" (default 8: bitmaps + byte-wide term freqs of the dense lists + doc matrix
  *        + doc signatures + position directories together stay below this multiple of the
- *        segment), "docmat" (0/1, default 1: the first 56 dense lists also get a column in a
+ *        segment), "docmat" (0/1, default 1: the first 40 dense lists also get a column in a
  *        doc-major matrix: one 8-byte word per doc = fieldnorm id + the doc's membership in those
- *        lists), "docsig" (0/1, default 1: one more 8-byte word per doc, a 64-bit signature of the
- *        prepared lists WITHOUT a column: a clear bit proves the doc is not in the list), "device_prepare" (0/1, default 0: tq_term_prepare
+ *        lists), "docsig" (0/1, default 1: the top 16 bits of those words are a signature of the
+ *        prepared lists WITHOUT a column: a clear bit proves the doc is not in such a list), "device_prepare" (0/1, default 0: tq_term_prepare
  *        works on the device copy even when a host copy exists; always so for segments from
  *        tq_segment_upload_device),
  *        "use_dpp" (0/1: DPP or ds_bpermute prefix sums) */
