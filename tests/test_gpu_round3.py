@@ -160,3 +160,83 @@ def test_segment_stats_account_for_the_resident_bytes(ta):
                                        + st["posdir_bytes"])
     finally:
         dev.close()
+
+
+def _big_tf_segment(with_positions):
+    """20k docs, 8 lists (5 dense with bitmaps / tf bytes, 3 sparse), term freqs mostly 1..3 with
+    255, 256, 300 and 1000 planted in every list — the saturated value of the byte-wide tfs and
+    the values beyond it."""
+    rng = np.random.default_rng(2026)
+    md = 20_000
+    dfs = [9000, 6000, 4000, 2500, 1200, 150, 90, 40]
+    lists, positions = [], []
+    for t, df in enumerate(dfs):
+        docs = np.sort(rng.choice(md, size=df, replace=False))
+        tfs = rng.integers(1, 4, size=df)
+        for j, big in enumerate((255, 256, 300, 1000)):
+            tfs[(7 * t + 31 * j) % df] = big
+        tfs[: min(df, 4)] = [254, 255, 3, 256][: min(df, 4)]  # one group of four holding both sides of 255
+        lists.append(list(zip(docs.tolist(), tfs.tolist())))
+        if with_positions:
+            positions.append([sorted(rng.choice(4000, size=int(tf), replace=False).tolist()) for tf in tfs])
+    if with_positions:  # plant the phrase "0 1 2 3" (positions 100..103) in 30 docs that hold all four terms
+        common = sorted(set.intersection(*[set(d for d, _ in lists[t]) for t in range(4)]))[:30]
+        for t in range(4):
+            at = {d: i for i, (d, _) in enumerate(lists[t])}
+            for d in common:
+                ps = [x for x in positions[t][at[d]] if not 100 <= x <= 103]
+                ps = sorted(ps[: len(positions[t][at[d]]) - 1] + [100 + t])
+                positions[t][at[d]] = ps
+    fieldnorms = rng.integers(1200, 4000, size=md).tolist()
+    return O.build_segment(md, lists, fieldnorms,
+                           record_option=O.WITH_FREQS_AND_POSITIONS if with_positions else O.WITH_FREQS,
+                           positions=positions if with_positions else None)
+
+
+@pytest.mark.parametrize("k", [3, 10, 100])
+def test_union_with_saturated_tf_bytes(ta, k):
+    """tf >= 255 does not fit the byte-wide tfs (TqdTerm::tf8): the shared-union kernel has to read the
+    packed value for exactly those postings.  Pruned == exhaustive == oracle."""
+    seg = _big_tf_segment(False)
+    qs = [(O.MODE_OR, [0, 1, 2, 3, 4]), (O.MODE_OR, [7, 0, 1]), (O.MODE_OR, [5, 6, 7, 2, 4]),
+          (O.MODE_OR, [6, 3]), (O.MODE_OR, [4]), (O.MODE_OR, [5, 0]), (O.MODE_OR, [1, 2, 3, 5, 6, 7, 0, 4])]
+    dev = ta.DeviceIndex([seg])
+    try:
+        dev.set_option("dense_ratio", 16)  # df >= 1250: lists 0..3 dense; 4 (df 1200) and below not
+        got = {}
+        for ex in (1, 0):
+            dev.set_option("exhaustive", ex)
+            got[ex] = dev.search(qs, k)
+        for a, b in zip(got[0], got[1]):
+            assert np.array_equal(a, b)
+        sc, _, docs, cnt = got[0]
+        for qi, (mode, terms) in enumerate(qs):
+            want = O.search(seg, terms, mode, k, pruned=False)
+            g = [(float(sc[qi, j]), int(docs[qi, j])) for j in range(int(cnt[qi]))]
+            assert [d for _, d in g] == [d for _, d in want], (terms, g, want)
+            for (gs, _), (ws, _) in zip(g, want):
+                assert rel_close(gs, ws, 1e-5)
+    finally:
+        dev.close()
+
+
+def test_phrase_with_saturated_tf_bytes(ta):
+    """The phrase kernels take a posting's tf and the index of its first position from the tf bytes
+    of its group of four: a saturated byte in the group must send them to the packed values."""
+    seg = _big_tf_segment(True)
+    qs = [(O.MODE_PHRASE, [0, 1]), (O.MODE_PHRASE, [1, 0, 2]), (O.MODE_PHRASE, [2, 3]), (O.MODE_PHRASE, [0, 1, 2, 3]),
+          (O.MODE_PHRASE, [3, 0])]
+    for ratio in (16, 2):  # all lists of the queries dense (sweep kernel) / only lists 0 and 1 dense
+        dev = ta.DeviceIndex([seg])
+        try:
+            dev.set_option("dense_ratio", ratio)
+            sc, _, docs, cnt = dev.search(qs, 20)
+            for qi, (mode, terms) in enumerate(qs):
+                want = O.search(seg, terms, mode, 20, pruned=False)
+                g = [(float(sc[qi, j]), int(docs[qi, j])) for j in range(int(cnt[qi]))]
+                assert [d for _, d in g] == [d for _, d in want], (ratio, terms, g, want)
+                assert terms != [0, 1, 2, 3] or len(want) == 20
+                for (gs, _), (ws, _) in zip(g, want):
+                    assert rel_close(gs, ws, 1e-5)
+        finally:
+            dev.close()
