@@ -1,5 +1,9 @@
 // tq_union.hip — unions and boolean queries: or_kernel (4096-doc windows) and union_kernel (candidate-driven).
 // Shared device helpers: tq_common.hpp.
+// (Since round 3 the pure unions of a batch — pruned, k <= 128, <= 8 terms, segment with a doc
+// matrix — run term by term in tq_ushare.hip; this file serves the boolean queries (union_kernel<..,
+// BOOL = true>, with the doc-matrix pre-stage b0_test in front of the exact walk), the unions the
+// shared launch does not take, and the exhaustive mode (or_kernel).)
 #include "tq_common.hpp"
 
 // build switches of the union kernel (tools/build_variant.py makes A/B libraries from them)
@@ -331,7 +335,7 @@ struct UnionLds {  // per wavefront
   // pure unions: survivors of the membership stage (doc, tf, membership bits | fieldnorm id << 16,
   // what the lists after the leader can still add) and per-query tables read by broadcast
   // (boolean queries: survivors of the doc-matrix pre-stage, doc and tf only)
-  uint32_t q2_doc[127], q2_tf[127], q2_mx[BOOL ? 1 : 127];
+  uint32_t q2_doc[BOOL ? 191 : 127], q2_tf[BOOL ? 191 : 127], q2_mx[BOOL ? 1 : 127];
   float q2_rest[BOOL ? 1 : 127];
   // boolean queries: doc-matrix bits of every Must clause after the leader set whose terms all
   // have a column (a doc with none of them cannot match), and of the MustNot terms with a column
@@ -848,17 +852,7 @@ __device__ __forceinline__ void union_body(const TqkScanParams &p) {
   // columns holds it in none of them (intersection.rs:120-179 / exclude.rs with the seeks replaced
   // by bit tests); or "leader score + weights of the other lists that hold or may hold it" cannot
   // reach the threshold.  Survivors (11..20 % on the bench shapes) take the exact walk of stage B.
-  auto stageB0 = [&](uint32_t n) __attribute__((always_inline)) {
-    const uint32_t base = q1n - n;
-    q1n = base;
-    if (p.debug & 64u) n_matches += n;  // COUNTERS
-    bool alive = (uint32_t)lane < n;
-    uint32_t doc = 0, tf = 0;
-    if (alive) {
-      doc = L.q1_doc[base + lane];
-      tf = L.q1_tf[base + lane];
-    }
-    const uint64_t mw = alive ? seg.docmat[doc] : 0ull;  // (column bits, signature bits, fieldnorm id)
+  auto b0_test = [&](uint64_t mw, uint32_t tf, bool alive) __attribute__((always_inline)) -> bool {
     // ownership: lists of the leader set before li
     uint64_t own = 0;
     for (uint32_t mm = mat_mask & ((1u << (li < n_lead ? li : n_lead)) - 1u); mm; mm &= mm - 1u)
@@ -878,6 +872,20 @@ __device__ __forceinline__ void union_body(const TqkScanParams &p) {
       const float sl = bm25_bound(w_lead, L.cache[(uint32_t)mw & 0xFFu], tf);
       alive = sortable((sl + rest) * 1.000004f + slack_abs) >= thr;
     }
+    return alive;
+  };
+  auto stageB0 = [&](uint32_t n) __attribute__((always_inline)) {
+    const uint32_t base = q1n - n;
+    q1n = base;
+    if (p.debug & 64u) n_matches += n;  // COUNTERS
+    bool alive = (uint32_t)lane < n;
+    uint32_t doc = 0, tf = 0;
+    if (alive) {
+      doc = L.q1_doc[base + lane];
+      tf = L.q1_tf[base + lane];
+    }
+    const uint64_t mw = alive ? seg.docmat[doc] : 0ull;  // (column bits, signature bits, fieldnorm id)
+    alive = b0_test(mw, tf, alive);
     const uint64_t mk = __ballot(alive);
     if (mk) {
       const uint32_t pos = q2n + mbcnt64(mk);
@@ -1244,6 +1252,35 @@ __device__ __forceinline__ void union_body(const TqkScanParams &p) {
       const uint64_t m0 = __ballot(alive0), m1 = __ballot(alive1);
       if (!(m0 | m1)) continue;
       if (p.debug & 1024u) continue;  // ABLATION: no stage B / C
+      if constexpr (BOOL) {
+        if (use_b0 && prune) {
+          // the doc-matrix pre-stage on the block's 128 docs at once: both gathers in flight with
+          // all lanes live, no queue in between (one round trip per block, not one per 64 candidates)
+          if (p.debug & 64u) n_matches += (uint32_t)__popcll(m0) + (uint32_t)__popcll(m1);  // COUNTERS
+          const uint64_t w0 = alive0 ? seg.docmat[c0] : 0ull;
+          const uint64_t w1 = alive1 ? seg.docmat[c1] : 0ull;
+          alive0 = b0_test(w0, t0, alive0);
+          alive1 = b0_test(w1, t1f, alive1);
+          const uint64_t k0 = __ballot(alive0), k1 = __ballot(alive1);
+          if (!(k0 | k1)) continue;
+          const uint32_t kn0 = (uint32_t)__popcll(k0);
+          const uint32_t p0 = q2n + mbcnt64(k0);
+          const uint32_t p1 = q2n + kn0 + mbcnt64(k1);
+          wave_mem_fence();
+          if (alive0) {
+            L.q2_doc[p0] = c0;
+            L.q2_tf[p0] = t0;
+          }
+          if (alive1) {
+            L.q2_doc[p1] = c1;
+            L.q2_tf[p1] = t1f;
+          }
+          wave_mem_fence();
+          q2n += kn0 + (uint32_t)__popcll(k1);
+          while (q2n >= 64u) stageB(64u, true);
+          continue;
+        }
+      }
       const uint32_t n0 = (uint32_t)__popcll(m0);
       const uint32_t pos0 = q1n + mbcnt64(m0);
       const uint32_t pos1 = q1n + n0 + mbcnt64(m1);

@@ -25,6 +25,15 @@ if len(sys.argv) > 2:  # child: one phase
     if wl == "or5":
         qs = [(O.MODE_OR, q.tolist()) for q in O.zipf_queries(1000, 5, 256, seed=20260922)]
         k = 100
+    elif wl == "bool":
+        import tantivy_amd as T
+        M, S, N = T.MUST, T.SHOULD, T.MUST_NOT
+        shapes = [(3, [M, M, M], [0, 1, 1]), (4, [M, M, M, M], [0, 0, 1, 1]), (3, [M, S, N], None), (3, [M, M, M], [0, 0, 1])]
+        qs = []
+        for i, q in enumerate(O.zipf_queries(2000, 4, 256, seed=20260924)):
+            nt, occ, cof = shapes[i % 4]
+            qs.append((T.MODE_BOOL, q.tolist()[:nt], occ, cof, 0))
+        k = 10
     elif wl == "and2":
         qs = [(O.MODE_AND, q.tolist()) for q in O.zipf_queries(10000, 2, 256, seed=20260921)]
         k = 10
@@ -39,7 +48,7 @@ if len(sys.argv) > 2:  # child: one phase
     print("phase %s kernel %.3f ms wave-cycles %.4g" % (sys.argv[2], st["kernel_ms"], st["matches"] * 16.0))
     dev.close()
 else:
-    if sys.argv[1] == "or5" and not os.environ.get("TQ_LIB_PATH"):  # the union kernel's timers are compiled out by default
+    if sys.argv[1] in ("or5", "bool") and not os.environ.get("TQ_LIB_PATH"):  # the union kernel's timers are compiled out by default
         lib = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "build_variant.py"), "timers",
                               "tq_union.hip", "-DTQ_U_TIMERS=1"], capture_output=True, text=True).stdout.strip().splitlines()[-1]
         os.environ["TQ_LIB_PATH"] = lib
