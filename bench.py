@@ -511,6 +511,9 @@ def main():
     for name in ("dense_ratio", "dense_budget_x", "docmat", "docsig", "device_prepare", "or_windows"):  # experiments: TQ_OPT_dense_ratio=...
         if os.environ.get("TQ_OPT_" + name):
             runner.set_option(name, int(os.environ["TQ_OPT_" + name]))
+    if os.environ.get("BENCH_PREWARM"):  # experiment: prepare another workload's terms first (term handles,
+        pq, _ = build_queries(O, os.environ["BENCH_PREWARM"], 10_000, None, args.terms)  # doc-matrix columns)
+        runner.dev.prepare(pq)
     queries, k = build_queries(O, args.workload, n_main, args.k, args.terms)
     n_q = len(queries)
     n_distinct = len({(q[0], tuple(sorted(q[1]))) for q in queries})
@@ -542,16 +545,23 @@ def main():
     # ---------------------------------------------------------------- other BASELINE configs (N=1)
     side = {}
     if world == 1 and not args.no_side:
-        for wl in ("or5", "phrase3", "mixed", "bool"):
+        for wl in os.environ.get("BENCH_SIDE_ORDER", "or5,phrase3,mixed,bool").split(","):
             if wl == args.workload:
                 continue
-            s_seg, s_runner = seg, runner
+            # Every side workload gets a DeviceIndex of its own (the same segment bytes uploaded again):
+            # its terms are prepared in ITS queries' order, as in a `--workload <wl> --no-side` run —
+            # the runs the profiles under profiles/ were taken from.  (On the main workload's index
+            # the or5 kernel measured 2.75 ms instead of 2.36: term handles, doc-matrix columns and
+            # table addresses follow the order in which the first workload prepared its terms.)
+            s_seg = seg
             if (wl == "phrase3") != with_pos:
                 s_seg = O.synth_segment(args.docs, n_terms=256, segment_ord=rank,
                                         with_positions=wl == "phrase3", phrase_terms=32)
-                s_runner = D.ShardRunner([s_seg], cl.local_rank)
-                s_runner.set_option("timing", 1)
+            s_runner = D.ShardRunner([s_seg], cl.local_rank)
+            s_runner.set_option("timing", 1)
             qs, kk = build_queries(O, wl, DEFAULT_QUERIES[wl], None)
+            if os.environ.get("BENCH_SIDE_SLEEP"):  # experiment: let the GPU idle before a side workload
+                time.sleep(float(os.environ["BENCH_SIDE_SLEEP"]))
             sm = measure(cl, s_runner, torch, qs, kk, args.side_steps, 2)
             if not sm["mode_parity"]:
                 raise SystemExit("%s: pruned and exhaustive results differ on %d queries" % (wl, sm["n_diff"]))

@@ -130,6 +130,12 @@ void tq_segment_free(tq_segment *seg);
 int tq_term_prepare(tq_segment *seg, uint64_t postings_off, uint32_t postings_len,
                     uint64_t positions_off, uint32_t positions_len, uint32_t doc_freq,
                     tq_term_handle *out);
+/* Optional, before the first tq_term_prepare: names the posting lists (by postings_off) that get
+ * the 40 columns of the segment's doc matrix — the caller knows every term's doc_freq from the
+ * term dictionary and passes the densest lists.  Without it the columns go to the first 40 dense
+ * lists that happen to be prepared, i.e. the layout (and 5..15 % of the union kernels' time)
+ * depends on the order of the first queries.  Lists beyond the 40 named are ignored. */
+int tq_segment_reserve_columns(tq_segment *seg, const uint64_t *postings_offs, uint32_t n);
 
 /* ---- search ----
  * replaces, for each query: TopBySortKeyCollector::collect_segment ->

@@ -72,7 +72,7 @@ EXPORTS = [
     "tq_term_prepare", "tq_search_batch", "tq_search_batch_device", "tq_search_batch_opts",
     "tq_search_batch_device_opts", "tq_merge_topk",
     "tq_merge_topk_device", "tq_decode_postings", "tq_decode_position_deltas",
-    "tq_last_batch_stats", "tq_segment_get_stats", "tq_set_option", "tq_segment_set_alive_bitset", "tq_count_batch",
+    "tq_last_batch_stats", "tq_segment_get_stats", "tq_segment_reserve_columns", "tq_set_option", "tq_segment_set_alive_bitset", "tq_count_batch",
     "tq_last_batch_match_counts", "tq_encoder_create", "tq_encoder_free", "tq_encode_postings",
     "tq_encode_positions", "tq_encode_postings_device", "tq_encode_positions_device",
     "tq_encoder_last_kernel_ms", "tq_comm_unique_id", "tq_comm_init", "tq_comm_free",
@@ -124,6 +124,7 @@ def lib():
                                             C.POINTER(C.c_uint64)]
     L.tq_last_batch_stats.argtypes = [vp, C.POINTER(TqBatchStats)]
     L.tq_segment_get_stats.argtypes = [vp, C.POINTER(TqSegmentStats)]
+    L.tq_segment_reserve_columns.argtypes = [vp, C.POINTER(C.c_uint64), C.c_uint32]
     L.tq_set_option.argtypes = [vp, C.c_char_p, C.c_int64]
     L.tq_segment_set_alive_bitset.argtypes = [vp, vp, C.c_size_t]
     L.tq_count_batch.argtypes = [vp, C.POINTER(TqQuery), C.c_uint32, u32p]

@@ -93,6 +93,7 @@ struct TermHost {
   void *pos_blob = nullptr;    // device-side prepare: positions tables (sized after the walk)
   uint32_t doc_freq = 0, n_blocks = 0, n_full = 0, n_tail = 0;
   uint32_t last_doc = 0;
+  bool wants_col = true;  // false: the segment's columns are reserved for other lists
   uint64_t postings_len = 0, positions_len = 0;
   uint64_t n_positions = 0;
 };
@@ -183,6 +184,9 @@ struct tq_segment {
   size_t bytes_term_tables = 0, bytes_bitmaps = 0, bytes_docmat = 0, bytes_posdir = 0, bytes_alive = 0;
   uint32_t n_dense_lists = 0;
   std::unordered_map<uint64_t, uint32_t> term_by_off;
+  // lists named by tq_segment_reserve_columns (postings_off): only they get doc-matrix columns
+  std::unordered_map<uint64_t, bool> reserved_cols;
+  bool cols_reserved = false;
   // batch scratch
   DevBuf d_stage, d_partials, d_out_scores, d_out_docs, d_out_counts, d_misc, d_thr, d_qmatches;
   DevBuf d_share_words, d_share_stage;  // shared-union launch: per-query words, staging lists
@@ -352,7 +356,7 @@ int build_dense(tq_segment *s, uint32_t handle) {
   if (rc != TQ_OK) return rc;
   // the list's column of the doc matrix (first TQD_MAT_SLOTS dense lists of the segment, while
   // the matrix fits the same memory budget as the bitmaps)
-  if (s->n_mat_slots < TQD_MAT_SLOTS && s->opt.docmat) {
+  if (s->n_mat_slots < TQD_MAT_SLOTS && s->opt.docmat && t.wants_col) {
     {
       const int mrc = ensure_docmat(s);
       if (mrc != TQ_OK) return mrc;
@@ -863,6 +867,7 @@ int register_term(tq_segment *s, const TqdTerm &dt, const TermHost &th, uint64_t
                   tq_term_handle *out) {
   const uint32_t handle = (uint32_t)s->terms.size();
   s->terms.push_back(th);
+  s->terms.back().wants_col = !s->cols_reserved || s->reserved_cols.count(postings_off) != 0;
   s->h_dterms.push_back(dt);
   s->d_terms_dirty = true;
   s->term_by_off.emplace(postings_off, handle);
@@ -1049,7 +1054,7 @@ int build_dense_device(tq_segment *s, uint32_t handle) {
   t.dense_blob = blob;
   s->h_dterms[handle].dense = (const uint2 *)blob;
   s->d_terms_dirty = true;
-  if (s->n_mat_slots < TQD_MAT_SLOTS && s->opt.docmat) {  // the list's column of the doc matrix
+  if (s->n_mat_slots < TQD_MAT_SLOTS && s->opt.docmat && t.wants_col) {  // the list's column of the doc matrix
     {
       const int mrc = ensure_docmat(s);
       if (mrc != TQ_OK) return mrc;
@@ -2617,6 +2622,16 @@ int tq_last_batch_stats(tq_segment *s, tq_batch_stats *out) {
     s->stats_pending = false;
   }
   *out = s->stats;
+  return TQ_OK;
+}
+
+int tq_segment_reserve_columns(tq_segment *s, const uint64_t *postings_offs, uint32_t n) {
+  if (!s || (!postings_offs && n)) return fail(TQ_ERR_INVALID, "tq_segment_reserve_columns: null argument");
+  if (!s->terms.empty())
+    return fail(TQ_ERR_INVALID, "tq_segment_reserve_columns: call it before the first tq_term_prepare");
+  s->reserved_cols.clear();
+  for (uint32_t i = 0; i < n && i < TQD_MAT_SLOTS; ++i) s->reserved_cols[postings_offs[i]] = true;
+  s->cols_reserved = true;
   return TQ_OK;
 }
 

@@ -92,6 +92,22 @@ int tqh_searcher_add_segment(tqh_searcher *s, int device, uint32_t max_doc, uint
       ti.positions_end = terms[i].positions_end;
       seg->add_term(terms[i].term_id, ti);
     }
+    {
+      // the doc matrix's columns go to the densest lists of the segment (every TermInfo is known
+      // here), not to whichever dense lists the first queries happen to touch
+      std::vector<std::pair<uint32_t, uint64_t>> by_df;
+      by_df.reserve(n_terms);
+      for (uint32_t i = 0; i < n_terms; ++i) by_df.emplace_back(terms[i].doc_freq, terms[i].postings_start);
+      const size_t keep = std::min<size_t>(by_df.size(), 64);
+      std::partial_sort(by_df.begin(), by_df.begin() + keep, by_df.end(),
+                        [](const std::pair<uint32_t, uint64_t> &a, const std::pair<uint32_t, uint64_t> &b) {
+                          return a.first != b.first ? a.first > b.first : a.second < b.second;
+                        });
+      std::vector<uint64_t> offs;
+      for (size_t i = 0; i < keep; ++i) offs.push_back(by_df[i].second);
+      if (tq_segment_reserve_columns(seg->raw(), offs.data(), (uint32_t)offs.size()) != TQ_OK)
+        throw TantivyError(TantivyError::SystemError, tq_last_error());
+    }
     s->segments.push_back(seg);
     s->searcher.reset(new Searcher(s->segments));
   });
