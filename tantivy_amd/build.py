@@ -11,6 +11,7 @@ SOURCES = [
     os.path.join(HERE, "csrc", "tq_and.hip"),
     os.path.join(HERE, "csrc", "tq_union.hip"),
     os.path.join(HERE, "csrc", "tq_ushare.hip"),
+    os.path.join(HERE, "csrc", "tq_xunion.hip"),
     os.path.join(HERE, "csrc", "tq_phrase.hip"),
     os.path.join(HERE, "csrc", "tq_misc.hip"),
     os.path.join(HERE, "csrc", "tq_encode.hip"),

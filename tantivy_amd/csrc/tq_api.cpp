@@ -91,6 +91,8 @@ struct TermHost {
   void *posdir_blob = nullptr; // position directory of a dense list with positions
   void *tf8_blob = nullptr;    // term freqs of a dense list as bytes (posting index -> min(tf, 255))
   void *pos_blob = nullptr;    // device-side prepare: positions tables (sized after the walk)
+  void *flat_blob = nullptr;   // a list without a bitmap as plain arrays (doc ids | byte-wide tfs), built on
+                               // first use by an unpruned union batch (tq_xunion.hip)
   uint32_t doc_freq = 0, n_blocks = 0, n_full = 0, n_tail = 0;
   uint32_t last_doc = 0;
   bool wants_col = true;  // false: the segment's columns are reserved for other lists
@@ -146,6 +148,10 @@ struct Options {
   int or_windows = -1;  // OR: 1 = window-parallel kernel, 0 = candidate-driven kernel, -1 = auto
   int bound_slack_ppm = 0;  // block-max bounds are widened by (1 + ppm * 1e-6), see block_max_score
                         // (windows for exhaustive scans, candidates when pruning)
+  // unpruned unions, doc-major (tq_xunion.hip): queries whose lists together hold at least
+  // max_doc / xunion_ratio postings (0 = never), if the batch has at least xunion_min_queries of them
+  int xunion_ratio = 6;
+  int xunion_min_queries = 16;
 };
 
 }  // namespace
@@ -268,6 +274,34 @@ int build_tf8(tq_segment *s, uint32_t handle, const uint32_t *d_tfs) {
   s->dense_bytes_total += bytes;
   s->bytes_bitmaps += bytes;
   s->d_terms_dirty = true;
+  return TQ_OK;
+}
+
+// A list WITHOUT a bitmap as plain arrays — doc ids, then min(tf, 255) per posting — for the
+// doc-major union launch (tq_xunion.hip), which scatters such a list into its tile row with a
+// cursor instead of decoding blocks.  Built on the batch's stream the first time an unpruned
+// union needs the list; counts against the side tables' budget (false = over it: *ok stays false).
+int build_flat(tq_segment *s, uint32_t handle, hipStream_t st, bool *ok) {
+  TermHost &t = s->terms[handle];
+  *ok = t.flat_blob != nullptr;
+  if (*ok || t.doc_freq == 0) return TQ_OK;
+  const size_t doc_bytes = ((size_t)t.doc_freq * sizeof(uint32_t) + 15) & ~(size_t)15;
+  const size_t bytes = doc_bytes + (((size_t)t.doc_freq + 15) & ~(size_t)15);
+  if (s->dense_bytes_total + bytes > s->dense_budget()) return TQ_OK;
+  int rc = sync_terms(s, st);
+  if (rc != TQ_OK) return rc;
+  void *blob = nullptr;
+  HIP_TRY(hipMalloc(&blob, bytes + PAD));
+  const hipError_t e = tqk_launch_flat_list(s->dseg, s->d_terms, handle, t.n_blocks, (uint32_t *)blob,
+                                            (uint8_t *)blob + doc_bytes, st);
+  if (e != hipSuccess) {
+    (void)hipFree(blob);
+    return fail(TQ_ERR_HIP, "flat list: %s", hipGetErrorString(e));
+  }
+  t.flat_blob = blob;
+  s->dense_bytes_total += bytes;
+  s->bytes_bitmaps += bytes;
+  *ok = true;
   return TQ_OK;
 }
 
@@ -578,6 +612,8 @@ void tq_segment_free(tq_segment *s) {
     if (t.tf8_blob) (void)hipFree(t.tf8_blob);
   for (auto &t : s->terms)
     if (t.pos_blob) (void)hipFree(t.pos_blob);
+  for (auto &t : s->terms)
+    if (t.flat_blob) (void)hipFree(t.flat_blob);
   if (s->d_terms) (void)hipFree(s->d_terms);
   if (s->d_idx) (void)hipFree(s->d_idx);
   if (s->d_pos) (void)hipFree(s->d_pos);
@@ -1154,7 +1190,13 @@ struct ShareKey {  // one (query, list) pair of the shared-union group
   uint32_t term, q;
 };
 struct PlanScratch {
-  Group groups[7];
+  Group groups[8];
+  // doc-major union group (tq_xunion.hip): the lists of the batch (<-> rows of the tile), the queries
+  std::vector<TqkDenseRow> xrows;
+  std::vector<TqkDenseQuery> xqueries;
+  std::vector<uint32_t> xrow_term;           // row -> term handle, in order of first use
+  std::unordered_map<uint32_t, uint32_t> xrow_of;  // term handle -> row
+  uint32_t xgrid = 0, x_bitmap_rows = 0, x_tiles_per_task = 1, x_list_stride = 0, x_max_terms = 1;
   // shared-union group (tq_ushare.hip): leads grouped by term, tasks in launch order
   std::vector<ShareKey> share_keys;
   std::vector<TqdLead> leads;
@@ -1695,6 +1737,64 @@ int build_share_plan(tq_segment *s, Group &g, PlanScratch &ps) {
 
 // Planning of one TQ_MODE_BOOL query: clause layout of the union kernel (tq_union.hip), pruning
 // flags, tile sizes.  An empty result leaves dq.n_terms == 0 and n_tiles == 0.
+// The doc-major union group (tq_xunion.hip): rows = the distinct lists of its queries, those with a
+// bitmap first; tasks = runs of 128-doc tiles handed out by an atomic counter to one workgroup per
+// CU; every query gets a result list of grid * k entries (a workgroup appends at most k).
+int build_dense_plan(tq_segment *s, Group &g, PlanScratch &ps, uint32_t cus) {
+  const uint32_t n_rows = (uint32_t)ps.xrow_term.size();
+  std::vector<uint32_t> new_row(n_rows, 0u);
+  ps.xrows.assign(n_rows, TqkDenseRow{});
+  uint32_t n_a = 0;
+  for (int pass = 0; pass < 2; ++pass)  // bitmap rows, then the others; first use order inside each
+    for (uint32_t r = 0, at = pass ? n_a : 0u; r < n_rows; ++r) {
+      const uint32_t h = ps.xrow_term[r];
+      const TermHost &th = s->terms[h];
+      const bool bitmap = th.dense_blob && th.tf8_blob;
+      if (bitmap != (pass == 0)) continue;
+      TqkDenseRow row{};
+      row.handle = h;
+      row.doc_freq = th.doc_freq;
+      if (bitmap) {
+        row.dense = (const uint2 *)th.dense_blob;
+        row.tf8 = (const uint8_t *)th.tf8_blob;
+        ++n_a;
+      } else {
+        const size_t doc_bytes = ((size_t)th.doc_freq * sizeof(uint32_t) + 15) & ~(size_t)15;
+        row.flat_docs = (const uint32_t *)th.flat_blob;
+        row.tf8 = (const uint8_t *)th.flat_blob + doc_bytes;
+      }
+      new_row[r] = at;
+      ps.xrows[at++] = row;
+    }
+  ps.x_bitmap_rows = n_a;
+  const uint32_t n_tiles = (s->max_doc + TQK_XU_TILE - 1) / TQK_XU_TILE;
+  static const uint32_t kTaskDiv = std::max<uint32_t>(1u, tune_u32("TQ_XU_TASKS_PER_CU", 16));
+  ps.x_tiles_per_task = std::min<uint32_t>(32u, std::max<uint32_t>(1u, n_tiles / (cus * kTaskDiv)));
+  const uint32_t n_tasks = (n_tiles + ps.x_tiles_per_task - 1) / ps.x_tiles_per_task;
+  ps.xgrid = std::min<uint32_t>(n_tasks, cus);
+  g.kpl = g.max_k <= 64 ? 1 : 2;
+  g.n_chunks = n_tasks;
+  g.total_tiles = n_tiles;
+  ps.x_list_stride = ps.xgrid * g.max_k;
+  ps.xqueries.assign(g.queries.size(), TqkDenseQuery{});
+  ps.x_max_terms = 1;
+  for (size_t qi = 0; qi < g.queries.size(); ++qi) {
+    TqdQuery &dq = g.queries[qi];
+    TqkDenseQuery &xq = ps.xqueries[qi];
+    for (uint32_t i = 0; i < 8u; ++i) {  // (beyond n_terms: the all-zero row at weight 0)
+      const uint32_t row = i < dq.n_terms ? new_row[ps.xrow_of[dq.term[i]]] : n_rows;
+      (i < 4 ? xq.rows_lo : xq.rows_hi) |= row << (8u * (i & 3u));
+      xq.w[i] = i < dq.n_terms ? dq.weight[i] : 0.0f;
+    }
+    ps.x_max_terms = std::max(ps.x_max_terms, dq.n_terms);
+    xq.nt_k = dq.n_terms | (dq.k << 8);
+    xq.thr_row = dq.thr_index;
+    dq.part_start = (uint32_t)(qi * ps.x_list_stride);
+    dq.n_parts = ps.x_list_stride;
+  }
+  return TQ_OK;
+}
+
 int plan_bool_query(tq_segment *s, const tq_query &q, uint32_t qi, TqdQuery &dq, uint64_t &qbytes,
                     uint32_t &n_tiles, uint32_t &tile_cost, uint32_t &n_thr_rows, bool exhaustive) {
   // BooleanQuery whose clauses are terms or unions of terms (`+a b -c`, `+a +(b OR c)`),
@@ -1872,13 +1972,21 @@ int search_batch_impl(tq_segment *s, const tq_query *queries, uint32_t n_queries
   // launch groups: AND queries whose non-leader lists all have a bitmap run a leaner kernel
   // instantiation (no seek / block-search code: fewer registers, less LDS, more waves per CU)
   // boolean queries (clauses with roles) run the candidate-driven union kernel's BOOL instantiation
-  constexpr int kGroups = 7, kAndGeneral = 3, kBool = 4, kShare = 5, kPhSweep = 6;
+  constexpr int kGroups = 8, kAndGeneral = 3, kBool = 4, kShare = 5, kPhSweep = 6, kDense = 7;
   // phrases whose lists ALL have a bitmap, byte-wide tfs and a position directory, the rarest one
   // still about a posting per bitmap word: the bitmap-AND sweep (phrase_sweep_kernel)
   static const uint32_t kPhSweepRatio = tune_u32("TQ_PH_SWEEP_RATIO", 64);  // 0 = never
   // pure unions, pruned, k <= 128, <= 8 terms, on a segment with a doc matrix: the shared-union
   // launch (term-major, tq_ushare.hip); everything else keeps the per-query union kernels
   static const bool kUseShare = tune_u32("TQ_USHARE", 1) != 0;
+  // pure unions, NOT pruned, k <= 128, <= 8 terms, positive weights, whose lists together hold at
+  // least 1/kDenseRatio of the segment: the doc-major launch (tq_xunion.hip) — up to 256 distinct
+  // lists and 8192 queries per batch, one Bm25Weight cache; the rest keeps the window kernel
+  static const uint32_t kDenseRatioEnv = tune_u32("TQ_XU_RATIO", 0xFFFFFFFFu);  // (experiments: overrides the option)
+  static const uint32_t kDenseMinEnv = tune_u32("TQ_XU_MIN_QUERIES", 0xFFFFFFFFu);
+  const uint64_t kDenseRatio = kDenseRatioEnv != 0xFFFFFFFFu ? kDenseRatioEnv : (uint32_t)s->opt.xunion_ratio;
+  const uint32_t kDenseMinQueries = std::max<uint32_t>(1u, kDenseMinEnv != 0xFFFFFFFFu ? kDenseMinEnv : (uint32_t)s->opt.xunion_min_queries);
+  uint32_t dense_cache = 0xFFFFFFFFu;
   if (s->share_span_terms != s->terms.size()) {  // (terms are prepared rarely)
     uint64_t lo = ~0ull, hi = 0;
     for (const TermHost &th : s->terms)
@@ -1898,6 +2006,9 @@ int search_batch_impl(tq_segment *s, const tq_query *queries, uint32_t n_queries
   groups[kBool].mode = TQ_MODE_OR;
   groups[kShare].mode = TQ_MODE_OR;
   groups[kPhSweep].mode = TQ_MODE_PHRASE;
+  groups[kDense].mode = TQ_MODE_OR;
+  s->plan->xrow_term.clear();
+  s->plan->xrow_of.clear();
   groups[0].mode = TQ_MODE_AND;
   groups[1].mode = TQ_MODE_OR;
   groups[2].mode = TQ_MODE_PHRASE;
@@ -2027,7 +2138,7 @@ int search_batch_impl(tq_segment *s, const tq_query *queries, uint32_t n_queries
         }
       }
     }
-    bool bool_done = false, share = false;
+    bool bool_done = false, share = false, dense_u = false;
     if (q.mode == TQ_MODE_BOOL) {
       const int rc = plan_bool_query(s, q, qi, dq, qbytes, n_tiles, tile_cost, n_thr_rows, opt_exhaustive != 0);
       if (rc != TQ_OK) return rc;
@@ -2085,6 +2196,37 @@ int search_batch_impl(tq_segment *s, const tq_query *queries, uint32_t n_queries
         for (uint32_t i = 0; i < dq.n_terms; ++i)
           max_last = std::max(max_last, s->terms[dq.term[i]].last_doc);
         if (dq.n_terms) n_tiles = max_last / TQD_OR_WINDOW + 1;
+        // the doc-major launch?
+        PlanScratch &ps = *s->plan;
+        dense_u = kDenseRatio && opt_exhaustive && s->opt.use_dense && dq.n_terms >= 1 && dq.n_terms <= 8 &&
+                  q.k <= 128 && (dense_cache == 0xFFFFFFFFu || dense_cache == cache_idx) &&
+                  groups[kDense].queries.size() < TQK_XU_MAX_QUERIES;
+        uint64_t sum_df = 0;
+        uint32_t new_rows = 0;
+        for (uint32_t i = 0; dense_u && i < dq.n_terms; ++i) {
+          if (!(dq.weight[i] > 0.0f)) dense_u = false;
+          sum_df += s->terms[dq.term[i]].doc_freq;
+          bool seen = ps.xrow_of.count(dq.term[i]) != 0;
+          for (uint32_t j = 0; j < i; ++j) seen = seen || dq.term[j] == dq.term[i];
+          if (!seen) ++new_rows;
+        }
+        if (dense_u && (sum_df * kDenseRatio < s->max_doc || ps.xrow_term.size() + new_rows > TQK_XU_MAX_ROWS - 1u))
+          dense_u = false;
+        for (uint32_t i = 0; dense_u && i < dq.n_terms; ++i) {
+          const TermHost &th = s->terms[dq.term[i]];
+          if (th.dense_blob && th.tf8_blob) continue;
+          bool ok = false;
+          const int frc = build_flat(s, dq.term[i], st, &ok);
+          if (frc != TQ_OK) return frc;
+          if (!ok) dense_u = false;
+        }
+        if (dense_u) {
+          dense_cache = cache_idx;
+          for (uint32_t i = 0; i < dq.n_terms; ++i)
+            if (ps.xrow_of.emplace(dq.term[i], (uint32_t)ps.xrow_term.size()).second) ps.xrow_term.push_back(dq.term[i]);
+          dq.thr_index = n_thr_rows;
+          n_thr_rows += 4u;
+        }
       } else if (dq.n_terms) {
         // candidate-driven: every list leads its own run of tiles; a candidate probes all the
         // other lists (non-dense ones cost a seek + a block search)
@@ -2109,7 +2251,7 @@ int search_batch_impl(tq_segment *s, const tq_query *queries, uint32_t n_queries
     }
     algo_bytes += qbytes;
     dq.n_tiles = n_tiles;
-    Group &g = groups[bool_done ? kBool : (share ? kShare : (ph_sweep ? kPhSweep : ((mode == TQ_MODE_AND && !all_dense) ? kAndGeneral : mode)))];
+    Group &g = groups[bool_done ? kBool : (share ? kShare : (dense_u ? kDense : (ph_sweep ? kPhSweep : ((mode == TQ_MODE_AND && !all_dense) ? kAndGeneral : mode))))];
     dq.mode = (uint32_t)mode;
     g.queries.push_back(dq);
     g.tile_cost.push_back(tile_cost);
@@ -2117,21 +2259,34 @@ int search_batch_impl(tq_segment *s, const tq_query *queries, uint32_t n_queries
     g.max_k = std::max(g.max_k, q.k);
   }
   const auto tr0b = std::chrono::steady_clock::now();
+  // too few queries to pay for the tile rows: they keep the window kernel
+  if (!groups[kDense].queries.empty() && groups[kDense].queries.size() < kDenseMinQueries) {
+    Group &d = groups[kDense], &o = groups[1];
+    o.queries.insert(o.queries.end(), d.queries.begin(), d.queries.end());
+    o.tile_cost.insert(o.tile_cost.end(), d.tile_cost.begin(), d.tile_cost.end());
+    o.out_index.insert(o.out_index.end(), d.out_index.begin(), d.out_index.end());
+    o.max_k = std::max(o.max_k, d.max_k);
+    d.reset();
+    d.mode = TQ_MODE_OR;
+  }
   // tiles -> chunks -> partial lists
   uint32_t total_parts = 0;
   size_t partial_bytes = 0;
+  int cus = 256;
+  (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, s->device);
   for (Group &g : groups) {
     if (g.queries.empty()) continue;
-    const int crc = &g == &groups[kShare] ? build_share_plan(s, g, *s->plan)
-                                          : build_group_chunks(g, or_windows_opt && &g != &groups[kBool], *s->plan);
+    const int crc = &g == &groups[kShare]   ? build_share_plan(s, g, *s->plan)
+                    : &g == &groups[kDense] ? build_dense_plan(s, g, *s->plan, (uint32_t)std::max(1, cus))
+                                            : build_group_chunks(g, or_windows_opt && &g != &groups[kBool], *s->plan);
     if (crc != TQ_OK) return crc;
   }
   // partial lists of all groups share one buffer; its stride is per group (kpl*64 keys)
-  size_t part_off_bytes[kGroups] = {0, 0, 0, 0, 0, 0, 0};
+  size_t part_off_bytes[kGroups] = {0, 0, 0, 0, 0, 0, 0, 0};
   for (int gi = 0; gi < kGroups; ++gi) {
     Group &g = groups[gi];
     part_off_bytes[gi] = partial_bytes;
-    if (gi == kShare) {  // result lists: part_start / n_parts count 8-byte entries (build_share_plan)
+    if (gi == kShare || gi == kDense) {  // result lists: part_start / n_parts count 8-byte entries (build_share_plan)
       if (!g.queries.empty())
         partial_bytes += ((size_t)g.queries.back().part_start + g.queries.back().n_parts) * sizeof(uint64_t);
       continue;
@@ -2177,6 +2332,14 @@ int search_batch_impl(tq_segment *s, const tq_query *queries, uint32_t n_queries
       g.o_tasks = stage;
       stage += s->plan->tasks.size() * sizeof(uint4);
     }
+    if (&g == &groups[kDense]) {  // (o_leads: the rows, o_tasks: the queries)
+      stage = (stage + 63) & ~(size_t)63;
+      g.o_leads = stage;
+      stage += s->plan->xrows.size() * sizeof(TqkDenseRow);
+      stage = (stage + 15) & ~(size_t)15;
+      g.o_tasks = stage;
+      stage += s->plan->xqueries.size() * sizeof(TqkDenseQuery);
+    }
   }
   const auto tr1 = std::chrono::steady_clock::now();
   if (s->stage_in_flight) {  // (the pinned staging buffer is reused: the previous batch's copy must have left it)
@@ -2205,6 +2368,10 @@ int search_batch_impl(tq_segment *s, const tq_query *queries, uint32_t n_queries
     if (&g == &groups[kShare]) {
       memcpy(hs + g.o_leads, s->plan->leads.data(), s->plan->leads.size() * sizeof(TqdLead));
       memcpy(hs + g.o_tasks, s->plan->tasks.data(), s->plan->tasks.size() * sizeof(uint4));
+    }
+    if (&g == &groups[kDense]) {
+      memcpy(hs + g.o_leads, s->plan->xrows.data(), s->plan->xrows.size() * sizeof(TqkDenseRow));
+      memcpy(hs + g.o_tasks, s->plan->xqueries.data(), s->plan->xqueries.size() * sizeof(TqkDenseQuery));
     }
   }
   for (int gi = 0; gi < kGroups; ++gi) {
@@ -2268,10 +2435,19 @@ int search_batch_impl(tq_segment *s, const tq_query *queries, uint32_t n_queries
   // staging lists of the persistent grid
   uint32_t share_grid = 0;
   const size_t n_share = groups[kShare].queries.size();
+  // (the doc-major launch only exists without pruning, the shared-union launch only with it: the
+  // two never meet in one batch and share the per-query words and the staging buffer)
+  const size_t n_dense = groups[kDense].queries.size();
+  if (n_dense) {
+    const size_t words = 2 * n_dense + 16;
+    rc = s->d_share_words.ensure(words * sizeof(uint32_t));
+    if (rc == TQ_OK)
+      rc = s->d_share_stage.ensure((size_t)s->plan->xgrid * n_dense * tqk_share_capl(groups[kDense].kpl) * sizeof(uint64_t));
+    if (rc != TQ_OK) return rc;
+    HIP_TRY(hipMemsetAsync(s->d_share_words.p, 0, words * sizeof(uint32_t), st));
+  }
   if (n_share) {
     static const uint32_t kGridMul = std::max<uint32_t>(1u, tune_u32("TQ_US_GRID_MUL", 16));
-    int cus = 256;
-    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, s->device);
     share_grid = (uint32_t)std::min<uint64_t>(groups[kShare].n_chunks, (uint64_t)std::max(1, cus) * kGridMul);
     const size_t words = 2 * n_share + 16;
     rc = s->d_share_words.ensure(words * sizeof(uint32_t));
@@ -2297,7 +2473,7 @@ int search_batch_impl(tq_segment *s, const tq_query *queries, uint32_t n_queries
     HIP_TRY(hipEventRecord(s->ev_fork, st));
     HIP_TRY(hipStreamWaitEvent(s->side_stream, s->ev_fork, 0));
   }
-  const int launch_order[kGroups] = {kAndGeneral, kBool, kShare, 1, 2, kPhSweep, 0};  // long serial chains first
+  const int launch_order[kGroups] = {kAndGeneral, kBool, kShare, kDense, 1, 2, kPhSweep, 0};  // long serial chains first
   for (int oi = 0; oi < kGroups; ++oi) {
     const int gi = launch_order[oi];
     Group &g = groups[gi];
@@ -2341,6 +2517,36 @@ int search_batch_impl(tq_segment *s, const tq_query *queries, uint32_t n_queries
         const hipError_t e = tqk_launch_share(sp, g.kpl, gst);
         if (e != hipSuccess) return fail(TQ_ERR_HIP, "shared-union launch: %s", hipGetErrorString(e));
       }
+      continue;
+    }
+    if (gi == kDense) {
+      TqkDenseParams dp{};
+      dp.seg = s->dseg;
+      dp.terms = s->d_terms;
+      dp.rows = (const TqkDenseRow *)(ds + g.o_leads);
+      dp.queries = (const TqkDenseQuery *)(ds + g.o_tasks);
+      dp.cache = (const float *)(ds + o_caches) + (size_t)dense_cache * 256u;
+      dp.sinks = (const TqkSinks *)(ds + g.o_sinks);
+      dp.thr_slots = (uint32_t *)s->d_thr.p;
+      dp.thr_val = (uint32_t *)s->d_share_words.p;
+      dp.list_count = dp.thr_val + n_dense;
+      dp.task_counter = dp.thr_val + 2 * n_dense;
+      dp.stage = (uint64_t *)s->d_share_stage.p;
+      dp.lists = (uint64_t *)((uint8_t *)s->d_partials.p + part_off_bytes[gi]);
+      dp.n_rows = (uint32_t)s->plan->xrows.size();
+      dp.n_bitmap_rows = s->plan->x_bitmap_rows;
+      dp.n_queries = (uint32_t)n_dense;
+      dp.max_terms = s->plan->x_max_terms;
+      dp.n_tasks = g.n_chunks;
+      dp.tiles_per_task = s->plan->x_tiles_per_task;
+      dp.list_stride = s->plan->x_list_stride;
+      dp.grid = s->plan->xgrid;
+      static const uint32_t kDebugX = tune_u32("TQ_DEBUG", 0);
+      dp.debug = kDebugX;
+      tiles_total += g.total_tiles;
+      chunks_total += g.n_chunks;
+      const hipError_t e = tqk_launch_xunion(dp, g.kpl, gst);
+      if (e != hipSuccess) return fail(TQ_ERR_HIP, "doc-major union launch: %s", hipGetErrorString(e));
       continue;
     }
     TqkScanParams p{};
@@ -2395,9 +2601,9 @@ int search_batch_impl(tq_segment *s, const tq_query *queries, uint32_t n_queries
     m.out_counts = d_out_counts;
     m.n_queries = (uint32_t)g.queries.size();
     m.out_stride = out_stride;
-    hipError_t e = gi == kShare
-                       ? tqk_launch_merge_lists(m, (const uint32_t *)s->d_share_words.p + n_share, g.kpl, st)
-                       : tqk_launch_merge(m, g.kpl, st);
+    hipError_t e = gi == kShare   ? tqk_launch_merge_lists(m, (const uint32_t *)s->d_share_words.p + n_share, g.kpl, st)
+                   : gi == kDense ? tqk_launch_merge_lists(m, (const uint32_t *)s->d_share_words.p + n_dense, g.kpl, st)
+                                  : tqk_launch_merge(m, g.kpl, st);
     if (e != hipSuccess) return fail(TQ_ERR_HIP, "merge kernel launch: %s", hipGetErrorString(e));
   }
   if (s->opt.timing) {
@@ -2683,6 +2889,10 @@ int tq_set_option(tq_segment *s, const char *name, int64_t value) {
     s->opt.docsig = value != 0;
   else if (!strcmp(name, "device_prepare"))  // affects terms prepared afterwards
     s->opt.device_prepare = value != 0;
+  else if (!strcmp(name, "xunion_ratio") && value >= 0 && value <= 0x7FFFFFFF)
+    s->opt.xunion_ratio = (int)value;
+  else if (!strcmp(name, "xunion_min_queries") && value >= 1 && value <= 0x7FFFFFFF)
+    s->opt.xunion_min_queries = (int)value;
   else
     return fail(TQ_ERR_INVALID, "unknown option '%s'", name);
   return TQ_OK;

@@ -64,6 +64,49 @@ struct TqkShareParams {
   float bound_slack;
 };
 
+// exhaustive pure unions, doc-major (tq_xunion.hip): a persistent grid of 16-wave workgroups; a
+// workgroup builds tf/(tf+norm) of EVERY list of the group for a tile of 128 docs in LDS, then
+// each of its waves evaluates its share of the group's queries against that tile
+constexpr uint32_t TQK_XU_TILE = 128;         // docs per tile (two per lane)
+constexpr uint32_t TQK_XU_MAX_ROWS = 256;     // rows of the tile: up to 255 distinct lists + the all-zero padding row
+constexpr uint32_t TQK_XU_MAX_QUERIES = 8192; // queries of a group
+constexpr uint32_t TQK_XU_WAVES = 16;
+struct TqkDenseRow {  // one posting list of the group.  Rows with a bitmap come first.
+  const uint2 *dense;         // bitmap + rank directory (TqdTermHead::dense), or null
+  const uint8_t *tf8;         // byte-wide tfs by posting index (with `dense`, or with `flat_docs`); null = every tf is 1
+  const uint32_t *flat_docs;  // lists without a bitmap: the decoded doc ids (doc_freq entries)
+  uint32_t handle;            // the list's term record (saturated tf bytes are read from the packed stream)
+  uint32_t doc_freq;
+};
+struct TqkDenseQuery {  // 48 bytes, loaded one query per lane
+  uint32_t rows_lo, rows_hi;  // row of list t in byte t (lists in score-sum order); beyond n_terms: row n_rows
+                              // (all zero) at weight 0
+  uint32_t nt_k;              // n_terms | k << 8
+  uint32_t thr_row;           // first row of the query's threshold slots (64 for k <= 16, else 256)
+  float w[8];
+};
+struct TqkDenseParams {
+  TqdSegment seg;
+  const TqdTerm *terms;
+  const TqkDenseRow *rows;
+  const TqkDenseQuery *queries;
+  const float *cache;           // Bm25Weight.cache of the group (256 floats)
+  const TqkSinks *sinks;
+  uint32_t *thr_slots;
+  uint32_t *thr_val;            // [n_queries]
+  uint32_t *list_count;         // [n_queries]
+  uint32_t *task_counter;
+  uint64_t *stage;              // [grid][n_queries][capl] staging lists private to a workgroup
+  uint64_t *lists;              // [n_queries][list_stride] result lists
+  uint32_t n_rows, n_bitmap_rows;
+  uint32_t n_queries;
+  uint32_t max_terms;           // the most lists a query of the launch has
+  uint32_t n_tasks, tiles_per_task;
+  uint32_t list_stride;
+  uint32_t grid;
+  uint32_t debug;
+};
+
 struct TqkMergeParams {
   const TqdQuery *queries;
   const uint64_t *partials;
@@ -96,6 +139,10 @@ hipError_t tqk_launch_share(const TqkShareParams &p, int kpl, hipStream_t st);
 hipError_t tqk_launch_merge_lists(const TqkMergeParams &m, const uint32_t *list_count, int kpl,
                                   hipStream_t st);
 uint32_t tqk_share_capl(int kpl);  // staging entries per lead slot
+hipError_t tqk_launch_xunion(const TqkDenseParams &p, int kpl, hipStream_t st);
+// a list without a bitmap as plain arrays: doc ids and min(tf, 255) per posting
+hipError_t tqk_launch_flat_list(const TqdSegment &seg, const TqdTerm *terms, uint32_t handle,
+                                uint32_t n_blocks, uint32_t *docs, uint8_t *tf8, hipStream_t st);
 hipError_t tqk_launch_decode_list(const TqdSegment &seg, const TqdTerm *terms, uint32_t handle,
                                   uint32_t n_blocks, uint32_t *docs, uint32_t *tfs, bool use_dpp,
                                   hipStream_t st);
