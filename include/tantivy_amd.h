@@ -348,7 +348,7 @@ int tq_segment_get_stats(tq_segment *seg, tq_segment_stats *out);
  *        prepared lists WITHOUT a column: a clear bit proves the doc is not in such a list), "device_prepare" (0/1, default 0: tq_term_prepare
  *        works on the device copy even when a host copy exists; always so for segments from
  *        tq_segment_upload_device),
- *        "xunion_ratio" (default 6, 0 = never) / "xunion_min_queries" (default 16): with
+ *        "xunion_ratio" (default 64, 0 = never) / "xunion_min_queries" (default 64): with
  *        "exhaustive", pure unions (<= 8 lists, k <= 128, positive weights) whose lists together
  *        hold >= max_doc / xunion_ratio postings are evaluated doc-major for the whole batch —
  *        every list's tf/(tf+norm) built once per 128-doc tile, every query reading its lists' rows —

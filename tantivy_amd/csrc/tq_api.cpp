@@ -150,8 +150,8 @@ struct Options {
                         // (windows for exhaustive scans, candidates when pruning)
   // unpruned unions, doc-major (tq_xunion.hip): queries whose lists together hold at least
   // max_doc / xunion_ratio postings (0 = never), if the batch has at least xunion_min_queries of them
-  int xunion_ratio = 6;
-  int xunion_min_queries = 16;
+  int xunion_ratio = 64;
+  int xunion_min_queries = 64;
 };
 
 }  // namespace
@@ -1194,8 +1194,8 @@ struct PlanScratch {
   // doc-major union group (tq_xunion.hip): the lists of the batch (<-> rows of the tile), the queries
   std::vector<TqkDenseRow> xrows;
   std::vector<TqkDenseQuery> xqueries;
-  std::vector<uint32_t> xrow_term;           // row -> term handle, in order of first use
-  std::unordered_map<uint32_t, uint32_t> xrow_of;  // term handle -> row
+  std::vector<uint64_t> xrow_term;           // row -> term handle << 32 | weight bits, in order of first use
+  std::unordered_map<uint64_t, uint32_t> xrow_of;  // ... -> row
   uint32_t xgrid = 0, x_bitmap_rows = 0, x_tiles_per_task = 1, x_list_stride = 0, x_max_terms = 1;
   // shared-union group (tq_ushare.hip): leads grouped by term, tasks in launch order
   std::vector<ShareKey> share_keys;
@@ -1737,7 +1737,12 @@ int build_share_plan(tq_segment *s, Group &g, PlanScratch &ps) {
 
 // Planning of one TQ_MODE_BOOL query: clause layout of the union kernel (tq_union.hip), pruning
 // flags, tile sizes.  An empty result leaves dq.n_terms == 0 and n_tiles == 0.
-// The doc-major union group (tq_xunion.hip): rows = the distinct lists of its queries, those with a
+inline uint64_t xrow_key(uint32_t term, float w) {
+  uint32_t wb;
+  memcpy(&wb, &w, sizeof wb);
+  return ((uint64_t)term << 32) | wb;
+}
+// The doc-major union group (tq_xunion.hip): rows = the distinct (list, weight) pairs of its queries, those with a
 // bitmap first; tasks = runs of 128-doc tiles handed out by an atomic counter to one workgroup per
 // CU; every query gets a result list of grid * k entries (a workgroup appends at most k).
 int build_dense_plan(tq_segment *s, Group &g, PlanScratch &ps, uint32_t cus) {
@@ -1747,13 +1752,17 @@ int build_dense_plan(tq_segment *s, Group &g, PlanScratch &ps, uint32_t cus) {
   uint32_t n_a = 0;
   for (int pass = 0; pass < 2; ++pass)  // bitmap rows, then the others; first use order inside each
     for (uint32_t r = 0, at = pass ? n_a : 0u; r < n_rows; ++r) {
-      const uint32_t h = ps.xrow_term[r];
+      const uint32_t h = (uint32_t)(ps.xrow_term[r] >> 32);
       const TermHost &th = s->terms[h];
       const bool bitmap = th.dense_blob && th.tf8_blob;
       if (bitmap != (pass == 0)) continue;
       TqkDenseRow row{};
       row.handle = h;
       row.doc_freq = th.doc_freq;
+      {
+        const uint32_t wb = (uint32_t)ps.xrow_term[r];
+        memcpy(&row.w, &wb, sizeof wb);
+      }
       if (bitmap) {
         row.dense = (const uint2 *)th.dense_blob;
         row.tf8 = (const uint8_t *)th.tf8_blob;
@@ -1781,10 +1790,9 @@ int build_dense_plan(tq_segment *s, Group &g, PlanScratch &ps, uint32_t cus) {
   for (size_t qi = 0; qi < g.queries.size(); ++qi) {
     TqdQuery &dq = g.queries[qi];
     TqkDenseQuery &xq = ps.xqueries[qi];
-    for (uint32_t i = 0; i < 8u; ++i) {  // (beyond n_terms: the all-zero row at weight 0)
-      const uint32_t row = i < dq.n_terms ? new_row[ps.xrow_of[dq.term[i]]] : n_rows;
+    for (uint32_t i = 0; i < 8u; ++i) {  // (beyond n_terms: the all-zero row)
+      const uint32_t row = i < dq.n_terms ? new_row[ps.xrow_of[xrow_key(dq.term[i], dq.weight[i])]] : n_rows;
       (i < 4 ? xq.rows_lo : xq.rows_hi) |= row << (8u * (i & 3u));
-      xq.w[i] = i < dq.n_terms ? dq.weight[i] : 0.0f;
     }
     ps.x_max_terms = std::max(ps.x_max_terms, dq.n_terms);
     xq.nt_k = dq.n_terms | (dq.k << 8);
@@ -2206,8 +2214,8 @@ int search_batch_impl(tq_segment *s, const tq_query *queries, uint32_t n_queries
         for (uint32_t i = 0; dense_u && i < dq.n_terms; ++i) {
           if (!(dq.weight[i] > 0.0f)) dense_u = false;
           sum_df += s->terms[dq.term[i]].doc_freq;
-          bool seen = ps.xrow_of.count(dq.term[i]) != 0;
-          for (uint32_t j = 0; j < i; ++j) seen = seen || dq.term[j] == dq.term[i];
+          bool seen = ps.xrow_of.count(xrow_key(dq.term[i], dq.weight[i])) != 0;
+          for (uint32_t j = 0; j < i; ++j) seen = seen || (dq.term[j] == dq.term[i] && dq.weight[j] == dq.weight[i]);
           if (!seen) ++new_rows;
         }
         if (dense_u && (sum_df * kDenseRatio < s->max_doc || ps.xrow_term.size() + new_rows > TQK_XU_MAX_ROWS - 1u))
@@ -2222,8 +2230,10 @@ int search_batch_impl(tq_segment *s, const tq_query *queries, uint32_t n_queries
         }
         if (dense_u) {
           dense_cache = cache_idx;
-          for (uint32_t i = 0; i < dq.n_terms; ++i)
-            if (ps.xrow_of.emplace(dq.term[i], (uint32_t)ps.xrow_term.size()).second) ps.xrow_term.push_back(dq.term[i]);
+          for (uint32_t i = 0; i < dq.n_terms; ++i) {
+            const uint64_t key = xrow_key(dq.term[i], dq.weight[i]);
+            if (ps.xrow_of.emplace(key, (uint32_t)ps.xrow_term.size()).second) ps.xrow_term.push_back(key);
+          }
           dq.thr_index = n_thr_rows;
           n_thr_rows += 4u;
         }

@@ -65,25 +65,28 @@ struct TqkShareParams {
 };
 
 // exhaustive pure unions, doc-major (tq_xunion.hip): a persistent grid of 16-wave workgroups; a
-// workgroup builds tf/(tf+norm) of EVERY list of the group for a tile of 128 docs in LDS, then
-// each of its waves evaluates its share of the group's queries against that tile
+// workgroup builds the BM25 term scores of EVERY (list, weight) pair of the group for a tile of 128
+// docs in LDS, then each of its waves evaluates its share of the group's queries against that tile
 constexpr uint32_t TQK_XU_TILE = 128;         // docs per tile (two per lane)
-constexpr uint32_t TQK_XU_MAX_ROWS = 256;     // rows of the tile: up to 255 distinct lists + the all-zero padding row
+constexpr uint32_t TQK_XU_MAX_ROWS = 256;     // rows of the tile: up to 255 distinct (list, weight) pairs + the all-zero padding row
 constexpr uint32_t TQK_XU_MAX_QUERIES = 8192; // queries of a group
-constexpr uint32_t TQK_XU_WAVES = 16;
+#ifndef TQK_XU_WAVES_N
+#define TQK_XU_WAVES_N 16
+#endif
+constexpr uint32_t TQK_XU_WAVES = TQK_XU_WAVES_N;
 struct TqkDenseRow {  // one posting list of the group.  Rows with a bitmap come first.
   const uint2 *dense;         // bitmap + rank directory (TqdTermHead::dense), or null
   const uint8_t *tf8;         // byte-wide tfs by posting index (with `dense`, or with `flat_docs`); null = every tf is 1
   const uint32_t *flat_docs;  // lists without a bitmap: the decoded doc ids (doc_freq entries)
   uint32_t handle;            // the list's term record (saturated tf bytes are read from the packed stream)
   uint32_t doc_freq;
+  float w;                    // the row holds w * tf/(tf+norm): a list used at two weights is two rows
+  uint32_t pad;
 };
-struct TqkDenseQuery {  // 48 bytes, loaded one query per lane
-  uint32_t rows_lo, rows_hi;  // row of list t in byte t (lists in score-sum order); beyond n_terms: row n_rows
-                              // (all zero) at weight 0
+struct TqkDenseQuery {  // 16 bytes, loaded one query per lane
+  uint32_t rows_lo, rows_hi;  // row of list t in byte t (lists in score-sum order); beyond n_terms: row n_rows (all zero)
   uint32_t nt_k;              // n_terms | k << 8
   uint32_t thr_row;           // first row of the query's threshold slots (64 for k <= 16, else 256)
-  float w[8];
 };
 struct TqkDenseParams {
   TqdSegment seg;

@@ -9,16 +9,17 @@
 // posting's tf/(tf+norm) does not depend on the query, only its weight does, and a batch touches
 // few distinct lists (256 here) — so here the loop is turned inside out:
 //   * a workgroup owns a TILE of 128 consecutive docs and builds, for EVERY list of the batch,
-//     tf/(tf+norm) of the tile's docs in LDS (0 where the doc is not in the list): one row of 128
-//     floats per list.  Lists with a bitmap: bitmap word + rank -> byte-wide tf -> one IEEE
+//     its BM25 score w * tf/(tf+norm) for the tile's docs in LDS (0 where the doc is not in the
+//     list): one row of 128 floats per list — a term's weight is the same in every query of a
+//     batch (idf * (1 + k1) * boost); were it not, the list takes one row per weight.  Lists with a bitmap: bitmap word + rank -> byte-wide tf -> one IEEE
 //     division per doc; lists without one are kept as plain doc/tf arrays (built on first use)
 //     and scattered into their row by one lane per list;
 //   * then each of its 16 waves takes its share of the queries: lane <-> two docs, per list of the
-//     query one 8-byte LDS read, a multiply and an add — summed in the query's list order (weight
+//     query one 8-byte LDS read and an add — summed in the query's list order (weight
 //     descending), i.e. the order of every other union kernel; adding the 0.0 of an absent list
 //     is exact, so the bits are those of the per-query kernels;
-//   * score > 0 <=> the doc is in the union (weights > 0, tf >= 1; a tile that met a tf of 0
-//     falls back to the lists' membership masks).  Matches are counted; those at or above the
+//   * score > 0 <=> the doc is in the union (weights > 0, tf >= 1; a posting with tf == 0 puts
+//     -0.0 in its row — x + -0.0 is x — and its tile tests the rows' bits instead).  Matches are counted; those at or above the
 //     query's threshold go to the collector.
 // Cost per (query, 128 docs): ~46 vector instructions whatever the lists hold — against 2.3 per
 // posting before; a query pays off here when its lists together hold more than a sixth of the
@@ -37,14 +38,25 @@ namespace {
 
 constexpr uint32_t XT = TQK_XU_TILE;
 constexpr uint32_t XW = TQK_XU_WAVES;
+#ifndef TQ_XU_BATCH
+#define TQ_XU_BATCH 4
+#endif
+#ifndef TQ_XU_TIMERS
+#define TQ_XU_TIMERS 0  // region timers (experiments): TQ_DEBUG bits 16..19 = 1 build, 2 evaluation, 3 barriers, 4 all
+#endif
+#ifndef TQ_XU_UNROLL
+#define TQ_XU_UNROLL 4
+#endif
+constexpr uint32_t XU_DEFAULT = TQ_XU_UNROLL;  // queries scored together (two when they have up to 8 lists: registers)
+constexpr uint32_t XB = TQ_XU_BATCH;  // bitmap rows whose tf bytes are requested together (8: scratch)
 
 struct XuLds {
-  float T[TQK_XU_MAX_ROWS][XT];        // tf/(tf+norm) of doc d0+i in list r, 0 = not in the list
-  uint64_t mask[TQK_XU_MAX_ROWS][2];   // [r][e]: lanes whose doc 2*lane+e is in list r
+  float T[TQK_XU_MAX_ROWS][XT];        // w * tf/(tf+norm) of doc d0+i in row r's list, 0 = not in the list
   float cache[256];                    // Bm25Weight.cache
   uint16_t cnt[TQK_XU_MAX_QUERIES];    // entries in this workgroup's staging list of the query
   uint32_t zflag[2];                   // the tile (by parity) met a posting with tf == 0
   uint32_t task;
+  uint2 wsc[XW][64];                   // per wave: the tile's bitmap words of its 16 rows ([4 * i + word])
 };
 static_assert(sizeof(XuLds) <= 160 * 1024, "one workgroup per CU: all of its LDS");
 
@@ -92,12 +104,15 @@ __device__ __forceinline__ float thr_as_float(uint32_t thr) {  // sortable bits 
 }
 
 // MT: the most lists a query of the launch has.  Queries with fewer are padded with the all-zero
-// row at weight 0 (x + 0 * 0 is x), so that the scoring loop has no branch and all of a query's
+// row (x + 0 is x), so that the scoring loop has no branch and all of a query's
 // LDS reads are in flight together.
-template <int KPL, int MT>
+// DEL: the segment has deletes (the alive bits are applied to the matches; without them a doc beyond
+// max_doc has all-zero rows and needs no test).
+template <int KPL, int MT, bool DEL>
 __global__ __launch_bounds__(XW * 64) void xunion_kernel(TqkDenseParams p) {
   constexpr int R = KPL + 1;
   constexpr uint32_t CAPL = (uint32_t)R * 64u;
+  constexpr uint32_t XU = MT > 5 ? (XU_DEFAULT < 2u ? XU_DEFAULT : 2u) : XU_DEFAULT;
   __shared__ XuLds L;
   const int lane = (int)__lane_id();
   const uint32_t tid = threadIdx.x;
@@ -111,13 +126,14 @@ __global__ __launch_bounds__(XW * 64) void xunion_kernel(TqkDenseParams p) {
   for (uint32_t i = tid; i < nq; i += XW * 64u) L.cnt[i] = 0;
   if (tid < 2u) L.zflag[tid] = 0u;
   if (tid < XT) L.T[p.n_rows][tid] = 0.0f;  // the padding row (n_rows < TQK_XU_MAX_ROWS)
-  if (tid < 2u) L.mask[p.n_rows][tid] = 0ull;
 
   // ---- this wave's queries: q = wave + XW * j, j = 64 * chunk + lane
   const uint32_t n_mine = nq > wave ? (nq - wave + XW - 1u) / XW : 0u;
   const uint32_t n_chunks = (n_mine + 63u) >> 6;
-  uint32_t d_rlo = 0, d_rhi = 0, d_ntk = 0, d_trow = 0, d_thr = 0;
-  float d_w[8] = {0, 0, 0, 0, 0, 0, 0, 0}, d_thr_f = -1.0f;
+  uint32_t d_off[MT], d_ntk = 0, d_trow = 0, d_thr = 0;  // d_off[t]: LDS byte offset of the row of list t
+#pragma unroll
+  for (int t = 0; t < MT; ++t) d_off[t] = 0;
+  float d_thr_f = -1.0f;
   uint32_t mc[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // docs matched, per chunk and lane (<-> query)
   auto load_chunk = [&](uint32_t c) __attribute__((always_inline)) {
     const uint32_t j = 64u * c + (uint32_t)lane;
@@ -125,20 +141,12 @@ __global__ __launch_bounds__(XW * 64) void xunion_kernel(TqkDenseParams p) {
     d_thr = 0;
     if (j < n_mine) {
       const uint32_t q = wave + XW * j;
-      const uint4 *src = reinterpret_cast<const uint4 *>(p.queries + q);
-      const uint4 a = src[0], b = src[1], c2 = src[2];
-      d_rlo = a.x;
-      d_rhi = a.y;
+      const uint4 a = *reinterpret_cast<const uint4 *>(p.queries + q);
+#pragma unroll
+      for (uint32_t t = 0; t < (uint32_t)MT; ++t)
+        d_off[t] = (((t < 4u ? a.x >> (8u * t) : a.y >> (8u * (t - 4u)))) & 0xFFu) * (XT * 4u);
       d_ntk = a.z;
       d_trow = a.w;
-      d_w[0] = __uint_as_float(b.x);
-      d_w[1] = __uint_as_float(b.y);
-      d_w[2] = __uint_as_float(b.z);
-      d_w[3] = __uint_as_float(b.w);
-      d_w[4] = __uint_as_float(c2.x);
-      d_w[5] = __uint_as_float(c2.y);
-      d_w[6] = __uint_as_float(c2.z);
-      d_w[7] = __uint_as_float(c2.w);
       d_thr = __hip_atomic_load(p.thr_val + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     d_thr_f = thr_as_float(d_thr);
@@ -174,16 +182,47 @@ __global__ __launch_bounds__(XW * 64) void xunion_kernel(TqkDenseParams p) {
   const uint32_t *b_docs = nullptr;
   const uint8_t *b_tf8 = nullptr;
   uint32_t b_df = 0, b_handle = 0, b_cur = 0;
+  float b_w = 0.0f;
   if (b_on) {
     const TqkDenseRow *rr = p.rows + b_row;
     b_docs = rr->flat_docs;
     b_tf8 = rr->tf8;
     b_df = rr->doc_freq;
     b_handle = rr->handle;
+    b_w = rr->w;
   }
   const uint32_t n_b_mine = n_rows > n_a + wave ? (n_rows - n_a - wave + XW - 1u) / XW : 0u;  // (<= 16)
+  // lists with a bitmap: this wave builds rows wave + XW * i, i < n_a_mine (<= 16).  Lane l fetches
+  // word (l & 3) of row slot (l >> 2) — ONE load per tile for all of the wave's rows; lane i < 16
+  // keeps row slot i's byte-wide tfs and term handle
+  const uint32_t n_a_mine = n_a > wave ? (n_a - wave + XW - 1u) / XW : 0u;
+  const uint2 *a_dense_w = nullptr;
+  const uint8_t *a_tf8 = nullptr;
+  uint32_t a_handle = 0;
+  float a_w = 0.0f;
+  {
+    const uint32_t rw = wave + XW * ((uint32_t)lane >> 2);
+    if (rw < n_a) a_dense_w = p.rows[rw].dense;
+    const uint32_t ri = wave + XW * (uint32_t)lane;
+    if ((uint32_t)lane < 16u && ri < n_a) {
+      a_tf8 = p.rows[ri].tf8;
+      a_handle = p.rows[ri].handle;
+      a_w = p.rows[ri].w;
+    }
+  }
+  uint32_t b_next = 0xFFFFFFFFu;  // the doc at b_cur (requested ahead of the tile that needs it)
+  uint2 pre_w = make_uint2(0u, 0u);  // the bitmap words of tile pre_d0, requested during the previous tile
+  uint32_t pre_d0 = 0xFFFFFFFFu;
   const uint32_t n_words = (seg.max_doc + 31u) >> 5;
   uint32_t n_scored = 0;
+  const uint32_t tphase = TQ_XU_TIMERS ? (p.debug >> 16) & 15u : 0u;
+  uint64_t tacc = 0, tlast = 0;
+  auto tb = [&](uint32_t ph) __attribute__((always_inline)) {
+    if (TQ_XU_TIMERS && (tphase == ph || tphase == 4u)) tlast = __builtin_readcyclecounter();
+  };
+  auto te = [&](uint32_t ph) __attribute__((always_inline)) {
+    if (TQ_XU_TIMERS && (tphase == ph || tphase == 4u)) tacc += __builtin_readcyclecounter() - tlast;
+  };
   uint32_t seq = 0;  // tiles this workgroup has processed (parity: which zflag)
   __syncthreads();
 
@@ -204,6 +243,7 @@ __global__ __launch_bounds__(XW * 64) void xunion_kernel(TqkDenseParams p) {
           hi = mid;
       }
       b_cur = lo;
+      b_next = lo < b_df ? b_docs[lo] : 0xFFFFFFFFu;
     }
     for (uint32_t ti = 0; ti < p.tiles_per_task; ++ti) {
       const uint32_t d0 = d_first + ti * XT;
@@ -214,7 +254,10 @@ __global__ __launch_bounds__(XW * 64) void xunion_kernel(TqkDenseParams p) {
       uint32_t thr_new = 0;
       if (n_chunks == 1u && (uint32_t)lane < n_mine)
         thr_new = __hip_atomic_load(p.thr_val + wave + XW * (uint32_t)lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      tb(3u);
       __syncthreads();  // (A) every wave is done with the previous tile's rows
+      te(3u);
+      tb(1u);
       if (tid == 0) L.zflag[par ^ 1u] = 0u;
       // ---- build: the lane's two docs
       const uint32_t doc0 = d0 + 2u * (uint32_t)lane;
@@ -226,46 +269,70 @@ __global__ __launch_bounds__(XW * 64) void xunion_kernel(TqkDenseParams p) {
         nrm1 = L.cache[f1];
       }
       bool al0 = in0, al1 = in1;
-      if (seg.alive) {
+      if (DEL && seg.alive) {
         const uint32_t ab = in0 ? (uint32_t)seg.alive[doc0 >> 3] : 0u;
         al0 = in0 && ((ab >> (doc0 & 7u)) & 1u);
         al1 = in1 && ((ab >> ((doc0 & 7u) + 1u)) & 1u);
       }
       const uint64_t valid0 = __ballot(al0), valid1 = __ballot(al1);
       bool zero_tf = false;
-      // rows with a bitmap: r = wave, wave + 16, ..
-      for (uint32_t r = wave; r < n_a; r += XW) {
-        const TqkDenseRow row = sload(p.rows + r);
-        const uint32_t wi = (d0 >> 5) + ((uint32_t)lane >> 4);
-        uint2 wd = make_uint2(0u, 0u);
-        if (wi < n_words) wd = row.dense[wi];
-        float v0 = 0.0f, v1 = 0.0f;
-        uint64_t m0 = 0, m1 = 0;
-        if (__ballot(wd.x != 0u)) {
-          const uint32_t b0 = 2u * ((uint32_t)lane & 15u);
-          const bool p0 = (wd.x >> b0) & 1u, p1 = (wd.x >> (b0 + 1u)) & 1u;
-          const uint32_t pi0 = wd.y + (uint32_t)__popc(wd.x & ((1u << b0) - 1u));
-          const uint32_t pi1 = pi0 + (p0 ? 1u : 0u);
-          uint32_t tf0 = 1u, tf1 = 1u;
-          if (row.tf8) {
-            if (p0) tf0 = row.tf8[pi0];
-            if (p1) tf1 = row.tf8[pi1];
-            if (__ballot((p0 && tf0 == 255u) || (p1 && tf1 == 255u))) {
-              if (p0 && tf0 == 255u) tf0 = exact_tf(idx, p.terms, row.handle, pi0);
-              if (p1 && tf1 == 255u) tf1 = exact_tf(idx, p.terms, row.handle, pi1);
-            }
-          }
-          zero_tf = zero_tf || (p0 && tf0 == 0u) || (p1 && tf1 == 0u);
-          const float f0 = (float)tf0, f1 = (float)tf1;
-          v0 = p0 ? f0 / (f0 + nrm0) : 0.0f;
-          v1 = p1 ? f1 / (f1 + nrm1) : 0.0f;
-          m0 = __ballot(p0);
-          m1 = __ballot(p1);
+      // rows with a bitmap.  Three round trips per tile: the words of all rows (one load), then the
+      // tf bytes of XB rows at a time
+      {
+        uint2 wdw = pre_w;
+        if (pre_d0 != d0) {  // (the first tile of a task)
+          const uint32_t wi = (d0 >> 5) + ((uint32_t)lane & 3u);
+          wdw = make_uint2(0u, 0u);
+          if (a_dense_w && wi < n_words) wdw = a_dense_w[wi];
         }
-        *reinterpret_cast<float2 *>(&L.T[r][2 * lane]) = make_float2(v0, v1);
-        if (lane == 0) {
-          L.mask[r][0] = m0;
-          L.mask[r][1] = m1;
+        L.wsc[wave][lane] = wdw;
+      }
+      wave_mem_fence();
+      const uint32_t b0 = 2u * ((uint32_t)lane & 15u);
+#pragma unroll 1
+      for (uint32_t i0 = 0; i0 < n_a_mine; i0 += XB) {
+        uint32_t wx[XB], tf0[XB], tf1[XB], pi0[XB];
+#pragma unroll
+        for (uint32_t u = 0; u < XB; ++u) {
+          const uint32_t i = i0 + u;
+          wx[u] = 0u;
+          tf0[u] = 1u;
+          tf1[u] = 1u;
+          pi0[u] = 0u;
+          if (i < n_a_mine) {  // (uniform)
+            const uint2 wd = L.wsc[wave][4u * i + ((uint32_t)lane >> 4)];
+            wx[u] = wd.x;
+            pi0[u] = wd.y + (uint32_t)__popc(wd.x & ((1u << b0) - 1u));
+            const uint8_t *tp = (const uint8_t *)readlane64((uint64_t)a_tf8, i);
+            if ((wd.x >> b0) & 1u) tf0[u] = tp[pi0[u]];
+            if ((wd.x >> (b0 + 1u)) & 1u) tf1[u] = tp[pi0[u] + ((wd.x >> b0) & 1u)];
+          }
+        }
+#pragma unroll
+        for (uint32_t u = 0; u < XB; ++u) {
+          const uint32_t i = i0 + u;
+          if (i < n_a_mine) {
+            const uint32_t r = wave + XW * i;
+            const bool p0 = (wx[u] >> b0) & 1u, p1 = (wx[u] >> (b0 + 1u)) & 1u;
+            uint32_t t0 = tf0[u], t1 = tf1[u];
+            const uint32_t odd = (p0 && (t0 == 255u || t0 == 0u)) || (p1 && (t1 == 255u || t1 == 0u));
+            if (__ballot(odd)) {  // saturated bytes: the packed value
+              const uint32_t h = (uint32_t)__builtin_amdgcn_readlane((int)a_handle, (int)i);
+              if (p0 && t0 == 255u) t0 = exact_tf(idx, p.terms, h, pi0[u]);
+              if (p1 && t1 == 255u) t1 = exact_tf(idx, p.terms, h, pi0[u] + (p0 ? 1u : 0u));
+              zero_tf = zero_tf || (p0 && t0 == 0u) || (p1 && t1 == 0u);
+            }
+            // bm25.rs:179-193, the bits of bm25() (tq_common.hpp).  (Tried: tf/(tf+norm) from a
+            // 256 x 256 table built per batch — one gather where the IEEE division is ten
+            // instructions; the second dependent load per row cost more than it saved: 10.2 vs 9.9 ms.)
+            const float w = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(a_w), (int)i));
+            const float f0 = (float)t0, f1 = (float)t1;
+            float v0 = p0 ? w * (f0 / (f0 + nrm0)) : 0.0f;
+            float v1 = p1 ? w * (f1 / (f1 + nrm1)) : 0.0f;
+            if (p0 && t0 == 0u) v0 = -0.0f;  // tf == 0: present with score 0 (x + -0.0 is x)
+            if (p1 && t1 == 0u) v1 = -0.0f;
+            *reinterpret_cast<float2 *>(&L.T[r][2 * lane]) = make_float2(v0, v1);
+          }
         }
       }
       // rows without one: cleared by the wave, then filled by the row's lane
@@ -273,29 +340,38 @@ __global__ __launch_bounds__(XW * 64) void xunion_kernel(TqkDenseParams p) {
         *reinterpret_cast<float2 *>(&L.T[n_a + wave + XW * i][2 * lane]) = make_float2(0.0f, 0.0f);
       wave_mem_fence();
       if (b_on) {
-        uint64_t m0 = 0, m1 = 0;
         const uint32_t d_end = d0 + XT;
-        while (b_cur < b_df) {
-          const uint32_t d = b_docs[b_cur];
-          if (d >= d_end) break;
-          uint32_t tf = b_tf8 ? (uint32_t)b_tf8[b_cur] : 1u;
-          if (tf == 255u) tf = exact_tf(idx, p.terms, b_handle, b_cur);
-          zero_tf = zero_tf || tf == 0u;
-          const uint32_t o = d - d0;
-          const float f = (float)tf;
-          L.T[b_row][o] = f / (f + L.cache[fieldnorm_id(seg, d)]);
-          if (o & 1u)
-            m1 |= 1ull << (o >> 1);
-          else
-            m0 |= 1ull << (o >> 1);
+        while (b_next < d_end) {  // (0xFFFFFFFF past the list's end)
+          const uint32_t d = b_next;
+          const uint32_t tf = b_tf8 ? (uint32_t)b_tf8[b_cur] : 1u;
+          float v;
+          if (tf == 0u) {
+            v = -0.0f;
+            zero_tf = true;
+          } else {
+            const float f = (float)(tf == 255u ? exact_tf(idx, p.terms, b_handle, b_cur) : tf);
+            v = b_w * (f / (f + L.cache[fieldnorm_id(seg, d)]));
+          }
+          L.T[b_row][d - d0] = v;
           ++b_cur;
+          b_next = b_cur < b_df ? b_docs[b_cur] : 0xFFFFFFFFu;
         }
-        L.mask[b_row][0] = m0;
-        L.mask[b_row][1] = m1;
       }
       if (zero_tf) L.zflag[par] = 1u;
+      // the next tile's bitmap words travel while this one is evaluated
+      pre_d0 = 0xFFFFFFFFu;
+      if (ti + 1u < p.tiles_per_task && d0 + XT < seg.max_doc) {
+        pre_d0 = d0 + XT;
+        const uint32_t wi = (pre_d0 >> 5) + ((uint32_t)lane & 3u);
+        pre_w = make_uint2(0u, 0u);
+        if (a_dense_w && wi < n_words) pre_w = a_dense_w[wi];
+      }
+      te(1u);
+      tb(3u);
       __syncthreads();  // (B) the tile's rows are complete
-      const bool generic = L.zflag[par] != 0u;
+      te(3u);
+      tb(2u);
+      const uint32_t generic = uni(L.zflag[par]);
 
       // ---- evaluate: this wave's queries against the tile
       for (uint32_t c = 0; c < n_chunks; ++c) {
@@ -306,43 +382,51 @@ __global__ __launch_bounds__(XW * 64) void xunion_kernel(TqkDenseParams p) {
           d_thr_f = thr_as_float(thr_new);
         }
         const uint32_t n_in = n_mine - 64u * c < 64u ? n_mine - 64u * c : 64u;
-        uint32_t mcount = 0;  // lane jj: docs of the tile matched by query jj
-        for (uint32_t jj = 0; jj < n_in; ++jj) {
-          const uint32_t rlo = (uint32_t)__builtin_amdgcn_readlane((int)d_rlo, (int)jj);
-          const uint32_t rhi = MT > 4 ? (uint32_t)__builtin_amdgcn_readlane((int)d_rhi, (int)jj) : 0u;
-          const float thr_f = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(d_thr_f), (int)jj));
+        uint32_t tilecnt = 0;  // lane jj: docs of the tile matched by query jj
+        // the scores of query jj for the lane's two docs
+        auto score = [&](uint32_t jj, float &s0, float &s1) __attribute__((always_inline)) {
           float2 v[MT];
 #pragma unroll
           for (uint32_t t = 0; t < (uint32_t)MT; ++t) {
-            const uint32_t row = ((t < 4u ? rlo >> (8u * t) : rhi >> (8u * (t - 4u)))) & 0xFFu;
-            v[t] = *reinterpret_cast<const float2 *>(&L.T[row][2 * lane]);
+            const uint32_t off = (uint32_t)__builtin_amdgcn_readlane((int)d_off[t], (int)jj);
+            v[t] = *reinterpret_cast<const float2 *>(reinterpret_cast<const char *>(&L.T[0][2 * lane]) + off);
           }
-          float s0 = 0.0f, s1 = 0.0f;
+          s0 = v[0].x;  // (0 + x is x)
+          s1 = v[0].y;
 #pragma unroll
-          for (uint32_t t = 0; t < (uint32_t)MT; ++t) {
-            const float w = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(d_w[t]), (int)jj));
-            s0 = s0 + w * v[t].x;
-            s1 = s1 + w * v[t].y;
+          for (uint32_t t = 1; t < (uint32_t)MT; ++t) {
+            s0 = s0 + v[t].x;
+            s1 = s1 + v[t].y;
           }
+        };
+        // count the matches, queue those at or above the query's threshold
+        auto finish = [&](uint32_t jj, float s0, float s1) __attribute__((always_inline)) {
+          const float thr_f = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(d_thr_f), (int)jj));
           uint64_t pres0 = __ballot(s0 > 0.0f), pres1 = __ballot(s1 > 0.0f);
-          if (generic) {  // a tf of 0 scores 0: membership from the lists' masks
-            uint64_t g0 = 0, g1 = 0;
+          if (generic != 0u) {  // a tf of 0 scores 0 (the row holds -0.0): any non-zero bits = present
+            uint32_t o0 = 0, o1 = 0;
 #pragma unroll
             for (uint32_t t = 0; t < (uint32_t)MT; ++t) {
-              const uint32_t row = ((t < 4u ? rlo >> (8u * t) : rhi >> (8u * (t - 4u)))) & 0xFFu;
-              g0 |= L.mask[row][0];
-              g1 |= L.mask[row][1];
+              const uint32_t off = (uint32_t)__builtin_amdgcn_readlane((int)d_off[t], (int)jj);
+              const float2 v = *reinterpret_cast<const float2 *>(reinterpret_cast<const char *>(&L.T[0][2 * lane]) + off);
+              o0 |= __float_as_uint(v.x);
+              o1 |= __float_as_uint(v.y);
             }
-            pres0 = uni64(g0);
-            pres1 = uni64(g1);
+            pres0 = __ballot(o0 != 0u);
+            pres1 = __ballot(o1 != 0u);
           }
-          pres0 &= valid0;
-          pres1 &= valid1;
+          if (DEL) {
+            pres0 &= valid0;
+            pres1 &= valid1;
+          }
           const uint32_t nm = (uint32_t)__popcll(pres0) + (uint32_t)__popcll(pres1);
-          if ((uint32_t)lane == jj) mcount += nm;
+          tilecnt = (uint32_t)lane == jj ? nm : tilecnt;
+          // (one compare and branch for both docs; scores are >= 0: their order is that of their bits)
+          const uint32_t b0s = __float_as_uint(s0), b1s = __float_as_uint(s1);
+          if (!__ballot(__uint_as_float(b0s > b1s ? b0s : b1s) >= thr_f)) return;
           const uint64_t pass0 = __ballot(s0 >= thr_f) & pres0;
           const uint64_t pass1 = __ballot(s1 >= thr_f) & pres1;
-          if (!(pass0 | pass1)) continue;
+          if (!(pass0 | pass1)) return;
 
           // ---- collector (rare): threshold slots, the staging list, its cut
           const uint32_t q = wave + XW * (64u * c + jj);
@@ -401,11 +485,49 @@ __global__ __launch_bounds__(XW * 64) void xunion_kernel(TqkDenseParams p) {
               d_thr_f = thr_as_float(thr_up);
             }
           }
+        };
+        // XU queries per step: their LDS reads travel together (the kernel waits for LDS and barriers
+        // two thirds of the time at 16 waves per CU: rocprofv3 SQ_WAIT_ANY / SQ_WAVE_CYCLES)
+        uint32_t jj = 0;
+        for (; jj + XU <= n_in; jj += XU) {
+          float a0[XU], a1[XU];
+          {  // (all lane reads first: a row offset read from a lane cannot feed the very next instruction)
+            uint32_t off[XU][MT];
+#pragma unroll
+            for (uint32_t u = 0; u < XU; ++u)
+#pragma unroll
+              for (uint32_t t = 0; t < (uint32_t)MT; ++t)
+                off[u][t] = (uint32_t)__builtin_amdgcn_readlane((int)d_off[t], (int)(jj + u));
+            float2 v[XU][MT];
+#pragma unroll
+            for (uint32_t u = 0; u < XU; ++u)
+#pragma unroll
+              for (uint32_t t = 0; t < (uint32_t)MT; ++t)
+                v[u][t] = *reinterpret_cast<const float2 *>(reinterpret_cast<const char *>(&L.T[0][2 * lane]) + off[u][t]);
+#pragma unroll
+            for (uint32_t u = 0; u < XU; ++u) {
+              a0[u] = v[u][0].x;  // (0 + x is x)
+              a1[u] = v[u][0].y;
+#pragma unroll
+              for (uint32_t t = 1; t < (uint32_t)MT; ++t) {
+                a0[u] = a0[u] + v[u][t].x;
+                a1[u] = a1[u] + v[u][t].y;
+              }
+            }
+          }
+#pragma unroll
+          for (uint32_t u = 0; u < XU; ++u) finish(jj + u, a0[u], a1[u]);
+        }
+        for (; jj < n_in; ++jj) {
+          float a0, a1;
+          score(jj, a0, a1);
+          finish(jj, a0, a1);
         }
 #pragma unroll
         for (uint32_t i = 0; i < 8u; ++i)
-          if (i == c) mc[i] += mcount;
+          if (i == c) mc[i] += tilecnt;
       }
+      te(2u);
     }
   }
 
@@ -458,6 +580,7 @@ __global__ __launch_bounds__(XW * 64) void xunion_kernel(TqkDenseParams p) {
   }
   // docs scored by the launch
   for (int o = 32; o > 0; o >>= 1) n_scored += __shfl_down(n_scored, o, WAVE);
+  if (tphase) n_scored = (uint32_t)(tacc >> 6);
   if (lane == 0 && n_scored) atomicAdd(sk.match_counter, (unsigned long long)n_scored);
 }
 
@@ -487,21 +610,28 @@ __global__ __launch_bounds__(256) void flat_list_kernel(TqdSegment seg, const Tq
 hipError_t tqk_launch_xunion(const TqkDenseParams &p, int kpl, hipStream_t st) {
   if (p.n_tasks == 0 || p.grid == 0 || p.n_queries == 0) return hipSuccess;
   const dim3 grid(p.grid), block(XW * 64);
-#define TQ_XU(K)                                                              \
+#define TQ_XU(K, D)                                                           \
   do {                                                                        \
     if (p.max_terms <= 2)                                                     \
-      xunion_kernel<K, 2><<<grid, block, 0, st>>>(p);                         \
+      xunion_kernel<K, 2, D><<<grid, block, 0, st>>>(p);                      \
     else if (p.max_terms <= 3)                                                \
-      xunion_kernel<K, 3><<<grid, block, 0, st>>>(p);                         \
+      xunion_kernel<K, 3, D><<<grid, block, 0, st>>>(p);                      \
     else if (p.max_terms <= 5)                                                \
-      xunion_kernel<K, 5><<<grid, block, 0, st>>>(p);                         \
+      xunion_kernel<K, 5, D><<<grid, block, 0, st>>>(p);                      \
     else                                                                      \
-      xunion_kernel<K, 8><<<grid, block, 0, st>>>(p);                         \
+      xunion_kernel<K, 8, D><<<grid, block, 0, st>>>(p);                      \
   } while (0)
-  if (kpl == 1)
-    TQ_XU(1);
-  else
-    TQ_XU(2);
+  if (p.seg.alive) {
+    if (kpl == 1)
+      TQ_XU(1, true);
+    else
+      TQ_XU(2, true);
+  } else {
+    if (kpl == 1)
+      TQ_XU(1, false);
+    else
+      TQ_XU(2, false);
+  }
 #undef TQ_XU
   return hipGetLastError();
 }

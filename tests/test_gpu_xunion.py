@@ -104,6 +104,8 @@ def test_unpruned_unions_with_saturated_tf_bytes(ta, k):
     dev = ta.DeviceIndex([seg])
     try:
         dev.set_option("dense_ratio", 16)  # lists 0..3 get bitmaps, 4..7 do not
+        dev.set_option("xunion_min_queries", 16)
+        dev.set_option("xunion_ratio", 6)  # ([6, 3] keeps the window kernel)
         dev.set_option("exhaustive", 1)
         got = dev.search(qs, k)
         _check_against_oracle(seg, qs, got, k)
@@ -116,7 +118,7 @@ def test_unpruned_unions_with_saturated_tf_bytes(ta, k):
 
 
 def test_small_and_mixed_batches_keep_the_window_kernel(ta, seg300k):
-    """Below 16 eligible queries, or with lists too sparse to pay for a pass over every doc, the
+    """Below 64 eligible queries, or with lists too sparse to pay for a pass over every doc, the
     batch stays with the per-query window kernel; AND queries of the same batch are untouched."""
     seg = seg300k
     queries = _or_stream(6, 5, 64, 9) + [(O.MODE_AND, [0, 1]), (O.MODE_OR, [62, 63])]

@@ -1,0 +1,7 @@
+#!/bin/bash
+R=${GRAFT_REPO_ROOT:-/root/repo}; cd $R; mkdir -p gpurun_out
+(timeout 600 python -m pytest tests/test_gpu_xunion.py -x -q) > gpurun_out/c19_xu.log 2>&1
+tail -2 gpurun_out/c19_xu.log
+echo -n "or5 "; timeout 300 bash tools/quick.sh or5 --exhaustive 2>&1 | tail -1
+bash tools/profile_workload.sh or5 r03x_or5 --exhaustive > gpurun_out/c19_prof.log 2>&1
+tail -3 gpurun_out/c19_prof.log | cut -c1-200
