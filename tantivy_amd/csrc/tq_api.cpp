@@ -9,7 +9,12 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
+#include <condition_variable>
+#include <mutex>
+#include <new>
+#include <cstdlib>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -1151,9 +1156,72 @@ int sync_terms(tq_segment *s, hipStream_t st) {
   return TQ_OK;
 }
 
+// A grow-only array of plain structs whose resize() leaves new elements uninitialised (the
+// descriptors of a 10 000-query batch are 3 MB: std::vector::resize would zero them just before
+// they are overwritten).
+template <typename T>
+class PodVec {
+ public:
+  PodVec() = default;
+  PodVec(const PodVec &) = delete;
+  PodVec &operator=(const PodVec &) = delete;
+  PodVec(PodVec &&o) noexcept : p_(o.p_), n_(o.n_), cap_(o.cap_) { o.p_ = nullptr, o.n_ = o.cap_ = 0; }
+  PodVec &operator=(PodVec &&o) noexcept {
+    swap(o);
+    return *this;
+  }
+  ~PodVec() { free(p_); }
+  size_t size() const { return n_; }
+  bool empty() const { return n_ == 0; }
+  T *data() { return p_; }
+  const T *data() const { return p_; }
+  T &operator[](size_t i) { return p_[i]; }
+  const T &operator[](size_t i) const { return p_[i]; }
+  T &back() { return p_[n_ - 1]; }
+  const T &back() const { return p_[n_ - 1]; }
+  T *begin() { return p_; }
+  T *end() { return p_ + n_; }
+  const T *begin() const { return p_; }
+  const T *end() const { return p_ + n_; }
+  void clear() { n_ = 0; }
+  void reserve(size_t n) {
+    if (n <= cap_) return;
+    const size_t ncap = std::max(n, cap_ * 2);
+    T *np = (T *)malloc(ncap * sizeof(T));
+    if (!np) throw std::bad_alloc();
+    if (n_) memcpy(np, p_, n_ * sizeof(T));
+    free(p_);
+    p_ = np;
+    cap_ = ncap;
+  }
+  void resize(size_t n) {  // (new elements are NOT initialised)
+    reserve(n);
+    n_ = n;
+  }
+  void push_back(const T &v) {
+    if (n_ == cap_) reserve(n_ + 1);
+    p_[n_++] = v;
+  }
+  void append(const T *first, const T *last) {
+    const size_t n = (size_t)(last - first);
+    reserve(n_ + n);
+    if (n) memcpy(p_ + n_, first, n * sizeof(T));
+    n_ += n;
+  }
+  void swap(PodVec &o) {
+    std::swap(p_, o.p_);
+    std::swap(n_, o.n_);
+    std::swap(cap_, o.cap_);
+  }
+
+ private:
+  T *p_ = nullptr;
+  size_t n_ = 0, cap_ = 0;
+};
+
 struct Group {
   int mode;
-  std::vector<TqdQuery> queries;
+  PodVec<TqdQuery> queries;
   std::vector<uint32_t> out_index;
   std::vector<uint32_t> tile_starts;
   std::vector<uint4> chunk_recs;      // launch order: {first tile, end tile, first query, chunk}
@@ -1189,8 +1257,18 @@ struct ShareKey {  // one (query, list) pair of the shared-union group
   uint64_t key;    // list position i << 56 | blocks of the term (rare terms first) << 32 | cache
   uint32_t term, q;
 };
+struct QuerySlab {  // one slab of a batch's queries, planned by one thread into groups of its own
+  Group groups[8];
+  uint32_t n_thr_rows = 0;
+  uint64_t algo_bytes = 0;
+  bool phrase_all_dense = true;
+  int rc = 0;
+  std::string err;
+};
 struct PlanScratch {
   Group groups[8];
+  std::vector<uint32_t> q_cache;      // per query of the batch: its Bm25Weight cache
+  std::vector<QuerySlab> q_slabs;
   // doc-major union group (tq_xunion.hip): the lists of the batch (<-> rows of the tile), the queries
   std::vector<TqkDenseRow> xrows;
   std::vector<TqkDenseQuery> xqueries;
@@ -1198,7 +1276,9 @@ struct PlanScratch {
   std::unordered_map<uint64_t, uint32_t> xrow_of;  // ... -> row
   uint32_t xgrid = 0, x_bitmap_rows = 0, x_tiles_per_task = 1, x_list_stride = 0, x_max_terms = 1;
   // shared-union group (tq_ushare.hip): leads grouped by term, tasks in launch order
-  std::vector<ShareKey> share_keys;
+  std::vector<ShareKey> share_keys, share_keys2;
+  std::vector<uint64_t> sort_keys, sort_keys2;
+  std::vector<uint32_t> term_rank, term_distinct;
   std::vector<TqdLead> leads;
   std::vector<uint4> tasks;
   std::vector<uint32_t> share_pairs;  // per query: (task, lead) pairs = result-list appends at most
@@ -1207,7 +1287,7 @@ struct PlanScratch {
   std::vector<uint32_t> lead_cost, sort_start;
   std::vector<PlanSlab> slabs;
   std::vector<std::pair<uint64_t, uint32_t>> keyed;
-  std::vector<TqdQuery> q_tmp;
+  PodVec<TqdQuery> q_tmp;
   std::vector<uint32_t> o_tmp, c_tmp, hist;
   std::vector<uint4> sorted_recs;
 };
@@ -1216,26 +1296,106 @@ void tq_free_plan_scratch(PlanScratch *p) { delete p; }
 namespace {
 
 // Planner threads (TQ_PLAN_THREADS, default 4, 1 = off): the chunk tables of a large batch are
-// built in slabs of queries / slices / records by a handful of short-lived threads.
+// built in slabs of queries / slices / records.  The helpers are a process-wide pool of detached
+// threads that sleep on a condition variable between jobs (created on first use, never torn
+// down: a batch plans in four parallel steps, and spawning threads for each of them cost more
+// than the steps themselves — 2.1 ms of host time per 10 000-query AND batch against 1.3 ms for
+// the same tables built by one thread).  One job at a time: a caller that finds the pool busy
+// (another segment planning on another thread) runs its slabs itself.
 static uint32_t plan_threads();
+class PlanPool {
+ public:
+  static PlanPool &get() {
+    static PlanPool *pool = new PlanPool();  // (leaked on purpose: its threads outlive static destruction)
+    return *pool;
+  }
+  // fn(ctx, slab) for slab in [0, n): the caller takes part, returns when all slabs are done
+  void run(uint32_t n, void (*fn)(void *, uint32_t), void *ctx) {
+    std::unique_lock<std::mutex> job_lock(job_mutex_, std::try_to_lock);
+    if (!job_lock.owns_lock() || !ensure_workers(std::min<uint32_t>(n, plan_threads()) - 1u)) {
+      for (uint32_t i = 0; i < n; ++i) fn(ctx, i);
+      return;
+    }
+    uint64_t gen;
+    {
+      std::lock_guard<std::mutex> lk(m_);
+      fn_ = fn;
+      ctx_ = ctx;
+      n_ = n;
+      gen = generation_.load(std::memory_order_relaxed) + 1;
+      done_.store(0, std::memory_order_relaxed);
+      ticket_.store(gen << 32, std::memory_order_release);
+      generation_.store(gen, std::memory_order_release);
+    }
+    cv_.notify_all();
+    work(gen, fn, ctx, n);
+    // (the slabs are short: spin for the last ones instead of sleeping)
+    while (done_.load(std::memory_order_acquire) < n) std::this_thread::yield();
+  }
+
+ private:
+  // Slabs are handed out through one word, generation << 32 | next slab: a helper that wakes up
+  // late (its job already over, maybe the next one under way) finds another generation there and
+  // takes nothing.
+  void work(uint64_t gen, void (*fn)(void *, uint32_t), void *ctx, uint32_t n) {
+    for (;;) {
+      uint64_t cur = ticket_.load(std::memory_order_acquire);
+      if ((cur >> 32) != (gen & 0xFFFFFFFFull) || (uint32_t)cur >= n) return;
+      if (!ticket_.compare_exchange_weak(cur, cur + 1, std::memory_order_acq_rel)) continue;
+      fn(ctx, (uint32_t)cur);
+      done_.fetch_add(1, std::memory_order_release);
+    }
+  }
+  bool ensure_workers(uint32_t want) {  // (under job_mutex_)
+    while (n_workers_ < want) {
+      try {
+        std::thread([this] { worker(); }).detach();
+        ++n_workers_;
+      } catch (...) {  // a thread limit: plan with what there is
+        break;
+      }
+    }
+    return n_workers_ > 0;
+  }
+  void worker() {
+    uint64_t seen = 0;
+    for (;;) {
+      void (*fn)(void *, uint32_t);
+      void *ctx;
+      uint32_t n;
+      // a batch brings a dozen jobs within a millisecond: stay awake for a while after each one (a
+      // wake-up through the condition variable costs 50-100 us, more than most of the jobs)
+      const auto spin_until = std::chrono::steady_clock::now() + std::chrono::microseconds(400);
+      while (generation_.load(std::memory_order_acquire) == seen && std::chrono::steady_clock::now() < spin_until)
+        __builtin_ia32_pause();
+      {
+        std::unique_lock<std::mutex> lk(m_);
+        cv_.wait(lk, [&] { return generation_.load(std::memory_order_relaxed) != seen; });
+        seen = generation_.load(std::memory_order_relaxed);
+        fn = fn_;
+        ctx = ctx_;
+        n = n_;
+      }
+      work(seen, fn, ctx, n);
+    }
+  }
+  std::mutex job_mutex_, m_;
+  std::condition_variable cv_;
+  void (*fn_)(void *, uint32_t) = nullptr;
+  void *ctx_ = nullptr;
+  uint32_t n_ = 0, n_workers_ = 0;
+  std::atomic<uint64_t> generation_{0};
+  std::atomic<uint64_t> ticket_{0};
+  std::atomic<uint32_t> done_{0};
+};
 template <typename F>
 static void parallel_slabs(uint32_t n_slabs, F &&fn) {  // fn(slab) for slab in [0, n_slabs)
   if (n_slabs <= 1) {
     if (n_slabs) fn(0u);
     return;
   }
-  // (std::thread's constructor throws std::system_error under a thread limit: this runs inside an
-  // extern "C" call, so the slabs that got no thread are planned by the calling thread instead)
-  std::vector<std::thread> th;
-  uint32_t spawned = 1;
-  try {
-    th.reserve(n_slabs - 1);
-    for (; spawned < n_slabs; ++spawned) th.emplace_back([&fn, spawned] { fn(spawned); });
-  } catch (...) {
-  }
-  fn(0u);
-  for (uint32_t i = spawned; i < n_slabs; ++i) fn(i);
-  for (std::thread &t : th) t.join();
+  PlanPool::get().run(
+      n_slabs, [](void *c, uint32_t i) { (*static_cast<typename std::remove_reference<F>::type *>(c))(i); }, (void *)&fn);
 }
 
 static uint32_t tune_u32(const char *name, uint32_t dflt) {
@@ -1261,7 +1421,7 @@ static uint32_t plan_threads() {
   return n;
 }
 // batches below this many chunks are planned by the calling thread alone (TQ_PLAN_PAR_MIN: tests)
-static const uint32_t kPlanParMin = tune_u32("TQ_PLAN_PAR_MIN", 65536);
+static const uint32_t kPlanParMin = tune_u32("TQ_PLAN_PAR_MIN", 16384);
 static const uint32_t kOrChunkMul = std::max<uint32_t>(1u, tune_u32("TQ_OR_CHUNK_MUL", 4));
 static const uint32_t kOrChunkMulSmallK = std::max<uint32_t>(1u, tune_u32("TQ_OR_CHUNK_MUL_SMALLK", 8));
 
@@ -1295,7 +1455,7 @@ int build_group_chunks(Group &g, bool or_windows, PlanScratch &ps) {
                   (uint32_t)i};
     }
     std::sort(keyed.begin(), keyed.end());  // (ties fall back to the query index: stable)
-    std::vector<TqdQuery> &q2 = ps.q_tmp;
+    PodVec<TqdQuery> &q2 = ps.q_tmp;
     std::vector<uint32_t> &o2 = ps.o_tmp, &c2 = ps.c_tmp;
     q2.resize(n);
     o2.resize(n);
@@ -1594,23 +1754,74 @@ int build_share_plan(tq_segment *s, Group &g, PlanScratch &ps) {
   static const uint32_t kGroupMax = std::min<uint32_t>(TQD_US_GROUP, std::max<uint32_t>(1u, tune_u32("TQ_US_GROUP", TQD_US_GROUP)));
   const size_t nq = g.queries.size();
   g.kpl = kpl_for(g.max_k);
+  static const bool ptrace = getenv("TQ_PLAN_TRACE") != nullptr;  // phase times of the planner
+  auto pt_last = std::chrono::steady_clock::now();
+  auto pt = [&](const char *what) {
+    if (!ptrace) return;
+    const auto now = std::chrono::steady_clock::now();
+    fprintf(stderr, "[tq share plan] %-12s %7.2f ms\n", what, std::chrono::duration<double, std::milli>(now - pt_last).count());
+    pt_last = now;
+  };
   // Leads by list position first: position 0 is every query's highest-weight list, and its docs
   // settle the query's threshold — all tasks of position i are launched (and done) before those of
   // position i + 1 (one launch per position).  Inside a position: by term, rare terms first.
+  // The order is (position, blocks of the term, term, cache, query).  The batch's distinct terms are
+  // ranked by (blocks, handle) first — a few hundred — and the pairs, generated in query order, go
+  // through a stable radix sort on position | rank | cache (a comparison sort of the 25 000 pairs of
+  // a 5000-query batch was two thirds of this function's time).
   std::vector<ShareKey> &keys = ps.share_keys;
-  keys.clear();
-  for (size_t q = 0; q < nq; ++q) {
-    const TqdQuery &dq = g.queries[q];
-    for (uint32_t i = 0; i < dq.n_terms; ++i) {
-      const uint64_t nb = std::min<uint64_t>(0xFFFFFFu, s->terms[dq.term[i]].n_blocks);
-      keys.push_back({((uint64_t)i << 56) | (nb << 32) | (uint64_t)(dq.cache_idx & 0xFFu), dq.term[i], (uint32_t)q});
+  {
+    std::vector<uint32_t> &rank = ps.term_rank, &distinct = ps.term_distinct;
+    if (rank.size() < s->terms.size()) rank.resize(s->terms.size(), 0u);
+    distinct.clear();
+    size_t n_pairs = 0;
+    for (size_t q = 0; q < nq; ++q) {
+      const TqdQuery &dq = g.queries[q];
+      n_pairs += dq.n_terms;
+      for (uint32_t i = 0; i < dq.n_terms; ++i)
+        if (rank[dq.term[i]] != 0xFFFFFFFFu) {  // (0xFFFFFFFF = seen in this batch; reset below)
+          rank[dq.term[i]] = 0xFFFFFFFFu;
+          distinct.push_back(dq.term[i]);
+        }
+    }
+    std::sort(distinct.begin(), distinct.end(), [&](uint32_t a, uint32_t b) {
+      const uint32_t na = s->terms[a].n_blocks, nb = s->terms[b].n_blocks;
+      return na != nb ? na < nb : a < b;
+    });
+    for (size_t r = 0; r < distinct.size(); ++r) rank[distinct[r]] = (uint32_t)r;
+    std::vector<uint64_t> &sk = ps.sort_keys, &sk2 = ps.sort_keys2;
+    std::vector<ShareKey> &k2 = ps.share_keys2;
+    keys.resize(n_pairs);
+    k2.resize(n_pairs);
+    sk.resize(n_pairs);
+    sk2.resize(n_pairs);
+    size_t at = 0;
+    for (size_t q = 0; q < nq; ++q) {
+      const TqdQuery &dq = g.queries[q];
+      for (uint32_t i = 0; i < dq.n_terms; ++i, ++at) {
+        const uint64_t nb = std::min<uint64_t>(0xFFFFFFu, s->terms[dq.term[i]].n_blocks);
+        keys[at] = {((uint64_t)i << 56) | (nb << 32) | (uint64_t)(dq.cache_idx & 0xFFu), dq.term[i], (uint32_t)q};
+        sk[at] = ((uint64_t)i << 40) | ((uint64_t)rank[dq.term[i]] << 8) | (uint64_t)(dq.cache_idx & 0xFFu);
+      }
+    }
+    for (uint32_t t : distinct) rank[t] = 0u;  // (any value but the marker)
+    for (uint32_t shift = 0; shift < 48; shift += 8) {  // LSD, one byte per pass; stable: queries stay in order
+      uint32_t hist[257] = {0};
+      for (size_t i = 0; i < n_pairs; ++i) ++hist[((sk[i] >> shift) & 0xFFu) + 1u];
+      bool one_bucket = false;
+      for (uint32_t d = 0; d < 256; ++d) one_bucket = one_bucket || hist[d + 1] == n_pairs;
+      if (one_bucket) continue;  // every key has the same byte here
+      for (uint32_t d = 0; d < 256; ++d) hist[d + 1] += hist[d];
+      for (size_t i = 0; i < n_pairs; ++i) {
+        const uint32_t o = hist[(sk[i] >> shift) & 0xFFu]++;
+        sk2[o] = sk[i];
+        k2[o] = keys[i];
+      }
+      sk.swap(sk2);
+      keys.swap(k2);
     }
   }
-  std::sort(keys.begin(), keys.end(), [](const ShareKey &a, const ShareKey &b) {
-    if (a.key != b.key) return a.key < b.key;
-    if (a.term != b.term) return a.term < b.term;
-    return a.q < b.q;
-  });
+  pt("keys + sort");
   std::vector<TqdLead> &leads = ps.leads;
   std::vector<uint4> &tasks = ps.tasks;
   std::vector<uint32_t> &pairs = ps.share_pairs;
@@ -1628,7 +1839,11 @@ int build_share_plan(tq_segment *s, Group &g, PlanScratch &ps) {
     const uint32_t slot1 = (s->h_dterms[handle].has_freq >> 8) & 0xFFu;
     return slot1 ? 8u + (slot1 - 1u) : 0u;
   };
-  for (size_t at = 0; at < keys.size(); ++at) {
+  // (a lead reads only its own query: the table is filled by the planner's threads, a slab each)
+  const uint32_t lead_slabs = keys.size() >= 8192 ? plan_threads() : 1u;
+  parallel_slabs(lead_slabs, [&](uint32_t sb) {
+  const size_t at0 = keys.size() * sb / lead_slabs, at1 = keys.size() * (sb + 1) / lead_slabs;
+  for (size_t at = at0; at < at1; ++at) {
     const ShareKey &k = keys[at];
     const uint32_t li = (uint32_t)(k.key >> 56);
     const TqdQuery &dq = g.queries[k.q];
@@ -1669,6 +1884,8 @@ int build_share_plan(tq_segment *s, Group &g, PlanScratch &ps) {
     ld.info = li | (ncols << 4) | (dq.n_terms << 8) | (uses_sig << 12) | (nocol << 16) | (nopc << 24);
     leads[at] = ld;
   }
+  });
+  pt("leads");
   // cost of every position's tasks together (a block costs its decode + one test per lead): a
   // position with little work is cut into smaller tasks, so that it still fills the chip and its
   // launch does not end on a few long tasks
@@ -1718,6 +1935,7 @@ int build_share_plan(tq_segment *s, Group &g, PlanScratch &ps) {
     r0 = r1;
   }
   while (phase < TQD_US_MAX_TERMS) ps.share_phase_first[++phase] = (uint32_t)tasks.size();
+  pt("tasks");
   if (tasks.size() > 0x7FFFFFFFull) return fail(TQ_ERR_UNSUPPORTED, "batch too large (tasks)");
   // result lists: every (task, lead) pair appends at most k entries
   uint64_t entries = 0;
@@ -2025,7 +2243,24 @@ int search_batch_impl(tq_segment *s, const tq_query *queries, uint32_t n_queries
   uint64_t algo_bytes = 0;
   uint32_t n_thr_rows = 0;
   bool phrase_all_dense = true;
+  // which Bm25Weight cache every query uses (pointer identity; a handful per batch)
+  PlanScratch &ps_plan = *s->plan;
+  ps_plan.q_cache.resize(n_queries);
   for (uint32_t qi = 0; qi < n_queries; ++qi) {
+    const float *tc = queries[qi].tf_cache;
+    uint32_t cache_idx = 0;
+    if (tc) {
+      for (; cache_idx < caches.size(); ++cache_idx)
+        if (caches[cache_idx] == tc) break;
+      if (cache_idx == caches.size()) caches.push_back(tc);
+    }
+    ps_plan.q_cache[qi] = cache_idx;
+  }
+  // One query -> its descriptor in its launch group.  Reads the segment and the caller's query only,
+  // writes to the groups / counters it is handed: large pruned batches are planned in slabs of
+  // queries by the planner's threads, each into its own groups, which are then laid end to end.
+  auto plan_query = [&](uint32_t qi, Group *groups, uint32_t &n_thr_rows, uint64_t &algo_bytes,
+                        bool &phrase_all_dense) -> int {
     const tq_query &q = queries[qi];
     if (q.n_terms == 0 || q.n_terms > TQ_MAX_TERMS)
       return fail(TQ_ERR_INVALID, "query %u: n_terms %u not in 1..%u", qi, q.n_terms, TQ_MAX_TERMS);
@@ -2045,10 +2280,7 @@ int search_batch_impl(tq_segment *s, const tq_query *queries, uint32_t n_queries
     for (uint32_t i = 0; i < (q.mode == TQ_MODE_PHRASE ? 1u : q.n_terms); ++i)
       if (!std::isfinite(q.weights[i]))
         return fail(TQ_ERR_INVALID, "query %u: weight %u is not finite", qi, i);
-    uint32_t cache_idx = 0;
-    for (; cache_idx < caches.size(); ++cache_idx)
-      if (caches[cache_idx] == q.tf_cache) break;
-    if (cache_idx == caches.size()) caches.push_back(q.tf_cache);
+    const uint32_t cache_idx = ps_plan.q_cache[qi];
 
     TqdQuery dq{};
     dq.thr_index = 0xFFFFFFFFu;
@@ -2267,12 +2499,79 @@ int search_batch_impl(tq_segment *s, const tq_query *queries, uint32_t n_queries
     g.tile_cost.push_back(tile_cost);
     g.out_index.push_back(qi);
     g.max_k = std::max(g.max_k, q.k);
+    return TQ_OK;
+  };
+  static const uint32_t kQuerySlabMin = tune_u32("TQ_PLAN_QUERY_PAR_MIN", 4096);
+  const uint32_t q_slabs = (!opt_exhaustive && n_queries >= kQuerySlabMin) ? std::min<uint32_t>(plan_threads(), 8u) : 1u;
+  if (q_slabs <= 1) {
+    for (uint32_t qi = 0; qi < n_queries; ++qi) {
+      const int qrc = plan_query(qi, groups, n_thr_rows, algo_bytes, phrase_all_dense);
+      if (qrc != TQ_OK) return qrc;
+    }
+  } else {
+    std::vector<QuerySlab> &qs = ps_plan.q_slabs;
+    if (qs.size() < q_slabs) qs.resize(q_slabs);
+    parallel_slabs(q_slabs, [&](uint32_t sb) {
+      QuerySlab &Q = qs[sb];
+      for (int gi = 0; gi < kGroups; ++gi) {
+        Q.groups[gi].reset();
+        Q.groups[gi].mode = groups[gi].mode;
+      }
+      Q.n_thr_rows = 0;
+      Q.algo_bytes = 0;
+      Q.phrase_all_dense = true;
+      Q.rc = TQ_OK;
+      const uint32_t q0 = (uint32_t)((uint64_t)n_queries * sb / q_slabs), q1 = (uint32_t)((uint64_t)n_queries * (sb + 1) / q_slabs);
+      for (uint32_t qi = q0; qi < q1; ++qi) {
+        Q.rc = plan_query(qi, Q.groups, Q.n_thr_rows, Q.algo_bytes, Q.phrase_all_dense);
+        if (Q.rc != TQ_OK) {
+          Q.err = g_last_error;  // (this thread's slot: handed to the caller's below)
+          break;
+        }
+      }
+    });
+    uint32_t thr_base[9] = {0};
+    size_t g_base[8][9] = {};
+    for (uint32_t sb = 0; sb < q_slabs; ++sb) {
+      if (qs[sb].rc != TQ_OK) {
+        g_last_error = qs[sb].err;
+        return qs[sb].rc;
+      }
+      thr_base[sb + 1] = thr_base[sb] + qs[sb].n_thr_rows;
+      algo_bytes += qs[sb].algo_bytes;
+      phrase_all_dense = phrase_all_dense && qs[sb].phrase_all_dense;
+      for (int gi = 0; gi < kGroups; ++gi) g_base[gi][sb + 1] = g_base[gi][sb] + qs[sb].groups[gi].queries.size();
+    }
+    n_thr_rows = thr_base[q_slabs];
+    for (int gi = 0; gi < kGroups; ++gi) {
+      Group &g = groups[gi];
+      const size_t total = g_base[gi][q_slabs];
+      g.queries.resize(total);
+      g.tile_cost.resize(total);
+      g.out_index.resize(total);
+      for (uint32_t sb = 0; sb < q_slabs; ++sb) g.max_k = std::max(g.max_k, qs[sb].groups[gi].max_k);
+    }
+    parallel_slabs(q_slabs, [&](uint32_t sb) {  // slab order = query order inside every group
+      for (int gi = 0; gi < kGroups; ++gi) {
+        const Group &src = qs[sb].groups[gi];
+        Group &g = groups[gi];
+        const size_t at = g_base[gi][sb], n = src.queries.size();
+        for (size_t i = 0; i < n; ++i) {
+          g.queries[at + i] = src.queries[i];
+          if (g.queries[at + i].thr_index != 0xFFFFFFFFu) g.queries[at + i].thr_index += thr_base[sb];
+        }
+        if (n) {
+          memcpy(g.tile_cost.data() + at, src.tile_cost.data(), n * sizeof(uint32_t));
+          memcpy(g.out_index.data() + at, src.out_index.data(), n * sizeof(uint32_t));
+        }
+      }
+    });
   }
   const auto tr0b = std::chrono::steady_clock::now();
   // too few queries to pay for the tile rows: they keep the window kernel
   if (!groups[kDense].queries.empty() && groups[kDense].queries.size() < kDenseMinQueries) {
     Group &d = groups[kDense], &o = groups[1];
-    o.queries.insert(o.queries.end(), d.queries.begin(), d.queries.end());
+    o.queries.append(d.queries.begin(), d.queries.end());
     o.tile_cost.insert(o.tile_cost.end(), d.tile_cost.begin(), d.tile_cost.end());
     o.out_index.insert(o.out_index.end(), d.out_index.begin(), d.out_index.end());
     o.max_k = std::max(o.max_k, d.max_k);
@@ -2369,14 +2668,23 @@ int search_batch_impl(tq_segment *s, const tq_query *queries, uint32_t n_queries
   uint8_t *hs = (uint8_t *)s->h_stage.p;
   for (size_t c = 0; c < caches.size(); ++c)
     memcpy(hs + o_caches + c * 256 * sizeof(float), caches[c], 256 * sizeof(float));
+  // the two big tables of a group (descriptors, chunk records: megabytes per 10 000-query batch) are
+  // copied by the planner's threads, a quarter each
+  auto big_copy = [&](uint8_t *dst, const void *src, size_t bytes) {
+    const uint32_t parts = bytes >= (1u << 20) ? std::min<uint32_t>(plan_threads(), 4u) : 1u;
+    parallel_slabs(parts, [&](uint32_t pi) {
+      const size_t a = (bytes * pi / parts) & ~(size_t)63, b = pi + 1 == parts ? bytes : (bytes * (pi + 1) / parts) & ~(size_t)63;
+      memcpy(dst + a, (const uint8_t *)src + a, b - a);
+    });
+  };
   for (Group &g : groups) {
     if (g.queries.empty()) continue;
-    memcpy(hs + g.o_queries, g.queries.data(), g.queries.size() * sizeof(TqdQuery));
+    big_copy(hs + g.o_queries, g.queries.data(), g.queries.size() * sizeof(TqdQuery));
     memcpy(hs + g.o_tiles, g.tile_starts.data(), g.tile_starts.size() * sizeof(uint32_t));
     memcpy(hs + g.o_outidx, g.out_index.data(), g.out_index.size() * sizeof(uint32_t));
-    memcpy(hs + g.o_chunks, g.chunk_recs.data(), g.chunk_recs.size() * sizeof(uint4));
+    big_copy(hs + g.o_chunks, g.chunk_recs.data(), g.chunk_recs.size() * sizeof(uint4));
     if (&g == &groups[kShare]) {
-      memcpy(hs + g.o_leads, s->plan->leads.data(), s->plan->leads.size() * sizeof(TqdLead));
+      big_copy(hs + g.o_leads, s->plan->leads.data(), s->plan->leads.size() * sizeof(TqdLead));
       memcpy(hs + g.o_tasks, s->plan->tasks.data(), s->plan->tasks.size() * sizeof(uint4));
     }
     if (&g == &groups[kDense]) {

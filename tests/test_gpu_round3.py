@@ -240,3 +240,47 @@ def test_phrase_with_saturated_tf_bytes(ta):
                     assert rel_close(gs, ws, 1e-5)
         finally:
             dev.close()
+
+
+def test_large_pruned_batch_is_planned_in_slabs(ta):
+    """Batches of >= 4096 queries are turned into descriptors by the planner's threads, a slab of
+    queries each, and laid end to end (tq_api.cpp: plan_query / QuerySlab); unpruned batches are
+    planned by the calling thread.  Every kind of query in one batch of 6000: the two plans must
+    give the same answers, bit for bit, and a sample of them the oracle's."""
+    seg = O.synth_segment(400_000, n_terms=64, with_positions=True, phrase_terms=16)
+    rng = np.random.default_rng(12)
+    M, S, N = O.MUST, O.SHOULD, O.MUST_NOT
+    a = O.zipf_queries(3000, 2, 64, seed=41)
+    o = O.zipf_queries(1500, 4, 64, seed=42)
+    queries = []
+    for i in range(6000):
+        kind = i % 4
+        if kind in (0, 2):
+            queries.append((O.MODE_AND, a[i // 2].tolist()))
+        elif kind == 1:
+            queries.append((O.MODE_OR, o[i // 4].tolist()))
+        elif i % 8 == 3:
+            t = rng.choice(16, size=2, replace=False).tolist()
+            queries.append((O.MODE_PHRASE, t, [0, 1]))
+        else:
+            t = rng.choice(64, size=3, replace=False).tolist()
+            queries.append((ta.MODE_BOOL, t, [M, S, N]))
+    dev = ta.DeviceIndex([seg])
+    try:
+        pr = dev.search(queries, 10)
+        dev.set_option("exhaustive", 1)
+        ex = dev.search(queries, 10)
+        for x, y in zip(pr, ex):
+            assert np.array_equal(x, y)
+        sc, _, docs, cnt = pr
+        for qi in range(0, 6000, 187):
+            q = queries[qi]
+            if q[0] == ta.MODE_BOOL:
+                continue
+            want = O.search(seg, q[1], q[0], 10, pruned=False, phrase_offsets=q[2] if q[0] == O.MODE_PHRASE else None)
+            g = [(float(sc[qi, j]), int(docs[qi, j])) for j in range(int(cnt[qi]))]
+            assert [d for _, d in g] == [d for _, d in want], (q, g, want)
+            for (gs, _), (ws, _) in zip(g, want):
+                assert rel_close(gs, ws, 1e-5)
+    finally:
+        dev.close()
