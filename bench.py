@@ -380,8 +380,9 @@ def load_traffic(key):
 
 def traffic_fields(tj, launches, kernel_ms):
     """roofline.traffic & co. from a committed PMC run (profiles/traffic.json), only while that
-    run measured THIS tree's kernels: entries carry the hash of tantivy_amd/csrc they were taken
-    on (tools/summarize_profile.py); with another hash the figures are withheld, not re-printed."""
+    run measured THIS tree's kernels: entries carry the hash of the sources of the kernels they
+    measured (tools/summarize_profile.py, tantivy_amd/build.py::kernel_hash); with another hash the
+    figures are withheld, not re-printed."""
     from tantivy_amd import build as product_build
 
     out = {"traffic": None, "physical_frac": None, "l2_hit_rate": None, "traffic_from_commit": None,
@@ -389,12 +390,19 @@ def traffic_fields(tj, launches, kernel_ms):
     if not tj:
         return out
     out["traffic_from_commit"] = tj.get("measured_on_commit")
-    same = tj.get("csrc_hash") == product_build.csrc_hash()
+    # the entry names the kernels it measured: valid while THEIR sources (and the device headers) are
+    # unchanged — the host planner or another kernel family moving on does not touch these bytes
+    if tj.get("kernel_hash"):
+        now = product_build.kernel_hash(tj.get("kernels", []))
+        same = tj["kernel_hash"] == now
+        what = "kernel hash %s, this tree %s" % (tj["kernel_hash"], now)
+    else:
+        same = tj.get("csrc_hash") == product_build.csrc_hash()
+        what = "csrc hash %s, this tree %s" % (tj.get("csrc_hash"), product_build.csrc_hash())
     out["traffic_matches_this_build"] = same
     if not same:
-        out["traffic_note"] = ("the committed PMC run (%s) measured other kernel sources (csrc hash %s, this "
-                               "tree %s): traffic / physical_frac withheld" %
-                               (tj.get("profile"), tj.get("csrc_hash"), product_build.csrc_hash()))
+        out["traffic_note"] = ("the committed PMC run (%s) measured other kernel sources (%s): traffic / "
+                               "physical_frac withheld" % (tj.get("profile"), what))
         return out
     out["traffic"] = tj["hbm_bytes_per_launch"] * launches
     out["traffic_note"] = tj["note"]

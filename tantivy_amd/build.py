@@ -52,6 +52,37 @@ def csrc_hash():
     return h.hexdigest()[:16]
 
 
+# which translation unit a scan kernel of a rocprofv3 trace comes from
+KERNEL_FILES = {"and_kernel": "tq_and.hip", "union_kernel_small": "tq_union.hip", "union_kernel": "tq_union.hip",
+                "or_kernel": "tq_union.hip", "ushare_kernel": "tq_ushare.hip", "xunion_kernel": "tq_xunion.hip",
+                "phrase_sweep_kernel": "tq_phrase.hip", "phrase_kernel": "tq_phrase.hip"}
+
+
+def kernel_hash(kernel_names, read=None):
+    """sha256 over the sources of the named scan kernels (their .hip files + the device headers all of
+    them share): what a PMC entry of profiles/traffic.json is valid for.  Finer than csrc_hash(): the
+    host planner or another kernel family changing does not invalidate the entry.  `read(name)`
+    returns a csrc file's bytes (default: the working tree; tools/ pass `git show` of a commit)."""
+    import hashlib
+    import re
+
+    files = {"tq_common.hpp", "tq_device.h"}
+    for k in kernel_names:
+        m = re.search(r"(\w+)<", k)
+        base = m.group(1) if m else k
+        if base in KERNEL_FILES:
+            files.add(KERNEL_FILES[base])
+    if read is None:
+        def read(name):
+            with open(os.path.join(HERE, "csrc", name), "rb") as f:
+                return f.read()
+    h = hashlib.sha256()
+    for name in sorted(files):
+        h.update(name.encode())
+        h.update(read(name))
+    return h.hexdigest()[:16]
+
+
 def up_to_date():
     if not os.path.exists(LIB):
         return False

@@ -117,6 +117,7 @@ def main():
     for key, v in fresh.items():
         # which tree was measured: bench.py drops physical_frac when its kernels differ from these
         v["csrc_hash"] = product_build.csrc_hash()
+        v["kernel_hash"] = product_build.kernel_hash(v["kernels"])  # the sources of THESE kernels only
         v["measured_on_commit"] = commit or "unknown (no .git on the GPU box and no stamp)"
         v["fetch_factor"] = factor
         v["hbm_bytes_per_launch"] = int(factor * v["fetch_bytes_raw"] + v["write_bytes_raw"])
