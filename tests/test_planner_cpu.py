@@ -48,3 +48,13 @@ def test_share_plan_invariants(plan_check, seed):
                            capture_output=True, text=True, timeout=300)
         assert r.returncode == 0, r.stderr + r.stdout
         assert "ok" in r.stdout
+
+
+@pytest.mark.parametrize("threads", [2, 4, 8])
+def test_planner_thread_pool_runs_every_slab_once(plan_check, threads):
+    """parallel_slabs / PlanPool: four host threads issuing 3000 jobs each (1..23 slabs) against the
+    shared pool — every slab exactly once, no lost or doubled work, no deadlock."""
+    r = subprocess.run([plan_check, "3", "pool"], env=dict(os.environ, TQ_PLAN_THREADS=str(threads)),
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "pool: 4 callers x 3000 jobs ok" in r.stdout

@@ -188,9 +188,43 @@ static int check_share(int seed) {
   return 0;
 }
 
+// The planner's thread pool (parallel_slabs / PlanPool): every slab of every job runs exactly once,
+// whatever the number of slabs, also when several host threads plan at the same time (the pool
+// serves one of them, the others run their slabs themselves) and when jobs follow each other faster
+// than the helpers go back to sleep.
+static int check_pool(int seed) {
+  std::atomic<long> bad{0};
+  auto caller = [&](uint32_t who) {
+    std::mt19937 rng(seed * 17 + who);
+    for (int job = 0; job < 3000; ++job) {
+      const uint32_t n = 1u + rng() % 23u;
+      std::vector<uint32_t> hits(n, 0u);
+      uint64_t sum = 0;
+      std::atomic<uint64_t> acc{0};
+      parallel_slabs(n, [&](uint32_t sb) {
+        ++hits[sb];  // (a slab is touched by one thread only)
+        acc.fetch_add((uint64_t)(sb + 1) * (who + 1), std::memory_order_relaxed);
+      });
+      for (uint32_t i = 0; i < n; ++i) {
+        if (hits[i] != 1u) ++bad;
+        sum += (uint64_t)(i + 1) * (who + 1);
+      }
+      if (acc.load() != sum) ++bad;
+      if (job % 500 == 0) std::this_thread::sleep_for(std::chrono::microseconds(700));  // let the helpers fall asleep
+    }
+  };
+  std::vector<std::thread> th;
+  for (uint32_t w = 0; w < 4; ++w) th.emplace_back(caller, w);
+  for (std::thread &t : th) t.join();
+  if (bad.load()) return fail_msg("pool: slabs run other than exactly once", bad.load());
+  printf("pool: 4 callers x 3000 jobs ok\n");
+  return 0;
+}
+
 int main(int argc, char **argv) {
   const int seed = argc > 1 ? atoi(argv[1]) : 1;
   if (argc > 2 && !strcmp(argv[2], "share")) return check_share(seed);
+  if (argc > 2 && !strcmp(argv[2], "pool")) return check_pool(seed);
   std::mt19937 rng(seed);
   auto uni = [&](uint32_t lo, uint32_t hi) { return std::uniform_int_distribution<uint32_t>(lo, hi)(rng); };
   PlanScratch ps;

@@ -6,7 +6,8 @@
 #      FETCH_SIZE / WRITE_SIZE, L2 hit rate
 # Every pass runs under `timeout`: a rocprofv3 that dies on a counter set hangs until killed.
 # Outputs land in gpurun_out/prof_<tag>/ (scratch); tools/summarize_profile.py turns them into the
-# committed summaries under profiles/.
+# committed summaries — on the box into gpurun_out/summaries/, which tools/merge_summaries.py folds
+# into profiles/ back home (in the order given: a later tag's traffic entries win).
 W=${1:-and2}; TAG=${2:-r02_$W}; shift; shift
 cd /tmp && export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-/root/repo}
@@ -21,4 +22,6 @@ timeout 150 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/p3 -o p3 -- $
 timeout 150 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/p4 -o p4 -- $B > $OUT/p4.log 2>&1
 timeout 150 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum --output-format csv -d $OUT/p5 -o p5 -- $B > $OUT/p5.log 2>&1
 tail -1 $OUT/kt.log | cut -c1-300
-python $R/tools/summarize_profile.py $OUT $TAG $W 10000000 "$KEY_SUFFIX"
+SUMMARY_DIR=$R/gpurun_out/summaries python $R/tools/summarize_profile.py $OUT $TAG $W 10000000 "$KEY_SUFFIX"
+# the raw per-dispatch CSVs stay on the box unless asked for (KEEP_RAW=1): gpurun merges at most 64 MiB back
+if [ -z "$KEEP_RAW" ]; then rm -rf $OUT/p1 $OUT/p2 $OUT/p3 $OUT/p4 $OUT/p5 $OUT/kt/kt_kernel_trace.csv $OUT/kt/*agent_info.csv; fi

@@ -132,6 +132,15 @@ def main():
         f.write("\n".join(lines) + "\n")
     with open(tpath, "w") as f:
         json.dump(traffic, f, indent=1, sort_keys=True)
+    # on the GPU box only gpurun_out/ travels back (<= 64 MiB per call, raw counter CSVs of an 8-segment
+    # run are 35 MB): the summaries go there too, tools/merge_summaries.py folds them into profiles/
+    emit = os.environ.get("SUMMARY_DIR")
+    if emit:
+        os.makedirs(emit, exist_ok=True)
+        for name in (tag + "_kernel_stats.csv", tag + "_pmc.md"):
+            shutil.copy(os.path.join(out, name), os.path.join(emit, name))
+        with open(os.path.join(emit, tag + "_traffic.json"), "w") as f:
+            json.dump(fresh, f, indent=1, sort_keys=True)
     print(open(os.path.join(out, tag + "_kernel_stats.csv")).read()[:3000])
     print(json.dumps({k: traffic[k] for k in fresh}, indent=1))
 
