@@ -75,10 +75,56 @@ static int bench_share(int n_queries, int reps) {
   return 0;
 }
 
+// build_group_chunks on the headline batch: 2-term ANDs over the 256 Zipf lists, leader = the rarer list,
+// 64-block tiles (all-dense group: tile cost = tile blocks)
+static int bench_and(int n_queries, int reps) {
+  const uint32_t max_doc = 10000000u, n_terms = 256;
+  std::mt19937 rng(7);
+  std::vector<double> cdf(n_terms);
+  double acc = 0;
+  for (uint32_t r = 0; r < n_terms; ++r) cdf[r] = (acc += 1.0 / (r + 1));
+  PlanScratch ps;
+  double best = 1e9;
+  for (int rep = 0; rep < reps; ++rep) {
+    Group &g = ps.groups[0];
+    g.reset();
+    g.mode = TQ_MODE_AND;
+    rng.seed(7);
+    for (int q = 0; q < n_queries; ++q) {
+      TqdQuery dq{};
+      uint32_t a, b;
+      do {
+        a = (uint32_t)(std::lower_bound(cdf.begin(), cdf.end(), std::uniform_real_distribution<double>(0, acc)(rng)) - cdf.begin());
+        b = (uint32_t)(std::lower_bound(cdf.begin(), cdf.end(), std::uniform_real_distribution<double>(0, acc)(rng)) - cdf.begin());
+      } while (a == b);
+      const uint32_t lead = std::max(a, b);
+      dq.n_terms = 2;
+      dq.k = 10;
+      dq.flags = TQD_QF_PRUNE;
+      dq.term[0] = lead;
+      dq.term[1] = std::min(a, b);
+      dq.tile_blocks = TQD_AND_TILE;
+      const uint32_t lead_blocks = (max_doc / 2 / (lead + 1) + 127) / 128;
+      dq.n_tiles = (lead_blocks + dq.tile_blocks - 1) / dq.tile_blocks;
+      g.queries.push_back(dq);
+      g.tile_cost.push_back(dq.tile_blocks);
+      g.out_index.push_back((uint32_t)q);
+      g.max_k = 10;
+    }
+    const auto t0 = std::chrono::steady_clock::now();
+    if (build_group_chunks(g, false, ps) != TQ_OK) return 1;
+    best = std::min(best, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
+  }
+  printf("and: queries %d chunks %u tiles %u: build_group_chunks %.2f ms (best of %d)\n", n_queries,
+         ps.groups[0].n_chunks, ps.groups[0].total_tiles, best, reps);
+  return 0;
+}
+
 int main(int argc, char **argv) {
   const int n_queries = argc > 1 ? atoi(argv[1]) : 5000;
   const int reps = argc > 2 ? atoi(argv[2]) : 5;
   if (argc > 3 && !strcmp(argv[3], "share")) return bench_share(n_queries, reps);
+  if (argc > 3 && !strcmp(argv[3], "and")) return bench_and(n_queries, reps);
   const uint32_t max_doc = 10000000u, n_terms = 256;
   std::vector<uint32_t> n_blocks(n_terms);
   for (uint32_t r = 0; r < n_terms; ++r) n_blocks[r] = (max_doc / 2 / (r + 1) + 127) / 128;
