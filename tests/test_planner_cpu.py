@@ -58,3 +58,13 @@ def test_planner_thread_pool_runs_every_slab_once(plan_check, threads):
                        capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "pool: 4 callers x 3000 jobs ok" in r.stdout
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_dense_union_plan_invariants(plan_check, seed):
+    """build_dense_plan (the doc-major union launch, tq_xunion.hip): one row per (list, weight) pair,
+    bitmap rows first, every query's row bytes lead back to its lists, padding = the all-zero row,
+    tasks cover every tile once, result lists disjoint."""
+    r = subprocess.run([plan_check, str(seed), "dense"], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "dense:" in r.stdout and "ok" in r.stdout

@@ -188,6 +188,97 @@ static int check_share(int seed) {
   return 0;
 }
 
+// The doc-major union plan (build_dense_plan): rows = the distinct (list, weight) pairs, lists with a
+// bitmap first; every query's row bytes lead back to its lists at its weights, padded with the
+// all-zero row; tasks cover every tile once; result lists are disjoint.
+static int check_dense(int seed) {
+  std::mt19937 rng(seed + 300);
+  auto uni = [&](uint32_t lo, uint32_t hi) { return std::uniform_int_distribution<uint32_t>(lo, hi)(rng); };
+  tq_segment seg;
+  const uint32_t n_terms = 200;
+  static uint8_t arena[1 << 20];
+  for (uint32_t t = 0; t < n_terms; ++t) {
+    TermHost th;
+    th.doc_freq = uni(10, 4000000);
+    th.n_blocks = (th.doc_freq + 127) / 128;
+    if (t % 3 == 0) {
+      th.dense_blob = arena + 4096u * t + 8u;
+      th.tf8_blob = arena + 4096u * t + 2048u;
+    } else {
+      th.flat_blob = arena + 4096u * t + 16u;
+    }
+    seg.terms.push_back(th);
+    seg.h_dterms.push_back(TqdTerm{});
+  }
+  seg.max_doc = uni(1, 3) == 1 ? uni(1, 5000) : uni(100000, 12000000);
+  PlanScratch ps;
+  Group &g = ps.groups[7];
+  g.reset();
+  g.mode = TQ_MODE_OR;
+  const uint32_t nq = uni(1, 900);
+  for (uint32_t q = 0; q < nq; ++q) {
+    TqdQuery dq{};
+    dq.n_terms = uni(1, 8);
+    dq.k = uni(1, 128);
+    dq.thr_index = 4u * q;
+    for (uint32_t i = 0; i < dq.n_terms; ++i) {
+      dq.term[i] = uni(0, 60);  // (few lists: the 255 rows are never exceeded, as the caller guarantees)
+      dq.weight[i] = (dq.term[i] % 7 == 0 && uni(0, 1)) ? 2.5f : 1.0f + 0.01f * (float)dq.term[i];  // some lists at two weights
+      const uint64_t key = xrow_key(dq.term[i], dq.weight[i]);
+      if (ps.xrow_of.emplace(key, (uint32_t)ps.xrow_term.size()).second) ps.xrow_term.push_back(key);
+    }
+    g.queries.push_back(dq);
+    g.tile_cost.push_back(1);
+    g.out_index.push_back(q);
+    g.max_k = std::max(g.max_k, dq.k);
+  }
+  const uint32_t cus = uni(1, 304);
+  if (build_dense_plan(&seg, g, ps, cus) != TQ_OK) return fail_msg("build_dense_plan failed");
+  const uint32_t n_rows = (uint32_t)ps.xrows.size();
+  if (n_rows != ps.xrow_term.size() || n_rows >= TQK_XU_MAX_ROWS) return fail_msg("row count", n_rows);
+  std::vector<uint64_t> seen;
+  for (uint32_t r = 0; r < n_rows; ++r) {
+    const TqkDenseRow &row = ps.xrows[r];
+    const TermHost &th = seg.terms[row.handle];
+    const bool bitmap = th.dense_blob && th.tf8_blob;
+    if (bitmap != (r < ps.x_bitmap_rows)) return fail_msg("bitmap rows first", r, ps.x_bitmap_rows);
+    if (bitmap ? ((const void *)row.dense != th.dense_blob || (const void *)row.tf8 != th.tf8_blob || row.flat_docs)
+               : ((const void *)row.flat_docs != th.flat_blob || row.dense || !row.tf8))
+      return fail_msg("row tables", r);
+    if (row.doc_freq != th.doc_freq) return fail_msg("row doc_freq", r);
+    seen.push_back(xrow_key(row.handle, row.w));
+  }
+  std::sort(seen.begin(), seen.end());
+  if (std::adjacent_find(seen.begin(), seen.end()) != seen.end()) return fail_msg("a (list, weight) pair twice");
+  uint32_t max_terms = 1;
+  uint64_t list_end = 0;
+  for (uint32_t q = 0; q < nq; ++q) {
+    const TqdQuery &dq = g.queries[q];
+    const TqkDenseQuery &xq = ps.xqueries[q];
+    max_terms = std::max(max_terms, dq.n_terms);
+    if ((xq.nt_k & 0xFFu) != dq.n_terms || (xq.nt_k >> 8) != dq.k || xq.thr_row != dq.thr_index) return fail_msg("query header", q);
+    for (uint32_t i = 0; i < 8u; ++i) {
+      const uint32_t row = ((i < 4 ? xq.rows_lo >> (8u * i) : xq.rows_hi >> (8u * (i - 4u)))) & 0xFFu;
+      if (i >= dq.n_terms) {
+        if (row != n_rows) return fail_msg("padding row", q, row);
+        continue;
+      }
+      if (row >= n_rows || ps.xrows[row].handle != dq.term[i] || ps.xrows[row].w != dq.weight[i]) return fail_msg("query row", q, i);
+    }
+    if (dq.part_start != list_end || dq.n_parts != ps.x_list_stride) return fail_msg("result list", q);
+    list_end += dq.n_parts;
+  }
+  if (ps.x_max_terms != max_terms) return fail_msg("max_terms", ps.x_max_terms, max_terms);
+  const uint32_t n_tiles = (seg.max_doc + TQK_XU_TILE - 1) / TQK_XU_TILE;
+  if (g.total_tiles != n_tiles || ps.x_tiles_per_task < 1 || ps.x_tiles_per_task > 32) return fail_msg("tiles", g.total_tiles, n_tiles);
+  if ((uint64_t)g.n_chunks * ps.x_tiles_per_task < n_tiles || (uint64_t)(g.n_chunks - 1) * ps.x_tiles_per_task >= n_tiles)
+    return fail_msg("tasks cover the tiles once", g.n_chunks, ps.x_tiles_per_task);
+  if (ps.xgrid < 1 || ps.xgrid > cus || ps.xgrid > g.n_chunks) return fail_msg("grid", ps.xgrid, cus);
+  if (ps.x_list_stride != ps.xgrid * g.max_k) return fail_msg("list stride", ps.x_list_stride);
+  printf("dense: %u queries, %u rows (%u with a bitmap), %u tasks ok\n", nq, n_rows, ps.x_bitmap_rows, g.n_chunks);
+  return 0;
+}
+
 // The planner's thread pool (parallel_slabs / PlanPool): every slab of every job runs exactly once,
 // whatever the number of slabs, also when several host threads plan at the same time (the pool
 // serves one of them, the others run their slabs themselves) and when jobs follow each other faster
@@ -225,6 +316,7 @@ int main(int argc, char **argv) {
   const int seed = argc > 1 ? atoi(argv[1]) : 1;
   if (argc > 2 && !strcmp(argv[2], "share")) return check_share(seed);
   if (argc > 2 && !strcmp(argv[2], "pool")) return check_pool(seed);
+  if (argc > 2 && !strcmp(argv[2], "dense")) return check_dense(seed);
   std::mt19937 rng(seed);
   auto uni = [&](uint32_t lo, uint32_t hi) { return std::uniform_int_distribution<uint32_t>(lo, hi)(rng); };
   PlanScratch ps;
