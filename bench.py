@@ -686,6 +686,8 @@ def main():
     k_ms = st["kernel_ms"]
     algo_bytes = m["algo_bytes_full"]
     achieved, frac = frac_of(algo_bytes, k_ms)
+    uniq_bytes = (st.get("unique_bytes", 0) + sum(x.max_doc for x in main_segs if x.fieldnorm is not None)
+                  + 8 * k * n_q) * 1
     other_st = m["exh_stats"] if pruned_mode else m["prn_stats"]
     o_ach, o_frac = frac_of(algo_bytes, other_st["kernel_ms"])
     tkey = "%s_%s_%d" % (args.workload, "pruned" if pruned_mode else "exhaustive", args.docs)
@@ -743,9 +745,17 @@ def main():
             "l2_hit_rate": tf["l2_hit_rate"],
             "traffic_from_commit": tf["traffic_from_commit"],
             "traffic_matches_this_build": tf["traffic_matches_this_build"],
-            "kernel": "and_kernel" if args.workload == "and2" else args.workload + " scan kernels",
+            "kernel": " + ".join(st.get("kernels") or [args.workload + " scan kernels"]),
             "kernel_ms_avg": round(k_ms, 4),
             "algorithmic_bytes_per_launch": int(algo_bytes),
+            "batch_unique_bytes": int(uniq_bytes),
+            "unique_frac": round(uniq_bytes / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if k_ms > 0 else None,
+            "unique_note": "batch_unique_bytes = every DISTINCT posting list of the batch once (tq_batch_stats."
+                           "unique_bytes) + the fieldnorm file once + 8k per query: what the launch needs from "
+                           "HBM when the queries of a batch share what they read (the term-major launches "
+                           "do); algorithmic_bytes_per_launch counts a list once per query that names it "
+                           "(SURVEY.md 8d), so frac can exceed 1 for a batch whose queries share lists — "
+                           "that is sharing, not skipped work: unique_frac is the floor",
             "docs_scored_per_launch": int(st["matches"]),
             "matches_per_launch": int(m["full_matches"]),
             "traffic_note": tf["traffic_note"],

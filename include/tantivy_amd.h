@@ -310,7 +310,22 @@ typedef struct tq_batch_stats {
   float host_plan_ms;         /* host CPU time inside tq_search_batch_device (validate + plan + stage +
                                  enqueue; waiting for the previous batch's staging copy excluded),
                                  mean over the calls since the last tq_last_batch_stats */
+  uint32_t kernel_mask;       /* TQ_KERNEL_*: the scan-kernel families the last batch was run by */
+  uint64_t unique_bytes;      /* each DISTINCT posting list (+ positions, phrases) of the last batch once:
+                                 what the batch needs from the index when no byte is read twice; the
+                                 per-query sum above counts a list once per query that names it */
 } tq_batch_stats;
+/* scan-kernel families (tq_batch_stats.kernel_mask) */
+#define TQ_KERNEL_AND_DENSE 0x001u    /* and_kernel, every non-leader list with a bitmap */
+#define TQ_KERNEL_AND 0x002u          /* and_kernel, general */
+#define TQ_KERNEL_UNION 0x004u        /* union_kernel (candidate-driven, per query) */
+#define TQ_KERNEL_OR_WINDOWS 0x008u   /* or_kernel (4096-doc windows) */
+#define TQ_KERNEL_PHRASE 0x010u       /* phrase_kernel */
+#define TQ_KERNEL_PHRASE_SWEEP 0x020u /* phrase_sweep_kernel */
+#define TQ_KERNEL_BOOL 0x040u         /* union_kernel, boolean instantiation */
+#define TQ_KERNEL_USHARE 0x080u       /* ushare_kernel (unions, term-major for the batch) */
+#define TQ_KERNEL_XUNION 0x100u       /* xunion_kernel (unpruned unions, doc-major for the batch) */
+#define TQ_KERNEL_ASHARE 0x200u       /* ashare_kernel (intersections, leader-major for the batch) */
 int tq_last_batch_stats(tq_segment *seg, tq_batch_stats *out);
 /* Bytes the segment keeps resident in HBM, by kind: the reference's own sub-files (copied
  * verbatim) and the derived side tables of DESIGN.md section 2 — term tables (unrolled skip

@@ -41,7 +41,18 @@ class TqBatchStats(C.Structure):
     _fields_ = [("algorithmic_bytes", C.c_uint64), ("matches", C.c_uint64),
                 ("kernel_ms", C.c_float), ("total_ms", C.c_float), ("tiles", C.c_uint32),
                 ("chunks", C.c_uint32), ("batches_averaged", C.c_uint32),
-                ("host_plan_ms", C.c_float)]
+                ("host_plan_ms", C.c_float), ("kernel_mask", C.c_uint32), ("unique_bytes", C.c_uint64)]
+
+
+# scan-kernel families (tq_batch_stats.kernel_mask, include/tantivy_amd.h)
+KERNEL_AND_DENSE, KERNEL_AND, KERNEL_UNION, KERNEL_OR_WINDOWS, KERNEL_PHRASE = 0x1, 0x2, 0x4, 0x8, 0x10
+KERNEL_PHRASE_SWEEP, KERNEL_BOOL, KERNEL_USHARE, KERNEL_XUNION, KERNEL_ASHARE = 0x20, 0x40, 0x80, 0x100, 0x200
+KERNEL_NAMES = {0x1: "and_dense", 0x2: "and", 0x4: "union", 0x8: "or_windows", 0x10: "phrase", 0x20: "phrase_sweep",
+                0x40: "bool", 0x80: "ushare", 0x100: "xunion", 0x200: "ashare"}
+
+
+def kernel_names(mask):
+    return [n for b, n in sorted(KERNEL_NAMES.items()) if mask & b]
 
 
 class TqSegmentStats(C.Structure):
@@ -555,7 +566,8 @@ class DeviceIndex:
         return {"algorithmic_bytes": st.algorithmic_bytes, "matches": st.matches,
                 "kernel_ms": st.kernel_ms, "total_ms": st.total_ms, "tiles": st.tiles,
                 "chunks": st.chunks, "batches_averaged": st.batches_averaged,
-                "host_plan_ms": st.host_plan_ms}
+                "host_plan_ms": st.host_plan_ms, "kernel_mask": int(st.kernel_mask),
+                "kernels": kernel_names(int(st.kernel_mask)), "unique_bytes": int(st.unique_bytes)}
 
     def segment_stats(self, segment_ord=0):
         """Resident HBM bytes of one segment by kind (tq_segment_get_stats)."""

@@ -201,6 +201,7 @@ struct tq_segment {
   // batch scratch
   DevBuf d_stage, d_partials, d_out_scores, d_out_docs, d_out_counts, d_misc, d_thr, d_qmatches;
   DevBuf d_share_words, d_share_stage;  // shared-union launch: per-query words, staging lists
+  DevBuf d_ashare_words, d_ashare_stage;  // shared-intersection launch (runs next to the shared-union one)
   // the shared-union launch addresses bitmaps / byte-wide tfs as 32-bit offsets (8-byte units) from
   // the lowest such table: usable while all of them lie within 32 GB of device addresses
   size_t share_span_terms = 0;  // number of terms the span was computed over
@@ -639,6 +640,8 @@ void tq_segment_free(tq_segment *s) {
   s->d_qmatches.release();
   s->d_share_words.release();
   s->d_share_stage.release();
+  s->d_ashare_words.release();
+  s->d_ashare_stage.release();
   s->h_stage.release();
   s->h_out.release();
   if (s->side_stream) (void)hipStreamSynchronize(s->side_stream);
@@ -1257,8 +1260,11 @@ struct ShareKey {  // one (query, list) pair of the shared-union group
   uint64_t key;    // list position i << 56 | blocks of the term (rare terms first) << 32 | cache
   uint32_t term, q;
 };
+// launch groups of a batch: 0 AND over bitmap lists, 1 unions, 2 phrases, 3 AND over any lists, 4 boolean
+// queries, 5 shared unions, 6 phrase sweep, 7 doc-major unions, 8 shared intersections
+constexpr int kNGroups = 9;
 struct QuerySlab {  // one slab of a batch's queries, planned by one thread into groups of its own
-  Group groups[8];
+  Group groups[kNGroups];
   uint32_t n_thr_rows = 0;
   uint64_t algo_bytes = 0;
   bool phrase_all_dense = true;
@@ -1266,7 +1272,7 @@ struct QuerySlab {  // one slab of a batch's queries, planned by one thread into
   std::string err;
 };
 struct PlanScratch {
-  Group groups[8];
+  Group groups[kNGroups];
   std::vector<uint32_t> q_cache;      // per query of the batch: its Bm25Weight cache
   std::vector<QuerySlab> q_slabs;
   // doc-major union group (tq_xunion.hip): the lists of the batch (<-> rows of the tile), the queries
@@ -1282,6 +1288,14 @@ struct PlanScratch {
   std::vector<TqdLead> leads;
   std::vector<uint4> tasks;
   std::vector<uint32_t> share_pairs;  // per query: (task, lead) pairs = result-list appends at most
+  // shared-intersection group (tq_ashare.hip): one lead per query, sorted by (leader, cache, mask)
+  std::vector<TqdALead> aleads;
+  std::vector<uint4> atasks, atasks_unsorted;
+  std::vector<uint32_t> atask_pos, alead_order, apairs;
+  std::vector<uint64_t> alead_key;
+  std::vector<uint32_t> and_lead_count;  // per term handle: AND queries of the batch it could lead in that launch
+  std::vector<uint32_t> term_stamp;      // per term handle: last batch that used the list (unique bytes)
+  uint32_t batch_stamp = 0;
   uint32_t share_phase_first[TQD_US_MAX_TERMS + 1];  // tasks of list position i: [first[i], first[i+1])
   uint64_t share_table_base = 0;  // TqdLead::dense_off / tf8_off are relative to this device address
   std::vector<uint32_t> lead_cost, sort_start;
@@ -1953,6 +1967,132 @@ int build_share_plan(tq_segment *s, Group &g, PlanScratch &ps) {
   return TQ_OK;
 }
 
+// The shared-intersection launch (tq_ashare.hip): one lead per AND query; the leads of one (leader
+// list, Bm25 cache) are sorted by their membership mask (the kernel keeps a block's membership
+// ballots across consecutive leads with the same mask), cut into groups of <= TQD_AS_GROUP, and every
+// group gets one task per run of blocks of the leader.  Tasks are launched in doc order (all
+// leaders' runs of the first 1/4096 of the doc-id space, then the next, ...): the chip works on one
+// part of the doc matrix at a time, and every query's threshold rises as its leader is walked.
+int build_ashare_plan(tq_segment *s, Group &g, PlanScratch &ps) {
+  static const uint32_t kTaskPairsEnv = std::max<uint32_t>(32u, tune_u32("TQ_AS_TASK_PAIRS", 512));
+  static const uint32_t kTaskBlocksMax = std::min<uint32_t>(0xFFFFu, std::max<uint32_t>(1u, tune_u32("TQ_AS_TASK_BLOCKS", 64)));
+  static const uint32_t kGroupMax = std::min<uint32_t>(TQD_AS_GROUP, std::max<uint32_t>(1u, tune_u32("TQ_AS_GROUP", TQD_AS_GROUP)));
+  static const uint64_t kListBudget = (uint64_t)std::max<uint32_t>(1u, tune_u32("TQ_AS_LIST_MB", 1024)) << 20;
+  const size_t nq = g.queries.size();
+  g.kpl = g.max_k <= 64 ? 1 : 2;
+  auto column_of = [&](uint32_t handle) -> uint32_t {  // doc-matrix bit of the list, or 0
+    const uint32_t slot1 = (s->h_dterms[handle].has_freq >> 8) & 0xFFu;
+    return slot1 ? 8u + (slot1 - 1u) : 0u;
+  };
+  ps.share_table_base = s->share_table_lo;
+  auto off_of = [&](const void *ptr) -> uint32_t {
+    return ptr ? (uint32_t)(((uint64_t)ptr - ps.share_table_base) >> 3) : 0u;
+  };
+  // ---- leads, in query order
+  std::vector<TqdALead> &leads = ps.aleads;
+  std::vector<uint64_t> &key = ps.alead_key;  // leader << 8 | cache, per query
+  leads.resize(nq);
+  key.resize(nq);
+  std::vector<TqdALead> unsorted(nq);
+  for (size_t q = 0; q < nq; ++q) {
+    const TqdQuery &dq = g.queries[q];
+    TqdALead ld{};
+    ld.query = (uint32_t)q;
+    ld.w = dq.weight[0];
+    float rest = 0.0f;
+    uint64_t mask = 0;
+    for (uint32_t m = 1; m < dq.n_terms; ++m) {
+      rest += dq.weight[m];
+      const uint32_t col = column_of(dq.term[m]);
+      const uint32_t sig1 = !col ? (s->h_dterms[dq.term[m]].has_freq >> 16) & 0xFFu : 0u;
+      const uint32_t bitpos = col ? col : (sig1 ? TQD_SIG_SHIFT + (sig1 - 1u) : 0u);
+      if (bitpos) mask |= 1ull << bitpos;
+    }
+    ld.rest = rest;
+    ld.mask_lo = (uint32_t)mask;
+    ld.mask_hi = (uint32_t)(mask >> 32);
+    ld.info = dq.n_terms | (column_of(dq.term[1]) ? 0x100u : 0u);
+    ld.dense_off = off_of(s->terms[dq.term[1]].dense_blob);
+    ld.tf8_off = off_of(s->terms[dq.term[1]].tf8_blob);
+    unsorted[q] = ld;
+    key[q] = ((uint64_t)dq.term[0] << 8) | (uint64_t)(dq.cache_idx & 0xFFu);
+  }
+  // ---- order: (leader, cache), then mask; stable in the query index
+  std::vector<uint32_t> &order = ps.alead_order;
+  order.resize(nq);
+  for (size_t q = 0; q < nq; ++q) order[q] = (uint32_t)q;
+  std::sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) {
+    if (key[a] != key[b]) return key[a] < key[b];
+    const uint64_t ma = ((uint64_t)unsorted[a].mask_hi << 32) | unsorted[a].mask_lo;
+    const uint64_t mb = ((uint64_t)unsorted[b].mask_hi << 32) | unsorted[b].mask_lo;
+    if (ma != mb) return ma < mb;
+    return a < b;
+  });
+  for (size_t i = 0; i < nq; ++i) leads[i] = unsorted[order[i]];
+  // ---- tasks: groups of leads x runs of blocks; fewer, longer tasks if the result lists (k entries
+  // per (task, lead) pair) would not fit the budget
+  std::vector<uint4> &tasks = ps.atasks, &raw = ps.atasks_unsorted;
+  std::vector<uint32_t> &pos = ps.atask_pos, &pairs = ps.apairs;
+  uint32_t task_pairs = kTaskPairsEnv;
+  for (;;) {
+    raw.clear();
+    pos.clear();
+    pairs.assign(nq, 0u);
+    uint64_t entries = 0;
+    for (size_t r0 = 0; r0 < nq;) {
+      size_t r1 = r0;
+      while (r1 < nq && key[order[r1]] == key[order[r0]]) ++r1;
+      const uint32_t term = (uint32_t)(key[order[r0]] >> 8), cache = (uint32_t)key[order[r0]] & 0xFFu;
+      const uint32_t n_blocks = s->terms[term].n_blocks;
+      const uint32_t n_run = (uint32_t)(r1 - r0);
+      const uint32_t n_groups = (n_run + kGroupMax - 1) / kGroupMax;
+      const uint32_t per_group = (n_run + n_groups - 1) / n_groups;
+      const uint32_t bpt = std::min<uint32_t>(kTaskBlocksMax, std::max<uint32_t>(1u, task_pairs / per_group));
+      for (uint32_t j0 = 0; j0 < n_blocks; j0 += bpt) {
+        const uint32_t nb = std::min<uint32_t>(bpt, n_blocks - j0);
+        const uint32_t slice = (uint32_t)(((uint64_t)j0 << 12) / n_blocks);
+        for (uint32_t gr = 0; gr < n_groups; ++gr) {
+          const uint32_t l0 = gr * per_group, l1 = std::min<uint32_t>(n_run, l0 + per_group);
+          if (l0 >= l1) continue;
+          raw.push_back(make_uint4(term, j0, nb | ((l1 - l0) << 16) | (cache << 24), (uint32_t)r0 + l0));
+          pos.push_back(slice);
+        }
+      }
+      const uint32_t n_runs = (n_blocks + bpt - 1) / bpt;
+      for (size_t a = r0; a < r1; ++a) {
+        pairs[order[a]] = n_runs;
+        entries += (uint64_t)n_runs * g.queries[order[a]].k;
+      }
+      r0 = r1;
+    }
+    if ((entries * sizeof(uint64_t) <= kListBudget && entries <= 0xFFFFFFFFull) || task_pairs >= (1u << 22)) {
+      if (entries > 0xFFFFFFFFull) return fail(TQ_ERR_UNSUPPORTED, "batch too large (result lists)");
+      break;
+    }
+    task_pairs *= 2u;
+  }
+  if (raw.size() > 0x7FFFFFFFull) return fail(TQ_ERR_UNSUPPORTED, "batch too large (tasks)");
+  {  // launch order: stable counting sort by doc slice
+    uint32_t hist[4097] = {0};
+    for (uint32_t p : pos) ++hist[p + 1u];
+    for (uint32_t i = 0; i < 4096; ++i) hist[i + 1] += hist[i];
+    tasks.resize(raw.size());
+    for (size_t i = 0; i < raw.size(); ++i) tasks[hist[pos[i]]++] = raw[i];
+  }
+  uint64_t entries = 0;
+  for (size_t q = 0; q < nq; ++q) {
+    TqdQuery &dq = g.queries[q];
+    const uint64_t cap = (uint64_t)pairs[q] * dq.k;
+    dq.part_start = (uint32_t)entries;
+    dq.n_parts = (uint32_t)cap;
+    dq.chunk_first = 0;
+    entries += cap;
+  }
+  g.total_tiles = (uint32_t)tasks.size();
+  g.n_chunks = (uint32_t)tasks.size();
+  return TQ_OK;
+}
+
 // Planning of one TQ_MODE_BOOL query: clause layout of the union kernel (tq_union.hip), pruning
 // flags, tile sizes.  An empty result leaves dq.n_terms == 0 and n_tiles == 0.
 inline uint64_t xrow_key(uint32_t term, float w) {
@@ -2198,7 +2338,12 @@ int search_batch_impl(tq_segment *s, const tq_query *queries, uint32_t n_queries
   // launch groups: AND queries whose non-leader lists all have a bitmap run a leaner kernel
   // instantiation (no seek / block-search code: fewer registers, less LDS, more waves per CU)
   // boolean queries (clauses with roles) run the candidate-driven union kernel's BOOL instantiation
-  constexpr int kGroups = 8, kAndGeneral = 3, kBool = 4, kShare = 5, kPhSweep = 6, kDense = 7;
+  constexpr int kGroups = kNGroups, kAndGeneral = 3, kBool = 4, kShare = 5, kPhSweep = 6, kDense = 7, kAShare = 8;
+  // AND queries whose other lists all have a bitmap + byte-wide tfs, pruned, k <= 128, <= 8 lists, on a
+  // segment with a doc matrix, whose leader (rarest list) leads at least kAShareMin such queries of the
+  // batch: the shared-intersection launch (leader-major, tq_ashare.hip).  TQ_ASHARE=0: the per-query kernel
+  static const bool kUseAShare = tune_u32("TQ_ASHARE", 1) != 0;
+  static const uint32_t kAShareMin = std::max<uint32_t>(1u, tune_u32("TQ_AS_MIN_LEADS", 4));
   // phrases whose lists ALL have a bitmap, byte-wide tfs and a position directory, the rarest one
   // still about a posting per bitmap word: the bitmap-AND sweep (phrase_sweep_kernel)
   static const uint32_t kPhSweepRatio = tune_u32("TQ_PH_SWEEP_RATIO", 64);  // 0 = never
@@ -2233,6 +2378,7 @@ int search_batch_impl(tq_segment *s, const tq_query *queries, uint32_t n_queries
   groups[kShare].mode = TQ_MODE_OR;
   groups[kPhSweep].mode = TQ_MODE_PHRASE;
   groups[kDense].mode = TQ_MODE_OR;
+  groups[kAShare].mode = TQ_MODE_AND;
   s->plan->xrow_term.clear();
   s->plan->xrow_of.clear();
   groups[0].mode = TQ_MODE_AND;
@@ -2255,6 +2401,60 @@ int search_batch_impl(tq_segment *s, const tq_query *queries, uint32_t n_queries
       if (cache_idx == caches.size()) caches.push_back(tc);
     }
     ps_plan.q_cache[qi] = cache_idx;
+  }
+  // Which list would lead an AND query in the shared-intersection launch (0xFFFFFFFF: the query does not
+  // qualify), and how many queries of the batch every list would lead; each distinct list's bytes once
+  // (tq_batch_stats.unique_bytes: what the batch needs from the index when nothing is read twice).
+  const bool ashare_on = kUseAShare && !opt_exhaustive && s->d_docmat && s->opt.use_dense && s->share_span_ok;
+  auto ashare_leader = [&](const tq_query &q, uint32_t cache_idx) -> uint32_t {
+    if (q.mode != TQ_MODE_AND || q.n_terms < 2 || q.n_terms > TQD_AS_MAX_TERMS || q.k == 0 || q.k > 128u ||
+        !q.terms || !q.weights || cache_idx >= 256u)
+      return 0xFFFFFFFFu;
+    uint32_t best = 0xFFFFFFFFu, best_i = 0;
+    for (uint32_t i = 0; i < q.n_terms; ++i) {
+      if (q.terms[i] == TQ_TERM_ABSENT || q.terms[i] >= s->terms.size() || !(q.weights[i] >= 0.0f)) return 0xFFFFFFFFu;
+      const uint32_t df = s->terms[q.terms[i]].doc_freq;
+      if (df < best) {  // (first of the rarest: what the stable sort by doc freq puts in front)
+        best = df;
+        best_i = i;
+      }
+    }
+    for (uint32_t i = 0; i < q.n_terms; ++i) {
+      if (i == best_i) continue;
+      const TermHost &th = s->terms[q.terms[i]];
+      if (!(th.dense_blob && th.tf8_blob)) return 0xFFFFFFFFu;
+    }
+    return q.terms[best_i];
+  };
+  uint64_t unique_bytes = 0;
+  {
+    PlanScratch &ps = ps_plan;
+    if (ps.term_stamp.size() < 2 * s->terms.size()) ps.term_stamp.resize(2 * s->terms.size(), 0u);
+    if (++ps.batch_stamp == 0u) {
+      std::fill(ps.term_stamp.begin(), ps.term_stamp.end(), 0u);
+      ps.batch_stamp = 1u;
+    }
+    ps.and_lead_count.assign(ashare_on ? s->terms.size() : 0, 0u);
+    for (uint32_t qi = 0; qi < n_queries; ++qi) {
+      const tq_query &q = queries[qi];
+      if (!q.terms || q.n_terms > TQ_MAX_TERMS) continue;  // (reported by plan_query)
+      for (uint32_t i = 0; i < q.n_terms; ++i) {
+        const uint32_t h = q.terms[i];
+        if (h >= s->terms.size()) continue;
+        if (ps.term_stamp[2 * h] != ps.batch_stamp) {
+          ps.term_stamp[2 * h] = ps.batch_stamp;
+          unique_bytes += s->terms[h].postings_len;
+        }
+        if (q.mode == TQ_MODE_PHRASE && ps.term_stamp[2 * h + 1] != ps.batch_stamp) {
+          ps.term_stamp[2 * h + 1] = ps.batch_stamp;
+          unique_bytes += s->terms[h].positions_len;
+        }
+      }
+      if (ashare_on) {
+        const uint32_t lh = ashare_leader(q, ps.q_cache[qi]);
+        if (lh != 0xFFFFFFFFu) ++ps.and_lead_count[lh];
+      }
+    }
   }
   // One query -> its descriptor in its launch group.  Reads the segment and the caller's query only,
   // writes to the groups / counters it is handed: large pruned batches are planned in slabs of
@@ -2297,7 +2497,7 @@ int search_batch_impl(tq_segment *s, const tq_query *queries, uint32_t n_queries
         return fail(TQ_ERR_INVALID, "query %u: unknown term handle %u", qi, q.terms[i]);
     }
     int mode = q.mode;
-    bool ph_sweep = false;
+    bool ph_sweep = false, ashare = false;
     uint32_t n_tiles = 0, tile_cost = 1;
     bool all_dense = true;
     uint64_t qbytes = 8ull * q.k;
@@ -2344,7 +2544,16 @@ int search_batch_impl(tq_segment *s, const tq_query *queries, uint32_t n_queries
           n_tiles = (lead_blocks + dq.tile_blocks - 1) / dq.tile_blocks;
           bool nonneg = true;
           for (uint32_t i = 0; i < q.n_terms; ++i) nonneg = nonneg && dq.weight[i] >= 0.0f;
-          if (!opt_exhaustive && nonneg) {  // block-max bounds need weights >= 0
+          if (ashare_on && nonneg && all_dense) {
+            const uint32_t lh = ashare_leader(q, cache_idx);
+            ashare = lh != 0xFFFFFFFFu && lh == dq.term[0] && ps_plan.and_lead_count[lh] >= kAShareMin;
+          }
+          if (ashare) {  // (planned per leader, not per query: build_ashare_plan)
+            dq.flags |= TQD_QF_PRUNE;
+            dq.thr_index = n_thr_rows;
+            n_thr_rows += q.k <= 16u ? 1u : 4u;  // 64 hashed score slots for k <= 16, 256 above
+            n_tiles = 0;
+          } else if (!opt_exhaustive && nonneg) {  // block-max bounds need weights >= 0
             dq.flags |= TQD_QF_PRUNE;
             // the shared threshold pays off on long lists only; k-th largest of 64 slots needs k <= 64
             if (q.k <= TQD_THR_SLOTS && n_tiles >= 2) dq.thr_index = n_thr_rows++;
@@ -2493,7 +2702,7 @@ int search_batch_impl(tq_segment *s, const tq_query *queries, uint32_t n_queries
     }
     algo_bytes += qbytes;
     dq.n_tiles = n_tiles;
-    Group &g = groups[bool_done ? kBool : (share ? kShare : (dense_u ? kDense : (ph_sweep ? kPhSweep : ((mode == TQ_MODE_AND && !all_dense) ? kAndGeneral : mode))))];
+    Group &g = groups[bool_done ? kBool : (share ? kShare : (dense_u ? kDense : (ph_sweep ? kPhSweep : (ashare ? kAShare : ((mode == TQ_MODE_AND && !all_dense) ? kAndGeneral : mode)))))];
     dq.mode = (uint32_t)mode;
     g.queries.push_back(dq);
     g.tile_cost.push_back(tile_cost);
@@ -2531,7 +2740,7 @@ int search_batch_impl(tq_segment *s, const tq_query *queries, uint32_t n_queries
       }
     });
     uint32_t thr_base[9] = {0};
-    size_t g_base[8][9] = {};
+    size_t g_base[kNGroups][9] = {};
     for (uint32_t sb = 0; sb < q_slabs; ++sb) {
       if (qs[sb].rc != TQ_OK) {
         g_last_error = qs[sb].err;
@@ -2585,17 +2794,18 @@ int search_batch_impl(tq_segment *s, const tq_query *queries, uint32_t n_queries
   (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, s->device);
   for (Group &g : groups) {
     if (g.queries.empty()) continue;
-    const int crc = &g == &groups[kShare]   ? build_share_plan(s, g, *s->plan)
-                    : &g == &groups[kDense] ? build_dense_plan(s, g, *s->plan, (uint32_t)std::max(1, cus))
-                                            : build_group_chunks(g, or_windows_opt && &g != &groups[kBool], *s->plan);
+    const int crc = &g == &groups[kShare]    ? build_share_plan(s, g, *s->plan)
+                    : &g == &groups[kAShare] ? build_ashare_plan(s, g, *s->plan)
+                    : &g == &groups[kDense]  ? build_dense_plan(s, g, *s->plan, (uint32_t)std::max(1, cus))
+                                             : build_group_chunks(g, or_windows_opt && &g != &groups[kBool], *s->plan);
     if (crc != TQ_OK) return crc;
   }
   // partial lists of all groups share one buffer; its stride is per group (kpl*64 keys)
-  size_t part_off_bytes[kGroups] = {0, 0, 0, 0, 0, 0, 0, 0};
+  size_t part_off_bytes[kGroups] = {};
   for (int gi = 0; gi < kGroups; ++gi) {
     Group &g = groups[gi];
     part_off_bytes[gi] = partial_bytes;
-    if (gi == kShare || gi == kDense) {  // result lists: part_start / n_parts count 8-byte entries (build_share_plan)
+    if (gi == kShare || gi == kDense || gi == kAShare) {  // result lists: part_start / n_parts count 8-byte entries (build_share_plan)
       if (!g.queries.empty())
         partial_bytes += ((size_t)g.queries.back().part_start + g.queries.back().n_parts) * sizeof(uint64_t);
       continue;
@@ -2640,6 +2850,14 @@ int search_batch_impl(tq_segment *s, const tq_query *queries, uint32_t n_queries
       stage = (stage + 15) & ~(size_t)15;
       g.o_tasks = stage;
       stage += s->plan->tasks.size() * sizeof(uint4);
+    }
+    if (&g == &groups[kAShare]) {
+      stage = (stage + 63) & ~(size_t)63;
+      g.o_leads = stage;
+      stage += s->plan->aleads.size() * sizeof(TqdALead);
+      stage = (stage + 15) & ~(size_t)15;
+      g.o_tasks = stage;
+      stage += s->plan->atasks.size() * sizeof(uint4);
     }
     if (&g == &groups[kDense]) {  // (o_leads: the rows, o_tasks: the queries)
       stage = (stage + 63) & ~(size_t)63;
@@ -2686,6 +2904,10 @@ int search_batch_impl(tq_segment *s, const tq_query *queries, uint32_t n_queries
     if (&g == &groups[kShare]) {
       big_copy(hs + g.o_leads, s->plan->leads.data(), s->plan->leads.size() * sizeof(TqdLead));
       memcpy(hs + g.o_tasks, s->plan->tasks.data(), s->plan->tasks.size() * sizeof(uint4));
+    }
+    if (&g == &groups[kAShare]) {
+      memcpy(hs + g.o_leads, s->plan->aleads.data(), s->plan->aleads.size() * sizeof(TqdALead));
+      big_copy(hs + g.o_tasks, s->plan->atasks.data(), s->plan->atasks.size() * sizeof(uint4));
     }
     if (&g == &groups[kDense]) {
       memcpy(hs + g.o_leads, s->plan->xrows.data(), s->plan->xrows.size() * sizeof(TqkDenseRow));
@@ -2776,6 +2998,21 @@ int search_batch_impl(tq_segment *s, const tq_query *queries, uint32_t n_queries
     HIP_TRY(hipMemsetAsync(s->d_share_words.p, 0, words * sizeof(uint32_t), st));
   }
 
+  uint32_t ashare_grid = 0;
+  const size_t n_ashare = groups[kAShare].queries.size();
+  if (n_ashare) {  // thr_val | list_count per query, then the task counter; staging lists of the persistent grid
+    static const uint32_t kAGridMul = tune_u32("TQ_AS_GRID_MUL", 0);
+    const uint32_t per_cu = kAGridMul ? kAGridMul : tqk_ashare_waves_per_cu();
+    ashare_grid = (uint32_t)std::min<uint64_t>(groups[kAShare].n_chunks, (uint64_t)std::max(1, cus) * per_cu);
+    const size_t words = 2 * n_ashare + 16;
+    rc = s->d_ashare_words.ensure(words * sizeof(uint32_t));
+    if (rc == TQ_OK)
+      rc = s->d_ashare_stage.ensure((size_t)ashare_grid * TQD_AS_GROUP * tqk_share_capl(groups[kAShare].kpl) *
+                                    sizeof(uint64_t));
+    if (rc != TQ_OK) return rc;
+    HIP_TRY(hipMemsetAsync(s->d_ashare_words.p, 0, words * sizeof(uint32_t), st));
+  }
+
   // ---- launch
   const uint8_t *ds = (const uint8_t *)dstage.p;
   if (s->opt.timing) HIP_TRY(hipEventRecord(s->ev_k0[slot], st));
@@ -2791,14 +3028,47 @@ int search_batch_impl(tq_segment *s, const tq_query *queries, uint32_t n_queries
     HIP_TRY(hipEventRecord(s->ev_fork, st));
     HIP_TRY(hipStreamWaitEvent(s->side_stream, s->ev_fork, 0));
   }
-  const int launch_order[kGroups] = {kAndGeneral, kBool, kShare, kDense, 1, 2, kPhSweep, 0};  // long serial chains first
+  const int launch_order[kGroups] = {kAndGeneral, kBool, kShare, kDense, 1, 2, kPhSweep, 0, kAShare};  // long serial chains first
+  // the group that keeps the caller's stream: the batch's intersections
+  const int main_group = n_ashare ? kAShare : 0;
+  uint32_t kernel_mask = 0;
   for (int oi = 0; oi < kGroups; ++oi) {
     const int gi = launch_order[oi];
     Group &g = groups[gi];
     if (g.queries.empty()) continue;
     // the big dense-AND group keeps the caller's stream, the others go to the side stream
-    hipStream_t gst = (fork && gi != 0) ? s->side_stream : st;
+    hipStream_t gst = (fork && gi != main_group) ? s->side_stream : st;
+    if (gi == kAShare) {
+      TqkAShareParams ap{};
+      ap.seg = s->dseg;
+      ap.terms = s->d_terms;
+      ap.queries = (const TqdQuery *)(ds + g.o_queries);
+      ap.caches = (const float *)(ds + o_caches);
+      ap.leads = (const TqdALead *)(ds + g.o_leads);
+      ap.tasks = (const uint4 *)(ds + g.o_tasks);
+      ap.sinks = (const TqkSinks *)(ds + g.o_sinks);
+      ap.thr_slots = (uint32_t *)s->d_thr.p;
+      ap.thr_val = (uint32_t *)s->d_ashare_words.p;
+      ap.list_count = ap.thr_val + n_ashare;
+      ap.task_counter = ap.thr_val + 2 * n_ashare;
+      ap.table_base = (const uint8_t *)s->plan->share_table_base;
+      ap.stage = (uint64_t *)s->d_ashare_stage.p;
+      ap.lists = (uint64_t *)((uint8_t *)s->d_partials.p + part_off_bytes[gi]);
+      ap.n_tasks = g.n_chunks;
+      ap.n_queries = (uint32_t)n_ashare;
+      ap.grid = ashare_grid;
+      static const uint32_t kDebugA = tune_u32("TQ_DEBUG", 0);
+      ap.debug = kDebugA;
+      ap.bound_slack = co.bound_slack;
+      tiles_total += g.total_tiles;
+      chunks_total += g.n_chunks;
+      kernel_mask |= TQ_KERNEL_ASHARE;
+      const hipError_t e = tqk_launch_ashare(ap, g.kpl, gst);
+      if (e != hipSuccess) return fail(TQ_ERR_HIP, "shared-intersection launch: %s", hipGetErrorString(e));
+      continue;
+    }
     if (gi == kShare) {
+      kernel_mask |= TQ_KERNEL_USHARE;
       TqkShareParams sp{};
       sp.seg = s->dseg;
       sp.terms = s->d_terms;
@@ -2838,6 +3108,7 @@ int search_batch_impl(tq_segment *s, const tq_query *queries, uint32_t n_queries
       continue;
     }
     if (gi == kDense) {
+      kernel_mask |= TQ_KERNEL_XUNION;
       TqkDenseParams dp{};
       dp.seg = s->dseg;
       dp.terms = s->d_terms;
@@ -2893,6 +3164,12 @@ int search_batch_impl(tq_segment *s, const tq_query *queries, uint32_t n_queries
     for (const TqdQuery &dq : g.queries) p.max_terms = std::max(p.max_terms, dq.n_terms);
     tiles_total += g.total_tiles;
     chunks_total += g.n_chunks;
+    kernel_mask |= gi == 0 ? TQ_KERNEL_AND_DENSE
+                   : gi == kAndGeneral ? TQ_KERNEL_AND
+                   : gi == kBool ? TQ_KERNEL_BOOL
+                   : gi == kPhSweep ? TQ_KERNEL_PHRASE_SWEEP
+                   : gi == 2 ? TQ_KERNEL_PHRASE
+                   : (p.or_windows ? TQ_KERNEL_OR_WINDOWS : TQ_KERNEL_UNION);
     hipError_t e = hipSuccess;
     if (g.mode == TQ_MODE_AND)
       e = tqk_launch_and(p, g.kpl, s->opt.use_dpp != 0, gst);
@@ -2919,7 +3196,8 @@ int search_batch_impl(tq_segment *s, const tq_query *queries, uint32_t n_queries
     m.out_counts = d_out_counts;
     m.n_queries = (uint32_t)g.queries.size();
     m.out_stride = out_stride;
-    hipError_t e = gi == kShare   ? tqk_launch_merge_lists(m, (const uint32_t *)s->d_share_words.p + n_share, g.kpl, st)
+    hipError_t e = gi == kAShare  ? tqk_launch_merge_lists(m, (const uint32_t *)s->d_ashare_words.p + n_ashare, g.kpl, st)
+                   : gi == kShare ? tqk_launch_merge_lists(m, (const uint32_t *)s->d_share_words.p + n_share, g.kpl, st)
                    : gi == kDense ? tqk_launch_merge_lists(m, (const uint32_t *)s->d_share_words.p + n_dense, g.kpl, st)
                                   : tqk_launch_merge(m, g.kpl, st);
     if (e != hipSuccess) return fail(TQ_ERR_HIP, "merge kernel launch: %s", hipGetErrorString(e));
@@ -2949,6 +3227,8 @@ int search_batch_impl(tq_segment *s, const tq_query *queries, uint32_t n_queries
   s->stats.kernel_ms = 0;
   s->stats.total_ms = 0;
   s->stats.host_plan_ms = 0;
+  s->stats.kernel_mask = kernel_mask;
+  s->stats.unique_bytes = unique_bytes;
   s->stats_pending = true;
   (void)total_parts;
   drain_on_error.armed = false;
@@ -3172,7 +3452,8 @@ int tq_segment_get_stats(tq_segment *s, tq_segment_stats *out) {
   r.posdir_bytes = s->bytes_posdir;
   r.scratch_bytes = s->d_stage.cap + s->d_stage_alt.cap + s->d_partials.cap + s->d_out_scores.cap +
                     s->d_out_docs.cap + s->d_out_counts.cap + s->d_misc.cap + s->d_thr.cap +
-                    s->d_qmatches.cap + s->d_share_words.cap + s->d_share_stage.cap;
+                    s->d_qmatches.cap + s->d_share_words.cap + s->d_share_stage.cap + s->d_ashare_words.cap +
+                    s->d_ashare_stage.cap;
   r.n_terms = (uint32_t)s->terms.size();
   r.n_dense_lists = s->n_dense_lists;
   r.n_docmat_columns = s->n_mat_slots;

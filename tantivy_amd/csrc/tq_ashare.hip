@@ -1,0 +1,475 @@
+// tq_ashare.hip — the AND queries of a batch, driven LEADER BY LEADER instead of query by query.
+// Shared device helpers: tq_common.hpp.
+//
+// block_wand_intersection (src/query/boolean_query/block_wand_intersection.rs:19-179) as and_kernel
+// (tq_and.hip) runs it per query: lists by doc freq ascending, the rarest one (the leader) is walked
+// block by block, a block whose block-max bound cannot reach the threshold is skipped (:81-85), the
+// docs of the others are tested for membership in the other lists, scored leader first, then in
+// ascending doc freq (:144-165), and offered to the collector.
+//
+// What changes is the loop order.  In a batch many queries lead with the same list (the 10 000
+// 2-term queries of the headline batch have 255 distinct leaders: every leader block was decoded
+// ~80 times per batch).  Here a TASK is a run of blocks of ONE leader list for a GROUP of up to 32
+// LEADS (queries that lead with it):
+//   pre-filter, lane <-> block: the block's record, its block-max tf/(tf+norm), and for every live
+//      lead "block-max score + weights of the other lists >= threshold" -> a lead mask per block;
+//   A  per surviving block: ONE decode (unpack + prefix sum), ONE 8-byte doc-matrix gather per doc
+//      (fieldnorm id, membership in the segment's column lists, the signature bits of the others),
+//      tf/(tf+norm) of the leader for both docs of a lane;
+//   F  per (block, lead in the block's mask): the lead's constants are LDS reads at a uniform
+//      address; "every other list of the query holds the doc" is two ORs, an AND and a compare per
+//      doc against the lead's column / signature mask (kept across consecutive leads with the
+//      same mask: the leads of a group are sorted by it), "leader score + weights of the others
+//      >= threshold" one float compare; survivors -> LDS queue, tagged with the lead slot;
+//   C  64 survivors, every lane with its own query: list 1 through its bitmap word (exact
+//      membership for signature-"maybe" lists, the posting index) -> the tf byte at that index,
+//      further lists of a 3+ term query the same way, the exact BM25 sum in the reference's order,
+//      then the collector.
+// Scores are and_kernel's bits (same operations in the same order); thresholds only ever hold scores
+// of k distinct real matches, candidates equal to the threshold are kept, so the top-k equals the
+// exhaustive run's, ties by doc id as TopNHeap resolves them (sort_by_score.rs:86-161).
+//
+// Collector and thresholds: tq_ushare.hip's — per-wave staging lists in global memory cut back by a
+// radix select, appended to the queries' result lists at the end of a task, merge_lists_kernel;
+// hashed atomic-max slots + thr_val[query].
+#include "tq_common.hpp"
+
+#ifndef TQ_AS_WAVES
+#define TQ_AS_WAVES 8
+#endif
+
+namespace {
+
+constexpr uint32_t AS_GROUP = TQD_AS_GROUP;
+
+struct AShareLds {  // per wavefront: 4212 bytes (32 wavefronts per CU fit the 160 KB)
+  float cache[256];                            // Bm25Weight.cache of the task's queries
+  uint32_t q_doc[127], q_tf[127], q_tag[127];  // survivors: doc, leader tf, lead slot | fieldnorm id << 8
+  TqdALead lead[AS_GROUP];                     // the leads of the task
+  uint32_t lthr[AS_GROUP];                     // the lead's threshold (sortable score bits); only ever rises
+  uint32_t lk[AS_GROUP];                       // k of its query (bits 0..7) | its row of threshold slots << 8
+  uint32_t cnt[AS_GROUP];                      // bits 0..15: entries in the slot's staging list; 16..31: docs scored
+  uint32_t pmask[TQD_AS_TILE];                 // per block of the current tile: the leads that still want it
+};
+
+// k-th largest of the n (<= 64 R) keys held R per lane (0 = empty); n >= k
+template <int R>
+__device__ __forceinline__ uint64_t as_kth_largest_key(const uint64_t (&v)[R], uint32_t k) {
+  uint64_t ans = 0;
+  for (int bit = 63; bit >= 0; --bit) {
+    const uint64_t trial = ans | (1ull << bit);
+    uint32_t c = 0;
+#pragma unroll
+    for (int r = 0; r < R; ++r) c += (uint32_t)__popcll(__ballot(v[r] >= trial));
+    if (c >= k) ans = trial;
+  }
+  return ans;
+}
+
+// tf of posting `pi` of list `handle` when its tf byte is saturated (>= 255): block record -> packed tf
+__device__ __forceinline__ uint32_t as_exact_tf(const uint8_t *idx, const TqdTerm *terms, uint32_t handle,
+                                                uint32_t pi) {
+  const TqdTermHead *h = terms + handle;
+  TermRef tr{};
+  tr.rec = h->rec;
+  tr.tail_tfs = h->tail_tfs;
+  tr.payload_base = h->payload_base;
+  tr.has_freq = h->has_freq & 1u;
+  const uint4 r = tr.rec[pi >> 7];
+  return block_tf_at(idx, tr, make_uint2(r.y, r.z), pi & 127u);
+}
+
+template <int KPL>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_num_sgpr(96), amdgpu_waves_per_eu(TQ_AS_WAVES, 8))) void
+ashare_kernel(TqkAShareParams p) {
+  constexpr bool USE_DPP = true;
+  constexpr int R = KPL + 1;                    // staging registers per lane
+  constexpr uint32_t CAPL = (uint32_t)R * 64u;  // staging entries per lead slot
+  __shared__ AShareLds L;
+  const int lane = (int)__lane_id();
+  const TqdSegment seg = p.seg;
+  const uint8_t *idx = seg.idx;
+  uint64_t *const my_stage = p.stage + (size_t)blockIdx.x * (size_t)(AS_GROUP * CAPL);
+  const uint8_t *const tbase = p.table_base;
+  uint32_t cache_loaded = 0xFFFFFFFFu;
+  uint32_t qn = 0;        // survivor queue fill
+  uint32_t n_scored = 0;  // docs scored by this wave (all tasks)
+  uint32_t n_leads = 0;
+
+  // a staging list is cut back to its k best; returns the k-th key (the list held n > k entries)
+  auto compact_slot = [&](uint32_t g, uint32_t n, uint32_t k) __attribute__((always_inline)) -> uint64_t {
+    uint64_t *sl = my_stage + (size_t)g * CAPL;
+    uint64_t v[R];
+    wave_mem_fence();
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const uint32_t i = (uint32_t)r * 64u + (uint32_t)lane;
+      v[r] = i < n ? sl[i] : 0ull;
+    }
+    const uint64_t kth = as_kth_largest_key<R>(v, k);
+    uint32_t base = 0;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const bool keep = v[r] >= kth && v[r] != 0ull;
+      const uint64_t m = __ballot(keep);
+      if (keep) sl[base + mbcnt64(m)] = v[r];
+      base += (uint32_t)__popcll(m);
+    }
+    wave_mem_fence();
+    return kth;
+  };
+
+  // ---- stage C: 64 survivors, every lane with its own query
+  auto stageC = [&](uint32_t n) __attribute__((always_inline)) {
+    const uint32_t base = qn - n;
+    qn = base;
+    if (p.debug & 64u) n_scored += n;  // COUNTERS
+    bool alive = (uint32_t)lane < n;
+    uint32_t doc = 0, tf = 0, tag = 0;
+    if (alive) {
+      doc = L.q_doc[base + lane];
+      tf = L.q_tf[base + lane];
+      tag = L.q_tag[base + lane];
+    }
+    const uint32_t g = tag & 31u;
+    const float norm = L.cache[(tag >> 8) & 0xFFu];
+    const TqdALead ld = L.lead[g];
+    const uint32_t thr = L.lthr[g];
+    const uint32_t k = L.lk[g] & 0xFFu;
+    const uint32_t thr_row = L.lk[g] >> 8;
+    const uint32_t q = ld.query;
+    const uint32_t nt = ld.info & 31u;
+    // leader first, then ascending doc freq (block_wand_intersection.rs:144-165)
+    float s = bm25(ld.w, norm, tf);
+    // list 1: bitmap word (exact membership, the posting index) -> tf byte
+    uint32_t pi = 0, tf1 = 0;
+    {
+      uint2 wd = make_uint2(0u, 0u);
+      if (alive) wd = reinterpret_cast<const uint2 *>(tbase + ((uint64_t)ld.dense_off << 3))[doc >> 5];
+      const uint32_t bit = doc & 31u;
+      alive = alive && ((wd.x >> bit) & 1u);
+      pi = wd.y + (uint32_t)__popc(wd.x & ((1u << bit) - 1u));
+      if (alive) tf1 = (tbase + ((uint64_t)ld.tf8_off << 3))[pi];
+    }
+    const bool more = alive && nt > 2u;
+    const uint64_t more_m = __ballot(more);
+    float w1 = ld.rest;
+    if (more_m) {
+      if (more) w1 = p.queries[q].weight[1];
+    }
+    if (__ballot(alive && tf1 == 255u)) {  // tf >= 255: block record -> packed tf
+      if (alive && tf1 == 255u) tf1 = as_exact_tf(idx, p.terms, p.queries[q].term[1], pi);
+    }
+    if (alive) s = s + bm25(w1, norm, tf1);
+    if (more_m) {  // lists 2.. of a 3+ term query: term table -> bitmap word -> tf byte, one list at a time
+      float rest = ld.rest - w1;
+      for (uint32_t m = 2; m < TQD_AS_MAX_TERMS; ++m) {
+        bool on = alive && m < nt;
+        if (on) {  // what the lists m.. can still add
+          const float r0 = rest > 0.0f ? rest : 0.0f;
+          if (!(sortable((s + r0) * 1.000002f + ld.rest * 4.0e-6f) >= thr)) {
+            alive = false;
+            on = false;
+          }
+        }
+        if (!__ballot(on)) break;  // (lanes with more lists than m are among the lanes with more than m - 1)
+        if (on) {
+          const uint32_t h = p.queries[q].term[m];
+          const float wm = p.queries[q].weight[m];
+          const TqdTerm *T = p.terms + h;
+          const uint2 *dn = T->dense;
+          const uint8_t *t8 = T->tf8;
+          const uint2 wd = dn[doc >> 5];
+          const uint32_t bit = doc & 31u;
+          if ((wd.x >> bit) & 1u) {
+            const uint32_t pm = wd.y + (uint32_t)__popc(wd.x & ((1u << bit) - 1u));
+            uint32_t tfm = t8[pm];
+            if (tfm == 255u) tfm = as_exact_tf(idx, p.terms, h, pm);
+            s = s + bm25(wm, norm, tfm);
+            rest -= wm;
+          } else {
+            alive = false;
+          }
+        }
+      }
+    }
+    // the score is final: below the threshold it cannot enter the top-k (equal scores stay: ties
+    // resolve by doc id in the collector)
+    if (alive) alive = sortable(s) >= thr;
+    if (alive) alive = doc_is_alive(seg, doc);
+    const uint64_t hit = __ballot(alive);
+    if (!hit) return;
+    if (!(p.debug & 992u)) n_scored += (uint32_t)__popcll(hit);  // COUNTERS (TQ_DEBUG): 32 (block, lead) pairs,
+    const uint64_t key = alive ? make_key(s, doc) : 0ull;        // 64 stage-C candidates, 256 blocks decoded
+    const uint32_t sb = (uint32_t)(key >> 32);
+    bool changed = false;
+    if (alive) {
+      const uint32_t hsh = (doc * 0x9E3779B1u) >> (k <= 16u ? 26 : 24);
+      const uint32_t old = atomicMax(p.thr_slots + (size_t)thr_row * TQD_THR_SLOTS + hsh, sb);
+      changed = old < sb;
+      const uint32_t pos = atomicAdd(&L.cnt[g], 0x10001u) & 0xFFFFu;  // (a list never overflows: see the cut below)
+      my_stage[(size_t)g * CAPL + pos] = key;
+    }
+    // queries whose slots changed: their k-th largest slot is the new shared threshold
+    uint64_t chg = __ballot(changed);
+    while (chg) {
+      const uint32_t l = (uint32_t)__builtin_ctzll(chg);
+      const uint32_t qs = (uint32_t)__builtin_amdgcn_readlane((int)q, (int)l);
+      const uint32_t ks = (uint32_t)__builtin_amdgcn_readlane((int)k, (int)l);
+      const uint32_t rs = (uint32_t)__builtin_amdgcn_readlane((int)thr_row, (int)l);
+      chg &= ~__ballot(changed && q == qs);
+      const uint32_t *slots = p.thr_slots + (size_t)rs * TQD_THR_SLOTS;
+      uint32_t sv[4] = {0u, 0u, 0u, 0u};
+      sv[0] = __hip_atomic_load(slots + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      uint32_t gth;
+      if (ks > 16u) {
+#pragma unroll
+        for (int r = 1; r < 4; ++r)
+          sv[r] = __hip_atomic_load(slots + 64 * r + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        gth = kth_largest_hi16<4>(sv, ks);
+      } else {
+        gth = kth_largest_hi16<1>(sv, ks);
+      }
+      if (gth) {
+        if (lane == 0) atomicMax(p.thr_val + qs, gth);
+        if ((uint32_t)lane < n_leads && L.lead[lane].query == qs && gth > L.lthr[lane]) L.lthr[lane] = gth;
+      }
+    }
+    // staging lists that could overflow with the next batch are cut back to their k best now
+    wave_mem_fence();
+    const uint32_t cn = (uint32_t)lane < AS_GROUP ? L.cnt[lane] & 0xFFFFu : 0u;
+    uint64_t full = __ballot(cn > CAPL - 64u);
+    while (full) {
+      const uint32_t gs = (uint32_t)__builtin_ctzll(full);
+      full &= full - 1ull;
+      const uint32_t ns = (uint32_t)__builtin_amdgcn_readlane((int)cn, (int)gs);
+      const uint32_t ks = uni(L.lk[gs]) & 0xFFu;
+      const uint64_t kth = compact_slot(gs, ns, ks);
+      const uint32_t t = (uint32_t)(kth >> 32);
+      if ((uint32_t)lane == gs) {
+        L.cnt[gs] = (L.cnt[gs] & 0xFFFF0000u) | ks;
+        if (t > L.lthr[gs]) L.lthr[gs] = t;
+        atomicMax(p.thr_val + L.lead[gs].query, t);  // k distinct docs of this query score >= t
+      }
+    }
+    wave_mem_fence();
+  };
+
+  for (;;) {
+    uint32_t task = 0;
+    if (lane == 0) task = atomicAdd(p.task_counter, 1u);
+    task = uni(task);
+    if (task >= p.n_tasks) break;
+    const uint4 trec = sload(p.tasks + task);
+    const uint32_t j0 = trec.y, nb_task = trec.z & 0xFFFFu, ci = trec.z >> 24, lead0 = trec.w;
+    n_leads = (trec.z >> 16) & 0xFFu;
+    const TermRef lead = load_term(p.terms, trec.x);
+    if (ci != cache_loaded) {
+      const float *cg = p.caches + (size_t)ci * 256u;
+      wave_mem_fence();
+      for (int i = lane; i < 256; i += WAVE) L.cache[i] = cg[i];
+      wave_mem_fence();
+      cache_loaded = ci;
+    }
+    // ---- the group's leads, one per lane
+    wave_mem_fence();
+    if ((uint32_t)lane < n_leads) {
+      const TqdALead mine = p.leads[lead0 + lane];
+      L.lead[lane] = mine;
+      const TqdQuery *Q = p.queries + mine.query;
+      L.lk[lane] = Q->k | (Q->thr_index << 8);
+      L.lthr[lane] = __hip_atomic_load(p.thr_val + mine.query, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if ((uint32_t)lane < AS_GROUP) L.cnt[lane] = 0u;
+    wave_mem_fence();
+    // a lead whose best possible score is below its threshold is done with the whole list
+    auto lead_alive = [&]() __attribute__((always_inline)) {
+      return (uint32_t)lane < n_leads &&
+             sortable((L.lead[lane].w + L.lead[lane].rest) * 1.000001f) >= L.lthr[lane];
+    };
+    auto refresh_thr = [&]() __attribute__((always_inline)) {  // one word per lead
+      if ((uint32_t)lane < n_leads) {
+        const uint32_t t = __hip_atomic_load(p.thr_val + L.lead[lane].query, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (t > L.lthr[lane]) L.lthr[lane] = t;
+      }
+      wave_mem_fence();
+    };
+    uint32_t live = (uint32_t)__ballot(lead_alive());
+
+    for (uint32_t jt = 0; jt < nb_task && live; jt += TQD_AS_TILE) {
+      if (jt) {  // thresholds may have risen since the last step
+        refresh_thr();
+        live = (uint32_t)__ballot(lead_alive());
+        if (!live) break;
+      }
+      // ---- pre-filter: lane <-> block
+      const uint32_t nb = nb_task - jt < TQD_AS_TILE ? nb_task - jt : TQD_AS_TILE;
+      const uint32_t i_base = j0 + jt;
+      const uint32_t i_mine = i_base + (uint32_t)lane;
+      const bool in_tile = (uint32_t)lane < nb && i_mine < lead.n_blocks;
+      uint4 rec_mine = make_uint4(0u, 0u, 0u, 0u);
+      if (in_tile) rec_mine = lead.rec[i_mine];
+      // block-max of tf/(tf+norm), the weight-free part of block_max_score (term_scorer.rs:58-75)
+      float tfn_max = 1.0f;
+      {
+        const uint32_t tfc = rec_mine.y >> 24;
+        if (!(rec_mine.y == META_TAIL || !lead.has_freq || tfc == 0u)) {
+          const float f = (float)(tfc == 255u ? 0xFFFFFFFFu : tfc);
+          tfn_max = f * __builtin_amdgcn_rcpf(f + L.cache[(rec_mine.y >> 16) & 0xFFu]);
+        }
+      }
+      uint32_t pass_mask = 0;  // leads that still want this block (block_wand_intersection.rs:81-85)
+      for (uint32_t lm = live; lm; lm &= lm - 1u) {
+        const uint32_t g = (uint32_t)__builtin_ctz(lm);
+        const float w = L.lead[g].w, rest = L.lead[g].rest;  // (uniform address: LDS broadcast)
+        const uint32_t thr = L.lthr[g];
+        const float ub = w * tfn_max * p.bound_slack;
+        if (in_tile && sortable((ub + rest) * 1.000004f + (w + rest) * 4.0e-6f) >= thr) pass_mask |= 1u << g;
+      }
+      uint64_t todo = __ballot(pass_mask != 0u);
+      wave_mem_fence();
+      L.pmask[lane] = pass_mask;
+      wave_mem_fence();
+      uint32_t since_refresh = 0;
+      while (todo) {
+        const uint32_t b = (uint32_t)__builtin_ctzll(todo);
+        todo &= todo - 1ull;
+        if (++since_refresh == 8u) {  // thresholds rise while the tile is walked
+          since_refresh = 0;
+          refresh_thr();
+          live = (uint32_t)__ballot(lead_alive());
+          if (!live) break;
+        }
+        uint32_t lm = uni(L.pmask[b]) & live;
+        if (!lm) continue;
+        const uint4 rec_b = sload(lead.rec + (i_base + b));
+        const uint32_t prev_l = block_prev_last(lead, i_base + b);
+        const uint2 mo_l = make_uint2(rec_b.y, rec_b.z);
+        if (p.debug & 256u) ++n_scored;  // COUNTERS
+        // ---- stage A: decode the block once (straight from global memory: no LDS staging — the
+        // blocks are decoded once per group here, not once per query)
+        uint32_t c0, c1, t0, t1;
+        decode_docs<USE_DPP>(idx, lead, mo_l, prev_l, lane, c0, c1);
+        decode_tfs(idx, lead, mo_l, lane, t0, t1);
+        const bool v0 = c0 != TQD_TERMINATED, v1 = c1 != TQD_TERMINATED;
+        // ONE gather per doc: fieldnorm id + membership in every column list + signature bits
+        const uint64_t mw0 = v0 ? seg.docmat[c0] : 0ull;
+        const uint64_t mw1 = v1 ? seg.docmat[c1] : 0ull;
+        const uint32_t nid0 = (uint32_t)mw0 & 0xFFu, nid1 = (uint32_t)mw1 & 0xFFu;
+        const float f0 = (float)t0, f1 = (float)t1;
+        const float tfn0 = f0 * __builtin_amdgcn_rcpf(f0 + L.cache[nid0]);
+        const float tfn1 = f1 * __builtin_amdgcn_rcpf(f1 + L.cache[nid1]);
+        const uint64_t valid0 = __ballot(v0), valid1 = __ballot(v1);
+        // ---- stage F: every lead that wants the block
+        uint32_t pm_lo = 0, pm_hi = 0;
+        uint64_t mem0 = valid0, mem1 = valid1;  // (mask 0: every doc)
+        for (; lm; lm &= lm - 1u) {
+          const uint32_t g = (uint32_t)__builtin_ctz(lm);
+          if (p.debug & 32u) ++n_scored;  // COUNTERS
+          const TqdALead &ld = L.lead[g];
+          const uint32_t thr = uni(L.lthr[g]);
+          const uint32_t mlo = uni(ld.mask_lo), mhi = uni(ld.mask_hi);
+          const float w = ld.w, rest = ld.rest;
+          if (mlo != pm_lo || mhi != pm_hi) {  // "every other list holds (or may hold) the doc"
+            pm_lo = mlo;
+            pm_hi = mhi;
+            const uint32_t x0 = ((uint32_t)mw0 | ~mlo) & ((uint32_t)(mw0 >> 32) | ~mhi);
+            const uint32_t x1 = ((uint32_t)mw1 | ~mlo) & ((uint32_t)(mw1 >> 32) | ~mhi);
+            mem0 = __ballot(x0 == 0xFFFFFFFFu) & valid0;
+            mem1 = __ballot(x1 == 0xFFFFFFFFu) & valid1;
+          }
+          if (!(mem0 | mem1)) continue;
+          // "leader score + weights of the other lists >= threshold" as one float compare per doc
+          // (scores are >= 0: the float order is the order of the sortable bits); the slack that the
+          // reciprocal-based tf/(tf+norm) and the summation order need is folded into the bound
+          // once per (block, lead): tfn >= (thr - rest) / w, widened by 1e-5 on every factor
+          float need = -1.0f;
+          if (thr) {
+            const float thr_f = __uint_as_float(thr ^ ((thr >> 31) ? 0x80000000u : 0xFFFFFFFFu));
+            const float num = thr_f * 0.99999f - rest * 1.00001f;
+            if (num > 0.0f) need = num * __builtin_amdgcn_rcpf(w) * 0.99999f;
+          }
+          const uint64_t a0m = __ballot(tfn0 >= need) & mem0;
+          const uint64_t a1m = __ballot(tfn1 >= need) & mem1;
+          if (!(a0m | a1m)) continue;
+          // the two docs of a lane are queued one after the other: the queue holds < 64 leftovers
+          // plus <= 64 new entries and is drained below 64 before the next push
+#pragma unroll 1
+          for (uint32_t e = 0; e < 2u; ++e) {
+            const uint64_t m = e ? a1m : a0m;
+            if (!m) continue;
+            const bool a = (m >> lane) & 1ull;
+            const uint32_t pos = qn + mbcnt64(m);
+            wave_mem_fence();
+            if (a) {
+              L.q_doc[pos] = e ? c1 : c0;
+              L.q_tf[pos] = e ? t1 : t0;
+              L.q_tag[pos] = g | ((e ? nid1 : nid0) << 8);
+            }
+            wave_mem_fence();
+            qn += (uint32_t)__popcll(m);
+            while (qn >= 64u) stageC(64u);
+          }
+        }
+      }
+    }
+    while (qn) stageC(qn < 64u ? qn : 64u);
+
+    // ---- flush: the staging lists go to their queries' result lists
+    wave_mem_fence();
+    const uint32_t cw = (uint32_t)lane < AS_GROUP ? L.cnt[lane] : 0u;
+    const uint32_t cn = cw & 0xFFFFu, sc = cw >> 16;
+    if (sc) atomicAdd(sload(&p.sinks->query_matches) + sload(&p.sinks->out_index)[L.lead[lane].query], sc);
+    uint64_t have = __ballot(cn != 0u);
+    while (have) {
+      const uint32_t gs = (uint32_t)__builtin_ctzll(have);
+      have &= have - 1ull;
+      uint32_t ns = (uint32_t)__builtin_amdgcn_readlane((int)cn, (int)gs);
+      const uint32_t ks = uni(L.lk[gs]) & 0xFFu;
+      const uint32_t qs = uni(L.lead[gs].query);
+      if (ns > ks) {
+        (void)compact_slot(gs, ns, ks);
+        ns = ks;
+      }
+      const uint32_t thr_now = __hip_atomic_load(p.thr_val + qs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const uint64_t *sl = my_stage + (size_t)gs * CAPL;
+      uint64_t v[R];
+      uint32_t keep_n = 0;
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        const uint32_t i = (uint32_t)r * 64u + (uint32_t)lane;
+        v[r] = i < ns ? sl[i] : 0ull;
+        if ((uint32_t)(v[r] >> 32) < thr_now) v[r] = 0ull;  // k docs of the query score higher by now
+        keep_n += (uint32_t)__popcll(__ballot(v[r] != 0ull));
+      }
+      if (!keep_n) continue;
+      uint32_t at = 0;
+      if (lane == 0) at = atomicAdd(p.list_count + qs, keep_n);
+      at = uni(at);
+      uint64_t *dst = p.lists + (size_t)sload(&p.queries[qs].part_start) + at;
+      uint32_t base = 0;
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        const uint64_t m = __ballot(v[r] != 0ull);
+        if (v[r] != 0ull) dst[base + mbcnt64(m)] = v[r];
+        base += (uint32_t)__popcll(m);
+      }
+    }
+  }
+  if (lane == 0 && n_scored) atomicAdd(sload(&p.sinks->match_counter), (unsigned long long)n_scored);
+}
+
+}  // namespace
+
+// =================================================================== launch wrappers
+uint32_t tqk_ashare_waves_per_cu() { return 4u * TQ_AS_WAVES; }
+
+hipError_t tqk_launch_ashare(const TqkAShareParams &p, int kpl, hipStream_t st) {
+  if (p.n_tasks == 0 || p.grid == 0) return hipSuccess;
+  const dim3 grid(p.grid), block(64);
+  switch (kpl) {
+    case 1: ashare_kernel<1><<<grid, block, 0, st>>>(p); break;
+    default: ashare_kernel<2><<<grid, block, 0, st>>>(p); break;
+  }
+  return hipGetLastError();
+}

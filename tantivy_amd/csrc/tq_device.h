@@ -91,7 +91,7 @@ struct TqdQuery {
 #define TQD_US_GROUP 32      // leads per group (one lane each at task setup)
 #define TQD_US_MAX_TERMS 8   // unions with more terms keep the per-query kernel
 #define TQD_US_TILE 64       // blocks per pre-filter step (one lane each)
-struct TqdLead {             // 72 bytes, written by the host planner
+struct TqdLead {             // 128 bytes, written by the host planner
   uint32_t query;            // launch-group query index
   uint32_t info;             // i (bits 0-3) | lists after i with a membership bit (4-7) | n_terms
                              // (8-11) | bit 12: some list uses the signature word | bit 16+m: list m
@@ -111,6 +111,28 @@ struct TqdLead {             // 72 bytes, written by the host planner
   uint32_t tf8_off[7];
 };
 static_assert(sizeof(TqdLead) == 128, "TqdLead is uploaded as raw bytes");
+
+// ---- shared-intersection launch (tq_ashare.hip): the AND queries of a batch, driven LEADER BY LEADER.
+// block_wand_intersection walks the rarest list of a query (its leader) block by block; in a batch
+// many queries lead with the same list.  A lead here is one query; the leads of one (leader list,
+// Bm25 cache) are cut into groups of <= TQD_AS_GROUP, a TASK is a run of blocks of that list for one
+// group: the blocks are decoded and their doc-matrix words gathered ONCE, every lead tests the 128
+// docs on registers against its own other lists (column / signature bits) and its own threshold.
+#define TQD_AS_GROUP 32      // leads per group (one lane each at task setup)
+#define TQD_AS_MAX_TERMS 8   // intersections with more lists keep the per-query kernel
+#define TQD_AS_TILE 64       // blocks per pre-filter step (one lane each)
+struct TqdALead {            // 32 bytes, written by the host planner
+  uint32_t query;            // launch-group query index
+  uint32_t info;             // n_terms (bits 0-4) | bit 8: list 1's membership bit is its column (exact)
+  float w;                   // weight of the leader in this query
+  float rest;                // weights of the other lists together: the most they can add (= weight of
+                             // list 1 in a 2-term query)
+  uint32_t mask_lo, mask_hi; // doc-matrix bits every match has: the other lists' columns (exact) and
+                             // signature bits (a clear bit proves absence, a set one means maybe)
+  uint32_t dense_off;        // list 1: bitmap + rank directory, byte-wide tfs, as offsets from
+  uint32_t tf8_off;          // TqkAShareParams::table_base in 8-byte units
+};
+static_assert(sizeof(TqdALead) == 32, "TqdALead is uploaded as raw bytes");
 
 #define TQD_ROLE_SHOULD 0u
 #define TQD_ROLE_MUST 1u

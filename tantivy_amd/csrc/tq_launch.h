@@ -64,6 +64,29 @@ struct TqkShareParams {
   float bound_slack;
 };
 
+// shared-intersection launch (tq_ashare.hip): a persistent grid of single-wave workgroups pulling tasks
+struct TqkAShareParams {
+  TqdSegment seg;
+  const TqdTerm *terms;
+  const TqdQuery *queries;      // the launch group's queries (part_start / n_parts count list ENTRIES)
+  const float *caches;
+  const TqdALead *leads;
+  const uint4 *tasks;           // {leader term handle, first block, n_blocks | n_leads << 16 | cache << 24, first lead}
+  const TqkSinks *sinks;
+  uint32_t *thr_slots;          // hashed score slots per query (as the other pruned kernels use)
+  uint32_t *thr_val;            // [n_queries] current lower bound of each query's k-th best score
+  uint32_t *task_counter;       // next task to hand out (zeroed per batch)
+  const uint8_t *table_base;    // TqdALead::dense_off / tf8_off count 8-byte units from here
+  uint64_t *stage;              // [grid][TQD_AS_GROUP][capl] per-wave staging lists
+  uint64_t *lists;              // per-query result lists (query q: entries part_start .. + n_parts)
+  uint32_t *list_count;         // [n_queries] entries written so far
+  uint32_t n_tasks;
+  uint32_t n_queries;
+  uint32_t grid;
+  uint32_t debug;
+  float bound_slack;
+};
+
 // exhaustive pure unions, doc-major (tq_xunion.hip): a persistent grid of 16-wave workgroups; a
 // workgroup builds the BM25 term scores of EVERY (list, weight) pair of the group for a tile of 128
 // docs in LDS, then each of its waves evaluates its share of the group's queries against that tile
@@ -142,6 +165,8 @@ hipError_t tqk_launch_share(const TqkShareParams &p, int kpl, hipStream_t st);
 hipError_t tqk_launch_merge_lists(const TqkMergeParams &m, const uint32_t *list_count, int kpl,
                                   hipStream_t st);
 uint32_t tqk_share_capl(int kpl);  // staging entries per lead slot
+hipError_t tqk_launch_ashare(const TqkAShareParams &p, int kpl, hipStream_t st);
+uint32_t tqk_ashare_waves_per_cu();  // resident wavefronts per CU the kernel is built for
 hipError_t tqk_launch_xunion(const TqkDenseParams &p, int kpl, hipStream_t st);
 // a list without a bitmap as plain arrays: doc ids and min(tf, 255) per posting
 hipError_t tqk_launch_flat_list(const TqdSegment &seg, const TqdTerm *terms, uint32_t handle,

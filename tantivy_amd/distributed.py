@@ -216,8 +216,10 @@ class ShardRunner:
                 out = dict(st)
             else:
                 for key in ("algorithmic_bytes", "matches", "kernel_ms", "total_ms", "tiles", "chunks",
-                            "host_plan_ms"):
+                            "host_plan_ms", "unique_bytes"):
                     out[key] += st[key]
+                out["kernel_mask"] |= st["kernel_mask"]
+                out["kernels"] = sorted(set(out["kernels"]) | set(st["kernels"]))
         return out
 
     def exchange_ms(self):

@@ -68,3 +68,17 @@ def test_dense_union_plan_invariants(plan_check, seed):
     r = subprocess.run([plan_check, str(seed), "dense"], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "dense:" in r.stdout and "ok" in r.stdout
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_ashare_plan_invariants(plan_check, seed):
+    """build_ashare_plan (the shared-intersection launch, tq_ashare.hip): one lead per query sorted by
+    (leader, cache, mask), lead records against their queries, the tasks of every lead group tile the
+    leader's blocks once, doc-slice launch order, disjoint result lists — also with small groups,
+    long tasks and a result-list budget that forces longer tasks."""
+    for env_extra in ({}, {"TQ_AS_GROUP": "5", "TQ_AS_TASK_PAIRS": "64"}, {"TQ_AS_TASK_BLOCKS": "7"},
+                      {"TQ_AS_LIST_MB": "1"}):
+        r = subprocess.run([plan_check, str(seed), "ashare"], env=dict(os.environ, **env_extra),
+                           capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr + r.stdout
+        assert "ashare:" in r.stdout and "ok" in r.stdout

@@ -188,6 +188,143 @@ static int check_share(int seed) {
   return 0;
 }
 
+// The shared-intersection planner (build_ashare_plan): every query is exactly one lead; the leads of
+// one (leader, cache) are contiguous and sorted by mask; every lead record describes its query; the
+// tasks of a lead group tile the leader's blocks exactly once; tasks are launched in doc-slice
+// order; the result-list regions are disjoint and hold k entries per (task, lead) pair.
+static int check_ashare(int seed) {
+  std::mt19937 rng(seed + 500);
+  auto uni = [&](uint32_t lo, uint32_t hi) { return std::uniform_int_distribution<uint32_t>(lo, hi)(rng); };
+  tq_segment seg;
+  const uint32_t n_terms = 120;
+  static uint8_t arena[1 << 20];
+  for (uint32_t t = 0; t < n_terms; ++t) {
+    TermHost th;
+    th.n_blocks = uni(1, 30000) >> (t / 8);
+    if (!th.n_blocks) th.n_blocks = 1;
+    th.doc_freq = th.n_blocks * 128u - uni(0, 127);
+    TqdTerm dt{};
+    dt.has_freq = 1u;
+    th.dense_blob = arena + 4096u * t + 8u;
+    th.tf8_blob = arena + 4096u * t + 2048u;
+    if (t < TQD_MAT_SLOTS) dt.has_freq |= (t + 1u) << 8;
+    else if (t % 5) dt.has_freq |= ((t * 7u) % TQD_SIG_BITS + 1u) << 16;  // (some lists with neither)
+    seg.terms.push_back(th);
+    seg.h_dterms.push_back(dt);
+  }
+  seg.max_doc = 10000000u;
+  PlanScratch ps;
+  Group &g = ps.groups[8];
+  g.reset();
+  g.mode = TQ_MODE_AND;
+  const uint32_t nq = uni(1, 4) == 1 ? uni(1, 40) : uni(500, 3000);
+  for (uint32_t q = 0; q < nq; ++q) {
+    TqdQuery dq{};
+    dq.n_terms = uni(0, 3) ? 2u : uni(2, TQD_AS_MAX_TERMS);
+    dq.k = uni(1, 128);
+    dq.flags = TQD_QF_PRUNE;
+    dq.cache_idx = uni(0, 9) ? 0u : uni(1, 2);
+    dq.thr_index = 4u * q;
+    uint32_t used[TQD_AS_MAX_TERMS];
+    for (uint32_t i = 0; i < dq.n_terms; ++i) {
+      uint32_t t;
+      bool dup;
+      do {
+        t = uni(0, 1) ? uni(0, 15) : uni(0, n_terms - 1);
+        dup = false;
+        for (uint32_t j = 0; j < i; ++j) dup |= used[j] == t;
+      } while (dup);
+      used[i] = t;
+    }
+    std::sort(used, used + dq.n_terms, [&](uint32_t a, uint32_t b) {  // doc freq ascending: term[0] leads
+      return seg.terms[a].doc_freq != seg.terms[b].doc_freq ? seg.terms[a].doc_freq < seg.terms[b].doc_freq : a < b;
+    });
+    for (uint32_t i = 0; i < dq.n_terms; ++i) {
+      dq.term[i] = used[i];
+      dq.weight[i] = 1.0f + 0.37f * (float)((used[i] * 13u + q) % 11u);
+    }
+    g.queries.push_back(dq);
+    g.tile_cost.push_back(1);
+    g.out_index.push_back(q);
+    g.max_k = std::max(g.max_k, dq.k);
+  }
+  seg.share_table_lo = (uint64_t)arena;
+  if (build_ashare_plan(&seg, g, ps) != TQ_OK) return fail_msg("build_ashare_plan failed");
+  if (ps.aleads.size() != nq) return fail_msg("lead count", (long)ps.aleads.size(), nq);
+  std::vector<uint8_t> seen(nq, 0);
+  uint64_t prev_key = 0, prev_mask = 0;
+  for (size_t i = 0; i < ps.aleads.size(); ++i) {
+    const TqdALead &ld = ps.aleads[i];
+    if (ld.query >= nq || seen[ld.query]++) return fail_msg("lead twice / out of range", (long)i, ld.query);
+    const TqdQuery &q = g.queries[ld.query];
+    if ((ld.info & 31u) != q.n_terms || ld.w != q.weight[0]) return fail_msg("lead header", (long)i);
+    float rest = 0;
+    uint64_t mask = 0;
+    for (uint32_t m = 1; m < q.n_terms; ++m) {
+      rest += q.weight[m];
+      const uint32_t hf = seg.h_dterms[q.term[m]].has_freq;
+      const uint32_t col = (hf >> 8) & 0xFFu ? 8u + ((hf >> 8) & 0xFFu) - 1u : 0u;
+      const uint32_t sig1 = col ? 0u : (hf >> 16) & 0xFFu;
+      if (col) mask |= 1ull << col;
+      else if (sig1) mask |= 1ull << (TQD_SIG_SHIFT + sig1 - 1u);
+    }
+    if (ld.rest != rest) return fail_msg("lead rest", (long)i);
+    if (q.n_terms == 2 && ld.rest != q.weight[1]) return fail_msg("2-term rest is list 1's weight", (long)i);
+    if ((((uint64_t)ld.mask_hi << 32) | ld.mask_lo) != mask) return fail_msg("lead mask", (long)i);
+    const bool col1 = ((seg.h_dterms[q.term[1]].has_freq >> 8) & 0xFFu) != 0u;
+    if (((ld.info >> 8) & 1u) != (col1 ? 1u : 0u)) return fail_msg("column flag", (long)i);
+    const TermHost &t1 = seg.terms[q.term[1]];
+    if ((uint64_t)ld.dense_off * 8u != (uint64_t)t1.dense_blob - ps.share_table_base ||
+        (uint64_t)ld.tf8_off * 8u != (uint64_t)t1.tf8_blob - ps.share_table_base)
+      return fail_msg("table offsets", (long)i);
+    const uint64_t key = ((uint64_t)q.term[0] << 8) | q.cache_idx;
+    if (i && (key < prev_key || (key == prev_key && mask < prev_mask))) return fail_msg("lead order", (long)i);
+    prev_key = key;
+    prev_mask = mask;
+  }
+  std::vector<uint32_t> pairs(nq, 0);
+  std::unordered_map<uint64_t, uint32_t> next_block;  // (first lead << 8 | n_leads) -> next expected block
+  std::unordered_map<uint64_t, uint32_t> covered;     // lead index -> tasks that name it (via its group)
+  uint32_t last_slice = 0;
+  for (size_t ti = 0; ti < ps.atasks.size(); ++ti) {
+    const uint4 t = ps.atasks[ti];
+    const uint32_t nb = t.z & 0xFFFFu, nl = (t.z >> 16) & 0xFFu, cache = t.z >> 24;
+    if (!nb || !nl || nl > TQD_AS_GROUP || t.w + nl > ps.aleads.size()) return fail_msg("task shape", (long)ti);
+    for (uint32_t l = 0; l < nl; ++l) {
+      const TqdALead &ld = ps.aleads[t.w + l];
+      const TqdQuery &q = g.queries[ld.query];
+      if (q.term[0] != t.x || q.cache_idx != cache) return fail_msg("task lead of another leader", (long)ti, l);
+      ++pairs[ld.query];
+    }
+    const uint32_t n_blocks = seg.terms[t.x].n_blocks;
+    const uint32_t slice = (uint32_t)(((uint64_t)t.y << 12) / n_blocks);
+    if (slice < last_slice) return fail_msg("tasks not in doc-slice order", (long)ti);
+    last_slice = slice;
+    // (tasks of one group appear in block order: the sort by slice is stable and slices follow blocks)
+    uint32_t &nx = next_block[((uint64_t)t.w << 8) | nl];
+    if (t.y != nx) return fail_msg("runs do not tile the list", (long)ti, t.y);
+    nx += nb;
+    if (nx > n_blocks) return fail_msg("run past the list", (long)ti);
+  }
+  size_t leads_in_groups = 0;
+  for (auto &kv : next_block) {
+    const TqdALead &ld = ps.aleads[kv.first >> 8];
+    if (kv.second != seg.terms[g.queries[ld.query].term[0]].n_blocks) return fail_msg("list not covered");
+    leads_in_groups += kv.first & 0xFFu;
+  }
+  if (leads_in_groups != nq) return fail_msg("lead groups do not partition the leads", (long)leads_in_groups, nq);
+  uint64_t at = 0;
+  for (uint32_t q = 0; q < nq; ++q) {
+    if (!pairs[q]) return fail_msg("query without a task", q);
+    if (g.queries[q].part_start != at) return fail_msg("result regions overlap", q);
+    if (g.queries[q].n_parts != pairs[q] * g.queries[q].k) return fail_msg("result region size", q);
+    at += g.queries[q].n_parts;
+  }
+  if (g.n_chunks != ps.atasks.size()) return fail_msg("n_chunks");
+  printf("ashare: %u queries, %zu tasks, %llu list entries ok\n", nq, ps.atasks.size(), (unsigned long long)at);
+  return 0;
+}
+
 // The doc-major union plan (build_dense_plan): rows = the distinct (list, weight) pairs, lists with a
 // bitmap first; every query's row bytes lead back to its lists at its weights, padded with the
 // all-zero row; tasks cover every tile once; result lists are disjoint.
@@ -317,6 +454,7 @@ int main(int argc, char **argv) {
   if (argc > 2 && !strcmp(argv[2], "share")) return check_share(seed);
   if (argc > 2 && !strcmp(argv[2], "pool")) return check_pool(seed);
   if (argc > 2 && !strcmp(argv[2], "dense")) return check_dense(seed);
+  if (argc > 2 && !strcmp(argv[2], "ashare")) return check_ashare(seed);
   std::mt19937 rng(seed);
   auto uni = [&](uint32_t lo, uint32_t hi) { return std::uniform_int_distribution<uint32_t>(lo, hi)(rng); };
   PlanScratch ps;
