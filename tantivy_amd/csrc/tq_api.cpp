@@ -1292,6 +1292,7 @@ struct PlanScratch {
   std::vector<TqdALead> aleads;
   std::vector<uint4> atasks, atasks_unsorted;
   std::vector<uint32_t> atask_pos, alead_order, apairs;
+  uint32_t a_warm_tasks = 0;  // tasks [0, a_warm_tasks) are the warm-up launch
   std::vector<uint64_t> alead_key;
   std::vector<uint32_t> and_lead_count;  // per term handle: AND queries of the batch it could lead in that launch
   std::vector<uint32_t> term_stamp;      // per term handle: last batch that used the list (unique bytes)
@@ -2030,7 +2031,13 @@ int build_ashare_plan(tq_segment *s, Group &g, PlanScratch &ps) {
   });
   for (size_t i = 0; i < nq; ++i) leads[i] = unsorted[order[i]];
   // ---- tasks: groups of leads x runs of blocks; fewer, longer tasks if the result lists (k entries
-  // per (task, lead) pair) would not fit the budget
+  // per (task, lead) pair) would not fit the budget.  The first kWarmPermille / 1000 of every leader go
+  // out as short tasks in a launch of their own: every resident wavefront starts a launch with the
+  // thresholds it finds, and with thresholds of zero the first wavefronts (an eighth of the batch)
+  // sent every match through the scoring stage — a warm-up over 2 % of the blocks leaves the main launch
+  // the k-th best of a 2 % sample of every query to start from.
+  static const uint32_t kWarmPermille = std::min<uint32_t>(1000u, tune_u32("TQ_AS_WARM_PERMILLE", 20));
+  static const uint32_t kWarmBlocks = std::max<uint32_t>(1u, tune_u32("TQ_AS_WARM_BLOCKS", 2));
   std::vector<uint4> &tasks = ps.atasks, &raw = ps.atasks_unsorted;
   std::vector<uint32_t> &pos = ps.atask_pos, &pairs = ps.apairs;
   uint32_t task_pairs = kTaskPairsEnv;
@@ -2048,17 +2055,22 @@ int build_ashare_plan(tq_segment *s, Group &g, PlanScratch &ps) {
       const uint32_t n_groups = (n_run + kGroupMax - 1) / kGroupMax;
       const uint32_t per_group = (n_run + n_groups - 1) / n_groups;
       const uint32_t bpt = std::min<uint32_t>(kTaskBlocksMax, std::max<uint32_t>(1u, task_pairs / per_group));
-      for (uint32_t j0 = 0; j0 < n_blocks; j0 += bpt) {
-        const uint32_t nb = std::min<uint32_t>(bpt, n_blocks - j0);
-        const uint32_t slice = (uint32_t)(((uint64_t)j0 << 12) / n_blocks);
+      const uint32_t nb_warm = (uint32_t)((uint64_t)n_blocks * kWarmPermille / 1000u);
+      uint32_t n_runs = 0;
+      for (uint32_t j0 = 0; j0 < n_blocks;) {
+        const bool warm = j0 < nb_warm;
+        const uint32_t nb = warm ? std::min<uint32_t>(kWarmBlocks, nb_warm - j0) : std::min<uint32_t>(bpt, n_blocks - j0);
+        // (slice 4096: the main launch's tasks sort behind every warm-up task)
+        const uint32_t slice = warm ? 0u : 1u + (uint32_t)(((uint64_t)j0 << 12) / n_blocks);
         for (uint32_t gr = 0; gr < n_groups; ++gr) {
           const uint32_t l0 = gr * per_group, l1 = std::min<uint32_t>(n_run, l0 + per_group);
           if (l0 >= l1) continue;
           raw.push_back(make_uint4(term, j0, nb | ((l1 - l0) << 16) | (cache << 24), (uint32_t)r0 + l0));
           pos.push_back(slice);
         }
+        j0 += nb;
+        ++n_runs;
       }
-      const uint32_t n_runs = (n_blocks + bpt - 1) / bpt;
       for (size_t a = r0; a < r1; ++a) {
         pairs[order[a]] = n_runs;
         entries += (uint64_t)n_runs * g.queries[order[a]].k;
@@ -2072,10 +2084,11 @@ int build_ashare_plan(tq_segment *s, Group &g, PlanScratch &ps) {
     task_pairs *= 2u;
   }
   if (raw.size() > 0x7FFFFFFFull) return fail(TQ_ERR_UNSUPPORTED, "batch too large (tasks)");
-  {  // launch order: stable counting sort by doc slice
-    uint32_t hist[4097] = {0};
+  {  // launch order: the warm-up tasks (slice 0), then stable counting sort by doc slice
+    uint32_t hist[4099] = {0};
     for (uint32_t p : pos) ++hist[p + 1u];
-    for (uint32_t i = 0; i < 4096; ++i) hist[i + 1] += hist[i];
+    for (uint32_t i = 0; i < 4098; ++i) hist[i + 1] += hist[i];
+    ps.a_warm_tasks = hist[1];
     tasks.resize(raw.size());
     for (size_t i = 0; i < raw.size(); ++i) tasks[hist[pos[i]]++] = raw[i];
   }
@@ -3050,21 +3063,27 @@ int search_batch_impl(tq_segment *s, const tq_query *queries, uint32_t n_queries
       ap.thr_slots = (uint32_t *)s->d_thr.p;
       ap.thr_val = (uint32_t *)s->d_ashare_words.p;
       ap.list_count = ap.thr_val + n_ashare;
-      ap.task_counter = ap.thr_val + 2 * n_ashare;
       ap.table_base = (const uint8_t *)s->plan->share_table_base;
       ap.stage = (uint64_t *)s->d_ashare_stage.p;
       ap.lists = (uint64_t *)((uint8_t *)s->d_partials.p + part_off_bytes[gi]);
-      ap.n_tasks = g.n_chunks;
       ap.n_queries = (uint32_t)n_ashare;
-      ap.grid = ashare_grid;
       static const uint32_t kDebugA = tune_u32("TQ_DEBUG", 0);
       ap.debug = kDebugA;
       ap.bound_slack = co.bound_slack;
       tiles_total += g.total_tiles;
       chunks_total += g.n_chunks;
       kernel_mask |= TQ_KERNEL_ASHARE;
-      const hipError_t e = tqk_launch_ashare(ap, g.kpl, gst);
-      if (e != hipSuccess) return fail(TQ_ERR_HIP, "shared-intersection launch: %s", hipGetErrorString(e));
+      // two launches: the warm-up tasks, then the rest (stream order = the barrier between them)
+      const uint32_t bounds[3] = {0u, s->plan->a_warm_tasks, g.n_chunks};
+      for (int ph = 0; ph < 2; ++ph) {
+        ap.task_begin = bounds[ph];
+        ap.n_tasks = bounds[ph + 1];
+        if (ap.n_tasks <= ap.task_begin) continue;
+        ap.task_counter = ap.thr_val + 2 * n_ashare + ph;
+        ap.grid = std::min<uint32_t>(ashare_grid, ap.n_tasks - ap.task_begin);
+        const hipError_t e = tqk_launch_ashare(ap, g.kpl, gst);
+        if (e != hipSuccess) return fail(TQ_ERR_HIP, "shared-intersection launch: %s", hipGetErrorString(e));
+      }
       continue;
     }
     if (gi == kShare) {

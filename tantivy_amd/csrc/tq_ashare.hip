@@ -124,6 +124,7 @@ ashare_kernel(TqkAShareParams p) {
     const uint32_t base = qn - n;
     qn = base;
     if (p.debug & 64u) n_scored += n;  // COUNTERS
+    if (p.debug & 512u) ++n_scored;
     bool alive = (uint32_t)lane < n;
     uint32_t doc = 0, tf = 0, tag = 0;
     if (alive) {
@@ -199,41 +200,17 @@ ashare_kernel(TqkAShareParams p) {
     if (alive) alive = doc_is_alive(seg, doc);
     const uint64_t hit = __ballot(alive);
     if (!hit) return;
-    if (!(p.debug & 992u)) n_scored += (uint32_t)__popcll(hit);  // COUNTERS (TQ_DEBUG): 32 (block, lead) pairs,
+    if (!(p.debug & 0x7FE0u)) n_scored += (uint32_t)__popcll(hit);  // COUNTERS (TQ_DEBUG): 32 (block, lead) pairs,
     const uint64_t key = alive ? make_key(s, doc) : 0ull;        // 64 stage-C candidates, 256 blocks decoded
     const uint32_t sb = (uint32_t)(key >> 32);
-    bool changed = false;
     if (alive) {
+      // the query's hashed score slots: fire and forget (the k-th largest slot is selected once per
+      // (task, lead) at the end of the task, not once per change: the selects were a quarter of the
+      // kernel's instructions)
       const uint32_t hsh = (doc * 0x9E3779B1u) >> (k <= 16u ? 26 : 24);
-      const uint32_t old = atomicMax(p.thr_slots + (size_t)thr_row * TQD_THR_SLOTS + hsh, sb);
-      changed = old < sb;
+      (void)atomicMax(p.thr_slots + (size_t)thr_row * TQD_THR_SLOTS + hsh, sb);
       const uint32_t pos = atomicAdd(&L.cnt[g], 0x10001u) & 0xFFFFu;  // (a list never overflows: see the cut below)
       my_stage[(size_t)g * CAPL + pos] = key;
-    }
-    // queries whose slots changed: their k-th largest slot is the new shared threshold
-    uint64_t chg = __ballot(changed);
-    while (chg) {
-      const uint32_t l = (uint32_t)__builtin_ctzll(chg);
-      const uint32_t qs = (uint32_t)__builtin_amdgcn_readlane((int)q, (int)l);
-      const uint32_t ks = (uint32_t)__builtin_amdgcn_readlane((int)k, (int)l);
-      const uint32_t rs = (uint32_t)__builtin_amdgcn_readlane((int)thr_row, (int)l);
-      chg &= ~__ballot(changed && q == qs);
-      const uint32_t *slots = p.thr_slots + (size_t)rs * TQD_THR_SLOTS;
-      uint32_t sv[4] = {0u, 0u, 0u, 0u};
-      sv[0] = __hip_atomic_load(slots + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      uint32_t gth;
-      if (ks > 16u) {
-#pragma unroll
-        for (int r = 1; r < 4; ++r)
-          sv[r] = __hip_atomic_load(slots + 64 * r + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        gth = kth_largest_hi16<4>(sv, ks);
-      } else {
-        gth = kth_largest_hi16<1>(sv, ks);
-      }
-      if (gth) {
-        if (lane == 0) atomicMax(p.thr_val + qs, gth);
-        if ((uint32_t)lane < n_leads && L.lead[lane].query == qs && gth > L.lthr[lane]) L.lthr[lane] = gth;
-      }
     }
     // staging lists that could overflow with the next batch are cut back to their k best now
     wave_mem_fence();
@@ -244,6 +221,7 @@ ashare_kernel(TqkAShareParams p) {
       full &= full - 1ull;
       const uint32_t ns = (uint32_t)__builtin_amdgcn_readlane((int)cn, (int)gs);
       const uint32_t ks = uni(L.lk[gs]) & 0xFFu;
+      if (p.debug & 4096u) ++n_scored;  // COUNTERS
       const uint64_t kth = compact_slot(gs, ns, ks);
       const uint32_t t = (uint32_t)(kth >> 32);
       if ((uint32_t)lane == gs) {
@@ -258,7 +236,7 @@ ashare_kernel(TqkAShareParams p) {
   for (;;) {
     uint32_t task = 0;
     if (lane == 0) task = atomicAdd(p.task_counter, 1u);
-    task = uni(task);
+    task = uni(task) + p.task_begin;
     if (task >= p.n_tasks) break;
     const uint4 trec = sload(p.tasks + task);
     const uint32_t j0 = trec.y, nb_task = trec.z & 0xFFFFu, ci = trec.z >> 24, lead0 = trec.w;
@@ -273,9 +251,18 @@ ashare_kernel(TqkAShareParams p) {
     }
     // ---- the group's leads, one per lane
     wave_mem_fence();
+    // lane g also keeps lead g's constants in registers: the loops over the leads of a block fetch
+    // them with v_readlane (no LDS round trip per (block, lead) pair); stage C, where every lane
+    // works for another lead, gathers them from the LDS copy
+    float my_w = 0.0f, my_rest = 0.0f;
+    uint32_t my_mlo = 0, my_mhi = 0;
     if ((uint32_t)lane < n_leads) {
       const TqdALead mine = p.leads[lead0 + lane];
       L.lead[lane] = mine;
+      my_w = mine.w;
+      my_rest = mine.rest;
+      my_mlo = mine.mask_lo;
+      my_mhi = mine.mask_hi;
       const TqdQuery *Q = p.queries + mine.query;
       L.lk[lane] = Q->k | (Q->thr_index << 8);
       L.lthr[lane] = __hip_atomic_load(p.thr_val + mine.query, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -284,8 +271,7 @@ ashare_kernel(TqkAShareParams p) {
     wave_mem_fence();
     // a lead whose best possible score is below its threshold is done with the whole list
     auto lead_alive = [&]() __attribute__((always_inline)) {
-      return (uint32_t)lane < n_leads &&
-             sortable((L.lead[lane].w + L.lead[lane].rest) * 1.000001f) >= L.lthr[lane];
+      return (uint32_t)lane < n_leads && sortable((my_w + my_rest) * 1.000001f) >= L.lthr[lane];
     };
     auto refresh_thr = [&]() __attribute__((always_inline)) {  // one word per lead
       if ((uint32_t)lane < n_leads) {
@@ -319,12 +305,16 @@ ashare_kernel(TqkAShareParams p) {
         }
       }
       uint32_t pass_mask = 0;  // leads that still want this block (block_wand_intersection.rs:81-85)
-      for (uint32_t lm = live; lm; lm &= lm - 1u) {
-        const uint32_t g = (uint32_t)__builtin_ctz(lm);
-        const float w = L.lead[g].w, rest = L.lead[g].rest;  // (uniform address: LDS broadcast)
-        const uint32_t thr = L.lthr[g];
-        const float ub = w * tfn_max * p.bound_slack;
-        if (in_tile && sortable((ub + rest) * 1.000004f + (w + rest) * 4.0e-6f) >= thr) pass_mask |= 1u << g;
+      {
+        const uint32_t my_thr = (uint32_t)lane < n_leads ? L.lthr[lane] : 0u;
+        for (uint32_t lm = live; lm; lm &= lm - 1u) {
+          const uint32_t g = (uint32_t)__builtin_ctz(lm);
+          const float w = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(my_w), (int)g));
+          const float rest = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(my_rest), (int)g));
+          const uint32_t thr = (uint32_t)__builtin_amdgcn_readlane((int)my_thr, (int)g);
+          const float ub = w * tfn_max * p.bound_slack;
+          if (in_tile && sortable((ub + rest) * 1.000004f + (w + rest) * 4.0e-6f) >= thr) pass_mask |= 1u << g;
+        }
       }
       uint64_t todo = __ballot(pass_mask != 0u);
       wave_mem_fence();
@@ -360,16 +350,29 @@ ashare_kernel(TqkAShareParams p) {
         const float tfn0 = f0 * __builtin_amdgcn_rcpf(f0 + L.cache[nid0]);
         const float tfn1 = f1 * __builtin_amdgcn_rcpf(f1 + L.cache[nid1]);
         const uint64_t valid0 = __ballot(v0), valid1 = __ballot(v1);
-        // ---- stage F: every lead that wants the block
+        // ---- stage F: every lead that wants the block.  "leader score + weights of the other lists
+        // >= threshold" is one float compare per doc (scores are >= 0: the float order is the order
+        // of the sortable bits): tfn >= (thr - rest) / w, every factor widened by 1e-5 for the
+        // reciprocal-based tf/(tf+norm) and the summation order — computed for all leads at once,
+        // lane g for lead g
+        float my_need = -1.0f;
+        {
+          const uint32_t thr = (uint32_t)lane < n_leads ? L.lthr[lane] : 0u;
+          if (thr) {
+            const float thr_f = __uint_as_float(thr ^ ((thr >> 31) ? 0x80000000u : 0xFFFFFFFFu));
+            const float num = thr_f * 0.99999f - my_rest * 1.00001f;
+            if (num > 0.0f) my_need = num * __builtin_amdgcn_rcpf(my_w) * 0.99999f;
+          }
+        }
         uint32_t pm_lo = 0, pm_hi = 0;
         uint64_t mem0 = valid0, mem1 = valid1;  // (mask 0: every doc)
+        if (p.debug & 2048u) lm = 0;  // ABLATION: decode only
         for (; lm; lm &= lm - 1u) {
           const uint32_t g = (uint32_t)__builtin_ctz(lm);
           if (p.debug & 32u) ++n_scored;  // COUNTERS
-          const TqdALead &ld = L.lead[g];
-          const uint32_t thr = uni(L.lthr[g]);
-          const uint32_t mlo = uni(ld.mask_lo), mhi = uni(ld.mask_hi);
-          const float w = ld.w, rest = ld.rest;
+          const uint32_t mlo = (uint32_t)__builtin_amdgcn_readlane((int)my_mlo, (int)g);
+          const uint32_t mhi = (uint32_t)__builtin_amdgcn_readlane((int)my_mhi, (int)g);
+          const float need = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(my_need), (int)g));
           if (mlo != pm_lo || mhi != pm_hi) {  // "every other list holds (or may hold) the doc"
             pm_lo = mlo;
             pm_hi = mhi;
@@ -379,19 +382,10 @@ ashare_kernel(TqkAShareParams p) {
             mem1 = __ballot(x1 == 0xFFFFFFFFu) & valid1;
           }
           if (!(mem0 | mem1)) continue;
-          // "leader score + weights of the other lists >= threshold" as one float compare per doc
-          // (scores are >= 0: the float order is the order of the sortable bits); the slack that the
-          // reciprocal-based tf/(tf+norm) and the summation order need is folded into the bound
-          // once per (block, lead): tfn >= (thr - rest) / w, widened by 1e-5 on every factor
-          float need = -1.0f;
-          if (thr) {
-            const float thr_f = __uint_as_float(thr ^ ((thr >> 31) ? 0x80000000u : 0xFFFFFFFFu));
-            const float num = thr_f * 0.99999f - rest * 1.00001f;
-            if (num > 0.0f) need = num * __builtin_amdgcn_rcpf(w) * 0.99999f;
-          }
           const uint64_t a0m = __ballot(tfn0 >= need) & mem0;
           const uint64_t a1m = __ballot(tfn1 >= need) & mem1;
           if (!(a0m | a1m)) continue;
+          if (p.debug & 1024u) continue;  // ABLATION: no queue, no stage C
           // the two docs of a lane are queued one after the other: the queue holds < 64 leftovers
           // plus <= 64 new entries and is drained below 64 before the next push
 #pragma unroll 1
@@ -420,6 +414,30 @@ ashare_kernel(TqkAShareParams p) {
     const uint32_t cw = (uint32_t)lane < AS_GROUP ? L.cnt[lane] : 0u;
     const uint32_t cn = cw & 0xFFFFu, sc = cw >> 16;
     if (sc) atomicAdd(sload(&p.sinks->query_matches) + sload(&p.sinks->out_index)[L.lead[lane].query], sc);
+    {  // queries that got new scores: the k-th largest of their slots is the new shared threshold
+      uint64_t upd = __ballot(sc != 0u);
+      while (upd) {
+        const uint32_t gs = (uint32_t)__builtin_ctzll(upd);
+        upd &= upd - 1ull;
+        if (p.debug & 16384u) ++n_scored;  // COUNTERS
+        const uint32_t lkv = uni(L.lk[gs]);
+        const uint32_t ks = lkv & 0xFFu, rs = lkv >> 8;
+        const uint32_t qs = uni(L.lead[gs].query);
+        const uint32_t *slots = p.thr_slots + (size_t)rs * TQD_THR_SLOTS;
+        uint32_t sv[4] = {0u, 0u, 0u, 0u};
+        sv[0] = __hip_atomic_load(slots + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        uint32_t gth;
+        if (ks > 16u) {
+#pragma unroll
+          for (int r = 1; r < 4; ++r)
+            sv[r] = __hip_atomic_load(slots + 64 * r + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          gth = kth_largest_hi16<4>(sv, ks);
+        } else {
+          gth = kth_largest_hi16<1>(sv, ks);
+        }
+        if (gth && lane == 0) atomicMax(p.thr_val + qs, gth);
+      }
+    }
     uint64_t have = __ballot(cn != 0u);
     while (have) {
       const uint32_t gs = (uint32_t)__builtin_ctzll(have);
@@ -427,12 +445,8 @@ ashare_kernel(TqkAShareParams p) {
       uint32_t ns = (uint32_t)__builtin_amdgcn_readlane((int)cn, (int)gs);
       const uint32_t ks = uni(L.lk[gs]) & 0xFFu;
       const uint32_t qs = uni(L.lead[gs].query);
-      if (ns > ks) {
-        (void)compact_slot(gs, ns, ks);
-        ns = ks;
-      }
       const uint32_t thr_now = __hip_atomic_load(p.thr_val + qs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      const uint64_t *sl = my_stage + (size_t)gs * CAPL;
+      uint64_t *sl = my_stage + (size_t)gs * CAPL;
       uint64_t v[R];
       uint32_t keep_n = 0;
 #pragma unroll
@@ -441,6 +455,16 @@ ashare_kernel(TqkAShareParams p) {
         v[r] = i < ns ? sl[i] : 0ull;
         if ((uint32_t)(v[r] >> 32) < thr_now) v[r] = 0ull;  // k docs of the query score higher by now
         keep_n += (uint32_t)__popcll(__ballot(v[r] != 0ull));
+      }
+      // (the threshold just selected from the slots drops most entries: the exact select over the
+      // list — 64 dependent steps — is only paid by the lists that still hold more than k)
+      if (keep_n > ks) {
+        if (p.debug & 8192u) ++n_scored;  // COUNTERS
+        const uint64_t kth = as_kth_largest_key<R>(v, ks);
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+          if (v[r] < kth) v[r] = 0ull;
+        keep_n = ks;
       }
       if (!keep_n) continue;
       uint32_t at = 0;
@@ -465,7 +489,7 @@ ashare_kernel(TqkAShareParams p) {
 uint32_t tqk_ashare_waves_per_cu() { return 4u * TQ_AS_WAVES; }
 
 hipError_t tqk_launch_ashare(const TqkAShareParams &p, int kpl, hipStream_t st) {
-  if (p.n_tasks == 0 || p.grid == 0) return hipSuccess;
+  if (p.n_tasks <= p.task_begin || p.grid == 0) return hipSuccess;
   const dim3 grid(p.grid), block(64);
   switch (kpl) {
     case 1: ashare_kernel<1><<<grid, block, 0, st>>>(p); break;

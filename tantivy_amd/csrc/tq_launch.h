@@ -80,7 +80,7 @@ struct TqkAShareParams {
   uint64_t *stage;              // [grid][TQD_AS_GROUP][capl] per-wave staging lists
   uint64_t *lists;              // per-query result lists (query q: entries part_start .. + n_parts)
   uint32_t *list_count;         // [n_queries] entries written so far
-  uint32_t n_tasks;
+  uint32_t task_begin, n_tasks; // this launch hands out tasks [task_begin, n_tasks)
   uint32_t n_queries;
   uint32_t grid;
   uint32_t debug;

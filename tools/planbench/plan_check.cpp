@@ -297,7 +297,9 @@ static int check_ashare(int seed) {
       ++pairs[ld.query];
     }
     const uint32_t n_blocks = seg.terms[t.x].n_blocks;
-    const uint32_t slice = (uint32_t)(((uint64_t)t.y << 12) / n_blocks);
+    // the warm-up launch (tasks [0, a_warm_tasks): the first blocks of every leader), then doc-slice order
+    const bool warm = ti < ps.a_warm_tasks;
+    const uint32_t slice = warm ? 0u : 1u + (uint32_t)(((uint64_t)t.y << 12) / n_blocks);
     if (slice < last_slice) return fail_msg("tasks not in doc-slice order", (long)ti);
     last_slice = slice;
     // (tasks of one group appear in block order: the sort by slice is stable and slices follow blocks)

@@ -22,7 +22,7 @@ from collections import defaultdict
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
-SCAN = re.compile(r"(and_kernel|union_kernel_small|union_kernel|ushare_kernel|xunion_kernel|or_kernel|phrase_sweep_kernel|phrase_kernel)<([^>]*)>")
+SCAN = re.compile(r"(and_kernel|union_kernel_small|union_kernel|ushare_kernel|ashare_kernel|xunion_kernel|or_kernel|phrase_sweep_kernel|phrase_kernel)<([^>]*)>")
 
 
 def classify(name):
@@ -33,8 +33,8 @@ def classify(name):
     fam, args = m.group(1), [a.strip() for a in m.group(2).split(",")]
     if fam in ("phrase_kernel", "phrase_sweep_kernel"):
         return fam, "both"  # the reference prunes nothing before positions are read
-    if fam == "ushare_kernel":
-        return fam, "pruned"  # the shared-union launch only exists in the pruned mode
+    if fam in ("ushare_kernel", "ashare_kernel"):
+        return fam, "pruned"  # the term-major launches only exist in the pruned mode
     if fam == "xunion_kernel":
         return fam, "exhaustive"  # the doc-major union launch only exists without pruning
     return fam, ("pruned" if args[1] == "true" else "exhaustive")
