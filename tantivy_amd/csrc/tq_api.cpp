@@ -1256,6 +1256,12 @@ struct alignas(128) PlanSlab {  // chunk tables of one slab of queries (build_gr
   size_t q0 = 0, q1 = 0;
   std::vector<uint32_t> starts, slice, query;
 };
+struct ALeadKey {  // sort key of one lead of the shared-intersection group
+  uint64_t k1;    // leader handle << 8 | cache
+  uint64_t mask;  // doc-matrix bits of the other lists
+  uint64_t sig;   // hash of the whole query (lists, weights, k): identical queries become neighbours
+  uint32_t q, pad;
+};
 struct ShareKey {  // one (query, list) pair of the shared-union group
   uint64_t key;    // list position i << 56 | blocks of the term (rare terms first) << 32 | cache
   uint32_t term, q;
@@ -1289,11 +1295,19 @@ struct PlanScratch {
   std::vector<uint4> tasks;
   std::vector<uint32_t> share_pairs;  // per query: (task, lead) pairs = result-list appends at most
   // shared-intersection group (tq_ashare.hip): one lead per query, sorted by (leader, cache, mask)
-  std::vector<TqdALead> aleads;
+  std::vector<TqdALead> aleads, aleads_unsorted;
+  std::vector<ALeadKey> alead_keys, alead_keys2;
+  std::vector<uint32_t> alead_bucket, alead_bucket_at, alead_bucket_starts;
+  std::vector<uint8_t> alead_same;
   std::vector<uint4> atasks, atasks_unsorted;
-  std::vector<uint32_t> atask_pos, alead_order, apairs;
+  std::vector<uint32_t> atask_pos, apairs, atask_hist, atask_slab_run;
+  struct ARun {  // the leads of one (leader, cache)
+    uint32_t r0, r1, term, cache, n_blocks, n_groups, per_group, bpt, nb_warm, n_runs;
+    size_t task0;
+  };
+  std::vector<ARun> aruns;
   uint32_t a_warm_tasks = 0;  // tasks [0, a_warm_tasks) are the warm-up launch
-  std::vector<uint64_t> alead_key;
+  std::vector<uint32_t> q_leader;        // per query of the batch: the list that would lead it there, or 0xFFFFFFFF
   std::vector<uint32_t> and_lead_count;  // per term handle: AND queries of the batch it could lead in that launch
   std::vector<uint32_t> term_stamp;      // per term handle: last batch that used the list (unique bytes)
   uint32_t batch_stamp = 0;
@@ -1439,6 +1453,21 @@ static uint32_t plan_threads() {
 static const uint32_t kPlanParMin = tune_u32("TQ_PLAN_PAR_MIN", 16384);
 static const uint32_t kOrChunkMul = std::max<uint32_t>(1u, tune_u32("TQ_OR_CHUNK_MUL", 4));
 static const uint32_t kOrChunkMulSmallK = std::max<uint32_t>(1u, tune_u32("TQ_OR_CHUNK_MUL_SMALLK", 8));
+
+// stable sort of a handful of items (<= TQ_MAX_TERMS): std::stable_sort allocates a buffer per call,
+// which was a quarter of the per-query planning time of a 10 000-query batch
+template <typename T, typename Less>
+inline void small_stable_sort(T *first, T *last, Less less) {
+  for (T *i = first + (first != last); i < last; ++i) {
+    T v = *i;
+    T *j = i;
+    while (j > first && less(v, j[-1])) {
+      *j = j[-1];
+      --j;
+    }
+    *j = v;
+  }
+}
 
 int kpl_for(uint32_t k) { return k <= 64 ? 1 : (k <= 128 ? 2 : (k <= 256 ? 4 : 16)); }
 
@@ -1979,6 +2008,14 @@ int build_ashare_plan(tq_segment *s, Group &g, PlanScratch &ps) {
   static const uint32_t kTaskBlocksMax = std::min<uint32_t>(0xFFFFu, std::max<uint32_t>(1u, tune_u32("TQ_AS_TASK_BLOCKS", 64)));
   static const uint32_t kGroupMax = std::min<uint32_t>(TQD_AS_GROUP, std::max<uint32_t>(1u, tune_u32("TQ_AS_GROUP", TQD_AS_GROUP)));
   static const uint64_t kListBudget = (uint64_t)std::max<uint32_t>(1u, tune_u32("TQ_AS_LIST_MB", 1024)) << 20;
+  static const bool ptrace = getenv("TQ_PLAN_TRACE") != nullptr;  // phase times of the planner
+  auto pt_last = std::chrono::steady_clock::now();
+  auto pt = [&](const char *what) {
+    if (!ptrace) return;
+    const auto now = std::chrono::steady_clock::now();
+    fprintf(stderr, "[tq ashare plan] %-12s %7.2f ms\n", what, std::chrono::duration<double, std::milli>(now - pt_last).count());
+    pt_last = now;
+  };
   const size_t nq = g.queries.size();
   g.kpl = g.max_k <= 64 ? 1 : 2;
   auto column_of = [&](uint32_t handle) -> uint32_t {  // doc-matrix bit of the list, or 0
@@ -1989,92 +2026,149 @@ int build_ashare_plan(tq_segment *s, Group &g, PlanScratch &ps) {
   auto off_of = [&](const void *ptr) -> uint32_t {
     return ptr ? (uint32_t)(((uint64_t)ptr - ps.share_table_base) >> 3) : 0u;
   };
-  // ---- leads, in query order
-  std::vector<TqdALead> &leads = ps.aleads;
-  std::vector<uint64_t> &key = ps.alead_key;  // leader << 8 | cache, per query
+  // ---- leads, in query order (filled by the planner's threads, a slab of queries each), with their
+  // sort keys: (leader, cache) | mask | a hash of the whole query (lists, weights, k)
+  std::vector<TqdALead> &leads = ps.aleads, &unsorted = ps.aleads_unsorted;
+  std::vector<ALeadKey> &keys = ps.alead_keys;
   leads.resize(nq);
-  key.resize(nq);
-  std::vector<TqdALead> unsorted(nq);
-  for (size_t q = 0; q < nq; ++q) {
-    const TqdQuery &dq = g.queries[q];
-    TqdALead ld{};
-    ld.query = (uint32_t)q;
-    ld.w = dq.weight[0];
-    float rest = 0.0f;
-    uint64_t mask = 0;
-    for (uint32_t m = 1; m < dq.n_terms; ++m) {
-      rest += dq.weight[m];
-      const uint32_t col = column_of(dq.term[m]);
-      const uint32_t sig1 = !col ? (s->h_dterms[dq.term[m]].has_freq >> 16) & 0xFFu : 0u;
-      const uint32_t bitpos = col ? col : (sig1 ? TQD_SIG_SHIFT + (sig1 - 1u) : 0u);
-      if (bitpos) mask |= 1ull << bitpos;
+  unsorted.resize(nq);
+  keys.resize(nq);
+  const uint32_t fill_slabs = nq >= 4096 ? plan_threads() : 1u;
+  parallel_slabs(fill_slabs, [&](uint32_t sb) {
+    const size_t q0 = nq * sb / fill_slabs, q1 = nq * (sb + 1) / fill_slabs;
+    for (size_t q = q0; q < q1; ++q) {
+      const TqdQuery &dq = g.queries[q];
+      TqdALead ld{};
+      ld.query = (uint32_t)q;
+      ld.w = dq.weight[0];
+      float rest = 0.0f;
+      uint64_t mask = 0, sig = 0x9E3779B97F4A7C15ull * (uint64_t)(dq.n_terms | (dq.k << 8));
+      for (uint32_t m = 0; m < dq.n_terms; ++m) {
+        uint32_t wb;
+        memcpy(&wb, &dq.weight[m], sizeof wb);
+        sig = (sig ^ (((uint64_t)dq.term[m] << 32) | wb)) * 0xFF51AFD7ED558CCDull;
+        sig ^= sig >> 29;
+        if (!m) continue;
+        rest += dq.weight[m];
+        const uint32_t col = column_of(dq.term[m]);
+        const uint32_t sig1 = !col ? (s->h_dterms[dq.term[m]].has_freq >> 16) & 0xFFu : 0u;
+        const uint32_t bitpos = col ? col : (sig1 ? TQD_SIG_SHIFT + (sig1 - 1u) : 0u);
+        if (bitpos) mask |= 1ull << bitpos;
+      }
+      ld.rest = rest;
+      ld.mask_lo = (uint32_t)mask;
+      ld.mask_hi = (uint32_t)(mask >> 32);
+      ld.info = dq.n_terms | (column_of(dq.term[1]) ? 0x100u : 0u);
+      ld.dense_off = off_of(s->terms[dq.term[1]].dense_blob);
+      ld.tf8_off = off_of(s->terms[dq.term[1]].tf8_blob);
+      ld.k = dq.k;
+      ld.thr_row = dq.thr_index;
+      unsorted[q] = ld;
+      keys[q] = ALeadKey{((uint64_t)dq.term[0] << 8) | (uint64_t)(dq.cache_idx & 0xFFu), mask, sig, (uint32_t)q, 0u};
     }
-    ld.rest = rest;
-    ld.mask_lo = (uint32_t)mask;
-    ld.mask_hi = (uint32_t)(mask >> 32);
-    ld.info = dq.n_terms | (column_of(dq.term[1]) ? 0x100u : 0u);
-    ld.dense_off = off_of(s->terms[dq.term[1]].dense_blob);
-    ld.tf8_off = off_of(s->terms[dq.term[1]].tf8_blob);
-    unsorted[q] = ld;
-    key[q] = ((uint64_t)dq.term[0] << 8) | (uint64_t)(dq.cache_idx & 0xFFu);
-  }
-  // ---- order: (leader, cache), then mask; stable in the query index
-  std::vector<uint32_t> &order = ps.alead_order;
-  order.resize(nq);
-  for (size_t q = 0; q < nq; ++q) order[q] = (uint32_t)q;
-  std::sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) {
-    if (key[a] != key[b]) return key[a] < key[b];
-    const uint64_t ma = ((uint64_t)unsorted[a].mask_hi << 32) | unsorted[a].mask_lo;
-    const uint64_t mb = ((uint64_t)unsorted[b].mask_hi << 32) | unsorted[b].mask_lo;
-    if (ma != mb) return ma < mb;
-    return a < b;
   });
-  for (size_t i = 0; i < nq; ++i) leads[i] = unsorted[order[i]];
+  pt("leads");
+  // ---- order: (leader, cache), then mask, then the query hash (identical queries become neighbours:
+  // twins), stable in the query index.  Buckets by leader first (a counting sort: a few hundred
+  // leaders), then every bucket by the rest of the key — the planner's threads take a share of the
+  // buckets each (a comparison sort of the whole table was half of this function's time)
+  {
+    std::vector<uint32_t> &cnt = ps.alead_bucket;
+    const size_t nt = s->terms.size();
+    cnt.assign(nt + 1, 0u);
+    for (size_t q = 0; q < nq; ++q) ++cnt[(size_t)(keys[q].k1 >> 8) + 1];
+    for (size_t t = 0; t < nt; ++t) cnt[t + 1] += cnt[t];
+    std::vector<ALeadKey> &tmp = ps.alead_keys2;
+    tmp.resize(nq);
+    std::vector<uint32_t> &at = ps.alead_bucket_at;
+    at.assign(cnt.begin(), cnt.end() - 1);
+    for (size_t q = 0; q < nq; ++q) tmp[at[(size_t)(keys[q].k1 >> 8)]++] = keys[q];
+    keys.swap(tmp);
+    // non-empty buckets, cut into slabs of about equal size
+    std::vector<uint32_t> &starts = ps.alead_bucket_starts;
+    starts.clear();
+    for (size_t t = 0; t < nt; ++t)
+      if (cnt[t + 1] > cnt[t]) starts.push_back(cnt[t]);
+    starts.push_back((uint32_t)nq);
+    const uint32_t n_b = (uint32_t)starts.size() - 1u;
+    const uint32_t sort_slabs = nq >= 4096 ? std::min<uint32_t>(plan_threads(), std::max<uint32_t>(1u, n_b)) : 1u;
+    parallel_slabs(sort_slabs, [&](uint32_t sb) {
+      for (uint32_t b = sb; b < n_b; b += sort_slabs)  // (interleaved: the big buckets are the first leaders)
+        std::sort(keys.begin() + starts[b], keys.begin() + starts[b + 1], [](const ALeadKey &a, const ALeadKey &b2) {
+          if (a.k1 != b2.k1) return a.k1 < b2.k1;
+          if (a.mask != b2.mask) return a.mask < b2.mask;
+          if (a.sig != b2.sig) return a.sig < b2.sig;
+          return a.q < b2.q;
+        });
+    });
+  }
+  pt("sort");
+  auto same_query = [&](const ALeadKey &a, const ALeadKey &b) -> bool {  // (the hash only proposes)
+    if (a.k1 != b.k1 || a.mask != b.mask || a.sig != b.sig) return false;
+    const TqdALead &la = unsorted[a.q], &lb = unsorted[b.q];
+    if ((la.info & 31u) != (lb.info & 31u) || la.k != lb.k || memcmp(&la.w, &lb.w, 4) || memcmp(&la.rest, &lb.rest, 4) ||
+        la.dense_off != lb.dense_off)
+      return false;
+    if ((la.info & 31u) == 2u) return true;  // (leader, list 1 — every list has its own bitmap —, both weights, k)
+    const TqdQuery &qa = g.queries[a.q], &qb = g.queries[b.q];
+    return !memcmp(qa.term, qb.term, qa.n_terms * sizeof(uint32_t)) &&
+           !memcmp(qa.weight, qb.weight, qa.n_terms * sizeof(float));
+  };
+  // identical queries share one row of threshold slots, whatever groups they end up in (a slot is
+  // hash(doc): the same doc lands in the same slot whichever group scored it)
+  std::vector<uint8_t> &same_as_prev = ps.alead_same;
+  same_as_prev.resize(nq);
+  const uint32_t gather_slabs = nq >= 4096 ? plan_threads() : 1u;
+  parallel_slabs(gather_slabs, [&](uint32_t sb) {
+    const size_t i0 = nq * sb / gather_slabs, i1 = nq * (sb + 1) / gather_slabs;
+    for (size_t i = i0; i < i1; ++i) {
+      leads[i] = unsorted[keys[i].q];
+      same_as_prev[i] = i && same_query(keys[i], keys[i - 1]) ? 1 : 0;
+    }
+  });
+  for (size_t i = 1; i < nq; ++i)
+    if (same_as_prev[i]) leads[i].thr_row = leads[i - 1].thr_row;
+  pt("gather");
   // ---- tasks: groups of leads x runs of blocks; fewer, longer tasks if the result lists (k entries
   // per (task, lead) pair) would not fit the budget.  The first kWarmPermille / 1000 of every leader go
   // out as short tasks in a launch of their own: every resident wavefront starts a launch with the
   // thresholds it finds, and with thresholds of zero the first wavefronts (an eighth of the batch)
-  // sent every match through the scoring stage — a warm-up over 2 % of the blocks leaves the main launch
-  // the k-th best of a 2 % sample of every query to start from.
-  static const uint32_t kWarmPermille = std::min<uint32_t>(1000u, tune_u32("TQ_AS_WARM_PERMILLE", 20));
+  // sent every match through the scoring stage — a warm-up over a fraction of a percent of the blocks
+  // leaves the main launch the k-th best of a sample of every query to start from.
+  static const uint32_t kWarmPermille = std::min<uint32_t>(1000u, tune_u32("TQ_AS_WARM_PERMILLE", 5));
   static const uint32_t kWarmBlocks = std::max<uint32_t>(1u, tune_u32("TQ_AS_WARM_BLOCKS", 2));
   std::vector<uint4> &tasks = ps.atasks, &raw = ps.atasks_unsorted;
   std::vector<uint32_t> &pos = ps.atask_pos, &pairs = ps.apairs;
+  pairs.resize(nq);
+  // the runs of one (leader, cache): their groups, task sizes and where their tasks start
+  std::vector<PlanScratch::ARun> &runs = ps.aruns;
   uint32_t task_pairs = kTaskPairsEnv;
+  size_t n_tasks = 0;
   for (;;) {
-    raw.clear();
-    pos.clear();
-    pairs.assign(nq, 0u);
+    runs.clear();
+    n_tasks = 0;
     uint64_t entries = 0;
     for (size_t r0 = 0; r0 < nq;) {
       size_t r1 = r0;
-      while (r1 < nq && key[order[r1]] == key[order[r0]]) ++r1;
-      const uint32_t term = (uint32_t)(key[order[r0]] >> 8), cache = (uint32_t)key[order[r0]] & 0xFFu;
-      const uint32_t n_blocks = s->terms[term].n_blocks;
+      uint64_t k_sum = 0;
+      while (r1 < nq && keys[r1].k1 == keys[r0].k1) k_sum += leads[r1++].k;
+      PlanScratch::ARun R;
+      R.r0 = (uint32_t)r0;
+      R.r1 = (uint32_t)r1;
+      R.term = (uint32_t)(keys[r0].k1 >> 8);
+      R.cache = (uint32_t)keys[r0].k1 & 0xFFu;
+      R.n_blocks = s->terms[R.term].n_blocks;
       const uint32_t n_run = (uint32_t)(r1 - r0);
       const uint32_t n_groups = (n_run + kGroupMax - 1) / kGroupMax;
-      const uint32_t per_group = (n_run + n_groups - 1) / n_groups;
-      const uint32_t bpt = std::min<uint32_t>(kTaskBlocksMax, std::max<uint32_t>(1u, task_pairs / per_group));
-      const uint32_t nb_warm = (uint32_t)((uint64_t)n_blocks * kWarmPermille / 1000u);
-      uint32_t n_runs = 0;
-      for (uint32_t j0 = 0; j0 < n_blocks;) {
-        const bool warm = j0 < nb_warm;
-        const uint32_t nb = warm ? std::min<uint32_t>(kWarmBlocks, nb_warm - j0) : std::min<uint32_t>(bpt, n_blocks - j0);
-        // (slice 4096: the main launch's tasks sort behind every warm-up task)
-        const uint32_t slice = warm ? 0u : 1u + (uint32_t)(((uint64_t)j0 << 12) / n_blocks);
-        for (uint32_t gr = 0; gr < n_groups; ++gr) {
-          const uint32_t l0 = gr * per_group, l1 = std::min<uint32_t>(n_run, l0 + per_group);
-          if (l0 >= l1) continue;
-          raw.push_back(make_uint4(term, j0, nb | ((l1 - l0) << 16) | (cache << 24), (uint32_t)r0 + l0));
-          pos.push_back(slice);
-        }
-        j0 += nb;
-        ++n_runs;
-      }
-      for (size_t a = r0; a < r1; ++a) {
-        pairs[order[a]] = n_runs;
-        entries += (uint64_t)n_runs * g.queries[order[a]].k;
-      }
+      R.per_group = (n_run + n_groups - 1) / n_groups;
+      R.n_groups = (n_run + R.per_group - 1) / R.per_group;  // (the non-empty ones)
+      R.bpt = std::min<uint32_t>(kTaskBlocksMax, std::max<uint32_t>(1u, task_pairs / R.per_group));
+      R.nb_warm = (uint32_t)((uint64_t)R.n_blocks * kWarmPermille / 1000u);
+      R.n_runs = (R.nb_warm + kWarmBlocks - 1) / kWarmBlocks + (R.n_blocks - R.nb_warm + R.bpt - 1) / R.bpt;
+      R.task0 = n_tasks;
+      n_tasks += (size_t)R.n_runs * R.n_groups;
+      entries += (uint64_t)R.n_runs * k_sum;
+      runs.push_back(R);
       r0 = r1;
     }
     if ((entries * sizeof(uint64_t) <= kListBudget && entries <= 0xFFFFFFFFull) || task_pairs >= (1u << 22)) {
@@ -2083,19 +2177,75 @@ int build_ashare_plan(tq_segment *s, Group &g, PlanScratch &ps) {
     }
     task_pairs *= 2u;
   }
-  if (raw.size() > 0x7FFFFFFFull) return fail(TQ_ERR_UNSUPPORTED, "batch too large (tasks)");
-  {  // launch order: the warm-up tasks (slice 0), then stable counting sort by doc slice
-    uint32_t hist[4099] = {0};
-    for (uint32_t p : pos) ++hist[p + 1u];
-    for (uint32_t i = 0; i < 4098; ++i) hist[i + 1] += hist[i];
-    ps.a_warm_tasks = hist[1];
-    tasks.resize(raw.size());
-    for (size_t i = 0; i < raw.size(); ++i) tasks[hist[pos[i]]++] = raw[i];
+  if (n_tasks > 0x7FFFFFFFull) return fail(TQ_ERR_UNSUPPORTED, "batch too large (tasks)");
+  raw.resize(n_tasks);
+  pos.resize(n_tasks);
+  tasks.resize(n_tasks);
+  // slabs of runs of about equal task counts: each fills its tasks and counts them by doc slice; the
+  // (slice, slab) prefix sums give every slab its places in the launch order (a stable counting sort:
+  // slice 0 = the warm-up launch, then the main launch's tasks by doc slice)
+  constexpr uint32_t kSl = 4098;
+  const uint32_t t_slabs = n_tasks >= 16384 ? std::min<uint32_t>(plan_threads(), (uint32_t)runs.size()) : 1u;
+  std::vector<uint32_t> &hist = ps.atask_hist;
+  hist.assign((size_t)t_slabs * kSl, 0u);
+  std::vector<uint32_t> &slab_run = ps.atask_slab_run;
+  slab_run.assign(t_slabs + 1, (uint32_t)runs.size());
+  {
+    uint32_t sb = 0;
+    slab_run[0] = 0;
+    for (uint32_t r = 0; r < runs.size() && sb + 1 < t_slabs; ++r)
+      if (runs[r].task0 >= n_tasks * (sb + 1) / t_slabs) slab_run[++sb] = r;
+    for (uint32_t x = sb + 1; x < t_slabs; ++x) slab_run[x] = (uint32_t)runs.size();
   }
+  parallel_slabs(t_slabs, [&](uint32_t sb) {
+    uint32_t *h = hist.data() + (size_t)sb * kSl;
+    for (uint32_t r = slab_run[sb]; r < slab_run[sb + 1]; ++r) {
+      const PlanScratch::ARun &R = runs[r];
+      for (uint32_t a = R.r0; a < R.r1; ++a) {  // twins: the same query as the lead before, inside one group
+        const bool twin = (a - R.r0) % R.per_group != 0 && same_as_prev[a];
+        leads[a].info = (leads[a].info & ~0x200u) | (twin ? 0x200u : 0u);
+        pairs[keys[a].q] = R.n_runs;
+      }
+      const uint32_t n_run = R.r1 - R.r0;
+      const uint64_t slice_mul = ((uint64_t)1 << 44) / R.n_blocks;  // (j0 << 12) / n_blocks without the division
+      size_t at = R.task0;
+      for (uint32_t j0 = 0; j0 < R.n_blocks;) {
+        const bool warm = j0 < R.nb_warm;
+        const uint32_t nb = warm ? std::min<uint32_t>(kWarmBlocks, R.nb_warm - j0) : std::min<uint32_t>(R.bpt, R.n_blocks - j0);
+        const uint32_t slice = warm ? 0u : 1u + std::min<uint32_t>(4095u, (uint32_t)((j0 * slice_mul) >> 32));
+        for (uint32_t gr = 0; gr < R.n_groups; ++gr) {
+          const uint32_t l0 = gr * R.per_group, l1 = std::min<uint32_t>(n_run, l0 + R.per_group);
+          raw[at] = make_uint4(R.term, j0, nb | ((l1 - l0) << 16) | (R.cache << 24), R.r0 + l0);
+          pos[at] = slice;
+          ++at;
+        }
+        h[slice] += R.n_groups;
+        j0 += nb;
+      }
+    }
+  });
+  {
+    uint32_t run = 0;
+    for (uint32_t sl = 0; sl < kSl; ++sl)
+      for (uint32_t sb = 0; sb < t_slabs; ++sb) {
+        const uint32_t n = hist[(size_t)sb * kSl + sl];
+        hist[(size_t)sb * kSl + sl] = run;  // becomes the slab's write position in this slice
+        run += n;
+        if (sl == 0 && sb + 1 == t_slabs) ps.a_warm_tasks = run;
+      }
+  }
+  parallel_slabs(t_slabs, [&](uint32_t sb) {
+    uint32_t *h = hist.data() + (size_t)sb * kSl;
+    const size_t t0 = slab_run[sb] < runs.size() ? runs[slab_run[sb]].task0 : n_tasks;
+    const size_t t1 = slab_run[sb + 1] < runs.size() ? runs[slab_run[sb + 1]].task0 : n_tasks;
+    for (size_t i = t0; i < t1; ++i) tasks[h[pos[i]]++] = raw[i];
+  });
+  pt("tasks");
   uint64_t entries = 0;
   for (size_t q = 0; q < nq; ++q) {
     TqdQuery &dq = g.queries[q];
     const uint64_t cap = (uint64_t)pairs[q] * dq.k;
+    if (entries + cap > 0xFFFFFFFFull) return fail(TQ_ERR_UNSUPPORTED, "batch too large (result lists)");
     dq.part_start = (uint32_t)entries;
     dq.n_parts = (uint32_t)cap;
     dq.chunk_first = 0;
@@ -2243,7 +2393,7 @@ int plan_bool_query(tq_segment *s, const tq_query &q, uint32_t qi, TqdQuery &dq,
       ++n;
     };
     auto put_by_weight = [&](uint32_t *idx, uint32_t cnt, uint32_t role) {
-      std::stable_sort(idx, idx + cnt,
+      small_stable_sort(idx, idx + cnt,
                        [&](uint32_t a, uint32_t b) { return q.weights[a] > q.weights[b]; });
       for (uint32_t i = 0; i < cnt; ++i) put(idx[i], role);
     };
@@ -2252,7 +2402,7 @@ int plan_bool_query(tq_segment *s, const tq_query &q, uint32_t qi, TqdQuery &dq,
       // Must clauses by cost ascending (intersect_scorers, intersection.rs:31): the cheapest
       // leads; then the MustNot terms (they only exclude: densest first), then the Should
       // terms in clause order
-      std::stable_sort(must, must + n_must,
+      small_stable_sort(must, must + n_must,
                        [&](uint32_t a, uint32_t b) { return cl[a].cost < cl[b].cost; });
       // optional Should lists lead too (MaxScore for RequiredOptionalScorer, see union_body)
       // (only when pruning: with every match scored the extra ownership probes cost 60 %)
@@ -2274,7 +2424,7 @@ int plan_bool_query(tq_segment *s, const tq_query &q, uint32_t qi, TqdQuery &dq,
       }
       for (uint32_t c = 0; c < n_not; ++c)
         for (uint32_t i = 0; i < cl[mustnot[c]].n; ++i) flat[n_flat++] = cl[mustnot[c]].terms[i];
-      std::stable_sort(flat, flat + n_flat, [&](uint32_t a, uint32_t b) {
+      small_stable_sort(flat, flat + n_flat, [&](uint32_t a, uint32_t b) {
         return s->terms[q.terms[a]].doc_freq > s->terms[q.terms[b]].doc_freq;
       });
       for (uint32_t i = 0; i < n_flat; ++i) put(flat[i], TQD_ROLE_MUST_NOT);
@@ -2448,6 +2598,7 @@ int search_batch_impl(tq_segment *s, const tq_query *queries, uint32_t n_queries
       ps.batch_stamp = 1u;
     }
     ps.and_lead_count.assign(ashare_on ? s->terms.size() : 0, 0u);
+    ps.q_leader.resize(ashare_on ? n_queries : 0);
     for (uint32_t qi = 0; qi < n_queries; ++qi) {
       const tq_query &q = queries[qi];
       if (!q.terms || q.n_terms > TQ_MAX_TERMS) continue;  // (reported by plan_query)
@@ -2465,6 +2616,7 @@ int search_batch_impl(tq_segment *s, const tq_query *queries, uint32_t n_queries
       }
       if (ashare_on) {
         const uint32_t lh = ashare_leader(q, ps.q_cache[qi]);
+        ps.q_leader[qi] = lh;
         if (lh != 0xFFFFFFFFu) ++ps.and_lead_count[lh];
       }
     }
@@ -2519,7 +2671,7 @@ int search_batch_impl(tq_segment *s, const tq_query *queries, uint32_t n_queries
         // stable sort by doc_freq asc (block_wand_intersection.rs:26-29 / intersection.rs:93)
         uint32_t order[TQ_MAX_TERMS];
         for (uint32_t i = 0; i < q.n_terms; ++i) order[i] = i;
-        std::stable_sort(order, order + q.n_terms, [&](uint32_t a, uint32_t b) {
+        small_stable_sort(order, order + q.n_terms, [&](uint32_t a, uint32_t b) {
           return s->terms[q.terms[a]].doc_freq < s->terms[q.terms[b]].doc_freq;
         });
         uint32_t max_off = 0;
@@ -2558,7 +2710,7 @@ int search_batch_impl(tq_segment *s, const tq_query *queries, uint32_t n_queries
           bool nonneg = true;
           for (uint32_t i = 0; i < q.n_terms; ++i) nonneg = nonneg && dq.weight[i] >= 0.0f;
           if (ashare_on && nonneg && all_dense) {
-            const uint32_t lh = ashare_leader(q, cache_idx);
+            const uint32_t lh = ps_plan.q_leader[qi];
             ashare = lh != 0xFFFFFFFFu && lh == dq.term[0] && ps_plan.and_lead_count[lh] >= kAShareMin;
           }
           if (ashare) {  // (planned per leader, not per query: build_ashare_plan)
@@ -2624,7 +2776,7 @@ int search_batch_impl(tq_segment *s, const tq_query *queries, uint32_t n_queries
       {
         uint32_t order[TQ_MAX_TERMS];
         for (uint32_t i = 0; i < dq.n_terms; ++i) order[i] = i;
-        std::stable_sort(order, order + dq.n_terms,
+        small_stable_sort(order, order + dq.n_terms,
                          [&](uint32_t a, uint32_t b) { return dq.weight[a] > dq.weight[b]; });
         uint32_t t2[TQ_MAX_TERMS];
         float w2[TQ_MAX_TERMS];
@@ -2723,6 +2875,7 @@ int search_batch_impl(tq_segment *s, const tq_query *queries, uint32_t n_queries
     g.max_k = std::max(g.max_k, q.k);
     return TQ_OK;
   };
+  const auto tr0a = std::chrono::steady_clock::now();  // (after validation of the context, the cache table and the pre-pass)
   static const uint32_t kQuerySlabMin = tune_u32("TQ_PLAN_QUERY_PAR_MIN", 4096);
   const uint32_t q_slabs = (!opt_exhaustive && n_queries >= kQuerySlabMin) ? std::min<uint32_t>(plan_threads(), 8u) : 1u;
   if (q_slabs <= 1) {
@@ -3236,8 +3389,8 @@ int search_batch_impl(tq_segment *s, const tq_query *queries, uint32_t n_queries
   if (trace) {
     const auto tr3 = std::chrono::steady_clock::now();
     auto us = [](auto a, auto b) { return (long)std::chrono::duration_cast<std::chrono::microseconds>(b - a).count(); };
-    fprintf(stderr, "[tq] plan %ld us (queries %ld us, chunks %ld us), stage fill %ld us, enqueue %ld us, stage bytes %zu\n",
-            us(tr0, tr1), us(tr0, tr0b), us(tr0b, tr1), us(tr1, tr2), us(tr2, tr3), stage);
+    fprintf(stderr, "[tq] plan %ld us (pre-pass %ld us, queries %ld us, chunks %ld us), stage fill %ld us, enqueue %ld us, stage bytes %zu\n",
+            us(tr0, tr1), us(tr0, tr0a), us(tr0a, tr0b), us(tr0b, tr1), us(tr1, tr2), us(tr2, tr3), stage);
   }
   s->stats.algorithmic_bytes = algo_bytes;
   s->stats.tiles = tiles_total;

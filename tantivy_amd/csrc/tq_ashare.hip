@@ -25,6 +25,13 @@
 //      membership for signature-"maybe" lists, the posting index) -> the tf byte at that index,
 //      further lists of a 3+ term query the same way, the exact BM25 sum in the reference's order,
 //      then the collector.
+// Twins: a batch repeats queries (the headline batch holds 3 877 distinct ones among its 10 000), and
+// the planner puts identical queries (same lists, weights, k) next to each other in a group.  A head
+// and its twins form a FAMILY that is evaluated once: blocks are tested, docs scored and collected for
+// the head; at the end of the task the head's list (<= k entries) is appended to the result list of
+// EVERY member, and the threshold to every member's word.  Identical queries also share one row of
+// threshold slots across groups (a slot is hash(doc): the same doc lands in the same slot whichever
+// group scored it).  Every query keeps its own result list and its own merge.
 // Scores are and_kernel's bits (same operations in the same order); thresholds only ever hold scores
 // of k distinct real matches, candidates equal to the threshold are kept, so the top-k equals the
 // exhaustive run's, ties by doc id as TopNHeap resolves them (sort_by_score.rs:86-161).
@@ -42,14 +49,14 @@ namespace {
 
 constexpr uint32_t AS_GROUP = TQD_AS_GROUP;
 
-struct AShareLds {  // per wavefront: 4212 bytes (32 wavefronts per CU fit the 160 KB)
+struct AShareLds {  // per wavefront: 3828 bytes (32 wavefronts per CU fit the 160 KB)
   float cache[256];                            // Bm25Weight.cache of the task's queries
   uint32_t q_doc[127], q_tf[127], q_tag[127];  // survivors: doc, leader tf, lead slot | fieldnorm id << 8
-  TqdALead lead[AS_GROUP];                     // the leads of the task
+  TqdALeadLds lead[AS_GROUP];                  // the leads of the task (what the scoring stage needs)
   uint32_t lthr[AS_GROUP];                     // the lead's threshold (sortable score bits); only ever rises
   uint32_t lk[AS_GROUP];                       // k of its query (bits 0..7) | its row of threshold slots << 8
   uint32_t cnt[AS_GROUP];                      // bits 0..15: entries in the slot's staging list; 16..31: docs scored
-  uint32_t pmask[TQD_AS_TILE];                 // per block of the current tile: the leads that still want it
+  uint32_t flen[AS_GROUP];                     // per family head: leads in the family (itself + its twins)
 };
 
 // k-th largest of the n (<= 64 R) keys held R per lane (0 = empty); n >= k
@@ -132,9 +139,9 @@ ashare_kernel(TqkAShareParams p) {
       tf = L.q_tf[base + lane];
       tag = L.q_tag[base + lane];
     }
-    const uint32_t g = tag & 31u;
+    const uint32_t g = tag & 31u;  // the family's head
     const float norm = L.cache[(tag >> 8) & 0xFFu];
-    const TqdALead ld = L.lead[g];
+    const TqdALeadLds ld = L.lead[g];
     const uint32_t thr = L.lthr[g];
     const uint32_t k = L.lk[g] & 0xFFu;
     const uint32_t thr_row = L.lk[g] >> 8;
@@ -200,13 +207,12 @@ ashare_kernel(TqkAShareParams p) {
     if (alive) alive = doc_is_alive(seg, doc);
     const uint64_t hit = __ballot(alive);
     if (!hit) return;
-    if (!(p.debug & 0x7FE0u)) n_scored += (uint32_t)__popcll(hit);  // COUNTERS (TQ_DEBUG): 32 (block, lead) pairs,
-    const uint64_t key = alive ? make_key(s, doc) : 0ull;        // 64 stage-C candidates, 256 blocks decoded
+    if (!(p.debug & 0x7FE0u)) n_scored += (uint32_t)__popcll(hit);  // COUNTERS (TQ_DEBUG): 32 (block, family) pairs,
+    const uint64_t key = alive ? make_key(s, doc) : 0ull;           // 64 stage-C candidates, 256 blocks decoded
     const uint32_t sb = (uint32_t)(key >> 32);
     if (alive) {
       // the query's hashed score slots: fire and forget (the k-th largest slot is selected once per
-      // (task, lead) at the end of the task, not once per change: the selects were a quarter of the
-      // kernel's instructions)
+      // (task, family) at the end of the task, not once per change)
       const uint32_t hsh = (doc * 0x9E3779B1u) >> (k <= 16u ? 26 : 24);
       (void)atomicMax(p.thr_slots + (size_t)thr_row * TQD_THR_SLOTS + hsh, sb);
       const uint32_t pos = atomicAdd(&L.cnt[g], 0x10001u) & 0xFFFFu;  // (a list never overflows: see the cut below)
@@ -256,18 +262,27 @@ ashare_kernel(TqkAShareParams p) {
     // works for another lead, gathers them from the LDS copy
     float my_w = 0.0f, my_rest = 0.0f;
     uint32_t my_mlo = 0, my_mhi = 0;
-    if ((uint32_t)lane < n_leads) {
+    bool twin = false;
+    const bool is_lead = (uint32_t)lane < n_leads;
+    if (is_lead) {
       const TqdALead mine = p.leads[lead0 + lane];
-      L.lead[lane] = mine;
+      L.lead[lane] = TqdALeadLds{mine.query, mine.info, mine.w, mine.rest, mine.dense_off, mine.tf8_off};
       my_w = mine.w;
       my_rest = mine.rest;
       my_mlo = mine.mask_lo;
       my_mhi = mine.mask_hi;
-      const TqdQuery *Q = p.queries + mine.query;
-      L.lk[lane] = Q->k | (Q->thr_index << 8);
+      twin = lane != 0 && (mine.info & 0x200u) != 0u;
+      L.lk[lane] = mine.k | (mine.thr_row << 8);
       L.lthr[lane] = __hip_atomic_load(p.thr_val + mine.query, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     if ((uint32_t)lane < AS_GROUP) L.cnt[lane] = 0u;
+    // families: a head and the twins behind it (the same query: same lists, weights, mask)
+    const bool is_head = is_lead && !twin;
+    const uint32_t heads = (uint32_t)__ballot(is_head);
+    if (is_head) {  // leads in the family
+      const uint32_t above = (uint32_t)lane >= 31u ? 0u : heads & ~((2u << lane) - 1u);
+      L.flen[lane] = (above ? (uint32_t)__builtin_ctz(above) : n_leads) - (uint32_t)lane;
+    }
     wave_mem_fence();
     // a lead whose best possible score is below its threshold is done with the whole list
     auto lead_alive = [&]() __attribute__((always_inline)) {
@@ -280,12 +295,29 @@ ashare_kernel(TqkAShareParams p) {
       }
       wave_mem_fence();
     };
-    uint32_t live = (uint32_t)__ballot(lead_alive());
+    // live families (heads), their thresholds and the bound derived from them: "leader score + weights
+    // of the other lists >= threshold" is one float compare per doc (scores are >= 0: the float order is
+    // the order of the sortable bits): tfn >= (thr - rest) / w, every factor widened by 1e-5 for the
+    // reciprocal-based tf/(tf+norm) and the summation order
+    uint32_t live = 0, live_heads = 0, fam_thr = 0;
+    float fam_need = -1.0f;
+    auto update_families = [&]() __attribute__((always_inline)) {
+      live = (uint32_t)__ballot(is_head && lead_alive());
+      live_heads = live;
+      fam_thr = is_head ? L.lthr[lane] : 0xFFFFFFFFu;
+      fam_need = -1.0f;
+      if (is_head && fam_thr != 0u) {
+        const float thr_f = __uint_as_float(fam_thr ^ ((fam_thr >> 31) ? 0x80000000u : 0xFFFFFFFFu));
+        const float num = thr_f * 0.99999f - my_rest * 1.00001f;
+        if (num > 0.0f) fam_need = num * __builtin_amdgcn_rcpf(my_w) * 0.99999f;
+      }
+    };
+    update_families();
 
     for (uint32_t jt = 0; jt < nb_task && live; jt += TQD_AS_TILE) {
       if (jt) {  // thresholds may have risen since the last step
         refresh_thr();
-        live = (uint32_t)__ballot(lead_alive());
+        update_families();
         if (!live) break;
       }
       // ---- pre-filter: lane <-> block
@@ -304,22 +336,19 @@ ashare_kernel(TqkAShareParams p) {
           tfn_max = f * __builtin_amdgcn_rcpf(f + L.cache[(rec_mine.y >> 16) & 0xFFu]);
         }
       }
-      uint32_t pass_mask = 0;  // leads that still want this block (block_wand_intersection.rs:81-85)
-      {
-        const uint32_t my_thr = (uint32_t)lane < n_leads ? L.lthr[lane] : 0u;
-        for (uint32_t lm = live; lm; lm &= lm - 1u) {
-          const uint32_t g = (uint32_t)__builtin_ctz(lm);
-          const float w = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(my_w), (int)g));
-          const float rest = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(my_rest), (int)g));
-          const uint32_t thr = (uint32_t)__builtin_amdgcn_readlane((int)my_thr, (int)g);
-          const float ub = w * tfn_max * p.bound_slack;
-          if (in_tile && sortable((ub + rest) * 1.000004f + (w + rest) * 4.0e-6f) >= thr) pass_mask |= 1u << g;
-        }
+      uint32_t pass_mask = 0;  // families that still want this block (block_wand_intersection.rs:81-85)
+      for (uint32_t lm = live_heads; lm; lm &= lm - 1u) {
+        const uint32_t g = (uint32_t)__builtin_ctz(lm);
+        const float w = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(my_w), (int)g));
+        const float rest = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(my_rest), (int)g));
+        const uint32_t thr = (uint32_t)__builtin_amdgcn_readlane((int)fam_thr, (int)g);
+        const float ub = w * tfn_max * p.bound_slack;
+        if (in_tile && sortable((ub + rest) * 1.000004f + (w + rest) * 4.0e-6f) >= thr) pass_mask |= 1u << g;
       }
       uint64_t todo = __ballot(pass_mask != 0u);
-      wave_mem_fence();
-      L.pmask[lane] = pass_mask;
-      wave_mem_fence();
+      // the block's record stays with its lane: {meta, payload offset, last doc of the block before}
+      uint32_t prev_mine = __shfl_up(rec_mine.x, 1, WAVE);
+      if (lane == 0) prev_mine = block_prev_last(lead, i_base);
       uint32_t since_refresh = 0;
       while (todo) {
         const uint32_t b = (uint32_t)__builtin_ctzll(todo);
@@ -327,14 +356,14 @@ ashare_kernel(TqkAShareParams p) {
         if (++since_refresh == 8u) {  // thresholds rise while the tile is walked
           since_refresh = 0;
           refresh_thr();
-          live = (uint32_t)__ballot(lead_alive());
+          update_families();
           if (!live) break;
         }
-        uint32_t lm = uni(L.pmask[b]) & live;
+        uint32_t lm = (uint32_t)__builtin_amdgcn_readlane((int)pass_mask, (int)b) & live_heads;
         if (!lm) continue;
-        const uint4 rec_b = sload(lead.rec + (i_base + b));
-        const uint32_t prev_l = block_prev_last(lead, i_base + b);
-        const uint2 mo_l = make_uint2(rec_b.y, rec_b.z);
+        const uint32_t prev_l = (uint32_t)__builtin_amdgcn_readlane((int)prev_mine, (int)b);
+        const uint2 mo_l = make_uint2((uint32_t)__builtin_amdgcn_readlane((int)rec_mine.y, (int)b),
+                                      (uint32_t)__builtin_amdgcn_readlane((int)rec_mine.z, (int)b));
         if (p.debug & 256u) ++n_scored;  // COUNTERS
         // ---- stage A: decode the block once (straight from global memory: no LDS staging — the
         // blocks are decoded once per group here, not once per query)
@@ -350,20 +379,7 @@ ashare_kernel(TqkAShareParams p) {
         const float tfn0 = f0 * __builtin_amdgcn_rcpf(f0 + L.cache[nid0]);
         const float tfn1 = f1 * __builtin_amdgcn_rcpf(f1 + L.cache[nid1]);
         const uint64_t valid0 = __ballot(v0), valid1 = __ballot(v1);
-        // ---- stage F: every lead that wants the block.  "leader score + weights of the other lists
-        // >= threshold" is one float compare per doc (scores are >= 0: the float order is the order
-        // of the sortable bits): tfn >= (thr - rest) / w, every factor widened by 1e-5 for the
-        // reciprocal-based tf/(tf+norm) and the summation order — computed for all leads at once,
-        // lane g for lead g
-        float my_need = -1.0f;
-        {
-          const uint32_t thr = (uint32_t)lane < n_leads ? L.lthr[lane] : 0u;
-          if (thr) {
-            const float thr_f = __uint_as_float(thr ^ ((thr >> 31) ? 0x80000000u : 0xFFFFFFFFu));
-            const float num = thr_f * 0.99999f - my_rest * 1.00001f;
-            if (num > 0.0f) my_need = num * __builtin_amdgcn_rcpf(my_w) * 0.99999f;
-          }
-        }
+        // ---- stage F: every family that wants the block
         uint32_t pm_lo = 0, pm_hi = 0;
         uint64_t mem0 = valid0, mem1 = valid1;  // (mask 0: every doc)
         if (p.debug & 2048u) lm = 0;  // ABLATION: decode only
@@ -372,7 +388,7 @@ ashare_kernel(TqkAShareParams p) {
           if (p.debug & 32u) ++n_scored;  // COUNTERS
           const uint32_t mlo = (uint32_t)__builtin_amdgcn_readlane((int)my_mlo, (int)g);
           const uint32_t mhi = (uint32_t)__builtin_amdgcn_readlane((int)my_mhi, (int)g);
-          const float need = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(my_need), (int)g));
+          const float need = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(fam_need), (int)g));
           if (mlo != pm_lo || mhi != pm_hi) {  // "every other list holds (or may hold) the doc"
             pm_lo = mlo;
             pm_hi = mhi;
@@ -409,44 +425,45 @@ ashare_kernel(TqkAShareParams p) {
     }
     while (qn) stageC(qn < 64u ? qn : 64u);
 
-    // ---- flush: the staging lists go to their queries' result lists
+    // ---- flush: the heads' staging lists go to the result lists of every member of their families
     wave_mem_fence();
     const uint32_t cw = (uint32_t)lane < AS_GROUP ? L.cnt[lane] : 0u;
     const uint32_t cn = cw & 0xFFFFu, sc = cw >> 16;
-    if (sc) atomicAdd(sload(&p.sinks->query_matches) + sload(&p.sinks->out_index)[L.lead[lane].query], sc);
-    {  // queries that got new scores: the k-th largest of their slots is the new shared threshold
-      uint64_t upd = __ballot(sc != 0u);
-      while (upd) {
-        const uint32_t gs = (uint32_t)__builtin_ctzll(upd);
-        upd &= upd - 1ull;
-        if (p.debug & 16384u) ++n_scored;  // COUNTERS
-        const uint32_t lkv = uni(L.lk[gs]);
-        const uint32_t ks = lkv & 0xFFu, rs = lkv >> 8;
-        const uint32_t qs = uni(L.lead[gs].query);
-        const uint32_t *slots = p.thr_slots + (size_t)rs * TQD_THR_SLOTS;
-        uint32_t sv[4] = {0u, 0u, 0u, 0u};
-        sv[0] = __hip_atomic_load(slots + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        uint32_t gth;
-        if (ks > 16u) {
-#pragma unroll
-          for (int r = 1; r < 4; ++r)
-            sv[r] = __hip_atomic_load(slots + 64 * r + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          gth = kth_largest_hi16<4>(sv, ks);
-        } else {
-          gth = kth_largest_hi16<1>(sv, ks);
-        }
-        if (gth && lane == 0) atomicMax(p.thr_val + qs, gth);
-      }
-    }
-    uint64_t have = __ballot(cn != 0u);
-    while (have) {
-      const uint32_t gs = (uint32_t)__builtin_ctzll(have);
-      have &= have - 1ull;
+    uint64_t upd = __ballot(sc != 0u);  // families that got new scores
+    while (upd) {
+      const uint32_t gs = (uint32_t)__builtin_ctzll(upd);
+      upd &= upd - 1ull;
+      if (p.debug & 16384u) ++n_scored;  // COUNTERS
+      const uint32_t lkv = uni(L.lk[gs]);
+      const uint32_t ks = lkv & 0xFFu, rs = lkv >> 8;
+      const uint32_t fl = uni(L.flen[gs]);
+      const uint32_t scs = (uint32_t)__builtin_amdgcn_readlane((int)sc, (int)gs);
       uint32_t ns = (uint32_t)__builtin_amdgcn_readlane((int)cn, (int)gs);
-      const uint32_t ks = uni(L.lk[gs]) & 0xFFu;
-      const uint32_t qs = uni(L.lead[gs].query);
-      const uint32_t thr_now = __hip_atomic_load(p.thr_val + qs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      uint64_t *sl = my_stage + (size_t)gs * CAPL;
+      // the k-th largest of the query's slots is the new shared threshold of the family's members
+      const uint32_t *slots = p.thr_slots + (size_t)rs * TQD_THR_SLOTS;
+      uint32_t sv[4] = {0u, 0u, 0u, 0u};
+      sv[0] = __hip_atomic_load(slots + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      uint32_t gth;
+      if (ks > 16u) {
+#pragma unroll
+        for (int r = 1; r < 4; ++r)
+          sv[r] = __hip_atomic_load(slots + 64 * r + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        gth = kth_largest_hi16<4>(sv, ks);
+      } else {
+        gth = kth_largest_hi16<1>(sv, ks);
+      }
+      // lane i < fl <-> member i of the family
+      uint32_t mq = 0, thr_now = 0;
+      if ((uint32_t)lane < fl) {
+        mq = L.lead[gs + (uint32_t)lane].query;
+        if (gth) atomicMax(p.thr_val + mq, gth);
+        atomicAdd(sload(&p.sinks->query_matches) + sload(&p.sinks->out_index)[mq], scs);
+      }
+      if (lane == 0) thr_now = __hip_atomic_load(p.thr_val + mq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      thr_now = uni(thr_now);
+      if (gth > thr_now) thr_now = gth;
+      if (!ns) continue;
+      const uint64_t *sl = my_stage + (size_t)gs * CAPL;
       uint64_t v[R];
       uint32_t keep_n = 0;
 #pragma unroll
@@ -467,16 +484,19 @@ ashare_kernel(TqkAShareParams p) {
         keep_n = ks;
       }
       if (!keep_n) continue;
-      uint32_t at = 0;
-      if (lane == 0) at = atomicAdd(p.list_count + qs, keep_n);
-      at = uni(at);
-      uint64_t *dst = p.lists + (size_t)sload(&p.queries[qs].part_start) + at;
-      uint32_t base = 0;
+      // one append per member: its place in its query's result list
+      uint32_t at_mine = 0;
+      if ((uint32_t)lane < fl) at_mine = p.queries[mq].part_start + atomicAdd(p.list_count + mq, keep_n);
+      for (uint32_t i = 0; i < fl; ++i) {
+        const uint32_t at = (uint32_t)__builtin_amdgcn_readlane((int)at_mine, (int)i);
+        uint64_t *dst = p.lists + (size_t)at;
+        uint32_t base = 0;
 #pragma unroll
-      for (int r = 0; r < R; ++r) {
-        const uint64_t m = __ballot(v[r] != 0ull);
-        if (v[r] != 0ull) dst[base + mbcnt64(m)] = v[r];
-        base += (uint32_t)__popcll(m);
+        for (int r = 0; r < R; ++r) {
+          const uint64_t m = __ballot(v[r] != 0ull);
+          if (v[r] != 0ull) dst[base + mbcnt64(m)] = v[r];
+          base += (uint32_t)__popcll(m);
+        }
       }
     }
   }

@@ -121,18 +121,29 @@ static_assert(sizeof(TqdLead) == 128, "TqdLead is uploaded as raw bytes");
 #define TQD_AS_GROUP 32      // leads per group (one lane each at task setup)
 #define TQD_AS_MAX_TERMS 8   // intersections with more lists keep the per-query kernel
 #define TQD_AS_TILE 64       // blocks per pre-filter step (one lane each)
-struct TqdALead {            // 32 bytes, written by the host planner
+struct TqdALead {            // 48 bytes, written by the host planner
   uint32_t query;            // launch-group query index
-  uint32_t info;             // n_terms (bits 0-4) | bit 8: list 1's membership bit is its column (exact)
+  uint32_t info;             // n_terms (bits 0-4) | bit 8: list 1's membership bit is its column (exact) |
+                             // bit 9: the same query (lists, weights, k) as the lead before it in its group: a
+                             // TWIN.  A group is a sequence of families (a head + its twins): a family is
+                             // evaluated once, its results go to every member's result list
   float w;                   // weight of the leader in this query
   float rest;                // weights of the other lists together: the most they can add (= weight of
                              // list 1 in a 2-term query)
-  uint32_t mask_lo, mask_hi; // doc-matrix bits every match has: the other lists' columns (exact) and
-                             // signature bits (a clear bit proves absence, a set one means maybe)
   uint32_t dense_off;        // list 1: bitmap + rank directory, byte-wide tfs, as offsets from
   uint32_t tf8_off;          // TqkAShareParams::table_base in 8-byte units
+  uint32_t mask_lo, mask_hi; // doc-matrix bits every match has: the other lists' columns (exact) and
+                             // signature bits (a clear bit proves absence, a set one means maybe)
+  uint32_t k;                // the query's k (<= 128)
+  uint32_t thr_row;          // its row of threshold slots (identical queries of a batch share one)
+  uint32_t pad[2];
 };
-static_assert(sizeof(TqdALead) == 32, "TqdALead is uploaded as raw bytes");
+static_assert(sizeof(TqdALead) == 48, "TqdALead is uploaded as raw bytes");
+struct TqdALeadLds {  // what the scoring stage keeps of a lead in LDS
+  uint32_t query, info;
+  float w, rest;
+  uint32_t dense_off, tf8_off;
+};
 
 #define TQD_ROLE_SHOULD 0u
 #define TQD_ROLE_MUST 1u

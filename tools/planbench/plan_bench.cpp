@@ -120,11 +120,75 @@ static int bench_and(int n_queries, int reps) {
   return 0;
 }
 
+// build_ashare_plan on the headline batch: 2-term ANDs over the 256 Zipf lists whose other list has a
+// bitmap (ranks < 64), leader = the rarer list
+static int bench_ashare(int n_queries, int reps) {
+  const uint32_t max_doc = 10000000u, n_terms = 256;
+  tq_segment seg;
+  static uint8_t arena[1 << 21];
+  for (uint32_t t = 0; t < n_terms; ++t) {
+    TermHost th;
+    th.doc_freq = max_doc / 2 / (t + 1);
+    th.n_blocks = (th.doc_freq + 127) / 128;
+    TqdTerm dt{};
+    dt.has_freq = 1u;
+    if (t < 64) {
+      th.dense_blob = arena + 4096u * t + 8u;
+      th.tf8_blob = arena + 4096u * t + 2048u;
+    }
+    if (t < TQD_MAT_SLOTS) dt.has_freq |= (t + 1u) << 8;
+    else dt.has_freq |= ((t * 7u) % TQD_SIG_BITS + 1u) << 16;
+    seg.terms.push_back(th);
+    seg.h_dterms.push_back(dt);
+  }
+  seg.max_doc = max_doc;
+  seg.share_table_lo = (uint64_t)arena;
+  std::mt19937 rng(7);
+  std::vector<double> cdf(n_terms);
+  double acc = 0;
+  for (uint32_t r = 0; r < n_terms; ++r) cdf[r] = (acc += 1.0 / (r + 1));
+  PlanScratch ps;
+  double best = 1e9;
+  for (int rep = 0; rep < reps; ++rep) {
+    Group &g = ps.groups[8];
+    g.reset();
+    g.mode = TQ_MODE_AND;
+    rng.seed(7);
+    for (int q = 0; q < n_queries; ++q) {
+      TqdQuery dq{};
+      uint32_t a, b;
+      do {
+        a = (uint32_t)(std::lower_bound(cdf.begin(), cdf.end(), std::uniform_real_distribution<double>(0, acc)(rng)) - cdf.begin());
+        b = (uint32_t)(std::lower_bound(cdf.begin(), cdf.end(), std::uniform_real_distribution<double>(0, acc)(rng)) - cdf.begin());
+      } while (a == b || std::min(a, b) >= 64);
+      dq.n_terms = 2;
+      dq.k = 10;
+      dq.flags = TQD_QF_PRUNE;
+      dq.thr_index = (uint32_t)q;
+      dq.term[0] = std::max(a, b);
+      dq.term[1] = std::min(a, b);
+      dq.weight[0] = 2.2f * logf(1.0f + (max_doc - seg.terms[dq.term[0]].doc_freq + 0.5f) / (seg.terms[dq.term[0]].doc_freq + 0.5f));
+      dq.weight[1] = 2.2f * logf(1.0f + (max_doc - seg.terms[dq.term[1]].doc_freq + 0.5f) / (seg.terms[dq.term[1]].doc_freq + 0.5f));
+      g.queries.push_back(dq);
+      g.tile_cost.push_back(1);
+      g.out_index.push_back((uint32_t)q);
+      g.max_k = 10;
+    }
+    const auto t0 = std::chrono::steady_clock::now();
+    if (build_ashare_plan(&seg, g, ps) != TQ_OK) return 1;
+    best = std::min(best, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
+  }
+  printf("ashare: queries %d tasks %zu (warm %u): build_ashare_plan %.2f ms (best of %d)\n", n_queries,
+         ps.atasks.size(), ps.a_warm_tasks, best, reps);
+  return 0;
+}
+
 int main(int argc, char **argv) {
   const int n_queries = argc > 1 ? atoi(argv[1]) : 5000;
   const int reps = argc > 2 ? atoi(argv[2]) : 5;
   if (argc > 3 && !strcmp(argv[3], "share")) return bench_share(n_queries, reps);
   if (argc > 3 && !strcmp(argv[3], "and")) return bench_and(n_queries, reps);
+  if (argc > 3 && !strcmp(argv[3], "ashare")) return bench_ashare(n_queries, reps);
   const uint32_t max_doc = 10000000u, n_terms = 256;
   std::vector<uint32_t> n_blocks(n_terms);
   for (uint32_t r = 0; r < n_terms; ++r) n_blocks[r] = (max_doc / 2 / (r + 1) + 127) / 128;

@@ -225,6 +225,16 @@ static int check_ashare(int seed) {
     dq.flags = TQD_QF_PRUNE;
     dq.cache_idx = uni(0, 9) ? 0u : uni(1, 2);
     dq.thr_index = 4u * q;
+    if (q && uni(0, 2) == 0) {  // a third of the queries repeat an earlier one (twins), some with another k
+      dq = g.queries[uni(0, q - 1)];
+      dq.thr_index = 4u * q;
+      if (uni(0, 1)) dq.k = uni(1, 128);
+      g.queries.push_back(dq);
+      g.tile_cost.push_back(1);
+      g.out_index.push_back(q);
+      g.max_k = std::max(g.max_k, dq.k);
+      continue;
+    }
     uint32_t used[TQD_AS_MAX_TERMS];
     for (uint32_t i = 0; i < dq.n_terms; ++i) {
       uint32_t t;
@@ -257,7 +267,7 @@ static int check_ashare(int seed) {
     const TqdALead &ld = ps.aleads[i];
     if (ld.query >= nq || seen[ld.query]++) return fail_msg("lead twice / out of range", (long)i, ld.query);
     const TqdQuery &q = g.queries[ld.query];
-    if ((ld.info & 31u) != q.n_terms || ld.w != q.weight[0]) return fail_msg("lead header", (long)i);
+    if ((ld.info & 31u) != q.n_terms || ld.w != q.weight[0] || ld.k != q.k) return fail_msg("lead header", (long)i);
     float rest = 0;
     uint64_t mask = 0;
     for (uint32_t m = 1; m < q.n_terms; ++m) {
@@ -295,11 +305,21 @@ static int check_ashare(int seed) {
       const TqdQuery &q = g.queries[ld.query];
       if (q.term[0] != t.x || q.cache_idx != cache) return fail_msg("task lead of another leader", (long)ti, l);
       ++pairs[ld.query];
+      // twin bit: set iff the lead is the same query (lists, weights) as the one before it in the group
+      bool same = false;
+      if (l) {
+        const TqdQuery &pq = g.queries[ps.aleads[t.w + l - 1].query];
+        same = pq.n_terms == q.n_terms && pq.k == q.k && !memcmp(pq.term, q.term, q.n_terms * 4) &&
+               !memcmp(pq.weight, q.weight, q.n_terms * 4);
+        if (same && ps.aleads[t.w + l - 1].thr_row != ld.thr_row) return fail_msg("twins share one row of threshold slots", (long)ti, l);
+      }
+      if ((((ld.info >> 9) & 1u) != 0u) != same) return fail_msg("twin bit", (long)ti, l);
     }
     const uint32_t n_blocks = seg.terms[t.x].n_blocks;
     // the warm-up launch (tasks [0, a_warm_tasks): the first blocks of every leader), then doc-slice order
     const bool warm = ti < ps.a_warm_tasks;
-    const uint32_t slice = warm ? 0u : 1u + (uint32_t)(((uint64_t)t.y << 12) / n_blocks);
+    // (the planner's slice of a run: (first block << 12) / n_blocks by a multiplication with 2^44 / n_blocks)
+    const uint32_t slice = warm ? 0u : 1u + std::min<uint32_t>(4095u, (uint32_t)((t.y * (((uint64_t)1 << 44) / n_blocks)) >> 32));
     if (slice < last_slice) return fail_msg("tasks not in doc-slice order", (long)ti);
     last_slice = slice;
     // (tasks of one group appear in block order: the sort by slice is stable and slices follow blocks)
