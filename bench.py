@@ -464,10 +464,8 @@ def main():
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         raise SystemExit(relaunch_ranks(args))
     cl = Cluster()
-    # planner worker threads per process: the granted CPUs are shared by the ranks of the node
-    # (8 ranks x 4 threads on a 16-CPU cgroup would make the host planner the bottleneck)
-    local_world = int(os.environ.get("LOCAL_WORLD_SIZE", cl.world))
-    os.environ.setdefault("TQ_PLAN_THREADS", str(max(1, min(4, usable_cpus() // max(1, local_world)))))
+    # (the host planner runs on the calling thread: TQ_PLAN_THREADS defaults to 1 — helper threads
+    # were no faster on any workload here and a descheduled helper stalled a step for tens of ms)
     if cl.world != args.gpus and cl.world > 1:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, cl.world))
     if args.selftest_launcher:
@@ -652,7 +650,7 @@ def main():
                          "local segments (validate + plan + stage + enqueue; overlaps the previous step's "
                          "kernels while it stays below them), kernel_ms = scan kernels (HIP events), "
                          "exchange_ms = all-gather + merge_top_k (stream events)",
-            "plan_threads": int(os.environ.get("TQ_PLAN_THREADS", "4")),
+            "plan_threads": int(os.environ.get("TQ_PLAN_THREADS", "1")),
             "exchange": cl.exchange_note, "pruned_equals_exhaustive": True,
             "parity_checked_queries": checked8,
             "parity_note": "oracle (exhaustive executor per segment, global Bm25Weights) -> gathered over "

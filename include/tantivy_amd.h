@@ -16,9 +16,10 @@
  * Thread-safety: one tq_segment may be searched from one thread at a time (it owns one HIP
  * stream and its scratch buffers); different segments may be searched concurrently — that is
  * tantivy's own "one task per segment" executor model (src/core/executor.rs:44-106).
- * Planning a large batch (>= 65536 chunks, i.e. thousands of union queries) forks up to 4
- * short-lived worker threads inside the call (TQ_PLAN_THREADS=1 turns that off); they touch only
- * the call's own planner scratch and are joined before it returns.
+ * Planning runs on the calling thread.  TQ_PLAN_THREADS=N (N > 1) lets a process-wide pool of N - 1
+ * helper threads take slabs of a large batch; they touch only the call's own planner scratch and
+ * the call returns after the last slab (off by default: no bench workload planned faster with it,
+ * and a descheduled helper stalls the batch).
  * Streams: consecutive batches on one segment share its scratch buffers.  A batch enqueued on
  * another stream than the previous one first waits (stream-side, no host block) for that batch;
  * the host paths (tq_search_batch, tq_count_batch, tq_decode_*, tq_segment_set_alive_bitset,

@@ -1446,7 +1446,11 @@ static const uint32_t kOrSubSlices = std::min<uint32_t>(256u, std::max<uint32_t>
 static const bool kOrSubMajor = tune_u32("TQ_OR_SUBMAJOR", 0) != 0;
 static const bool kOrSortQueries = tune_u32("TQ_OR_SORT", 1) != 0;
 static uint32_t plan_threads() {
-  static const uint32_t n = std::min<uint32_t>(16u, std::max<uint32_t>(1u, tune_u32("TQ_PLAN_THREADS", 4)));
+  // (default 1 since round 4: with the per-query sorts gone and the intersections planned per leader the
+  // calling thread plans a 10 000-query batch in about a millisecond; helper threads were no faster on
+  // any bench workload and a descheduled helper — the GPU box shares its cores — stalled a batch for
+  // up to 70 ms)
+  static const uint32_t n = std::min<uint32_t>(16u, std::max<uint32_t>(1u, tune_u32("TQ_PLAN_THREADS", 1)));
   return n;
 }
 // batches below this many chunks are planned by the calling thread alone (TQ_PLAN_PAR_MIN: tests)
