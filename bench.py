@@ -364,6 +364,46 @@ def measure(cl, runner, torch, queries, k, steps, warmup, time_exhaustive=False)
             "algo_bytes_full": exh_st["algorithmic_bytes"], "full_matches": exh_st["matches"]}
 
 
+def latency_curve(dev, queries, k):
+    """Latency against throughput, outside the timed region (BASELINE.json's metric is queries/sec AND
+    p50 latency).  (a) One caller handing over batches of b queries, synchronously (Query::weight done
+    before, like the timed steps): per-batch wall time -> QPS, p50, p99.  (b) tantivy's own call
+    pattern: T host threads each calling Searcher::search with ONE query at a time
+    (searcher.rs:180-238); the library coalesces the per-segment calls of concurrent threads into
+    batched launches (tq_search_one) — per-query wall time, QPS, mean queries per launch."""
+    def pct(v, p):
+        v = sorted(v)
+        return round(float(v[min(len(v) - 1, int(len(v) * p))]) * 1e3, 4)
+
+    out = {"note": "and2 stream, k=%d, one 10M-doc segment; batch: one caller, synchronous batches (plan + H2D + "
+                   "kernels + D2H per call); threads: T host threads x single-query Searcher::search calls, "
+                   "coalesced by tq_search_one (submit_window_us = 100)" % k, "batch": {}, "threads": {}}
+    for b in (1, 16, 256, 4096, 10000):
+        b = min(b, len(queries))
+        dev.prepare(queries[:b])
+        reps = 200 if b <= 16 else (60 if b <= 256 else 25)
+        t = []
+        for _ in range(reps + 3):
+            t1 = time.perf_counter()
+            dev.search_prepared(k)
+            t.append(time.perf_counter() - t1)
+        t = t[3:]
+        out["batch"][str(b)] = {"qps": round(b * len(t) / sum(t), 1), "p50_ms": pct(t, 0.5), "p99_ms": pct(t, 0.99)}
+    for nthreads in (1, 16, 64):
+        n = min(len(queries), 400 if nthreads == 1 else nthreads * 150)
+        dev.search_concurrent(queries[:min(n, 4 * nthreads)], k, nthreads)  # (threads + queue warm)
+        dev.submit_stats(reset=True)
+        _, _, _, _, lat_ms, wall_ms = dev.search_concurrent(queries[:n], k, nthreads)
+        st = dev.submit_stats()
+        v = sorted(float(x) for x in lat_ms)
+        out["threads"][str(nthreads)] = {
+            "qps": round(n / (wall_ms * 1e-3), 1), "p50_ms": round(v[len(v) // 2], 4),
+            "p99_ms": round(v[min(len(v) - 1, int(len(v) * 0.99))], 4), "queries": n,
+            "launches": st["batches"], "queries_per_launch": round(st["queries"] / max(1, st["batches"]), 2),
+            "max_queries_per_launch": st["max_batch"]}
+    return out
+
+
 def frac_of(algo_bytes, kernel_ms):
     a = algo_bytes / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
     return round(a, 1), round(a / HBM_PEAK_GBS, 4)
@@ -529,12 +569,14 @@ def main():
 
     # ---- single-query latency (p50), outside the timed region
     lat = []
+    curve = None
     if rank == 0 and world == 1 and args.latency_queries > 0:
         for i in range(min(args.latency_queries, n_q)):
             runner.dev.prepare([queries[i]])
             t1 = time.perf_counter()
             runner.dev.search_prepared(k)
             lat.append(time.perf_counter() - t1)
+        curve = latency_curve(runner.dev, queries, k)
 
     gstats_main = global_stats(all_stats)
     parity_checked = spot_check(O, cl, main_segs, rank * S_main, gstats_main, args.workload, queries, k,
@@ -772,6 +814,9 @@ def main():
         "pruned_equals_exhaustive": bool(m["mode_parity"]),
         "cpu_baseline": cpu,
         "p50_latency_ms": round(float(np.median(lat)) * 1e3, 4) if lat else None,
+        "p50_latency_note": "one query per call, one caller (the batch = 1 point of latency_curve); the "
+                            "headline batch's own p50 is latency_curve.batch['10000'].p50_ms",
+        "latency_curve": curve,
         "parity_checked_queries": parity_checked,
         "other_workloads": side or None,
         "strong_scaling": strong,

@@ -13,9 +13,12 @@
  * Every function returns TQ_OK (0) or an error code; tq_last_error() gives the message of the
  * last failure on the calling thread.  Nothing here panics or throws across the boundary.
  *
- * Thread-safety: one tq_segment may be searched from one thread at a time (it owns one HIP
- * stream and its scratch buffers); different segments may be searched concurrently — that is
- * tantivy's own "one task per segment" executor model (src/core/executor.rs:44-106).
+ * Thread-safety: every entry point that takes a tq_segment locks it for the duration of the call
+ * (term table, planner scratch and staging buffers are per segment), so concurrent callers on one
+ * segment are serialised, never undefined; different segments run concurrently — tantivy's own
+ * "one task per segment" executor model (src/core/executor.rs:44-106).  Many threads each issuing
+ * single queries should use tq_search_one / tq_submit + tq_wait below: their queries are coalesced
+ * into batched launches instead of queueing up one launch each.
  * Planning runs on the calling thread.  TQ_PLAN_THREADS=N (N > 1) lets a process-wide pool of N - 1
  * helper threads take slabs of a large batch; they touch only the call's own planner scratch and
  * the call returns after the last slab (off by default: no bench workload planned faster with it,
@@ -183,6 +186,37 @@ int tq_search_batch_device_opts(tq_segment *seg, const tq_query *queries, uint32
                                 uint32_t out_stride, float *d_out_scores, uint32_t *d_out_docs,
                                 uint32_t *d_out_counts, const tq_search_opts *opts,
                                 void *hip_stream);
+
+/* ---- concurrent single-query entry (tantivy's own call pattern) ----
+ * replaces: Collector::collect_segment(&dyn Weight, segment_ord, &SegmentReader) as
+ * Searcher::search_with_executor calls it — from any number of threads at once, one query per call
+ * (src/core/searcher.rs:180-238, src/collector/mod.rs:173-183; `Weight: Send + Sync`,
+ * src/query/weight.rs:66).  One query per launch is the ~0.3 ms regime of the device; these entry
+ * points coalesce the single queries of concurrent callers into the batched launch:
+ *   tq_submit      puts one query on the segment's pending list and returns a ticket.  The query's
+ *                  arrays (terms, weights, tf_cache, ...) and the output buffers (k scores / docs,
+ *                  one count) are borrowed until tq_wait returns.
+ *   tq_wait        blocks until the launch that carried the query has finished and frees the
+ *                  ticket.  Whoever waits while no batch is running LEADS the next one: it takes
+ *                  everything pending that runs under the same options, issues ONE tq_search_batch
+ *                  for it and hands every caller its rows (callers keep arriving while the previous
+ *                  batch runs — nobody waits for a batch to fill).  Work only happens inside
+ *                  tq_wait: a ticket that is never waited for is never run (and leaks).
+ *   tq_search_one  = tq_submit + tq_wait: the blocking, thread-safe single-query call.
+ * A query the device does not take fails alone (TQ_ERR_*; tq_last_error on the waiting thread), its
+ * batch mates are re-run without it. */
+typedef struct tq_ticket tq_ticket;
+int tq_submit(tq_segment *seg, const tq_query *query, const tq_search_opts *opts, float *out_scores,
+              uint32_t *out_docs, uint32_t *out_count, tq_ticket **out);
+int tq_wait(tq_ticket *ticket);
+int tq_search_one(tq_segment *seg, const tq_query *query, const tq_search_opts *opts,
+                  float *out_scores, uint32_t *out_docs, uint32_t *out_count);
+typedef struct tq_submit_stats {
+  uint64_t batches;   /* launches issued for submitted queries */
+  uint64_t queries;   /* queries they carried */
+  uint64_t max_batch; /* the largest of them */
+} tq_submit_stats;
+int tq_get_submit_stats(tq_segment *seg, tq_submit_stats *out, int reset);
 
 /* replaces: TopBySortKeyCollector::merge_fruits -> merge_top_k
  * (src/collector/sort_key_top_collector.rs:54-95; ordering top_score_collector.rs:590-600):
@@ -370,6 +404,9 @@ int tq_segment_get_stats(tq_segment *seg, tq_segment_stats *out);
  *        every list's tf/(tf+norm) built once per 128-doc tile, every query reading its lists' rows —
  *        when the batch has that many of them (up to 255 distinct lists and 8192 queries; lists
  *        without a bitmap are then also kept as plain doc / tf arrays, inside "dense_budget_x"),
+ *        "submit_window_us" (default 100): tq_submit / tq_search_one — how long the leader of a batch
+ *        holds it open for the callers of the previous batch to come back with their next query
+ *        (0 = launch with whatever is pending),
  *        "use_dpp" (0/1: DPP or ds_bpermute prefix sums) */
 int tq_set_option(tq_segment *seg, const char *name, int64_t value);
 

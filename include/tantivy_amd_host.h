@@ -69,6 +69,14 @@ int tqh_prepare_batch(tqh_searcher *s, const tqh_query *queries, uint32_t n);
  * outputs [n][limit], (score desc, segment_ord asc, doc asc). */
 int tqh_search_prepared(tqh_searcher *s, uint32_t offset, uint32_t limit, float *scores,
                         uint32_t *segment_ords, uint32_t *docs, uint32_t *counts);
+/* Searcher::search called from n_threads host threads at once, one query per call — the reference's
+ * own call pattern (src/core/searcher.rs:180-238): thread t takes queries t, t + n_threads, ...;
+ * every call is Query::weight + one tq_search_one per segment (the calls of concurrent threads ride
+ * in shared launches) + merge_fruits.  Outputs [n][limit] as tqh_search_prepared; latency_ms[q] =
+ * wall time of query q's call (may be NULL); *wall_ms = the whole run (may be NULL). */
+int tqh_search_concurrent(tqh_searcher *s, const tqh_query *queries, uint32_t n, uint32_t offset,
+                          uint32_t limit, uint32_t n_threads, float *scores, uint32_t *segment_ords,
+                          uint32_t *docs, uint32_t *counts, float *latency_ms, double *wall_ms);
 /* Searcher::search(&query, &Count) of the prepared batch (src/collector/count_collector.rs:39-80):
  * counts[q] = alive matching docs summed over the segments. */
 int tqh_count_prepared(tqh_searcher *s, uint64_t *counts);

@@ -55,6 +55,10 @@ def kernel_names(mask):
     return [n for b, n in sorted(KERNEL_NAMES.items()) if mask & b]
 
 
+class TqSubmitStats(C.Structure):
+    _fields_ = [("batches", C.c_uint64), ("queries", C.c_uint64), ("max_batch", C.c_uint64)]
+
+
 class TqSegmentStats(C.Structure):
     _fields_ = [(n, C.c_uint64) for n in (
         "index_bytes", "positions_bytes", "fieldnorm_bytes", "alive_bytes", "term_table_bytes",
@@ -165,6 +169,12 @@ def lib():
                                            C.c_uint32]
     L.tqh_prepare_batch.argtypes = [vp, C.POINTER(TqhQuery), C.c_uint32]
     L.tqh_search_prepared.argtypes = [vp, C.c_uint32, C.c_uint32, f32p, u32p, u32p, u32p]
+    L.tqh_search_concurrent.argtypes = [vp, C.POINTER(TqhQuery), C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
+                                        f32p, u32p, u32p, u32p, f32p, C.POINTER(C.c_double)]
+    L.tq_get_submit_stats.argtypes = [vp, C.POINTER(TqSubmitStats), C.c_int]
+    L.tq_search_one.argtypes = [vp, C.POINTER(TqQuery), C.POINTER(TqSearchOpts), f32p, u32p, u32p]
+    L.tq_submit.argtypes = [vp, C.POINTER(TqQuery), C.POINTER(TqSearchOpts), f32p, u32p, u32p, C.POINTER(vp)]
+    L.tq_wait.argtypes = [vp]
     L.tqh_collect_segment_prepared.argtypes = [vp, C.c_uint32, C.c_uint32, f32p, u32p, u32p]
     L.tqh_collect_segment_prepared_device.argtypes = [vp, C.c_uint32, C.c_uint32, vp, vp, vp, vp]
     L.tqh_searcher_add_remote_stats.argtypes = [vp, C.c_uint64, C.c_uint64, u32p, u32p, C.c_uint32]
@@ -431,8 +441,8 @@ class DeviceIndex:
             pass
 
     # ---- host-mirror path (Query::weight + Searcher::search)
-    def prepare(self, queries):
-        """queries: list of (mode, [term ids]), (MODE_PHRASE, [term ids], [offsets]) or
+    def _host_queries(self, queries):
+        """-> (tqh_query array, keep-alive list).  queries: list of (mode, [term ids]), (MODE_PHRASE, [term ids], [offsets]) or
         (MODE_BOOL, [term ids], [occurs][, clause_of | None[, min_should_match]]) with occurs in
         {SHOULD, MUST, MUST_NOT}; terms sharing a clause_of value form one nested union.  A trailing
         dict {"boosts": [...]} wraps every term query in BoostQuery(boost); {"nested_occurs": [...]}
@@ -473,8 +483,37 @@ class DeviceIndex:
                 oa = (C.c_uint32 * len(terms))(*[int(o) for o in q[2]])
                 keep.append(oa)
                 qs[i].phrase_offsets = C.cast(oa, C.POINTER(C.c_uint32))
+        return qs, keep
+
+    def prepare(self, queries):
+        """Query::weight for a batch (see _host_queries for the query tuples)."""
+        qs, keep = self._host_queries(queries)
+        n = len(queries)
         _check(lib().tqh_prepare_batch(self._s, qs, n), host=True)
         self._n_prepared = n
+
+    def search_concurrent(self, queries, limit, n_threads, offset=0):
+        """Searcher::search from n_threads host threads at once, one query per call (tantivy's own call
+        pattern): the per-segment calls of concurrent threads are coalesced into batched launches
+        (tq_search_one).  Returns (scores, segment_ords, docs, counts, latency_ms per query, wall_ms)."""
+        qs, keep = self._host_queries(queries)
+        n = len(queries)
+        scores = np.zeros((n, limit), np.float32)
+        ords = np.zeros((n, limit), np.uint32)
+        docs = np.zeros((n, limit), np.uint32)
+        counts = np.zeros(n, np.uint32)
+        lat = np.zeros(max(1, n), np.float32)
+        wall = C.c_double()
+        _check(lib().tqh_search_concurrent(self._s, qs, n, int(offset), int(limit), int(n_threads),
+                                           _f32(scores), _u32(ords), _u32(docs), _u32(counts), _f32(lat),
+                                           C.byref(wall)), host=True)
+        return scores, ords, docs, counts, lat[:n], float(wall.value)
+
+    def submit_stats(self, segment_ord=0, reset=False):
+        """Launches issued for queries that came through tq_submit / tq_search_one on one segment."""
+        st = TqSubmitStats()
+        _check(lib().tq_get_submit_stats(self.segment_raw(segment_ord), C.byref(st), 1 if reset else 0))
+        return {"batches": int(st.batches), "queries": int(st.queries), "max_batch": int(st.max_batch)}
 
     def search_prepared(self, limit, offset=0):
         n = self._n_prepared

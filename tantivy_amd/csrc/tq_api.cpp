@@ -12,6 +12,7 @@
 #include <atomic>
 #include <chrono>
 #include <condition_variable>
+#include <deque>
 #include <mutex>
 #include <new>
 #include <cstdlib>
@@ -157,6 +158,9 @@ struct Options {
   // max_doc / xunion_ratio postings (0 = never), if the batch has at least xunion_min_queries of them
   int xunion_ratio = 64;
   int xunion_min_queries = 64;
+  // tq_submit / tq_search_one: how long the leader of a batch waits for the callers of the previous
+  // batch to come back with their next query (0 = launch with whatever is pending)
+  int submit_window_us = 100;
 };
 
 }  // namespace
@@ -245,9 +249,17 @@ struct tq_segment {
   // host planner scratch (launch groups, chunk tables): kept between batches so that planning a
   // batch does not start by page-faulting tens of megabytes of fresh vectors
   struct PlanScratch *plan = nullptr;
+  // One call at a time works on a segment's state (term table, planner scratch, staging buffers):
+  // every entry point takes this lock, so concurrent callers are serialised, not undefined.
+  // (recursive: tq_count_batch -> tq_search_batch -> ...)
+  std::recursive_mutex exec_m;
+  // tq_submit / tq_wait / tq_search_one: single queries of concurrent callers, coalesced into batches
+  struct SubmitQueue *submit = nullptr;
 };
 
 void tq_free_plan_scratch(PlanScratch *p);  // (defined next to the planner)
+void tq_free_submit_queue(struct SubmitQueue *q);
+#define TQ_SEGMENT_LOCK(seg) std::lock_guard<std::recursive_mutex> tq_exec_lock_((seg)->exec_m)
 
 namespace {
 int sync_terms(tq_segment *s, hipStream_t st);
@@ -637,6 +649,8 @@ void tq_segment_free(tq_segment *s) {
   s->d_thr.release();
   tq_free_plan_scratch(s->plan);
   s->plan = nullptr;
+  tq_free_submit_queue(s->submit);
+  s->submit = nullptr;
   s->d_qmatches.release();
   s->d_share_words.release();
   s->d_share_stage.release();
@@ -663,6 +677,7 @@ int tq_term_prepare(tq_segment *s, uint64_t postings_off, uint32_t postings_len,
                     uint64_t positions_off, uint32_t positions_len, uint32_t doc_freq,
                     tq_term_handle *out) {
   if (!s || !out) return fail(TQ_ERR_INVALID, "tq_term_prepare: null argument");
+  TQ_SEGMENT_LOCK(s);
   auto it = s->term_by_off.find(postings_off);
   if (it != s->term_by_off.end()) {
     *out = it->second;
@@ -3448,6 +3463,7 @@ int tq_search_batch_device_opts(tq_segment *s, const tq_query *queries, uint32_t
                                 uint32_t *d_out_counts, const tq_search_opts *opts,
                                 void *hip_stream) {
   if (!s) return fail(TQ_ERR_INVALID, "tq_search_batch: null segment");
+  TQ_SEGMENT_LOCK(s);
   CallOpts co;
   const int rc = resolve_opts(s, opts, co);
   if (rc != TQ_OK) return rc;
@@ -3466,6 +3482,7 @@ int tq_search_batch_opts(tq_segment *s, const tq_query *queries, uint32_t n_quer
                          uint32_t out_stride, float *out_scores, uint32_t *out_docs,
                          uint32_t *out_counts, const tq_search_opts *opts) {
   if (!s) return fail(TQ_ERR_INVALID, "tq_search_batch: null segment");
+  TQ_SEGMENT_LOCK(s);
   CallOpts co;
   const int rc = resolve_opts(s, opts, co);
   if (rc != TQ_OK) return rc;
@@ -3505,6 +3522,7 @@ extern "C" {
 
 int tq_segment_set_alive_bitset(tq_segment *s, const uint8_t *bytes, size_t len) {
   if (!s) return fail(TQ_ERR_INVALID, "tq_segment_set_alive_bitset: null segment");
+  TQ_SEGMENT_LOCK(s);
   HIP_TRY(hipSetDevice(s->device));
   {
     const int wrc = wait_segment_idle(s);  // batches may run on a caller's stream
@@ -3532,6 +3550,7 @@ int tq_segment_set_alive_bitset(tq_segment *s, const uint8_t *bytes, size_t len)
 
 int tq_last_batch_match_counts(tq_segment *s, uint32_t *out, uint32_t n) {
   if (!s || !out) return fail(TQ_ERR_INVALID, "tq_last_batch_match_counts: null argument");
+  TQ_SEGMENT_LOCK(s);
   if (n > s->last_batch_queries) return fail(TQ_ERR_INVALID, "the last batch had %u queries", s->last_batch_queries);
   HIP_TRY(hipSetDevice(s->device));
   {
@@ -3546,6 +3565,7 @@ int tq_count_batch(tq_segment *s, const tq_query *queries, uint32_t n_queries,
                    uint32_t *out_counts) {
   if (!s || (!queries && n_queries) || !out_counts)
     return fail(TQ_ERR_INVALID, "tq_count_batch: null argument");
+  TQ_SEGMENT_LOCK(s);
   if (n_queries == 0) return TQ_OK;
   // every match has to be visited: exhaustive scan, smallest top-k
   std::vector<tq_query> qs(queries, queries + n_queries);
@@ -3563,6 +3583,7 @@ int tq_count_batch(tq_segment *s, const tq_query *queries, uint32_t n_queries,
 
 int tq_last_batch_stats(tq_segment *s, tq_batch_stats *out) {
   if (!s || !out) return fail(TQ_ERR_INVALID, "tq_last_batch_stats: null argument");
+  TQ_SEGMENT_LOCK(s);
   HIP_TRY(hipSetDevice(s->device));
   if (s->stats_pending) {
     {
@@ -3607,6 +3628,7 @@ int tq_last_batch_stats(tq_segment *s, tq_batch_stats *out) {
 
 int tq_segment_reserve_columns(tq_segment *s, const uint64_t *postings_offs, uint32_t n) {
   if (!s || (!postings_offs && n)) return fail(TQ_ERR_INVALID, "tq_segment_reserve_columns: null argument");
+  TQ_SEGMENT_LOCK(s);
   if (!s->terms.empty())
     return fail(TQ_ERR_INVALID, "tq_segment_reserve_columns: call it before the first tq_term_prepare");
   s->reserved_cols.clear();
@@ -3617,6 +3639,7 @@ int tq_segment_reserve_columns(tq_segment *s, const uint64_t *postings_offs, uin
 
 int tq_segment_get_stats(tq_segment *s, tq_segment_stats *out) {
   if (!s || !out) return fail(TQ_ERR_INVALID, "tq_segment_get_stats: null argument");
+  TQ_SEGMENT_LOCK(s);
   tq_segment_stats r{};
   r.index_bytes = s->idx_len;
   r.positions_bytes = s->pos_len;
@@ -3640,6 +3663,7 @@ int tq_segment_get_stats(tq_segment *s, tq_segment_stats *out) {
 
 int tq_set_option(tq_segment *s, const char *name, int64_t value) {
   if (!s || !name) return fail(TQ_ERR_INVALID, "tq_set_option: null argument");
+  TQ_SEGMENT_LOCK(s);
   if (!strcmp(name, "exhaustive"))
     s->opt.exhaustive = value != 0;
   else if (!strcmp(name, "timing"))
@@ -3668,6 +3692,8 @@ int tq_set_option(tq_segment *s, const char *name, int64_t value) {
     s->opt.xunion_ratio = (int)value;
   else if (!strcmp(name, "xunion_min_queries") && value >= 1 && value <= 0x7FFFFFFF)
     s->opt.xunion_min_queries = (int)value;
+  else if (!strcmp(name, "submit_window_us") && value >= 0 && value <= 1000000)
+    s->opt.submit_window_us = (int)value;
   else
     return fail(TQ_ERR_INVALID, "unknown option '%s'", name);
   return TQ_OK;
@@ -3675,6 +3701,7 @@ int tq_set_option(tq_segment *s, const char *name, int64_t value) {
 
 int tq_decode_postings(tq_segment *s, tq_term_handle term, uint32_t *docs, uint32_t *tfs) {
   if (!s || !docs || !tfs) return fail(TQ_ERR_INVALID, "tq_decode_postings: null argument");
+  TQ_SEGMENT_LOCK(s);
   if (term >= s->terms.size()) return fail(TQ_ERR_INVALID, "unknown term handle %u", term);
   HIP_TRY(hipSetDevice(s->device));
   int rc = sync_terms(s, s->stream);
@@ -3696,6 +3723,7 @@ int tq_decode_postings(tq_segment *s, tq_term_handle term, uint32_t *docs, uint3
 int tq_decode_position_deltas(tq_segment *s, tq_term_handle term, uint32_t *out, uint64_t cap,
                               uint64_t *n_out) {
   if (!s || !n_out) return fail(TQ_ERR_INVALID, "tq_decode_position_deltas: null argument");
+  TQ_SEGMENT_LOCK(s);
   if (term >= s->terms.size()) return fail(TQ_ERR_INVALID, "unknown term handle %u", term);
   const TermHost &t = s->terms[term];
   if (t.positions_len == 0) return fail(TQ_ERR_UNSUPPORTED, "term has no positions on the device");
@@ -3715,6 +3743,202 @@ int tq_decode_position_deltas(tq_segment *s, tq_term_handle term, uint32_t *out,
   return TQ_OK;
 }
 
+}  // extern "C"
+
+// ---- concurrent single-query entry: tq_submit / tq_wait / tq_search_one
+// tantivy lets any number of threads call Searcher::search at once, one query per call
+// (src/core/searcher.rs:180-238; Weight is Send + Sync, src/query/weight.rs:66), and each call ends
+// in one collect_segment per segment (src/collector/mod.rs:173-183).  One query per launch is the
+// 0.3 ms / 3 k queries/s regime of this device; the batched launch needs the queries of MANY callers.
+// Leader / followers: a caller puts its query on the segment's pending list; whoever waits while no
+// batch is running becomes the leader, takes everything pending (callers keep arriving while the
+// previous batch runs: that IS the batching), runs it as one tq_search_batch under the segment
+// lock, hands every caller its rows and wakes them up.  Nobody waits for a batch to fill.
+struct tq_ticket {
+  tq_segment *seg = nullptr;
+  tq_query q{};
+  CallOpts co{};
+  float *out_scores = nullptr;
+  uint32_t *out_docs = nullptr, *out_count = nullptr;
+  int rc = TQ_OK;
+  std::string err;
+  bool done = false;
+};
+struct SubmitQueue {
+  std::mutex m;
+  std::condition_variable cv;
+  std::condition_variable cv_arrive;  // a query was submitted (the leader's arrival window)
+  std::deque<tq_ticket *> pending;
+  bool leader_active = false;
+  size_t last_batch = 0;  // queries the previous batch carried
+  tq_submit_stats stats{};
+  // the leader's scratch
+  std::vector<tq_query> qs;
+  std::vector<float> sc;
+  std::vector<uint32_t> dc, ct;
+};
+void tq_free_submit_queue(SubmitQueue *q) { delete q; }
+
+namespace {
+constexpr size_t kSubmitMaxBatch = 16384;
+std::mutex g_submit_create_m;
+
+SubmitQueue *submit_queue(tq_segment *s) {
+  std::lock_guard<std::mutex> lk(g_submit_create_m);
+  if (!s->submit) s->submit = new SubmitQueue();
+  return s->submit;
+}
+
+// one launch for the tickets of `batch` (same options); rows go to the callers' buffers
+void run_ticket_batch(SubmitQueue &Q, tq_segment *s, std::vector<tq_ticket *> &batch) {
+  const uint32_t n = (uint32_t)batch.size();
+  uint32_t stride = 1;
+  Q.qs.resize(n);
+  for (uint32_t i = 0; i < n; ++i) {
+    Q.qs[i] = batch[i]->q;
+    stride = std::max(stride, batch[i]->q.k);
+  }
+  Q.sc.resize((size_t)n * stride);
+  Q.dc.resize((size_t)n * stride);
+  Q.ct.resize(n);
+  int rc;
+  {
+    TQ_SEGMENT_LOCK(s);
+    rc = search_batch_host(s, Q.qs.data(), n, stride, Q.sc.data(), Q.dc.data(), Q.ct.data(), batch[0]->co);
+  }
+  if (rc == TQ_OK) {
+    for (uint32_t i = 0; i < n; ++i) {
+      tq_ticket *t = batch[i];
+      const uint32_t k = t->q.k;
+      memcpy(t->out_scores, Q.sc.data() + (size_t)i * stride, k * sizeof(float));
+      memcpy(t->out_docs, Q.dc.data() + (size_t)i * stride, k * sizeof(uint32_t));
+      *t->out_count = Q.ct[i];
+      t->rc = TQ_OK;
+    }
+    return;
+  }
+  if (n == 1) {
+    batch[0]->rc = rc;
+    batch[0]->err = g_last_error;
+    return;
+  }
+  // one query the device does not take (an unsupported shape, a bad handle) must not fail its
+  // neighbours: the batch is run again query by query, every caller gets its own verdict
+  for (uint32_t i = 0; i < n; ++i) {
+    std::vector<tq_ticket *> one{batch[i]};
+    run_ticket_batch(Q, s, one);
+  }
+}
+
+int ticket_wait(tq_ticket *t) {
+  tq_segment *s = t->seg;
+  SubmitQueue &Q = *s->submit;
+  std::unique_lock<std::mutex> lk(Q.m);
+  std::vector<tq_ticket *> batch;
+  while (!t->done) {
+    if (Q.leader_active || Q.pending.empty()) {
+      Q.cv.wait(lk);
+      continue;
+    }
+    // lead one batch: everything pending that runs under the first ticket's options.  Callers of
+    // the batch that just finished are on their way back with their next query: the leader gives them
+    // up to submit_window_us to arrive (until as many are pending as the last batch carried) — without
+    // it the first caller back leads a batch of one and everybody else waits a whole launch longer
+    Q.leader_active = true;
+    if (Q.pending.size() < Q.last_batch && s->opt.submit_window_us > 0) {
+      const auto deadline = std::chrono::steady_clock::now() + std::chrono::microseconds(s->opt.submit_window_us);
+      while (Q.pending.size() < Q.last_batch && Q.pending.size() < kSubmitMaxBatch)
+        if (Q.cv_arrive.wait_until(lk, deadline) == std::cv_status::timeout) break;
+    }
+    batch.clear();
+    const CallOpts co = Q.pending.front()->co;
+    for (auto it = Q.pending.begin(); it != Q.pending.end() && batch.size() < kSubmitMaxBatch;) {
+      if ((*it)->co.exhaustive == co.exhaustive && (*it)->co.bound_slack == co.bound_slack) {
+        batch.push_back(*it);
+        it = Q.pending.erase(it);
+      } else {
+        ++it;
+      }
+    }
+    lk.unlock();
+    run_ticket_batch(Q, s, batch);
+    lk.lock();
+    ++Q.stats.batches;
+    Q.stats.queries += batch.size();
+    Q.stats.max_batch = std::max<uint64_t>(Q.stats.max_batch, batch.size());
+    for (tq_ticket *b : batch) b->done = true;
+    Q.last_batch = batch.size();
+    Q.leader_active = false;
+    Q.cv.notify_all();
+  }
+  const int rc = t->rc;
+  if (rc != TQ_OK) g_last_error = t->err;  // (this thread's slot)
+  return rc;
+}
+}  // namespace
+
+extern "C" {
+
+int tq_submit(tq_segment *s, const tq_query *q, const tq_search_opts *opts, float *out_scores,
+              uint32_t *out_docs, uint32_t *out_count, tq_ticket **out) {
+  if (!s || !q || !out_scores || !out_docs || !out_count || !out)
+    return fail(TQ_ERR_INVALID, "tq_submit: null argument");
+  // what can be judged without the segment's state is judged here: a bad query never joins a batch
+  if (q->n_terms == 0 || q->n_terms > TQ_MAX_TERMS)
+    return fail(TQ_ERR_INVALID, "tq_submit: n_terms %u not in 1..%u", q->n_terms, TQ_MAX_TERMS);
+  if (q->k == 0 || q->k > TQ_MAX_K) return fail(TQ_ERR_INVALID, "tq_submit: k %u not in 1..%u", q->k, TQ_MAX_K);
+  if (!q->terms || !q->weights || !q->tf_cache) return fail(TQ_ERR_INVALID, "tq_submit: null terms/weights/tf_cache");
+  CallOpts co;
+  {
+    TQ_SEGMENT_LOCK(s);
+    const int rc = resolve_opts(s, opts, co);
+    if (rc != TQ_OK) return rc;
+  }
+  tq_ticket *t = new (std::nothrow) tq_ticket();
+  if (!t) return fail(TQ_ERR_INVALID, "tq_submit: out of memory");
+  t->seg = s;
+  t->q = *q;
+  t->co = co;
+  t->out_scores = out_scores;
+  t->out_docs = out_docs;
+  t->out_count = out_count;
+  SubmitQueue *Q = submit_queue(s);
+  {
+    std::lock_guard<std::mutex> lk(Q->m);
+    Q->pending.push_back(t);
+  }
+  Q->cv_arrive.notify_one();  // (a leader may be holding its batch open for this query)
+  *out = t;
+  return TQ_OK;
+}
+
+int tq_wait(tq_ticket *t) {
+  if (!t) return fail(TQ_ERR_INVALID, "tq_wait: null ticket");
+  const int rc = ticket_wait(t);
+  delete t;
+  return rc;
+}
+
+int tq_search_one(tq_segment *s, const tq_query *q, const tq_search_opts *opts, float *out_scores,
+                  uint32_t *out_docs, uint32_t *out_count) {
+  tq_ticket *t = nullptr;
+  const int rc = tq_submit(s, q, opts, out_scores, out_docs, out_count, &t);
+  if (rc != TQ_OK) return rc;
+  return tq_wait(t);
+}
+
+int tq_get_submit_stats(tq_segment *s, tq_submit_stats *out, int reset) {
+  if (!s || !out) return fail(TQ_ERR_INVALID, "tq_get_submit_stats: null argument");
+  SubmitQueue *Q = submit_queue(s);
+  std::lock_guard<std::mutex> lk(Q->m);
+  *out = Q->stats;
+  if (reset) Q->stats = tq_submit_stats{};
+  return TQ_OK;
+}
+
+}  // extern "C"
+
+extern "C" {
 // ---- cross-segment merge (merge_top_k)
 int tq_merge_topk(const float *scores, const uint32_t *docs, const uint32_t *counts,
                   uint32_t n_segments, uint32_t n_queries, uint32_t stride, uint32_t offset,

@@ -1,9 +1,11 @@
 // host_capi.cpp — flat C entry points over the C++ host mirror (searcher.hpp), so that the
 // Python tests/bench drive exactly the host code a C++ application would.  Exceptions never
 // cross this boundary: they become status codes + tqh_last_error().
+#include <chrono>
 #include <cstring>
 #include <memory>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "searcher.hpp"
@@ -164,6 +166,70 @@ int tqh_searcher_add_remote_stats(tqh_searcher *s, uint64_t max_doc, uint64_t to
   });
 }
 
+// tqh_query -> Query (the shapes of tantivy_amd_host.h)
+static Query build_query(const tqh_query &q) {
+  Query query;
+  if (q.mode > TQH_MODE_TERM)
+    throw TantivyError(TantivyError::InvalidArgument, "unknown query mode");
+  if (q.n_terms == 0) throw TantivyError(TantivyError::InvalidArgument, "query without terms");
+  if (q.mode == TQ_MODE_BOOL) {
+    if (!q.occurs) throw TantivyError(TantivyError::InvalidArgument, "TQ_MODE_BOOL needs occurs");
+    std::vector<std::pair<Occur, Query>> clauses;
+    std::vector<int> ids;  // clause_of value of every clause built so far
+    std::vector<uint32_t> first_term_of;  // index (in q.terms) of the clause's first term
+    for (uint32_t t = 0; t < q.n_terms; ++t) {
+      if (q.occurs[t] > 2) throw TantivyError(TantivyError::InvalidArgument, "bad occur");
+      const Occur oc = q.occurs[t] == 1 ? Occur::Must
+                                        : (q.occurs[t] == 2 ? Occur::MustNot : Occur::Should);
+      const int id = q.clause_of ? (int)q.clause_of[t] : -1;
+      size_t c = ids.size();
+      if (id >= 0)
+        for (c = 0; c < ids.size() && ids[c] != id; ++c) {}
+      if (c == ids.size()) {
+        ids.push_back(id);
+        first_term_of.push_back(t);
+        clauses.emplace_back(oc, Query::term_query(q.terms[t]).boosted(q.boosts ? q.boosts[t] : 1.0f));
+        continue;
+      }
+      if (clauses[c].first != oc)
+        throw TantivyError(TantivyError::InvalidArgument, "a clause mixes occurs");
+      Query &sub = clauses[c].second;
+      // occur of a term INSIDE its clause: Should (a nested union) unless nested_occurs says
+      // otherwise (`+a +(+b -c)`: clause_of {0,1,1}, occurs {1,1,1}, nested_occurs {255,1,2})
+      auto inner = [&](uint32_t tt) {
+        const uint8_t v = q.nested_occurs ? q.nested_occurs[tt] : 255;
+        if (v != 255 && v > 2) throw TantivyError(TantivyError::InvalidArgument, "bad nested occur");
+        return v == 1 ? Occur::Must : (v == 2 ? Occur::MustNot : Occur::Should);
+      };
+      if (sub.kind == Query::Term) {  // second term of the clause: it becomes a nested query
+        const Query first = sub;
+        sub = Query::boolean({{inner(first_term_of[c]), first}});
+      }
+      sub.clauses.emplace_back(inner(t),
+                               Query::term_query(q.terms[t]).boosted(q.boosts ? q.boosts[t] : 1.0f));
+    }
+    query = Query::boolean(std::move(clauses));
+    query.set_minimum_number_should_match(q.min_should_match);
+  } else if (q.mode == TQH_MODE_TERM || (q.n_terms == 1 && q.mode != TQ_MODE_PHRASE)) {
+    query = Query::term_query(q.terms[0]).boosted(q.boosts ? q.boosts[0] : 1.0f);
+  } else if (q.mode == TQ_MODE_PHRASE) {
+    std::vector<std::pair<uint32_t, uint32_t>> pt;
+    for (uint32_t t = 0; t < q.n_terms; ++t)
+      pt.emplace_back(q.phrase_offsets ? q.phrase_offsets[t] : t, q.terms[t]);
+    query = Query::phrase_with_offsets(std::move(pt));
+    // BoostQuery around the PhraseQuery: PhraseWeight applies it with boost_by
+    // (phrase_weight.rs:42-69); boosts[0] is the factor of the whole phrase
+    if (q.boosts) query.boosted(q.boosts[0]);
+  } else {
+    std::vector<std::pair<Occur, Query>> clauses;
+    for (uint32_t t = 0; t < q.n_terms; ++t)
+      clauses.emplace_back(q.mode == TQ_MODE_AND ? Occur::Must : Occur::Should,
+                           Query::term_query(q.terms[t]).boosted(q.boosts ? q.boosts[t] : 1.0f));
+    query = Query::boolean(std::move(clauses));
+  }
+  return query;
+}
+
 // Query::weight for a batch (global statistics, executor choice).  Kept so that a benchmark can
 // time execution separately from weight construction, like tantivy's own benches do.
 int tqh_prepare_batch(tqh_searcher *s, const tqh_query *queries, uint32_t n) {
@@ -171,69 +237,7 @@ int tqh_prepare_batch(tqh_searcher *s, const tqh_query *queries, uint32_t n) {
     if (!s || !s->searcher) throw TantivyError(TantivyError::InvalidArgument, "no segments");
     s->prepared.clear();
     s->prepared.reserve(n);
-    for (uint32_t i = 0; i < n; ++i) {
-      const tqh_query &q = queries[i];
-      Query query;
-      if (q.mode > TQH_MODE_TERM)
-        throw TantivyError(TantivyError::InvalidArgument, "unknown query mode");
-      if (q.n_terms == 0) throw TantivyError(TantivyError::InvalidArgument, "query without terms");
-      if (q.mode == TQ_MODE_BOOL) {
-        if (!q.occurs) throw TantivyError(TantivyError::InvalidArgument, "TQ_MODE_BOOL needs occurs");
-        std::vector<std::pair<Occur, Query>> clauses;
-        std::vector<int> ids;  // clause_of value of every clause built so far
-        std::vector<uint32_t> first_term_of;  // index (in q.terms) of the clause's first term
-        for (uint32_t t = 0; t < q.n_terms; ++t) {
-          if (q.occurs[t] > 2) throw TantivyError(TantivyError::InvalidArgument, "bad occur");
-          const Occur oc = q.occurs[t] == 1 ? Occur::Must
-                                            : (q.occurs[t] == 2 ? Occur::MustNot : Occur::Should);
-          const int id = q.clause_of ? (int)q.clause_of[t] : -1;
-          size_t c = ids.size();
-          if (id >= 0)
-            for (c = 0; c < ids.size() && ids[c] != id; ++c) {}
-          if (c == ids.size()) {
-            ids.push_back(id);
-            first_term_of.push_back(t);
-            clauses.emplace_back(oc, Query::term_query(q.terms[t]).boosted(q.boosts ? q.boosts[t] : 1.0f));
-            continue;
-          }
-          if (clauses[c].first != oc)
-            throw TantivyError(TantivyError::InvalidArgument, "a clause mixes occurs");
-          Query &sub = clauses[c].second;
-          // occur of a term INSIDE its clause: Should (a nested union) unless nested_occurs says
-          // otherwise (`+a +(+b -c)`: clause_of {0,1,1}, occurs {1,1,1}, nested_occurs {255,1,2})
-          auto inner = [&](uint32_t tt) {
-            const uint8_t v = q.nested_occurs ? q.nested_occurs[tt] : 255;
-            if (v != 255 && v > 2) throw TantivyError(TantivyError::InvalidArgument, "bad nested occur");
-            return v == 1 ? Occur::Must : (v == 2 ? Occur::MustNot : Occur::Should);
-          };
-          if (sub.kind == Query::Term) {  // second term of the clause: it becomes a nested query
-            const Query first = sub;
-            sub = Query::boolean({{inner(first_term_of[c]), first}});
-          }
-          sub.clauses.emplace_back(inner(t),
-                                   Query::term_query(q.terms[t]).boosted(q.boosts ? q.boosts[t] : 1.0f));
-        }
-        query = Query::boolean(std::move(clauses));
-        query.set_minimum_number_should_match(q.min_should_match);
-      } else if (q.mode == TQH_MODE_TERM || (q.n_terms == 1 && q.mode != TQ_MODE_PHRASE)) {
-        query = Query::term_query(q.terms[0]).boosted(q.boosts ? q.boosts[0] : 1.0f);
-      } else if (q.mode == TQ_MODE_PHRASE) {
-        std::vector<std::pair<uint32_t, uint32_t>> pt;
-        for (uint32_t t = 0; t < q.n_terms; ++t)
-          pt.emplace_back(q.phrase_offsets ? q.phrase_offsets[t] : t, q.terms[t]);
-        query = Query::phrase_with_offsets(std::move(pt));
-        // BoostQuery around the PhraseQuery: PhraseWeight applies it with boost_by
-        // (phrase_weight.rs:42-69); boosts[0] is the factor of the whole phrase
-        if (q.boosts) query.boosted(q.boosts[0]);
-      } else {
-        std::vector<std::pair<Occur, Query>> clauses;
-        for (uint32_t t = 0; t < q.n_terms; ++t)
-          clauses.emplace_back(q.mode == TQ_MODE_AND ? Occur::Must : Occur::Should,
-                               Query::term_query(q.terms[t]).boosted(q.boosts ? q.boosts[t] : 1.0f));
-        query = Query::boolean(std::move(clauses));
-      }
-      s->prepared.push_back(s->searcher->weight(query));
-    }
+    for (uint32_t i = 0; i < n; ++i) s->prepared.push_back(s->searcher->weight(build_query(queries[i])));
   });
 }
 
@@ -253,6 +257,54 @@ int tqh_search_prepared(tqh_searcher *s, uint32_t offset, uint32_t limit, float 
         docs[q * limit + i] = real ? res[q][i].second.doc_id : TERMINATED;
       }
     }
+  });
+}
+
+// Searcher::search called from n_threads host threads at once, one query per call (the reference's
+// own call pattern, searcher.rs:180-238): thread t takes queries t, t + n_threads, ...  Every call
+// is Query::weight + one collect_segment per segment (tq_search_one: the calls of concurrent
+// threads ride in shared launches) + merge_fruits.  Outputs [n][limit] as tqh_search_prepared;
+// latency_ms[q] = wall time of query q's call (or null); *wall_ms = the whole run.
+int tqh_search_concurrent(tqh_searcher *s, const tqh_query *queries, uint32_t n, uint32_t offset,
+                          uint32_t limit, uint32_t n_threads, float *scores, uint32_t *segment_ords,
+                          uint32_t *docs, uint32_t *counts, float *latency_ms, double *wall_ms) {
+  return guard([&] {
+    if (!s || !s->searcher) throw TantivyError(TantivyError::InvalidArgument, "no segments");
+    if (!queries || !scores || !segment_ords || !docs || !counts || !n_threads)
+      throw TantivyError(TantivyError::InvalidArgument, "null argument");
+    const TopDocs td = TopDocs::with_limit(limit).and_offset(offset);
+    std::vector<std::string> errors(n_threads);
+    std::vector<TantivyError::Kind> kinds(n_threads, TantivyError::InvalidArgument);
+    const auto t0 = std::chrono::steady_clock::now();
+    auto work = [&](uint32_t t) {
+      try {
+        for (uint32_t qi = t; qi < n; qi += n_threads) {
+          const auto q0 = std::chrono::steady_clock::now();
+          const Fruit res = s->searcher->search(build_query(queries[qi]), td);
+          if (latency_ms)
+            latency_ms[qi] = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - q0).count();
+          counts[qi] = (uint32_t)res.size();
+          for (uint32_t i = 0; i < limit; ++i) {
+            const bool real = i < res.size();
+            scores[(size_t)qi * limit + i] = real ? res[i].first : 0.0f;
+            segment_ords[(size_t)qi * limit + i] = real ? res[i].second.segment_ord : 0xFFFFFFFFu;
+            docs[(size_t)qi * limit + i] = real ? res[i].second.doc_id : TERMINATED;
+          }
+        }
+      } catch (const TantivyError &e) {
+        errors[t] = e.what();
+        kinds[t] = e.kind;
+      } catch (const std::exception &e) {
+        errors[t] = e.what();
+      }
+    };
+    std::vector<std::thread> threads;
+    for (uint32_t t = 1; t < n_threads; ++t) threads.emplace_back(work, t);
+    work(0);
+    for (std::thread &th : threads) th.join();
+    if (wall_ms) *wall_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    for (uint32_t t = 0; t < n_threads; ++t)
+      if (!errors[t].empty()) throw TantivyError(kinds[t], errors[t]);
   });
 }
 

@@ -50,6 +50,7 @@ void SegmentReader::set_term_info_store(std::shared_ptr<const TermInfoStore> sto
   store_ = std::move(store);
 }
 const TermInfo *SegmentReader::get_term_info(uint32_t term_id) const {
+  std::lock_guard<std::mutex> lk(m_);  // (entries are never erased: the pointer stays valid)
   auto it = terms_.find(term_id);
   if (it == terms_.end() && store_ && term_id < store_->num_terms())
     it = terms_.emplace(term_id, store_->get(term_id)).first;
@@ -57,8 +58,11 @@ const TermInfo *SegmentReader::get_term_info(uint32_t term_id) const {
   return &it->second;
 }
 tq_term_handle SegmentReader::term_handle(uint32_t term_id) {
-  auto h = handles_.find(term_id);
-  if (h != handles_.end()) return h->second;
+  {
+    std::lock_guard<std::mutex> lk(m_);
+    auto h = handles_.find(term_id);
+    if (h != handles_.end()) return h->second;
+  }
   const TermInfo *ti = get_term_info(term_id);
   tq_term_handle handle = TQ_TERM_ABSENT;
   if (ti) {
@@ -67,8 +71,9 @@ tq_term_handle SegmentReader::term_handle(uint32_t term_id) {
                                    ti->positions_start,
                                    (uint32_t)(ti->positions_end - ti->positions_start),
                                    ti->doc_freq, &handle);
-    if (rc != TQ_OK) throw_tq(rc);
-  }
+    if (rc != TQ_OK) throw_tq(rc);  // (tq_term_prepare is idempotent per postings offset: two threads
+  }                                 // preparing the same term get the same handle)
+  std::lock_guard<std::mutex> lk(m_);
   handles_[term_id] = handle;
   return handle;
 }
@@ -107,12 +112,15 @@ Weight Searcher::weight(const Query &query) const {
   const uint64_t nd = total_num_docs(), nt = total_num_tokens();
   if (nd == 0)
     throw TantivyError(TantivyError::InvalidArgument, "no documents: BM25 statistics undefined");
-  if (!shared_cache_) {
-    const Score avg = (Score)nt / (Score)nd;
-    shared_cache_ = std::make_shared<Bm25Weight>(Bm25Weight::from_idf(0.0f, avg));
-  }
   Weight w;
-  w.bm25 = shared_cache_;
+  {
+    std::lock_guard<std::mutex> lk(cache_m_);
+    if (!shared_cache_) {
+      const Score avg = (Score)nt / (Score)nd;
+      shared_cache_ = std::make_shared<Bm25Weight>(Bm25Weight::from_idf(0.0f, avg));
+    }
+    w.bm25 = shared_cache_;
+  }
   // Weight::scorer(reader, boost) starts at 1.0; every BoostWeight multiplies its own factor in
   // (boost_query.rs:70-72) and the leaf applies Bm25Weight::boost_by(boost) (bm25.rs:82-92)
   auto boost_by = [](Score weight, Score boost) { return boost == 1.0f ? weight : weight * boost; };
@@ -362,8 +370,48 @@ std::vector<Fruit> Searcher::search_batch(const std::vector<Weight> &weights,
 }
 
 Fruit Searcher::search(const Query &query, const TopDocs &collector) {
-  std::vector<Weight> w{weight(query)};
-  return search_batch(w, collector)[0];
+  // Searcher::search_with_executor (searcher.rs:215-238): the weight once, then collect_segment per
+  // segment, then merge_fruits.  Callable from many threads: each collect_segment is a tq_search_one,
+  // which rides in whatever batch the segment launches next.
+  const Weight w = weight(query);
+  const size_t S = segments_.size();
+  const uint32_t k = (uint32_t)(collector.offset() + collector.limit());
+  if (k > TQ_MAX_K)
+    throw TantivyError(TantivyError::Unsupported, "offset+limit above the device heap size");
+  std::vector<float> all_scores(S * k);
+  std::vector<uint32_t> all_docs(S * k), all_counts(S);
+  std::vector<tq_term_handle> handles(w.terms.size());
+  for (size_t s = 0; s < S; ++s) {
+    SegmentReader &seg = *segments_[s];
+    for (size_t i = 0; i < w.terms.size(); ++i) handles[i] = seg.term_handle(w.terms[i]);
+    tq_query q{};
+    q.n_terms = (uint32_t)w.terms.size();
+    q.terms = handles.data();
+    q.weights = w.weights.data();
+    q.tf_cache = w.bm25->cache;
+    q.mode = w.mode;
+    q.phrase_offsets = w.phrase_offsets.empty() ? nullptr : w.phrase_offsets.data();
+    q.k = k;
+    q.occurs = w.occurs.empty() ? nullptr : w.occurs.data();
+    q.clause_of = w.clause_of.empty() ? nullptr : w.clause_of.data();
+    q.min_should_match = w.min_should_match;
+    const tq_search_opts opts{-1, bound_slack_ppm(seg)};
+    const int rc = tq_search_one(seg.raw(), &q, &opts, all_scores.data() + s * k, all_docs.data() + s * k,
+                                 all_counts.data() + s);
+    if (rc != TQ_OK) throw_tq(rc);
+  }
+  const uint32_t limit = (uint32_t)collector.limit(), offset = (uint32_t)collector.offset();
+  std::vector<float> out_s(limit);
+  std::vector<uint32_t> out_o(limit), out_d(limit);
+  uint32_t out_c = 0;
+  const int rc = tq_merge_topk(all_scores.data(), all_docs.data(), all_counts.data(), (uint32_t)S, 1u, k, offset,
+                               limit, out_s.data(), out_o.data(), out_d.data(), &out_c);
+  if (rc != TQ_OK) throw_tq(rc);
+  Fruit res;
+  res.reserve(out_c);
+  for (uint32_t i = 0; i < out_c; ++i)
+    res.push_back({out_s[i], DocAddress{segments_[out_o[i]]->segment_ord(), out_d[i]}});
+  return res;
 }
 
 }  // namespace tantivy_amd

@@ -10,6 +10,7 @@
 // plus a term -> TermInfo table that the reference's TermDictionary would supply.
 #pragma once
 #include <memory>
+#include <mutex>
 #include <stdexcept>
 #include <string>
 #include <unordered_map>
@@ -77,6 +78,7 @@ class SegmentReader {
   uint32_t segment_ord_, max_doc_;
   uint8_t record_option_;
   uint64_t total_num_tokens_ = 0;
+  mutable std::mutex m_;  // term tables: Searcher::search may be called from many threads
   mutable std::unordered_map<uint32_t, TermInfo> terms_;
   std::unordered_map<uint32_t, tq_term_handle> handles_;
   std::shared_ptr<const class TermInfoStore> store_;
@@ -189,7 +191,9 @@ class Searcher {
                              const std::vector<std::pair<uint32_t, uint32_t>> &term_doc_freqs);
 
   Weight weight(const Query &query) const;
-  // Searcher::search (searcher.rs:180-238) for one query / a batch of queries
+  // Searcher::search (searcher.rs:180-238) for one query / a batch of queries.  search() may be
+  // called from any number of threads at once, like the reference's: the per-segment
+  // collect_segment calls of concurrent searches are coalesced into batched launches (tq_search_one)
   Fruit search(const Query &query, const TopDocs &collector);
   std::vector<Fruit> search_batch(const std::vector<Weight> &weights, const TopDocs &collector);
   // Searcher::search(&query, &Count) for a batch (count_collector.rs:39-80: per-segment counts of
@@ -211,6 +215,7 @@ class Searcher {
   // passed with every call (tq_search_opts)
   uint32_t bound_slack_ppm(const SegmentReader &seg) const;
   std::vector<std::shared_ptr<SegmentReader>> segments_;
+  mutable std::mutex cache_m_;
   mutable std::shared_ptr<Bm25Weight> shared_cache_;  // one tf cache per field (avg fieldnorm)
   uint64_t remote_docs_ = 0, remote_tokens_ = 0;
   std::unordered_map<uint32_t, uint64_t> remote_doc_freq_;
