@@ -26,7 +26,13 @@ import subprocess
 import sys
 import time
 
-import numpy as np
+# The GPU box shows 256 CPUs and grants 16 (cgroup cpu.max): OpenMP / BLAS pools sized by the former
+# (torch: 128 threads) spin between parallel regions, burn the quota and get the WHOLE process throttled
+# for the rest of a 100 ms period — seen as 10-70 ms stalls of single steps.  Nothing here needs them.
+for _v in ("OMP_NUM_THREADS", "OPENBLAS_NUM_THREADS", "MKL_NUM_THREADS", "NUMEXPR_NUM_THREADS"):
+    os.environ.setdefault(_v, "4")
+
+import numpy as np  # noqa: E402
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
@@ -134,7 +140,7 @@ def build_queries(O, workload, n, k, terms=256):
         # the shapes of the reference's union_intersection group (benches/and_or_queries.rs:150-153):
         # `+c +(b OR d)`, `+e +(c OR a)`, `+(c OR b) +(d OR e)`, plus `+a b -c`
         import tantivy_amd as T
-        ids = O.zipf_queries(n, 4, 256, seed=20260924)
+        ids = O.zipf_queries(n, 4, terms, seed=20260924)
         M, S, N = T.MUST, T.SHOULD, T.MUST_NOT
         shapes = [(3, [M, M, M], [0, 1, 1]), (4, [M, M, M, M], [0, 0, 1, 1]),
                   (3, [M, S, N], None), (3, [M, M, M], [0, 0, 1])]
@@ -344,16 +350,23 @@ def measure(cl, runner, torch, queries, k, steps, warmup, time_exhaustive=False)
     _, prn_st2 = one(False, 2)
     same = all(np.array_equal(a, b) for a, b in zip(exh_out, prn_out))
     runner.set_option("exhaustive", 1 if time_exhaustive else 0)
-    for _ in range(warmup):
-        runner.enqueue()
-        runner.synchronize()
+    for _ in range(warmup):  # (pipelined like the timed steps: the first time two steps are in flight
+        runner.enqueue()     # at once the runtime grows its pools — a 7-10 ms hiccup that belongs here)
+    runner.synchronize()
     runner.batch_stats()  # start a fresh timing window
     cl.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
+    marks = []
     for _ in range(steps):
         runner.enqueue()  # steps are pipelined: one synchronisation closes the timed region
+        if os.environ.get("BENCH_TRACE"):
+            marks.append(time.perf_counter())
     runner.synchronize()
+    if marks:  # (diagnosis: host time of every enqueue call, then the final wait)
+        print("[bench] enqueue ms: %s | final wait %.3f" % (
+            " ".join("%.2f" % ((b - a) * 1e3) for a, b in zip([t0] + marks[:-1], marks)),
+            (time.perf_counter() - marks[-1]) * 1e3), file=sys.stderr)
     torch.cuda.synchronize()
     cl.barrier()
     elapsed = cl.max_over_ranks(time.perf_counter() - t0)
@@ -512,6 +525,7 @@ def main():
         raise SystemExit(selftest_launcher(cl.rank, cl.world))
     import torch
 
+    torch.set_num_threads(4)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (no CPU fallback exists for the product path)")
     if torch.cuda.device_count() <= cl.local_rank:

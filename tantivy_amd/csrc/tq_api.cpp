@@ -3408,8 +3408,8 @@ int search_batch_impl(tq_segment *s, const tq_query *queries, uint32_t n_queries
   if (trace) {
     const auto tr3 = std::chrono::steady_clock::now();
     auto us = [](auto a, auto b) { return (long)std::chrono::duration_cast<std::chrono::microseconds>(b - a).count(); };
-    fprintf(stderr, "[tq] plan %ld us (pre-pass %ld us, queries %ld us, chunks %ld us), stage fill %ld us, enqueue %ld us, stage bytes %zu\n",
-            us(tr0, tr1), us(tr0, tr0a), us(tr0a, tr0b), us(tr0b, tr1), us(tr1, tr2), us(tr2, tr3), stage);
+    fprintf(stderr, "[tq] plan %ld us (pre-pass %ld us, queries %ld us, chunks %ld us), wait for the staging buffer %ld us, stage fill %ld us, enqueue %ld us, stage bytes %zu\n",
+            us(tr0, tr1), us(tr0, tr0a), us(tr0a, tr0b), us(tr0b, tr1), us(tr1, tr1w), us(tr1w, tr2), us(tr2, tr3), stage);
   }
   s->stats.algorithmic_bytes = algo_bytes;
   s->stats.tiles = tiles_total;
