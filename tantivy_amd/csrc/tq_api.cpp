@@ -195,6 +195,14 @@ struct tq_segment {
   size_t d_terms_cap = 0;
   bool d_terms_dirty = false;
   size_t dense_bytes_total = 0;
+  // The side tables of the dense lists (bitmaps + rank directories, byte-wide tfs, position directories,
+  // plain lists) live in ONE device allocation of dense_budget() bytes, made with the first of them:
+  // the term-major launches address them as 32-bit offsets (8-byte units) from its base.  (With one
+  // hipMalloc per table the allocator now and then returned addresses more than 32 GB apart and the
+  // launches silently fell back to the per-query kernels.)  What does not fit falls back to hipMalloc.
+  uint8_t *dense_arena = nullptr;
+  size_t dense_arena_cap = 0, dense_arena_used = 0;
+  std::vector<void *> dense_extra;  // tables allocated outside the arena
   // resident bytes by kind (tq_segment_get_stats)
   size_t bytes_term_tables = 0, bytes_bitmaps = 0, bytes_docmat = 0, bytes_posdir = 0, bytes_alive = 0;
   uint32_t n_dense_lists = 0;
@@ -276,15 +284,53 @@ int ensure_docmat(tq_segment *s);
 // packed value"): with the posting index from the bitmap's rank the tf of a candidate is ONE load,
 // where block record -> packed tf bits are two dependent ones (the shared-union kernel's scoring
 // stage is a chain of dependent gathers, 1.6 us each under load).  d_tfs = the decoded tfs.
+// a side table of a dense list: from the segment's arena, else a device allocation of its own
+int dense_alloc(tq_segment *s, size_t bytes, void **out) {
+  const size_t need = (bytes + 255) & ~(size_t)255;
+  if (!s->dense_arena && s->dense_arena_cap == 0) {
+    const size_t cap = std::max<size_t>(s->dense_budget(), (size_t)1 << 20) + PAD;
+    void *base = nullptr;
+    if (hipMalloc(&base, cap) == hipSuccess) {
+      s->dense_arena = (uint8_t *)base;
+      s->dense_arena_cap = cap;
+    } else {
+      (void)hipGetLastError();
+      s->dense_arena_cap = 1;  // (tried once: every table gets its own allocation)
+    }
+  }
+  if (s->dense_arena && s->dense_arena_used + need + PAD <= s->dense_arena_cap) {
+    *out = s->dense_arena + s->dense_arena_used;
+    s->dense_arena_used += need;
+    return TQ_OK;
+  }
+  void *ptr = nullptr;
+  HIP_TRY(hipMalloc(&ptr, bytes));
+  s->dense_extra.push_back(ptr);
+  *out = ptr;
+  return TQ_OK;
+}
+// (tables are only ever released with the segment; a failed build leaves its bytes unused)
+void dense_release(tq_segment *s, void *ptr) {
+  for (size_t i = 0; i < s->dense_extra.size(); ++i)
+    if (s->dense_extra[i] == ptr) {
+      (void)hipFree(ptr);
+      s->dense_extra.erase(s->dense_extra.begin() + (long)i);
+      return;
+    }
+}
+
 int build_tf8(tq_segment *s, uint32_t handle, const uint32_t *d_tfs) {
   TermHost &t = s->terms[handle];
   const size_t bytes = ((size_t)t.doc_freq + 7) & ~(size_t)7;
   if (s->dense_bytes_total + bytes > s->dense_budget()) return TQ_OK;
   void *blob = nullptr;
-  HIP_TRY(hipMalloc(&blob, bytes + PAD));
+  {
+    const int arc = dense_alloc(s, bytes + PAD, &blob);
+    if (arc != TQ_OK) return arc;
+  }
   hipError_t e = tqk_launch_tf8_pack(d_tfs, t.doc_freq, (uint8_t *)blob, s->stream);
   if (e != hipSuccess) {
-    (void)hipFree(blob);
+    dense_release(s, blob);
     return fail(TQ_ERR_HIP, "tf8 pack: %s", hipGetErrorString(e));
   }
   t.tf8_blob = blob;
@@ -309,11 +355,14 @@ int build_flat(tq_segment *s, uint32_t handle, hipStream_t st, bool *ok) {
   int rc = sync_terms(s, st);
   if (rc != TQ_OK) return rc;
   void *blob = nullptr;
-  HIP_TRY(hipMalloc(&blob, bytes + PAD));
+  {
+    const int arc = dense_alloc(s, bytes + PAD, &blob);
+    if (arc != TQ_OK) return arc;
+  }
   const hipError_t e = tqk_launch_flat_list(s->dseg, s->d_terms, handle, t.n_blocks, (uint32_t *)blob,
                                             (uint8_t *)blob + doc_bytes, st);
   if (e != hipSuccess) {
-    (void)hipFree(blob);
+    dense_release(s, blob);
     return fail(TQ_ERR_HIP, "flat list: %s", hipGetErrorString(e));
   }
   t.flat_blob = blob;
@@ -444,12 +493,15 @@ int build_dense(tq_segment *s, uint32_t handle) {
     running += (uint32_t)__builtin_popcount(tab[w].x);
   }
   void *blob = nullptr;
-  HIP_TRY(hipMalloc(&blob, n_words * sizeof(uint2)));
+  {
+    const int arc = dense_alloc(s, n_words * sizeof(uint2), &blob);
+    if (arc != TQ_OK) return arc;
+  }
   s->bytes_bitmaps += n_words * sizeof(uint2);
   ++s->n_dense_lists;
   hipError_t ce = hipMemcpy(blob, tab.data(), n_words * sizeof(uint2), hipMemcpyHostToDevice);
   if (ce != hipSuccess) {
-    (void)hipFree(blob);
+    dense_release(s, blob);
     return fail(TQ_ERR_HIP, "dense upload: %s", hipGetErrorString(ce));
   }
   t.dense_blob = blob;
@@ -468,10 +520,13 @@ int build_dense(tq_segment *s, uint32_t handle) {
       return fail(TQ_ERR_FORMAT, "term freqs sum to %llu positions, the stream holds %llu",
                   (unsigned long long)run, (unsigned long long)t.n_positions);
     void *db = nullptr;
-    HIP_TRY(hipMalloc(&db, n_dir * sizeof(uint32_t) + PAD));
+    {
+      const int arc = dense_alloc(s, n_dir * sizeof(uint32_t) + PAD, &db);
+      if (arc != TQ_OK) return arc;
+    }
     hipError_t de = hipMemcpy(db, dir.data(), n_dir * sizeof(uint32_t), hipMemcpyHostToDevice);
     if (de != hipSuccess) {
-      (void)hipFree(db);
+      dense_release(s, db);
       return fail(TQ_ERR_HIP, "position directory upload: %s", hipGetErrorString(de));
     }
     t.posdir_blob = db;
@@ -623,15 +678,10 @@ void tq_segment_free(tq_segment *s) {
   for (auto &t : s->terms)
     if (t.blob) (void)hipFree(t.blob);
   for (auto &t : s->terms)
-    if (t.dense_blob) (void)hipFree(t.dense_blob);
-  for (auto &t : s->terms)
-    if (t.posdir_blob) (void)hipFree(t.posdir_blob);
-  for (auto &t : s->terms)
-    if (t.tf8_blob) (void)hipFree(t.tf8_blob);
-  for (auto &t : s->terms)
     if (t.pos_blob) (void)hipFree(t.pos_blob);
-  for (auto &t : s->terms)
-    if (t.flat_blob) (void)hipFree(t.flat_blob);
+  // (bitmaps, byte-wide tfs, position directories, plain lists: the arena and its overflow)
+  if (s->dense_arena) (void)hipFree(s->dense_arena);
+  for (void *ptr : s->dense_extra) (void)hipFree(ptr);
   if (s->d_terms) (void)hipFree(s->d_terms);
   if (s->d_idx) (void)hipFree(s->d_idx);
   if (s->d_pos) (void)hipFree(s->d_pos);
@@ -1094,7 +1144,10 @@ int build_dense_device(tq_segment *s, uint32_t handle) {
   if (rc != TQ_OK) return rc;
   const size_t n_words = ((size_t)s->max_doc + 31) / 32 + 1;
   void *blob = nullptr;
-  HIP_TRY(hipMalloc(&blob, n_words * sizeof(uint2)));
+  {
+    const int arc = dense_alloc(s, n_words * sizeof(uint2), &blob);
+    if (arc != TQ_OK) return arc;
+  }
   s->bytes_bitmaps += n_words * sizeof(uint2);
   ++s->n_dense_lists;
   uint32_t *bad = (uint32_t *)s->d_tp_info;
@@ -1106,7 +1159,7 @@ int build_dense_device(tq_segment *s, uint32_t handle) {
   if (e == hipSuccess) e = hipMemcpyAsync(&h_bad, bad, 4, hipMemcpyDeviceToHost, s->stream);
   if (e == hipSuccess) e = hipStreamSynchronize(s->stream);
   if (e != hipSuccess || h_bad) {
-    (void)hipFree(blob);
+    dense_release(s, blob);
     return e != hipSuccess ? fail(TQ_ERR_HIP, "dense tables: %s", hipGetErrorString(e))
                            : fail(TQ_ERR_FORMAT, "posting list not strictly increasing below max_doc");
   }
@@ -1128,14 +1181,17 @@ int build_dense_device(tq_segment *s, uint32_t handle) {
   if (t.positions_len > 0) {  // position directory: positions before every fourth posting
     const size_t n_dir = ((size_t)t.doc_freq + 3) / 4 + 1;
     void *db = nullptr;
-    HIP_TRY(hipMalloc(&db, n_dir * sizeof(uint32_t) + PAD));
+    {
+      const int arc = dense_alloc(s, n_dir * sizeof(uint32_t) + PAD, &db);
+      if (arc != TQ_OK) return arc;
+    }
     e = tqp_launch_posdir(dt, t.doc_freq, (uint32_t *)db, (uint32_t)n_dir, s->stream);
     uint32_t total = 0;
     if (e == hipSuccess)
       e = hipMemcpyAsync(&total, (uint32_t *)db + (n_dir - 1), 4, hipMemcpyDeviceToHost, s->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(s->stream);
     if (e != hipSuccess || total != (uint32_t)t.n_positions) {
-      (void)hipFree(db);
+      dense_release(s, db);
       return e != hipSuccess ? fail(TQ_ERR_HIP, "position directory: %s", hipGetErrorString(e))
                              : fail(TQ_ERR_FORMAT, "term freqs sum to %u positions, the stream holds %llu",
                                     total, (unsigned long long)t.n_positions);
@@ -2154,7 +2210,7 @@ int build_ashare_plan(tq_segment *s, Group &g, PlanScratch &ps) {
   // thresholds it finds, and with thresholds of zero the first wavefronts (an eighth of the batch)
   // sent every match through the scoring stage — a warm-up over a fraction of a percent of the blocks
   // leaves the main launch the k-th best of a sample of every query to start from.
-  static const uint32_t kWarmPermille = std::min<uint32_t>(1000u, tune_u32("TQ_AS_WARM_PERMILLE", 5));
+  static const uint32_t kWarmPermille = std::min<uint32_t>(1000u, tune_u32("TQ_AS_WARM_PERMILLE", 2));
   static const uint32_t kWarmBlocks = std::max<uint32_t>(1u, tune_u32("TQ_AS_WARM_BLOCKS", 2));
   std::vector<uint4> &tasks = ps.atasks, &raw = ps.atasks_unsorted;
   std::vector<uint32_t> &pos = ps.atask_pos, &pairs = ps.apairs;

@@ -44,12 +44,18 @@
 #ifndef TQ_AS_WAVES
 #define TQ_AS_WAVES 8
 #endif
+#ifndef TQ_AS_TIMERS
+#define TQ_AS_TIMERS 0  // region timers (tools/probe_ashare_regions.sh builds a variant with them)
+#endif
+#ifndef TQ_AS_PREFETCH
+#define TQ_AS_PREFETCH 0  // 1: the next wanted block's payload is fetched into LDS (global_load_lds) under the current block's work — measured: no gain (the chain is the doc-matrix gather), 1 KB of LDS
+#endif
 
 namespace {
 
 constexpr uint32_t AS_GROUP = TQD_AS_GROUP;
 
-struct AShareLds {  // per wavefront: 3828 bytes (32 wavefronts per CU fit the 160 KB)
+struct AShareLds {  // per wavefront: 4868 bytes (32 wavefronts per CU fit the 160 KB)
   float cache[256];                            // Bm25Weight.cache of the task's queries
   uint32_t q_doc[127], q_tf[127], q_tag[127];  // survivors: doc, leader tf, lead slot | fieldnorm id << 8
   TqdALeadLds lead[AS_GROUP];                  // the leads of the task (what the scoring stage needs)
@@ -57,6 +63,9 @@ struct AShareLds {  // per wavefront: 3828 bytes (32 wavefronts per CU fit the 1
   uint32_t lk[AS_GROUP];                       // k of its query (bits 0..7) | its row of threshold slots << 8
   uint32_t cnt[AS_GROUP];                      // bits 0..15: entries in the slot's staging list; 16..31: docs scored
   uint32_t flen[AS_GROUP];                     // per family head: leads in the family (itself + its twins)
+#if TQ_AS_PREFETCH
+  uint32_t pay[260];                           // the NEXT wanted block's bitpacked payload (<= 1008 B), landed by LDS-DMA
+#endif
 };
 
 // k-th largest of the n (<= 64 R) keys held R per lane (0 = empty); n >= k
@@ -102,6 +111,19 @@ ashare_kernel(TqkAShareParams p) {
   uint32_t qn = 0;        // survivor queue fill
   uint32_t n_scored = 0;  // docs scored by this wave (all tasks)
   uint32_t n_leads = 0;
+  // PROFILING (-DTQ_AS_TIMERS=1, TQ_DEBUG bits 16..19 = region): wave cycles spent inside ONE region per
+  // run, summed into the match counter (>> 6).  1 everything, 2 task fetch + setup, 3 pre-filter, 4 stage A
+  // (payload + unpack + prefix sum), 5 stage A: doc-matrix gather + tf/(tf+norm), 6 stage F, 7 stage C,
+  // 8 flush, 9 threshold refresh
+  const uint32_t tphase = TQ_AS_TIMERS ? (p.debug >> 16) & 15u : 0u;
+  uint64_t tacc = 0, tlast = 0;
+  auto tb = [&](uint32_t ph) __attribute__((always_inline)) {
+    if (TQ_AS_TIMERS && tphase == ph) tlast = __builtin_readcyclecounter();
+  };
+  auto te = [&](uint32_t ph) __attribute__((always_inline)) {
+    if (TQ_AS_TIMERS && tphase == ph) tacc += __builtin_readcyclecounter() - tlast;
+  };
+  tb(1u);
 
   // a staging list is cut back to its k best; returns the k-th key (the list held n > k entries)
   auto compact_slot = [&](uint32_t g, uint32_t n, uint32_t k) __attribute__((always_inline)) -> uint64_t {
@@ -128,6 +150,8 @@ ashare_kernel(TqkAShareParams p) {
 
   // ---- stage C: 64 survivors, every lane with its own query
   auto stageC = [&](uint32_t n) __attribute__((always_inline)) {
+    te(6u);
+    tb(7u);
     const uint32_t base = qn - n;
     qn = base;
     if (p.debug & 64u) n_scored += n;  // COUNTERS
@@ -206,7 +230,11 @@ ashare_kernel(TqkAShareParams p) {
     if (alive) alive = sortable(s) >= thr;
     if (alive) alive = doc_is_alive(seg, doc);
     const uint64_t hit = __ballot(alive);
-    if (!hit) return;
+    if (!hit) {
+      te(7u);
+      tb(6u);
+      return;
+    }
     if (!(p.debug & 0x7FE0u)) n_scored += (uint32_t)__popcll(hit);  // COUNTERS (TQ_DEBUG): 32 (block, family) pairs,
     const uint64_t key = alive ? make_key(s, doc) : 0ull;           // 64 stage-C candidates, 256 blocks decoded
     const uint32_t sb = (uint32_t)(key >> 32);
@@ -237,9 +265,12 @@ ashare_kernel(TqkAShareParams p) {
       }
     }
     wave_mem_fence();
+    te(7u);
+    tb(6u);
   };
 
   for (;;) {
+    tb(2u);
     uint32_t task = 0;
     if (lane == 0) task = atomicAdd(p.task_counter, 1u);
     task = uni(task) + p.task_begin;
@@ -313,13 +344,17 @@ ashare_kernel(TqkAShareParams p) {
       }
     };
     update_families();
+    te(2u);
 
     for (uint32_t jt = 0; jt < nb_task && live; jt += TQD_AS_TILE) {
       if (jt) {  // thresholds may have risen since the last step
+        tb(9u);
         refresh_thr();
         update_families();
+        te(9u);
         if (!live) break;
       }
+      tb(3u);
       // ---- pre-filter: lane <-> block
       const uint32_t nb = nb_task - jt < TQD_AS_TILE ? nb_task - jt : TQD_AS_TILE;
       const uint32_t i_base = j0 + jt;
@@ -350,35 +385,113 @@ ashare_kernel(TqkAShareParams p) {
       uint32_t prev_mine = __shfl_up(rec_mine.x, 1, WAVE);
       if (lane == 0) prev_mine = block_prev_last(lead, i_base);
       uint32_t since_refresh = 0;
+      te(3u);
+#if TQ_AS_PREFETCH
+      // The payload of the NEXT wanted block travels to LDS (global_load_lds: one 16-byte row per lane,
+      // no registers) while the current block's doc-matrix gathers, tests and scoring run: a block's
+      // chain of dependent round trips loses its first link.
+      auto prefetch = [&](uint64_t rest) __attribute__((always_inline)) {
+        if (!rest) return;
+        const uint32_t nb2 = (uint32_t)__builtin_ctzll(rest);
+        const uint32_t meta = (uint32_t)__builtin_amdgcn_readlane((int)rec_mine.y, (int)nb2);
+        const uint32_t off = (uint32_t)__builtin_amdgcn_readlane((int)rec_mine.z, (int)nb2);
+        if (meta == META_TAIL) return;
+        const uint32_t nbytes = 16u * ((meta & 31u) + (lead.has_freq ? (meta >> 8) & 0xFFu : 0u));
+        const uint32_t o = 16u * (uint32_t)lane;
+        if (o < nbytes)
+          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(idx + lead.payload_base + off + o),
+                                           (__attribute__((address_space(3))) void *)L.pay, 16, 0, 0);
+      };
+      wave_mem_fence();
+      prefetch(todo);
+#endif
       while (todo) {
         const uint32_t b = (uint32_t)__builtin_ctzll(todo);
         todo &= todo - 1ull;
         if (++since_refresh == 8u) {  // thresholds rise while the tile is walked
           since_refresh = 0;
+          tb(9u);
           refresh_thr();
           update_families();
+          te(9u);
           if (!live) break;
         }
+        tb(4u);
         uint32_t lm = (uint32_t)__builtin_amdgcn_readlane((int)pass_mask, (int)b) & live_heads;
-        if (!lm) continue;
         const uint32_t prev_l = (uint32_t)__builtin_amdgcn_readlane((int)prev_mine, (int)b);
         const uint2 mo_l = make_uint2((uint32_t)__builtin_amdgcn_readlane((int)rec_mine.y, (int)b),
                                       (uint32_t)__builtin_amdgcn_readlane((int)rec_mine.z, (int)b));
+#if TQ_AS_PREFETCH
+        if (!lm) {  // (its families died since the pre-filter: the landed payload is dropped)
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          wave_mem_fence();
+          prefetch(todo);
+          te(4u);
+          continue;
+        }
+#else
+        if (!lm) {
+          te(4u);
+          continue;
+        }
+#endif
         if (p.debug & 256u) ++n_scored;  // COUNTERS
-        // ---- stage A: decode the block once (straight from global memory: no LDS staging — the
-        // blocks are decoded once per group here, not once per query)
+        // ---- stage A: decode the block once
         uint32_t c0, c1, t0, t1;
+#if TQ_AS_PREFETCH
+        if (mo_l.x == META_TAIL) {
+          decode_docs<USE_DPP>(idx, lead, mo_l, prev_l, lane, c0, c1);
+          decode_tfs(idx, lead, mo_l, lane, t0, t1);
+        } else {
+          const uint32_t doc_bits = mo_l.x & 31u;
+          const uint32_t strict = (mo_l.x >> 6) & 1u;
+          const uint32_t tf_bits = lead.has_freq ? (mo_l.x >> 8) & 0xFFu : 0u;
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the prefetched payload has landed
+          wave_mem_fence();
+          if (lead.has_freq) {
+            unpack2_lds(L.pay + 4u * doc_bits, tf_bits, lane, t0, t1);
+            t0 += strict;  // minus-one encoding is tied to the strict flag
+            t1 += strict;
+          } else {
+            t0 = 1u;
+            t1 = 1u;
+          }
+          uint32_t x0, x1;
+          unpack2_lds(L.pay, doc_bits, lane, x0, x1);
+          finish_docs<USE_DPP>(x0, x1, strict, prev_l, lane, c0, c1);
+        }
+        wave_mem_fence();  // (every lane has read its payload words: the next block's may land)
+        prefetch(todo);
+#else
         decode_docs<USE_DPP>(idx, lead, mo_l, prev_l, lane, c0, c1);
         decode_tfs(idx, lead, mo_l, lane, t0, t1);
+#endif
+        if (TQ_AS_TIMERS && tphase == 4u && c0 == 0xFFFFFFFEu) ++n_scored;  // (the decode has to land inside the region)
+        te(4u);
+        tb(5u);
         const bool v0 = c0 != TQD_TERMINATED, v1 = c1 != TQD_TERMINATED;
-        // ONE gather per doc: fieldnorm id + membership in every column list + signature bits
-        const uint64_t mw0 = v0 ? seg.docmat[c0] : 0ull;
-        const uint64_t mw1 = v1 ? seg.docmat[c1] : 0ull;
-        const uint32_t nid0 = (uint32_t)mw0 & 0xFFu, nid1 = (uint32_t)mw1 & 0xFFu;
+        // The leader's tf/(tf+norm) from the fieldnorm BYTES first (1 B per doc: the part of the file the
+        // chip is working on stays in the L2s), and the loosest bound any family of this block still
+        // accepts: only docs that pass it pay the doc-matrix gather (8 B per doc out of a table that does
+        // not fit the L2s: a 128-byte fabric request each — with every doc gathered the launch moved
+        // 5.5 TB/s of them and waited for that).
+        float block_need = 3.0e38f;
+        for (uint32_t x = lm; x; x &= x - 1u) {
+          const float nd = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(fam_need), (int)__builtin_ctz(x)));
+          block_need = nd < block_need ? nd : block_need;
+        }
+        const uint32_t nid0 = v0 ? fieldnorm_id(seg, c0) : 0u, nid1 = v1 ? fieldnorm_id(seg, c1) : 0u;
         const float f0 = (float)t0, f1 = (float)t1;
         const float tfn0 = f0 * __builtin_amdgcn_rcpf(f0 + L.cache[nid0]);
         const float tfn1 = f1 * __builtin_amdgcn_rcpf(f1 + L.cache[nid1]);
-        const uint64_t valid0 = __ballot(v0), valid1 = __ballot(v1);
+        const bool g0 = v0 && tfn0 >= block_need, g1 = v1 && tfn1 >= block_need;
+        // ONE gather per doc that may matter: membership in every column list + signature bits
+        const uint64_t mw0 = g0 ? seg.docmat[c0] : 0ull;
+        const uint64_t mw1 = g1 ? seg.docmat[c1] : 0ull;
+        const uint64_t valid0 = __ballot(g0), valid1 = __ballot(g1);
+        if (TQ_AS_TIMERS && tphase == 5u && (uint32_t)mw0 == 0xFFFFFFFEu) ++n_scored;  // (the gathers have to land inside the region)
+        te(5u);
+        tb(6u);
         // ---- stage F: every family that wants the block
         uint32_t pm_lo = 0, pm_hi = 0;
         uint64_t mem0 = valid0, mem1 = valid1;  // (mask 0: every doc)
@@ -421,9 +534,13 @@ ashare_kernel(TqkAShareParams p) {
             while (qn >= 64u) stageC(64u);
           }
         }
+        te(6u);
       }
     }
+    tb(6u);
     while (qn) stageC(qn < 64u ? qn : 64u);
+    te(6u);
+    tb(8u);
 
     // ---- flush: the heads' staging lists go to the result lists of every member of their families
     wave_mem_fence();
@@ -459,8 +576,9 @@ ashare_kernel(TqkAShareParams p) {
         if (gth) atomicMax(p.thr_val + mq, gth);
         atomicAdd(sload(&p.sinks->query_matches) + sload(&p.sinks->out_index)[mq], scs);
       }
-      if (lane == 0) thr_now = __hip_atomic_load(p.thr_val + mq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      thr_now = uni(thr_now);
+      // (what this wave knows: the head's threshold as of its last refresh and the select just done;
+      // another round trip for the word's current value bought nothing)
+      thr_now = uni(L.lthr[gs]);
       if (gth > thr_now) thr_now = gth;
       if (!ns) continue;
       const uint64_t *sl = my_stage + (size_t)gs * CAPL;
@@ -499,7 +617,10 @@ ashare_kernel(TqkAShareParams p) {
         }
       }
     }
+    te(8u);
   }
+  te(1u);
+  if (tphase) n_scored = (uint32_t)(tacc >> 6);
   if (lane == 0 && n_scored) atomicAdd(sload(&p.sinks->match_counter), (unsigned long long)n_scored);
 }
 
