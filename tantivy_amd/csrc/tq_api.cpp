@@ -1528,6 +1528,10 @@ static uint32_t plan_threads() {
 static const uint32_t kPlanParMin = tune_u32("TQ_PLAN_PAR_MIN", 16384);
 static const uint32_t kOrChunkMul = std::max<uint32_t>(1u, tune_u32("TQ_OR_CHUNK_MUL", 4));
 static const uint32_t kOrChunkMulSmallK = std::max<uint32_t>(1u, tune_u32("TQ_OR_CHUNK_MUL_SMALLK", 8));
+// boolean queries (the union kernel's BOOL instantiation): measured on the bench shapes, kernel / host ms
+// per 2000 queries: x8 6.05 / 4.26, x4 6.02 / 3.48, x2 6.04 / 1.77, x1 6.32 / 1.13 — the chunk records
+// and partial lists of 1 M chunks bought nothing
+static const uint32_t kBoolChunkMul = std::max<uint32_t>(1u, tune_u32("TQ_BOOL_CHUNK_MUL", 2));
 
 // stable sort of a handful of items (<= TQ_MAX_TERMS): std::stable_sort allocates a buffer per call,
 // which was a quarter of the per-query planning time of a 10 000-query batch
@@ -1548,7 +1552,7 @@ int kpl_for(uint32_t k) { return k <= 64 ? 1 : (k <= 128 ? 2 : (k <= 256 ? 4 : 1
 
 // tiles -> chunks of one launch group: runs of consecutive tiles of about equal estimated cost,
 // their launch order (doc-range slices) and the number of partial lists per query
-int build_group_chunks(Group &g, bool or_windows, PlanScratch &ps) {
+int build_group_chunks(Group &g, bool or_windows, PlanScratch &ps, bool boolean_group = false) {
   static const bool ptrace = getenv("TQ_PLAN_TRACE") != nullptr;  // phase times of the planner
   auto pt_last = std::chrono::steady_clock::now();
   auto pt = [&](const char *what) {
@@ -1657,7 +1661,9 @@ int build_group_chunks(Group &g, bool or_windows, PlanScratch &ps) {
   // threshold); with large k the partial lists (1 KB per chunk and query) and the host's
   // planning time per chunk weigh more
   const uint64_t n_target =
-      or_win ? 8192u : (or_cand ? (g.max_k <= 16u ? kOrChunkMulSmallK : kOrChunkMul) * kAndChunks : kAndChunks);
+      or_win ? 8192u
+             : (or_cand ? (boolean_group ? kBoolChunkMul : (g.max_k <= 16u ? kOrChunkMulSmallK : kOrChunkMul)) * kAndChunks
+                        : kAndChunks);
   const uint64_t cost_target = std::max<uint64_t>(or_win ? 1u : 128u,
                                                   (total_cost + n_target - 1) / n_target);
   pt("costs");
@@ -3038,7 +3044,8 @@ int search_batch_impl(tq_segment *s, const tq_query *queries, uint32_t n_queries
     const int crc = &g == &groups[kShare]    ? build_share_plan(s, g, *s->plan)
                     : &g == &groups[kAShare] ? build_ashare_plan(s, g, *s->plan)
                     : &g == &groups[kDense]  ? build_dense_plan(s, g, *s->plan, (uint32_t)std::max(1, cus))
-                                             : build_group_chunks(g, or_windows_opt && &g != &groups[kBool], *s->plan);
+                                             : build_group_chunks(g, or_windows_opt && &g != &groups[kBool], *s->plan,
+                                                                  &g == &groups[kBool]);
     if (crc != TQ_OK) return crc;
   }
   // partial lists of all groups share one buffer; its stride is per group (kpl*64 keys)

@@ -207,6 +207,8 @@ def test_union_with_saturated_tf_bytes(ta, k):
         for ex in (1, 0):
             dev.set_option("exhaustive", ex)
             got[ex] = dev.search(qs, k)
+            if ex == 0:  # the kernel this test is about
+                assert dev.last_batch_stats()["kernel_mask"] == ta.binding.KERNEL_USHARE, dev.last_batch_stats()
         for a, b in zip(got[0], got[1]):
             assert np.array_equal(a, b)
         sc, _, docs, cnt = got[0]

@@ -61,6 +61,7 @@ def test_unpruned_unions_run_doc_major_and_match_the_oracle(ta, seg300k, k):
         st = dev.last_batch_stats()
         _check_against_oracle(seg, queries, got, k)
         assert st["tiles"] == (seg.max_doc + 127) // 128, st  # every query of the batch was eligible
+        assert st["kernel_mask"] == ta.binding.KERNEL_XUNION, st
         # every match was visited: the per-query counts are the union sizes
         counts = dev.last_batch_match_counts(len(queries))
         for qi, (mode, terms) in enumerate(queries):
@@ -68,6 +69,7 @@ def test_unpruned_unions_run_doc_major_and_match_the_oracle(ta, seg300k, k):
         # the pruned kernels return the same bits
         dev.set_option("exhaustive", 0)
         pr = dev.search(queries, k)
+        assert dev.last_batch_stats()["kernel_mask"] & ta.binding.KERNEL_USHARE  # (the shared-union launch)
         for a, b in zip(got, pr):
             assert np.array_equal(a, b)
     finally:
@@ -126,6 +128,8 @@ def test_small_and_mixed_batches_keep_the_window_kernel(ta, seg300k):
     try:
         dev.set_option("exhaustive", 1)
         got = dev.search(queries, 10)
+        st = dev.last_batch_stats()
+        assert not (st["kernel_mask"] & ta.binding.KERNEL_XUNION) and st["kernel_mask"] & ta.binding.KERNEL_OR_WINDOWS, st
         _check_against_oracle(seg, queries, got, 10)
     finally:
         dev.close()
