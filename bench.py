@@ -507,7 +507,9 @@ def resident_bytes(runner):
     tot = {}
     for s in range(runner.n_local):
         for key, v in runner.dev.segment_stats(s).items():
-            if key.endswith("_bytes"):
+            if key == "device_scratch_bytes":  # one set per device, shared by its segments
+                tot[key] = max(tot.get(key, 0), v)
+            elif key.endswith("_bytes"):
                 tot[key] = tot.get(key, 0) + v
     return tot
 

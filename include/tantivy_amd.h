@@ -370,9 +370,12 @@ int tq_last_batch_stats(tq_segment *seg, tq_batch_stats *out);
 typedef struct tq_segment_stats {
   uint64_t index_bytes, positions_bytes, fieldnorm_bytes, alive_bytes; /* tantivy's bytes */
   uint64_t term_table_bytes, bitmap_bytes /* + byte-wide tfs */, docmat_bytes, posdir_bytes; /* derived */
-  uint64_t scratch_bytes;       /* staging, partial lists, threshold slots, result slabs */
+  uint64_t scratch_bytes;       /* the segment's own batch scratch: staging, threshold slots, result slabs */
   uint64_t dense_budget_bytes;  /* cap on bitmap (+ byte-wide tf) + docmat + posdir bytes ("dense_budget_x") */
   uint32_t n_terms, n_dense_lists, n_docmat_columns;
+  uint32_t pad_;
+  uint64_t device_scratch_bytes; /* partial / result lists + staging lists of the term-major launches: ONE set
+                                    per device, shared by all its segments (count it once per device) */
 } tq_segment_stats;
 int tq_segment_get_stats(tq_segment *seg, tq_segment_stats *out);
 /* knobs: "exhaustive" (0/1, default 0: block-max pruning as block_wand / block_wand_intersection

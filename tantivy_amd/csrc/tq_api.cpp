@@ -13,6 +13,7 @@
 #include <chrono>
 #include <condition_variable>
 #include <deque>
+#include <map>
 #include <mutex>
 #include <new>
 #include <cstdlib>
@@ -165,8 +166,38 @@ struct Options {
 
 }  // namespace
 
+// The big per-batch buffers — partial / result lists, the staging lists of the two term-major launches —
+// exist once per DEVICE, not once per segment: a device runs one batch at a time anyway (the kernels fill
+// it), and 100 segments on a GPU must not mean 100 copies (8 segments held 13.9 GB of scratch in round 3).
+// A batch takes the lock when it sizes the buffers and keeps it until the event behind its last kernel is
+// recorded; a batch on another stream than the previous user's first waits for that event (stream side).
+struct DeviceScratch {
+  std::mutex m;
+  DevBuf partials, share_stage, ashare_stage;
+  hipEvent_t ev_last = nullptr;
+  hipStream_t last_stream = nullptr;
+  bool in_flight = false;
+};
 struct tq_ctx {
   std::vector<int> devices;
+  std::mutex m;
+  std::map<int, DeviceScratch *> scratch;
+  DeviceScratch *scratch_for(int device) {
+    std::lock_guard<std::mutex> lk(m);
+    DeviceScratch *&p = scratch[device];
+    if (!p) p = new DeviceScratch();
+    return p;
+  }
+  ~tq_ctx() {
+    for (auto &kv : scratch) {
+      (void)hipSetDevice(kv.first);
+      if (kv.second->ev_last) (void)hipEventDestroy(kv.second->ev_last);
+      kv.second->partials.release();
+      kv.second->share_stage.release();
+      kv.second->ashare_stage.release();
+      delete kv.second;
+    }
+  }
 };
 
 int tq_internal_fail(int code, const char *where, const char *what) {
@@ -211,9 +242,10 @@ struct tq_segment {
   std::unordered_map<uint64_t, bool> reserved_cols;
   bool cols_reserved = false;
   // batch scratch
-  DevBuf d_stage, d_partials, d_out_scores, d_out_docs, d_out_counts, d_misc, d_thr, d_qmatches;
-  DevBuf d_share_words, d_share_stage;  // shared-union launch: per-query words, staging lists
-  DevBuf d_ashare_words, d_ashare_stage;  // shared-intersection launch (runs next to the shared-union one)
+  DevBuf d_stage, d_out_scores, d_out_docs, d_out_counts, d_misc, d_thr, d_qmatches;
+  DevBuf d_share_words;   // shared-union launch: per-query words
+  DevBuf d_ashare_words;  // shared-intersection launch (runs next to the shared-union one)
+  DeviceScratch *dscratch = nullptr;  // partial / result lists and staging lists: the device's (tq_ctx)
   // the shared-union launch addresses bitmaps / byte-wide tfs as 32-bit offsets (8-byte units) from
   // the lowest such table: usable while all of them lie within 32 GB of device addresses
   size_t share_span_terms = 0;  // number of terms the span was computed over
@@ -584,6 +616,7 @@ static int segment_upload_common(tq_ctx *ctx, int device, uint32_t max_doc, cons
   tq_segment *s = new tq_segment();
   s->ctx = ctx;
   s->device = device;
+  s->dscratch = ctx->scratch_for(device);
   s->max_doc = max_doc;
   s->record_option = record_option;
   s->idx_len = idx_len;
@@ -691,7 +724,6 @@ void tq_segment_free(tq_segment *s) {
   if (s->d_tp_info) (void)hipFree(s->d_tp_info);
   if (s->d_match_counter) (void)hipFree(s->d_match_counter);
   s->d_stage.release();
-  s->d_partials.release();
   s->d_out_scores.release();
   s->d_out_docs.release();
   s->d_out_counts.release();
@@ -703,9 +735,7 @@ void tq_segment_free(tq_segment *s) {
   s->submit = nullptr;
   s->d_qmatches.release();
   s->d_share_words.release();
-  s->d_share_stage.release();
   s->d_ashare_words.release();
-  s->d_ashare_stage.release();
   s->h_stage.release();
   s->h_out.release();
   if (s->side_stream) (void)hipStreamSynchronize(s->side_stream);
@@ -3066,7 +3096,11 @@ int search_batch_impl(tq_segment *s, const tq_query *queries, uint32_t n_queries
     total_parts += parts;
     partial_bytes += (size_t)parts * (size_t)g.kpl * 64u * sizeof(uint64_t);
   }
-  rc = s->d_partials.ensure(partial_bytes + 256);
+  // From here to the event behind the batch's last kernel the device's shared scratch is this batch's.
+  DeviceScratch &sc = *s->dscratch;
+  std::unique_lock<std::mutex> scratch_lock(sc.m);
+  if (!sc.ev_last) HIP_TRY(hipEventCreateWithFlags(&sc.ev_last, hipEventDisableTiming));
+  rc = sc.partials.ensure(partial_bytes + 256);
   if (rc == TQ_OK) rc = s->d_qmatches.ensure((size_t)n_queries * sizeof(uint32_t));
   if (rc != TQ_OK) return rc;
 
@@ -3166,7 +3200,7 @@ int search_batch_impl(tq_segment *s, const tq_query *queries, uint32_t n_queries
     Group &g = groups[gi];
     if (g.queries.empty()) continue;
     TqkSinks sk{};
-    sk.partials = (uint64_t *)((uint8_t *)s->d_partials.p + part_off_bytes[gi]);
+    sk.partials = (uint64_t *)((uint8_t *)sc.partials.p + part_off_bytes[gi]);
     sk.match_counter = s->d_match_counter;
     sk.query_matches = (uint32_t *)s->d_qmatches.p;
     sk.out_index = (const uint32_t *)((const uint8_t *)dstage.p + g.o_outidx);
@@ -3177,6 +3211,8 @@ int search_batch_impl(tq_segment *s, const tq_query *queries, uint32_t n_queries
   // the scratch below is shared with the previous batch: wait for it if it ran on another stream
   rc = order_after_last_batch(s, st);
   if (rc != TQ_OK) return rc;
+  // ... and the device's shared scratch with whichever segment's batch used it last
+  if (sc.in_flight && sc.last_stream != st) HIP_TRY(hipStreamWaitEvent(st, sc.ev_last, 0));
   if (s->opt.timing) HIP_TRY(hipEventRecord(s->ev_t0[slot], st));
   // From here on work is in flight that reads the staging buffer: a failure below must not let the
   // next call overwrite it under kernels that were already launched (the events that order the
@@ -3230,7 +3266,7 @@ int search_batch_impl(tq_segment *s, const tq_query *queries, uint32_t n_queries
     const size_t words = 2 * n_dense + 16;
     rc = s->d_share_words.ensure(words * sizeof(uint32_t));
     if (rc == TQ_OK)
-      rc = s->d_share_stage.ensure((size_t)s->plan->xgrid * n_dense * tqk_share_capl(groups[kDense].kpl) * sizeof(uint64_t));
+      rc = sc.share_stage.ensure((size_t)s->plan->xgrid * n_dense * tqk_share_capl(groups[kDense].kpl) * sizeof(uint64_t));
     if (rc != TQ_OK) return rc;
     HIP_TRY(hipMemsetAsync(s->d_share_words.p, 0, words * sizeof(uint32_t), st));
   }
@@ -3240,7 +3276,7 @@ int search_batch_impl(tq_segment *s, const tq_query *queries, uint32_t n_queries
     const size_t words = 2 * n_share + 16;
     rc = s->d_share_words.ensure(words * sizeof(uint32_t));
     if (rc == TQ_OK)
-      rc = s->d_share_stage.ensure((size_t)share_grid * TQD_US_GROUP * tqk_share_capl(groups[kShare].kpl) *
+      rc = sc.share_stage.ensure((size_t)share_grid * TQD_US_GROUP * tqk_share_capl(groups[kShare].kpl) *
                                    sizeof(uint64_t));
     if (rc != TQ_OK) return rc;
     HIP_TRY(hipMemsetAsync(s->d_share_words.p, 0, words * sizeof(uint32_t), st));
@@ -3255,7 +3291,7 @@ int search_batch_impl(tq_segment *s, const tq_query *queries, uint32_t n_queries
     const size_t words = 2 * n_ashare + 16;
     rc = s->d_ashare_words.ensure(words * sizeof(uint32_t));
     if (rc == TQ_OK)
-      rc = s->d_ashare_stage.ensure((size_t)ashare_grid * TQD_AS_GROUP * tqk_share_capl(groups[kAShare].kpl) *
+      rc = sc.ashare_stage.ensure((size_t)ashare_grid * TQD_AS_GROUP * tqk_share_capl(groups[kAShare].kpl) *
                                     sizeof(uint64_t));
     if (rc != TQ_OK) return rc;
     HIP_TRY(hipMemsetAsync(s->d_ashare_words.p, 0, words * sizeof(uint32_t), st));
@@ -3299,8 +3335,8 @@ int search_batch_impl(tq_segment *s, const tq_query *queries, uint32_t n_queries
       ap.thr_val = (uint32_t *)s->d_ashare_words.p;
       ap.list_count = ap.thr_val + n_ashare;
       ap.table_base = (const uint8_t *)s->plan->share_table_base;
-      ap.stage = (uint64_t *)s->d_ashare_stage.p;
-      ap.lists = (uint64_t *)((uint8_t *)s->d_partials.p + part_off_bytes[gi]);
+      ap.stage = (uint64_t *)sc.ashare_stage.p;
+      ap.lists = (uint64_t *)((uint8_t *)sc.partials.p + part_off_bytes[gi]);
       ap.n_queries = (uint32_t)n_ashare;
       static const uint32_t kDebugA = tune_u32("TQ_DEBUG", 0);
       ap.debug = kDebugA;
@@ -3335,8 +3371,8 @@ int search_batch_impl(tq_segment *s, const tq_query *queries, uint32_t n_queries
       sp.thr_val = (uint32_t *)s->d_share_words.p;
       sp.list_count = sp.thr_val + n_share;
       uint32_t *const counters = sp.thr_val + 2 * n_share;  // one task counter per launch
-      sp.stage = (uint64_t *)s->d_share_stage.p;
-      sp.lists = (uint64_t *)((uint8_t *)s->d_partials.p + part_off_bytes[gi]);
+      sp.stage = (uint64_t *)sc.share_stage.p;
+      sp.lists = (uint64_t *)((uint8_t *)sc.partials.p + part_off_bytes[gi]);
       sp.n_queries = (uint32_t)n_share;
       static const uint32_t kDebugS = tune_u32("TQ_DEBUG", 0);
       sp.debug = kDebugS;
@@ -3374,8 +3410,8 @@ int search_batch_impl(tq_segment *s, const tq_query *queries, uint32_t n_queries
       dp.thr_val = (uint32_t *)s->d_share_words.p;
       dp.list_count = dp.thr_val + n_dense;
       dp.task_counter = dp.thr_val + 2 * n_dense;
-      dp.stage = (uint64_t *)s->d_share_stage.p;
-      dp.lists = (uint64_t *)((uint8_t *)s->d_partials.p + part_off_bytes[gi]);
+      dp.stage = (uint64_t *)sc.share_stage.p;
+      dp.lists = (uint64_t *)((uint8_t *)sc.partials.p + part_off_bytes[gi]);
       dp.n_rows = (uint32_t)s->plan->xrows.size();
       dp.n_bitmap_rows = s->plan->x_bitmap_rows;
       dp.n_queries = (uint32_t)n_dense;
@@ -3443,7 +3479,7 @@ int search_batch_impl(tq_segment *s, const tq_query *queries, uint32_t n_queries
     if (g.queries.empty()) continue;
     TqkMergeParams m{};
     m.queries = (const TqdQuery *)(ds + g.o_queries);
-    m.partials = (const uint64_t *)((const uint8_t *)s->d_partials.p + part_off_bytes[gi]);
+    m.partials = (const uint64_t *)((const uint8_t *)sc.partials.p + part_off_bytes[gi]);
     m.out_index = (const uint32_t *)(ds + g.o_outidx);
     m.out_scores = d_out_scores;
     m.out_docs = d_out_docs;
@@ -3461,6 +3497,9 @@ int search_batch_impl(tq_segment *s, const tq_query *queries, uint32_t n_queries
     ++s->batches_timed;
   }
   HIP_TRY(hipEventRecord(s->ev_batch_done, st));
+  HIP_TRY(hipEventRecord(sc.ev_last, st));
+  sc.last_stream = st;
+  sc.in_flight = true;
   if (kCopyStream) {
     HIP_TRY(hipEventRecord(s->ev_buf_free[bx], st));
     s->buf_used[bx] = true;
@@ -3712,10 +3751,13 @@ int tq_segment_get_stats(tq_segment *s, tq_segment_stats *out) {
   r.bitmap_bytes = s->bytes_bitmaps;
   r.docmat_bytes = s->bytes_docmat;
   r.posdir_bytes = s->bytes_posdir;
-  r.scratch_bytes = s->d_stage.cap + s->d_stage_alt.cap + s->d_partials.cap + s->d_out_scores.cap +
-                    s->d_out_docs.cap + s->d_out_counts.cap + s->d_misc.cap + s->d_thr.cap +
-                    s->d_qmatches.cap + s->d_share_words.cap + s->d_share_stage.cap + s->d_ashare_words.cap +
-                    s->d_ashare_stage.cap;
+  r.scratch_bytes = s->d_stage.cap + s->d_stage_alt.cap + s->d_out_scores.cap + s->d_out_docs.cap +
+                    s->d_out_counts.cap + s->d_misc.cap + s->d_thr.cap + s->d_qmatches.cap + s->d_share_words.cap +
+                    s->d_ashare_words.cap;
+  {
+    std::lock_guard<std::mutex> lk(s->dscratch->m);
+    r.device_scratch_bytes = s->dscratch->partials.cap + s->dscratch->share_stage.cap + s->dscratch->ashare_stage.cap;
+  }
   r.n_terms = (uint32_t)s->terms.size();
   r.n_dense_lists = s->n_dense_lists;
   r.n_docmat_columns = s->n_mat_slots;
