@@ -103,6 +103,28 @@ class Comm:
             self._c = C.c_void_p()
 
 
+def exchange_topk(local, n, k, n_local, world, comm=None, torch_group=None, gathered=None, stream=None,
+                  force=False):
+    """The path's one exchange step: every rank's [S * n, k] slabs (S local segments, n queries) ->
+    the per-segment results of the whole index as [world * S, n, k] / [world * S, n] views, rank order
+    == segment order (rank r holds segments r * S .. r * S + S - 1).  `comm`: an object with
+    allgather_topk(scores, docs, counts, out, stream) filling out = ([world, S * n, k] x 2,
+    [world, S * n]) — the C-ABI communicator (tq_allgather_topk: three gathers in one grouped RCCL
+    launch); else torch.distributed's group (one packed gather).  world == 1: no exchange."""
+    sc, dc, ct = local
+    S, W = n_local, world
+    if W > 1 or force:
+        if comm is not None:
+            comm.allgather_topk(sc, dc, ct, gathered, stream)
+            g = gathered
+        else:  # RCCL through torch.distributed (same wire, torch's communicator)
+            g = allgather_topk(sc, dc, ct, group=torch_group)
+    else:
+        g = (sc.unsqueeze(0), dc.unsqueeze(0), ct.unsqueeze(0))
+    # [world][S*n][k] == [world*S segments][n][k]
+    return g[0].reshape(W * S, n, k), g[1].reshape(W * S, n, k), g[2].reshape(W * S, n)
+
+
 class ShardRunner:
     """One rank's share of a sharded index: `segments` (its contiguous run, in global segment
     order) resident on `device`, the global statistics of the others added as remote statistics.
@@ -153,9 +175,11 @@ class ShardRunner:
         torch = self.torch
         self.dev.prepare(queries)
         n, S, W = len(queries), self.n_local, self.world
-        self._agree("(queries per batch, k)", (n, k))  # (before the early return: every rank calls it)
         if (n, k) == (self.n, self.k):
             return
+        # (a changed shape: every rank changes it in the same call, so every rank takes part here —
+        # not a blocking host collective on every batch)
+        self._agree("(queries per batch, k)", (n, k))
         self.n, self.k = n, k
         cuda = torch.device("cuda", self.device)
         self.local = (torch.empty((S * n, k), dtype=torch.float32, device=cuda),
@@ -182,18 +206,10 @@ class ShardRunner:
                     self.stream)
             ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
             ev[0].record(self.stream_obj)
-            if W > 1 or self.force_exchange:
-                if self.comm is not None:
-                    self.comm.allgather_topk(sc, dc, ct, self.gathered, self.stream)
-                    g = self.gathered
-                else:  # RCCL through torch.distributed (same wire, torch's communicator)
-                    g = allgather_topk(sc, dc, ct, group=self.torch_group)
-            else:
-                g = (sc.unsqueeze(0), dc.unsqueeze(0), ct.unsqueeze(0))
-            # [world][S*n][k] == [world*S segments][n][k]: rank order is segment order
-            merge_gathered_device(self.dev.ctx, self.device, g[0].reshape(W * S, n, k),
-                                  g[1].reshape(W * S, n, k), g[2].reshape(W * S, n), 0, k,
-                                  self.stream, out=self.merged)
+            g = exchange_topk((sc, dc, ct), n, k, S, W, self.comm, self.torch_group,
+                              getattr(self, "gathered", None), self.stream, self.force_exchange)
+            merge_gathered_device(self.dev.ctx, self.device, g[0], g[1], g[2], 0, k, self.stream,
+                                  out=self.merged)
             ev[1].record(self.stream_obj)
             self._ex_events = (self._ex_events + [ev])[-16:]
             for h, t in zip(self.host, self.merged):

@@ -82,3 +82,47 @@ def test_ashare_plan_invariants(plan_check, seed):
                            capture_output=True, text=True, timeout=300)
         assert r.returncode == 0, r.stderr + r.stdout
         assert "ashare:" in r.stdout and "ok" in r.stdout
+
+
+def test_eight_planners_at_once(tmp_path_factory):
+    """eight ranks of a node plan their batches at the same time on the node's few
+    granted CPUs.  Eight concurrent processes (one per CPU where there are eight) each plan the headline
+    batch's shared-intersection tables 40 times on the calling thread (TQ_PLAN_THREADS defaults to 1: no
+    helper threads to oversubscribe the cores with): the median under that load must stay within 2.5 x
+    the uncontended median — planning must not collapse when every rank plans at once."""
+    import re
+    import shutil
+
+    from tantivy_amd import build as B
+
+    B.build()
+    out = tmp_path_factory.mktemp("planb") / "plan_bench"
+    obj = str(out) + ".o"
+    src = os.path.join(ROOT, "tools", "planbench", "plan_bench.cpp")
+    subprocess.check_call([HIPCC, "-O3", "-std=c++17", "-Wno-unused-function", "-fPIC", "-c", src, "-o", obj],
+                          cwd=str(out.parent))
+    objs = [os.path.join(B.OBJ_DIR, os.path.basename(s) + ".o") for s in B.SOURCES
+            if os.path.basename(s).endswith(".hip") or os.path.basename(s) == "tq_comm.cpp"]
+    subprocess.check_call([HIPCC, "--offload-arch=gfx950", "-o", str(out), obj] + objs + ["-ldl", "-lpthread"],
+                          cwd=str(out.parent))
+
+    def median_of(stdout):
+        m = re.search(r"median ([0-9.]+) ms", stdout)
+        assert m, stdout
+        return float(m.group(1))
+
+    env = dict(os.environ, TQ_PLAN_THREADS="1")
+    alone = median_of(subprocess.run([str(out), "10000", "40", "ashare"], env=env, capture_output=True, text=True,
+                                     timeout=300).stdout)
+    cpus = sorted(os.sched_getaffinity(0))
+    pin = shutil.which("taskset") is not None
+    procs = []
+    for i in range(8):
+        cmd = [str(out), "10000", "40", "ashare"]
+        if pin:
+            cmd = ["taskset", "-c", str(cpus[i % len(cpus)])] + cmd
+        procs.append(subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True))
+    meds = [median_of(p.communicate(timeout=600)[0]) for p in procs]
+    assert all(p.returncode == 0 for p in procs)
+    slack = 2.5 * max(1.0, 8.0 / len(cpus))  # (fewer than eight CPUs: the processes share cores)
+    assert max(meds) <= slack * alone + 0.5, (alone, meds)

@@ -149,6 +149,7 @@ static int bench_ashare(int n_queries, int reps) {
   for (uint32_t r = 0; r < n_terms; ++r) cdf[r] = (acc += 1.0 / (r + 1));
   PlanScratch ps;
   double best = 1e9;
+  std::vector<double> all_ms;
   for (int rep = 0; rep < reps; ++rep) {
     Group &g = ps.groups[8];
     g.reset();
@@ -176,10 +177,13 @@ static int bench_ashare(int n_queries, int reps) {
     }
     const auto t0 = std::chrono::steady_clock::now();
     if (build_ashare_plan(&seg, g, ps) != TQ_OK) return 1;
-    best = std::min(best, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
+    all_ms.push_back(std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
+    best = std::min(best, all_ms.back());
   }
-  printf("ashare: queries %d tasks %zu (warm %u): build_ashare_plan %.2f ms (best of %d)\n", n_queries,
-         ps.atasks.size(), ps.a_warm_tasks, best, reps);
+  std::sort(all_ms.begin(), all_ms.end());
+  printf("ashare: queries %d tasks %zu (warm %u): build_ashare_plan %.2f ms (best of %d), median %.2f ms, p90 %.2f ms\n",
+         n_queries, ps.atasks.size(), ps.a_warm_tasks, best, reps, all_ms[all_ms.size() / 2],
+         all_ms[std::min(all_ms.size() - 1, all_ms.size() * 9 / 10)]);
   return 0;
 }
 
