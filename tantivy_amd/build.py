@@ -18,6 +18,12 @@ SOURCES = [
     os.path.join(HERE, "csrc", "tq_encode.hip"),
     os.path.join(HERE, "csrc", "tq_prepare.hip"),
     os.path.join(HERE, "csrc", "tq_api.cpp"),
+    os.path.join(HERE, "csrc", "tq_terms.cpp"),
+    os.path.join(HERE, "csrc", "tq_plan_chunks.cpp"),
+    os.path.join(HERE, "csrc", "tq_plan_share.cpp"),
+    os.path.join(HERE, "csrc", "tq_plan_misc.cpp"),
+    os.path.join(HERE, "csrc", "tq_search.cpp"),
+    os.path.join(HERE, "csrc", "tq_submit.cpp"),
     os.path.join(HERE, "csrc", "tq_comm.cpp"),
     os.path.join(HERE, "host", "searcher.cpp"),
     os.path.join(HERE, "host", "host_capi.cpp"),
@@ -28,6 +34,7 @@ HEADERS = [
     os.path.join(HERE, "csrc", "tq_device.h"),
     os.path.join(HERE, "csrc", "tq_launch.h"),
     os.path.join(HERE, "csrc", "tq_prepare.h"),
+    os.path.join(HERE, "csrc", "tq_internal.hpp"),
     os.path.join(HERE, "host", "searcher.hpp"),
     os.path.join(HERE, "host", "bm25.hpp"),
     os.path.join(HERE, "host", "term_info_store.hpp"),

@@ -1,0 +1,218 @@
+// tq_plan_misc.cpp — build_dense_plan (unpruned unions, doc-major: rows and queries of tq_xunion.hip) and
+// plan_bool_query (clause layout of the union kernel's boolean instantiation)
+// Part of the C ABI library of include/tantivy_amd.h (internal declarations: tq_internal.hpp).
+#include "tq_internal.hpp"
+
+namespace tqi {
+
+// The doc-major union group (tq_xunion.hip): rows = the distinct (list, weight) pairs of its queries, those with a
+// bitmap first; tasks = runs of 128-doc tiles handed out by an atomic counter to one workgroup per
+// CU; every query gets a result list of grid * k entries (a workgroup appends at most k).
+int build_dense_plan(tq_segment *s, Group &g, PlanScratch &ps, uint32_t cus) {
+  const uint32_t n_rows = (uint32_t)ps.xrow_term.size();
+  std::vector<uint32_t> new_row(n_rows, 0u);
+  ps.xrows.assign(n_rows, TqkDenseRow{});
+  uint32_t n_a = 0;
+  for (int pass = 0; pass < 2; ++pass)  // bitmap rows, then the others; first use order inside each
+    for (uint32_t r = 0, at = pass ? n_a : 0u; r < n_rows; ++r) {
+      const uint32_t h = (uint32_t)(ps.xrow_term[r] >> 32);
+      const TermHost &th = s->terms[h];
+      const bool bitmap = th.dense_blob && th.tf8_blob;
+      if (bitmap != (pass == 0)) continue;
+      TqkDenseRow row{};
+      row.handle = h;
+      row.doc_freq = th.doc_freq;
+      {
+        const uint32_t wb = (uint32_t)ps.xrow_term[r];
+        memcpy(&row.w, &wb, sizeof wb);
+      }
+      if (bitmap) {
+        row.dense = (const uint2 *)th.dense_blob;
+        row.tf8 = (const uint8_t *)th.tf8_blob;
+        ++n_a;
+      } else {
+        const size_t doc_bytes = ((size_t)th.doc_freq * sizeof(uint32_t) + 15) & ~(size_t)15;
+        row.flat_docs = (const uint32_t *)th.flat_blob;
+        row.tf8 = (const uint8_t *)th.flat_blob + doc_bytes;
+      }
+      new_row[r] = at;
+      ps.xrows[at++] = row;
+    }
+  ps.x_bitmap_rows = n_a;
+  const uint32_t n_tiles = (s->max_doc + TQK_XU_TILE - 1) / TQK_XU_TILE;
+  static const uint32_t kTaskDiv = std::max<uint32_t>(1u, tune_u32("TQ_XU_TASKS_PER_CU", 16));
+  ps.x_tiles_per_task = std::min<uint32_t>(32u, std::max<uint32_t>(1u, n_tiles / (cus * kTaskDiv)));
+  const uint32_t n_tasks = (n_tiles + ps.x_tiles_per_task - 1) / ps.x_tiles_per_task;
+  ps.xgrid = std::min<uint32_t>(n_tasks, cus);
+  g.kpl = g.max_k <= 64 ? 1 : 2;
+  g.n_chunks = n_tasks;
+  g.total_tiles = n_tiles;
+  ps.x_list_stride = ps.xgrid * g.max_k;
+  ps.xqueries.assign(g.queries.size(), TqkDenseQuery{});
+  ps.x_max_terms = 1;
+  for (size_t qi = 0; qi < g.queries.size(); ++qi) {
+    TqdQuery &dq = g.queries[qi];
+    TqkDenseQuery &xq = ps.xqueries[qi];
+    for (uint32_t i = 0; i < 8u; ++i) {  // (beyond n_terms: the all-zero row)
+      const uint32_t row = i < dq.n_terms ? new_row[ps.xrow_of[xrow_key(dq.term[i], dq.weight[i])]] : n_rows;
+      (i < 4 ? xq.rows_lo : xq.rows_hi) |= row << (8u * (i & 3u));
+    }
+    ps.x_max_terms = std::max(ps.x_max_terms, dq.n_terms);
+    xq.nt_k = dq.n_terms | (dq.k << 8);
+    xq.thr_row = dq.thr_index;
+    dq.part_start = (uint32_t)(qi * ps.x_list_stride);
+    dq.n_parts = ps.x_list_stride;
+  }
+  return TQ_OK;
+}
+
+// Planning of one TQ_MODE_BOOL query: clause layout of the union kernel (tq_union.hip), pruning
+// flags, tile sizes.  An empty result leaves dq.n_terms == 0 and n_tiles == 0.
+int plan_bool_query(tq_segment *s, const tq_query &q, uint32_t qi, TqdQuery &dq, uint64_t &qbytes,
+                    uint32_t &n_tiles, uint32_t &tile_cost, uint32_t &n_thr_rows, bool exhaustive) {
+  // BooleanQuery whose clauses are terms or unions of terms (`+a b -c`, `+a +(b OR c)`),
+  // BooleanWeight::complex_scorer (boolean_weight.rs:236-431).  A clause = the terms sharing
+  // one clause_of value.  Absent terms are EmptyScorers: they drop out of unions, an empty
+  // Must clause empties the query (:249-251), empty Should / MustNot clauses are removed.
+  struct Clause {
+    uint8_t occur;
+    uint32_t id, n = 0, terms[TQ_MAX_TERMS];
+    uint64_t cost = 0;  // BufferedUnionScorer::cost = sum of the lists' costs (doc freqs)
+  };
+  Clause cl[TQ_MAX_TERMS];
+  uint32_t n_cl = 0;
+  bool empty = false;
+  for (uint32_t i = 0; i < q.n_terms; ++i) {
+    if (q.occurs[i] > TQ_MUST_NOT) return fail(TQ_ERR_INVALID, "query %u: bad occur", qi);
+    const uint32_t id = q.clause_of ? q.clause_of[i] : i;
+    uint32_t c = 0;
+    while (c < n_cl && cl[c].id != id) ++c;
+    if (c == n_cl) {
+      cl[n_cl].id = id;
+      cl[n_cl].occur = q.occurs[i];
+      ++n_cl;
+    } else if (cl[c].occur != q.occurs[i]) {
+      return fail(TQ_ERR_INVALID, "query %u: clause %u mixes occurs", qi, id);
+    }
+    if (q.terms[i] == TQ_TERM_ABSENT) continue;
+    cl[c].terms[cl[c].n++] = i;
+    cl[c].cost += s->terms[q.terms[i]].doc_freq;
+  }
+  uint32_t must[TQ_MAX_TERMS], should[TQ_MAX_TERMS], mustnot[TQ_MAX_TERMS];
+  uint32_t n_must = 0, n_should = 0, n_not = 0;
+  for (uint32_t c = 0; c < n_cl; ++c) {
+    if (cl[c].occur == TQ_MUST) {
+      if (cl[c].n == 0) empty = true;
+      must[n_must++] = c;
+    } else if (cl[c].n) {
+      if (cl[c].occur == TQ_SHOULD)
+        should[n_should++] = c;
+      else
+        mustnot[n_not++] = c;
+    }
+  }
+  // minimum_number_should_match (:272-305): more than there are Should clauses matches
+  // nothing; all of them turns them into Must clauses; 1 makes the union required
+  uint32_t msm = q.min_should_match;
+  if (msm > n_should) empty = true;
+  if (!empty && msm >= 2 && msm == n_should) {
+    for (uint32_t i = 0; i < n_should; ++i) must[n_must++] = should[i];
+    n_should = 0;
+    msm = 0;
+  }
+  if (msm >= 2)
+    for (uint32_t i = 0; i < n_should; ++i)
+      if (cl[should[i]].n > 1)
+        return fail(TQ_ERR_UNSUPPORTED,
+                    "query %u: min_should_match > 1 over nested unions stays on the CPU", qi);
+  // MustNot clauses only: no include scorer, EmptyScorer (boolean_weight.rs:340-349)
+  if (n_must == 0 && n_should == 0) empty = true;
+  if (!empty) {
+    uint32_t n = 0;
+    auto put = [&](uint32_t i, uint32_t role) {
+      dq.term[n] = q.terms[i];
+      dq.weight[n] = role == TQD_ROLE_MUST_NOT ? 0.0f : q.weights[i];
+      dq.roles |= role << (2u * n);
+      qbytes += s->terms[q.terms[i]].postings_len;
+      ++n;
+    };
+    auto put_by_weight = [&](uint32_t *idx, uint32_t cnt, uint32_t role) {
+      small_stable_sort(idx, idx + cnt,
+                       [&](uint32_t a, uint32_t b) { return q.weights[a] > q.weights[b]; });
+      for (uint32_t i = 0; i < cnt; ++i) put(idx[i], role);
+    };
+    uint32_t flat[TQ_MAX_TERMS], n_flat = 0;
+    if (n_must) {
+      // Must clauses by cost ascending (intersect_scorers, intersection.rs:31): the cheapest
+      // leads; then the MustNot terms (they only exclude: densest first), then the Should
+      // terms in clause order
+      small_stable_sort(must, must + n_must,
+                       [&](uint32_t a, uint32_t b) { return cl[a].cost < cl[b].cost; });
+      // optional Should lists lead too (MaxScore for RequiredOptionalScorer, see union_body)
+      // (only when pruning: with every match scored the extra ownership probes cost 60 %)
+      const bool opt_lead = n_should > 0 && msm == 0 && !exhaustive;
+      if (opt_lead) {
+        for (uint32_t c = 0; c < n_should; ++c)
+          for (uint32_t i = 0; i < cl[should[c]].n; ++i) flat[n_flat++] = cl[should[c]].terms[i];
+        put_by_weight(flat, n_flat, TQD_ROLE_SHOULD);
+        dq.n_opt_lead = n;
+        n_flat = 0;
+        n_should = 0;
+      }
+      Clause &lead = cl[must[0]];
+      put_by_weight(lead.terms, lead.n, TQD_ROLE_MUST);
+      dq.n_lead = n;
+      for (uint32_t c = 1; c < n_must; ++c) {
+        for (uint32_t i = 0; i < cl[must[c]].n; ++i) put(cl[must[c]].terms[i], TQD_ROLE_MUST);
+        dq.clause_end |= 1u << (n - 1u);
+      }
+      for (uint32_t c = 0; c < n_not; ++c)
+        for (uint32_t i = 0; i < cl[mustnot[c]].n; ++i) flat[n_flat++] = cl[mustnot[c]].terms[i];
+      small_stable_sort(flat, flat + n_flat, [&](uint32_t a, uint32_t b) {
+        return s->terms[q.terms[a]].doc_freq > s->terms[q.terms[b]].doc_freq;
+      });
+      for (uint32_t i = 0; i < n_flat; ++i) put(flat[i], TQD_ROLE_MUST_NOT);
+      for (uint32_t c = 0; c < n_should; ++c)
+        for (uint32_t i = 0; i < cl[should[c]].n; ++i) put(cl[should[c]].terms[i], TQD_ROLE_SHOULD);
+    } else {
+      // no Must: the Should terms form the leading union (by weight descending, as the pure
+      // union does), MustNot terms exclude
+      for (uint32_t c = 0; c < n_should; ++c)
+        for (uint32_t i = 0; i < cl[should[c]].n; ++i) flat[n_flat++] = cl[should[c]].terms[i];
+      put_by_weight(flat, n_flat, TQD_ROLE_SHOULD);
+      dq.n_lead = n;
+      for (uint32_t c = 0; c < n_not; ++c)
+        for (uint32_t i = 0; i < cl[mustnot[c]].n; ++i) put(cl[mustnot[c]].terms[i], TQD_ROLE_MUST_NOT);
+    }
+    dq.min_should = msm;
+    dq.n_terms = n;
+    bool nonneg = true;
+    uint32_t sparse = 0;
+    for (uint32_t i = 0; i < n; ++i) {
+      nonneg = nonneg && dq.weight[i] >= 0.0f;
+      if (!(s->terms[dq.term[i]].dense_blob && s->opt.use_dense)) ++sparse;
+    }
+    if (!exhaustive && nonneg) {
+      dq.flags |= TQD_QF_PRUNE;
+      if (q.k <= 2 * TQD_THR_SLOTS) {
+        dq.thr_index = n_thr_rows;
+        n_thr_rows += 4u;  // union kernel: 64 slots for k <= 16, 256 above; the window kernel 64 / 128
+      }
+    }
+    const uint32_t c_lb = 1u + n + 8u * sparse;
+    static const uint32_t kBoolTileNum = std::max<uint32_t>(1u, tune_u32("TQ_BOOL_TILE_NUM", TQD_AND_TILE * 2u));
+    dq.tile_blocks = std::min<uint32_t>(TQD_AND_TILE, std::max<uint32_t>(1u, kBoolTileNum / c_lb));
+    tile_cost = dq.tile_blocks * c_lb;
+    uint32_t acc_tiles = 0;
+    for (uint32_t i = 0; i <= TQ_MAX_TERMS; ++i) {
+      dq.lead_tile_start[i] = acc_tiles;
+      if (i < dq.n_lead)
+        acc_tiles += (s->terms[dq.term[i]].n_blocks + dq.tile_blocks - 1) / dq.tile_blocks;
+    }
+    n_tiles = acc_tiles;
+  }
+  return TQ_OK;
+}
+
+
+}  // namespace tqi

@@ -1,0 +1,477 @@
+// tq_plan_share.cpp — the term-major launches' planners: build_share_plan (pure unions: leads and tasks per term,
+// tq_ushare.hip) and build_ashare_plan (intersections: leads per leader list, twins, warm-up and main tasks,
+// tq_ashare.hip)
+// Part of the C ABI library of include/tantivy_amd.h (internal declarations: tq_internal.hpp).
+#include "tq_internal.hpp"
+
+namespace tqi {
+
+// The shared-union launch (tq_ushare.hip): the (query, list) pairs of the group's pure unions are
+// sorted by term, cut into groups of <= TQD_US_GROUP leads, and every group gets one task per run of
+// blocks of its term.  Rare (high-weight) terms come first in the task order: their matches raise
+// the thresholds that let the tasks of the dense terms end at their first look at them.
+int build_share_plan(tq_segment *s, Group &g, PlanScratch &ps) {
+  static const uint32_t kTaskCost = std::max<uint32_t>(64u, tune_u32("TQ_US_TASK_COST", 2048));
+  static const uint32_t kTaskBlocksMax = std::max<uint32_t>(1u, tune_u32("TQ_US_TASK_BLOCKS", 64));
+  static const uint32_t kGroupMax = std::min<uint32_t>(TQD_US_GROUP, std::max<uint32_t>(1u, tune_u32("TQ_US_GROUP", TQD_US_GROUP)));
+  const size_t nq = g.queries.size();
+  g.kpl = kpl_for(g.max_k);
+  static const bool ptrace = getenv("TQ_PLAN_TRACE") != nullptr;  // phase times of the planner
+  auto pt_last = std::chrono::steady_clock::now();
+  auto pt = [&](const char *what) {
+    if (!ptrace) return;
+    const auto now = std::chrono::steady_clock::now();
+    fprintf(stderr, "[tq share plan] %-12s %7.2f ms\n", what, std::chrono::duration<double, std::milli>(now - pt_last).count());
+    pt_last = now;
+  };
+  // Leads by list position first: position 0 is every query's highest-weight list, and its docs
+  // settle the query's threshold — all tasks of position i are launched (and done) before those of
+  // position i + 1 (one launch per position).  Inside a position: by term, rare terms first.
+  // The order is (position, blocks of the term, term, cache, query).  The batch's distinct terms are
+  // ranked by (blocks, handle) first — a few hundred — and the pairs, generated in query order, go
+  // through a stable radix sort on position | rank | cache (a comparison sort of the 25 000 pairs of
+  // a 5000-query batch was two thirds of this function's time).
+  std::vector<ShareKey> &keys = ps.share_keys;
+  {
+    std::vector<uint32_t> &rank = ps.term_rank, &distinct = ps.term_distinct;
+    if (rank.size() < s->terms.size()) rank.resize(s->terms.size(), 0u);
+    distinct.clear();
+    size_t n_pairs = 0;
+    for (size_t q = 0; q < nq; ++q) {
+      const TqdQuery &dq = g.queries[q];
+      n_pairs += dq.n_terms;
+      for (uint32_t i = 0; i < dq.n_terms; ++i)
+        if (rank[dq.term[i]] != 0xFFFFFFFFu) {  // (0xFFFFFFFF = seen in this batch; reset below)
+          rank[dq.term[i]] = 0xFFFFFFFFu;
+          distinct.push_back(dq.term[i]);
+        }
+    }
+    std::sort(distinct.begin(), distinct.end(), [&](uint32_t a, uint32_t b) {
+      const uint32_t na = s->terms[a].n_blocks, nb = s->terms[b].n_blocks;
+      return na != nb ? na < nb : a < b;
+    });
+    for (size_t r = 0; r < distinct.size(); ++r) rank[distinct[r]] = (uint32_t)r;
+    std::vector<uint64_t> &sk = ps.sort_keys, &sk2 = ps.sort_keys2;
+    std::vector<ShareKey> &k2 = ps.share_keys2;
+    keys.resize(n_pairs);
+    k2.resize(n_pairs);
+    sk.resize(n_pairs);
+    sk2.resize(n_pairs);
+    size_t at = 0;
+    for (size_t q = 0; q < nq; ++q) {
+      const TqdQuery &dq = g.queries[q];
+      for (uint32_t i = 0; i < dq.n_terms; ++i, ++at) {
+        const uint64_t nb = std::min<uint64_t>(0xFFFFFFu, s->terms[dq.term[i]].n_blocks);
+        keys[at] = {((uint64_t)i << 56) | (nb << 32) | (uint64_t)(dq.cache_idx & 0xFFu), dq.term[i], (uint32_t)q};
+        sk[at] = ((uint64_t)i << 40) | ((uint64_t)rank[dq.term[i]] << 8) | (uint64_t)(dq.cache_idx & 0xFFu);
+      }
+    }
+    for (uint32_t t : distinct) rank[t] = 0u;  // (any value but the marker)
+    for (uint32_t shift = 0; shift < 48; shift += 8) {  // LSD, one byte per pass; stable: queries stay in order
+      uint32_t hist[257] = {0};
+      for (size_t i = 0; i < n_pairs; ++i) ++hist[((sk[i] >> shift) & 0xFFu) + 1u];
+      bool one_bucket = false;
+      for (uint32_t d = 0; d < 256; ++d) one_bucket = one_bucket || hist[d + 1] == n_pairs;
+      if (one_bucket) continue;  // every key has the same byte here
+      for (uint32_t d = 0; d < 256; ++d) hist[d + 1] += hist[d];
+      for (size_t i = 0; i < n_pairs; ++i) {
+        const uint32_t o = hist[(sk[i] >> shift) & 0xFFu]++;
+        sk2[o] = sk[i];
+        k2[o] = keys[i];
+      }
+      sk.swap(sk2);
+      keys.swap(k2);
+    }
+  }
+  pt("keys + sort");
+  std::vector<TqdLead> &leads = ps.leads;
+  std::vector<uint4> &tasks = ps.tasks;
+  std::vector<uint32_t> &pairs = ps.share_pairs;
+  leads.resize(keys.size());
+  tasks.clear();
+  pairs.assign(nq, 0u);
+  // bitmaps and byte-wide tfs are addressed as 32-bit offsets (8-byte units) from one base: the
+  // lowest table address of the segment (the caller checked that they span less than 32 GB:
+  // otherwise the unions keep the per-query kernel)
+  ps.share_table_base = s->share_table_lo;
+  auto off_of = [&](const void *ptr) -> uint32_t {
+    return ptr ? (uint32_t)(((uint64_t)ptr - ps.share_table_base) >> 3) : 0u;
+  };
+  auto column_of = [&](uint32_t handle) -> uint32_t {  // doc-matrix bit of the list, or 0
+    const uint32_t slot1 = (s->h_dterms[handle].has_freq >> 8) & 0xFFu;
+    return slot1 ? 8u + (slot1 - 1u) : 0u;
+  };
+  // (a lead reads only its own query: the table is filled by the planner's threads, a slab each)
+  const uint32_t lead_slabs = keys.size() >= 8192 ? plan_threads() : 1u;
+  parallel_slabs(lead_slabs, [&](uint32_t sb) {
+  const size_t at0 = keys.size() * sb / lead_slabs, at1 = keys.size() * (sb + 1) / lead_slabs;
+  for (size_t at = at0; at < at1; ++at) {
+    const ShareKey &k = keys[at];
+    const uint32_t li = (uint32_t)(k.key >> 56);
+    const TqdQuery &dq = g.queries[k.q];
+    TqdLead ld{};
+    ld.query = k.q;
+    ld.w = dq.weight[li];
+    uint32_t ncols = 0, nocol = 0, nopc = 0, uses_sig = 0;
+    float suffix = 0.0f, sparse_after = 0.0f;
+    for (uint32_t m = dq.n_terms; m-- > li;) suffix += dq.weight[m];
+    for (uint32_t m = 0; m < dq.n_terms; ++m) {
+      const uint32_t col = column_of(dq.term[m]);
+      // lists without a column: their signature bit (docsig), if the segment keeps signatures
+      const uint32_t sig1 = !col ? (s->h_dterms[dq.term[m]].has_freq >> 16) & 0xFFu : 0u;
+      ld.sig[m] = (uint8_t)sig1;
+      if (!col) nocol |= 1u << m;
+      if (!col && !sig1) nopc |= 1u << m;
+      if (sig1 && m != li) uses_sig = 1;
+      if (m < li) {
+        if (col) ld.before_mask |= 1ull << col;
+      } else if (m > li) {
+        ld.dense_off[m - li - 1u] = off_of(s->opt.use_dense ? s->terms[dq.term[m]].dense_blob : nullptr);
+        ld.tf8_off[m - li - 1u] = off_of(s->terms[dq.term[m]].tf8_blob);
+        const uint32_t bitpos = col ? col : (sig1 ? TQD_SIG_SHIFT + (sig1 - 1u) : 0u);
+        if (bitpos) {
+          if (ncols < 4u)
+            ld.cols_lo |= bitpos << (8u * ncols);
+          else
+            ld.cols_hi |= bitpos << (8u * (ncols - 4u));
+          ld.aw[ncols] = dq.weight[m];
+          ++ncols;
+        } else {
+          sparse_after += dq.weight[m];
+        }
+      }
+    }
+    ld.suffix = suffix;
+    ld.sparse_after = sparse_after;
+    ld.info = li | (ncols << 4) | (dq.n_terms << 8) | (uses_sig << 12) | (nocol << 16) | (nopc << 24);
+    leads[at] = ld;
+  }
+  });
+  pt("leads");
+  // cost of every position's tasks together (a block costs its decode + one test per lead): a
+  // position with little work is cut into smaller tasks, so that it still fills the chip and its
+  // launch does not end on a few long tasks
+  // (measured, kernel ms: or5 at k = 100 wants ~6144 tasks per position — 3072: 2.65, 4096: 2.54, 5120:
+  // 2.44, 6144: 2.36, 7168: 2.51, 10240: 2.83 — the mixed stream at k = 10 ~4096: 3072: 9.75, 4096: 9.02,
+  // 5120: 9.19, 6144: 9.54: its thresholds settle after a few docs, and longer tasks keep the
+  // feedback inside one wave)
+  static const uint32_t kPhaseTasksEnv = tune_u32("TQ_US_PHASE_TASKS", 0);
+  const uint32_t kPhaseTasks = kPhaseTasksEnv ? kPhaseTasksEnv : (g.max_k <= 16u ? 4096u : 6144u);
+  uint64_t phase_cost[TQD_US_MAX_TERMS] = {};
+  for (size_t r0 = 0; r0 < keys.size();) {
+    size_t r1 = r0;
+    while (r1 < keys.size() && keys[r1].key == keys[r0].key && keys[r1].term == keys[r0].term) ++r1;
+    const uint32_t n_run = (uint32_t)(r1 - r0);
+    const uint32_t n_groups = (n_run + kGroupMax - 1) / kGroupMax;
+    phase_cost[keys[r0].key >> 56] += (uint64_t)s->terms[keys[r0].term].n_blocks * (4u * n_groups + n_run);
+    r0 = r1;
+  }
+  // runs of one (position, term, cache): groups of leads x runs of blocks
+  for (uint32_t i = 0; i <= TQD_US_MAX_TERMS; ++i) ps.share_phase_first[i] = 0;
+  uint32_t phase = 0;
+  for (size_t r0 = 0; r0 < keys.size();) {
+    size_t r1 = r0;
+    while (r1 < keys.size() && keys[r1].key == keys[r0].key && keys[r1].term == keys[r0].term) ++r1;
+    const uint32_t li = (uint32_t)(keys[r0].key >> 56);
+    const uint32_t task_cost = (uint32_t)std::min<uint64_t>(kTaskCost, std::max<uint64_t>(36u, phase_cost[li] / kPhaseTasks));
+    while (phase < li) ps.share_phase_first[++phase] = (uint32_t)tasks.size();
+    const uint32_t term = keys[r0].term, cache = (uint32_t)keys[r0].key & 0xFFu;
+    const uint32_t n_blocks = s->terms[term].n_blocks;
+    const uint32_t n_run = (uint32_t)(r1 - r0);
+    const uint32_t n_groups = (n_run + kGroupMax - 1) / kGroupMax;
+    const uint32_t per_group = (n_run + n_groups - 1) / n_groups;
+    // blocks per task: about equal cost (a block costs its decode + one test per lead); small
+    // tasks keep the share of the batch that is in flight before thresholds exist small
+    uint32_t bpt = task_cost / (4u + per_group);
+    bpt = std::min<uint32_t>(kTaskBlocksMax, std::max<uint32_t>(1u, bpt));
+    for (uint32_t j0 = 0; j0 < n_blocks; j0 += bpt) {
+      const uint32_t nb = std::min<uint32_t>(bpt, n_blocks - j0);
+      for (uint32_t gr = 0; gr < n_groups; ++gr) {
+        const uint32_t l0 = gr * per_group, l1 = std::min<uint32_t>(n_run, l0 + per_group);
+        if (l0 >= l1) continue;
+        tasks.push_back(make_uint4(term, j0, nb | ((l1 - l0) << 16) | (cache << 24), (uint32_t)r0 + l0));
+      }
+    }
+    const uint32_t n_runs = (n_blocks + bpt - 1) / bpt;
+    for (size_t a = r0; a < r1; ++a) pairs[keys[a].q] += n_runs;
+    r0 = r1;
+  }
+  while (phase < TQD_US_MAX_TERMS) ps.share_phase_first[++phase] = (uint32_t)tasks.size();
+  pt("tasks");
+  if (tasks.size() > 0x7FFFFFFFull) return fail(TQ_ERR_UNSUPPORTED, "batch too large (tasks)");
+  // result lists: every (task, lead) pair appends at most k entries
+  uint64_t entries = 0;
+  for (size_t q = 0; q < nq; ++q) {
+    TqdQuery &dq = g.queries[q];
+    const uint64_t cap = (uint64_t)pairs[q] * dq.k;
+    if (entries + cap > 0xFFFFFFFFull) return fail(TQ_ERR_UNSUPPORTED, "batch too large (result lists)");
+    dq.part_start = (uint32_t)entries;
+    dq.n_parts = (uint32_t)cap;
+    dq.chunk_first = 0;
+    entries += cap;
+  }
+  g.total_tiles = (uint32_t)tasks.size();
+  g.n_chunks = (uint32_t)tasks.size();
+  return TQ_OK;
+}
+
+// The shared-intersection launch (tq_ashare.hip): one lead per AND query; the leads of one (leader
+// list, Bm25 cache) are sorted by their membership mask (the kernel keeps a block's membership
+// ballots across consecutive leads with the same mask), cut into groups of <= TQD_AS_GROUP, and every
+// group gets one task per run of blocks of the leader.  Tasks are launched in doc order (all
+// leaders' runs of the first 1/4096 of the doc-id space, then the next, ...): the chip works on one
+// part of the doc matrix at a time, and every query's threshold rises as its leader is walked.
+int build_ashare_plan(tq_segment *s, Group &g, PlanScratch &ps) {
+  static const uint32_t kTaskPairsEnv = std::max<uint32_t>(32u, tune_u32("TQ_AS_TASK_PAIRS", 512));
+  static const uint32_t kTaskBlocksMax = std::min<uint32_t>(0xFFFFu, std::max<uint32_t>(1u, tune_u32("TQ_AS_TASK_BLOCKS", 64)));
+  static const uint32_t kGroupMax = std::min<uint32_t>(TQD_AS_GROUP, std::max<uint32_t>(1u, tune_u32("TQ_AS_GROUP", TQD_AS_GROUP)));
+  static const uint64_t kListBudget = (uint64_t)std::max<uint32_t>(1u, tune_u32("TQ_AS_LIST_MB", 1024)) << 20;
+  static const bool ptrace = getenv("TQ_PLAN_TRACE") != nullptr;  // phase times of the planner
+  auto pt_last = std::chrono::steady_clock::now();
+  auto pt = [&](const char *what) {
+    if (!ptrace) return;
+    const auto now = std::chrono::steady_clock::now();
+    fprintf(stderr, "[tq ashare plan] %-12s %7.2f ms\n", what, std::chrono::duration<double, std::milli>(now - pt_last).count());
+    pt_last = now;
+  };
+  const size_t nq = g.queries.size();
+  g.kpl = g.max_k <= 64 ? 1 : 2;
+  auto column_of = [&](uint32_t handle) -> uint32_t {  // doc-matrix bit of the list, or 0
+    const uint32_t slot1 = (s->h_dterms[handle].has_freq >> 8) & 0xFFu;
+    return slot1 ? 8u + (slot1 - 1u) : 0u;
+  };
+  ps.share_table_base = s->share_table_lo;
+  auto off_of = [&](const void *ptr) -> uint32_t {
+    return ptr ? (uint32_t)(((uint64_t)ptr - ps.share_table_base) >> 3) : 0u;
+  };
+  // ---- leads, in query order (filled by the planner's threads, a slab of queries each), with their
+  // sort keys: (leader, cache) | mask | a hash of the whole query (lists, weights, k)
+  std::vector<TqdALead> &leads = ps.aleads, &unsorted = ps.aleads_unsorted;
+  std::vector<ALeadKey> &keys = ps.alead_keys;
+  leads.resize(nq);
+  unsorted.resize(nq);
+  keys.resize(nq);
+  const uint32_t fill_slabs = nq >= 4096 ? plan_threads() : 1u;
+  parallel_slabs(fill_slabs, [&](uint32_t sb) {
+    const size_t q0 = nq * sb / fill_slabs, q1 = nq * (sb + 1) / fill_slabs;
+    for (size_t q = q0; q < q1; ++q) {
+      const TqdQuery &dq = g.queries[q];
+      TqdALead ld{};
+      ld.query = (uint32_t)q;
+      ld.w = dq.weight[0];
+      float rest = 0.0f;
+      uint64_t mask = 0, sig = 0x9E3779B97F4A7C15ull * (uint64_t)(dq.n_terms | (dq.k << 8));
+      for (uint32_t m = 0; m < dq.n_terms; ++m) {
+        uint32_t wb;
+        memcpy(&wb, &dq.weight[m], sizeof wb);
+        sig = (sig ^ (((uint64_t)dq.term[m] << 32) | wb)) * 0xFF51AFD7ED558CCDull;
+        sig ^= sig >> 29;
+        if (!m) continue;
+        rest += dq.weight[m];
+        const uint32_t col = column_of(dq.term[m]);
+        const uint32_t sig1 = !col ? (s->h_dterms[dq.term[m]].has_freq >> 16) & 0xFFu : 0u;
+        const uint32_t bitpos = col ? col : (sig1 ? TQD_SIG_SHIFT + (sig1 - 1u) : 0u);
+        if (bitpos) mask |= 1ull << bitpos;
+      }
+      ld.rest = rest;
+      ld.mask_lo = (uint32_t)mask;
+      ld.mask_hi = (uint32_t)(mask >> 32);
+      ld.info = dq.n_terms | (column_of(dq.term[1]) ? 0x100u : 0u);
+      ld.dense_off = off_of(s->terms[dq.term[1]].dense_blob);
+      ld.tf8_off = off_of(s->terms[dq.term[1]].tf8_blob);
+      ld.k = dq.k;
+      ld.thr_row = dq.thr_index;
+      unsorted[q] = ld;
+      keys[q] = ALeadKey{((uint64_t)dq.term[0] << 8) | (uint64_t)(dq.cache_idx & 0xFFu), mask, sig, (uint32_t)q, 0u};
+    }
+  });
+  pt("leads");
+  // ---- order: (leader, cache), then mask, then the query hash (identical queries become neighbours:
+  // twins), stable in the query index.  Buckets by leader first (a counting sort: a few hundred
+  // leaders), then every bucket by the rest of the key — the planner's threads take a share of the
+  // buckets each (a comparison sort of the whole table was half of this function's time)
+  {
+    std::vector<uint32_t> &cnt = ps.alead_bucket;
+    const size_t nt = s->terms.size();
+    cnt.assign(nt + 1, 0u);
+    for (size_t q = 0; q < nq; ++q) ++cnt[(size_t)(keys[q].k1 >> 8) + 1];
+    for (size_t t = 0; t < nt; ++t) cnt[t + 1] += cnt[t];
+    std::vector<ALeadKey> &tmp = ps.alead_keys2;
+    tmp.resize(nq);
+    std::vector<uint32_t> &at = ps.alead_bucket_at;
+    at.assign(cnt.begin(), cnt.end() - 1);
+    for (size_t q = 0; q < nq; ++q) tmp[at[(size_t)(keys[q].k1 >> 8)]++] = keys[q];
+    keys.swap(tmp);
+    // non-empty buckets, cut into slabs of about equal size
+    std::vector<uint32_t> &starts = ps.alead_bucket_starts;
+    starts.clear();
+    for (size_t t = 0; t < nt; ++t)
+      if (cnt[t + 1] > cnt[t]) starts.push_back(cnt[t]);
+    starts.push_back((uint32_t)nq);
+    const uint32_t n_b = (uint32_t)starts.size() - 1u;
+    const uint32_t sort_slabs = nq >= 4096 ? std::min<uint32_t>(plan_threads(), std::max<uint32_t>(1u, n_b)) : 1u;
+    parallel_slabs(sort_slabs, [&](uint32_t sb) {
+      for (uint32_t b = sb; b < n_b; b += sort_slabs)  // (interleaved: the big buckets are the first leaders)
+        std::sort(keys.begin() + starts[b], keys.begin() + starts[b + 1], [](const ALeadKey &a, const ALeadKey &b2) {
+          if (a.k1 != b2.k1) return a.k1 < b2.k1;
+          if (a.mask != b2.mask) return a.mask < b2.mask;
+          if (a.sig != b2.sig) return a.sig < b2.sig;
+          return a.q < b2.q;
+        });
+    });
+  }
+  pt("sort");
+  auto same_query = [&](const ALeadKey &a, const ALeadKey &b) -> bool {  // (the hash only proposes)
+    if (a.k1 != b.k1 || a.mask != b.mask || a.sig != b.sig) return false;
+    const TqdALead &la = unsorted[a.q], &lb = unsorted[b.q];
+    if ((la.info & 31u) != (lb.info & 31u) || la.k != lb.k || memcmp(&la.w, &lb.w, 4) || memcmp(&la.rest, &lb.rest, 4) ||
+        la.dense_off != lb.dense_off)
+      return false;
+    if ((la.info & 31u) == 2u) return true;  // (leader, list 1 — every list has its own bitmap —, both weights, k)
+    const TqdQuery &qa = g.queries[a.q], &qb = g.queries[b.q];
+    return !memcmp(qa.term, qb.term, qa.n_terms * sizeof(uint32_t)) &&
+           !memcmp(qa.weight, qb.weight, qa.n_terms * sizeof(float));
+  };
+  // identical queries share one row of threshold slots, whatever groups they end up in (a slot is
+  // hash(doc): the same doc lands in the same slot whichever group scored it)
+  std::vector<uint8_t> &same_as_prev = ps.alead_same;
+  same_as_prev.resize(nq);
+  const uint32_t gather_slabs = nq >= 4096 ? plan_threads() : 1u;
+  parallel_slabs(gather_slabs, [&](uint32_t sb) {
+    const size_t i0 = nq * sb / gather_slabs, i1 = nq * (sb + 1) / gather_slabs;
+    for (size_t i = i0; i < i1; ++i) {
+      leads[i] = unsorted[keys[i].q];
+      same_as_prev[i] = i && same_query(keys[i], keys[i - 1]) ? 1 : 0;
+    }
+  });
+  for (size_t i = 1; i < nq; ++i)
+    if (same_as_prev[i]) leads[i].thr_row = leads[i - 1].thr_row;
+  pt("gather");
+  // ---- tasks: groups of leads x runs of blocks; fewer, longer tasks if the result lists (k entries
+  // per (task, lead) pair) would not fit the budget.  The first kWarmPermille / 1000 of every leader go
+  // out as short tasks in a launch of their own: every resident wavefront starts a launch with the
+  // thresholds it finds, and with thresholds of zero the first wavefronts (an eighth of the batch)
+  // sent every match through the scoring stage — a warm-up over a fraction of a percent of the blocks
+  // leaves the main launch the k-th best of a sample of every query to start from.
+  static const uint32_t kWarmPermille = std::min<uint32_t>(1000u, tune_u32("TQ_AS_WARM_PERMILLE", 2));
+  static const uint32_t kWarmBlocks = std::max<uint32_t>(1u, tune_u32("TQ_AS_WARM_BLOCKS", 2));
+  std::vector<uint4> &tasks = ps.atasks, &raw = ps.atasks_unsorted;
+  std::vector<uint32_t> &pos = ps.atask_pos, &pairs = ps.apairs;
+  pairs.resize(nq);
+  // the runs of one (leader, cache): their groups, task sizes and where their tasks start
+  std::vector<PlanScratch::ARun> &runs = ps.aruns;
+  uint32_t task_pairs = kTaskPairsEnv;
+  size_t n_tasks = 0;
+  for (;;) {
+    runs.clear();
+    n_tasks = 0;
+    uint64_t entries = 0;
+    for (size_t r0 = 0; r0 < nq;) {
+      size_t r1 = r0;
+      uint64_t k_sum = 0;
+      while (r1 < nq && keys[r1].k1 == keys[r0].k1) k_sum += leads[r1++].k;
+      PlanScratch::ARun R;
+      R.r0 = (uint32_t)r0;
+      R.r1 = (uint32_t)r1;
+      R.term = (uint32_t)(keys[r0].k1 >> 8);
+      R.cache = (uint32_t)keys[r0].k1 & 0xFFu;
+      R.n_blocks = s->terms[R.term].n_blocks;
+      const uint32_t n_run = (uint32_t)(r1 - r0);
+      const uint32_t n_groups = (n_run + kGroupMax - 1) / kGroupMax;
+      R.per_group = (n_run + n_groups - 1) / n_groups;
+      R.n_groups = (n_run + R.per_group - 1) / R.per_group;  // (the non-empty ones)
+      R.bpt = std::min<uint32_t>(kTaskBlocksMax, std::max<uint32_t>(1u, task_pairs / R.per_group));
+      R.nb_warm = (uint32_t)((uint64_t)R.n_blocks * kWarmPermille / 1000u);
+      R.n_runs = (R.nb_warm + kWarmBlocks - 1) / kWarmBlocks + (R.n_blocks - R.nb_warm + R.bpt - 1) / R.bpt;
+      R.task0 = n_tasks;
+      n_tasks += (size_t)R.n_runs * R.n_groups;
+      entries += (uint64_t)R.n_runs * k_sum;
+      runs.push_back(R);
+      r0 = r1;
+    }
+    if ((entries * sizeof(uint64_t) <= kListBudget && entries <= 0xFFFFFFFFull) || task_pairs >= (1u << 22)) {
+      if (entries > 0xFFFFFFFFull) return fail(TQ_ERR_UNSUPPORTED, "batch too large (result lists)");
+      break;
+    }
+    task_pairs *= 2u;
+  }
+  if (n_tasks > 0x7FFFFFFFull) return fail(TQ_ERR_UNSUPPORTED, "batch too large (tasks)");
+  raw.resize(n_tasks);
+  pos.resize(n_tasks);
+  tasks.resize(n_tasks);
+  // slabs of runs of about equal task counts: each fills its tasks and counts them by doc slice; the
+  // (slice, slab) prefix sums give every slab its places in the launch order (a stable counting sort:
+  // slice 0 = the warm-up launch, then the main launch's tasks by doc slice)
+  constexpr uint32_t kSl = 4098;
+  const uint32_t t_slabs = n_tasks >= 16384 ? std::min<uint32_t>(plan_threads(), (uint32_t)runs.size()) : 1u;
+  std::vector<uint32_t> &hist = ps.atask_hist;
+  hist.assign((size_t)t_slabs * kSl, 0u);
+  std::vector<uint32_t> &slab_run = ps.atask_slab_run;
+  slab_run.assign(t_slabs + 1, (uint32_t)runs.size());
+  {
+    uint32_t sb = 0;
+    slab_run[0] = 0;
+    for (uint32_t r = 0; r < runs.size() && sb + 1 < t_slabs; ++r)
+      if (runs[r].task0 >= n_tasks * (sb + 1) / t_slabs) slab_run[++sb] = r;
+    for (uint32_t x = sb + 1; x < t_slabs; ++x) slab_run[x] = (uint32_t)runs.size();
+  }
+  parallel_slabs(t_slabs, [&](uint32_t sb) {
+    uint32_t *h = hist.data() + (size_t)sb * kSl;
+    for (uint32_t r = slab_run[sb]; r < slab_run[sb + 1]; ++r) {
+      const PlanScratch::ARun &R = runs[r];
+      for (uint32_t a = R.r0; a < R.r1; ++a) {  // twins: the same query as the lead before, inside one group
+        const bool twin = (a - R.r0) % R.per_group != 0 && same_as_prev[a];
+        leads[a].info = (leads[a].info & ~0x200u) | (twin ? 0x200u : 0u);
+        pairs[keys[a].q] = R.n_runs;
+      }
+      const uint32_t n_run = R.r1 - R.r0;
+      const uint64_t slice_mul = ((uint64_t)1 << 44) / R.n_blocks;  // (j0 << 12) / n_blocks without the division
+      size_t at = R.task0;
+      for (uint32_t j0 = 0; j0 < R.n_blocks;) {
+        const bool warm = j0 < R.nb_warm;
+        const uint32_t nb = warm ? std::min<uint32_t>(kWarmBlocks, R.nb_warm - j0) : std::min<uint32_t>(R.bpt, R.n_blocks - j0);
+        const uint32_t slice = warm ? 0u : 1u + std::min<uint32_t>(4095u, (uint32_t)((j0 * slice_mul) >> 32));
+        for (uint32_t gr = 0; gr < R.n_groups; ++gr) {
+          const uint32_t l0 = gr * R.per_group, l1 = std::min<uint32_t>(n_run, l0 + R.per_group);
+          raw[at] = make_uint4(R.term, j0, nb | ((l1 - l0) << 16) | (R.cache << 24), R.r0 + l0);
+          pos[at] = slice;
+          ++at;
+        }
+        h[slice] += R.n_groups;
+        j0 += nb;
+      }
+    }
+  });
+  {
+    uint32_t run = 0;
+    for (uint32_t sl = 0; sl < kSl; ++sl)
+      for (uint32_t sb = 0; sb < t_slabs; ++sb) {
+        const uint32_t n = hist[(size_t)sb * kSl + sl];
+        hist[(size_t)sb * kSl + sl] = run;  // becomes the slab's write position in this slice
+        run += n;
+        if (sl == 0 && sb + 1 == t_slabs) ps.a_warm_tasks = run;
+      }
+  }
+  parallel_slabs(t_slabs, [&](uint32_t sb) {
+    uint32_t *h = hist.data() + (size_t)sb * kSl;
+    const size_t t0 = slab_run[sb] < runs.size() ? runs[slab_run[sb]].task0 : n_tasks;
+    const size_t t1 = slab_run[sb + 1] < runs.size() ? runs[slab_run[sb + 1]].task0 : n_tasks;
+    for (size_t i = t0; i < t1; ++i) tasks[h[pos[i]]++] = raw[i];
+  });
+  pt("tasks");
+  uint64_t entries = 0;
+  for (size_t q = 0; q < nq; ++q) {
+    TqdQuery &dq = g.queries[q];
+    const uint64_t cap = (uint64_t)pairs[q] * dq.k;
+    if (entries + cap > 0xFFFFFFFFull) return fail(TQ_ERR_UNSUPPORTED, "batch too large (result lists)");
+    dq.part_start = (uint32_t)entries;
+    dq.n_parts = (uint32_t)cap;
+    dq.chunk_first = 0;
+    entries += cap;
+  }
+  g.total_tiles = (uint32_t)tasks.size();
+  g.n_chunks = (uint32_t)tasks.size();
+  return TQ_OK;
+}
+
+}  // namespace tqi

@@ -1,0 +1,198 @@
+// tq_submit.cpp — tq_submit / tq_wait / tq_search_one: single queries of concurrent callers coalesced into
+// batched launches (leader / followers)
+// Part of the C ABI library of include/tantivy_amd.h (internal declarations: tq_internal.hpp).
+#include "tq_internal.hpp"
+
+// ---- concurrent single-query entry: tq_submit / tq_wait / tq_search_one
+// tantivy lets any number of threads call Searcher::search at once, one query per call
+// (src/core/searcher.rs:180-238; Weight is Send + Sync, src/query/weight.rs:66), and each call ends
+// in one collect_segment per segment (src/collector/mod.rs:173-183).  One query per launch is the
+// 0.3 ms / 3 k queries/s regime of this device; the batched launch needs the queries of MANY callers.
+// Leader / followers: a caller puts its query on the segment's pending list; whoever waits while no
+// batch is running becomes the leader, takes everything pending (callers keep arriving while the
+// previous batch runs: that IS the batching), runs it as one tq_search_batch under the segment
+// lock, hands every caller its rows and wakes them up.  Nobody waits for a batch to fill.
+struct tq_ticket {
+  tq_segment *seg = nullptr;
+  tq_query q{};
+  CallOpts co{};
+  float *out_scores = nullptr;
+  uint32_t *out_docs = nullptr, *out_count = nullptr;
+  int rc = TQ_OK;
+  std::string err;
+  bool done = false;
+};
+struct SubmitQueue {
+  std::mutex m;
+  std::condition_variable cv;
+  std::condition_variable cv_arrive;  // a query was submitted (the leader's arrival window)
+  std::deque<tq_ticket *> pending;
+  bool leader_active = false;
+  size_t last_batch = 0;  // queries the previous batch carried
+  tq_submit_stats stats{};
+  // the leader's scratch
+  std::vector<tq_query> qs;
+  std::vector<float> sc;
+  std::vector<uint32_t> dc, ct;
+};
+void tq_free_submit_queue(SubmitQueue *q) { delete q; }
+
+namespace tqi {
+constexpr size_t kSubmitMaxBatch = 16384;
+std::mutex g_submit_create_m;
+
+SubmitQueue *submit_queue(tq_segment *s) {
+  std::lock_guard<std::mutex> lk(g_submit_create_m);
+  if (!s->submit) s->submit = new SubmitQueue();
+  return s->submit;
+}
+
+// one launch for the tickets of `batch` (same options); rows go to the callers' buffers
+void run_ticket_batch(SubmitQueue &Q, tq_segment *s, std::vector<tq_ticket *> &batch) {
+  const uint32_t n = (uint32_t)batch.size();
+  uint32_t stride = 1;
+  Q.qs.resize(n);
+  for (uint32_t i = 0; i < n; ++i) {
+    Q.qs[i] = batch[i]->q;
+    stride = std::max(stride, batch[i]->q.k);
+  }
+  Q.sc.resize((size_t)n * stride);
+  Q.dc.resize((size_t)n * stride);
+  Q.ct.resize(n);
+  int rc;
+  {
+    TQ_SEGMENT_LOCK(s);
+    rc = search_batch_host(s, Q.qs.data(), n, stride, Q.sc.data(), Q.dc.data(), Q.ct.data(), batch[0]->co);
+  }
+  if (rc == TQ_OK) {
+    for (uint32_t i = 0; i < n; ++i) {
+      tq_ticket *t = batch[i];
+      const uint32_t k = t->q.k;
+      memcpy(t->out_scores, Q.sc.data() + (size_t)i * stride, k * sizeof(float));
+      memcpy(t->out_docs, Q.dc.data() + (size_t)i * stride, k * sizeof(uint32_t));
+      *t->out_count = Q.ct[i];
+      t->rc = TQ_OK;
+    }
+    return;
+  }
+  if (n == 1) {
+    batch[0]->rc = rc;
+    batch[0]->err = g_last_error;
+    return;
+  }
+  // one query the device does not take (an unsupported shape, a bad handle) must not fail its
+  // neighbours: the batch is run again query by query, every caller gets its own verdict
+  for (uint32_t i = 0; i < n; ++i) {
+    std::vector<tq_ticket *> one{batch[i]};
+    run_ticket_batch(Q, s, one);
+  }
+}
+
+int ticket_wait(tq_ticket *t) {
+  tq_segment *s = t->seg;
+  SubmitQueue &Q = *s->submit;
+  std::unique_lock<std::mutex> lk(Q.m);
+  std::vector<tq_ticket *> batch;
+  while (!t->done) {
+    if (Q.leader_active || Q.pending.empty()) {
+      Q.cv.wait(lk);
+      continue;
+    }
+    // lead one batch: everything pending that runs under the first ticket's options.  Callers of
+    // the batch that just finished are on their way back with their next query: the leader gives them
+    // up to submit_window_us to arrive (until as many are pending as the last batch carried) — without
+    // it the first caller back leads a batch of one and everybody else waits a whole launch longer
+    Q.leader_active = true;
+    if (Q.pending.size() < Q.last_batch && s->opt.submit_window_us > 0) {
+      const auto deadline = std::chrono::steady_clock::now() + std::chrono::microseconds(s->opt.submit_window_us);
+      while (Q.pending.size() < Q.last_batch && Q.pending.size() < kSubmitMaxBatch)
+        if (Q.cv_arrive.wait_until(lk, deadline) == std::cv_status::timeout) break;
+    }
+    batch.clear();
+    const CallOpts co = Q.pending.front()->co;
+    for (auto it = Q.pending.begin(); it != Q.pending.end() && batch.size() < kSubmitMaxBatch;) {
+      if ((*it)->co.exhaustive == co.exhaustive && (*it)->co.bound_slack == co.bound_slack) {
+        batch.push_back(*it);
+        it = Q.pending.erase(it);
+      } else {
+        ++it;
+      }
+    }
+    lk.unlock();
+    run_ticket_batch(Q, s, batch);
+    lk.lock();
+    ++Q.stats.batches;
+    Q.stats.queries += batch.size();
+    Q.stats.max_batch = std::max<uint64_t>(Q.stats.max_batch, batch.size());
+    for (tq_ticket *b : batch) b->done = true;
+    Q.last_batch = batch.size();
+    Q.leader_active = false;
+    Q.cv.notify_all();
+  }
+  const int rc = t->rc;
+  if (rc != TQ_OK) g_last_error = t->err;  // (this thread's slot)
+  return rc;
+}
+}  // namespace tqi
+
+extern "C" {
+
+int tq_submit(tq_segment *s, const tq_query *q, const tq_search_opts *opts, float *out_scores,
+              uint32_t *out_docs, uint32_t *out_count, tq_ticket **out) {
+  if (!s || !q || !out_scores || !out_docs || !out_count || !out)
+    return fail(TQ_ERR_INVALID, "tq_submit: null argument");
+  // what can be judged without the segment's state is judged here: a bad query never joins a batch
+  if (q->n_terms == 0 || q->n_terms > TQ_MAX_TERMS)
+    return fail(TQ_ERR_INVALID, "tq_submit: n_terms %u not in 1..%u", q->n_terms, TQ_MAX_TERMS);
+  if (q->k == 0 || q->k > TQ_MAX_K) return fail(TQ_ERR_INVALID, "tq_submit: k %u not in 1..%u", q->k, TQ_MAX_K);
+  if (!q->terms || !q->weights || !q->tf_cache) return fail(TQ_ERR_INVALID, "tq_submit: null terms/weights/tf_cache");
+  CallOpts co;
+  {
+    TQ_SEGMENT_LOCK(s);
+    const int rc = resolve_opts(s, opts, co);
+    if (rc != TQ_OK) return rc;
+  }
+  tq_ticket *t = new (std::nothrow) tq_ticket();
+  if (!t) return fail(TQ_ERR_INVALID, "tq_submit: out of memory");
+  t->seg = s;
+  t->q = *q;
+  t->co = co;
+  t->out_scores = out_scores;
+  t->out_docs = out_docs;
+  t->out_count = out_count;
+  SubmitQueue *Q = submit_queue(s);
+  {
+    std::lock_guard<std::mutex> lk(Q->m);
+    Q->pending.push_back(t);
+  }
+  Q->cv_arrive.notify_one();  // (a leader may be holding its batch open for this query)
+  *out = t;
+  return TQ_OK;
+}
+
+int tq_wait(tq_ticket *t) {
+  if (!t) return fail(TQ_ERR_INVALID, "tq_wait: null ticket");
+  const int rc = ticket_wait(t);
+  delete t;
+  return rc;
+}
+
+int tq_search_one(tq_segment *s, const tq_query *q, const tq_search_opts *opts, float *out_scores,
+                  uint32_t *out_docs, uint32_t *out_count) {
+  tq_ticket *t = nullptr;
+  const int rc = tq_submit(s, q, opts, out_scores, out_docs, out_count, &t);
+  if (rc != TQ_OK) return rc;
+  return tq_wait(t);
+}
+
+int tq_get_submit_stats(tq_segment *s, tq_submit_stats *out, int reset) {
+  if (!s || !out) return fail(TQ_ERR_INVALID, "tq_get_submit_stats: null argument");
+  SubmitQueue *Q = submit_queue(s);
+  std::lock_guard<std::mutex> lk(Q->m);
+  *out = Q->stats;
+  if (reset) Q->stats = tq_submit_stats{};
+  return TQ_OK;
+}
+
+}  // extern "C"
+

@@ -1,0 +1,789 @@
+// tq_terms.cpp — tq_term_prepare: the skip list of a posting list unrolled into random-access tables (host walk or
+// device walk), the dense lists' side tables (bitmap + rank directory, byte-wide tfs, position directory, plain
+// lists) in the segment's arena, the doc matrix and its signature bits.
+//
+// Host-side format walkers restate (file:line under the tantivy checkout):
+//   skip entries        src/postings/skip.rs:205-253,275-302
+//   list framing        src/postings/block_segment_postings.rs:78-88,107-116
+//   vint tail           src/postings/compression/vint.rs:44-108
+//   positions framing   src/positions/reader.rs:43-56,84-101
+// Part of the C ABI library of include/tantivy_amd.h (internal declarations: tq_internal.hpp).
+#include "tq_internal.hpp"
+
+namespace tqi {
+int term_prepare_device(tq_segment *s, uint64_t postings_off, uint32_t postings_len,
+                        uint64_t positions_off, uint32_t positions_len, uint32_t doc_freq,
+                        tq_term_handle *out);
+int build_dense_device(tq_segment *s, uint32_t handle);
+int register_term(tq_segment *s, const TqdTerm &dt, const TermHost &th, uint64_t postings_off,
+                  tq_term_handle *out);
+int add_to_doc_signatures(tq_segment *s, uint32_t handle);
+int ensure_docmat(tq_segment *s);
+
+// Dense lists also get their term freqs as one byte per posting (255 = "255 or more: read the
+// packed value"): with the posting index from the bitmap's rank the tf of a candidate is ONE load,
+// where block record -> packed tf bits are two dependent ones (the shared-union kernel's scoring
+// stage is a chain of dependent gathers, 1.6 us each under load).  d_tfs = the decoded tfs.
+
+// a side table of a dense list: from the segment's arena, else a device allocation of its own
+int dense_alloc(tq_segment *s, size_t bytes, void **out) {
+  const size_t need = (bytes + 255) & ~(size_t)255;
+  if (!s->dense_arena && s->dense_arena_cap == 0) {
+    const size_t cap = std::max<size_t>(s->dense_budget(), (size_t)1 << 20) + PAD;
+    void *base = nullptr;
+    if (hipMalloc(&base, cap) == hipSuccess) {
+      s->dense_arena = (uint8_t *)base;
+      s->dense_arena_cap = cap;
+    } else {
+      (void)hipGetLastError();
+      s->dense_arena_cap = 1;  // (tried once: every table gets its own allocation)
+    }
+  }
+  if (s->dense_arena && s->dense_arena_used + need + PAD <= s->dense_arena_cap) {
+    *out = s->dense_arena + s->dense_arena_used;
+    s->dense_arena_used += need;
+    return TQ_OK;
+  }
+  void *ptr = nullptr;
+  HIP_TRY(hipMalloc(&ptr, bytes));
+  s->dense_extra.push_back(ptr);
+  *out = ptr;
+  return TQ_OK;
+}
+// (tables are only ever released with the segment; a failed build leaves its bytes unused)
+void dense_release(tq_segment *s, void *ptr) {
+  for (size_t i = 0; i < s->dense_extra.size(); ++i)
+    if (s->dense_extra[i] == ptr) {
+      (void)hipFree(ptr);
+      s->dense_extra.erase(s->dense_extra.begin() + (long)i);
+      return;
+    }
+}
+
+int build_tf8(tq_segment *s, uint32_t handle, const uint32_t *d_tfs) {
+  TermHost &t = s->terms[handle];
+  const size_t bytes = ((size_t)t.doc_freq + 7) & ~(size_t)7;
+  if (s->dense_bytes_total + bytes > s->dense_budget()) return TQ_OK;
+  void *blob = nullptr;
+  {
+    const int arc = dense_alloc(s, bytes + PAD, &blob);
+    if (arc != TQ_OK) return arc;
+  }
+  hipError_t e = tqk_launch_tf8_pack(d_tfs, t.doc_freq, (uint8_t *)blob, s->stream);
+  if (e != hipSuccess) {
+    dense_release(s, blob);
+    return fail(TQ_ERR_HIP, "tf8 pack: %s", hipGetErrorString(e));
+  }
+  t.tf8_blob = blob;
+  s->h_dterms[handle].tf8 = (const uint8_t *)blob;
+  s->dense_bytes_total += bytes;
+  s->bytes_bitmaps += bytes;
+  s->d_terms_dirty = true;
+  return TQ_OK;
+}
+
+// A list WITHOUT a bitmap as plain arrays — doc ids, then min(tf, 255) per posting — for the
+// doc-major union launch (tq_xunion.hip), which scatters such a list into its tile row with a
+// cursor instead of decoding blocks.  Built on the batch's stream the first time an unpruned
+// union needs the list; counts against the side tables' budget (false = over it: *ok stays false).
+int build_flat(tq_segment *s, uint32_t handle, hipStream_t st, bool *ok) {
+  TermHost &t = s->terms[handle];
+  *ok = t.flat_blob != nullptr;
+  if (*ok || t.doc_freq == 0) return TQ_OK;
+  const size_t doc_bytes = ((size_t)t.doc_freq * sizeof(uint32_t) + 15) & ~(size_t)15;
+  const size_t bytes = doc_bytes + (((size_t)t.doc_freq + 15) & ~(size_t)15);
+  if (s->dense_bytes_total + bytes > s->dense_budget()) return TQ_OK;
+  int rc = sync_terms(s, st);
+  if (rc != TQ_OK) return rc;
+  void *blob = nullptr;
+  {
+    const int arc = dense_alloc(s, bytes + PAD, &blob);
+    if (arc != TQ_OK) return arc;
+  }
+  const hipError_t e = tqk_launch_flat_list(s->dseg, s->d_terms, handle, t.n_blocks, (uint32_t *)blob,
+                                            (uint8_t *)blob + doc_bytes, st);
+  if (e != hipSuccess) {
+    dense_release(s, blob);
+    return fail(TQ_ERR_HIP, "flat list: %s", hipGetErrorString(e));
+  }
+  t.flat_blob = blob;
+  s->dense_bytes_total += bytes;
+  s->bytes_bitmaps += bytes;
+  *ok = true;
+  return TQ_OK;
+}
+
+// Orders work about to be enqueued on `st` after the segment's previous batch, whatever stream
+// that batch ran on (no-op when it is the same stream: stream order already holds).
+int order_after_last_batch(tq_segment *s, hipStream_t st) {
+  if (s->batch_in_flight && s->last_stream != st)
+    HIP_TRY(hipStreamWaitEvent(st, s->ev_batch_done, 0));
+  return TQ_OK;
+}
+// Host-side wait for everything the segment has in flight (its own stream and the last batch).
+int wait_segment_idle(tq_segment *s) {
+  HIP_TRY(hipStreamSynchronize(s->stream));
+  if (s->batch_in_flight) {
+    HIP_TRY(hipEventSynchronize(s->ev_batch_done));
+    s->batch_in_flight = false;
+  }
+  return TQ_OK;
+}
+
+// The doc matrix (TqdSegment::docmat): allocated with the first list that needs it.
+int ensure_docmat(tq_segment *s) {
+  if (s->d_docmat) return TQ_OK;
+  const size_t mat_bytes = (size_t)s->max_doc * sizeof(uint64_t);
+  if (s->dense_bytes_total + mat_bytes > s->dense_budget()) return TQ_OK;  // (stays null: over budget)
+  HIP_TRY(hipMalloc((void **)&s->d_docmat, mat_bytes + PAD));
+  HIP_TRY(hipMemsetAsync((uint8_t *)s->d_docmat + mat_bytes, 0, PAD, s->stream));
+  const hipError_t e = tqk_launch_docmat_init(s->d_docmat, s->d_fn, s->dseg.const_fieldnorm_id, s->max_doc, s->stream);
+  if (e != hipSuccess) return fail(TQ_ERR_HIP, "docmat init: %s", hipGetErrorString(e));
+  s->dense_bytes_total += mat_bytes;
+  s->bytes_docmat = mat_bytes;
+  s->dseg.docmat = s->d_docmat;
+  return TQ_OK;
+}
+
+// Lists WITHOUT a column in the doc matrix (the sparse, high-weight lists; dense lists beyond the
+// 40 columns) share the top 16 bits of the doc-matrix words: every such list sets bit
+// 48 + hash(handle) of the docs it holds.  A clear bit proves "not in the list"; a set bit means
+// "maybe" (another list with the same bit, or this one).  The union kernels test it where they
+// used to assume the list holds every candidate — a rare list holds a fraction of a percent of
+// them, and each wrong guess cost a seek and a block search.  The same gather that brings a
+// candidate's fieldnorm id and column bits brings its signature.  Only prepared (queried) lists
+// set bits; built by one decode of the list.
+int add_to_doc_signatures(tq_segment *s, uint32_t handle) {
+  if (!s->opt.docsig || !s->opt.docmat || !s->opt.dense || s->max_doc < 4096u) return TQ_OK;
+  if ((s->h_dterms[handle].has_freq >> 8) & 0xFFu) return TQ_OK;  // the list has a column
+  TermHost &t = s->terms[handle];
+  if (t.doc_freq == 0) return TQ_OK;
+  int rc = ensure_docmat(s);
+  if (rc != TQ_OK) return rc;
+  if (!s->d_docmat) return TQ_OK;
+  rc = sync_terms(s, s->stream);
+  if (rc != TQ_OK) return rc;
+  const size_t bytes = (size_t)t.doc_freq * sizeof(uint32_t);
+  rc = s->d_misc.ensure(2 * bytes + 64);
+  if (rc != TQ_OK) return rc;
+  uint32_t *dd = (uint32_t *)s->d_misc.p, *dt = dd + t.doc_freq;
+  hipError_t e = tqk_launch_decode_list(s->dseg, s->d_terms, handle, t.n_blocks, dd, dt,
+                                        s->opt.use_dpp != 0, s->stream);
+  if (e != hipSuccess) return fail(TQ_ERR_HIP, "decode launch: %s", hipGetErrorString(e));
+  const uint32_t bit = (handle * 0x9E3779B1u) >> (32 - 4);  // 0 .. TQD_SIG_BITS - 1
+  e = tqk_launch_docmat_set(s->d_docmat, dd, t.doc_freq, (TQD_SIG_SHIFT - 8u) + bit, s->max_doc, s->stream);
+  if (e != hipSuccess) return fail(TQ_ERR_HIP, "docmat signature: %s", hipGetErrorString(e));
+  s->h_dterms[handle].has_freq |= (bit + 1u) << 16;
+  s->d_terms_dirty = true;
+  return TQ_OK;
+}
+
+// Dense lists (doc_freq >= max_doc/TQD_DENSE_RATIO) also get a membership bitmap with a rank
+// directory: the list is decoded once on the device (the same kernel as tq_decode_postings),
+// and {32 doc bits, number of postings before them} pairs are uploaded.  A probe of doc d then
+// costs one 8-byte load instead of a block decode; the posting index (=> block, slot, tf) falls
+// out of the rank.  Derived data like the unrolled skip table; the index bytes stay untouched.
+int build_dense(tq_segment *s, uint32_t handle) {
+  int rc = sync_terms(s, s->stream);
+  if (rc != TQ_OK) return rc;
+  TermHost &t = s->terms[handle];
+  const size_t bytes = (size_t)t.doc_freq * sizeof(uint32_t);
+  rc = s->d_misc.ensure(2 * bytes + 64);
+  if (rc != TQ_OK) return rc;
+  uint32_t *dd = (uint32_t *)s->d_misc.p, *dt = dd + t.doc_freq;
+  hipError_t e = tqk_launch_decode_list(s->dseg, s->d_terms, handle, t.n_blocks, dd, dt,
+                                        s->opt.use_dpp != 0, s->stream);
+  if (e != hipSuccess) return fail(TQ_ERR_HIP, "decode launch: %s", hipGetErrorString(e));
+  rc = build_tf8(s, handle, dt);
+  if (rc != TQ_OK) return rc;
+  // the list's column of the doc matrix (first TQD_MAT_SLOTS dense lists of the segment, while
+  // the matrix fits the same memory budget as the bitmaps)
+  if (s->n_mat_slots < TQD_MAT_SLOTS && s->opt.docmat && t.wants_col) {
+    {
+      const int mrc = ensure_docmat(s);
+      if (mrc != TQ_OK) return mrc;
+    }
+    if (s->d_docmat) {
+      const uint32_t slot = s->n_mat_slots++;
+      e = tqk_launch_docmat_set(s->d_docmat, dd, t.doc_freq, slot, s->max_doc, s->stream);
+      if (e != hipSuccess) return fail(TQ_ERR_HIP, "docmat set: %s", hipGetErrorString(e));
+      s->h_dterms[handle].has_freq |= (slot + 1u) << 8;
+    }
+  }
+  std::vector<uint32_t> docs(t.doc_freq), tfs;
+  HIP_TRY(hipMemcpyAsync(docs.data(), dd, bytes, hipMemcpyDeviceToHost, s->stream));
+  const bool want_dir = t.positions_len > 0;
+  if (want_dir) {
+    tfs.resize(t.doc_freq);
+    HIP_TRY(hipMemcpyAsync(tfs.data(), dt, bytes, hipMemcpyDeviceToHost, s->stream));
+  }
+  HIP_TRY(hipStreamSynchronize(s->stream));
+  const size_t n_words = ((size_t)s->max_doc + 31) / 32 + 1;
+  std::vector<uint2> tab(n_words, make_uint2(0u, 0u));
+  uint32_t prev = 0;
+  for (uint32_t i = 0; i < t.doc_freq; ++i) {
+    const uint32_t d = docs[i];
+    if (d >= s->max_doc || (i && d <= prev))
+      return fail(TQ_ERR_FORMAT, "posting list not strictly increasing below max_doc");
+    tab[d >> 5].x |= 1u << (d & 31u);
+    prev = d;
+  }
+  uint32_t running = 0;
+  for (size_t w = 0; w < n_words; ++w) {
+    tab[w].y = running;
+    running += (uint32_t)__builtin_popcount(tab[w].x);
+  }
+  void *blob = nullptr;
+  {
+    const int arc = dense_alloc(s, n_words * sizeof(uint2), &blob);
+    if (arc != TQ_OK) return arc;
+  }
+  s->bytes_bitmaps += n_words * sizeof(uint2);
+  ++s->n_dense_lists;
+  hipError_t ce = hipMemcpy(blob, tab.data(), n_words * sizeof(uint2), hipMemcpyHostToDevice);
+  if (ce != hipSuccess) {
+    dense_release(s, blob);
+    return fail(TQ_ERR_HIP, "dense upload: %s", hipGetErrorString(ce));
+  }
+  t.dense_blob = blob;
+  s->h_dterms[handle].dense = (const uint2 *)blob;
+  s->d_terms_dirty = true;
+  if (want_dir) {  // position directory: positions before every fourth posting
+    const size_t n_dir = ((size_t)t.doc_freq + 3) / 4 + 1;
+    std::vector<uint32_t> dir(n_dir);
+    uint64_t run = 0;
+    for (uint32_t i = 0; i < t.doc_freq; ++i) {
+      if ((i & 3u) == 0u) dir[i >> 2] = (uint32_t)run;
+      run += tfs[i];
+    }
+    dir[n_dir - 1] = (uint32_t)run;
+    if (run != t.n_positions)
+      return fail(TQ_ERR_FORMAT, "term freqs sum to %llu positions, the stream holds %llu",
+                  (unsigned long long)run, (unsigned long long)t.n_positions);
+    void *db = nullptr;
+    {
+      const int arc = dense_alloc(s, n_dir * sizeof(uint32_t) + PAD, &db);
+      if (arc != TQ_OK) return arc;
+    }
+    hipError_t de = hipMemcpy(db, dir.data(), n_dir * sizeof(uint32_t), hipMemcpyHostToDevice);
+    if (de != hipSuccess) {
+      dense_release(s, db);
+      return fail(TQ_ERR_HIP, "position directory upload: %s", hipGetErrorString(de));
+    }
+    t.posdir_blob = db;
+    s->h_dterms[handle].pos_dir = (const uint32_t *)db;
+    s->dense_bytes_total += n_dir * sizeof(uint32_t);
+    s->bytes_posdir += n_dir * sizeof(uint32_t);
+  }
+  return TQ_OK;
+}
+}  // namespace tqi
+
+extern "C" {
+
+int tq_term_prepare(tq_segment *s, uint64_t postings_off, uint32_t postings_len,
+                    uint64_t positions_off, uint32_t positions_len, uint32_t doc_freq,
+                    tq_term_handle *out) {
+  if (!s || !out) return fail(TQ_ERR_INVALID, "tq_term_prepare: null argument");
+  TQ_SEGMENT_LOCK(s);
+  auto it = s->term_by_off.find(postings_off);
+  if (it != s->term_by_off.end()) {
+    *out = it->second;
+    return TQ_OK;
+  }
+  if (doc_freq == 0) return fail(TQ_ERR_INVALID, "tq_term_prepare: doc_freq 0 (term absent)");
+  const size_t body_len = s->idx_len - 8;
+  if (postings_off > body_len || (uint64_t)postings_len > body_len - postings_off)
+    return fail(TQ_ERR_FORMAT, "postings_range [%llu,+%u) outside the idx body (%zu)",
+                (unsigned long long)postings_off, postings_len, body_len);
+  HIP_TRY(hipSetDevice(s->device));
+  if (s->device_prepare())
+    return term_prepare_device(s, postings_off, postings_len, positions_off, positions_len, doc_freq,
+                               out);
+  const uint8_t *data = s->h_idx.data() + 8 + postings_off;
+  const size_t len = postings_len;
+  const uint64_t abs0 = 8 + postings_off;  // offset of `data` inside the uploaded sub-file
+
+  int record = s->record_option;
+  const uint32_t n_full = doc_freq / 128u, n_tail = doc_freq % 128u;
+  size_t at = 0;
+  const uint8_t *skip = nullptr;
+  size_t skip_len = 0;
+  if (doc_freq >= 128u) {  // block_segment_postings.rs:78-88
+    uint64_t sl;
+    if (!read_vint(data, len, at, sl) || sl > len - at)
+      return fail(TQ_ERR_FORMAT, "bad skip_len for term at %llu", (unsigned long long)postings_off);
+    skip = data + at;
+    skip_len = (size_t)sl;
+    at += skip_len;
+    if (skip_len < 8ull * n_full) record = TQ_BASIC;  // :107-116 (JSON terms without freqs)
+  }
+  const size_t entry = record == TQ_BASIC ? 5 : (record == TQ_WITH_FREQS ? 8 : 12);
+  if (skip_len < entry * n_full)
+    return fail(TQ_ERR_FORMAT, "skip data too short: %zu < %zu", skip_len, entry * n_full);
+  const bool has_freq = record != TQ_BASIC;
+  const size_t payload = at;
+
+  const uint32_t n_blocks = n_full + (n_tail ? 1u : 0u);
+  std::vector<uint32_t> b_last(n_blocks), b_meta(n_blocks), b_off(n_blocks);
+  std::vector<uint32_t> block_pos(n_blocks + 1, 0);
+  size_t running = 0;
+  uint64_t running_pos = 0;
+  uint32_t last_doc = 0;
+  for (uint32_t i = 0; i < n_full; ++i) {  // skip.rs:205-253,275-302
+    const uint8_t *e = skip + entry * i;
+    const uint32_t ld = rd32(e);
+    const uint32_t doc_bits = e[4] & 0x1Fu, strict = (e[4] >> 6) & 1u;
+    uint32_t tf_bits = 0, tf_sum = 0, bm_fn = 0, bm_tf = 0;
+    if (record == TQ_WITH_FREQS) {
+      tf_bits = e[5];
+      bm_fn = e[6];
+      bm_tf = e[7];
+    } else if (record == TQ_WITH_FREQS_AND_POSITIONS) {
+      tf_bits = e[5];
+      tf_sum = rd32(e + 6);
+      bm_fn = e[10];
+      bm_tf = e[11];
+    }
+    if (tf_bits > 32u) return fail(TQ_ERR_FORMAT, "tf bit width %u > 32", tf_bits);
+    if (i && ld <= last_doc) return fail(TQ_ERR_FORMAT, "skip last_doc not increasing");
+    if (running_pos > 0xFFFFFFFFull)
+      return fail(TQ_ERR_UNSUPPORTED, "term with more than 2^32 positions");
+    b_last[i] = ld;
+    b_meta[i] = doc_bits | (strict << 6) | (tf_bits << 8) | (bm_fn << 16) | (bm_tf << 24);
+    b_off[i] = (uint32_t)running;  // < postings_len, a u32 (term_info.rs:10-17)
+    block_pos[i] = (uint32_t)running_pos;
+    running += 16u * (size_t)(doc_bits + tf_bits);
+    running_pos += tf_sum;
+    last_doc = ld;
+  }
+  if (payload + running > len) return fail(TQ_ERR_FORMAT, "bitpacked payload exceeds the list");
+  std::vector<uint32_t> tail_docs(n_tail), tail_tfs(n_tail, 1u);
+  if (n_tail) {  // vint.rs:44-108; docs delta from the last full block (0 if none)
+    size_t t = payload + running;
+    uint32_t prev = n_full ? last_doc : 0u;
+    for (uint32_t i = 0; i < n_tail; ++i) {
+      uint32_t d;
+      if (!read_vint32_block(data, len, t, d)) return fail(TQ_ERR_FORMAT, "truncated vint docs");
+      prev += d;
+      tail_docs[i] = prev;
+    }
+    if (has_freq && t < len) {
+      for (uint32_t i = 0; i < n_tail; ++i)
+        if (!read_vint32_block(data, len, t, tail_tfs[i]))
+          return fail(TQ_ERR_FORMAT, "truncated vint term freqs");
+    }
+    if (running_pos > 0xFFFFFFFFull)
+      return fail(TQ_ERR_UNSUPPORTED, "term with more than 2^32 positions");
+    b_last[n_full] = tail_docs[n_tail - 1];
+    b_meta[n_full] = 0xFFFFFFFFu;
+    b_off[n_full] = 0;
+    block_pos[n_full] = (uint32_t)running_pos;
+    if (record == TQ_WITH_FREQS_AND_POSITIONS)  // tf sums only index a positions stream
+      for (uint32_t i = 0; i < n_tail; ++i) running_pos += tail_tfs[i];
+    last_doc = tail_docs[n_tail - 1];
+  }
+  if (running_pos > 0xFFFFFFFFull)
+    return fail(TQ_ERR_UNSUPPORTED, "term with more than 2^32 positions");
+  block_pos[n_blocks] = (uint32_t)running_pos;
+  if (last_doc >= TQ_TERMINATED) return fail(TQ_ERR_FORMAT, "doc id >= TERMINATED");
+  if (last_doc >= s->max_doc)
+    return fail(TQ_ERR_FORMAT, "doc id %u >= max_doc %u", last_doc, s->max_doc);
+
+  // coarse[b] = first block j with last_doc[j] >= b << shift, about one block per bucket
+  uint32_t shift = 7;
+  while (shift < 31 && ((uint64_t)(s->max_doc - 1) >> shift) + 1 > 2ull * n_blocks + 2) ++shift;
+  const uint32_t n_buckets = (uint32_t)(((uint64_t)(s->max_doc - 1)) >> shift) + 1;
+  std::vector<uint32_t> coarse(n_buckets + 1);
+  {
+    uint32_t j = 0;
+    for (uint32_t b = 0; b <= n_buckets; ++b) {
+      const uint64_t lo = (uint64_t)b << shift;
+      while (j < n_blocks && (uint64_t)b_last[j] < lo) ++j;
+      coarse[b] = j;
+    }
+  }
+
+  // positions stream (positions/reader.rs:43-56,84-101)
+  std::vector<uint64_t> pos_block_off;
+  std::vector<uint8_t> pos_widths;
+  std::vector<uint32_t> pos_tail;
+  const bool want_pos = s->record_option == TQ_WITH_FREQS_AND_POSITIONS && !s->h_pos.empty() &&
+                        record == TQ_WITH_FREQS_AND_POSITIONS;
+  if (want_pos) {
+    if (positions_off > s->h_pos.size() || (uint64_t)positions_len > s->h_pos.size() - positions_off)
+      return fail(TQ_ERR_FORMAT, "positions_range outside the pos file");
+    const uint8_t *pd = s->h_pos.data() + positions_off;
+    size_t pa = 0;
+    uint64_t nb;
+    if (!read_vint(pd, positions_len, pa, nb) || nb > positions_len - pa)
+      return fail(TQ_ERR_FORMAT, "bad positions header");
+    pos_widths.assign(pd + pa, pd + pa + nb);
+    pa += (size_t)nb;
+    size_t prun = 0;
+    pos_block_off.resize((size_t)nb);
+    for (size_t i = 0; i < nb; ++i) {
+      if (pos_widths[i] > 32) return fail(TQ_ERR_FORMAT, "position bit width > 32");
+      pos_block_off[i] = (uint64_t)(positions_off + pa + prun) | ((uint64_t)pos_widths[i] << 56);
+      prun += 16u * (size_t)pos_widths[i];
+    }
+    size_t t = pa + prun;
+    if (t > positions_len) return fail(TQ_ERR_FORMAT, "bitpacked positions exceed the range");
+    while (t < positions_len) {  // uncompress_vint_unsorted_until_end
+      uint32_t v;
+      if (!read_vint32_block(pd, positions_len, t, v))
+        return fail(TQ_ERR_FORMAT, "truncated vint positions");
+      pos_tail.push_back(v);
+    }
+    const uint64_t n_pos = (uint64_t)nb * 128u + pos_tail.size();
+    if (n_pos != running_pos)
+      return fail(TQ_ERR_FORMAT, "positions stream holds %llu values, postings say %llu",
+                  (unsigned long long)n_pos, (unsigned long long)running_pos);
+  }
+
+  // one blob holding every per-term array
+  auto align16 = [](size_t x) { return (x + 15) & ~(size_t)15; };
+  size_t total = 0;
+  auto place = [&](size_t bytes) {
+    const size_t o = total;
+    total = align16(total + bytes);
+    return o;
+  };
+  const size_t o_rec = place(16 * (size_t)(n_blocks + 1));
+  const size_t o_coarse = place(4 * coarse.size());
+  const size_t o_tdocs = place(4 * (size_t)n_tail);
+  const size_t o_ttfs = place(4 * (size_t)n_tail);
+  const size_t o_pboff = place(8 * pos_block_off.size());
+  const size_t o_ptail = place(4 * pos_tail.size());
+  total += PAD;
+  std::vector<uint8_t> hb(total, 0);
+  for (uint32_t i = 0; i <= n_blocks; ++i) {
+    const uint32_t r[4] = {i < n_blocks ? b_last[i] : TQ_TERMINATED, i < n_blocks ? b_meta[i] : 0u,
+                           i < n_blocks ? b_off[i] : 0u, block_pos[i]};
+    memcpy(hb.data() + o_rec + 16 * (size_t)i, r, 16);
+  }
+  memcpy(hb.data() + o_coarse, coarse.data(), 4 * coarse.size());
+  if (n_tail) {
+    memcpy(hb.data() + o_tdocs, tail_docs.data(), 4 * (size_t)n_tail);
+    memcpy(hb.data() + o_ttfs, tail_tfs.data(), 4 * (size_t)n_tail);
+  }
+  if (!pos_block_off.empty()) memcpy(hb.data() + o_pboff, pos_block_off.data(), 8 * pos_block_off.size());
+  if (!pos_tail.empty()) memcpy(hb.data() + o_ptail, pos_tail.data(), 4 * pos_tail.size());
+  uint8_t *blob = nullptr;
+  HIP_TRY(hipMalloc((void **)&blob, total));
+  s->bytes_term_tables += total;
+  hipError_t ce = hipMemcpy(blob, hb.data(), total, hipMemcpyHostToDevice);
+  if (ce != hipSuccess) {
+    (void)hipFree(blob);
+    return fail(TQ_ERR_HIP, "term upload: %s", hipGetErrorString(ce));
+  }
+  TqdTerm dt{};
+  dt.rec = (const uint4 *)(blob + o_rec);
+  dt.coarse = (const uint32_t *)(blob + o_coarse);
+  dt.tail_docs = (const uint32_t *)(blob + o_tdocs);
+  dt.tail_tfs = (const uint32_t *)(blob + o_ttfs);
+  dt.pos_blk = (const uint64_t *)(blob + o_pboff);
+  dt.pos_tail = (const uint32_t *)(blob + o_ptail);
+  dt.payload_base = abs0 + payload;
+  dt.n_full = n_full;
+  dt.n_tail = n_tail;
+  dt.n_blocks = n_blocks;
+  dt.doc_freq = doc_freq;
+  dt.n_pos_blocks = (uint32_t)pos_block_off.size();
+  dt.n_pos_tail = (uint32_t)pos_tail.size();
+  dt.has_freq = has_freq ? 1u : 0u;
+  dt.coarse_shift = shift;
+
+  TermHost th;
+  th.blob = blob;
+  th.doc_freq = doc_freq;
+  th.n_blocks = n_blocks;
+  th.n_full = n_full;
+  th.n_tail = n_tail;
+  th.last_doc = last_doc;
+  th.postings_len = postings_len;
+  th.positions_len = want_pos ? positions_len : 0;
+  th.n_positions = want_pos ? running_pos : 0;
+  return register_term(s, dt, th, postings_off, out);
+}
+
+}  // extern "C"
+
+namespace tqi {
+
+
+const char *tqp_message(uint32_t st) {
+  switch (st) {
+    case TQP_BAD_SKIP_LEN: return "bad skip_len";
+    case TQP_SKIP_TOO_SHORT: return "skip data too short";
+    case TQP_NOT_INCREASING: return "skip last_doc not increasing";
+    case TQP_BAD_TF_WIDTH: return "tf bit width > 32";
+    case TQP_TOO_MANY_POSITIONS: return "term with more than 2^32 positions";
+    case TQP_PAYLOAD_TOO_LONG: return "bitpacked payload exceeds the list";
+    case TQP_TRUNCATED_TAIL: return "truncated vint tail";
+    case TQP_DOC_OUT_OF_RANGE: return "doc id >= max_doc / TERMINATED";
+    case TQP_BAD_POS_HEADER: return "bad positions header";
+    case TQP_POS_COUNT_MISMATCH: return "positions stream and postings disagree on the number of positions";
+    case TQP_BAD_POS_WIDTH: return "position bit width > 32";
+    case TQP_POS_PAYLOAD_TOO_LONG: return "bitpacked positions exceed the range";
+    default: return "unknown";
+  }
+}
+
+// the part of tq_term_prepare both paths share: the handle, and the dense-list structures
+int register_term(tq_segment *s, const TqdTerm &dt, const TermHost &th, uint64_t postings_off,
+                  tq_term_handle *out) {
+  const uint32_t handle = (uint32_t)s->terms.size();
+  s->terms.push_back(th);
+  s->terms.back().wants_col = !s->cols_reserved || s->reserved_cols.count(postings_off) != 0;
+  s->h_dterms.push_back(dt);
+  s->d_terms_dirty = true;
+  s->term_by_off.emplace(postings_off, handle);
+  *out = handle;
+  // 0.25 B/doc per bitmap: worth it for lists whose 128-doc blocks span few docs, and only while
+  // the bitmaps together stay within a fixed multiple of the segment's own size
+  const size_t dense_bytes = (((size_t)s->max_doc + 31) / 32 + 1) * sizeof(uint2);
+  const size_t budget = s->dense_budget();
+  if (s->opt.dense && s->max_doc >= 4096u &&
+      (uint64_t)th.doc_freq * (uint64_t)s->opt.dense_ratio >= s->max_doc &&
+      s->dense_bytes_total + dense_bytes <= budget) {
+    s->dense_bytes_total += dense_bytes;
+    const int rc = s->device_prepare() ? build_dense_device(s, handle) : build_dense(s, handle);
+    if (rc != TQ_OK) return rc;
+  }
+  return add_to_doc_signatures(s, handle);
+}
+
+// tq_term_prepare without a host copy of the index: two small kernels walk the list's skip data
+// and positions header where they lie in HBM (tq_prepare.hip); the host sizes the tables from
+// TermInfo, and reads back 48 bytes of facts in between (no index bytes).
+int term_prepare_device(tq_segment *s, uint64_t postings_off, uint32_t postings_len,
+                        uint64_t positions_off, uint32_t positions_len, uint32_t doc_freq,
+                        tq_term_handle *out) {
+  const uint32_t n_full = doc_freq / 128u, n_tail = doc_freq % 128u;
+  const uint32_t n_blocks = n_full + (n_tail ? 1u : 0u);
+  uint32_t shift = 7;
+  while (shift < 31 && ((uint64_t)(s->max_doc - 1) >> shift) + 1 > 2ull * n_blocks + 2) ++shift;
+  const uint32_t n_buckets = (uint32_t)(((uint64_t)(s->max_doc - 1)) >> shift) + 1;
+  const bool maybe_pos = s->record_option == TQ_WITH_FREQS_AND_POSITIONS && s->d_pos != nullptr;
+  if (maybe_pos && (positions_off > s->pos_len || (uint64_t)positions_len > s->pos_len - positions_off))
+    return fail(TQ_ERR_FORMAT, "positions_range outside the pos file");
+  auto align16 = [](size_t x) { return (x + 15) & ~(size_t)15; };
+  size_t total = 0;
+  auto place = [&](size_t bytes) {
+    const size_t o = total;
+    total = align16(total + bytes);
+    return o;
+  };
+  const size_t o_rec = place(16 * (size_t)(n_blocks + 1));
+  const size_t o_coarse = place(4 * (size_t)(n_buckets + 1));
+  const size_t o_tdocs = place(4 * (size_t)n_tail);
+  const size_t o_ttfs = place(4 * (size_t)n_tail);
+  total += PAD;
+  uint8_t *blob = nullptr;
+  HIP_TRY(hipMalloc((void **)&blob, total));
+  s->bytes_term_tables += total;
+  auto bail = [&](int rc) {
+    (void)hipFree(blob);
+    return rc;
+  };
+  hipError_t e = hipMemsetAsync(blob, 0, total, s->stream);
+  TqpPostingsParams pp{};
+  pp.idx = s->d_idx;
+  pp.pos = s->d_pos;
+  pp.postings_off = postings_off;
+  pp.positions_off = positions_off;
+  pp.postings_len = postings_len;
+  pp.positions_len = positions_len;
+  pp.doc_freq = doc_freq;
+  pp.record_option = s->record_option;
+  pp.max_doc = s->max_doc;
+  pp.want_pos = maybe_pos ? 1u : 0u;
+  pp.rec = (uint4 *)(blob + o_rec);
+  pp.tail_docs = (uint32_t *)(blob + o_tdocs);
+  pp.tail_tfs = (uint32_t *)(blob + o_ttfs);
+  pp.info = s->d_tp_info;
+  if (e == hipSuccess) e = tqp_launch_postings(pp, s->stream);
+  TqpInfo info{};
+  if (e == hipSuccess) e = hipMemcpyAsync(&info, s->d_tp_info, sizeof info, hipMemcpyDeviceToHost, s->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(s->stream);
+  if (e != hipSuccess) return bail(fail(TQ_ERR_HIP, "device term prepare: %s", hipGetErrorString(e)));
+  if (info.status != TQP_OK)
+    return bail(fail(info.status == TQP_TOO_MANY_POSITIONS ? TQ_ERR_UNSUPPORTED : TQ_ERR_FORMAT,
+                     "term at %llu: %s", (unsigned long long)postings_off, tqp_message(info.status)));
+  e = tqp_launch_coarse((const uint4 *)(blob + o_rec), n_blocks, shift, n_buckets,
+                        (uint32_t *)(blob + o_coarse), s->stream);
+  if (e != hipSuccess) return bail(fail(TQ_ERR_HIP, "coarse table: %s", hipGetErrorString(e)));
+  // positions tables, sized from the walk
+  const bool want_pos = maybe_pos && info.record == TQ_WITH_FREQS_AND_POSITIONS;
+  uint8_t *pblob = nullptr;
+  uint32_t n_pos_tail = 0;
+  size_t o_pboff = 0, o_ptail = 0;
+  if (want_pos) {
+    const uint64_t tail_cap = info.n_positions - info.n_pos_blocks * 128ull;
+    if (tail_cap > 127ull)
+      return bail(fail(TQ_ERR_FORMAT, "positions stream and postings disagree on the number of positions"));
+    size_t ptotal = 0;
+    o_pboff = 0;
+    ptotal = align16(8 * (size_t)info.n_pos_blocks);
+    o_ptail = ptotal;
+    ptotal = align16(ptotal + 4 * (size_t)tail_cap) + PAD;
+    e = hipMalloc((void **)&pblob, ptotal);
+    if (e == hipSuccess) s->bytes_term_tables += ptotal;
+    if (e == hipSuccess) e = hipMemsetAsync(pblob, 0, ptotal, s->stream);
+    TqpPositionsParams qp{};
+    qp.pos = s->d_pos;
+    qp.positions_off = positions_off;
+    qp.pos_hdr = info.pos_hdr;
+    qp.n_pos_blocks = info.n_pos_blocks;
+    qp.n_positions = info.n_positions;
+    qp.positions_len = positions_len;
+    qp.pos_tail_cap = (uint32_t)tail_cap;
+    qp.pos_blk = (uint64_t *)(pblob + o_pboff);
+    qp.pos_tail = (uint32_t *)(pblob + o_ptail);
+    qp.result = (uint32_t *)(s->d_tp_info + 1);
+    uint32_t res[2] = {0, 0};
+    if (e == hipSuccess) e = tqp_launch_positions(qp, s->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(res, s->d_tp_info + 1, sizeof res, hipMemcpyDeviceToHost, s->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(s->stream);
+    if (e != hipSuccess || res[0] != TQP_OK) {
+      if (pblob) (void)hipFree(pblob);
+      return bail(e != hipSuccess ? fail(TQ_ERR_HIP, "device positions prepare: %s", hipGetErrorString(e))
+                                  : fail(TQ_ERR_FORMAT, "term at %llu: %s", (unsigned long long)postings_off,
+                                         tqp_message(res[0])));
+    }
+    n_pos_tail = res[1];
+  } else {
+    HIP_TRY(hipStreamSynchronize(s->stream));
+  }
+  TqdTerm dt{};
+  dt.rec = (const uint4 *)(blob + o_rec);
+  dt.coarse = (const uint32_t *)(blob + o_coarse);
+  dt.tail_docs = (const uint32_t *)(blob + o_tdocs);
+  dt.tail_tfs = (const uint32_t *)(blob + o_ttfs);
+  dt.pos_blk = (const uint64_t *)(pblob ? pblob + o_pboff : blob + o_rec);
+  dt.pos_tail = (const uint32_t *)(pblob ? pblob + o_ptail : blob + o_rec);
+  dt.payload_base = 8 + postings_off + info.payload;
+  dt.n_full = n_full;
+  dt.n_tail = n_tail;
+  dt.n_blocks = n_blocks;
+  dt.doc_freq = doc_freq;
+  dt.n_pos_blocks = want_pos ? (uint32_t)info.n_pos_blocks : 0u;
+  dt.n_pos_tail = n_pos_tail;
+  dt.has_freq = info.record != TQ_BASIC ? 1u : 0u;
+  dt.coarse_shift = shift;
+  TermHost th;
+  th.blob = blob;
+  th.pos_blob = pblob;
+  th.doc_freq = doc_freq;
+  th.n_blocks = n_blocks;
+  th.n_full = n_full;
+  th.n_tail = n_tail;
+  th.last_doc = info.last_doc;
+  th.postings_len = postings_len;
+  th.positions_len = want_pos ? positions_len : 0;
+  th.n_positions = want_pos ? info.n_positions : 0;
+  return register_term(s, dt, th, postings_off, out);
+}
+
+// build_dense without the host: bitmap bits by atomic OR, rank directory and position directory
+// by device scans; 4 bytes (the validity flag) come back.
+int build_dense_device(tq_segment *s, uint32_t handle) {
+  int rc = sync_terms(s, s->stream);
+  if (rc != TQ_OK) return rc;
+  TermHost &t = s->terms[handle];
+  const size_t bytes = (size_t)t.doc_freq * sizeof(uint32_t);
+  rc = s->d_misc.ensure(2 * bytes + 64);
+  if (rc != TQ_OK) return rc;
+  uint32_t *dd = (uint32_t *)s->d_misc.p, *dt = dd + t.doc_freq;
+  hipError_t e = tqk_launch_decode_list(s->dseg, s->d_terms, handle, t.n_blocks, dd, dt,
+                                        s->opt.use_dpp != 0, s->stream);
+  if (e != hipSuccess) return fail(TQ_ERR_HIP, "decode launch: %s", hipGetErrorString(e));
+  rc = build_tf8(s, handle, dt);
+  if (rc != TQ_OK) return rc;
+  const size_t n_words = ((size_t)s->max_doc + 31) / 32 + 1;
+  void *blob = nullptr;
+  {
+    const int arc = dense_alloc(s, n_words * sizeof(uint2), &blob);
+    if (arc != TQ_OK) return arc;
+  }
+  s->bytes_bitmaps += n_words * sizeof(uint2);
+  ++s->n_dense_lists;
+  uint32_t *bad = (uint32_t *)s->d_tp_info;
+  e = hipMemsetAsync(blob, 0, n_words * sizeof(uint2), s->stream);
+  if (e == hipSuccess) e = hipMemsetAsync(bad, 0, 4, s->stream);
+  if (e == hipSuccess)
+    e = tqp_launch_dense(dd, t.doc_freq, s->max_doc, (uint2 *)blob, (uint32_t)n_words, bad, s->stream);
+  uint32_t h_bad = 0;
+  if (e == hipSuccess) e = hipMemcpyAsync(&h_bad, bad, 4, hipMemcpyDeviceToHost, s->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(s->stream);
+  if (e != hipSuccess || h_bad) {
+    dense_release(s, blob);
+    return e != hipSuccess ? fail(TQ_ERR_HIP, "dense tables: %s", hipGetErrorString(e))
+                           : fail(TQ_ERR_FORMAT, "posting list not strictly increasing below max_doc");
+  }
+  t.dense_blob = blob;
+  s->h_dterms[handle].dense = (const uint2 *)blob;
+  s->d_terms_dirty = true;
+  if (s->n_mat_slots < TQD_MAT_SLOTS && s->opt.docmat && t.wants_col) {  // the list's column of the doc matrix
+    {
+      const int mrc = ensure_docmat(s);
+      if (mrc != TQ_OK) return mrc;
+    }
+    if (s->d_docmat) {
+      const uint32_t slot = s->n_mat_slots++;
+      e = tqk_launch_docmat_set(s->d_docmat, dd, t.doc_freq, slot, s->max_doc, s->stream);
+      if (e != hipSuccess) return fail(TQ_ERR_HIP, "docmat set: %s", hipGetErrorString(e));
+      s->h_dterms[handle].has_freq |= (slot + 1u) << 8;
+    }
+  }
+  if (t.positions_len > 0) {  // position directory: positions before every fourth posting
+    const size_t n_dir = ((size_t)t.doc_freq + 3) / 4 + 1;
+    void *db = nullptr;
+    {
+      const int arc = dense_alloc(s, n_dir * sizeof(uint32_t) + PAD, &db);
+      if (arc != TQ_OK) return arc;
+    }
+    e = tqp_launch_posdir(dt, t.doc_freq, (uint32_t *)db, (uint32_t)n_dir, s->stream);
+    uint32_t total = 0;
+    if (e == hipSuccess)
+      e = hipMemcpyAsync(&total, (uint32_t *)db + (n_dir - 1), 4, hipMemcpyDeviceToHost, s->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(s->stream);
+    if (e != hipSuccess || total != (uint32_t)t.n_positions) {
+      dense_release(s, db);
+      return e != hipSuccess ? fail(TQ_ERR_HIP, "position directory: %s", hipGetErrorString(e))
+                             : fail(TQ_ERR_FORMAT, "term freqs sum to %u positions, the stream holds %llu",
+                                    total, (unsigned long long)t.n_positions);
+    }
+    t.posdir_blob = db;
+    s->h_dterms[handle].pos_dir = (const uint32_t *)db;
+    s->dense_bytes_total += n_dir * sizeof(uint32_t);
+    s->bytes_posdir += n_dir * sizeof(uint32_t);
+  }
+  HIP_TRY(hipStreamSynchronize(s->stream));
+  return TQ_OK;
+}
+
+
+int sync_terms(tq_segment *s, hipStream_t st) {
+  if (!s->d_terms_dirty) return TQ_OK;
+  const size_t n = s->h_dterms.size();
+  // nothing in flight may still read the table while it is rewritten (terms are prepared rarely)
+  {
+    const int wrc = wait_segment_idle(s);
+    if (wrc != TQ_OK) return wrc;
+  }
+  if (n > s->d_terms_cap) {
+    HIP_TRY(hipStreamSynchronize(st));
+    if (s->d_terms) (void)hipFree(s->d_terms);
+    s->d_terms = nullptr;
+    size_t cap = std::max<size_t>(256, n * 2);
+    HIP_TRY(hipMalloc((void **)&s->d_terms, cap * sizeof(TqdTerm)));
+    s->d_terms_cap = cap;
+  }
+  HIP_TRY(hipMemcpy(s->d_terms, s->h_dterms.data(), n * sizeof(TqdTerm), hipMemcpyHostToDevice));
+  s->d_terms_dirty = false;
+  return TQ_OK;
+}
+
+}  // namespace tqi

@@ -22,8 +22,7 @@ def plan_check(tmp_path_factory):
     src = os.path.join(ROOT, "tools", "planbench", "plan_check.cpp")
     subprocess.check_call([HIPCC, "-O1", "-std=c++17", "-Wno-unused-function", "-fPIC", "-c", src, "-o", obj],
                           cwd=str(out.parent))
-    objs = [os.path.join(B.OBJ_DIR, os.path.basename(s) + ".o") for s in B.SOURCES
-            if os.path.basename(s).endswith(".hip") or os.path.basename(s) == "tq_comm.cpp"]
+    objs = [os.path.join(B.OBJ_DIR, os.path.basename(s) + ".o") for s in B.SOURCES if os.sep + "csrc" + os.sep in s]
     subprocess.check_call([HIPCC, "--offload-arch=gfx950", "-o", str(out), obj] + objs + ["-ldl", "-lpthread"],
                           cwd=str(out.parent))
     return str(out)
@@ -101,8 +100,7 @@ def test_eight_planners_at_once(tmp_path_factory):
     src = os.path.join(ROOT, "tools", "planbench", "plan_bench.cpp")
     subprocess.check_call([HIPCC, "-O3", "-std=c++17", "-Wno-unused-function", "-fPIC", "-c", src, "-o", obj],
                           cwd=str(out.parent))
-    objs = [os.path.join(B.OBJ_DIR, os.path.basename(s) + ".o") for s in B.SOURCES
-            if os.path.basename(s).endswith(".hip") or os.path.basename(s) == "tq_comm.cpp"]
+    objs = [os.path.join(B.OBJ_DIR, os.path.basename(s) + ".o") for s in B.SOURCES if os.sep + "csrc" + os.sep in s]
     subprocess.check_call([HIPCC, "--offload-arch=gfx950", "-o", str(out), obj] + objs + ["-ldl", "-lpthread"],
                           cwd=str(out.parent))
 

@@ -2,7 +2,7 @@
 // group shaped like the union half of the mixed bench stream: 5000 5-term candidate unions over a
 // 256-term Zipf vocabulary, 10M docs.  No GPU needed: the planner is plain host code.
 //   hipcc -O3 -std=c++17 -I tantivy_amd/csrc tools/planbench/plan_bench.cpp -o /tmp/plan_bench
-#include "../../tantivy_amd/csrc/tq_api.cpp"
+#include "../../tantivy_amd/csrc/tq_internal.hpp"
 
 #include <chrono>
 #include <random>

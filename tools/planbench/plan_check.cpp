@@ -5,7 +5,7 @@
 //   * a chunk's query is the query that holds its first tile;
 //   * chunk_recs is a permutation of the chunks (every chunk launched exactly once);
 //   * chunk_first / n_parts of a query = the chunks that hold its tiles.
-#include "../../tantivy_amd/csrc/tq_api.cpp"
+#include "../../tantivy_amd/csrc/tq_internal.hpp"
 
 #include <random>
 
