@@ -535,7 +535,11 @@ class PlanPool {
       // wake-up through the condition variable costs 50-100 us, more than most of the jobs)
       const auto spin_until = std::chrono::steady_clock::now() + std::chrono::microseconds(400);
       while (generation_.load(std::memory_order_acquire) == seen && std::chrono::steady_clock::now() < spin_until)
+#if defined(__x86_64__) || defined(__i386__)
         __builtin_ia32_pause();
+#else
+        std::this_thread::yield();
+#endif
       {
         std::unique_lock<std::mutex> lk(m_);
         cv_.wait(lk, [&] { return generation_.load(std::memory_order_relaxed) != seen; });

@@ -45,6 +45,11 @@ int build_dense_plan(tq_segment *s, Group &g, PlanScratch &ps, uint32_t cus) {
   const uint32_t n_tasks = (n_tiles + ps.x_tiles_per_task - 1) / ps.x_tiles_per_task;
   ps.xgrid = std::min<uint32_t>(n_tasks, cus);
   g.kpl = g.max_k <= 64 ? 1 : 2;
+  {  // a staging list per (workgroup, query): fewer workgroups rather than gigabytes of staging (TQ_XU_STAGE_MB)
+    static const uint64_t kStageBudget = (uint64_t)std::max<uint32_t>(1u, tune_u32("TQ_XU_STAGE_MB", 1024)) << 20;
+    const uint64_t per_wg = (uint64_t)g.queries.size() * (uint64_t)(g.kpl + 1) * 64u * sizeof(uint64_t);
+    ps.xgrid = (uint32_t)std::max<uint64_t>(1u, std::min<uint64_t>(ps.xgrid, kStageBudget / std::max<uint64_t>(1u, per_wg)));
+  }
   g.n_chunks = n_tasks;
   g.total_tiles = n_tiles;
   ps.x_list_stride = ps.xgrid * g.max_k;

@@ -166,7 +166,15 @@ int build_share_plan(tq_segment *s, Group &g, PlanScratch &ps) {
     phase_cost[keys[r0].key >> 56] += (uint64_t)s->terms[keys[r0].term].n_blocks * (4u * n_groups + n_run);
     r0 = r1;
   }
-  // runs of one (position, term, cache): groups of leads x runs of blocks
+  // runs of one (position, term, cache): groups of leads x runs of blocks.  Every (task, lead) pair may
+  // append k entries to its query's result list: if the lists of the batch would not fit the budget
+  // (TQ_US_LIST_MB; 10 000 five-term unions at k = 100 asked for several GB) the tasks are made longer —
+  // fewer pairs, the same blocks — instead of failing the batch
+  static const uint64_t kListBudget = (uint64_t)std::max<uint32_t>(1u, tune_u32("TQ_US_LIST_MB", 2048)) << 20;
+  uint32_t stretch = 1;
+retry_tasks:
+  tasks.clear();
+  pairs.assign(nq, 0u);
   for (uint32_t i = 0; i <= TQD_US_MAX_TERMS; ++i) ps.share_phase_first[i] = 0;
   uint32_t phase = 0;
   for (size_t r0 = 0; r0 < keys.size();) {
@@ -184,6 +192,7 @@ int build_share_plan(tq_segment *s, Group &g, PlanScratch &ps) {
     // tasks keep the share of the batch that is in flight before thresholds exist small
     uint32_t bpt = task_cost / (4u + per_group);
     bpt = std::min<uint32_t>(kTaskBlocksMax, std::max<uint32_t>(1u, bpt));
+    bpt = (uint32_t)std::min<uint64_t>(0xFFFFu, (uint64_t)bpt * stretch);
     for (uint32_t j0 = 0; j0 < n_blocks; j0 += bpt) {
       const uint32_t nb = std::min<uint32_t>(bpt, n_blocks - j0);
       for (uint32_t gr = 0; gr < n_groups; ++gr) {
@@ -200,6 +209,14 @@ int build_share_plan(tq_segment *s, Group &g, PlanScratch &ps) {
   pt("tasks");
   if (tasks.size() > 0x7FFFFFFFull) return fail(TQ_ERR_UNSUPPORTED, "batch too large (tasks)");
   // result lists: every (task, lead) pair appends at most k entries
+  {
+    uint64_t total = 0;
+    for (size_t q = 0; q < nq; ++q) total += (uint64_t)pairs[q] * g.queries[q].k;
+    if ((total * sizeof(uint64_t) > kListBudget || total > 0xFFFFFFFFull) && stretch < 65536u) {
+      stretch *= 2u;
+      goto retry_tasks;
+    }
+  }
   uint64_t entries = 0;
   for (size_t q = 0; q < nq; ++q) {
     TqdQuery &dq = g.queries[q];

@@ -42,7 +42,8 @@ def test_chunk_tables_cover_every_tile_once(plan_check, threads, chunks):
 def test_share_plan_invariants(plan_check, seed):
     """build_share_plan (the shared-union launch's planner): leads, lead records, tasks and result
     regions against a host-side restatement of their definitions."""
-    for env_extra in ({}, {"TQ_US_TASK_COST": "256", "TQ_US_GROUP": "8"}, {"TQ_US_TASK_BLOCKS": "16"}):
+    for env_extra in ({}, {"TQ_US_TASK_COST": "256", "TQ_US_GROUP": "8"}, {"TQ_US_TASK_BLOCKS": "16"},
+                      {"TQ_US_LIST_MB": "1"}):  # (a result-list budget that forces longer tasks)
         r = subprocess.run([plan_check, str(seed), "share"], env=dict(os.environ, **env_extra),
                            capture_output=True, text=True, timeout=300)
         assert r.returncode == 0, r.stderr + r.stdout
@@ -124,3 +125,35 @@ def test_eight_planners_at_once(tmp_path_factory):
     assert all(p.returncode == 0 for p in procs)
     slack = 2.5 * max(1.0, 8.0 / len(cpus))  # (fewer than eight CPUs: the processes share cores)
     assert max(meds) <= slack * alone + 0.5, (alone, meds)
+
+
+def test_planners_under_thread_sanitizer(tmp_path_factory):
+    """the planner translation units and the thread pool built with
+    -fsanitize=thread, every check of plan_check run with four planner threads: no data race report."""
+    from tantivy_amd import build as B
+
+    B.build()
+    d = tmp_path_factory.mktemp("tsan")
+    csrc = os.path.join(ROOT, "tantivy_amd", "csrc")
+    units = ["tq_plan_chunks.cpp", "tq_plan_share.cpp", "tq_plan_misc.cpp"]
+    tsan_objs = []
+    for u in units + [os.path.join(ROOT, "tools", "planbench", "plan_check.cpp")]:
+        src = u if os.path.isabs(u) else os.path.join(csrc, u)
+        obj = str(d / (os.path.basename(src) + ".o"))
+        r = subprocess.run([HIPCC, "--offload-arch=gfx950", "-O1", "-g", "-std=c++17", "-ffp-contract=off", "-fPIC",
+                            "-Wno-unused-function", "-fsanitize=thread", "-c", src, "-o", obj], capture_output=True, text=True)
+        if r.returncode != 0:
+            pytest.skip("no ThreadSanitizer build here: " + r.stderr[-300:])
+        tsan_objs.append(obj)
+    others = [os.path.join(B.OBJ_DIR, os.path.basename(s) + ".o") for s in B.SOURCES
+              if os.sep + "csrc" + os.sep in s and os.path.basename(s) not in units]
+    exe = str(d / "plan_check_tsan")
+    r = subprocess.run([HIPCC, "--offload-arch=gfx950", "-fsanitize=thread", "-o", exe] + tsan_objs + others +
+                       ["-ldl", "-lpthread"], capture_output=True, text=True)
+    if r.returncode != 0:
+        pytest.skip("ThreadSanitizer runtime not linkable here: " + r.stderr[-300:])
+    env = dict(os.environ, TQ_PLAN_THREADS="4", TQ_PLAN_PAR_MIN="1", TQ_CHUNKS="512")
+    for args in (["1"], ["2", "share"], ["3", "ashare"], ["3", "pool"], ["1", "dense"]):
+        r = subprocess.run([exe] + args, env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stdout + r.stderr
+        assert "ThreadSanitizer" not in r.stdout + r.stderr, (args, (r.stdout + r.stderr)[-2000:])
