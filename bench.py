@@ -59,7 +59,7 @@ def parse_args(argv=None):
                          "beyond the 256 MB Infinity Cache (implies --no-side, --no-cpu-baseline)")
     ap.add_argument("--queries", type=int, default=None,
                     help="queries per batch (default: 10000 for and2 / mixed, 1000 for or5 / phrase3 / bool)")
-    ap.add_argument("--workload", default="and2", choices=["and2", "or5", "phrase3", "mixed", "bool"])
+    ap.add_argument("--workload", default="and2", choices=["and2", "and2_distinct", "or5", "phrase3", "mixed", "bool"])
     ap.add_argument("--k", type=int, default=None)
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -122,13 +122,28 @@ def selftest_launcher(rank, world):
 
 
 # ----------------------------------------------------------------------------- workloads
-DEFAULT_QUERIES = {"and2": 10_000, "mixed": 10_000, "or5": 1_000, "phrase3": 1_000, "bool": 2_000}
+DEFAULT_QUERIES = {"and2": 10_000, "and2_distinct": 10_000, "mixed": 10_000, "or5": 1_000, "phrase3": 1_000,
+                   "bool": 2_000}
 
 
 def build_queries(O, workload, n, k, terms=256):
     if workload == "and2":
         ids = O.zipf_queries(n, 2, terms, seed=20260921)
         return [(O.MODE_AND, q.tolist()) for q in ids], k or 10
+    if workload == "and2_distinct":
+        # the headline stream with every repeated query dropped (the 10 000 Zipf draws of and2 hold 3 877
+        # distinct pairs): what the shared-intersection launch does when no two queries are the same
+        seen, qs, seed = set(), [], 20260921
+        while len(qs) < n:
+            for q in O.zipf_queries(4 * n, 2, terms, seed=seed):
+                key = tuple(sorted(q.tolist()))
+                if key not in seen:
+                    seen.add(key)
+                    qs.append((O.MODE_AND, q.tolist()))
+                    if len(qs) == n:
+                        break
+            seed += 1
+        return qs, k or 10
     if workload == "or5":
         ids = O.zipf_queries(n, 5, terms, seed=20260922)
         return [(O.MODE_OR, q.tolist()) for q in ids], k or 100
@@ -192,9 +207,10 @@ def global_stats(all_stats):
 
 def oracle_spec(O, seg, workload, q, k, gstats):
     """QuerySpec of one query on one segment with the index-wide Bm25Weights."""
-    if q[0] not in (O.MODE_AND, O.MODE_OR, O.MODE_PHRASE):  # boolean shapes: the generic scorer tree
-        return O.bool_spec(seg, q[1], q[2], q[3], q[4], k)
     nd, nt, dfs = gstats if gstats is not None else (None, None, None)
+    if q[0] not in (O.MODE_AND, O.MODE_OR, O.MODE_PHRASE):  # boolean shapes: the generic scorer tree
+        return O.bool_spec(seg, q[1], q[2], q[3], q[4], k, None, nd, nt,
+                           None if dfs is None else [int(dfs[t]) for t in q[1]])
     w = O.default_weights(seg, q[1], q[0], nd, nt, None if dfs is None else [int(dfs[t]) for t in q[1]])
     return O.QuerySpec(seg, q[1], w, q[0], k,
                        list(range(len(q[1]))) if q[0] == O.MODE_PHRASE else None)
@@ -475,8 +491,6 @@ def spot_check(O, cl, segs, first_ord, gstats, workload, queries, k, final, n_ch
     from concurrent.futures import ThreadPoolExecutor
 
     n_q = len(queries)
-    if workload == "bool" and (len(segs) > 1 or cl.world > 1):
-        return 0  # (the restated scorer tree takes segment-local weights only)
     many = len(segs) > 1 or cl.world > 1
     sample = sorted(set(int(x) for x in np.linspace(0, n_q - 1, min(n_check, n_q))))
 
@@ -609,7 +623,7 @@ def main():
     # ---------------------------------------------------------------- other BASELINE configs (N=1)
     side = {}
     if world == 1 and not args.no_side:
-        for wl in os.environ.get("BENCH_SIDE_ORDER", "or5,phrase3,mixed,bool").split(","):
+        for wl in os.environ.get("BENCH_SIDE_ORDER", "and2_distinct,or5,phrase3,mixed,bool").split(","):
             if wl == args.workload:
                 continue
             # Every side workload gets a DeviceIndex of its own (the same segment bytes uploaded again):
@@ -646,6 +660,9 @@ def main():
                 "algorithmic_bytes_per_launch": int(sm["algo_bytes_full"]),
                 "docs_scored_per_launch": int(sm["stats"]["matches"]),
                 "host_plan_ms": round(sm["stats"]["host_plan_ms"], 3),
+                "kernels": " + ".join(sm["stats"].get("kernels") or []),
+                "distinct_queries": len({(q[0], tuple(sorted(q[1]))) + tuple(map(str, q[2:])) for q in qs}),
+                "batch_unique_bytes": int(sm["stats"].get("unique_bytes", 0)),
                 "pruned_equals_exhaustive": True, "parity_checked_queries": checked,
             }
             side[wl].update(traffic_fields(load_traffic("%s_pruned_%d" % (wl, args.docs)), 1, k_ms))

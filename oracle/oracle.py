@@ -803,9 +803,12 @@ def bool_match_all(seg, term_ids, occurs, clause_of=None, min_should_match=0):
     return docs.astype(np.uint32), score[docs]
 
 
-def bool_spec(seg, term_ids, occurs, clause_of=None, min_should_match=0, k=1, boosts=None):
-    """QuerySpec of a boolean query for the C executor restatement (generic scorer tree)."""
-    ws = default_weights(seg, term_ids, MODE_OR, boosts=boosts)
+def bool_spec(seg, term_ids, occurs, clause_of=None, min_should_match=0, k=1, boosts=None,
+              total_num_docs=None, total_num_tokens=None, dfs=None):
+    """QuerySpec of a boolean query for the C executor restatement (generic scorer tree); with the
+    index-wide statistics (total_num_docs / total_num_tokens / doc freqs over all segments) the
+    Bm25Weights are the ones Searcher hands every segment (bm25.rs:27-50)."""
+    ws = default_weights(seg, term_ids, MODE_OR, total_num_docs, total_num_tokens, dfs, boosts=boosts)
     return QuerySpec(seg, term_ids, ws, MODE_BOOL, k, None, occurs, clause_of, min_should_match)
 
 
