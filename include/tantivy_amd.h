@@ -361,6 +361,7 @@ typedef struct tq_batch_stats {
 #define TQ_KERNEL_USHARE 0x080u       /* ushare_kernel (unions, term-major for the batch) */
 #define TQ_KERNEL_XUNION 0x100u       /* xunion_kernel (unpruned unions, doc-major for the batch) */
 #define TQ_KERNEL_ASHARE 0x200u       /* ashare_kernel (intersections, leader-major for the batch) */
+#define TQ_KERNEL_BSHARE 0x400u       /* ashare_kernel, boolean leads (TQ_MODE_BOOL, leader-major) */
 int tq_last_batch_stats(tq_segment *seg, tq_batch_stats *out);
 /* Bytes the segment keeps resident in HBM, by kind: the reference's own sub-files (copied
  * verbatim) and the derived side tables of DESIGN.md section 2 — term tables (unrolled skip

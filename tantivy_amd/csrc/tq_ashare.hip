@@ -41,6 +41,12 @@
 // hashed atomic-max slots + thr_val[query].
 #include "tq_common.hpp"
 
+#ifndef TQ_BS_SGPR
+#define TQ_BS_SGPR 96
+#endif
+#ifndef TQ_BS_WAVES
+#define TQ_BS_WAVES 5  // (boolean leads: 96 registers; 6 waves of 80 spilled 60 of them and ran 18 % slower)
+#endif
 #ifndef TQ_AS_WAVES
 #define TQ_AS_WAVES 8
 #endif
@@ -55,7 +61,8 @@ namespace {
 
 constexpr uint32_t AS_GROUP = TQD_AS_GROUP;
 
-struct AShareLds {  // per wavefront: 4868 bytes (32 wavefronts per CU fit the 160 KB)
+template <bool BOOLQ>
+struct AShareLds {  // per wavefront: 4868 bytes (32 wavefronts per CU fit the 160 KB); boolean leads: + 1 KB
   float cache[256];                            // Bm25Weight.cache of the task's queries
   uint32_t q_doc[127], q_tf[127], q_tag[127];  // survivors: doc, leader tf, lead slot | fieldnorm id << 8
   TqdALeadLds lead[AS_GROUP];                  // the leads of the task (what the scoring stage needs)
@@ -63,6 +70,7 @@ struct AShareLds {  // per wavefront: 4868 bytes (32 wavefronts per CU fit the 1
   uint32_t lk[AS_GROUP];                       // k of its query (bits 0..7) | its row of threshold slots << 8
   uint32_t cnt[AS_GROUP];                      // bits 0..15: entries in the slot's staging list; 16..31: docs scored
   uint32_t flen[AS_GROUP];                     // per family head: leads in the family (itself + its twins)
+  float bw[BOOLQ ? AS_GROUP * TQD_AS_MAX_TERMS : 1];  // boolean leads: what every list of the query can add to the lead's docs
 #if TQ_AS_PREFETCH
   uint32_t pay[260];                           // the NEXT wanted block's bitpacked payload (<= 1008 B), landed by LDS-DMA
 #endif
@@ -95,13 +103,17 @@ __device__ __forceinline__ uint32_t as_exact_tf(const uint8_t *idx, const TqdTer
   return block_tf_at(idx, tr, make_uint2(r.y, r.z), pi & 127u);
 }
 
-template <int KPL>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_num_sgpr(96), amdgpu_waves_per_eu(TQ_AS_WAVES, 8))) void
+// BOOLQ: the leads are (boolean query, leading list) pairs (TQ_MODE_BOOL: Must / Should / MustNot clauses of
+// terms and unions of terms, BooleanWeight::complex_scorer, boolean_weight.rs:236-431) — the doc set and the
+// score walk of union_kernel<.., BOOL = true> (tq_union.hip), with every list but the leader reached through
+// its bitmap.
+template <int KPL, bool BOOLQ>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_num_sgpr(TQ_BS_SGPR), amdgpu_waves_per_eu(BOOLQ ? TQ_BS_WAVES : TQ_AS_WAVES, 8))) void
 ashare_kernel(TqkAShareParams p) {
   constexpr bool USE_DPP = true;
   constexpr int R = KPL + 1;                    // staging registers per lane
   constexpr uint32_t CAPL = (uint32_t)R * 64u;  // staging entries per lead slot
-  __shared__ AShareLds L;
+  __shared__ AShareLds<BOOLQ> L;
   const int lane = (int)__lane_id();
   const TqdSegment seg = p.seg;
   const uint8_t *idx = seg.idx;
@@ -171,8 +183,94 @@ ashare_kernel(TqkAShareParams p) {
     const uint32_t thr_row = L.lk[g] >> 8;
     const uint32_t q = ld.query;
     const uint32_t nt = ld.info & 31u;
-    // leader first, then ascending doc freq (block_wand_intersection.rs:144-165)
     float s = bm25(ld.w, norm, tf);
+    if constexpr (BOOLQ) {
+      // The score walk of union_kernel<.., BOOL = true> (tq_union.hip, "leader set" comment): the lists after
+      // the leader in the query's order, wrapping around to the ones before it; a doc found in a lead-set
+      // list before the leader belongs to that list's lead; Must clauses (unions of terms) are summed as
+      // Intersection::score does (left + right + sum(others), intersection.rs:325-329), MustNot lists
+      // exclude (exclude.rs), optional Should lists add (RequiredOptionalScorer::score = req + opt,
+      // reqopt_scorer.rs:85-98).  Same operations in the same order: the same bits.
+      const TqdQuery *Q = p.queries + q;
+      const uint32_t li = (ld.info >> 16) & 15u;
+      const uint32_t pb = tag >> 16;  // bit m clear: list m does not hold the doc (its doc-matrix column says so)
+      uint32_t roles = 0, clause_end = 0, n_lead = 0, n_opt_lead = 0, min_should = 0;
+      if (alive) {
+        roles = Q->roles;
+        clause_end = Q->clause_end;
+        n_lead = Q->n_lead;
+        n_opt_lead = Q->n_opt_lead;
+        min_should = Q->min_should;
+      }
+      float opt = 0.0f, oth = 0.0f, csum = 0.0f;
+      bool cfound = false;
+      bool lcfound = li >= n_opt_lead;  // the lead Must clause holds the doc
+      if (li < n_opt_lead) {            // an optional list leads: its score is optional
+        opt = s;
+        s = 0.0f;
+      }
+      uint32_t clause = 1u;
+      uint32_t n_should = ((roles >> (2u * li)) & 3u) == TQD_ROLE_SHOULD ? 1u : 0u;
+      for (uint32_t mm = 1; mm < TQD_AS_MAX_TERMS; ++mm) {
+        const bool on = alive && mm < nt;
+        if (!__ballot(on)) break;
+        if (on) {
+          uint32_t m = li + mm;
+          if (m >= nt) m -= nt;
+          const uint32_t role = (roles >> (2u * m)) & 3u;
+          bool found = false;
+          float sc = 0.0f;
+          if ((pb >> m) & 1u) {  // bitmap word (exact membership, the posting index) -> tf byte
+            const uint2 bl = p.qlists[(size_t)q * TQD_AS_MAX_TERMS + m];
+            const uint2 wd = reinterpret_cast<const uint2 *>(tbase + ((uint64_t)bl.x << 3))[doc >> 5];
+            const uint32_t bit = doc & 31u;
+            found = (wd.x >> bit) & 1u;
+            if (found && role != TQD_ROLE_MUST_NOT && !(m < li && m < n_lead)) {
+              const uint32_t pm = wd.y + (uint32_t)__popc(wd.x & ((1u << bit) - 1u));
+              uint32_t tfm = (tbase + ((uint64_t)bl.y << 3))[pm];
+              if (tfm == 255u) tfm = as_exact_tf(idx, p.terms, Q->term[m], pm);
+              sc = bm25(L.bw[g * TQD_AS_MAX_TERMS + m], norm, tfm);
+            }
+          }
+          if (role == TQD_ROLE_MUST_NOT) {
+            if (found) alive = false;
+          } else if (m < n_lead) {
+            if (found) {
+              if (m < li) {
+                alive = false;  // this doc is scored by list m's lead
+              } else if (m < n_opt_lead) {
+                opt = opt + sc;
+                ++n_should;
+              } else {
+                s = s + sc;
+                lcfound = true;
+                if (role == TQD_ROLE_SHOULD) ++n_should;
+              }
+            }
+            if (m + 1u == n_lead && !lcfound) alive = false;  // not in the lead Must clause
+          } else if (role == TQD_ROLE_MUST) {
+            cfound = cfound || found;
+            if (found) csum = csum + sc;
+            if ((clause_end >> m) & 1u) {
+              if (!cfound) alive = false;
+              if (clause == 1u)
+                s = s + csum;
+              else
+                oth = oth + csum;
+              ++clause;
+              csum = 0.0f;
+              cfound = false;
+            }
+          } else if (found) {
+            opt = opt + sc;
+            ++n_should;
+          }
+        }
+      }
+      s = (s + oth) + opt;
+      if (n_should < min_should) alive = false;
+    } else {
+    // leader first, then ascending doc freq (block_wand_intersection.rs:144-165)
     // list 1: bitmap word (exact membership, the posting index) -> tf byte
     uint32_t pi = 0, tf1 = 0;
     {
@@ -224,6 +322,7 @@ ashare_kernel(TqkAShareParams p) {
           }
         }
       }
+    }
     }
     // the score is final: below the threshold it cannot enter the top-k (equal scores stay: ties
     // resolve by doc id in the collector)
@@ -293,6 +392,8 @@ ashare_kernel(TqkAShareParams p) {
     // works for another lead, gathers them from the LDS copy
     float my_w = 0.0f, my_rest = 0.0f;
     uint32_t my_mlo = 0, my_mhi = 0;
+    uint32_t my_xlo = 0, my_xhi = 0, my_a1lo = 0, my_a1hi = 0, my_a2lo = 0, my_a2hi = 0;  // (boolean leads)
+    uint32_t my_blo = 0, my_bhi = 0;  // (boolean leads) byte m: doc-matrix bit of the query's list m, 0 = none
     bool twin = false;
     const bool is_lead = (uint32_t)lane < n_leads;
     if (is_lead) {
@@ -302,6 +403,22 @@ ashare_kernel(TqkAShareParams p) {
       my_rest = mine.rest;
       my_mlo = mine.mask_lo;
       my_mhi = mine.mask_hi;
+      if constexpr (BOOLQ) {
+        my_xlo = mine.excl_lo;
+        my_xhi = mine.excl_hi;
+        my_a1lo = mine.any1_lo;
+        my_a1hi = mine.any1_hi;
+        my_a2lo = mine.any2_lo;
+        my_a2hi = mine.any2_hi;
+        my_blo = mine.dense_off;
+        my_bhi = mine.tf8_off;
+        // what the query's other lists can add to a doc of this lead: the lists after the leader (a doc held
+        // by a list of the lead set before it belongs to that list's lead; MustNot lists weigh 0)
+        const TqdQuery *Q = p.queries + mine.query;
+        const uint32_t li = (mine.info >> 16) & 15u, nt = mine.info & 31u;
+#pragma unroll
+        for (uint32_t m = 0; m < TQD_AS_MAX_TERMS; ++m) L.bw[(uint32_t)lane * TQD_AS_MAX_TERMS + m] = (m > li && m < nt) ? Q->weight[m] : 0.0f;
+      }
       twin = lane != 0 && (mine.info & 0x200u) != 0u;
       L.lk[lane] = mine.k | (mine.thr_row << 8);
       L.lthr[lane] = __hip_atomic_load(p.thr_val + mine.query, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -331,14 +448,16 @@ ashare_kernel(TqkAShareParams p) {
     // the order of the sortable bits): tfn >= (thr - rest) / w, every factor widened by 1e-5 for the
     // reciprocal-based tf/(tf+norm) and the summation order
     uint32_t live = 0, live_heads = 0, fam_thr = 0;
-    float fam_need = -1.0f;
+    float fam_need = -1.0f, fam_thr_f = -1.0f;
     auto update_families = [&]() __attribute__((always_inline)) {
       live = (uint32_t)__ballot(is_head && lead_alive());
       live_heads = live;
       fam_thr = is_head ? L.lthr[lane] : 0xFFFFFFFFu;
       fam_need = -1.0f;
+      fam_thr_f = -1.0f;
       if (is_head && fam_thr != 0u) {
         const float thr_f = __uint_as_float(fam_thr ^ ((fam_thr >> 31) ? 0x80000000u : 0xFFFFFFFFu));
+        fam_thr_f = thr_f * 0.99999f;
         const float num = thr_f * 0.99999f - my_rest * 1.00001f;
         if (num > 0.0f) fam_need = num * __builtin_amdgcn_rcpf(my_w) * 0.99999f;
       }
@@ -495,6 +614,7 @@ ashare_kernel(TqkAShareParams p) {
         // ---- stage F: every family that wants the block
         uint32_t pm_lo = 0, pm_hi = 0;
         uint64_t mem0 = valid0, mem1 = valid1;  // (mask 0: every doc)
+        uint32_t pb0 = 0xFFu, pb1 = 0xFFu;       // (boolean leads) lists the doc's doc-matrix word does not rule out
         if (p.debug & 2048u) lm = 0;  // ABLATION: decode only
         for (; lm; lm &= lm - 1u) {
           const uint32_t g = (uint32_t)__builtin_ctz(lm);
@@ -502,7 +622,61 @@ ashare_kernel(TqkAShareParams p) {
           const uint32_t mlo = (uint32_t)__builtin_amdgcn_readlane((int)my_mlo, (int)g);
           const uint32_t mhi = (uint32_t)__builtin_amdgcn_readlane((int)my_mhi, (int)g);
           const float need = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(fam_need), (int)g));
-          if (mlo != pm_lo || mhi != pm_hi) {  // "every other list holds (or may hold) the doc"
+          if constexpr (BOOLQ) {  // none of the excluded lists, one list of every Must clause (columns: exact;
+                                  // signature bits: maybe), per family
+            const uint32_t xlo = (uint32_t)__builtin_amdgcn_readlane((int)my_xlo, (int)g);
+            const uint32_t xhi = (uint32_t)__builtin_amdgcn_readlane((int)my_xhi, (int)g);
+            const uint32_t a1lo = (uint32_t)__builtin_amdgcn_readlane((int)my_a1lo, (int)g);
+            const uint32_t a1hi = (uint32_t)__builtin_amdgcn_readlane((int)my_a1hi, (int)g);
+            const uint32_t a2lo = (uint32_t)__builtin_amdgcn_readlane((int)my_a2lo, (int)g);
+            const uint32_t a2hi = (uint32_t)__builtin_amdgcn_readlane((int)my_a2hi, (int)g);
+            const uint32_t l0 = (uint32_t)mw0, h0 = (uint32_t)(mw0 >> 32), l1 = (uint32_t)mw1, h1 = (uint32_t)(mw1 >> 32);
+            bool b0 = !((l0 & xlo) | (h0 & xhi));
+            bool b1 = !((l1 & xlo) | (h1 & xhi));
+            if (a1lo | a1hi) {
+              b0 = b0 && ((l0 & a1lo) | (h0 & a1hi));
+              b1 = b1 && ((l1 & a1lo) | (h1 & a1hi));
+            }
+            if (a2lo | a2hi) {
+              b0 = b0 && ((l0 & a2lo) | (h0 & a2hi));
+              b1 = b1 && ((l1 & a2lo) | (h1 & a2hi));
+            }
+            // (the family's bound with every other list in it first: most (block, family) pairs end here)
+            b0 = b0 && tfn0 >= need;
+            b1 = b1 && tfn1 >= need;
+            if (!((__ballot(b0) & valid0) | (__ballot(b1) & valid1))) continue;
+            // the doc's own bound: the leader's score + the weights of the lists its doc-matrix word does not
+            // rule out (mask_lo: the sum over the lists without a bit) — `+a b -c` sends a doc of a that is
+            // not in b on with a's score alone, not with a's + the weight of b.  Bytes: the lists after the
+            // leader that can add to the score and have a bit; info bits 20-27: clear = a list the masks above
+            // have already ruled out (the scoring stage does not probe it)
+            const uint32_t blo = (uint32_t)__builtin_amdgcn_readlane((int)my_blo, (int)g);
+            const uint32_t bhi = (uint32_t)__builtin_amdgcn_readlane((int)my_bhi, (int)g);
+            pb0 = pb1 = (uni(L.lead[g].info) >> 20) & 0xFFu;
+            if (blo | bhi) {
+              const float wl = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(my_w), (int)g));
+              const float thr_f = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(fam_thr_f), (int)g));
+              const float4 wa = *reinterpret_cast<const float4 *>(&L.bw[g * TQD_AS_MAX_TERMS]);
+              const float4 wb = *reinterpret_cast<const float4 *>(&L.bw[g * TQD_AS_MAX_TERMS + 4u]);
+              const float wv[8] = {wa.x, wa.y, wa.z, wa.w, wb.x, wb.y, wb.z, wb.w};
+              float ps0 = __uint_as_float(mlo), ps1 = ps0;
+#pragma unroll
+              for (uint32_t m = 0; m < TQD_AS_MAX_TERMS; ++m) {
+                const uint32_t bp = ((m < 4u ? blo : bhi) >> (8u * (m & 3u))) & 0xFFu;
+                if (!bp) continue;  // (uniform)
+                const uint32_t sh = bp & 31u;
+                const uint32_t p0 = ((bp & 32u ? h0 : l0) >> sh) & 1u, p1 = ((bp & 32u ? h1 : l1) >> sh) & 1u;
+                ps0 += p0 ? wv[m] : 0.0f;
+                ps1 += p1 ? wv[m] : 0.0f;
+                pb0 &= ~((p0 ^ 1u) << m);
+                pb1 &= ~((p1 ^ 1u) << m);
+              }
+              b0 = b0 && (wl * tfn0 + ps0) * 1.00001f >= thr_f;
+              b1 = b1 && (wl * tfn1 + ps1) * 1.00001f >= thr_f;
+            }
+            mem0 = __ballot(b0) & valid0;
+            mem1 = __ballot(b1) & valid1;
+          } else if (mlo != pm_lo || mhi != pm_hi) {  // "every other list holds (or may hold) the doc"
             pm_lo = mlo;
             pm_hi = mhi;
             const uint32_t x0 = ((uint32_t)mw0 | ~mlo) & ((uint32_t)(mw0 >> 32) | ~mhi);
@@ -527,7 +701,7 @@ ashare_kernel(TqkAShareParams p) {
             if (a) {
               L.q_doc[pos] = e ? c1 : c0;
               L.q_tf[pos] = e ? t1 : t0;
-              L.q_tag[pos] = g | ((e ? nid1 : nid0) << 8);
+              L.q_tag[pos] = g | ((e ? nid1 : nid0) << 8) | (BOOLQ ? (e ? pb1 : pb0) << 16 : 0u);
             }
             wave_mem_fence();
             qn += (uint32_t)__popcll(m);
@@ -628,13 +802,21 @@ ashare_kernel(TqkAShareParams p) {
 
 // =================================================================== launch wrappers
 uint32_t tqk_ashare_waves_per_cu() { return 4u * TQ_AS_WAVES; }
+uint32_t tqk_bshare_waves_per_cu() { return 4u * TQ_BS_WAVES; }
 
 hipError_t tqk_launch_ashare(const TqkAShareParams &p, int kpl, hipStream_t st) {
   if (p.n_tasks <= p.task_begin || p.grid == 0) return hipSuccess;
   const dim3 grid(p.grid), block(64);
-  switch (kpl) {
-    case 1: ashare_kernel<1><<<grid, block, 0, st>>>(p); break;
-    default: ashare_kernel<2><<<grid, block, 0, st>>>(p); break;
+  if (p.boolean) {
+    switch (kpl) {
+      case 1: ashare_kernel<1, true><<<grid, block, 0, st>>>(p); break;
+      default: ashare_kernel<2, true><<<grid, block, 0, st>>>(p); break;
+    }
+  } else {
+    switch (kpl) {
+      case 1: ashare_kernel<1, false><<<grid, block, 0, st>>>(p); break;
+      default: ashare_kernel<2, false><<<grid, block, 0, st>>>(p); break;
+    }
   }
   return hipGetLastError();
 }

@@ -121,24 +121,34 @@ static_assert(sizeof(TqdLead) == 128, "TqdLead is uploaded as raw bytes");
 #define TQD_AS_GROUP 32      // leads per group (one lane each at task setup)
 #define TQD_AS_MAX_TERMS 8   // intersections with more lists keep the per-query kernel
 #define TQD_AS_TILE 64       // blocks per pre-filter step (one lane each)
-struct TqdALead {            // 48 bytes, written by the host planner
+struct TqdALead {            // 64 bytes, written by the host planner
   uint32_t query;            // launch-group query index
   uint32_t info;             // n_terms (bits 0-4) | bit 8: list 1's membership bit is its column (exact) |
                              // bit 9: the same query (lists, weights, k) as the lead before it in its group: a
                              // TWIN.  A group is a sequence of families (a head + its twins): a family is
-                             // evaluated once, its results go to every member's result list
+                             // evaluated once, its results go to every member's result list |
+                             // bits 16-19 (boolean leads): which list of the query leads here |
+                             // bits 20-27 (boolean leads): bit m clear = the lead's exclusion mask has ruled
+                             // list m out for every doc that gets to the scoring stage (never probed)
   float w;                   // weight of the leader in this query
-  float rest;                // weights of the other lists together: the most they can add (= weight of
-                             // list 1 in a 2-term query)
-  uint32_t dense_off;        // list 1: bitmap + rank directory, byte-wide tfs, as offsets from
-  uint32_t tf8_off;          // TqkAShareParams::table_base in 8-byte units
+  float rest;                // what the other lists can add at most (AND: their weights together = the weight
+                             // of list 1 in a 2-term query; boolean: the weights of the lists after the leader)
+  uint32_t dense_off;        // AND, list 1: bitmap + rank directory, byte-wide tfs, as offsets from
+  uint32_t tf8_off;          // TqkAShareParams::table_base in 8-byte units.  Boolean leads: byte m of the two
+                             // words = the doc-matrix bit of the query's list m (0: it has none): a doc whose
+                             // word has the bit clear is not in the list
   uint32_t mask_lo, mask_hi; // doc-matrix bits every match has: the other lists' columns (exact) and
-                             // signature bits (a clear bit proves absence, a set one means maybe)
+                             // signature bits (a clear bit proves absence, a set one means maybe).  Boolean
+                             // leads: mask_lo = (float) the weights of the lists after the leader that have no
+                             // doc-matrix bit, mask_hi unused
   uint32_t k;                // the query's k (<= 128)
   uint32_t thr_row;          // its row of threshold slots (identical queries of a batch share one)
-  uint32_t pad[2];
+  // boolean leads (TQ_MODE_BOOL through the shared launch): a match has NONE of the excl bits (columns of
+  // MustNot lists and of the lead-set lists before the leader: found there = excluded / another lead's doc)
+  // and AT LEAST ONE bit of any1 and of any2 (the columns / signature bits of a Must clause each; 0 = no
+  // such clause).  Further clauses are verified by the scoring stage only.
+  uint32_t excl_lo, excl_hi, any1_lo, any1_hi, any2_lo, any2_hi;
 };
-static_assert(sizeof(TqdALead) == 48, "TqdALead is uploaded as raw bytes");
 struct TqdALeadLds {  // what the scoring stage keeps of a lead in LDS
   uint32_t query, info;
   float w, rest;

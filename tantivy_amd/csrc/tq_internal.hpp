@@ -176,7 +176,7 @@ using namespace tqi;  // (the objects below are the ABI's opaque types: global)
 // recorded; a batch on another stream than the previous user's first waits for that event (stream side).
 struct DeviceScratch {
   std::mutex m;
-  DevBuf partials, share_stage, ashare_stage;
+  DevBuf partials, share_stage, ashare_stage, bshare_stage;
   hipEvent_t ev_last = nullptr;
   hipStream_t last_stream = nullptr;
   bool in_flight = false;
@@ -198,6 +198,7 @@ struct tq_ctx {
       kv.second->partials.release();
       kv.second->share_stage.release();
       kv.second->ashare_stage.release();
+      kv.second->bshare_stage.release();
       delete kv.second;
     }
   }
@@ -240,7 +241,7 @@ struct tq_segment {
   // batch scratch
   DevBuf d_stage, d_out_scores, d_out_docs, d_out_counts, d_misc, d_thr, d_qmatches;
   DevBuf d_share_words;   // shared-union launch: per-query words
-  DevBuf d_ashare_words;  // shared-intersection launch (runs next to the shared-union one)
+  DevBuf d_ashare_words, d_bshare_words;  // shared-intersection launches (run next to the shared-union one)
   DeviceScratch *dscratch = nullptr;  // partial / result lists and staging lists: the device's (tq_ctx)
   // the shared-union launch addresses bitmaps / byte-wide tfs as 32-bit offsets (8-byte units) from
   // the lowest such table: usable while all of them lie within 32 GB of device addresses
@@ -373,7 +374,7 @@ struct Group {
   int kpl = 1;
   // offsets inside the staging blob
   size_t o_queries = 0, o_tiles = 0, o_outidx = 0, o_chunks = 0, o_perm = 0, o_sinks = 0;
-  size_t o_leads = 0, o_tasks = 0;  // shared-union group
+  size_t o_leads = 0, o_tasks = 0, o_lists = 0;  // shared-union group
   void reset() {  // keeps the vectors' capacity
     queries.clear();
     out_index.clear();
@@ -385,7 +386,7 @@ struct Group {
     max_k = 1;
     kpl = 1;
     o_queries = o_tiles = o_outidx = o_chunks = o_perm = o_sinks = 0;
-    o_leads = o_tasks = 0;
+    o_leads = o_tasks = o_lists = 0;
   }
 };
 
@@ -407,8 +408,9 @@ struct ShareKey {  // one (query, list) pair of the shared-union group
   uint32_t term, q;
 };
 // launch groups of a batch: 0 AND over bitmap lists, 1 unions, 2 phrases, 3 AND over any lists, 4 boolean
-// queries, 5 shared unions, 6 phrase sweep, 7 doc-major unions, 8 shared intersections
-constexpr int kNGroups = 9;
+// queries, 5 shared unions, 6 phrase sweep, 7 doc-major unions, 8 shared intersections, 9 boolean queries
+// through the shared-intersection launch
+constexpr int kNGroups = 10;
 struct QuerySlab {  // one slab of a batch's queries, planned by one thread into groups of its own
   Group groups[kNGroups];
   uint32_t n_thr_rows = 0;
@@ -434,19 +436,24 @@ struct PlanScratch {
   std::vector<TqdLead> leads;
   std::vector<uint4> tasks;
   std::vector<uint32_t> share_pairs;  // per query: (task, lead) pairs = result-list appends at most
-  // shared-intersection group (tq_ashare.hip): one lead per query, sorted by (leader, cache, mask)
-  std::vector<TqdALead> aleads, aleads_unsorted;
-  std::vector<ALeadKey> alead_keys, alead_keys2;
-  std::vector<uint32_t> alead_bucket, alead_bucket_at, alead_bucket_starts;
-  std::vector<uint8_t> alead_same;
-  std::vector<uint4> atasks, atasks_unsorted;
-  std::vector<uint32_t> atask_pos, apairs, atask_hist, atask_slab_run;
-  struct ARun {  // the leads of one (leader, cache)
-    uint32_t r0, r1, term, cache, n_blocks, n_groups, per_group, bpt, nb_warm, n_runs;
-    size_t task0;
+  // shared-intersection launches (tq_ashare.hip): [0] the AND group (one lead per query), [1] the boolean
+  // group (one lead per (query, list of its lead set)); leads sorted by (leader, cache, mask, query hash)
+  struct ASharePlan {
+    std::vector<TqdALead> aleads, aleads_unsorted;
+    std::vector<ALeadKey> alead_keys, alead_keys2;
+    std::vector<uint32_t> alead_first, alead_bucket, alead_bucket_at, alead_bucket_starts;
+    std::vector<uint8_t> alead_same;
+    std::vector<uint4> atasks, atasks_unsorted;
+    std::vector<uint2> alists;  // boolean group: [query][list] = {bitmap, tf bytes} as offsets from the table base
+    std::vector<uint32_t> atask_pos, apairs, atask_hist, atask_slab_run;
+    struct ARun {  // the leads of one (leader, cache)
+      uint32_t r0, r1, term, cache, n_blocks, n_groups, per_group, bpt, nb_warm, n_runs;
+      size_t task0;
+    };
+    std::vector<ARun> aruns;
+    uint32_t a_warm_tasks = 0;  // tasks [0, a_warm_tasks) are the warm-up launch
   };
-  std::vector<ARun> aruns;
-  uint32_t a_warm_tasks = 0;  // tasks [0, a_warm_tasks) are the warm-up launch
+  ASharePlan ap[2];
   std::vector<uint32_t> q_leader;        // per query of the batch: the list that would lead it there, or 0xFFFFFFFF
   std::vector<uint32_t> and_lead_count;  // per term handle: AND queries of the batch it could lead in that launch
   std::vector<uint32_t> term_stamp;      // per term handle: last batch that used the list (unique bytes)
@@ -606,7 +613,7 @@ int wait_segment_idle(tq_segment *s);
 // ---- the planners
 int build_group_chunks(Group &g, bool or_windows, PlanScratch &ps, bool boolean_group = false);
 int build_share_plan(tq_segment *s, Group &g, PlanScratch &ps);
-int build_ashare_plan(tq_segment *s, Group &g, PlanScratch &ps);
+int build_ashare_plan(tq_segment *s, Group &g, PlanScratch &ps, bool boolean = false);
 int build_dense_plan(tq_segment *s, Group &g, PlanScratch &ps, uint32_t cus);
 int plan_bool_query(tq_segment *s, const tq_query &q, uint32_t qi, TqdQuery &dq, uint64_t &qbytes,
                     uint32_t &n_tiles, uint32_t &tile_cost, uint32_t &n_thr_rows, bool exhaustive);

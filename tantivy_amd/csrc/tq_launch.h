@@ -72,6 +72,7 @@ struct TqkAShareParams {
   const float *caches;
   const TqdALead *leads;
   const uint4 *tasks;           // {leader term handle, first block, n_blocks | n_leads << 16 | cache << 24, first lead}
+  const uint2 *qlists;          // boolean leads: [query][TQD_AS_MAX_TERMS] = {bitmap, tf bytes} of its lists (as dense_off / tf8_off)
   const TqkSinks *sinks;
   uint32_t *thr_slots;          // hashed score slots per query (as the other pruned kernels use)
   uint32_t *thr_val;            // [n_queries] current lower bound of each query's k-th best score
@@ -84,6 +85,7 @@ struct TqkAShareParams {
   uint32_t n_queries;
   uint32_t grid;
   uint32_t debug;
+  uint32_t boolean;             // the leads are (TQ_MODE_BOOL query, leading list) pairs
   float bound_slack;
 };
 
@@ -167,6 +169,7 @@ hipError_t tqk_launch_merge_lists(const TqkMergeParams &m, const uint32_t *list_
 uint32_t tqk_share_capl(int kpl);  // staging entries per lead slot
 hipError_t tqk_launch_ashare(const TqkAShareParams &p, int kpl, hipStream_t st);
 uint32_t tqk_ashare_waves_per_cu();  // resident wavefronts per CU the kernel is built for
+uint32_t tqk_bshare_waves_per_cu();  // ... its boolean instantiation
 hipError_t tqk_launch_xunion(const TqkDenseParams &p, int kpl, hipStream_t st);
 // a list without a bitmap as plain arrays: doc ids and min(tf, 255) per posting
 hipError_t tqk_launch_flat_list(const TqdSegment &seg, const TqdTerm *terms, uint32_t handle,

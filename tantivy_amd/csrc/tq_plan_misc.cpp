@@ -155,7 +155,8 @@ int plan_bool_query(tq_segment *s, const tq_query &q, uint32_t qi, TqdQuery &dq,
                        [&](uint32_t a, uint32_t b) { return cl[a].cost < cl[b].cost; });
       // optional Should lists lead too (MaxScore for RequiredOptionalScorer, see union_body)
       // (only when pruning: with every match scored the extra ownership probes cost 60 %)
-      const bool opt_lead = n_should > 0 && msm == 0 && !exhaustive;
+      static const bool kOptLead = tune_u32("TQ_BOOL_OPT_LEAD", 1) != 0;
+      const bool opt_lead = kOptLead && n_should > 0 && msm == 0 && !exhaustive;
       if (opt_lead) {
         for (uint32_t c = 0; c < n_should; ++c)
           for (uint32_t i = 0; i < cl[should[c]].n; ++i) flat[n_flat++] = cl[should[c]].terms[i];

@@ -238,7 +238,8 @@ retry_tasks:
 // group gets one task per run of blocks of the leader.  Tasks are launched in doc order (all
 // leaders' runs of the first 1/4096 of the doc-id space, then the next, ...): the chip works on one
 // part of the doc matrix at a time, and every query's threshold rises as its leader is walked.
-int build_ashare_plan(tq_segment *s, Group &g, PlanScratch &ps) {
+int build_ashare_plan(tq_segment *s, Group &g, PlanScratch &ps, bool boolean) {
+  PlanScratch::ASharePlan &A = ps.ap[boolean ? 1 : 0];
   static const uint32_t kTaskPairsEnv = std::max<uint32_t>(32u, tune_u32("TQ_AS_TASK_PAIRS", 512));
   static const uint32_t kTaskBlocksMax = std::min<uint32_t>(0xFFFFu, std::max<uint32_t>(1u, tune_u32("TQ_AS_TASK_BLOCKS", 64)));
   static const uint32_t kGroupMax = std::min<uint32_t>(TQD_AS_GROUP, std::max<uint32_t>(1u, tune_u32("TQ_AS_GROUP", TQD_AS_GROUP)));
@@ -263,43 +264,142 @@ int build_ashare_plan(tq_segment *s, Group &g, PlanScratch &ps) {
   };
   // ---- leads, in query order (filled by the planner's threads, a slab of queries each), with their
   // sort keys: (leader, cache) | mask | a hash of the whole query (lists, weights, k)
-  std::vector<TqdALead> &leads = ps.aleads, &unsorted = ps.aleads_unsorted;
-  std::vector<ALeadKey> &keys = ps.alead_keys;
-  leads.resize(nq);
-  unsorted.resize(nq);
-  keys.resize(nq);
+  std::vector<TqdALead> &leads = A.aleads, &unsorted = A.aleads_unsorted;
+  std::vector<ALeadKey> &keys = A.alead_keys;
+  // (leads per query: one for an intersection; one per list of the lead set for a boolean query)
+  std::vector<uint32_t> &lead0 = A.alead_first;  // first lead of every query
+  lead0.resize(nq + 1);
+  size_t nl = 0;
+  for (size_t q = 0; q < nq; ++q) {
+    lead0[q] = (uint32_t)nl;
+    nl += boolean ? std::max<uint32_t>(1u, g.queries[q].n_lead) : 1u;
+  }
+  lead0[nq] = (uint32_t)nl;
+  leads.resize(nl);
+  unsorted.resize(nl);
+  keys.resize(nl);
+  if (boolean) A.alists.assign(nq * TQD_AS_MAX_TERMS, make_uint2(0u, 0u));
   const uint32_t fill_slabs = nq >= 4096 ? plan_threads() : 1u;
   parallel_slabs(fill_slabs, [&](uint32_t sb) {
     const size_t q0 = nq * sb / fill_slabs, q1 = nq * (sb + 1) / fill_slabs;
     for (size_t q = q0; q < q1; ++q) {
       const TqdQuery &dq = g.queries[q];
-      TqdALead ld{};
-      ld.query = (uint32_t)q;
-      ld.w = dq.weight[0];
-      float rest = 0.0f;
-      uint64_t mask = 0, sig = 0x9E3779B97F4A7C15ull * (uint64_t)(dq.n_terms | (dq.k << 8));
+      uint64_t sig = 0x9E3779B97F4A7C15ull * (uint64_t)(dq.n_terms | (dq.k << 8));
       for (uint32_t m = 0; m < dq.n_terms; ++m) {
         uint32_t wb;
         memcpy(&wb, &dq.weight[m], sizeof wb);
         sig = (sig ^ (((uint64_t)dq.term[m] << 32) | wb)) * 0xFF51AFD7ED558CCDull;
         sig ^= sig >> 29;
-        if (!m) continue;
-        rest += dq.weight[m];
-        const uint32_t col = column_of(dq.term[m]);
-        const uint32_t sig1 = !col ? (s->h_dterms[dq.term[m]].has_freq >> 16) & 0xFFu : 0u;
-        const uint32_t bitpos = col ? col : (sig1 ? TQD_SIG_SHIFT + (sig1 - 1u) : 0u);
-        if (bitpos) mask |= 1ull << bitpos;
       }
-      ld.rest = rest;
-      ld.mask_lo = (uint32_t)mask;
-      ld.mask_hi = (uint32_t)(mask >> 32);
-      ld.info = dq.n_terms | (column_of(dq.term[1]) ? 0x100u : 0u);
-      ld.dense_off = off_of(s->terms[dq.term[1]].dense_blob);
-      ld.tf8_off = off_of(s->terms[dq.term[1]].tf8_blob);
-      ld.k = dq.k;
-      ld.thr_row = dq.thr_index;
-      unsorted[q] = ld;
-      keys[q] = ALeadKey{((uint64_t)dq.term[0] << 8) | (uint64_t)(dq.cache_idx & 0xFFu), mask, sig, (uint32_t)q, 0u};
+      auto bit_of = [&](uint32_t handle) -> uint32_t {  // the list's doc-matrix bit: column (exact) or signature (maybe)
+        const uint32_t col = column_of(handle);
+        const uint32_t sig1 = !col ? (s->h_dterms[handle].has_freq >> 16) & 0xFFu : 0u;
+        return col ? col : (sig1 ? TQD_SIG_SHIFT + (sig1 - 1u) : 0u);
+      };
+      if (!boolean) {
+        TqdALead ld{};
+        ld.query = (uint32_t)q;
+        ld.w = dq.weight[0];
+        float rest = 0.0f;
+        uint64_t mask = 0;
+        for (uint32_t m = 1; m < dq.n_terms; ++m) {
+          rest += dq.weight[m];
+          const uint32_t bitpos = bit_of(dq.term[m]);
+          if (bitpos) mask |= 1ull << bitpos;
+        }
+        ld.rest = rest;
+        ld.mask_lo = (uint32_t)mask;
+        ld.mask_hi = (uint32_t)(mask >> 32);
+        ld.info = dq.n_terms | (column_of(dq.term[1]) ? 0x100u : 0u);
+        ld.dense_off = off_of(s->terms[dq.term[1]].dense_blob);
+        ld.tf8_off = off_of(s->terms[dq.term[1]].tf8_blob);
+        ld.k = dq.k;
+        ld.thr_row = dq.thr_index;
+        unsorted[lead0[q]] = ld;
+        keys[lead0[q]] = ALeadKey{((uint64_t)dq.term[0] << 8) | (uint64_t)(dq.cache_idx & 0xFFu), mask, sig, lead0[q], 0u};
+        continue;
+      }
+      // boolean query (plan_bool_query's layout: [optional leading Should lists | lead Must clause | other
+      // Must clauses | MustNot lists | Should lists]): one lead per list of the lead set
+      sig = (sig ^ (((uint64_t)dq.roles << 32) | dq.clause_end)) * 0xFF51AFD7ED558CCDull;
+      sig = (sig ^ (((uint64_t)dq.n_lead << 40) | ((uint64_t)dq.n_opt_lead << 20) | dq.min_should)) * 0xFF51AFD7ED558CCDull;
+      const uint32_t n_lead = std::max<uint32_t>(1u, dq.n_lead);
+      for (uint32_t m = 0; m < dq.n_terms; ++m)
+        A.alists[q * TQD_AS_MAX_TERMS + m] = make_uint2(off_of(s->terms[dq.term[m]].dense_blob), off_of(s->terms[dq.term[m]].tf8_blob));
+      for (uint32_t li = 0; li < n_lead; ++li) {
+        TqdALead ld{};
+        ld.query = (uint32_t)q;
+        ld.w = dq.weight[li];
+        float rest = 0.0f;
+        for (uint32_t m = dq.n_terms; m-- > li + 1u;) rest += dq.weight[m];  // (suffix[li + 1], summed as tq_union.hip does)
+        uint64_t excl = 0, any[TQ_MAX_TERMS + 1] = {0};
+        uint32_t n_any = 0;
+        if (li < dq.n_opt_lead) {  // an optional list leads: the doc must be in the lead Must clause as well
+          uint64_t m1 = 0;
+          for (uint32_t m = dq.n_opt_lead; m < dq.n_lead; ++m) {
+            const uint32_t b = bit_of(dq.term[m]);
+            m1 = b && m1 != ~0ull ? m1 | (1ull << b) : ~0ull;
+          }
+          if (m1 != ~0ull && m1) any[n_any++] = m1;
+        }
+        uint64_t cm = 0;
+        for (uint32_t m = 0; m < dq.n_terms; ++m) {
+          if (m == li) continue;
+          const uint32_t role = (dq.roles >> (2u * m)) & 3u;
+          const uint32_t col = column_of(dq.term[m]);
+          if (role == TQD_ROLE_MUST_NOT) {
+            if (col) excl |= 1ull << col;
+          } else if (m < dq.n_lead) {
+            if (m < li && col) excl |= 1ull << col;  // held by an earlier list of the lead set: that lead's doc
+          } else if (role == TQD_ROLE_MUST) {
+            const uint32_t b = bit_of(dq.term[m]);
+            cm = b && cm != ~0ull ? cm | (1ull << b) : ~0ull;
+            if ((dq.clause_end >> m) & 1u) {
+              if (cm != ~0ull && cm) any[n_any++] = cm;
+              cm = 0;
+            }
+          }
+        }
+        // one byte per list after the leader that can add to the score and has a doc-matrix bit: a doc
+        // without the bit does not get the list's weight in its bound, and the scoring stage does not probe
+        // the list; the lists without a bit add `rest_base`.  Lists the exclusion mask has ruled out (columns
+        // of MustNot lists and of the lead-set lists before the leader) are never probed (info bits 20-27).
+        uint64_t bytes = 0;
+        float rest_base = 0.0f;
+        uint32_t maybe = 0xFFu;
+        for (uint32_t m = 0; m < dq.n_terms; ++m) {
+          if (m == li) continue;
+          const uint32_t role = (dq.roles >> (2u * m)) & 3u;
+          if ((role == TQD_ROLE_MUST_NOT || m < li) && column_of(dq.term[m])) maybe &= ~(1u << m);
+          if (m < li || role == TQD_ROLE_MUST_NOT) continue;
+          const uint32_t b = bit_of(dq.term[m]);
+          bytes |= (uint64_t)b << (8u * m);
+          if (!b) rest_base += dq.weight[m];
+        }
+        ld.dense_off = (uint32_t)bytes;
+        ld.tf8_off = (uint32_t)(bytes >> 32);
+        memcpy(&ld.mask_lo, &rest_base, sizeof(float));
+        ld.rest = rest;
+        ld.excl_lo = (uint32_t)excl;
+        ld.excl_hi = (uint32_t)(excl >> 32);
+        if (n_any > 0) {
+          ld.any1_lo = (uint32_t)any[0];
+          ld.any1_hi = (uint32_t)(any[0] >> 32);
+        }
+        if (n_any > 1) {
+          ld.any2_lo = (uint32_t)any[1];
+          ld.any2_hi = (uint32_t)(any[1] >> 32);
+        }
+        ld.info = dq.n_terms | (li << 16) | (maybe << 20);
+        ld.k = dq.k;
+        ld.thr_row = dq.thr_index;
+        const size_t L = lead0[q] + li;
+        unsorted[L] = ld;
+        // (sort key: the masks that decide membership, folded; the hash carries the leading list too)
+        const uint64_t mk = excl ^ (n_any > 0 ? any[0] * 0x9E3779B97F4A7C15ull : 0ull) ^ (n_any > 1 ? any[1] * 0xC2B2AE3D27D4EB4Full : 0ull);
+        keys[L] = ALeadKey{((uint64_t)dq.term[li] << 8) | (uint64_t)(dq.cache_idx & 0xFFu), mk,
+                           (sig ^ li) * 0xFF51AFD7ED558CCDull, (uint32_t)L, 0u};
+      }
     }
   });
   pt("leads");
@@ -308,25 +408,25 @@ int build_ashare_plan(tq_segment *s, Group &g, PlanScratch &ps) {
   // leaders), then every bucket by the rest of the key — the planner's threads take a share of the
   // buckets each (a comparison sort of the whole table was half of this function's time)
   {
-    std::vector<uint32_t> &cnt = ps.alead_bucket;
+    std::vector<uint32_t> &cnt = A.alead_bucket;
     const size_t nt = s->terms.size();
     cnt.assign(nt + 1, 0u);
-    for (size_t q = 0; q < nq; ++q) ++cnt[(size_t)(keys[q].k1 >> 8) + 1];
+    for (size_t q = 0; q < nl; ++q) ++cnt[(size_t)(keys[q].k1 >> 8) + 1];
     for (size_t t = 0; t < nt; ++t) cnt[t + 1] += cnt[t];
-    std::vector<ALeadKey> &tmp = ps.alead_keys2;
-    tmp.resize(nq);
-    std::vector<uint32_t> &at = ps.alead_bucket_at;
+    std::vector<ALeadKey> &tmp = A.alead_keys2;
+    tmp.resize(nl);
+    std::vector<uint32_t> &at = A.alead_bucket_at;
     at.assign(cnt.begin(), cnt.end() - 1);
-    for (size_t q = 0; q < nq; ++q) tmp[at[(size_t)(keys[q].k1 >> 8)]++] = keys[q];
+    for (size_t q = 0; q < nl; ++q) tmp[at[(size_t)(keys[q].k1 >> 8)]++] = keys[q];
     keys.swap(tmp);
     // non-empty buckets, cut into slabs of about equal size
-    std::vector<uint32_t> &starts = ps.alead_bucket_starts;
+    std::vector<uint32_t> &starts = A.alead_bucket_starts;
     starts.clear();
     for (size_t t = 0; t < nt; ++t)
       if (cnt[t + 1] > cnt[t]) starts.push_back(cnt[t]);
-    starts.push_back((uint32_t)nq);
+    starts.push_back((uint32_t)nl);
     const uint32_t n_b = (uint32_t)starts.size() - 1u;
-    const uint32_t sort_slabs = nq >= 4096 ? std::min<uint32_t>(plan_threads(), std::max<uint32_t>(1u, n_b)) : 1u;
+    const uint32_t sort_slabs = nl >= 4096 ? std::min<uint32_t>(plan_threads(), std::max<uint32_t>(1u, n_b)) : 1u;
     parallel_slabs(sort_slabs, [&](uint32_t sb) {
       for (uint32_t b = sb; b < n_b; b += sort_slabs)  // (interleaved: the big buckets are the first leaders)
         std::sort(keys.begin() + starts[b], keys.begin() + starts[b + 1], [](const ALeadKey &a, const ALeadKey &b2) {
@@ -341,27 +441,30 @@ int build_ashare_plan(tq_segment *s, Group &g, PlanScratch &ps) {
   auto same_query = [&](const ALeadKey &a, const ALeadKey &b) -> bool {  // (the hash only proposes)
     if (a.k1 != b.k1 || a.mask != b.mask || a.sig != b.sig) return false;
     const TqdALead &la = unsorted[a.q], &lb = unsorted[b.q];
-    if ((la.info & 31u) != (lb.info & 31u) || la.k != lb.k || memcmp(&la.w, &lb.w, 4) || memcmp(&la.rest, &lb.rest, 4) ||
+    if (la.info != lb.info || la.k != lb.k || memcmp(&la.w, &lb.w, 4) || memcmp(&la.rest, &lb.rest, 4) ||
         la.dense_off != lb.dense_off)
       return false;
-    if ((la.info & 31u) == 2u) return true;  // (leader, list 1 — every list has its own bitmap —, both weights, k)
-    const TqdQuery &qa = g.queries[a.q], &qb = g.queries[b.q];
+    if (!boolean && (la.info & 31u) == 2u) return true;  // (leader, list 1 — every list has its own bitmap —, both weights, k)
+    const TqdQuery &qa = g.queries[la.query], &qb = g.queries[lb.query];
+    if (boolean && (qa.roles != qb.roles || qa.clause_end != qb.clause_end || qa.n_lead != qb.n_lead ||
+                    qa.n_opt_lead != qb.n_opt_lead || qa.min_should != qb.min_should))
+      return false;
     return !memcmp(qa.term, qb.term, qa.n_terms * sizeof(uint32_t)) &&
            !memcmp(qa.weight, qb.weight, qa.n_terms * sizeof(float));
   };
   // identical queries share one row of threshold slots, whatever groups they end up in (a slot is
   // hash(doc): the same doc lands in the same slot whichever group scored it)
-  std::vector<uint8_t> &same_as_prev = ps.alead_same;
-  same_as_prev.resize(nq);
-  const uint32_t gather_slabs = nq >= 4096 ? plan_threads() : 1u;
+  std::vector<uint8_t> &same_as_prev = A.alead_same;
+  same_as_prev.resize(nl);
+  const uint32_t gather_slabs = nl >= 4096 ? plan_threads() : 1u;
   parallel_slabs(gather_slabs, [&](uint32_t sb) {
-    const size_t i0 = nq * sb / gather_slabs, i1 = nq * (sb + 1) / gather_slabs;
+    const size_t i0 = nl * sb / gather_slabs, i1 = nl * (sb + 1) / gather_slabs;
     for (size_t i = i0; i < i1; ++i) {
       leads[i] = unsorted[keys[i].q];
       same_as_prev[i] = i && same_query(keys[i], keys[i - 1]) ? 1 : 0;
     }
   });
-  for (size_t i = 1; i < nq; ++i)
+  for (size_t i = 1; i < nl; ++i)
     if (same_as_prev[i]) leads[i].thr_row = leads[i - 1].thr_row;
   pt("gather");
   // ---- tasks: groups of leads x runs of blocks; fewer, longer tasks if the result lists (k entries
@@ -372,22 +475,22 @@ int build_ashare_plan(tq_segment *s, Group &g, PlanScratch &ps) {
   // leaves the main launch the k-th best of a sample of every query to start from.
   static const uint32_t kWarmPermille = std::min<uint32_t>(1000u, tune_u32("TQ_AS_WARM_PERMILLE", 2));
   static const uint32_t kWarmBlocks = std::max<uint32_t>(1u, tune_u32("TQ_AS_WARM_BLOCKS", 2));
-  std::vector<uint4> &tasks = ps.atasks, &raw = ps.atasks_unsorted;
-  std::vector<uint32_t> &pos = ps.atask_pos, &pairs = ps.apairs;
+  std::vector<uint4> &tasks = A.atasks, &raw = A.atasks_unsorted;
+  std::vector<uint32_t> &pos = A.atask_pos, &pairs = A.apairs;
   pairs.resize(nq);
   // the runs of one (leader, cache): their groups, task sizes and where their tasks start
-  std::vector<PlanScratch::ARun> &runs = ps.aruns;
+  std::vector<PlanScratch::ASharePlan::ARun> &runs = A.aruns;
   uint32_t task_pairs = kTaskPairsEnv;
   size_t n_tasks = 0;
   for (;;) {
     runs.clear();
     n_tasks = 0;
     uint64_t entries = 0;
-    for (size_t r0 = 0; r0 < nq;) {
+    for (size_t r0 = 0; r0 < nl;) {
       size_t r1 = r0;
       uint64_t k_sum = 0;
-      while (r1 < nq && keys[r1].k1 == keys[r0].k1) k_sum += leads[r1++].k;
-      PlanScratch::ARun R;
+      while (r1 < nl && keys[r1].k1 == keys[r0].k1) k_sum += leads[r1++].k;
+      PlanScratch::ASharePlan::ARun R;
       R.r0 = (uint32_t)r0;
       R.r1 = (uint32_t)r1;
       R.term = (uint32_t)(keys[r0].k1 >> 8);
@@ -421,9 +524,9 @@ int build_ashare_plan(tq_segment *s, Group &g, PlanScratch &ps) {
   // slice 0 = the warm-up launch, then the main launch's tasks by doc slice)
   constexpr uint32_t kSl = 4098;
   const uint32_t t_slabs = n_tasks >= 16384 ? std::min<uint32_t>(plan_threads(), (uint32_t)runs.size()) : 1u;
-  std::vector<uint32_t> &hist = ps.atask_hist;
+  std::vector<uint32_t> &hist = A.atask_hist;
   hist.assign((size_t)t_slabs * kSl, 0u);
-  std::vector<uint32_t> &slab_run = ps.atask_slab_run;
+  std::vector<uint32_t> &slab_run = A.atask_slab_run;
   slab_run.assign(t_slabs + 1, (uint32_t)runs.size());
   {
     uint32_t sb = 0;
@@ -435,11 +538,10 @@ int build_ashare_plan(tq_segment *s, Group &g, PlanScratch &ps) {
   parallel_slabs(t_slabs, [&](uint32_t sb) {
     uint32_t *h = hist.data() + (size_t)sb * kSl;
     for (uint32_t r = slab_run[sb]; r < slab_run[sb + 1]; ++r) {
-      const PlanScratch::ARun &R = runs[r];
+      const PlanScratch::ASharePlan::ARun &R = runs[r];
       for (uint32_t a = R.r0; a < R.r1; ++a) {  // twins: the same query as the lead before, inside one group
         const bool twin = (a - R.r0) % R.per_group != 0 && same_as_prev[a];
         leads[a].info = (leads[a].info & ~0x200u) | (twin ? 0x200u : 0u);
-        pairs[keys[a].q] = R.n_runs;
       }
       const uint32_t n_run = R.r1 - R.r0;
       const uint64_t slice_mul = ((uint64_t)1 << 44) / R.n_blocks;  // (j0 << 12) / n_blocks without the division
@@ -466,7 +568,7 @@ int build_ashare_plan(tq_segment *s, Group &g, PlanScratch &ps) {
         const uint32_t n = hist[(size_t)sb * kSl + sl];
         hist[(size_t)sb * kSl + sl] = run;  // becomes the slab's write position in this slice
         run += n;
-        if (sl == 0 && sb + 1 == t_slabs) ps.a_warm_tasks = run;
+        if (sl == 0 && sb + 1 == t_slabs) A.a_warm_tasks = run;
       }
   }
   parallel_slabs(t_slabs, [&](uint32_t sb) {
@@ -476,6 +578,10 @@ int build_ashare_plan(tq_segment *s, Group &g, PlanScratch &ps) {
     for (size_t i = t0; i < t1; ++i) tasks[h[pos[i]]++] = raw[i];
   });
   pt("tasks");
+  // result lists: k entries per (task, lead) pair of the query
+  std::fill(pairs.begin(), pairs.end(), 0u);
+  for (const PlanScratch::ASharePlan::ARun &R : runs)
+    for (uint32_t a = R.r0; a < R.r1; ++a) pairs[leads[a].query] += R.n_runs;
   uint64_t entries = 0;
   for (size_t q = 0; q < nq; ++q) {
     TqdQuery &dq = g.queries[q];

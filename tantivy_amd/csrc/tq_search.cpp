@@ -24,7 +24,7 @@ int search_batch_impl(tq_segment *s, const tq_query *queries, uint32_t n_queries
   // launch groups: AND queries whose non-leader lists all have a bitmap run a leaner kernel
   // instantiation (no seek / block-search code: fewer registers, less LDS, more waves per CU)
   // boolean queries (clauses with roles) run the candidate-driven union kernel's BOOL instantiation
-  constexpr int kGroups = kNGroups, kAndGeneral = 3, kBool = 4, kShare = 5, kPhSweep = 6, kDense = 7, kAShare = 8;
+  constexpr int kGroups = kNGroups, kAndGeneral = 3, kBool = 4, kShare = 5, kPhSweep = 6, kDense = 7, kAShare = 8, kBShare = 9;
   // AND queries whose other lists all have a bitmap + byte-wide tfs, pruned, k <= 128, <= 8 lists, on a
   // segment with a doc matrix, whose leader (rarest list) leads at least kAShareMin such queries of the
   // batch: the shared-intersection launch (leader-major, tq_ashare.hip).  TQ_ASHARE=0: the per-query kernel
@@ -65,6 +65,7 @@ int search_batch_impl(tq_segment *s, const tq_query *queries, uint32_t n_queries
   groups[kPhSweep].mode = TQ_MODE_PHRASE;
   groups[kDense].mode = TQ_MODE_OR;
   groups[kAShare].mode = TQ_MODE_AND;
+  groups[kBShare].mode = TQ_MODE_OR;
   s->plan->xrow_term.clear();
   s->plan->xrow_of.clear();
   groups[0].mode = TQ_MODE_AND;
@@ -185,7 +186,7 @@ int search_batch_impl(tq_segment *s, const tq_query *queries, uint32_t n_queries
         return fail(TQ_ERR_INVALID, "query %u: unknown term handle %u", qi, q.terms[i]);
     }
     int mode = q.mode;
-    bool ph_sweep = false, ashare = false;
+    bool ph_sweep = false, ashare = false, bshare = false;
     uint32_t n_tiles = 0, tile_cost = 1;
     bool all_dense = true;
     uint64_t qbytes = 8ull * q.k;
@@ -281,6 +282,15 @@ int search_batch_impl(tq_segment *s, const tq_query *queries, uint32_t n_queries
       if (rc != TQ_OK) return rc;
       mode = TQ_MODE_OR;  // runs in the union launch group
       bool_done = true;
+      // the shared launch (tq_ashare.hip, boolean leads): every list reached through its bitmap and tf bytes
+      // (the only list of a lead set of one is only ever decoded)
+      static const bool kUseBShare = tune_u32("TQ_BSHARE", 1) != 0;
+      bshare = kUseBShare && ashare_on && (dq.flags & TQD_QF_PRUNE) && dq.thr_index != 0xFFFFFFFFu && dq.n_terms >= 1 &&
+               dq.n_terms <= TQD_AS_MAX_TERMS && q.k <= 128u && ps_plan.q_cache[qi] < 256u && dq.n_lead >= 1;
+      for (uint32_t i = 0; bshare && i < dq.n_terms; ++i) {
+        const TermHost &th = s->terms[dq.term[i]];
+        if (!(th.dense_blob && th.tf8_blob) && !(dq.n_lead == 1 && i == 0)) bshare = false;
+      }
     }
     if (mode == TQ_MODE_OR && !bool_done) {
       if (q.mode == TQ_MODE_OR) {
@@ -390,7 +400,7 @@ int search_batch_impl(tq_segment *s, const tq_query *queries, uint32_t n_queries
     }
     algo_bytes += qbytes;
     dq.n_tiles = n_tiles;
-    Group &g = groups[bool_done ? kBool : (share ? kShare : (dense_u ? kDense : (ph_sweep ? kPhSweep : (ashare ? kAShare : ((mode == TQ_MODE_AND && !all_dense) ? kAndGeneral : mode)))))];
+    Group &g = groups[bool_done ? (bshare ? kBShare : kBool) : (share ? kShare : (dense_u ? kDense : (ph_sweep ? kPhSweep : (ashare ? kAShare : ((mode == TQ_MODE_AND && !all_dense) ? kAndGeneral : mode)))))];
     dq.mode = (uint32_t)mode;
     g.queries.push_back(dq);
     g.tile_cost.push_back(tile_cost);
@@ -484,7 +494,8 @@ int search_batch_impl(tq_segment *s, const tq_query *queries, uint32_t n_queries
   for (Group &g : groups) {
     if (g.queries.empty()) continue;
     const int crc = &g == &groups[kShare]    ? build_share_plan(s, g, *s->plan)
-                    : &g == &groups[kAShare] ? build_ashare_plan(s, g, *s->plan)
+                    : &g == &groups[kAShare] ? build_ashare_plan(s, g, *s->plan, false)
+                    : &g == &groups[kBShare] ? build_ashare_plan(s, g, *s->plan, true)
                     : &g == &groups[kDense]  ? build_dense_plan(s, g, *s->plan, (uint32_t)std::max(1, cus))
                                              : build_group_chunks(g, or_windows_opt && &g != &groups[kBool], *s->plan,
                                                                   &g == &groups[kBool]);
@@ -495,7 +506,7 @@ int search_batch_impl(tq_segment *s, const tq_query *queries, uint32_t n_queries
   for (int gi = 0; gi < kGroups; ++gi) {
     Group &g = groups[gi];
     part_off_bytes[gi] = partial_bytes;
-    if (gi == kShare || gi == kDense || gi == kAShare) {  // result lists: part_start / n_parts count 8-byte entries (build_share_plan)
+    if (gi == kShare || gi == kDense || gi == kAShare || gi == kBShare) {  // result lists: part_start / n_parts count 8-byte entries (build_share_plan)
       if (!g.queries.empty())
         partial_bytes += ((size_t)g.queries.back().part_start + g.queries.back().n_parts) * sizeof(uint64_t);
       continue;
@@ -545,13 +556,16 @@ int search_batch_impl(tq_segment *s, const tq_query *queries, uint32_t n_queries
       g.o_tasks = stage;
       stage += s->plan->tasks.size() * sizeof(uint4);
     }
-    if (&g == &groups[kAShare]) {
+    if (&g == &groups[kAShare] || &g == &groups[kBShare]) {
+      const PlanScratch::ASharePlan &A = s->plan->ap[&g == &groups[kBShare] ? 1 : 0];
       stage = (stage + 63) & ~(size_t)63;
       g.o_leads = stage;
-      stage += s->plan->aleads.size() * sizeof(TqdALead);
+      stage += A.aleads.size() * sizeof(TqdALead);
       stage = (stage + 15) & ~(size_t)15;
       g.o_tasks = stage;
-      stage += s->plan->atasks.size() * sizeof(uint4);
+      stage += A.atasks.size() * sizeof(uint4);
+      g.o_lists = stage;
+      if (&g == &groups[kBShare]) stage += A.alists.size() * sizeof(uint2);
     }
     if (&g == &groups[kDense]) {  // (o_leads: the rows, o_tasks: the queries)
       stage = (stage + 63) & ~(size_t)63;
@@ -599,9 +613,11 @@ int search_batch_impl(tq_segment *s, const tq_query *queries, uint32_t n_queries
       big_copy(hs + g.o_leads, s->plan->leads.data(), s->plan->leads.size() * sizeof(TqdLead));
       memcpy(hs + g.o_tasks, s->plan->tasks.data(), s->plan->tasks.size() * sizeof(uint4));
     }
-    if (&g == &groups[kAShare]) {
-      memcpy(hs + g.o_leads, s->plan->aleads.data(), s->plan->aleads.size() * sizeof(TqdALead));
-      big_copy(hs + g.o_tasks, s->plan->atasks.data(), s->plan->atasks.size() * sizeof(uint4));
+    if (&g == &groups[kAShare] || &g == &groups[kBShare]) {
+      const PlanScratch::ASharePlan &A = s->plan->ap[&g == &groups[kBShare] ? 1 : 0];
+      memcpy(hs + g.o_leads, A.aleads.data(), A.aleads.size() * sizeof(TqdALead));
+      big_copy(hs + g.o_tasks, A.atasks.data(), A.atasks.size() * sizeof(uint4));
+      if (&g == &groups[kBShare]) memcpy(hs + g.o_lists, A.alists.data(), A.alists.size() * sizeof(uint2));
     }
     if (&g == &groups[kDense]) {
       memcpy(hs + g.o_leads, s->plan->xrows.data(), s->plan->xrows.size() * sizeof(TqkDenseRow));
@@ -694,19 +710,24 @@ int search_batch_impl(tq_segment *s, const tq_query *queries, uint32_t n_queries
     HIP_TRY(hipMemsetAsync(s->d_share_words.p, 0, words * sizeof(uint32_t), st));
   }
 
-  uint32_t ashare_grid = 0;
-  const size_t n_ashare = groups[kAShare].queries.size();
-  if (n_ashare) {  // thr_val | list_count per query, then the task counter; staging lists of the persistent grid
+  // the shared-intersection launches: [0] intersections, [1] boolean queries
+  const int a_group[2] = {kAShare, kBShare};
+  uint32_t ashare_grid[2] = {0, 0};
+  const size_t n_ashare_of[2] = {groups[kAShare].queries.size(), groups[kBShare].queries.size()};
+  const size_t n_ashare = n_ashare_of[0];
+  for (int ai = 0; ai < 2; ++ai) {
+    if (!n_ashare_of[ai]) continue;  // thr_val | list_count per query, then the task counters; staging lists of the persistent grid
     static const uint32_t kAGridMul = tune_u32("TQ_AS_GRID_MUL", 0);
-    const uint32_t per_cu = kAGridMul ? kAGridMul : tqk_ashare_waves_per_cu();
-    ashare_grid = (uint32_t)std::min<uint64_t>(groups[kAShare].n_chunks, (uint64_t)std::max(1, cus) * per_cu);
-    const size_t words = 2 * n_ashare + 16;
-    rc = s->d_ashare_words.ensure(words * sizeof(uint32_t));
+    const uint32_t per_cu = kAGridMul ? kAGridMul : (ai ? tqk_bshare_waves_per_cu() : tqk_ashare_waves_per_cu());
+    ashare_grid[ai] = (uint32_t)std::min<uint64_t>(groups[a_group[ai]].n_chunks, (uint64_t)std::max(1, cus) * per_cu);
+    const size_t words = 2 * n_ashare_of[ai] + 16;
+    DevBuf &wb = ai ? s->d_bshare_words : s->d_ashare_words;
+    rc = wb.ensure(words * sizeof(uint32_t));
     if (rc == TQ_OK)
-      rc = sc.ashare_stage.ensure((size_t)ashare_grid * TQD_AS_GROUP * tqk_share_capl(groups[kAShare].kpl) *
-                                    sizeof(uint64_t));
+      rc = (ai ? sc.bshare_stage : sc.ashare_stage)
+               .ensure((size_t)ashare_grid[ai] * TQD_AS_GROUP * tqk_share_capl(groups[a_group[ai]].kpl) * sizeof(uint64_t));
     if (rc != TQ_OK) return rc;
-    HIP_TRY(hipMemsetAsync(s->d_ashare_words.p, 0, words * sizeof(uint32_t), st));
+    HIP_TRY(hipMemsetAsync(wb.p, 0, words * sizeof(uint32_t), st));
   }
 
   // ---- launch
@@ -724,7 +745,7 @@ int search_batch_impl(tq_segment *s, const tq_query *queries, uint32_t n_queries
     HIP_TRY(hipEventRecord(s->ev_fork, st));
     HIP_TRY(hipStreamWaitEvent(s->side_stream, s->ev_fork, 0));
   }
-  const int launch_order[kGroups] = {kAndGeneral, kBool, kShare, kDense, 1, 2, kPhSweep, 0, kAShare};  // long serial chains first
+  const int launch_order[kGroups] = {kAndGeneral, kBool, kBShare, kShare, kDense, 1, 2, kPhSweep, 0, kAShare};  // long serial chains first
   // the group that keeps the caller's stream: the batch's intersections
   const int main_group = n_ashare ? kAShare : 0;
   uint32_t kernel_mask = 0;
@@ -734,7 +755,9 @@ int search_batch_impl(tq_segment *s, const tq_query *queries, uint32_t n_queries
     if (g.queries.empty()) continue;
     // the big dense-AND group keeps the caller's stream, the others go to the side stream
     hipStream_t gst = (fork && gi != main_group) ? s->side_stream : st;
-    if (gi == kAShare) {
+    if (gi == kAShare || gi == kBShare) {
+      const int ai = gi == kBShare ? 1 : 0;
+      const size_t n_a = n_ashare_of[ai];
       TqkAShareParams ap{};
       ap.seg = s->dseg;
       ap.terms = s->d_terms;
@@ -742,28 +765,30 @@ int search_batch_impl(tq_segment *s, const tq_query *queries, uint32_t n_queries
       ap.caches = (const float *)(ds + o_caches);
       ap.leads = (const TqdALead *)(ds + g.o_leads);
       ap.tasks = (const uint4 *)(ds + g.o_tasks);
+      ap.qlists = (const uint2 *)(ds + g.o_lists);
       ap.sinks = (const TqkSinks *)(ds + g.o_sinks);
       ap.thr_slots = (uint32_t *)s->d_thr.p;
-      ap.thr_val = (uint32_t *)s->d_ashare_words.p;
-      ap.list_count = ap.thr_val + n_ashare;
+      ap.thr_val = (uint32_t *)(ai ? s->d_bshare_words : s->d_ashare_words).p;
+      ap.list_count = ap.thr_val + n_a;
       ap.table_base = (const uint8_t *)s->plan->share_table_base;
-      ap.stage = (uint64_t *)sc.ashare_stage.p;
+      ap.stage = (uint64_t *)(ai ? sc.bshare_stage : sc.ashare_stage).p;
       ap.lists = (uint64_t *)((uint8_t *)sc.partials.p + part_off_bytes[gi]);
-      ap.n_queries = (uint32_t)n_ashare;
+      ap.n_queries = (uint32_t)n_a;
+      ap.boolean = (uint32_t)ai;
       static const uint32_t kDebugA = tune_u32("TQ_DEBUG", 0);
       ap.debug = kDebugA;
       ap.bound_slack = co.bound_slack;
       tiles_total += g.total_tiles;
       chunks_total += g.n_chunks;
-      kernel_mask |= TQ_KERNEL_ASHARE;
+      kernel_mask |= ai ? TQ_KERNEL_BSHARE : TQ_KERNEL_ASHARE;
       // two launches: the warm-up tasks, then the rest (stream order = the barrier between them)
-      const uint32_t bounds[3] = {0u, s->plan->a_warm_tasks, g.n_chunks};
+      const uint32_t bounds[3] = {0u, s->plan->ap[ai].a_warm_tasks, g.n_chunks};
       for (int ph = 0; ph < 2; ++ph) {
         ap.task_begin = bounds[ph];
         ap.n_tasks = bounds[ph + 1];
         if (ap.n_tasks <= ap.task_begin) continue;
-        ap.task_counter = ap.thr_val + 2 * n_ashare + ph;
-        ap.grid = std::min<uint32_t>(ashare_grid, ap.n_tasks - ap.task_begin);
+        ap.task_counter = ap.thr_val + 2 * n_a + ph;
+        ap.grid = std::min<uint32_t>(ashare_grid[ai], ap.n_tasks - ap.task_begin);
         const hipError_t e = tqk_launch_ashare(ap, g.kpl, gst);
         if (e != hipSuccess) return fail(TQ_ERR_HIP, "shared-intersection launch: %s", hipGetErrorString(e));
       }
@@ -899,6 +924,7 @@ int search_batch_impl(tq_segment *s, const tq_query *queries, uint32_t n_queries
     m.n_queries = (uint32_t)g.queries.size();
     m.out_stride = out_stride;
     hipError_t e = gi == kAShare  ? tqk_launch_merge_lists(m, (const uint32_t *)s->d_ashare_words.p + n_ashare, g.kpl, st)
+                   : gi == kBShare ? tqk_launch_merge_lists(m, (const uint32_t *)s->d_bshare_words.p + n_ashare_of[1], g.kpl, st)
                    : gi == kShare ? tqk_launch_merge_lists(m, (const uint32_t *)s->d_share_words.p + n_share, g.kpl, st)
                    : gi == kDense ? tqk_launch_merge_lists(m, (const uint32_t *)s->d_share_words.p + n_dense, g.kpl, st)
                                   : tqk_launch_merge(m, g.kpl, st);
@@ -922,6 +948,9 @@ int search_batch_impl(tq_segment *s, const tq_query *queries, uint32_t n_queries
   if (trace) {
     const auto tr3 = std::chrono::steady_clock::now();
     auto us = [](auto a, auto b) { return (long)std::chrono::duration_cast<std::chrono::microseconds>(b - a).count(); };
+    for (int gi = 0; gi < kGroups; ++gi)
+      if (!groups[gi].queries.empty())
+        fprintf(stderr, "[tq] group %d: %zu queries, %u tasks\n", gi, groups[gi].queries.size(), groups[gi].n_chunks);
     fprintf(stderr, "[tq] plan %ld us (pre-pass %ld us, queries %ld us, chunks %ld us), wait for the staging buffer %ld us, stage fill %ld us, enqueue %ld us, stage bytes %zu\n",
             us(tr0, tr1), us(tr0, tr0a), us(tr0a, tr0b), us(tr0b, tr1), us(tr1, tr1w), us(tr1w, tr2), us(tr2, tr3), stage);
   }

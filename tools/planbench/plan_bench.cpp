@@ -182,7 +182,7 @@ static int bench_ashare(int n_queries, int reps) {
   }
   std::sort(all_ms.begin(), all_ms.end());
   printf("ashare: queries %d tasks %zu (warm %u): build_ashare_plan %.2f ms (best of %d), median %.2f ms, p90 %.2f ms\n",
-         n_queries, ps.atasks.size(), ps.a_warm_tasks, best, reps, all_ms[all_ms.size() / 2],
+         n_queries, ps.ap[0].atasks.size(), ps.ap[0].a_warm_tasks, best, reps, all_ms[all_ms.size() / 2],
          all_ms[std::min(all_ms.size() - 1, all_ms.size() * 9 / 10)]);
   return 0;
 }

@@ -260,11 +260,11 @@ static int check_ashare(int seed) {
   }
   seg.share_table_lo = (uint64_t)arena;
   if (build_ashare_plan(&seg, g, ps) != TQ_OK) return fail_msg("build_ashare_plan failed");
-  if (ps.aleads.size() != nq) return fail_msg("lead count", (long)ps.aleads.size(), nq);
+  if (ps.ap[0].aleads.size() != nq) return fail_msg("lead count", (long)ps.ap[0].aleads.size(), nq);
   std::vector<uint8_t> seen(nq, 0);
   uint64_t prev_key = 0, prev_mask = 0;
-  for (size_t i = 0; i < ps.aleads.size(); ++i) {
-    const TqdALead &ld = ps.aleads[i];
+  for (size_t i = 0; i < ps.ap[0].aleads.size(); ++i) {
+    const TqdALead &ld = ps.ap[0].aleads[i];
     if (ld.query >= nq || seen[ld.query]++) return fail_msg("lead twice / out of range", (long)i, ld.query);
     const TqdQuery &q = g.queries[ld.query];
     if ((ld.info & 31u) != q.n_terms || ld.w != q.weight[0] || ld.k != q.k) return fail_msg("lead header", (long)i);
@@ -296,28 +296,28 @@ static int check_ashare(int seed) {
   std::unordered_map<uint64_t, uint32_t> next_block;  // (first lead << 8 | n_leads) -> next expected block
   std::unordered_map<uint64_t, uint32_t> covered;     // lead index -> tasks that name it (via its group)
   uint32_t last_slice = 0;
-  for (size_t ti = 0; ti < ps.atasks.size(); ++ti) {
-    const uint4 t = ps.atasks[ti];
+  for (size_t ti = 0; ti < ps.ap[0].atasks.size(); ++ti) {
+    const uint4 t = ps.ap[0].atasks[ti];
     const uint32_t nb = t.z & 0xFFFFu, nl = (t.z >> 16) & 0xFFu, cache = t.z >> 24;
-    if (!nb || !nl || nl > TQD_AS_GROUP || t.w + nl > ps.aleads.size()) return fail_msg("task shape", (long)ti);
+    if (!nb || !nl || nl > TQD_AS_GROUP || t.w + nl > ps.ap[0].aleads.size()) return fail_msg("task shape", (long)ti);
     for (uint32_t l = 0; l < nl; ++l) {
-      const TqdALead &ld = ps.aleads[t.w + l];
+      const TqdALead &ld = ps.ap[0].aleads[t.w + l];
       const TqdQuery &q = g.queries[ld.query];
       if (q.term[0] != t.x || q.cache_idx != cache) return fail_msg("task lead of another leader", (long)ti, l);
       ++pairs[ld.query];
       // twin bit: set iff the lead is the same query (lists, weights) as the one before it in the group
       bool same = false;
       if (l) {
-        const TqdQuery &pq = g.queries[ps.aleads[t.w + l - 1].query];
+        const TqdQuery &pq = g.queries[ps.ap[0].aleads[t.w + l - 1].query];
         same = pq.n_terms == q.n_terms && pq.k == q.k && !memcmp(pq.term, q.term, q.n_terms * 4) &&
                !memcmp(pq.weight, q.weight, q.n_terms * 4);
-        if (same && ps.aleads[t.w + l - 1].thr_row != ld.thr_row) return fail_msg("twins share one row of threshold slots", (long)ti, l);
+        if (same && ps.ap[0].aleads[t.w + l - 1].thr_row != ld.thr_row) return fail_msg("twins share one row of threshold slots", (long)ti, l);
       }
       if ((((ld.info >> 9) & 1u) != 0u) != same) return fail_msg("twin bit", (long)ti, l);
     }
     const uint32_t n_blocks = seg.terms[t.x].n_blocks;
     // the warm-up launch (tasks [0, a_warm_tasks): the first blocks of every leader), then doc-slice order
-    const bool warm = ti < ps.a_warm_tasks;
+    const bool warm = ti < ps.ap[0].a_warm_tasks;
     // (the planner's slice of a run: (first block << 12) / n_blocks by a multiplication with 2^44 / n_blocks)
     const uint32_t slice = warm ? 0u : 1u + std::min<uint32_t>(4095u, (uint32_t)((t.y * (((uint64_t)1 << 44) / n_blocks)) >> 32));
     if (slice < last_slice) return fail_msg("tasks not in doc-slice order", (long)ti);
@@ -330,7 +330,7 @@ static int check_ashare(int seed) {
   }
   size_t leads_in_groups = 0;
   for (auto &kv : next_block) {
-    const TqdALead &ld = ps.aleads[kv.first >> 8];
+    const TqdALead &ld = ps.ap[0].aleads[kv.first >> 8];
     if (kv.second != seg.terms[g.queries[ld.query].term[0]].n_blocks) return fail_msg("list not covered");
     leads_in_groups += kv.first & 0xFFu;
   }
@@ -342,8 +342,8 @@ static int check_ashare(int seed) {
     if (g.queries[q].n_parts != pairs[q] * g.queries[q].k) return fail_msg("result region size", q);
     at += g.queries[q].n_parts;
   }
-  if (g.n_chunks != ps.atasks.size()) return fail_msg("n_chunks");
-  printf("ashare: %u queries, %zu tasks, %llu list entries ok\n", nq, ps.atasks.size(), (unsigned long long)at);
+  if (g.n_chunks != ps.ap[0].atasks.size()) return fail_msg("n_chunks");
+  printf("ashare: %u queries, %zu tasks, %llu list entries ok\n", nq, ps.ap[0].atasks.size(), (unsigned long long)at);
   return 0;
 }
 

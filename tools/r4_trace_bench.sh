@@ -3,7 +3,7 @@
 R=${GRAFT_REPO_ROOT:-/root/repo}
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/kt_b
-timeout 300 rocprofv3 --kernel-trace --memory-copy-trace --output-format csv -d /tmp/kt_b -o kt -- python $R/bench.py --workload and2 --no-side --no-cpu-baseline --latency-queries 0 --steps 6 --warmup 2 "$@" > /tmp/kt_b.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --memory-copy-trace --output-format csv -d /tmp/kt_b -o kt -- python $R/bench.py --workload ${W:-and2} --no-side --no-cpu-baseline --latency-queries 0 --steps 6 --warmup 2 "$@" > /tmp/kt_b.log 2>&1
 tail -1 /tmp/kt_b.log | cut -c1-200
 python - <<'PY'
 import csv,glob,re
