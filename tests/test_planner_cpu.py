@@ -84,6 +84,20 @@ def test_ashare_plan_invariants(plan_check, seed):
         assert "ashare:" in r.stdout and "ok" in r.stdout
 
 
+@pytest.mark.parametrize("seed", range(6))
+def test_boolean_share_plan_invariants(plan_check, seed):
+    """build_ashare_plan with boolean leads (TQ_MODE_BOOL through the shared launch): one lead per (query,
+    list of its lead set), tasks tile every lead's list once, result regions hold k entries per (task, lead)
+    pair — and the filter stage is SAFE: over random doc-matrix words (exact columns, signature bits with
+    false positives) no lead's masks drop a doc the query matches, no doc's bound is below what it can
+    score, no list holding the doc is marked never-probed."""
+    for env_extra in ({}, {"TQ_AS_GROUP": "3", "TQ_AS_TASK_PAIRS": "64"}, {"TQ_AS_LIST_MB": "1"}):
+        r = subprocess.run([plan_check, str(seed), "bshare"], env=dict(os.environ, **env_extra),
+                           capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr + r.stdout
+        assert "bshare:" in r.stdout and "ok" in r.stdout
+
+
 def test_eight_planners_at_once(tmp_path_factory):
     """eight ranks of a node plan their batches at the same time on the node's few
     granted CPUs.  Eight concurrent processes (one per CPU where there are eight) each plan the headline

@@ -347,6 +347,211 @@ static int check_ashare(int seed) {
   return 0;
 }
 
+// The boolean leads of the shared launch (build_ashare_plan(.., boolean = true)): one lead per (query,
+// list of its lead set); the tasks of a lead group tile the leader's blocks exactly once; result
+// regions hold k entries per (task, lead) pair of the query.  And what the device's filter stage does
+// with a lead's masks is SAFE: for random membership vectors (doc-matrix words with exact column bits and
+// signature bits that may be set for non-members), a doc that the query matches and that belongs to this
+// lead is never dropped by the masks, and its bound (leader weight + the weights of the lists its word
+// does not rule out) is never below the score the doc can reach; a list the lead marks "never probed"
+// never holds such a doc.
+static int check_bshare(int seed) {
+  std::mt19937 rng(seed + 900);
+  auto uni = [&](uint32_t lo, uint32_t hi) { return std::uniform_int_distribution<uint32_t>(lo, hi)(rng); };
+  tq_segment seg;
+  const uint32_t n_terms = 90;
+  static uint8_t arena[1 << 20];
+  for (uint32_t t = 0; t < n_terms; ++t) {
+    TermHost th;
+    th.n_blocks = std::max<uint32_t>(1u, uni(1, 20000) >> (t / 8));
+    th.doc_freq = th.n_blocks * 128u - uni(0, 127);
+    TqdTerm dt{};
+    dt.has_freq = 1u;
+    th.dense_blob = arena + 4096u * t + 8u;
+    th.tf8_blob = arena + 4096u * t + 2048u;
+    if (t < TQD_MAT_SLOTS) dt.has_freq |= (t + 1u) << 8;
+    else if (t % 5) dt.has_freq |= ((t * 7u) % TQD_SIG_BITS + 1u) << 16;  // (some lists with neither)
+    seg.terms.push_back(th);
+    seg.h_dterms.push_back(dt);
+  }
+  seg.max_doc = 10000000u;
+  seg.share_table_lo = (uint64_t)arena;
+  PlanScratch ps;
+  Group &g = ps.groups[9];
+  g.reset();
+  g.mode = TQ_MODE_OR;
+  const uint32_t nq = uni(1, 3) == 1 ? uni(1, 30) : uni(300, 1500);
+  for (uint32_t q = 0; q < nq; ++q) {
+    TqdQuery dq{};
+    if (q && uni(0, 3) == 0) {  // repeats (twins)
+      dq = g.queries[uni(0, q - 1)];
+    } else {
+      // plan_bool_query's layout: [optional leading Should | lead Must clause | Must clauses | MustNot | Should]
+      const bool has_must = uni(0, 3) != 0;
+      const uint32_t n_opt = has_must ? uni(0, 2) : 0u;
+      const uint32_t n_leadc = has_must ? uni(1, 2) : uni(1, 4);
+      uint32_t n = 0;
+      auto put = [&](uint32_t role) {
+        uint32_t t;
+        bool dup;
+        do {
+          t = uni(0, 2) ? uni(0, 47) : uni(0, n_terms - 1);
+          dup = false;
+          for (uint32_t j = 0; j < n; ++j) dup |= dq.term[j] == t;
+        } while (dup);
+        dq.term[n] = t;
+        dq.weight[n] = role == TQD_ROLE_MUST_NOT ? 0.0f : 0.5f + 0.25f * (float)uni(0, 12);
+        dq.roles |= role << (2u * n);
+        ++n;
+      };
+      for (uint32_t i = 0; i < n_opt; ++i) put(TQD_ROLE_SHOULD);
+      dq.n_opt_lead = n_opt;
+      for (uint32_t i = 0; i < n_leadc; ++i) put(has_must ? TQD_ROLE_MUST : TQD_ROLE_SHOULD);
+      dq.n_lead = n;
+      if (has_must) {
+        const uint32_t n_clauses = uni(0, 2);
+        for (uint32_t c = 0; c < n_clauses && n + 2 < TQD_AS_MAX_TERMS; ++c) {
+          const uint32_t w = uni(1, 2);
+          for (uint32_t i = 0; i < w; ++i) put(TQD_ROLE_MUST);
+          dq.clause_end |= 1u << (n - 1u);
+        }
+      }
+      for (uint32_t i = uni(0, 2); i > 0 && n < TQD_AS_MAX_TERMS; --i) put(TQD_ROLE_MUST_NOT);
+      if (has_must && !n_opt)
+        for (uint32_t i = uni(0, 2); i > 0 && n < TQD_AS_MAX_TERMS; --i) put(TQD_ROLE_SHOULD);
+      dq.n_terms = n;
+      dq.cache_idx = uni(0, 9) ? 0u : 1u;
+      dq.flags = TQD_QF_PRUNE;
+    }
+    dq.k = uni(1, 128);
+    dq.thr_index = 4u * q;
+    g.queries.push_back(dq);
+    g.tile_cost.push_back(1);
+    g.out_index.push_back(q);
+    g.max_k = std::max(g.max_k, dq.k);
+  }
+  if (build_ashare_plan(&seg, g, ps, true) != TQ_OK) return fail_msg("build_ashare_plan (boolean) failed");
+  const PlanScratch::ASharePlan &A = ps.ap[1];
+  size_t want_leads = 0;
+  for (const TqdQuery &q : g.queries) want_leads += q.n_lead;
+  if (A.aleads.size() != want_leads) return fail_msg("lead count", (long)A.aleads.size(), (long)want_leads);
+  auto bit_of = [&](uint32_t handle) -> uint32_t {
+    const uint32_t hf = seg.h_dterms[handle].has_freq;
+    const uint32_t slot1 = (hf >> 8) & 0xFFu, sig1 = (hf >> 16) & 0xFFu;
+    return slot1 ? 8u + slot1 - 1u : (sig1 ? TQD_SIG_SHIFT + sig1 - 1u : 0u);
+  };
+  std::vector<uint32_t> seen(nq, 0);
+  uint64_t prev_key = 0;
+  for (size_t i = 0; i < A.aleads.size(); ++i) {
+    const TqdALead &ld = A.aleads[i];
+    if (ld.query >= nq) return fail_msg("lead out of range", (long)i);
+    const TqdQuery &q = g.queries[ld.query];
+    const uint32_t li = (ld.info >> 16) & 15u;
+    if (li >= q.n_lead || (seen[ld.query] >> li) & 1u) return fail_msg("lead twice / not a lead-set list", (long)i, li);
+    seen[ld.query] |= 1u << li;
+    if ((ld.info & 31u) != q.n_terms || ld.w != q.weight[li] || ld.k != q.k) return fail_msg("lead header", (long)i);
+    const uint64_t key = ((uint64_t)q.term[li] << 8) | q.cache_idx;
+    if (i && key < prev_key) return fail_msg("lead order", (long)i);
+    prev_key = key;
+    for (uint32_t m = 0; m < q.n_terms; ++m) {
+      const uint2 bl = A.alists[(size_t)ld.query * TQD_AS_MAX_TERMS + m];
+      if ((uint64_t)bl.x * 8u != (uint64_t)seg.terms[q.term[m]].dense_blob - ps.share_table_base ||
+          (uint64_t)bl.y * 8u != (uint64_t)seg.terms[q.term[m]].tf8_blob - ps.share_table_base)
+        return fail_msg("list table", (long)i, m);
+    }
+    const uint64_t excl = ((uint64_t)ld.excl_hi << 32) | ld.excl_lo, any1 = ((uint64_t)ld.any1_hi << 32) | ld.any1_lo,
+                   any2 = ((uint64_t)ld.any2_hi << 32) | ld.any2_lo, bytes = ((uint64_t)ld.tf8_off << 32) | ld.dense_off;
+    float rest_base;
+    memcpy(&rest_base, &ld.mask_lo, sizeof(float));
+    const uint32_t maybe = (ld.info >> 20) & 0xFFu;
+    // random docs of this lead's list
+    for (int trial = 0; trial < 24; ++trial) {
+      bool in[TQD_AS_MAX_TERMS];
+      uint64_t word = 0;
+      for (uint32_t m = 0; m < q.n_terms; ++m) {
+        in[m] = m == li || uni(0, 2) == 0;
+        const uint32_t b = bit_of(q.term[m]);
+        if (b && (in[m] || (b >= TQD_SIG_SHIFT && uni(0, 3) == 0))) word |= 1ull << b;  // (signature bits: false positives)
+      }
+      word |= (uint64_t)uni(0, 0xFFFFu) << TQD_SIG_SHIFT & (uni(0, 1) ? ~0ull : 0ull);  // (other lists' signature bits)
+      for (uint32_t b = 8; b < TQD_SIG_SHIFT; ++b) {  // other lists' columns, at random
+        bool ours = false;
+        for (uint32_t m = 0; m < q.n_terms; ++m) ours |= bit_of(q.term[m]) == b;
+        if (!ours && uni(0, 3) == 0) word |= 1ull << b;
+      }
+      // does the query match the doc, and does the doc belong to this lead?
+      bool match = true, lead_clause = q.n_opt_lead == q.n_lead;  // (no Must: the lead set is the union itself)
+      float reach = 0.0f;
+      bool cfound = false;
+      for (uint32_t m = 0; m < q.n_terms; ++m) {
+        const uint32_t role = (q.roles >> (2u * m)) & 3u;
+        if (role == TQD_ROLE_MUST_NOT) {
+          if (in[m]) match = false;
+          continue;
+        }
+        if (m < li && in[m]) match = false;  // an earlier list of the lead set holds it: that lead's doc
+        if (m >= q.n_opt_lead && m < q.n_lead && in[m]) lead_clause = true;
+        if (m >= q.n_lead && role == TQD_ROLE_MUST) {
+          cfound |= in[m];
+          if ((q.clause_end >> m) & 1u) {
+            if (!cfound) match = false;
+            cfound = false;
+          }
+        }
+        if (m > li && in[m]) reach += q.weight[m];
+      }
+      if (q.n_opt_lead < q.n_lead && !lead_clause) match = false;
+      if (!match) continue;
+      if (word & excl) return fail_msg("exclusion mask drops a match", (long)i, trial);
+      if (any1 && !(word & any1)) return fail_msg("clause mask 1 drops a match", (long)i, trial);
+      if (any2 && !(word & any2)) return fail_msg("clause mask 2 drops a match", (long)i, trial);
+      float bound = rest_base;
+      for (uint32_t m = 0; m < q.n_terms; ++m) {
+        const uint32_t bp = (uint32_t)(bytes >> (8u * m)) & 0xFFu;
+        if (bp && ((word >> bp) & 1ull)) bound += q.weight[m];
+        const bool probed = ((maybe >> m) & 1u) && (!bp || ((word >> bp) & 1ull));
+        if (m != li && in[m] && !probed) return fail_msg("a list that holds the doc is not probed", (long)i, m);
+      }
+      if (bound * 1.00001f < reach) return fail_msg("doc bound below its reach", (long)i, trial);
+      if (ld.rest * 1.00001f < reach) return fail_msg("lead rest below a reach", (long)i, trial);
+    }
+  }
+  for (uint32_t q = 0; q < nq; ++q)
+    if (seen[q] != (1u << g.queries[q].n_lead) - 1u) return fail_msg("a lead-set list without a lead", q);
+  // tasks: groups of leads x runs of blocks, every (lead, block) once
+  std::vector<uint32_t> pairs(nq, 0);
+  std::unordered_map<uint64_t, uint32_t> next_block;
+  for (size_t ti = 0; ti < A.atasks.size(); ++ti) {
+    const uint4 t = A.atasks[ti];
+    const uint32_t nb = t.z & 0xFFFFu, nl = (t.z >> 16) & 0xFFu;
+    if (!nb || !nl || nl > TQD_AS_GROUP || t.w + nl > A.aleads.size()) return fail_msg("task shape", (long)ti);
+    for (uint32_t l = 0; l < nl; ++l) {
+      const TqdALead &ld = A.aleads[t.w + l];
+      const TqdQuery &q = g.queries[ld.query];
+      if (q.term[(ld.info >> 16) & 15u] != t.x || q.cache_idx != (t.z >> 24)) return fail_msg("task lead mismatch", (long)ti, l);
+      ++pairs[ld.query];
+    }
+    uint32_t &nx = next_block[((uint64_t)t.w << 8) | nl];
+    if (t.y != nx) return fail_msg("runs do not tile the list", (long)ti, t.y);
+    nx += nb;
+    if (nx > seg.terms[t.x].n_blocks) return fail_msg("run past the list", (long)ti);
+    if ((ti < A.a_warm_tasks) != (t.y < seg.terms[t.x].n_blocks * 2ull / 1000ull)) return fail_msg("warm-up split", (long)ti);
+  }
+  for (auto &kv : next_block) {
+    const TqdALead &ld = A.aleads[kv.first >> 8];
+    if (kv.second != seg.terms[g.queries[ld.query].term[(ld.info >> 16) & 15u]].n_blocks) return fail_msg("list not covered");
+  }
+  uint64_t at = 0;
+  for (uint32_t q = 0; q < nq; ++q) {
+    if (!pairs[q]) return fail_msg("query without a task", q);
+    if (g.queries[q].part_start != at) return fail_msg("result regions overlap", q);
+    if (g.queries[q].n_parts != pairs[q] * g.queries[q].k) return fail_msg("result region size", q);
+    at += g.queries[q].n_parts;
+  }
+  printf("bshare: %u queries, %zu leads, %zu tasks, %llu list entries ok\n", nq, A.aleads.size(), A.atasks.size(), (unsigned long long)at);
+  return 0;
+}
+
 // The doc-major union plan (build_dense_plan): rows = the distinct (list, weight) pairs, lists with a
 // bitmap first; every query's row bytes lead back to its lists at its weights, padded with the
 // all-zero row; tasks cover every tile once; result lists are disjoint.
@@ -477,6 +682,7 @@ int main(int argc, char **argv) {
   if (argc > 2 && !strcmp(argv[2], "pool")) return check_pool(seed);
   if (argc > 2 && !strcmp(argv[2], "dense")) return check_dense(seed);
   if (argc > 2 && !strcmp(argv[2], "ashare")) return check_ashare(seed);
+  if (argc > 2 && !strcmp(argv[2], "bshare")) return check_bshare(seed);
   std::mt19937 rng(seed);
   auto uni = [&](uint32_t lo, uint32_t hi) { return std::uniform_int_distribution<uint32_t>(lo, hi)(rng); };
   PlanScratch ps;

@@ -20,6 +20,8 @@ dev = T.DeviceIndex([seg], devices=[0])
 dev.set_option("timing", 1)
 if ratio:
     dev.set_option("dense_ratio", ratio)
+if os.environ.get("PROBE_DENSE_BUDGET"):
+    dev.set_option("dense_budget_x", int(os.environ["PROBE_DENSE_BUDGET"]))
 ids = O.zipf_queries(nq, 4, vocab, seed=20260924)
 M, S, N = T.MUST, T.SHOULD, T.MUST_NOT
 shapes = [(3, [M, M, M], [0, 1, 1]), (4, [M, M, M, M], [0, 0, 1, 1]), (3, [M, S, N], None), (3, [M, M, M], [0, 0, 1])]
@@ -40,4 +42,6 @@ st = dev.last_batch_stats()
 print("%s kernel %.3f ms host %.3f ms wall/step %.3f ms counter %.4g tasks %d kernels %s" %
       (" ".join("%s=%s" % (k, v) for k, v in sorted(os.environ.items()) if k.startswith(("TQ_", "PROBE_"))),
        st["kernel_ms"], st["host_plan_ms"], wall * 1e3, st["matches"], st["chunks"], st["kernels"]))
+ss = dev.segment_stats(0)
+print("segment: terms %d dense lists %d columns %d bitmap MB %.0f docmat MB %.0f" % (ss["n_terms"], ss["n_dense_lists"], ss["n_docmat_columns"], ss["bitmap_bytes"] / 1e6, ss["docmat_bytes"] / 1e6))
 dev.close()
