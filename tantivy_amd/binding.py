@@ -48,8 +48,9 @@ class TqBatchStats(C.Structure):
 KERNEL_AND_DENSE, KERNEL_AND, KERNEL_UNION, KERNEL_OR_WINDOWS, KERNEL_PHRASE = 0x1, 0x2, 0x4, 0x8, 0x10
 KERNEL_PHRASE_SWEEP, KERNEL_BOOL, KERNEL_USHARE, KERNEL_XUNION, KERNEL_ASHARE = 0x20, 0x40, 0x80, 0x100, 0x200
 KERNEL_BSHARE = 0x400
+KERNEL_COUNT_BITMAPS = 0x800
 KERNEL_NAMES = {0x1: "and_dense", 0x2: "and", 0x4: "union", 0x8: "or_windows", 0x10: "phrase", 0x20: "phrase_sweep",
-                0x40: "bool", 0x80: "ushare", 0x100: "xunion", 0x200: "ashare", 0x400: "bshare"}
+                0x40: "bool", 0x80: "ushare", 0x100: "xunion", 0x200: "ashare", 0x400: "bshare", 0x800: "count_bitmaps"}
 
 
 def kernel_names(mask):

@@ -193,6 +193,8 @@ void tq_segment_free(tq_segment *s) {
   s->d_share_words.release();
   s->d_ashare_words.release();
   s->d_bshare_words.release();
+  s->d_count_queries.release();
+  s->d_count_out.release();
   s->h_stage.release();
   s->h_out.release();
   if (s->side_stream) (void)hipStreamSynchronize(s->side_stream);
@@ -261,18 +263,7 @@ int tq_count_batch(tq_segment *s, const tq_query *queries, uint32_t n_queries,
     return fail(TQ_ERR_INVALID, "tq_count_batch: null argument");
   TQ_SEGMENT_LOCK(s);
   if (n_queries == 0) return TQ_OK;
-  // every match has to be visited: exhaustive scan, smallest top-k
-  std::vector<tq_query> qs(queries, queries + n_queries);
-  for (tq_query &q : qs) q.k = 1;
-  std::vector<float> sc(n_queries);
-  std::vector<uint32_t> dc(n_queries), ct(n_queries);
-  CallOpts co;
-  int rc = resolve_opts(s, nullptr, co);
-  if (rc != TQ_OK) return rc;
-  co.exhaustive = true;  // per call: the segment's options are not touched
-  rc = search_batch_host(s, qs.data(), n_queries, 1, sc.data(), dc.data(), ct.data(), co);
-  if (rc != TQ_OK) return rc;
-  return tq_last_batch_match_counts(s, out_counts, n_queries);
+  return count_batch(s, queries, n_queries, out_counts);
 }
 
 int tq_last_batch_stats(tq_segment *s, tq_batch_stats *out) {
@@ -388,6 +379,10 @@ int tq_set_option(tq_segment *s, const char *name, int64_t value) {
     s->opt.device_prepare = value != 0;
   else if (!strcmp(name, "xunion_ratio") && value >= 0 && value <= 0x7FFFFFFF)
     s->opt.xunion_ratio = (int)value;
+  else if (!strcmp(name, "count_bitmap_ratio") && value >= 0 && value <= 0x7FFFFFFF)
+    s->opt.count_bitmap_ratio = (int)value;
+  else if (!strcmp(name, "ashare_min_batch") && value >= 0 && value <= 0x7FFFFFFF)
+    s->opt.ashare_min_batch = (int)value;
   else if (!strcmp(name, "xunion_min_queries") && value >= 1 && value <= 0x7FFFFFFF)
     s->opt.xunion_min_queries = (int)value;
   else if (!strcmp(name, "submit_window_us") && value >= 0 && value <= 1000000)

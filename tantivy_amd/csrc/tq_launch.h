@@ -167,6 +167,27 @@ hipError_t tqk_launch_share(const TqkShareParams &p, int kpl, hipStream_t st);
 hipError_t tqk_launch_merge_lists(const TqkMergeParams &m, const uint32_t *list_count, int kpl,
                                   hipStream_t st);
 uint32_t tqk_share_capl(int kpl);  // staging entries per lead slot
+// ---- Count collector over bitmaps (tq_count.hip)
+#define TQK_COUNT_MUST 0u
+#define TQK_COUNT_NOT 1u
+#define TQK_COUNT_SHOULD 2u
+#define TQK_COUNT_HAS_MUST 1u     // flags: the doc set is the intersection of the Must clauses (else: the union of the Should lists)
+#define TQK_COUNT_NEED_SHOULD 2u  // flags: ... and at least one Should list (minimum_number_should_match = 1)
+struct TqkCountQuery {            // 144 bytes
+  uint32_t n_terms;               // lists: Must clauses first (a clause = a union of lists), then MustNot, then Should
+  uint32_t kinds;                 // 2 bits per list: TQK_COUNT_*
+  uint32_t clause_end;            // bit m: list m is the last of its Must clause
+  uint32_t flags;
+  const uint2 *dense[TQD_MAX_TERMS];  // the lists' bitmaps: {32 doc bits, postings before the word}
+};
+struct TqkCountParams {
+  const TqkCountQuery *queries;
+  const uint8_t *alive;  // AliveBitSet bits or null
+  uint32_t *out_counts;  // [n_queries], zeroed by the caller
+  uint32_t n_queries, n_words;
+};
+hipError_t tqk_launch_count_bitmaps(const TqkCountParams &p, hipStream_t st);
+uint32_t tqk_count_tile_words();
 hipError_t tqk_launch_ashare(const TqkAShareParams &p, int kpl, hipStream_t st);
 uint32_t tqk_ashare_waves_per_cu();  // resident wavefronts per CU the kernel is built for
 uint32_t tqk_bshare_waves_per_cu();  // ... its boolean instantiation

@@ -93,6 +93,7 @@ int search_batch_impl(tq_segment *s, const tq_query *queries, uint32_t n_queries
   // qualify), and how many queries of the batch every list would lead; each distinct list's bytes once
   // (tq_batch_stats.unique_bytes: what the batch needs from the index when nothing is read twice).
   const bool ashare_on = kUseAShare && !opt_exhaustive && s->d_docmat && s->opt.use_dense && s->share_span_ok;
+  bool ashare_and = ashare_on;  // (intersections: also needs "ashare_min_batch" qualifying queries)
   auto ashare_leader = [&](const tq_query &q, uint32_t cache_idx) -> uint32_t {
     if (q.mode != TQ_MODE_AND || q.n_terms < 2 || q.n_terms > TQD_AS_MAX_TERMS || q.k == 0 || q.k > 128u ||
         !q.terms || !q.weights || cache_idx >= 256u)
@@ -143,6 +144,16 @@ int search_batch_impl(tq_segment *s, const tq_query *queries, uint32_t n_queries
         ps.q_leader[qi] = lh;
         if (lh != 0xFFFFFFFFu) ++ps.and_lead_count[lh];
       }
+    }
+    if (ashare_on) {  // a small batch keeps the per-query kernels ("ashare_min_batch")
+      static const uint32_t kMinBatchEnv = tune_u32("TQ_AS_MIN_BATCH", 0xFFFFFFFFu);
+      const uint32_t min_batch = kMinBatchEnv != 0xFFFFFFFFu ? kMinBatchEnv : (uint32_t)s->opt.ashare_min_batch;
+      uint32_t n_el = 0;
+      for (uint32_t qi = 0; qi < n_queries && n_el < min_batch; ++qi) {
+        const uint32_t lh = ps.q_leader[qi];
+        if (lh != 0xFFFFFFFFu && ps.and_lead_count[lh] >= kAShareMin) ++n_el;
+      }
+      ashare_and = n_el >= min_batch;
     }
   }
   // One query -> its descriptor in its launch group.  Reads the segment and the caller's query only,
@@ -233,7 +244,7 @@ int search_batch_impl(tq_segment *s, const tq_query *queries, uint32_t n_queries
           n_tiles = (lead_blocks + dq.tile_blocks - 1) / dq.tile_blocks;
           bool nonneg = true;
           for (uint32_t i = 0; i < q.n_terms; ++i) nonneg = nonneg && dq.weight[i] >= 0.0f;
-          if (ashare_on && nonneg && all_dense) {
+          if (ashare_and && nonneg && all_dense) {
             const uint32_t lh = ps_plan.q_leader[qi];
             ashare = lh != 0xFFFFFFFFu && lh == dq.term[0] && ps_plan.and_lead_count[lh] >= kAShareMin;
           }
