@@ -13,3 +13,7 @@ else
   run r04_or5 or5
   run r04_phrase3 phrase3
 fi
+if [ "${PART:-1}" = 2 ]; then  # work counters of the headline batch
+  for d in 0 32 64 256 512 4096 8192 16384; do TQ_DEBUG=$d python tools/probe_ashare.py 2>&1 | tail -1; done > gpurun_out/r04_ashare_counters.txt
+  cat gpurun_out/r04_ashare_counters.txt
+fi
