@@ -368,12 +368,33 @@ ashare_kernel(TqkAShareParams p) {
     tb(6u);
   };
 
+  // Task queues (experiment, TQ_AS_QUEUES; default ONE queue): the launch's tasks are in doc-slice order;
+  // queue x = the x-th of n_queues equal shares of them = one contiguous part of the doc-id space, a
+  // workgroup's home queue = the XCD it runs on, a workgroup whose queue is empty moves on to the next.
+  // Meant to keep an XCD's L2 on one part of the index; measured 11-19 % slower than one queue.
+  const uint32_t n_launch = p.n_tasks - p.task_begin;
+  const uint32_t nq = p.n_queues ? p.n_queues : 1u;
+  // (XCC_ID: hardware register 20, bits 0..3 — the XCD this wavefront runs on)
+  const uint32_t xcc = (uint32_t)__builtin_amdgcn_s_getreg((3 << 11) | 20) & 7u;
+  const uint32_t home = xcc % nq;
+  uint32_t q_tried = 0;
   for (;;) {
     tb(2u);
-    uint32_t task = 0;
-    if (lane == 0) task = atomicAdd(p.task_counter, 1u);
-    task = uni(task) + p.task_begin;
-    if (task >= p.n_tasks) break;
+    uint32_t task = 0xFFFFFFFFu;
+    while (q_tried < nq) {
+      uint32_t qx = home + q_tried;
+      if (qx >= nq) qx -= nq;
+      const uint32_t q0 = (uint32_t)((uint64_t)n_launch * qx / nq), q1 = (uint32_t)((uint64_t)n_launch * (qx + 1u) / nq);
+      uint32_t t = 0;
+      if (lane == 0) t = atomicAdd(p.task_counter + qx, 1u);
+      t = uni(t) + q0;
+      if (t < q1) {
+        task = t + p.task_begin;
+        break;
+      }
+      ++q_tried;
+    }
+    if (task == 0xFFFFFFFFu) break;
     const uint4 trec = sload(p.tasks + task);
     const uint32_t j0 = trec.y, nb_task = trec.z & 0xFFFFu, ci = trec.z >> 24, lead0 = trec.w;
     n_leads = (trec.z >> 16) & 0xFFu;

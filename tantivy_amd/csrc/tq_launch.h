@@ -76,7 +76,7 @@ struct TqkAShareParams {
   const TqkSinks *sinks;
   uint32_t *thr_slots;          // hashed score slots per query (as the other pruned kernels use)
   uint32_t *thr_val;            // [n_queries] current lower bound of each query's k-th best score
-  uint32_t *task_counter;       // next task to hand out (zeroed per batch)
+  uint32_t *task_counter;       // [n_queues] next task of each queue to hand out (zeroed per batch)
   const uint8_t *table_base;    // TqdALead::dense_off / tf8_off count 8-byte units from here
   uint64_t *stage;              // [grid][TQD_AS_GROUP][capl] per-wave staging lists
   uint64_t *lists;              // per-query result lists (query q: entries part_start .. + n_parts)
@@ -87,6 +87,7 @@ struct TqkAShareParams {
   uint32_t debug;
   uint32_t boolean;             // the leads are (TQ_MODE_BOOL query, leading list) pairs
   float bound_slack;
+  uint32_t n_queues;            // task queues of this launch (1, or 8 = one per XCD)
 };
 
 // exhaustive pure unions, doc-major (tq_xunion.hip): a persistent grid of 16-wave workgroups; a
