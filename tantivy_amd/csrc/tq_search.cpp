@@ -115,6 +115,9 @@ int search_batch_impl(tq_segment *s, const tq_query *queries, uint32_t n_queries
     return q.terms[best_i];
   };
   uint64_t unique_bytes = 0;
+  uint32_t n_union_queries = 0;
+  for (uint32_t qi = 0; qi < n_queries; ++qi)  // (a one-list intersection runs as a union)
+    n_union_queries += (queries[qi].mode == TQ_MODE_OR || (queries[qi].mode == TQ_MODE_AND && queries[qi].n_terms == 1)) ? 1u : 0u;
   {
     PlanScratch &ps = ps_plan;
     if (ps.term_stamp.size() < 2 * s->terms.size()) ps.term_stamp.resize(2 * s->terms.size(), 0u);
@@ -356,7 +359,9 @@ int search_batch_impl(tq_segment *s, const tq_query *queries, uint32_t n_queries
         if (dq.n_terms) n_tiles = max_last / TQD_OR_WINDOW + 1;
         // the doc-major launch?
         PlanScratch &ps = *s->plan;
-        dense_u = kDenseRatio && opt_exhaustive && s->opt.use_dense && dq.n_terms >= 1 && dq.n_terms <= 8 &&
+        // (a batch with fewer unions than the launch needs never builds plain lists for it: those stay
+        // charged to the segment's table budget for good — ADVICE r03)
+        dense_u = kDenseRatio && n_union_queries >= kDenseMinQueries && opt_exhaustive && s->opt.use_dense && dq.n_terms >= 1 && dq.n_terms <= 8 &&
                   q.k <= 128 && (dense_cache == 0xFFFFFFFFu || dense_cache == cache_idx) &&
                   groups[kDense].queries.size() < TQK_XU_MAX_QUERIES;
         uint64_t sum_df = 0;

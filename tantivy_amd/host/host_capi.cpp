@@ -76,6 +76,30 @@ int tqh_searcher_new(tq_ctx *ctx, tqh_searcher **out) {
 }
 void tqh_searcher_free(tqh_searcher *s) { delete s; }
 
+// The doc matrix's columns go to the densest lists of the segment (every TermInfo is known when a
+// segment is added: from the caller's array or from its TermInfoStore), not to whichever dense lists the
+// first queries happen to touch — the union kernels' time depended on the order of the first queries.
+static void reserve_densest_columns(SegmentReader &seg, std::vector<std::pair<uint32_t, uint64_t>> &by_df) {
+  const size_t keep = std::min<size_t>(by_df.size(), 40);  // (TQD_MAT_SLOTS columns)
+  std::partial_sort(by_df.begin(), by_df.begin() + keep, by_df.end(),
+                    [](const std::pair<uint32_t, uint64_t> &a, const std::pair<uint32_t, uint64_t> &b) {
+                      return a.first != b.first ? a.first > b.first : a.second < b.second;
+                    });
+  std::vector<uint64_t> offs;
+  for (size_t i = 0; i < keep; ++i) offs.push_back(by_df[i].second);
+  if (tq_segment_reserve_columns(seg.raw(), offs.data(), (uint32_t)offs.size()) != TQ_OK)
+    throw TantivyError(TantivyError::SystemError, tq_last_error());
+}
+static void reserve_densest_columns(SegmentReader &seg, const TermInfoStore &st) {
+  std::vector<std::pair<uint32_t, uint64_t>> by_df;
+  by_df.reserve(st.num_terms());
+  for (uint64_t o = 0; o < st.num_terms(); ++o) {
+    const TermInfo ti = st.get(o);
+    by_df.emplace_back(ti.doc_freq, ti.postings_start);
+  }
+  reserve_densest_columns(seg, by_df);
+}
+
 int tqh_searcher_add_segment(tqh_searcher *s, int device, uint32_t max_doc, uint8_t record_option,
                              const uint8_t *idx, size_t idx_len, const uint8_t *pos,
                              size_t pos_len, const uint8_t *fieldnorm, size_t fn_len,
@@ -95,20 +119,10 @@ int tqh_searcher_add_segment(tqh_searcher *s, int device, uint32_t max_doc, uint
       seg->add_term(terms[i].term_id, ti);
     }
     {
-      // the doc matrix's columns go to the densest lists of the segment (every TermInfo is known
-      // here), not to whichever dense lists the first queries happen to touch
       std::vector<std::pair<uint32_t, uint64_t>> by_df;
       by_df.reserve(n_terms);
       for (uint32_t i = 0; i < n_terms; ++i) by_df.emplace_back(terms[i].doc_freq, terms[i].postings_start);
-      const size_t keep = std::min<size_t>(by_df.size(), 64);
-      std::partial_sort(by_df.begin(), by_df.begin() + keep, by_df.end(),
-                        [](const std::pair<uint32_t, uint64_t> &a, const std::pair<uint32_t, uint64_t> &b) {
-                          return a.first != b.first ? a.first > b.first : a.second < b.second;
-                        });
-      std::vector<uint64_t> offs;
-      for (size_t i = 0; i < keep; ++i) offs.push_back(by_df[i].second);
-      if (tq_segment_reserve_columns(seg->raw(), offs.data(), (uint32_t)offs.size()) != TQ_OK)
-        throw TantivyError(TantivyError::SystemError, tq_last_error());
+      reserve_densest_columns(*seg, by_df);
     }
     s->segments.push_back(seg);
     s->searcher.reset(new Searcher(s->segments));
@@ -129,6 +143,7 @@ int tqh_searcher_add_segment_with_store(tqh_searcher *s, int device, uint32_t ma
                                                max_doc, record_option, idx, idx_len, pos, pos_len,
                                                fieldnorm, fn_len);
     seg->set_term_info_store(st);
+    reserve_densest_columns(*seg, *st);
     s->segments.push_back(seg);
     s->searcher.reset(new Searcher(s->segments));
   });
@@ -149,6 +164,7 @@ int tqh_searcher_add_segment_device_with_store(tqh_searcher *s, int device, uint
                                                d_idx, idx_len, d_pos, pos_len, d_fieldnorm, fn_len,
                                                total_num_tokens);
     seg->set_term_info_store(st);
+    reserve_densest_columns(*seg, *st);
     s->segments.push_back(seg);
     s->searcher.reset(new Searcher(s->segments));
   });
