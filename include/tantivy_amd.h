@@ -409,10 +409,10 @@ int tq_segment_get_stats(tq_segment *seg, tq_segment_stats *out);
  *        every list's tf/(tf+norm) built once per 128-doc tile, every query reading its lists' rows —
  *        when the batch has that many of them (up to 255 distinct lists and 8192 queries; lists
  *        without a bitmap are then also kept as plain doc / tf arrays, inside "dense_budget_x"),
- *        "count_bitmap_ratio" (default 32, 0 = never): tq_count_batch evaluates a query whose lists all
- *        have bitmaps as a bitwise expression over the bitmap words (8 bytes per list per 32 docs, no
- *        postings decoded) when the clause a scan would walk holds at least max_doc / ratio postings
- *        per list of the query,
+ *        "count_bitmap_ratio" (default 128, 0 = never): tq_count_batch evaluates a query as a bitwise
+ *        expression over bitmap words (4-8 bytes per list per 32 docs, no postings decoded; a list
+ *        without a bitmap is scattered into a scratch bitmap once per batch) when the clause a scan
+ *        would walk holds at least max_doc / ratio postings per list of the query,
  *        "ashare_min_batch" (default 1024): intersections take the shared leader-major launch
  *        (TQ_KERNEL_ASHARE) when at least this many queries of the batch qualify for it — below, its
  *        two launches and per-task set-up cost more than sharing the leader blocks saves (256 queries:

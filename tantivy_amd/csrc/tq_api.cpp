@@ -195,6 +195,8 @@ void tq_segment_free(tq_segment *s) {
   s->d_bshare_words.release();
   s->d_count_queries.release();
   s->d_count_out.release();
+  s->d_count_bits.release();
+  s->d_count_wgs.release();
   s->h_stage.release();
   s->h_out.release();
   if (s->side_stream) (void)hipStreamSynchronize(s->side_stream);
@@ -336,7 +338,8 @@ int tq_segment_get_stats(tq_segment *s, tq_segment_stats *out) {
   r.posdir_bytes = s->bytes_posdir;
   r.scratch_bytes = s->d_stage.cap + s->d_stage_alt.cap + s->d_out_scores.cap + s->d_out_docs.cap +
                     s->d_out_counts.cap + s->d_misc.cap + s->d_thr.cap + s->d_qmatches.cap + s->d_share_words.cap +
-                    s->d_ashare_words.cap + s->d_bshare_words.cap;
+                    s->d_ashare_words.cap + s->d_bshare_words.cap + s->d_count_queries.cap + s->d_count_out.cap +
+                    s->d_count_bits.cap + s->d_count_wgs.cap;
   {
     std::lock_guard<std::mutex> lk(s->dscratch->m);
     r.device_scratch_bytes = s->dscratch->partials.cap + s->dscratch->share_stage.cap + s->dscratch->ashare_stage.cap +

@@ -3,12 +3,15 @@
 // tq_count.hip (a bitwise expression per 32 docs); the others by an exhaustive scan with the smallest top-k.
 #include "tq_internal.hpp"
 
+#include <unordered_map>
+
 namespace tqi {
 
 // The query as a bitwise expression, or false if it has to be scanned (a phrase, a list without a bitmap,
 // minimum_number_should_match >= 2 over fewer Should clauses than that, malformed input — the scan reports it).
 // `known` = the count is known without looking (an absent Must term, MustNot clauses only, ...): 0 matches.
-static bool count_expression(tq_segment *s, const tq_query &q, TqkCountQuery &cq, bool &known, uint64_t &driver_postings) {
+static bool count_expression(tq_segment *s, const tq_query &q, TqkCountQuery &cq, bool &known, uint64_t &driver_postings,
+                             std::unordered_map<uint32_t, uint32_t> &temp_slot, uint32_t max_temp) {
   known = false;
   driver_postings = 0;
   cq = TqkCountQuery{};
@@ -40,7 +43,11 @@ static bool count_expression(tq_segment *s, const tq_query &q, TqkCountQuery &cq
     const uint32_t h = q.terms[i];
     if (h == TQ_TERM_ABSENT) continue;
     if (h >= s->terms.size()) return false;
-    if (!(s->terms[h].dense_blob && s->opt.use_dense)) return false;
+    if (!(s->terms[h].dense_blob && s->opt.use_dense)) {
+      // a list without a bitmap gets one for the duration of the batch (count_scatter_kernel), while the
+      // batch's scratch has room for another
+      if (!temp_slot.count(h) && temp_slot.size() >= max_temp) return false;
+    }
     cl[c].terms[cl[c].n++] = h;
     cl[c].cost += s->terms[h].doc_freq;
   }
@@ -72,7 +79,14 @@ static bool count_expression(tq_segment *s, const tq_query &q, TqkCountQuery &cq
   uint64_t must_cost = ~0ull, should_cost = 0;
   auto put = [&](const Clause &c, uint32_t kind, bool clause_union) {
     for (uint32_t i = 0; i < c.n; ++i) {
-      cq.dense[n] = (const uint2 *)s->terms[c.terms[i]].dense_blob;
+      const TermHost &th = s->terms[c.terms[i]];
+      if (th.dense_blob && s->opt.use_dense) {
+        cq.dense[n] = (const uint2 *)th.dense_blob;
+      } else {  // (the slot for now; the pointer once the scratch is allocated)
+        const uint32_t slot = temp_slot.emplace(c.terms[i], (uint32_t)temp_slot.size()).first->second;
+        cq.dense[n] = (const uint2 *)(uintptr_t)slot;
+        cq.narrow |= 1u << n;
+      }
       cq.kinds |= kind << (2u * n);
       if (kind == TQK_COUNT_MUST && (!clause_union || i + 1 == c.n)) cq.clause_end |= 1u << n;
       ++n;
@@ -107,18 +121,25 @@ int count_batch(tq_segment *s, const tq_query *queries, uint32_t n_queries, uint
   // least max_doc / ratio postings per list of the expression ("count_bitmap_ratio", 0 = never).
   static const uint32_t kRatioEnv = tune_u32("TQ_COUNT_BITMAP_RATIO", 0xFFFFFFFFu);
   const uint32_t kRatio = kRatioEnv != 0xFFFFFFFFu ? kRatioEnv : (uint32_t)s->opt.count_bitmap_ratio;
+  static const uint64_t kTempBudget = (uint64_t)std::max<uint32_t>(1u, tune_u32("TQ_COUNT_TEMP_MB", 1024)) << 20;
+  const uint32_t n_words = (uint32_t)(((uint64_t)s->max_doc + 31u) / 32u);
+  const uint32_t words_per_list = (n_words + 63u) & ~63u;
+  const uint32_t max_temp = (uint32_t)std::min<uint64_t>(4096u, kTempBudget / ((uint64_t)words_per_list * 4u));
   std::vector<TqkCountQuery> cqs;
   std::vector<uint32_t> bitmap_q, scan_q;
+  std::unordered_map<uint32_t, uint32_t> temp_slot, trial;  // lists without a bitmap -> slot of the batch's scratch
   for (uint32_t qi = 0; qi < n_queries; ++qi) {
     TqkCountQuery cq;
     bool known = false;
     uint64_t driver = 0;
-    const bool expr = kRatio && count_expression(s, queries[qi], cq, known, driver);
+    trial = temp_slot;  // (a query that ends up scanned leaves no slots behind)
+    const bool expr = kRatio && count_expression(s, queries[qi], cq, known, driver, trial, max_temp);
     if (expr && known) {
       out_counts[qi] = 0;
     } else if (expr && driver * kRatio >= (uint64_t)cq.n_terms * s->max_doc) {
       cqs.push_back(cq);
       bitmap_q.push_back(qi);
+      temp_slot.swap(trial);
     } else {
       scan_q.push_back(qi);
     }
@@ -156,6 +177,25 @@ int count_batch(tq_segment *s, const tq_query *queries, uint32_t n_queries, uint
     int rc = s->d_count_queries.ensure((size_t)n * sizeof(TqkCountQuery));
     if (rc == TQ_OK) rc = s->d_count_out.ensure((size_t)n * sizeof(uint32_t));
     if (rc != TQ_OK) return rc;
+    if (!temp_slot.empty()) {  // the batch's lists without a bitmap, as bits
+      const int src = sync_terms(s, s->stream);
+      if (src != TQ_OK) return src;
+      std::vector<uint4> wgs;
+      for (const auto &kv : temp_slot)
+        for (uint32_t j = 0; j < s->terms[kv.first].n_blocks; j += 4u) wgs.push_back(make_uint4(kv.first, j, kv.second, 0u));
+      rc = s->d_count_bits.ensure((size_t)temp_slot.size() * words_per_list * sizeof(uint32_t));
+      if (rc == TQ_OK) rc = s->d_count_wgs.ensure(wgs.size() * sizeof(uint4));
+      if (rc != TQ_OK) return rc;
+      HIP_TRY(hipMemsetAsync(s->d_count_bits.p, 0, (size_t)temp_slot.size() * words_per_list * sizeof(uint32_t), s->stream));
+      HIP_TRY(hipMemcpyAsync(s->d_count_wgs.p, wgs.data(), wgs.size() * sizeof(uint4), hipMemcpyHostToDevice, s->stream));
+      const hipError_t se = tqk_launch_count_scatter(s->dseg, s->d_terms, (const uint4 *)s->d_count_wgs.p, (uint32_t)wgs.size(),
+                                                     (uint32_t *)s->d_count_bits.p, words_per_list, s->stream);
+      if (se != hipSuccess) return fail(TQ_ERR_HIP, "count scatter launch: %s", hipGetErrorString(se));
+      for (TqkCountQuery &cq : cqs)
+        for (uint32_t m = 0; m < cq.n_terms; ++m)
+          if ((cq.narrow >> m) & 1u)
+            cq.dense[m] = (const uint2 *)((const uint32_t *)s->d_count_bits.p + (size_t)(uintptr_t)cq.dense[m] * words_per_list);
+    }
     HIP_TRY(hipMemcpyAsync(s->d_count_queries.p, cqs.data(), (size_t)n * sizeof(TqkCountQuery), hipMemcpyHostToDevice, s->stream));
     HIP_TRY(hipMemsetAsync(s->d_count_out.p, 0, (size_t)n * sizeof(uint32_t), s->stream));
     TqkCountParams p{};
@@ -163,7 +203,7 @@ int count_batch(tq_segment *s, const tq_query *queries, uint32_t n_queries, uint
     p.alive = s->d_alive;
     p.out_counts = (uint32_t *)s->d_count_out.p;
     p.n_queries = n;
-    p.n_words = (uint32_t)(((uint64_t)s->max_doc + 31u) / 32u);
+    p.n_words = n_words;
     const hipError_t e = tqk_launch_count_bitmaps(p, s->stream);
     if (e != hipSuccess) return fail(TQ_ERR_HIP, "count kernel launch: %s", hipGetErrorString(e));
     std::vector<uint32_t> got(n);

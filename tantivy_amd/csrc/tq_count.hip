@@ -20,7 +20,7 @@ __global__ __launch_bounds__(COUNT_THREADS) void count_bitmap_kernel(TqkCountPar
   const uint32_t q = blockIdx.x % p.n_queries, tile = blockIdx.x / p.n_queries;
   const TqkCountQuery *Q = p.queries + q;
   const uint32_t nt = sload(&Q->n_terms), kinds = sload(&Q->kinds), clause_end = sload(&Q->clause_end),
-                 flags = sload(&Q->flags);
+                 flags = sload(&Q->flags), narrow = sload(&Q->narrow);
   uint32_t cnt = 0;
 #pragma unroll 2
   for (uint32_t i = 0; i < COUNT_WORDS_PER_THREAD; ++i) {
@@ -28,7 +28,7 @@ __global__ __launch_bounds__(COUNT_THREADS) void count_bitmap_kernel(TqkCountPar
     if (w >= p.n_words) break;
     uint32_t must = 0xFFFFFFFFu, nots = 0u, should = 0u, clause = 0u;
     for (uint32_t m = 0; m < nt; ++m) {
-      const uint32_t bits = Q->dense[m][w].x;
+      const uint32_t bits = ((narrow >> m) & 1u) ? reinterpret_cast<const uint32_t *>(Q->dense[m])[w] : Q->dense[m][w].x;
       const uint32_t kind = (kinds >> (2u * m)) & 3u;
       if (kind == TQK_COUNT_MUST) {
         clause |= bits;
@@ -54,7 +54,29 @@ __global__ __launch_bounds__(COUNT_THREADS) void count_bitmap_kernel(TqkCountPar
   if ((threadIdx.x & 63u) == 0u && cnt) atomicAdd(p.out_counts + q, cnt);
 }
 
+// A list without a bitmap, for the duration of one Count batch: one wave per 128-doc block, every doc a bit.
+__global__ __launch_bounds__(256) void count_scatter_kernel(TqdSegment seg, const TqdTerm *terms, const uint4 *wgs,
+                                                            uint32_t *bits, uint32_t words_per_list) {
+  const int lane = (int)__lane_id();
+  const uint32_t wave = uni(threadIdx.x >> 6);
+  const uint4 w = sload(wgs + blockIdx.x);
+  const TermRef t = load_term(terms, w.x);
+  const uint32_t j = w.y + wave;
+  if (j >= t.n_blocks) return;
+  const Dec d = decode_block<true, false>(uni_ptr(seg.idx), t, j, lane);
+  uint32_t *b = bits + (size_t)w.z * words_per_list;
+  if (d.d0 != TQD_TERMINATED) atomicOr(b + (d.d0 >> 5), 1u << (d.d0 & 31u));
+  if (d.d1 != TQD_TERMINATED) atomicOr(b + (d.d1 >> 5), 1u << (d.d1 & 31u));
+}
+
 }  // namespace
+
+hipError_t tqk_launch_count_scatter(const TqdSegment &seg, const TqdTerm *terms, const uint4 *wgs, uint32_t n_wgs,
+                                    uint32_t *bits, uint32_t words_per_list, hipStream_t st) {
+  if (!n_wgs) return hipSuccess;
+  count_scatter_kernel<<<dim3(n_wgs), dim3(256), 0, st>>>(seg, terms, wgs, bits, words_per_list);
+  return hipGetLastError();
+}
 
 uint32_t tqk_count_tile_words() { return COUNT_TILE_WORDS; }
 

@@ -155,7 +155,7 @@ struct Options {
   // max_doc / xunion_ratio postings (0 = never), if the batch has at least xunion_min_queries of them
   int xunion_ratio = 64;
   int xunion_min_queries = 64;
-  int count_bitmap_ratio = 32;  // Count: bitmap words instead of a scan if the driving clause holds >= max_doc / ratio postings per list
+  int count_bitmap_ratio = 128;  // Count: bitmap words instead of a scan if the driving clause holds >= max_doc / ratio postings per list
   int ashare_min_batch = 1024;  // intersections: the shared launch needs this many qualifying queries in the batch
   // tq_submit / tq_search_one: how long the leader of a batch waits for the callers of the previous
   // batch to come back with their next query (0 = launch with whatever is pending)
@@ -243,7 +243,7 @@ struct tq_segment {
   // batch scratch
   DevBuf d_stage, d_out_scores, d_out_docs, d_out_counts, d_misc, d_thr, d_qmatches;
   DevBuf d_share_words;   // shared-union launch: per-query words
-  DevBuf d_count_queries, d_count_out;    // Count collector over bitmaps (tq_count.hip)
+  DevBuf d_count_queries, d_count_out, d_count_bits, d_count_wgs;  // Count collector over bitmaps (tq_count.hip)
   DevBuf d_ashare_words, d_bshare_words;  // shared-intersection launches (run next to the shared-union one)
   DeviceScratch *dscratch = nullptr;  // partial / result lists and staging lists: the device's (tq_ctx)
   // the shared-union launch addresses bitmaps / byte-wide tfs as 32-bit offsets (8-byte units) from

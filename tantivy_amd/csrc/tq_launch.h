@@ -174,11 +174,13 @@ uint32_t tqk_share_capl(int kpl);  // staging entries per lead slot
 #define TQK_COUNT_SHOULD 2u
 #define TQK_COUNT_HAS_MUST 1u     // flags: the doc set is the intersection of the Must clauses (else: the union of the Should lists)
 #define TQK_COUNT_NEED_SHOULD 2u  // flags: ... and at least one Should list (minimum_number_should_match = 1)
-struct TqkCountQuery {            // 144 bytes
+struct TqkCountQuery {            // 152 bytes
   uint32_t n_terms;               // lists: Must clauses first (a clause = a union of lists), then MustNot, then Should
   uint32_t kinds;                 // 2 bits per list: TQK_COUNT_*
   uint32_t clause_end;            // bit m: list m is the last of its Must clause
   uint32_t flags;
+  uint32_t narrow;                // bit m: list m's bitmap is a plain array of 32-bit words (a list without a
+  uint32_t pad_;                  // bitmap of its own, scattered into the batch's scratch: count_scatter_kernel)
   const uint2 *dense[TQD_MAX_TERMS];  // the lists' bitmaps: {32 doc bits, postings before the word}
 };
 struct TqkCountParams {
@@ -188,6 +190,9 @@ struct TqkCountParams {
   uint32_t n_queries, n_words;
 };
 hipError_t tqk_launch_count_bitmaps(const TqkCountParams &p, hipStream_t st);
+// the docs of lists without a bitmap as bits: wgs[i] = {term handle, first block, slot, -}: 4 blocks per workgroup
+hipError_t tqk_launch_count_scatter(const TqdSegment &seg, const TqdTerm *terms, const uint4 *wgs, uint32_t n_wgs,
+                                    uint32_t *bits, uint32_t words_per_list, hipStream_t st);
 uint32_t tqk_count_tile_words();
 hipError_t tqk_launch_ashare(const TqkAShareParams &p, int kpl, hipStream_t st);
 uint32_t tqk_ashare_waves_per_cu();  // resident wavefronts per CU the kernel is built for

@@ -15,7 +15,7 @@ dev = tantivy_amd.DeviceIndex([seg], devices=[0])
 streams = {"or5": [(O.MODE_OR, q.tolist()) for q in O.zipf_queries(1000, 5, 256, seed=20260922)],
            "and2": [(O.MODE_AND, q.tolist()) for q in O.zipf_queries(10000, 2, 256, seed=20260921)]}
 for name, qs in streams.items():
-    for ratio in (32, 0):
+    for ratio in [int(x) for x in os.environ.get("PROBE_RATIOS", "32,0").split(",")]:
         dev.set_option("count_bitmap_ratio", ratio)
         ref = dev.count(qs)
         t0 = time.perf_counter()
