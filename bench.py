@@ -584,7 +584,7 @@ def main():
     cl.make_comm(runner.dev.ctx)
     runner.comm, runner.torch_group = cl.comm, cl.torch_group
     runner.set_option("timing", 1)
-    for name in ("dense_ratio", "dense_budget_x", "docmat", "docsig", "device_prepare", "or_windows"):  # experiments: TQ_OPT_dense_ratio=...
+    for name in ("dense_ratio", "dense_budget_x", "probe_budget_x", "docmat", "docsig", "device_prepare", "or_windows"):  # experiments: TQ_OPT_dense_ratio=...
         if os.environ.get("TQ_OPT_" + name):
             runner.set_option(name, int(os.environ["TQ_OPT_" + name]))
     if os.environ.get("BENCH_PREWARM"):  # experiment: prepare another workload's terms first (term handles,

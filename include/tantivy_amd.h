@@ -409,6 +409,11 @@ int tq_segment_get_stats(tq_segment *seg, tq_segment_stats *out);
  *        every list's tf/(tf+norm) built once per 128-doc tile, every query reading its lists' rows —
  *        when the batch has that many of them (up to 255 distinct lists and 8192 queries; lists
  *        without a bitmap are then also kept as plain doc / tf arrays, inside "dense_budget_x"),
+ *        "probe_budget_x" (default 16, 0 = never): a boolean query rides in the shared leader-major launch
+ *        (TQ_KERNEL_BSHARE) only if every list it probes has a bitmap + byte-wide tfs; for lists below
+ *        "dense_ratio" they are built the first time a boolean query names the list, while such tables
+ *        together stay below this multiple of the segment (the other kernels keep treating these lists as
+ *        sparse),
  *        "count_bitmap_ratio" (default 128, 0 = never): tq_count_batch evaluates a query as a bitwise
  *        expression over bitmap words (4-8 bytes per list per 32 docs, no postings decoded; a list
  *        without a bitmap is scattered into a scratch bitmap once per batch) when the clause a scan

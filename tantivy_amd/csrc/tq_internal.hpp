@@ -94,6 +94,9 @@ struct TermHost {
   void *posdir_blob = nullptr; // position directory of a dense list with positions
   void *tf8_blob = nullptr;    // term freqs of a dense list as bytes (posting index -> min(tf, 255))
   void *pos_blob = nullptr;    // device-side prepare: positions tables (sized after the walk)
+  void *probe_dense_blob = nullptr, *probe_tf8_blob = nullptr;  // a list below "dense_ratio" that boolean queries
+                               // probe in the shared launch: bitmap + rank directory and tf bytes built on first
+                               // use ("probe_budget_x"); the other kernels do not see them
   void *flat_blob = nullptr;   // a list without a bitmap as plain arrays (doc ids | byte-wide tfs), built on
                                // first use by an unpruned union batch (tq_xunion.hip)
   uint32_t doc_freq = 0, n_blocks = 0, n_full = 0, n_tail = 0;
@@ -155,6 +158,7 @@ struct Options {
   // max_doc / xunion_ratio postings (0 = never), if the batch has at least xunion_min_queries of them
   int xunion_ratio = 64;
   int xunion_min_queries = 64;
+  int probe_budget_x = 16;  // bitmaps + tf bytes built on demand for the lists boolean queries probe: at most this multiple of the segment
   int count_bitmap_ratio = 128;  // Count: bitmap words instead of a scan if the driving clause holds >= max_doc / ratio postings per list
   int ashare_min_batch = 1024;  // intersections: the shared launch needs this many qualifying queries in the batch
   // tq_submit / tq_search_one: how long the leader of a batch waits for the callers of the previous
@@ -283,6 +287,8 @@ struct tq_segment {
   unsigned long long *d_match_counter = nullptr;
   Options opt;
   size_t dense_budget() const { return (size_t)opt.dense_budget_x * (idx_len + pos_len + max_doc); }
+  size_t probe_budget() const { return (size_t)opt.probe_budget_x * (idx_len + pos_len + max_doc); }
+  size_t probe_bytes_total = 0;
   bool device_prepare() const { return h_idx.empty() || opt.device_prepare != 0; }
   tq_batch_stats stats{};
   bool stats_pending = false;
@@ -613,6 +619,7 @@ int sync_terms(tq_segment *s, hipStream_t st);
 int build_flat(tq_segment *s, uint32_t handle, hipStream_t st, bool *ok);
 int order_after_last_batch(tq_segment *s, hipStream_t st);
 int wait_segment_idle(tq_segment *s);
+int build_probe_tables(tq_segment *s, uint32_t handle, bool *ok);
 int count_batch(tq_segment *s, const tq_query *queries, uint32_t n_queries, uint32_t *out_counts);
 // ---- the planners
 int build_group_chunks(Group &g, bool or_windows, PlanScratch &ps, bool boolean_group = false);

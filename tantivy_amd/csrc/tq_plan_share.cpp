@@ -325,7 +325,11 @@ int build_ashare_plan(tq_segment *s, Group &g, PlanScratch &ps, bool boolean) {
       sig = (sig ^ (((uint64_t)dq.n_lead << 40) | ((uint64_t)dq.n_opt_lead << 20) | dq.min_should)) * 0xFF51AFD7ED558CCDull;
       const uint32_t n_lead = std::max<uint32_t>(1u, dq.n_lead);
       for (uint32_t m = 0; m < dq.n_terms; ++m)
-        A.alists[q * TQD_AS_MAX_TERMS + m] = make_uint2(off_of(s->terms[dq.term[m]].dense_blob), off_of(s->terms[dq.term[m]].tf8_blob));
+      {  // (the list's own tables, or the ones built for boolean probes: build_probe_tables)
+        const TermHost &th = s->terms[dq.term[m]];
+        const bool own = th.dense_blob && th.tf8_blob;
+        A.alists[q * TQD_AS_MAX_TERMS + m] = make_uint2(off_of(own ? th.dense_blob : th.probe_dense_blob), off_of(own ? th.tf8_blob : th.probe_tf8_blob));
+      }
       for (uint32_t li = 0; li < n_lead; ++li) {
         TqdALead ld{};
         ld.query = (uint32_t)q;

@@ -18,6 +18,27 @@ int search_batch_impl(tq_segment *s, const tq_query *queries, uint32_t n_queries
   int rc = sync_terms(s, st);
   if (rc != TQ_OK) return rc;
   const int opt_exhaustive = co.exhaustive ? 1 : 0;
+  // Boolean queries ride in the shared leader-major launch if every list they probe has a bitmap + tf
+  // bytes: lists below "dense_ratio" get them the first time a boolean query names them ("probe_budget_x")
+  static const bool kUseBShare = tune_u32("TQ_BSHARE", 1) != 0;
+  if (!opt_exhaustive && kUseBShare && s->opt.use_dense && s->opt.dense && s->opt.probe_budget_x > 0) {
+    bool built = false;
+    for (uint32_t qi = 0; qi < n_queries; ++qi) {
+      const tq_query &q = queries[qi];
+      if (q.mode != TQ_MODE_BOOL || !q.terms || q.n_terms > TQD_AS_MAX_TERMS || q.k > 128u) continue;
+      for (uint32_t i = 0; i < q.n_terms; ++i) {
+        const uint32_t h = q.terms[i];
+        if (h >= s->terms.size()) continue;  // (absent, or reported by plan_query)
+        const TermHost &th = s->terms[h];
+        if ((th.dense_blob && th.tf8_blob) || (th.probe_dense_blob && th.probe_tf8_blob)) continue;
+        bool ok = false;
+        const int prc = build_probe_tables(s, h, &ok);
+        if (prc != TQ_OK) return prc;
+        built = built || ok;
+      }
+    }
+    if (built) s->share_span_terms = ~(size_t)0;  // (the tables' address span is taken again below)
+  }
 
   // ---- plan
   const bool or_windows_opt = s->opt.or_windows < 0 ? opt_exhaustive != 0 : s->opt.or_windows != 0;
@@ -47,7 +68,7 @@ int search_batch_impl(tq_segment *s, const tq_query *queries, uint32_t n_queries
   if (s->share_span_terms != s->terms.size()) {  // (terms are prepared rarely)
     uint64_t lo = ~0ull, hi = 0;
     for (const TermHost &th : s->terms)
-      for (const void *ptr : {th.dense_blob, th.tf8_blob})
+      for (const void *ptr : {th.dense_blob, th.tf8_blob, th.probe_dense_blob, th.probe_tf8_blob})
         if (ptr) {
           lo = std::min<uint64_t>(lo, (uint64_t)ptr);
           hi = std::max<uint64_t>(hi, (uint64_t)ptr);
@@ -298,12 +319,11 @@ int search_batch_impl(tq_segment *s, const tq_query *queries, uint32_t n_queries
       bool_done = true;
       // the shared launch (tq_ashare.hip, boolean leads): every list reached through its bitmap and tf bytes
       // (the only list of a lead set of one is only ever decoded)
-      static const bool kUseBShare = tune_u32("TQ_BSHARE", 1) != 0;
       bshare = kUseBShare && ashare_on && (dq.flags & TQD_QF_PRUNE) && dq.thr_index != 0xFFFFFFFFu && dq.n_terms >= 1 &&
                dq.n_terms <= TQD_AS_MAX_TERMS && q.k <= 128u && ps_plan.q_cache[qi] < 256u && dq.n_lead >= 1;
       for (uint32_t i = 0; bshare && i < dq.n_terms; ++i) {
         const TermHost &th = s->terms[dq.term[i]];
-        if (!(th.dense_blob && th.tf8_blob) && !(dq.n_lead == 1 && i == 0)) bshare = false;
+        if (!(th.dense_blob && th.tf8_blob) && !(th.probe_dense_blob && th.probe_tf8_blob) && !(dq.n_lead == 1 && i == 0)) bshare = false;
       }
     }
     if (mode == TQ_MODE_OR && !bool_done) {

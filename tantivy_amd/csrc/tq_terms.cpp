@@ -29,7 +29,7 @@ int ensure_docmat(tq_segment *s);
 int dense_alloc(tq_segment *s, size_t bytes, void **out) {
   const size_t need = (bytes + 255) & ~(size_t)255;
   if (!s->dense_arena && s->dense_arena_cap == 0) {
-    const size_t cap = std::max<size_t>(s->dense_budget(), (size_t)1 << 20) + PAD;
+    const size_t cap = std::max<size_t>(s->dense_budget() + s->probe_budget(), (size_t)1 << 20) + PAD;
     void *base = nullptr;
     if (hipMalloc(&base, cap) == hipSuccess) {
       s->dense_arena = (uint8_t *)base;
@@ -764,6 +764,58 @@ int build_dense_device(tq_segment *s, uint32_t handle) {
   return TQ_OK;
 }
 
+
+// Bitmap + rank directory and byte-wide tfs of a list BELOW "dense_ratio", for the boolean leads of the
+// shared launch only (tq_ashare.hip probes every list but the leader through them): built the first time a
+// boolean query names the list, inside "probe_budget_x"; no doc-matrix column, no position directory, and
+// TermHost::dense_blob stays null — the other kernels and planners keep treating the list as sparse.
+// *ok = the list can be probed (it has its own tables, or these).
+int build_probe_tables(tq_segment *s, uint32_t handle, bool *ok) {
+  TermHost &t = s->terms[handle];
+  *ok = (t.dense_blob && t.tf8_blob) || (t.probe_dense_blob && t.probe_tf8_blob);
+  if (*ok || !s->opt.dense || !s->opt.use_dense || s->max_doc < 4096u || !t.doc_freq) return TQ_OK;
+  const size_t n_words = ((size_t)s->max_doc + 31) / 32 + 1;
+  const size_t tf_bytes = ((size_t)t.doc_freq + 7) & ~(size_t)7;
+  const size_t need = n_words * sizeof(uint2) + tf_bytes;
+  if (s->probe_bytes_total + need > s->probe_budget()) return TQ_OK;
+  HIP_TRY(hipSetDevice(s->device));
+  int rc = sync_terms(s, s->stream);
+  if (rc != TQ_OK) return rc;
+  const size_t bytes = (size_t)t.doc_freq * sizeof(uint32_t);
+  rc = s->d_misc.ensure(2 * bytes + 64);
+  if (rc != TQ_OK) return rc;
+  uint32_t *dd = (uint32_t *)s->d_misc.p, *dt = dd + t.doc_freq;
+  hipError_t e = tqk_launch_decode_list(s->dseg, s->d_terms, handle, t.n_blocks, dd, dt, s->opt.use_dpp != 0, s->stream);
+  if (e != hipSuccess) return fail(TQ_ERR_HIP, "decode launch: %s", hipGetErrorString(e));
+  void *tfb = nullptr, *blob = nullptr;
+  rc = dense_alloc(s, tf_bytes + PAD, &tfb);
+  if (rc != TQ_OK) return rc;
+  rc = dense_alloc(s, n_words * sizeof(uint2), &blob);
+  if (rc != TQ_OK) {
+    dense_release(s, tfb);
+    return rc;
+  }
+  uint32_t *bad = (uint32_t *)s->d_tp_info;
+  e = tqk_launch_tf8_pack(dt, t.doc_freq, (uint8_t *)tfb, s->stream);
+  if (e == hipSuccess) e = hipMemsetAsync(blob, 0, n_words * sizeof(uint2), s->stream);
+  if (e == hipSuccess) e = hipMemsetAsync(bad, 0, 4, s->stream);
+  if (e == hipSuccess) e = tqp_launch_dense(dd, t.doc_freq, s->max_doc, (uint2 *)blob, (uint32_t)n_words, bad, s->stream);
+  uint32_t h_bad = 0;
+  if (e == hipSuccess) e = hipMemcpyAsync(&h_bad, bad, 4, hipMemcpyDeviceToHost, s->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(s->stream);
+  if (e != hipSuccess || h_bad) {
+    dense_release(s, blob);
+    dense_release(s, tfb);
+    return e != hipSuccess ? fail(TQ_ERR_HIP, "probe tables: %s", hipGetErrorString(e))
+                           : fail(TQ_ERR_FORMAT, "posting list not strictly increasing below max_doc");
+  }
+  t.probe_dense_blob = blob;
+  t.probe_tf8_blob = tfb;
+  s->probe_bytes_total += need;
+  s->bytes_bitmaps += need;
+  *ok = true;
+  return TQ_OK;
+}
 
 int sync_terms(tq_segment *s, hipStream_t st) {
   if (!s->d_terms_dirty) return TQ_OK;
