@@ -189,11 +189,17 @@ class ShardRunner:
             self.gathered = (torch.empty((W, S * n, k), dtype=torch.float32, device=cuda),
                              torch.empty((W, S * n, k), dtype=torch.int32, device=cuda),
                              torch.empty((W, S * n), dtype=torch.int32, device=cuda))
-        self.merged = (torch.empty((n, k), dtype=torch.float32, device=cuda),
-                       torch.empty((n, k), dtype=torch.int32, device=cuda),
-                       torch.empty((n, k), dtype=torch.int32, device=cuda),
-                       torch.empty(n, dtype=torch.int32, device=cuda))
-        self.host = [torch.empty(t.shape, dtype=t.dtype).pin_memory() for t in self.merged]
+        # merged rows: scores | segment ordinals | docs | counts as views of ONE buffer, so that a step's
+        # results leave the device in one copy (four copies cost 75 us of a 1.7 ms step in stream order)
+        self._merged_all = torch.empty(n * (3 * k + 1), dtype=torch.int32, device=cuda)
+        self._host_all = torch.empty(n * (3 * k + 1), dtype=torch.int32).pin_memory()
+
+        def views(buf):
+            return (buf[0:n * k].view(torch.float32).view(n, k), buf[n * k:2 * n * k].view(n, k),
+                    buf[2 * n * k:3 * n * k].view(n, k), buf[3 * n * k:3 * n * k + n])
+
+        self.merged = views(self._merged_all)
+        self.host = list(views(self._host_all))
 
     def enqueue(self):
         torch = self.torch
@@ -212,8 +218,7 @@ class ShardRunner:
                                   out=self.merged)
             ev[1].record(self.stream_obj)
             self._ex_events = (self._ex_events + [ev])[-16:]
-            for h, t in zip(self.host, self.merged):
-                h.copy_(t, non_blocking=True)
+            self._host_all.copy_(self._merged_all, non_blocking=True)
 
     def synchronize(self):
         self.stream_obj.synchronize()
