@@ -311,8 +311,12 @@ int build_ashare_plan(tq_segment *s, Group &g, PlanScratch &ps, bool boolean) {
         ld.mask_lo = (uint32_t)mask;
         ld.mask_hi = (uint32_t)(mask >> 32);
         ld.info = dq.n_terms | (column_of(dq.term[1]) ? 0x100u : 0u);
-        ld.dense_off = off_of(s->terms[dq.term[1]].dense_blob);
-        ld.tf8_off = off_of(s->terms[dq.term[1]].tf8_blob);
+        {  // (list 1's own tables, or the ones built for probes: build_probe_tables)
+          const TermHost &t1 = s->terms[dq.term[1]];
+          const bool own = t1.dense_blob && t1.tf8_blob;
+          ld.dense_off = off_of(own ? t1.dense_blob : t1.probe_dense_blob);
+          ld.tf8_off = off_of(own ? t1.tf8_blob : t1.probe_tf8_blob);
+        }
         ld.k = dq.k;
         ld.thr_row = dq.thr_index;
         unsorted[lead0[q]] = ld;

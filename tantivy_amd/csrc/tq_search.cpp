@@ -21,12 +21,40 @@ int search_batch_impl(tq_segment *s, const tq_query *queries, uint32_t n_queries
   // Boolean queries ride in the shared leader-major launch if every list they probe has a bitmap + tf
   // bytes: lists below "dense_ratio" get them the first time a boolean query names them ("probe_budget_x")
   static const bool kUseBShare = tune_u32("TQ_BSHARE", 1) != 0;
-  if (!opt_exhaustive && kUseBShare && s->opt.use_dense && s->opt.dense && s->opt.probe_budget_x > 0) {
+  // 2-term intersections that probe a list without tables of its own: on the per-query kernel they run on
+  // the side stream next to the shared launch, almost for free while they are few (5 % of the headline
+  // batch: pulling them into the shared launch cost 7 % of kernel time — no doc-matrix column, so nothing
+  // filters their docs before the scoring stage — for the same step time); when they are many (22 % at
+  // 4 096 terms) the shared launch with probe tables is 12 % faster.  TQ_AS_PROBE: 0 never, 1 from 10 % of
+  // the batch (default), 2 always.
+  static const uint32_t kProbeAnd = tune_u32("TQ_AS_PROBE", 1);
+  bool and_probe = false;
+  if (kProbeAnd && !opt_exhaustive && s->opt.use_dense && s->opt.dense && s->opt.probe_budget_x > 0 &&
+      n_queries >= (uint32_t)s->opt.ashare_min_batch) {
+    uint32_t n_sparse2 = 0;
+    for (uint32_t qi = 0; qi < n_queries; ++qi) {
+      const tq_query &q = queries[qi];
+      if (q.mode != TQ_MODE_AND || q.n_terms != 2 || !q.terms || q.terms[0] >= s->terms.size() || q.terms[1] >= s->terms.size()) continue;
+      const TermHost &a = s->terms[q.terms[0]], &b = s->terms[q.terms[1]];
+      const TermHost &probed = b.doc_freq < a.doc_freq ? a : b;
+      if (!(probed.dense_blob && probed.tf8_blob)) ++n_sparse2;
+    }
+    and_probe = kProbeAnd >= 2 || (uint64_t)n_sparse2 * 10u >= n_queries;
+  }
+  if (!opt_exhaustive && (kUseBShare || and_probe) && s->opt.use_dense && s->opt.dense && s->opt.probe_budget_x > 0) {
     bool built = false;
     for (uint32_t qi = 0; qi < n_queries; ++qi) {
       const tq_query &q = queries[qi];
-      if (q.mode != TQ_MODE_BOOL || !q.terms || q.n_terms > TQD_AS_MAX_TERMS || q.k > 128u) continue;
+      // (2-term intersections of a batch large enough for the shared launch: the list that is probed — the
+      // more frequent one — the same way; lists 2.. of longer intersections are reached through the term
+      // table, which only knows a list's own tables)
+      const bool and2 = and_probe && q.mode == TQ_MODE_AND && q.n_terms == 2;
+      if (!((q.mode == TQ_MODE_BOOL && kUseBShare) || and2) || !q.terms || q.n_terms > TQD_AS_MAX_TERMS || q.k > 128u) continue;
+      uint32_t skip = 0xFFFFFFFFu;  // (the leader of an intersection is decoded, never probed)
+      if (and2 && q.terms[0] < s->terms.size() && q.terms[1] < s->terms.size())
+        skip = s->terms[q.terms[1]].doc_freq < s->terms[q.terms[0]].doc_freq ? 1u : 0u;
       for (uint32_t i = 0; i < q.n_terms; ++i) {
+        if (i == skip) continue;
         const uint32_t h = q.terms[i];
         if (h >= s->terms.size()) continue;  // (absent, or reported by plan_query)
         const TermHost &th = s->terms[h];
@@ -131,7 +159,7 @@ int search_batch_impl(tq_segment *s, const tq_query *queries, uint32_t n_queries
     for (uint32_t i = 0; i < q.n_terms; ++i) {
       if (i == best_i) continue;
       const TermHost &th = s->terms[q.terms[i]];
-      if (!(th.dense_blob && th.tf8_blob)) return 0xFFFFFFFFu;
+      if (!(th.dense_blob && th.tf8_blob) && !(and_probe && q.n_terms == 2 && th.probe_dense_blob && th.probe_tf8_blob)) return 0xFFFFFFFFu;
     }
     return q.terms[best_i];
   };
@@ -268,7 +296,7 @@ int search_batch_impl(tq_segment *s, const tq_query *queries, uint32_t n_queries
           n_tiles = (lead_blocks + dq.tile_blocks - 1) / dq.tile_blocks;
           bool nonneg = true;
           for (uint32_t i = 0; i < q.n_terms; ++i) nonneg = nonneg && dq.weight[i] >= 0.0f;
-          if (ashare_and && nonneg && all_dense) {
+          if (ashare_and && nonneg && (all_dense || q.n_terms == 2)) {  // (2 lists: list 1 may have probe tables, q_leader knows)
             const uint32_t lh = ps_plan.q_leader[qi];
             ashare = lh != 0xFFFFFFFFu && lh == dq.term[0] && ps_plan.and_lead_count[lh] >= kAShareMin;
           }
