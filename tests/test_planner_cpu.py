@@ -167,7 +167,7 @@ def test_planners_under_thread_sanitizer(tmp_path_factory):
     if r.returncode != 0:
         pytest.skip("ThreadSanitizer runtime not linkable here: " + r.stderr[-300:])
     env = dict(os.environ, TQ_PLAN_THREADS="4", TQ_PLAN_PAR_MIN="1", TQ_CHUNKS="512")
-    for args in (["1"], ["2", "share"], ["3", "ashare"], ["3", "pool"], ["1", "dense"]):
+    for args in (["1"], ["2", "share"], ["3", "ashare"], ["2", "bshare"], ["3", "pool"], ["1", "dense"]):
         r = subprocess.run([exe] + args, env=env, capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, r.stdout + r.stderr
         assert "ThreadSanitizer" not in r.stdout + r.stderr, (args, (r.stdout + r.stderr)[-2000:])
