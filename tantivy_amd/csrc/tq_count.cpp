@@ -52,14 +52,14 @@ static bool count_expression(tq_segment *s, const tq_query &q, TqkCountQuery &cq
     cl[c].cost += s->terms[h].doc_freq;
   }
   // BooleanWeight::complex_scorer (boolean_weight.rs:236-431), as plan_bool_query restates it
-  uint32_t n_must = 0, n_should = 0, n_not = 0;
+  uint32_t n_must = 0, n_should = 0;
   bool empty = false;
   for (uint32_t c = 0; c < n_cl; ++c) {
     if (cl[c].occur == TQ_MUST) {
       if (cl[c].n == 0) empty = true;
       ++n_must;
     } else if (cl[c].n) {
-      if (cl[c].occur == TQ_SHOULD) ++n_should; else ++n_not;
+      if (cl[c].occur == TQ_SHOULD) ++n_should;
     }
   }
   uint32_t msm = q.mode == TQ_MODE_BOOL ? q.min_should_match : 0u;
