@@ -10,8 +10,8 @@ namespace tqi {
 // The query as a bitwise expression, or false if it has to be scanned (a phrase, a list without a bitmap,
 // minimum_number_should_match >= 2 over fewer Should clauses than that, malformed input — the scan reports it).
 // `known` = the count is known without looking (an absent Must term, MustNot clauses only, ...): 0 matches.
-static bool count_expression(tq_segment *s, const tq_query &q, TqkCountQuery &cq, bool &known, uint64_t &driver_postings,
-                             std::unordered_map<uint32_t, uint32_t> &temp_slot, uint32_t max_temp) {
+bool count_expression(tq_segment *s, const tq_query &q, TqkCountQuery &cq, bool &known, uint64_t &driver_postings,
+                      std::unordered_map<uint32_t, uint32_t> &temp_slot, uint32_t max_temp) {
   known = false;
   driver_postings = 0;
   cq = TqkCountQuery{};

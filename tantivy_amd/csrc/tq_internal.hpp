@@ -621,6 +621,9 @@ int order_after_last_batch(tq_segment *s, hipStream_t st);
 int wait_segment_idle(tq_segment *s);
 int build_probe_tables(tq_segment *s, uint32_t handle, bool *ok);
 int count_batch(tq_segment *s, const tq_query *queries, uint32_t n_queries, uint32_t *out_counts);
+// a query as a bitwise expression over bitmap words (tq_count.cpp; checked on the CPU by tools/planbench/plan_check.cpp)
+bool count_expression(tq_segment *s, const tq_query &q, TqkCountQuery &cq, bool &known, uint64_t &driver_postings,
+                      std::unordered_map<uint32_t, uint32_t> &temp_slot, uint32_t max_temp);
 // ---- the planners
 int build_group_chunks(Group &g, bool or_windows, PlanScratch &ps, bool boolean_group = false);
 int build_share_plan(tq_segment *s, Group &g, PlanScratch &ps);

@@ -98,6 +98,17 @@ def test_boolean_share_plan_invariants(plan_check, seed):
         assert "bshare:" in r.stdout and "ok" in r.stdout
 
 
+@pytest.mark.parametrize("seed", range(4))
+def test_count_expressions_match_boolean_semantics(plan_check, seed):
+    """tq_count.cpp::count_expression (a query as a bitwise expression over bitmap words) + the loop body of
+    count_bitmap_kernel restated on the host: 4 000 random AND / OR / boolean queries per seed (nested unions,
+    absent terms, minimum_number_should_match, lists with and without a bitmap of their own) over random doc
+    sets count exactly BooleanWeight's doc set; only m-of-n Should queries are handed to the scan."""
+    r = subprocess.run([plan_check, str(seed), "count"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr + r.stdout
+    assert "count:" in r.stdout and "ok" in r.stdout
+
+
 def test_eight_planners_at_once(tmp_path_factory):
     """eight ranks of a node plan their batches at the same time on the node's few
     granted CPUs.  Eight concurrent processes (one per CPU where there are eight) each plan the headline

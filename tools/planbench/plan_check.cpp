@@ -676,6 +676,138 @@ static int check_pool(int seed) {
   return 0;
 }
 
+// Count over bitmap words (tq_count.cpp::count_expression + the expression count_bitmap_kernel evaluates,
+// restated here word for word): for random AND / OR / boolean queries — nested unions, absent terms,
+// minimum_number_should_match, lists with and without a bitmap of their own — over random doc sets, the
+// expression's doc set equals BooleanWeight's: all Must clauses, no MustNot clause, at least
+// max(msm, 1 if there is no Must clause) Should clauses.  Queries count_expression hands to the scan are
+// only the ones that are no bitwise expression of this shape (m of n Should clauses with 2 <= m < n).
+static int check_count(int seed) {
+  std::mt19937 rng(seed + 1300);
+  auto uni = [&](uint32_t lo, uint32_t hi) { return std::uniform_int_distribution<uint32_t>(lo, hi)(rng); };
+  tq_segment seg;
+  const uint32_t n_terms = 24, n_words = 8;  // 256 docs
+  seg.max_doc = 32 * n_words;
+  std::vector<std::vector<uint2>> wide(n_terms);      // lists with a bitmap of their own
+  std::vector<std::vector<uint32_t>> bits(n_terms);   // every list's doc bits
+  for (uint32_t t = 0; t < n_terms; ++t) {
+    TermHost th;
+    bits[t].resize(n_words);
+    uint32_t df = 0;
+    for (uint32_t w = 0; w < n_words; ++w) {
+      bits[t][w] = (uint32_t)rng() & (uint32_t)rng() & (t % 3 ? 0xFFFFFFFFu : (uint32_t)rng());
+      df += (uint32_t)__builtin_popcount(bits[t][w]);
+    }
+    th.doc_freq = df ? df : 1;
+    if (t % 2 == 0) {
+      wide[t].resize(n_words);
+      for (uint32_t w = 0; w < n_words; ++w) wide[t][w] = make_uint2(bits[t][w], 0u);
+      th.dense_blob = wide[t].data();
+      th.tf8_blob = wide[t].data();
+    }
+    seg.terms.push_back(th);
+    seg.h_dterms.push_back(TqdTerm{});
+  }
+  uint32_t n_expr = 0, n_scan = 0, n_known = 0;
+  for (int trial = 0; trial < 4000; ++trial) {
+    tq_query q{};
+    uint32_t terms[TQ_MAX_TERMS];
+    uint8_t occurs[TQ_MAX_TERMS], clause_of[TQ_MAX_TERMS];
+    float weights[TQ_MAX_TERMS];
+    q.n_terms = uni(1, 7);
+    q.mode = (uint8_t)(uni(0, 3) == 0 ? TQ_MODE_AND : (uni(0, 2) == 0 ? TQ_MODE_OR : TQ_MODE_BOOL));
+    const bool nested = q.mode == TQ_MODE_BOOL && uni(0, 1);
+    uint8_t occ_of_clause[TQ_MAX_TERMS];
+    for (uint32_t c = 0; c < TQ_MAX_TERMS; ++c) occ_of_clause[c] = (uint8_t)uni(0, 2);
+    for (uint32_t i = 0; i < q.n_terms; ++i) {
+      terms[i] = uni(0, 9) == 0 ? TQ_TERM_ABSENT : uni(0, n_terms - 1);
+      clause_of[i] = (uint8_t)(nested ? uni(0, 3) : i);
+      occurs[i] = occ_of_clause[clause_of[i]];  // (one occur per clause)
+      weights[i] = 1.0f;
+    }
+    q.terms = terms;
+    q.weights = weights;
+    q.occurs = q.mode == TQ_MODE_BOOL ? occurs : nullptr;
+    q.clause_of = nested ? clause_of : nullptr;
+    q.min_should_match = q.mode == TQ_MODE_BOOL ? (uni(0, 2) ? 0u : uni(1, 3)) : 0u;
+    q.k = 1;
+    // BooleanWeight's doc set, clause by clause
+    struct Cl { uint32_t id, occur; std::vector<uint32_t> ts; };
+    std::vector<Cl> cls;
+    for (uint32_t i = 0; i < q.n_terms; ++i) {
+      const uint32_t id = q.mode == TQ_MODE_BOOL ? clause_of[i] : i;
+      const uint32_t oc = q.mode == TQ_MODE_AND ? TQ_MUST : (q.mode == TQ_MODE_OR ? TQ_SHOULD : occurs[i]);
+      size_t c = 0;
+      while (c < cls.size() && cls[c].id != id) ++c;
+      if (c == cls.size()) cls.push_back(Cl{id, oc, {}});
+      if (terms[i] != TQ_TERM_ABSENT) cls[c].ts.push_back(terms[i]);
+    }
+    uint32_t n_must = 0, n_should = 0;
+    for (const Cl &c : cls) {
+      if (c.occur == TQ_MUST) ++n_must;
+      else if (c.occur == TQ_SHOULD && !c.ts.empty()) ++n_should;
+    }
+    const uint32_t need_should = std::max<uint32_t>(q.min_should_match, n_must ? 0u : 1u);
+    uint32_t want = 0;
+    for (uint32_t d = 0; d < seg.max_doc; ++d) {
+      bool all_must = true, any_not = false;
+      uint32_t sc = 0;
+      for (const Cl &c : cls) {
+        bool in = false;
+        for (uint32_t t : c.ts) in = in || ((bits[t][d >> 5] >> (d & 31u)) & 1u);
+        if (c.occur == TQ_MUST) all_must = all_must && in;
+        else if (c.occur == TQ_MUST_NOT) any_not = any_not || in;
+        else if (in) ++sc;
+      }
+      if (all_must && !any_not && sc >= need_should) ++want;
+    }
+    TqkCountQuery cq;
+    bool known = false;
+    uint64_t driver = 0;
+    std::unordered_map<uint32_t, uint32_t> slots;
+    const bool expr = count_expression(&seg, q, cq, known, driver, slots, 64);
+    if (!expr) {
+      if (!(q.min_should_match >= 2 && q.min_should_match < n_should))
+        return fail_msg("a query that is a bitwise expression was handed to the scan", trial, (long)q.min_should_match);
+      ++n_scan;
+      continue;
+    }
+    if (known) {
+      if (want != 0) return fail_msg("a query known to be empty has matches", trial, (long)want);
+      ++n_known;
+      continue;
+    }
+    std::vector<uint32_t> slot_term(slots.size());
+    for (const auto &kv : slots) slot_term[kv.second] = kv.first;
+    uint32_t got = 0;
+    for (uint32_t w = 0; w < n_words; ++w) {  // count_bitmap_kernel's loop body
+      uint32_t must = 0xFFFFFFFFu, nots = 0u, should = 0u, clause = 0u;
+      for (uint32_t m = 0; m < cq.n_terms; ++m) {
+        const uint32_t b = ((cq.narrow >> m) & 1u) ? bits[slot_term[(size_t)(uintptr_t)cq.dense[m]]][w] : cq.dense[m][w].x;
+        const uint32_t kind = (cq.kinds >> (2u * m)) & 3u;
+        if (kind == TQK_COUNT_MUST) {
+          clause |= b;
+          if ((cq.clause_end >> m) & 1u) {
+            must &= clause;
+            clause = 0u;
+          }
+        } else if (kind == TQK_COUNT_NOT) {
+          nots |= b;
+        } else {
+          should |= b;
+        }
+      }
+      uint32_t res = ((cq.flags & TQK_COUNT_HAS_MUST) ? must : should) & ~nots;
+      if (cq.flags & TQK_COUNT_NEED_SHOULD) res &= should;
+      got += (uint32_t)__builtin_popcount(res);
+    }
+    if (got != want) return fail_msg("expression count differs from the boolean semantics", (long)got, (long)want);
+    ++n_expr;
+  }
+  printf("count: %u expressions, %u known empty, %u handed to the scan ok\n", n_expr, n_known, n_scan);
+  return 0;
+}
+
 int main(int argc, char **argv) {
   const int seed = argc > 1 ? atoi(argv[1]) : 1;
   if (argc > 2 && !strcmp(argv[2], "share")) return check_share(seed);
@@ -683,6 +815,7 @@ int main(int argc, char **argv) {
   if (argc > 2 && !strcmp(argv[2], "dense")) return check_dense(seed);
   if (argc > 2 && !strcmp(argv[2], "ashare")) return check_ashare(seed);
   if (argc > 2 && !strcmp(argv[2], "bshare")) return check_bshare(seed);
+  if (argc > 2 && !strcmp(argv[2], "count")) return check_count(seed);
   std::mt19937 rng(seed);
   auto uni = [&](uint32_t lo, uint32_t hi) { return std::uniform_int_distribution<uint32_t>(lo, hi)(rng); };
   PlanScratch ps;
