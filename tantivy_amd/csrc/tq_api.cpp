@@ -369,7 +369,7 @@ int tq_set_option(tq_segment *s, const char *name, int64_t value) {
   else if (!strcmp(name, "dense_ratio") && value >= 1)  // affects terms prepared afterwards
     s->opt.dense_ratio = (int)value;
   else if (!strcmp(name, "probe_budget_x") && value >= 0 && value <= 0x7FFFFFFF)
-    s->opt.probe_budget_x = (int)value;
+    s->opt.probe_budget_x = (int)value, s->probe_full = false;
   else if (!strcmp(name, "dense_budget_x") && value >= 0)
     s->opt.dense_budget_x = (int)value;
   else if (!strcmp(name, "bound_slack_ppm") && value >= 0 && value <= 1000000000)

@@ -289,6 +289,7 @@ struct tq_segment {
   size_t dense_budget() const { return (size_t)opt.dense_budget_x * (idx_len + pos_len + max_doc); }
   size_t probe_budget() const { return (size_t)opt.probe_budget_x * (idx_len + pos_len + max_doc); }
   size_t probe_bytes_total = 0;
+  bool probe_full = false;  // the probe-table budget is used up (until "probe_budget_x" changes)
   bool device_prepare() const { return h_idx.empty() || opt.device_prepare != 0; }
   tq_batch_stats stats{};
   bool stats_pending = false;

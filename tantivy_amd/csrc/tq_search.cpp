@@ -41,7 +41,8 @@ int search_batch_impl(tq_segment *s, const tq_query *queries, uint32_t n_queries
     }
     and_probe = kProbeAnd >= 2 || (uint64_t)n_sparse2 * 10u >= n_queries;
   }
-  if (!opt_exhaustive && (kUseBShare || and_probe) && s->opt.use_dense && s->opt.dense && s->opt.probe_budget_x > 0) {
+  if (!opt_exhaustive && (kUseBShare || and_probe) && s->opt.use_dense && s->opt.dense && s->opt.probe_budget_x > 0 &&
+      !s->probe_full) {
     bool built = false;
     for (uint32_t qi = 0; qi < n_queries; ++qi) {
       const tq_query &q = queries[qi];

@@ -777,7 +777,11 @@ int build_probe_tables(tq_segment *s, uint32_t handle, bool *ok) {
   const size_t n_words = ((size_t)s->max_doc + 31) / 32 + 1;
   const size_t tf_bytes = ((size_t)t.doc_freq + 7) & ~(size_t)7;
   const size_t need = n_words * sizeof(uint2) + tf_bytes;
-  if (s->probe_bytes_total + need > s->probe_budget()) return TQ_OK;
+  if (s->probe_bytes_total + need > s->probe_budget()) {
+    // (no list fits any more — a bitmap alone is n_words * 8 bytes: later batches stop asking)
+    if (s->probe_bytes_total + n_words * sizeof(uint2) > s->probe_budget()) s->probe_full = true;
+    return TQ_OK;
+  }
   HIP_TRY(hipSetDevice(s->device));
   int rc = sync_terms(s, s->stream);
   if (rc != TQ_OK) return rc;
