@@ -70,6 +70,11 @@ static int segment_upload_common(tq_ctx *ctx, int device, uint32_t max_doc, cons
     return fail(TQ_ERR_INVALID, "device %d not part of this context", device);
   HIP_TRY(hipSetDevice(device));
   tq_segment *s = new tq_segment();
+  s->submit = tq_new_submit_queue();  // (exists for the segment's whole life: tq_submit takes no creation lock)
+  if (!s->submit) {
+    delete s;
+    return fail(TQ_ERR_INVALID, "tq_segment_upload: out of memory");
+  }
   s->ctx = ctx;
   s->device = device;
   s->dscratch = ctx->scratch_for(device);
@@ -356,8 +361,8 @@ int tq_segment_get_stats(tq_segment *s, tq_segment_stats *out) {
 int tq_set_option(tq_segment *s, const char *name, int64_t value) {
   if (!s || !name) return fail(TQ_ERR_INVALID, "tq_set_option: null argument");
   TQ_SEGMENT_LOCK(s);
-  if (!strcmp(name, "exhaustive"))
-    s->opt.exhaustive = value != 0;
+  if (!strcmp(name, "exhaustive"))  // (the two words tq_submit reads without the segment lock: atomic stores)
+    __atomic_store_n(&s->opt.exhaustive, value != 0 ? 1 : 0, __ATOMIC_RELAXED);
   else if (!strcmp(name, "timing"))
     s->opt.timing = value != 0;
   else if (!strcmp(name, "use_dpp"))
@@ -373,7 +378,7 @@ int tq_set_option(tq_segment *s, const char *name, int64_t value) {
   else if (!strcmp(name, "dense_budget_x") && value >= 0)
     s->opt.dense_budget_x = (int)value;
   else if (!strcmp(name, "bound_slack_ppm") && value >= 0 && value <= 1000000000)
-    s->opt.bound_slack_ppm = (int)value;
+    __atomic_store_n(&s->opt.bound_slack_ppm, (int)value, __ATOMIC_RELAXED);
   else if (!strcmp(name, "dense"))  // affects terms prepared afterwards
     s->opt.dense = value != 0;
   else if (!strcmp(name, "docmat"))  // affects terms prepared afterwards

@@ -54,12 +54,17 @@ constexpr size_t PAD = 1088;  // over-read slack after every device byte buffer 
 struct DevBuf {
   void *p = nullptr;
   size_t cap = 0;
+  // (the old buffer goes first — a grown buffer next to its predecessor would double the peak — and the
+  // capacity with it: a failed allocation leaves {null, 0}, never a stale capacity over a null pointer)
   int ensure(size_t n) {
     if (n <= cap) return TQ_OK;
+    const size_t ncap = std::max(n, cap * 2);
     if (p) (void)hipFree(p);
     p = nullptr;
-    size_t ncap = std::max(n, cap * 2);
-    HIP_TRY(hipMalloc(&p, ncap));
+    cap = 0;
+    void *np = nullptr;
+    HIP_TRY(hipMalloc(&np, ncap));
+    p = np;
     cap = ncap;
     return TQ_OK;
   }
@@ -74,10 +79,13 @@ struct PinnedBuf {
   size_t cap = 0;
   int ensure(size_t n) {
     if (n <= cap) return TQ_OK;
+    const size_t ncap = std::max(n, cap * 2);
     if (p) (void)hipHostFree(p);
     p = nullptr;
-    size_t ncap = std::max(n, cap * 2);
-    HIP_TRY(hipHostMalloc(&p, ncap, hipHostMallocDefault));
+    cap = 0;
+    void *np = nullptr;
+    HIP_TRY(hipHostMalloc(&np, ncap, hipHostMallocDefault));
+    p = np;
     cap = ncap;
     return TQ_OK;
   }
@@ -306,6 +314,7 @@ struct tq_segment {
 
 void tq_free_plan_scratch(PlanScratch *p);  // (defined next to the planner)
 void tq_free_submit_queue(struct SubmitQueue *q);
+struct SubmitQueue *tq_new_submit_queue();
 #define TQ_SEGMENT_LOCK(seg) std::lock_guard<std::recursive_mutex> tq_exec_lock_((seg)->exec_m)
 
 namespace tqi {
@@ -462,6 +471,7 @@ struct PlanScratch {
     };
     std::vector<ARun> aruns;
     uint32_t a_warm_tasks = 0;  // tasks [0, a_warm_tasks) are the warm-up launch
+    bool over_budget = false;   // the last plan failed because its result lists exceed TQ_AS_LIST_MB at the longest tasks
   };
   ASharePlan ap[2];
   std::vector<uint32_t> q_leader;        // per query of the batch: the list that would lead it there, or 0xFFFFFFFF
@@ -614,6 +624,7 @@ inline uint64_t xrow_key(uint32_t term, float w) {
 struct CallOpts {
   bool exhaustive;
   float bound_slack;
+  bool no_ashare = false, no_bshare = false;  // (internal) this call keeps intersections / boolean queries off the shared launch
 };
 // ---- tq_terms.cpp
 int sync_terms(tq_segment *s, hipStream_t st);

@@ -253,6 +253,7 @@ int build_ashare_plan(tq_segment *s, Group &g, PlanScratch &ps, bool boolean) {
     pt_last = now;
   };
   const size_t nq = g.queries.size();
+  A.over_budget = false;
   g.kpl = g.max_k <= 64 ? 1 : 2;
   auto column_of = [&](uint32_t handle) -> uint32_t {  // doc-matrix bit of the list, or 0
     const uint32_t slot1 = (s->h_dterms[handle].has_freq >> 8) & 0xFFu;
@@ -491,12 +492,20 @@ int build_ashare_plan(tq_segment *s, Group &g, PlanScratch &ps, bool boolean) {
   // (boolean leads: 128 pairs per task measured 8 % faster than 512, 64 pairs 10 % slower — their scoring stage is long, shorter
   // tasks balance the tail; intersections: 512, §3.1a)
   static const uint32_t kBoolTaskPairs = std::max<uint32_t>(32u, tune_u32("TQ_BS_TASK_PAIRS", 128));
-  uint32_t task_pairs = boolean ? kBoolTaskPairs : kTaskPairsEnv;
+  const uint32_t task_pairs = boolean ? kBoolTaskPairs : kTaskPairsEnv;
+  // `stretch` multiplies a run's blocks per task AFTER the cap of kTaskBlocksMax (as build_share_plan does):
+  // doubling the pairs per task stopped shrinking the lists once every run sat at the cap, and a large-k batch
+  // over long leaders went on to allocate gigabytes of result lists.  The kernel walks a task in
+  // tiles of TQD_AS_TILE blocks, so long tasks are safe.
+  // (a lead's docs scored per task are counted in 16 bits next to its list length: 511 blocks x 128 docs fit)
+  const uint32_t kStretchedBlocksMax = std::max<uint32_t>(kTaskBlocksMax, 511u);
+  uint32_t stretch = 1;
   size_t n_tasks = 0;
   for (;;) {
     runs.clear();
     n_tasks = 0;
     uint64_t entries = 0;
+    bool can_stretch = false;  // some run still has more than one main task
     for (size_t r0 = 0; r0 < nl;) {
       size_t r1 = r0;
       uint64_t k_sum = 0;
@@ -511,20 +520,23 @@ int build_ashare_plan(tq_segment *s, Group &g, PlanScratch &ps, bool boolean) {
       const uint32_t n_groups = (n_run + kGroupMax - 1) / kGroupMax;
       R.per_group = (n_run + n_groups - 1) / n_groups;
       R.n_groups = (n_run + R.per_group - 1) / R.per_group;  // (the non-empty ones)
-      R.bpt = std::min<uint32_t>(kTaskBlocksMax, std::max<uint32_t>(1u, task_pairs / R.per_group));
+      R.bpt = (uint32_t)std::min<uint64_t>(kStretchedBlocksMax, (uint64_t)std::min<uint32_t>(kTaskBlocksMax, std::max<uint32_t>(1u, task_pairs / R.per_group)) * stretch);
       R.nb_warm = (uint32_t)((uint64_t)R.n_blocks * kWarmPermille / 1000u);
       R.n_runs = (R.nb_warm + kWarmBlocks - 1) / kWarmBlocks + (R.n_blocks - R.nb_warm + R.bpt - 1) / R.bpt;
+      can_stretch = can_stretch || (R.bpt < kStretchedBlocksMax && R.bpt < R.n_blocks);
       R.task0 = n_tasks;
       n_tasks += (size_t)R.n_runs * R.n_groups;
       entries += (uint64_t)R.n_runs * k_sum;
       runs.push_back(R);
       r0 = r1;
     }
-    if ((entries * sizeof(uint64_t) <= kListBudget && entries <= 0xFFFFFFFFull) || task_pairs >= (1u << 22)) {
-      if (entries > 0xFFFFFFFFull) return fail(TQ_ERR_UNSUPPORTED, "batch too large (result lists)");
-      break;
+    if (entries * sizeof(uint64_t) <= kListBudget && entries <= 0xFFFFFFFFull) break;
+    if (!can_stretch) {  // the longest tasks the kernel takes, and the lists still do not fit: the caller plans
+      A.over_budget = true;  // the batch again without the shared launch (search_batch_impl)
+      return fail(TQ_ERR_UNSUPPORTED, "batch too large (result lists of the shared launch: %llu entries over the %llu MB budget)",
+                  (unsigned long long)entries, (unsigned long long)(kListBudget >> 20));
     }
-    task_pairs *= 2u;
+    stretch *= 2u;
   }
   if (n_tasks > 0x7FFFFFFFull) return fail(TQ_ERR_UNSUPPORTED, "batch too large (tasks)");
   raw.resize(n_tasks);

@@ -143,7 +143,7 @@ int search_batch_impl(tq_segment *s, const tq_query *queries, uint32_t n_queries
   // qualify), and how many queries of the batch every list would lead; each distinct list's bytes once
   // (tq_batch_stats.unique_bytes: what the batch needs from the index when nothing is read twice).
   const bool ashare_on = kUseAShare && !opt_exhaustive && s->d_docmat && s->opt.use_dense && s->share_span_ok;
-  bool ashare_and = ashare_on;  // (intersections: also needs "ashare_min_batch" qualifying queries)
+  bool ashare_and = ashare_on && !co.no_ashare;  // (intersections: also needs "ashare_min_batch" qualifying queries)
   auto ashare_leader = [&](const tq_query &q, uint32_t cache_idx) -> uint32_t {
     if (q.mode != TQ_MODE_AND || q.n_terms < 2 || q.n_terms > TQD_AS_MAX_TERMS || q.k == 0 || q.k > 128u ||
         !q.terms || !q.weights || cache_idx >= 256u)
@@ -348,7 +348,7 @@ int search_batch_impl(tq_segment *s, const tq_query *queries, uint32_t n_queries
       bool_done = true;
       // the shared launch (tq_ashare.hip, boolean leads): every list reached through its bitmap and tf bytes
       // (the only list of a lead set of one is only ever decoded)
-      bshare = kUseBShare && ashare_on && (dq.flags & TQD_QF_PRUNE) && dq.thr_index != 0xFFFFFFFFu && dq.n_terms >= 1 &&
+      bshare = kUseBShare && !co.no_bshare && ashare_on && (dq.flags & TQD_QF_PRUNE) && dq.thr_index != 0xFFFFFFFFu && dq.n_terms >= 1 &&
                dq.n_terms <= TQD_AS_MAX_TERMS && q.k <= 128u && ps_plan.q_cache[qi] < 256u && dq.n_lead >= 1;
       for (uint32_t i = 0; bshare && i < dq.n_terms; ++i) {
         const TermHost &th = s->terms[dq.term[i]];
@@ -564,6 +564,14 @@ int search_batch_impl(tq_segment *s, const tq_query *queries, uint32_t n_queries
                     : &g == &groups[kDense]  ? build_dense_plan(s, g, *s->plan, (uint32_t)std::max(1, cus))
                                              : build_group_chunks(g, or_windows_opt && &g != &groups[kBool], *s->plan,
                                                                   &g == &groups[kBool]);
+    // result lists of a shared-intersection launch over the budget even with the longest tasks: the same batch
+    // through the per-query kernels (nothing has been enqueued yet)
+    if (crc == TQ_ERR_UNSUPPORTED && (&g == &groups[kAShare] || &g == &groups[kBShare]) &&
+        s->plan->ap[&g == &groups[kBShare] ? 1 : 0].over_budget) {
+      CallOpts co2 = co;
+      (&g == &groups[kBShare] ? co2.no_bshare : co2.no_ashare) = true;
+      return search_batch_impl(s, queries, n_queries, out_stride, d_out_scores, d_out_docs, d_out_counts, hip_stream, co2);
+    }
     if (crc != TQ_OK) return crc;
   }
   // partial lists of all groups share one buffer; its stride is per group (kpl*64 keys)
@@ -1041,8 +1049,9 @@ int search_batch_impl(tq_segment *s, const tq_query *queries, uint32_t n_queries
 }
 
 int resolve_opts(const tq_segment *s, const tq_search_opts *o, CallOpts &co) {
-  co.exhaustive = s->opt.exhaustive != 0;
-  uint32_t ppm = (uint32_t)s->opt.bound_slack_ppm;
+  // (atomic loads: tq_submit resolves a call's options without the segment lock)
+  co.exhaustive = __atomic_load_n(&s->opt.exhaustive, __ATOMIC_RELAXED) != 0;
+  uint32_t ppm = (uint32_t)__atomic_load_n(&s->opt.bound_slack_ppm, __ATOMIC_RELAXED);
   if (o) {
     if (o->exhaustive == 0 || o->exhaustive == 1)
       co.exhaustive = o->exhaustive != 0;
@@ -1096,12 +1105,18 @@ int tq_search_batch_device_opts(tq_segment *s, const tq_query *queries, uint32_t
                                 uint32_t *d_out_counts, const tq_search_opts *opts,
                                 void *hip_stream) {
   if (!s) return fail(TQ_ERR_INVALID, "tq_search_batch: null segment");
-  TQ_SEGMENT_LOCK(s);
-  CallOpts co;
-  const int rc = resolve_opts(s, opts, co);
-  if (rc != TQ_OK) return rc;
-  return search_batch_impl(s, queries, n_queries, out_stride, d_out_scores, d_out_docs,
-                           d_out_counts, hip_stream, co);
+  try {  // (the planner allocates: nothing may unwind across the C boundary)
+    TQ_SEGMENT_LOCK(s);
+    CallOpts co;
+    const int rc = resolve_opts(s, opts, co);
+    if (rc != TQ_OK) return rc;
+    return search_batch_impl(s, queries, n_queries, out_stride, d_out_scores, d_out_docs,
+                             d_out_counts, hip_stream, co);
+  } catch (const std::exception &e) {
+    return fail(TQ_ERR_HIP, "tq_search_batch_device: %s", e.what());
+  } catch (...) {
+    return fail(TQ_ERR_HIP, "tq_search_batch_device: unknown exception");
+  }
 }
 
 int tq_search_batch(tq_segment *s, const tq_query *queries, uint32_t n_queries,
@@ -1115,11 +1130,17 @@ int tq_search_batch_opts(tq_segment *s, const tq_query *queries, uint32_t n_quer
                          uint32_t out_stride, float *out_scores, uint32_t *out_docs,
                          uint32_t *out_counts, const tq_search_opts *opts) {
   if (!s) return fail(TQ_ERR_INVALID, "tq_search_batch: null segment");
-  TQ_SEGMENT_LOCK(s);
-  CallOpts co;
-  const int rc = resolve_opts(s, opts, co);
-  if (rc != TQ_OK) return rc;
-  return search_batch_host(s, queries, n_queries, out_stride, out_scores, out_docs, out_counts, co);
+  try {
+    TQ_SEGMENT_LOCK(s);
+    CallOpts co;
+    const int rc = resolve_opts(s, opts, co);
+    if (rc != TQ_OK) return rc;
+    return search_batch_host(s, queries, n_queries, out_stride, out_scores, out_docs, out_counts, co);
+  } catch (const std::exception &e) {
+    return fail(TQ_ERR_HIP, "tq_search_batch: %s", e.what());
+  } catch (...) {
+    return fail(TQ_ERR_HIP, "tq_search_batch: unknown exception");
+  }
 }
 
 }  // extern "C"

@@ -36,25 +36,29 @@ struct SubmitQueue {
   std::vector<uint32_t> dc, ct;
 };
 void tq_free_submit_queue(SubmitQueue *q) { delete q; }
+SubmitQueue *tq_new_submit_queue() { return new (std::nothrow) SubmitQueue(); }
 
 namespace tqi {
 constexpr size_t kSubmitMaxBatch = 16384;
-std::mutex g_submit_create_m;
 
-SubmitQueue *submit_queue(tq_segment *s) {
-  std::lock_guard<std::mutex> lk(g_submit_create_m);
-  if (!s->submit) s->submit = new SubmitQueue();
-  return s->submit;
-}
+// The queue exists from segment upload on (tq_api.cpp: tq_new_submit_queue): no process-wide mutex on the
+// submit path, no lazy creation to race on.
+SubmitQueue *submit_queue(tq_segment *s) { return s->submit; }
 
-// one launch for the tickets of `batch` (same options); rows go to the callers' buffers
-void run_ticket_batch(SubmitQueue &Q, tq_segment *s, std::vector<tq_ticket *> &batch) {
-  const uint32_t n = (uint32_t)batch.size();
+// one launch for tickets [lo, hi) of `batch` (same options); rows go to the callers' buffers.
+// A batch-level failure is split only when it can be one query's fault — an unsupported shape, a bad
+// argument, a corrupt list (TQ_ERR_UNSUPPORTED / INVALID / FORMAT): the batch is bisected, so one bad query
+// among n costs about 2 log2(n) extra launches and every caller gets its own verdict.  A device error
+// (TQ_ERR_HIP, out of memory) fails the whole batch once: re-running thousands of queries one at a time
+// against a device that cannot allocate would stall every caller of the segment for seconds.
+void run_ticket_range(SubmitQueue &Q, tq_segment *s, std::vector<tq_ticket *> &batch, size_t lo, size_t hi) {
+  const uint32_t n = (uint32_t)(hi - lo);
+  if (!n) return;
   uint32_t stride = 1;
   Q.qs.resize(n);
   for (uint32_t i = 0; i < n; ++i) {
-    Q.qs[i] = batch[i]->q;
-    stride = std::max(stride, batch[i]->q.k);
+    Q.qs[i] = batch[lo + i]->q;
+    stride = std::max(stride, batch[lo + i]->q.k);
   }
   Q.sc.resize((size_t)n * stride);
   Q.dc.resize((size_t)n * stride);
@@ -62,11 +66,11 @@ void run_ticket_batch(SubmitQueue &Q, tq_segment *s, std::vector<tq_ticket *> &b
   int rc;
   {
     TQ_SEGMENT_LOCK(s);
-    rc = search_batch_host(s, Q.qs.data(), n, stride, Q.sc.data(), Q.dc.data(), Q.ct.data(), batch[0]->co);
+    rc = search_batch_host(s, Q.qs.data(), n, stride, Q.sc.data(), Q.dc.data(), Q.ct.data(), batch[lo]->co);
   }
   if (rc == TQ_OK) {
     for (uint32_t i = 0; i < n; ++i) {
-      tq_ticket *t = batch[i];
+      tq_ticket *t = batch[lo + i];
       const uint32_t k = t->q.k;
       memcpy(t->out_scores, Q.sc.data() + (size_t)i * stride, k * sizeof(float));
       memcpy(t->out_docs, Q.dc.data() + (size_t)i * stride, k * sizeof(uint32_t));
@@ -75,16 +79,39 @@ void run_ticket_batch(SubmitQueue &Q, tq_segment *s, std::vector<tq_ticket *> &b
     }
     return;
   }
-  if (n == 1) {
-    batch[0]->rc = rc;
-    batch[0]->err = g_last_error;
+  const bool per_query = rc == TQ_ERR_UNSUPPORTED || rc == TQ_ERR_INVALID || rc == TQ_ERR_FORMAT;
+  if (n == 1 || !per_query) {
+    const std::string err = g_last_error;
+    for (size_t i = lo; i < hi; ++i) {
+      batch[i]->rc = rc;
+      batch[i]->err = err;
+    }
     return;
   }
-  // one query the device does not take (an unsupported shape, a bad handle) must not fail its
-  // neighbours: the batch is run again query by query, every caller gets its own verdict
-  for (uint32_t i = 0; i < n; ++i) {
-    std::vector<tq_ticket *> one{batch[i]};
-    run_ticket_batch(Q, s, one);
+  const size_t mid = lo + n / 2;
+  run_ticket_range(Q, s, batch, lo, mid);
+  run_ticket_range(Q, s, batch, mid, hi);
+}
+
+// Never throws: the planner allocates (std::vector, PodVec::reserve) and an exception escaping the leader
+// would leave leader_active set for good — every waiter of the segment deadlocked — and cross the extern "C"
+// boundary.  Whatever was not answered is failed.
+void run_ticket_batch(SubmitQueue &Q, tq_segment *s, std::vector<tq_ticket *> &batch) noexcept {
+  for (tq_ticket *t : batch) t->rc = TQ_ERR_HIP;  // (overwritten by every verdict)
+  try {
+    run_ticket_range(Q, s, batch, 0, batch.size());
+  } catch (const std::exception &e) {
+    for (tq_ticket *t : batch)
+      if (t->rc != TQ_OK) {
+        t->rc = TQ_ERR_HIP;
+        t->err = std::string("tq_wait: ") + e.what();
+      }
+  } catch (...) {
+    for (tq_ticket *t : batch)
+      if (t->rc != TQ_OK) {
+        t->rc = TQ_ERR_HIP;
+        t->err = "tq_wait: unknown exception in the batch";
+      }
   }
 }
 
@@ -103,8 +130,9 @@ int ticket_wait(tq_ticket *t) {
     // up to submit_window_us to arrive (until as many are pending as the last batch carried) — without
     // it the first caller back leads a batch of one and everybody else waits a whole launch longer
     Q.leader_active = true;
-    if (Q.pending.size() < Q.last_batch && s->opt.submit_window_us > 0) {
-      const auto deadline = std::chrono::steady_clock::now() + std::chrono::microseconds(s->opt.submit_window_us);
+    const int window_us = __atomic_load_n(&s->opt.submit_window_us, __ATOMIC_RELAXED);
+    if (Q.pending.size() < Q.last_batch && window_us > 0) {
+      const auto deadline = std::chrono::steady_clock::now() + std::chrono::microseconds(window_us);
       while (Q.pending.size() < Q.last_batch && Q.pending.size() < kSubmitMaxBatch)
         if (Q.cv_arrive.wait_until(lk, deadline) == std::cv_status::timeout) break;
     }
@@ -146,9 +174,11 @@ int tq_submit(tq_segment *s, const tq_query *q, const tq_search_opts *opts, floa
     return fail(TQ_ERR_INVALID, "tq_submit: n_terms %u not in 1..%u", q->n_terms, TQ_MAX_TERMS);
   if (q->k == 0 || q->k > TQ_MAX_K) return fail(TQ_ERR_INVALID, "tq_submit: k %u not in 1..%u", q->k, TQ_MAX_K);
   if (!q->terms || !q->weights || !q->tf_cache) return fail(TQ_ERR_INVALID, "tq_submit: null terms/weights/tf_cache");
+  if (!s->submit) return fail(TQ_ERR_INVALID, "tq_submit: segment without a submit queue");
+  // (no segment lock here: the leader of the running batch holds it for the whole launch, and a submit
+  // must not wait for that — resolve_opts reads the two option words with atomic loads)
   CallOpts co;
   {
-    TQ_SEGMENT_LOCK(s);
     const int rc = resolve_opts(s, opts, co);
     if (rc != TQ_OK) return rc;
   }
@@ -188,6 +218,7 @@ int tq_search_one(tq_segment *s, const tq_query *q, const tq_search_opts *opts, 
 int tq_get_submit_stats(tq_segment *s, tq_submit_stats *out, int reset) {
   if (!s || !out) return fail(TQ_ERR_INVALID, "tq_get_submit_stats: null argument");
   SubmitQueue *Q = submit_queue(s);
+  if (!Q) return fail(TQ_ERR_INVALID, "tq_get_submit_stats: segment without a submit queue");
   std::lock_guard<std::mutex> lk(Q->m);
   *out = Q->stats;
   if (reset) Q->stats = tq_submit_stats{};

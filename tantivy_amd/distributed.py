@@ -168,6 +168,20 @@ class ShardRunner:
         if any(v != value for v in seen):
             raise ValueError("ShardRunner: ranks disagree on %s: %r" % (what, seen))
 
+    def _any_rank(self, flag):
+        """True on every rank iff `flag` is true on at least one (control plane; the local flag where
+        there is none)."""
+        if self.world <= 1:
+            return bool(flag)
+        import torch.distributed as dist
+
+        if not (dist.is_available() and dist.is_initialized()):
+            return bool(flag)
+        dev = self.torch.device("cuda", self.device) if dist.get_backend() == "nccl" else "cpu"
+        t = self.torch.tensor([1 if flag else 0], dtype=self.torch.int32, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return bool(int(t.item()))
+
     def set_option(self, name, value):
         self.dev.set_option(name, value)
 
@@ -175,11 +189,14 @@ class ShardRunner:
         torch = self.torch
         self.dev.prepare(queries)
         n, S, W = len(queries), self.n_local, self.world
-        if (n, k) == (self.n, self.k):
+        changed = (n, k) != (self.n, self.k)
+        # Every rank enters the agreement whenever ANY rank's shape changed (one small all-reduce per
+        # prepare, not per step): a rank that changed alone would otherwise block in the all-gather of
+        # _agree while the others go on to the RCCL gather with other sizes.
+        if self._any_rank(changed):
+            self._agree("(queries per batch, k)", (n, k))
+        if not changed:
             return
-        # (a changed shape: every rank changes it in the same call, so every rank takes part here —
-        # not a blocking host collective on every batch)
-        self._agree("(queries per batch, k)", (n, k))
         self.n, self.k = n, k
         cuda = torch.device("cuda", self.device)
         self.local = (torch.empty((S * n, k), dtype=torch.float32, device=cuda),

@@ -259,7 +259,20 @@ static int check_ashare(int seed) {
     g.max_k = std::max(g.max_k, dq.k);
   }
   seg.share_table_lo = (uint64_t)arena;
-  if (build_ashare_plan(&seg, g, ps) != TQ_OK) return fail_msg("build_ashare_plan failed");
+  const uint64_t list_budget = (uint64_t)std::max<uint32_t>(1u, tune_u32("TQ_AS_LIST_MB", 1024)) << 20;
+  if (build_ashare_plan(&seg, g, ps) != TQ_OK) {
+    // the only failure a well-formed group may see: result lists over the budget with every run at the longest
+    // task the kernel takes (511 blocks: a lead's docs scored per task are counted in 16 bits) — the caller
+    // then plans the batch without the shared launch
+    if (!ps.ap[0].over_budget) return fail_msg("build_ashare_plan failed");
+    uint64_t floor_entries = 0;  // what the lists need at 511-block tasks, no warm-up
+    for (uint32_t q = 0; q < nq; ++q)
+      floor_entries += (uint64_t)((seg.terms[g.queries[q].term[0]].n_blocks + 510u) / 511u + 1u) * g.queries[q].k;  // (+ warm-up tasks, at least)
+    if (floor_entries * 8u <= list_budget) return fail_msg("over_budget reported, but the longest tasks fit");
+    printf("ashare: %u queries over the %llu MB list budget at the longest tasks (%llu entries): refused ok\n", nq,
+           (unsigned long long)(list_budget >> 20), (unsigned long long)floor_entries);
+    return 0;
+  }
   if (ps.ap[0].aleads.size() != nq) return fail_msg("lead count", (long)ps.ap[0].aleads.size(), nq);
   std::vector<uint8_t> seen(nq, 0);
   uint64_t prev_key = 0, prev_mask = 0;
@@ -343,6 +356,7 @@ static int check_ashare(int seed) {
     at += g.queries[q].n_parts;
   }
   if (g.n_chunks != ps.ap[0].atasks.size()) return fail_msg("n_chunks");
+  if (at * 8u > list_budget) return fail_msg("result lists over the budget", (long)at);
   printf("ashare: %u queries, %zu tasks, %llu list entries ok\n", nq, ps.ap[0].atasks.size(), (unsigned long long)at);
   return 0;
 }
@@ -430,7 +444,11 @@ static int check_bshare(int seed) {
     g.out_index.push_back(q);
     g.max_k = std::max(g.max_k, dq.k);
   }
-  if (build_ashare_plan(&seg, g, ps, true) != TQ_OK) return fail_msg("build_ashare_plan (boolean) failed");
+  if (build_ashare_plan(&seg, g, ps, true) != TQ_OK) {
+    if (!ps.ap[1].over_budget) return fail_msg("build_ashare_plan (boolean) failed");
+    printf("bshare: %u queries over the result-list budget at the longest tasks: refused ok\n", nq);  // (the caller plans without the shared launch)
+    return 0;
+  }
   const PlanScratch::ASharePlan &A = ps.ap[1];
   size_t want_leads = 0;
   for (const TqdQuery &q : g.queries) want_leads += q.n_lead;
