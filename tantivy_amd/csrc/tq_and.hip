@@ -180,7 +180,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_num_sgpr(80))) void and_k
     if (alive) alive = doc_is_alive(seg, doc);
     const uint64_t hit = __ballot(alive);
     if (hit) {
-      if (!(p.debug & 224u)) n_matches += (uint32_t)__popcll(hit);  // COUNTERS
+      if (!(p.debug & (224u | 0xF00000u))) n_matches += (uint32_t)__popcll(hit);  // COUNTERS (bits 20..23: the shared launch's byte counters, nothing here)
       n_q += (uint32_t)__popcll(hit);
       const uint64_t key = alive ? make_key(s, doc) : 0ull;
       if (slots) {

@@ -3,6 +3,7 @@
 // points: tq_terms.cpp (tq_term_prepare), tq_search.cpp (tq_search_batch*), tq_submit.cpp (tq_submit /
 // tq_wait / tq_search_one), tq_encode.hip, tq_comm.cpp.
 #include "tq_internal.hpp"
+#include "../host/bm25.hpp"
 
 namespace tqi {
 
@@ -145,6 +146,26 @@ static int segment_upload_common(tq_ctx *ctx, int device, uint32_t max_doc, cons
     }
     s->dseg.min_fieldnorm_id = max_doc ? mn : 0;
   }
+  // Bm25Weight.cache under the segment's own average fieldnorm (bm25.rs:62-69 with avg = total_num_tokens /
+  // max_doc, the 8-byte header of the .idx sub-file): the range maxima of lists with bitmaps are built under it
+  {
+    uint64_t total_tokens = 0;
+    hipError_t e = hipSuccess;
+    if (!from_device)
+      memcpy(&total_tokens, idx, 8);
+    else
+      e = hipMemcpy(&total_tokens, s->d_idx, 8, hipMemcpyDeviceToHost);
+    const float avg = max_doc ? (float)total_tokens / (float)max_doc : 0.0f;
+    if (e == hipSuccess && total_tokens && std::isfinite(avg) && avg > 0.0f) {
+      const tantivy_amd::Bm25Weight w = tantivy_amd::Bm25Weight::from_idf(1.0f, avg);
+      e = hipMalloc((void **)&s->d_local_cache, 256 * sizeof(float));
+      if (e == hipSuccess) e = hipMemcpy(s->d_local_cache, w.cache, 256 * sizeof(float), hipMemcpyHostToDevice);
+    }
+    if (e != hipSuccess) {
+      tq_segment_free(s);
+      return fail(TQ_ERR_HIP, "segment cache: %s", hipGetErrorString(e));
+    }
+  }
   *out = s;
   return TQ_OK;
 }
@@ -183,6 +204,7 @@ void tq_segment_free(tq_segment *s) {
   if (s->d_alive) (void)hipFree(s->d_alive);
   if (s->d_docmat) (void)hipFree(s->d_docmat);
   if (s->d_tp_info) (void)hipFree(s->d_tp_info);
+  if (s->d_local_cache) (void)hipFree(s->d_local_cache);
   if (s->d_match_counter) (void)hipFree(s->d_match_counter);
   s->d_stage.release();
   s->d_out_scores.release();
@@ -395,6 +417,8 @@ int tq_set_option(tq_segment *s, const char *name, int64_t value) {
     s->opt.ashare_min_batch = (int)value;
   else if (!strcmp(name, "xunion_min_queries") && value >= 1 && value <= 0x7FFFFFFF)
     s->opt.xunion_min_queries = (int)value;
+  else if (!strcmp(name, "debug") && value >= -1 && value <= 0x7FFFFFFF)  // (diagnosis: the kernels' TQ_DEBUG word)
+    s->opt.debug = (int)value;
   else if (!strcmp(name, "submit_window_us") && value >= 0 && value <= 1000000)
     s->opt.submit_window_us = (int)value;
   else

@@ -60,6 +60,12 @@
 namespace {
 
 constexpr uint32_t AS_GROUP = TQD_AS_GROUP;
+// TQ_DEBUG / option "debug" bits that turn the launch's match counter into a work counter (one per run): 32
+// (block, family) pairs, 64 stage-C candidates, 256 blocks decoded, 512 stage-C steps, 4096 / 8192 / 16384
+// compactions / flush selects / flushes; bytes the lanes consume (bench.py's useful_bytes): 0x100000 payload +
+// record bytes of the decoded blocks, 0x200000 fieldnorm bytes, 0x400000 doc-matrix words gathered, 0x800000
+// range-maxima bytes.  None of them changes a result.
+constexpr uint32_t AS_COUNTER_BITS = 0x7FE0u | 0xF00000u;
 
 template <bool BOOLQ>
 struct AShareLds {  // per wavefront: 4868 bytes (32 wavefronts per CU fit the 160 KB); boolean leads: + 1 KB
@@ -119,6 +125,7 @@ ashare_kernel(TqkAShareParams p) {
   const uint8_t *idx = seg.idx;
   uint64_t *const my_stage = p.stage + (size_t)blockIdx.x * (size_t)(AS_GROUP * CAPL);
   const uint8_t *const tbase = p.table_base;
+  const uint32_t bmode = BOOLQ ? 0u : p.bound_mode;  // TQ_AS_BOUND bits (tq_search.cpp)
   uint32_t cache_loaded = 0xFFFFFFFFu;
   uint32_t qn = 0;        // survivor queue fill
   uint32_t n_scored = 0;  // docs scored by this wave (all tasks)
@@ -334,7 +341,7 @@ ashare_kernel(TqkAShareParams p) {
       tb(6u);
       return;
     }
-    if (!(p.debug & 0x7FE0u)) n_scored += (uint32_t)__popcll(hit);  // COUNTERS (TQ_DEBUG): 32 (block, family) pairs,
+    if (!(p.debug & AS_COUNTER_BITS)) n_scored += (uint32_t)__popcll(hit);  // COUNTERS (TQ_DEBUG): 32 (block, family) pairs,
     const uint64_t key = alive ? make_key(s, doc) : 0ull;           // 64 stage-C candidates, 256 blocks decoded
     const uint32_t sb = (uint32_t)(key >> 32);
     if (alive) {
@@ -440,6 +447,15 @@ ashare_kernel(TqkAShareParams p) {
 #pragma unroll
         for (uint32_t m = 0; m < TQD_AS_MAX_TERMS; ++m) L.bw[(uint32_t)lane * TQD_AS_MAX_TERMS + m] = (m > li && m < nt) ? Q->weight[m] : 0.0f;
       }
+      if constexpr (!BOOLQ) {
+        // 2-term intersections: list 1's range maxima (TqdALead comment); `rest` = list 1's weight — in the
+        // lead's LDS record — becomes what the list can add anywhere: its largest range maximum
+        my_xlo = (bmode && (mine.info & 31u) == 2u) ? mine.excl_lo : 0u;
+        if (my_xlo) {
+          const float r1 = mine.rest * p.bound_slack * (1.00002f / 255.0f) * (float)(mine.any1_hi & 0xFFu);
+          my_rest = r1 < mine.rest ? r1 : mine.rest;
+        }
+      }
       twin = lane != 0 && (mine.info & 0x200u) != 0u;
       L.lk[lane] = mine.k | (mine.thr_row << 8);
       L.lthr[lane] = __hip_atomic_load(p.thr_val + mine.query, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -511,19 +527,58 @@ ashare_kernel(TqkAShareParams p) {
           tfn_max = f * __builtin_amdgcn_rcpf(f + L.cache[(rec_mine.y >> 16) & 0xFFu]);
         }
       }
-      uint32_t pass_mask = 0;  // families that still want this block (block_wand_intersection.rs:81-85)
-      for (uint32_t lm = live_heads; lm; lm &= lm - 1u) {
-        const uint32_t g = (uint32_t)__builtin_ctz(lm);
-        const float w = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(my_w), (int)g));
-        const float rest = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(my_rest), (int)g));
-        const uint32_t thr = (uint32_t)__builtin_amdgcn_readlane((int)fam_thr, (int)g);
-        const float ub = w * tfn_max * p.bound_slack;
-        if (in_tile && sortable((ub + rest) * 1.000004f + (w + rest) * 4.0e-6f) >= thr) pass_mask |= 1u << g;
-      }
-      uint64_t todo = __ballot(pass_mask != 0u);
       // the block's record stays with its lane: {meta, payload offset, last doc of the block before}
       uint32_t prev_mine = __shfl_up(rec_mine.x, 1, WAVE);
       if (lane == 0) prev_mine = block_prev_last(lead, i_base);
+      // (intersections) the level of list 1's range maxima at which this block's doc span [first, last] touches at
+      // most two entries, and the two entries' indices there (no such level: the span is wider than the coarsest
+      // level's entries, and the list's largest entry — already in the lead's `rest` — stands in)
+      uint32_t rm_at = 0, rm_i0 = 0, rm_i1 = 0;
+      bool rm_ok = false;
+      if constexpr (!BOOLQ) {
+        if ((bmode & 1u) && in_tile) {
+          const uint32_t first = i_mine ? prev_mine + 1u : 0u, last = rec_mine.x;
+          const uint32_t wide = last >= first ? (last - first) >> TQD_RM_SHIFT : 0xFFFFFFFFu;  // span in level-0 entries
+          const uint32_t lvl = wide ? (33u - (uint32_t)__builtin_clz(wide)) >> 1 : 0u;       // 0 | 1..3 | 4..15 | ... -> 0 | 1 | 2 | ...
+          rm_ok = lvl < TQD_RM_LEVELS;
+          const uint32_t sh = TQD_RM_SHIFT + 2u * lvl;
+          rm_at = tqd_rm_level_off(seg.max_doc, rm_ok ? lvl : 0u);
+          rm_i0 = rm_ok ? first >> sh : 0u;
+          rm_i1 = rm_ok ? last >> sh : 0u;
+        }
+      }
+      uint32_t pass_mask = 0;  // families that still want this block (block_wand_intersection.rs:81-85)
+      float need_blk = 3.0e38f;  // the loosest leader tf/(tf+norm) any of them still accepts from this block
+      for (uint32_t lm = live_heads; lm; lm &= lm - 1u) {
+        const uint32_t g = (uint32_t)__builtin_ctz(lm);
+        const float w = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(my_w), (int)g));
+        float rest = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(my_rest), (int)g));
+        const uint32_t thr = (uint32_t)__builtin_amdgcn_readlane((int)fam_thr, (int)g);
+        if constexpr (!BOOLQ) {
+          // list 1 over this block's doc span: the larger of the (at most) two range maxima the span touches
+          // (block_wand_intersection.rs:59-85: leader block-max + the secondaries' block-max)
+          const uint32_t rmo = (uint32_t)__builtin_amdgcn_readlane((int)my_xlo, (int)g);
+          if ((bmode & 1u) && rmo) {
+            const uint8_t *rt = tbase + ((uint64_t)rmo << 3) + rm_at;
+            const uint32_t qa = rm_ok ? (uint32_t)rt[rm_i0] : 255u, qb = rm_ok ? (uint32_t)rt[rm_i1] : 255u;
+            if (p.debug & 0x800000u) n_scored += 2u * (uint32_t)__popcll(__ballot(rm_ok));  // COUNTERS
+            const float w1 = uni_f(L.lead[g].rest);  // (a 2-term query: the weight of list 1)
+            const float r1 = w1 * p.bound_slack * (1.00002f / 255.0f) * (float)(qa > qb ? qa : qb);
+            rest = r1 < rest ? r1 : rest;
+          }
+        }
+        const float ub = w * tfn_max * p.bound_slack;
+        if (in_tile && sortable((ub + rest) * 1.000004f + (w + rest) * 4.0e-6f) >= thr) {
+          pass_mask |= 1u << g;
+          if constexpr (!BOOLQ) {
+            const float thr_f = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(fam_thr_f), (int)g));
+            const float num = thr_f - rest * 1.00001f;
+            const float nd = (thr_f > 0.0f && num > 0.0f) ? num * __builtin_amdgcn_rcpf(w) * 0.99999f : -1.0f;
+            need_blk = nd < need_blk ? nd : need_blk;
+          }
+        }
+      }
+      uint64_t todo = __ballot(pass_mask != 0u);
       uint32_t since_refresh = 0;
       te(3u);
 #if TQ_AS_PREFETCH
@@ -576,6 +631,8 @@ ashare_kernel(TqkAShareParams p) {
         }
 #endif
         if (p.debug & 256u) ++n_scored;  // COUNTERS
+        if (p.debug & 0x100000u)
+          n_scored += 16u + (mo_l.x == META_TAIL ? 8u * lead.n_tail : 16u * ((mo_l.x & 31u) + (lead.has_freq ? (mo_l.x >> 8) & 0xFFu : 0u)));
         // ---- stage A: decode the block once
         uint32_t c0, c1, t0, t1;
 #if TQ_AS_PREFETCH
@@ -620,6 +677,14 @@ ashare_kernel(TqkAShareParams p) {
           const float nd = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(fam_need), (int)__builtin_ctz(x)));
           block_need = nd < block_need ? nd : block_need;
         }
+        if constexpr (!BOOLQ) {
+          // (the pre-filter's cut knows list 1's range maxima over this block, the loop above the thresholds as of
+          // the last refresh: both are lower bounds of what any family of the block accepts)
+          if (bmode & 2u) {
+            const float nb = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(need_blk), (int)b));
+            block_need = nb > block_need ? nb : block_need;
+          }
+        }
         const uint32_t nid0 = v0 ? fieldnorm_id(seg, c0) : 0u, nid1 = v1 ? fieldnorm_id(seg, c1) : 0u;
         const float f0 = (float)t0, f1 = (float)t1;
         const float tfn0 = f0 * __builtin_amdgcn_rcpf(f0 + L.cache[nid0]);
@@ -629,6 +694,8 @@ ashare_kernel(TqkAShareParams p) {
         const uint64_t mw0 = g0 ? seg.docmat[c0] : 0ull;
         const uint64_t mw1 = g1 ? seg.docmat[c1] : 0ull;
         const uint64_t valid0 = __ballot(g0), valid1 = __ballot(g1);
+        if (p.debug & 0x200000u) n_scored += (uint32_t)(__popcll(__ballot(v0)) + __popcll(__ballot(v1)));  // COUNTERS
+        if (p.debug & 0x400000u) n_scored += (uint32_t)(__popcll(valid0) + __popcll(valid1));
         if (TQ_AS_TIMERS && tphase == 5u && (uint32_t)mw0 == 0xFFFFFFFEu) ++n_scored;  // (the gathers have to land inside the region)
         te(5u);
         tb(6u);
@@ -706,8 +773,33 @@ ashare_kernel(TqkAShareParams p) {
             mem1 = __ballot(x1 == 0xFFFFFFFFu) & valid1;
           }
           if (!(mem0 | mem1)) continue;
-          const uint64_t a0m = __ballot(tfn0 >= need) & mem0;
-          const uint64_t a1m = __ballot(tfn1 >= need) & mem1;
+          uint64_t a0m = 0, a1m = 0;
+          bool ranged = false;
+          if constexpr (!BOOLQ) {
+            const uint32_t rmo = (uint32_t)__builtin_amdgcn_readlane((int)my_xlo, (int)g);
+            if ((bmode & 4u) && rmo) {
+              // list 1 can add at most its range maximum at the doc's own range (one byte per 1024 docs out of a
+              // 10 KB table per list: L2-resident), not its weight: "leader + list 1's share >= threshold - others"
+              ranged = true;
+              const uint8_t *rt = tbase + ((uint64_t)rmo << 3);
+              const bool m0 = (mem0 >> lane) & 1ull, m1 = (mem1 >> lane) & 1ull;
+              const uint32_t q0 = m0 ? (uint32_t)rt[c0 >> TQD_RM_SHIFT] : 0u, q1 = m1 ? (uint32_t)rt[c1 >> TQD_RM_SHIFT] : 0u;
+              if (p.debug & 0x800000u) n_scored += (uint32_t)(__popcll(mem0) + __popcll(mem1));  // COUNTERS
+              // tfn0 + min(cq * q, cw) >= threshold / w, every factor widened like `need` above
+              const float w1 = uni_f(L.lead[g].rest);  // (a 2-term query: the weight of list 1)
+              const float rw = __builtin_amdgcn_rcpf(__uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(my_w), (int)g)));
+              const float thr_f = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(fam_thr_f), (int)g));
+              const float base = thr_f > 0.0f ? thr_f * rw * 0.99999f : -1.0f;
+              const float cw = w1 * rw * 1.00002f, cq = cw * p.bound_slack * (1.00001f / 255.0f);
+              const float s0 = cq * (float)q0, s1 = cq * (float)q1;
+              a0m = __ballot(m0 && tfn0 + (s0 < cw ? s0 : cw) >= base);
+              a1m = __ballot(m1 && tfn1 + (s1 < cw ? s1 : cw) >= base);
+            }
+          }
+          if (!ranged) {
+            a0m = __ballot(tfn0 >= need) & mem0;
+            a1m = __ballot(tfn1 >= need) & mem1;
+          }
           if (!(a0m | a1m)) continue;
           if (p.debug & 1024u) continue;  // ABLATION: no queue, no stage C
           // the two docs of a lane are queued one after the other: the queue holds < 64 leftovers

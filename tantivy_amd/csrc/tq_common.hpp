@@ -35,6 +35,10 @@ constexpr int WAVE = 64;
 __device__ __forceinline__ uint32_t uni(uint32_t x) {
   return (uint32_t)__builtin_amdgcn_readfirstlane((int)x);
 }
+// (a float passed to uni() would be CONVERTED to an integer: its own overload, and no implicit ones)
+__device__ __forceinline__ float uni_f(float x) { return __uint_as_float(uni(__float_as_uint(x))); }
+__device__ uint32_t uni(float) = delete;
+__device__ uint32_t uni(double) = delete;
 __device__ __forceinline__ uint64_t uni64(uint64_t x) {
   uint32_t lo = uni((uint32_t)x), hi = uni((uint32_t)(x >> 32));
   return ((uint64_t)hi << 32) | lo;

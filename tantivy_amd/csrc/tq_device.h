@@ -16,6 +16,20 @@
 #define TQD_MAT_SLOTS 40      // dense lists per segment with a column in the doc matrix (bits 8..47 of a word)
 #define TQD_SIG_SHIFT 48      // bits 48..63 of a doc-matrix word: the signature of the lists WITHOUT a column
 #define TQD_SIG_BITS 16
+// Range maxima of a list with a bitmap (tq_terms.cpp build_rmax, tq_ashare.hip): level l holds one byte per
+// (1 << (TQD_RM_SHIFT + 2 l)) docs — the list's largest tf/(tf+norm) in that doc range, rounded up to 1/255 —
+// level l + 1 is the maximum over four entries of level l.  A leader block picks the finest level at which its doc
+// span touches at most two entries; a single doc reads level 0.
+#define TQD_RM_SHIFT 10
+#define TQD_RM_LEVELS 5
+static inline __host__ __device__ uint32_t tqd_rm_level_entries(uint32_t max_doc, uint32_t level) {
+  return (((max_doc >> (TQD_RM_SHIFT + 2u * level)) + 2u) + 3u) & ~3u;
+}
+static inline __host__ __device__ uint32_t tqd_rm_level_off(uint32_t max_doc, uint32_t level) {  // byte offset of a level
+  uint32_t off = 0;
+  for (uint32_t l = 0; l < level; ++l) off += tqd_rm_level_entries(max_doc, l);
+  return off;
+}
 
 // A posting list on the device.  The skip list of src/postings/skip.rs:205-253 is unrolled from
 // its sequential form (running byte / position offsets made absolute) into structure-of-arrays
@@ -143,6 +157,9 @@ struct TqdALead {            // 64 bytes, written by the host planner
                              // doc-matrix bit, mask_hi unused
   uint32_t k;                // the query's k (<= 128)
   uint32_t thr_row;          // its row of threshold slots (identical queries of a batch share one)
+  // intersections: excl_lo = list 1's range-maxima table (TermHost::rmax_blob) as an offset from table_base in
+  // 8-byte units (0 = none: list 1 is bounded by its weight), excl_hi = (float) list 1's weight, any1_lo =
+  // (float) the weights of lists 2.. together, any1_hi = the largest entry of the table (255 = none).
   // boolean leads (TQ_MODE_BOOL through the shared launch): a match has NONE of the excl bits (columns of
   // MustNot lists and of the lead-set lists before the leader: found there = excluded / another lead's doc)
   // and AT LEAST ONE bit of any1 and of any2 (the columns / signature bits of a Must clause each; 0 = no

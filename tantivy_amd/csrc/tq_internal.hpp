@@ -105,6 +105,9 @@ struct TermHost {
   void *probe_dense_blob = nullptr, *probe_tf8_blob = nullptr;  // a list below "dense_ratio" that boolean queries
                                // probe in the shared launch: bitmap + rank directory and tf bytes built on first
                                // use ("probe_budget_x"); the other kernels do not see them
+  void *rmax_blob = nullptr;   // range maxima of a list with a bitmap (its own or the probe tables'): one byte per
+                               // TQD_RM_SHIFT docs, tq_ashare.hip's bound on non-leader lists
+  uint32_t rmax_list = 255;    // ... the largest of them
   void *flat_blob = nullptr;   // a list without a bitmap as plain arrays (doc ids | byte-wide tfs), built on
                                // first use by an unpruned union batch (tq_xunion.hip)
   uint32_t doc_freq = 0, n_blocks = 0, n_full = 0, n_tail = 0;
@@ -172,6 +175,7 @@ struct Options {
   // tq_submit / tq_search_one: how long the leader of a batch waits for the callers of the previous
   // batch to come back with their next query (0 = launch with whatever is pending)
   int submit_window_us = 100;
+  int debug = -1;  // >= 0: overrides TQ_DEBUG for this segment's launches (work counters / ablations: diagnosis only)
 };
 
 
@@ -228,6 +232,8 @@ struct tq_segment {
   size_t idx_len = 0, pos_len = 0;    // sizes of the sub-files in HBM
   TqpInfo *d_tp_info = nullptr;       // device-side prepare: result slots (info + positions result)
   uint8_t *d_idx = nullptr, *d_pos = nullptr, *d_fn = nullptr, *d_alive = nullptr;
+  float *d_local_cache = nullptr;  // Bm25Weight.cache under the segment's OWN average fieldnorm (256 floats; null:
+                                   // the header holds no usable token count): what the range maxima are built under
   uint64_t *d_docmat = nullptr;  // doc-major matrix of the dense lists (TqdSegment::docmat)
   uint32_t n_mat_slots = 0;
   TqdSegment dseg{};
@@ -390,6 +396,7 @@ struct Group {
   std::vector<uint4> chunk_recs;      // launch order: {first tile, end tile, first query, chunk}
   std::vector<uint32_t> tile_cost;  // per query, cost units per tile
   uint32_t total_tiles = 0, n_chunks = 0, max_k = 1;
+  uint64_t list_entries = 0;  // term-major / doc-major groups: 8-byte entries of the group's result lists
   int kpl = 1;
   // offsets inside the staging blob
   size_t o_queries = 0, o_tiles = 0, o_outidx = 0, o_chunks = 0, o_perm = 0, o_sinks = 0;
@@ -402,6 +409,7 @@ struct Group {
     tile_cost.clear();
     total_tiles = 0;
     n_chunks = 0;
+    list_entries = 0;
     max_k = 1;
     kpl = 1;
     o_queries = o_tiles = o_outidx = o_chunks = o_perm = o_sinks = 0;
@@ -462,6 +470,7 @@ struct PlanScratch {
     std::vector<ALeadKey> alead_keys, alead_keys2;
     std::vector<uint32_t> alead_first, alead_bucket, alead_bucket_at, alead_bucket_starts;
     std::vector<uint8_t> alead_same;
+    std::vector<uint32_t> aowner;  // per query of the group: the query whose result list it reads (itself, or the identical query before it)
     std::vector<uint4> atasks, atasks_unsorted;
     std::vector<uint2> alists;  // boolean group: [query][list] = {bitmap, tf bytes} as offsets from the table base
     std::vector<uint32_t> atask_pos, apairs, atask_hist, atask_slab_run;

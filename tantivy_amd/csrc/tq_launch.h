@@ -88,6 +88,7 @@ struct TqkAShareParams {
   uint32_t boolean;             // the leads are (TQ_MODE_BOOL query, leading list) pairs
   float bound_slack;
   uint32_t n_queues;            // task queues of this launch (1, or 8 = one per XCD)
+  uint32_t bound_mode;          // TQ_AS_BOUND bits: where list 1's range maxima replace its weight as the bound
 };
 
 // exhaustive pure unions, doc-major (tq_xunion.hip): a persistent grid of 16-wave workgroups; a

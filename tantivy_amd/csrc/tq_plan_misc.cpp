@@ -67,6 +67,7 @@ int build_dense_plan(tq_segment *s, Group &g, PlanScratch &ps, uint32_t cus) {
     xq.thr_row = dq.thr_index;
     dq.part_start = (uint32_t)(qi * ps.x_list_stride);
     dq.n_parts = ps.x_list_stride;
+    dq.chunk_first = (uint32_t)qi;  // (merge_lists_kernel: the query whose list_count word counts this list)
   }
   return TQ_OK;
 }

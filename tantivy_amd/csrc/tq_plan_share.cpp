@@ -224,9 +224,10 @@ retry_tasks:
     if (entries + cap > 0xFFFFFFFFull) return fail(TQ_ERR_UNSUPPORTED, "batch too large (result lists)");
     dq.part_start = (uint32_t)entries;
     dq.n_parts = (uint32_t)cap;
-    dq.chunk_first = 0;
+    dq.chunk_first = (uint32_t)q;  // (merge_lists_kernel: the query whose list_count word counts this list)
     entries += cap;
   }
+  g.list_entries = entries;
   g.total_tiles = (uint32_t)tasks.size();
   g.n_chunks = (uint32_t)tasks.size();
   return TQ_OK;
@@ -240,7 +241,13 @@ retry_tasks:
 // part of the doc matrix at a time, and every query's threshold rises as its leader is walked.
 int build_ashare_plan(tq_segment *s, Group &g, PlanScratch &ps, bool boolean) {
   PlanScratch::ASharePlan &A = ps.ap[boolean ? 1 : 0];
-  static const uint32_t kTaskPairsEnv = std::max<uint32_t>(32u, tune_u32("TQ_AS_TASK_PAIRS", 512));
+  // (block, lead) pairs per task of the intersections: 0 = sized per batch so that the launch has about
+  // kTargetTasks tasks (three per resident wavefront), between 64 and 512 pairs — with identical queries evaluated
+  // once the headline batch holds 2.4 M pairs: at round 4's fixed 512 that was 5.7 k tasks for 8 192 resident
+  // wavefronts (no balance, no threshold feedback between tasks: 1.23 ms; 128 pairs: 0.94 ms), while the batch
+  // without repeats (6 M pairs) ran best at 256
+  static const uint32_t kTaskPairsEnv = tune_u32("TQ_AS_TASK_PAIRS", 0);
+  static const uint32_t kTargetTasks = std::max<uint32_t>(1u, tune_u32("TQ_AS_TARGET_TASKS", 24576));
   static const uint32_t kTaskBlocksMax = std::min<uint32_t>(0xFFFFu, std::max<uint32_t>(1u, tune_u32("TQ_AS_TASK_BLOCKS", 64)));
   static const uint32_t kGroupMax = std::min<uint32_t>(TQD_AS_GROUP, std::max<uint32_t>(1u, tune_u32("TQ_AS_GROUP", TQD_AS_GROUP)));
   static const uint64_t kListBudget = (uint64_t)std::max<uint32_t>(1u, tune_u32("TQ_AS_LIST_MB", 1024)) << 20;
@@ -252,6 +259,7 @@ int build_ashare_plan(tq_segment *s, Group &g, PlanScratch &ps, bool boolean) {
     fprintf(stderr, "[tq ashare plan] %-12s %7.2f ms\n", what, std::chrono::duration<double, std::milli>(now - pt_last).count());
     pt_last = now;
   };
+  static const bool kUseRanges = tune_u32("TQ_AS_BOUND", 3) != 0;
   const size_t nq = g.queries.size();
   A.over_budget = false;
   g.kpl = g.max_k <= 64 ? 1 : 2;
@@ -317,6 +325,16 @@ int build_ashare_plan(tq_segment *s, Group &g, PlanScratch &ps, bool boolean) {
           const bool own = t1.dense_blob && t1.tf8_blob;
           ld.dense_off = off_of(own ? t1.dense_blob : t1.probe_dense_blob);
           ld.tf8_off = off_of(own ? t1.tf8_blob : t1.probe_tf8_blob);
+        }
+        {  // list 1's range maxima (tq_terms.cpp build_rmax), the split of `rest` the kernel bounds with them
+          const TermHost &t1 = s->terms[dq.term[1]];
+          const float w1 = dq.weight[1];
+          float others = 0.0f;
+          for (uint32_t m = 2; m < dq.n_terms; ++m) others += dq.weight[m];
+          ld.excl_lo = kUseRanges && t1.rmax_blob ? off_of(t1.rmax_blob) : 0u;
+          memcpy(&ld.excl_hi, &w1, sizeof(float));
+          memcpy(&ld.any1_lo, &others, sizeof(float));
+          ld.any1_hi = ld.excl_lo ? t1.rmax_list : 255u;
         }
         ld.k = dq.k;
         ld.thr_row = dq.thr_index;
@@ -475,6 +493,35 @@ int build_ashare_plan(tq_segment *s, Group &g, PlanScratch &ps, bool boolean) {
   });
   for (size_t i = 1; i < nl; ++i)
     if (same_as_prev[i]) leads[i].thr_row = leads[i - 1].thr_row;
+  // Identical queries (lists, weights, k — and roles for boolean queries) are evaluated ONCE per batch: the
+  // first of them (the smallest query index: the sort is stable) keeps its leads, the others read its result
+  // list at merge time (TqdQuery::chunk_first = the owner of the list, merge_lists_kernel).  Round 4 evaluated
+  // a repeated query once per GROUP of 32 leads: the 267 copies of the headline batch's most frequent pair
+  // had its leader decoded nine times.  TQ_AS_DEDUPE=0: one lead per query as before (twins inside a group).
+  static const bool kDedupe = tune_u32("TQ_AS_DEDUPE", 1) != 0;
+  std::vector<uint32_t> &owner = A.aowner;
+  owner.resize(nq);
+  for (size_t q = 0; q < nq; ++q) owner[q] = (uint32_t)q;
+  if (kDedupe) {
+    size_t w = 0;
+    uint32_t head_q = 0;
+    for (size_t i = 0; i < nl; ++i) {
+      if (same_as_prev[i]) {
+        owner[leads[i].query] = head_q;
+        continue;
+      }
+      head_q = leads[i].query;
+      if (w != i) {
+        leads[w] = leads[i];
+        keys[w] = keys[i];
+      }
+      ++w;
+    }
+    nl = w;
+    leads.resize(nl);
+    keys.resize(nl);
+    std::fill(same_as_prev.begin(), same_as_prev.begin() + (long)nl, (uint8_t)0);
+  }
   pt("gather");
   // ---- tasks: groups of leads x runs of blocks; fewer, longer tasks if the result lists (k entries
   // per (task, lead) pair) would not fit the budget.  The first kWarmPermille / 1000 of every leader go
@@ -492,7 +539,18 @@ int build_ashare_plan(tq_segment *s, Group &g, PlanScratch &ps, bool boolean) {
   // (boolean leads: 128 pairs per task measured 8 % faster than 512, 64 pairs 10 % slower — their scoring stage is long, shorter
   // tasks balance the tail; intersections: 512, §3.1a)
   static const uint32_t kBoolTaskPairs = std::max<uint32_t>(32u, tune_u32("TQ_BS_TASK_PAIRS", 128));
-  const uint32_t task_pairs = boolean ? kBoolTaskPairs : kTaskPairsEnv;
+  uint32_t task_pairs = boolean ? kBoolTaskPairs : kTaskPairsEnv;
+  if (!boolean && !task_pairs) {
+    uint64_t total_pairs = 0;
+    for (size_t r0 = 0; r0 < nl;) {
+      size_t r1 = r0;
+      while (r1 < nl && keys[r1].k1 == keys[r0].k1) ++r1;
+      total_pairs += (uint64_t)(r1 - r0) * s->terms[(size_t)(keys[r0].k1 >> 8)].n_blocks;
+      r0 = r1;
+    }
+    task_pairs = (uint32_t)std::min<uint64_t>(512u, std::max<uint64_t>(64u, total_pairs / kTargetTasks));
+  }
+  task_pairs = std::max<uint32_t>(32u, task_pairs);
   // `stretch` multiplies a run's blocks per task AFTER the cap of kTaskBlocksMax (as build_share_plan does):
   // doubling the pairs per task stopped shrinking the lists once every run sat at the cap, and a large-k batch
   // over long leaders went on to allocate gigabytes of result lists.  The kernel walks a task in
@@ -608,13 +666,20 @@ int build_ashare_plan(tq_segment *s, Group &g, PlanScratch &ps, bool boolean) {
   uint64_t entries = 0;
   for (size_t q = 0; q < nq; ++q) {
     TqdQuery &dq = g.queries[q];
+    if (owner[q] != q) {  // reads the list of the identical query before it (owner[q] < q: already placed)
+      dq.part_start = g.queries[owner[q]].part_start;
+      dq.n_parts = g.queries[owner[q]].n_parts;
+      dq.chunk_first = owner[q];
+      continue;
+    }
     const uint64_t cap = (uint64_t)pairs[q] * dq.k;
     if (entries + cap > 0xFFFFFFFFull) return fail(TQ_ERR_UNSUPPORTED, "batch too large (result lists)");
     dq.part_start = (uint32_t)entries;
     dq.n_parts = (uint32_t)cap;
-    dq.chunk_first = 0;
+    dq.chunk_first = (uint32_t)q;  // (merge_lists_kernel: the query whose list_count word counts this list)
     entries += cap;
   }
+  g.list_entries = entries;
   g.total_tiles = (uint32_t)tasks.size();
   g.n_chunks = (uint32_t)tasks.size();
   return TQ_OK;

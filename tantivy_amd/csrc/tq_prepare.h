@@ -57,9 +57,19 @@ hipError_t tqp_launch_coarse(const uint4 *rec, uint32_t n_blocks, uint32_t shift
 hipError_t tqp_launch_positions(const TqpPositionsParams &p, hipStream_t st);
 // bitmap + rank directory of a dense list from its decoded doc ids (tab zeroed by the caller);
 // *bad != 0 afterwards: the list was not strictly increasing below max_doc
+// scan_scratch: tqp_scan_scratch_words(n_words) u32 of device memory (tile sums of the grid-wide scan)
+uint32_t tqp_scan_scratch_words(uint32_t n_items);
 hipError_t tqp_launch_dense(const uint32_t *docs, uint32_t n, uint32_t max_doc, uint2 *tab,
-                            uint32_t n_words, uint32_t *bad, hipStream_t st);
+                            uint32_t n_words, uint32_t *bad, uint32_t *scan_scratch, hipStream_t st);
+// position directory of a dense list: dir[j] = positions before posting 4j (n_dir = (n + 3) / 4 + 1 entries);
+// scan_scratch: tqp_scan_scratch_words(n_dir) u32
 hipError_t tqp_launch_posdir(const uint32_t *tfs, uint32_t n, uint32_t *dir, uint32_t n_dir,
-                             hipStream_t st);
+                             uint32_t *scan_scratch, hipStream_t st);
+// range maxima of a list with a bitmap (tq_device.h TQD_RM_*: tq_ashare.hip's bound on the non-leader lists);
+// acc = (max_doc >> TQD_RM_SHIFT) + 1 ZEROED u32 of scratch, out = tqd_rm_level_off(max_doc, TQD_RM_LEVELS) bytes,
+// *list_max zeroed
+hipError_t tqp_launch_rmax(const uint32_t *docs, const uint32_t *tfs, uint32_t n, const uint8_t *fieldnorm,
+                           uint32_t const_id, const float *cache, uint32_t *acc, uint32_t max_doc, uint8_t *out,
+                           uint32_t *list_max, hipStream_t st);
 hipError_t tqp_launch_min_fieldnorm(const uint8_t *fieldnorm, uint32_t max_doc, uint32_t *out,
                                     hipStream_t st);

@@ -262,59 +262,170 @@ __global__ void td_check_bits_kernel(const uint32_t *docs, uint32_t n, uint32_t 
   }
   atomicOr(&tab[d >> 5].x, 1u << (d & 31u));
 }
-// rank directory: tab[w].y = number of postings before word w.  One workgroup walks the words
-// in chunks with a carry (n_words = max_doc / 32: a few hundred thousand).
-__global__ __launch_bounds__(1024) void td_rank_kernel(uint2 *tab, uint32_t n_words) {
-  __shared__ uint32_t sh[1024];
-  __shared__ uint32_t carry_s;
-  if (threadIdx.x == 0) carry_s = 0;
+// ---- grid-wide exclusive scans (rank directory, position directory).
+// Round 4 ranked a 10M-bit bitmap with ONE 1024-thread workgroup walking the words in chunks, a 20-barrier
+// Hillis-Steele scan per 1024 words: 0.59 ms per list on a 256-CU chip — 113 ms of a first batch that
+// probes 192 new lists, 298 ms at 4 096 terms (VERDICT r04 weak point 5).  Now three small launches over
+// tiles of SCAN_TILE items: per-tile sums, one workgroup scans the sums, every tile scans itself again on
+// top of its offset (a wavefront scan + 4 words of LDS per workgroup: one barrier per tile).
+constexpr uint32_t SCAN_THREADS = 256, SCAN_PER_THREAD = 8, SCAN_TILE = SCAN_THREADS * SCAN_PER_THREAD;
+struct RankItems {  // item i = popcount of bitmap word i
+  const uint2 *tab;
+  __device__ __forceinline__ uint32_t at(uint32_t i, uint32_t n) const { return i < n ? (uint32_t)__popc(tab[i].x) : 0u; }
+};
+struct PosdirItems {  // item j = the tfs of postings 4j .. 4j+3
+  const uint32_t *tfs;
+  uint32_t n_postings;
+  __device__ __forceinline__ uint32_t at(uint32_t j, uint32_t n) const {
+    if (j >= n) return 0u;
+    uint32_t v = 0;
+    const uint64_t i0 = 4ull * j;
+    for (uint32_t e = 0; e < 4u; ++e)
+      if (i0 + e < n_postings) v += tfs[i0 + e];
+    return v;
+  }
+};
+__device__ __forceinline__ uint32_t wave_incl_scan32(uint32_t x, int lane) {
+#pragma unroll
+  for (int d = 1; d < WAVE; d <<= 1) {
+    const uint32_t y = (uint32_t)__shfl_up((int)x, d, WAVE);
+    if (lane >= d) x += y;
+  }
+  return x;
+}
+// exclusive prefix of `mine` over the workgroup's 256 threads + the workgroup's total
+__device__ __forceinline__ uint32_t wg_excl_scan(uint32_t mine, uint32_t &total) {
+  __shared__ uint32_t wsum[SCAN_THREADS / WAVE];
+  const int lane = (int)__lane_id();
+  const uint32_t wv = threadIdx.x >> 6;
+  const uint32_t incl = wave_incl_scan32(mine, lane);
+  if (lane == WAVE - 1) wsum[wv] = incl;
   __syncthreads();
-  for (uint32_t base = 0; base < n_words; base += 1024u) {
+  uint32_t before = 0, all = 0;
+#pragma unroll
+  for (uint32_t w = 0; w < SCAN_THREADS / WAVE; ++w) {
+    const uint32_t v = wsum[w];
+    before += w < wv ? v : 0u;
+    all += v;
+  }
+  total = all;
+  return before + incl - mine;
+}
+template <typename Items>
+__global__ __launch_bounds__(SCAN_THREADS) void td_scan_sums_kernel(Items it, uint32_t n, uint32_t *tile_sums) {
+  const uint32_t i0 = blockIdx.x * SCAN_TILE + threadIdx.x * SCAN_PER_THREAD;
+  uint32_t mine = 0;
+#pragma unroll
+  for (uint32_t e = 0; e < SCAN_PER_THREAD; ++e) mine += it.at(i0 + e, n);
+  uint32_t total;
+  (void)wg_excl_scan(mine, total);
+  if (threadIdx.x == 0) tile_sums[blockIdx.x] = total;
+}
+// one workgroup: tile_sums -> exclusive prefix, in place; tile_sums[n_tiles] = the grand total
+__global__ __launch_bounds__(SCAN_THREADS) void td_scan_tiles_kernel(uint32_t *tile_sums, uint32_t n_tiles) {
+  uint32_t carry = 0;
+  for (uint32_t base = 0; base < n_tiles; base += SCAN_THREADS) {
     const uint32_t i = base + threadIdx.x;
-    const uint32_t v = i < n_words ? (uint32_t)__popc(tab[i].x) : 0u;
-    sh[threadIdx.x] = v;
-    __syncthreads();
-    for (uint32_t o = 1; o < 1024u; o <<= 1) {
-      const uint32_t u = threadIdx.x >= o ? sh[threadIdx.x - o] : 0u;
-      __syncthreads();
-      sh[threadIdx.x] += u;
-      __syncthreads();
-    }
-    const uint32_t carry = carry_s;
-    if (i < n_words) tab[i].y = carry + sh[threadIdx.x] - v;
-    __syncthreads();
-    if (threadIdx.x == 1023u) carry_s = carry + sh[1023];
-    __syncthreads();
+    const uint32_t v = i < n_tiles ? tile_sums[i] : 0u;
+    uint32_t total;
+    const uint32_t ex = wg_excl_scan(v, total);
+    if (i < n_tiles) tile_sums[i] = carry + ex;
+    carry += total;
+    __syncthreads();  // (wg_excl_scan's LDS words are reused by the next chunk)
+  }
+  if (threadIdx.x == 0) tile_sums[n_tiles] = carry;
+}
+// rank directory: tab[w].y = number of postings before word w
+__global__ __launch_bounds__(SCAN_THREADS) void td_rank_apply_kernel(uint2 *tab, uint32_t n_words, const uint32_t *tile_off) {
+  const RankItems it{tab};
+  const uint32_t i0 = blockIdx.x * SCAN_TILE + threadIdx.x * SCAN_PER_THREAD;
+  uint32_t v[SCAN_PER_THREAD], mine = 0;
+#pragma unroll
+  for (uint32_t e = 0; e < SCAN_PER_THREAD; ++e) {
+    v[e] = it.at(i0 + e, n_words);
+    mine += v[e];
+  }
+  uint32_t total;
+  uint32_t run = tile_off[blockIdx.x] + wg_excl_scan(mine, total);
+#pragma unroll
+  for (uint32_t e = 0; e < SCAN_PER_THREAD; ++e) {
+    if (i0 + e < n_words) tab[i0 + e].y = run;
+    run += v[e];
   }
 }
 // position directory: dir[j] = sum of the tfs of postings 0..4j-1; dir[n_dir-1] = the total
-__global__ __launch_bounds__(1024) void td_posdir_kernel(const uint32_t *tfs, uint32_t n, uint32_t *dir,
-                                                         uint32_t n_dir) {
-  __shared__ uint32_t sh[1024];
-  __shared__ uint32_t carry_s;
-  if (threadIdx.x == 0) carry_s = 0;
-  __syncthreads();
-  for (uint32_t base = 0; base < n_dir; base += 1024u) {  // one group of four postings per thread
-    const uint32_t j = base + threadIdx.x;
-    uint32_t v = 0;
-    for (uint32_t e = 0; e < 4u; ++e) {
-      const uint64_t i = 4ull * j + e;
-      if (i < n) v += tfs[i];
-    }
-    sh[threadIdx.x] = v;
-    __syncthreads();
-    for (uint32_t o = 1; o < 1024u; o <<= 1) {
-      const uint32_t u = threadIdx.x >= o ? sh[threadIdx.x - o] : 0u;
-      __syncthreads();
-      sh[threadIdx.x] += u;
-      __syncthreads();
-    }
-    const uint32_t carry = carry_s;
-    if (j < n_dir) dir[j] = carry + sh[threadIdx.x] - v;
-    __syncthreads();
-    if (threadIdx.x == 1023u) carry_s = carry + sh[1023];
-    __syncthreads();
+__global__ __launch_bounds__(SCAN_THREADS) void td_posdir_apply_kernel(const uint32_t *tfs, uint32_t n, uint32_t *dir,
+                                                                      uint32_t n_dir, const uint32_t *tile_off) {
+  const PosdirItems it{tfs, n};
+  const uint32_t i0 = blockIdx.x * SCAN_TILE + threadIdx.x * SCAN_PER_THREAD;
+  uint32_t v[SCAN_PER_THREAD], mine = 0;
+#pragma unroll
+  for (uint32_t e = 0; e < SCAN_PER_THREAD; ++e) {
+    v[e] = it.at(i0 + e, n_dir);
+    mine += v[e];
   }
+  uint32_t total;
+  uint32_t run = tile_off[blockIdx.x] + wg_excl_scan(mine, total);
+#pragma unroll
+  for (uint32_t e = 0; e < SCAN_PER_THREAD; ++e) {
+    if (i0 + e < n_dir) dir[i0 + e] = run;
+    run += v[e];
+  }
+}
+// ---- range maxima of a list with a bitmap (tq_ashare.hip bounds the non-leader lists of an intersection
+// with them — block_wand_intersection.rs:59-85 takes the block-max of every secondary's current block; with
+// every other list reached through its bitmap there are no "current blocks", so the bound is kept per fixed
+// doc range): rm[r] = max over the list's postings in docs [r << TQD_RM_SHIFT, (r + 1) << TQD_RM_SHIFT) of
+// tf/(tf + norm) under the segment's OWN Bm25 cache, as a byte rounded UP to the next 1/255 (0 = no posting
+// in the range).  Like the stored block-max pairs it is exact under the segment's average fieldnorm and off
+// by at most the caller's bound_slack under a global one.
+__global__ __launch_bounds__(256) void td_rmax_scatter_kernel(const uint32_t *docs, const uint32_t *tfs, uint32_t n,
+                                                              const uint8_t *fieldnorm, uint32_t const_id,
+                                                              const float *cache, uint32_t *acc) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int lane = (int)__lane_id();
+  uint32_t r = 0xFFFFFFFFu, q = 0;
+  if (i < n) {
+    const uint32_t d = docs[i];
+    const float f = (float)tfs[i];
+    const float tfn = f / (f + cache[fieldnorm ? (uint32_t)fieldnorm[d] : const_id]);
+    q = (uint32_t)(tfn * 255.0f) + 1u;
+    q = q > 255u ? 255u : q;
+    r = d >> TQD_RM_SHIFT;
+  }
+  // postings are in doc order: equal ranges are contiguous in the wavefront — a segmented max, then one
+  // atomic per (wavefront, range)
+#pragma unroll
+  for (int d = 1; d < WAVE; d <<= 1) {
+    const uint32_t orr = (uint32_t)__shfl_down((int)r, d, WAVE), oq = (uint32_t)__shfl_down((int)q, d, WAVE);
+    if (lane + d < WAVE && orr == r && oq > q) q = oq;
+  }
+  const uint32_t before = (uint32_t)__shfl_up((int)r, 1, WAVE);
+  if (r != 0xFFFFFFFFu && (lane == 0 || before != r)) atomicMax(acc + r, q);
+}
+// level 0 as bytes + the list's largest entry
+__global__ void td_rmax_pack_kernel(const uint32_t *acc, uint32_t n_ranges, uint8_t *out, uint32_t n_out, uint32_t *list_max) {
+  const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t v = r < n_ranges ? acc[r] : 0u;
+  if (r < n_out) out[r] = (uint8_t)v;  // (the padding behind the last range reads as 0)
+  uint32_t m = v;
+  for (int o = 32; o; o >>= 1) {
+    const uint32_t other = (uint32_t)__shfl_xor((int)m, o, WAVE);
+    m = other > m ? other : m;
+  }
+  if ((threadIdx.x & 63u) == 0u && m) atomicMax(list_max, m);
+}
+// level l + 1 from level l: the maximum of four entries
+__global__ void td_rmax_pool_kernel(const uint8_t *in, uint32_t n_in, uint8_t *out, uint32_t n_out) {
+  const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= n_out) return;
+  uint32_t m = 0;
+  for (uint32_t e = 0; e < 4u; ++e) {
+    const uint32_t i = 4u * r + e;
+    const uint32_t v = i < n_in ? in[i] : 0u;
+    m = v > m ? v : m;
+  }
+  out[r] = (uint8_t)m;
 }
 __global__ void td_min_fieldnorm_kernel(const uint8_t *fieldnorm, uint32_t max_doc, uint32_t *out) {
   uint32_t mn = 255u;
@@ -343,19 +454,44 @@ hipError_t tqp_launch_positions(const TqpPositionsParams &p, hipStream_t st) {
   hipLaunchKernelGGL(tp_positions_kernel, dim3(1), dim3(64), 0, st, p);
   return hipGetLastError();
 }
+uint32_t tqp_scan_scratch_words(uint32_t n_items) { return (n_items + SCAN_TILE - 1) / SCAN_TILE + 2u; }
 hipError_t tqp_launch_dense(const uint32_t *docs, uint32_t n, uint32_t max_doc, uint2 *tab,
-                            uint32_t n_words, uint32_t *bad, hipStream_t st) {
+                            uint32_t n_words, uint32_t *bad, uint32_t *scan_scratch, hipStream_t st) {
   if (n) hipLaunchKernelGGL(td_check_bits_kernel, dim3((n + 255) / 256), dim3(256), 0, st, docs, n, max_doc, tab, bad);
-  hipLaunchKernelGGL(td_rank_kernel, dim3(1), dim3(1024), 0, st, tab, n_words);
+  const uint32_t n_tiles = (n_words + SCAN_TILE - 1) / SCAN_TILE;
+  if (!n_tiles) return hipGetLastError();
+  hipLaunchKernelGGL((td_scan_sums_kernel<RankItems>), dim3(n_tiles), dim3(SCAN_THREADS), 0, st, RankItems{tab}, n_words, scan_scratch);
+  hipLaunchKernelGGL(td_scan_tiles_kernel, dim3(1), dim3(SCAN_THREADS), 0, st, scan_scratch, n_tiles);
+  hipLaunchKernelGGL(td_rank_apply_kernel, dim3(n_tiles), dim3(SCAN_THREADS), 0, st, tab, n_words, scan_scratch);
   return hipGetLastError();
 }
 hipError_t tqp_launch_posdir(const uint32_t *tfs, uint32_t n, uint32_t *dir, uint32_t n_dir,
-                             hipStream_t st) {
-  hipLaunchKernelGGL(td_posdir_kernel, dim3(1), dim3(1024), 0, st, tfs, n, dir, n_dir);
+                             uint32_t *scan_scratch, hipStream_t st) {
+  const uint32_t n_tiles = (n_dir + SCAN_TILE - 1) / SCAN_TILE;
+  if (!n_tiles) return hipSuccess;
+  hipLaunchKernelGGL((td_scan_sums_kernel<PosdirItems>), dim3(n_tiles), dim3(SCAN_THREADS), 0, st, PosdirItems{tfs, n}, n_dir, scan_scratch);
+  hipLaunchKernelGGL(td_scan_tiles_kernel, dim3(1), dim3(SCAN_THREADS), 0, st, scan_scratch, n_tiles);
+  hipLaunchKernelGGL(td_posdir_apply_kernel, dim3(n_tiles), dim3(SCAN_THREADS), 0, st, tfs, n, dir, n_dir, scan_scratch);
   return hipGetLastError();
 }
 hipError_t tqp_launch_min_fieldnorm(const uint8_t *fieldnorm, uint32_t max_doc, uint32_t *out,
                                     hipStream_t st) {
   hipLaunchKernelGGL(td_min_fieldnorm_kernel, dim3(256), dim3(256), 0, st, fieldnorm, max_doc, out);
+  return hipGetLastError();
+}
+// range maxima (td_rmax_*): acc = (max_doc >> TQD_RM_SHIFT) + 1 zeroed u32 of scratch, out = the table (all
+// levels, tqd_rm_level_off), *list_max zeroed
+hipError_t tqp_launch_rmax(const uint32_t *docs, const uint32_t *tfs, uint32_t n, const uint8_t *fieldnorm,
+                           uint32_t const_id, const float *cache, uint32_t *acc, uint32_t max_doc, uint8_t *out,
+                           uint32_t *list_max, hipStream_t st) {
+  const uint32_t n_ranges = (max_doc >> TQD_RM_SHIFT) + 1u;
+  if (n) hipLaunchKernelGGL(td_rmax_scatter_kernel, dim3((n + 255) / 256), dim3(256), 0, st, docs, tfs, n, fieldnorm, const_id, cache, acc);
+  const uint32_t n0 = tqd_rm_level_entries(max_doc, 0);
+  hipLaunchKernelGGL(td_rmax_pack_kernel, dim3((n0 + 255) / 256), dim3(256), 0, st, acc, n_ranges, out, n0, list_max);
+  for (uint32_t l = 1; l < TQD_RM_LEVELS; ++l) {
+    const uint32_t n_in = tqd_rm_level_entries(max_doc, l - 1), n_out = tqd_rm_level_entries(max_doc, l);
+    hipLaunchKernelGGL(td_rmax_pool_kernel, dim3((n_out + 255) / 256), dim3(256), 0, st, out + tqd_rm_level_off(max_doc, l - 1), n_in,
+                       out + tqd_rm_level_off(max_doc, l), n_out);
+  }
   return hipGetLastError();
 }

@@ -97,7 +97,7 @@ int search_batch_impl(tq_segment *s, const tq_query *queries, uint32_t n_queries
   if (s->share_span_terms != s->terms.size()) {  // (terms are prepared rarely)
     uint64_t lo = ~0ull, hi = 0;
     for (const TermHost &th : s->terms)
-      for (const void *ptr : {th.dense_blob, th.tf8_blob, th.probe_dense_blob, th.probe_tf8_blob})
+      for (const void *ptr : {th.dense_blob, th.tf8_blob, th.probe_dense_blob, th.probe_tf8_blob, th.rmax_blob})
         if (ptr) {
           lo = std::min<uint64_t>(lo, (uint64_t)ptr);
           hi = std::max<uint64_t>(hi, (uint64_t)ptr);
@@ -580,8 +580,8 @@ int search_batch_impl(tq_segment *s, const tq_query *queries, uint32_t n_queries
     Group &g = groups[gi];
     part_off_bytes[gi] = partial_bytes;
     if (gi == kShare || gi == kDense || gi == kAShare || gi == kBShare) {  // result lists: part_start / n_parts count 8-byte entries (build_share_plan)
-      if (!g.queries.empty())
-        partial_bytes += ((size_t)g.queries.back().part_start + g.queries.back().n_parts) * sizeof(uint64_t);
+      if (!g.queries.empty())  // (list_entries: the last query of a group may read an earlier query's list)
+        partial_bytes += std::max<size_t>((size_t)g.list_entries, (size_t)g.queries.back().part_start + g.queries.back().n_parts) * sizeof(uint64_t);
       continue;
     }
     uint32_t parts = 0;
@@ -800,7 +800,11 @@ int search_batch_impl(tq_segment *s, const tq_query *queries, uint32_t n_queries
       rc = (ai ? sc.bshare_stage : sc.ashare_stage)
                .ensure((size_t)ashare_grid[ai] * TQD_AS_GROUP * tqk_share_capl(groups[a_group[ai]].kpl) * sizeof(uint64_t));
     if (rc != TQ_OK) return rc;
-    HIP_TRY(hipMemsetAsync(wb.p, 0, words * sizeof(uint32_t), st));
+    // (TQ_KEEP_THR=1, experiments only: the threshold words keep the previous batch's final values — what a
+    // launch costs whose thresholds are right from its first task)
+    static const bool kKeepThrWords = tune_u32("TQ_KEEP_THR", 0) != 0;
+    const size_t keep = (kKeepThrWords && s->thr_seeded) ? n_ashare_of[ai] : 0;
+    HIP_TRY(hipMemsetAsync((uint32_t *)wb.p + keep, 0, (words - keep) * sizeof(uint32_t), st));
   }
 
   // ---- launch
@@ -849,8 +853,15 @@ int search_batch_impl(tq_segment *s, const tq_query *queries, uint32_t n_queries
       ap.n_queries = (uint32_t)n_a;
       ap.boolean = (uint32_t)ai;
       static const uint32_t kDebugA = tune_u32("TQ_DEBUG", 0);
-      ap.debug = kDebugA;
+      ap.debug = s->opt.debug >= 0 ? (uint32_t)s->opt.debug : kDebugA;  // (option "debug": work counters of one batch, bench.py)
       ap.bound_slack = co.bound_slack;
+      // TQ_AS_BOUND (A/B of the bound on the non-leader list of an intersection; every setting is exact):
+      // bit 0 the block pre-filter takes list 1's range maxima over the leader block's doc span, bit 1 the
+      // gather cut of a block comes from that pre-filter, bit 2 the per-(doc, lead) test reads the doc's own
+      // range (measured slower: two more dependent byte gathers per (block, lead) pair cost more than the 7 % of
+      // scoring-stage candidates they remove); 0 = round 4: list 1 is bounded by its weight.  Default 3.
+      static const uint32_t kBoundMode = tune_u32("TQ_AS_BOUND", 3);
+      ap.bound_mode = kBoundMode;
       tiles_total += g.total_tiles;
       chunks_total += g.n_chunks;
       kernel_mask |= ai ? TQ_KERNEL_BSHARE : TQ_KERNEL_ASHARE;
@@ -889,7 +900,7 @@ int search_batch_impl(tq_segment *s, const tq_query *queries, uint32_t n_queries
       sp.lists = (uint64_t *)((uint8_t *)sc.partials.p + part_off_bytes[gi]);
       sp.n_queries = (uint32_t)n_share;
       static const uint32_t kDebugS = tune_u32("TQ_DEBUG", 0);
-      sp.debug = kDebugS;
+      sp.debug = s->opt.debug >= 0 ? (uint32_t)s->opt.debug : kDebugS;
       sp.bound_slack = co.bound_slack;
       tiles_total += g.total_tiles;
       chunks_total += g.n_chunks;
@@ -959,7 +970,7 @@ int search_batch_impl(tq_segment *s, const tq_query *queries, uint32_t n_queries
     p.use_dense = (uint32_t)s->opt.use_dense;
     p.all_dense = (gi == 0 || (gi == 2 && phrase_all_dense)) ? 1u : 0u;
     static const uint32_t kDebug = tune_u32("TQ_DEBUG", 0);
-    p.debug = kDebug;
+    p.debug = s->opt.debug >= 0 ? (uint32_t)s->opt.debug : kDebug;
     p.or_windows = gi == kPhSweep ? 2u : ((or_windows_opt && gi != kBool) ? 1u : 0u);  // (2 = phrase sweep)
     p.boolean = gi == kBool ? 1u : 0u;
     p.small_k = g.max_k <= 16u ? 1u : 0u;

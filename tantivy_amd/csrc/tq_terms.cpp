@@ -82,6 +82,35 @@ int build_tf8(tq_segment *s, uint32_t handle, const uint32_t *d_tfs) {
   return TQ_OK;
 }
 
+// Range maxima of a list that gets a bitmap (its own or the probe tables'): tq_ashare.hip bounds the non-leader
+// lists of an intersection per TQD_RM_SHIFT-doc range instead of by their weight (block_wand_intersection.rs:59-85
+// uses the block-max of the secondaries' current blocks).  dd / dt = the decoded list; acc = n_ranges + 1 u32 of
+// scratch.  13 KB per list of a 10M-doc segment (five levels, one byte per 1024 docs at the finest).
+int build_rmax(tq_segment *s, uint32_t handle, const uint32_t *dd, const uint32_t *dt, uint32_t *acc) {
+  TermHost &t = s->terms[handle];
+  if (t.rmax_blob || !s->d_local_cache || !t.doc_freq) return TQ_OK;
+  const uint32_t n_ranges = (s->max_doc >> TQD_RM_SHIFT) + 1u;
+  const uint32_t n_out = tqd_rm_level_off(s->max_doc, TQD_RM_LEVELS);  // every level (tq_device.h)
+  void *blob = nullptr;
+  const int arc = dense_alloc(s, n_out, &blob);
+  if (arc != TQ_OK) return arc;
+  hipError_t e = hipMemsetAsync(acc, 0, ((size_t)n_ranges + 1u) * sizeof(uint32_t), s->stream);
+  if (e == hipSuccess)
+    e = tqp_launch_rmax(dd, dt, t.doc_freq, s->d_fn, s->dseg.const_fieldnorm_id, s->d_local_cache, acc, s->max_doc,
+                        (uint8_t *)blob, acc + n_ranges, s->stream);
+  uint32_t lmax = 0;
+  if (e == hipSuccess) e = hipMemcpyAsync(&lmax, acc + n_ranges, 4, hipMemcpyDeviceToHost, s->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(s->stream);
+  if (e != hipSuccess) {
+    dense_release(s, blob);
+    return fail(TQ_ERR_HIP, "range maxima: %s", hipGetErrorString(e));
+  }
+  t.rmax_blob = blob;
+  t.rmax_list = lmax ? std::min<uint32_t>(lmax, 255u) : 255u;
+  s->bytes_bitmaps += n_out;
+  return TQ_OK;
+}
+
 // A list WITHOUT a bitmap as plain arrays — doc ids, then min(tf, 255) per posting — for the
 // doc-major union launch (tq_xunion.hip), which scatters such a list into its tile row with a
 // cursor instead of decoding blocks.  Built on the batch's stream the first time an unpruned
@@ -178,105 +207,6 @@ int add_to_doc_signatures(tq_segment *s, uint32_t handle) {
   return TQ_OK;
 }
 
-// Dense lists (doc_freq >= max_doc/TQD_DENSE_RATIO) also get a membership bitmap with a rank
-// directory: the list is decoded once on the device (the same kernel as tq_decode_postings),
-// and {32 doc bits, number of postings before them} pairs are uploaded.  A probe of doc d then
-// costs one 8-byte load instead of a block decode; the posting index (=> block, slot, tf) falls
-// out of the rank.  Derived data like the unrolled skip table; the index bytes stay untouched.
-int build_dense(tq_segment *s, uint32_t handle) {
-  int rc = sync_terms(s, s->stream);
-  if (rc != TQ_OK) return rc;
-  TermHost &t = s->terms[handle];
-  const size_t bytes = (size_t)t.doc_freq * sizeof(uint32_t);
-  rc = s->d_misc.ensure(2 * bytes + 64);
-  if (rc != TQ_OK) return rc;
-  uint32_t *dd = (uint32_t *)s->d_misc.p, *dt = dd + t.doc_freq;
-  hipError_t e = tqk_launch_decode_list(s->dseg, s->d_terms, handle, t.n_blocks, dd, dt,
-                                        s->opt.use_dpp != 0, s->stream);
-  if (e != hipSuccess) return fail(TQ_ERR_HIP, "decode launch: %s", hipGetErrorString(e));
-  rc = build_tf8(s, handle, dt);
-  if (rc != TQ_OK) return rc;
-  // the list's column of the doc matrix (first TQD_MAT_SLOTS dense lists of the segment, while
-  // the matrix fits the same memory budget as the bitmaps)
-  if (s->n_mat_slots < TQD_MAT_SLOTS && s->opt.docmat && t.wants_col) {
-    {
-      const int mrc = ensure_docmat(s);
-      if (mrc != TQ_OK) return mrc;
-    }
-    if (s->d_docmat) {
-      const uint32_t slot = s->n_mat_slots++;
-      e = tqk_launch_docmat_set(s->d_docmat, dd, t.doc_freq, slot, s->max_doc, s->stream);
-      if (e != hipSuccess) return fail(TQ_ERR_HIP, "docmat set: %s", hipGetErrorString(e));
-      s->h_dterms[handle].has_freq |= (slot + 1u) << 8;
-    }
-  }
-  std::vector<uint32_t> docs(t.doc_freq), tfs;
-  HIP_TRY(hipMemcpyAsync(docs.data(), dd, bytes, hipMemcpyDeviceToHost, s->stream));
-  const bool want_dir = t.positions_len > 0;
-  if (want_dir) {
-    tfs.resize(t.doc_freq);
-    HIP_TRY(hipMemcpyAsync(tfs.data(), dt, bytes, hipMemcpyDeviceToHost, s->stream));
-  }
-  HIP_TRY(hipStreamSynchronize(s->stream));
-  const size_t n_words = ((size_t)s->max_doc + 31) / 32 + 1;
-  std::vector<uint2> tab(n_words, make_uint2(0u, 0u));
-  uint32_t prev = 0;
-  for (uint32_t i = 0; i < t.doc_freq; ++i) {
-    const uint32_t d = docs[i];
-    if (d >= s->max_doc || (i && d <= prev))
-      return fail(TQ_ERR_FORMAT, "posting list not strictly increasing below max_doc");
-    tab[d >> 5].x |= 1u << (d & 31u);
-    prev = d;
-  }
-  uint32_t running = 0;
-  for (size_t w = 0; w < n_words; ++w) {
-    tab[w].y = running;
-    running += (uint32_t)__builtin_popcount(tab[w].x);
-  }
-  void *blob = nullptr;
-  {
-    const int arc = dense_alloc(s, n_words * sizeof(uint2), &blob);
-    if (arc != TQ_OK) return arc;
-  }
-  s->bytes_bitmaps += n_words * sizeof(uint2);
-  ++s->n_dense_lists;
-  hipError_t ce = hipMemcpy(blob, tab.data(), n_words * sizeof(uint2), hipMemcpyHostToDevice);
-  if (ce != hipSuccess) {
-    dense_release(s, blob);
-    return fail(TQ_ERR_HIP, "dense upload: %s", hipGetErrorString(ce));
-  }
-  t.dense_blob = blob;
-  s->h_dterms[handle].dense = (const uint2 *)blob;
-  s->d_terms_dirty = true;
-  if (want_dir) {  // position directory: positions before every fourth posting
-    const size_t n_dir = ((size_t)t.doc_freq + 3) / 4 + 1;
-    std::vector<uint32_t> dir(n_dir);
-    uint64_t run = 0;
-    for (uint32_t i = 0; i < t.doc_freq; ++i) {
-      if ((i & 3u) == 0u) dir[i >> 2] = (uint32_t)run;
-      run += tfs[i];
-    }
-    dir[n_dir - 1] = (uint32_t)run;
-    if (run != t.n_positions)
-      return fail(TQ_ERR_FORMAT, "term freqs sum to %llu positions, the stream holds %llu",
-                  (unsigned long long)run, (unsigned long long)t.n_positions);
-    void *db = nullptr;
-    {
-      const int arc = dense_alloc(s, n_dir * sizeof(uint32_t) + PAD, &db);
-      if (arc != TQ_OK) return arc;
-    }
-    hipError_t de = hipMemcpy(db, dir.data(), n_dir * sizeof(uint32_t), hipMemcpyHostToDevice);
-    if (de != hipSuccess) {
-      dense_release(s, db);
-      return fail(TQ_ERR_HIP, "position directory upload: %s", hipGetErrorString(de));
-    }
-    t.posdir_blob = db;
-    s->h_dterms[handle].pos_dir = (const uint32_t *)db;
-    s->dense_bytes_total += n_dir * sizeof(uint32_t);
-    s->bytes_posdir += n_dir * sizeof(uint32_t);
-  }
-  return TQ_OK;
-}
 }  // namespace tqi
 
 extern "C" {
@@ -548,7 +478,9 @@ int register_term(tq_segment *s, const TqdTerm &dt, const TermHost &th, uint64_t
       (uint64_t)th.doc_freq * (uint64_t)s->opt.dense_ratio >= s->max_doc &&
       s->dense_bytes_total + dense_bytes <= budget) {
     s->dense_bytes_total += dense_bytes;
-    const int rc = s->device_prepare() ? build_dense_device(s, handle) : build_dense(s, handle);
+    // (device scans whether or not a host copy of the index exists: round 4's host builder pulled the decoded
+    // list back, built bitmap and rank directory in a loop and uploaded 2.5 MB per list)
+    const int rc = build_dense_device(s, handle);
     if (rc != TQ_OK) return rc;
   }
   return add_to_doc_signatures(s, handle);
@@ -686,22 +618,34 @@ int term_prepare_device(tq_segment *s, uint64_t postings_off, uint32_t postings_
   return register_term(s, dt, th, postings_off, out);
 }
 
-// build_dense without the host: bitmap bits by atomic OR, rank directory and position directory
-// by device scans; 4 bytes (the validity flag) come back.
+// Dense lists (doc_freq >= max_doc/TQD_DENSE_RATIO) also get a membership bitmap with a rank directory,
+// {32 doc bits, number of postings before them} per 32 docs: a probe of doc d costs one 8-byte load instead
+// of a block decode; the posting index (=> block, slot, tf) falls out of the rank.  Derived data like the
+// unrolled skip table; the index bytes stay untouched.  The list is decoded once on the device (the kernel of
+// tq_decode_postings), bitmap bits set by atomic OR, rank directory and position directory by grid-wide
+// scans (tq_prepare.hip); 4 bytes (the validity flag) come back.
 int build_dense_device(tq_segment *s, uint32_t handle) {
   int rc = sync_terms(s, s->stream);
   if (rc != TQ_OK) return rc;
   TermHost &t = s->terms[handle];
   const size_t bytes = (size_t)t.doc_freq * sizeof(uint32_t);
-  rc = s->d_misc.ensure(2 * bytes + 64);
+  const size_t n_words = ((size_t)s->max_doc + 31) / 32 + 1;
+  const size_t scan_words = tqp_scan_scratch_words((uint32_t)std::max<size_t>(n_words, (size_t)t.doc_freq / 4 + 2));
+  const size_t rm_words = ((size_t)s->max_doc >> TQD_RM_SHIFT) + 8;
+  rc = s->d_misc.ensure(2 * bytes + 64 + (scan_words + rm_words) * sizeof(uint32_t));
   if (rc != TQ_OK) return rc;
   uint32_t *dd = (uint32_t *)s->d_misc.p, *dt = dd + t.doc_freq;
+  uint32_t *scan_scratch = dt + t.doc_freq + 16;  // (tile sums of the scans below)
+  uint32_t *rm_acc = scan_scratch + scan_words;
   hipError_t e = tqk_launch_decode_list(s->dseg, s->d_terms, handle, t.n_blocks, dd, dt,
                                         s->opt.use_dpp != 0, s->stream);
   if (e != hipSuccess) return fail(TQ_ERR_HIP, "decode launch: %s", hipGetErrorString(e));
   rc = build_tf8(s, handle, dt);
   if (rc != TQ_OK) return rc;
-  const size_t n_words = ((size_t)s->max_doc + 31) / 32 + 1;
+  if (t.tf8_blob) {  // (the shared launches probe a list through bitmap + tf bytes: only then is it bounded by ranges)
+    rc = build_rmax(s, handle, dd, dt, rm_acc);
+    if (rc != TQ_OK) return rc;
+  }
   void *blob = nullptr;
   {
     const int arc = dense_alloc(s, n_words * sizeof(uint2), &blob);
@@ -713,7 +657,7 @@ int build_dense_device(tq_segment *s, uint32_t handle) {
   e = hipMemsetAsync(blob, 0, n_words * sizeof(uint2), s->stream);
   if (e == hipSuccess) e = hipMemsetAsync(bad, 0, 4, s->stream);
   if (e == hipSuccess)
-    e = tqp_launch_dense(dd, t.doc_freq, s->max_doc, (uint2 *)blob, (uint32_t)n_words, bad, s->stream);
+    e = tqp_launch_dense(dd, t.doc_freq, s->max_doc, (uint2 *)blob, (uint32_t)n_words, bad, scan_scratch, s->stream);
   uint32_t h_bad = 0;
   if (e == hipSuccess) e = hipMemcpyAsync(&h_bad, bad, 4, hipMemcpyDeviceToHost, s->stream);
   if (e == hipSuccess) e = hipStreamSynchronize(s->stream);
@@ -744,7 +688,7 @@ int build_dense_device(tq_segment *s, uint32_t handle) {
       const int arc = dense_alloc(s, n_dir * sizeof(uint32_t) + PAD, &db);
       if (arc != TQ_OK) return arc;
     }
-    e = tqp_launch_posdir(dt, t.doc_freq, (uint32_t *)db, (uint32_t)n_dir, s->stream);
+    e = tqp_launch_posdir(dt, t.doc_freq, (uint32_t *)db, (uint32_t)n_dir, scan_scratch, s->stream);
     uint32_t total = 0;
     if (e == hipSuccess)
       e = hipMemcpyAsync(&total, (uint32_t *)db + (n_dir - 1), 4, hipMemcpyDeviceToHost, s->stream);
@@ -786,9 +730,12 @@ int build_probe_tables(tq_segment *s, uint32_t handle, bool *ok) {
   int rc = sync_terms(s, s->stream);
   if (rc != TQ_OK) return rc;
   const size_t bytes = (size_t)t.doc_freq * sizeof(uint32_t);
-  rc = s->d_misc.ensure(2 * bytes + 64);
+  const size_t scan_words = tqp_scan_scratch_words((uint32_t)n_words);
+  rc = s->d_misc.ensure(2 * bytes + 64 + (scan_words + ((size_t)s->max_doc >> TQD_RM_SHIFT) + 8) * sizeof(uint32_t));
   if (rc != TQ_OK) return rc;
   uint32_t *dd = (uint32_t *)s->d_misc.p, *dt = dd + t.doc_freq;
+  uint32_t *scan_scratch = dt + t.doc_freq + 16;
+  uint32_t *rm_acc = scan_scratch + scan_words;
   hipError_t e = tqk_launch_decode_list(s->dseg, s->d_terms, handle, t.n_blocks, dd, dt, s->opt.use_dpp != 0, s->stream);
   if (e != hipSuccess) return fail(TQ_ERR_HIP, "decode launch: %s", hipGetErrorString(e));
   void *tfb = nullptr, *blob = nullptr;
@@ -803,7 +750,7 @@ int build_probe_tables(tq_segment *s, uint32_t handle, bool *ok) {
   e = tqk_launch_tf8_pack(dt, t.doc_freq, (uint8_t *)tfb, s->stream);
   if (e == hipSuccess) e = hipMemsetAsync(blob, 0, n_words * sizeof(uint2), s->stream);
   if (e == hipSuccess) e = hipMemsetAsync(bad, 0, 4, s->stream);
-  if (e == hipSuccess) e = tqp_launch_dense(dd, t.doc_freq, s->max_doc, (uint2 *)blob, (uint32_t)n_words, bad, s->stream);
+  if (e == hipSuccess) e = tqp_launch_dense(dd, t.doc_freq, s->max_doc, (uint2 *)blob, (uint32_t)n_words, bad, scan_scratch, s->stream);
   uint32_t h_bad = 0;
   if (e == hipSuccess) e = hipMemcpyAsync(&h_bad, bad, 4, hipMemcpyDeviceToHost, s->stream);
   if (e == hipSuccess) e = hipStreamSynchronize(s->stream);
@@ -815,6 +762,8 @@ int build_probe_tables(tq_segment *s, uint32_t handle, bool *ok) {
   }
   t.probe_dense_blob = blob;
   t.probe_tf8_blob = tfb;
+  rc = build_rmax(s, handle, dd, dt, rm_acc);
+  if (rc != TQ_OK) return rc;
   s->probe_bytes_total += need;
   s->bytes_bitmaps += need;
   *ok = true;

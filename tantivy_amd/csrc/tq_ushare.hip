@@ -794,7 +794,9 @@ __global__ __launch_bounds__(64) void merge_lists_kernel(TqkMergeParams p, const
   if (q >= p.n_queries) return;
   const TqdQuery *Q = uni_ptr(p.queries + q);
   const uint32_t k = uni(Q->k);
-  const uint32_t n = uni(list_count[q]);
+  // (chunk_first: the query that owns the list — q itself, or the identical query of the batch that was
+  // evaluated in its place, build_ashare_plan)
+  const uint32_t n = uni(list_count[uni(Q->chunk_first)]);
   const uint64_t *src = p.partials + (size_t)uni(Q->part_start);
   TopK<KPL> tk;
   tk.reset(k);

@@ -273,12 +273,34 @@ static int check_ashare(int seed) {
            (unsigned long long)(list_budget >> 20), (unsigned long long)floor_entries);
     return 0;
   }
-  if (ps.ap[0].aleads.size() != nq) return fail_msg("lead count", (long)ps.ap[0].aleads.size(), nq);
+  // identical queries (lists, weights, k, cache) are evaluated once: the first of them owns the leads and the
+  // result list, the others name it in chunk_first (what merge_lists_kernel reads)
+  auto identical = [&](const TqdQuery &a, const TqdQuery &b) {
+    return a.n_terms == b.n_terms && a.k == b.k && a.cache_idx == b.cache_idx && !memcmp(a.term, b.term, a.n_terms * 4) &&
+           !memcmp(a.weight, b.weight, a.n_terms * 4);
+  };
+  uint32_t n_heads = 0;
+  for (uint32_t q = 0; q < nq; ++q) {
+    const uint32_t o = g.queries[q].chunk_first;
+    if (o > q || o >= nq) return fail_msg("list owner out of range", q, o);
+    if (o == q) {
+      ++n_heads;
+      for (uint32_t e = 0; e < q; ++e)
+        if (g.queries[e].chunk_first == e && identical(g.queries[e], g.queries[q])) return fail_msg("an identical query before this one was not made its owner", q, e);
+      continue;
+    }
+    if (g.queries[o].chunk_first != o) return fail_msg("the owner of a list is not a head", q, o);
+    if (!identical(g.queries[o], g.queries[q])) return fail_msg("list owner is another query", q, o);
+    if (g.queries[q].part_start != g.queries[o].part_start || g.queries[q].n_parts != g.queries[o].n_parts)
+      return fail_msg("a repeated query does not read its owner's list", q, o);
+  }
+  if (ps.ap[0].aleads.size() != n_heads) return fail_msg("lead count", (long)ps.ap[0].aleads.size(), n_heads);
   std::vector<uint8_t> seen(nq, 0);
   uint64_t prev_key = 0, prev_mask = 0;
   for (size_t i = 0; i < ps.ap[0].aleads.size(); ++i) {
     const TqdALead &ld = ps.ap[0].aleads[i];
     if (ld.query >= nq || seen[ld.query]++) return fail_msg("lead twice / out of range", (long)i, ld.query);
+    if (g.queries[ld.query].chunk_first != ld.query) return fail_msg("a lead for a query that reads another's list", (long)i, ld.query);
     const TqdQuery &q = g.queries[ld.query];
     if ((ld.info & 31u) != q.n_terms || ld.w != q.weight[0] || ld.k != q.k) return fail_msg("lead header", (long)i);
     float rest = 0;
@@ -347,14 +369,19 @@ static int check_ashare(int seed) {
     if (kv.second != seg.terms[g.queries[ld.query].term[0]].n_blocks) return fail_msg("list not covered");
     leads_in_groups += kv.first & 0xFFu;
   }
-  if (leads_in_groups != nq) return fail_msg("lead groups do not partition the leads", (long)leads_in_groups, nq);
+  if (leads_in_groups != n_heads) return fail_msg("lead groups do not partition the leads", (long)leads_in_groups, n_heads);
   uint64_t at = 0;
   for (uint32_t q = 0; q < nq; ++q) {
+    if (g.queries[q].chunk_first != q) {
+      if (pairs[q]) return fail_msg("a repeated query has tasks of its own", q);
+      continue;
+    }
     if (!pairs[q]) return fail_msg("query without a task", q);
     if (g.queries[q].part_start != at) return fail_msg("result regions overlap", q);
     if (g.queries[q].n_parts != pairs[q] * g.queries[q].k) return fail_msg("result region size", q);
     at += g.queries[q].n_parts;
   }
+  if (g.list_entries != at) return fail_msg("list_entries", (long)g.list_entries);
   if (g.n_chunks != ps.ap[0].atasks.size()) return fail_msg("n_chunks");
   if (at * 8u > list_budget) return fail_msg("result lists over the budget", (long)at);
   printf("ashare: %u queries, %zu tasks, %llu list entries ok\n", nq, ps.ap[0].atasks.size(), (unsigned long long)at);
@@ -450,8 +477,20 @@ static int check_bshare(int seed) {
     return 0;
   }
   const PlanScratch::ASharePlan &A = ps.ap[1];
-  size_t want_leads = 0;
-  for (const TqdQuery &q : g.queries) want_leads += q.n_lead;
+  size_t want_leads = 0;  // (a query identical to an earlier one reads that query's list: chunk_first names it)
+  for (uint32_t q = 0; q < nq; ++q) {
+    const TqdQuery &dq = g.queries[q];
+    if (dq.chunk_first == q) {
+      want_leads += dq.n_lead;
+      continue;
+    }
+    const TqdQuery &o = g.queries[dq.chunk_first];
+    if (dq.chunk_first > q || o.chunk_first != dq.chunk_first || o.n_terms != dq.n_terms || o.k != dq.k || o.roles != dq.roles ||
+        o.clause_end != dq.clause_end || o.n_lead != dq.n_lead || o.n_opt_lead != dq.n_opt_lead || o.min_should != dq.min_should ||
+        o.cache_idx != dq.cache_idx || memcmp(o.term, dq.term, dq.n_terms * 4) || memcmp(o.weight, dq.weight, dq.n_terms * 4) ||
+        o.part_start != dq.part_start || o.n_parts != dq.n_parts)
+      return fail_msg("a repeated boolean query and the owner of its list differ", q, dq.chunk_first);
+  }
   if (A.aleads.size() != want_leads) return fail_msg("lead count", (long)A.aleads.size(), (long)want_leads);
   auto bit_of = [&](uint32_t handle) -> uint32_t {
     const uint32_t hf = seg.h_dterms[handle].has_freq;
@@ -535,7 +574,7 @@ static int check_bshare(int seed) {
     }
   }
   for (uint32_t q = 0; q < nq; ++q)
-    if (seen[q] != (1u << g.queries[q].n_lead) - 1u) return fail_msg("a lead-set list without a lead", q);
+    if (seen[q] != (g.queries[q].chunk_first == q ? (1u << g.queries[q].n_lead) - 1u : 0u)) return fail_msg("a lead-set list without a lead", q);
   // tasks: groups of leads x runs of blocks, every (lead, block) once
   std::vector<uint32_t> pairs(nq, 0);
   std::unordered_map<uint64_t, uint32_t> next_block;
@@ -561,6 +600,10 @@ static int check_bshare(int seed) {
   }
   uint64_t at = 0;
   for (uint32_t q = 0; q < nq; ++q) {
+    if (g.queries[q].chunk_first != q) {
+      if (pairs[q]) return fail_msg("a repeated query has tasks of its own", q);
+      continue;
+    }
     if (!pairs[q]) return fail_msg("query without a task", q);
     if (g.queries[q].part_start != at) return fail_msg("result regions overlap", q);
     if (g.queries[q].n_parts != pairs[q] * g.queries[q].k) return fail_msg("result region size", q);

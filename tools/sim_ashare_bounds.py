@@ -67,7 +67,7 @@ def main():
         seen[key] = seen.get(key, 0) + 1
     print("%d queries, %d distinct" % (len(qs), len(seen)))
     k = 10
-    tot = {"matches": 0, "weight": 0, "class": 0, "collected_floor": 0}
+    tot = {"matches": 0, "weight": 0, "class": 0, "collected_floor": 0, "weight_x_groups": 0, "range1024_x_groups": 0, "leader_docs_x_groups": 0, "leader_pass_weight_x_groups": 0}
     for R in RANGES:
         tot["range%d" % R] = 0
         tot["rtf%d" % R] = 0
@@ -91,8 +91,19 @@ def main():
         sc = s0 + s1
         thr = np.partition(sc, -k)[-k] if len(sc) >= k else np.float32(0)
         tot["matches"] += len(d)
+        # the threshold as the kernel knows it: k-th largest of 64 hashed slots, upper 16 bits of the score
+        thr16 = (np.array([thr], dtype=np.float32).view(np.uint32) & np.uint32(0xFFFF0000)).view(np.float32)[0]
+        tot["weight_thr16"] = tot.get("weight_thr16", 0) + int((s0 + w1 >= thr16).sum())
+        thr24 = (np.array([thr], dtype=np.float32).view(np.uint32) & np.uint32(0xFFFFFF00)).view(np.float32)[0]
+        tot["weight_thr24"] = tot.get("weight_thr24", 0) + int((s0 + w1 >= thr24).sum())
+        tot["range1024_thr16"] = tot.get("range1024_thr16", 0) + int((s0 + w1 * rmax_tfn[1024][s][d // 1024] >= thr16).sum())
+        tot["range1024_thr24"] = tot.get("range1024_thr24", 0) + int((s0 + w1 * rmax_tfn[1024][s][d // 1024] >= thr24).sum())
         tot["collected_floor"] += int((sc >= thr).sum())
         tot["weight"] += int((s0 + w1 >= thr).sum())
+        groups = (mult + 31) // 32  # a family is evaluated once per group of <= 32 leads
+        tot["weight_x_groups"] += groups * int((s0 + w1 >= thr).sum())
+        tot["leader_docs_x_groups"] += groups * len(d0)
+        tot["leader_pass_weight_x_groups"] += groups * int((w0 * (tf0 / (tf0 + norm_doc[d0])) + w1 >= thr).sum())
         br = {}
         for R in RANGES:
             b_r = w1 * rmax_tfn[R][s][d // R]
@@ -100,6 +111,8 @@ def main():
             b_t = w1 * (tm / (tm + n0))
             br[R] = (b_r, b_t)
             tot["range%d" % R] += int((s0 + b_r >= thr).sum())
+            if R == 1024:
+                tot["range1024_x_groups"] += groups * int((s0 + b_r >= thr).sum())
             tot["rtf%d" % R] += int((s0 + b_t >= thr).sum())
         tot["min(range1024,rtf1024)"] += int((s0 + np.minimum(br[1024][0], br[1024][1]) >= thr).sum())
         lm = np.float32(list_max_tf[s])
