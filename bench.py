@@ -73,6 +73,16 @@ def parse_args(argv=None):
     ap.add_argument("--side-steps", type=int, default=10)
     ap.add_argument("--selftest-launcher", action="store_true",
                     help="CPU plumbing check of the rank launcher (gloo, no GPU work, no timing)")
+    ap.add_argument("--no-pmc-inline", action="store_true",
+                    help="skip the rocprofv3 passes that measure the fabric traffic of THIS run's kernels (outside the "
+                         "timed region; roofline.traffic / frac then come from profiles/traffic.json if its kernel hash matches)")
+    ap.add_argument("--pmc-child", default=None, help="(internal) the workload a rocprofv3 pass of --pmc-inline runs")
+    ap.add_argument("--no-stream", action="store_true", help="skip the stream block (different batches, Query::weight timed)")
+    ap.add_argument("--stream-vocabs", default="256,4096,65536",
+                    help="vocabularies of the stream block (comma separated; each its own 10M-doc segment)")
+    ap.add_argument("--stream-batches", type=int, default=24)
+    ap.add_argument("--check-queries", type=int, default=512,
+                    help="queries of every workload checked against the oracle, spread over the kernel families that ran")
     return ap.parse_args(argv)
 
 
@@ -170,6 +180,12 @@ def build_queries(O, workload, n, k, terms=256):
     for i in range(n):
         qs.append((O.MODE_AND, a[i // 2].tolist()) if i % 2 == 0 else (O.MODE_OR, o[i // 2].tolist()))
     return qs, k or 10
+
+
+def tantivy_amd_kernel_name(bit):
+    from tantivy_amd import binding as TB
+
+    return TB.KERNEL_NAMES.get(int(bit), hex(int(bit)))
 
 
 def usable_cpus():
@@ -481,7 +497,125 @@ def traffic_fields(tj, launches, kernel_ms):
     return out
 
 
-def spot_check(O, cl, segs, first_ord, gstats, workload, queries, k, final, n_check=64):
+SCAN_KERNEL_RE = r"(and_kernel|union_kernel_small|union_kernel|ushare_kernel|ashare_kernel|xunion_kernel|or_kernel|phrase_sweep_kernel|phrase_kernel)<"
+
+
+def pmc_child(args):
+    """One workload, pruned mode, S synchronous steps on one segment and nothing else: what a rocprofv3 pass of
+    pmc_inline() profiles (every scan-kernel dispatch of the process belongs to one of the S steps)."""
+    import torch
+
+    torch.set_num_threads(4)
+    torch.cuda.set_device(0)
+    from oracle import oracle as O
+    from tantivy_amd import distributed as D
+
+    wl = args.pmc_child
+    seg = O.synth_segment(args.docs, n_terms=args.terms, segment_ord=0, with_positions=wl == "phrase3", phrase_terms=32)
+    runner = D.ShardRunner([seg], 0)
+    for name in ("dense_ratio", "dense_budget_x", "probe_budget_x", "docmat", "docsig", "device_prepare", "or_windows"):
+        if os.environ.get("TQ_OPT_" + name):
+            runner.set_option(name, int(os.environ["TQ_OPT_" + name]))
+    queries, k = build_queries(O, wl, args.queries or DEFAULT_QUERIES[wl], args.k, args.terms)
+    runner.prepare(queries, k)
+    runner.set_option("exhaustive", 0)
+    for _ in range(args.steps):
+        runner.enqueue()
+        runner.synchronize()
+    print(json.dumps({"pmc_child": wl, "steps": args.steps, "kernels": runner.batch_stats().get("kernels")}))
+    runner.close()
+    return 0
+
+
+def pmc_inline(args, workload, n_queries, k, steps=4):
+    """Fabric traffic of THIS build's scan kernels on THIS box, measured outside the timed region: three
+    rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE, L2 hits / misses: separate passes, counters only — no trace
+    domains) over a child process that runs `steps` synchronous pruned steps of the workload.  Units and
+    corrections as MI355X_MICROARCH.md (HBM section) prescribes and profiles/fetch_calibration.json confirmed for
+    this path's gathers: FETCH_SIZE / WRITE_SIZE are KiB; on gfx950 a 128-byte fabric read request is tallied as
+    64 B, so read bytes = 2 x FETCH_SIZE; both counters sit on the fabric side of the L2 (Infinity-Cache hits
+    included).  -> dict per step, or {"error": ...}."""
+    import csv
+    import glob
+    import re
+    import shutil
+    import tempfile
+
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return {"error": "rocprofv3 not found"}
+    scan = re.compile(SCAN_KERNEL_RE)
+    tot = {}       # counter -> total over the scan-kernel dispatches of the child
+    by_kernel = {}  # kernel family -> counter -> total
+    t0 = time.time()
+    for counters in (["FETCH_SIZE"], ["WRITE_SIZE"], ["TCC_HIT_sum", "TCC_MISS_sum"]):
+        tmp = tempfile.mkdtemp(prefix="tq_pmc_", dir="/tmp")
+        cmd = [exe, "--pmc"] + counters + ["--output-format", "csv", "-d", tmp, "-o", "p", "--", sys.executable,
+               os.path.abspath(__file__), "--pmc-child", workload, "--docs", str(args.docs), "--terms", str(args.terms),
+               "--queries", str(n_queries), "--k", str(k), "--steps", str(steps)]
+        env = dict(os.environ, TMPDIR="/tmp")
+        try:
+            r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=300)
+        except subprocess.TimeoutExpired:
+            shutil.rmtree(tmp, ignore_errors=True)
+            return {"error": "rocprofv3 pass timed out (%s)" % counters}
+        files = glob.glob(os.path.join(tmp, "**", "*counter_collection.csv"), recursive=True)
+        if r.returncode != 0 or not files:
+            shutil.rmtree(tmp, ignore_errors=True)
+            return {"error": "rocprofv3 pass failed (%s): rc %d %s" % (counters, r.returncode, (r.stderr or "")[-300:])}
+        for f in files:
+            with open(f) as fh:
+                for row in csv.DictReader(fh):
+                    m = scan.search(row["Kernel_Name"])
+                    if not m:
+                        continue
+                    c, v = row["Counter_Name"], float(row["Counter_Value"])
+                    tot[c] = tot.get(c, 0.0) + v
+                    fam = by_kernel.setdefault(m.group(1), {})
+                    fam[c] = fam.get(c, 0.0) + v
+        shutil.rmtree(tmp, ignore_errors=True)
+    if "FETCH_SIZE" not in tot:
+        return {"error": "no scan-kernel dispatch in the counter files"}
+
+    def fabric(d):
+        rd = 2.0 * d.get("FETCH_SIZE", 0.0) * 1024.0 / steps
+        wr = d.get("WRITE_SIZE", 0.0) * 1024.0 / steps
+        return rd, wr
+
+    rd, wr = fabric(tot)
+    hit, miss = tot.get("TCC_HIT_sum", 0.0), tot.get("TCC_MISS_sum", 0.0)
+    out = {"traffic": int(rd + wr), "read_bytes": int(rd), "write_bytes": int(wr),
+           "read_requests": int(rd / 128.0), "write_requests": int(wr / 64.0),
+           "l2_hit_rate": round(hit / (hit + miss), 4) if hit + miss > 0 else None,
+           "l2_misses": int(miss / steps), "steps": steps, "seconds": round(time.time() - t0, 1),
+           "by_kernel": {fam: {"traffic": int(sum(fabric(d))), "read_requests": int(fabric(d)[0] / 128.0)}
+                         for fam, d in sorted(by_kernel.items())},
+           "source": "rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE | TCC_HIT_sum TCC_MISS_sum (three passes, counters only) around "
+                     "`bench.py --pmc-child %s` in this run, %d synchronous pruned steps, scan-kernel dispatches only; "
+                     "bytes = 2 x FETCH_SIZE KiB x 1024 (gfx950: a 128-B fabric read request is tallied as 64 B) + "
+                     "WRITE_SIZE KiB x 1024; requests: reads of 128 B, writes counted as 64 B each (uncalibrated)" %
+                     (workload, steps)}
+    return out
+
+
+def stratified_sample(n_q, kernels_of, n_check):
+    """Indices of the queries to check against the oracle: spread evenly over the batch, every scan-kernel family
+    that ran gets at least min(32, its queries) of them (kernels_of: TQ_KERNEL_* bit per query, or None)."""
+    base = set(int(x) for x in np.linspace(0, n_q - 1, min(n_check, n_q)))
+    per = {}
+    if kernels_of is not None:
+        for fam in sorted(set(int(x) for x in kernels_of)):
+            idx = np.nonzero(kernels_of == fam)[0]
+            have = sum(1 for i in base if int(kernels_of[i]) == fam)
+            want = min(32, len(idx))
+            if have < want:
+                extra = [int(idx[int(j)]) for j in np.linspace(0, len(idx) - 1, want)]
+                base.update(extra)
+            per[fam] = sum(1 for i in base if int(kernels_of[i]) == fam)
+    return sorted(base), per
+
+
+def spot_check(O, cl, segs, first_ord, gstats, workload, queries, k, final, n_check=64, kernels_of=None):
     """A sample of the batch against the oracle, at the run's own size: every rank runs the oracle's
     exhaustive executor on each of its local segments with the index-wide Bm25Weights, the hits
     are gathered over the control plane (gloo), merged by the oracle's merge_top_k (score desc,
@@ -492,7 +626,7 @@ def spot_check(O, cl, segs, first_ord, gstats, workload, queries, k, final, n_ch
 
     n_q = len(queries)
     many = len(segs) > 1 or cl.world > 1
-    sample = sorted(set(int(x) for x in np.linspace(0, n_q - 1, min(n_check, n_q))))
+    sample, per_family = stratified_sample(n_q, kernels_of, n_check)
 
     def local_hits(i):
         hits = []
@@ -513,7 +647,125 @@ def spot_check(O, cl, segs, first_ord, gstats, workload, queries, k, final, n_ch
         assert len(got) == len(want), (workload, i, got, want)
         for (gs, go, gd), (ws, wo, wd) in zip(got, want):
             assert (go, gd) == (wo, wd) and abs(gs - ws) <= 1e-5 * abs(ws), (workload, i, got, want)
+    spot_check.last_by_family = per_family
     return len(sample)
+
+
+def query_kernels(runner, n_q):
+    """TQ_KERNEL_* bit of every query of the prepared batch in the pruned mode (one extra untimed step with the
+    library's "record_query_kernels" option; the local segments plan alike: segment 0 speaks for them)."""
+    runner.set_option("record_query_kernels", 1)
+    runner.set_option("exhaustive", 0)
+    runner.enqueue()
+    runner.synchronize()
+    kern = runner.dev.last_batch_query_kernels(n_q, 0)
+    runner.set_option("record_query_kernels", 0)
+    return kern
+
+
+def physical_roofline(k_ms, pm, committed, launches=1):
+    """roofline.achieved / frac / traffic from bytes that crossed the fabric: this run's inline PMC passes if they
+    ran, else the committed PMC run of the same kernel sources (profiles/traffic.json), else nothing."""
+    out = {"traffic": None, "achieved": None, "frac": None, "l2_hit_rate": None, "traffic_source": "none: no PMC run "
+           "(--no-pmc-inline or rocprofv3 failed) and no committed entry for this tree's kernels"}
+    if pm and pm.get("traffic"):
+        out.update(traffic=int(pm["traffic"] * launches), l2_hit_rate=pm.get("l2_hit_rate"), traffic_source=pm["source"],
+                   read_requests=int(pm["read_requests"] * launches), write_requests=int(pm["write_requests"] * launches),
+                   traffic_by_kernel=pm.get("by_kernel"), pmc_seconds=pm.get("seconds"))
+    elif committed and committed.get("traffic") is not None:
+        out.update(traffic=int(committed["traffic"]), l2_hit_rate=committed.get("l2_hit_rate"),
+                   traffic_source="profiles/traffic.json, commit %s (same kernel sources): %s" %
+                                  (committed.get("traffic_from_commit"), committed.get("traffic_note")))
+    if pm and pm.get("error"):
+        out["pmc_inline_error"] = pm["error"]
+    if out["traffic"] is not None and k_ms > 0:
+        out["achieved"] = round(out["traffic"] / (k_ms * 1e-3) / 1e9, 1)
+        out["frac"] = round(out["achieved"] / HBM_PEAK_GBS, 4)
+    return out
+
+
+ASHARE_COUNTERS = (("blocks_decoded", 256), ("block_lead_pairs", 32), ("scoring_stage_candidates", 64), ("docs_collected", 0),
+                   ("payload_bytes", 0x100000), ("fieldnorm_bytes", 0x200000), ("docmat_words", 0x400000),
+                   ("range_maxima_bytes", 0x800000))
+
+
+def ashare_useful_bytes(runner, queries, kern, k, ashare_bit, reads_ashare):
+    """Bytes the lanes of the shared-intersection launch CONSUME per batch, from its work counters (one untimed
+    step per counter on the sub-batch that rode in it — the library's "debug" option; no counter changes a
+    result): bit-packed payload + block records of the decoded leader blocks, one fieldnorm byte per decoded doc,
+    8 B per doc-matrix word gathered, the range-maxima bytes, 9 B (bitmap word + tf byte) per scoring-stage
+    candidate, 12 B (staging entry + threshold slot) per collected doc.  Task and lead records (16 / 64 B per
+    task / lead) are not counted.  request_efficiency = useful bytes / (128 B x the launch's fabric read requests)."""
+    sub = [q for q, kk in zip(queries, kern) if int(kk) == ashare_bit]
+    if len(sub) < 64:
+        return None
+    runner.prepare(sub, k)
+    runner.set_option("exhaustive", 0)
+    c = {}
+    for name, bit in ASHARE_COUNTERS:
+        runner.set_option("debug", bit)
+        runner.enqueue()
+        runner.synchronize()
+        c[name] = int(runner.batch_stats()["matches"])
+    runner.set_option("debug", -1)
+    useful = (c["payload_bytes"] + c["fieldnorm_bytes"] + 8 * c["docmat_words"] + c["range_maxima_bytes"]
+              + 9 * c["scoring_stage_candidates"] + 12 * c["docs_collected"])
+    out = {"queries": len(sub), "counters": c, "useful_bytes": int(useful)}
+    if reads_ashare:
+        out["fabric_read_requests"] = int(reads_ashare)
+        out["request_efficiency"] = round(useful / (128.0 * reads_ashare), 4)
+    return out
+
+
+def stream_block(O, D, cl, torch, args, vocab, seg, n_batches, n_q, k):
+    """tantivy's serving pattern: every batch is NEW — seeds s, s+1, ... of the headline stream — and
+    Query::weight (BM25 statistics, term lookups, tq_term_prepare of terms not seen before, their bitmaps /
+    range maxima / probe tables on first use: tqh_prepare_batch) runs INSIDE the timed region, on a segment no
+    query has touched.  Only the Python-side struct building of the request is done ahead.  Steps are pipelined
+    like the replayed-batch loop (Searcher::search_with_executor, searcher.rs:180-238)."""
+    runner = D.ShardRunner([seg], cl.local_rank)
+    runner.set_option("timing", 1)
+    batches = [[(O.MODE_AND, q.tolist()) for q in O.zipf_queries(n_q, 2, vocab, seed=20260921 + 7919 * (i + 1))]
+               for i in range(n_batches)]
+    marsh = [runner.dev.marshal(b) for b in batches]
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    runner.prepare(batches[0], k, marsh[0])  # cold: every term of the batch is prepared here
+    t_prep0 = time.perf_counter() - t0
+    runner.enqueue()
+    runner.synchronize()
+    cold_ms = (time.perf_counter() - t0) * 1e3
+    first = runner.results()
+    prep_s, t1 = 0.0, time.perf_counter()
+    n_warm = min(3, n_batches - 2)
+    for i in range(1, n_batches):
+        if i == 1 + n_warm:  # steady state from here: the first batches still meet new terms
+            runner.synchronize()
+            runner.batch_stats()
+            prep_s, t1 = 0.0, time.perf_counter()
+        tp = time.perf_counter()
+        runner.prepare(batches[i], k, marsh[i])
+        prep_s += time.perf_counter() - tp
+        runner.enqueue()
+    runner.synchronize()
+    wall = time.perf_counter() - t1
+    timed = n_batches - 1 - n_warm
+    st = runner.batch_stats()
+    # the last batch against the oracle (a stream that returned wrong rows fast would be worthless)
+    checked = spot_check(O, cl, [seg], cl.rank, None, "and2", batches[-1], k, runner.results(), 32)
+    seg_stats = runner.dev.segment_stats(0)
+    runner.close()
+    del first
+    return {"terms": vocab, "batches": n_batches, "queries_per_batch": n_q, "k": k,
+            "cold_first_batch_ms": round(cold_ms, 2), "cold_prepare_ms": round(t_prep0 * 1e3, 2),
+            "steady_batches_timed": timed, "steady_qps": round(n_q * timed / wall, 1),
+            "steady_ms_per_batch": round(wall / timed * 1e3, 3),
+            "prepare_ms_per_batch": round(prep_s / timed * 1e3, 3),
+            "prepare_share": round(prep_s / wall, 3),
+            "kernel_ms_avg": round(st["kernel_ms"], 4), "host_plan_ms": round(st["host_plan_ms"], 3),
+            "kernels": " + ".join(st.get("kernels") or []),
+            "derived_bytes": seg_stats["derived_bytes"], "tantivy_bytes": seg_stats["tantivy_bytes"],
+            "parity_checked_queries": checked}
 
 
 def resident_bytes(runner):
@@ -530,6 +782,8 @@ def resident_bytes(runner):
 
 def main():
     args = parse_args()
+    if args.pmc_child:
+        raise SystemExit(pmc_child(args))
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         raise SystemExit(relaunch_ranks(args))
     cl = Cluster()
@@ -609,10 +863,24 @@ def main():
         curve = latency_curve(runner.dev, queries, k)
 
     gstats_main = global_stats(all_stats)
+    runner.prepare(queries, k)  # (the latency legs prepared other batches)
+    kern_main = query_kernels(runner, n_q)  # which kernel family ran which query: the oracle sample covers every family
     parity_checked = spot_check(O, cl, main_segs, rank * S_main, gstats_main, args.workload, queries, k,
-                                m["final"], 64)
+                                m["final"], args.check_queries, kern_main)
+    parity_by_family = {tantivy_amd_kernel_name(b): c for b, c in spot_check.last_by_family.items()}
     main_resident = resident_bytes(runner)
     main_exchange_ms = runner.exchange_ms()
+    # ---- fabric traffic of this run's kernels (rocprofv3 passes around a child process) and what the lanes consume
+    pmc_on = world == 1 and S_main == 1 and not args.no_pmc_inline
+    pm_main = pmc_inline(args, args.workload, n_q, k) if (pmc_on and rank == 0 and pruned_mode) else None
+    useful = None
+    if world == 1 and S_main == 1 and pruned_mode and args.workload in ("and2", "and2_distinct"):
+        from tantivy_amd import binding as TB
+
+        reads_a = None
+        if pm_main and pm_main.get("by_kernel", {}).get("ashare_kernel"):
+            reads_a = pm_main["by_kernel"]["ashare_kernel"]["read_requests"]
+        useful = ashare_useful_bytes(runner, queries, kern_main, k, TB.KERNEL_ASHARE, reads_a)
     # The CPU baselines run AFTER every GPU measurement of the run: 10 s of all granted host cores
     # exhaust the cgroup's CPU quota, and the host planner of the next GPU measurement pays for it
     # (one run had the or5 step at 8.1 ms right after the baseline, 5.2 ms without).
@@ -622,6 +890,7 @@ def main():
 
     # ---------------------------------------------------------------- other BASELINE configs (N=1)
     side = {}
+    pm_mixed = {}  # the mixed stream's inline PMC figures (config 5 at N = 1 runs the same stream on 8 segments)
     if world == 1 and not args.no_side:
         for wl in os.environ.get("BENCH_SIDE_ORDER", "and2_distinct,or5,phrase3,mixed,bool").split(","):
             if wl == args.workload:
@@ -643,9 +912,17 @@ def main():
             sm = measure(cl, s_runner, torch, qs, kk, args.side_steps, 2)
             if not sm["mode_parity"]:
                 raise SystemExit("%s: pruned and exhaustive results differ on %d queries" % (wl, sm["n_diff"]))
-            checked = spot_check(O, cl, [s_seg], rank, None, wl, qs, kk, sm["final"], 64)
+            s_kern = query_kernels(s_runner, len(qs))
+            checked = spot_check(O, cl, [s_seg], rank, None, wl, qs, kk, sm["final"], args.check_queries, s_kern)
+            s_by_family = {tantivy_amd_kernel_name(b): c for b, c in spot_check.last_by_family.items()}
             k_ms = sm["stats"]["kernel_ms"]
             ach, fr = frac_of(sm["algo_bytes_full"], k_ms)
+            # this run's own PMC passes for every workload (about 10 s each): roofline_frac = bytes that crossed the
+            # fabric / kernel time / peak; the SURVEY 8d figure (algorithmic_frac) exceeds 1 where a launch shares lists
+            s_pm = pmc_inline(args, wl, len(qs), kk) if pmc_on else None
+            if wl == "mixed":
+                pm_mixed.update(s_pm or {})
+            phys = physical_roofline(k_ms, s_pm, traffic_fields(load_traffic("%s_pruned_%d" % (wl, args.docs)), 1, k_ms))
             ach_e, fr_e = frac_of(sm["algo_bytes_full"], sm["exh_stats"]["kernel_ms"])
             side[wl] = {
                 "config": "%s: %d queries/batch, k=%d, same %dM-doc segment%s" %
@@ -654,9 +931,11 @@ def main():
                 "qps": round(len(qs) * args.side_steps / sm["elapsed"], 1),
                 "ms_per_step": round(sm["elapsed"] / args.side_steps * 1e3, 3),
                 "kernel_ms_avg": round(k_ms, 4),
-                "roofline_achieved_GBps": ach, "roofline_frac": fr,
+                "roofline_achieved_GBps": phys["achieved"], "roofline_frac": phys["frac"],
+                "traffic": phys["traffic"], "l2_hit_rate": phys["l2_hit_rate"], "traffic_source": phys["traffic_source"],
+                "algorithmic_GBps": ach, "algorithmic_frac": fr,
                 "exhaustive_kernel_ms": round(sm["exh_stats"]["kernel_ms"], 4),
-                "exhaustive_roofline_frac": fr_e,
+                "exhaustive_algorithmic_frac": fr_e,
                 "algorithmic_bytes_per_launch": int(sm["algo_bytes_full"]),
                 "docs_scored_per_launch": int(sm["stats"]["matches"]),
                 "host_plan_ms": round(sm["stats"]["host_plan_ms"], 3),
@@ -664,8 +943,8 @@ def main():
                 "distinct_queries": len({(q[0], tuple(sorted(q[1]))) + tuple(map(str, q[2:])) for q in qs}),
                 "batch_unique_bytes": int(sm["stats"].get("unique_bytes", 0)),
                 "pruned_equals_exhaustive": True, "parity_checked_queries": checked,
+                "parity_checked_by_kernel": s_by_family,
             }
-            side[wl].update(traffic_fields(load_traffic("%s_pruned_%d" % (wl, args.docs)), 1, k_ms))
             if not args.no_cpu_baseline:
                 cpu_jobs.append((wl, [s_seg], wl, qs, kk, max(2.0, args.cpu_seconds / 3), False, None))
             if s_runner is not runner:
@@ -698,7 +977,14 @@ def main():
         k_ms = sm["stats"]["kernel_ms"]
         ach, fr = frac_of(sm["algo_bytes_full"], k_ms)
         gstats8 = global_stats(everyone)
-        checked8 = spot_check(O, cl, segs, ords[0], gstats8, "mixed", qs, kk, sm["final"], 64)
+        kern8 = query_kernels(srun, len(qs))
+        checked8 = spot_check(O, cl, segs, ords[0], gstats8, "mixed", qs, kk, sm["final"], args.check_queries, kern8)
+        by_family8 = {tantivy_amd_kernel_name(b): c for b, c in spot_check.last_by_family.items()}
+        # fabric bytes per step and GPU: the mixed stream's figure of this run (one segment, inline PMC passes) times
+        # the local segments — the per-segment traffic does not depend on how many segments share the GPU
+        # (profiles/r04_and2_s8_pmc.md: same FETCH per segment with 8 segments resident)
+        phys8 = physical_roofline(k_ms, pm_mixed if pm_mixed.get("traffic") else None,
+                                  traffic_fields(load_traffic("mixed_pruned_%d" % args.docs), s_local, k_ms), launches=s_local)
         res8 = resident_bytes(srun)
         strong = {
             "config": "BASELINE configs[4]: %d x %dM-doc segments (%dM docs), mixed 50%% 2-term AND / "
@@ -711,7 +997,9 @@ def main():
             "qps": round(len(qs) * strong_steps / sm["elapsed"], 1),
             "ms_per_step": round(sm["elapsed"] / strong_steps * 1e3, 3),
             "kernel_ms_per_gpu": round(k_ms, 4),
-            "roofline_achieved_GBps_per_gpu": ach, "roofline_frac_per_gpu": fr,
+            "roofline_achieved_GBps_per_gpu": phys8["achieved"], "roofline_frac_per_gpu": phys8["frac"],
+            "traffic_per_step_per_gpu": phys8["traffic"], "traffic_source": phys8["traffic_source"],
+            "algorithmic_GBps_per_gpu": ach, "algorithmic_frac_per_gpu": fr,
             "algorithmic_bytes_per_step_per_gpu": int(sm["algo_bytes_full"]),
             "resident_bytes_per_gpu": res8,
             "hbm_resident_note": "tantivy's bytes %.3f GB + derived side tables %.3f GB resident per GPU "
@@ -727,7 +1015,7 @@ def main():
                          "exchange_ms = all-gather + merge_top_k (stream events)",
             "plan_threads": int(os.environ.get("TQ_PLAN_THREADS", "1")),
             "exchange": cl.exchange_note, "pruned_equals_exhaustive": True,
-            "parity_checked_queries": checked8,
+            "parity_checked_queries": checked8, "parity_checked_by_kernel": by_family8,
             "parity_note": "oracle (exhaustive executor per segment, global Bm25Weights) -> gathered over "
                            "the control plane -> oracle merge_top_k, against the merged device result",
             "index_build_s": round(t_gen8, 2),
@@ -744,6 +1032,22 @@ def main():
             cl.dist.destroy_process_group()
         return
 
+    # the stream block: different batches, Query::weight inside the timed region (rank 0, one GPU)
+    stream = None
+    if world == 1 and S_main == 1 and not args.no_stream and args.workload == "and2":
+        stream = {"note": "and2 stream, %d NEW batches per vocabulary (seeds differ), one fresh 10M-doc segment each: "
+                          "tqh_prepare_batch (Query::weight: BM25 statistics, term lookups, tq_term_prepare and first-use "
+                          "tables) inside the timed region, steps pipelined; steady_* = after the first %d batches; "
+                          "replayed_qps = the headline loop's figure on the same vocabulary (one prepared batch replayed)" %
+                          (args.stream_batches, 1 + min(3, args.stream_batches - 2)), "by_terms": {}}
+        for vocab in [int(x) for x in args.stream_vocabs.split(",") if x]:
+            t_s = time.time()
+            v_seg = main_segs[0] if (vocab == args.terms and not with_pos) else O.synth_segment(args.docs, n_terms=vocab, segment_ord=rank)
+            sb = stream_block(O, D, cl, torch, args, vocab, v_seg, args.stream_batches, n_q, k)
+            sb["derived_x"] = round(sb["derived_bytes"] / max(1, sb["tantivy_bytes"]), 2)
+            sb["seconds"] = round(time.time() - t_s, 1)
+            stream["by_terms"][str(vocab)] = sb
+            del v_seg
     cpu = None
     for key, c_segs, c_wl, c_qs, c_k, c_sec, c_sweep, c_gs in cpu_jobs:
         c = cpu_baseline(O, c_segs, c_wl, c_qs, c_k, c_sec, sweep=c_sweep, gstats=c_gs)
@@ -769,6 +1073,7 @@ def main():
     if S_main != 1:
         tkey += "_s%d" % S_main
     tf = traffic_fields(load_traffic(tkey), S_main, k_ms)  # per step: one scan launch per local segment
+    phys = physical_roofline(k_ms, pm_main, tf)
     total_units = n_q * args.steps * world  # one unit = one query evaluated on one segment
     value = total_units / m["elapsed"]
     out = {
@@ -809,17 +1114,25 @@ def main():
         },
         "roofline": {
             "bound": "hbm",
-            "achieved": achieved,
+            "achieved": phys["achieved"],
             "peak": HBM_PEAK_GBS,
             "unit": "GB/s",
-            "frac": frac,
-            "traffic": tf["traffic"],
-            "physical_frac": tf["physical_frac"],
-            "l2_hit_rate": tf["l2_hit_rate"],
-            "traffic_from_commit": tf["traffic_from_commit"],
-            "traffic_matches_this_build": tf["traffic_matches_this_build"],
+            "frac": phys["frac"],
+            "traffic": phys["traffic"],
+            "traffic_source": phys["traffic_source"],
+            "fabric_read_requests": phys.get("read_requests"),
+            "fabric_write_requests": phys.get("write_requests"),
+            "traffic_by_kernel": phys.get("traffic_by_kernel"),
+            "l2_hit_rate": phys["l2_hit_rate"],
+            "pmc_inline_error": phys.get("pmc_inline_error"),
+            "pmc_inline_seconds": phys.get("pmc_seconds"),
+            "shared_launch_useful_bytes": useful,
+            "committed_pmc_run": {"traffic": tf["traffic"], "physical_frac": tf["physical_frac"],
+                                  "from_commit": tf["traffic_from_commit"], "matches_this_build": tf["traffic_matches_this_build"]},
             "kernel": " + ".join(st.get("kernels") or [args.workload + " scan kernels"]),
             "kernel_ms_avg": round(k_ms, 4),
+            "algorithmic_GBps": achieved,
+            "algorithmic_frac": frac,
             "algorithmic_bytes_per_launch": int(algo_bytes),
             "batch_unique_bytes": int(uniq_bytes),
             "unique_frac": round(uniq_bytes / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if k_ms > 0 else None,
@@ -835,11 +1148,14 @@ def main():
             "host_plan_ms": round(st["host_plan_ms"], 3),
             "exchange_ms": round(main_exchange_ms, 4),
             "resident_bytes": main_resident,
-            "frac_note": "frac = algorithmic bytes (SURVEY.md §8d: postings ranges + 1 B per match + 8k; "
-                         "what a full scan would read) / kernel time / 8 TB/s — the pruned kernel skips "
-                         "most of them, so this is work-equivalent bandwidth, not achieved HBM bandwidth; "
-                         "physical_frac = rocprofv3 fabric bytes (committed PMC run, calibrated per "
-                         "DESIGN.md §3.0) / kernel time / 8 TB/s",
+            "frac_note": "achieved / frac = bytes that crossed the L2's fabric side (traffic: this run's rocprofv3 "
+                         "passes, see traffic_source; Infinity-Cache hits included) / scan-kernel time (HIP events on "
+                         "the launch streams) / 8 TB/s: a fraction of the HBM peak, <= 1 by construction.  "
+                         "algorithmic_* = SURVEY.md 8d bytes (postings ranges of every query + 1 B per match + 8k: what "
+                         "one scan PER QUERY would read) / the same time: work-equivalent bandwidth — above the peak "
+                         "when the queries of a batch share leader blocks and block-max pruning skips the rest; "
+                         "shared_launch_useful_bytes = what the lanes of the shared launch consume (work counters), "
+                         "request_efficiency = that / (128 B x its fabric read requests)",
         },
         "roofline_other_mode": {"mode": "exhaustive" if pruned_mode else "pruned", "achieved": o_ach,
                                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": o_frac,
@@ -851,6 +1167,8 @@ def main():
                             "headline batch's own p50 is latency_curve.batch['10000'].p50_ms",
         "latency_curve": curve,
         "parity_checked_queries": parity_checked,
+        "parity_checked_by_kernel": parity_by_family,
+        "stream": stream,
         "other_workloads": side or None,
         "strong_scaling": strong,
     }

@@ -364,6 +364,10 @@ typedef struct tq_batch_stats {
 #define TQ_KERNEL_BSHARE 0x400u       /* ashare_kernel, boolean leads (TQ_MODE_BOOL, leader-major) */
 #define TQ_KERNEL_COUNT_BITMAPS 0x800u /* count_bitmap_kernel (tq_count_batch over bitmap words) */
 int tq_last_batch_stats(tq_segment *seg, tq_batch_stats *out);
+/* Which scan-kernel family (one TQ_KERNEL_* bit) evaluated every query of the last tq_search_batch* call on this
+ * segment; needs the option "record_query_kernels" set before that call (diagnosis / parity tooling: bench.py
+ * draws its oracle sample from every family a batch ran on). */
+int tq_last_batch_query_kernels(tq_segment *seg, uint32_t *out, uint32_t n_queries);
 /* Bytes the segment keeps resident in HBM, by kind: the reference's own sub-files (copied
  * verbatim) and the derived side tables of DESIGN.md section 2 — term tables (unrolled skip
  * records, coarse seek tables, decoded vint tails, position-block tables: what SkipReader /
@@ -425,7 +429,9 @@ int tq_segment_get_stats(tq_segment *seg, tq_segment_stats *out);
  *        "submit_window_us" (default 100): tq_submit / tq_search_one — how long the leader of a batch
  *        holds it open for the callers of the previous batch to come back with their next query
  *        (0 = launch with whatever is pending),
- *        "use_dpp" (0/1: DPP or ds_bpermute prefix sums) */
+ *        "use_dpp" (0/1: DPP or ds_bpermute prefix sums),
+ *        "record_query_kernels" (0/1, default 0: see tq_last_batch_query_kernels), "debug" (-1 = the TQ_DEBUG
+ *        environment word, else the kernels' diagnosis word for this segment: work counters / ablations) */
 int tq_set_option(tq_segment *seg, const char *name, int64_t value);
 
 #ifdef __cplusplus

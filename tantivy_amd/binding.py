@@ -91,7 +91,7 @@ EXPORTS = [
     "tq_search_batch_device_opts", "tq_merge_topk",
     "tq_merge_topk_device", "tq_decode_postings", "tq_decode_position_deltas",
     "tq_last_batch_stats", "tq_segment_get_stats", "tq_segment_reserve_columns", "tq_set_option", "tq_segment_set_alive_bitset", "tq_count_batch",
-    "tq_last_batch_match_counts", "tq_encoder_create", "tq_encoder_free", "tq_encode_postings",
+    "tq_last_batch_match_counts", "tq_last_batch_query_kernels", "tq_encoder_create", "tq_encoder_free", "tq_encode_postings",
     "tq_encode_positions", "tq_encode_postings_device", "tq_encode_positions_device",
     "tq_encoder_last_kernel_ms", "tq_comm_unique_id", "tq_comm_init", "tq_comm_free",
     "tq_comm_info", "tq_allgather_topk",
@@ -147,6 +147,7 @@ def lib():
     L.tq_segment_set_alive_bitset.argtypes = [vp, vp, C.c_size_t]
     L.tq_count_batch.argtypes = [vp, C.POINTER(TqQuery), C.c_uint32, u32p]
     L.tq_last_batch_match_counts.argtypes = [vp, u32p, C.c_uint32]
+    L.tq_last_batch_query_kernels.argtypes = [vp, u32p, C.c_uint32]
     u64p = C.POINTER(C.c_uint64)
     L.tq_encoder_create.argtypes = [vp, C.c_int, C.POINTER(vp)]
     L.tq_encoder_free.argtypes = [vp]
@@ -490,8 +491,17 @@ class DeviceIndex:
 
     def prepare(self, queries):
         """Query::weight for a batch (see _host_queries for the query tuples)."""
+        self.prepare_marshalled(self.marshal(queries))
+
+    def marshal(self, queries):
+        """The query tuples of a batch as the C structs tqh_prepare_batch takes (the Python side of a caller's
+        request decoding: done ahead of a timed region that is to hold Query::weight itself)."""
         qs, keep = self._host_queries(queries)
-        n = len(queries)
+        return qs, keep, len(queries)
+
+    def prepare_marshalled(self, m):
+        """Query::weight (+ tq_term_prepare and first-use tables of terms not seen before) for a marshalled batch."""
+        qs, _, n = m
         _check(lib().tqh_prepare_batch(self._s, qs, n), host=True)
         self._n_prepared = n
 
@@ -595,6 +605,12 @@ class DeviceIndex:
     def last_batch_match_counts(self, n, segment_ord=0):
         out = np.zeros(max(1, n), np.uint32)
         _check(lib().tq_last_batch_match_counts(self.segment_raw(segment_ord), _u32(out), n))
+        return out[:n]
+
+    def last_batch_query_kernels(self, n, segment_ord=0):
+        """TQ_KERNEL_* bit of every query of the last batch (option "record_query_kernels" set before it)."""
+        out = np.zeros(max(1, n), np.uint32)
+        _check(lib().tq_last_batch_query_kernels(self.segment_raw(segment_ord), _u32(out), n))
         return out[:n]
 
     def set_option(self, name, value, segment_ord=None):

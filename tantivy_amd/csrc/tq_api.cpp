@@ -286,6 +286,15 @@ int tq_last_batch_match_counts(tq_segment *s, uint32_t *out, uint32_t n) {
   return TQ_OK;
 }
 
+int tq_last_batch_query_kernels(tq_segment *s, uint32_t *out, uint32_t n) {
+  if (!s || !out) return fail(TQ_ERR_INVALID, "tq_last_batch_query_kernels: null argument");
+  TQ_SEGMENT_LOCK(s);
+  if (!s->opt.record_query_kernels || s->last_query_kernel.size() < n)
+    return fail(TQ_ERR_INVALID, "the last batch recorded %zu queries (option \"record_query_kernels\")", s->last_query_kernel.size());
+  memcpy(out, s->last_query_kernel.data(), (size_t)n * sizeof(uint32_t));
+  return TQ_OK;
+}
+
 int tq_count_batch(tq_segment *s, const tq_query *queries, uint32_t n_queries,
                    uint32_t *out_counts) {
   if (!s || (!queries && n_queries) || !out_counts)
@@ -417,6 +426,8 @@ int tq_set_option(tq_segment *s, const char *name, int64_t value) {
     s->opt.ashare_min_batch = (int)value;
   else if (!strcmp(name, "xunion_min_queries") && value >= 1 && value <= 0x7FFFFFFF)
     s->opt.xunion_min_queries = (int)value;
+  else if (!strcmp(name, "record_query_kernels"))
+    s->opt.record_query_kernels = value != 0;
   else if (!strcmp(name, "debug") && value >= -1 && value <= 0x7FFFFFFF)  // (diagnosis: the kernels' TQ_DEBUG word)
     s->opt.debug = (int)value;
   else if (!strcmp(name, "submit_window_us") && value >= 0 && value <= 1000000)

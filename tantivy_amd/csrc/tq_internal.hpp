@@ -98,6 +98,8 @@ struct PinnedBuf {
 
 struct TermHost {
   void *blob = nullptr;  // one device allocation holding every per-term array
+  const TqdTerm *d_self = nullptr;  // ... and a copy of the term's record as of its upload (rec / coarse / tail /
+                                    // payload fields: what the kernels that build its side tables read)
   void *dense_blob = nullptr;  // bitmap + rank directory of a dense list
   void *posdir_blob = nullptr; // position directory of a dense list with positions
   void *tf8_blob = nullptr;    // term freqs of a dense list as bytes (posting index -> min(tf, 255))
@@ -175,6 +177,7 @@ struct Options {
   // tq_submit / tq_search_one: how long the leader of a batch waits for the callers of the previous
   // batch to come back with their next query (0 = launch with whatever is pending)
   int submit_window_us = 100;
+  int record_query_kernels = 0;  // tq_last_batch_query_kernels: remember which scan-kernel family ran every query
   int debug = -1;  // >= 0: overrides TQ_DEBUG for this segment's launches (work counters / ablations: diagnosis only)
 };
 
@@ -242,6 +245,8 @@ struct tq_segment {
   TqdTerm *d_terms = nullptr;
   size_t d_terms_cap = 0;
   bool d_terms_dirty = false;
+  size_t d_terms_dirty_from = ~(size_t)0;  // the lowest term record changed since the last sync
+  size_t d_terms_synced = 0;               // records the device table holds (and batches in flight may read)
   size_t dense_bytes_total = 0;
   // The side tables of the dense lists (bitmaps + rank directories, byte-wide tfs, position directories,
   // plain lists) live in ONE device allocation of dense_budget() bytes, made with the first of them:
@@ -270,6 +275,7 @@ struct tq_segment {
   uint64_t share_table_lo = 0;
   bool share_span_ok = true;
   uint32_t last_batch_queries = 0;
+  std::vector<uint32_t> last_query_kernel;  // option "record_query_kernels": TQ_KERNEL_* of every query of the last batch
   PinnedBuf h_stage, h_out;
   // timing: a ring of event quadruples, one per batch, so that pipelined batches (no host sync
   // between them) can all be timed; tq_last_batch_stats averages the batches since its last call
@@ -637,6 +643,7 @@ struct CallOpts {
 };
 // ---- tq_terms.cpp
 int sync_terms(tq_segment *s, hipStream_t st);
+void mark_term_dirty(tq_segment *s, uint32_t handle);
 int build_flat(tq_segment *s, uint32_t handle, hipStream_t st, bool *ok);
 int order_after_last_batch(tq_segment *s, hipStream_t st);
 int wait_segment_idle(tq_segment *s);

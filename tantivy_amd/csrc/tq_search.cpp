@@ -15,8 +15,22 @@ int search_batch_impl(tq_segment *s, const tq_query *queries, uint32_t n_queries
   const auto tr0 = std::chrono::steady_clock::now();
   HIP_TRY(hipSetDevice(s->device));
   hipStream_t st = hip_stream ? (hipStream_t)hip_stream : s->stream;
-  int rc = sync_terms(s, st);
-  if (rc != TQ_OK) return rc;
+  // Terms prepared since the last batch: their records are APPENDED to the device table through this batch's
+  // staging blob (a device-to-device copy on the batch's stream, below) — the batches in flight never read beyond
+  // the records they were planned with, so nothing waits for them.  A grown table, or a changed record that a
+  // batch in flight may read, takes the blocking road (sync_terms).
+  int rc = TQ_OK;
+  size_t terms_from = 0, terms_to = 0;
+  if (s->d_terms_dirty) {
+    const size_t n_terms_now = s->h_dterms.size();
+    if (s->d_terms && n_terms_now <= s->d_terms_cap && s->d_terms_dirty_from >= s->d_terms_synced) {
+      terms_from = std::min(s->d_terms_dirty_from, n_terms_now);
+      terms_to = n_terms_now;
+    } else {
+      rc = sync_terms(s, st);
+      if (rc != TQ_OK) return rc;
+    }
+  }
   const int opt_exhaustive = co.exhaustive ? 1 : 0;
   // Boolean queries ride in the shared leader-major launch if every list they probe has a bitmap + tf
   // bytes: lists below "dense_ratio" get them the first time a boolean query names them ("probe_budget_x")
@@ -649,6 +663,9 @@ int search_batch_impl(tq_segment *s, const tq_query *queries, uint32_t n_queries
       stage += s->plan->xqueries.size() * sizeof(TqkDenseQuery);
     }
   }
+  stage = (stage + 15) & ~(size_t)15;
+  const size_t o_terms = stage;
+  stage += (terms_to - terms_from) * sizeof(TqdTerm);
   const auto tr1 = std::chrono::steady_clock::now();
   if (s->stage_in_flight) {  // (the pinned staging buffer is reused: the previous batch's copy must have left it)
     HIP_TRY(hipEventSynchronize(s->ev_stage_done));
@@ -667,6 +684,7 @@ int search_batch_impl(tq_segment *s, const tq_query *queries, uint32_t n_queries
   uint8_t *hs = (uint8_t *)s->h_stage.p;
   for (size_t c = 0; c < caches.size(); ++c)
     memcpy(hs + o_caches + c * 256 * sizeof(float), caches[c], 256 * sizeof(float));
+  if (terms_to > terms_from) memcpy(hs + o_terms, s->h_dterms.data() + terms_from, (terms_to - terms_from) * sizeof(TqdTerm));
   // the two big tables of a group (descriptors, chunk records: megabytes per 10 000-query batch) are
   // copied by the planner's threads, a quarter each
   auto big_copy = [&](uint8_t *dst, const void *src, size_t bytes) {
@@ -742,6 +760,13 @@ int search_batch_impl(tq_segment *s, const tq_query *queries, uint32_t n_queries
     HIP_TRY(hipEventRecord(s->ev_stage_done, st));
   }
   s->stage_in_flight = true;
+  if (terms_to > terms_from) {  // the new term records: staging blob -> the table's tail, in stream order before the kernels
+    HIP_TRY(hipMemcpyAsync(s->d_terms + terms_from, (const uint8_t *)dstage.p + o_terms, (terms_to - terms_from) * sizeof(TqdTerm),
+                           hipMemcpyDeviceToDevice, st));
+    s->d_terms_dirty = false;
+    s->d_terms_dirty_from = ~(size_t)0;
+    s->d_terms_synced = terms_to;
+  }
   HIP_TRY(hipMemsetAsync(s->d_match_counter, 0, sizeof(unsigned long long), st));
   HIP_TRY(hipMemsetAsync(s->d_qmatches.p, 0, (size_t)n_queries * sizeof(uint32_t), st));
   s->last_batch_queries = n_queries;
@@ -993,6 +1018,18 @@ int search_batch_impl(tq_segment *s, const tq_query *queries, uint32_t n_queries
     else
       e = tqk_launch_phrase(p, g.kpl, s->opt.use_dpp != 0, gst);
     if (e != hipSuccess) return fail(TQ_ERR_HIP, "scan kernel launch: %s", hipGetErrorString(e));
+  }
+  if (s->opt.record_query_kernels) {  // (diagnosis: which family ran which query, tq_last_batch_query_kernels)
+    s->last_query_kernel.assign(n_queries, 0u);
+    for (int gi = 0; gi < kGroups; ++gi) {
+      const Group &g = groups[gi];
+      if (g.queries.empty()) continue;
+      const uint32_t bit = gi == kAShare ? TQ_KERNEL_ASHARE : gi == kBShare ? TQ_KERNEL_BSHARE : gi == kShare ? TQ_KERNEL_USHARE
+                           : gi == kDense ? TQ_KERNEL_XUNION : gi == 0 ? TQ_KERNEL_AND_DENSE : gi == kAndGeneral ? TQ_KERNEL_AND
+                           : gi == kBool ? TQ_KERNEL_BOOL : gi == kPhSweep ? TQ_KERNEL_PHRASE_SWEEP : gi == 2 ? TQ_KERNEL_PHRASE
+                           : ((or_windows_opt && gi != kBool) ? TQ_KERNEL_OR_WINDOWS : TQ_KERNEL_UNION);
+      for (uint32_t qi : g.out_index) s->last_query_kernel[qi] = bit;
+    }
   }
   if (fork) {
     HIP_TRY(hipEventRecord(s->ev_join, s->side_stream));

@@ -78,7 +78,7 @@ int build_tf8(tq_segment *s, uint32_t handle, const uint32_t *d_tfs) {
   s->h_dterms[handle].tf8 = (const uint8_t *)blob;
   s->dense_bytes_total += bytes;
   s->bytes_bitmaps += bytes;
-  s->d_terms_dirty = true;
+  mark_term_dirty(s, handle);
   return TQ_OK;
 }
 
@@ -122,14 +122,12 @@ int build_flat(tq_segment *s, uint32_t handle, hipStream_t st, bool *ok) {
   const size_t doc_bytes = ((size_t)t.doc_freq * sizeof(uint32_t) + 15) & ~(size_t)15;
   const size_t bytes = doc_bytes + (((size_t)t.doc_freq + 15) & ~(size_t)15);
   if (s->dense_bytes_total + bytes > s->dense_budget()) return TQ_OK;
-  int rc = sync_terms(s, st);
-  if (rc != TQ_OK) return rc;
   void *blob = nullptr;
   {
     const int arc = dense_alloc(s, bytes + PAD, &blob);
     if (arc != TQ_OK) return arc;
   }
-  const hipError_t e = tqk_launch_flat_list(s->dseg, s->d_terms, handle, t.n_blocks, (uint32_t *)blob,
+  const hipError_t e = tqk_launch_flat_list(s->dseg, t.d_self, 0u, t.n_blocks, (uint32_t *)blob,
                                             (uint8_t *)blob + doc_bytes, st);
   if (e != hipSuccess) {
     dense_release(s, blob);
@@ -190,20 +188,18 @@ int add_to_doc_signatures(tq_segment *s, uint32_t handle) {
   int rc = ensure_docmat(s);
   if (rc != TQ_OK) return rc;
   if (!s->d_docmat) return TQ_OK;
-  rc = sync_terms(s, s->stream);
-  if (rc != TQ_OK) return rc;
   const size_t bytes = (size_t)t.doc_freq * sizeof(uint32_t);
   rc = s->d_misc.ensure(2 * bytes + 64);
   if (rc != TQ_OK) return rc;
   uint32_t *dd = (uint32_t *)s->d_misc.p, *dt = dd + t.doc_freq;
-  hipError_t e = tqk_launch_decode_list(s->dseg, s->d_terms, handle, t.n_blocks, dd, dt,
+  hipError_t e = tqk_launch_decode_list(s->dseg, t.d_self, 0u, t.n_blocks, dd, dt,
                                         s->opt.use_dpp != 0, s->stream);
   if (e != hipSuccess) return fail(TQ_ERR_HIP, "decode launch: %s", hipGetErrorString(e));
   const uint32_t bit = (handle * 0x9E3779B1u) >> (32 - 4);  // 0 .. TQD_SIG_BITS - 1
   e = tqk_launch_docmat_set(s->d_docmat, dd, t.doc_freq, (TQD_SIG_SHIFT - 8u) + bit, s->max_doc, s->stream);
   if (e != hipSuccess) return fail(TQ_ERR_HIP, "docmat signature: %s", hipGetErrorString(e));
   s->h_dterms[handle].has_freq |= (bit + 1u) << 16;
-  s->d_terms_dirty = true;
+  mark_term_dirty(s, handle);
   return TQ_OK;
 }
 
@@ -385,7 +381,8 @@ int tq_term_prepare(tq_segment *s, uint64_t postings_off, uint32_t postings_len,
   const size_t o_ttfs = place(4 * (size_t)n_tail);
   const size_t o_pboff = place(8 * pos_block_off.size());
   const size_t o_ptail = place(4 * pos_tail.size());
-  total += PAD;
+  const size_t o_self = place(sizeof(TqdTerm));  // the term's own record: what the table-building kernels of its
+  total += PAD;                                  // preparation read (the segment's term table is synced per batch)
   std::vector<uint8_t> hb(total, 0);
   for (uint32_t i = 0; i <= n_blocks; ++i) {
     const uint32_t r[4] = {i < n_blocks ? b_last[i] : TQ_TERMINATED, i < n_blocks ? b_meta[i] : 0u,
@@ -402,11 +399,6 @@ int tq_term_prepare(tq_segment *s, uint64_t postings_off, uint32_t postings_len,
   uint8_t *blob = nullptr;
   HIP_TRY(hipMalloc((void **)&blob, total));
   s->bytes_term_tables += total;
-  hipError_t ce = hipMemcpy(blob, hb.data(), total, hipMemcpyHostToDevice);
-  if (ce != hipSuccess) {
-    (void)hipFree(blob);
-    return fail(TQ_ERR_HIP, "term upload: %s", hipGetErrorString(ce));
-  }
   TqdTerm dt{};
   dt.rec = (const uint4 *)(blob + o_rec);
   dt.coarse = (const uint32_t *)(blob + o_coarse);
@@ -423,9 +415,16 @@ int tq_term_prepare(tq_segment *s, uint64_t postings_off, uint32_t postings_len,
   dt.n_pos_tail = (uint32_t)pos_tail.size();
   dt.has_freq = has_freq ? 1u : 0u;
   dt.coarse_shift = shift;
+  memcpy(hb.data() + o_self, &dt, sizeof dt);
+  hipError_t ce = hipMemcpy(blob, hb.data(), total, hipMemcpyHostToDevice);
+  if (ce != hipSuccess) {
+    (void)hipFree(blob);
+    return fail(TQ_ERR_HIP, "term upload: %s", hipGetErrorString(ce));
+  }
 
   TermHost th;
   th.blob = blob;
+  th.d_self = (const TqdTerm *)(blob + o_self);
   th.doc_freq = doc_freq;
   th.n_blocks = n_blocks;
   th.n_full = n_full;
@@ -467,7 +466,7 @@ int register_term(tq_segment *s, const TqdTerm &dt, const TermHost &th, uint64_t
   s->terms.push_back(th);
   s->terms.back().wants_col = !s->cols_reserved || s->reserved_cols.count(postings_off) != 0;
   s->h_dterms.push_back(dt);
-  s->d_terms_dirty = true;
+  mark_term_dirty(s, handle);
   s->term_by_off.emplace(postings_off, handle);
   *out = handle;
   // 0.25 B/doc per bitmap: worth it for lists whose 128-doc blocks span few docs, and only while
@@ -511,6 +510,7 @@ int term_prepare_device(tq_segment *s, uint64_t postings_off, uint32_t postings_
   const size_t o_coarse = place(4 * (size_t)(n_buckets + 1));
   const size_t o_tdocs = place(4 * (size_t)n_tail);
   const size_t o_ttfs = place(4 * (size_t)n_tail);
+  const size_t o_self = place(sizeof(TqdTerm));
   total += PAD;
   uint8_t *blob = nullptr;
   HIP_TRY(hipMalloc((void **)&blob, total));
@@ -604,8 +604,16 @@ int term_prepare_device(tq_segment *s, uint64_t postings_off, uint32_t postings_
   dt.n_pos_tail = n_pos_tail;
   dt.has_freq = info.record != TQ_BASIC ? 1u : 0u;
   dt.coarse_shift = shift;
+  {
+    const hipError_t se = hipMemcpy(blob + o_self, &dt, sizeof dt, hipMemcpyHostToDevice);
+    if (se != hipSuccess) {
+      if (pblob) (void)hipFree(pblob);
+      return bail(fail(TQ_ERR_HIP, "term record upload: %s", hipGetErrorString(se)));
+    }
+  }
   TermHost th;
   th.blob = blob;
+  th.d_self = (const TqdTerm *)(blob + o_self);
   th.pos_blob = pblob;
   th.doc_freq = doc_freq;
   th.n_blocks = n_blocks;
@@ -625,8 +633,7 @@ int term_prepare_device(tq_segment *s, uint64_t postings_off, uint32_t postings_
 // tq_decode_postings), bitmap bits set by atomic OR, rank directory and position directory by grid-wide
 // scans (tq_prepare.hip); 4 bytes (the validity flag) come back.
 int build_dense_device(tq_segment *s, uint32_t handle) {
-  int rc = sync_terms(s, s->stream);
-  if (rc != TQ_OK) return rc;
+  int rc = TQ_OK;
   TermHost &t = s->terms[handle];
   const size_t bytes = (size_t)t.doc_freq * sizeof(uint32_t);
   const size_t n_words = ((size_t)s->max_doc + 31) / 32 + 1;
@@ -637,7 +644,7 @@ int build_dense_device(tq_segment *s, uint32_t handle) {
   uint32_t *dd = (uint32_t *)s->d_misc.p, *dt = dd + t.doc_freq;
   uint32_t *scan_scratch = dt + t.doc_freq + 16;  // (tile sums of the scans below)
   uint32_t *rm_acc = scan_scratch + scan_words;
-  hipError_t e = tqk_launch_decode_list(s->dseg, s->d_terms, handle, t.n_blocks, dd, dt,
+  hipError_t e = tqk_launch_decode_list(s->dseg, t.d_self, 0u, t.n_blocks, dd, dt,
                                         s->opt.use_dpp != 0, s->stream);
   if (e != hipSuccess) return fail(TQ_ERR_HIP, "decode launch: %s", hipGetErrorString(e));
   rc = build_tf8(s, handle, dt);
@@ -668,7 +675,7 @@ int build_dense_device(tq_segment *s, uint32_t handle) {
   }
   t.dense_blob = blob;
   s->h_dterms[handle].dense = (const uint2 *)blob;
-  s->d_terms_dirty = true;
+  mark_term_dirty(s, handle);
   if (s->n_mat_slots < TQD_MAT_SLOTS && s->opt.docmat && t.wants_col) {  // the list's column of the doc matrix
     {
       const int mrc = ensure_docmat(s);
@@ -727,8 +734,7 @@ int build_probe_tables(tq_segment *s, uint32_t handle, bool *ok) {
     return TQ_OK;
   }
   HIP_TRY(hipSetDevice(s->device));
-  int rc = sync_terms(s, s->stream);
-  if (rc != TQ_OK) return rc;
+  int rc = TQ_OK;
   const size_t bytes = (size_t)t.doc_freq * sizeof(uint32_t);
   const size_t scan_words = tqp_scan_scratch_words((uint32_t)n_words);
   rc = s->d_misc.ensure(2 * bytes + 64 + (scan_words + ((size_t)s->max_doc >> TQD_RM_SHIFT) + 8) * sizeof(uint32_t));
@@ -736,7 +742,7 @@ int build_probe_tables(tq_segment *s, uint32_t handle, bool *ok) {
   uint32_t *dd = (uint32_t *)s->d_misc.p, *dt = dd + t.doc_freq;
   uint32_t *scan_scratch = dt + t.doc_freq + 16;
   uint32_t *rm_acc = scan_scratch + scan_words;
-  hipError_t e = tqk_launch_decode_list(s->dseg, s->d_terms, handle, t.n_blocks, dd, dt, s->opt.use_dpp != 0, s->stream);
+  hipError_t e = tqk_launch_decode_list(s->dseg, t.d_self, 0u, t.n_blocks, dd, dt, s->opt.use_dpp != 0, s->stream);
   if (e != hipSuccess) return fail(TQ_ERR_HIP, "decode launch: %s", hipGetErrorString(e));
   void *tfb = nullptr, *blob = nullptr;
   rc = dense_alloc(s, tf_bytes + PAD, &tfb);
@@ -770,10 +776,19 @@ int build_probe_tables(tq_segment *s, uint32_t handle, bool *ok) {
   return TQ_OK;
 }
 
+void mark_term_dirty(tq_segment *s, uint32_t handle) {
+  s->d_terms_dirty = true;
+  s->d_terms_dirty_from = std::min<size_t>(s->d_terms_dirty_from, handle);
+}
+
+// The device copy of the term table, brought up to date (blocking form: codec access, Count, a grown table).
+// tq_search_batch* takes the cheap road when it can: the records of the terms prepared since the last batch are
+// appended through the batch's own staging blob (terms_pending_sync / tq_search.cpp) — no wait for the batches in
+// flight, which never read beyond the entries they were planned with.
 int sync_terms(tq_segment *s, hipStream_t st) {
   if (!s->d_terms_dirty) return TQ_OK;
   const size_t n = s->h_dterms.size();
-  // nothing in flight may still read the table while it is rewritten (terms are prepared rarely)
+  // nothing in flight may still read the table while it is rewritten
   {
     const int wrc = wait_segment_idle(s);
     if (wrc != TQ_OK) return wrc;
@@ -782,12 +797,18 @@ int sync_terms(tq_segment *s, hipStream_t st) {
     HIP_TRY(hipStreamSynchronize(st));
     if (s->d_terms) (void)hipFree(s->d_terms);
     s->d_terms = nullptr;
-    size_t cap = std::max<size_t>(256, n * 2);
+    s->d_terms_cap = 0;
+    size_t cap = std::max<size_t>(1024, n * 2);
     HIP_TRY(hipMalloc((void **)&s->d_terms, cap * sizeof(TqdTerm)));
     s->d_terms_cap = cap;
+    s->d_terms_dirty_from = 0;
   }
-  HIP_TRY(hipMemcpy(s->d_terms, s->h_dterms.data(), n * sizeof(TqdTerm), hipMemcpyHostToDevice));
+  const size_t from = std::min(s->d_terms_dirty_from, n);
+  if (n > from)
+    HIP_TRY(hipMemcpy(s->d_terms + from, s->h_dterms.data() + from, (n - from) * sizeof(TqdTerm), hipMemcpyHostToDevice));
   s->d_terms_dirty = false;
+  s->d_terms_dirty_from = ~(size_t)0;
+  s->d_terms_synced = n;
   return TQ_OK;
 }
 

