@@ -60,7 +60,8 @@ enum tq_record_option { TQ_BASIC = 0, TQ_WITH_FREQS = 1, TQ_WITH_FREQS_AND_POSIT
  * OR     = all-Should term clauses -> block_wand / BufferedUnionScorer
  * PHRASE = PhraseQuery (slop 0)    -> PhraseScorer */
 enum tq_mode { TQ_MODE_AND = 0, TQ_MODE_OR = 1, TQ_MODE_PHRASE = 2, TQ_MODE_BOOL = 3 };
-/* TQ_MODE_BOOL = BooleanQuery whose clauses are terms or unions of terms, with mixed occurs
+/* TQ_MODE_BOOL = BooleanQuery whose clauses are terms or BooleanQuerys of terms (unions of terms; since round 5
+ * also nested intersections / exclusions / minimums: tq_query.nested_occurs), with mixed occurs
  * (`+a b -c`, `+a +(b OR c)`, `+(a OR b) +(c OR d)`) and minimum_number_should_match: the
  * Intersection / RequiredOptionalScorer / Exclude / Disjunction part of
  * BooleanWeight::complex_scorer (boolean_weight.rs:236-431, intersection.rs:20-56,
@@ -93,6 +94,18 @@ typedef struct tq_query {
                                     one nested all-Should BooleanQuery, `+a +(b OR c)`); NULL =
                                     every term is its own clause */
   uint32_t min_should_match;     /* TQ_MODE_BOOL: BooleanQuery::minimum_number_should_match */
+  /* TQ_MODE_BOOL, one level of nesting beyond unions of terms (round 5): a clause_of group is a nested
+   * BooleanQuery of terms, every term with its own occur INSIDE it — `+a +(+b +c)`, `(+b +c) d`, `+a -(+b +c)`,
+   * `+a +(+b c -d)` — and its own minimum_number_should_match.  Both NULL (or every nested occur TQ_SHOULD and every
+   * nested minimum <= 1) = unions of terms as before.  Evaluated over the lists' bitmaps (TQ_KERNEL_TREE). */
+  const uint8_t *nested_occurs;      /* n_terms x enum tq_occur: the term's occur inside its clause_of group; or NULL */
+  const uint8_t *clause_min_should;  /* TQ_MAX_TERMS entries indexed by clause_of value: the nested query's
+                                        minimum_number_should_match; or NULL */
+  const uint8_t *atom_of;            /* n_terms values, or NULL: terms of one clause_of group that share an atom_of
+                                        value form a CONJUNCTION — a BooleanQuery of Must terms one level further down,
+                                        `+a +((+b +c) d)`: present where all its terms are, scoring their sum; its occur
+                                        inside the group is nested_occurs of its terms (equal for all of them).  NULL =
+                                        every term is its own member of its group. */
 } tq_query;
 
 /* ---- lifecycle ---- */
@@ -363,6 +376,7 @@ typedef struct tq_batch_stats {
 #define TQ_KERNEL_ASHARE 0x200u       /* ashare_kernel (intersections, leader-major for the batch) */
 #define TQ_KERNEL_BSHARE 0x400u       /* ashare_kernel, boolean leads (TQ_MODE_BOOL, leader-major) */
 #define TQ_KERNEL_COUNT_BITMAPS 0x800u /* count_bitmap_kernel (tq_count_batch over bitmap words) */
+#define TQ_KERNEL_TREE 0x1000u         /* tree_kernel (nested boolean queries over bitmap words) */
 int tq_last_batch_stats(tq_segment *seg, tq_batch_stats *out);
 /* Which scan-kernel family (one TQ_KERNEL_* bit) evaluated every query of the last tq_search_batch* call on this
  * segment; needs the option "record_query_kernels" set before that call (diagnosis / parity tooling: bench.py

@@ -30,9 +30,11 @@ typedef struct tqh_term_info {
  *       (`+a +(b OR c)`) or, with nested_occurs, a BooleanQuery with an occur per term
  *       (`+a +(+b -c)`: clause_of {0,1,1}, occurs {1,1,1}, nested_occurs {255,1,2}; 255 / NULL =
  *       Should).  A Must clause holding a nested query with a Must term is hoisted into its
- *       parent (boolean_weight.rs:308-431: same docs, same score terms); other nestings
- *       (an intersection inside a union or under MustNot) are TQ_ERR_UNSUPPORTED and stay on
- *       tantivy's CPU scorer;
+ *       parent (boolean_weight.rs:308-431: same docs, same score terms); the other nestings of
+ *       depth 2 — an intersection inside a union or under MustNot, nested MustNot / optional
+ *       terms, a nested minimum_number_should_match (clause_min_should) — run on the device over
+ *       the lists' bitmaps (TQ_KERNEL_TREE); deeper trees and phrases inside boolean queries are
+ *       TQ_ERR_UNSUPPORTED and stay on tantivy's CPU scorer;
  *       min_should_match as BooleanQuery::set_minimum_number_should_match —
  *       plus TQH_MODE_TERM (4) = TermQuery.  Anything else: TQ_ERR_INVALID. */
 #define TQH_MODE_TERM 4
@@ -48,6 +50,11 @@ typedef struct tqh_query {
                           PHRASE: boosts[0] wraps the PhraseQuery; NULL = 1 */
   const uint8_t *nested_occurs; /* TQ_MODE_BOOL: occur of a term inside its clause_of group (read for
                                    groups of >= 2 terms); NULL = unions */
+  const uint8_t *clause_min_should; /* TQ_MODE_BOOL: minimum_number_should_match of the nested query of a
+                                       clause_of group, 16 entries indexed by the clause_of value; NULL = 0 */
+  const uint8_t *atom_of; /* TQ_MODE_BOOL: terms of one clause_of group sharing an atom_of value are ONE member of the
+                             nested query — an intersection of terms one level further down (`+a +((+b +c) d)`:
+                             clause_of {0,1,1,1}, atom_of {0,1,1,2}, nested_occurs {-,0,0,0}); NULL = every term its own */
 } tqh_query;
 
 const char *tqh_last_error(void);

@@ -803,6 +803,109 @@ def bool_match_all(seg, term_ids, occurs, clause_of=None, min_should_match=0):
     return docs.astype(np.uint32), score[docs]
 
 
+def _combine_scorers(md, items, msm):
+    """BooleanWeight::complex_scorer (src/query/boolean_query/boolean_weight.rs:236-431) over already evaluated
+    sub-scorers: items = [(occur, (hit bool[md], score f32[md], cost))].  Returns (match, score, cost) or None for
+    an EmptyScorer.  Must scorers intersect cheapest first, Intersection::score = left + right + sum(others)
+    (intersection.rs:31,325-329); Should scorers: removed when empty (:255-257), minimum_number_should_match
+    (:272-305) above their number matches nothing, == all of them (>= 2) makes them Must, else a union /
+    disjunction that is required (no Must, or minimum >= 1) or optional (RequiredOptionalScorer::score = req + opt,
+    reqopt_scorer.rs:85-98); MustNot scorers exclude (exclude.rs); MustNot alone matches nothing (:340-349).
+    cost: an intersection costs its cheapest member (size_hint of the left scorer), a union the sum of its members
+    (buffered_union.rs:326-328)."""
+    must = [x for o, x in items if o == MUST]
+    if any(x is None or not x[0].any() for x in must):
+        return None
+    should = [x for o, x in items if o == SHOULD and x is not None and x[0].any()]
+    mustnot = [x for o, x in items if o == MUST_NOT and x is not None]
+    if msm > len(should):
+        return None
+    if msm >= 2 and msm == len(should):
+        must, should, msm = must + should, [], 0
+    n_hit = np.zeros(md, np.int32)
+    opt = np.zeros(md, np.float32)
+    for hit, sc, _ in should:
+        opt = (opt + np.where(hit, sc, np.float32(0))).astype(np.float32)
+        n_hit += hit
+    if must:
+        must = sorted(must, key=lambda c: c[2])  # stable, like sort_by_key(cost)
+        match = np.ones(md, bool)
+        for hit, _, _ in must:
+            match &= hit
+        score = must[0][1]
+        if len(must) > 1:
+            score = (score + must[1][1]).astype(np.float32)
+        if len(must) > 2:
+            oth = np.zeros(md, np.float32)
+            for _, sc, _ in must[2:]:
+                oth = (oth + sc).astype(np.float32)
+            score = (score + oth).astype(np.float32)
+        if should:
+            score = (score + opt).astype(np.float32)
+            if msm:
+                match &= n_hit >= msm
+        cost = must[0][2]
+    elif should:
+        match, score = n_hit >= max(1, msm), opt
+        cost = sum(c for _, _, c in should)
+    else:
+        return None
+    for hit, _, _ in mustnot:
+        match = match & ~hit
+    return match, np.where(match, score, np.float32(0)).astype(np.float32), cost
+
+
+def tree_match_all(seg, clauses, min_should_match=0):
+    """A BooleanQuery whose clauses are terms or BooleanQuerys of terms (depth 2), restated from
+    BooleanWeight::complex_scorer applied on both levels (boolean_weight.rs:236-431; the nested query's scorer is
+    just another Box<dyn Scorer> of its parent, :225-233).  clauses = [(occur, term_id) |
+    (occur, [(inner occur, term_id | [term ids of a nested intersection]), ...], nested minimum_number_should_match)].  Every term scores with its own
+    Bm25Weight.  Returns (docs ascending, f32 scores).  Sums of 3+ terms compare within 1e-5 (the reference's own
+    order follows scorer removal / cursor order)."""
+    md = seg.max_doc
+    per = {}
+
+    def leaf(t):
+        if t not in per:
+            hit = np.zeros(md, bool)
+            sc = np.zeros(md, np.float32)
+            if seg.terms[t].doc_freq:
+                d, s = match_all(seg, [t], MODE_OR)
+                hit[d] = True
+                sc[d] = s
+            per[t] = (hit, sc, seg.terms[t].doc_freq)
+        return per[t]
+
+    items = []
+    for cl in clauses:
+        if isinstance(cl[1], (list, tuple)):
+            inner_msm = cl[2] if len(cl) > 2 else 0
+            members = []
+            for o, t in cl[1]:
+                if isinstance(t, (list, tuple)):  # an intersection of terms one level further down
+                    members.append((o, _combine_scorers(md, [(MUST, leaf(x)) for x in t], 0)))
+                else:
+                    members.append((o, leaf(t)))
+            items.append((cl[0], _combine_scorers(md, members, inner_msm)))
+        else:
+            items.append((cl[0], leaf(cl[1])))
+    res = _combine_scorers(md, items, min_should_match)
+    if res is None:
+        return np.zeros(0, np.uint32), np.zeros(0, np.float32)
+    docs = np.nonzero(res[0])[0]
+    return docs.astype(np.uint32), res[1][docs]
+
+
+def tree_search(seg, clauses, k, min_should_match=0, deleted=None):
+    """Top-k of tree_match_all by (score desc, doc asc): [(score, doc)]."""
+    d, s = tree_match_all(seg, clauses, min_should_match)
+    if deleted is not None and len(d):
+        keep = ~np.isin(d, deleted)
+        d, s = d[keep], s[keep]
+    order = np.lexsort((d, -s.astype(np.float64)))[:k]
+    return [(float(s[i]), int(d[i])) for i in order]
+
+
 def bool_spec(seg, term_ids, occurs, clause_of=None, min_should_match=0, k=1, boosts=None,
               total_num_docs=None, total_num_tokens=None, dfs=None):
     """QuerySpec of a boolean query for the C executor restatement (generic scorer tree); with the

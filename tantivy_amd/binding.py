@@ -27,7 +27,9 @@ class TqQuery(C.Structure):
                 ("weights", C.POINTER(C.c_float)), ("tf_cache", C.POINTER(C.c_float)),
                 ("mode", C.c_uint8), ("phrase_offsets", C.POINTER(C.c_uint32)),
                 ("k", C.c_uint32), ("occurs", C.POINTER(C.c_uint8)),
-                ("clause_of", C.POINTER(C.c_uint8)), ("min_should_match", C.c_uint32)]
+                ("clause_of", C.POINTER(C.c_uint8)), ("min_should_match", C.c_uint32),
+                ("nested_occurs", C.POINTER(C.c_uint8)), ("clause_min_should", C.POINTER(C.c_uint8)),
+                ("atom_of", C.POINTER(C.c_uint8))]
 
 
 class TqSearchOpts(C.Structure):
@@ -49,8 +51,10 @@ KERNEL_AND_DENSE, KERNEL_AND, KERNEL_UNION, KERNEL_OR_WINDOWS, KERNEL_PHRASE = 0
 KERNEL_PHRASE_SWEEP, KERNEL_BOOL, KERNEL_USHARE, KERNEL_XUNION, KERNEL_ASHARE = 0x20, 0x40, 0x80, 0x100, 0x200
 KERNEL_BSHARE = 0x400
 KERNEL_COUNT_BITMAPS = 0x800
+KERNEL_TREE = 0x1000
 KERNEL_NAMES = {0x1: "and_dense", 0x2: "and", 0x4: "union", 0x8: "or_windows", 0x10: "phrase", 0x20: "phrase_sweep",
-                0x40: "bool", 0x80: "ushare", 0x100: "xunion", 0x200: "ashare", 0x400: "bshare", 0x800: "count_bitmaps"}
+                0x40: "bool", 0x80: "ushare", 0x100: "xunion", 0x200: "ashare", 0x400: "bshare", 0x800: "count_bitmaps",
+                0x1000: "tree"}
 
 
 def kernel_names(mask):
@@ -79,7 +83,8 @@ class TqhQuery(C.Structure):
     _fields_ = [("mode", C.c_uint8), ("n_terms", C.c_uint32), ("terms", C.POINTER(C.c_uint32)),
                 ("phrase_offsets", C.POINTER(C.c_uint32)), ("occurs", C.POINTER(C.c_uint8)),
                 ("clause_of", C.POINTER(C.c_uint8)), ("min_should_match", C.c_uint32),
-                ("boosts", C.POINTER(C.c_float)), ("nested_occurs", C.POINTER(C.c_uint8))]
+                ("boosts", C.POINTER(C.c_float)), ("nested_occurs", C.POINTER(C.c_uint8)),
+                ("clause_min_should", C.POINTER(C.c_uint8)), ("atom_of", C.POINTER(C.c_uint8))]
 
 
 _lib = None
@@ -468,6 +473,14 @@ class DeviceIndex:
                 na = (C.c_uint8 * len(terms))(*[int(o) for o in extra["nested_occurs"]])
                 keep.append(na)
                 qs[i].nested_occurs = C.cast(na, C.POINTER(C.c_uint8))
+            if extra and extra.get("atom_of") is not None:
+                aa = (C.c_uint8 * len(terms))(*[int(o) for o in extra["atom_of"]])
+                keep.append(aa)
+                qs[i].atom_of = C.cast(aa, C.POINTER(C.c_uint8))
+            if extra and extra.get("clause_min_should") is not None:  # {clause_of value: nested minimum}
+                ma = (C.c_uint8 * 16)(*[int(extra["clause_min_should"].get(c, 0)) for c in range(16)])
+                keep.append(ma)
+                qs[i].clause_min_should = C.cast(ma, C.POINTER(C.c_uint8))
             ta = (C.c_uint32 * len(terms))(*[int(t) for t in terms])
             keep.append(ta)
             qs[i].mode = mode

@@ -13,6 +13,7 @@ SOURCES = [
     os.path.join(HERE, "csrc", "tq_ushare.hip"),
     os.path.join(HERE, "csrc", "tq_ashare.hip"),
     os.path.join(HERE, "csrc", "tq_count.hip"),
+    os.path.join(HERE, "csrc", "tq_tree.hip"),
     os.path.join(HERE, "csrc", "tq_count.cpp"),
     os.path.join(HERE, "csrc", "tq_xunion.hip"),
     os.path.join(HERE, "csrc", "tq_phrase.hip"),
@@ -64,7 +65,7 @@ def csrc_hash():
 
 # which translation unit a scan kernel of a rocprofv3 trace comes from
 KERNEL_FILES = {"and_kernel": "tq_and.hip", "union_kernel_small": "tq_union.hip", "union_kernel": "tq_union.hip",
-                "or_kernel": "tq_union.hip", "ushare_kernel": "tq_ushare.hip", "ashare_kernel": "tq_ashare.hip", "count_bitmap_kernel": "tq_count.hip", "xunion_kernel": "tq_xunion.hip",
+                "or_kernel": "tq_union.hip", "ushare_kernel": "tq_ushare.hip", "ashare_kernel": "tq_ashare.hip", "count_bitmap_kernel": "tq_count.hip", "tree_kernel": "tq_tree.hip", "xunion_kernel": "tq_xunion.hip",
                 "phrase_sweep_kernel": "tq_phrase.hip", "phrase_kernel": "tq_phrase.hip"}
 
 

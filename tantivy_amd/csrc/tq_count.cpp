@@ -17,6 +17,7 @@ bool count_expression(tq_segment *s, const tq_query &q, TqkCountQuery &cq, bool 
   cq = TqkCountQuery{};
   if (!q.terms || q.n_terms == 0 || q.n_terms > TQ_MAX_TERMS || q.mode == TQ_MODE_PHRASE || q.mode > TQ_MODE_BOOL) return false;
   if (q.mode == TQ_MODE_BOOL && !q.occurs) return false;
+  if (bool_query_is_tree(q)) return false;  // (nested queries: the scan — tq_tree.hip — counts them from bitmap words itself)
   struct Clause {
     uint32_t id, occur, n = 0, terms[TQ_MAX_TERMS];
     uint64_t cost = 0;

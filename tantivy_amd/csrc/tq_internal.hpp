@@ -401,6 +401,7 @@ struct Group {
   std::vector<uint32_t> tile_starts;
   std::vector<uint4> chunk_recs;      // launch order: {first tile, end tile, first query, chunk}
   std::vector<uint32_t> tile_cost;  // per query, cost units per tile
+  std::vector<TqdTreeQuery> tree;   // group 10: the nested boolean queries' descriptors (tq_tree.hip), one per query
   uint32_t total_tiles = 0, n_chunks = 0, max_k = 1;
   uint64_t list_entries = 0;  // term-major / doc-major groups: 8-byte entries of the group's result lists
   int kpl = 1;
@@ -413,6 +414,7 @@ struct Group {
     tile_starts.clear();
     chunk_recs.clear();
     tile_cost.clear();
+    tree.clear();
     total_tiles = 0;
     n_chunks = 0;
     list_entries = 0;
@@ -443,7 +445,7 @@ struct ShareKey {  // one (query, list) pair of the shared-union group
 // launch groups of a batch: 0 AND over bitmap lists, 1 unions, 2 phrases, 3 AND over any lists, 4 boolean
 // queries, 5 shared unions, 6 phrase sweep, 7 doc-major unions, 8 shared intersections, 9 boolean queries
 // through the shared-intersection launch
-constexpr int kNGroups = 10;
+constexpr int kNGroups = 11;  // (10: nested boolean queries over bitmaps, tq_tree.hip)
 struct QuerySlab {  // one slab of a batch's queries, planned by one thread into groups of its own
   Group groups[kNGroups];
   uint32_t n_thr_rows = 0;
@@ -659,6 +661,8 @@ int build_ashare_plan(tq_segment *s, Group &g, PlanScratch &ps, bool boolean = f
 int build_dense_plan(tq_segment *s, Group &g, PlanScratch &ps, uint32_t cus);
 int plan_bool_query(tq_segment *s, const tq_query &q, uint32_t qi, TqdQuery &dq, uint64_t &qbytes,
                     uint32_t &n_tiles, uint32_t &tile_cost, uint32_t &n_thr_rows, bool exhaustive);
+bool bool_query_is_tree(const tq_query &q);
+int plan_tree_query(tq_segment *s, const tq_query &q, uint32_t qi, TqdTreeQuery &tq, uint64_t &qbytes, uint64_t table_base);
 // ---- tq_search.cpp
 int resolve_opts(const tq_segment *s, const tq_search_opts *o, CallOpts &co);
 int search_batch_impl(tq_segment *s, const tq_query *queries, uint32_t n_queries, uint32_t out_stride,

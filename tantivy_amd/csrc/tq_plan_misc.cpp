@@ -223,3 +223,197 @@ int plan_bool_query(tq_segment *s, const tq_query &q, uint32_t qi, TqdQuery &dq,
 
 
 }  // namespace tqi
+
+namespace tqi {
+
+// Does a TQ_MODE_BOOL query need the nested-tree evaluator (tq_tree.hip)?  A clause of several terms whose terms
+// are not all Should inside it (an intersection / exclusion / optional terms inside the nested query), a nested
+// minimum_number_should_match above 1, or a top-level minimum above 1 next to a nested clause.
+bool bool_query_is_tree(const tq_query &q) {
+  if (q.mode != TQ_MODE_BOOL || !q.occurs || !q.terms) return false;
+  uint32_t size_of[TQ_MAX_TERMS] = {0};
+  bool multi = false;
+  for (uint32_t i = 0; i < q.n_terms && i < TQ_MAX_TERMS; ++i) {
+    const uint32_t id = q.clause_of ? q.clause_of[i] : i;
+    if (id >= TQ_MAX_TERMS) return false;  // (reported by the planners)
+    multi = multi || ++size_of[id] > 1;
+  }
+  if (!multi) {  // every clause is one term: a nested occur other than Must / Should makes it a tree (a lone MustNot matches nothing)
+    if (q.nested_occurs)
+      for (uint32_t i = 0; i < q.n_terms; ++i)
+        if (q.nested_occurs[i] == TQ_MUST_NOT) return true;
+    return false;
+  }
+  for (uint32_t i = 0; i < q.n_terms; ++i) {
+    const uint32_t id = q.clause_of ? q.clause_of[i] : i;
+    if (q.nested_occurs && q.nested_occurs[i] != TQ_SHOULD && (size_of[id] > 1 || q.nested_occurs[i] == TQ_MUST_NOT)) return true;
+    if (q.clause_min_should && q.clause_min_should[id] >= 2) return true;
+  }
+  if (q.atom_of)  // a conjunction of several terms inside a clause
+    for (uint32_t i = 0; i < q.n_terms; ++i)
+      for (uint32_t j = 0; j < i; ++j)
+        if (q.atom_of[i] == q.atom_of[j] && (q.clause_of ? q.clause_of[i] == q.clause_of[j] : false)) return true;
+  return q.min_should_match >= 2;
+}
+
+// One nested boolean query -> its descriptor for tq_tree.hip.  BooleanWeight::complex_scorer on every level
+// (boolean_weight.rs:236-431): absent terms are EmptyScorers — an absent term empties its conjunction, an empty Must
+// member empties its (nested) query, empty Should / MustNot members are removed; minimum_number_should_match above the
+// number of Should scorers left matches nothing; a nested query that cannot match empties the query when it is a Must
+// clause and is removed otherwise; a query without Must and Should clauses matches nothing (:340-349).  Clause order =
+// score-sum order: Must clauses by cost ascending (intersect_scorers, intersection.rs:31: an intersection costs its
+// cheapest member, a union the sum of its members), then Should, then MustNot; inside a clause Must members by cost
+// ascending, then Should, then MustNot; inside a conjunction terms by doc freq ascending.  tq.n_terms == 0: the
+// query matches nothing.
+int plan_tree_query(tq_segment *s, const tq_query &q, uint32_t qi, TqdTreeQuery &tq, uint64_t &qbytes, uint64_t table_base) {
+  tq = TqdTreeQuery{};
+  tq.k = q.k;
+  struct Atom {  // a member of a nested query: one term, or a conjunction of terms
+    uint32_t id, inner, n = 0, handle[TQ_MAX_TERMS];
+    float w[TQ_MAX_TERMS];
+    bool empty = false;
+    uint64_t cost = ~0ull;  // its rarest list
+  };
+  struct Clause {
+    uint32_t id, outer, n = 0, msm = 0;
+    uint32_t atom[TQ_MAX_TERMS];  // indices into atoms[]
+    bool empty = false;
+    uint64_t cost = 0;
+  };
+  Atom atoms[TQ_MAX_TERMS];
+  Clause cl[TQ_MAX_TERMS];
+  uint32_t n_cl = 0, n_at = 0;
+  for (uint32_t i = 0; i < q.n_terms; ++i) {
+    if (q.occurs[i] > TQ_MUST_NOT) return fail(TQ_ERR_INVALID, "query %u: bad occur", qi);
+    const uint32_t inner = q.nested_occurs ? q.nested_occurs[i] : (uint32_t)TQ_SHOULD;
+    if (inner > TQ_MUST_NOT) return fail(TQ_ERR_INVALID, "query %u: bad nested occur", qi);
+    const uint32_t id = q.clause_of ? q.clause_of[i] : i;
+    if (id >= TQ_MAX_TERMS) return fail(TQ_ERR_INVALID, "query %u: clause_of value %u above %u", qi, id, TQ_MAX_TERMS - 1u);
+    uint32_t c = 0;
+    while (c < n_cl && cl[c].id != id) ++c;
+    if (c == n_cl) {
+      cl[n_cl].id = id;
+      cl[n_cl].outer = q.occurs[i];
+      cl[n_cl].msm = q.clause_min_should ? q.clause_min_should[id] : 0u;
+      ++n_cl;
+    } else if (cl[c].outer != q.occurs[i]) {
+      return fail(TQ_ERR_INVALID, "query %u: clause %u mixes occurs", qi, id);
+    }
+    // the term's atom inside its clause (atom_of NULL: every term its own)
+    const uint32_t aid = q.atom_of ? (uint32_t)q.atom_of[i] : 0x100u + i;
+    uint32_t a = TQ_MAX_TERMS;
+    for (uint32_t x = 0; x < cl[c].n; ++x)
+      if (atoms[cl[c].atom[x]].id == aid) a = cl[c].atom[x];
+    if (a == TQ_MAX_TERMS) {
+      a = n_at++;
+      atoms[a].id = aid;
+      atoms[a].inner = inner;
+      cl[c].atom[cl[c].n++] = a;
+    } else if (atoms[a].inner != inner) {
+      return fail(TQ_ERR_INVALID, "query %u: a conjunction (atom_of %u) mixes nested occurs", qi, aid);
+    }
+    if (q.terms[i] == TQ_TERM_ABSENT) {
+      atoms[a].empty = true;  // an EmptyScorer inside the conjunction
+      continue;
+    }
+    if (q.terms[i] >= s->terms.size()) return fail(TQ_ERR_INVALID, "query %u: unknown term handle %u", qi, q.terms[i]);
+    if (!(q.weights[i] >= 0.0f)) return fail(TQ_ERR_UNSUPPORTED, "query %u: negative boost inside a nested boolean query", qi);
+    atoms[a].handle[atoms[a].n] = q.terms[i];
+    atoms[a].w[atoms[a].n++] = q.weights[i];
+    atoms[a].cost = std::min<uint64_t>(atoms[a].cost, s->terms[q.terms[i]].doc_freq);
+    qbytes += s->terms[q.terms[i]].postings_len;
+  }
+  for (uint32_t a = 0; a < n_at; ++a) {  // conjunctions: rarest list first (Intersection::score sums in that order)
+    Atom &A = atoms[a];
+    for (uint32_t i = 1; i < A.n; ++i)
+      for (uint32_t j = i; j > 0 && s->terms[A.handle[j]].doc_freq < s->terms[A.handle[j - 1]].doc_freq; --j) {
+        std::swap(A.handle[j], A.handle[j - 1]);
+        std::swap(A.w[j], A.w[j - 1]);
+      }
+    if (A.n == 0) A.empty = true;
+  }
+  auto rank_of = [](uint32_t occur) { return occur == TQ_MUST ? 0u : (occur == TQ_SHOULD ? 1u : 2u); };
+  // every clause on its own level
+  for (uint32_t c = 0; c < n_cl; ++c) {
+    Clause &C = cl[c];
+    uint32_t keep = 0;
+    for (uint32_t x = 0; x < C.n; ++x) {  // empty members: a Must one empties the clause, the others are removed
+      const Atom &A = atoms[C.atom[x]];
+      if (A.empty) {
+        if (A.inner == TQ_MUST) C.empty = true;
+        continue;
+      }
+      C.atom[keep++] = C.atom[x];
+    }
+    C.n = keep;
+    std::stable_sort(C.atom, C.atom + C.n, [&](uint32_t x, uint32_t y) {
+      const uint32_t rx = rank_of(atoms[x].inner), ry = rank_of(atoms[y].inner);
+      if (rx != ry) return rx < ry;
+      return rx == 0u && atoms[x].cost < atoms[y].cost;
+    });
+    uint32_t n_m = 0, n_s = 0;
+    uint64_t min_must = ~0ull, sum_should = 0;
+    for (uint32_t x = 0; x < C.n; ++x) {
+      const Atom &A = atoms[C.atom[x]];
+      if (A.inner == TQ_MUST) {
+        ++n_m;
+        min_must = std::min(min_must, A.cost);
+      } else if (A.inner == TQ_SHOULD) {
+        ++n_s;
+        sum_should += A.cost;
+      }
+    }
+    if (C.msm > n_s || (n_m == 0 && n_s == 0)) C.empty = true;
+    C.msm = n_m ? C.msm : std::max<uint32_t>(1u, C.msm);  // without a Must member the union of the Should members is the doc set
+    C.cost = n_m ? min_must : sum_should;
+  }
+  uint32_t order[TQ_MAX_TERMS], n_ord = 0, n_must = 0, n_should = 0;
+  for (uint32_t pass = 0; pass < 3; ++pass)
+    for (uint32_t c = 0; c < n_cl; ++c) {
+      const uint32_t want = pass == 0 ? (uint32_t)TQ_MUST : (pass == 1 ? (uint32_t)TQ_SHOULD : (uint32_t)TQ_MUST_NOT);
+      if (cl[c].outer != want) continue;
+      if (cl[c].empty) {
+        if (want == TQ_MUST) return TQ_OK;  // (tq.n_terms == 0: nothing matches)
+        continue;
+      }
+      order[n_ord++] = c;
+      n_must += want == TQ_MUST ? 1u : 0u;
+      n_should += want == TQ_SHOULD ? 1u : 0u;
+    }
+  std::stable_sort(order, order + n_must, [&](uint32_t a, uint32_t b) { return cl[a].cost < cl[b].cost; });
+  if (q.min_should_match > n_should || (n_must == 0 && n_should == 0)) return TQ_OK;
+  tq.top_has_must = n_must ? 1u : 0u;
+  tq.top_need = n_must ? q.min_should_match : std::max<uint32_t>(1u, q.min_should_match);
+  if (tq.top_need > 15u) return fail(TQ_ERR_UNSUPPORTED, "query %u: minimum_number_should_match above 15", qi);
+  uint32_t n = 0;
+  for (uint32_t o = 0; o < n_ord; ++o) {
+    const Clause &C = cl[order[o]];
+    if (C.msm > 15u) return fail(TQ_ERR_UNSUPPORTED, "query %u: nested minimum_number_should_match above 15", qi);
+    tq.first_term[o] = n;
+    tq.outer[o] = C.outer;
+    tq.inner_need[o] = C.msm;
+    for (uint32_t x = 0; x < C.n; ++x) {
+      const Atom &A = atoms[C.atom[x]];
+      for (uint32_t i = 0; i < A.n; ++i) {
+        const TermHost &th = s->terms[A.handle[i]];
+        const bool own = th.dense_blob && th.tf8_blob;
+        const void *bm = own ? th.dense_blob : th.probe_dense_blob, *t8 = own ? th.tf8_blob : th.probe_tf8_blob;
+        if (!bm || !t8)
+          return fail(TQ_ERR_UNSUPPORTED, "query %u: a nested boolean query names a list without a bitmap (probe-table budget \"probe_budget_x\" used up)", qi);
+        tq.dense_off[n] = (uint32_t)(((uint64_t)bm - table_base) >> 3);
+        tq.tf8_off[n] = (uint32_t)(((uint64_t)t8 - table_base) >> 3);
+        memcpy(&tq.weight_bits[n], &A.w[i], sizeof(float));
+        tq.handle[n] = A.handle[i];
+        tq.inner[n] = A.inner;
+        tq.atom_end[n] = i + 1u == A.n ? 1u : 0u;
+        ++n;
+      }
+    }
+  }
+  tq.first_term[n_ord] = n;
+  tq.n_terms = n;
+  tq.n_clauses = n_ord;
+  return TQ_OK;
+}
+
+}  // namespace tqi

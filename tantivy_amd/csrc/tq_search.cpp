@@ -83,12 +83,32 @@ int search_batch_impl(tq_segment *s, const tq_query *queries, uint32_t n_queries
     if (built) s->share_span_terms = ~(size_t)0;  // (the tables' address span is taken again below)
   }
 
+  // nested boolean queries (tq_tree.hip) reach EVERY list through a bitmap, in both modes
+  if (s->opt.use_dense && s->opt.dense && s->opt.probe_budget_x > 0) {
+    bool built = false;
+    for (uint32_t qi = 0; qi < n_queries; ++qi) {
+      const tq_query &q = queries[qi];
+      if (q.mode != TQ_MODE_BOOL || !q.terms || q.n_terms > TQ_MAX_TERMS || !bool_query_is_tree(q)) continue;
+      for (uint32_t i = 0; i < q.n_terms; ++i) {
+        const uint32_t h = q.terms[i];
+        if (h >= s->terms.size()) continue;
+        const TermHost &th = s->terms[h];
+        if ((th.dense_blob && th.tf8_blob) || (th.probe_dense_blob && th.probe_tf8_blob)) continue;
+        bool ok = false;
+        const int prc = build_probe_tables(s, h, &ok);
+        if (prc != TQ_OK) return prc;
+        built = built || ok;
+      }
+    }
+    if (built) s->share_span_terms = ~(size_t)0;
+  }
+
   // ---- plan
   const bool or_windows_opt = s->opt.or_windows < 0 ? opt_exhaustive != 0 : s->opt.or_windows != 0;
   // launch groups: AND queries whose non-leader lists all have a bitmap run a leaner kernel
   // instantiation (no seek / block-search code: fewer registers, less LDS, more waves per CU)
   // boolean queries (clauses with roles) run the candidate-driven union kernel's BOOL instantiation
-  constexpr int kGroups = kNGroups, kAndGeneral = 3, kBool = 4, kShare = 5, kPhSweep = 6, kDense = 7, kAShare = 8, kBShare = 9;
+  constexpr int kGroups = kNGroups, kAndGeneral = 3, kBool = 4, kShare = 5, kPhSweep = 6, kDense = 7, kAShare = 8, kBShare = 9, kTree = 10;
   // AND queries whose other lists all have a bitmap + byte-wide tfs, pruned, k <= 128, <= 8 lists, on a
   // segment with a doc matrix, whose leader (rarest list) leads at least kAShareMin such queries of the
   // batch: the shared-intersection launch (leader-major, tq_ashare.hip).  TQ_ASHARE=0: the per-query kernel
@@ -130,6 +150,7 @@ int search_batch_impl(tq_segment *s, const tq_query *queries, uint32_t n_queries
   groups[kDense].mode = TQ_MODE_OR;
   groups[kAShare].mode = TQ_MODE_AND;
   groups[kBShare].mode = TQ_MODE_OR;
+  groups[kTree].mode = TQ_MODE_OR;
   s->plan->xrow_term.clear();
   s->plan->xrow_of.clear();
   groups[0].mode = TQ_MODE_AND;
@@ -354,8 +375,23 @@ int search_batch_impl(tq_segment *s, const tq_query *queries, uint32_t n_queries
         }
       }
     }
-    bool bool_done = false, share = false, dense_u = false;
-    if (q.mode == TQ_MODE_BOOL) {
+    bool bool_done = false, share = false, dense_u = false, tree = false;
+    if (q.mode == TQ_MODE_BOOL && bool_query_is_tree(q)) {
+      // a clause that is itself a BooleanQuery of terms (intersection inside a union / under MustNot, nested
+      // minimums: tq_query.nested_occurs): evaluated over the lists' bitmaps, tq_tree.hip
+      if (!s->share_span_ok || !s->opt.use_dense)
+        return fail(TQ_ERR_UNSUPPORTED, "query %u: nested boolean queries need the lists' bitmaps (\"use_dense\", one 32 GB table span)", qi);
+      TqdTreeQuery tq;
+      const int rc = plan_tree_query(s, q, qi, tq, qbytes, s->share_table_lo);
+      if (rc != TQ_OK) return rc;
+      tq.cache_idx = cache_idx;
+      groups[kTree].tree.push_back(tq);
+      dq.n_terms = tq.n_terms;
+      mode = TQ_MODE_OR;
+      n_tiles = 0;
+      bool_done = true;
+      tree = true;
+    } else if (q.mode == TQ_MODE_BOOL) {
       const int rc = plan_bool_query(s, q, qi, dq, qbytes, n_tiles, tile_cost, n_thr_rows, opt_exhaustive != 0);
       if (rc != TQ_OK) return rc;
       mode = TQ_MODE_OR;  // runs in the union launch group
@@ -479,7 +515,7 @@ int search_batch_impl(tq_segment *s, const tq_query *queries, uint32_t n_queries
     }
     algo_bytes += qbytes;
     dq.n_tiles = n_tiles;
-    Group &g = groups[bool_done ? (bshare ? kBShare : kBool) : (share ? kShare : (dense_u ? kDense : (ph_sweep ? kPhSweep : (ashare ? kAShare : ((mode == TQ_MODE_AND && !all_dense) ? kAndGeneral : mode)))))];
+    Group &g = groups[tree ? kTree : bool_done ? (bshare ? kBShare : kBool) : (share ? kShare : (dense_u ? kDense : (ph_sweep ? kPhSweep : (ashare ? kAShare : ((mode == TQ_MODE_AND && !all_dense) ? kAndGeneral : mode)))))];
     dq.mode = (uint32_t)mode;
     g.queries.push_back(dq);
     g.tile_cost.push_back(tile_cost);
@@ -537,6 +573,7 @@ int search_batch_impl(tq_segment *s, const tq_query *queries, uint32_t n_queries
       g.tile_cost.resize(total);
       g.out_index.resize(total);
       for (uint32_t sb = 0; sb < q_slabs; ++sb) g.max_k = std::max(g.max_k, qs[sb].groups[gi].max_k);
+      for (uint32_t sb = 0; sb < q_slabs; ++sb) g.tree.insert(g.tree.end(), qs[sb].groups[gi].tree.begin(), qs[sb].groups[gi].tree.end());
     }
     parallel_slabs(q_slabs, [&](uint32_t sb) {  // slab order = query order inside every group
       for (int gi = 0; gi < kGroups; ++gi) {
@@ -572,6 +609,13 @@ int search_batch_impl(tq_segment *s, const tq_query *queries, uint32_t n_queries
   (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, s->device);
   for (Group &g : groups) {
     if (g.queries.empty()) continue;
+    if (&g == &groups[kTree]) {  // one partial list per (query, tile of bitmap words); no chunk tables
+      const uint32_t tiles = tqk_tree_tiles((s->max_doc + 31u) / 32u);
+      g.kpl = kpl_for(g.max_k);
+      for (TqdQuery &dq : g.queries) dq.n_parts = tiles;
+      g.n_chunks = g.total_tiles = (uint32_t)g.queries.size() * tiles;
+      continue;
+    }
     const int crc = &g == &groups[kShare]    ? build_share_plan(s, g, *s->plan)
                     : &g == &groups[kAShare] ? build_ashare_plan(s, g, *s->plan, false)
                     : &g == &groups[kBShare] ? build_ashare_plan(s, g, *s->plan, true)
@@ -654,6 +698,11 @@ int search_batch_impl(tq_segment *s, const tq_query *queries, uint32_t n_queries
       g.o_lists = stage;
       if (&g == &groups[kBShare]) stage += A.alists.size() * sizeof(uint2);
     }
+    if (&g == &groups[kTree]) {  // (o_leads: the tree descriptors)
+      stage = (stage + 63) & ~(size_t)63;
+      g.o_leads = stage;
+      stage += g.tree.size() * sizeof(TqdTreeQuery);
+    }
     if (&g == &groups[kDense]) {  // (o_leads: the rows, o_tasks: the queries)
       stage = (stage + 63) & ~(size_t)63;
       g.o_leads = stage;
@@ -709,6 +758,10 @@ int search_batch_impl(tq_segment *s, const tq_query *queries, uint32_t n_queries
       memcpy(hs + g.o_leads, A.aleads.data(), A.aleads.size() * sizeof(TqdALead));
       big_copy(hs + g.o_tasks, A.atasks.data(), A.atasks.size() * sizeof(uint4));
       if (&g == &groups[kBShare]) memcpy(hs + g.o_lists, A.alists.data(), A.alists.size() * sizeof(uint2));
+    }
+    if (&g == &groups[kTree]) {
+      for (size_t i = 0; i < g.tree.size(); ++i) g.tree[i].part_start = g.queries[i].part_start;
+      memcpy(hs + g.o_leads, g.tree.data(), g.tree.size() * sizeof(TqdTreeQuery));
     }
     if (&g == &groups[kDense]) {
       memcpy(hs + g.o_leads, s->plan->xrows.data(), s->plan->xrows.size() * sizeof(TqkDenseRow));
@@ -847,7 +900,7 @@ int search_batch_impl(tq_segment *s, const tq_query *queries, uint32_t n_queries
     HIP_TRY(hipEventRecord(s->ev_fork, st));
     HIP_TRY(hipStreamWaitEvent(s->side_stream, s->ev_fork, 0));
   }
-  const int launch_order[kGroups] = {kAndGeneral, kBool, kBShare, kShare, kDense, 1, 2, kPhSweep, 0, kAShare};  // long serial chains first
+  const int launch_order[kGroups] = {kAndGeneral, kBool, kBShare, kShare, kDense, kTree, 1, 2, kPhSweep, 0, kAShare};  // long serial chains first
   // the group that keeps the caller's stream: the batch's intersections
   const int main_group = n_ashare ? kAShare : 0;
   uint32_t kernel_mask = 0;
@@ -947,6 +1000,23 @@ int search_batch_impl(tq_segment *s, const tq_query *queries, uint32_t n_queries
       }
       continue;
     }
+    if (gi == kTree) {
+      kernel_mask |= TQ_KERNEL_TREE;
+      TqkTreeParams tp{};
+      tp.seg = s->dseg;
+      tp.terms = s->d_terms;
+      tp.queries = (const TqdTreeQuery *)(ds + g.o_leads);
+      tp.caches = (const float *)(ds + o_caches);
+      tp.sinks = (const TqkSinks *)(ds + g.o_sinks);
+      tp.table_base = (const uint8_t *)s->share_table_lo;
+      tp.n_queries = (uint32_t)g.queries.size();
+      tp.n_words = (s->max_doc + 31u) / 32u;
+      tiles_total += g.total_tiles;
+      chunks_total += g.n_chunks;
+      const hipError_t e = tqk_launch_tree(tp, g.kpl, gst);
+      if (e != hipSuccess) return fail(TQ_ERR_HIP, "nested boolean launch: %s", hipGetErrorString(e));
+      continue;
+    }
     if (gi == kDense) {
       kernel_mask |= TQ_KERNEL_XUNION;
       TqkDenseParams dp{};
@@ -1025,7 +1095,7 @@ int search_batch_impl(tq_segment *s, const tq_query *queries, uint32_t n_queries
       const Group &g = groups[gi];
       if (g.queries.empty()) continue;
       const uint32_t bit = gi == kAShare ? TQ_KERNEL_ASHARE : gi == kBShare ? TQ_KERNEL_BSHARE : gi == kShare ? TQ_KERNEL_USHARE
-                           : gi == kDense ? TQ_KERNEL_XUNION : gi == 0 ? TQ_KERNEL_AND_DENSE : gi == kAndGeneral ? TQ_KERNEL_AND
+                           : gi == kDense ? TQ_KERNEL_XUNION : gi == kTree ? TQ_KERNEL_TREE : gi == 0 ? TQ_KERNEL_AND_DENSE : gi == kAndGeneral ? TQ_KERNEL_AND
                            : gi == kBool ? TQ_KERNEL_BOOL : gi == kPhSweep ? TQ_KERNEL_PHRASE_SWEEP : gi == 2 ? TQ_KERNEL_PHRASE
                            : ((or_windows_opt && gi != kBool) ? TQ_KERNEL_OR_WINDOWS : TQ_KERNEL_UNION);
       for (uint32_t qi : g.out_index) s->last_query_kernel[qi] = bit;

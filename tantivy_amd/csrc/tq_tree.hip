@@ -1,0 +1,210 @@
+// tq_tree.hip — boolean queries whose clauses are themselves boolean queries of terms: the
+// `SpecializedScorer::Other` trees of BooleanWeight::complex_scorer (boolean_weight.rs:236-431) that do not
+// flatten — an intersection inside a union (`(+b +c) d`), under MustNot (`+a -(+b +c)`), a nested query with its
+// own MustNot / optional terms / minimum_number_should_match, minimum_number_should_match over nested groups
+// (disjunction.rs:113-139).  Every clause is a term or a BooleanQuery whose members are terms or CONJUNCTIONS of
+// terms ("atoms": `+a +((+b +c) d)` — an atom is present where all its terms are and scores their sum,
+// Intersection::score): three levels when the innermost is an intersection of terms.
+//
+// Every list is reached through its bitmap (its own, or the probe tables of tq_terms.cpp): the doc set of such a
+// tree is a bitwise expression over the lists' bitmap words — per nested query AND over its Must terms, AND NOT
+// over its MustNot terms, "at least m of its Should terms" from a bit-sliced counter; the same one level up over
+// the clauses — so a lane evaluates 32 docs per step from one coalesced 8-byte load per list (what tq_count.hip
+// does for Count), and only the docs that MATCH are scored: bitmap word -> rank -> tf byte per term of a matching
+// clause, BM25 summed clause by clause (Intersection::score: left + right + others, intersection.rs:325-329;
+// RequiredOptionalScorer::score = req + opt, reqopt_scorer.rs:85-98; a union's SumCombiner), the per-wave top-k
+// in registers, partial lists reduced by merge_kernel.  Nothing is pruned: the reference runs these trees through
+// the generic for_each_pruning_scorer (weight.rs:47-60), which only filters by threshold.
+//
+// HBM-bound by construction: 8 B per list per 32 docs of the segment, whatever the lists hold.
+#include "tq_common.hpp"
+#include "tq_launch.h"
+
+namespace {
+
+constexpr uint32_t TREE_TILE_WORDS = TQK_TREE_TILE_WORDS;  // bitmap words per (query, tile) wavefront
+
+// bit-sliced counter of up to 15 one-bit-per-doc inputs (4 planes): add, and "count >= m"
+struct SlicedCount {
+  uint32_t p0 = 0, p1 = 0, p2 = 0, p3 = 0;
+  __device__ __forceinline__ void add(uint32_t x) {
+    uint32_t c = p0 & x;
+    p0 ^= x;
+    x = c;
+    c = p1 & x;
+    p1 ^= x;
+    x = c;
+    c = p2 & x;
+    p2 ^= x;
+    x = c;
+    p3 ^= x;
+  }
+  __device__ __forceinline__ uint32_t at_least(uint32_t m) const {  // m wave-uniform, 0..15
+    if (m == 0u) return 0xFFFFFFFFu;
+    uint32_t gt = 0u, eq = 0xFFFFFFFFu;
+    const uint32_t pl[4] = {p0, p1, p2, p3};
+#pragma unroll
+    for (int i = 3; i >= 0; --i) {
+      if ((m >> i) & 1u) {
+        eq &= pl[i];
+      } else {
+        gt |= eq & pl[i];
+        eq &= ~pl[i];
+      }
+    }
+    return gt | eq;
+  }
+};
+
+template <int KPL>
+__global__ __launch_bounds__(64) void tree_kernel(TqkTreeParams p) {
+  const int lane = (int)__lane_id();
+  const uint32_t q = blockIdx.x % p.n_queries, tile = blockIdx.x / p.n_queries;
+  const TqdTreeQuery *Q = p.queries + q;
+  const uint32_t nt = sload(&Q->n_terms), nc = sload(&Q->n_clauses), k = sload(&Q->k);
+  const uint32_t top_need = sload(&Q->top_need), top_has_must = sload(&Q->top_has_must);
+  const float *cache = p.caches + (size_t)sload(&Q->cache_idx) * 256u;
+  const uint8_t *tbase = p.table_base;
+  const TqdSegment seg = p.seg;
+  TopK<KPL> tk;
+  tk.reset(k);
+  uint32_t n_matches = 0;
+  if (nt == 0 || nc == 0) {  // (a query the planner found empty: an absent Must term, too few Should clauses, ...)
+    flush_partial(tk, sload(&p.sinks->partials), sload(&Q->part_start) + tile, lane);
+    return;
+  }
+  const uint32_t w_end = (tile + 1u) * TREE_TILE_WORDS < p.n_words ? (tile + 1u) * TREE_TILE_WORDS : p.n_words;
+  for (uint32_t w0 = tile * TREE_TILE_WORDS; w0 < w_end; w0 += 64u) {
+    const uint32_t w = w0 + (uint32_t)lane;
+    const bool in = w < w_end;
+    // ---- the doc set of 32 docs per lane: clause by clause, then the clauses one level up
+    uint32_t top_must = 0xFFFFFFFFu, top_not = 0u;
+    SlicedCount top_should;
+    for (uint32_t c = 0; c < nc; ++c) {
+      const uint32_t t0 = sload(Q->first_term + c), t1 = sload(Q->first_term + c + 1u);
+      uint32_t must = 0xFFFFFFFFu, nots = 0u;
+      SlicedCount should;
+      uint32_t atom = 0xFFFFFFFFu;  // the docs that hold every term of the current atom so far
+      for (uint32_t t = t0; t < t1; ++t) {
+        const uint2 *bm = reinterpret_cast<const uint2 *>(tbase + ((uint64_t)sload(Q->dense_off + t) << 3));
+        atom &= in ? bm[w].x : 0u;
+        if (!sload(Q->atom_end + t)) continue;
+        const uint32_t inner = sload(Q->inner + t);
+        if (inner == TQD_ROLE_MUST)
+          must &= atom;
+        else if (inner == TQD_ROLE_MUST_NOT)
+          nots |= atom;
+        else
+          should.add(atom);
+        atom = 0xFFFFFFFFu;
+      }
+      const uint32_t cm = must & ~nots & should.at_least(sload(Q->inner_need + c));
+      const uint32_t outer = sload(Q->outer + c);
+      if (outer == TQD_ROLE_MUST)
+        top_must &= cm;
+      else if (outer == TQD_ROLE_MUST_NOT)
+        top_not |= cm;
+      else
+        top_should.add(cm);
+    }
+    uint32_t match = (top_has_must ? top_must : 0xFFFFFFFFu) & ~top_not & top_should.at_least(top_need);
+    if (!in) match = 0u;
+    if (seg.alive) match &= in ? reinterpret_cast<const uint32_t *>(seg.alive)[w] : 0u;  // AliveBitSet (alive_bitset.rs:58-61)
+    n_matches += (uint32_t)__popc(match);
+    // ---- score the matching docs: every lane takes the lowest doc of its word until none has one left
+    while (__ballot(match != 0u)) {
+      const bool has = match != 0u;
+      const uint32_t bit = has ? (uint32_t)__builtin_ctz(match) : 0u;
+      match &= match - 1u;
+      const uint32_t doc = (w << 5) | bit;
+      const float norm = cache[has ? fieldnorm_id(seg, doc) : 0u];
+      float musts_first = 0.0f, musts_second = 0.0f, musts_others = 0.0f, opt = 0.0f;
+      uint32_t n_must_clauses = 0;
+      for (uint32_t c = 0; c < nc; ++c) {
+        const uint32_t t0 = sload(Q->first_term + c), t1 = sload(Q->first_term + c + 1u);
+        const uint32_t outer = sload(Q->outer + c);
+        if (outer == TQD_ROLE_MUST_NOT) continue;  // (the doc set already excludes them)
+        bool must_ok = true, not_ok = true;
+        uint32_t ns = 0;
+        float csum = 0.0f;
+        bool atom_ok = true;    // the doc holds every term of the current atom so far
+        float atom_sum = 0.0f;  // ... and what they score together (Intersection::score)
+        for (uint32_t t = t0; t < t1; ++t) {
+          const uint32_t inner = sload(Q->inner + t);
+          const uint2 *bm = reinterpret_cast<const uint2 *>(tbase + ((uint64_t)sload(Q->dense_off + t) << 3));
+          uint2 wd = make_uint2(0u, 0u);
+          if (has) wd = bm[w];
+          const bool present = has && ((wd.x >> bit) & 1u);
+          atom_ok = atom_ok && present;
+          if (present && inner != TQD_ROLE_MUST_NOT) {
+            const uint32_t pi = wd.y + (uint32_t)__popc(wd.x & ((1u << bit) - 1u));
+            uint32_t tf = (tbase + ((uint64_t)sload(Q->tf8_off + t) << 3))[pi];
+            if (tf == 255u) {  // saturated byte: block record -> packed tf (tq_common.hpp)
+              const TqdTermHead *h = p.terms + sload(Q->handle + t);
+              TermRef tr{};
+              tr.rec = h->rec;
+              tr.tail_tfs = h->tail_tfs;
+              tr.payload_base = h->payload_base;
+              tr.has_freq = h->has_freq & 1u;
+              const uint4 r = tr.rec[pi >> 7];
+              tf = block_tf_at(seg.idx, tr, make_uint2(r.y, r.z), pi & 127u);
+            }
+            atom_sum = atom_sum + bm25(__uint_as_float(sload(Q->weight_bits + t)), norm, tf);
+          }
+          if (!sload(Q->atom_end + t)) continue;
+          if (inner == TQD_ROLE_MUST_NOT) {
+            not_ok = not_ok && !atom_ok;
+          } else {
+            if (inner == TQD_ROLE_MUST) must_ok = must_ok && atom_ok;
+            if (atom_ok) {
+              if (inner == TQD_ROLE_SHOULD) ++ns;
+              csum = csum + atom_sum;
+            }
+          }
+          atom_ok = true;
+          atom_sum = 0.0f;
+        }
+        const bool cmatch = has && must_ok && not_ok && ns >= sload(Q->inner_need + c);
+        if (outer == TQD_ROLE_MUST) {  // Intersection::score: left + right + sum(others), clauses cheapest first
+          if (n_must_clauses == 0u)
+            musts_first = csum;
+          else if (n_must_clauses == 1u)
+            musts_second = csum;
+          else
+            musts_others = musts_others + csum;
+          ++n_must_clauses;
+        } else if (cmatch) {
+          opt = opt + csum;  // a Should clause that matches adds its score (SumCombiner / RequiredOptionalScorer)
+        }
+      }
+      float s = musts_first;
+      if (n_must_clauses >= 2u) s = s + musts_second;
+      if (n_must_clauses >= 3u) s = s + musts_others;
+      s = n_must_clauses ? s + opt : opt;
+      tk.offer(has, make_key(s, doc), lane);
+    }
+  }
+  flush_partial(tk, sload(&p.sinks->partials), sload(&Q->part_start) + tile, lane);
+  for (int off = 32; off > 0; off >>= 1) n_matches += __shfl_down(n_matches, off, 64);
+  if (lane == 0 && n_matches) {
+    atomicAdd(sload(&p.sinks->query_matches) + sload(&p.sinks->out_index)[q], n_matches);
+    atomicAdd(sload(&p.sinks->match_counter), (unsigned long long)n_matches);
+  }
+}
+
+}  // namespace
+
+uint32_t tqk_tree_tiles(uint32_t n_words) { return (n_words + TREE_TILE_WORDS - 1u) / TREE_TILE_WORDS; }
+
+hipError_t tqk_launch_tree(const TqkTreeParams &p, int kpl, hipStream_t st) {
+  const uint32_t tiles = tqk_tree_tiles(p.n_words);
+  if (!tiles || !p.n_queries) return hipSuccess;
+  const dim3 grid(tiles * p.n_queries), block(64);
+  switch (kpl) {
+    case 1: tree_kernel<1><<<grid, block, 0, st>>>(p); break;
+    case 2: tree_kernel<2><<<grid, block, 0, st>>>(p); break;
+    case 4: tree_kernel<4><<<grid, block, 0, st>>>(p); break;
+    default: tree_kernel<16><<<grid, block, 0, st>>>(p); break;
+  }
+  return hipGetLastError();
+}

@@ -62,6 +62,8 @@ struct tqh_query {
   uint32_t min_should_match;       // TQ_MODE_BOOL
   const float *boosts;             // BoostQuery factor per term query (PHRASE: boosts[0] = the phrase's); or null
   const uint8_t *nested_occurs;    // TQ_MODE_BOOL, or null: see tantivy_amd_host.h
+  const uint8_t *clause_min_should;  // TQ_MODE_BOOL, or null: minimum_number_should_match of the nested query, by clause_of value
+  const uint8_t *atom_of;            // TQ_MODE_BOOL, or null: terms of one clause_of group sharing a value form a nested intersection
 };
 
 const char *tqh_last_error(void) { return g_err.c_str(); }
@@ -193,6 +195,7 @@ static Query build_query(const tqh_query &q) {
     std::vector<std::pair<Occur, Query>> clauses;
     std::vector<int> ids;  // clause_of value of every clause built so far
     std::vector<uint32_t> first_term_of;  // index (in q.terms) of the clause's first term
+    std::vector<std::vector<int>> atom_ids(TQ_MAX_TERMS + 1);  // per clause: atom_of value of every member built so far
     for (uint32_t t = 0; t < q.n_terms; ++t) {
       if (q.occurs[t] > 2) throw TantivyError(TantivyError::InvalidArgument, "bad occur");
       const Occur oc = q.occurs[t] == 1 ? Occur::Must
@@ -220,10 +223,33 @@ static Query build_query(const tqh_query &q) {
       if (sub.kind == Query::Term) {  // second term of the clause: it becomes a nested query
         const Query first = sub;
         sub = Query::boolean({{inner(first_term_of[c]), first}});
+        atom_ids[c] = {q.atom_of ? (int)q.atom_of[first_term_of[c]] : -1};
       }
-      sub.clauses.emplace_back(inner(t),
-                               Query::term_query(q.terms[t]).boosted(q.boosts ? q.boosts[t] : 1.0f));
+      Query leaf = Query::term_query(q.terms[t]).boosted(q.boosts ? q.boosts[t] : 1.0f);
+      // atom_of: terms of the clause sharing a value are one member — an intersection of terms one level down
+      // (`+a +((+b +c) d)`), with the member's occur = nested_occurs of its terms
+      const int aid = q.atom_of ? (int)q.atom_of[t] : -1;
+      size_t m = sub.clauses.size();
+      if (aid >= 0)
+        for (m = 0; m < atom_ids[c].size() && atom_ids[c][m] != aid; ++m) {}
+      if (m >= sub.clauses.size()) {
+        sub.clauses.emplace_back(inner(t), std::move(leaf));
+        atom_ids[c].push_back(aid);
+        continue;
+      }
+      if (sub.clauses[m].first != inner(t))
+        throw TantivyError(TantivyError::InvalidArgument, "a conjunction mixes nested occurs");
+      Query &member = sub.clauses[m].second;
+      if (member.kind == Query::Term) member = Query::boolean({{Occur::Must, Query(member)}});
+      member.clauses.emplace_back(Occur::Must, std::move(leaf));
     }
+    if (q.clause_min_should)  // BooleanQuery::set_minimum_number_should_match on the nested queries
+      for (size_t c = 0; c < clauses.size(); ++c)
+        if (ids[c] >= 0 && ids[c] < (int)TQ_MAX_TERMS && q.clause_min_should[ids[c]]) {
+          Query &sub = clauses[c].second;
+          if (sub.kind == Query::Term) sub = Query::boolean({{Occur::Should, sub}});  // (a one-term nested query)
+          sub.set_minimum_number_should_match(q.clause_min_should[ids[c]]);
+        }
     query = Query::boolean(std::move(clauses));
     query.set_minimum_number_should_match(q.min_should_match);
   } else if (q.mode == TQH_MODE_TERM || (q.n_terms == 1 && q.mode != TQ_MODE_PHRASE)) {

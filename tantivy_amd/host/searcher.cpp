@@ -197,27 +197,46 @@ Weight Searcher::weight(const Query &query) const {
         }
       }
       const std::vector<std::pair<Occur, Query>> &clauses = *clauses_p;
-      bool all_must = true, all_should = true, flat = true;
+      bool all_must = true, all_should = true, flat = true, tree = false;
+      // a clause is a term, a union of terms, or (round 5) any BooleanQuery of TERMS — an intersection inside a
+      // union or under MustNot, nested MustNot / optional terms, a nested minimum_number_should_match: depth 2,
+      // evaluated over the lists' bitmaps (tq_tree.hip).  Deeper trees and phrases inside boolean queries keep
+      // tantivy's CPU scorer (SpecializedScorer::Other, boolean_weight.rs:595-597).
+      // (a member of a nested query: a term, or an intersection of terms — `(+b +c) d`)
+      auto is_conjunction = [](const Query &q) {
+        if (q.kind != Query::Boolean || q.clauses.empty() || q.minimum_number_should_match != 0) return false;
+        for (auto &c : q.clauses)
+          if (c.first != Occur::Must || c.second.kind != Query::Term) return false;
+        return true;
+      };
+      auto is_query_of_terms = [&](const Query &q) {
+        if (q.kind != Query::Boolean || q.clauses.empty()) return false;
+        for (auto &c : q.clauses)
+          if (c.second.kind != Query::Term && !is_conjunction(c.second)) return false;
+        return true;
+      };
       auto is_term_union = [](const Query &q) {
-        if (q.kind != Query::Boolean || q.clauses.empty() || q.minimum_number_should_match > 1)
-          return false;
+        if (q.minimum_number_should_match > 1) return false;
         for (auto &c : q.clauses)
           if (c.first != Occur::Should || c.second.kind != Query::Term) return false;
         return true;
       };
       for (auto &c : clauses) {
         if (c.second.kind != Query::Term) {
-          if (!is_term_union(c.second))
+          if (!is_query_of_terms(c.second))
             throw TantivyError(TantivyError::Unsupported,
-                               "nested boolean trees other than unions of terms stay on the CPU "
-                               "scorer path");
+                               "boolean trees deeper than two levels and phrases inside boolean queries stay "
+                               "on the CPU scorer path");
+          tree = tree || !is_term_union(c.second);
           flat = false;
         }
         all_must &= c.first == Occur::Must;
         all_should &= c.first == Occur::Should;
       }
       const size_t msm = query.minimum_number_should_match;
-      if (flat && all_must && msm == 0)
+      if (tree)
+        w.mode = TQ_MODE_BOOL;
+      else if (flat && all_must && msm == 0)
         w.mode = TQ_MODE_AND;
       else if (flat && all_should && msm <= 1)
         w.mode = TQ_MODE_OR;
@@ -230,18 +249,37 @@ Weight Searcher::weight(const Query &query) const {
                                : (c.first == Occur::MustNot ? (uint8_t)TQ_MUST_NOT
                                                             : (uint8_t)TQ_SHOULD);
         const Score bc = b0 * c.second.boost;  // the clause's own BoostQuery wrapper, if any
-        auto add = [&](uint32_t term, Score boost) {
+        uint8_t member = 0;
+        auto add = [&](uint32_t term, Score boost, Occur inner) {
           w.terms.push_back(term);
           w.weights.push_back(term_weight(term, boost));
           if (w.mode == TQ_MODE_BOOL) {
             w.occurs.push_back(oc);
             w.clause_of.push_back(clause);
+            if (tree) {
+              w.nested_occurs.push_back(inner == Occur::Must ? (uint8_t)TQ_MUST
+                                                             : (inner == Occur::MustNot ? (uint8_t)TQ_MUST_NOT : (uint8_t)TQ_SHOULD));
+              w.atom_of.push_back(member);
+            }
           }
         };
-        if (c.second.kind == Query::Term)
-          add(c.second.term, bc);
-        else
-          for (auto &sub : c.second.clauses) add(sub.second.term, bc * sub.second.boost);
+        if (c.second.kind == Query::Term) {
+          add(c.second.term, bc, Occur::Must);  // (a one-term clause: the term itself)
+        } else {
+          for (auto &sub : c.second.clauses) {
+            if (sub.second.kind == Query::Term)
+              add(sub.second.term, bc * sub.second.boost, sub.first);
+            else  // an intersection of terms one level down: one member of the nested query
+              for (auto &leaf : sub.second.clauses) add(leaf.second.term, bc * sub.second.boost * leaf.second.boost, sub.first);
+            ++member;
+          }
+          if (tree && c.second.minimum_number_should_match) {
+            if (clause >= TQ_MAX_TERMS || c.second.minimum_number_should_match > 255)
+              throw TantivyError(TantivyError::Unsupported, "nested minimum_number_should_match out of range");
+            if (w.clause_min_should.empty()) w.clause_min_should.assign(TQ_MAX_TERMS, 0);
+            w.clause_min_should[clause] = (uint8_t)c.second.minimum_number_should_match;
+          }
+        }
         ++clause;
       }
       if (w.terms.size() > TQ_MAX_TERMS)
@@ -280,6 +318,9 @@ struct SegmentBatch {
       q.occurs = w.occurs.empty() ? nullptr : w.occurs.data();
       q.clause_of = w.clause_of.empty() ? nullptr : w.clause_of.data();
       q.min_should_match = w.min_should_match;
+      q.nested_occurs = w.nested_occurs.empty() ? nullptr : w.nested_occurs.data();
+      q.clause_min_should = w.clause_min_should.empty() ? nullptr : w.clause_min_should.data();
+      q.atom_of = w.atom_of.empty() ? nullptr : w.atom_of.data();
     }
   }
 };
@@ -395,6 +436,9 @@ Fruit Searcher::search(const Query &query, const TopDocs &collector) {
     q.occurs = w.occurs.empty() ? nullptr : w.occurs.data();
     q.clause_of = w.clause_of.empty() ? nullptr : w.clause_of.data();
     q.min_should_match = w.min_should_match;
+    q.nested_occurs = w.nested_occurs.empty() ? nullptr : w.nested_occurs.data();
+    q.clause_min_should = w.clause_min_should.empty() ? nullptr : w.clause_min_should.data();
+    q.atom_of = w.atom_of.empty() ? nullptr : w.atom_of.data();
     const tq_search_opts opts{-1, bound_slack_ppm(seg)};
     const int rc = tq_search_one(seg.raw(), &q, &opts, all_scores.data() + s * k, all_docs.data() + s * k,
                                  all_counts.data() + s);

@@ -171,6 +171,12 @@ struct Weight {
   std::vector<uint32_t> phrase_offsets;  // phrase
   std::vector<uint8_t> occurs;           // TQ_MODE_BOOL: enum tq_occur per term
   std::vector<uint8_t> clause_of;        // TQ_MODE_BOOL: clause index per term
+  std::vector<uint8_t> nested_occurs;    // TQ_MODE_BOOL: the term's occur inside its clause (a nested BooleanQuery of
+                                         // terms); empty = every clause is a term or a union of terms
+  std::vector<uint8_t> atom_of;          // TQ_MODE_BOOL: member index of the term inside its clause (terms sharing one are
+                                         // a nested intersection of terms); empty = every term its own member
+  std::vector<uint8_t> clause_min_should;  // TQ_MODE_BOOL: the nested queries' minimum_number_should_match by clause
+                                           // index (TQ_MAX_TERMS entries), or empty
   uint32_t min_should_match = 0;         // TQ_MODE_BOOL
   std::shared_ptr<Bm25Weight> bm25;      // holds the shared tf cache
 };
