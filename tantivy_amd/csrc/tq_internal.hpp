@@ -241,6 +241,9 @@ struct tq_segment {
   uint32_t n_mat_slots = 0;
   TqdSegment dseg{};
   std::vector<TermHost> terms;
+  std::vector<void *> term_slabs;  // the terms' table blobs are carved out of 4 MB slabs (term_alloc)
+  uint8_t *term_slab_cur = nullptr;
+  size_t term_slab_left = 0;
   std::vector<TqdTerm> h_dterms;
   TqdTerm *d_terms = nullptr;
   size_t d_terms_cap = 0;

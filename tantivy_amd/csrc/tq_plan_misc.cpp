@@ -253,7 +253,20 @@ bool bool_query_is_tree(const tq_query &q) {
     for (uint32_t i = 0; i < q.n_terms; ++i)
       for (uint32_t j = 0; j < i; ++j)
         if (q.atom_of[i] == q.atom_of[j] && (q.clause_of ? q.clause_of[i] == q.clause_of[j] : false)) return true;
-  return q.min_should_match >= 2;
+  // "at least m of n" over nested unions (disjunction.rs:113-139): what plan_bool_query does not take — m == n turns
+  // the Should clauses into Must clauses there, m > n matches nothing
+  if (q.min_should_match >= 2) {
+    uint32_t present[TQ_MAX_TERMS] = {0}, n_should = 0;
+    bool multi_should = false;
+    for (uint32_t i = 0; i < q.n_terms; ++i) {
+      if (q.occurs[i] != TQ_SHOULD || q.terms[i] == TQ_TERM_ABSENT) continue;
+      const uint32_t id = q.clause_of ? q.clause_of[i] : i;
+      if (++present[id] == 1u) ++n_should;
+      multi_should = multi_should || present[id] > 1u;
+    }
+    return multi_should && q.min_should_match < n_should;
+  }
+  return false;
 }
 
 // One nested boolean query -> its descriptor for tq_tree.hip.  BooleanWeight::complex_scorer on every level

@@ -25,6 +25,31 @@ int ensure_docmat(tq_segment *s);
 // where block record -> packed tf bits are two dependent ones (the shared-union kernel's scoring
 // stage is a chain of dependent gathers, 1.6 us each under load).  d_tfs = the decoded tfs.
 
+// A term's table blob (block records, coarse table, tail, position-block table): carved out of 4 MB slabs — one
+// hipMalloc per prepared term was most of the 40 us a sparse term cost to prepare, i.e. most of a batch that names
+// two thousand new terms (the 65 536-term stream of bench.py).  Slabs live as long as the segment; a blob handed
+// back by a failed preparation is simply not reused.  Large blobs get an allocation of their own.
+int term_alloc(tq_segment *s, size_t bytes, uint8_t **out) {
+  constexpr size_t kSlab = (size_t)4 << 20;
+  const size_t need = (bytes + 255) & ~(size_t)255;
+  if (need > kSlab / 4) {
+    HIP_TRY(hipMalloc((void **)out, bytes));
+    s->term_slabs.push_back(*out);
+    return TQ_OK;
+  }
+  if (need > s->term_slab_left) {
+    void *slab = nullptr;
+    HIP_TRY(hipMalloc(&slab, kSlab));
+    s->term_slabs.push_back(slab);
+    s->term_slab_cur = (uint8_t *)slab;
+    s->term_slab_left = kSlab;
+  }
+  *out = s->term_slab_cur;
+  s->term_slab_cur += need;
+  s->term_slab_left -= need;
+  return TQ_OK;
+}
+
 // a side table of a dense list: from the segment's arena, else a device allocation of its own
 int dense_alloc(tq_segment *s, size_t bytes, void **out) {
   const size_t need = (bytes + 255) & ~(size_t)255;
@@ -397,7 +422,10 @@ int tq_term_prepare(tq_segment *s, uint64_t postings_off, uint32_t postings_len,
   if (!pos_block_off.empty()) memcpy(hb.data() + o_pboff, pos_block_off.data(), 8 * pos_block_off.size());
   if (!pos_tail.empty()) memcpy(hb.data() + o_ptail, pos_tail.data(), 4 * pos_tail.size());
   uint8_t *blob = nullptr;
-  HIP_TRY(hipMalloc((void **)&blob, total));
+  {
+    const int arc = term_alloc(s, total, &blob);
+    if (arc != TQ_OK) return arc;
+  }
   s->bytes_term_tables += total;
   TqdTerm dt{};
   dt.rec = (const uint4 *)(blob + o_rec);
@@ -417,10 +445,7 @@ int tq_term_prepare(tq_segment *s, uint64_t postings_off, uint32_t postings_len,
   dt.coarse_shift = shift;
   memcpy(hb.data() + o_self, &dt, sizeof dt);
   hipError_t ce = hipMemcpy(blob, hb.data(), total, hipMemcpyHostToDevice);
-  if (ce != hipSuccess) {
-    (void)hipFree(blob);
-    return fail(TQ_ERR_HIP, "term upload: %s", hipGetErrorString(ce));
-  }
+  if (ce != hipSuccess) return fail(TQ_ERR_HIP, "term upload: %s", hipGetErrorString(ce));
 
   TermHost th;
   th.blob = blob;
@@ -513,12 +538,12 @@ int term_prepare_device(tq_segment *s, uint64_t postings_off, uint32_t postings_
   const size_t o_self = place(sizeof(TqdTerm));
   total += PAD;
   uint8_t *blob = nullptr;
-  HIP_TRY(hipMalloc((void **)&blob, total));
+  {
+    const int arc = term_alloc(s, total, &blob);
+    if (arc != TQ_OK) return arc;
+  }
   s->bytes_term_tables += total;
-  auto bail = [&](int rc) {
-    (void)hipFree(blob);
-    return rc;
-  };
+  auto bail = [&](int rc) { return rc; };  // (the blob stays in its slab)
   hipError_t e = hipMemsetAsync(blob, 0, total, s->stream);
   TqpPostingsParams pp{};
   pp.idx = s->d_idx;
@@ -560,8 +585,8 @@ int term_prepare_device(tq_segment *s, uint64_t postings_off, uint32_t postings_
     ptotal = align16(8 * (size_t)info.n_pos_blocks);
     o_ptail = ptotal;
     ptotal = align16(ptotal + 4 * (size_t)tail_cap) + PAD;
-    e = hipMalloc((void **)&pblob, ptotal);
-    if (e == hipSuccess) s->bytes_term_tables += ptotal;
+    if (term_alloc(s, ptotal, &pblob) != TQ_OK) return bail(TQ_ERR_HIP);
+    s->bytes_term_tables += ptotal;
     if (e == hipSuccess) e = hipMemsetAsync(pblob, 0, ptotal, s->stream);
     TqpPositionsParams qp{};
     qp.pos = s->d_pos;
@@ -579,7 +604,6 @@ int term_prepare_device(tq_segment *s, uint64_t postings_off, uint32_t postings_
     if (e == hipSuccess) e = hipMemcpyAsync(res, s->d_tp_info + 1, sizeof res, hipMemcpyDeviceToHost, s->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(s->stream);
     if (e != hipSuccess || res[0] != TQP_OK) {
-      if (pblob) (void)hipFree(pblob);
       return bail(e != hipSuccess ? fail(TQ_ERR_HIP, "device positions prepare: %s", hipGetErrorString(e))
                                   : fail(TQ_ERR_FORMAT, "term at %llu: %s", (unsigned long long)postings_off,
                                          tqp_message(res[0])));
@@ -606,10 +630,7 @@ int term_prepare_device(tq_segment *s, uint64_t postings_off, uint32_t postings_
   dt.coarse_shift = shift;
   {
     const hipError_t se = hipMemcpy(blob + o_self, &dt, sizeof dt, hipMemcpyHostToDevice);
-    if (se != hipSuccess) {
-      if (pblob) (void)hipFree(pblob);
-      return bail(fail(TQ_ERR_HIP, "term record upload: %s", hipGetErrorString(se)));
-    }
+    if (se != hipSuccess) return bail(fail(TQ_ERR_HIP, "term record upload: %s", hipGetErrorString(se)));
   }
   TermHost th;
   th.blob = blob;

@@ -279,7 +279,15 @@ int tqh_prepare_batch(tqh_searcher *s, const tqh_query *queries, uint32_t n) {
     if (!s || !s->searcher) throw TantivyError(TantivyError::InvalidArgument, "no segments");
     s->prepared.clear();
     s->prepared.reserve(n);
-    for (uint32_t i = 0; i < n; ++i) s->prepared.push_back(s->searcher->weight(build_query(queries[i])));
+    for (uint32_t i = 0; i < n; ++i) {
+      const tqh_query &q = queries[i];
+      // unboosted all-Must / all-Should term clauses (what a query parser makes of `+a +b` / `a b c`): the weight
+      // without the detour through a Query tree — the same f32 arithmetic as Searcher::weight
+      if ((q.mode == TQ_MODE_AND || q.mode == TQ_MODE_OR) && !q.boosts && q.n_terms >= 1 && q.terms)
+        s->prepared.push_back(s->searcher->weight_flat(q.mode, q.terms, q.n_terms));
+      else
+        s->prepared.push_back(s->searcher->weight(build_query(q)));
+    }
   });
 }
 

@@ -43,7 +43,10 @@ SegmentReader::SegmentReader(DeviceResident, tq_ctx *ctx, int device, uint32_t s
                                           d_fieldnorm, fn_len, record_option, &seg_);
   if (rc != TQ_OK) throw_tq(rc);
 }
-SegmentReader::~SegmentReader() { tq_segment_free(seg_); }
+SegmentReader::~SegmentReader() {
+  tq_segment_free(seg_);
+  delete[] fast_handles_.load(std::memory_order_relaxed);
+}
 
 void SegmentReader::add_term(uint32_t term_id, const TermInfo &info) { terms_[term_id] = info; }
 void SegmentReader::set_term_info_store(std::shared_ptr<const TermInfoStore> store) {
@@ -58,6 +61,13 @@ const TermInfo *SegmentReader::get_term_info(uint32_t term_id) const {
   return &it->second;
 }
 tq_term_handle SegmentReader::term_handle(uint32_t term_id) {
+  if (term_id < kFastHandles) {  // (the table exists from the first prepared term on)
+    std::atomic<tq_term_handle> *fast = fast_handles_.load(std::memory_order_acquire);
+    if (fast) {
+      const tq_term_handle h = fast[term_id].load(std::memory_order_acquire);
+      if (h != kHandleUnknown) return h;
+    }
+  }
   {
     std::lock_guard<std::mutex> lk(m_);
     auto h = handles_.find(term_id);
@@ -75,11 +85,21 @@ tq_term_handle SegmentReader::term_handle(uint32_t term_id) {
   }                                 // preparing the same term get the same handle)
   std::lock_guard<std::mutex> lk(m_);
   handles_[term_id] = handle;
+  if (term_id < kFastHandles) {
+    std::atomic<tq_term_handle> *fast = fast_handles_.load(std::memory_order_relaxed);
+    if (!fast) {
+      fast = new std::atomic<tq_term_handle>[kFastHandles];
+      for (uint32_t i = 0; i < kFastHandles; ++i) fast[i].store(kHandleUnknown, std::memory_order_relaxed);
+      fast_handles_.store(fast, std::memory_order_release);  // (readers that still see null take the locked path)
+    }
+    fast[term_id].store(handle, std::memory_order_release);
+  }
   return handle;
 }
 
 Searcher::Searcher(std::vector<std::shared_ptr<SegmentReader>> segments)
     : segments_(std::move(segments)) {}
+Searcher::~Searcher() { delete[] fast_weights_.load(std::memory_order_relaxed); }
 
 void Searcher::add_remote_statistics(
     uint64_t max_doc, uint64_t total_num_tokens,
@@ -88,6 +108,58 @@ void Searcher::add_remote_statistics(
   remote_tokens_ += total_num_tokens;
   for (auto &tf : term_doc_freqs) remote_doc_freq_[tf.first] += tf.second;
   shared_cache_.reset();
+  if (std::atomic<uint32_t> *fw = fast_weights_.load(std::memory_order_acquire))  // (the statistics changed)
+    for (uint32_t i = 0; i < kFastWeights; ++i) fw[i].store(0xFFFFFFFFu, std::memory_order_relaxed);
+}
+
+Score Searcher::term_weight_cached(uint32_t term, uint64_t nd) const {
+  std::atomic<uint32_t> *fw = term < kFastWeights ? fast_weights_.load(std::memory_order_acquire) : nullptr;
+  if (fw) {
+    const uint32_t bits = fw[term].load(std::memory_order_relaxed);
+    if (bits != 0xFFFFFFFFu) {
+      Score w;
+      std::memcpy(&w, &bits, sizeof w);
+      return w;
+    }
+  }
+  const Score w = idf(doc_freq(term), nd) * (1.0f + K1);  // TermQuery::specialized_weight -> Bm25Weight::for_terms
+  if (term < kFastWeights) {
+    if (!fw) {
+      std::lock_guard<std::mutex> lk(cache_m_);
+      fw = fast_weights_.load(std::memory_order_relaxed);
+      if (!fw) {
+        fw = new std::atomic<uint32_t>[kFastWeights];
+        for (uint32_t i = 0; i < kFastWeights; ++i) fw[i].store(0xFFFFFFFFu, std::memory_order_relaxed);
+        fast_weights_.store(fw, std::memory_order_release);
+      }
+    }
+    uint32_t bits;
+    std::memcpy(&bits, &w, sizeof bits);
+    fw[term].store(bits, std::memory_order_relaxed);
+  }
+  return w;
+}
+
+Weight Searcher::weight_flat(uint8_t mode, const uint32_t *terms, uint32_t n_terms) const {
+  const uint64_t nd = total_num_docs(), nt = total_num_tokens();
+  if (nd == 0)
+    throw TantivyError(TantivyError::InvalidArgument, "no documents: BM25 statistics undefined");
+  if (n_terms > TQ_MAX_TERMS)
+    throw TantivyError(TantivyError::Unsupported, "more than 16 terms stay on the CPU");
+  Weight w;
+  {
+    std::lock_guard<std::mutex> lk(cache_m_);
+    if (!shared_cache_) {
+      const Score avg = (Score)nt / (Score)nd;
+      shared_cache_ = std::make_shared<Bm25Weight>(Bm25Weight::from_idf(0.0f, avg));
+    }
+    w.bm25 = shared_cache_;
+  }
+  w.mode = n_terms == 1 ? (uint8_t)TQ_MODE_OR : mode;  // (a one-term query: TermWeight::for_each_pruning)
+  w.terms.assign(terms, terms + n_terms);
+  w.weights.resize(n_terms);
+  for (uint32_t i = 0; i < n_terms; ++i) w.weights[i] = term_weight_cached(terms[i], nd);
+  return w;
 }
 uint64_t Searcher::total_num_docs() const {
   uint64_t n = remote_docs_;

@@ -546,12 +546,18 @@ def test_nested_must_queries_are_hoisted(ta):
         for i, q in enumerate(flat):
             want = O.bool_search(seg, q[1], q[2], 10, q[3], q[4])
             _assert_hits_close(_hits(s, d, c, i), want)
-        # not hoistable: an intersection inside a union, under MustNot, or with msm on either level
-        for bad in [(ta.MODE_BOOL, [1, 2, 3], [S, S, S], [0, 1, 1], 0, {"nested_occurs": [255, 1, 1]}),
-                    (ta.MODE_BOOL, [1, 2, 3], [M, N, N], [0, 1, 1], 0, {"nested_occurs": [255, 1, 1]}),
-                    (ta.MODE_BOOL, [1, 2, 3, 4], [M, M, M, S], [0, 1, 1, 2], 1, {"nested_occurs": [255, 1, 1, 255]})]:
-            with pytest.raises(ta.TantivyAmdError) as e:
-                dev.search([bad], 10)
-            assert e.value.code == 4, e.value  # TQ_ERR_UNSUPPORTED
+        # not hoistable — an intersection inside a union, under MustNot, or with a minimum on the parent: since
+        # round 5 these run on the device over the lists' bitmaps (tq_tree.hip; tests/test_gpu_tree.py); doc ids as the
+        # nested-tree oracle's
+        trees = [((ta.MODE_BOOL, [1, 2, 3], [S, S, S], [0, 1, 1], 0, {"nested_occurs": [255, 1, 1]}),
+                  [(S, 1), (S, [(M, 2), (M, 3)], 0)], 0),
+                 ((ta.MODE_BOOL, [1, 2, 3], [M, N, N], [0, 1, 1], 0, {"nested_occurs": [255, 1, 1]}),
+                  [(M, 1), (N, [(M, 2), (M, 3)], 0)], 0),
+                 ((ta.MODE_BOOL, [1, 2, 3, 4], [M, M, M, S], [0, 1, 1, 2], 1, {"nested_occurs": [255, 1, 1, 255]}),
+                  [(M, 1), (M, [(M, 2), (M, 3)], 0), (S, 4)], 1)]
+        for q, tree, msm in trees:
+            s, _, d, c = dev.search([q], 10)
+            want = O.tree_search(seg, tree, 10, msm)
+            assert sorted(int(d[0, j]) for j in range(int(c[0]))) == sorted(x for _, x in want), q
     finally:
         dev.close()
