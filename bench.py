@@ -497,7 +497,7 @@ def traffic_fields(tj, launches, kernel_ms):
     return out
 
 
-SCAN_KERNEL_RE = r"(and_kernel|union_kernel_small|union_kernel|ushare_kernel|ashare_kernel|xunion_kernel|or_kernel|phrase_sweep_kernel|phrase_kernel)<"
+SCAN_KERNEL_RE = r"(and_kernel|union_kernel_small|union_kernel|ushare_kernel|ashare_kernel|xunion_kernel|or_kernel|phrase_sweep_kernel|phrase_kernel|tree_kernel)<"
 
 
 def pmc_child(args):
@@ -871,16 +871,15 @@ def main():
     main_resident = resident_bytes(runner)
     main_exchange_ms = runner.exchange_ms()
     # ---- fabric traffic of this run's kernels (rocprofv3 passes around a child process) and what the lanes consume
+    # (the rocprofv3 passes themselves run after every timed leg of the run — three child processes per workload
+    # keep the host's CPU quota busy for ten seconds, and a host-bound step measured right after them pays for it)
     pmc_on = world == 1 and S_main == 1 and not args.no_pmc_inline
-    pm_main = pmc_inline(args, args.workload, n_q, k) if (pmc_on and rank == 0 and pruned_mode) else None
+    pmc_jobs = [("main", args.workload, n_q, k)] if (pmc_on and rank == 0 and pruned_mode) else []
     useful = None
     if world == 1 and S_main == 1 and pruned_mode and args.workload in ("and2", "and2_distinct"):
         from tantivy_amd import binding as TB
 
-        reads_a = None
-        if pm_main and pm_main.get("by_kernel", {}).get("ashare_kernel"):
-            reads_a = pm_main["by_kernel"]["ashare_kernel"]["read_requests"]
-        useful = ashare_useful_bytes(runner, queries, kern_main, k, TB.KERNEL_ASHARE, reads_a)
+        useful = ashare_useful_bytes(runner, queries, kern_main, k, TB.KERNEL_ASHARE, None)
     # The CPU baselines run AFTER every GPU measurement of the run: 10 s of all granted host cores
     # exhaust the cgroup's CPU quota, and the host planner of the next GPU measurement pays for it
     # (one run had the or5 step at 8.1 ms right after the baseline, 5.2 ms without).
@@ -919,10 +918,9 @@ def main():
             ach, fr = frac_of(sm["algo_bytes_full"], k_ms)
             # this run's own PMC passes for every workload (about 10 s each): roofline_frac = bytes that crossed the
             # fabric / kernel time / peak; the SURVEY 8d figure (algorithmic_frac) exceeds 1 where a launch shares lists
-            s_pm = pmc_inline(args, wl, len(qs), kk) if pmc_on else None
-            if wl == "mixed":
-                pm_mixed.update(s_pm or {})
-            phys = physical_roofline(k_ms, s_pm, traffic_fields(load_traffic("%s_pruned_%d" % (wl, args.docs)), 1, k_ms))
+            if pmc_on:
+                pmc_jobs.append((wl, wl, len(qs), kk))
+            phys = physical_roofline(k_ms, None, None)  # (filled in after the PMC passes, at the end of the run)
             ach_e, fr_e = frac_of(sm["algo_bytes_full"], sm["exh_stats"]["kernel_ms"])
             side[wl] = {
                 "config": "%s: %d queries/batch, k=%d, same %dM-doc segment%s" %
@@ -983,8 +981,7 @@ def main():
         # fabric bytes per step and GPU: the mixed stream's figure of this run (one segment, inline PMC passes) times
         # the local segments — the per-segment traffic does not depend on how many segments share the GPU
         # (profiles/r04_and2_s8_pmc.md: same FETCH per segment with 8 segments resident)
-        phys8 = physical_roofline(k_ms, pm_mixed if pm_mixed.get("traffic") else None,
-                                  traffic_fields(load_traffic("mixed_pruned_%d" % args.docs), s_local, k_ms), launches=s_local)
+        phys8 = physical_roofline(k_ms, None, None)  # (filled in after the PMC passes)
         res8 = resident_bytes(srun)
         strong = {
             "config": "BASELINE configs[4]: %d x %dM-doc segments (%dM docs), mixed 50%% 2-term AND / "
@@ -1048,6 +1045,29 @@ def main():
             sb["seconds"] = round(time.time() - t_s, 1)
             stream["by_terms"][str(vocab)] = sb
             del v_seg
+    # ---- this run's PMC passes, after everything that is timed: fabric bytes per workload -> roofline fields
+    pm_main = None
+    for key, wl, nn, kk in pmc_jobs:
+        pm = pmc_inline(args, wl, nn, kk)
+        if key == "main":
+            pm_main = pm
+            continue
+        sw = side[key]
+        ph = physical_roofline(sw["kernel_ms_avg"], pm, traffic_fields(load_traffic("%s_pruned_%d" % (wl, args.docs)), 1, sw["kernel_ms_avg"]))
+        sw.update({"roofline_achieved_GBps": ph["achieved"], "roofline_frac": ph["frac"], "traffic": ph["traffic"],
+                   "l2_hit_rate": ph["l2_hit_rate"], "traffic_source": ph["traffic_source"]})
+        if key == "mixed" and strong is not None and pm.get("traffic"):
+            # config 5 at this N: the mixed stream's figure of this run (one segment) times the local segments — the
+            # per-segment traffic does not depend on how many segments share the GPU (profiles/r04_and2_s8_pmc.md)
+            s_loc = strong["segments_per_gpu"]
+            ph8 = physical_roofline(strong["kernel_ms_per_gpu"], pm, None, launches=s_loc)
+            strong.update({"roofline_achieved_GBps_per_gpu": ph8["achieved"], "roofline_frac_per_gpu": ph8["frac"],
+                           "traffic_per_step_per_gpu": ph8["traffic"],
+                           "traffic_source": "%d x the mixed stream's fabric bytes per batch of this run (%s)" % (s_loc, ph8["traffic_source"])})
+    if useful and pm_main and pm_main.get("by_kernel", {}).get("ashare_kernel"):
+        reads_a = pm_main["by_kernel"]["ashare_kernel"]["read_requests"]
+        useful["fabric_read_requests"] = int(reads_a)
+        useful["request_efficiency"] = round(useful["useful_bytes"] / (128.0 * reads_a), 4) if reads_a else None
     cpu = None
     for key, c_segs, c_wl, c_qs, c_k, c_sec, c_sweep, c_gs in cpu_jobs:
         c = cpu_baseline(O, c_segs, c_wl, c_qs, c_k, c_sec, sweep=c_sweep, gstats=c_gs)

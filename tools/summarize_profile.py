@@ -22,7 +22,7 @@ from collections import defaultdict
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
-SCAN = re.compile(r"(and_kernel|union_kernel_small|union_kernel|ushare_kernel|ashare_kernel|xunion_kernel|or_kernel|phrase_sweep_kernel|phrase_kernel)<([^>]*)>")
+SCAN = re.compile(r"(and_kernel|union_kernel_small|union_kernel|ushare_kernel|ashare_kernel|xunion_kernel|or_kernel|phrase_sweep_kernel|phrase_kernel|tree_kernel)<([^>]*)>")
 
 
 def classify(name):
@@ -35,6 +35,8 @@ def classify(name):
         return fam, "both"  # the reference prunes nothing before positions are read
     if fam in ("ushare_kernel", "ashare_kernel"):
         return fam, "pruned"  # the term-major launches only exist in the pruned mode
+    if fam == "tree_kernel":
+        return fam, "both"  # nested boolean queries: nothing is pruned
     if fam == "xunion_kernel":
         return fam, "exhaustive"  # the doc-major union launch only exists without pruning
     return fam, ("pruned" if args[1] == "true" else "exhaustive")
