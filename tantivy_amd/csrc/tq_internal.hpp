@@ -441,6 +441,10 @@ struct ALeadKey {  // sort key of one lead of the shared-intersection group
   uint64_t sig;   // hash of the whole query (lists, weights, k): identical queries become neighbours
   uint32_t q, pad;
 };
+// (the shared-intersection planner orders the leads of one (leader, cache) by this bin of their mask: leads with the
+// same mask are neighbours, two masks in one bin — 2 048 bins — may interleave; tools/planbench/plan_check.cpp)
+constexpr uint32_t kALeadMaskBins = 2048;
+inline uint32_t alead_mask_bin(uint64_t m) { return (uint32_t)((m * 0x9E3779B97F4A7C15ull) >> 53); }
 struct ShareKey {  // one (query, list) pair of the shared-union group
   uint64_t key;    // list position i << 56 | blocks of the term (rare terms first) << 32 | cache
   uint32_t term, q;
@@ -481,10 +485,16 @@ struct PlanScratch {
     std::vector<ALeadKey> alead_keys, alead_keys2;
     std::vector<uint32_t> alead_first, alead_bucket, alead_bucket_at, alead_bucket_starts;
     std::vector<uint8_t> alead_same;
+    std::vector<uint64_t> aq_sig;   // per query of the group: hash of the whole query (lists, weights, k, roles)
+    std::vector<uint64_t> aq_slot;  // open-addressing table over aq_sig: the first query with that content
+    struct QKey {
+      uint32_t t0, t1, w0, w1, k, shape;
+    };
+    std::vector<QKey> aq_key;
     std::vector<uint32_t> aowner;  // per query of the group: the query whose result list it reads (itself, or the identical query before it)
-    std::vector<uint4> atasks, atasks_unsorted;
+    std::vector<uint4> atasks;
     std::vector<uint2> alists;  // boolean group: [query][list] = {bitmap, tf bytes} as offsets from the table base
-    std::vector<uint32_t> atask_pos, apairs, atask_hist, atask_slab_run;
+    std::vector<uint32_t> apairs, atask_hist, atask_slab_run;
     struct ARun {  // the leads of one (leader, cache)
       uint32_t r0, r1, term, cache, n_blocks, n_groups, per_group, bpt, nb_warm, n_runs;
       size_t task0;

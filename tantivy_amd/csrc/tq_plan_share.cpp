@@ -277,10 +277,83 @@ int build_ashare_plan(tq_segment *s, Group &g, PlanScratch &ps, bool boolean) {
   std::vector<ALeadKey> &keys = A.alead_keys;
   // (leads per query: one for an intersection; one per list of the lead set for a boolean query)
   std::vector<uint32_t> &lead0 = A.alead_first;  // first lead of every query
+  // Identical queries (lists, weights, k — and roles for boolean queries) are evaluated ONCE per batch: the
+  // first of them (the smallest query index) gets leads, the others read its result list at merge time
+  // (TqdQuery::chunk_first = the owner of the list, merge_lists_kernel).  Round 4 evaluated a repeated query
+  // once per GROUP of 32 leads: the 267 copies of the headline batch's most frequent pair had its leader
+  // decoded nine times.  The owners are found BEFORE any lead is built (an open-addressing table over the
+  // query hashes: 6 of 10 headline queries never reach the sort).  TQ_AS_DEDUPE=0: one lead per query,
+  // identical queries found as neighbours of the sorted table (twins inside a group).
+  static const bool kDedupe = tune_u32("TQ_AS_DEDUPE", 1) != 0;
+  std::vector<uint32_t> &owner = A.aowner;
+  std::vector<uint64_t> &sigs = A.aq_sig;
+  owner.resize(nq);
+  sigs.resize(nq);
+  // (what a query of <= 2 lists IS, in 24 bytes: the table compares these instead of two 328-byte descriptors)
+  std::vector<PlanScratch::ASharePlan::QKey> &qk = A.aq_key;
+  qk.resize(nq);
+  for (size_t q = 0; q < nq; ++q) {
+    const TqdQuery &dq = g.queries[q];
+    uint64_t sig = 0x9E3779B97F4A7C15ull * (uint64_t)(dq.n_terms | (dq.k << 8));
+    for (uint32_t m = 0; m < dq.n_terms; ++m) {
+      uint32_t wb;
+      memcpy(&wb, &dq.weight[m], sizeof wb);
+      sig = (sig ^ (((uint64_t)dq.term[m] << 32) | wb)) * 0xFF51AFD7ED558CCDull;
+      sig ^= sig >> 29;
+    }
+    if (boolean) {
+      sig = (sig ^ (((uint64_t)dq.roles << 32) | dq.clause_end)) * 0xFF51AFD7ED558CCDull;
+      sig = (sig ^ (((uint64_t)dq.n_lead << 40) | ((uint64_t)dq.n_opt_lead << 20) | dq.min_should)) * 0xFF51AFD7ED558CCDull;
+    }
+    sigs[q] = sig;
+    owner[q] = (uint32_t)q;
+    PlanScratch::ASharePlan::QKey &key = qk[q];
+    key.t0 = dq.term[0];
+    key.t1 = dq.n_terms > 1 ? dq.term[1] : 0u;
+    memcpy(&key.w0, &dq.weight[0], 4);
+    memcpy(&key.w1, &dq.weight[dq.n_terms > 1 ? 1 : 0], 4);
+    key.k = dq.k;
+    key.shape = dq.n_terms | (dq.cache_idx << 8) | (!boolean && dq.n_terms <= 2 ? 0x80000000u : 0u);  // bit 31: the key is the whole query
+  }
+  pt("sigs");
+  if (kDedupe && nq > 1) {
+    size_t cap = 16;
+    while (cap < 2 * nq) cap <<= 1;
+    std::vector<uint64_t> &slot = A.aq_slot;  // (32 bits of the hash) << 32 | query, or ~0
+    slot.assign(cap, ~0ull);
+    auto same = [&](size_t o, size_t q) -> bool {
+      if (memcmp(&qk[o], &qk[q], sizeof(qk[0]))) return false;
+      if (qk[q].shape >> 31) return true;
+      const TqdQuery &a = g.queries[o], &b = g.queries[q];
+      if (boolean && (a.roles != b.roles || a.clause_end != b.clause_end || a.n_lead != b.n_lead ||
+                      a.n_opt_lead != b.n_opt_lead || a.min_should != b.min_should))
+        return false;
+      return !memcmp(a.term, b.term, a.n_terms * sizeof(uint32_t)) && !memcmp(a.weight, b.weight, a.n_terms * sizeof(float));
+    };
+    constexpr size_t kAhead = 8;
+    for (size_t q = 0; q < nq; ++q) {
+      if (q + kAhead < nq) __builtin_prefetch(&slot[(size_t)(sigs[q + kAhead] >> 20) & (cap - 1)], 1);
+      const uint64_t tag = sigs[q] & 0xFFFFFFFF00000000ull;
+      size_t h = (size_t)(sigs[q] >> 20) & (cap - 1);
+      for (;; h = (h + 1) & (cap - 1)) {
+        const uint64_t e = slot[h];
+        if (e == ~0ull) {
+          slot[h] = tag | (uint64_t)q;
+          break;
+        }
+        if ((e & 0xFFFFFFFF00000000ull) == tag && same((size_t)(uint32_t)e, q)) {  // (the hash only proposes)
+          owner[q] = (uint32_t)e;
+          break;
+        }
+      }
+    }
+  }
+  pt("dedupe");
   lead0.resize(nq + 1);
   size_t nl = 0;
   for (size_t q = 0; q < nq; ++q) {
     lead0[q] = (uint32_t)nl;
+    if (owner[q] != q) continue;
     nl += boolean ? std::max<uint32_t>(1u, g.queries[q].n_lead) : 1u;
   }
   lead0[nq] = (uint32_t)nl;
@@ -292,14 +365,9 @@ int build_ashare_plan(tq_segment *s, Group &g, PlanScratch &ps, bool boolean) {
   parallel_slabs(fill_slabs, [&](uint32_t sb) {
     const size_t q0 = nq * sb / fill_slabs, q1 = nq * (sb + 1) / fill_slabs;
     for (size_t q = q0; q < q1; ++q) {
+      if (owner[q] != q) continue;
       const TqdQuery &dq = g.queries[q];
-      uint64_t sig = 0x9E3779B97F4A7C15ull * (uint64_t)(dq.n_terms | (dq.k << 8));
-      for (uint32_t m = 0; m < dq.n_terms; ++m) {
-        uint32_t wb;
-        memcpy(&wb, &dq.weight[m], sizeof wb);
-        sig = (sig ^ (((uint64_t)dq.term[m] << 32) | wb)) * 0xFF51AFD7ED558CCDull;
-        sig ^= sig >> 29;
-      }
+      const uint64_t sig = sigs[q];
       auto bit_of = [&](uint32_t handle) -> uint32_t {  // the list's doc-matrix bit: column (exact) or signature (maybe)
         const uint32_t col = column_of(handle);
         const uint32_t sig1 = !col ? (s->h_dterms[handle].has_freq >> 16) & 0xFFu : 0u;
@@ -344,8 +412,6 @@ int build_ashare_plan(tq_segment *s, Group &g, PlanScratch &ps, bool boolean) {
       }
       // boolean query (plan_bool_query's layout: [optional leading Should lists | lead Must clause | other
       // Must clauses | MustNot lists | Should lists]): one lead per list of the lead set
-      sig = (sig ^ (((uint64_t)dq.roles << 32) | dq.clause_end)) * 0xFF51AFD7ED558CCDull;
-      sig = (sig ^ (((uint64_t)dq.n_lead << 40) | ((uint64_t)dq.n_opt_lead << 20) | dq.min_should)) * 0xFF51AFD7ED558CCDull;
       const uint32_t n_lead = std::max<uint32_t>(1u, dq.n_lead);
       for (uint32_t m = 0; m < dq.n_terms; ++m)
       {  // (the list's own tables, or the ones built for boolean probes: build_probe_tables)
@@ -430,39 +496,60 @@ int build_ashare_plan(tq_segment *s, Group &g, PlanScratch &ps, bool boolean) {
     }
   });
   pt("leads");
-  // ---- order: (leader, cache), then mask, then the query hash (identical queries become neighbours:
-  // twins), stable in the query index.  Buckets by leader first (a counting sort: a few hundred
-  // leaders), then every bucket by the rest of the key — the planner's threads take a share of the
-  // buckets each (a comparison sort of the whole table was half of this function's time)
+  // ---- order: (leader, cache), then mask (the kernel keeps a block's membership ballots across consecutive
+  // leads with the same mask), stable in the query index: two counting sorts, 11 bits of a hash of the mask,
+  // then the leader (a comparison sort of the table was 0.40 of this function's 1.08 ms on the headline
+  // batch).  TQ_AS_DEDUPE=0 needs identical queries as neighbours: buckets by leader, then every bucket
+  // sorted by (mask, query hash).
   {
     std::vector<uint32_t> &cnt = A.alead_bucket;
     const size_t nt = s->terms.size();
-    cnt.assign(nt + 1, 0u);
-    for (size_t q = 0; q < nl; ++q) ++cnt[(size_t)(keys[q].k1 >> 8) + 1];
-    for (size_t t = 0; t < nt; ++t) cnt[t + 1] += cnt[t];
     std::vector<ALeadKey> &tmp = A.alead_keys2;
     tmp.resize(nl);
     std::vector<uint32_t> &at = A.alead_bucket_at;
+    if (kDedupe) {
+      at.assign(kALeadMaskBins + 1, 0u);
+      uint64_t cache_diff = 0;
+      for (size_t i = 0; i < nl; ++i) {
+        ++at[alead_mask_bin(keys[i].mask) + 1];
+        cache_diff |= (keys[i].k1 ^ keys[0].k1) & 0xFFu;
+      }
+      for (uint32_t b = 0; b < kALeadMaskBins; ++b) at[b + 1] += at[b];
+      for (size_t i = 0; i < nl; ++i) tmp[at[alead_mask_bin(keys[i].mask)]++] = keys[i];
+      keys.swap(tmp);
+      if (cache_diff) {  // more than one Bm25 cache in the batch (fields, boosts of the average): (leader, cache) runs
+        at.assign(257, 0u);
+        for (size_t i = 0; i < nl; ++i) ++at[(keys[i].k1 & 0xFFu) + 1];
+        for (uint32_t b = 0; b < 256; ++b) at[b + 1] += at[b];
+        for (size_t i = 0; i < nl; ++i) tmp[at[keys[i].k1 & 0xFFu]++] = keys[i];
+        keys.swap(tmp);
+      }
+    }
+    cnt.assign(nt + 1, 0u);
+    for (size_t q = 0; q < nl; ++q) ++cnt[(size_t)(keys[q].k1 >> 8) + 1];
+    for (size_t t = 0; t < nt; ++t) cnt[t + 1] += cnt[t];
     at.assign(cnt.begin(), cnt.end() - 1);
     for (size_t q = 0; q < nl; ++q) tmp[at[(size_t)(keys[q].k1 >> 8)]++] = keys[q];
     keys.swap(tmp);
-    // non-empty buckets, cut into slabs of about equal size
-    std::vector<uint32_t> &starts = A.alead_bucket_starts;
-    starts.clear();
-    for (size_t t = 0; t < nt; ++t)
-      if (cnt[t + 1] > cnt[t]) starts.push_back(cnt[t]);
-    starts.push_back((uint32_t)nl);
-    const uint32_t n_b = (uint32_t)starts.size() - 1u;
-    const uint32_t sort_slabs = nl >= 4096 ? std::min<uint32_t>(plan_threads(), std::max<uint32_t>(1u, n_b)) : 1u;
-    parallel_slabs(sort_slabs, [&](uint32_t sb) {
-      for (uint32_t b = sb; b < n_b; b += sort_slabs)  // (interleaved: the big buckets are the first leaders)
-        std::sort(keys.begin() + starts[b], keys.begin() + starts[b + 1], [](const ALeadKey &a, const ALeadKey &b2) {
-          if (a.k1 != b2.k1) return a.k1 < b2.k1;
-          if (a.mask != b2.mask) return a.mask < b2.mask;
-          if (a.sig != b2.sig) return a.sig < b2.sig;
-          return a.q < b2.q;
-        });
-    });
+    if (!kDedupe) {
+      // non-empty buckets, cut into slabs of about equal size
+      std::vector<uint32_t> &starts = A.alead_bucket_starts;
+      starts.clear();
+      for (size_t t = 0; t < nt; ++t)
+        if (cnt[t + 1] > cnt[t]) starts.push_back(cnt[t]);
+      starts.push_back((uint32_t)nl);
+      const uint32_t n_b = (uint32_t)starts.size() - 1u;
+      const uint32_t sort_slabs = nl >= 4096 ? std::min<uint32_t>(plan_threads(), std::max<uint32_t>(1u, n_b)) : 1u;
+      parallel_slabs(sort_slabs, [&](uint32_t sb) {
+        for (uint32_t b = sb; b < n_b; b += sort_slabs)  // (interleaved: the big buckets are the first leaders)
+          std::sort(keys.begin() + starts[b], keys.begin() + starts[b + 1], [](const ALeadKey &a, const ALeadKey &b2) {
+            if (a.k1 != b2.k1) return a.k1 < b2.k1;
+            if (a.mask != b2.mask) return a.mask < b2.mask;
+            if (a.sig != b2.sig) return a.sig < b2.sig;
+            return a.q < b2.q;
+          });
+      });
+    }
   }
   pt("sort");
   auto same_query = [&](const ALeadKey &a, const ALeadKey &b) -> bool {  // (the hash only proposes)
@@ -479,8 +566,8 @@ int build_ashare_plan(tq_segment *s, Group &g, PlanScratch &ps, bool boolean) {
     return !memcmp(qa.term, qb.term, qa.n_terms * sizeof(uint32_t)) &&
            !memcmp(qa.weight, qb.weight, qa.n_terms * sizeof(float));
   };
-  // identical queries share one row of threshold slots, whatever groups they end up in (a slot is
-  // hash(doc): the same doc lands in the same slot whichever group scored it)
+  // TQ_AS_DEDUPE=0: identical queries share one row of threshold slots, whatever groups they end up in (a slot
+  // is hash(doc): the same doc lands in the same slot whichever group scored it)
   std::vector<uint8_t> &same_as_prev = A.alead_same;
   same_as_prev.resize(nl);
   const uint32_t gather_slabs = nl >= 4096 ? plan_threads() : 1u;
@@ -488,40 +575,12 @@ int build_ashare_plan(tq_segment *s, Group &g, PlanScratch &ps, bool boolean) {
     const size_t i0 = nl * sb / gather_slabs, i1 = nl * (sb + 1) / gather_slabs;
     for (size_t i = i0; i < i1; ++i) {
       leads[i] = unsorted[keys[i].q];
-      same_as_prev[i] = i && same_query(keys[i], keys[i - 1]) ? 1 : 0;
+      same_as_prev[i] = !kDedupe && i && same_query(keys[i], keys[i - 1]) ? 1 : 0;
     }
   });
-  for (size_t i = 1; i < nl; ++i)
-    if (same_as_prev[i]) leads[i].thr_row = leads[i - 1].thr_row;
-  // Identical queries (lists, weights, k — and roles for boolean queries) are evaluated ONCE per batch: the
-  // first of them (the smallest query index: the sort is stable) keeps its leads, the others read its result
-  // list at merge time (TqdQuery::chunk_first = the owner of the list, merge_lists_kernel).  Round 4 evaluated
-  // a repeated query once per GROUP of 32 leads: the 267 copies of the headline batch's most frequent pair
-  // had its leader decoded nine times.  TQ_AS_DEDUPE=0: one lead per query as before (twins inside a group).
-  static const bool kDedupe = tune_u32("TQ_AS_DEDUPE", 1) != 0;
-  std::vector<uint32_t> &owner = A.aowner;
-  owner.resize(nq);
-  for (size_t q = 0; q < nq; ++q) owner[q] = (uint32_t)q;
-  if (kDedupe) {
-    size_t w = 0;
-    uint32_t head_q = 0;
-    for (size_t i = 0; i < nl; ++i) {
-      if (same_as_prev[i]) {
-        owner[leads[i].query] = head_q;
-        continue;
-      }
-      head_q = leads[i].query;
-      if (w != i) {
-        leads[w] = leads[i];
-        keys[w] = keys[i];
-      }
-      ++w;
-    }
-    nl = w;
-    leads.resize(nl);
-    keys.resize(nl);
-    std::fill(same_as_prev.begin(), same_as_prev.begin() + (long)nl, (uint8_t)0);
-  }
+  if (!kDedupe)
+    for (size_t i = 1; i < nl; ++i)
+      if (same_as_prev[i]) leads[i].thr_row = leads[i - 1].thr_row;
   pt("gather");
   // ---- tasks: groups of leads x runs of blocks; fewer, longer tasks if the result lists (k entries
   // per (task, lead) pair) would not fit the budget.  The first kWarmPermille / 1000 of every leader go
@@ -531,8 +590,8 @@ int build_ashare_plan(tq_segment *s, Group &g, PlanScratch &ps, bool boolean) {
   // leaves the main launch the k-th best of a sample of every query to start from.
   static const uint32_t kWarmPermille = std::min<uint32_t>(1000u, tune_u32("TQ_AS_WARM_PERMILLE", 2));
   static const uint32_t kWarmBlocks = std::max<uint32_t>(1u, tune_u32("TQ_AS_WARM_BLOCKS", 2));
-  std::vector<uint4> &tasks = A.atasks, &raw = A.atasks_unsorted;
-  std::vector<uint32_t> &pos = A.atask_pos, &pairs = A.apairs;
+  std::vector<uint4> &tasks = A.atasks;
+  std::vector<uint32_t> &pairs = A.apairs;
   pairs.resize(nq);
   // the runs of one (leader, cache): their groups, task sizes and where their tasks start
   std::vector<PlanScratch::ASharePlan::ARun> &runs = A.aruns;
@@ -597,12 +656,10 @@ int build_ashare_plan(tq_segment *s, Group &g, PlanScratch &ps, bool boolean) {
     stretch *= 2u;
   }
   if (n_tasks > 0x7FFFFFFFull) return fail(TQ_ERR_UNSUPPORTED, "batch too large (tasks)");
-  raw.resize(n_tasks);
-  pos.resize(n_tasks);
   tasks.resize(n_tasks);
-  // slabs of runs of about equal task counts: each fills its tasks and counts them by doc slice; the
-  // (slice, slab) prefix sums give every slab its places in the launch order (a stable counting sort:
-  // slice 0 = the warm-up launch, then the main launch's tasks by doc slice)
+  // slabs of runs of about equal task counts: each counts its tasks by doc slice; the (slice, slab) prefix
+  // sums give every slab its places in the launch order (a stable counting sort: slice 0 = the warm-up
+  // launch, then the main launch's tasks by doc slice); a second walk over the runs writes the tasks there
   constexpr uint32_t kSl = 4098;
   const uint32_t t_slabs = n_tasks >= 16384 ? std::min<uint32_t>(plan_threads(), (uint32_t)runs.size()) : 1u;
   std::vector<uint32_t> &hist = A.atask_hist;
@@ -616,6 +673,15 @@ int build_ashare_plan(tq_segment *s, Group &g, PlanScratch &ps, bool boolean) {
       if (runs[r].task0 >= n_tasks * (sb + 1) / t_slabs) slab_run[++sb] = r;
     for (uint32_t x = sb + 1; x < t_slabs; ++x) slab_run[x] = (uint32_t)runs.size();
   }
+  auto walk_run = [&](const PlanScratch::ASharePlan::ARun &R, auto &&emit) {  // emit(j0, nb, slice) per run of blocks
+    const uint64_t slice_mul = ((uint64_t)1 << 44) / R.n_blocks;  // (j0 << 12) / n_blocks without the division
+    for (uint32_t j0 = 0; j0 < R.n_blocks;) {
+      const bool warm = j0 < R.nb_warm;
+      const uint32_t nb = warm ? std::min<uint32_t>(kWarmBlocks, R.nb_warm - j0) : std::min<uint32_t>(R.bpt, R.n_blocks - j0);
+      emit(j0, nb, warm ? 0u : 1u + std::min<uint32_t>(4095u, (uint32_t)((j0 * slice_mul) >> 32)));
+      j0 += nb;
+    }
+  };
   parallel_slabs(t_slabs, [&](uint32_t sb) {
     uint32_t *h = hist.data() + (size_t)sb * kSl;
     for (uint32_t r = slab_run[sb]; r < slab_run[sb + 1]; ++r) {
@@ -624,22 +690,7 @@ int build_ashare_plan(tq_segment *s, Group &g, PlanScratch &ps, bool boolean) {
         const bool twin = (a - R.r0) % R.per_group != 0 && same_as_prev[a];
         leads[a].info = (leads[a].info & ~0x200u) | (twin ? 0x200u : 0u);
       }
-      const uint32_t n_run = R.r1 - R.r0;
-      const uint64_t slice_mul = ((uint64_t)1 << 44) / R.n_blocks;  // (j0 << 12) / n_blocks without the division
-      size_t at = R.task0;
-      for (uint32_t j0 = 0; j0 < R.n_blocks;) {
-        const bool warm = j0 < R.nb_warm;
-        const uint32_t nb = warm ? std::min<uint32_t>(kWarmBlocks, R.nb_warm - j0) : std::min<uint32_t>(R.bpt, R.n_blocks - j0);
-        const uint32_t slice = warm ? 0u : 1u + std::min<uint32_t>(4095u, (uint32_t)((j0 * slice_mul) >> 32));
-        for (uint32_t gr = 0; gr < R.n_groups; ++gr) {
-          const uint32_t l0 = gr * R.per_group, l1 = std::min<uint32_t>(n_run, l0 + R.per_group);
-          raw[at] = make_uint4(R.term, j0, nb | ((l1 - l0) << 16) | (R.cache << 24), R.r0 + l0);
-          pos[at] = slice;
-          ++at;
-        }
-        h[slice] += R.n_groups;
-        j0 += nb;
-      }
+      walk_run(R, [&](uint32_t, uint32_t, uint32_t slice) { h[slice] += R.n_groups; });
     }
   });
   {
@@ -654,9 +705,18 @@ int build_ashare_plan(tq_segment *s, Group &g, PlanScratch &ps, bool boolean) {
   }
   parallel_slabs(t_slabs, [&](uint32_t sb) {
     uint32_t *h = hist.data() + (size_t)sb * kSl;
-    const size_t t0 = slab_run[sb] < runs.size() ? runs[slab_run[sb]].task0 : n_tasks;
-    const size_t t1 = slab_run[sb + 1] < runs.size() ? runs[slab_run[sb + 1]].task0 : n_tasks;
-    for (size_t i = t0; i < t1; ++i) tasks[h[pos[i]]++] = raw[i];
+    for (uint32_t r = slab_run[sb]; r < slab_run[sb + 1]; ++r) {
+      const PlanScratch::ASharePlan::ARun &R = runs[r];
+      const uint32_t n_run = R.r1 - R.r0;
+      walk_run(R, [&](uint32_t j0, uint32_t nb, uint32_t slice) {
+        uint4 *out = tasks.data() + h[slice];
+        h[slice] += R.n_groups;
+        for (uint32_t gr = 0; gr < R.n_groups; ++gr) {
+          const uint32_t l0 = gr * R.per_group, l1 = std::min<uint32_t>(n_run, l0 + R.per_group);
+          out[gr] = make_uint4(R.term, j0, nb | ((l1 - l0) << 16) | (R.cache << 24), R.r0 + l0);
+        }
+      });
+    }
   });
   pt("tasks");
   // result lists: k entries per (task, lead) pair of the query

@@ -323,7 +323,10 @@ static int check_ashare(int seed) {
         (uint64_t)ld.tf8_off * 8u != (uint64_t)t1.tf8_blob - ps.share_table_base)
       return fail_msg("table offsets", (long)i);
     const uint64_t key = ((uint64_t)q.term[0] << 8) | q.cache_idx;
-    if (i && (key < prev_key || (key == prev_key && mask < prev_mask))) return fail_msg("lead order", (long)i);
+    // (TQ_AS_DEDUPE=1: by the planner's bin of the mask; =0: by the mask itself — either way equal masks are neighbours)
+    const bool by_bin = !getenv("TQ_AS_DEDUPE") || atoi(getenv("TQ_AS_DEDUPE")) != 0;
+    const uint64_t mk = by_bin ? alead_mask_bin(mask) : mask, prev_mk = by_bin ? alead_mask_bin(prev_mask) : prev_mask;
+    if (i && (key < prev_key || (key == prev_key && mk < prev_mk))) return fail_msg("lead order", (long)i);
     prev_key = key;
     prev_mask = mask;
   }
