@@ -71,6 +71,8 @@ enum tq_mode { TQ_MODE_AND = 0, TQ_MODE_OR = 1, TQ_MODE_PHRASE = 2, TQ_MODE_BOOL
  * (left + right + sum(others)) + the matching Should terms.  Values of tq_query.occurs follow
  * src/query/occur.rs. */
 enum tq_occur { TQ_SHOULD = 0, TQ_MUST = 1, TQ_MUST_NOT = 2 };
+/* tq_query.nested_occurs[i] | TQ_NESTED_PHRASE: the terms of the clause that share atom_of[i] are a PhraseQuery */
+#define TQ_NESTED_PHRASE 0x10
 
 typedef struct tq_ctx tq_ctx;
 typedef struct tq_segment tq_segment;
@@ -87,7 +89,7 @@ typedef struct tq_query {
   const float *weights;          /* AND/OR: n_terms x (idf*(1+K1)*boost); PHRASE: weights[0] */
   const float *tf_cache;         /* Bm25Weight.cache: 256 f32, K1*(1-B+B*fieldnorm/avg) */
   uint8_t mode;                  /* enum tq_mode */
-  const uint32_t *phrase_offsets; /* PHRASE: term offsets inside the phrase; else NULL */
+  const uint32_t *phrase_offsets; /* PHRASE: term offsets inside the phrase; BOOL with phrase atoms: per term; else NULL */
   uint32_t k;                    /* TopDocs offset+limit, 1..TQ_MAX_K */
   const uint8_t *occurs;         /* TQ_MODE_BOOL: n_terms x enum tq_occur; else NULL */
   const uint8_t *clause_of;      /* TQ_MODE_BOOL: clause index per term (terms sharing a value form
@@ -105,7 +107,14 @@ typedef struct tq_query {
                                         value form a CONJUNCTION — a BooleanQuery of Must terms one level further down,
                                         `+a +((+b +c) d)`: present where all its terms are, scoring their sum; its occur
                                         inside the group is nested_occurs of its terms (equal for all of them).  NULL =
-                                        every term is its own member of its group. */
+                                        every term is its own member of its group.
+                                        A PHRASE inside the boolean query (`+"a b" +c`, `"a b" c`, `+c -"a b"`,
+                                        `+a +("b c" d)`; PhraseQuery as a clause of BooleanQuery: PhraseScorer under
+                                        Intersection / union / Exclude, phrase_scorer.rs:347-587): the terms of the
+                                        phrase share an atom_of value, carry nested_occurs | TQ_NESTED_PHRASE, their
+                                        phrase_offsets[i] (0 on the other terms) and — each of them — the PHRASE's
+                                        weight ((1 + K1) * boost * sum of idfs) in weights[i].  2..4 terms per phrase; a
+                                        phrase that is a clause of its own is a clause_of group of one atom. */
 } tq_query;
 
 /* ---- lifecycle ---- */

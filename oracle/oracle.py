@@ -859,7 +859,8 @@ def tree_match_all(seg, clauses, min_should_match=0):
     """A BooleanQuery whose clauses are terms or BooleanQuerys of terms (depth 2), restated from
     BooleanWeight::complex_scorer applied on both levels (boolean_weight.rs:236-431; the nested query's scorer is
     just another Box<dyn Scorer> of its parent, :225-233).  clauses = [(occur, term_id) |
-    (occur, [(inner occur, term_id | [term ids of a nested intersection]), ...], nested minimum_number_should_match)].  Every term scores with its own
+    (occur, [(inner occur, term_id | [term ids of a nested intersection]), ...], nested minimum_number_should_match)];
+    a term_id can also be ("ph", [term ids][, offsets]): a PhraseQuery (as a clause or as a member).  Every term scores with its own
     Bm25Weight.  Returns (docs ascending, f32 scores).  Sums of 3+ terms compare within 1e-5 (the reference's own
     order follows scorer removal / cursor order)."""
     md = seg.max_doc
@@ -876,13 +877,40 @@ def tree_match_all(seg, clauses, min_should_match=0):
             per[t] = (hit, sc, seg.terms[t].doc_freq)
         return per[t]
 
+    def phrase(terms, offsets=None):
+        # PhraseScorer (phrase_scorer.rs:347-587): docs where the terms line up, bm25(sum of idfs, norm, phrase count);
+        # cost = size_hint of the intersection of its lists * 10 * terms (:566-573, size_hint.rs:11-36)
+        hit = np.zeros(md, bool)
+        sc = np.zeros(md, np.float32)
+        if all(seg.terms[t].doc_freq for t in terms):
+            d, s = match_all(seg, list(terms), MODE_PHRASE, phrase_offsets=offsets)
+            hit[d] = True
+            sc[d] = s
+        est, smallest, f = 0.0, 0.0, 1.3
+        for i, t in enumerate(terms):
+            df = float(seg.terms[t].doc_freq)
+            if i == 0:
+                est = smallest = df
+            else:
+                f = max(1.0, f - 0.1)
+                est *= df / md * f
+                smallest = min(smallest, df)
+        return hit, sc, int(min(round(est), smallest)) * 10 * len(terms)
+
+    def is_phrase(t):
+        return isinstance(t, tuple) and len(t) >= 2 and t[0] == "ph"
+
     items = []
     for cl in clauses:
-        if isinstance(cl[1], (list, tuple)):
+        if is_phrase(cl[1]):  # a PhraseQuery as a clause: ("ph", [term ids][, offsets])
+            items.append((cl[0], phrase(*cl[1][1:])))
+        elif isinstance(cl[1], (list, tuple)):
             inner_msm = cl[2] if len(cl) > 2 else 0
             members = []
             for o, t in cl[1]:
-                if isinstance(t, (list, tuple)):  # an intersection of terms one level further down
+                if is_phrase(t):
+                    members.append((o, phrase(*t[1:])))
+                elif isinstance(t, (list, tuple)):  # an intersection of terms one level further down
                     members.append((o, _combine_scorers(md, [(MUST, leaf(x)) for x in t], 0)))
                 else:
                     members.append((o, leaf(t)))

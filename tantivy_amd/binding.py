@@ -52,6 +52,7 @@ KERNEL_PHRASE_SWEEP, KERNEL_BOOL, KERNEL_USHARE, KERNEL_XUNION, KERNEL_ASHARE = 
 KERNEL_BSHARE = 0x400
 KERNEL_COUNT_BITMAPS = 0x800
 KERNEL_TREE = 0x1000
+NESTED_PHRASE = 0x10  # tq_query.nested_occurs flag: the atom is a PhraseQuery (include/tantivy_amd.h)
 KERNEL_NAMES = {0x1: "and_dense", 0x2: "and", 0x4: "union", 0x8: "or_windows", 0x10: "phrase", 0x20: "phrase_sweep",
                 0x40: "bool", 0x80: "ushare", 0x100: "xunion", 0x200: "ashare", 0x400: "bshare", 0x800: "count_bitmaps",
                 0x1000: "tree"}
@@ -456,7 +457,10 @@ class DeviceIndex:
         {SHOULD, MUST, MUST_NOT}; terms sharing a clause_of value form one nested union.  A trailing
         dict {"boosts": [...]} wraps every term query in BoostQuery(boost); {"nested_occurs": [...]}
         gives the occur of every term INSIDE its clause_of group (255 = Should: a nested union), e.g.
-        `+a +(+b -c)` = (MODE_BOOL, [a, b, c], [MUST]*3, [0, 1, 1], 0, {"nested_occurs": [255, 1, 2]})."""
+        `+a +(+b -c)` = (MODE_BOOL, [a, b, c], [MUST]*3, [0, 1, 1], 0, {"nested_occurs": [255, 1, 2]}).  A phrase
+        inside a boolean query: its terms share an "atom_of" value, carry nested_occurs | NESTED_PHRASE and their
+        "phrase_offsets" — `+"a b" +c` = (MODE_BOOL, [a, b, c], [MUST]*3, [0, 0, 1], 0, {"nested_occurs": [0x11, 0x11, 1],
+        "atom_of": [0, 0, 0], "phrase_offsets": [0, 1, 0]})."""
         n = len(queries)
         qs = (TqhQuery * max(1, n))()
         keep = []
@@ -477,6 +481,10 @@ class DeviceIndex:
                 aa = (C.c_uint8 * len(terms))(*[int(o) for o in extra["atom_of"]])
                 keep.append(aa)
                 qs[i].atom_of = C.cast(aa, C.POINTER(C.c_uint8))
+            if extra and extra.get("phrase_offsets") is not None:  # MODE_BOOL: offsets of the terms of phrases inside it
+                pa = (C.c_uint32 * len(terms))(*[int(o) for o in extra["phrase_offsets"]])
+                keep.append(pa)
+                qs[i].phrase_offsets = C.cast(pa, C.POINTER(C.c_uint32))
             if extra and extra.get("clause_min_should") is not None:  # {clause_of value: nested minimum}
                 ma = (C.c_uint8 * 16)(*[int(extra["clause_min_should"].get(c, 0)) for c in range(16)])
                 keep.append(ma)

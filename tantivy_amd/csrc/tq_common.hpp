@@ -677,4 +677,53 @@ __device__ __forceinline__ uint32_t position_delta(const uint8_t *pos, const Tqd
   return t->pos_tail[i - ((uint64_t)t->n_pos_blocks << 7)];
 }
 
+// ---- positions of one posting, one at a time (the phrase kernels' cursor merge; tq_tree.hip's phrase atoms)
+struct PosCursor {
+  uint32_t idx, end, cur;
+  bool valid;
+};
+__device__ __forceinline__ void pos_advance(PosCursor &c, const uint8_t *pos, const TqdTerm *t) {
+  if (c.idx < c.end) {
+    c.cur += position_delta(pos, t, c.idx);
+    c.idx++;
+  } else {
+    c.valid = false;
+  }
+}
+
+
+// Term freq of posting `at` of a block and the sum of the term freqs of the <= 3 postings before
+// it in its group of four (slots 4g..4g+3 are value g of the four bit streams: they share one
+// 16-byte row of the tf payload, or two when the value straddles a word).  rec = the block's
+// record; per-lane arguments.
+__device__ __forceinline__ void group_tfs(const uint8_t *idx, const TermRef &t, const uint4 rec,
+                                          uint32_t at, uint32_t &tf, uint32_t &excl) {
+  uint32_t v[4];
+  if (rec.y == META_TAIL) {
+    const uint32_t g0 = at & ~3u;
+#pragma unroll
+    for (uint32_t l = 0; l < 4u; ++l) v[l] = g0 + l < t.n_tail ? t.tail_tfs[g0 + l] : 0u;
+  } else {
+    const uint32_t doc_bits = rec.y & 31u;
+    const uint32_t strict = (rec.y >> 6) & 1u;
+    const uint32_t b = (rec.y >> 8) & 0xFFu;
+    const uint32_t bitpos = (at >> 2) * b;
+    const uint32_t w = bitpos >> 5, sh = bitpos & 31u;
+    const uint8_t *q = idx + t.payload_base + rec.z + 16u * doc_bits + 16u * w;
+    U4Unaligned r0 = {0u, 0u, 0u, 0u}, r1 = {0u, 0u, 0u, 0u};
+    if (b) {  // (b == 0: every tf of the block is `strict`)
+      r0 = *reinterpret_cast<const U4Unaligned *>(q);
+      r1 = *reinterpret_cast<const U4Unaligned *>(q + 16);  // may over-read: buffers are padded
+    }
+    const uint32_t mask = b >= 32u ? 0xFFFFFFFFu : ((1u << b) - 1u);
+    v[0] = (__funnelshift_r(r0.x, r1.x, sh) & mask) + strict;
+    v[1] = (__funnelshift_r(r0.y, r1.y, sh) & mask) + strict;
+    v[2] = (__funnelshift_r(r0.z, r1.z, sh) & mask) + strict;
+    v[3] = (__funnelshift_r(r0.w, r1.w, sh) & mask) + strict;
+  }
+  const uint32_t l0 = at & 3u;
+  tf = l0 == 0u ? v[0] : (l0 == 1u ? v[1] : (l0 == 2u ? v[2] : v[3]));
+  excl = (l0 > 0u ? v[0] : 0u) + (l0 > 1u ? v[1] : 0u) + (l0 > 2u ? v[2] : 0u);
+}
+
 }  // namespace

@@ -107,6 +107,8 @@ struct TermHost {
   void *probe_dense_blob = nullptr, *probe_tf8_blob = nullptr;  // a list below "dense_ratio" that boolean queries
                                // probe in the shared launch: bitmap + rank directory and tf bytes built on first
                                // use ("probe_budget_x"); the other kernels do not see them
+  void *probe_posdir_blob = nullptr;  // ... and its position directory (TqdTerm::pos_dir layout), built the first time
+                                      // a phrase INSIDE a boolean query names the list (tq_tree.hip)
   void *rmax_blob = nullptr;   // range maxima of a list with a bitmap (its own or the probe tables'): one byte per
                                // TQD_RM_SHIFT docs, tq_ashare.hip's bound on non-leader lists
   uint32_t rmax_list = 255;    // ... the largest of them
@@ -663,6 +665,7 @@ int build_flat(tq_segment *s, uint32_t handle, hipStream_t st, bool *ok);
 int order_after_last_batch(tq_segment *s, hipStream_t st);
 int wait_segment_idle(tq_segment *s);
 int build_probe_tables(tq_segment *s, uint32_t handle, bool *ok);
+int build_probe_posdir(tq_segment *s, uint32_t handle, bool *ok);
 int count_batch(tq_segment *s, const tq_query *queries, uint32_t n_queries, uint32_t *out_counts);
 // a query as a bitwise expression over bitmap words (tq_count.cpp; checked on the CPU by tools/planbench/plan_check.cpp)
 bool count_expression(tq_segment *s, const tq_query &q, TqkCountQuery &cq, bool &known, uint64_t &driver_postings,

@@ -165,20 +165,24 @@ struct TqkSegMergeParams {
 // then MustNot); inside a clause Must terms first.  Occurs: TQD_ROLE_* (= enum tq_occur).
 constexpr uint32_t TQK_TREE_TILE_WORDS = 4096;  // bitmap words (131 072 docs) per (query, tile) wavefront
 constexpr uint32_t TQK_TREE_MAX_TERMS = 16;
+constexpr uint32_t TQK_TREE_PHRASE_TERMS = 4;  // terms of a phrase inside a boolean query (one position cursor each, in registers)
 struct TqdTreeQuery {
   uint32_t n_terms, n_clauses;   // 0 / 0: the planner found the query empty
   uint32_t k, cache_idx;
   uint32_t part_start;           // first partial top-k list (one per tile)
   uint32_t top_has_must;         // the query has Must clauses (else: the union of its Should clauses)
   uint32_t top_need;             // Should clauses that have to match: minimum_number_should_match, at least 1 without a Must clause
-  uint32_t pad_;
+  uint32_t has_phrase;           // some atom is a PhraseQuery (atom_end bit 1): the bitmap expression is a superset, every doc is re-checked
   uint32_t dense_off[TQK_TREE_MAX_TERMS];    // bitmap + rank directory / byte-wide tfs of the term's list, as offsets
   uint32_t tf8_off[TQK_TREE_MAX_TERMS];      // from TqkTreeParams::table_base in 8-byte units
   uint32_t weight_bits[TQK_TREE_MAX_TERMS];  // (float) idf * (1 + k1) * boost
   uint32_t handle[TQK_TREE_MAX_TERMS];       // term handle (saturated tf bytes read the packed value)
   uint32_t inner[TQK_TREE_MAX_TERMS];        // occur of the term's ATOM inside its clause (an atom = a run of terms that
                                              // must all be present: one term, or a nested intersection of terms)
-  uint32_t atom_end[TQK_TREE_MAX_TERMS];     // 1: the term is the last of its atom
+  uint32_t atom_end[TQK_TREE_MAX_TERMS];     // bit 0: the term is the last of its atom; bit 1 (on every term of the atom): the atom is
+                                             // a PhraseQuery of <= TQK_TREE_PHRASE_TERMS terms (weight_bits = the phrase's weight)
+  uint32_t dir_off[TQK_TREE_MAX_TERMS];      // phrase terms: position directory of the list (TqdTerm::pos_dir layout), 8-byte units
+  uint32_t phrase_off[TQK_TREE_MAX_TERMS];   // phrase terms: max_offset - term_offset (phrase_scorer.rs:372-385)
   uint32_t outer[TQK_TREE_MAX_TERMS];        // per clause: its occur in the query
   uint32_t inner_need[TQK_TREE_MAX_TERMS];   // per clause: Should terms that have to be present
   uint32_t first_term[TQK_TREE_MAX_TERMS + 1];  // per clause: its terms are [first_term[c], first_term[c + 1])
@@ -191,6 +195,7 @@ struct TqkTreeParams {
   const TqkSinks *sinks;
   const uint8_t *table_base;
   uint32_t n_queries, n_words;
+  uint32_t any_phrase;  // some query of the launch has a phrase atom (selects the kernel instantiation)
 };
 hipError_t tqk_launch_tree(const TqkTreeParams &p, int kpl, hipStream_t st);
 uint32_t tqk_tree_tiles(uint32_t n_words);

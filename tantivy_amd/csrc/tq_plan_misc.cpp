@@ -231,6 +231,9 @@ namespace tqi {
 // minimum_number_should_match above 1, or a top-level minimum above 1 next to a nested clause.
 bool bool_query_is_tree(const tq_query &q) {
   if (q.mode != TQ_MODE_BOOL || !q.occurs || !q.terms) return false;
+  if (q.nested_occurs)  // a PhraseQuery inside the boolean query
+    for (uint32_t i = 0; i < q.n_terms && i < TQ_MAX_TERMS; ++i)
+      if (q.nested_occurs[i] != 255u && (q.nested_occurs[i] & TQ_NESTED_PHRASE)) return true;
   uint32_t size_of[TQ_MAX_TERMS] = {0};
   bool multi = false;
   for (uint32_t i = 0; i < q.n_terms && i < TQ_MAX_TERMS; ++i) {
@@ -281,11 +284,12 @@ bool bool_query_is_tree(const tq_query &q) {
 int plan_tree_query(tq_segment *s, const tq_query &q, uint32_t qi, TqdTreeQuery &tq, uint64_t &qbytes, uint64_t table_base) {
   tq = TqdTreeQuery{};
   tq.k = q.k;
-  struct Atom {  // a member of a nested query: one term, or a conjunction of terms
-    uint32_t id, inner, n = 0, handle[TQ_MAX_TERMS];
+  struct Atom {  // a member of a nested query: one term, a conjunction of terms, or a phrase
+    uint32_t id, inner, n = 0, handle[TQ_MAX_TERMS], off[TQ_MAX_TERMS];
     float w[TQ_MAX_TERMS];
-    bool empty = false;
-    uint64_t cost = ~0ull;  // its rarest list
+    bool empty = false, phrase = false;
+    uint32_t n_named = 0;   // terms the caller named (absent ones included)
+    uint64_t cost = ~0ull;  // its rarest list; a phrase: PhraseScorer::cost (phrase_scorer.rs:566-573)
   };
   struct Clause {
     uint32_t id, outer, n = 0, msm = 0;
@@ -298,8 +302,12 @@ int plan_tree_query(tq_segment *s, const tq_query &q, uint32_t qi, TqdTreeQuery 
   uint32_t n_cl = 0, n_at = 0;
   for (uint32_t i = 0; i < q.n_terms; ++i) {
     if (q.occurs[i] > TQ_MUST_NOT) return fail(TQ_ERR_INVALID, "query %u: bad occur", qi);
-    const uint32_t inner = q.nested_occurs ? q.nested_occurs[i] : (uint32_t)TQ_SHOULD;
+    uint32_t inner = q.nested_occurs ? q.nested_occurs[i] : (uint32_t)TQ_SHOULD;
+    const bool in_phrase = inner != 255u && (inner & TQ_NESTED_PHRASE);
+    if (in_phrase) inner &= ~(uint32_t)TQ_NESTED_PHRASE;
     if (inner > TQ_MUST_NOT) return fail(TQ_ERR_INVALID, "query %u: bad nested occur", qi);
+    if (in_phrase && (!q.atom_of || !q.phrase_offsets))
+      return fail(TQ_ERR_INVALID, "query %u: a phrase inside a boolean query needs atom_of and phrase_offsets", qi);
     const uint32_t id = q.clause_of ? q.clause_of[i] : i;
     if (id >= TQ_MAX_TERMS) return fail(TQ_ERR_INVALID, "query %u: clause_of value %u above %u", qi, id, TQ_MAX_TERMS - 1u);
     uint32_t c = 0;
@@ -321,23 +329,51 @@ int plan_tree_query(tq_segment *s, const tq_query &q, uint32_t qi, TqdTreeQuery 
       a = n_at++;
       atoms[a].id = aid;
       atoms[a].inner = inner;
+      atoms[a].phrase = in_phrase;
       cl[c].atom[cl[c].n++] = a;
-    } else if (atoms[a].inner != inner) {
+    } else if (atoms[a].inner != inner || atoms[a].phrase != in_phrase) {
       return fail(TQ_ERR_INVALID, "query %u: a conjunction (atom_of %u) mixes nested occurs", qi, aid);
     }
+    ++atoms[a].n_named;
     if (q.terms[i] == TQ_TERM_ABSENT) {
       atoms[a].empty = true;  // an EmptyScorer inside the conjunction
       continue;
     }
     if (q.terms[i] >= s->terms.size()) return fail(TQ_ERR_INVALID, "query %u: unknown term handle %u", qi, q.terms[i]);
     if (!(q.weights[i] >= 0.0f)) return fail(TQ_ERR_UNSUPPORTED, "query %u: negative boost inside a nested boolean query", qi);
+    if (in_phrase && s->terms[q.terms[i]].positions_len == 0)
+      return fail(TQ_ERR_UNSUPPORTED, "query %u: phrase on a field without positions", qi);
     atoms[a].handle[atoms[a].n] = q.terms[i];
+    atoms[a].off[atoms[a].n] = in_phrase ? q.phrase_offsets[i] : 0u;
     atoms[a].w[atoms[a].n++] = q.weights[i];
     atoms[a].cost = std::min<uint64_t>(atoms[a].cost, s->terms[q.terms[i]].doc_freq);
     qbytes += s->terms[q.terms[i]].postings_len;
   }
   for (uint32_t a = 0; a < n_at; ++a) {  // conjunctions: rarest list first (Intersection::score sums in that order)
     Atom &A = atoms[a];
+    if (A.phrase) {
+      // PhraseQuery::new needs two terms (phrase_query.rs:51-55); one cursor per term in registers
+      if (A.n_named < 2) return fail(TQ_ERR_INVALID, "query %u: a phrase needs >= 2 terms", qi);
+      if (A.n_named > TQK_TREE_PHRASE_TERMS)
+        return fail(TQ_ERR_UNSUPPORTED, "query %u: a phrase inside a boolean query takes at most %u terms", qi, TQK_TREE_PHRASE_TERMS);
+      if (!A.empty) {
+        // PhraseScorer::cost = size_hint of the intersection of its lists * 10 * terms (phrase_scorer.rs:566-573;
+        // estimate_intersection, size_hint.rs:11-36: co-location factor 1.3 shrinking by 0.1 per list)
+        double est = 0.0, smallest = 0.0, f = 1.3;
+        for (uint32_t i = 0; i < A.n; ++i) {
+          const double df = (double)s->terms[A.handle[i]].doc_freq;
+          if (i == 0) {
+            est = smallest = df;
+          } else {
+            f = std::max(1.0, f - 0.1);
+            est *= df / (double)std::max<uint32_t>(1u, s->max_doc) * f;
+            smallest = std::min(smallest, df);
+          }
+        }
+        A.cost = (uint64_t)std::min(std::round(est), smallest) * 10u * A.n;
+      }
+      continue;  // (the terms keep the caller's order: their offsets say where they stand)
+    }
     for (uint32_t i = 1; i < A.n; ++i)
       for (uint32_t j = i; j > 0 && s->terms[A.handle[j]].doc_freq < s->terms[A.handle[j - 1]].doc_freq; --j) {
         std::swap(A.handle[j], A.handle[j - 1]);
@@ -407,6 +443,8 @@ int plan_tree_query(tq_segment *s, const tq_query &q, uint32_t qi, TqdTreeQuery 
     tq.inner_need[o] = C.msm;
     for (uint32_t x = 0; x < C.n; ++x) {
       const Atom &A = atoms[C.atom[x]];
+      uint32_t max_off = 0;
+      for (uint32_t i = 0; i < A.n; ++i) max_off = std::max(max_off, A.off[i]);
       for (uint32_t i = 0; i < A.n; ++i) {
         const TermHost &th = s->terms[A.handle[i]];
         const bool own = th.dense_blob && th.tf8_blob;
@@ -415,10 +453,18 @@ int plan_tree_query(tq_segment *s, const tq_query &q, uint32_t qi, TqdTreeQuery 
           return fail(TQ_ERR_UNSUPPORTED, "query %u: a nested boolean query names a list without a bitmap (probe-table budget \"probe_budget_x\" used up)", qi);
         tq.dense_off[n] = (uint32_t)(((uint64_t)bm - table_base) >> 3);
         tq.tf8_off[n] = (uint32_t)(((uint64_t)t8 - table_base) >> 3);
-        memcpy(&tq.weight_bits[n], &A.w[i], sizeof(float));
+        memcpy(&tq.weight_bits[n], &A.w[A.phrase ? 0u : i], sizeof(float));  // (a phrase scores with ONE weight: the sum of its idfs)
         tq.handle[n] = A.handle[i];
         tq.inner[n] = A.inner;
-        tq.atom_end[n] = i + 1u == A.n ? 1u : 0u;
+        tq.atom_end[n] = (i + 1u == A.n ? 1u : 0u) | (A.phrase ? 2u : 0u);
+        if (A.phrase) {
+          const void *dir = own && th.posdir_blob ? th.posdir_blob : th.probe_posdir_blob;
+          if (!dir)
+            return fail(TQ_ERR_UNSUPPORTED, "query %u: a phrase inside a boolean query names a list without a position directory (probe-table budget \"probe_budget_x\" used up)", qi);
+          tq.dir_off[n] = (uint32_t)(((uint64_t)dir - table_base) >> 3);
+          tq.phrase_off[n] = max_off - A.off[i];
+          tq.has_phrase = 1u;
+        }
         ++n;
       }
     }

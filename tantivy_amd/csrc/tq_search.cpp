@@ -93,11 +93,20 @@ int search_batch_impl(tq_segment *s, const tq_query *queries, uint32_t n_queries
         const uint32_t h = q.terms[i];
         if (h >= s->terms.size()) continue;
         const TermHost &th = s->terms[h];
-        if ((th.dense_blob && th.tf8_blob) || (th.probe_dense_blob && th.probe_tf8_blob)) continue;
-        bool ok = false;
-        const int prc = build_probe_tables(s, h, &ok);
-        if (prc != TQ_OK) return prc;
-        built = built || ok;
+        if (!((th.dense_blob && th.tf8_blob) || (th.probe_dense_blob && th.probe_tf8_blob))) {
+          bool ok = false;
+          const int prc = build_probe_tables(s, h, &ok);
+          if (prc != TQ_OK) return prc;
+          built = built || ok;
+        }
+        // a term of a phrase inside the boolean query: its positions are reached from the bitmap's rank
+        if (q.nested_occurs && q.nested_occurs[i] != 255u && (q.nested_occurs[i] & TQ_NESTED_PHRASE) &&
+            !s->terms[h].posdir_blob && !s->terms[h].probe_posdir_blob) {
+          bool ok = false;
+          const int prc = build_probe_posdir(s, h, &ok);
+          if (prc != TQ_OK) return prc;
+          built = built || ok;
+        }
       }
     }
     if (built) s->share_span_terms = ~(size_t)0;
@@ -131,7 +140,7 @@ int search_batch_impl(tq_segment *s, const tq_query *queries, uint32_t n_queries
   if (s->share_span_terms != s->terms.size()) {  // (terms are prepared rarely)
     uint64_t lo = ~0ull, hi = 0;
     for (const TermHost &th : s->terms)
-      for (const void *ptr : {th.dense_blob, th.tf8_blob, th.probe_dense_blob, th.probe_tf8_blob, th.rmax_blob})
+      for (const void *ptr : {th.dense_blob, th.tf8_blob, th.probe_dense_blob, th.probe_tf8_blob, th.rmax_blob, th.posdir_blob, th.probe_posdir_blob})
         if (ptr) {
           lo = std::min<uint64_t>(lo, (uint64_t)ptr);
           hi = std::max<uint64_t>(hi, (uint64_t)ptr);
@@ -1011,6 +1020,7 @@ int search_batch_impl(tq_segment *s, const tq_query *queries, uint32_t n_queries
       tp.table_base = (const uint8_t *)s->share_table_lo;
       tp.n_queries = (uint32_t)g.queries.size();
       tp.n_words = (s->max_doc + 31u) / 32u;
+      for (const TqdTreeQuery &tq : g.tree) tp.any_phrase |= tq.has_phrase;
       tiles_total += g.total_tiles;
       chunks_total += g.n_chunks;
       const hipError_t e = tqk_launch_tree(tp, g.kpl, gst);

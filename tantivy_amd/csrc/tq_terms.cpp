@@ -797,6 +797,46 @@ int build_probe_tables(tq_segment *s, uint32_t handle, bool *ok) {
   return TQ_OK;
 }
 
+// The position directory of a list that has a bitmap but no directory yet (its tables came from
+// build_probe_tables): entry j = positions before posting 4 j, what a phrase inside a boolean query needs to find
+// a doc's positions from the bitmap's rank (tq_tree.hip).  Counted against the same budget.
+int build_probe_posdir(tq_segment *s, uint32_t handle, bool *ok) {
+  TermHost &t = s->terms[handle];
+  *ok = t.posdir_blob || t.probe_posdir_blob;
+  if (*ok || !t.doc_freq || t.positions_len == 0) return TQ_OK;
+  if (!((t.dense_blob && t.tf8_blob) || (t.probe_dense_blob && t.probe_tf8_blob))) return TQ_OK;
+  const size_t n_dir = ((size_t)t.doc_freq + 3) / 4 + 1;
+  const size_t need = n_dir * sizeof(uint32_t);
+  if (s->probe_bytes_total + need > s->probe_budget()) return TQ_OK;
+  HIP_TRY(hipSetDevice(s->device));
+  const size_t bytes = (size_t)t.doc_freq * sizeof(uint32_t);
+  const size_t scan_words = tqp_scan_scratch_words((uint32_t)n_dir);
+  int rc = s->d_misc.ensure(2 * bytes + 64 + (scan_words + 8) * sizeof(uint32_t));
+  if (rc != TQ_OK) return rc;
+  uint32_t *dd = (uint32_t *)s->d_misc.p, *dt = dd + t.doc_freq;
+  uint32_t *scan_scratch = dt + t.doc_freq + 16;
+  hipError_t e = tqk_launch_decode_list(s->dseg, t.d_self, 0u, t.n_blocks, dd, dt, s->opt.use_dpp != 0, s->stream);
+  if (e != hipSuccess) return fail(TQ_ERR_HIP, "decode launch: %s", hipGetErrorString(e));
+  void *db = nullptr;
+  rc = dense_alloc(s, need + PAD, &db);
+  if (rc != TQ_OK) return rc;
+  e = tqp_launch_posdir(dt, t.doc_freq, (uint32_t *)db, (uint32_t)n_dir, scan_scratch, s->stream);
+  uint32_t total = 0;
+  if (e == hipSuccess) e = hipMemcpyAsync(&total, (uint32_t *)db + (n_dir - 1), 4, hipMemcpyDeviceToHost, s->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(s->stream);
+  if (e != hipSuccess || total != (uint32_t)t.n_positions) {
+    dense_release(s, db);
+    return e != hipSuccess ? fail(TQ_ERR_HIP, "position directory: %s", hipGetErrorString(e))
+                           : fail(TQ_ERR_FORMAT, "term freqs sum to %u positions, the stream holds %llu", total,
+                                  (unsigned long long)t.n_positions);
+  }
+  t.probe_posdir_blob = db;
+  s->probe_bytes_total += need;
+  s->bytes_posdir += need;
+  *ok = true;
+  return TQ_OK;
+}
+
 void mark_term_dirty(tq_segment *s, uint32_t handle) {
   s->d_terms_dirty = true;
   s->d_terms_dirty_from = std::min<size_t>(s->d_terms_dirty_from, handle);

@@ -17,6 +17,15 @@
 // the generic for_each_pruning_scorer (weight.rs:47-60), which only filters by threshold.
 //
 // HBM-bound by construction: 8 B per list per 32 docs of the segment, whatever the lists hold.
+//
+// PHRASES inside boolean queries (`+"a b" +c`, `"a b" c`, `+c -"a b"`, `+a +("b c" d)`: VERDICT r04 item 4): an atom
+// can be a PhraseQuery of <= 4 terms (tree_kernel<KPL, true>).  Where all its lists hold the doc, the lane walks the
+// positions of the doc in every list with one cursor per term (bitmap rank -> tf bytes + position directory -> first
+// position index, then PositionReader deltas one at a time: PhraseScorer::phrase_match / compute_phrase_count,
+// phrase_scorer.rs:347-587) and the atom is present where the count is > 0, scoring bm25(sum of idfs, norm, count)
+// (phrase_scorer.rs:576-587).  The bitmap expression then only proposes docs: a phrase atom enters it as the AND of
+// its lists where that can only ADD docs (positive polarity) and as nothing where it could remove some (under an odd
+// number of MustNots), and every proposed doc is decided by the exact per-doc evaluation of the scoring stage.
 #include "tq_common.hpp"
 #include "tq_launch.h"
 
@@ -56,7 +65,7 @@ struct SlicedCount {
   }
 };
 
-template <int KPL>
+template <int KPL, bool PH>
 __global__ __launch_bounds__(64) void tree_kernel(TqkTreeParams p) {
   const int lane = (int)__lane_id();
   const uint32_t q = blockIdx.x % p.n_queries, tile = blockIdx.x / p.n_queries;
@@ -82,14 +91,19 @@ __global__ __launch_bounds__(64) void tree_kernel(TqkTreeParams p) {
     SlicedCount top_should;
     for (uint32_t c = 0; c < nc; ++c) {
       const uint32_t t0 = sload(Q->first_term + c), t1 = sload(Q->first_term + c + 1u);
+      const uint32_t outer_c = sload(Q->outer + c);
       uint32_t must = 0xFFFFFFFFu, nots = 0u;
       SlicedCount should;
       uint32_t atom = 0xFFFFFFFFu;  // the docs that hold every term of the current atom so far
       for (uint32_t t = t0; t < t1; ++t) {
         const uint2 *bm = reinterpret_cast<const uint2 *>(tbase + ((uint64_t)sload(Q->dense_off + t) << 3));
         atom &= in ? bm[w].x : 0u;
-        if (!sload(Q->atom_end + t)) continue;
+        const uint32_t ae = sload(Q->atom_end + t);
+        if (!(ae & 1u)) continue;
         const uint32_t inner = sload(Q->inner + t);
+        if constexpr (PH) {  // a phrase under an odd number of MustNots must not remove docs it only MAY hold
+          if ((ae & 2u) && ((outer_c == TQD_ROLE_MUST_NOT) != (inner == TQD_ROLE_MUST_NOT))) atom = 0u;
+        }
         if (inner == TQD_ROLE_MUST)
           must &= atom;
         else if (inner == TQD_ROLE_MUST_NOT)
@@ -99,7 +113,7 @@ __global__ __launch_bounds__(64) void tree_kernel(TqkTreeParams p) {
         atom = 0xFFFFFFFFu;
       }
       const uint32_t cm = must & ~nots & should.at_least(sload(Q->inner_need + c));
-      const uint32_t outer = sload(Q->outer + c);
+      const uint32_t outer = outer_c;
       if (outer == TQD_ROLE_MUST)
         top_must &= cm;
       else if (outer == TQD_ROLE_MUST_NOT)
@@ -110,7 +124,7 @@ __global__ __launch_bounds__(64) void tree_kernel(TqkTreeParams p) {
     uint32_t match = (top_has_must ? top_must : 0xFFFFFFFFu) & ~top_not & top_should.at_least(top_need);
     if (!in) match = 0u;
     if (seg.alive) match &= in ? reinterpret_cast<const uint32_t *>(seg.alive)[w] : 0u;  // AliveBitSet (alive_bitset.rs:58-61)
-    n_matches += (uint32_t)__popc(match);
+    if constexpr (!PH) n_matches += (uint32_t)__popc(match);
     // ---- score the matching docs: every lane takes the lowest doc of its word until none has one left
     while (__ballot(match != 0u)) {
       const bool has = match != 0u;
@@ -120,23 +134,27 @@ __global__ __launch_bounds__(64) void tree_kernel(TqkTreeParams p) {
       const float norm = cache[has ? fieldnorm_id(seg, doc) : 0u];
       float musts_first = 0.0f, musts_second = 0.0f, musts_others = 0.0f, opt = 0.0f;
       uint32_t n_must_clauses = 0;
+      bool all_must = true, any_not = false;  // (PH: the doc's own verdict)
+      uint32_t n_should_clauses = 0;
       for (uint32_t c = 0; c < nc; ++c) {
         const uint32_t t0 = sload(Q->first_term + c), t1 = sload(Q->first_term + c + 1u);
         const uint32_t outer = sload(Q->outer + c);
-        if (outer == TQD_ROLE_MUST_NOT) continue;  // (the doc set already excludes them)
+        if (!PH && outer == TQD_ROLE_MUST_NOT) continue;  // (the doc set already excludes them)
         bool must_ok = true, not_ok = true;
         uint32_t ns = 0;
         float csum = 0.0f;
         bool atom_ok = true;    // the doc holds every term of the current atom so far
         float atom_sum = 0.0f;  // ... and what they score together (Intersection::score)
+        uint32_t atom_t0 = t0;
         for (uint32_t t = t0; t < t1; ++t) {
           const uint32_t inner = sload(Q->inner + t);
+          const uint32_t ae = sload(Q->atom_end + t);
           const uint2 *bm = reinterpret_cast<const uint2 *>(tbase + ((uint64_t)sload(Q->dense_off + t) << 3));
           uint2 wd = make_uint2(0u, 0u);
           if (has) wd = bm[w];
           const bool present = has && ((wd.x >> bit) & 1u);
           atom_ok = atom_ok && present;
-          if (present && inner != TQD_ROLE_MUST_NOT) {
+          if (present && inner != TQD_ROLE_MUST_NOT && !(PH && (ae & 2u))) {
             const uint32_t pi = wd.y + (uint32_t)__popc(wd.x & ((1u << bit) - 1u));
             uint32_t tf = (tbase + ((uint64_t)sload(Q->tf8_off + t) << 3))[pi];
             if (tf == 255u) {  // saturated byte: block record -> packed tf (tq_common.hpp)
@@ -151,7 +169,75 @@ __global__ __launch_bounds__(64) void tree_kernel(TqkTreeParams p) {
             }
             atom_sum = atom_sum + bm25(__uint_as_float(sload(Q->weight_bits + t)), norm, tf);
           }
-          if (!sload(Q->atom_end + t)) continue;
+          if (!(ae & 1u)) continue;
+          if constexpr (PH) {
+            if (ae & 2u) {  // a PhraseQuery: count the positions where its terms line up (lanes that hold them all)
+              uint32_t cnt = 0;
+              if (atom_ok) {
+                PosCursor cur[TQK_TREE_PHRASE_TERMS];
+                const uint32_t n_ph = t + 1u - atom_t0;
+#pragma unroll
+                for (uint32_t m = 0; m < TQK_TREE_PHRASE_TERMS; ++m) {
+                  cur[m].valid = false;
+                  cur[m].idx = cur[m].end = cur[m].cur = 0;
+                  if (m < n_ph) {
+                    const uint32_t tt = atom_t0 + m;
+                    const uint2 wm = reinterpret_cast<const uint2 *>(tbase + ((uint64_t)sload(Q->dense_off + tt) << 3))[w];
+                    const uint32_t pi = wm.y + (uint32_t)__popc(wm.x & ((1u << bit) - 1u));
+                    // the four tf bytes of the posting's group of four + the group's directory entry
+                    const uint32_t tw = *reinterpret_cast<const uint32_t *>(tbase + ((uint64_t)sload(Q->tf8_off + tt) << 3) + (pi & ~3u));
+                    const uint32_t dv = reinterpret_cast<const uint32_t *>(tbase + ((uint64_t)sload(Q->dir_off + tt) << 3))[pi >> 2];
+                    const uint32_t l0 = pi & 3u;
+                    const uint32_t b0 = tw & 0xFFu, b1 = (tw >> 8) & 0xFFu, b2 = (tw >> 16) & 0xFFu, b3 = tw >> 24;
+                    uint32_t tf = l0 == 0u ? b0 : (l0 == 1u ? b1 : (l0 == 2u ? b2 : b3));
+                    uint32_t ex = (l0 > 0u ? b0 : 0u) + (l0 > 1u ? b1 : 0u) + (l0 > 2u ? b2 : 0u);
+                    if (tf == 255u || (l0 > 0u && b0 == 255u) || (l0 > 1u && b1 == 255u) || (l0 > 2u && b2 == 255u)) {
+                      const TqdTermHead *h = p.terms + sload(Q->handle + tt);  // a saturated byte: the packed values
+                      TermRef tr{};
+                      tr.rec = h->rec;
+                      tr.tail_tfs = h->tail_tfs;
+                      tr.payload_base = h->payload_base;
+                      tr.has_freq = h->has_freq & 1u;
+                      tr.n_tail = h->n_tail;
+                      group_tfs(seg.idx, tr, tr.rec[pi >> 7], pi & 127u, tf, ex);
+                    }
+                    const TqdTerm *term = p.terms + sload(Q->handle + tt);
+                    const uint32_t fp = dv + ex;  // index of the doc's first position in the term's stream
+                    cur[m].idx = fp + 1u;
+                    cur[m].end = fp + tf;
+                    cur[m].valid = tf >= 1u;
+                    if (cur[m].valid) cur[m].cur = sload(Q->phrase_off + tt) + position_delta(seg.pos, term, fp);
+                  }
+                }
+                bool done = false;
+                while (cur[0].valid && !done) {
+                  const uint32_t av = cur[0].cur;
+                  bool okv = true;
+#pragma unroll
+                  for (uint32_t m = 1; m < TQK_TREE_PHRASE_TERMS; ++m) {
+                    if (m < n_ph && !done) {
+                      const TqdTerm *term = p.terms + sload(Q->handle + atom_t0 + m);
+                      while (cur[m].valid && cur[m].cur < av) pos_advance(cur[m], seg.pos, term);
+                      if (!cur[m].valid)
+                        done = true;
+                      else if (cur[m].cur != av)
+                        okv = false;
+                    }
+                  }
+                  if (done) break;
+                  if (okv) {
+                    ++cnt;
+#pragma unroll
+                    for (uint32_t m = 1; m < TQK_TREE_PHRASE_TERMS; ++m)
+                      if (m < n_ph) pos_advance(cur[m], seg.pos, p.terms + sload(Q->handle + atom_t0 + m));
+                  }
+                  pos_advance(cur[0], seg.pos, p.terms + sload(Q->handle + atom_t0));
+                }
+              }
+              atom_ok = cnt > 0u;
+              atom_sum = atom_ok ? bm25(__uint_as_float(sload(Q->weight_bits + atom_t0)), norm, cnt) : 0.0f;
+            }
+          }
           if (inner == TQD_ROLE_MUST_NOT) {
             not_ok = not_ok && !atom_ok;
           } else {
@@ -163,6 +249,7 @@ __global__ __launch_bounds__(64) void tree_kernel(TqkTreeParams p) {
           }
           atom_ok = true;
           atom_sum = 0.0f;
+          atom_t0 = t + 1u;
         }
         const bool cmatch = has && must_ok && not_ok && ns >= sload(Q->inner_need + c);
         if (outer == TQD_ROLE_MUST) {  // Intersection::score: left + right + sum(others), clauses cheapest first
@@ -173,15 +260,25 @@ __global__ __launch_bounds__(64) void tree_kernel(TqkTreeParams p) {
           else
             musts_others = musts_others + csum;
           ++n_must_clauses;
+          all_must = all_must && cmatch;
+        } else if (outer == TQD_ROLE_MUST_NOT) {
+          any_not = any_not || cmatch;
         } else if (cmatch) {
           opt = opt + csum;  // a Should clause that matches adds its score (SumCombiner / RequiredOptionalScorer)
+          ++n_should_clauses;
         }
       }
       float s = musts_first;
       if (n_must_clauses >= 2u) s = s + musts_second;
       if (n_must_clauses >= 3u) s = s + musts_others;
       s = n_must_clauses ? s + opt : opt;
-      tk.offer(has, make_key(s, doc), lane);
+      if constexpr (PH) {  // the bitmap expression only proposed the doc
+        const bool doc_ok = has && all_must && !any_not && n_should_clauses >= top_need;
+        n_matches += doc_ok ? 1u : 0u;
+        tk.offer(doc_ok, make_key(s, doc), lane);
+      } else {
+        tk.offer(has, make_key(s, doc), lane);
+      }
     }
   }
   flush_partial(tk, sload(&p.sinks->partials), sload(&Q->part_start) + tile, lane);
@@ -196,15 +293,22 @@ __global__ __launch_bounds__(64) void tree_kernel(TqkTreeParams p) {
 
 uint32_t tqk_tree_tiles(uint32_t n_words) { return (n_words + TREE_TILE_WORDS - 1u) / TREE_TILE_WORDS; }
 
+template <bool PH>
+static void launch_tree_t(const TqkTreeParams &p, int kpl, dim3 grid, dim3 block, hipStream_t st) {
+  switch (kpl) {
+    case 1: tree_kernel<1, PH><<<grid, block, 0, st>>>(p); break;
+    case 2: tree_kernel<2, PH><<<grid, block, 0, st>>>(p); break;
+    case 4: tree_kernel<4, PH><<<grid, block, 0, st>>>(p); break;
+    default: tree_kernel<16, PH><<<grid, block, 0, st>>>(p); break;
+  }
+}
 hipError_t tqk_launch_tree(const TqkTreeParams &p, int kpl, hipStream_t st) {
   const uint32_t tiles = tqk_tree_tiles(p.n_words);
   if (!tiles || !p.n_queries) return hipSuccess;
   const dim3 grid(tiles * p.n_queries), block(64);
-  switch (kpl) {
-    case 1: tree_kernel<1><<<grid, block, 0, st>>>(p); break;
-    case 2: tree_kernel<2><<<grid, block, 0, st>>>(p); break;
-    case 4: tree_kernel<4><<<grid, block, 0, st>>>(p); break;
-    default: tree_kernel<16><<<grid, block, 0, st>>>(p); break;
-  }
+  if (p.any_phrase)
+    launch_tree_t<true>(p, kpl, grid, block, st);
+  else
+    launch_tree_t<false>(p, kpl, grid, block, st);
   return hipGetLastError();
 }

@@ -196,6 +196,16 @@ static Query build_query(const tqh_query &q) {
     std::vector<int> ids;  // clause_of value of every clause built so far
     std::vector<uint32_t> first_term_of;  // index (in q.terms) of the clause's first term
     std::vector<std::vector<int>> atom_ids(TQ_MAX_TERMS + 1);  // per clause: atom_of value of every member built so far
+    std::vector<char> nested_built(TQ_MAX_TERMS + 1, 0);       // per clause: already a nested BooleanQuery
+    // a term of a PhraseQuery inside the boolean query: nested_occurs | TQ_NESTED_PHRASE, its offset in phrase_offsets
+    auto in_phrase = [&](uint32_t tt) {
+      return q.nested_occurs && q.nested_occurs[tt] != 255 && (q.nested_occurs[tt] & TQ_NESTED_PHRASE) != 0;
+    };
+    auto leaf_of = [&](uint32_t tt) {
+      if (in_phrase(tt))  // (the phrase's first term: the others are appended to phrase_terms below)
+        return Query::phrase_with_offsets({{q.phrase_offsets ? q.phrase_offsets[tt] : 0u, q.terms[tt]}}).boosted(q.boosts ? q.boosts[tt] : 1.0f);
+      return Query::term_query(q.terms[tt]).boosted(q.boosts ? q.boosts[tt] : 1.0f);
+    };
     for (uint32_t t = 0; t < q.n_terms; ++t) {
       if (q.occurs[t] > 2) throw TantivyError(TantivyError::InvalidArgument, "bad occur");
       const Occur oc = q.occurs[t] == 1 ? Occur::Must
@@ -207,7 +217,7 @@ static Query build_query(const tqh_query &q) {
       if (c == ids.size()) {
         ids.push_back(id);
         first_term_of.push_back(t);
-        clauses.emplace_back(oc, Query::term_query(q.terms[t]).boosted(q.boosts ? q.boosts[t] : 1.0f));
+        clauses.emplace_back(oc, leaf_of(t));
         continue;
       }
       if (clauses[c].first != oc)
@@ -216,32 +226,48 @@ static Query build_query(const tqh_query &q) {
       // occur of a term INSIDE its clause: Should (a nested union) unless nested_occurs says
       // otherwise (`+a +(+b -c)`: clause_of {0,1,1}, occurs {1,1,1}, nested_occurs {255,1,2})
       auto inner = [&](uint32_t tt) {
-        const uint8_t v = q.nested_occurs ? q.nested_occurs[tt] : 255;
+        uint8_t v = q.nested_occurs ? q.nested_occurs[tt] : 255;
+        if (v != 255) v &= (uint8_t)~TQ_NESTED_PHRASE;
         if (v != 255 && v > 2) throw TantivyError(TantivyError::InvalidArgument, "bad nested occur");
         return v == 1 ? Occur::Must : (v == 2 ? Occur::MustNot : Occur::Should);
       };
-      if (sub.kind == Query::Term) {  // second term of the clause: it becomes a nested query
+      if (!nested_built[c]) {  // second term of the clause: it becomes a nested query
         const Query first = sub;
         sub = Query::boolean({{inner(first_term_of[c]), first}});
         atom_ids[c] = {q.atom_of ? (int)q.atom_of[first_term_of[c]] : -1};
+        nested_built[c] = true;
       }
-      Query leaf = Query::term_query(q.terms[t]).boosted(q.boosts ? q.boosts[t] : 1.0f);
       // atom_of: terms of the clause sharing a value are one member — an intersection of terms one level down
-      // (`+a +((+b +c) d)`), with the member's occur = nested_occurs of its terms
+      // (`+a +((+b +c) d)`) or a phrase, with the member's occur = nested_occurs of its terms
       const int aid = q.atom_of ? (int)q.atom_of[t] : -1;
       size_t m = sub.clauses.size();
       if (aid >= 0)
         for (m = 0; m < atom_ids[c].size() && atom_ids[c][m] != aid; ++m) {}
       if (m >= sub.clauses.size()) {
-        sub.clauses.emplace_back(inner(t), std::move(leaf));
+        sub.clauses.emplace_back(inner(t), leaf_of(t));
         atom_ids[c].push_back(aid);
         continue;
       }
       if (sub.clauses[m].first != inner(t))
         throw TantivyError(TantivyError::InvalidArgument, "a conjunction mixes nested occurs");
       Query &member = sub.clauses[m].second;
+      if (member.kind == Query::Phrase || in_phrase(t)) {
+        if (member.kind != Query::Phrase || !in_phrase(t))
+          throw TantivyError(TantivyError::InvalidArgument, "a member mixes phrase and plain terms");
+        member.phrase_terms.emplace_back(q.phrase_offsets ? q.phrase_offsets[t] : (uint32_t)member.phrase_terms.size(), q.terms[t]);
+        continue;
+      }
       if (member.kind == Query::Term) member = Query::boolean({{Occur::Must, Query(member)}});
-      member.clauses.emplace_back(Occur::Must, std::move(leaf));
+      member.clauses.emplace_back(Occur::Must, leaf_of(t));
+    }
+    // a clause that is ONE phrase (`+"a b"`): the one-member nested query is the phrase itself
+    for (size_t c = 0; c < clauses.size(); ++c) {
+      Query &sub = clauses[c].second;
+      if (nested_built[c] && sub.clauses.size() == 1 && sub.clauses[0].second.kind == Query::Phrase &&
+          sub.clauses[0].first != Occur::MustNot && !(q.clause_min_should && ids[c] >= 0 && ids[c] < (int)TQ_MAX_TERMS && q.clause_min_should[ids[c]])) {
+        Query ph = sub.clauses[0].second;
+        sub = std::move(ph);
+      }
     }
     if (q.clause_min_should)  // BooleanQuery::set_minimum_number_should_match on the nested queries
       for (size_t c = 0; c < clauses.size(); ++c)

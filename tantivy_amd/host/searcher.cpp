@@ -272,7 +272,7 @@ Weight Searcher::weight(const Query &query) const {
       bool all_must = true, all_should = true, flat = true, tree = false;
       // a clause is a term, a union of terms, or (round 5) any BooleanQuery of TERMS — an intersection inside a
       // union or under MustNot, nested MustNot / optional terms, a nested minimum_number_should_match: depth 2,
-      // evaluated over the lists' bitmaps (tq_tree.hip).  Deeper trees and phrases inside boolean queries keep
+      // evaluated over the lists' bitmaps (tq_tree.hip).  Deeper trees keep
       // tantivy's CPU scorer (SpecializedScorer::Other, boolean_weight.rs:595-597).
       // (a member of a nested query: a term, or an intersection of terms — `(+b +c) d`)
       auto is_conjunction = [](const Query &q) {
@@ -281,10 +281,13 @@ Weight Searcher::weight(const Query &query) const {
           if (c.first != Occur::Must || c.second.kind != Query::Term) return false;
         return true;
       };
+      // (round 5, second half: a member — or a clause — can be a PhraseQuery of <= 4 terms: PhraseScorer under
+      // Intersection / union / Exclude, the position check done per candidate doc on the device)
+      bool any_phrase = false;
       auto is_query_of_terms = [&](const Query &q) {
         if (q.kind != Query::Boolean || q.clauses.empty()) return false;
         for (auto &c : q.clauses)
-          if (c.second.kind != Query::Term && !is_conjunction(c.second)) return false;
+          if (c.second.kind != Query::Term && c.second.kind != Query::Phrase && !is_conjunction(c.second)) return false;
         return true;
       };
       auto is_term_union = [](const Query &q) {
@@ -294,12 +297,15 @@ Weight Searcher::weight(const Query &query) const {
         return true;
       };
       for (auto &c : clauses) {
-        if (c.second.kind != Query::Term) {
+        if (c.second.kind == Query::Phrase) {
+          any_phrase = tree = true;
+          flat = false;
+        } else if (c.second.kind != Query::Term) {
           if (!is_query_of_terms(c.second))
             throw TantivyError(TantivyError::Unsupported,
-                               "boolean trees deeper than two levels and phrases inside boolean queries stay "
-                               "on the CPU scorer path");
-          tree = tree || !is_term_union(c.second);
+                               "boolean trees deeper than two levels stay on the CPU scorer path");
+          for (auto &sub : c.second.clauses) any_phrase = any_phrase || sub.second.kind == Query::Phrase;
+          tree = tree || any_phrase || !is_term_union(c.second);
           flat = false;
         }
         all_must &= c.first == Occur::Must;
@@ -335,12 +341,39 @@ Weight Searcher::weight(const Query &query) const {
             }
           }
         };
+        // a PhraseQuery as one member: its terms share the member index, carry TQ_NESTED_PHRASE, their offsets
+        // and — each — the phrase's weight (Bm25Weight::for_terms over the phrase's terms, bm25.rs:121-128)
+        auto add_phrase = [&](const Query &ph, Score boost, Occur inner) {
+          if (ph.phrase_terms.size() < 2)
+            throw TantivyError(TantivyError::InvalidArgument,
+                               "A phrase query is required to have strictly more than one term.");
+          if (ph.phrase_terms.size() > 4)
+            throw TantivyError(TantivyError::Unsupported, "a phrase inside a boolean query takes at most 4 terms on the device");
+          Score idf_sum = 0.0f;
+          for (auto &ot : ph.phrase_terms) idf_sum += idf(doc_freq(ot.second), nd);
+          const Score pw = boost_by(idf_sum * (1.0f + K1), boost);
+          for (auto &ot : ph.phrase_terms) {
+            w.phrase_offsets.resize(w.terms.size(), 0u);
+            w.phrase_offsets.push_back(ot.first);
+            w.terms.push_back(ot.second);
+            w.weights.push_back(pw);
+            w.occurs.push_back(oc);
+            w.clause_of.push_back(clause);
+            w.nested_occurs.push_back((uint8_t)((inner == Occur::Must ? TQ_MUST : (inner == Occur::MustNot ? TQ_MUST_NOT : TQ_SHOULD)) |
+                                                TQ_NESTED_PHRASE));
+            w.atom_of.push_back(member);
+          }
+        };
         if (c.second.kind == Query::Term) {
           add(c.second.term, bc, Occur::Must);  // (a one-term clause: the term itself)
+        } else if (c.second.kind == Query::Phrase) {
+          add_phrase(c.second, bc, Occur::Must);  // (a clause of its own: a one-member nested query)
         } else {
           for (auto &sub : c.second.clauses) {
             if (sub.second.kind == Query::Term)
               add(sub.second.term, bc * sub.second.boost, sub.first);
+            else if (sub.second.kind == Query::Phrase)
+              add_phrase(sub.second, bc * sub.second.boost, sub.first);
             else  // an intersection of terms one level down: one member of the nested query
               for (auto &leaf : sub.second.clauses) add(leaf.second.term, bc * sub.second.boost * leaf.second.boost, sub.first);
             ++member;
@@ -356,6 +389,7 @@ Weight Searcher::weight(const Query &query) const {
       }
       if (w.terms.size() > TQ_MAX_TERMS)
         throw TantivyError(TantivyError::Unsupported, "more than 16 terms stay on the CPU");
+      if (any_phrase) w.phrase_offsets.resize(w.terms.size(), 0u);
       w.min_should_match = (uint32_t)std::min<size_t>(msm, 0xFFFFu);
       return w;
     }

@@ -125,8 +125,8 @@ def test_nested_queries_through_searcher_search_and_count(ta, seg):
 
 
 def test_unsupported_shapes_are_reported(ta, seg):
-    """deeper trees (a union inside an intersection inside a union) and phrases inside boolean queries stay with
-    tantivy's CPU scorer: TantivyAmdError(Unsupported), nothing silently approximated"""
+    """malformed trees are refused (what is too deep for the flattened form cannot be expressed in it: the host
+    mirror reports Unsupported for those, tests/test_host_cpu.py); nothing is silently approximated"""
     dev = ta.DeviceIndex([seg])
     try:
         # a conjunction that mixes nested occurs is malformed
@@ -151,5 +151,91 @@ def test_nested_queries_on_a_small_segment_with_saturated_tfs(ta):
     dev = ta.DeviceIndex([seg])
     try:
         _check(ta, dev, seg, specs, 10)
+    finally:
+        dev.close()
+
+
+# ---- phrases inside boolean queries (`+"a b" +c`; tree_kernel<KPL, true>)
+@pytest.fixture(scope="module")
+def pseg():
+    return O.synth_segment(300_000, n_terms=48, with_positions=True, phrase_terms=16)
+
+
+def test_phrases_inside_boolean_queries(ta, pseg):
+    """every shape of tests/tree_shapes.PHRASE_SHAPES over frequent and rare lists: a PhraseQuery as a Must / Should /
+    MustNot clause, as a member of a nested query, two phrases in one query; doc ids exact against the oracle (the C
+    PhraseScorer under numpy's complex_scorer), scores within 1e-5, pruned == exhaustive, Count"""
+    from tests.tree_shapes import PHRASE_SHAPES
+
+    rng = np.random.default_rng(11)
+    specs = []
+    for shape, msm in PHRASE_SHAPES:
+        for hi in (6, 12, 16):  # the most frequent lists (many matches), then rarer ones (probe tables + directories)
+            specs.append((shape(rng.permutation(hi)[:8].tolist() if hi >= 8 else (rng.permutation(hi).tolist() + [6, 7])), msm))
+    dev = ta.DeviceIndex([pseg])
+    try:
+        dev.set_option("dense_ratio", 16)
+        n_hits = 0
+        for k in (1, 10, 100):
+            out = _check(ta, dev, pseg, specs, k)
+            n_hits += int(out[3].sum())
+        assert n_hits > 500
+        counts = dev.count([to_device(ta, sp, msm) for sp, msm in specs])
+        for i, (sp, msm) in enumerate(specs):
+            assert int(counts[i]) == len(O.tree_match_all(pseg, to_oracle(sp), msm)[0]), (sp, msm)
+        st = dev.segment_stats(0)
+        assert st["n_dense_lists"] < 16  # some phrase lists were reached through probe tables
+    finally:
+        dev.close()
+
+
+def test_phrases_inside_boolean_queries_with_deletes_and_large_tfs(ta):
+    """term freqs >= 255 in phrase lists (the tf byte saturates: the packed values give the position index), a fifth
+    of the docs deleted, one query per call from 8 threads"""
+    rng = np.random.default_rng(12)
+    docs = []
+    for d in range(6000):
+        n = int(rng.integers(3, 30))
+        toks = rng.integers(0, 6, size=n).tolist()
+        if d % 97 == 0:
+            toks = [0, 1] * 300 + toks  # tf 300 of terms 0 and 1, the phrase "0 1" 300 times
+        docs.append(" ".join("t%d" % t for t in toks))
+    from tests.helpers import corpus_segment
+
+    seg, vocab = corpus_segment(docs, with_positions=True)
+    assert [vocab["t%d" % i] for i in range(6)] == list(range(6))
+    deleted = np.sort(rng.choice(seg.max_doc, size=seg.max_doc // 5, replace=False)).astype(np.uint32)
+    alive = np.ones(seg.max_doc, bool)
+    alive[deleted] = False
+    bits = np.packbits(alive, bitorder="little")
+    body = np.uint32(seg.max_doc).tobytes() + bits.tobytes() + b"\0" * ((-len(bits)) % 8)
+    from tests.tree_shapes import PHRASE_SHAPES
+
+    specs = [(shape([0, 1, 2, 3, 4, 5, 0, 1]), msm) for shape, msm in PHRASE_SHAPES]
+    specs += [(shape([1, 0, 3, 2, 5, 4, 1, 0]), msm) for shape, msm in PHRASE_SHAPES]
+    dev = ta.DeviceIndex([seg])
+    try:
+        dev.set_alive_bitset(body)
+        _check(ta, dev, seg, specs, 10, deleted)
+        queries = [to_device(ta, sp, msm) for sp, msm in specs]
+        sc, _, dc, ct, _, _ = dev.search_concurrent(queries, 10, 8)
+        for i, (sp, msm) in enumerate(specs):
+            want = O.tree_search(seg, to_oracle(sp), 10, msm, deleted)
+            assert sorted(int(dc[i, j]) for j in range(int(ct[i]))) == sorted(d for _, d in want), (sp, msm)
+    finally:
+        dev.close()
+
+
+def test_phrase_in_boolean_errors(ta, pseg):
+    """a one-term phrase is the reference's InvalidArgument; five terms stay on the CPU (Unsupported)"""
+    dev = ta.DeviceIndex([pseg])
+    try:
+        one = (ta.MODE_BOOL, [1, 2], [M, M], [0, 1], 0, {"nested_occurs": [M | 0x10, M], "atom_of": [0, 0], "phrase_offsets": [0, 0]})
+        with pytest.raises(ta.TantivyAmdError):
+            dev.search([one], 10)
+        five = (ta.MODE_BOOL, [0, 1, 2, 3, 4, 5], [M] * 6, [0] * 5 + [1], 0,
+                {"nested_occurs": [M | 0x10] * 5 + [M], "atom_of": [0] * 6, "phrase_offsets": [0, 1, 2, 3, 4, 0]})
+        with pytest.raises(ta.TantivyAmdError):
+            dev.search([five], 10)
     finally:
         dev.close()

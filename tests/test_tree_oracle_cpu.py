@@ -94,3 +94,68 @@ def test_device_tuples_name_every_term_once():
             else:
                 flat.append(cl[1])
         assert q[1] == flat
+
+
+# ---- phrases inside boolean queries (tests/tree_shapes.PHRASE_SHAPES)
+@pytest.fixture(scope="module")
+def pseg():
+    return O.synth_segment(60_000, n_terms=16, with_positions=True, phrase_terms=8)
+
+
+def _phrase_docs(seg, terms):
+    d, s = O.match_all(seg, list(terms), O.MODE_PHRASE)
+    return dict(zip(d.tolist(), s.tolist()))
+
+
+def test_phrase_leaves_follow_the_set_algebra_and_score_like_the_phrase_scorer(pseg):
+    """a PhraseQuery inside a BooleanQuery is one more scorer of complex_scorer: its doc set is the phrase's (the C
+    restatement of PhraseScorer, pinned by the reference's phrase KATs), its score the phrase's score"""
+    from tests.tree_shapes import PHRASE_SHAPES
+
+    t = [0, 1, 2, 3, 4, 5]
+    L = [_docs(pseg, x) for x in t]
+    ab, abc, cd, bc = (_phrase_docs(pseg, x) for x in ([0, 1], [0, 1, 2], [2, 3], [1, 2]))
+    assert len(ab) > 50 and len(bc) > 50
+    A, ABC, CD, BC = set(ab), set(abc), set(cd), set(bc)
+    n2 = lambda *sets: {d for d in set().union(*sets) if sum(d in x for x in sets) >= 2}
+    want = [
+        A & L[2],
+        A,
+        A | L[2],
+        L[2] - A,
+        (ABC & L[3]) - L[4],
+        L[0] & (BC | L[3]),
+        n2(A, CD, L[4]),
+        (L[0] & L[1]) - CD,
+        A & BC,
+    ]
+    for (shape, msm), w in zip(PHRASE_SHAPES, want):
+        d, s = O.tree_match_all(pseg, shape(t), msm)
+        assert set(d.tolist()) == w, shape(t)
+        assert (s > 0).all()
+    # +"a b" +c scores phrase + term, in either order bit for bit (two summands)
+    d, s = O.tree_match_all(pseg, [(M, ("ph", [0, 1])), (M, 2)])
+    dc, sc = O.match_all(pseg, [2], O.MODE_OR)
+    c_score = dict(zip(dc.tolist(), sc.tolist()))
+    for doc, got in zip(d.tolist(), s.tolist()):
+        assert np.float32(got) == np.float32(np.float32(ab[doc]) + np.float32(c_score[doc]))
+
+
+def test_device_tuples_of_phrase_shapes():
+    import tantivy_amd as ta
+    from tests.tree_shapes import PHRASE_SHAPES
+
+    for shape, msm in PHRASE_SHAPES:
+        spec = shape(list(range(8)))
+        q = to_device(ta, spec, msm)
+        ex = q[5]
+        n = len(q[1])
+        assert len(ex["nested_occurs"]) == len(ex["atom_of"]) == len(ex["phrase_offsets"]) == n
+        # the terms of one phrase: same clause, same member, the flag on each, offsets 0..n-1
+        groups = {}
+        for i in range(n):
+            if ex["nested_occurs"][i] & 0x10:
+                groups.setdefault((q[3][i], ex["atom_of"][i]), []).append(ex["phrase_offsets"][i])
+            else:
+                assert ex["phrase_offsets"][i] == 0
+        assert groups and all(v == list(range(len(v))) and len(v) >= 2 for v in groups.values())

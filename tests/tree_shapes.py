@@ -3,7 +3,8 @@
 A spec is a list of clauses: (outer occur, term id) for a term clause, or (outer occur, [(inner occur, term id |
 [term ids of a nested intersection]), ...], nested minimum_number_should_match) for a nested BooleanQuery — the
 structure O.tree_match_all takes.  to_device() flattens it into the host mirror's query tuple (tqh_query: occurs /
-clause_of / nested_occurs / atom_of / clause_min_should, include/tantivy_amd_host.h)."""
+clause_of / nested_occurs / atom_of / clause_min_should, include/tantivy_amd_host.h).  A term id can be
+("ph", [term ids]): a PhraseQuery, as a clause of its own or as a member of a nested query (PHRASE_SHAPES)."""
 from oracle import oracle as O
 
 M, S, N = O.MUST, O.SHOULD, O.MUST_NOT
@@ -31,30 +32,72 @@ SHAPES = [
 ]
 
 
+# phrases inside boolean queries (`+"a b" +c`), over term ids with positions
+PHRASE_SHAPES = [
+    # +"a b" +c
+    (lambda t: [(M, ("ph", [t[0], t[1]])), (M, t[2])], 0),
+    # +"a b" c: the phrase required, a term optional (RequiredOptionalScorer)
+    (lambda t: [(M, ("ph", [t[0], t[1]])), (S, t[2])], 0),
+    # "a b" c: a union of a phrase and a term
+    (lambda t: [(S, ("ph", [t[0], t[1]])), (S, t[2])], 0),
+    # +c -"a b": a phrase under MustNot (Exclude)
+    (lambda t: [(M, t[2]), (N, ("ph", [t[0], t[1]]))], 0),
+    # +"a b c" +d -e: a three-term phrase
+    (lambda t: [(M, ("ph", [t[0], t[1], t[2]])), (M, t[3]), (N, t[4])], 0),
+    # +a +("b c" d): a phrase as a member of a nested union
+    (lambda t: [(M, t[0]), (M, [(S, ("ph", [t[1], t[2]])), (S, t[3])], 0)], 0),
+    # "a b" "c d" e ~2: two phrases and a term, at least two of them
+    (lambda t: [(S, ("ph", [t[0], t[1]])), (S, ("ph", [t[2], t[3]])), (S, t[4])], 2),
+    # +a +(+b -"c d"): a phrase excluded inside a nested query
+    (lambda t: [(M, t[0]), (M, [(M, t[1]), (N, ("ph", [t[2], t[3]]))], 0)], 0),
+    # +"a b" +"b c": two phrases that share a term
+    (lambda t: [(M, ("ph", [t[0], t[1]])), (M, ("ph", [t[1], t[2]]))], 0),
+]
+
+
+def _is_phrase(x):
+    return isinstance(x, tuple) and len(x) >= 2 and x[0] == "ph"
+
+
 def to_oracle(spec):
     return spec
 
 
 def to_device(ta, spec, msm=0):
-    terms, occurs, clause_of, nested, atom_of, cms = [], [], [], [], [], {}
+    PH = 0x10  # TQ_NESTED_PHRASE
+    terms, occurs, clause_of, nested, atom_of, offs, cms = [], [], [], [], [], [], {}
+    any_phrase = False
+
+    def add(t, outer, ci, inner, mi, off=0):
+        terms.append(t)
+        occurs.append(outer)
+        clause_of.append(ci)
+        nested.append(inner)
+        atom_of.append(mi)
+        offs.append(off)
+
     for ci, cl in enumerate(spec):
+        if _is_phrase(cl[1]):  # a phrase as a clause of its own: a one-member group
+            any_phrase = True
+            for o, t in enumerate(cl[1][1]):
+                add(t, cl[0], ci, M | PH, 0, o)
+            continue
         if not isinstance(cl[1], (list, tuple)):
-            terms.append(cl[1])
-            occurs.append(cl[0])
-            clause_of.append(ci)
-            nested.append(M)
-            atom_of.append(0)
+            add(cl[1], cl[0], ci, M, 0)
             continue
         for mi, (inner, member) in enumerate(cl[1]):
+            if _is_phrase(member):
+                any_phrase = True
+                for o, t in enumerate(member[1]):
+                    add(t, cl[0], ci, inner | PH, mi, o)
+                continue
             for t in (member if isinstance(member, (list, tuple)) else [member]):
-                terms.append(t)
-                occurs.append(cl[0])
-                clause_of.append(ci)
-                nested.append(inner)
-                atom_of.append(mi)
+                add(t, cl[0], ci, inner, mi)
         if len(cl) > 2 and cl[2]:
             cms[ci] = cl[2]
     extra = {"nested_occurs": nested, "atom_of": atom_of}
+    if any_phrase:
+        extra["phrase_offsets"] = offs
     if cms:
         extra["clause_min_should"] = cms
     return (ta.MODE_BOOL, terms, occurs, clause_of, msm, extra)
