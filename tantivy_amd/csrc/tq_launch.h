@@ -146,7 +146,16 @@ struct TqkMergeParams {
   uint32_t *out_counts;
   uint32_t n_queries;
   uint32_t out_stride;
+  // two-level merge (queries with thousands of partial lists: a small batch cut into short tiles): `pre_slices` > 0 =
+  // a first launch of n_queries x pre_slices wavefronts reduces slice s of every query's lists — lists [s * per,
+  // (s + 1) * per), per = tqk_merge_slice_lists(n_parts, pre_slices) — into the slice's FIRST list, in place; the
+  // final launch then reads one list per slice.  Queries with fewer than TQK_MERGE_PRE_MIN lists are left alone.
+  uint32_t pre_slices;
 };
+constexpr uint32_t TQK_MERGE_PRE_MIN = 96;
+inline __host__ __device__ uint32_t tqk_merge_slice_lists(uint32_t n_parts, uint32_t pre_slices) {
+  return (pre_slices == 0u || n_parts < TQK_MERGE_PRE_MIN) ? 1u : (n_parts + pre_slices - 1u) / pre_slices;
+}
 
 struct TqkSegMergeParams {
   const float *scores;          // [segment][query][stride]

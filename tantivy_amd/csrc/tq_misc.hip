@@ -6,14 +6,29 @@ namespace {
 
 // =================================================================== merge kernel
 // One wavefront per query: reduce its partial lists to the final top-k, sorted.
-template <int KPL>
+// PRE: the first level of a two-level merge (TqkMergeParams::pre_slices): wavefront (q, s) reduces slice s of query
+// q's lists into the slice's first list; the final launch reads one list per slice.
+template <int KPL, bool PRE>
 __global__ __launch_bounds__(64) void merge_kernel(TqkMergeParams p) {
   const int lane = (int)__lane_id();
-  const uint32_t q = blockIdx.x;
+  const uint32_t q = PRE ? blockIdx.x % p.n_queries : blockIdx.x;
   if (q >= p.n_queries) return;
   const TqdQuery *Q = uni_ptr(p.queries + q);
   const uint32_t k = uni(Q->k);
-  const uint32_t part_start = uni(Q->part_start), n_parts = uni(Q->n_parts);
+  uint32_t part_start = uni(Q->part_start), n_parts = uni(Q->n_parts);
+  const uint32_t per = tqk_merge_slice_lists(n_parts, p.pre_slices);
+  uint32_t stride = 1u;  // (in lists)
+  if constexpr (PRE) {
+    if (per == 1u) return;  // few lists: the final launch reads them all
+    const uint32_t sl = blockIdx.x / p.n_queries;
+    if (sl * per >= n_parts) return;
+    part_start += sl * per;
+    n_parts = n_parts - sl * per < per ? n_parts - sl * per : per;
+    if (n_parts == 1u) return;  // (already "merged")
+  } else {
+    stride = per;
+    n_parts = (n_parts + per - 1u) / per;
+  }
   TopK<KPL> tk;
   tk.reset(k);
   // a full partial list's k-th key is a lower bound of the final k-th key: the largest of them
@@ -21,7 +36,7 @@ __global__ __launch_bounds__(64) void merge_kernel(TqkMergeParams p) {
   // serial insertions below
   uint64_t floor_key = 0;
   for (uint32_t pi = (uint32_t)lane; pi < n_parts; pi += WAVE) {
-    const uint64_t kth = p.partials[(uint64_t)(part_start + pi) * (uint64_t)(KPL * 64) + (k - 1u)];
+    const uint64_t kth = p.partials[(uint64_t)(part_start + pi * stride) * (uint64_t)(KPL * 64) + (k - 1u)];
     floor_key = kth > floor_key ? kth : floor_key;
   }
   for (int o = 32; o; o >>= 1) {
@@ -37,7 +52,7 @@ __global__ __launch_bounds__(64) void merge_kernel(TqkMergeParams p) {
 #pragma unroll
     for (uint32_t g = 0; g < GROUP; ++g) {
       const uint32_t pi = pi0 + g < n_parts ? pi0 + g : n_parts - 1u;  // clamped: unconditional loads
-      const uint64_t *src = p.partials + (uint64_t)(part_start + pi) * (uint64_t)(KPL * 64);
+      const uint64_t *src = p.partials + (uint64_t)(part_start + pi * stride) * (uint64_t)(KPL * 64);
 #pragma unroll
       for (int r = 0; r < KPL; ++r) keys[g][r] = src[(uint32_t)r * 64u + (uint32_t)lane];
     }
@@ -48,6 +63,10 @@ __global__ __launch_bounds__(64) void merge_kernel(TqkMergeParams p) {
       for (int r = 0; r < KPL; ++r)
         tk.offer(keys[g][r] != 0ull && keys[g][r] >= floor_key, keys[g][r], lane);
     }
+  }
+  if constexpr (PRE) {  // the slice's top-k replaces its first list (nothing else reads this slice's lists meanwhile)
+    flush_partial<KPL>(tk, const_cast<uint64_t *>(p.partials), part_start, lane);
+    return;
   }
   const uint32_t out_q = p.out_index ? p.out_index[q] : q;
   uint32_t count = 0;
@@ -188,15 +207,24 @@ hipError_t tqk_launch_docmat_set(uint64_t *mat, const uint32_t *docs, uint32_t n
                      max_doc);
   return hipGetLastError();
 }
+template <bool PRE>
+static void launch_merge_t(const TqkMergeParams &p, int kpl, dim3 grid, dim3 block, hipStream_t st) {
+  switch (kpl) {
+    case 1: merge_kernel<1, PRE><<<grid, block, 0, st>>>(p); break;
+    case 2: merge_kernel<2, PRE><<<grid, block, 0, st>>>(p); break;
+    case 4: merge_kernel<4, PRE><<<grid, block, 0, st>>>(p); break;
+    default: merge_kernel<16, PRE><<<grid, block, 0, st>>>(p); break;
+  }
+}
 hipError_t tqk_launch_merge(const TqkMergeParams &p, int kpl, hipStream_t st) {
   if (p.n_queries == 0) return hipSuccess;
-  const dim3 grid(p.n_queries), block(64);
-  switch (kpl) {
-    case 1: merge_kernel<1><<<grid, block, 0, st>>>(p); break;
-    case 2: merge_kernel<2><<<grid, block, 0, st>>>(p); break;
-    case 4: merge_kernel<4><<<grid, block, 0, st>>>(p); break;
-    default: merge_kernel<16><<<grid, block, 0, st>>>(p); break;
+  const dim3 block(64);
+  if (p.pre_slices) {
+    launch_merge_t<true>(p, kpl, dim3(p.n_queries * p.pre_slices), block, st);
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
   }
+  launch_merge_t<false>(p, kpl, dim3(p.n_queries), block, st);
   return hipGetLastError();
 }
 hipError_t tqk_launch_decode_list(const TqdSegment &seg, const TqdTerm *terms, uint32_t handle,

@@ -153,8 +153,17 @@ int build_group_chunks(Group &g, bool or_windows, PlanScratch &ps, bool boolean_
       or_win ? 8192u
              : (or_cand ? (boolean_group ? kBoolChunkMul : (g.max_k <= 16u ? kOrChunkMulSmallK : kOrChunkMul)) * kAndChunks
                         : kAndChunks);
-  const uint64_t cost_target = std::max<uint64_t>(or_win ? 1u : 128u,
-                                                  (total_cost + n_target - 1) / n_target);
+  // a chunk is at least 128 cost units (two 64-block tiles of an intersection) — unless the whole launch would then
+  // be a few dozen wavefronts: a small batch (one query over a 50 k-doc leader = 4 chunks) is cut into about
+  // kSmallChunks chunks of at least 8 units, tq_search.cpp sizes its tiles to match and the partial lists that makes
+  // are merged in two levels
+  // (only the smallest launches: from 16 queries on more wavefronts measured SLOWER — every wavefront starts from
+  // the thresholds it finds, and a query cut into a hundred of them scores most of its matches before any of them
+  // has a k-th best score to share: profiles/r05_small_batches.txt)
+  static const uint64_t kSmallChunks = std::max<uint32_t>(1u, tune_u32("TQ_AND_SMALL_TILES", 2048));
+  static const uint64_t kSmallCost = tune_u32("TQ_AND_SMALL_BLOCKS", 8192);
+  const uint64_t cost_floor = or_win ? 1u : (total_cost < kSmallCost ? std::min<uint64_t>(128u, std::max<uint64_t>(8u, total_cost / kSmallChunks)) : 128u);
+  const uint64_t cost_target = std::max<uint64_t>(cost_floor, (total_cost + n_target - 1) / n_target);
   pt("costs");
   const uint32_t per_chunk = or_win ? TQD_WAVES_PER_WG : 1u;
   const uint32_t li_cap = n_slices * 8u / kOrSubSlices - 1u;

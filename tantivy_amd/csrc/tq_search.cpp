@@ -209,6 +209,7 @@ int search_batch_impl(tq_segment *s, const tq_query *queries, uint32_t n_queries
     return q.terms[best_i];
   };
   uint64_t unique_bytes = 0;
+  uint64_t and_lead_blocks = 0;  // leader blocks of the batch's intersections (sizes their tiles below)
   uint32_t n_union_queries = 0;
   for (uint32_t qi = 0; qi < n_queries; ++qi)  // (a one-list intersection runs as a union)
     n_union_queries += (queries[qi].mode == TQ_MODE_OR || (queries[qi].mode == TQ_MODE_AND && queries[qi].n_terms == 1)) ? 1u : 0u;
@@ -224,9 +225,11 @@ int search_batch_impl(tq_segment *s, const tq_query *queries, uint32_t n_queries
     for (uint32_t qi = 0; qi < n_queries; ++qi) {
       const tq_query &q = queries[qi];
       if (!q.terms || q.n_terms > TQ_MAX_TERMS) continue;  // (reported by plan_query)
+      uint32_t lead_blocks = 0xFFFFFFFFu;
       for (uint32_t i = 0; i < q.n_terms; ++i) {
         const uint32_t h = q.terms[i];
         if (h >= s->terms.size()) continue;
+        lead_blocks = std::min(lead_blocks, s->terms[h].n_blocks);
         if (ps.term_stamp[2 * h] != ps.batch_stamp) {
           ps.term_stamp[2 * h] = ps.batch_stamp;
           unique_bytes += s->terms[h].postings_len;
@@ -236,6 +239,7 @@ int search_batch_impl(tq_segment *s, const tq_query *queries, uint32_t n_queries
           unique_bytes += s->terms[h].positions_len;
         }
       }
+      if (q.mode == TQ_MODE_AND && q.n_terms >= 2 && lead_blocks != 0xFFFFFFFFu) and_lead_blocks += lead_blocks;
       if (ashare_on) {
         const uint32_t lh = ashare_leader(q, ps.q_cache[qi]);
         ps.q_leader[qi] = lh;
@@ -253,6 +257,17 @@ int search_batch_impl(tq_segment *s, const tq_query *queries, uint32_t n_queries
       ashare_and = n_el >= min_batch;
     }
   }
+  // Tiles of the per-query intersection kernel: 64 leader blocks — unless the whole batch would then be a few hundred
+  // wavefronts walking their tiles serially (one query over a 250 k-doc leader = 31 wavefronts x 64 blocks = 0.23 of
+  // a 0.27 ms call): a batch of fewer than kSmallBatchBlocks leader blocks (one to four queries) is cut into about
+  // kSmallBatchTiles tiles of at least kMinTileBlocks blocks, and the hundreds of partial lists that makes are merged in
+  // two levels (tqk_launch_merge).  One query per call: 0.27 -> 0.14 ms.
+  static const uint32_t kSmallBatchTiles = std::max<uint32_t>(1u, tune_u32("TQ_AND_SMALL_TILES", 2048));
+  static const uint32_t kMinTileBlocks = std::min<uint32_t>(TQD_AND_TILE, std::max<uint32_t>(1u, tune_u32("TQ_AND_MIN_TILE", 4)));
+  static const uint64_t kSmallBatchBlocks = tune_u32("TQ_AND_SMALL_BLOCKS", 8192);  // (tq_plan_chunks.cpp: the chunk floor follows)
+  const uint32_t and_tile_cap = and_lead_blocks < kSmallBatchBlocks
+                                    ? (uint32_t)std::min<uint64_t>(TQD_AND_TILE, std::max<uint64_t>(kMinTileBlocks, and_lead_blocks / kSmallBatchTiles))
+                                    : TQD_AND_TILE;
   // One query -> its descriptor in its launch group.  Reads the segment and the caller's query only,
   // writes to the groups / counters it is handed: large pruned batches are planned in slabs of
   // queries by the planner's threads, each into its own groups, which are then laid end to end.
@@ -336,7 +351,7 @@ int search_batch_impl(tq_segment *s, const tq_query *queries, uint32_t n_queries
             c_lb += 2u * std::min<uint32_t>(128u, (th.n_blocks + lead_blocks - 1) / lead_blocks);
           }
           static const uint32_t kAndTileNum = std::max<uint32_t>(1u, tune_u32("TQ_AND_TILE_NUM", TQD_AND_TILE));
-          dq.tile_blocks = std::min<uint32_t>(TQD_AND_TILE, std::max<uint32_t>(1u, kAndTileNum / c_lb));
+          dq.tile_blocks = std::min<uint32_t>(and_tile_cap, std::max<uint32_t>(1u, kAndTileNum / c_lb));
           tile_cost = dq.tile_blocks * c_lb;
           n_tiles = (lead_blocks + dq.tile_blocks - 1) / dq.tile_blocks;
           bool nonneg = true;
@@ -1128,6 +1143,14 @@ int search_batch_impl(tq_segment *s, const tq_query *queries, uint32_t n_queries
     m.out_counts = d_out_counts;
     m.n_queries = (uint32_t)g.queries.size();
     m.out_stride = out_stride;
+    if (gi != kAShare && gi != kBShare && gi != kShare && gi != kDense) {
+      // a query with hundreds of partial lists (a small batch cut into short tiles): its lists are reduced by up
+      // to 32 wavefronts first — one wavefront walking 2 000 lists was most of a one-query call
+      uint32_t max_parts = 0;
+      for (const TqdQuery &dq : g.queries) max_parts = std::max(max_parts, dq.n_parts);
+      if (max_parts >= TQK_MERGE_PRE_MIN && m.n_queries <= 4096u)
+        m.pre_slices = std::min<uint32_t>(32u, std::max<uint32_t>(2u, (uint32_t)std::sqrt((double)max_parts)));
+    }
     hipError_t e = gi == kAShare  ? tqk_launch_merge_lists(m, (const uint32_t *)s->d_ashare_words.p + n_ashare, g.kpl, st)
                    : gi == kBShare ? tqk_launch_merge_lists(m, (const uint32_t *)s->d_bshare_words.p + n_ashare_of[1], g.kpl, st)
                    : gi == kShare ? tqk_launch_merge_lists(m, (const uint32_t *)s->d_share_words.p + n_share, g.kpl, st)

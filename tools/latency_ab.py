@@ -16,7 +16,7 @@ ids = O.zipf_queries(10000, 2, 256, seed=20260921)
 qs = [(O.MODE_AND, q.tolist()) for q in ids]
 dev.set_option("exhaustive", 0)
 row = []
-for b in (1, 16, 64, 256, 1024, 4096):
+for b in [int(x) for x in os.environ.get("BATCHES", "1,16,64,256,1024,4096").split(",")]:
     dev.prepare(qs[:b])
     t = []
     for _ in range(63):
