@@ -215,6 +215,16 @@ hipError_t tqk_launch_phrase(const TqkScanParams &p, int kpl, bool use_dpp, hipS
 hipError_t tqk_launch_merge(const TqkMergeParams &p, int kpl, hipStream_t st);
 hipError_t tqk_launch_share(const TqkShareParams &p, int kpl, hipStream_t st);
 // merge of the shared-union launch's per-query lists (m.partials = lists, list_count per query)
+// the words a batch zeroes before its kernels (match counters, threshold slots, the shared launches' per-query words):
+// ONE launch instead of a fill per buffer (five fills and their gaps were 30 us of a 1.1 ms headline step, 15 of a
+// 140 us one-query call)
+constexpr int TQK_ZERO_MAX = 8;
+struct TqkZeroParams {
+  uint32_t *ptr[TQK_ZERO_MAX];  // 4-byte aligned
+  uint32_t words[TQK_ZERO_MAX];
+  uint32_t n;
+};
+hipError_t tqk_launch_zero(const TqkZeroParams &p, hipStream_t st);
 hipError_t tqk_launch_merge_lists(const TqkMergeParams &m, const uint32_t *list_count, int kpl,
                                   hipStream_t st);
 uint32_t tqk_share_capl(int kpl);  // staging entries per lead slot

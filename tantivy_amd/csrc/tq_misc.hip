@@ -87,6 +87,23 @@ __global__ __launch_bounds__(64) void merge_kernel(TqkMergeParams p) {
   if (lane == 0) p.out_counts[out_q] = count;
 }
 
+// =================================================================== batch-start zeroing
+__global__ __launch_bounds__(256) void zero_regions_kernel(TqkZeroParams p) {
+  const uint32_t r = blockIdx.y;
+  uint32_t *dst = p.ptr[r];
+  const uint32_t n = p.words[r];
+  // 16-byte stores over the aligned middle, single words at the ends
+  const uint32_t head = (uint32_t)((16u - ((uintptr_t)dst & 15u)) & 15u) >> 2;
+  const uint32_t h = head < n ? head : n;
+  const uint32_t tid = blockIdx.x * 256u + threadIdx.x, stride = gridDim.x * 256u;
+  if (tid < h) dst[tid] = 0u;
+  const uint32_t n4 = (n - h) >> 2;
+  uint4 *d4 = reinterpret_cast<uint4 *>(dst + h);
+  for (uint32_t i = tid; i < n4; i += stride) d4[i] = make_uint4(0u, 0u, 0u, 0u);
+  const uint32_t tail0 = h + (n4 << 2);
+  if (tid < n - tail0) dst[tail0 + tid] = 0u;
+}
+
 // =================================================================== whole-list decode (codec parity)
 template <bool USE_DPP>
 __global__ __launch_bounds__(256) void decode_list_kernel(TqdSegment seg, const TqdTerm *terms,
@@ -205,6 +222,15 @@ hipError_t tqk_launch_docmat_set(uint64_t *mat, const uint32_t *docs, uint32_t n
   if (n == 0) return hipSuccess;
   hipLaunchKernelGGL(docmat_set_kernel, dim3((n + 255) / 256), dim3(256), 0, st, mat, docs, n, slot,
                      max_doc);
+  return hipGetLastError();
+}
+hipError_t tqk_launch_zero(const TqkZeroParams &p, hipStream_t st) {
+  if (p.n == 0) return hipSuccess;
+  uint32_t max_words = 0;
+  for (uint32_t i = 0; i < p.n; ++i) max_words = max_words > p.words[i] ? max_words : p.words[i];
+  if (max_words == 0) return hipSuccess;
+  const uint32_t bx = (max_words / 4u + 2047u) / 2048u;  // (<= 8 16-byte stores per thread)
+  hipLaunchKernelGGL(zero_regions_kernel, dim3(bx ? (bx > 256u ? 256u : bx) : 1u, p.n), dim3(256), 0, st, p);
   return hipGetLastError();
 }
 template <bool PRE>

@@ -844,8 +844,20 @@ int search_batch_impl(tq_segment *s, const tq_query *queries, uint32_t n_queries
     s->d_terms_dirty_from = ~(size_t)0;
     s->d_terms_synced = terms_to;
   }
-  HIP_TRY(hipMemsetAsync(s->d_match_counter, 0, sizeof(unsigned long long), st));
-  HIP_TRY(hipMemsetAsync(s->d_qmatches.p, 0, (size_t)n_queries * sizeof(uint32_t), st));
+  TqkZeroParams zp{};  // every buffer the batch zeroes, cleared by one launch below
+  auto zero_later = [&](void *ptr, size_t bytes) -> int {
+    if (!bytes) return TQ_OK;
+    if (zp.n == (uint32_t)TQK_ZERO_MAX || (bytes & 3u) || ((uintptr_t)ptr & 3u) || bytes > 0xFFFFFFFFull * 4u) {
+      HIP_TRY(hipMemsetAsync(ptr, 0, bytes, st));  // (never taken today: at most six aligned buffers)
+      return TQ_OK;
+    }
+    zp.ptr[zp.n] = (uint32_t *)ptr;
+    zp.words[zp.n++] = (uint32_t)(bytes >> 2);
+    return TQ_OK;
+  };
+  rc = zero_later(s->d_match_counter, sizeof(unsigned long long));
+  if (rc == TQ_OK) rc = zero_later(s->d_qmatches.p, (size_t)n_queries * sizeof(uint32_t));
+  if (rc != TQ_OK) return rc;
   s->last_batch_queries = n_queries;
   if (n_thr_rows) {
     const size_t thr_bytes = (size_t)n_thr_rows * TQD_THR_SLOTS * sizeof(uint32_t);
@@ -854,7 +866,10 @@ int search_batch_impl(tq_segment *s, const tq_query *queries, uint32_t n_queries
     // TQ_KEEP_THR=1 (experiments only): the slots keep the previous batch's final values, i.e. the
     // same batch run again starts from its final thresholds (what perfect threshold knowledge buys)
     static const bool kKeepThr = tune_u32("TQ_KEEP_THR", 0) != 0;
-    if (!kKeepThr || !s->thr_seeded) HIP_TRY(hipMemsetAsync(s->d_thr.p, 0, thr_bytes, st));
+    if (!kKeepThr || !s->thr_seeded) {
+      rc = zero_later(s->d_thr.p, thr_bytes);
+      if (rc != TQ_OK) return rc;
+    }
     s->thr_seeded = true;
   }
 
@@ -871,7 +886,8 @@ int search_batch_impl(tq_segment *s, const tq_query *queries, uint32_t n_queries
     if (rc == TQ_OK)
       rc = sc.share_stage.ensure((size_t)s->plan->xgrid * n_dense * tqk_share_capl(groups[kDense].kpl) * sizeof(uint64_t));
     if (rc != TQ_OK) return rc;
-    HIP_TRY(hipMemsetAsync(s->d_share_words.p, 0, words * sizeof(uint32_t), st));
+    rc = zero_later(s->d_share_words.p, words * sizeof(uint32_t));
+    if (rc != TQ_OK) return rc;
   }
   if (n_share) {
     static const uint32_t kGridMul = std::max<uint32_t>(1u, tune_u32("TQ_US_GRID_MUL", 16));
@@ -882,7 +898,8 @@ int search_batch_impl(tq_segment *s, const tq_query *queries, uint32_t n_queries
       rc = sc.share_stage.ensure((size_t)share_grid * TQD_US_GROUP * tqk_share_capl(groups[kShare].kpl) *
                                    sizeof(uint64_t));
     if (rc != TQ_OK) return rc;
-    HIP_TRY(hipMemsetAsync(s->d_share_words.p, 0, words * sizeof(uint32_t), st));
+    rc = zero_later(s->d_share_words.p, words * sizeof(uint32_t));
+    if (rc != TQ_OK) return rc;
   }
 
   // the shared-intersection launches: [0] intersections, [1] boolean queries
@@ -906,7 +923,12 @@ int search_batch_impl(tq_segment *s, const tq_query *queries, uint32_t n_queries
     // launch costs whose thresholds are right from its first task)
     static const bool kKeepThrWords = tune_u32("TQ_KEEP_THR", 0) != 0;
     const size_t keep = (kKeepThrWords && s->thr_seeded) ? n_ashare_of[ai] : 0;
-    HIP_TRY(hipMemsetAsync((uint32_t *)wb.p + keep, 0, (words - keep) * sizeof(uint32_t), st));
+    rc = zero_later((uint32_t *)wb.p + keep, (words - keep) * sizeof(uint32_t));
+    if (rc != TQ_OK) return rc;
+  }
+  {
+    const hipError_t ze = tqk_launch_zero(zp, st);
+    if (ze != hipSuccess) return fail(TQ_ERR_HIP, "zero launch: %s", hipGetErrorString(ze));
   }
 
   // ---- launch
