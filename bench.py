@@ -1166,6 +1166,7 @@ def main():
             "matches_per_launch": int(m["full_matches"]),
             "traffic_note": tf["traffic_note"],
             "host_plan_ms": round(st["host_plan_ms"], 3),
+            "gpu_batch_ms": round(st["total_ms"], 4),  # the batch on its stream: zeroing + scan kernels + merges (HIP events)
             "exchange_ms": round(main_exchange_ms, 4),
             "resident_bytes": main_resident,
             "frac_note": "achieved / frac = bytes that crossed the L2's fabric side (traffic: this run's rocprofv3 "
