@@ -386,6 +386,10 @@ def measure(cl, runner, torch, queries, k, steps, warmup, time_exhaustive=False)
         runner.enqueue()     # at once the runtime grows its pools — a 7-10 ms hiccup that belongs here)
     runner.synchronize()
     runner.batch_stats()  # start a fresh timing window
+    import gc
+    gc.collect()  # (a collection inside a 20 ms timed region is a tenth of it)
+    gc_was = gc.isenabled()
+    gc.disable()
     cl.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -402,6 +406,8 @@ def measure(cl, runner, torch, queries, k, steps, warmup, time_exhaustive=False)
     torch.cuda.synchronize()
     cl.barrier()
     elapsed = cl.max_over_ranks(time.perf_counter() - t0)
+    if gc_was:
+        gc.enable()
     st = runner.batch_stats()  # HIP-event kernel time, mean over the timed steps (<= last 16)
     return {"elapsed": elapsed, "stats": st, "final": runner.results(), "mode_parity": same,
             "n_diff": int(np.sum(np.any(exh_out[2] != prn_out[2], axis=1))),

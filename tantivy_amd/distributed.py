@@ -148,6 +148,10 @@ class ShardRunner:
         self.force_exchange = force_exchange  # tests: run the all-gather even with one rank
         self.stream_obj = torch.cuda.Stream(device=device)
         self.stream = self.stream_obj.cuda_stream
+        # (timing events are created once: two hipEventCreate per step inside a pipelined loop now and then cost
+        # milliseconds when the runtime grew its pools)
+        self._ev_ring = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(16)]
+        self._ev_at = 0
         self.n = self.k = 0
         self._ex_events = []  # (start, end) torch events around exchange + merge, last 16 steps
         self._agree("local segments per rank", self.n_local)
@@ -232,14 +236,15 @@ class ShardRunner:
                 self.dev.collect_segment_prepared_device(
                     s, k, sc[s * n:(s + 1) * n], dc[s * n:(s + 1) * n], ct[s * n:(s + 1) * n],
                     self.stream)
-            ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            ev = self._ev_ring[self._ev_at % 16]
+            self._ev_at += 1
             ev[0].record(self.stream_obj)
             g = exchange_topk((sc, dc, ct), n, k, S, W, self.comm, self.torch_group,
                               getattr(self, "gathered", None), self.stream, self.force_exchange)
             merge_gathered_device(self.dev.ctx, self.device, g[0], g[1], g[2], 0, k, self.stream,
                                   out=self.merged)
             ev[1].record(self.stream_obj)
-            self._ex_events = (self._ex_events + [ev])[-16:]
+            self._ex_events = [e for e in self._ex_events if e is not ev][-15:] + [ev]
             self._host_all.copy_(self._merged_all, non_blocking=True)
 
     def synchronize(self):
