@@ -382,14 +382,14 @@ def measure(cl, runner, torch, queries, k, steps, warmup, time_exhaustive=False)
     _, prn_st2 = one(False, 2)
     same = all(np.array_equal(a, b) for a, b in zip(exh_out, prn_out))
     runner.set_option("exhaustive", 1 if time_exhaustive else 0)
+    import gc
+    gc.collect()  # (before the warm-up, not between it and the timed steps: a collection evicts the planner's tables
+    gc_was = gc.isenabled()  # from the caches — the first timed step then took 1.7 instead of 1.0 ms — and one inside a
+    gc.disable()             # 20 ms timed region is a tenth of it)
     for _ in range(warmup):  # (pipelined like the timed steps: the first time two steps are in flight
         runner.enqueue()     # at once the runtime grows its pools — a 7-10 ms hiccup that belongs here)
     runner.synchronize()
     runner.batch_stats()  # start a fresh timing window
-    import gc
-    gc.collect()  # (a collection inside a 20 ms timed region is a tenth of it)
-    gc_was = gc.isenabled()
-    gc.disable()
     cl.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
