@@ -429,7 +429,7 @@ def latency_curve(dev, queries, k):
     out = {"note": "and2 stream, k=%d, one 10M-doc segment; batch: one caller, synchronous batches (plan + H2D + "
                    "kernels + D2H per call); threads: T host threads x single-query Searcher::search calls, "
                    "coalesced by tq_search_one (submit_window_us = 100)" % k, "batch": {}, "threads": {}}
-    for b in (1, 16, 256, 4096, 10000):
+    for b in (1, 4, 16, 256, 4096, 10000):
         b = min(b, len(queries))
         dev.prepare(queries[:b])
         reps = 200 if b <= 16 else (60 if b <= 256 else 25)
@@ -440,8 +440,8 @@ def latency_curve(dev, queries, k):
             t.append(time.perf_counter() - t1)
         t = t[3:]
         out["batch"][str(b)] = {"qps": round(b * len(t) / sum(t), 1), "p50_ms": pct(t, 0.5), "p99_ms": pct(t, 0.99)}
-    for nthreads in (1, 16, 64):
-        n = min(len(queries), 400 if nthreads == 1 else nthreads * 150)
+    for nthreads in (1, 16, 64, 256, 1024):
+        n = min(len(queries), 400 if nthreads == 1 else nthreads * (150 if nthreads <= 64 else 40))
         dev.search_concurrent(queries[:min(n, 4 * nthreads)], k, nthreads)  # (threads + queue warm)
         dev.submit_stats(reset=True)
         _, _, _, _, lat_ms, wall_ms = dev.search_concurrent(queries[:n], k, nthreads)
