@@ -257,6 +257,11 @@ int tq_merge_topk_device(tq_ctx *ctx, int device, const float *d_scores, const u
                          uint32_t offset, uint32_t limit, float *d_out_scores,
                          uint32_t *d_out_segment_ords, uint32_t *d_out_docs,
                          uint32_t *d_out_counts, void *hip_stream);
+/* The merged rows' way back to the host: an asynchronous copy of `bytes` from device memory on `device` to PINNED host
+ * memory, enqueued on hip_stream behind the merge.  replaces: nothing in the reference (its fruits are host vectors);
+ * what a Rust host does with hipMemcpyAsync after tq_merge_topk_device. */
+int tq_copy_to_host_async(tq_ctx *ctx, int device, void *dst_pinned_host, const void *src_device, size_t bytes,
+                          void *hip_stream);
 
 /* ---- cross-GPU exchange (one segment set per GPU) ----
  * replaces: the fan-in of Searcher::search_with_executor (src/core/searcher.rs:230-235: the

@@ -95,7 +95,7 @@ EXPORTS = [
     "tq_segment_free",
     "tq_term_prepare", "tq_search_batch", "tq_search_batch_device", "tq_search_batch_opts",
     "tq_search_batch_device_opts", "tq_merge_topk",
-    "tq_merge_topk_device", "tq_decode_postings", "tq_decode_position_deltas",
+    "tq_merge_topk_device", "tq_copy_to_host_async", "tq_decode_postings", "tq_decode_position_deltas",
     "tq_last_batch_stats", "tq_segment_get_stats", "tq_segment_reserve_columns", "tq_set_option", "tq_segment_set_alive_bitset", "tq_count_batch",
     "tq_last_batch_match_counts", "tq_last_batch_query_kernels", "tq_encoder_create", "tq_encoder_free", "tq_encode_postings",
     "tq_encode_positions", "tq_encode_postings_device", "tq_encode_positions_device",
@@ -141,6 +141,7 @@ def lib():
                                               vp, vp, C.POINTER(TqSearchOpts), vp]
     L.tq_merge_topk.argtypes = [f32p, u32p, u32p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
                                 C.c_uint32, f32p, u32p, u32p, u32p]
+    L.tq_copy_to_host_async.argtypes = [vp, C.c_int, vp, vp, C.c_size_t, vp]
     L.tq_merge_topk_device.argtypes = [vp, C.c_int, vp, vp, vp, vp, C.c_uint32, C.c_uint32,
                                        C.c_uint32, C.c_uint32, C.c_uint32, vp, vp, vp, vp, vp]
     L.tq_decode_postings.argtypes = [vp, C.c_uint32, u32p, u32p]

@@ -561,4 +561,13 @@ int tq_merge_topk_device(tq_ctx *ctx, int device, const float *d_scores, const u
   return TQ_OK;
 }
 
+int tq_copy_to_host_async(tq_ctx *ctx, int device, void *dst_pinned_host, const void *src_device, size_t bytes,
+                          void *hip_stream) {
+  if (!ctx || !dst_pinned_host || !src_device) return fail(TQ_ERR_INVALID, "tq_copy_to_host_async: null argument");
+  if (!bytes) return TQ_OK;
+  HIP_TRY(hipSetDevice(device));
+  HIP_TRY(hipMemcpyAsync(dst_pinned_host, src_device, bytes, hipMemcpyDeviceToHost, (hipStream_t)hip_stream));
+  return TQ_OK;
+}
+
 }  // extern "C"

@@ -245,7 +245,11 @@ class ShardRunner:
                                   out=self.merged)
             ev[1].record(self.stream_obj)
             self._ex_events = [e for e in self._ex_events if e is not ev][-15:] + [ev]
-            self._host_all.copy_(self._merged_all, non_blocking=True)
+            # (not torch's copy_: its pinned-memory bookkeeping now and then took 7 ms on the host inside a pipelined
+            # loop — three of ten 20-step runs lost a third of their time to one such call)
+            B._check(B.lib().tq_copy_to_host_async(
+                self.dev.ctx, int(self.device), self._host_all.data_ptr(), self._merged_all.data_ptr(),
+                self._merged_all.numel() * 4, C.c_void_p(self.stream)))
 
     def synchronize(self):
         self.stream_obj.synchronize()

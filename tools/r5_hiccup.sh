@@ -2,7 +2,7 @@
 # repeated headline runs with the host time of every enqueue call: where a slow run (1.5 instead of 1.15 ms per step)
 # loses its time
 for i in $(seq 1 ${RUNS:-8}); do
-  BENCH_TRACE=1 python bench.py --workload and2 --no-side --no-cpu-baseline --latency-queries 0 --no-pmc-inline --no-stream --steps 20 --warmup 5 > /tmp/hic.json 2> /tmp/hic.err
+  BENCH_TRACE=1 python bench.py --workload ${W:-and2} --no-side --no-cpu-baseline --latency-queries 0 --no-pmc-inline --no-stream --steps 20 --warmup 5 > /tmp/hic.json 2> /tmp/hic.err
   python - <<'PY'
 import json
 j=json.loads(open('/tmp/hic.json').read().strip().splitlines()[-1])
