@@ -81,6 +81,9 @@ def parse_args(argv=None):
     ap.add_argument("--stream-vocabs", default="256,4096,65536",
                     help="vocabularies of the stream block (comma separated; each its own 10M-doc segment)")
     ap.add_argument("--stream-batches", type=int, default=24)
+    ap.add_argument("--stream-serial", action="store_true",
+                    help="stream block: Query::weight on the enqueueing thread (default: a second host thread prepares the next "
+                         "batch while this one is planned and enqueued; profiles/r05_stream_prepare_thread.txt has both)")
     ap.add_argument("--check-queries", type=int, default=512,
                     help="queries of every workload checked against the oracle, spread over the kernel families that ran")
     return ap.parse_args(argv)
@@ -744,14 +747,24 @@ def stream_block(O, D, cl, torch, args, vocab, seg, n_batches, n_q, k):
     first = runner.results()
     prep_s, t1 = 0.0, time.perf_counter()
     n_warm = min(3, n_batches - 2)
+    # Query::weight of batch i + 1 on a second host thread while this one plans and enqueues batch i (what a server's
+    # request threads do); --stream-serial: one thread does both in turn
+    overlap = not getattr(args, "stream_serial", False)
+    if overlap:
+        runner.prepare_next(batches[1], k, marsh[1])
     for i in range(1, n_batches):
         if i == 1 + n_warm:  # steady state from here: the first batches still meet new terms
             runner.synchronize()
             runner.batch_stats()
             prep_s, t1 = 0.0, time.perf_counter()
-        tp = time.perf_counter()
-        runner.prepare(batches[i], k, marsh[i])
-        prep_s += time.perf_counter() - tp
+        if overlap:
+            prep_s += runner.commit_next()
+            if i + 1 < n_batches:
+                runner.prepare_next(batches[i + 1], k, marsh[i + 1])
+        else:
+            tp = time.perf_counter()
+            runner.prepare(batches[i], k, marsh[i])
+            prep_s += time.perf_counter() - tp
         runner.enqueue()
     runner.synchronize()
     wall = time.perf_counter() - t1
@@ -768,6 +781,8 @@ def stream_block(O, D, cl, torch, args, vocab, seg, n_batches, n_q, k):
             "steady_ms_per_batch": round(wall / timed * 1e3, 3),
             "prepare_ms_per_batch": round(prep_s / timed * 1e3, 3),
             "prepare_share": round(prep_s / wall, 3),
+            "prepare_thread": "second host thread, one batch ahead" if overlap else "the enqueueing thread",
+
             "kernel_ms_avg": round(st["kernel_ms"], 4), "host_plan_ms": round(st["host_plan_ms"], 3),
             "kernels": " + ".join(st.get("kernels") or []),
             "derived_bytes": seg_stats["derived_bytes"], "tantivy_bytes": seg_stats["tantivy_bytes"],
@@ -1040,7 +1055,8 @@ def main():
     if world == 1 and S_main == 1 and not args.no_stream and args.workload == "and2":
         stream = {"note": "and2 stream, %d NEW batches per vocabulary (seeds differ), one fresh 10M-doc segment each: "
                           "tqh_prepare_batch (Query::weight: BM25 statistics, term lookups, tq_term_prepare and first-use "
-                          "tables) inside the timed region, steps pipelined; steady_* = after the first %d batches; "
+                          "tables) inside the timed region, on a second host thread one batch ahead of the thread that plans and "
+                          "enqueues (prepare_thread; --stream-serial: one thread does both), steps pipelined; steady_* = after the first %d batches; "
                           "replayed_qps = the headline loop's figure on the same vocabulary (one prepared batch replayed)" %
                           (args.stream_batches, 1 + min(3, args.stream_batches - 2)), "by_terms": {}}
         for vocab in [int(x) for x in args.stream_vocabs.split(",") if x]:

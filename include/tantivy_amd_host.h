@@ -72,6 +72,11 @@ int tqh_searcher_add_remote_stats(tqh_searcher *s, uint64_t max_doc, uint64_t to
                                   uint32_t n_terms);
 /* Query::weight for every query of a batch (global BM25 statistics + executor choice). */
 int tqh_prepare_batch(tqh_searcher *s, const tqh_query *queries, uint32_t n);
+/* Query::weight of the NEXT batch while the current one executes on another thread (a second slot; thread-safe next to
+ * the tqh_collect_* / tqh_search_* calls of the current batch), and the switch to it: tqh_commit_next is called by the
+ * executing thread between two batches, after tqh_prepare_batch_next has returned. */
+int tqh_prepare_batch_next(tqh_searcher *s, const tqh_query *queries, uint32_t n);
+int tqh_commit_next(tqh_searcher *s);
 /* Searcher::search of the prepared batch with TopDocs::with_limit(limit).and_offset(offset):
  * outputs [n][limit], (score desc, segment_ord asc, doc asc). */
 int tqh_search_prepared(tqh_searcher *s, uint32_t offset, uint32_t limit, float *scores,

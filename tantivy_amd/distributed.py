@@ -227,6 +227,16 @@ class ShardRunner:
         self.merged = views(self._merged_all)
         self.host = list(views(self._host_all))
 
+    def prepare_next(self, queries, k, marshalled):
+        """Query::weight of the NEXT batch on a helper thread while this thread enqueues the current one (same number
+        of queries and k as the current batch: nothing to agree on, no buffer changes); commit_next() switches to it."""
+        if (len(queries), k) != (self.n, self.k):
+            raise ValueError("prepare_next: the next batch must have the shape of the current one")
+        self.dev.prepare_next_async(marshalled)
+
+    def commit_next(self):
+        return self.dev.commit_next()
+
     def enqueue(self):
         torch = self.torch
         n, k, S, W = self.n, self.k, self.n_local, self.world

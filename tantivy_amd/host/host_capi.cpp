@@ -40,6 +40,7 @@ struct tqh_searcher {
   std::vector<std::shared_ptr<SegmentReader>> segments;
   std::unique_ptr<Searcher> searcher;
   std::vector<Weight> prepared;  // weights of the last tqh_prepare_batch
+  std::vector<Weight> prepared_next;  // ... of the last tqh_prepare_batch_next: the batch AFTER the one being executed
 };
 
 extern "C" {
@@ -300,20 +301,49 @@ static Query build_query(const tqh_query &q) {
 
 // Query::weight for a batch (global statistics, executor choice).  Kept so that a benchmark can
 // time execution separately from weight construction, like tantivy's own benches do.
-int tqh_prepare_batch(tqh_searcher *s, const tqh_query *queries, uint32_t n) {
-  return guard([&] {
-    if (!s || !s->searcher) throw TantivyError(TantivyError::InvalidArgument, "no segments");
-    s->prepared.clear();
-    s->prepared.reserve(n);
-    for (uint32_t i = 0; i < n; ++i) {
-      const tqh_query &q = queries[i];
-      // unboosted all-Must / all-Should term clauses (what a query parser makes of `+a +b` / `a b c`): the weight
-      // without the detour through a Query tree — the same f32 arithmetic as Searcher::weight
-      if ((q.mode == TQ_MODE_AND || q.mode == TQ_MODE_OR) && !q.boosts && q.n_terms >= 1 && q.terms)
-        s->prepared.push_back(s->searcher->weight_flat(q.mode, q.terms, q.n_terms));
-      else
-        s->prepared.push_back(s->searcher->weight(build_query(q)));
+static void prepare_into(tqh_searcher *s, const tqh_query *queries, uint32_t n, std::vector<Weight> &out) {
+  if (!s || !s->searcher) throw TantivyError(TantivyError::InvalidArgument, "no segments");
+  static const bool trace = getenv("TQH_TRACE") != nullptr;
+  const auto t0 = std::chrono::steady_clock::now();
+  struct Report {
+    bool on;
+    std::chrono::steady_clock::time_point t0;
+    uint32_t n;
+    ~Report() {
+      if (on)
+        fprintf(stderr, "[tqh] prepare %u queries: %.3f ms\n", n,
+                std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
     }
+  } report{trace, t0, n};
+  out.clear();
+  out.resize(n);
+  Searcher::FlatContext fc;  // (statistics + the field's tf cache: looked up with the first flat query of the batch)
+  for (uint32_t i = 0; i < n; ++i) {
+    const tqh_query &q = queries[i];
+    // unboosted all-Must / all-Should term clauses (what a query parser makes of `+a +b` / `a b c`): the weight
+    // without the detour through a Query tree — the same f32 arithmetic as Searcher::weight
+    if ((q.mode == TQ_MODE_AND || q.mode == TQ_MODE_OR) && !q.boosts && q.n_terms >= 1 && q.terms) {
+      if (!fc.cache) fc = s->searcher->flat_context();
+      s->searcher->weight_flat_into(fc, q.mode, q.terms, q.n_terms, out[i]);
+    } else {
+      out[i] = s->searcher->weight(build_query(q));
+    }
+  }
+}
+int tqh_prepare_batch(tqh_searcher *s, const tqh_query *queries, uint32_t n) {
+  return guard([&] { prepare_into(s, queries, n, s->prepared); });
+}
+// The serving pattern's pipeline: Query::weight of batch i + 1 on one thread while another executes batch i
+// (Searcher::weight is thread-safe: concurrent Searcher::search calls do the same).  tqh_prepare_batch_next fills a
+// second slot and touches nothing the execution of the current batch reads; tqh_commit_next makes that slot the
+// current batch (call it from the executing thread, between two batches, after the preparing call has returned).
+int tqh_prepare_batch_next(tqh_searcher *s, const tqh_query *queries, uint32_t n) {
+  return guard([&] { prepare_into(s, queries, n, s->prepared_next); });
+}
+int tqh_commit_next(tqh_searcher *s) {
+  return guard([&] {
+    if (!s) throw TantivyError(TantivyError::InvalidArgument, "null searcher");
+    s->prepared.swap(s->prepared_next);
   });
 }
 

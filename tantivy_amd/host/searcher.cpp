@@ -140,25 +140,32 @@ Score Searcher::term_weight_cached(uint32_t term, uint64_t nd) const {
   return w;
 }
 
-Weight Searcher::weight_flat(uint8_t mode, const uint32_t *terms, uint32_t n_terms) const {
-  const uint64_t nd = total_num_docs(), nt = total_num_tokens();
-  if (nd == 0)
+Searcher::FlatContext Searcher::flat_context() const {
+  FlatContext fc;
+  fc.nd = total_num_docs();
+  const uint64_t nt = total_num_tokens();
+  if (fc.nd == 0)
     throw TantivyError(TantivyError::InvalidArgument, "no documents: BM25 statistics undefined");
+  std::lock_guard<std::mutex> lk(cache_m_);
+  if (!shared_cache_) {
+    const Score avg = (Score)nt / (Score)fc.nd;
+    shared_cache_ = std::make_shared<Bm25Weight>(Bm25Weight::from_idf(0.0f, avg));
+  }
+  fc.cache = shared_cache_;
+  return fc;
+}
+void Searcher::weight_flat_into(const FlatContext &fc, uint8_t mode, const uint32_t *terms, uint32_t n_terms, Weight &w) const {
   if (n_terms > TQ_MAX_TERMS)
     throw TantivyError(TantivyError::Unsupported, "more than 16 terms stay on the CPU");
-  Weight w;
-  {
-    std::lock_guard<std::mutex> lk(cache_m_);
-    if (!shared_cache_) {
-      const Score avg = (Score)nt / (Score)nd;
-      shared_cache_ = std::make_shared<Bm25Weight>(Bm25Weight::from_idf(0.0f, avg));
-    }
-    w.bm25 = shared_cache_;
-  }
+  w.bm25 = fc.cache;
   w.mode = n_terms == 1 ? (uint8_t)TQ_MODE_OR : mode;  // (a one-term query: TermWeight::for_each_pruning)
   w.terms.assign(terms, terms + n_terms);
   w.weights.resize(n_terms);
-  for (uint32_t i = 0; i < n_terms; ++i) w.weights[i] = term_weight_cached(terms[i], nd);
+  for (uint32_t i = 0; i < n_terms; ++i) w.weights[i] = term_weight_cached(terms[i], fc.nd);
+}
+Weight Searcher::weight_flat(uint8_t mode, const uint32_t *terms, uint32_t n_terms) const {
+  Weight w;
+  weight_flat_into(flat_context(), mode, terms, n_terms, w);
   return w;
 }
 uint64_t Searcher::total_num_docs() const {

@@ -170,10 +170,98 @@ using Fruit = std::vector<std::pair<Score, DocAddress>>;
 
 // Query -> per-index Weight: executor choice + global BM25 statistics (Query::weight,
 // src/query/query.rs:128-160; BooleanQuery::weight boolean_query.rs:157-169).
+// A vector that keeps up to N elements inside the object (a Weight's term ids and weights: two heap allocations per
+// query were most of Query::weight for a batch of 10 000 two-term queries, and made a second preparing thread six
+// times slower than one), heap storage beyond that.  Trivially copyable element types only.
+template <typename T, size_t N>
+class InlineVec {
+ public:
+  InlineVec() = default;
+  InlineVec(const InlineVec &o) { assign(o.begin(), o.end()); }
+  InlineVec(InlineVec &&o) noexcept { steal(o); }
+  InlineVec &operator=(const InlineVec &o) {
+    if (this != &o) assign(o.begin(), o.end());
+    return *this;
+  }
+  InlineVec &operator=(InlineVec &&o) noexcept {
+    if (this != &o) {
+      release();
+      steal(o);
+    }
+    return *this;
+  }
+  InlineVec &operator=(std::initializer_list<T> il) {
+    assign(il.begin(), il.end());
+    return *this;
+  }
+  ~InlineVec() { release(); }
+  size_t size() const { return n_; }
+  bool empty() const { return n_ == 0; }
+  T *data() { return heap_ ? heap_ : inl_; }
+  const T *data() const { return heap_ ? heap_ : inl_; }
+  T *begin() { return data(); }
+  T *end() { return data() + n_; }
+  const T *begin() const { return data(); }
+  const T *end() const { return data() + n_; }
+  T &operator[](size_t i) { return data()[i]; }
+  const T &operator[](size_t i) const { return data()[i]; }
+  void clear() { n_ = 0; }
+  void push_back(const T &v) {
+    grow(n_ + 1);
+    data()[n_++] = v;
+  }
+  void resize(size_t n, const T &fill = T()) {
+    grow(n);
+    for (size_t i = n_; i < n; ++i) data()[i] = fill;
+    n_ = n;
+  }
+  template <typename It>
+  void assign(It first, It last) {
+    const size_t n = (size_t)(last - first);
+    n_ = 0;
+    grow(n);
+    T *d = data();
+    for (size_t i = 0; i < n; ++i) d[i] = first[i];
+    n_ = n;
+  }
+
+ private:
+  void grow(size_t want) {
+    if (want <= cap_) return;
+    size_t cap = cap_ * 2;
+    if (cap < want) cap = want;
+    T *h = new T[cap];
+    const T *d = data();
+    for (size_t i = 0; i < n_; ++i) h[i] = d[i];
+    delete[] heap_;
+    heap_ = h;
+    cap_ = cap;
+  }
+  void release() {
+    delete[] heap_;
+    heap_ = nullptr;
+    cap_ = N;
+    n_ = 0;
+  }
+  void steal(InlineVec &o) {
+    n_ = o.n_;
+    cap_ = o.cap_;
+    heap_ = o.heap_;
+    if (!heap_)
+      for (size_t i = 0; i < n_; ++i) inl_[i] = o.inl_[i];
+    o.heap_ = nullptr;
+    o.cap_ = N;
+    o.n_ = 0;
+  }
+  T inl_[N];
+  T *heap_ = nullptr;
+  size_t n_ = 0, cap_ = N;
+};
+
 struct Weight {
   uint8_t mode = TQ_MODE_AND;
-  std::vector<uint32_t> terms;           // term ids in query order
-  std::vector<Score> weights;            // per term (AND/OR) or one (phrase)
+  InlineVec<uint32_t, 4> terms;          // term ids in query order
+  InlineVec<Score, 4> weights;           // per term (AND/OR) or one (phrase)
   std::vector<uint32_t> phrase_offsets;  // phrase
   std::vector<uint8_t> occurs;           // TQ_MODE_BOOL: enum tq_occur per term
   std::vector<uint8_t> clause_of;        // TQ_MODE_BOOL: clause index per term
@@ -210,6 +298,13 @@ class Searcher {
   // (TQ_MODE_OR) — the same arithmetic as weight() without building the Query tree; term weights are cached
   // per Searcher (idf is a log per term per query otherwise)
   Weight weight_flat(uint8_t mode, const uint32_t *terms, uint32_t n_terms) const;
+  // ... for a batch: the statistics and the field's tf cache are looked up once (FlatContext), not per query
+  struct FlatContext {
+    uint64_t nd = 0;
+    std::shared_ptr<Bm25Weight> cache;
+  };
+  FlatContext flat_context() const;
+  void weight_flat_into(const FlatContext &fc, uint8_t mode, const uint32_t *terms, uint32_t n_terms, Weight &w) const;
   // Searcher::search (searcher.rs:180-238) for one query / a batch of queries.  search() may be
   // called from any number of threads at once, like the reference's: the per-segment
   // collect_segment calls of concurrent searches are coalesced into batched launches (tq_search_one)
