@@ -70,7 +70,9 @@ def parse_args(argv=None):
     ap.add_argument("--pruned", action="store_true", help="(default; kept for old command lines)")
     ap.add_argument("--no-side", action="store_true",
                     help="only the main workload (profiling runs): skip other_workloads and strong_scaling")
-    ap.add_argument("--side-steps", type=int, default=10)
+    ap.add_argument("--side-steps", type=int, default=20,
+                    help="timed steps of every side workload (pipelined like the main loop: with 10 steps the fill and the drain of the "
+                         "pipeline were a fifth of the time)")
     ap.add_argument("--selftest-launcher", action="store_true",
                     help="CPU plumbing check of the rank launcher (gloo, no GPU work, no timing)")
     ap.add_argument("--no-pmc-inline", action="store_true",
@@ -948,7 +950,7 @@ def main():
             qs, kk = build_queries(O, wl, DEFAULT_QUERIES[wl], None)
             if os.environ.get("BENCH_SIDE_SLEEP"):  # experiment: let the GPU idle before a side workload
                 time.sleep(float(os.environ["BENCH_SIDE_SLEEP"]))
-            sm = measure(cl, s_runner, torch, qs, kk, args.side_steps, 2)
+            sm = measure(cl, s_runner, torch, qs, kk, args.side_steps, 3)
             if not sm["mode_parity"]:
                 raise SystemExit("%s: pruned and exhaustive results differ on %d queries" % (wl, sm["n_diff"]))
             s_kern = query_kernels(s_runner, len(qs))
@@ -1008,7 +1010,7 @@ def main():
         srun.comm, srun.torch_group = cl.comm, cl.torch_group
         srun.set_option("timing", 1)
         qs, kk = build_queries(O, "mixed", DEFAULT_QUERIES["mixed"], None)
-        strong_steps = max(3, args.side_steps // 2)
+        strong_steps = max(3, args.side_steps // 4)
         sm = measure(cl, srun, torch, qs, kk, strong_steps, 1)
         if not sm["mode_parity"]:
             raise SystemExit("strong: pruned and exhaustive results differ on %d queries" % sm["n_diff"])
