@@ -239,3 +239,57 @@ def test_phrase_in_boolean_errors(ta, pseg):
             dev.search([five], 10)
     finally:
         dev.close()
+
+
+def test_phrases_with_absent_terms(ta):
+    """a phrase naming a term the segment does not hold is an EmptyScorer (Must: nothing matches; Should / MustNot: the
+    clause is dropped), also one level down (boolean_weight.rs:255-257, 340-349)"""
+    rng = np.random.default_rng(13)
+
+    def docs_of(n, seed):
+        r = np.random.default_rng(seed)
+        out = []
+        for _ in range(n):
+            toks = r.integers(0, 5, size=int(r.integers(3, 25))).tolist()  # terms t0..t4; t5 never occurs
+            out.append(" ".join("t%d" % t for t in toks) + " t6")
+        return out
+
+    from tests.helpers import corpus_segment
+
+    seg, vocab = corpus_segment(docs_of(5000, 1), with_positions=True)
+    ids = [vocab["t%d" % i] for i in range(5)]
+    absent = len(vocab) + 3  # a term id the segment has no TermInfo for
+    a, b, c, d = ids[0], ids[1], ids[2], ids[3]
+    specs = [
+        ([(M, ("ph", [a, absent])), (M, c)], 0),             # +"a ?" +c: nothing
+        ([(S, ("ph", [a, absent])), (S, c)], 0),             # "a ?" c: c alone
+        ([(M, c), (N, ("ph", [absent, b]))], 0),             # +c -"? b": c
+        ([(M, a), (M, [(S, ("ph", [b, absent])), (S, d)], 0)], 0),  # +a +("b ?" d)
+        ([(M, ("ph", [a, b])), (S, absent)], 0),             # +"a b" ?: the optional term is dropped
+    ]
+    dev = ta.DeviceIndex([seg])
+    try:
+        queries = [to_device(ta, sp, msm) for sp, msm in specs]
+        sc, _, dc, ct = dev.search(queries, 10)
+        assert int(ct[0]) == 0
+        for i, (sp, msm) in enumerate(specs[1:], start=1):
+            # the oracle's view of an absent term: drop it the way complex_scorer drops an EmptyScorer
+            def strip(cl):
+                if isinstance(cl, tuple) and len(cl) >= 2 and cl[0] == "ph":
+                    return None if absent in cl[1] else cl
+                return None if cl == absent else cl
+            tree = []
+            for cl in sp:
+                if isinstance(cl[1], list):
+                    members = [(o, strip(m)) for o, m in cl[1]]
+                    members = [(o, m) for o, m in members if m is not None]
+                    tree.append((cl[0], members, cl[2]))
+                elif strip(cl[1]) is not None:
+                    tree.append(cl)
+            want = O.tree_search(seg, tree, 10, msm)
+            got = [(float(sc[i, j]), int(dc[i, j])) for j in range(int(ct[i]))]
+            assert sorted(x[1] for x in got) == sorted(x[1] for x in want), (sp, got, want)
+            for (gs, _), (ws, _) in zip(sorted(got, key=lambda x: x[1]), sorted(want, key=lambda x: x[1])):
+                assert rel_close(gs, ws, 1e-5), (sp, got, want)
+    finally:
+        dev.close()
