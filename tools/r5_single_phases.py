@@ -18,8 +18,9 @@ qs = [(O.MODE_AND, q.tolist()) for q in ids]
 dev.set_option("exhaustive", 0)
 dev.set_option("timing", 1)
 dev.search(qs, 10)
-for qi in (0, 1, 2, 3, 5, 8):
-    q = qs[qi:qi + 1]
+B = int(os.environ.get("BATCH", "1"))
+for qi in ((0, 1, 2, 3, 5, 8) if B == 1 else (0, 16, 32)):
+    q = qs[qi:qi + B]
     dfs = sorted(seg.terms[t].doc_freq for t in q[0][1])
     dev.prepare(q)
     row = []
@@ -34,6 +35,6 @@ for qi in (0, 1, 2, 3, 5, 8):
         row.append("%s=%d" % ("wall_us" if ph == 0 else "r%d" % ph, sorted(t)[6] * 1e6 if ph == 0 else st["matches"]))
         if ph == 0:
             row.append("kernel_us=%d tiles=%d" % (st["kernel_ms"] * 1e3, st.get("tiles", 0)))
-    print("query %s leader %d blocks, other df %d: %s" % (q[0][1], (dfs[0] + 127) // 128, dfs[1], " ".join(row)), flush=True)
+    print("%d quer%s from %s leader %d blocks, other df %d: %s kernels %s" % (B, "y" if B == 1 else "ies", q[0][1], (dfs[0] + 127) // 128, dfs[1], " ".join(row), "+".join(st["kernels"])), flush=True)
 dev.set_option("debug", 0)
 dev.close()
