@@ -7,6 +7,9 @@ through the C ABI's tq_allgather_topk; gloo on CPU in the tests) before `merge_t
 statistics are sums of per-segment counters known to the host before dispatch (bm25.rs:27-50).
 """
 import ctypes as C
+import os
+import sys
+import time
 
 import numpy as np
 
@@ -152,6 +155,7 @@ class ShardRunner:
         # milliseconds when the runtime grew its pools)
         self._ev_ring = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(16)]
         self._ev_at = 0
+        self._trace = bool(os.environ.get("TQ_RUNNER_TRACE"))
         self.n = self.k = 0
         self._ex_events = []  # (start, end) torch events around exchange + merge, last 16 steps
         self._agree("local segments per rank", self.n_local)
@@ -224,8 +228,14 @@ class ShardRunner:
             return (buf[0:n * k].view(torch.float32).view(n, k), buf[n * k:2 * n * k].view(n, k),
                     buf[2 * n * k:3 * n * k].view(n, k), buf[3 * n * k:3 * n * k + n])
 
-        self.merged = views(self._merged_all)
+        # merge_top_k writes its rows STRAIGHT into the pinned host buffer (hipHostMalloc memory is mapped into the
+        # device's address space): no device-to-host copy operation at all.  An asynchronous copy — torch's copy_, then
+        # hipMemcpyAsync through the C ABI — blocked the calling thread for 7 ms now and then (one to three of ten
+        # 20-step runs lost a third of their time to ONE such call; tools/r5_hiccup.sh, TQ_RUNNER_TRACE=1).
+        # TQ_RUNNER_D2H_COPY=1: merge into device memory, then tq_copy_to_host_async.
+        self._zero_copy = os.environ.get("TQ_RUNNER_D2H_COPY", "0") != "1"
         self.host = list(views(self._host_all))
+        self.merged = tuple(self.host) if self._zero_copy else views(self._merged_all)
 
     def prepare_next(self, queries, k, marshalled):
         """Query::weight of the NEXT batch on a helper thread while this thread enqueues the current one (same number
@@ -241,25 +251,39 @@ class ShardRunner:
         torch = self.torch
         n, k, S, W = self.n, self.k, self.n_local, self.world
         sc, dc, ct = self.local
+        tr = self._trace  # (TQ_RUNNER_TRACE=1: host time of every part of a step that took more than 3 ms)
+        t0 = time.perf_counter() if tr else 0.0
         with torch.cuda.stream(self.stream_obj):
+            t0b = time.perf_counter() if tr else 0.0
             for s in range(S):
                 self.dev.collect_segment_prepared_device(
                     s, k, sc[s * n:(s + 1) * n], dc[s * n:(s + 1) * n], ct[s * n:(s + 1) * n],
                     self.stream)
+            t1 = time.perf_counter() if tr else 0.0
             ev = self._ev_ring[self._ev_at % 16]
             self._ev_at += 1
             ev[0].record(self.stream_obj)
+            t2 = time.perf_counter() if tr else 0.0
             g = exchange_topk((sc, dc, ct), n, k, S, W, self.comm, self.torch_group,
                               getattr(self, "gathered", None), self.stream, self.force_exchange)
             merge_gathered_device(self.dev.ctx, self.device, g[0], g[1], g[2], 0, k, self.stream,
                                   out=self.merged)
+            t3 = time.perf_counter() if tr else 0.0
             ev[1].record(self.stream_obj)
             self._ex_events = [e for e in self._ex_events if e is not ev][-15:] + [ev]
+            t4 = time.perf_counter() if tr else 0.0
             # (not torch's copy_: its pinned-memory bookkeeping now and then took 7 ms on the host inside a pipelined
             # loop — three of ten 20-step runs lost a third of their time to one such call)
-            B._check(B.lib().tq_copy_to_host_async(
-                self.dev.ctx, int(self.device), self._host_all.data_ptr(), self._merged_all.data_ptr(),
-                self._merged_all.numel() * 4, C.c_void_p(self.stream)))
+            if not self._zero_copy:
+                B._check(B.lib().tq_copy_to_host_async(
+                    self.dev.ctx, int(self.device), self._host_all.data_ptr(), self._merged_all.data_ptr(),
+                    self._merged_all.numel() * 4, C.c_void_p(self.stream)))
+            t5 = time.perf_counter() if tr else 0.0
+        if tr and time.perf_counter() - t0 > 0.003:
+            t6 = time.perf_counter()
+            print("[runner] enter-stream %.2f collect %.2f ev0 %.2f exchange+merge %.2f ev1 %.2f copy %.2f exit-stream %.2f ms" %
+                  tuple((b - a) * 1e3 for a, b in ((t0, t0b), (t0b, t1), (t1, t2), (t2, t3), (t3, t4), (t4, t5), (t5, t6))),
+                  file=sys.stderr)
 
     def synchronize(self):
         self.stream_obj.synchronize()
