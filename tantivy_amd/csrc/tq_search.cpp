@@ -1255,6 +1255,26 @@ int search_batch_host(tq_segment *s, const tq_query *queries, uint32_t n_queries
   if (n_queries == 0) return TQ_OK;
   HIP_TRY(hipSetDevice(s->device));
   const size_t n = (size_t)n_queries * out_stride;
+  // The merge kernels write the rows STRAIGHT into pinned host memory (hipHostMalloc memory is mapped into the
+  // device's address space): scores | docs | counts in one buffer, no device-to-host copy operations — three copies into
+  // the caller's pageable arrays were three staged, blocking operations (and an asynchronous copy into pinned memory
+  // now and then held the calling thread for 7 ms, tantivy_amd/distributed.py).  TQ_HOST_OUT_COPY=1: the copies.
+  static const bool kCopyOut = tune_u32("TQ_HOST_OUT_COPY", 0) != 0;
+  if (!kCopyOut) {
+    const size_t o_docs = (n * sizeof(float) + 255) & ~(size_t)255;
+    const size_t o_counts = (o_docs + n * sizeof(uint32_t) + 255) & ~(size_t)255;
+    int rc = s->h_out.ensure(o_counts + (size_t)n_queries * sizeof(uint32_t));
+    if (rc != TQ_OK) return rc;
+    uint8_t *h = (uint8_t *)s->h_out.p;
+    rc = search_batch_impl(s, queries, n_queries, out_stride, (float *)h, (uint32_t *)(h + o_docs),
+                           (uint32_t *)(h + o_counts), nullptr, co);
+    if (rc != TQ_OK) return rc;
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    memcpy(out_scores, h, n * sizeof(float));
+    memcpy(out_docs, h + o_docs, n * sizeof(uint32_t));
+    memcpy(out_counts, h + o_counts, (size_t)n_queries * sizeof(uint32_t));
+    return TQ_OK;
+  }
   int rc = s->d_out_scores.ensure(n * sizeof(float));
   if (rc == TQ_OK) rc = s->d_out_docs.ensure(n * sizeof(uint32_t));
   if (rc == TQ_OK) rc = s->d_out_counts.ensure((size_t)n_queries * sizeof(uint32_t));
