@@ -450,10 +450,10 @@ int tq_segment_get_stats(tq_segment *seg, tq_segment_stats *out);
  *        expression over bitmap words (4-8 bytes per list per 32 docs, no postings decoded; a list
  *        without a bitmap is scattered into a scratch bitmap once per batch) when the clause a scan
  *        would walk holds at least max_doc / ratio postings per list of the query,
- *        "ashare_min_batch" (default 1024): intersections take the shared leader-major launch
+ *        "ashare_min_batch" (default 512): intersections take the shared leader-major launch
  *        (TQ_KERNEL_ASHARE) when at least this many queries of the batch qualify for it — below, its
  *        two launches and per-task set-up cost more than sharing the leader blocks saves (256 queries:
- *        0.91 ms against 0.75 ms per-query; 4096: 2.2 against 3.8),
+ *        0.82 ms against 0.77 ms per-query; 1 024: 1.17 against 1.39; 4 096: 1.72 against 3.8),
  *        "submit_window_us" (default 100): tq_submit / tq_search_one — how long the leader of a batch
  *        holds it open for the callers of the previous batch to come back with their next query
  *        (0 = launch with whatever is pending),

@@ -149,7 +149,10 @@ int search_batch_impl(tq_segment *s, const tq_query *queries, uint32_t n_queries
   // segment with a doc matrix, whose leader (rarest list) leads at least kAShareMin such queries of the
   // batch: the shared-intersection launch (leader-major, tq_ashare.hip).  TQ_ASHARE=0: the per-query kernel
   static const bool kUseAShare = tune_u32("TQ_ASHARE", 1) != 0;
-  static const uint32_t kAShareMin = std::max<uint32_t>(1u, tune_u32("TQ_AS_MIN_LEADS", 4));
+  // (round 4 asked for 4 queries per leader: the others ran on the per-query kernel NEXT to the shared launch, and two
+  // kernel families sharing the chip cost more than lone leads in the shared launch do — 1 024 queries 1.39 -> 1.17 ms,
+  // 2 048 1.63 -> 1.40, 4 096 1.95 -> 1.72, the mixed stream 7.6 -> 7.3 ms per batch with every qualifying query in it)
+  static const uint32_t kAShareMin = std::max<uint32_t>(1u, tune_u32("TQ_AS_MIN_LEADS", 1));
   // phrases whose lists ALL have a bitmap, byte-wide tfs and a position directory, the rarest one
   // still about a posting per bitmap word: the bitmap-AND sweep (phrase_sweep_kernel)
   static const uint32_t kPhSweepRatio = tune_u32("TQ_PH_SWEEP_RATIO", 64);  // 0 = never

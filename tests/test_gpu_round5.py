@@ -97,15 +97,16 @@ def _check_batch(ta, dev, seg, queries, k, per_family, want_mask, forbid_mask=0,
 def test_full_size_large_vocabulary_intersections(ta, big_vocab):
     """10M docs, 4 096 / 65 536 terms, 4 000 Zipf 2-term ANDs: a fifth to a third of them probe a list below
     dense_ratio — those lists get probe tables on first use and the queries ride in the shared launch
-    (TQ_AS_PROBE), the rest of the batch on and_dense / and."""
+    (TQ_AS_PROBE), what the probe-table budget does not reach on and_dense / and."""
     vocab, seg = big_vocab
     queries = [(O.MODE_AND, t.tolist()) for t in O.zipf_queries(4000, 2, vocab, seed=501)]
     dev = ta.DeviceIndex([seg])
     try:
-        dev.set_option("ashare_min_batch", 256)  # (4 000 queries over 65 536 terms: fewer than 1 024 share a leader with three others)
-        st, kern, n = _check_batch(ta, dev, seg, queries, 10, 24, ta.binding.KERNEL_ASHARE)
+        st, kern, n = _check_batch(ta, dev, seg, queries, 10, 40, ta.binding.KERNEL_ASHARE)
         fams = {ta.binding.KERNEL_NAMES[int(f)] for f in set(kern.tolist())}
-        assert "ashare" in fams and len(fams) >= 2, fams  # the shared launch and at least one per-query family
+        # the shared launch takes every query whose probed list has (or gets) a bitmap — lone leaders included since
+        # TQ_AS_MIN_LEADS = 1 —, a per-query family whatever the probe-table budget did not reach
+        assert "ashare" in fams, fams
         # probe tables were built (bitmap bytes beyond the segment's own dense lists' 2.5 MB each)
         sst = dev.segment_stats(0)
         assert sst["bitmap_bytes"] > sst["n_dense_lists"] * 2_600_000, sst
@@ -139,10 +140,9 @@ def test_full_size_large_vocabulary_mixed_stream(ta, big_vocab):
         queries.append((O.MODE_AND, a[i // 2].tolist()) if i % 2 == 0 else (O.MODE_OR, o[i // 2].tolist()))
     dev = ta.DeviceIndex([seg])
     try:
-        dev.set_option("ashare_min_batch", 200)  # (1 500 intersections over 4 096+ terms: fewer than the default 1 024 share a leader with three others)
-        # (at 65 536 terms 1 500 intersections hold too few that share a leader: they keep and_dense / and)
-        want = ta.binding.KERNEL_USHARE | (ta.binding.KERNEL_ASHARE if vocab == 4096 else 0)
-        _check_batch(ta, dev, seg, queries, 10, 12, want, exact2=True)
+        dev.set_option("ashare_min_batch", 200)
+        want = ta.binding.KERNEL_USHARE | ta.binding.KERNEL_ASHARE  # (lone leaders ride in the shared launch too: TQ_AS_MIN_LEADS = 1)
+        _check_batch(ta, dev, seg, queries, 10, 20, want, exact2=True)
     finally:
         dev.close()
 
