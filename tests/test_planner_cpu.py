@@ -77,7 +77,7 @@ def test_ashare_plan_invariants(plan_check, seed):
     leader's blocks once, doc-slice launch order, disjoint result lists — also with small groups,
     long tasks and a result-list budget that forces longer tasks."""
     for env_extra in ({}, {"TQ_AS_GROUP": "5", "TQ_AS_TASK_PAIRS": "64"}, {"TQ_AS_TASK_BLOCKS": "7"},
-                      {"TQ_AS_LIST_MB": "1"}):
+                      {"TQ_AS_LIST_MB": "1"}, {"TQ_AS_DEDUPE": "0"}):  # (0: the comparison sort, identical queries as twins)
         r = subprocess.run([plan_check, str(seed), "ashare"], env=dict(os.environ, **env_extra),
                            capture_output=True, text=True, timeout=300)
         assert r.returncode == 0, r.stderr + r.stdout
@@ -91,7 +91,8 @@ def test_boolean_share_plan_invariants(plan_check, seed):
     pair — and the filter stage is SAFE: over random doc-matrix words (exact columns, signature bits with
     false positives) no lead's masks drop a doc the query matches, no doc's bound is below what it can
     score, no list holding the doc is marked never-probed."""
-    for env_extra in ({}, {"TQ_AS_GROUP": "3", "TQ_BS_TASK_PAIRS": "32"}, {"TQ_AS_LIST_MB": "1"}, {"TQ_AS_TASK_BLOCKS": "3"}):
+    for env_extra in ({}, {"TQ_AS_GROUP": "3", "TQ_BS_TASK_PAIRS": "32"}, {"TQ_AS_LIST_MB": "1"}, {"TQ_AS_TASK_BLOCKS": "3"},
+                      {"TQ_AS_DEDUPE": "0"}):
         r = subprocess.run([plan_check, str(seed), "bshare"], env=dict(os.environ, **env_extra),
                            capture_output=True, text=True, timeout=300)
         assert r.returncode == 0, r.stderr + r.stdout

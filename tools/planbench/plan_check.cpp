@@ -285,7 +285,8 @@ static int check_ashare(int seed) {
     if (o > q || o >= nq) return fail_msg("list owner out of range", q, o);
     if (o == q) {
       ++n_heads;
-      for (uint32_t e = 0; e < q; ++e)
+      const bool dedupe = !getenv("TQ_AS_DEDUPE") || atoi(getenv("TQ_AS_DEDUPE")) != 0;  // (0: every query keeps its own lead)
+      for (uint32_t e = 0; dedupe && e < q; ++e)
         if (g.queries[e].chunk_first == e && identical(g.queries[e], g.queries[q])) return fail_msg("an identical query before this one was not made its owner", q, e);
       continue;
     }
