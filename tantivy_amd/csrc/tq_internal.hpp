@@ -686,5 +686,18 @@ int search_batch_impl(tq_segment *s, const tq_query *queries, uint32_t n_queries
                       const CallOpts &co);
 int search_batch_host(tq_segment *s, const tq_query *queries, uint32_t n_queries, uint32_t out_stride,
                       float *out_scores, uint32_t *out_docs, uint32_t *out_counts, const CallOpts &co);
+// The same in two halves (the submit queue: the next coalesced batch is planned and enqueued while this one runs):
+// _begin plans and enqueues the batch on the segment's stream (caller holds the segment lock) — the merge kernels write
+// scores | docs | counts into the slot's pinned host buffer — and records the slot's event; _end waits for that event
+// (no lock needed) and leaves the rows readable at out.p, out.p + o_docs, out.p + o_counts.
+struct HostBatchSlot {
+  PinnedBuf out;
+  hipEvent_t done = nullptr;
+  size_t o_docs = 0, o_counts = 0;
+  uint32_t n = 0, stride = 0;
+};
+int search_batch_host_begin(tq_segment *s, const tq_query *queries, uint32_t n_queries, uint32_t out_stride,
+                            const CallOpts &co, HostBatchSlot &slot);
+int search_batch_host_end(tq_segment *s, HostBatchSlot &slot);
 
 }  // namespace tqi

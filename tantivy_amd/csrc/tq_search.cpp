@@ -1294,6 +1294,30 @@ int search_batch_host(tq_segment *s, const tq_query *queries, uint32_t n_queries
   HIP_TRY(hipStreamSynchronize(s->stream));
   return TQ_OK;
 }
+int search_batch_host_begin(tq_segment *s, const tq_query *queries, uint32_t n_queries, uint32_t out_stride,
+                            const CallOpts &co, HostBatchSlot &slot) {
+  if (!s || !n_queries) return fail(TQ_ERR_INVALID, "tq_submit: empty batch");
+  HIP_TRY(hipSetDevice(s->device));
+  const size_t n = (size_t)n_queries * out_stride;
+  slot.o_docs = (n * sizeof(float) + 255) & ~(size_t)255;
+  slot.o_counts = (slot.o_docs + n * sizeof(uint32_t) + 255) & ~(size_t)255;
+  slot.n = n_queries;
+  slot.stride = out_stride;
+  int rc = slot.out.ensure(slot.o_counts + (size_t)n_queries * sizeof(uint32_t));
+  if (rc != TQ_OK) return rc;
+  if (!slot.done) HIP_TRY(hipEventCreateWithFlags(&slot.done, hipEventDisableTiming));
+  uint8_t *h = (uint8_t *)slot.out.p;
+  rc = search_batch_impl(s, queries, n_queries, out_stride, (float *)h, (uint32_t *)(h + slot.o_docs),
+                         (uint32_t *)(h + slot.o_counts), nullptr, co);
+  if (rc != TQ_OK) return rc;
+  HIP_TRY(hipEventRecord(slot.done, s->stream));
+  return TQ_OK;
+}
+int search_batch_host_end(tq_segment *s, HostBatchSlot &slot) {
+  (void)s;
+  HIP_TRY(hipEventSynchronize(slot.done));
+  return TQ_OK;
+}
 }  // namespace tqi
 
 extern "C" {

@@ -35,10 +35,18 @@ struct SubmitQueue {
   bool leader_active = false;
   size_t last_batch = 0;  // queries the previous batch carried
   tq_submit_stats stats{};
-  // the leader's scratch
+  // the leader's scratch (the synchronous road: a batch that has to be bisected)
   std::vector<tq_query> qs;
   std::vector<float> sc;
   std::vector<uint32_t> dc, ct;
+  // Two coalesced batches can be in flight: the leader of batch i hands leadership on as soon as the batch is
+  // ENQUEUED, waits for its rows off the lock, and the next leader plans and enqueues batch i + 1 behind it on the
+  // segment's stream meanwhile (the library pipelines two batches: two staging buffers).
+  static constexpr int kSlots = 2;
+  tqi::HostBatchSlot slot[kSlots];
+  std::vector<tq_query> slot_qs[kSlots];
+  bool slot_busy[kSlots] = {false, false};
+  std::condition_variable cv_slot;
 };
 void tq_free_submit_queue(SubmitQueue *q) { delete q; }
 SubmitQueue *tq_new_submit_queue() { return new (std::nothrow) SubmitQueue(); }
@@ -165,31 +173,109 @@ int ticket_wait(tq_ticket *t) {
         ++it;
       }
     }
-    lk.unlock();
-    run_ticket_batch(Q, s, batch);
-    lk.lock();
-    ++Q.stats.batches;
-    Q.stats.queries += batch.size();
-    Q.stats.max_batch = std::max<uint64_t>(Q.stats.max_batch, batch.size());
-    for (tq_ticket *b : batch) {
-      b->done = true;
-      if (b != t) b->cv.notify_one();
-    }
     Q.last_batch = batch.size();
-    Q.leader_active = false;
-    // two blocked callers whose queries are still open are woken, the first to take the mutex leads the next batch
-    // (callers that are not blocked yet lead themselves when they arrive and find nobody leading).  1 024 threads:
-    // 35 k q/s at p99 94 ms with notify_all on one shared variable, 56-85 k at p99 25-80 ms with 1 / 2 / 4 / 64 woken;
-    // 16 and 64 threads do not care
-    if (!t->done || !Q.pending.empty()) {
+    // wake-ups (under the lock): two blocked callers whose queries are still open, the first to take the mutex leads
+    // the next batch (callers that are not blocked yet lead themselves when they arrive and find nobody leading).
+    // 1 024 threads: 35 k q/s at p99 94 ms with notify_all on one shared variable, 56-85 k at p99 25-80 ms with
+    // 1 / 2 / 4 / 64 woken; 16 and 64 threads do not care
+    auto wake_a_leader = [&]() {
       static const uint32_t kWake = std::max<uint32_t>(1u, tune_u32("TQ_SUBMIT_WAKE", 2));
+      if (Q.pending.empty()) return;
       uint32_t woken = 0;
       for (tq_ticket *w : Q.waiting)
         if (!w->done && w != t) {
           w->cv.notify_one();
           if (++woken == kWake) break;
         }
+    };
+    auto finish = [&]() {  // (under the lock) the batch's verdicts are in: its callers go home
+      ++Q.stats.batches;
+      Q.stats.queries += batch.size();
+      Q.stats.max_batch = std::max<uint64_t>(Q.stats.max_batch, batch.size());
+      for (tq_ticket *b : batch) {
+        b->done = true;
+        if (b != t) b->cv.notify_one();
+      }
+    };
+    static const bool kOverlap = tune_u32("TQ_SUBMIT_OVERLAP", 1) != 0;
+    int si = -1;
+    if (kOverlap) {
+      while (Q.slot_busy[0] && Q.slot_busy[1]) Q.cv_slot.wait(lk);
+      si = Q.slot_busy[0] ? 1 : 0;
+      Q.slot_busy[si] = true;
     }
+    lk.unlock();
+    bool enqueued = false;
+    if (si >= 0) {  // plan + enqueue under the segment lock, then let the next leader in
+      int brc = TQ_ERR_HIP;
+      for (tq_ticket *b : batch) b->rc = TQ_ERR_HIP;
+      try {
+        std::vector<tq_query> &qs = Q.slot_qs[si];
+        qs.resize(batch.size());
+        uint32_t stride = 1;
+        for (size_t i = 0; i < batch.size(); ++i) {
+          qs[i] = batch[i]->q;
+          stride = std::max(stride, batch[i]->q.k);
+        }
+        TQ_SEGMENT_LOCK(s);
+        brc = search_batch_host_begin(s, qs.data(), (uint32_t)qs.size(), stride, co, Q.slot[si]);
+      } catch (...) {
+        brc = TQ_ERR_HIP;
+      }
+      enqueued = brc == TQ_OK;
+    }
+    if (enqueued) {
+      // The batch is on the stream.  If a batch's worth of queries is already waiting (hundreds of callers), the next
+      // leader may form and enqueue it behind this one right away; with few callers the ones that matter are IN this
+      // batch, and a leader let in now would launch the handful left over (16 threads: 6 queries per launch instead
+      // of 14, 21 k instead of 28 k q/s) — leadership is then handed on when the rows are back, as before.
+      // (256 threads: 113 k q/s one batch at a time, 139 k handing over always, 122 / 132 / 130 k with a threshold of
+      // a half / a quarter / a sixteenth of the batch, at least 32; 64 threads 68 / 58 / 72 / 73 / 67 k)
+      static const size_t kOverlapMin = std::max<uint32_t>(1u, tune_u32("TQ_SUBMIT_OVERLAP_MIN", 32));
+      lk.lock();
+      static const size_t kOverlapDiv = std::max<uint32_t>(1u, tune_u32("TQ_SUBMIT_OVERLAP_DIV", 4));
+      const bool handed_over = Q.pending.size() >= std::max(kOverlapMin, batch.size() / kOverlapDiv);
+      if (handed_over) {
+        Q.leader_active = false;
+        wake_a_leader();
+      }
+      lk.unlock();
+      tqi::HostBatchSlot &S = Q.slot[si];
+      const int erc = search_batch_host_end(s, S);
+      const std::string err = erc == TQ_OK ? std::string() : g_last_error;
+      for (size_t i = 0; i < batch.size(); ++i) {
+        tq_ticket *b = batch[i];
+        if (erc == TQ_OK) {
+          const uint8_t *h = (const uint8_t *)S.out.p;
+          const uint32_t k = b->q.k;
+          memcpy(b->out_scores, h + ((size_t)i * S.stride) * sizeof(float), k * sizeof(float));
+          memcpy(b->out_docs, h + S.o_docs + ((size_t)i * S.stride) * sizeof(uint32_t), k * sizeof(uint32_t));
+          *b->out_count = ((const uint32_t *)(h + S.o_counts))[i];
+          b->rc = TQ_OK;
+        } else {
+          b->rc = erc;
+          b->err = err;
+        }
+      }
+      lk.lock();
+      Q.slot_busy[si] = false;
+      Q.cv_slot.notify_one();
+      finish();
+      if (!handed_over) Q.leader_active = false;
+      if (!Q.leader_active) wake_a_leader();  // (whoever was woken at hand-over may have been in this batch)
+      continue;
+    }
+    // the synchronous road: no slot (TQ_SUBMIT_OVERLAP=0), or the batch could not be enqueued — a query the device
+    // refuses, a bad argument: the batch is bisected, every caller gets its own verdict (this leader stays the leader)
+    run_ticket_batch(Q, s, batch);
+    lk.lock();
+    if (si >= 0) {
+      Q.slot_busy[si] = false;
+      Q.cv_slot.notify_one();
+    }
+    finish();
+    Q.leader_active = false;
+    wake_a_leader();
   }
   leave_waiting();
   const int rc = t->rc;

@@ -3,7 +3,8 @@ translation unit built with -fsanitize=thread around a stand-in for search_batch
 short sleep for the launch, TQ_ERR_UNSUPPORTED for a batch that holds a marked query), 64 threads x 250 single-query
 calls.  Checks: every caller gets ITS rows, a refused query fails alone (the batch is bisected), calls are coalesced,
 nothing deadlocks, ThreadSanitizer reports no race — the per-ticket wake-ups of round 5 (a finished batch wakes its
-callers and two candidates to lead the next one)."""
+callers and two candidates to lead the next one) and the hand-over of leadership once a batch is enqueued (two coalesced
+batches in flight: search_batch_host_begin / _end)."""
 import os
 import subprocess
 
@@ -37,10 +38,47 @@ int fake_search_batch_host(tq_segment *, const tq_query *queries, uint32_t n, ui
   g_queries += n;
   return TQ_OK;
 }
+// the two halves of the pipelined road: _begin "enqueues" (rows computed into the slot's buffer, plain memory here),
+// _end is the wait for the device
+int fake_begin(tq_segment *s, const tq_query *queries, uint32_t n, uint32_t stride, const CallOpts &co, HostBatchSlot &slot) {
+  const size_t cells = (size_t)n * stride;
+  slot.o_docs = (cells * sizeof(float) + 255) & ~(size_t)255;
+  slot.o_counts = (slot.o_docs + cells * sizeof(uint32_t) + 255) & ~(size_t)255;
+  slot.n = n;
+  slot.stride = stride;
+  const size_t need = slot.o_counts + (size_t)n * sizeof(uint32_t);
+  if (slot.out.cap < need) {
+    slot.out.p = realloc(slot.out.p, need);
+    slot.out.cap = need;
+  }
+  uint8_t *h = (uint8_t *)slot.out.p;
+  for (uint32_t i = 0; i < n; ++i)
+    if (queries[i].terms[0] % 97u == 0u) return fail(TQ_ERR_UNSUPPORTED, "query %u refused", i);
+  for (uint32_t i = 0; i < n; ++i) {
+    for (uint32_t j = 0; j < queries[i].k; ++j) {
+      ((float *)h)[(size_t)i * stride + j] = (float)(queries[i].terms[0] % 1000u) + (float)j;
+      ((uint32_t *)(h + slot.o_docs))[(size_t)i * stride + j] = queries[i].terms[0] * 16u + j;
+    }
+    ((uint32_t *)(h + slot.o_counts))[i] = queries[i].k;
+  }
+  (void)s;
+  (void)co;
+  ++g_launches;
+  g_queries += n;
+  return TQ_OK;
+}
+int fake_end(tq_segment *, HostBatchSlot &) {
+  std::this_thread::sleep_for(std::chrono::microseconds(60));
+  return TQ_OK;
+}
 }  // namespace tqi
 #define search_batch_host fake_search_batch_host
+#define search_batch_host_begin fake_begin
+#define search_batch_host_end fake_end
 #include "tq_submit.cpp"
 #undef search_batch_host
+#undef search_batch_host_begin
+#undef search_batch_host_end
 
 int main(int argc, char **argv) {
   const int T = argc > 1 ? atoi(argv[1]) : 64, N = argc > 2 ? atoi(argv[2]) : 250;
@@ -126,8 +164,10 @@ def test_submit_queue_stress(tmp_path_factory, sanitize):
     if r.returncode != 0 and sanitize == "thread":
         pytest.skip("ThreadSanitizer runtime not linkable here: " + r.stderr[-300:])
     assert r.returncode == 0, r.stderr[-3000:]
-    for args in (["64", "250", "100"], ["16", "400", "0"], ["200", "60", "30"]):
-        r = subprocess.run([exe] + args, capture_output=True, text=True, timeout=600)  # (a deadlock is a timeout)
+    for args, env_extra in ((["64", "250", "100"], {}), (["16", "400", "0"], {}), (["200", "60", "30"], {}),
+                            (["64", "120", "100"], {"TQ_SUBMIT_OVERLAP": "0"})):  # (0: one batch at a time, the synchronous road)
+        r = subprocess.run([exe] + args, env=dict(os.environ, **env_extra), capture_output=True, text=True,
+                           timeout=600)  # (a deadlock is a timeout)
         out = r.stdout + r.stderr
         assert r.returncode == 0, out[-3000:]
         assert "ThreadSanitizer" not in out, out[-3000:]
