@@ -48,7 +48,15 @@ struct SubmitQueue {
   bool slot_busy[kSlots] = {false, false};
   std::condition_variable cv_slot;
 };
-void tq_free_submit_queue(SubmitQueue *q) { delete q; }
+void tq_free_submit_queue(SubmitQueue *q) {
+  if (!q) return;
+  for (tqi::HostBatchSlot &sl : q->slot) {  // (the segment is idle: tq_segment_free has drained its streams)
+    if (sl.done) (void)hipEventDestroy(sl.done);
+    sl.done = nullptr;
+    sl.out.release();
+  }
+  delete q;
+}
 SubmitQueue *tq_new_submit_queue() { return new (std::nothrow) SubmitQueue(); }
 
 namespace tqi {
