@@ -59,7 +59,7 @@ def parse_args(argv=None):
                          "beyond the 256 MB Infinity Cache (implies --no-side, --no-cpu-baseline)")
     ap.add_argument("--queries", type=int, default=None,
                     help="queries per batch (default: 10000 for and2 / mixed, 1000 for or5 / phrase3 / bool)")
-    ap.add_argument("--workload", default="and2", choices=["and2", "and2_distinct", "or5", "phrase3", "mixed", "bool"])
+    ap.add_argument("--workload", default="and2", choices=["and2", "and2_distinct", "or5", "phrase3", "phrase3_adj", "mixed", "bool"])
     ap.add_argument("--k", type=int, default=None)
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -138,7 +138,9 @@ def selftest_launcher(rank, world):
 
 # ----------------------------------------------------------------------------- workloads
 DEFAULT_QUERIES = {"and2": 10_000, "and2_distinct": 10_000, "mixed": 10_000, "or5": 1_000, "phrase3": 1_000,
-                   "bool": 2_000}
+                   "phrase3_adj": 1_000, "bool": 2_000}
+PHRASE_TERMS = 64  # ranks with planted phrase positions in a segment built with positions
+PHRASE_WORKLOADS = ("phrase3", "phrase3_adj")
 
 
 def build_queries(O, workload, n, k, terms=256):
@@ -163,6 +165,18 @@ def build_queries(O, workload, n, k, terms=256):
         ids = O.zipf_queries(n, 5, terms, seed=20260922)
         return [(O.MODE_OR, q.tolist()) for q in ids], k or 100
     if workload == "phrase3":
+        # Three DISTINCT ranks ~ Zipf(1) over the 64 most frequent terms, in rank order, as one PhraseQuery::new_with_offset
+        # (phrase_query.rs:47-70) whose term offsets are the rank differences: the generator plants rank r's first
+        # position at base(doc) + r - 1 in 1/20 of the docs, so every such triple has real matches.  ~950 distinct
+        # phrases per 1000 (rounds 2-5 drew 30 adjacent triples of ranks 1..32 — phrase3_adj keeps that stream: it
+        # re-read 43 MB of lists out of the L2 a thousand times).
+        ids = O.zipf_queries(n, 3, PHRASE_TERMS, seed=20260923)
+        qs = []
+        for q in ids:
+            r = sorted(int(x) for x in q)
+            qs.append((O.MODE_PHRASE, r, [0, r[1] - r[0], r[2] - r[0]]))
+        return qs, k or 10
+    if workload == "phrase3_adj":
         rng = np.random.default_rng(20260923)
         starts = rng.integers(0, 30, size=n)
         return [(O.MODE_PHRASE, [int(s), int(s) + 1, int(s) + 2]) for s in starts], k or 10
@@ -233,8 +247,10 @@ def oracle_spec(O, seg, workload, q, k, gstats):
         return O.bool_spec(seg, q[1], q[2], q[3], q[4], k, None, nd, nt,
                            None if dfs is None else [int(dfs[t]) for t in q[1]])
     w = O.default_weights(seg, q[1], q[0], nd, nt, None if dfs is None else [int(dfs[t]) for t in q[1]])
-    return O.QuerySpec(seg, q[1], w, q[0], k,
-                       list(range(len(q[1]))) if q[0] == O.MODE_PHRASE else None)
+    offs = None
+    if q[0] == O.MODE_PHRASE:
+        offs = list(q[2]) if len(q) > 2 and q[2] is not None else list(range(len(q[1])))
+    return O.QuerySpec(seg, q[1], w, q[0], k, offs)
 
 
 def cpu_baseline(O, segs, workload, queries, k, seconds, sweep, gstats=None):
@@ -522,7 +538,7 @@ def pmc_child(args):
     from tantivy_amd import distributed as D
 
     wl = args.pmc_child
-    seg = O.synth_segment(args.docs, n_terms=args.terms, segment_ord=0, with_positions=wl == "phrase3", phrase_terms=32)
+    seg = O.synth_segment(args.docs, n_terms=args.terms, segment_ord=0, with_positions=wl in PHRASE_WORKLOADS, phrase_terms=PHRASE_TERMS)
     runner = D.ShardRunner([seg], 0)
     for name in ("dense_ratio", "dense_budget_x", "probe_budget_x", "docmat", "docsig", "device_prepare", "or_windows"):
         if os.environ.get("TQ_OPT_" + name):
@@ -862,7 +878,7 @@ def main():
         return (seg.max_doc, seg.total_num_tokens, [t.doc_freq for t in seg.terms])
 
     # ---------------------------------------------------------------- main workload (weak)
-    with_pos = args.workload == "phrase3"
+    with_pos = args.workload in PHRASE_WORKLOADS
     t0 = time.time()
     if args.terms != 256 or args.segments != 1:
         args.no_side = True
@@ -871,7 +887,7 @@ def main():
         args.no_cpu_baseline = True
         args.latency_queries = 0
     main_segs = [O.synth_segment(args.docs, n_terms=args.terms, segment_ord=rank * S_main + j,
-                                 with_positions=with_pos, phrase_terms=32) for j in range(S_main)]
+                                 with_positions=with_pos, phrase_terms=PHRASE_TERMS) for j in range(S_main)]
     seg = main_segs[0]
     t_gen = time.time() - t0
     all_stats = cl.all_gather_object([stats_of(x) for x in main_segs])
@@ -931,9 +947,10 @@ def main():
 
     # ---------------------------------------------------------------- other BASELINE configs (N=1)
     side = {}
+    pos_seg = None
     pm_mixed = {}  # the mixed stream's inline PMC figures (config 5 at N = 1 runs the same stream on 8 segments)
     if world == 1 and not args.no_side:
-        for wl in os.environ.get("BENCH_SIDE_ORDER", "and2_distinct,or5,phrase3,mixed,bool").split(","):
+        for wl in os.environ.get("BENCH_SIDE_ORDER", "and2_distinct,or5,phrase3,phrase3_adj,mixed,bool").split(","):
             if wl == args.workload:
                 continue
             # Every side workload gets a DeviceIndex of its own (the same segment bytes uploaded again):
@@ -942,9 +959,14 @@ def main():
             # the or5 kernel measured 2.75 ms instead of 2.36: term handles, doc-matrix columns and
             # table addresses follow the order in which the first workload prepared its terms.)
             s_seg = seg
-            if (wl == "phrase3") != with_pos:
-                s_seg = O.synth_segment(args.docs, n_terms=256, segment_ord=rank,
-                                        with_positions=wl == "phrase3", phrase_terms=32)
+            if (wl in PHRASE_WORKLOADS) != with_pos:
+                if wl in PHRASE_WORKLOADS and pos_seg is not None:
+                    s_seg = pos_seg  # (the segment the other phrase stream built)
+                else:
+                    s_seg = O.synth_segment(args.docs, n_terms=256, segment_ord=rank,
+                                            with_positions=wl in PHRASE_WORKLOADS, phrase_terms=PHRASE_TERMS)
+                if wl in PHRASE_WORKLOADS:
+                    pos_seg = s_seg
             s_runner = D.ShardRunner([s_seg], cl.local_rank)
             s_runner.set_option("timing", 1)
             qs, kk = build_queries(O, wl, DEFAULT_QUERIES[wl], None)
@@ -967,7 +989,7 @@ def main():
             side[wl] = {
                 "config": "%s: %d queries/batch, k=%d, same %dM-doc segment%s" %
                           (wl, len(qs), kk, args.docs // 1_000_000,
-                           " (with positions)" if wl == "phrase3" else ""),
+                           " (with positions)" if wl in PHRASE_WORKLOADS else ""),
                 "qps": round(len(qs) * args.side_steps / sm["elapsed"], 1),
                 "ms_per_step": round(sm["elapsed"] / args.side_steps * 1e3, 3),
                 "kernel_ms_avg": round(k_ms, 4),
@@ -1208,6 +1230,7 @@ def main():
                            "(SURVEY.md 8d), so frac can exceed 1 for a batch whose queries share lists — "
                            "that is sharing, not skipped work: unique_frac is the floor",
             "docs_scored_per_launch": int(st["matches"]),
+            "launch_tasks": int(st.get("chunks", 0)),
             "matches_per_launch": int(m["full_matches"]),
             "traffic_note": tf["traffic_note"],
             "host_plan_ms": round(st["host_plan_ms"], 3),

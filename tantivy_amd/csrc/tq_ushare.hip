@@ -45,20 +45,24 @@
 #ifndef TQ_US_WAVES
 #define TQ_US_WAVES 4
 #endif
+#ifndef TQ_US_FWIDE
+#define TQ_US_FWIDE 1  // stage F reads a lead's constants as four 16-byte LDS reads (0: field by field, round 3)
+#endif
 
 namespace {
 
 constexpr uint32_t US_GROUP = TQD_US_GROUP;
 constexpr uint32_t CH = TQ_US_CHUNK;
 
-struct ShareLds {  // per wavefront
+struct alignas(16) ShareLds {  // per wavefront
+  // The leads of the task, one per slot: kept in LDS, not in lane g's registers — stage C needs
+  // its registers for four lists' worth of loads in flight, and 20 live lead registers across it
+  // ended in scratch (3 spill reloads per (block, lead) pair: 7000 cycles each, measured).
+  // First member: 16-byte aligned, so that stage F reads a record's first 64 bytes as four ds_read_b128.
+  TqdLead lead[US_GROUP];
   uint32_t pay[516];  // staged payload of the leader block / four 512-byte regions of the block search
   float cache[256];   // Bm25Weight.cache of the task's queries
   uint32_t q_doc[127], q_tf[127], q_tag[127];  // survivors: doc, leader tf, g | fieldnorm id << 8 | column bits << 16
-  // The leads of the task, one per slot: kept in LDS, not in lane g's registers — stage C needs
-  // its registers for four lists' worth of loads in flight, and 20 live lead registers across it
-  // ended in scratch (3 spill reloads per (block, lead) pair: 7000 cycles each, measured)
-  TqdLead lead[US_GROUP];
   uint32_t lthr[US_GROUP];     // the lead's threshold (sortable score bits); only ever rises
   uint32_t lk[US_GROUP];       // k of its query (bits 0..7: k <= 128) | its row of threshold slots << 8
   // per block of the current tile: the leads that still want it; per doc of the current block:
@@ -686,13 +690,31 @@ ushare_kernel(TqkShareParams p) {
         for (; lm; lm &= lm - 1u) {
           const uint32_t g = (uint32_t)__builtin_ctz(lm);
           if (p.debug & 32u) ++n_scored;  // COUNTERS
-          // the lead's constants: LDS reads at a uniform address (broadcast), used as vector operands
+          // the lead's constants: the first 64 bytes of its record as FOUR 16-byte LDS reads at a uniform address
+          // (broadcast) issued together with the threshold word and the two tf/(tf+norm) of the lane — one wait for
+          // the lot (field by field the loop waited for LDS five times per (block, lead) pair)
+#if TQ_US_FWIDE
+          const uint4 *lp = reinterpret_cast<const uint4 *>(&L.lead[g]);
+          const uint4 r0 = lp[0], r1 = lp[1], r2 = lp[2], r3 = lp[3];
+          const uint32_t thr = uni(L.lthr[g]);
+          const float tfn0 = L.tfn[0][lane], tfn1 = L.tfn[1][lane];
+          const float w = __uint_as_float(r0.z), suf = __uint_as_float(r0.w), sp = __uint_as_float(r1.x);
+          const uint32_t ncols = uni((r0.y >> 4) & 15u);
+          const uint32_t b_lo = r3.z, b_hi = r3.w;
+          const uint32_t cols_lo = r1.y, cols_hi = r1.z;
+          const float awv[7] = {__uint_as_float(r1.w), __uint_as_float(r2.x), __uint_as_float(r2.y), __uint_as_float(r2.z),
+                                __uint_as_float(r2.w), __uint_as_float(r3.x), __uint_as_float(r3.y)};
+#else  // (A/B: round 3's field-by-field reads)
           const TqdLead &ld = L.lead[g];
           const uint32_t thr = uni(L.lthr[g]);
           const float w = ld.w, suf = ld.suffix, sp = ld.sparse_after;
           const uint32_t ncols = uni((ld.info >> 4) & 15u);
           const uint32_t b_lo = (uint32_t)ld.before_mask, b_hi = (uint32_t)(ld.before_mask >> 32);
           const uint32_t cols_lo = uni(ld.cols_lo), cols_hi = uni(ld.cols_hi);
+          const float *awv = ld.aw;
+#define tfn0 L.tfn[0][lane]
+#define tfn1 L.tfn[1][lane]
+#endif
           // "leader score + weights of the later lists that hold / may hold the doc >= threshold" as
           // one fused multiply-add and one float compare per doc: scores are >= 0, so the float
           // order is the order of the sortable bits; the slack that the reciprocal-based tfn and the
@@ -704,13 +726,13 @@ ushare_kernel(TqkShareParams p) {
           for (uint32_t c = 0; c < 7u; ++c) {
             if (c < ncols) {  // (wave-uniform)
               const uint32_t col = ((c < 4u ? cols_lo >> (8u * c) : cols_hi >> (8u * (c - 4u)))) & 0xFFu;
-              const float aw = ld.aw[c];
+              const float aw = awv[c];
               rest0 = fmaf((float)((uint32_t)(mw0 >> col) & 1u), aw, rest0);
               rest1 = fmaf((float)((uint32_t)(mw1 >> col) & 1u), aw, rest1);
             }
           }
-          const bool a0 = v0 && !(((uint32_t)mw0 & b_lo) | ((uint32_t)(mw0 >> 32) & b_hi)) && fmaf(w, L.tfn[0][lane], rest0) >= need;
-          const bool a1 = v1 && !(((uint32_t)mw1 & b_lo) | ((uint32_t)(mw1 >> 32) & b_hi)) && fmaf(w, L.tfn[1][lane], rest1) >= need;
+          const bool a0 = v0 && !(((uint32_t)mw0 & b_lo) | ((uint32_t)(mw0 >> 32) & b_hi)) && fmaf(w, tfn0, rest0) >= need;
+          const bool a1 = v1 && !(((uint32_t)mw1 & b_lo) | ((uint32_t)(mw1 >> 32) & b_hi)) && fmaf(w, tfn1, rest1) >= need;
           if (!(__ballot(a0) | __ballot(a1))) continue;
           // the two docs of a lane are queued one after the other: the queue holds < 64 leftovers
           // plus <= 64 new entries and is drained below 64 before the next push
