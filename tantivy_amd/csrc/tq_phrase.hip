@@ -100,6 +100,21 @@ __device__ __forceinline__ uint32_t pos_run_delta(const PosRun &r, uint32_t k) {
   return bb ? (__funnelshift_r(lo, tail ? 0u : hi, sh) & mask) : 0u;
 }
 
+// the largest x (1..8) of the lanes that are `on`, 0 if none: wave-uniform, so that the position loops below run to
+// the longest run of the 64 candidates instead of to 8 (term freqs are mostly 1 or 2: the unrolled 8 x 8 compare and
+// the 8 clamped delta fetches per term were two thirds of the sweep kernel's vector instructions)
+#ifndef TQ_PH_KMAX
+#define TQ_PH_KMAX 1  // 0: the loops run to 8 whatever the candidates hold (rounds 2-5)
+#endif
+__device__ __forceinline__ uint32_t wave_max_le8(uint32_t x, bool on) {
+  if (!TQ_PH_KMAX) return 8u;
+  uint32_t m = 0;
+#pragma unroll
+  for (uint32_t v = 1; v <= 8u; ++v)
+    if (__ballot(on && x >= v)) m = v;
+  return m;
+}
+
 // (5 waves per SIMD: what the 8 KB of LDS per wavefront admit)
 template <int KPL, int NT_MAX, bool DENSE>
 __global__ __launch_bounds__(64, DENSE ? TQ_PH_WAVES_DENSE : 5) void phrase_kernel(TqkScanParams p) {
@@ -364,10 +379,13 @@ __global__ __launch_bounds__(64, DENSE ? TQ_PH_WAVES_DENSE : 5) void phrase_kern
       bool fast = lead_tf - 1u < TM;
       for (uint32_t m = 1; m < nt; ++m) fast = fast && L.ph_tf[m - 1u][lane] - 1u < TM;
       uint32_t count = 0xFFFFFFFFu;  // = resolved by the cursor merge
+      const uint32_t km0 = wave_max_le8(lead_tf, fast);
       if (fast) {
         // adjusted positions of the leader term, then one term at a time: bit i of `ok` stays set
         // while every term seen so far has a position equal to the leader's i-th
         uint32_t a[TM], d[TM];
+#pragma unroll
+        for (uint32_t k = 0; k < TM; ++k) a[k] = d[k] = 0;
         // the block records of every term's run first (one round trip for all of them)
         uint64_t e0[NT_MAX], e1[NT_MAX];
         uint32_t pis[NT_MAX];
@@ -385,11 +403,14 @@ __global__ __launch_bounds__(64, DENSE ? TQ_PH_WAVES_DENSE : 5) void phrase_kern
           if (!TQ_PH_HOIST) pos_run_records(L.pt_blk[0], L.pt_nblk[0], lead_pi, e0[0], e1[0]);
           const PosRun run = pos_run_of(pos, e0[0], e1[0], L.pt_tail[0], L.pt_nblk[0], lead_pi);
 #pragma unroll
-          for (uint32_t k = 0; k < TM; ++k)  // clamped: unconditional, independent loads
+          for (uint32_t k = 0; k < TM; ++k) {  // clamped: unconditional, independent loads
+            if (k >= km0) break;               // (wave-uniform)
             d[k] = pos_run_delta(run, k < lead_tf ? k : lead_tf - 1u);
+          }
           uint32_t c = L.pt_off[0];
 #pragma unroll
           for (uint32_t k = 0; k < TM; ++k) {
+            if (k >= km0) break;
             c += d[k];
             a[k] = c;
           }
@@ -401,15 +422,23 @@ __global__ __launch_bounds__(64, DENSE ? TQ_PH_WAVES_DENSE : 5) void phrase_kern
           const uint32_t tfm = L.ph_tf[m - 1][lane];
           if (!TQ_PH_HOIST) pos_run_records(L.pt_blk[m], L.pt_nblk[m], pis[m], e0[m], e1[m]);
           const PosRun run = pos_run_of(pos, e0[m], e1[m], L.pt_tail[m], L.pt_nblk[m], pis[m]);
+          const uint32_t kmm = wave_max_le8(tfm, true);  // (inside `if (fast)`: the lanes here are the fast ones)
 #pragma unroll
-          for (uint32_t k = 0; k < TM; ++k) d[k] = pos_run_delta(run, k < tfm ? k : tfm - 1u);
+          for (uint32_t k = 0; k < TM; ++k) {
+            if (k >= kmm) break;
+            d[k] = pos_run_delta(run, k < tfm ? k : tfm - 1u);
+          }
           uint32_t c = L.pt_off[m], hit = 0;
 #pragma unroll
           for (uint32_t k = 0; k < TM; ++k) {
+            if (k >= kmm) break;
             c += d[k];  // (k >= tfm repeats the last delta; those sums are masked out below)
             uint32_t eq = 0;
 #pragma unroll
-            for (uint32_t i = 0; i < TM; ++i) eq |= (a[i] == c ? 1u : 0u) << i;
+            for (uint32_t i = 0; i < TM; ++i) {
+              if (i >= km0) break;
+              eq |= (a[i] == c ? 1u : 0u) << i;
+            }
             hit |= k < tfm ? eq : 0u;
           }
           ok &= hit;
@@ -746,6 +775,7 @@ __global__ __launch_bounds__(64, TQ_PH_SWEEP_WAVES) void phrase_sweep_kernel(Tqk
       }
     }
     uint32_t count = 0xFFFFFFFFu;  // = resolved by the cursor merge
+    const uint32_t km0 = wave_max_le8(tf[0], fast);
     if (fast) {
       // level 2: the block records of every term's run; then the deltas, term by term
       uint64_t e0[SWEEP_NT], e1[SWEEP_NT];
@@ -756,13 +786,19 @@ __global__ __launch_bounds__(64, TQ_PH_SWEEP_WAVES) void phrase_sweep_kernel(Tqk
         if (m < nt) pos_run_records(L.blk[m], L.nblk[m], fp[m], e0[m], e1[m]);
       }
       uint32_t a[TM], d[TM];
+#pragma unroll
+      for (uint32_t k = 0; k < TM; ++k) a[k] = d[k] = 0;
       {
         const PosRun run = pos_run_of(pos, e0[0], e1[0], L.tail[0], L.nblk[0], fp[0]);
 #pragma unroll
-        for (uint32_t k = 0; k < TM; ++k) d[k] = pos_run_delta(run, k < tf[0] ? k : tf[0] - 1u);
+        for (uint32_t k = 0; k < TM; ++k) {
+          if (k >= km0) break;  // (wave-uniform: the longest run among the 64 candidates)
+          d[k] = pos_run_delta(run, k < tf[0] ? k : tf[0] - 1u);
+        }
         uint32_t c = L.off[0];
 #pragma unroll
         for (uint32_t k = 0; k < TM; ++k) {
+          if (k >= km0) break;
           c += d[k];
           a[k] = c;
         }
@@ -772,15 +808,23 @@ __global__ __launch_bounds__(64, TQ_PH_SWEEP_WAVES) void phrase_sweep_kernel(Tqk
       for (uint32_t m = 1; m < SWEEP_NT; ++m) {
         if (m >= nt) break;
         const PosRun run = pos_run_of(pos, e0[m], e1[m], L.tail[m], L.nblk[m], fp[m]);
+        const uint32_t kmm = wave_max_le8(tf[m], true);  // (inside `if (fast)`)
 #pragma unroll
-        for (uint32_t k = 0; k < TM; ++k) d[k] = pos_run_delta(run, k < tf[m] ? k : tf[m] - 1u);
+        for (uint32_t k = 0; k < TM; ++k) {
+          if (k >= kmm) break;
+          d[k] = pos_run_delta(run, k < tf[m] ? k : tf[m] - 1u);
+        }
         uint32_t c = L.off[m], hit = 0;
 #pragma unroll
         for (uint32_t k = 0; k < TM; ++k) {
+          if (k >= kmm) break;
           c += d[k];  // (k >= tf repeats the last delta; those sums are masked out below)
           uint32_t eq = 0;
 #pragma unroll
-          for (uint32_t i = 0; i < TM; ++i) eq |= (a[i] == c ? 1u : 0u) << i;
+          for (uint32_t i = 0; i < TM; ++i) {
+            if (i >= km0) break;
+            eq |= (a[i] == c ? 1u : 0u) << i;
+          }
           hit |= k < tf[m] ? eq : 0u;
         }
         ok &= hit;
