@@ -68,6 +68,10 @@ struct TqdTerm : TqdTermHead {
   const uint32_t *pos_dir;
   // dense lists: min(tf, 255) per posting, indexed by the posting index (bitmap rank), or null
   const uint8_t *tf8;
+  // dense lists with positions: the bitmap's doc bits alone, bits[w] = dense[w].x, zero-padded to a multiple of 256
+  // words — what the phrase sweep streams (16-byte loads, 128 docs per lane and list; the rank half of `dense` is
+  // gathered for the docs that survive the AND only), or null
+  const uint32_t *bits;
 };
 
 struct TqdQuery {

@@ -675,8 +675,8 @@ constexpr uint32_t SWEEP_WORDS = 2048; // bitmap words per tile (65536 docs)
 #endif
 constexpr uint32_t SWEEP_UNROLL = TQ_PH_SWEEP_UNROLL;  // 64-word steps whose loads are in flight together
 struct SweepLds {  // per wavefront
-  uint32_t q_doc[127];
-  uint32_t q_pi[SWEEP_NT][127];  // posting index of the doc in every list
+  uint32_t q_doc[191];  // (< 64 leftovers + up to 64 new docs per extraction step)
+  const uint32_t *bits[SWEEP_NT];
   const uint2 *dense[SWEEP_NT];
   const uint8_t *tf8[SWEEP_NT];
   const uint32_t *dir[SWEEP_NT];
@@ -704,6 +704,11 @@ __global__ __launch_bounds__(64, TQ_PH_SWEEP_WAVES) void phrase_sweep_kernel(Tqk
   const float *cache_g = nullptr;
   TopK<KPL> tk;
   uint32_t n_matches = 0, n_q = 0, qn = 0;
+  // pruned mode: the query's shared threshold slots (the other pruned kernels' protocol: every match that beats the
+  // bound does a fire-and-forget atomicMax into slot[hash(doc)]; the k-th largest slot is a lower bound of the final
+  // k-th best score) and the bound itself, sortable score bits
+  uint32_t *slots = nullptr;
+  uint32_t thr_g = 0;
 
   auto setup_query = [&]() __attribute__((always_inline)) {
     q_tile_start = sload(p.tile_starts + q);
@@ -712,10 +717,17 @@ __global__ __launch_bounds__(64, TQ_PH_SWEEP_WAVES) void phrase_sweep_kernel(Tqk
     nt = sload(&Q->n_terms);
     weight = sload(&Q->weight[0]);
     cache_g = p.caches + (size_t)sload(&Q->cache_idx) * 256u;
+    {
+      const uint32_t thr_index = sload(&Q->thr_index);
+      const bool prune = !p.exhaustive && (sload(&Q->flags) & TQD_QF_PRUNE) != 0u && thr_index != 0xFFFFFFFFu;
+      slots = prune ? p.thr_slots + (size_t)thr_index * TQD_THR_SLOTS : nullptr;
+      thr_g = 0;
+    }
     tk.reset(sload(&Q->k));
     wave_mem_fence();
     if ((uint32_t)lane < nt) {
       const TqdTerm *tt = p.terms + Q->term[lane];
+      L.bits[lane] = tt->bits;
       L.dense[lane] = tt->dense;
       L.tf8[lane] = tt->tf8;
       L.dir[lane] = tt->pos_dir;
@@ -733,11 +745,19 @@ __global__ __launch_bounds__(64, TQ_PH_SWEEP_WAVES) void phrase_sweep_kernel(Tqk
     const bool alive = (uint32_t)lane < n;
     uint32_t doc = 0;
     uint32_t pi[SWEEP_NT] = {0u, 0u, 0u, 0u};
-    if (alive) {
-      doc = L.q_doc[base + lane];
+    if (alive) doc = L.q_doc[base + lane];
+    const uint32_t nid = alive ? fieldnorm_id(seg, doc) : 0u;  // (requested with the level-0 words)
+    {
+      // level 0: the doc's {bits, rank} word of every list (the sweep itself streams the bits alone) -> posting index
+      uint2 wd[SWEEP_NT];
 #pragma unroll
-      for (uint32_t m = 0; m < SWEEP_NT; ++m)
-        if (m < nt) pi[m] = L.q_pi[m][base + lane];
+      for (uint32_t m = 0; m < SWEEP_NT; ++m) {
+        wd[m] = make_uint2(0u, 0u);
+        if (m < nt && alive) wd[m] = L.dense[m][doc >> 5];
+      }
+      const uint32_t below = (1u << (doc & 31u)) - 1u;
+#pragma unroll
+      for (uint32_t m = 0; m < SWEEP_NT; ++m) pi[m] = wd[m].y + (uint32_t)__popc(wd[m].x & below);
     }
     // level 1: the four tf bytes of the posting's group + the group's directory entry, every list
     uint32_t tw[SWEEP_NT], dv[SWEEP_NT];
@@ -774,6 +794,23 @@ __global__ __launch_bounds__(64, TQ_PH_SWEEP_WAVES) void phrase_sweep_kernel(Tqk
         fast = fast && t - 1u < TM;  // (tf 0 — a corrupt index — takes the cursor merge: no position)
       }
     }
+    // pruned mode: count <= min tf, so bm25(weight, norm, min tf) bounds the doc — below the query's threshold its
+    // positions are never read (1.000002: the bound is compared across a different rounding path than the score)
+    bool walk = alive;
+    if (slots) {
+      uint32_t mintf = tf[0];
+#pragma unroll
+      for (uint32_t m = 1; m < SWEEP_NT; ++m)
+        if (m < nt) mintf = tf[m] < mintf ? tf[m] : mintf;
+      uint32_t thr_here = thr_g;
+      if (tk.thr) {
+        const uint32_t own = (uint32_t)(tk.thr >> 32);
+        thr_here = own > thr_here ? own : thr_here;
+      }
+      if (walk && mintf && sortable(bm25(weight, cache_g[nid], mintf) * 1.000002f) < thr_here) walk = false;
+      if (!__ballot(walk)) return;
+    }
+    fast = fast && walk;
     uint32_t count = 0xFFFFFFFFu;  // = resolved by the cursor merge
     const uint32_t km0 = wave_max_le8(tf[0], fast);
     if (fast) {
@@ -831,8 +868,8 @@ __global__ __launch_bounds__(64, TQ_PH_SWEEP_WAVES) void phrase_sweep_kernel(Tqk
       }
       count = (uint32_t)__popc(ok);
     }
-    if (__ballot(alive && count == 0xFFFFFFFFu)) {
-      if (alive && count == 0xFFFFFFFFu) {  // the n-way cursor merge, one position at a time
+    if (__ballot(walk && count == 0xFFFFFFFFu)) {
+      if (walk && count == 0xFFFFFFFFu) {  // the n-way cursor merge, one position at a time
         PosCursor cur[SWEEP_NT];
 #pragma unroll
         for (uint32_t m = 0; m < SWEEP_NT; ++m) {
@@ -874,14 +911,18 @@ __global__ __launch_bounds__(64, TQ_PH_SWEEP_WAVES) void phrase_sweep_kernel(Tqk
     }
     bool has = false;
     uint64_t key = 0;
-    if (alive && count > 0u && doc_is_alive(seg, doc)) {
+    if (walk && count > 0u && doc_is_alive(seg, doc)) {
       has = true;
-      key = make_key(bm25(weight, cache_g[fieldnorm_id(seg, doc)], count), doc);
+      key = make_key(bm25(weight, cache_g[nid], count), doc);
     }
     const uint64_t hit = __ballot(has);
     if (hit) {
       n_matches += (uint32_t)__popcll(hit);
       n_q += (uint32_t)__popcll(hit);
+      if (slots) {
+        const uint32_t sb = (uint32_t)(key >> 32);
+        if (has && sb > thr_g) atomicMax(slots + ((doc * 0x9E3779B1u) >> 26), sb);
+      }
       tk.offer(has, key, lane);
     }
   };
@@ -903,42 +944,51 @@ __global__ __launch_bounds__(64, TQ_PH_SWEEP_WAVES) void phrase_sweep_kernel(Tqk
     }
     const uint32_t w_begin = (t - q_tile_start) * SWEEP_WORDS;
     const uint32_t w_end = w_begin + SWEEP_WORDS < n_words ? w_begin + SWEEP_WORDS : n_words;
-    // (the words of SWEEP_UNROLL steps are requested together: a step is a chain of one round trip)
-    for (uint32_t wb0 = w_begin; wb0 < w_end; wb0 += 64u * SWEEP_UNROLL) {
-     uint2 wdu[SWEEP_UNROLL][SWEEP_NT];
+    if (slots) {  // the other wavefronts of the query may have raised its threshold
+      const uint32_t sv = __hip_atomic_load(slots + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const uint32_t g = kth_largest64(sv, tk.k);
+      if (g > thr_g) thr_g = g;
+    }
+    // Every lane takes FOUR consecutive words (128 docs) of every list's doc bits per step — one 16-byte load per list,
+    // SWEEP_UNROLL steps requested together — ANDs them and hands the surviving docs to the queue, lowest first.
+    // (Rounds 3-5 streamed the {bits, rank} words, one per lane and list: twice the bytes and four times the
+    // steps per tile; the loop around them was two thirds of the kernel's vector instructions.)
+    for (uint32_t wb0 = w_begin; wb0 < w_end; wb0 += 256u * SWEEP_UNROLL) {
+      uint4 bu[SWEEP_UNROLL][SWEEP_NT];
 #pragma unroll
-     for (uint32_t u = 0; u < SWEEP_UNROLL; ++u) {
-       const uint32_t w = wb0 + 64u * u + (uint32_t)lane;
+      for (uint32_t u = 0; u < SWEEP_UNROLL; ++u) {
+        const uint32_t w = wb0 + 256u * u + 4u * (uint32_t)lane;
 #pragma unroll
-       for (uint32_t m = 0; m < SWEEP_NT; ++m) {
-         wdu[u][m] = make_uint2(m < nt ? 0u : 0xFFFFFFFFu, 0u);
-         if (m < nt && w < w_end) wdu[u][m] = L.dense[m][w];
-       }
-     }
-#pragma unroll
-     for (uint32_t u = 0; u < SWEEP_UNROLL; ++u) {
-      const uint32_t w = wb0 + 64u * u + (uint32_t)lane;
-      const uint2 (&wd)[SWEEP_NT] = wdu[u];
-      uint32_t cand = wd[0].x & wd[1].x & wd[2].x & wd[3].x;
-      while (__ballot(cand != 0u)) {
-        const bool has = cand != 0u;
-        const uint32_t bit = has ? (uint32_t)__builtin_ctz(cand) : 0u;
-        cand &= cand - 1u;
-        const uint64_t mk = __ballot(has);
-        const uint32_t at = qn + mbcnt64(mk);
-        wave_mem_fence();
-        if (has) {
-          const uint32_t below = (1u << bit) - 1u;
-          L.q_doc[at] = (w << 5) + bit;
-#pragma unroll
-          for (uint32_t m = 0; m < SWEEP_NT; ++m)
-            if (m < nt) L.q_pi[m][at] = wd[m].y + (uint32_t)__popc(wd[m].x & below);
+        for (uint32_t m = 0; m < SWEEP_NT; ++m) {
+          const uint32_t fill = m < nt ? 0u : 0xFFFFFFFFu;
+          bu[u][m] = make_uint4(fill, fill, fill, fill);
+          if (m < nt && w < w_end) bu[u][m] = *reinterpret_cast<const uint4 *>(L.bits[m] + w);  // (zero-padded past n_words)
         }
-        wave_mem_fence();
-        qn += (uint32_t)__popcll(mk);
-        while (qn >= 64u) stageC(64u);
       }
-     }
+#pragma unroll
+      for (uint32_t u = 0; u < SWEEP_UNROLL; ++u) {
+        const uint32_t w = wb0 + 256u * u + 4u * (uint32_t)lane;
+        uint32_t c0 = bu[u][0].x & bu[u][1].x & bu[u][2].x & bu[u][3].x;
+        uint32_t c1 = bu[u][0].y & bu[u][1].y & bu[u][2].y & bu[u][3].y;
+        uint32_t c2 = bu[u][0].z & bu[u][1].z & bu[u][2].z & bu[u][3].z;
+        uint32_t c3 = bu[u][0].w & bu[u][1].w & bu[u][2].w & bu[u][3].w;
+        while (__ballot((c0 | c1 | c2 | c3) != 0u)) {
+          const bool has = (c0 | c1 | c2 | c3) != 0u;
+          // the lane's lowest doc: first non-empty word, its lowest bit
+          const uint32_t j = c0 ? 0u : (c1 ? 1u : (c2 ? 2u : 3u));
+          const uint32_t cw = c0 ? c0 : (c1 ? c1 : (c2 ? c2 : c3));
+          const uint32_t bit = has ? (uint32_t)__builtin_ctz(cw) : 0u;
+          const uint32_t rest = cw & (cw - 1u);
+          if (c0) c0 = rest; else if (c1) c1 = rest; else if (c2) c2 = rest; else c3 = rest;
+          const uint64_t mk = __ballot(has);
+          const uint32_t at = qn + mbcnt64(mk);
+          wave_mem_fence();
+          if (has) L.q_doc[at] = ((w + j) << 5) + bit;
+          wave_mem_fence();
+          qn += (uint32_t)__popcll(mk);
+          while (qn >= 64u) stageC(64u);
+        }
+      }
     }
   }
   if (q_tile_end > q_tile_start) flush_query();

@@ -65,6 +65,8 @@ hipError_t tqp_launch_dense(const uint32_t *docs, uint32_t n, uint32_t max_doc, 
 // scan_scratch: tqp_scan_scratch_words(n_dir) u32
 hipError_t tqp_launch_posdir(const uint32_t *tfs, uint32_t n, uint32_t *dir, uint32_t n_dir,
                              uint32_t *scan_scratch, hipStream_t st);
+// the doc bits of a bitmap + rank directory alone: bits[w] = tab[w].x for w < n_words, 0 up to n_padded
+hipError_t tqp_launch_bits(const uint2 *tab, uint32_t n_words, uint32_t *bits, uint32_t n_padded, hipStream_t st);
 // range maxima of a list with a bitmap (tq_device.h TQD_RM_*: tq_ashare.hip's bound on the non-leader lists);
 // acc = (max_doc >> TQD_RM_SHIFT) + 1 ZEROED u32 of scratch, out = tqd_rm_level_off(max_doc, TQD_RM_LEVELS) bytes,
 // *list_max zeroed

@@ -474,6 +474,17 @@ hipError_t tqp_launch_posdir(const uint32_t *tfs, uint32_t n, uint32_t *dir, uin
   hipLaunchKernelGGL(td_posdir_apply_kernel, dim3(n_tiles), dim3(SCAN_THREADS), 0, st, tfs, n, dir, n_dir, scan_scratch);
   return hipGetLastError();
 }
+namespace {
+__global__ void td_bits_kernel(const uint2 *tab, uint32_t n_words, uint32_t *bits, uint32_t n_padded) {
+  const uint32_t w = blockIdx.x * blockDim.x + threadIdx.x;
+  if (w < n_padded) bits[w] = w < n_words ? tab[w].x : 0u;
+}
+}  // namespace
+hipError_t tqp_launch_bits(const uint2 *tab, uint32_t n_words, uint32_t *bits, uint32_t n_padded, hipStream_t st) {
+  if (!n_padded) return hipSuccess;
+  hipLaunchKernelGGL(td_bits_kernel, dim3((n_padded + 255) / 256), dim3(256), 0, st, tab, n_words, bits, n_padded);
+  return hipGetLastError();
+}
 hipError_t tqp_launch_min_fieldnorm(const uint8_t *fieldnorm, uint32_t max_doc, uint32_t *out,
                                     hipStream_t st) {
   hipLaunchKernelGGL(td_min_fieldnorm_kernel, dim3(256), dim3(256), 0, st, fieldnorm, max_doc, out);

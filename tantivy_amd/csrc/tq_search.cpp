@@ -408,6 +408,16 @@ int search_batch_impl(tq_segment *s, const tq_query *queries, uint32_t n_queries
             n_tiles = (n_words + 2047u) / 2048u;
             tile_cost = 64u;
           }
+          // A phrase matches a doc at most min(tf of its terms) times: bm25(sum of idfs, norm, min tf) bounds the doc's
+          // score BEFORE its positions are read.  The reference filters finished scores only (weight.rs:47-60); with
+          // the query's threshold shared across its wavefronts (the slots of the other pruned kernels) the phrase
+          // kernels skip the position walk of every candidate that cannot reach the top-k — the same top-k, bit for bit
+          // (candidates EQUAL to the bound are walked: ties resolve by doc id).
+          static const bool kPhPrune = tune_u32("TQ_PH_PRUNE", 1) != 0;
+          if (kPhPrune && !opt_exhaustive && q.weights[0] >= 0.0f && q.k <= TQD_THR_SLOTS) {
+            dq.flags |= TQD_QF_PRUNE;
+            dq.thr_index = n_thr_rows++;
+          }
         }
       }
     }

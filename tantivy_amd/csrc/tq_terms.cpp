@@ -711,12 +711,17 @@ int build_dense_device(tq_segment *s, uint32_t handle) {
   }
   if (t.positions_len > 0) {  // position directory: positions before every fourth posting
     const size_t n_dir = ((size_t)t.doc_freq + 3) / 4 + 1;
+    // ... followed by the bitmap's doc bits alone (TqdTerm::bits: the phrase sweep's stream), 16-byte aligned
+    const size_t dir_bytes = (n_dir * sizeof(uint32_t) + PAD + 15) & ~(size_t)15;
+    const size_t n_bits = (n_words + 255) & ~(size_t)255;
     void *db = nullptr;
     {
-      const int arc = dense_alloc(s, n_dir * sizeof(uint32_t) + PAD, &db);
+      const int arc = dense_alloc(s, dir_bytes + n_bits * sizeof(uint32_t) + PAD, &db);
       if (arc != TQ_OK) return arc;
     }
     e = tqp_launch_posdir(dt, t.doc_freq, (uint32_t *)db, (uint32_t)n_dir, scan_scratch, s->stream);
+    if (e == hipSuccess)
+      e = tqp_launch_bits((const uint2 *)blob, (uint32_t)n_words, (uint32_t *)((uint8_t *)db + dir_bytes), (uint32_t)n_bits, s->stream);
     uint32_t total = 0;
     if (e == hipSuccess)
       e = hipMemcpyAsync(&total, (uint32_t *)db + (n_dir - 1), 4, hipMemcpyDeviceToHost, s->stream);
@@ -729,8 +734,9 @@ int build_dense_device(tq_segment *s, uint32_t handle) {
     }
     t.posdir_blob = db;
     s->h_dterms[handle].pos_dir = (const uint32_t *)db;
-    s->dense_bytes_total += n_dir * sizeof(uint32_t);
-    s->bytes_posdir += n_dir * sizeof(uint32_t);
+    s->h_dterms[handle].bits = (const uint32_t *)((uint8_t *)db + dir_bytes);
+    s->dense_bytes_total += n_dir * sizeof(uint32_t) + n_bits * sizeof(uint32_t);
+    s->bytes_posdir += n_dir * sizeof(uint32_t) + n_bits * sizeof(uint32_t);
   }
   HIP_TRY(hipStreamSynchronize(s->stream));
   return TQ_OK;
