@@ -73,6 +73,10 @@ enum tq_mode { TQ_MODE_AND = 0, TQ_MODE_OR = 1, TQ_MODE_PHRASE = 2, TQ_MODE_BOOL
 enum tq_occur { TQ_SHOULD = 0, TQ_MUST = 1, TQ_MUST_NOT = 2 };
 /* tq_query.nested_occurs[i] | TQ_NESTED_PHRASE: the terms of the clause that share atom_of[i] are a PhraseQuery */
 #define TQ_NESTED_PHRASE 0x10
+/* tq_query.nested_occurs[i] | TQ_NESTED_ANY: the terms of the clause that share atom_of[i] are a UNION — a BooleanQuery
+ * of Should terms one level further down, `(+(b c) +d) e`, `+a +(+(b c) +d)`: present where ANY of its terms is, scoring
+ * the sum of the present ones (BufferedUnionScorer's SumCombiner) */
+#define TQ_NESTED_ANY 0x20
 
 typedef struct tq_ctx tq_ctx;
 typedef struct tq_segment tq_segment;
@@ -113,8 +117,9 @@ typedef struct tq_query {
                                         Intersection / union / Exclude, phrase_scorer.rs:347-587): the terms of the
                                         phrase share an atom_of value, carry nested_occurs | TQ_NESTED_PHRASE, their
                                         phrase_offsets[i] (0 on the other terms) and — each of them — the PHRASE's
-                                        weight ((1 + K1) * boost * sum of idfs) in weights[i].  2..4 terms per phrase; a
-                                        phrase that is a clause of its own is a clause_of group of one atom. */
+                                        weight ((1 + K1) * boost * sum of idfs) in weights[i].  2..8 terms per phrase; a
+                                        phrase that is a clause of its own is a clause_of group of one atom.
+                                        A UNION one level further down (nested_occurs | TQ_NESTED_ANY, round 6): see above. */
 } tq_query;
 
 /* ---- lifecycle ---- */
@@ -156,6 +161,19 @@ void tq_segment_free(tq_segment *seg);
 int tq_term_prepare(tq_segment *seg, uint64_t postings_off, uint32_t postings_len,
                     uint64_t positions_off, uint32_t positions_len, uint32_t doc_freq,
                     tq_term_handle *out);
+/* The same for many terms at once (the new terms of a query batch): one staged upload, one wait, one launch for the
+ * doc signatures of the lists without a column — tq_term_prepare costs a blocking copy and two launches per term.
+ * infos[i] = the fields of the term's TermInfo (postings/term_info.rs:10-17); out[i] = its handle (terms already
+ * prepared: the handle they have).  Replaces n calls of InvertedIndexReader::read_block_postings_from_terminfo
+ * (src/index/inverted_index_reader.rs:204-247) + BlockSegmentPostings::open (block_segment_postings.rs:97-140). */
+typedef struct tq_term_info {
+  uint64_t postings_off;
+  uint64_t positions_off;
+  uint32_t postings_len, positions_len;
+  uint32_t doc_freq;
+  uint32_t pad_;
+} tq_term_info;
+int tq_term_prepare_batch(tq_segment *seg, const tq_term_info *infos, uint32_t n, tq_term_handle *out);
 /* Optional, before the first tq_term_prepare: names the posting lists (by postings_off) that get
  * the 40 columns of the segment's doc matrix — the caller knows every term's doc_freq from the
  * term dictionary and passes the densest lists.  Without it the columns go to the first 40 dense
@@ -407,7 +425,7 @@ typedef struct tq_segment_stats {
   uint64_t scratch_bytes;       /* the segment's own batch scratch: staging, threshold slots, result slabs */
   uint64_t dense_budget_bytes;  /* cap on bitmap (+ byte-wide tf) + docmat + posdir bytes ("dense_budget_x") */
   uint32_t n_terms, n_dense_lists, n_docmat_columns;
-  uint32_t pad_;
+  uint32_t probe_evictions;     /* lists whose probe tables ("probe_budget_x") gave their slot to another list */
   uint64_t device_scratch_bytes; /* partial / result lists + staging lists of the term-major launches: ONE set
                                     per device, shared by all its segments (count it once per device) */
 } tq_segment_stats;
@@ -443,9 +461,12 @@ int tq_segment_get_stats(tq_segment *seg, tq_segment_stats *out);
  *        without a bitmap are then also kept as plain doc / tf arrays, inside "dense_budget_x"),
  *        "probe_budget_x" (default 16, 0 = never): a boolean query rides in the shared leader-major launch
  *        (TQ_KERNEL_BSHARE) only if every list it probes has a bitmap + byte-wide tfs; for lists below
- *        "dense_ratio" they are built the first time a boolean query names the list, while such tables
- *        together stay below this multiple of the segment (the other kernels keep treating these lists as
- *        sparse),
+ *        "dense_ratio" they are built the first time a boolean query (or a nested one: TQ_KERNEL_TREE reaches EVERY
+ *        list through a bitmap) names the list, into one of the equal slots of the segment's probe pool — this
+ *        multiple of the segment's bytes worth of slots, at least TQ_MAX_TERMS; a list that needs a slot when all are
+ *        taken gets the slot of the list used longest ago (tq_segment_stats.probe_evictions), never one the batch
+ *        being planned uses: a batch that names more such lists than the budget holds grows the pool (the other
+ *        kernels keep treating these lists as sparse),
  *        "count_bitmap_ratio" (default 128, 0 = never): tq_count_batch evaluates a query as a bitwise
  *        expression over bitmap words (4-8 bytes per list per 32 docs, no postings decoded; a list
  *        without a bitmap is scattered into a scratch bitmap once per batch) when the clause a scan

@@ -73,6 +73,11 @@ class Query(C.Structure):
     ]
 
 
+class TreeNode(C.Structure):  # to_tree_node
+    _fields_ = [("kind", C.c_uint8), ("occur", C.c_uint8), ("n_kids", C.c_uint16), ("first", C.c_uint32),
+                ("msm", C.c_uint32)]
+
+
 class Hit(C.Structure):
     _fields_ = [("score", C.c_float), ("doc", C.c_uint32)]
 
@@ -179,6 +184,9 @@ def lib():
     L.to_search_exhaustive.argtypes = [C.POINTER(SegmentView), C.POINTER(Query), C.POINTER(Hit)]
     L.to_match_all.restype = C.c_size_t
     L.to_match_all.argtypes = [C.POINTER(SegmentView), C.POINTER(Query), u32p, f32p, C.c_size_t]
+    L.to_tree_match_all.restype = C.c_size_t
+    L.to_tree_match_all.argtypes = [C.POINTER(SegmentView), C.POINTER(TreeNode), C.c_size_t, C.POINTER(TermInfo),
+                                    C.POINTER(Bm25), u32p, C.c_size_t, u32p, f32p, C.c_size_t]
     L.to_sort_hits.argtypes = [C.POINTER(Hit), C.c_size_t]
     L.to_decode_postings.restype = C.c_size_t
     L.to_decode_postings.argtypes = [C.POINTER(SegmentView), C.POINTER(TermInfo), u32p, u32p]
@@ -855,14 +863,37 @@ def _combine_scorers(md, items, msm):
     return match, np.where(match, score, np.float32(0)).astype(np.float32), cost
 
 
-def tree_match_all(seg, clauses, min_should_match=0):
-    """A BooleanQuery whose clauses are terms or BooleanQuerys of terms (depth 2), restated from
-    BooleanWeight::complex_scorer applied on both levels (boolean_weight.rs:236-431; the nested query's scorer is
-    just another Box<dyn Scorer> of its parent, :225-233).  clauses = [(occur, term_id) |
-    (occur, [(inner occur, term_id | [term ids of a nested intersection]), ...], nested minimum_number_should_match)];
-    a term_id can also be ("ph", [term ids][, offsets]): a PhraseQuery (as a clause or as a member).  Every term scores with its own
-    Bm25Weight.  Returns (docs ascending, f32 scores).  Sums of 3+ terms compare within 1e-5 (the reference's own
-    order follows scorer removal / cursor order)."""
+def _is_phrase(t):
+    return isinstance(t, tuple) and len(t) >= 2 and t[0] == "ph"
+
+
+def tree_general(clauses, min_should_match=0):
+    """The clause-list form tree_match_all takes (tests/tree_shapes.py) as a GENERAL tree: a node is a term id,
+    ("ph", [term ids][, offsets]) or ("bool", [(occur, node), ...], minimum_number_should_match).  A member that is a
+    list of term ids is a nested intersection (a BooleanQuery of Must terms), ("any", [term ids]) a nested union."""
+    def member(t):
+        if _is_phrase(t):
+            return t
+        if isinstance(t, tuple) and len(t) == 2 and t[0] == "any":
+            return ("bool", [(SHOULD, x) for x in t[1]], 0)
+        if isinstance(t, tuple) and len(t) >= 2 and t[0] == "bool":
+            return t
+        if isinstance(t, (list, tuple)):
+            return ("bool", [(MUST, x) for x in t], 0)
+        return t
+
+    top = []
+    for cl in clauses:
+        if _is_phrase(cl[1]) or not isinstance(cl[1], (list, tuple)) or (isinstance(cl[1], tuple) and cl[1][0] in ("bool", "any")):
+            top.append((cl[0], member(cl[1])))
+        else:
+            top.append((cl[0], ("bool", [(o, member(t)) for o, t in cl[1]], cl[2] if len(cl) > 2 else 0)))
+    return ("bool", top, min_should_match)
+
+
+def tree_match_all_general(seg, node):
+    """BooleanWeight::complex_scorer applied recursively (boolean_weight.rs:225-233,236-431) in numpy over dense
+    (match, score) arrays: every level through _combine_scorers.  Returns (docs ascending, f32 scores)."""
     md = seg.max_doc
     per = {}
 
@@ -897,31 +928,75 @@ def tree_match_all(seg, clauses, min_should_match=0):
                 smallest = min(smallest, df)
         return hit, sc, int(min(round(est), smallest)) * 10 * len(terms)
 
-    def is_phrase(t):
-        return isinstance(t, tuple) and len(t) >= 2 and t[0] == "ph"
+    def ev(n):
+        if _is_phrase(n):
+            return phrase(*n[1:])
+        if isinstance(n, tuple) and n[0] == "bool":
+            return _combine_scorers(md, [(o, ev(c)) for o, c in n[1]], n[2] if len(n) > 2 else 0)
+        return leaf(n)
 
-    items = []
-    for cl in clauses:
-        if is_phrase(cl[1]):  # a PhraseQuery as a clause: ("ph", [term ids][, offsets])
-            items.append((cl[0], phrase(*cl[1][1:])))
-        elif isinstance(cl[1], (list, tuple)):
-            inner_msm = cl[2] if len(cl) > 2 else 0
-            members = []
-            for o, t in cl[1]:
-                if is_phrase(t):
-                    members.append((o, phrase(*t[1:])))
-                elif isinstance(t, (list, tuple)):  # an intersection of terms one level further down
-                    members.append((o, _combine_scorers(md, [(MUST, leaf(x)) for x in t], 0)))
-                else:
-                    members.append((o, leaf(t)))
-            items.append((cl[0], _combine_scorers(md, members, inner_msm)))
-        else:
-            items.append((cl[0], leaf(cl[1])))
-    res = _combine_scorers(md, items, min_should_match)
+    res = ev(node)
     if res is None:
         return np.zeros(0, np.uint32), np.zeros(0, np.float32)
     docs = np.nonzero(res[0])[0]
     return docs.astype(np.uint32), res[1][docs]
+
+
+def tree_match_all(seg, clauses, min_should_match=0):
+    """A BooleanQuery whose clauses are terms, phrases or BooleanQuerys (tests/tree_shapes.py's clause-list form),
+    restated from BooleanWeight::complex_scorer applied on every level (boolean_weight.rs:236-431; a nested query's
+    scorer is just another Box<dyn Scorer> of its parent, :225-233).  clauses = [(occur, term_id) |
+    (occur, [(inner occur, term_id | [term ids of a nested intersection] | ("any", [term ids of a nested union])), ...],
+    nested minimum_number_should_match)]; a term_id can also be ("ph", [term ids][, offsets]): a PhraseQuery.  Every
+    term scores with its own Bm25Weight.  Returns (docs ascending, f32 scores).  Sums of 3+ terms compare within
+    1e-5 (the reference's own order follows scorer removal / cursor order)."""
+    return tree_match_all_general(seg, tree_general(clauses, min_should_match))
+
+
+def tree_match_all_c(seg, node):
+    """The same tree through the C transliteration of the scorer tree (to_query.c: gs_build_node -> gs_complex:
+    Intersection / BufferedUnionScorer / Disjunction / RequiredOptionalScorer / Exclude, PhraseScorer as a docset),
+    driven like for_each_pruning_scorer.  node: the general form (tree_general)."""
+    nodes, terms, weights, offs = [], [], [], []
+
+    def add_term(t, w):
+        terms.append(seg.terms[t])
+        weights.append(w)
+        offs.append(0)
+        return len(terms) - 1
+
+    def walk(n, occur):
+        if _is_phrase(n):
+            tl = list(n[1])
+            ol = list(n[2]) if len(n) > 2 and n[2] is not None else list(range(len(tl)))
+            w = default_weights(seg, tl, MODE_PHRASE)[0]
+            first = len(terms)
+            for t, o in zip(tl, ol):
+                i = add_term(t, w)
+                offs[i] = o
+            nodes.append(TreeNode(2, occur, len(tl), first, 0))
+        elif isinstance(n, tuple) and n[0] == "bool":
+            at = len(nodes)
+            nodes.append(TreeNode(1, occur, len(n[1]), 0, int(n[2]) if len(n) > 2 else 0))
+            for o, c in n[1]:
+                walk(c, int(o))
+            assert nodes[at].n_kids == len(n[1])
+        else:
+            w = default_weights(seg, [n], MODE_OR)[0]
+            nodes.append(TreeNode(0, occur, 0, add_term(n, w), 0))
+
+    walk(node, MUST)
+    na = (TreeNode * len(nodes))(*nodes)
+    ta = (TermInfo * max(1, len(terms)))(*terms)
+    wa = (Bm25 * max(1, len(weights)))(*weights)
+    oa = (C.c_uint32 * max(1, len(offs)))(*offs)
+    cap = max(1, seg.max_doc)
+    docs = np.zeros(cap, np.uint32)
+    scores = np.zeros(cap, np.float32)
+    n = lib().to_tree_match_all(C.byref(seg.view), na, len(nodes), ta, wa, oa, len(terms), _u32(docs),
+                                scores.ctypes.data_as(C.POINTER(C.c_float)), cap)
+    assert n != (1 << 64) - 1, "malformed tree"
+    return docs[:n], scores[:n]
 
 
 def tree_search(seg, clauses, k, min_should_match=0, deleted=None):

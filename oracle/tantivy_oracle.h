@@ -301,6 +301,24 @@ typedef struct {
   uint32_t min_should_match;
 } to_query;
 
+/* A nested boolean query of any depth, prefix order (a node, then its children's subtrees): the scorer tree
+ * BooleanWeight::complex_scorer builds recursively (boolean_weight.rs:225-233,236-431). */
+enum { TO_TREE_TERM = 0, TO_TREE_BOOL = 1, TO_TREE_PHRASE = 2 };
+typedef struct {
+  uint8_t kind;    /* TO_TREE_* */
+  uint8_t occur;   /* the node's occur inside its parent (src/query/occur.rs: 0 Should, 1 Must, 2 MustNot) */
+  uint16_t n_kids; /* BOOL: children; PHRASE: terms (consecutive in terms[], from `first`) */
+  uint32_t first;  /* TERM: index into terms[]; PHRASE: index of its first term (its Bm25Weight: weights[first]) */
+  uint32_t msm;    /* BOOL: minimum_number_should_match */
+} to_tree_node;
+/* 1 (default): a union re-seeks a member that a failed Intersection::seek_danger left half-seeked (the scorer tree's
+ * intended semantics); 0: BufferedUnionScorer::seek exactly as written (buffered_union.rs:254-259) — see to_query.c */
+void to_set_union_reseek_invalid(int on);
+/* every match of the tree, docs ascending: returns their number ((size_t)-1: malformed tree) */
+size_t to_tree_match_all(const to_segment_view *seg, const to_tree_node *nodes, size_t n_nodes,
+                         const to_term_info *terms, const to_bm25 *weights, const uint32_t *phrase_offsets,
+                         size_t n_terms, uint32_t *docs, float *scores, size_t cap);
+
 /* Faithful executors (what the reference runs for TopDocs order_by_score):
  *   AND    -> block_wand_intersection (boolean_query/block_wand_intersection.rs:19-179)
  *   OR     -> block_wand / block_wand_single_scorer (boolean_query/block_wand_union.rs)

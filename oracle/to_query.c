@@ -4,6 +4,7 @@
 
 #include <assert.h>
 #include <stdlib.h>
+#include <math.h>
 #include <string.h>
 
 /* ------------------------------------------------------------------ TopNHeap
@@ -810,7 +811,7 @@ uint32_t to_ts_last_doc_in_block(void *t) { return ts_last_doc_in_block((term_sc
  * (exclude.rs:31-115), driven by for_each_pruning_scorer (weight.rs:47-60).  Clauses are terms or
  * unions of terms (the shapes the device path takes, include/tantivy_amd.h TQ_MODE_BOOL). */
 typedef struct gscorer gscorer;
-enum { GS_TERM, GS_UNION, GS_INTER, GS_REQOPT, GS_EXCLUDE, GS_DISJ, GS_EMPTY };
+enum { GS_TERM, GS_UNION, GS_INTER, GS_REQOPT, GS_EXCLUDE, GS_DISJ, GS_EMPTY, GS_LIST };
 #define GS_HORIZON 4096u
 struct gscorer {
   int kind;
@@ -832,7 +833,33 @@ struct gscorer {
   /* disjunction */
   size_t min_match;
   uint32_t *heap_doc;          /* ScorerWrapper::current_doc per kid */
+  /* GS_LIST: a PhraseScorer as a docset — its docs / scores (exhaustive_phrase, pinned by the reference's phrase
+   * KATs) walked by a cursor, its cost = PhraseScorer::cost (phrase_scorer.rs:566-573) */
+  uint32_t *l_docs;
+  float *l_scores;
+  size_t l_n, l_at;
+  uint64_t l_cost;
+  int invalid; /* GS_INTER: a seek_danger that failed half-way left the members on different docs (see below) */
 };
+/* Intersection::seek_danger (intersection.rs:193-210) returns at the first member that misses: the members before it
+ * stand on `target`, the missing one beyond it, the others where they were — and Intersection::doc() (= left.doc())
+ * names a doc >= target that the intersection need not hold: the "danger zone" contract (docset.rs:70-111) lets the
+ * CALLER re-seek.  BufferedUnionScorer::seek does so only `if docset.doc() < target` (buffered_union.rs:254-259): when
+ * ANOTHER member of the union hit `target`, a half-seeked intersection is refilled as it stands and adds left.score()
+ * + right.score() of two DIFFERENT docs to the sum of left's doc — `+a +((+b +c) d)` on a doc that holds a, b, d but
+ * not c; or, when left's doc is one no member holds, reports that doc as a match of the union (a doc too many in
+ * `+a +(...)` if a holds it).  g_reseek_invalid = 1 (default): such a member is re-seeked,
+ * i.e. the scorer tree's intended semantics — what the dense restatement (oracle.py tree_match_all_general) and
+ * the device compute; 0: the reference's code path as written (tests/test_tree_oracle_cpu.py shows both). */
+static int g_reseek_invalid = 1;
+void to_set_union_reseek_invalid(int on) { g_reseek_invalid = on; }
+static int gs_is_invalid(const gscorer *s) {
+  switch (s->kind) {
+    case GS_INTER: return s->invalid;
+    case GS_REQOPT: case GS_EXCLUDE: return gs_is_invalid(s->req);
+    default: return 0;
+  }
+}
 static uint32_t gs_doc(gscorer *s);
 static uint32_t gs_advance(gscorer *s);
 static uint32_t gs_seek(gscorer *s, uint32_t target);
@@ -859,6 +886,7 @@ static uint64_t gs_cost(gscorer *s) {
       }
       return c;
     }
+    case GS_LIST: return s->l_cost;
     default: return 0;
   }
 }
@@ -963,7 +991,7 @@ static uint32_t union_seek(gscorer *u, uint32_t target) { /* :226-275 */
   size_t i = 0;
   while (i < u->n_kids) {
     gscorer *sc = u->kids[i];
-    if (gs_doc(sc) < target) gs_seek(sc, target);
+    if (gs_doc(sc) < target || (g_reseek_invalid && gs_is_invalid(sc))) gs_seek(sc, target);
     if (gs_doc(sc) == TO_TERMINATED) {
       u->kids[i] = u->kids[u->n_kids - 1];
       u->n_kids--;
@@ -1123,14 +1151,18 @@ static uint32_t gs_doc(gscorer *s) {
     case GS_UNION: case GS_DISJ: return s->doc;
     case GS_INTER: return gs_doc(s->kids[0]);
     case GS_REQOPT: case GS_EXCLUDE: return gs_doc(s->req);
+    case GS_LIST: return s->l_at < s->l_n ? s->l_docs[s->l_at] : TO_TERMINATED;
     default: return TO_TERMINATED;
   }
 }
 static uint32_t gs_advance(gscorer *s) {
   switch (s->kind) {
+    case GS_LIST:
+      if (s->l_at < s->l_n) s->l_at++;
+      return gs_doc(s);
     case GS_TERM: return to_sp_advance(&s->term->sp);
     case GS_UNION: return union_advance(s);
-    case GS_INTER: return inter_advance(s);
+    case GS_INTER: s->invalid = 0; return inter_advance(s);
     case GS_REQOPT: s->has_cache = 0; return gs_advance(s->req);
     case GS_EXCLUDE: return excl_advance(s);
     case GS_DISJ: return disj_advance(s);
@@ -1142,6 +1174,7 @@ static uint32_t gs_seek(gscorer *s, uint32_t target) {
     case GS_TERM: return to_sp_seek(&s->term->sp, target);
     case GS_UNION: return union_seek(s, target);
     case GS_INTER: { /* :177-187 */
+      s->invalid = 0;
       gs_seek(s->kids[0], target);
       return go_to_first_doc(s->kids, s->n_kids);
     }
@@ -1153,6 +1186,7 @@ static uint32_t gs_seek(gscorer *s, uint32_t target) {
       return excl_advance(s);
     }
     case GS_DISJ: return default_seek(s, target);
+    case GS_LIST: return default_seek(s, target);
     default: return TO_TERMINATED;
   }
 }
@@ -1161,7 +1195,11 @@ static int gs_seek_danger(gscorer *s, uint32_t target, uint32_t *lower) {
     case GS_UNION: return union_seek_danger(s, target, lower);
     case GS_INTER: { /* :193-210 */
       for (size_t i = 0; i < s->n_kids; i++)
-        if (!gs_seek_danger(s->kids[i], target, lower)) return 0;
+        if (!gs_seek_danger(s->kids[i], target, lower)) {
+          s->invalid = 1; /* members 0..i moved (member i past the target), the others did not */
+          return 0;
+        }
+      s->invalid = 0;
       return 1;
     }
     case GS_REQOPT: s->has_cache = 0; return gs_seek_danger(s->req, target, lower);
@@ -1189,20 +1227,22 @@ static float gs_score(gscorer *s) {
       return sc;
     }
     case GS_EXCLUDE: return gs_score(s->req);
+    case GS_LIST: return s->l_at < s->l_n ? s->l_scores[s->l_at] : 0.0f;
     default: return 0.0f;
   }
 }
 
 /* arena of nodes for one query */
 typedef struct {
-  gscorer nodes[4 * TO_MAX_TERMS + 8];
+  gscorer nodes[8 * TO_MAX_TERMS + 8];
   size_t n_nodes;
-  gscorer *ptrs[8 * TO_MAX_TERMS + 16];
+  gscorer *ptrs[16 * TO_MAX_TERMS + 16];
   size_t n_ptrs;
   uint64_t *bits;
   float *acc;
   size_t n_windows;
-  uint32_t heap_docs[TO_MAX_TERMS];
+  uint32_t heap_docs[4 * TO_MAX_TERMS]; /* one run per disjunction node */
+  size_t n_heap;
 } gs_arena;
 static gscorer *gs_new(gs_arena *a, int kind) {
   gscorer *s = &a->nodes[a->n_nodes++];
@@ -1259,46 +1299,11 @@ static gscorer *gs_make_inter(gs_arena *a, gscorer **kids, size_t n) {
   return s;
 }
 
-/* BooleanWeight::complex_scorer for clauses that are terms or unions of terms.  Returns NULL for
- * an empty result. */
-static gscorer *gs_build(gs_arena *a, const to_segment_view *seg, const to_query *q,
-                         term_scorer *store) {
-  gscorer *clause[TO_MAX_TERMS];
-  uint8_t clause_occ[TO_MAX_TERMS];
-  uint32_t clause_id[TO_MAX_TERMS];
-  gscorer *members[TO_MAX_TERMS][TO_MAX_TERMS > 16 ? 16 : TO_MAX_TERMS];
-  size_t n_members[TO_MAX_TERMS];
-  size_t n_clauses = 0;
-  if (q->n_terms > 16) return NULL;
-  for (uint32_t i = 0; i < q->n_terms; i++) {
-    uint32_t id = q->clause_of ? q->clause_of[i] : i;
-    size_t c = 0;
-    while (c < n_clauses && clause_id[c] != id) c++;
-    if (c == n_clauses) {
-      clause_id[c] = id;
-      clause_occ[c] = q->occurs[i];
-      n_members[c] = 0;
-      n_clauses++;
-    }
-    if (q->terms[i].doc_freq == 0) continue; /* EmptyScorer: drops out of its union */
-    if (ts_open(&store[i], seg, &q->terms[i], &q->weights[i], TO_WITH_FREQS)) return NULL;
-    gscorer *t = gs_new(a, GS_TERM);
-    t->term = &store[i];
-    members[c][n_members[c]++] = t;
-  }
-  gscorer *must[TO_MAX_TERMS], *should[TO_MAX_TERMS], *excl[TO_MAX_TERMS];
-  size_t n_must = 0, n_should = 0, n_excl = 0;
-  for (size_t c = 0; c < n_clauses; c++) {
-    if (n_members[c] == 0) { /* the clause's scorer is an EmptyScorer */
-      if (clause_occ[c] == 1) return NULL; /* boolean_weight.rs:249-251 */
-      continue;                            /* removed from should / exclude (:253-262) */
-    }
-    clause[c] = gs_make_union(a, members[c], n_members[c]);
-    if (clause_occ[c] == 1) must[n_must++] = clause[c];
-    else if (clause_occ[c] == 0) should[n_should++] = clause[c];
-    else excl[n_excl++] = clause[c];
-  }
-  size_t msm = q->min_should_match;
+/* BooleanWeight::complex_scorer (boolean_weight.rs:236-431) over sub-scorers that already exist (EmptyScorers removed by
+ * the caller: an empty Must member makes the caller return NULL).  Returns NULL for an EmptyScorer.  must / should may
+ * be extended in place (minimum == number of Should scorers turns them into Must, :293-298): room for both. */
+static gscorer *gs_complex(gs_arena *a, gscorer **must, size_t n_must, gscorer **should, size_t n_should,
+                           gscorer **excl, size_t n_excl, size_t msm) {
   if (msm > n_should) return NULL; /* :275-279 */
   gscorer *should_sc = NULL;
   int should_required = 0;
@@ -1315,7 +1320,8 @@ static gscorer *gs_build(gs_arena *a, const to_segment_view *seg, const to_query
   } else {
     gscorer *d = gs_new(a, GS_DISJ); /* scorer_disjunction :23-41 */
     d->kids = gs_ptrs(a, n_should);
-    d->heap_doc = a->heap_docs;
+    d->heap_doc = a->heap_docs + a->n_heap;
+    a->n_heap += n_should;
     d->n_kids = n_should;
     for (size_t i = 0; i < n_should; i++) d->kids[i] = should[i];
     /* heapify on the scorers' current docs */
@@ -1365,10 +1371,52 @@ static gscorer *gs_build(gs_arena *a, const to_segment_view *seg, const to_query
   return e;
 }
 
+/* BooleanWeight::complex_scorer for clauses that are terms or unions of terms.  Returns NULL for
+ * an empty result. */
+static gscorer *gs_build(gs_arena *a, const to_segment_view *seg, const to_query *q,
+                         term_scorer *store) {
+  gscorer *clause[TO_MAX_TERMS];
+  uint8_t clause_occ[TO_MAX_TERMS];
+  uint32_t clause_id[TO_MAX_TERMS];
+  gscorer *members[TO_MAX_TERMS][TO_MAX_TERMS > 16 ? 16 : TO_MAX_TERMS];
+  size_t n_members[TO_MAX_TERMS];
+  size_t n_clauses = 0;
+  if (q->n_terms > 16) return NULL;
+  for (uint32_t i = 0; i < q->n_terms; i++) {
+    uint32_t id = q->clause_of ? q->clause_of[i] : i;
+    size_t c = 0;
+    while (c < n_clauses && clause_id[c] != id) c++;
+    if (c == n_clauses) {
+      clause_id[c] = id;
+      clause_occ[c] = q->occurs[i];
+      n_members[c] = 0;
+      n_clauses++;
+    }
+    if (q->terms[i].doc_freq == 0) continue; /* EmptyScorer: drops out of its union */
+    if (ts_open(&store[i], seg, &q->terms[i], &q->weights[i], TO_WITH_FREQS)) return NULL;
+    gscorer *t = gs_new(a, GS_TERM);
+    t->term = &store[i];
+    members[c][n_members[c]++] = t;
+  }
+  gscorer *must[2 * TO_MAX_TERMS], *should[TO_MAX_TERMS], *excl[TO_MAX_TERMS];
+  size_t n_must = 0, n_should = 0, n_excl = 0;
+  for (size_t c = 0; c < n_clauses; c++) {
+    if (n_members[c] == 0) { /* the clause's scorer is an EmptyScorer */
+      if (clause_occ[c] == 1) return NULL; /* boolean_weight.rs:249-251 */
+      continue;                            /* removed from should / exclude (:253-262) */
+    }
+    clause[c] = gs_make_union(a, members[c], n_members[c]);
+    if (clause_occ[c] == 1) must[n_must++] = clause[c];
+    else if (clause_occ[c] == 0) should[n_should++] = clause[c];
+    else excl[n_excl++] = clause[c];
+  }
+  return gs_complex(a, must, n_must, should, n_should, excl, n_excl, q->min_should_match);
+}
+
 static void run_bool(const to_segment_view *seg, const to_query *q, match_fn fn, void *ctx) {
   term_scorer *store = (term_scorer *)malloc(sizeof(term_scorer) * (q->n_terms ? q->n_terms : 1));
   gs_arena *a = (gs_arena *)malloc(sizeof(gs_arena));
-  a->n_nodes = a->n_ptrs = a->n_windows = 0;
+  a->n_nodes = a->n_ptrs = a->n_windows = a->n_heap = 0;
   a->bits = (uint64_t *)malloc((size_t)(q->n_terms + 2) * 64 * sizeof(uint64_t));
   a->acc = (float *)malloc((size_t)(q->n_terms + 2) * GS_HORIZON * sizeof(float));
   gscorer *s = gs_build(a, seg, q, store);
@@ -1380,4 +1428,170 @@ static void run_bool(const to_segment_view *seg, const to_query *q, match_fn fn,
   free(a->acc);
   free(a);
   free(store);
+}
+
+/* ================================================================== nested boolean queries (any depth)
+ * BooleanWeight::complex_scorer applied recursively (boolean_weight.rs:225-233: a clause's scorer is
+ * `weight.scorer(...)` of ITS query — another complex_scorer for a nested BooleanQuery, a PhraseScorer for a
+ * PhraseQuery, a TermScorer for a term), the tree given in prefix order: a node, then the subtrees of its children.
+ * A PhraseScorer enters as a docset over its docs and scores (exhaustive_phrase above: the restatement the
+ * reference's phrase KATs pin) with PhraseScorer::cost (phrase_scorer.rs:566-573: size_hint of the intersection
+ * of its lists, size_hint.rs:11-36, * 10 * terms), which orders it among the Must scorers (intersection.rs:31). */
+typedef struct {
+  uint32_t *docs;
+  float *scores;
+  size_t n, cap;
+} list_ctx;
+static void list_match(void *ctx, uint32_t doc, float score) {
+  list_ctx *c = (list_ctx *)ctx;
+  if (c->n == c->cap) {
+    c->cap = c->cap ? 2 * c->cap : 1024;
+    c->docs = (uint32_t *)realloc(c->docs, c->cap * sizeof(uint32_t));
+    c->scores = (float *)realloc(c->scores, c->cap * sizeof(float));
+  }
+  c->docs[c->n] = doc;
+  c->scores[c->n] = score;
+  c->n++;
+}
+typedef struct {
+  gs_arena *a;
+  const to_segment_view *seg;
+  const to_tree_node *nodes;
+  size_t n_nodes;
+  const to_term_info *terms;
+  const to_bm25 *weights;
+  const uint32_t *phrase_offsets;
+  term_scorer *store;   /* one per term */
+  size_t n_terms;
+  void *owned[4 * TO_MAX_TERMS]; /* arrays of the phrase leaves, freed by the caller */
+  size_t n_owned;
+  int error;
+} tree_build;
+
+/* the scorer of the subtree at *pos (advanced past it); NULL = EmptyScorer */
+static gscorer *gs_build_node(tree_build *tb, size_t *pos) {
+  if (*pos >= tb->n_nodes) {
+    tb->error = 1;
+    return NULL;
+  }
+  const to_tree_node *nd = &tb->nodes[(*pos)++];
+  if (nd->kind == TO_TREE_TERM) {
+    if (nd->first >= tb->n_terms) {
+      tb->error = 1;
+      return NULL;
+    }
+    if (tb->terms[nd->first].doc_freq == 0) return NULL; /* EmptyScorer (term_weight.rs:179-190) */
+    if (ts_open(&tb->store[nd->first], tb->seg, &tb->terms[nd->first], &tb->weights[nd->first], TO_WITH_FREQS)) {
+      tb->error = 1;
+      return NULL;
+    }
+    gscorer *t = gs_new(tb->a, GS_TERM);
+    t->term = &tb->store[nd->first];
+    return t;
+  }
+  if (nd->kind == TO_TREE_PHRASE) {
+    const uint32_t n = nd->n_kids;
+    if (n < 2 || n > TO_MAX_TERMS || nd->first + n > tb->n_terms || tb->n_owned + 2 > 4 * TO_MAX_TERMS) {
+      tb->error = 1;
+      return NULL;
+    }
+    for (uint32_t i = 0; i < n; i++)
+      if (tb->terms[nd->first + i].doc_freq == 0) return NULL; /* phrase_weight.rs:53-62 */
+    phrase_term pt[TO_MAX_TERMS];
+    uint32_t max_off = 0;
+    double est = 0.0, smallest = 0.0, f = 1.3;
+    for (uint32_t i = 0; i < n; i++) {
+      const uint32_t ti = nd->first + i;
+      if (ts_open(&tb->store[ti], tb->seg, &tb->terms[ti], &tb->weights[nd->first], TO_WITH_FREQS_AND_POSITIONS)) {
+        tb->error = 1;
+        return NULL;
+      }
+      if (tb->phrase_offsets[ti] > max_off) max_off = tb->phrase_offsets[ti];
+      /* estimate_intersection (size_hint.rs:11-36), lists in the caller's order as the device planner counts them */
+      const double df = (double)tb->terms[ti].doc_freq;
+      if (i == 0) {
+        est = smallest = df;
+      } else {
+        f = f - 0.1 > 1.0 ? f - 0.1 : 1.0;
+        est *= df / (double)(tb->seg->max_doc ? tb->seg->max_doc : 1u) * f;
+        if (df < smallest) smallest = df;
+      }
+    }
+    for (uint32_t i = 0; i < n; i++) {
+      pt[i].ts = &tb->store[nd->first + i];
+      pt[i].offset = max_off - tb->phrase_offsets[nd->first + i];
+    }
+    list_ctx lc = {NULL, NULL, 0, 0};
+    exhaustive_phrase(pt, n, &tb->weights[nd->first], list_match, &lc);
+    tb->owned[tb->n_owned++] = lc.docs;
+    tb->owned[tb->n_owned++] = lc.scores;
+    if (lc.n == 0) return NULL; /* (a PhraseScorer positioned on TERMINATED: removed like an EmptyScorer) */
+    gscorer *l = gs_new(tb->a, GS_LIST);
+    l->l_docs = lc.docs;
+    l->l_scores = lc.scores;
+    l->l_n = lc.n;
+    l->l_at = 0;
+    double r = round(est);
+    if (smallest < r) r = smallest;
+    l->l_cost = (uint64_t)r * 10u * n;
+    return l;
+  }
+  if (nd->kind != TO_TREE_BOOL || nd->n_kids > TO_MAX_TERMS) {
+    tb->error = 1;
+    return NULL;
+  }
+  gscorer *must[2 * TO_MAX_TERMS], *should[TO_MAX_TERMS], *excl[TO_MAX_TERMS];
+  size_t n_must = 0, n_should = 0, n_excl = 0;
+  int empty_must = 0;
+  for (uint32_t c = 0; c < nd->n_kids; c++) {
+    if (*pos >= tb->n_nodes) {
+      tb->error = 1;
+      return NULL;
+    }
+    const uint8_t occ = tb->nodes[*pos].occur;
+    gscorer *k = gs_build_node(tb, pos); /* (every subtree is walked: the positions of the later ones follow) */
+    if (tb->error) return NULL;
+    if (k && k->kind == GS_EMPTY) k = NULL;
+    if (k && gs_doc(k) == TO_TERMINATED) k = NULL; /* :249-262 test `scorer.is::<EmptyScorer>()`; an exhausted scorer behaves alike */
+    if (!k) {
+      if (occ == 1) empty_must = 1; /* boolean_weight.rs:249-251 */
+      continue;
+    }
+    if (occ == 1) must[n_must++] = k;
+    else if (occ == 0) should[n_should++] = k;
+    else excl[n_excl++] = k;
+  }
+  if (empty_must) return NULL;
+  return gs_complex(tb->a, must, n_must, should, n_should, excl, n_excl, nd->msm);
+}
+
+size_t to_tree_match_all(const to_segment_view *seg, const to_tree_node *nodes, size_t n_nodes,
+                         const to_term_info *terms, const to_bm25 *weights, const uint32_t *phrase_offsets,
+                         size_t n_terms, uint32_t *docs, float *scores, size_t cap) {
+  if (!n_nodes || n_terms > TO_MAX_TERMS) return 0;
+  tree_build tb;
+  memset(&tb, 0, sizeof tb);
+  tb.a = (gs_arena *)malloc(sizeof(gs_arena));
+  tb.a->n_nodes = tb.a->n_ptrs = tb.a->n_windows = tb.a->n_heap = 0;
+  tb.a->bits = (uint64_t *)malloc((n_nodes + n_terms + 2) * 64 * sizeof(uint64_t));
+  tb.a->acc = (float *)malloc((n_nodes + n_terms + 2) * GS_HORIZON * sizeof(float));
+  tb.seg = seg;
+  tb.nodes = nodes;
+  tb.n_nodes = n_nodes;
+  tb.terms = terms;
+  tb.weights = weights;
+  tb.phrase_offsets = phrase_offsets;
+  tb.n_terms = n_terms;
+  tb.store = (term_scorer *)malloc(sizeof(term_scorer) * (n_terms ? n_terms : 1));
+  all_ctx out = {docs, scores, cap, 0};
+  size_t pos = 0;
+  gscorer *s = gs_build_node(&tb, &pos);
+  if (s && !tb.error && s->kind != GS_EMPTY)
+    for (uint32_t d = gs_doc(s); d != TO_TERMINATED; d = gs_advance(s)) all_match(&out, d, gs_score(s));
+  for (size_t i = 0; i < tb.n_owned; i++) free(tb.owned[i]);
+  free(tb.store);
+  free(tb.a->bits);
+  free(tb.a->acc);
+  free(tb.a);
+  return tb.error ? (size_t)-1 : out.n;
 }

@@ -70,7 +70,7 @@ class TqSegmentStats(C.Structure):
     _fields_ = [(n, C.c_uint64) for n in (
         "index_bytes", "positions_bytes", "fieldnorm_bytes", "alive_bytes", "term_table_bytes",
         "bitmap_bytes", "docmat_bytes", "posdir_bytes", "scratch_bytes", "dense_budget_bytes")] + [
-        (n, C.c_uint32) for n in ("n_terms", "n_dense_lists", "n_docmat_columns", "pad_")] + [
+        (n, C.c_uint32) for n in ("n_terms", "n_dense_lists", "n_docmat_columns", "probe_evictions")] + [
         ("device_scratch_bytes", C.c_uint64)]
 
 

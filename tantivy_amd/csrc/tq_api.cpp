@@ -208,6 +208,7 @@ void tq_segment_free(tq_segment *s) {
   s->d_out_docs.release();
   s->d_out_counts.release();
   s->d_misc.release();
+  s->h_prep_stage.release();
   s->d_thr.release();
   tq_free_plan_scratch(s->plan);
   s->plan = nullptr;
@@ -381,6 +382,7 @@ int tq_segment_get_stats(tq_segment *s, tq_segment_stats *out) {
   r.n_terms = (uint32_t)s->terms.size();
   r.n_dense_lists = s->n_dense_lists;
   r.n_docmat_columns = s->n_mat_slots;
+  r.probe_evictions = (uint32_t)std::min<uint64_t>(s->probe_evictions, 0xFFFFFFFFull);
   r.dense_budget_bytes = s->dense_budget();
   *out = r;
   return TQ_OK;

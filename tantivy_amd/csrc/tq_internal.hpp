@@ -109,6 +109,8 @@ struct TermHost {
                                // use ("probe_budget_x"); the other kernels do not see them
   void *probe_posdir_blob = nullptr;  // ... and its position directory (TqdTerm::pos_dir layout), built the first time
                                       // a phrase INSIDE a boolean query names the list (tq_tree.hip)
+  int32_t probe_slot = -1;            // the slot of the segment's probe pool that holds them (tq_terms.cpp), or -1
+  uint8_t *probe_own_dir = nullptr;   // a list too long for a slot: room for its position directory next to its own tables
   void *rmax_blob = nullptr;   // range maxima of a list with a bitmap (its own or the probe tables'): one byte per
                                // TQD_RM_SHIFT docs, tq_ashare.hip's bound on non-leader lists
   uint32_t rmax_list = 255;    // ... the largest of them
@@ -313,8 +315,25 @@ struct tq_segment {
   Options opt;
   size_t dense_budget() const { return (size_t)opt.dense_budget_x * (idx_len + pos_len + max_doc); }
   size_t probe_budget() const { return (size_t)opt.probe_budget_x * (idx_len + pos_len + max_doc); }
+  PinnedBuf h_prep_stage;  // tq_term_prepare_batch: the blobs of a batch's new terms on their way up
   size_t probe_bytes_total = 0;
-  bool probe_full = false;  // the probe-table budget is used up (until "probe_budget_x" changes)
+  bool probe_full = false;  // (kept for tq_set_option; the pool below evicts instead of latching)
+  // Probe pool (round 6): the private tables of lists below "dense_ratio" live in equal SLOTS — [bitmap + rank
+  // directory | tf bytes | position directory | range maxima] — "probe_budget_x" worth of them (at least one query's:
+  // TQ_MAX_TERMS).  A list that needs tables when every slot is taken gets the slot of the list that was used longest
+  // ago (by batch); slots touched by the batch being planned are never taken — a batch that names more such lists
+  // than the budget holds grows the pool for good.  Before, the budget latched ("probe_full") and every later
+  // query that named a new sparse list fell back or — nested boolean queries — failed.
+  struct ProbeSlot {
+    uint8_t *base = nullptr;
+    uint32_t owner = 0xFFFFFFFFu;  // term handle, or none
+    uint64_t last_batch = 0;
+  };
+  std::vector<ProbeSlot> probe_slots;
+  size_t probe_slot_bytes = 0, probe_bm_bytes = 0, probe_tf_cap = 0, probe_dir_cap = 0, probe_rm_bytes = 0;
+  uint64_t probe_batch = 1;        // sequence number of the batch being planned
+  uint64_t probe_evictions = 0;
+  bool probe_waited = false;       // this batch already waited for the batches in flight before reusing a slot
   bool device_prepare() const { return h_idx.empty() || opt.device_prepare != 0; }
   tq_batch_stats stats{};
   bool stats_pending = false;
@@ -664,8 +683,10 @@ void mark_term_dirty(tq_segment *s, uint32_t handle);
 int build_flat(tq_segment *s, uint32_t handle, hipStream_t st, bool *ok);
 int order_after_last_batch(tq_segment *s, hipStream_t st);
 int wait_segment_idle(tq_segment *s);
-int build_probe_tables(tq_segment *s, uint32_t handle, bool *ok);
+int build_probe_tables(tq_segment *s, uint32_t handle, bool *ok, bool any_size = false);
 int build_probe_posdir(tq_segment *s, uint32_t handle, bool *ok);
+void probe_begin_batch(tq_segment *s);             // a new batch is being planned (the pool's clock)
+void probe_touch(tq_segment *s, uint32_t handle);  // the batch being planned uses the list's probe tables
 int count_batch(tq_segment *s, const tq_query *queries, uint32_t n_queries, uint32_t *out_counts);
 // a query as a bitwise expression over bitmap words (tq_count.cpp; checked on the CPU by tools/planbench/plan_check.cpp)
 bool count_expression(tq_segment *s, const tq_query &q, TqkCountQuery &cq, bool &known, uint64_t &driver_postings,

@@ -174,7 +174,7 @@ struct TqkSegMergeParams {
 // then MustNot); inside a clause Must terms first.  Occurs: TQD_ROLE_* (= enum tq_occur).
 constexpr uint32_t TQK_TREE_TILE_WORDS = 4096;  // bitmap words (131 072 docs) per (query, tile) wavefront
 constexpr uint32_t TQK_TREE_MAX_TERMS = 16;
-constexpr uint32_t TQK_TREE_PHRASE_TERMS = 4;  // terms of a phrase inside a boolean query (one position cursor each, in registers)
+constexpr uint32_t TQK_TREE_PHRASE_TERMS = 8;  // terms of a phrase inside a boolean query (one position cursor each, in registers)
 struct TqdTreeQuery {
   uint32_t n_terms, n_clauses;   // 0 / 0: the planner found the query empty
   uint32_t k, cache_idx;
@@ -189,7 +189,9 @@ struct TqdTreeQuery {
   uint32_t inner[TQK_TREE_MAX_TERMS];        // occur of the term's ATOM inside its clause (an atom = a run of terms that
                                              // must all be present: one term, or a nested intersection of terms)
   uint32_t atom_end[TQK_TREE_MAX_TERMS];     // bit 0: the term is the last of its atom; bit 1 (on every term of the atom): the atom is
-                                             // a PhraseQuery of <= TQK_TREE_PHRASE_TERMS terms (weight_bits = the phrase's weight)
+                                             // a PhraseQuery of <= TQK_TREE_PHRASE_TERMS terms (weight_bits = the phrase's weight);
+                                             // bit 2 (on every term of the atom): the atom is a UNION of its terms (present where
+                                             // any of them is, scoring the present ones) instead of a conjunction
   uint32_t dir_off[TQK_TREE_MAX_TERMS];      // phrase terms: position directory of the list (TqdTerm::pos_dir layout), 8-byte units
   uint32_t phrase_off[TQK_TREE_MAX_TERMS];   // phrase terms: max_offset - term_offset (phrase_scorer.rs:372-385)
   uint32_t outer[TQK_TREE_MAX_TERMS];        // per clause: its occur in the query
@@ -225,6 +227,9 @@ struct TqkZeroParams {
   uint32_t n;
 };
 hipError_t tqk_launch_zero(const TqkZeroParams &p, hipStream_t st);
+// signature bits (TQD_SIG_SHIFT + bits[i]) of n lists, given by their own records, into the doc matrix: one launch
+hipError_t tqk_launch_docsig_batch(const TqdSegment &seg, const TqdTerm *const *selfs, const uint32_t *bits, uint32_t n,
+                                   uint64_t *mat, bool use_dpp, hipStream_t st);
 hipError_t tqk_launch_merge_lists(const TqkMergeParams &m, const uint32_t *list_count, int kpl,
                                   hipStream_t st);
 uint32_t tqk_share_capl(int kpl);  // staging entries per lead slot

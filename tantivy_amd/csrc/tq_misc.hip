@@ -197,6 +197,23 @@ __global__ void docmat_set_kernel(uint64_t *mat, const uint32_t *docs, uint32_t 
     atomicOr((unsigned long long *)(mat + docs[i]), 1ull << (8u + slot));
 }
 
+// The signature bits of MANY lists in one launch (tq_term_prepare_batch: a batch's new sparse terms): one workgroup of
+// four wavefronts per list, a wavefront per 128-doc block, the docs' doc-matrix words get bit items[i].y.
+template <bool USE_DPP>
+__global__ __launch_bounds__(256) void docsig_batch_kernel(TqdSegment seg, const TqdTerm *const *selfs, const uint32_t *bits,
+                                                           uint64_t *mat) {
+  const int lane = (int)__lane_id();
+  const uint32_t wave = uni(threadIdx.x >> 6);
+  const TqdTerm *self = selfs[blockIdx.x];
+  const TermRef t = load_term(self, 0u);
+  const uint64_t bit = 1ull << (TQD_SIG_SHIFT + bits[blockIdx.x]);
+  for (uint32_t j = wave; j < t.n_blocks; j += 4u) {
+    const Dec d = decode_block<USE_DPP, false>(uni_ptr(seg.idx), t, j, lane);
+    if (d.d0 < seg.max_doc) atomicOr((unsigned long long *)(mat + d.d0), (unsigned long long)bit);
+    if (d.d1 < seg.max_doc) atomicOr((unsigned long long *)(mat + d.d1), (unsigned long long)bit);
+  }
+}
+
 __global__ void tf8_pack_kernel(const uint32_t *tfs, uint32_t n, uint8_t *out) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) out[i] = (uint8_t)(tfs[i] < 255u ? tfs[i] : 255u);
@@ -222,6 +239,15 @@ hipError_t tqk_launch_docmat_set(uint64_t *mat, const uint32_t *docs, uint32_t n
   if (n == 0) return hipSuccess;
   hipLaunchKernelGGL(docmat_set_kernel, dim3((n + 255) / 256), dim3(256), 0, st, mat, docs, n, slot,
                      max_doc);
+  return hipGetLastError();
+}
+hipError_t tqk_launch_docsig_batch(const TqdSegment &seg, const TqdTerm *const *selfs, const uint32_t *bits, uint32_t n,
+                                   uint64_t *mat, bool use_dpp, hipStream_t st) {
+  if (n == 0) return hipSuccess;
+  if (use_dpp)
+    hipLaunchKernelGGL((docsig_batch_kernel<true>), dim3(n), dim3(256), 0, st, seg, selfs, bits, mat);
+  else
+    hipLaunchKernelGGL((docsig_batch_kernel<false>), dim3(n), dim3(256), 0, st, seg, selfs, bits, mat);
   return hipGetLastError();
 }
 hipError_t tqk_launch_zero(const TqkZeroParams &p, hipStream_t st) {

@@ -233,7 +233,7 @@ bool bool_query_is_tree(const tq_query &q) {
   if (q.mode != TQ_MODE_BOOL || !q.occurs || !q.terms) return false;
   if (q.nested_occurs)  // a PhraseQuery inside the boolean query
     for (uint32_t i = 0; i < q.n_terms && i < TQ_MAX_TERMS; ++i)
-      if (q.nested_occurs[i] != 255u && (q.nested_occurs[i] & TQ_NESTED_PHRASE)) return true;
+      if (q.nested_occurs[i] != 255u && (q.nested_occurs[i] & (TQ_NESTED_PHRASE | TQ_NESTED_ANY))) return true;
   uint32_t size_of[TQ_MAX_TERMS] = {0};
   bool multi = false;
   for (uint32_t i = 0; i < q.n_terms && i < TQ_MAX_TERMS; ++i) {
@@ -288,6 +288,7 @@ int plan_tree_query(tq_segment *s, const tq_query &q, uint32_t qi, TqdTreeQuery 
     uint32_t id, inner, n = 0, handle[TQ_MAX_TERMS], off[TQ_MAX_TERMS];
     float w[TQ_MAX_TERMS];
     bool empty = false, phrase = false;
+    bool any = false;       // a UNION of its terms (TQ_NESTED_ANY) instead of a conjunction
     uint32_t n_named = 0;   // terms the caller named (absent ones included)
     uint64_t cost = ~0ull;  // its rarest list; a phrase: PhraseScorer::cost (phrase_scorer.rs:566-573)
   };
@@ -304,7 +305,10 @@ int plan_tree_query(tq_segment *s, const tq_query &q, uint32_t qi, TqdTreeQuery 
     if (q.occurs[i] > TQ_MUST_NOT) return fail(TQ_ERR_INVALID, "query %u: bad occur", qi);
     uint32_t inner = q.nested_occurs ? q.nested_occurs[i] : (uint32_t)TQ_SHOULD;
     const bool in_phrase = inner != 255u && (inner & TQ_NESTED_PHRASE);
-    if (in_phrase) inner &= ~(uint32_t)TQ_NESTED_PHRASE;
+    const bool in_any = inner != 255u && (inner & TQ_NESTED_ANY);
+    if (in_phrase && in_any) return fail(TQ_ERR_INVALID, "query %u: a member is a phrase or a union, not both", qi);
+    if (inner != 255u) inner &= ~(uint32_t)(TQ_NESTED_PHRASE | TQ_NESTED_ANY);
+    if (in_any && !q.atom_of) return fail(TQ_ERR_INVALID, "query %u: a union inside a nested boolean query needs atom_of", qi);
     if (inner > TQ_MUST_NOT) return fail(TQ_ERR_INVALID, "query %u: bad nested occur", qi);
     if (in_phrase && (!q.atom_of || !q.phrase_offsets))
       return fail(TQ_ERR_INVALID, "query %u: a phrase inside a boolean query needs atom_of and phrase_offsets", qi);
@@ -330,13 +334,14 @@ int plan_tree_query(tq_segment *s, const tq_query &q, uint32_t qi, TqdTreeQuery 
       atoms[a].id = aid;
       atoms[a].inner = inner;
       atoms[a].phrase = in_phrase;
+      atoms[a].any = in_any;
       cl[c].atom[cl[c].n++] = a;
-    } else if (atoms[a].inner != inner || atoms[a].phrase != in_phrase) {
+    } else if (atoms[a].inner != inner || atoms[a].phrase != in_phrase || atoms[a].any != in_any) {
       return fail(TQ_ERR_INVALID, "query %u: a conjunction (atom_of %u) mixes nested occurs", qi, aid);
     }
     ++atoms[a].n_named;
     if (q.terms[i] == TQ_TERM_ABSENT) {
-      atoms[a].empty = true;  // an EmptyScorer inside the conjunction
+      if (!in_any) atoms[a].empty = true;  // an EmptyScorer inside the conjunction (a union just loses the term)
       continue;
     }
     if (q.terms[i] >= s->terms.size()) return fail(TQ_ERR_INVALID, "query %u: unknown term handle %u", qi, q.terms[i]);
@@ -346,7 +351,10 @@ int plan_tree_query(tq_segment *s, const tq_query &q, uint32_t qi, TqdTreeQuery 
     atoms[a].handle[atoms[a].n] = q.terms[i];
     atoms[a].off[atoms[a].n] = in_phrase ? q.phrase_offsets[i] : 0u;
     atoms[a].w[atoms[a].n++] = q.weights[i];
-    atoms[a].cost = std::min<uint64_t>(atoms[a].cost, s->terms[q.terms[i]].doc_freq);
+    if (in_any)  // BufferedUnionScorer::cost = the sum of its scorers' (buffered_union.rs:326-328)
+      atoms[a].cost = (atoms[a].cost == ~0ull ? 0ull : atoms[a].cost) + s->terms[q.terms[i]].doc_freq;
+    else
+      atoms[a].cost = std::min<uint64_t>(atoms[a].cost, s->terms[q.terms[i]].doc_freq);
     qbytes += s->terms[q.terms[i]].postings_len;
   }
   for (uint32_t a = 0; a < n_at; ++a) {  // conjunctions: rarest list first (Intersection::score sums in that order)
@@ -374,7 +382,7 @@ int plan_tree_query(tq_segment *s, const tq_query &q, uint32_t qi, TqdTreeQuery 
       }
       continue;  // (the terms keep the caller's order: their offsets say where they stand)
     }
-    for (uint32_t i = 1; i < A.n; ++i)
+    for (uint32_t i = 1; i < A.n && !A.any; ++i)
       for (uint32_t j = i; j > 0 && s->terms[A.handle[j]].doc_freq < s->terms[A.handle[j - 1]].doc_freq; --j) {
         std::swap(A.handle[j], A.handle[j - 1]);
         std::swap(A.w[j], A.w[j - 1]);
@@ -450,17 +458,17 @@ int plan_tree_query(tq_segment *s, const tq_query &q, uint32_t qi, TqdTreeQuery 
         const bool own = th.dense_blob && th.tf8_blob;
         const void *bm = own ? th.dense_blob : th.probe_dense_blob, *t8 = own ? th.tf8_blob : th.probe_tf8_blob;
         if (!bm || !t8)
-          return fail(TQ_ERR_UNSUPPORTED, "query %u: a nested boolean query names a list without a bitmap (probe-table budget \"probe_budget_x\" used up)", qi);
+          return fail(TQ_ERR_UNSUPPORTED, "query %u: a nested boolean query names a list without a bitmap (options \"dense\" / \"use_dense\" / \"probe_budget_x\" off, or a list of more than max_doc / 32 postings whose own tables did not fit \"dense_budget_x\")", qi);
         tq.dense_off[n] = (uint32_t)(((uint64_t)bm - table_base) >> 3);
         tq.tf8_off[n] = (uint32_t)(((uint64_t)t8 - table_base) >> 3);
         memcpy(&tq.weight_bits[n], &A.w[A.phrase ? 0u : i], sizeof(float));  // (a phrase scores with ONE weight: the sum of its idfs)
         tq.handle[n] = A.handle[i];
         tq.inner[n] = A.inner;
-        tq.atom_end[n] = (i + 1u == A.n ? 1u : 0u) | (A.phrase ? 2u : 0u);
+        tq.atom_end[n] = (i + 1u == A.n ? 1u : 0u) | (A.phrase ? 2u : 0u) | (A.any ? 4u : 0u);
         if (A.phrase) {
           const void *dir = own && th.posdir_blob ? th.posdir_blob : th.probe_posdir_blob;
           if (!dir)
-            return fail(TQ_ERR_UNSUPPORTED, "query %u: a phrase inside a boolean query names a list without a position directory (probe-table budget \"probe_budget_x\" used up)", qi);
+            return fail(TQ_ERR_UNSUPPORTED, "query %u: a phrase inside a boolean query names a list without a position directory (the list has no positions table that fits its probe slot)", qi);
           tq.dir_off[n] = (uint32_t)(((uint64_t)dir - table_base) >> 3);
           tq.phrase_off[n] = max_off - A.off[i];
           tq.has_phrase = 1u;

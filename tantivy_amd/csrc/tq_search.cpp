@@ -82,8 +82,8 @@ int search_batch_impl(tq_segment *s, const tq_query *queries, uint32_t n_queries
   if (kProbeAnd && !opt_exhaustive && s->opt.use_dense && s->opt.dense && s->opt.probe_budget_x > 0 &&
       n_queries >= (uint32_t)s->opt.ashare_min_batch)
     and_probe = kProbeAnd >= 2 || (uint64_t)n_sparse2 * 10u >= n_queries;
-  if (!opt_exhaustive && ((kUseBShare && n_bool_queries) || and_probe) && s->opt.use_dense && s->opt.dense && s->opt.probe_budget_x > 0 &&
-      !s->probe_full) {
+  probe_begin_batch(s);  // (the probe pool's clock: tables this batch uses are not evicted for one another)
+  if (!opt_exhaustive && ((kUseBShare && n_bool_queries) || and_probe) && s->opt.use_dense && s->opt.dense && s->opt.probe_budget_x > 0) {
     bool built = false;
     for (uint32_t qi = 0; qi < n_queries; ++qi) {
       const tq_query &q = queries[qi];
@@ -100,11 +100,12 @@ int search_batch_impl(tq_segment *s, const tq_query *queries, uint32_t n_queries
         const uint32_t h = q.terms[i];
         if (h >= s->terms.size()) continue;  // (absent, or reported by plan_query)
         const TermHost &th = s->terms[h];
-        if ((th.dense_blob && th.tf8_blob) || (th.probe_dense_blob && th.probe_tf8_blob)) continue;
+        if (th.dense_blob && th.tf8_blob) continue;
+        const bool had = th.probe_dense_blob && th.probe_tf8_blob;
         bool ok = false;
-        const int prc = build_probe_tables(s, h, &ok);
+        const int prc = build_probe_tables(s, h, &ok);  // (tables it already has: marked as used by this batch)
         if (prc != TQ_OK) return prc;
-        built = built || ok;
+        built = built || (ok && !had);
       }
     }
     if (built) s->share_span_terms = ~(size_t)0;  // (the tables' address span is taken again below)
@@ -120,11 +121,12 @@ int search_batch_impl(tq_segment *s, const tq_query *queries, uint32_t n_queries
         const uint32_t h = q.terms[i];
         if (h >= s->terms.size()) continue;
         const TermHost &th = s->terms[h];
-        if (!((th.dense_blob && th.tf8_blob) || (th.probe_dense_blob && th.probe_tf8_blob))) {
+        if (!(th.dense_blob && th.tf8_blob)) {
+          const bool had = th.probe_dense_blob && th.probe_tf8_blob;
           bool ok = false;
-          const int prc = build_probe_tables(s, h, &ok);
+          const int prc = build_probe_tables(s, h, &ok, true);
           if (prc != TQ_OK) return prc;
-          built = built || ok;
+          built = built || (ok && !had);
         }
         // a term of a phrase inside the boolean query: its positions are reached from the bitmap's rank
         if (q.nested_occurs && q.nested_occurs[i] != 255u && (q.nested_occurs[i] & TQ_NESTED_PHRASE) &&

@@ -230,27 +230,18 @@ int add_to_doc_signatures(tq_segment *s, uint32_t handle) {
 
 }  // namespace tqi
 
-extern "C" {
-
-int tq_term_prepare(tq_segment *s, uint64_t postings_off, uint32_t postings_len,
-                    uint64_t positions_off, uint32_t positions_len, uint32_t doc_freq,
-                    tq_term_handle *out) {
-  if (!s || !out) return fail(TQ_ERR_INVALID, "tq_term_prepare: null argument");
-  TQ_SEGMENT_LOCK(s);
-  auto it = s->term_by_off.find(postings_off);
-  if (it != s->term_by_off.end()) {
-    *out = it->second;
-    return TQ_OK;
-  }
-  if (doc_freq == 0) return fail(TQ_ERR_INVALID, "tq_term_prepare: doc_freq 0 (term absent)");
-  const size_t body_len = s->idx_len - 8;
-  if (postings_off > body_len || (uint64_t)postings_len > body_len - postings_off)
-    return fail(TQ_ERR_FORMAT, "postings_range [%llu,+%u) outside the idx body (%zu)",
-                (unsigned long long)postings_off, postings_len, body_len);
-  HIP_TRY(hipSetDevice(s->device));
-  if (s->device_prepare())
-    return term_prepare_device(s, postings_off, postings_len, positions_off, positions_len, doc_freq,
-                               out);
+namespace tqi {
+// What the host walk of one posting list leaves: the bytes of the term's blob (records, coarse table, tails, position
+// tables, room for its own record) and everything of its records but the device pointers.
+struct WalkedTerm {
+  std::vector<uint8_t> hb;
+  size_t total = 0, o_rec = 0, o_coarse = 0, o_tdocs = 0, o_ttfs = 0, o_pboff = 0, o_ptail = 0, o_self = 0;
+  TqdTerm dt{};
+  TermHost th;
+  uint64_t postings_off = 0;
+};
+static int host_walk_term(tq_segment *s, uint64_t postings_off, uint32_t postings_len, uint64_t positions_off,
+                          uint32_t positions_len, uint32_t doc_freq, WalkedTerm &w) {
   const uint8_t *data = s->h_idx.data() + 8 + postings_off;
   const size_t len = postings_len;
   const uint64_t abs0 = 8 + postings_off;  // offset of `data` inside the uploaded sub-file
@@ -408,7 +399,8 @@ int tq_term_prepare(tq_segment *s, uint64_t postings_off, uint32_t postings_len,
   const size_t o_ptail = place(4 * pos_tail.size());
   const size_t o_self = place(sizeof(TqdTerm));  // the term's own record: what the table-building kernels of its
   total += PAD;                                  // preparation read (the segment's term table is synced per batch)
-  std::vector<uint8_t> hb(total, 0);
+  std::vector<uint8_t> &hb = w.hb;
+  hb.assign(total, 0);
   for (uint32_t i = 0; i <= n_blocks; ++i) {
     const uint32_t r[4] = {i < n_blocks ? b_last[i] : TQ_TERMINATED, i < n_blocks ? b_meta[i] : 0u,
                            i < n_blocks ? b_off[i] : 0u, block_pos[i]};
@@ -421,19 +413,12 @@ int tq_term_prepare(tq_segment *s, uint64_t postings_off, uint32_t postings_len,
   }
   if (!pos_block_off.empty()) memcpy(hb.data() + o_pboff, pos_block_off.data(), 8 * pos_block_off.size());
   if (!pos_tail.empty()) memcpy(hb.data() + o_ptail, pos_tail.data(), 4 * pos_tail.size());
-  uint8_t *blob = nullptr;
-  {
-    const int arc = term_alloc(s, total, &blob);
-    if (arc != TQ_OK) return arc;
-  }
-  s->bytes_term_tables += total;
-  TqdTerm dt{};
-  dt.rec = (const uint4 *)(blob + o_rec);
-  dt.coarse = (const uint32_t *)(blob + o_coarse);
-  dt.tail_docs = (const uint32_t *)(blob + o_tdocs);
-  dt.tail_tfs = (const uint32_t *)(blob + o_ttfs);
-  dt.pos_blk = (const uint64_t *)(blob + o_pboff);
-  dt.pos_tail = (const uint32_t *)(blob + o_ptail);
+  w.total = total;
+  w.o_rec = o_rec, w.o_coarse = o_coarse, w.o_tdocs = o_tdocs, w.o_ttfs = o_ttfs, w.o_pboff = o_pboff, w.o_ptail = o_ptail,
+  w.o_self = o_self;
+  w.postings_off = postings_off;
+  TqdTerm &dt = w.dt;
+  dt = TqdTerm{};
   dt.payload_base = abs0 + payload;
   dt.n_full = n_full;
   dt.n_tail = n_tail;
@@ -443,13 +428,8 @@ int tq_term_prepare(tq_segment *s, uint64_t postings_off, uint32_t postings_len,
   dt.n_pos_tail = (uint32_t)pos_tail.size();
   dt.has_freq = has_freq ? 1u : 0u;
   dt.coarse_shift = shift;
-  memcpy(hb.data() + o_self, &dt, sizeof dt);
-  hipError_t ce = hipMemcpy(blob, hb.data(), total, hipMemcpyHostToDevice);
-  if (ce != hipSuccess) return fail(TQ_ERR_HIP, "term upload: %s", hipGetErrorString(ce));
-
-  TermHost th;
-  th.blob = blob;
-  th.d_self = (const TqdTerm *)(blob + o_self);
+  TermHost &th = w.th;
+  th = TermHost{};
   th.doc_freq = doc_freq;
   th.n_blocks = n_blocks;
   th.n_full = n_full;
@@ -458,7 +438,191 @@ int tq_term_prepare(tq_segment *s, uint64_t postings_off, uint32_t postings_len,
   th.postings_len = postings_len;
   th.positions_len = want_pos ? positions_len : 0;
   th.n_positions = want_pos ? running_pos : 0;
-  return register_term(s, dt, th, postings_off, out);
+  return TQ_OK;
+}
+// the device pointers of a walked term whose blob lives at `blob` (its own record goes into the blob's last slot)
+static void place_walked_term(WalkedTerm &w, uint8_t *blob) {
+  TqdTerm &dt = w.dt;
+  dt.rec = (const uint4 *)(blob + w.o_rec);
+  dt.coarse = (const uint32_t *)(blob + w.o_coarse);
+  dt.tail_docs = (const uint32_t *)(blob + w.o_tdocs);
+  dt.tail_tfs = (const uint32_t *)(blob + w.o_ttfs);
+  dt.pos_blk = (const uint64_t *)(blob + w.o_pboff);
+  dt.pos_tail = (const uint32_t *)(blob + w.o_ptail);
+  memcpy(w.hb.data() + w.o_self, &dt, sizeof dt);
+  w.th.blob = blob;
+  w.th.d_self = (const TqdTerm *)(blob + w.o_self);
+}
+}  // namespace tqi
+
+extern "C" {
+
+int tq_term_prepare(tq_segment *s, uint64_t postings_off, uint32_t postings_len,
+                    uint64_t positions_off, uint32_t positions_len, uint32_t doc_freq,
+                    tq_term_handle *out) {
+  if (!s || !out) return fail(TQ_ERR_INVALID, "tq_term_prepare: null argument");
+  TQ_SEGMENT_LOCK(s);
+  auto it = s->term_by_off.find(postings_off);
+  if (it != s->term_by_off.end()) {
+    *out = it->second;
+    return TQ_OK;
+  }
+  if (doc_freq == 0) return fail(TQ_ERR_INVALID, "tq_term_prepare: doc_freq 0 (term absent)");
+  const size_t body_len = s->idx_len - 8;
+  if (postings_off > body_len || (uint64_t)postings_len > body_len - postings_off)
+    return fail(TQ_ERR_FORMAT, "postings_range [%llu,+%u) outside the idx body (%zu)",
+                (unsigned long long)postings_off, postings_len, body_len);
+  HIP_TRY(hipSetDevice(s->device));
+  if (s->device_prepare())
+    return term_prepare_device(s, postings_off, postings_len, positions_off, positions_len, doc_freq,
+                               out);
+  WalkedTerm w;
+  {
+    const int wrc = host_walk_term(s, postings_off, postings_len, positions_off, positions_len, doc_freq, w);
+    if (wrc != TQ_OK) return wrc;
+  }
+  uint8_t *blob = nullptr;
+  {
+    const int arc = term_alloc(s, w.total, &blob);
+    if (arc != TQ_OK) return arc;
+  }
+  s->bytes_term_tables += w.total;
+  place_walked_term(w, blob);
+  hipError_t ce = hipMemcpy(blob, w.hb.data(), w.total, hipMemcpyHostToDevice);
+  if (ce != hipSuccess) return fail(TQ_ERR_HIP, "term upload: %s", hipGetErrorString(ce));
+  return register_term(s, w.dt, w.th, postings_off, out);
+}
+
+// The new terms of a batch together: every list is walked on the host as tq_term_prepare walks
+// it, the blobs go up from ONE pinned staging buffer with asynchronous copies and one wait, and the signature bits of
+// all the lists without a column are set by ONE launch (tq_term_prepare costs a blocking copy and two launches per
+// term: two thousand new terms per 10 000-query batch while a 65 536-term vocabulary is being discovered).  Lists
+// dense enough for tables of their own are prepared one by one as before (there are at most a few hundred per
+// segment).  out[i] = the handle of infos[i] (known terms: the one they have).
+int tq_term_prepare_batch(tq_segment *s, const tq_term_info *infos, uint32_t n, tq_term_handle *out) {
+  if (!s || (!infos && n) || (!out && n)) return fail(TQ_ERR_INVALID, "tq_term_prepare_batch: null argument");
+  TQ_SEGMENT_LOCK(s);
+  HIP_TRY(hipSetDevice(s->device));
+  std::vector<uint32_t> fresh;  // indices of infos that need preparing
+  for (uint32_t i = 0; i < n; ++i) {
+    auto it = s->term_by_off.find(infos[i].postings_off);
+    if (it != s->term_by_off.end()) {
+      out[i] = it->second;
+      continue;
+    }
+    out[i] = TQ_TERM_ABSENT;
+    fresh.push_back(i);
+  }
+  if (fresh.empty()) return TQ_OK;
+  const size_t dense_bytes = (((size_t)s->max_doc + 31) / 32 + 1) * sizeof(uint2);
+  auto one_by_one = [&](uint32_t i) {
+    return tq_term_prepare(s, infos[i].postings_off, infos[i].postings_len, infos[i].positions_off, infos[i].positions_len,
+                           infos[i].doc_freq, &out[i]);
+  };
+  if (s->device_prepare()) {  // (no host copy of the index: the device walk, term by term)
+    for (uint32_t i : fresh) {
+      const int rc = one_by_one(i);
+      if (rc != TQ_OK) return rc;
+    }
+    return TQ_OK;
+  }
+  const size_t body_len = s->idx_len - 8;
+  std::vector<WalkedTerm> walked;
+  std::vector<uint32_t> walked_of;
+  walked.reserve(fresh.size());
+  size_t stage_bytes = 0;
+  for (uint32_t i : fresh) {
+    const tq_term_info &ti = infos[i];
+    if (s->term_by_off.count(ti.postings_off)) {  // (named twice in this call)
+      out[i] = s->term_by_off[ti.postings_off];
+      continue;
+    }
+    if (ti.doc_freq == 0) return fail(TQ_ERR_INVALID, "tq_term_prepare_batch: doc_freq 0 (term absent)");
+    if (ti.postings_off > body_len || (uint64_t)ti.postings_len > body_len - ti.postings_off)
+      return fail(TQ_ERR_FORMAT, "postings_range [%llu,+%u) outside the idx body (%zu)", (unsigned long long)ti.postings_off,
+                  ti.postings_len, body_len);
+    const bool dense = s->opt.dense && s->max_doc >= 4096u && (uint64_t)ti.doc_freq * (uint64_t)s->opt.dense_ratio >= s->max_doc &&
+                       s->dense_bytes_total + dense_bytes <= s->dense_budget();
+    bool dup = false;
+    for (size_t k = 0; k < walked.size() && !dup; ++k) dup = walked[k].postings_off == ti.postings_off;
+    if (dense || dup) {
+      if (!dup) {
+        const int rc = one_by_one(i);
+        if (rc != TQ_OK) return rc;
+      }
+      continue;
+    }
+    walked.emplace_back();
+    const int wrc = host_walk_term(s, ti.postings_off, ti.postings_len, ti.positions_off, ti.positions_len, ti.doc_freq, walked.back());
+    if (wrc != TQ_OK) return wrc;
+    walked_of.push_back(i);
+    stage_bytes += (walked.back().total + 255) & ~(size_t)255;
+  }
+  if (!walked.empty()) {
+    // blobs: device room from the slabs, bytes through one pinned buffer, asynchronous copies on the segment's stream
+    const size_t ptr_bytes = walked.size() * (sizeof(const TqdTerm *) + sizeof(uint32_t)) + 64;
+    int rc = s->h_prep_stage.ensure(stage_bytes + ptr_bytes);
+    if (rc != TQ_OK) return rc;
+    uint8_t *hs = (uint8_t *)s->h_prep_stage.p;
+    size_t at = 0;
+    hipError_t e = hipSuccess;
+    for (WalkedTerm &w : walked) {
+      uint8_t *blob = nullptr;
+      rc = term_alloc(s, w.total, &blob);
+      if (rc != TQ_OK) return rc;
+      s->bytes_term_tables += w.total;
+      place_walked_term(w, blob);
+      memcpy(hs + at, w.hb.data(), w.total);
+      if (e == hipSuccess) e = hipMemcpyAsync(blob, hs + at, w.total, hipMemcpyHostToDevice, s->stream);
+      at += (w.total + 255) & ~(size_t)255;
+    }
+    if (e != hipSuccess) return fail(TQ_ERR_HIP, "term upload: %s", hipGetErrorString(e));
+    // handles; which of them get signature bits
+    const bool sigs = s->opt.docsig && s->opt.docmat && s->opt.dense && s->max_doc >= 4096u;
+    if (sigs) {
+      rc = ensure_docmat(s);
+      if (rc != TQ_OK) return rc;
+    }
+    const TqdTerm **h_selfs = (const TqdTerm **)(hs + stage_bytes);
+    uint32_t *h_bits = (uint32_t *)(h_selfs + walked.size());
+    uint32_t n_sig = 0;
+    for (size_t k = 0; k < walked.size(); ++k) {
+      WalkedTerm &w = walked[k];
+      const uint32_t handle = (uint32_t)s->terms.size();
+      s->terms.push_back(w.th);
+      s->terms.back().wants_col = !s->cols_reserved || s->reserved_cols.count(w.postings_off) != 0;
+      s->h_dterms.push_back(w.dt);
+      mark_term_dirty(s, handle);
+      s->term_by_off.emplace(w.postings_off, handle);
+      out[walked_of[k]] = handle;
+      if (sigs && s->d_docmat && w.th.doc_freq) {
+        const uint32_t bit = (handle * 0x9E3779B1u) >> (32 - 4);  // (add_to_doc_signatures' bit)
+        h_selfs[n_sig] = w.th.d_self;
+        h_bits[n_sig] = bit;
+        ++n_sig;
+        s->h_dterms[handle].has_freq |= (bit + 1u) << 16;
+      }
+    }
+    if (n_sig) {
+      rc = s->d_misc.ensure((size_t)n_sig * (sizeof(const TqdTerm *) + sizeof(uint32_t)) + 64);
+      if (rc != TQ_OK) return rc;
+      const TqdTerm **d_selfs = (const TqdTerm **)s->d_misc.p;
+      uint32_t *d_bits = (uint32_t *)(d_selfs + n_sig);
+      // (the bits follow the pointers in the staging buffer: compact them behind n_sig pointers first)
+      memmove(h_selfs + n_sig, h_bits, (size_t)n_sig * sizeof(uint32_t));
+      e = hipMemcpyAsync(d_selfs, h_selfs, (size_t)n_sig * (sizeof(const TqdTerm *) + sizeof(uint32_t)), hipMemcpyHostToDevice, s->stream);
+      if (e == hipSuccess)
+        e = tqk_launch_docsig_batch(s->dseg, d_selfs, d_bits, n_sig, s->d_docmat, s->opt.use_dpp != 0, s->stream);
+      if (e != hipSuccess) return fail(TQ_ERR_HIP, "signature launch: %s", hipGetErrorString(e));
+    }
+    HIP_TRY(hipStreamSynchronize(s->stream));  // (the staging buffer and d_misc are reused by the next call)
+  }
+  for (uint32_t i : fresh)  // (a term named twice in one call)
+    if (out[i] == TQ_TERM_ABSENT) {
+      auto it = s->term_by_off.find(infos[i].postings_off);
+      if (it != s->term_by_off.end()) out[i] = it->second;
+    }
+  return TQ_OK;
 }
 
 }  // extern "C"
@@ -748,72 +912,179 @@ int build_dense_device(tq_segment *s, uint32_t handle) {
 // boolean query names the list, inside "probe_budget_x"; no doc-matrix column, no position directory, and
 // TermHost::dense_blob stays null — the other kernels and planners keep treating the list as sparse.
 // *ok = the list can be probed (it has its own tables, or these).
-int build_probe_tables(tq_segment *s, uint32_t handle, bool *ok) {
+void probe_begin_batch(tq_segment *s) {
+  ++s->probe_batch;
+  s->probe_waited = false;
+}
+void probe_touch(tq_segment *s, uint32_t handle) {
+  const int32_t sl = s->terms[handle].probe_slot;
+  if (sl >= 0) s->probe_slots[(size_t)sl].last_batch = s->probe_batch;
+}
+namespace {
+// a slot for `handle`: a free one, a new one while the pool is below its budget, else the least recently used one
+// (its owner loses its tables: the batches in flight are waited for first), else — every slot belongs to the batch
+// being planned — one more.  *slot = -1: the list does not fit a slot (more postings than max_doc / 32: such a list
+// gets tables of its own long before the budget of the dense lists is used up).
+int probe_slot_acquire(tq_segment *s, uint32_t handle, int32_t *slot) {
+  *slot = -1;
+  TermHost &t = s->terms[handle];
+  if (!s->probe_slot_bytes) {
+    const size_t n_words = ((size_t)s->max_doc + 31) / 32 + 1;
+    auto up = [](size_t x) { return (x + 255) & ~(size_t)255; };
+    s->probe_bm_bytes = up(n_words * sizeof(uint2));
+    s->probe_tf_cap = up(std::max<size_t>((size_t)s->max_doc / 32u, 4096u) + PAD);
+    s->probe_dir_cap = up(s->probe_tf_cap + 16 + PAD);  // ((df + 3) / 4 + 1) * 4 bytes
+    s->probe_rm_bytes = up(tqd_rm_level_off(s->max_doc, TQD_RM_LEVELS));
+    s->probe_slot_bytes = s->probe_bm_bytes + s->probe_tf_cap + s->probe_dir_cap + s->probe_rm_bytes;
+  }
+  if ((size_t)t.doc_freq + 8 > s->probe_tf_cap - PAD) return TQ_OK;
+  const size_t budget_slots = std::max<size_t>(TQ_MAX_TERMS, s->probe_budget() / s->probe_slot_bytes);
+  int32_t pick = -1;
+  for (size_t i = 0; i < s->probe_slots.size() && pick < 0; ++i)
+    if (s->probe_slots[i].owner == 0xFFFFFFFFu) pick = (int32_t)i;
+  if (pick < 0 && s->probe_slots.size() >= budget_slots) {  // least recently used, not by this batch
+    uint64_t oldest = s->probe_batch;
+    for (size_t i = 0; i < s->probe_slots.size(); ++i)
+      if (s->probe_slots[i].last_batch < oldest) {
+        oldest = s->probe_slots[i].last_batch;
+        pick = (int32_t)i;
+      }
+    if (pick >= 0) {
+      if (!s->probe_waited) {  // a batch in flight may still read the slot
+        const int wrc = wait_segment_idle(s);
+        if (wrc != TQ_OK) return wrc;
+        s->probe_waited = true;
+      }
+      TermHost &old = s->terms[s->probe_slots[(size_t)pick].owner];
+      old.probe_dense_blob = old.probe_tf8_blob = old.probe_posdir_blob = nullptr;
+      if (old.rmax_blob && !old.dense_blob) {  // (the range maxima lived in the slot)
+        old.rmax_blob = nullptr;
+        old.rmax_list = 255;
+      }
+      old.probe_slot = -1;
+      s->probe_slots[(size_t)pick].owner = 0xFFFFFFFFu;
+      ++s->probe_evictions;
+      s->share_span_terms = ~(size_t)0;
+    }
+  }
+  if (pick < 0) {  // a new slot (below the budget, or every slot is this batch's)
+    void *base = nullptr;
+    const int arc = dense_alloc(s, s->probe_slot_bytes, &base);
+    if (arc != TQ_OK) return arc;
+    tq_segment::ProbeSlot ps;
+    ps.base = (uint8_t *)base;
+    s->probe_slots.push_back(ps);
+    s->probe_bytes_total += s->probe_slot_bytes;
+    s->bytes_bitmaps += s->probe_slot_bytes;
+    pick = (int32_t)s->probe_slots.size() - 1;
+  }
+  s->probe_slots[(size_t)pick].owner = handle;
+  s->probe_slots[(size_t)pick].last_batch = s->probe_batch;
+  t.probe_slot = pick;
+  *slot = pick;
+  return TQ_OK;
+}
+void probe_slot_release(tq_segment *s, uint32_t handle) {  // (a failed build)
+  TermHost &t = s->terms[handle];
+  if (t.probe_slot < 0) return;
+  s->probe_slots[(size_t)t.probe_slot].owner = 0xFFFFFFFFu;
+  t.probe_slot = -1;
+}
+}  // namespace
+
+int build_probe_tables(tq_segment *s, uint32_t handle, bool *ok, bool any_size) {
   TermHost &t = s->terms[handle];
   *ok = (t.dense_blob && t.tf8_blob) || (t.probe_dense_blob && t.probe_tf8_blob);
-  if (*ok || !s->opt.dense || !s->opt.use_dense || s->max_doc < 4096u || !t.doc_freq) return TQ_OK;
-  const size_t n_words = ((size_t)s->max_doc + 31) / 32 + 1;
-  const size_t tf_bytes = ((size_t)t.doc_freq + 7) & ~(size_t)7;
-  const size_t need = n_words * sizeof(uint2) + tf_bytes;
-  if (s->probe_bytes_total + need > s->probe_budget()) {
-    // (no list fits any more — a bitmap alone is n_words * 8 bytes: later batches stop asking)
-    if (s->probe_bytes_total + n_words * sizeof(uint2) > s->probe_budget()) s->probe_full = true;
+  if (*ok) {
+    probe_touch(s, handle);
     return TQ_OK;
   }
+  if (!s->opt.dense || !s->opt.use_dense || !t.doc_freq || s->opt.probe_budget_x <= 0) return TQ_OK;
+  // (segments below 4096 docs: the shared launches are not used there — only nested boolean queries, which reach every
+  // list through a bitmap whatever the segment's size, ask with any_size)
+  if (s->max_doc < 4096u && !any_size) return TQ_OK;
+  const size_t n_words = ((size_t)s->max_doc + 31) / 32 + 1;
   HIP_TRY(hipSetDevice(s->device));
-  int rc = TQ_OK;
+  int32_t slot = -1;
+  int rc = probe_slot_acquire(s, handle, &slot);
+  if (rc != TQ_OK) return rc;
+  uint8_t *base = nullptr;
+  if (slot >= 0) {
+    base = s->probe_slots[(size_t)slot].base;
+  } else {
+    // a list of more postings than a slot holds ("dense_ratio" below 32 leaves such lists without tables of their
+    // own): tables of its own size, kept for good — there are at most 32 of them
+    const size_t tf_room = (((size_t)t.doc_freq + 8 + PAD) + 255) & ~(size_t)255;
+    void *own = nullptr;
+    rc = dense_alloc(s, s->probe_bm_bytes + 2 * tf_room + 256 + s->probe_rm_bytes, &own);
+    if (rc != TQ_OK) return rc;
+    base = (uint8_t *)own;
+    s->probe_bytes_total += s->probe_bm_bytes + 2 * tf_room + 256 + s->probe_rm_bytes;
+    s->bytes_bitmaps += s->probe_bm_bytes + 2 * tf_room + 256 + s->probe_rm_bytes;
+  }
+  // (layout of a slot: bitmap | tf bytes | position directory | range maxima; an oversize list: the same, its own sizes)
+  const size_t tf_cap = slot >= 0 ? s->probe_tf_cap : ((((size_t)t.doc_freq + 8 + PAD) + 255) & ~(size_t)255);
+  const size_t dir_cap = slot >= 0 ? s->probe_dir_cap : tf_cap + 256;
   const size_t bytes = (size_t)t.doc_freq * sizeof(uint32_t);
   const size_t scan_words = tqp_scan_scratch_words((uint32_t)n_words);
   rc = s->d_misc.ensure(2 * bytes + 64 + (scan_words + ((size_t)s->max_doc >> TQD_RM_SHIFT) + 8) * sizeof(uint32_t));
-  if (rc != TQ_OK) return rc;
+  if (rc != TQ_OK) {
+    probe_slot_release(s, handle);
+    return rc;
+  }
   uint32_t *dd = (uint32_t *)s->d_misc.p, *dt = dd + t.doc_freq;
   uint32_t *scan_scratch = dt + t.doc_freq + 16;
   uint32_t *rm_acc = scan_scratch + scan_words;
   hipError_t e = tqk_launch_decode_list(s->dseg, t.d_self, 0u, t.n_blocks, dd, dt, s->opt.use_dpp != 0, s->stream);
-  if (e != hipSuccess) return fail(TQ_ERR_HIP, "decode launch: %s", hipGetErrorString(e));
-  void *tfb = nullptr, *blob = nullptr;
-  rc = dense_alloc(s, tf_bytes + PAD, &tfb);
-  if (rc != TQ_OK) return rc;
-  rc = dense_alloc(s, n_words * sizeof(uint2), &blob);
-  if (rc != TQ_OK) {
-    dense_release(s, tfb);
-    return rc;
-  }
+  void *blob = base, *tfb = base + s->probe_bm_bytes;
   uint32_t *bad = (uint32_t *)s->d_tp_info;
-  e = tqk_launch_tf8_pack(dt, t.doc_freq, (uint8_t *)tfb, s->stream);
+  if (e == hipSuccess) e = tqk_launch_tf8_pack(dt, t.doc_freq, (uint8_t *)tfb, s->stream);
   if (e == hipSuccess) e = hipMemsetAsync(blob, 0, n_words * sizeof(uint2), s->stream);
   if (e == hipSuccess) e = hipMemsetAsync(bad, 0, 4, s->stream);
   if (e == hipSuccess) e = tqp_launch_dense(dd, t.doc_freq, s->max_doc, (uint2 *)blob, (uint32_t)n_words, bad, scan_scratch, s->stream);
-  uint32_t h_bad = 0;
+  // range maxima of the list (tq_ashare.hip's bound on a probed list), into the slot
+  const uint32_t n_ranges = (s->max_doc >> TQD_RM_SHIFT) + 1u;
+  uint8_t *rmb = base + s->probe_bm_bytes + tf_cap + dir_cap;
+  const bool want_rm = !t.rmax_blob && s->d_local_cache;
+  if (want_rm) {
+    if (e == hipSuccess) e = hipMemsetAsync(rm_acc, 0, ((size_t)n_ranges + 1u) * sizeof(uint32_t), s->stream);
+    if (e == hipSuccess)
+      e = tqp_launch_rmax(dd, dt, t.doc_freq, s->d_fn, s->dseg.const_fieldnorm_id, s->d_local_cache, rm_acc, s->max_doc,
+                          rmb, rm_acc + n_ranges, s->stream);
+  }
+  uint32_t h_bad = 0, lmax = 0;
   if (e == hipSuccess) e = hipMemcpyAsync(&h_bad, bad, 4, hipMemcpyDeviceToHost, s->stream);
+  if (e == hipSuccess && want_rm) e = hipMemcpyAsync(&lmax, rm_acc + n_ranges, 4, hipMemcpyDeviceToHost, s->stream);
   if (e == hipSuccess) e = hipStreamSynchronize(s->stream);
   if (e != hipSuccess || h_bad) {
-    dense_release(s, blob);
-    dense_release(s, tfb);
+    probe_slot_release(s, handle);
     return e != hipSuccess ? fail(TQ_ERR_HIP, "probe tables: %s", hipGetErrorString(e))
                            : fail(TQ_ERR_FORMAT, "posting list not strictly increasing below max_doc");
   }
   t.probe_dense_blob = blob;
   t.probe_tf8_blob = tfb;
-  rc = build_rmax(s, handle, dd, dt, rm_acc);
-  if (rc != TQ_OK) return rc;
-  s->probe_bytes_total += need;
-  s->bytes_bitmaps += need;
+  if (slot < 0) t.probe_own_dir = base + s->probe_bm_bytes + tf_cap;  // (where its position directory goes)
+  if (want_rm) {
+    t.rmax_blob = rmb;
+    t.rmax_list = lmax ? std::min<uint32_t>(lmax, 255u) : 255u;
+  }
   *ok = true;
   return TQ_OK;
 }
 
-// The position directory of a list that has a bitmap but no directory yet (its tables came from
-// build_probe_tables): entry j = positions before posting 4 j, what a phrase inside a boolean query needs to find
-// a doc's positions from the bitmap's rank (tq_tree.hip).  Counted against the same budget.
+// The position directory of a list whose tables came from build_probe_tables: entry j = positions before posting
+// 4 j, what a phrase inside a boolean query needs to find a doc's positions from the bitmap's rank (tq_tree.hip).
+// Lives in the list's slot of the probe pool.
 int build_probe_posdir(tq_segment *s, uint32_t handle, bool *ok) {
   TermHost &t = s->terms[handle];
   *ok = t.posdir_blob || t.probe_posdir_blob;
   if (*ok || !t.doc_freq || t.positions_len == 0) return TQ_OK;
-  if (!((t.dense_blob && t.tf8_blob) || (t.probe_dense_blob && t.probe_tf8_blob))) return TQ_OK;
+  const bool own = t.dense_blob && t.tf8_blob;  // (a dense list whose directory did not fit when its tables were built)
+  if (!own && !(t.probe_dense_blob && t.probe_tf8_blob)) return TQ_OK;
+  if (!own && t.probe_slot < 0 && !t.probe_own_dir) return TQ_OK;
   const size_t n_dir = ((size_t)t.doc_freq + 3) / 4 + 1;
   const size_t need = n_dir * sizeof(uint32_t);
-  if (s->probe_bytes_total + need > s->probe_budget()) return TQ_OK;
+  if (!own && t.probe_slot >= 0 && need + PAD > s->probe_dir_cap) return TQ_OK;
   HIP_TRY(hipSetDevice(s->device));
   const size_t bytes = (size_t)t.doc_freq * sizeof(uint32_t);
   const size_t scan_words = tqp_scan_scratch_words((uint32_t)n_dir);
@@ -824,21 +1095,24 @@ int build_probe_posdir(tq_segment *s, uint32_t handle, bool *ok) {
   hipError_t e = tqk_launch_decode_list(s->dseg, t.d_self, 0u, t.n_blocks, dd, dt, s->opt.use_dpp != 0, s->stream);
   if (e != hipSuccess) return fail(TQ_ERR_HIP, "decode launch: %s", hipGetErrorString(e));
   void *db = nullptr;
-  rc = dense_alloc(s, need + PAD, &db);
-  if (rc != TQ_OK) return rc;
+  if (own) {
+    rc = dense_alloc(s, need + PAD, &db);
+    if (rc != TQ_OK) return rc;
+    s->bytes_posdir += need;
+  } else if (t.probe_slot >= 0) {
+    db = s->probe_slots[(size_t)t.probe_slot].base + s->probe_bm_bytes + s->probe_tf_cap;
+  } else {
+    db = t.probe_own_dir;
+  }
   e = tqp_launch_posdir(dt, t.doc_freq, (uint32_t *)db, (uint32_t)n_dir, scan_scratch, s->stream);
   uint32_t total = 0;
   if (e == hipSuccess) e = hipMemcpyAsync(&total, (uint32_t *)db + (n_dir - 1), 4, hipMemcpyDeviceToHost, s->stream);
   if (e == hipSuccess) e = hipStreamSynchronize(s->stream);
-  if (e != hipSuccess || total != (uint32_t)t.n_positions) {
-    dense_release(s, db);
+  if (e != hipSuccess || total != (uint32_t)t.n_positions)
     return e != hipSuccess ? fail(TQ_ERR_HIP, "position directory: %s", hipGetErrorString(e))
                            : fail(TQ_ERR_FORMAT, "term freqs sum to %u positions, the stream holds %llu", total,
                                   (unsigned long long)t.n_positions);
-  }
   t.probe_posdir_blob = db;
-  s->probe_bytes_total += need;
-  s->bytes_posdir += need;
   *ok = true;
   return TQ_OK;
 }

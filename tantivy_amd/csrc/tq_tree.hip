@@ -33,7 +33,9 @@ namespace {
 
 constexpr uint32_t TREE_TILE_WORDS = TQK_TREE_TILE_WORDS;  // bitmap words per (query, tile) wavefront
 
-// bit-sliced counter of up to 15 one-bit-per-doc inputs (4 planes): add, and "count >= m"
+// bit-sliced counter of one-bit-per-doc inputs (4 planes), SATURATING at 15: add, and "count >= m" for m <= 15.
+// (A query holds up to TQ_MAX_TERMS = 16 Should inputs on one level: without the saturation a doc that held all 16
+// wrapped to 0 and fell out of the doc set — the best-scoring doc of the query.)
 struct SlicedCount {
   uint32_t p0 = 0, p1 = 0, p2 = 0, p3 = 0;
   __device__ __forceinline__ void add(uint32_t x) {
@@ -46,7 +48,12 @@ struct SlicedCount {
     c = p2 & x;
     p2 ^= x;
     x = c;
+    c = p3 & x;  // the carry out of the top plane: the count sticks at 15
     p3 ^= x;
+    p0 |= c;
+    p1 |= c;
+    p2 |= c;
+    p3 |= c;
   }
   __device__ __forceinline__ uint32_t at_least(uint32_t m) const {  // m wave-uniform, 0..15
     if (m == 0u) return 0xFFFFFFFFu;
@@ -95,11 +102,16 @@ __global__ __launch_bounds__(64) void tree_kernel(TqkTreeParams p) {
       uint32_t must = 0xFFFFFFFFu, nots = 0u;
       SlicedCount should;
       uint32_t atom = 0xFFFFFFFFu;  // the docs that hold every term of the current atom so far
+      uint32_t atom_any = 0u;       // ... or any of them (a union one level down: atom_end bit 2)
       for (uint32_t t = t0; t < t1; ++t) {
         const uint2 *bm = reinterpret_cast<const uint2 *>(tbase + ((uint64_t)sload(Q->dense_off + t) << 3));
-        atom &= in ? bm[w].x : 0u;
+        const uint32_t bits = in ? bm[w].x : 0u;
+        atom &= bits;
+        atom_any |= bits;
         const uint32_t ae = sload(Q->atom_end + t);
         if (!(ae & 1u)) continue;
+        if (ae & 4u) atom = atom_any;
+        atom_any = 0u;
         const uint32_t inner = sload(Q->inner + t);
         if constexpr (PH) {  // a phrase under an odd number of MustNots must not remove docs it only MAY hold
           if ((ae & 2u) && ((outer_c == TQD_ROLE_MUST_NOT) != (inner == TQD_ROLE_MUST_NOT))) atom = 0u;
@@ -144,7 +156,8 @@ __global__ __launch_bounds__(64) void tree_kernel(TqkTreeParams p) {
         uint32_t ns = 0;
         float csum = 0.0f;
         bool atom_ok = true;    // the doc holds every term of the current atom so far
-        float atom_sum = 0.0f;  // ... and what they score together (Intersection::score)
+        bool atom_some = false; // ... or any of them (a union one level down)
+        float atom_sum = 0.0f;  // ... and what they score together (Intersection::score / SumCombiner)
         uint32_t atom_t0 = t0;
         for (uint32_t t = t0; t < t1; ++t) {
           const uint32_t inner = sload(Q->inner + t);
@@ -154,6 +167,7 @@ __global__ __launch_bounds__(64) void tree_kernel(TqkTreeParams p) {
           if (has) wd = bm[w];
           const bool present = has && ((wd.x >> bit) & 1u);
           atom_ok = atom_ok && present;
+          atom_some = atom_some || present;
           if (present && inner != TQD_ROLE_MUST_NOT && !(PH && (ae & 2u))) {
             const uint32_t pi = wd.y + (uint32_t)__popc(wd.x & ((1u << bit) - 1u));
             uint32_t tf = (tbase + ((uint64_t)sload(Q->tf8_off + t) << 3))[pi];
@@ -170,6 +184,7 @@ __global__ __launch_bounds__(64) void tree_kernel(TqkTreeParams p) {
             atom_sum = atom_sum + bm25(__uint_as_float(sload(Q->weight_bits + t)), norm, tf);
           }
           if (!(ae & 1u)) continue;
+          if (ae & 4u) atom_ok = atom_some;  // (a union: the present terms' scores are already in atom_sum)
           if constexpr (PH) {
             if (ae & 2u) {  // a PhraseQuery: count the positions where its terms line up (lanes that hold them all)
               uint32_t cnt = 0;
@@ -248,6 +263,7 @@ __global__ __launch_bounds__(64) void tree_kernel(TqkTreeParams p) {
             }
           }
           atom_ok = true;
+          atom_some = false;
           atom_sum = 0.0f;
           atom_t0 = t + 1u;
         }

@@ -228,7 +228,7 @@ static Query build_query(const tqh_query &q) {
       // otherwise (`+a +(+b -c)`: clause_of {0,1,1}, occurs {1,1,1}, nested_occurs {255,1,2})
       auto inner = [&](uint32_t tt) {
         uint8_t v = q.nested_occurs ? q.nested_occurs[tt] : 255;
-        if (v != 255) v &= (uint8_t)~TQ_NESTED_PHRASE;
+        if (v != 255) v &= (uint8_t)~(TQ_NESTED_PHRASE | TQ_NESTED_ANY);
         if (v != 255 && v > 2) throw TantivyError(TantivyError::InvalidArgument, "bad nested occur");
         return v == 1 ? Occur::Must : (v == 2 ? Occur::MustNot : Occur::Should);
       };
@@ -258,8 +258,13 @@ static Query build_query(const tqh_query &q) {
         member.phrase_terms.emplace_back(q.phrase_offsets ? q.phrase_offsets[t] : (uint32_t)member.phrase_terms.size(), q.terms[t]);
         continue;
       }
-      if (member.kind == Query::Term) member = Query::boolean({{Occur::Must, Query(member)}});
-      member.clauses.emplace_back(Occur::Must, leaf_of(t));
+      // (TQ_NESTED_ANY: the member is a UNION of its terms — a BooleanQuery of Should terms one level down)
+      const bool any = q.nested_occurs && q.nested_occurs[t] != 255 && (q.nested_occurs[t] & TQ_NESTED_ANY) != 0;
+      const Occur leaf_occur = any ? Occur::Should : Occur::Must;
+      if (member.kind == Query::Term) member = Query::boolean({{leaf_occur, Query(member)}});
+      if (!member.clauses.empty() && member.clauses[0].first != leaf_occur)
+        throw TantivyError(TantivyError::InvalidArgument, "a member mixes union and intersection terms");
+      member.clauses.emplace_back(leaf_occur, leaf_of(t));
     }
     // a clause that is ONE phrase (`+"a b"`): the one-member nested query is the phrase itself
     for (size_t c = 0; c < clauses.size(); ++c) {

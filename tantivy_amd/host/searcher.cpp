@@ -291,10 +291,19 @@ Weight Searcher::weight(const Query &query) const {
       // (round 5, second half: a member — or a clause — can be a PhraseQuery of <= 4 terms: PhraseScorer under
       // Intersection / union / Exclude, the position check done per candidate doc on the device)
       bool any_phrase = false;
+      // (round 6: ... or a UNION of terms one level down — `(+(b c) +d) e`: BufferedUnionScorer as a member)
+      auto is_member_union = [](const Query &q) {
+        if (q.kind != Query::Boolean || q.clauses.size() < 2 || q.minimum_number_should_match > 1) return false;
+        for (auto &c : q.clauses)
+          if (c.first != Occur::Should || c.second.kind != Query::Term) return false;
+        return true;
+      };
       auto is_query_of_terms = [&](const Query &q) {
         if (q.kind != Query::Boolean || q.clauses.empty()) return false;
         for (auto &c : q.clauses)
-          if (c.second.kind != Query::Term && c.second.kind != Query::Phrase && !is_conjunction(c.second)) return false;
+          if (c.second.kind != Query::Term && c.second.kind != Query::Phrase && !is_conjunction(c.second) &&
+              !is_member_union(c.second))
+            return false;
         return true;
       };
       auto is_term_union = [](const Query &q) {
@@ -310,7 +319,7 @@ Weight Searcher::weight(const Query &query) const {
         } else if (c.second.kind != Query::Term) {
           if (!is_query_of_terms(c.second))
             throw TantivyError(TantivyError::Unsupported,
-                               "boolean trees deeper than two levels stay on the CPU scorer path");
+                               "boolean trees deeper than three levels (or with a nested query below the second) stay on the CPU scorer path");
           for (auto &sub : c.second.clauses) any_phrase = any_phrase || sub.second.kind == Query::Phrase;
           tree = tree || any_phrase || !is_term_union(c.second);
           flat = false;
@@ -335,15 +344,15 @@ Weight Searcher::weight(const Query &query) const {
                                                             : (uint8_t)TQ_SHOULD);
         const Score bc = b0 * c.second.boost;  // the clause's own BoostQuery wrapper, if any
         uint8_t member = 0;
-        auto add = [&](uint32_t term, Score boost, Occur inner) {
+        auto add = [&](uint32_t term, Score boost, Occur inner, uint8_t flag = 0) {
           w.terms.push_back(term);
           w.weights.push_back(term_weight(term, boost));
           if (w.mode == TQ_MODE_BOOL) {
             w.occurs.push_back(oc);
             w.clause_of.push_back(clause);
             if (tree) {
-              w.nested_occurs.push_back(inner == Occur::Must ? (uint8_t)TQ_MUST
-                                                             : (inner == Occur::MustNot ? (uint8_t)TQ_MUST_NOT : (uint8_t)TQ_SHOULD));
+              w.nested_occurs.push_back((uint8_t)((inner == Occur::Must ? (uint8_t)TQ_MUST
+                                                                         : (inner == Occur::MustNot ? (uint8_t)TQ_MUST_NOT : (uint8_t)TQ_SHOULD)) | flag));
               w.atom_of.push_back(member);
             }
           }
@@ -354,8 +363,8 @@ Weight Searcher::weight(const Query &query) const {
           if (ph.phrase_terms.size() < 2)
             throw TantivyError(TantivyError::InvalidArgument,
                                "A phrase query is required to have strictly more than one term.");
-          if (ph.phrase_terms.size() > 4)
-            throw TantivyError(TantivyError::Unsupported, "a phrase inside a boolean query takes at most 4 terms on the device");
+          if (ph.phrase_terms.size() > 8)
+            throw TantivyError(TantivyError::Unsupported, "a phrase inside a boolean query takes at most 8 terms on the device");
           Score idf_sum = 0.0f;
           for (auto &ot : ph.phrase_terms) idf_sum += idf(doc_freq(ot.second), nd);
           const Score pw = boost_by(idf_sum * (1.0f + K1), boost);
@@ -381,6 +390,8 @@ Weight Searcher::weight(const Query &query) const {
               add(sub.second.term, bc * sub.second.boost, sub.first);
             else if (sub.second.kind == Query::Phrase)
               add_phrase(sub.second, bc * sub.second.boost, sub.first);
+            else if (is_member_union(sub.second))  // a union of terms one level down: one member (TQ_NESTED_ANY)
+              for (auto &leaf : sub.second.clauses) add(leaf.second.term, bc * sub.second.boost * leaf.second.boost, sub.first, TQ_NESTED_ANY);
             else  // an intersection of terms one level down: one member of the nested query
               for (auto &leaf : sub.second.clauses) add(leaf.second.term, bc * sub.second.boost * leaf.second.boost, sub.first);
             ++member;

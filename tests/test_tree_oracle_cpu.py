@@ -7,7 +7,8 @@ import numpy as np
 import pytest
 
 from oracle import oracle as O
-from tests.tree_shapes import SHAPES, to_device
+from tests.helpers import corpus_segment
+from tests.tree_shapes import DEEP_SHAPES, PHRASE_SHAPES, SHAPES, to_device, wide_minimum
 
 M, S, N = O.MUST, O.SHOULD, O.MUST_NOT
 
@@ -159,3 +160,111 @@ def test_device_tuples_of_phrase_shapes():
             else:
                 assert ex["phrase_offsets"][i] == 0
         assert groups and all(v == list(range(len(v))) and len(v) >= 2 for v in groups.values())
+
+
+# ---- round 6: the C transliteration of the scorer tree, any depth (to_query.c gs_build_node / gs_complex)
+def _both(seg, spec, msm=0):
+    g = O.tree_general(spec, msm)
+    d1, s1 = O.tree_match_all_general(seg, g)
+    d2, s2 = O.tree_match_all_c(seg, g)
+    assert np.array_equal(d1, d2), spec
+    assert np.allclose(s1, s2, rtol=1e-5, atol=0), spec
+    return d1, s1
+
+
+def test_c_scorer_tree_equals_the_dense_restatement_on_every_shape(seg, pseg):
+    """complex_scorer as a tree of Intersection / BufferedUnionScorer / Disjunction / RequiredOptionalScorer / Exclude
+    cursors (C) against complex_scorer over dense match / score arrays (numpy), every nested shape of the device tests"""
+    rng = np.random.default_rng(11)
+    n_docs = 0
+    for shape, msm in SHAPES + DEEP_SHAPES:
+        for _ in range(3):
+            d, _ = _both(seg, shape(rng.choice(20, size=8, replace=False).tolist()), msm)
+            n_docs += len(d)
+    for shape, msm in PHRASE_SHAPES:
+        for _ in range(2):
+            d, _ = _both(pseg, shape(sorted(rng.choice(10, size=8, replace=False).tolist())), msm)
+            n_docs += len(d)
+    for m in (2, 9, 15):
+        d, _ = _both(seg, wide_minimum(list(range(16)), m))
+        n_docs += len(d)
+    assert n_docs > 10_000
+    # deeper than the device's flattened form: four levels
+    t = list(range(8))
+    deep = ("bool", [(M, t[0]), (S, ("bool", [(M, ("bool", [(S, t[1]), (S, ("bool", [(M, t[2]), (M, t[3])], 0))], 0)), (N, t[4])], 0))], 0)
+    d1, s1 = O.tree_match_all_general(seg, deep)
+    d2, s2 = O.tree_match_all_c(seg, deep)
+    assert np.array_equal(d1, d2) and np.allclose(s1, s2, rtol=1e-5, atol=0) and len(d1)
+
+
+def _ids(vocab, *words):
+    return [vocab[w] for w in words]
+
+
+def test_reference_boolean_doc_set_kats_on_both_tree_oracles():
+    """the doc sets the reference asserts: boolean_query/mod.rs:109-219 (test_boolean_query, ..._two_excluded),
+    :48-56 (`(+a +b) d` counts 3), boolean_query.rs:287-352 (test_minimum_required, test_union, test_intersection)"""
+    seg, v = corpus_segment(["a b c", "a c", "b c", "a b c d", "d"])
+    a, b, c, d = _ids(v, "a", "b", "c", "d")
+
+    def docs(spec, msm=0):
+        return _both(seg, spec, msm)[0].tolist()
+
+    assert docs([(M, a)]) == [0, 1, 3]
+    assert docs([(S, a)]) == [0, 1, 3]
+    assert docs([(S, a), (S, b)]) == [0, 1, 2, 3]
+    assert docs([(M, a), (S, b)]) == [0, 1, 3]
+    assert docs([(M, a), (S, b), (N, d)]) == [0, 1]
+    assert docs([(N, d)]) == []
+    # test_boolean_query_two_excluded: doc 4 alone, scored as `+d` scores it
+    d_only, s_only = _both(seg, [(M, d)])
+    dx, sx = _both(seg, [(M, d), (N, a), (N, b)])
+    assert dx.tolist() == [4] and d_only.tolist() == [3, 4]
+    assert sx[0] == s_only[1] and s_only[1] > s_only[0]
+    # test_boolean_non_all_term_disjunction: `(+a +b) d` matches docs {0, 3, 4}
+    assert docs([(S, [(M, a), (M, b)], 0), (S, d)]) == [0, 3, 4]
+    # boolean_query.rs: test_minimum_required
+    seg2, v2 = corpus_segment(["a b c", "a c e", "d f g", "z z z", "c i b"])
+    g = lambda *w: [(S, v2[x]) for x in w if x in v2]  # noqa: E731
+    assert _both(seg2, g("a", "c", "z", "i"), 2)[0].tolist() == [0, 1, 4]
+    assert _both(seg2, g("a", "b", "c", "e"), 3)[0].tolist() == [0, 1]
+    assert _both(seg2, g("a", "b"), 3)[0].tolist() == []
+    assert _both(seg2, g("a", "z"), 1)[0].tolist() == [0, 1, 3]
+    assert _both(seg2, g("a", "b"), 0)[0].tolist() == [0, 1, 4]
+    # test_union / test_intersection
+    seg3, v3 = corpus_segment(["b c", "a c", "a b", "a d"])
+    assert _both(seg3, [(S, v3["a"]), (S, v3["d"])])[0].tolist() == [1, 2, 3]
+    assert _both(seg3, [(M, v3["a"]), (M, v3["b"])])[0].tolist() == [2]
+    assert _both(seg3, [(M, v3["a"]), (M, v3["c"])])[0].tolist() == [1]
+    assert _both(seg3, [(M, v3["b"]), (M, v3["c"])])[0].tolist() == [0]
+
+
+def test_union_refills_a_half_seeked_intersection_as_written_in_the_reference(seg):
+    """A finding about the reference, kept as a test: Intersection::seek_danger (intersection.rs:193-210) may leave its
+    members on different docs, and BufferedUnionScorer::seek only re-seeks members with doc() < target
+    (buffered_union.rs:254-259).  With the code path as written, `+a +((+b +c) d)` adds b's and c's scores of two
+    different docs to a doc that holds a, b, d but not c — or reports a doc of b's that the union does not hold at all.
+    The default of the oracle (and what the device computes) is the scorer tree's intended semantics: the doc sets the
+    reference's own tests assert (test_reference_boolean_doc_set_kats_on_both_tree_oracles)."""
+    rng = np.random.default_rng(5)
+    inflated = extra = 0
+    for _ in range(12):
+        t = rng.choice(24, size=8, replace=False).tolist()
+        g = O.tree_general(SHAPES[0][0](t), 0)
+        d1, s1 = O.tree_match_all_general(seg, g)
+        try:
+            O.lib().to_set_union_reseek_invalid(0)
+            d3, s3 = O.tree_match_all_c(seg, g)
+        finally:
+            O.lib().to_set_union_reseek_invalid(1)
+        d2, s2 = O.tree_match_all_c(seg, g)
+        assert np.array_equal(d1, d2) and np.allclose(s1, s2, rtol=1e-5, atol=0)
+        # as written: every doc of the intended result, now and then one more (the union reports the half-seeked
+        # intersection's doc() although no member holds it), now and then an inflated score — never less
+        assert np.isin(d1, d3).all()
+        extra += len(d3) - len(d1)
+        common = np.isin(d3, d1)
+        bad = np.abs(s1 - s3[common]) > 1e-5 * np.abs(s1)
+        inflated += int(bad.sum())
+        assert (s3[common][bad] > s1[bad]).all()
+    assert inflated + extra >= 1

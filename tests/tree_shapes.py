@@ -32,6 +32,27 @@ SHAPES = [
 ]
 
 
+# round 6: a UNION one level further down (TQ_NESTED_ANY: `("any", [term ids])` as a member) — the depth-3 trees whose
+# innermost level is not a conjunction — and the widest minimum the flattened form holds
+DEEP_SHAPES = [
+    # (+(b c) +d) e: a union inside an intersection inside a union
+    (lambda t: [(S, [(M, ("any", [t[1], t[2]])), (M, t[3])], 0), (S, t[4])], 0),
+    # +a +(+(b c) +d): ... inside an intersection
+    (lambda t: [(M, t[0]), (M, [(M, ("any", [t[1], t[2]])), (M, t[3])], 0)], 0),
+    # +a +(+(b c) -(d e)): a required and an excluded union one level down
+    (lambda t: [(M, t[0]), (M, [(M, ("any", [t[1], t[2]])), (N, ("any", [t[3], t[4]]))], 0)], 0),
+    # ((a b) (+c +d) e)~2 f: unions, an intersection and a term under a nested minimum
+    (lambda t: [(S, [(S, ("any", [t[0], t[1]])), (S, [t[2], t[3]]), (S, t[4])], 2), (S, t[5])], 0),
+    # +(+(a b) +(c d)) -(e f): two unions required together, a union excluded
+    (lambda t: [(M, [(M, ("any", [t[0], t[1]])), (M, ("any", [t[2], t[3]]))], 0), (N, [(S, t[4]), (S, t[5])], 0)], 0),
+]
+
+
+def wide_minimum(t16, m):
+    """16 Should terms, at least m of them (m <= 15): the bit-sliced counter of tq_tree.hip saturates at 15"""
+    return [(M, [(S, x) for x in t16], m)]
+
+
 # phrases inside boolean queries (VERDICT r04 item 4: `+"a b" +c`), over term ids with positions
 PHRASE_SHAPES = [
     # +"a b" +c
@@ -90,6 +111,10 @@ def to_device(ta, spec, msm=0):
                 any_phrase = True
                 for o, t in enumerate(member[1]):
                     add(t, cl[0], ci, inner | PH, mi, o)
+                continue
+            if isinstance(member, tuple) and len(member) == 2 and member[0] == "any":  # a union one level down
+                for t in member[1]:
+                    add(t, cl[0], ci, inner | 0x20, mi)  # TQ_NESTED_ANY
                 continue
             for t in (member if isinstance(member, (list, tuple)) else [member]):
                 add(t, cl[0], ci, inner, mi)
