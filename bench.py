@@ -80,7 +80,7 @@ def parse_args(argv=None):
                          "timed region; roofline.traffic / frac then come from profiles/traffic.json if its kernel hash matches)")
     ap.add_argument("--pmc-child", default=None, help="(internal) the workload a rocprofv3 pass of --pmc-inline runs")
     ap.add_argument("--no-stream", action="store_true", help="skip the stream block (different batches, Query::weight timed)")
-    ap.add_argument("--stream-vocabs", default="256,4096,65536",
+    ap.add_argument("--stream-vocabs", default="256,4096,65536,1048576",
                     help="vocabularies of the stream block (comma separated; each its own 10M-doc segment)")
     ap.add_argument("--stream-batches", type=int, default=24)
     ap.add_argument("--stream-serial", action="store_true",
@@ -805,7 +805,7 @@ def stream_block(O, D, cl, torch, args, vocab, seg, n_batches, n_q, k):
     wall2 = time.perf_counter() - t2
     st2 = runner.batch_stats()
     # the last batch against the oracle (a stream that returned wrong rows fast would be worthless)
-    checked = spot_check(O, cl, [seg], cl.rank, None, "and2", batches[-1], k, runner.results(), 32)
+    checked = spot_check(O, cl, [seg], cl.rank, None, "and2", batches[-1], k, runner.results(), 256)
     seg_stats = runner.dev.segment_stats(0)
     runner.close()
     del first

@@ -208,7 +208,11 @@ void tq_segment_free(tq_segment *s) {
   s->d_out_docs.release();
   s->d_out_counts.release();
   s->d_misc.release();
-  s->h_prep_stage.release();
+  for (int i = 0; i < 2; ++i) {
+    s->h_prep_stage[i].release();
+    if (s->ev_prep[i]) (void)hipEventDestroy(s->ev_prep[i]);
+  }
+  if (s->ev_prep_order) (void)hipEventDestroy(s->ev_prep_order);
   s->d_thr.release();
   tq_free_plan_scratch(s->plan);
   s->plan = nullptr;

@@ -315,7 +315,13 @@ struct tq_segment {
   Options opt;
   size_t dense_budget() const { return (size_t)opt.dense_budget_x * (idx_len + pos_len + max_doc); }
   size_t probe_budget() const { return (size_t)opt.probe_budget_x * (idx_len + pos_len + max_doc); }
-  PinnedBuf h_prep_stage;  // tq_term_prepare_batch: the blobs of a batch's new terms on their way up
+  // tq_term_prepare_batch: the blobs of a batch's new terms on their way up (two buffers, an event each), and which
+  // of the two events the next batch has to wait for (-1: none)
+  PinnedBuf h_prep_stage[2];
+  hipEvent_t ev_prep[2] = {nullptr, nullptr}, ev_prep_order = nullptr;
+  bool prep_used[2] = {false, false};
+  uint32_t prep_calls = 0;
+  int prep_pending = -1;
   size_t probe_bytes_total = 0;
   bool probe_full = false;  // (kept for tq_set_option; the pool below evicts instead of latching)
   // Probe pool (round 6): the private tables of lists below "dense_ratio" live in equal SLOTS — [bitmap + rank
@@ -333,6 +339,9 @@ struct tq_segment {
   size_t probe_slot_bytes = 0, probe_bm_bytes = 0, probe_tf_cap = 0, probe_dir_cap = 0, probe_rm_bytes = 0;
   uint64_t probe_batch = 1;        // sequence number of the batch being planned
   uint64_t probe_evictions = 0;
+  uint64_t probe_replaced_batch = 0;  // ... and how many slots such candidates took over in it
+  uint32_t probe_replaced_n = 0;
+  uint64_t probe_no_room_batch = 0;  // the batch in which a shared-launch candidate found no slot to take
   bool probe_waited = false;       // this batch already waited for the batches in flight before reusing a slot
   bool device_prepare() const { return h_idx.empty() || opt.device_prepare != 0; }
   tq_batch_stats stats{};
@@ -683,7 +692,9 @@ void mark_term_dirty(tq_segment *s, uint32_t handle);
 int build_flat(tq_segment *s, uint32_t handle, hipStream_t st, bool *ok);
 int order_after_last_batch(tq_segment *s, hipStream_t st);
 int wait_segment_idle(tq_segment *s);
-int build_probe_tables(tq_segment *s, uint32_t handle, bool *ok, bool any_size = false);
+// must: the caller cannot run without the tables (nested boolean queries): any segment size, the least recently used
+// slot if none is free; else: only a free slot or one idle for a while
+int build_probe_tables(tq_segment *s, uint32_t handle, bool *ok, bool must = false);
 int build_probe_posdir(tq_segment *s, uint32_t handle, bool *ok);
 void probe_begin_batch(tq_segment *s);             // a new batch is being planned (the pool's clock)
 void probe_touch(tq_segment *s, uint32_t handle);  // the batch being planned uses the list's probe tables

@@ -15,6 +15,10 @@ int search_batch_impl(tq_segment *s, const tq_query *queries, uint32_t n_queries
   const auto tr0 = std::chrono::steady_clock::now();
   HIP_TRY(hipSetDevice(s->device));
   hipStream_t st = hip_stream ? (hipStream_t)hip_stream : s->stream;
+  if (s->prep_pending >= 0) {  // terms uploaded by tq_term_prepare_batch on the copy stream: this batch reads them
+    if (st != s->stream) HIP_TRY(hipStreamWaitEvent(st, s->ev_prep[s->prep_pending], 0));
+    s->prep_pending = -1;
+  }
   // Terms prepared since the last batch: their records are APPENDED to the device table through this batch's
   // staging blob (a device-to-device copy on the batch's stream, below) — the batches in flight never read beyond
   // the records they were planned with, so nothing waits for them.  A grown table, or a changed record that a

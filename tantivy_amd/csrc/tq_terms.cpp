@@ -267,8 +267,12 @@ static int host_walk_term(tq_segment *s, uint64_t postings_off, uint32_t posting
   const size_t payload = at;
 
   const uint32_t n_blocks = n_full + (n_tail ? 1u : 0u);
-  std::vector<uint32_t> b_last(n_blocks), b_meta(n_blocks), b_off(n_blocks);
-  std::vector<uint32_t> block_pos(n_blocks + 1, 0);
+  // (scratch kept per thread: eight allocations per term were a third of a sparse term's walk)
+  static thread_local std::vector<uint32_t> b_last, b_meta, b_off, block_pos, tail_docs, tail_tfs, coarse;
+  b_last.assign(n_blocks, 0u);
+  b_meta.assign(n_blocks, 0u);
+  b_off.assign(n_blocks, 0u);
+  block_pos.assign(n_blocks + 1, 0u);
   size_t running = 0;
   uint64_t running_pos = 0;
   uint32_t last_doc = 0;
@@ -300,7 +304,8 @@ static int host_walk_term(tq_segment *s, uint64_t postings_off, uint32_t posting
     last_doc = ld;
   }
   if (payload + running > len) return fail(TQ_ERR_FORMAT, "bitpacked payload exceeds the list");
-  std::vector<uint32_t> tail_docs(n_tail), tail_tfs(n_tail, 1u);
+  tail_docs.assign(n_tail, 0u);
+  tail_tfs.assign(n_tail, 1u);
   if (n_tail) {  // vint.rs:44-108; docs delta from the last full block (0 if none)
     size_t t = payload + running;
     uint32_t prev = n_full ? last_doc : 0u;
@@ -336,7 +341,7 @@ static int host_walk_term(tq_segment *s, uint64_t postings_off, uint32_t posting
   uint32_t shift = 7;
   while (shift < 31 && ((uint64_t)(s->max_doc - 1) >> shift) + 1 > 2ull * n_blocks + 2) ++shift;
   const uint32_t n_buckets = (uint32_t)(((uint64_t)(s->max_doc - 1)) >> shift) + 1;
-  std::vector<uint32_t> coarse(n_buckets + 1);
+  coarse.assign(n_buckets + 1, 0u);
   {
     uint32_t j = 0;
     for (uint32_t b = 0; b <= n_buckets; ++b) {
@@ -501,19 +506,38 @@ int tq_term_prepare(tq_segment *s, uint64_t postings_off, uint32_t postings_len,
 // segment).  out[i] = the handle of infos[i] (known terms: the one they have).
 int tq_term_prepare_batch(tq_segment *s, const tq_term_info *infos, uint32_t n, tq_term_handle *out) {
   if (!s || (!infos && n) || (!out && n)) return fail(TQ_ERR_INVALID, "tq_term_prepare_batch: null argument");
-  TQ_SEGMENT_LOCK(s);
-  HIP_TRY(hipSetDevice(s->device));
   std::vector<uint32_t> fresh;  // indices of infos that need preparing
-  for (uint32_t i = 0; i < n; ++i) {
-    auto it = s->term_by_off.find(infos[i].postings_off);
-    if (it != s->term_by_off.end()) {
-      out[i] = it->second;
-      continue;
+  {
+    TQ_SEGMENT_LOCK(s);
+    for (uint32_t i = 0; i < n; ++i) {
+      auto it = s->term_by_off.find(infos[i].postings_off);
+      if (it != s->term_by_off.end()) {
+        out[i] = it->second;
+        continue;
+      }
+      out[i] = TQ_TERM_ABSENT;
+      fresh.push_back(i);
     }
-    out[i] = TQ_TERM_ABSENT;
-    fresh.push_back(i);
   }
   if (fresh.empty()) return TQ_OK;
+  // The host walk of the new lists runs WITHOUT the segment's lock (it reads the host copy of the index and a few
+  // options): a second host thread can walk the next batch's terms while the first plans and enqueues this one.
+  std::vector<WalkedTerm> prewalked;
+  std::vector<char> prewalked_ok;
+  if (!s->device_prepare()) {
+    const size_t body = s->idx_len - 8;
+    prewalked.resize(fresh.size());
+    prewalked_ok.assign(fresh.size(), 0);
+    for (size_t k = 0; k < fresh.size(); ++k) {
+      const tq_term_info &ti = infos[fresh[k]];
+      if (ti.doc_freq == 0 || ti.postings_off > body || (uint64_t)ti.postings_len > body - ti.postings_off) continue;  // (reported below)
+      if (s->opt.dense && s->max_doc >= 4096u && (uint64_t)ti.doc_freq * (uint64_t)s->opt.dense_ratio >= s->max_doc) continue;
+      if (host_walk_term(s, ti.postings_off, ti.postings_len, ti.positions_off, ti.positions_len, ti.doc_freq, prewalked[k]) == TQ_OK)
+        prewalked_ok[k] = 1;  // (a malformed list: walked again under the lock, where its error is reported)
+    }
+  }
+  TQ_SEGMENT_LOCK(s);
+  HIP_TRY(hipSetDevice(s->device));
   const size_t dense_bytes = (((size_t)s->max_doc + 31) / 32 + 1) * sizeof(uint2);
   auto one_by_one = [&](uint32_t i) {
     return tq_term_prepare(s, infos[i].postings_off, infos[i].postings_len, infos[i].positions_off, infos[i].positions_len,
@@ -531,9 +555,9 @@ int tq_term_prepare_batch(tq_segment *s, const tq_term_info *infos, uint32_t n, 
   std::vector<uint32_t> walked_of;
   walked.reserve(fresh.size());
   size_t stage_bytes = 0;
-  for (uint32_t i : fresh) {
+  for (const uint32_t &i : fresh) {
     const tq_term_info &ti = infos[i];
-    if (s->term_by_off.count(ti.postings_off)) {  // (named twice in this call)
+    if (s->term_by_off.count(ti.postings_off)) {  // (named twice in this call, or prepared by another thread meanwhile)
       out[i] = s->term_by_off[ti.postings_off];
       continue;
     }
@@ -552,39 +576,48 @@ int tq_term_prepare_batch(tq_segment *s, const tq_term_info *infos, uint32_t n, 
       }
       continue;
     }
-    walked.emplace_back();
-    const int wrc = host_walk_term(s, ti.postings_off, ti.postings_len, ti.positions_off, ti.positions_len, ti.doc_freq, walked.back());
-    if (wrc != TQ_OK) return wrc;
+    const size_t fk = (size_t)(&i - fresh.data());
+    if (fk < prewalked_ok.size() && prewalked_ok[fk]) {
+      walked.push_back(std::move(prewalked[fk]));
+    } else {
+      walked.emplace_back();
+      const int wrc = host_walk_term(s, ti.postings_off, ti.postings_len, ti.positions_off, ti.positions_len, ti.doc_freq, walked.back());
+      if (wrc != TQ_OK) return wrc;
+    }
     walked_of.push_back(i);
     stage_bytes += (walked.back().total + 255) & ~(size_t)255;
   }
   if (!walked.empty()) {
-    // blobs: device room from the slabs, bytes through one pinned buffer, asynchronous copies on the segment's stream
-    const size_t ptr_bytes = walked.size() * (sizeof(const TqdTerm *) + sizeof(uint32_t)) + 64;
-    int rc = s->h_prep_stage.ensure(stage_bytes + ptr_bytes);
+    // blobs: ONE device region for the lot, the bytes through one of two pinned buffers, one asynchronous copy on the
+    // segment's copy stream — and no wait: an event orders every later reader (the next batch's kernels, table
+    // builders on the segment's stream) behind the copy and the signature launch.  (A copy per term was 3 us of host
+    // time each; a wait for the segment's stream stalled the batches in flight for a millisecond per call.)
+    hipStream_t cs = s->copy_stream ? s->copy_stream : s->stream;
+    const size_t ptr_bytes = (walked.size() * (sizeof(const TqdTerm *) + sizeof(uint32_t)) + 255) & ~(size_t)255;
+    const uint32_t bx = s->prep_calls++ & 1u;
+    if (!s->ev_prep[bx]) HIP_TRY(hipEventCreateWithFlags(&s->ev_prep[bx], hipEventDisableTiming));
+    if (s->prep_used[bx]) HIP_TRY(hipEventSynchronize(s->ev_prep[bx]));  // (the copy of two calls ago: long done)
+    int rc = s->h_prep_stage[bx].ensure(stage_bytes + ptr_bytes);
     if (rc != TQ_OK) return rc;
-    uint8_t *hs = (uint8_t *)s->h_prep_stage.p;
+    uint8_t *hs = (uint8_t *)s->h_prep_stage[bx].p;
     size_t at = 0;
-    hipError_t e = hipSuccess;
+    uint8_t *region = nullptr;
+    rc = term_alloc(s, stage_bytes + ptr_bytes, &region);
+    if (rc != TQ_OK) return rc;
+    s->bytes_term_tables += stage_bytes + ptr_bytes;
     for (WalkedTerm &w : walked) {
-      uint8_t *blob = nullptr;
-      rc = term_alloc(s, w.total, &blob);
-      if (rc != TQ_OK) return rc;
-      s->bytes_term_tables += w.total;
-      place_walked_term(w, blob);
+      place_walked_term(w, region + at);
       memcpy(hs + at, w.hb.data(), w.total);
-      if (e == hipSuccess) e = hipMemcpyAsync(blob, hs + at, w.total, hipMemcpyHostToDevice, s->stream);
       at += (w.total + 255) & ~(size_t)255;
     }
-    if (e != hipSuccess) return fail(TQ_ERR_HIP, "term upload: %s", hipGetErrorString(e));
-    // handles; which of them get signature bits
+    // handles; which of them get signature bits (their record pointers and bits ride behind the blobs)
     const bool sigs = s->opt.docsig && s->opt.docmat && s->opt.dense && s->max_doc >= 4096u;
     if (sigs) {
       rc = ensure_docmat(s);
       if (rc != TQ_OK) return rc;
     }
     const TqdTerm **h_selfs = (const TqdTerm **)(hs + stage_bytes);
-    uint32_t *h_bits = (uint32_t *)(h_selfs + walked.size());
+    std::vector<uint32_t> bits;
     uint32_t n_sig = 0;
     for (size_t k = 0; k < walked.size(); ++k) {
       WalkedTerm &w = walked[k];
@@ -597,25 +630,29 @@ int tq_term_prepare_batch(tq_segment *s, const tq_term_info *infos, uint32_t n, 
       out[walked_of[k]] = handle;
       if (sigs && s->d_docmat && w.th.doc_freq) {
         const uint32_t bit = (handle * 0x9E3779B1u) >> (32 - 4);  // (add_to_doc_signatures' bit)
-        h_selfs[n_sig] = w.th.d_self;
-        h_bits[n_sig] = bit;
-        ++n_sig;
+        h_selfs[n_sig++] = w.th.d_self;
+        bits.push_back(bit);
         s->h_dterms[handle].has_freq |= (bit + 1u) << 16;
       }
     }
-    if (n_sig) {
-      rc = s->d_misc.ensure((size_t)n_sig * (sizeof(const TqdTerm *) + sizeof(uint32_t)) + 64);
-      if (rc != TQ_OK) return rc;
-      const TqdTerm **d_selfs = (const TqdTerm **)s->d_misc.p;
-      uint32_t *d_bits = (uint32_t *)(d_selfs + n_sig);
-      // (the bits follow the pointers in the staging buffer: compact them behind n_sig pointers first)
-      memmove(h_selfs + n_sig, h_bits, (size_t)n_sig * sizeof(uint32_t));
-      e = hipMemcpyAsync(d_selfs, h_selfs, (size_t)n_sig * (sizeof(const TqdTerm *) + sizeof(uint32_t)), hipMemcpyHostToDevice, s->stream);
-      if (e == hipSuccess)
-        e = tqk_launch_docsig_batch(s->dseg, d_selfs, d_bits, n_sig, s->d_docmat, s->opt.use_dpp != 0, s->stream);
-      if (e != hipSuccess) return fail(TQ_ERR_HIP, "signature launch: %s", hipGetErrorString(e));
+    if (n_sig) memcpy(h_selfs + n_sig, bits.data(), (size_t)n_sig * sizeof(uint32_t));
+    // (the doc matrix may just have been created on the segment's stream: the copy stream follows it)
+    hipError_t e = hipSuccess;
+    if (cs != s->stream) {
+      if (!s->ev_prep_order) e = hipEventCreateWithFlags(&s->ev_prep_order, hipEventDisableTiming);
+      if (e == hipSuccess) e = hipEventRecord(s->ev_prep_order, s->stream);
+      if (e == hipSuccess) e = hipStreamWaitEvent(cs, s->ev_prep_order, 0);
     }
-    HIP_TRY(hipStreamSynchronize(s->stream));  // (the staging buffer and d_misc are reused by the next call)
+    if (e == hipSuccess) e = hipMemcpyAsync(region, hs, stage_bytes + ptr_bytes, hipMemcpyHostToDevice, cs);
+    if (e == hipSuccess && n_sig) {
+      const TqdTerm **d_selfs = (const TqdTerm **)(region + stage_bytes);
+      e = tqk_launch_docsig_batch(s->dseg, d_selfs, (const uint32_t *)(d_selfs + n_sig), n_sig, s->d_docmat, s->opt.use_dpp != 0, cs);
+    }
+    if (e == hipSuccess) e = hipEventRecord(s->ev_prep[bx], cs);
+    if (e == hipSuccess && cs != s->stream) e = hipStreamWaitEvent(s->stream, s->ev_prep[bx], 0);
+    if (e != hipSuccess) return fail(TQ_ERR_HIP, "term upload: %s", hipGetErrorString(e));
+    s->prep_used[bx] = true;
+    s->prep_pending = (int)bx;  // (the next batch on a stream of the caller's waits for the event too: tq_search.cpp)
   }
   for (uint32_t i : fresh)  // (a term named twice in one call)
     if (out[i] == TQ_TERM_ABSENT) {
@@ -925,14 +962,17 @@ namespace {
 // (its owner loses its tables: the batches in flight are waited for first), else — every slot belongs to the batch
 // being planned — one more.  *slot = -1: the list does not fit a slot (more postings than max_doc / 32: such a list
 // gets tables of its own long before the budget of the dense lists is used up).
-int probe_slot_acquire(tq_segment *s, uint32_t handle, int32_t *slot) {
+int probe_slot_acquire(tq_segment *s, uint32_t handle, bool must, int32_t *slot, bool *no_room) {
+  *no_room = false;
   *slot = -1;
   TermHost &t = s->terms[handle];
   if (!s->probe_slot_bytes) {
     const size_t n_words = ((size_t)s->max_doc + 31) / 32 + 1;
     auto up = [](size_t x) { return (x + 255) & ~(size_t)255; };
     s->probe_bm_bytes = up(n_words * sizeof(uint2));
-    s->probe_tf_cap = up(std::max<size_t>((size_t)s->max_doc / 32u, 4096u) + PAD);
+    // (lists below "dense_ratio" are the ones that need probe tables: max_doc / dense_ratio postings at most; a longer
+    // list that did not get tables of its own takes the oversize road of build_probe_tables)
+    s->probe_tf_cap = up(std::max<size_t>((size_t)s->max_doc / (size_t)std::max(1, std::min(s->opt.dense_ratio, 1 << 20)), 4096u) + PAD);
     s->probe_dir_cap = up(s->probe_tf_cap + 16 + PAD);  // ((df + 3) / 4 + 1) * 4 bytes
     s->probe_rm_bytes = up(tqd_rm_level_off(s->max_doc, TQD_RM_LEVELS));
     s->probe_slot_bytes = s->probe_bm_bytes + s->probe_tf_cap + s->probe_dir_cap + s->probe_rm_bytes;
@@ -943,14 +983,36 @@ int probe_slot_acquire(tq_segment *s, uint32_t handle, int32_t *slot) {
   for (size_t i = 0; i < s->probe_slots.size() && pick < 0; ++i)
     if (s->probe_slots[i].owner == 0xFFFFFFFFu) pick = (int32_t)i;
   if (pick < 0 && s->probe_slots.size() >= budget_slots) {  // least recently used, not by this batch
-    uint64_t oldest = s->probe_batch;
+    // (a query that can run without the tables — a shared-launch candidate — only takes a slot nobody has used for
+    // kIdle batches: with a working set above the budget plain LRU rebuilt hundreds of tables per batch, 47 ms of
+    // host time at 4 096 terms; a nested query MUST have its bitmaps and takes the least recently used slot)
+    static const uint64_t kIdle = std::max<uint32_t>(1u, tune_u32("TQ_PROBE_IDLE_BATCHES", 64));
+    uint64_t oldest = must ? s->probe_batch : (s->probe_batch > kIdle ? s->probe_batch - kIdle : 0);
     for (size_t i = 0; i < s->probe_slots.size(); ++i)
       if (s->probe_slots[i].last_batch < oldest) {
         oldest = s->probe_slots[i].last_batch;
         pick = (int32_t)i;
       }
+    if (pick < 0 && !must) {
+      *no_room = true;
+      s->probe_no_room_batch = s->probe_batch;  // (the rest of this batch does not scan the slots again)
+      return TQ_OK;
+    }
+    if (pick >= 0 && !must) {  // (a full pool takes few new lists per batch from callers that can do without)
+      static const uint32_t kPerBatch = tune_u32("TQ_PROBE_REPLACE_PER_BATCH", 1);
+      if (s->probe_replaced_batch != s->probe_batch) {
+        s->probe_replaced_batch = s->probe_batch;
+        s->probe_replaced_n = 0;
+      }
+      if (s->probe_replaced_n++ >= kPerBatch) {
+        *no_room = true;
+        s->probe_no_room_batch = s->probe_batch;
+        return TQ_OK;
+      }
+    }
     if (pick >= 0) {
-      if (!s->probe_waited) {  // a batch in flight may still read the slot
+      // a batch in flight may still read the slot — unless nobody has used it for three batches (two are in flight at most)
+      if (!s->probe_waited && s->probe_slots[(size_t)pick].last_batch + 3 > s->probe_batch) {
         const int wrc = wait_segment_idle(s);
         if (wrc != TQ_OK) return wrc;
         s->probe_waited = true;
@@ -992,7 +1054,8 @@ void probe_slot_release(tq_segment *s, uint32_t handle) {  // (a failed build)
 }
 }  // namespace
 
-int build_probe_tables(tq_segment *s, uint32_t handle, bool *ok, bool any_size) {
+int build_probe_tables(tq_segment *s, uint32_t handle, bool *ok, bool must) {
+  const bool any_size = must;
   TermHost &t = s->terms[handle];
   *ok = (t.dense_blob && t.tf8_blob) || (t.probe_dense_blob && t.probe_tf8_blob);
   if (*ok) {
@@ -1000,14 +1063,16 @@ int build_probe_tables(tq_segment *s, uint32_t handle, bool *ok, bool any_size) 
     return TQ_OK;
   }
   if (!s->opt.dense || !s->opt.use_dense || !t.doc_freq || s->opt.probe_budget_x <= 0) return TQ_OK;
+  if (!must && s->probe_no_room_batch == s->probe_batch) return TQ_OK;
   // (segments below 4096 docs: the shared launches are not used there — only nested boolean queries, which reach every
   // list through a bitmap whatever the segment's size, ask with any_size)
   if (s->max_doc < 4096u && !any_size) return TQ_OK;
   const size_t n_words = ((size_t)s->max_doc + 31) / 32 + 1;
   HIP_TRY(hipSetDevice(s->device));
   int32_t slot = -1;
-  int rc = probe_slot_acquire(s, handle, &slot);
-  if (rc != TQ_OK) return rc;
+  bool no_room = false;
+  int rc = probe_slot_acquire(s, handle, must, &slot, &no_room);
+  if (rc != TQ_OK || no_room) return rc;
   uint8_t *base = nullptr;
   if (slot >= 0) {
     base = s->probe_slots[(size_t)slot].base;

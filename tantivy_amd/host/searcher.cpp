@@ -97,6 +97,55 @@ tq_term_handle SegmentReader::term_handle(uint32_t term_id) {
   return handle;
 }
 
+void SegmentReader::prepare_terms(const uint32_t *term_ids, size_t n) {
+  // the ones without a handle yet, each once
+  std::vector<uint32_t> fresh;
+  {
+    std::atomic<tq_term_handle> *fast = fast_handles_.load(std::memory_order_acquire);
+    std::unordered_map<uint32_t, char> seen;
+    for (size_t i = 0; i < n; ++i) {
+      const uint32_t t = term_ids[i];
+      if (t < kFastHandles && fast && fast[t].load(std::memory_order_acquire) != kHandleUnknown) continue;
+      if (!seen.emplace(t, 1).second) continue;
+      {
+        std::lock_guard<std::mutex> lk(m_);
+        if (handles_.count(t)) continue;
+      }
+      fresh.push_back(t);
+    }
+  }
+  if (fresh.size() < 2) return;  // (one term: term_handle's own road)
+  std::vector<tq_term_info> infos;
+  std::vector<uint32_t> ids;
+  for (uint32_t t : fresh) {
+    const TermInfo *ti = get_term_info(t);
+    if (!ti) continue;  // (absent: term_handle records TQ_TERM_ABSENT)
+    tq_term_info x{};
+    x.postings_off = ti->postings_start;
+    x.postings_len = (uint32_t)(ti->postings_end - ti->postings_start);
+    x.positions_off = ti->positions_start;
+    x.positions_len = (uint32_t)(ti->positions_end - ti->positions_start);
+    x.doc_freq = ti->doc_freq;
+    infos.push_back(x);
+    ids.push_back(t);
+  }
+  if (infos.empty()) return;
+  std::vector<tq_term_handle> hs(infos.size(), TQ_TERM_ABSENT);
+  const int rc = tq_term_prepare_batch(seg_, infos.data(), (uint32_t)infos.size(), hs.data());
+  if (rc != TQ_OK) throw_tq(rc);
+  std::lock_guard<std::mutex> lk(m_);
+  std::atomic<tq_term_handle> *fast = fast_handles_.load(std::memory_order_relaxed);
+  if (!fast) {
+    fast = new std::atomic<tq_term_handle>[kFastHandles];
+    for (uint32_t i = 0; i < kFastHandles; ++i) fast[i].store(kHandleUnknown, std::memory_order_relaxed);
+    fast_handles_.store(fast, std::memory_order_release);
+  }
+  for (size_t i = 0; i < ids.size(); ++i) {
+    handles_[ids[i]] = hs[i];
+    if (ids[i] < kFastHandles) fast[ids[i]].store(hs[i], std::memory_order_release);
+  }
+}
+
 Searcher::Searcher(std::vector<std::shared_ptr<SegmentReader>> segments)
     : segments_(std::move(segments)) {}
 Searcher::~Searcher() { delete[] fast_weights_.load(std::memory_order_relaxed); }
@@ -427,6 +476,12 @@ struct SegmentBatch {
     size_t total_terms = 0;
     for (auto &w : weights) total_terms += w.terms.size();
     handles.reserve(total_terms);
+    if (n > 1) {  // the batch's new terms are prepared together before any handle is asked for
+      std::vector<uint32_t> all;
+      all.reserve(total_terms);
+      for (auto &w : weights) all.insert(all.end(), w.terms.begin(), w.terms.end());
+      seg.prepare_terms(all.data(), all.size());
+    }
     for (size_t i = 0; i < n; ++i) {
       const Weight &w = weights[i];
       const size_t at = handles.size();

@@ -68,6 +68,9 @@ class SegmentReader {
   void set_term_info_store(std::shared_ptr<const class TermInfoStore> store);
   const TermInfo *get_term_info(uint32_t term_id) const;  // None => nullptr
   tq_term_handle term_handle(uint32_t term_id);            // prepares on first use
+  // the terms of a batch that no query has named yet, prepared TOGETHER (tq_term_prepare_batch: one staged upload,
+  // one signature launch) — term_handle then finds every one of them
+  void prepare_terms(const uint32_t *term_ids, size_t n);
   uint32_t max_doc() const { return max_doc_; }
   uint32_t segment_ord() const { return segment_ord_; }
   uint64_t total_num_tokens() const { return total_num_tokens_; }  // inverted_index_reader.rs:72-73
