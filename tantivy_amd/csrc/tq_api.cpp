@@ -200,6 +200,7 @@ void tq_segment_free(tq_segment *s) {
   if (s->d_fn) (void)hipFree(s->d_fn);
   if (s->d_alive) (void)hipFree(s->d_alive);
   if (s->d_docmat) (void)hipFree(s->d_docmat);
+  if (s->d_doccls) (void)hipFree(s->d_doccls);
   if (s->d_tp_info) (void)hipFree(s->d_tp_info);
   if (s->d_local_cache) (void)hipFree(s->d_local_cache);
   if (s->d_match_counter) (void)hipFree(s->d_match_counter);

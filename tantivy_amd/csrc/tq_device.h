@@ -14,6 +14,7 @@
 #define TQD_THR_SLOTS 64      // shared threshold slots per query (pruned mode)
 #define TQD_OR_WINDOW 4096    // docs per OR tile (one workgroup)
 #define TQD_MAT_SLOTS 40      // dense lists per segment with a column in the doc matrix (bits 8..47 of a word)
+#define TQD_CLS_SLOTS 32     // column lists with a 2-bit tf class per doc in TqdSegment::doccls
 #define TQD_SIG_SHIFT 48      // bits 48..63 of a doc-matrix word: the signature of the lists WITHOUT a column
 #define TQD_SIG_BITS 16
 // Range maxima of a list with a bitmap (tq_terms.cpp build_rmax, tq_ashare.hip): level l holds one byte per
@@ -52,7 +53,8 @@ struct TqdTermHead {  // what every kernel needs: fetched with scalar loads
   uint64_t payload_base;      // absolute offset (inside the .idx sub-file) of block 0's payload
   uint32_t n_blocks, n_tail;
   uint32_t has_freq;          // bit 0: 0 => every tf reads as 1; bits 8..15: doc-matrix slot + 1 (0 = none);
-                              // bits 16..23: signature bit (0..15) + 1 of a list without a column (0 = none)
+                              // bits 16..23: signature bit (0..15) + 1 of a list without a column (0 = none);
+                              // bit 24: the list's tf classes are in TqdSegment::doccls (its slot < TQD_CLS_SLOTS)
   uint32_t coarse_shift;
 };
 struct TqdTerm : TqdTermHead {
@@ -193,6 +195,10 @@ struct TqdSegment {
   // membership in every dense list of the query — the scan kernels are bound by the number of
   // divergent gathers, not by bytes.  Derived data, built at tq_term_prepare like the bitmaps.
   const uint64_t *docmat;
+  // tf classes of the first TQD_CLS_SLOTS column lists, or null: doccls[d] holds 2 bits per column slot — 0 the doc is
+  // not in the list, 1 / 2 its term freq, 3 = three or more (read the tf byte).  ONE 8-byte gather bounds a phrase
+  // candidate by min tf before any of its lists is touched (tq_phrase.hip); the exact tf of ~90 % of the postings.
+  const uint64_t *doccls;
   uint32_t max_doc;
   uint32_t const_fieldnorm_id;
   uint32_t min_fieldnorm_id;  // smallest fieldnorm id present (lower bound of every doc's norm)

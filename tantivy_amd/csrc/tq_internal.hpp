@@ -242,6 +242,7 @@ struct tq_segment {
   float *d_local_cache = nullptr;  // Bm25Weight.cache under the segment's OWN average fieldnorm (256 floats; null:
                                    // the header holds no usable token count): what the range maxima are built under
   uint64_t *d_docmat = nullptr;  // doc-major matrix of the dense lists (TqdSegment::docmat)
+  uint64_t *d_doccls = nullptr;  // tf classes of the first TQD_CLS_SLOTS column lists (TqdSegment::doccls)
   uint32_t n_mat_slots = 0;
   TqdSegment dseg{};
   std::vector<TermHost> terms;

@@ -226,6 +226,9 @@ struct TqkZeroParams {
   uint32_t words[TQK_ZERO_MAX];
   uint32_t n;
 };
+// tf classes of a column list into TqdSegment::doccls (slot < TQD_CLS_SLOTS; the words zeroed at allocation)
+hipError_t tqk_launch_doccls_set(uint64_t *cls, const uint32_t *docs, const uint32_t *tfs, uint32_t n, uint32_t slot,
+                                 uint32_t max_doc, hipStream_t st);
 hipError_t tqk_launch_zero(const TqkZeroParams &p, hipStream_t st);
 // signature bits (TQD_SIG_SHIFT + bits[i]) of n lists, given by their own records, into the doc matrix: one launch
 hipError_t tqk_launch_docsig_batch(const TqdSegment &seg, const TqdTerm *const *selfs, const uint32_t *bits, uint32_t n,

@@ -214,6 +214,16 @@ __global__ __launch_bounds__(256) void docsig_batch_kernel(TqdSegment seg, const
   }
 }
 
+__global__ void doccls_set_kernel(uint64_t *cls, const uint32_t *docs, const uint32_t *tfs, uint32_t n, uint32_t slot,
+                                  uint32_t max_doc) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n && docs[i] < max_doc) {
+    const uint32_t tf = tfs[i];
+    const uint64_t c = tf >= 3u ? 3ull : (tf ? (uint64_t)tf : 3ull);  // (tf 0 — a corrupt index — reads the tf byte)
+    atomicOr((unsigned long long *)(cls + docs[i]), (unsigned long long)(c << (2u * slot)));
+  }
+}
+
 __global__ void tf8_pack_kernel(const uint32_t *tfs, uint32_t n, uint8_t *out) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) out[i] = (uint8_t)(tfs[i] < 255u ? tfs[i] : 255u);
@@ -248,6 +258,12 @@ hipError_t tqk_launch_docsig_batch(const TqdSegment &seg, const TqdTerm *const *
     hipLaunchKernelGGL((docsig_batch_kernel<true>), dim3(n), dim3(256), 0, st, seg, selfs, bits, mat);
   else
     hipLaunchKernelGGL((docsig_batch_kernel<false>), dim3(n), dim3(256), 0, st, seg, selfs, bits, mat);
+  return hipGetLastError();
+}
+hipError_t tqk_launch_doccls_set(uint64_t *cls, const uint32_t *docs, const uint32_t *tfs, uint32_t n, uint32_t slot,
+                                 uint32_t max_doc, hipStream_t st) {
+  if (n == 0) return hipSuccess;
+  hipLaunchKernelGGL(doccls_set_kernel, dim3((n + 255) / 256), dim3(256), 0, st, cls, docs, tfs, n, slot, max_doc);
   return hipGetLastError();
 }
 hipError_t tqk_launch_zero(const TqkZeroParams &p, hipStream_t st) {

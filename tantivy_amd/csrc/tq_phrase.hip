@@ -676,6 +676,8 @@ constexpr uint32_t SWEEP_WORDS = 2048; // bitmap words per tile (65536 docs)
 constexpr uint32_t SWEEP_UNROLL = TQ_PH_SWEEP_UNROLL;  // 64-word steps whose loads are in flight together
 struct SweepLds {  // per wavefront
   uint32_t q_doc[191];  // (< 64 leftovers + up to 64 new docs per extraction step)
+  uint32_t q0_doc[127]; // pruned mode with tf classes: the extraction's docs before the class test (stage P)
+  uint32_t cls_sh[SWEEP_NT];  // ... and the shifts of the phrase's lists in a doc's class word
   const uint32_t *bits[SWEEP_NT];
   const uint2 *dense[SWEEP_NT];
   const uint8_t *tf8[SWEEP_NT];
@@ -709,6 +711,10 @@ __global__ __launch_bounds__(64, TQ_PH_SWEEP_WAVES) void phrase_sweep_kernel(Tqk
   // k-th best score) and the bound itself, sortable score bits
   uint32_t *slots = nullptr;
   uint32_t thr_g = 0;
+  // ... and, when every list of the phrase has its tf classes in the segment's class matrix (TqdSegment::doccls), the
+  // shifts of its lists in a doc's class word: stage P bounds a candidate with ONE 8-byte gather + its fieldnorm byte
+  bool cls_ok = false;
+  uint32_t q0n = 0;
 
   auto setup_query = [&]() __attribute__((always_inline)) {
     q_tile_start = sload(p.tile_starts + q);
@@ -722,6 +728,12 @@ __global__ __launch_bounds__(64, TQ_PH_SWEEP_WAVES) void phrase_sweep_kernel(Tqk
       const bool prune = !p.exhaustive && (sload(&Q->flags) & TQD_QF_PRUNE) != 0u && thr_index != 0xFFFFFFFFu;
       slots = prune ? p.thr_slots + (size_t)thr_index * TQD_THR_SLOTS : nullptr;
       thr_g = 0;
+      cls_ok = slots != nullptr && seg.doccls != nullptr;
+      for (uint32_t m = 0; m < nt; ++m) {
+        const uint32_t hf = sload(&(p.terms + sload(&Q->term[m]))->has_freq);
+        cls_ok = cls_ok && ((hf >> 24) & 1u);
+        if (lane == 0) L.cls_sh[m] = 2u * (((hf >> 8) & 0xFFu) - 1u);
+      }
     }
     tk.reset(sload(&Q->k));
     wave_mem_fence();
@@ -927,8 +939,56 @@ __global__ __launch_bounds__(64, TQ_PH_SWEEP_WAVES) void phrase_sweep_kernel(Tqk
     }
   };
 
+  // ---- stage P (pruned mode, every list has tf classes): 64 docs of the AND, one per lane — ONE class word + the
+  // fieldnorm byte per doc: count <= min tf, so bm25(weight, norm, min tf) bounds the doc; below the query's threshold it
+  // never reaches the scoring stage (ten gathers: rank words, tf bytes, directory entries).  Class 3 = "three or more":
+  // no bound.  Survivors -> q_doc.
+  auto stageP = [&](uint32_t n) __attribute__((always_inline)) {
+    const uint32_t base = q0n - n;
+    q0n = base;
+    const bool alive = (uint32_t)lane < n;
+    uint32_t doc = 0;
+    if (alive) doc = L.q0_doc[base + lane];
+    const uint64_t cw = alive ? seg.doccls[doc] : 0ull;
+    const uint32_t nid = alive ? fieldnorm_id(seg, doc) : 0u;
+    uint32_t mincls = 3u;
+#pragma unroll
+    for (uint32_t m = 0; m < SWEEP_NT; ++m)
+      if (m < nt) {
+        const uint32_t c = (uint32_t)(cw >> L.cls_sh[m]) & 3u;
+        mincls = c < mincls ? c : mincls;
+      }
+    uint32_t thr_here = thr_g;
+    if (tk.thr) {
+      const uint32_t own = (uint32_t)(tk.thr >> 32);
+      thr_here = own > thr_here ? own : thr_here;
+    }
+    // (mincls 0 cannot happen for a doc of the AND; it is kept, like class 3)
+    const bool keep = alive && !(mincls - 1u < 2u && sortable(bm25(weight, cache_g[nid], mincls) * 1.000002f) < thr_here);
+    const uint64_t mk = __ballot(keep);
+    if (!mk) return;
+    const uint32_t at = qn + mbcnt64(mk);
+    wave_mem_fence();
+    if (keep) L.q_doc[at] = doc;
+    wave_mem_fence();
+    qn += (uint32_t)__popcll(mk);
+  };
+  // the two stages, each as long as it has a full batch (final: whatever is left) — ONE place, so that the scoring
+  // stage is instantiated twice (here for the extraction loop, here for the flush), not once per caller of a caller
+  auto pump = [&](bool final) __attribute__((always_inline)) {
+    for (;;) {
+      if (q0n >= 64u || (final && q0n)) {
+        stageP(q0n < 64u ? q0n : 64u);
+      } else if (qn >= 64u || (final && qn)) {
+        stageC(qn < 64u ? qn : 64u);
+      } else {
+        break;
+      }
+    }
+  };
+
   auto flush_query = [&]() __attribute__((always_inline)) {
-    while (qn) stageC(qn < 64u ? qn : 64u);
+    pump(true);
     const uint32_t part = sload(&Q->part_start) + (chunk - sload(&Q->chunk_first));
     flush_partial<KPL>(tk, sload(&p.sinks->partials), part, lane);
     if (lane == 0 && n_q) atomicAdd(sload(&p.sinks->query_matches) + sload(sload(&p.sinks->out_index) + q), n_q);
@@ -981,12 +1041,17 @@ __global__ __launch_bounds__(64, TQ_PH_SWEEP_WAVES) void phrase_sweep_kernel(Tqk
           const uint32_t rest = cw & (cw - 1u);
           if (c0) c0 = rest; else if (c1) c1 = rest; else if (c2) c2 = rest; else c3 = rest;
           const uint64_t mk = __ballot(has);
-          const uint32_t at = qn + mbcnt64(mk);
+          // (cls_ok, wave-uniform: through the class test first)
+          uint32_t *const qd = cls_ok ? L.q0_doc : L.q_doc;
+          const uint32_t at = (cls_ok ? q0n : qn) + mbcnt64(mk);
           wave_mem_fence();
-          if (has) L.q_doc[at] = ((w + j) << 5) + bit;
+          if (has) qd[at] = ((w + j) << 5) + bit;
           wave_mem_fence();
-          qn += (uint32_t)__popcll(mk);
-          while (qn >= 64u) stageC(64u);
+          if (cls_ok)
+            q0n += (uint32_t)__popcll(mk);
+          else
+            qn += (uint32_t)__popcll(mk);
+          pump(false);
         }
       }
     }

@@ -1125,7 +1125,7 @@ int search_batch_impl(tq_segment *s, const tq_query *queries, uint32_t n_queries
     }
     TqkScanParams p{};
     p.seg = s->dseg;
-    if (!s->opt.use_dense) p.seg.docmat = nullptr;
+    if (!s->opt.use_dense) p.seg.docmat = nullptr, p.seg.doccls = nullptr;
     p.terms = s->d_terms;
     p.queries = (const TqdQuery *)(ds + g.o_queries);
     p.tile_starts = (const uint32_t *)(ds + g.o_tiles);

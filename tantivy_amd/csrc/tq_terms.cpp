@@ -907,6 +907,23 @@ int build_dense_device(tq_segment *s, uint32_t handle) {
       const uint32_t slot = s->n_mat_slots++;
       e = tqk_launch_docmat_set(s->d_docmat, dd, t.doc_freq, slot, s->max_doc, s->stream);
       if (e != hipSuccess) return fail(TQ_ERR_HIP, "docmat set: %s", hipGetErrorString(e));
+      // the list's tf classes (the first TQD_CLS_SLOTS columns; 8 B per doc once, inside the dense budget)
+      static const bool kDocCls = tune_u32("TQ_DOCCLS", 1) != 0;
+      if (kDocCls && slot < TQD_CLS_SLOTS && t.tf8_blob) {
+        const size_t cls_bytes = (size_t)s->max_doc * sizeof(uint64_t);
+        if (!s->d_doccls && s->dense_bytes_total + cls_bytes <= s->dense_budget()) {
+          HIP_TRY(hipMalloc((void **)&s->d_doccls, cls_bytes + PAD));
+          HIP_TRY(hipMemsetAsync(s->d_doccls, 0, cls_bytes + PAD, s->stream));
+          s->dense_bytes_total += cls_bytes;
+          s->bytes_docmat += cls_bytes;
+          s->dseg.doccls = s->d_doccls;
+        }
+        if (s->d_doccls) {
+          e = tqk_launch_doccls_set(s->d_doccls, dd, dt, t.doc_freq, slot, s->max_doc, s->stream);
+          if (e != hipSuccess) return fail(TQ_ERR_HIP, "doccls set: %s", hipGetErrorString(e));
+          s->h_dterms[handle].has_freq |= 1u << 24;  // (TqdTermHead::has_freq bit 24: the list's classes are in doccls)
+        }
+      }
       s->h_dterms[handle].has_freq |= (slot + 1u) << 8;
     }
   }
