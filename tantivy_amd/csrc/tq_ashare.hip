@@ -279,14 +279,30 @@ ashare_kernel(TqkAShareParams p) {
     } else {
     // leader first, then ascending doc freq (block_wand_intersection.rs:144-165)
     // list 1: bitmap word (exact membership, the posting index) -> tf byte
+    // (round 6: a list with tf classes in the segment's class matrix — ONE 8-byte gather says "absent", "tf 1", "tf 2"
+    // or "three or more: read the tf byte"; 91 % of the bench's postings need nothing else)
     uint32_t pi = 0, tf1 = 0;
+    bool chain = alive;
     {
+      const uint32_t cslot1 = (ld.info >> 10) & 0x3Fu;
+      if (__ballot(alive && cslot1)) {
+        uint64_t cw = 0;
+        if (alive && cslot1) cw = seg.doccls[doc];
+        const uint32_t c = (uint32_t)(cw >> (2u * (cslot1 - 1u))) & 3u;
+        if (alive && cslot1) {
+          if (c == 0u) alive = false;  // (exact: the class matrix holds every posting of the list)
+          tf1 = c;
+          chain = c == 3u;
+        }
+      }
+    }
+    if (__ballot(chain)) {
       uint2 wd = make_uint2(0u, 0u);
-      if (alive) wd = reinterpret_cast<const uint2 *>(tbase + ((uint64_t)ld.dense_off << 3))[doc >> 5];
+      if (chain) wd = reinterpret_cast<const uint2 *>(tbase + ((uint64_t)ld.dense_off << 3))[doc >> 5];
       const uint32_t bit = doc & 31u;
-      alive = alive && ((wd.x >> bit) & 1u);
+      if (chain) alive = alive && ((wd.x >> bit) & 1u);
       pi = wd.y + (uint32_t)__popc(wd.x & ((1u << bit) - 1u));
-      if (alive) tf1 = (tbase + ((uint64_t)ld.tf8_off << 3))[pi];
+      if (chain && alive) tf1 = (tbase + ((uint64_t)ld.tf8_off << 3))[pi];
     }
     const bool more = alive && nt > 2u;
     const uint64_t more_m = __ballot(more);

@@ -388,6 +388,11 @@ int build_ashare_plan(tq_segment *s, Group &g, PlanScratch &ps, bool boolean) {
         ld.mask_lo = (uint32_t)mask;
         ld.mask_hi = (uint32_t)(mask >> 32);
         ld.info = dq.n_terms | (column_of(dq.term[1]) ? 0x100u : 0u);
+        {  // list 1's tf classes in the segment's class matrix (bits 10-15: column slot + 1): its tf without bitmap word + tf byte
+          static const bool kUseCls = tune_u32("TQ_AS_CLS", 1) != 0;
+          const uint32_t hf = s->h_dterms[dq.term[1]].has_freq;
+          if (kUseCls && s->d_doccls && ((hf >> 24) & 1u)) ld.info |= ((hf >> 8) & 0x3Fu) << 10;
+        }
         {  // (list 1's own tables, or the ones built for probes: build_probe_tables)
           const TermHost &t1 = s->terms[dq.term[1]];
           const bool own = t1.dense_blob && t1.tf8_blob;
