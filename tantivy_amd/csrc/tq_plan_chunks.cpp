@@ -165,6 +165,40 @@ int build_group_chunks(Group &g, bool or_windows, PlanScratch &ps, bool boolean_
   const uint64_t cost_floor = or_win ? 1u : (total_cost < kSmallCost ? std::min<uint64_t>(128u, std::max<uint64_t>(8u, total_cost / kSmallChunks)) : 128u);
   const uint64_t cost_target = std::max<uint64_t>(cost_floor, (total_cost + n_target - 1) / n_target);
   pt("costs");
+  // Every query with the same number of tiles of the same cost (the phrase sweep: a tile is 2 048 bitmap words whatever
+  // the query): the records follow from arithmetic — chunk j of query q = tiles [j tpc, (j + 1) tpc), launched j-major
+  // (all queries' first doc range, then the next) — instead of from the packing loop, the counting sort by slice and the
+  // deal (0.72 ms per 1 000-phrase batch, which had become the step's bound once the kernels took 0.77 ms).
+  if (!or_cand && !or_win && !g.queries.empty() && g.queries[0].n_tiles) {
+    bool uniform = true;
+    const uint32_t nt0 = g.queries[0].n_tiles, tc0 = std::max<uint32_t>(1u, g.tile_cost[0]);
+    for (size_t i = 1; i < g.queries.size() && uniform; ++i)
+      uniform = g.queries[i].n_tiles == nt0 && std::max<uint32_t>(1u, g.tile_cost[i]) == tc0;
+    if (uniform && g.queries.size() >= 64) {
+      const uint32_t tpc = (uint32_t)std::max<uint64_t>(1u, std::min<uint64_t>(nt0, (cost_target + tc0 - 1) / tc0));
+      const uint32_t cpq = (nt0 + tpc - 1) / tpc;
+      const size_t nq = g.queries.size();
+      if ((uint64_t)cpq * nq > 0x7FFFFFFFull) return fail(TQ_ERR_UNSUPPORTED, "batch too large (chunks)");
+      g.n_chunks = (uint32_t)(cpq * nq);
+      g.chunk_recs.resize(g.n_chunks);
+      for (size_t q = 0; q < nq; ++q) {
+        TqdQuery &dq = g.queries[q];
+        dq.part_start = 0;
+        dq.chunk_first = (uint32_t)(q * cpq);
+        dq.n_parts = cpq;
+      }
+      uint4 *out = g.chunk_recs.data();
+      for (uint32_t j = 0; j < cpq; ++j) {
+        const uint32_t t0 = j * tpc, t1 = std::min<uint32_t>(nt0, t0 + tpc);
+        for (size_t q = 0; q < nq; ++q) {
+          const uint32_t base = g.tile_starts[q];
+          *out++ = make_uint4(base + t0, base + t1, (uint32_t)q, (uint32_t)(q * cpq + j));
+        }
+      }
+      pt("uniform records");
+      return TQ_OK;
+    }
+  }
   const uint32_t per_chunk = or_win ? TQD_WAVES_PER_WG : 1u;
   const uint32_t li_cap = n_slices * 8u / kOrSubSlices - 1u;
   // The queries are cut into slabs of about equal cost; every slab builds its chunks on its own
