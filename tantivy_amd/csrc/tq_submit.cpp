@@ -249,8 +249,15 @@ int ticket_wait(tq_ticket *t) {
       }
       lk.unlock();
       tqi::HostBatchSlot &S = Q.slot[si];
-      const int erc = search_batch_host_end(s, S);
-      const std::string err = erc == TQ_OK ? std::string() : g_last_error;
+      // (nothing may leave this block by exception: the slot, the tickets and — without a hand-over — the leadership
+      // are released below; a bad_alloc here used to unwind through tq_wait with all three still held, and every
+      // caller of the batch waited for good.  ADVICE r05)
+      int erc = TQ_ERR_HIP;
+      try {
+        erc = search_batch_host_end(s, S);
+      } catch (...) {
+        erc = TQ_ERR_HIP;
+      }
       for (size_t i = 0; i < batch.size(); ++i) {
         tq_ticket *b = batch[i];
         if (erc == TQ_OK) {
@@ -262,7 +269,10 @@ int ticket_wait(tq_ticket *t) {
           b->rc = TQ_OK;
         } else {
           b->rc = erc;
-          b->err = err;
+          try {
+            b->err = g_last_error;
+          } catch (...) {  // (the status code still reaches the caller)
+          }
         }
       }
       lk.lock();

@@ -293,6 +293,9 @@ class Searcher {
 
   // Statistics of segments held by OTHER ranks (one segment per GPU): the reference lets the
   // caller supply its own Bm25StatisticsProvider (bm25.rs:11-25) for exactly this.
+  // NOT to be called while searches are in progress on this Searcher: the cached term weights are reset entry by
+  // entry, and a concurrent weight() may store an idf computed from the statistics of before the call (tantivy
+  // builds a new Searcher per reader reload; so does the host mirror's caller).
   void add_remote_statistics(uint64_t max_doc, uint64_t total_num_tokens,
                              const std::vector<std::pair<uint32_t, uint32_t>> &term_doc_freqs);
 
