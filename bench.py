@@ -765,6 +765,7 @@ def stream_block(O, D, cl, torch, args, vocab, seg, n_batches, n_q, k):
     first = runner.results()
     prep_s, t1 = 0.0, time.perf_counter()
     n_warm = min(3, n_batches - 2)
+    loop_s = [0.0, 0.0, 0.0]
     # Query::weight of batch i + 1 on a second host thread while this one plans and enqueues batch i (what a server's
     # request threads do); --stream-serial: one thread does both in turn
     overlap = not getattr(args, "stream_serial", False)
@@ -775,17 +776,29 @@ def stream_block(O, D, cl, torch, args, vocab, seg, n_batches, n_q, k):
             runner.synchronize()
             runner.batch_stats()
             prep_s, t1 = 0.0, time.perf_counter()
+        ta = time.perf_counter()
         if overlap:
             prep_s += runner.commit_next()
+            tb = time.perf_counter()
             if i + 1 < n_batches:
                 runner.prepare_next(batches[i + 1], k, marsh[i + 1])
         else:
-            tp = time.perf_counter()
+            tp = tb = time.perf_counter()
             runner.prepare(batches[i], k, marsh[i])
             prep_s += time.perf_counter() - tp
+        tc = time.perf_counter()
         runner.enqueue()
+        td = time.perf_counter()
+        if i == 1 + n_warm:
+            loop_s = [0.0, 0.0, 0.0]
+        if i >= 1 + n_warm:
+            loop_s[0] += tb - ta
+            loop_s[1] += tc - tb
+            loop_s[2] += td - tc
+    ta = time.perf_counter()
     runner.synchronize()
     wall = time.perf_counter() - t1
+    loop_s.append(time.perf_counter() - ta)
     timed = n_batches - 1 - n_warm
     st = runner.batch_stats()
     # second pass over the same batches: every term now has its tables (what the stream costs once a segment has been
@@ -815,6 +828,8 @@ def stream_block(O, D, cl, torch, args, vocab, seg, n_batches, n_q, k):
             "steady_ms_per_batch": round(wall / timed * 1e3, 3),
             "prepare_ms_per_batch": round(prep_s / timed * 1e3, 3),
             "prepare_share": round(prep_s / wall, 3),
+            "loop_ms_per_batch": {"wait_for_weights": round(loop_s[0] / timed * 1e3, 3), "kick_next_weights": round(loop_s[1] / timed * 1e3, 3),
+                                  "plan_and_enqueue": round(loop_s[2] / timed * 1e3, 3), "final_wait": round(loop_s[3] / timed * 1e3, 3)},
             "prepare_thread": "second host thread, one batch ahead" if overlap else "the enqueueing thread",
             "second_pass_qps": round(n_q * (n_batches - 1) / wall2, 1),
             "second_pass_ms_per_batch": round(wall2 / (n_batches - 1) * 1e3, 3),

@@ -467,6 +467,16 @@ int tq_segment_get_stats(tq_segment *seg, tq_segment_stats *out);
  *        taken gets the slot of the list used longest ago (tq_segment_stats.probe_evictions), never one the batch
  *        being planned uses: a batch that names more such lists than the budget holds grows the pool (the other
  *        kernels keep treating these lists as sparse),
+ *        "rdir_budget_x" (default 4, 0 = never): tq_term_prepare / tq_term_prepare_batch also give a list below
+ *        "dense_ratio" with at least 256 postings a RANGE DIRECTORY — one u32 per posting in posting order (16 bits of
+ *        the doc id, min(tf, 0xFFFF)) and the number of postings before every 2^S-doc range, S chosen per list so
+ *        that a range holds two to four postings: 5-6 bytes per posting, counted in
+ *        tq_segment_stats.term_table_bytes — while the directories stay below this multiple of the segment's bytes.
+ *        The shared intersection launch (TQ_KERNEL_ASHARE) probes the second list of a 2-term intersection through
+ *        it ("is doc d in the list, with which tf": two directory slots and the range's entries) and drops the
+ *        leader blocks in whose doc span the directory counts no posting; before, such a list needed a
+ *        max_doc / 4-byte slot of the probe pool (19 x the segment's bytes resident after a 65 536-term stream,
+ *        5 x with directories),
  *        "count_bitmap_ratio" (default 128, 0 = never): tq_count_batch evaluates a query as a bitwise
  *        expression over bitmap words (4-8 bytes per list per 32 docs, no postings decoded; a list
  *        without a bitmap is scattered into a scratch bitmap once per batch) when the clause a scan

@@ -190,6 +190,7 @@ void tq_segment_free(tq_segment *s) {
   (void)hipSetDevice(s->device);
   if (s->stream) (void)hipStreamSynchronize(s->stream);
   if (s->batch_in_flight && s->ev_batch_done) (void)hipEventSynchronize(s->ev_batch_done);
+  for (auto &ch : s->rdir_chunks) (void)hipFree(ch.first);
   for (void *slab : s->term_slabs) (void)hipFree(slab);  // (the terms' table blobs: tq_terms.cpp term_alloc)
   // (bitmaps, byte-wide tfs, position directories, plain lists: the arena and its overflow)
   if (s->dense_arena) (void)hipFree(s->dense_arena);
@@ -408,6 +409,8 @@ int tq_set_option(tq_segment *s, const char *name, int64_t value) {
     s->opt.or_windows = value < 0 ? -1 : (value != 0);
   else if (!strcmp(name, "dense_ratio") && value >= 1)  // affects terms prepared afterwards
     s->opt.dense_ratio = (int)value;
+  else if (!strcmp(name, "rdir_budget_x") && value >= 0 && value <= 0x7FFFFFFF)
+    s->opt.rdir_budget_x = (int)value;
   else if (!strcmp(name, "probe_budget_x") && value >= 0 && value <= 0x7FFFFFFF)
     s->opt.probe_budget_x = (int)value, s->probe_full = false;
   else if (!strcmp(name, "dense_budget_x") && value >= 0)

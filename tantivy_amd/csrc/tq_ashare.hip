@@ -48,7 +48,11 @@
 #define TQ_BS_WAVES 5  // (boolean leads: 96 registers; 6 waves of 80 spilled 60 of them and ran 18 % slower)
 #endif
 #ifndef TQ_AS_WAVES
-#define TQ_AS_WAVES 8
+// (intersections: 8 waves of 64 registers until round 6 — by then the scoring stage had grown (class matrix, range
+// directories) and spilled 150 bytes per lane; 5 waves of 96 registers: and2 0.93 -> 0.83 ms, and2_distinct 1.43 ->
+// 1.25, 4 096 terms 1.18 -> 0.90; fewer waves in flight also see higher thresholds (a fifth fewer docs scored).
+// 7 / 6 / 4 waves: 0.89 / 0.88 / 0.92 ms)
+#define TQ_AS_WAVES 5
 #endif
 #ifndef TQ_AS_TIMERS
 #define TQ_AS_TIMERS 0  // region timers (tools/probe_ashare_regions.sh builds a variant with them)
@@ -185,9 +189,8 @@ ashare_kernel(TqkAShareParams p) {
     const uint32_t g = tag & 31u;  // the family's head
     const float norm = L.cache[(tag >> 8) & 0xFFu];
     const TqdALeadLds ld = L.lead[g];
-    const uint32_t thr = L.lthr[g];
-    const uint32_t k = L.lk[g] & 0xFFu;
-    const uint32_t thr_row = L.lk[g] >> 8;
+    // (the family's threshold, k and threshold row are read from LDS where they are first needed: fewer registers live
+    // across the probes of the other lists)
     const uint32_t q = ld.query;
     const uint32_t nt = ld.info & 31u;
     float s = bm25(ld.w, norm, tf);
@@ -281,8 +284,22 @@ ashare_kernel(TqkAShareParams p) {
     // list 1: bitmap word (exact membership, the posting index) -> tf byte
     // (round 6: a list with tf classes in the segment's class matrix — ONE 8-byte gather says "absent", "tf 1", "tf 2"
     // or "three or more: read the tf byte"; 91 % of the bench's postings need nothing else)
+    // (round 6: a sparse list 1 with a range directory — rdir_lookup, tq_common.hpp: two directory slots, then the
+    // range's few entries — says "absent" or the tf and the posting's index)
     uint32_t pi = 0, tf1 = 0;
     bool chain = alive;
+    uint32_t esc = 255u;  // the tf value that means "that or more: read the packed value"
+    if (__ballot(alive && (ld.info & TQD_AL_RDIR))) {
+      const bool ron = alive && (ld.info & TQD_AL_RDIR);
+      const bool found = rdir_lookup(reinterpret_cast<const uint32_t *>(tbase + ((uint64_t)ld.dense_off << 3)),
+                                     reinterpret_cast<const uint32_t *>(tbase + ((uint64_t)ld.tf8_off << 3)), (ld.info >> 16) & 31u,
+                                     doc, ron, tf1, pi);
+      if (ron) {
+        alive = found;
+        chain = false;
+        esc = 0xFFFFu;
+      }
+    }
     {
       const uint32_t cslot1 = (ld.info >> 10) & 0x3Fu;
       if (__ballot(alive && cslot1)) {
@@ -301,7 +318,7 @@ ashare_kernel(TqkAShareParams p) {
       if (chain) wd = reinterpret_cast<const uint2 *>(tbase + ((uint64_t)ld.dense_off << 3))[doc >> 5];
       const uint32_t bit = doc & 31u;
       if (chain) alive = alive && ((wd.x >> bit) & 1u);
-      pi = wd.y + (uint32_t)__popc(wd.x & ((1u << bit) - 1u));
+      if (chain) pi = wd.y + (uint32_t)__popc(wd.x & ((1u << bit) - 1u));
       if (chain && alive) tf1 = (tbase + ((uint64_t)ld.tf8_off << 3))[pi];
     }
     const bool more = alive && nt > 2u;
@@ -310,8 +327,8 @@ ashare_kernel(TqkAShareParams p) {
     if (more_m) {
       if (more) w1 = p.queries[q].weight[1];
     }
-    if (__ballot(alive && tf1 == 255u)) {  // tf >= 255: block record -> packed tf
-      if (alive && tf1 == 255u) tf1 = as_exact_tf(idx, p.terms, p.queries[q].term[1], pi);
+    if (__ballot(alive && tf1 == esc)) {  // tf >= 255 (65535): block record -> packed tf
+      if (alive && tf1 == esc) tf1 = as_exact_tf(idx, p.terms, p.queries[q].term[1], pi);
     }
     if (alive) s = s + bm25(w1, norm, tf1);
     if (more_m) {  // lists 2.. of a 3+ term query: term table -> bitmap word -> tf byte, one list at a time
@@ -320,7 +337,7 @@ ashare_kernel(TqkAShareParams p) {
         bool on = alive && m < nt;
         if (on) {  // what the lists m.. can still add
           const float r0 = rest > 0.0f ? rest : 0.0f;
-          if (!(sortable((s + r0) * 1.000002f + ld.rest * 4.0e-6f) >= thr)) {
+          if (!(sortable((s + r0) * 1.000002f + ld.rest * 4.0e-6f) >= L.lthr[g])) {
             alive = false;
             on = false;
           }
@@ -349,7 +366,7 @@ ashare_kernel(TqkAShareParams p) {
     }
     // the score is final: below the threshold it cannot enter the top-k (equal scores stay: ties
     // resolve by doc id in the collector)
-    if (alive) alive = sortable(s) >= thr;
+    if (alive) alive = sortable(s) >= L.lthr[g];
     if (alive) alive = doc_is_alive(seg, doc);
     const uint64_t hit = __ballot(alive);
     if (!hit) {
@@ -363,8 +380,9 @@ ashare_kernel(TqkAShareParams p) {
     if (alive) {
       // the query's hashed score slots: fire and forget (the k-th largest slot is selected once per
       // (task, family) at the end of the task, not once per change)
-      const uint32_t hsh = (doc * 0x9E3779B1u) >> (k <= 16u ? 26 : 24);
-      (void)atomicMax(p.thr_slots + (size_t)thr_row * TQD_THR_SLOTS + hsh, sb);
+      const uint32_t kr = L.lk[g];  // k | threshold row << 8
+      const uint32_t hsh = (doc * 0x9E3779B1u) >> ((kr & 0xFFu) <= 16u ? 26 : 24);
+      (void)atomicMax(p.thr_slots + (size_t)(kr >> 8) * TQD_THR_SLOTS + hsh, sb);
       const uint32_t pos = atomicAdd(&L.cnt[g], 0x10001u) & 0xFFFFu;  // (a list never overflows: see the cut below)
       my_stage[(size_t)g * CAPL + pos] = key;
     }
@@ -467,7 +485,11 @@ ashare_kernel(TqkAShareParams p) {
         // 2-term intersections: list 1's range maxima (TqdALead comment); `rest` = list 1's weight — in the
         // lead's LDS record — becomes what the list can add anywhere: its largest range maximum
         my_xlo = (bmode && (mine.info & 31u) == 2u) ? mine.excl_lo : 0u;
-        if (my_xlo) {
+        // (list 1 probed through its range directory: the directory — which leader blocks the list has postings in —
+        // and its shift; the list's largest tf/(tf + norm) bounds it as the largest range maximum does)
+        const bool rdir = bmode && (mine.info & TQD_AL_RDIR) != 0u;
+        my_xhi = rdir ? mine.dense_off | ((mine.info >> 16) & 31u) : 0u;  // (the directory is 256-byte aligned)
+        if (my_xlo || rdir) {
           const float r1 = mine.rest * p.bound_slack * (1.00002f / 255.0f) * (float)(mine.any1_hi & 0xFFu);
           my_rest = r1 < mine.rest ? r1 : mine.rest;
         }
@@ -549,18 +571,15 @@ ashare_kernel(TqkAShareParams p) {
       // (intersections) the level of list 1's range maxima at which this block's doc span [first, last] touches at
       // most two entries, and the two entries' indices there (no such level: the span is wider than the coarsest
       // level's entries, and the list's largest entry — already in the lead's `rest` — stands in)
-      uint32_t rm_at = 0, rm_i0 = 0, rm_i1 = 0;
-      bool rm_ok = false;
+      // (blk_first / blk_last = the block's doc span, rm_pack = the level's byte offset | its shift << 24, shift 0 = none)
+      uint32_t rm_pack = 0, blk_first = 1u, blk_last = 0u;
       if constexpr (!BOOLQ) {
         if ((bmode & 1u) && in_tile) {
-          const uint32_t first = i_mine ? prev_mine + 1u : 0u, last = rec_mine.x;
-          const uint32_t wide = last >= first ? (last - first) >> TQD_RM_SHIFT : 0xFFFFFFFFu;  // span in level-0 entries
-          const uint32_t lvl = wide ? (33u - (uint32_t)__builtin_clz(wide)) >> 1 : 0u;       // 0 | 1..3 | 4..15 | ... -> 0 | 1 | 2 | ...
-          rm_ok = lvl < TQD_RM_LEVELS;
-          const uint32_t sh = TQD_RM_SHIFT + 2u * lvl;
-          rm_at = tqd_rm_level_off(seg.max_doc, rm_ok ? lvl : 0u);
-          rm_i0 = rm_ok ? first >> sh : 0u;
-          rm_i1 = rm_ok ? last >> sh : 0u;
+          blk_first = i_mine ? prev_mine + 1u : 0u;
+          blk_last = rec_mine.x;
+          const uint32_t wide = blk_last >= blk_first ? (blk_last - blk_first) >> TQD_RM_SHIFT : 0xFFFFFFFFu;  // span in level-0 entries
+          const uint32_t lvl = wide ? (33u - (uint32_t)__builtin_clz(wide)) >> 1 : 0u;                      // 0 | 1..3 | 4..15 | ... -> 0 | 1 | 2 | ...
+          if (lvl < TQD_RM_LEVELS) rm_pack = tqd_rm_level_off(seg.max_doc, lvl) | ((TQD_RM_SHIFT + 2u * lvl) << 24);
         }
       }
       uint32_t pass_mask = 0;  // families that still want this block (block_wand_intersection.rs:81-85)
@@ -575,16 +594,26 @@ ashare_kernel(TqkAShareParams p) {
           // (block_wand_intersection.rs:59-85: leader block-max + the secondaries' block-max)
           const uint32_t rmo = (uint32_t)__builtin_amdgcn_readlane((int)my_xlo, (int)g);
           if ((bmode & 1u) && rmo) {
-            const uint8_t *rt = tbase + ((uint64_t)rmo << 3) + rm_at;
-            const uint32_t qa = rm_ok ? (uint32_t)rt[rm_i0] : 255u, qb = rm_ok ? (uint32_t)rt[rm_i1] : 255u;
-            if (p.debug & 0x800000u) n_scored += 2u * (uint32_t)__popcll(__ballot(rm_ok));  // COUNTERS
+            const uint8_t *rt = tbase + ((uint64_t)rmo << 3) + (rm_pack & 0xFFFFFFu);
+            const uint32_t sh = rm_pack >> 24;
+            const uint32_t qa = sh ? (uint32_t)rt[blk_first >> sh] : 255u, qb = sh ? (uint32_t)rt[blk_last >> sh] : 255u;
+            if (p.debug & 0x800000u) n_scored += 2u * (uint32_t)__popcll(__ballot(sh != 0u));  // COUNTERS
             const float w1 = uni_f(L.lead[g].rest);  // (a 2-term query: the weight of list 1)
             const float r1 = w1 * p.bound_slack * (1.00002f / 255.0f) * (float)(qa > qb ? qa : qb);
             rest = r1 < rest ? r1 : rest;
           }
         }
+        bool empty = false;  // list 1 has no posting in this block's doc span (its range directory says so)
+        if constexpr (!BOOLQ) {
+          const uint32_t rdo = (uint32_t)__builtin_amdgcn_readlane((int)my_xhi, (int)g);  // (directory | shift: 256-byte aligned)
+          if ((bmode & 1u) && rdo) {
+            const uint32_t S = rdo & 31u;
+            const uint32_t *dr = reinterpret_cast<const uint32_t *>(tbase + ((uint64_t)(rdo & ~31u) << 3));
+            if (blk_last >= blk_first) empty = dr[blk_first >> S] == dr[(blk_last >> S) + 1u];
+          }
+        }
         const float ub = w * tfn_max * p.bound_slack;
-        if (in_tile && sortable((ub + rest) * 1.000004f + (w + rest) * 4.0e-6f) >= thr) {
+        if (in_tile && !empty && sortable((ub + rest) * 1.000004f + (w + rest) * 4.0e-6f) >= thr) {
           pass_mask |= 1u << g;
           if constexpr (!BOOLQ) {
             const float thr_f = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(fam_thr_f), (int)g));

@@ -302,6 +302,45 @@ __device__ __forceinline__ Dec decode_block(const uint8_t *idx, const TermRef &t
   return r;
 }
 
+// ---- range directory of a sparse list (TermHost::rdir_blob, tq_terms.cpp): the list's postings as one u32 each, in
+// posting order — (doc & (2^S - 1)) << 16 | min(tf, 0xFFFF) — and dir[r] = the number of postings with doc < r << S
+// for r = 0 .. (max_doc >> S) + 1 (S <= 16, chosen per list so that a range holds two to four postings on average).
+// "Is doc d in the list, with which tf" is dir[d >> S], dir[(d >> S) + 1] and the few entries between them; docs that
+// are close lie close in both arrays (a bitmap's locality at 5-6 bytes per posting instead of max_doc / 4 per list).
+__device__ __forceinline__ uint32_t rdir_entry(uint32_t doc, uint32_t tf, uint32_t S) {
+  return ((doc & ((1u << S) - 1u)) << 16) | (tf < 0xFFFFu ? tf : 0xFFFFu);
+}
+// every lane its own list and doc (on = the lane asks): found -> tf (0xFFFF = that or more: the packed value) and the
+// posting's index
+__device__ __forceinline__ bool rdir_lookup(const uint32_t *dir, const uint32_t *ent, uint32_t S, uint32_t doc, bool on,
+                                            uint32_t &tf, uint32_t &pi) {
+  uint32_t lo = 0, hi = 0;
+  if (on) {
+    const uint32_t r = doc >> S;
+    lo = dir[r];
+    hi = dir[r + 1u];
+  }
+  const uint32_t key = doc & ((1u << S) - 1u);
+  bool found = false;
+  on = on && lo < hi;
+  while (__ballot(on)) {
+    if (on) {
+      const uint32_t e0 = ent[lo], e1 = lo + 1u < hi ? ent[lo + 1u] : 0xFFFFFFFFu;  // (two at a time: entries ascend inside a range)
+      const bool m0 = (e0 >> 16) == key, m1 = lo + 1u < hi && (e1 >> 16) == key;
+      if (m0 | m1) {
+        tf = (m0 ? e0 : e1) & 0xFFFFu;
+        pi = lo + (m0 ? 0u : 1u);
+        found = true;
+        on = false;
+      } else {
+        lo += 2u;
+        on = lo < hi && (e1 >> 16) < key;
+      }
+    }
+  }
+  return found;
+}
+
 // first block index j in [0, n_blocks) with last_doc(j) >= doc, else n_blocks, for a per-lane
 // target (BlockSegmentPostings::seek_block, skip.rs:263-273, made O(1)):
 // the coarse table brackets the answer, a short binary search finishes.  doc < max_doc.

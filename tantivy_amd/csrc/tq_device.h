@@ -141,6 +141,8 @@ static_assert(sizeof(TqdLead) == 128, "TqdLead is uploaded as raw bytes");
 #define TQD_AS_GROUP 32      // leads per group (one lane each at task setup)
 #define TQD_AS_MAX_TERMS 8   // intersections with more lists keep the per-query kernel
 #define TQD_AS_TILE 64       // blocks per pre-filter step (one lane each)
+#define TQD_AL_RDIR 0x10000000u  // TqdALead::info bit 28 (AND leads): list 1 is probed through its range directory
+                                 // (rdir_lookup, tq_common.hpp), bits 16-20 = the directory's shift
 struct TqdALead {            // 64 bytes, written by the host planner
   uint32_t query;            // launch-group query index
   uint32_t info;             // n_terms (bits 0-4) | bit 8: list 1's membership bit is its column (exact) |
@@ -154,7 +156,8 @@ struct TqdALead {            // 64 bytes, written by the host planner
   float rest;                // what the other lists can add at most (AND: their weights together = the weight
                              // of list 1 in a 2-term query; boolean: the weights of the lists after the leader)
   uint32_t dense_off;        // AND, list 1: bitmap + rank directory, byte-wide tfs, as offsets from
-  uint32_t tf8_off;          // TqkAShareParams::table_base in 8-byte units.  Boolean leads: byte m of the two
+  uint32_t tf8_off;          // TqkAShareParams::table_base in 8-byte units (TQD_AL_RDIR: the list's directory
+                             // and its entries).  Boolean leads: byte m of the two
                              // words = the doc-matrix bit of the query's list m (0: it has none): a doc whose
                              // word has the bit clear is not in the list
   uint32_t mask_lo, mask_hi; // doc-matrix bits every match has: the other lists' columns (exact) and

@@ -28,6 +28,7 @@
 #include <cstring>
 #include <string>
 #include <unordered_map>
+#include <unordered_set>
 #include <thread>
 #include <vector>
 
@@ -110,6 +111,13 @@ struct TermHost {
   void *probe_posdir_blob = nullptr;  // ... and its position directory (TqdTerm::pos_dir layout), built the first time
                                       // a phrase INSIDE a boolean query names the list (tq_tree.hip)
   int32_t probe_slot = -1;            // the slot of the segment's probe pool that holds them (tq_terms.cpp), or -1
+  // a list below "dense_ratio": its range directory (rdir_lookup, tq_common.hpp: one u32 per posting in posting order +
+  // a directory of posting counts per 2^rdir_shift docs; 5-6 bytes per posting), built when the term is prepared, while
+  // such tables stay within "rdir_budget_x": the shared intersection launch asks it "is d in the list, with which tf" —
+  // what a max_doc / 4-byte bitmap + rank directory + tf bytes from the probe pool answered before
+  void *rdir_blob = nullptr;          // the directory (256-byte aligned: the shift rides in the low bits of its offset)
+  void *rdir_ent = nullptr;           // the entries, right behind it
+  uint32_t rdir_shift = 0;
   uint8_t *probe_own_dir = nullptr;   // a list too long for a slot: room for its position directory next to its own tables
   void *rmax_blob = nullptr;   // range maxima of a list with a bitmap (its own or the probe tables'): one byte per
                                // TQD_RM_SHIFT docs, tq_ashare.hip's bound on non-leader lists
@@ -175,6 +183,7 @@ struct Options {
   // max_doc / xunion_ratio postings (0 = never), if the batch has at least xunion_min_queries of them
   int xunion_ratio = 64;
   int xunion_min_queries = 64;
+  int rdir_budget_x = 4;    // range directories of the lists below "dense_ratio" (5-6 B per posting): at most this multiple of the segment
   int probe_budget_x = 16;  // bitmaps + tf bytes built on demand for the lists boolean queries probe: at most this multiple of the segment
   int count_bitmap_ratio = 128;  // Count: bitmap words instead of a scan if the driving clause holds >= max_doc / ratio postings per list
   int ashare_min_batch = 512;   // intersections: the shared launch needs this many qualifying queries in the batch
@@ -246,6 +255,10 @@ struct tq_segment {
   uint32_t n_mat_slots = 0;
   TqdSegment dseg{};
   std::vector<TermHost> terms;
+  std::vector<std::pair<void *, size_t>> rdir_chunks;  // the range directories' chunks (rdir_alloc, tq_terms.cpp)
+  uint8_t *rdir_chunk_cur = nullptr;
+  size_t rdir_chunk_left = 0;
+  bool rdir_span_ok = false;       // ... all within the 32 GB the shared launches' table offsets reach (tq_search.cpp)
   std::vector<void *> term_slabs;  // the terms' table blobs are carved out of 4 MB slabs (term_alloc)
   uint8_t *term_slab_cur = nullptr;
   size_t term_slab_left = 0;
@@ -316,6 +329,8 @@ struct tq_segment {
   Options opt;
   size_t dense_budget() const { return (size_t)opt.dense_budget_x * (idx_len + pos_len + max_doc); }
   size_t probe_budget() const { return (size_t)opt.probe_budget_x * (idx_len + pos_len + max_doc); }
+  size_t rdir_budget() const { return (size_t)opt.rdir_budget_x * (idx_len + pos_len + max_doc); }
+  size_t rdir_bytes_total = 0;
   // tq_term_prepare_batch: the blobs of a batch's new terms on their way up (two buffers, an event each), and which
   // of the two events the next batch has to wait for (-1: none)
   PinnedBuf h_prep_stage[2];
@@ -323,6 +338,11 @@ struct tq_segment {
   bool prep_used[2] = {false, false};
   uint32_t prep_calls = 0;
   int prep_pending = -1;
+  // the largest tf/(tf + norm) of every list whose range directory a tq_term_prepare_batch call built: written by the build
+  // launch, copied into the call's pinned buffer behind the blobs; TermHost::rmax_list gets it once the call's event has
+  // completed (prep_apply_lmax: no wait — until then the list's weight bounds it)
+  std::vector<uint32_t> prep_lmax_handles[2];
+  const uint32_t *prep_lmax_host[2] = {nullptr, nullptr};
   size_t probe_bytes_total = 0;
   bool probe_full = false;  // (kept for tq_set_option; the pool below evicts instead of latching)
   // Probe pool (round 6): the private tables of lists below "dense_ratio" live in equal SLOTS — [bitmap + rank
@@ -697,6 +717,7 @@ int wait_segment_idle(tq_segment *s);
 // slot if none is free; else: only a free slot or one idle for a while
 int build_probe_tables(tq_segment *s, uint32_t handle, bool *ok, bool must = false);
 int build_probe_posdir(tq_segment *s, uint32_t handle, bool *ok);
+void prep_apply_lmax(tq_segment *s, bool wait);    // rmax_list of lists prepared by finished tq_term_prepare_batch calls
 void probe_begin_batch(tq_segment *s);             // a new batch is being planned (the pool's clock)
 void probe_touch(tq_segment *s, uint32_t handle);  // the batch being planned uses the list's probe tables
 int count_batch(tq_segment *s, const tq_query *queries, uint32_t n_queries, uint32_t *out_counts);

@@ -231,8 +231,16 @@ hipError_t tqk_launch_doccls_set(uint64_t *cls, const uint32_t *docs, const uint
                                  uint32_t max_doc, hipStream_t st);
 hipError_t tqk_launch_zero(const TqkZeroParams &p, hipStream_t st);
 // signature bits (TQD_SIG_SHIFT + bits[i]) of n lists, given by their own records, into the doc matrix: one launch
+// ... and, where tabs[i] is not null, the list's range directory (rdir_lookup, tq_common.hpp: tabs[i] = (max_doc >>
+// shifts[i]) + 2 directory slots padded to a multiple of four, then dfs[i] entries; nothing needs zeroing); bits[i] =
+// 0xFFFFFFFF: no signature bit for list i; mat may be null.  cache (256 floats: the segment's own Bm25 cache) not null:
+// lmax_out[i] (zeroed) gets the list's largest tf/(tf + norm) as build_rmax rounds it
 hipError_t tqk_launch_docsig_batch(const TqdSegment &seg, const TqdTerm *const *selfs, const uint32_t *bits, uint32_t n,
-                                   uint64_t *mat, bool use_dpp, hipStream_t st);
+                                   uint64_t *mat, uint32_t *const *tabs, const uint32_t *shifts, const uint32_t *dfs,
+                                   const float *cache, uint32_t *lmax_out, bool use_dpp, hipStream_t st);
+// ... from a decoded list (docs / tfs: n postings, ascending)
+hipError_t tqk_launch_rdir_fill(const uint32_t *docs, const uint32_t *tfs, uint32_t n, uint32_t max_doc, uint32_t *dir,
+                                uint32_t S, hipStream_t st);
 hipError_t tqk_launch_merge_lists(const TqkMergeParams &m, const uint32_t *list_count, int kpl,
                                   hipStream_t st);
 uint32_t tqk_share_capl(int kpl);  // staging entries per lead slot

@@ -199,19 +199,79 @@ __global__ void docmat_set_kernel(uint64_t *mat, const uint32_t *docs, uint32_t 
 
 // The signature bits of MANY lists in one launch (tq_term_prepare_batch: a batch's new sparse terms): one workgroup of
 // four wavefronts per list, a wavefront per 128-doc block, the docs' doc-matrix words get bit items[i].y.
+// ... and, where tabs[i] is not null, the list's range directory (rdir_lookup, tq_common.hpp): tabs[i] = the directory
+// ((max_doc >> S) + 2 slots, padded to a multiple of four), the dfs[i] entries right behind it, shifts[i] = the list's S.  Entries are
+// written where their posting's index says; a posting fills the directory slots of the ranges that begin after its
+// predecessor's doc, the last posting the slots after its own.  With a Bm25 cache: lmax_out[i] (zeroed) gets the list's
+// largest tf/(tf + norm) as a byte rounded up (td_rmax_scatter_kernel's value: what build_rmax calls the list maximum).
 template <bool USE_DPP>
 __global__ __launch_bounds__(256) void docsig_batch_kernel(TqdSegment seg, const TqdTerm *const *selfs, const uint32_t *bits,
-                                                           uint64_t *mat) {
+                                                           uint64_t *mat, uint32_t *const *tabs, const uint32_t *shifts,
+                                                           const uint32_t *dfs, const float *cache, uint32_t *lmax_out) {
   const int lane = (int)__lane_id();
   const uint32_t wave = uni(threadIdx.x >> 6);
   const TqdTerm *self = selfs[blockIdx.x];
   const TermRef t = load_term(self, 0u);
-  const uint64_t bit = 1ull << (TQD_SIG_SHIFT + bits[blockIdx.x]);
+  const uint32_t b = bits[blockIdx.x];
+  const uint64_t bit = 1ull << (TQD_SIG_SHIFT + (b & 15u));
+  const bool sig = mat != nullptr && b != 0xFFFFFFFFu;
+  uint32_t *dir = tabs ? tabs[blockIdx.x] : nullptr;
+  const uint32_t S = dir ? shifts[blockIdx.x] : 0u, df = dir ? dfs[blockIdx.x] : 0u;
+  const uint32_t n_ranges = (seg.max_doc >> S) + 1u;
+  uint32_t *ent = dir ? dir + ((n_ranges + 1u + 3u) & ~3u) : nullptr;
+  uint32_t lmax = 0;
   for (uint32_t j = wave; j < t.n_blocks; j += 4u) {
     const Dec d = decode_block<USE_DPP, false>(uni_ptr(seg.idx), t, j, lane);
-    if (d.d0 < seg.max_doc) atomicOr((unsigned long long *)(mat + d.d0), (unsigned long long)bit);
-    if (d.d1 < seg.max_doc) atomicOr((unsigned long long *)(mat + d.d1), (unsigned long long)bit);
+    if (sig) {
+      if (d.d0 < seg.max_doc) atomicOr((unsigned long long *)(mat + d.d0), (unsigned long long)bit);
+      if (d.d1 < seg.max_doc) atomicOr((unsigned long long *)(mat + d.d1), (unsigned long long)bit);
+    }
+    if (ent) {
+      const uint32_t i0 = 128u * j + 2u * (uint32_t)lane;
+      const uint32_t up = (uint32_t)__shfl_up((int)d.d1, 1, WAVE);
+      // (the range after the predecessor's; the list's first posting starts at range 0)
+      uint32_t r_from = lane ? (up >> S) + 1u : (j ? (block_prev_last(t, j) >> S) + 1u : 0u);
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        const uint32_t doc = e ? d.d1 : d.d0, tf = e ? d.t1 : d.t0, i = i0 + (uint32_t)e;
+        if (i < df && doc < seg.max_doc) {
+          ent[i] = rdir_entry(doc, tf, S);
+          const uint32_t r_to = doc >> S;
+          for (uint32_t r = r_from; r <= r_to; ++r) dir[r] = i;
+          r_from = r_to + 1u;
+          if (i + 1u == df)
+            for (uint32_t r = r_from; r <= n_ranges; ++r) dir[r] = df;
+          if (cache) {
+            const float f = (float)tf;
+            const float tfn = f / (f + cache[seg.fieldnorm ? (uint32_t)seg.fieldnorm[doc] : seg.const_fieldnorm_id]);
+            uint32_t q = (uint32_t)(tfn * 255.0f) + 1u;
+            q = q > 255u ? 255u : q;
+            lmax = q > lmax ? q : lmax;
+          }
+        }
+      }
+    }
   }
+  if (!ent || !cache) return;  // (uniform per workgroup)
+  for (int o = 32; o; o >>= 1) {
+    const uint32_t other = (uint32_t)__shfl_xor((int)lmax, o, WAVE);
+    lmax = other > lmax ? other : lmax;
+  }
+  if (lane == 0 && lmax) atomicMax(lmax_out + blockIdx.x, lmax);
+}
+// the same from a decoded list (docs ascending, n of them): tq_term_prepare's path
+__global__ void rdir_fill_kernel(const uint32_t *docs, const uint32_t *tfs, uint32_t n, uint32_t max_doc, uint32_t *dir,
+                                 uint32_t S) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  uint32_t *ent = dir + (((max_doc >> S) + 2u + 3u) & ~3u);
+  const uint32_t doc = docs[i];
+  if (doc >= max_doc) return;
+  ent[i] = rdir_entry(doc, tfs[i], S);
+  const uint32_t r_to = doc >> S;
+  for (uint32_t r = i ? (docs[i - 1u] >> S) + 1u : 0u; r <= r_to; ++r) dir[r] = i;
+  if (i + 1u == n)
+    for (uint32_t r = r_to + 1u; r <= (max_doc >> S) + 1u; ++r) dir[r] = n;
 }
 
 __global__ void doccls_set_kernel(uint64_t *cls, const uint32_t *docs, const uint32_t *tfs, uint32_t n, uint32_t slot,
@@ -252,12 +312,19 @@ hipError_t tqk_launch_docmat_set(uint64_t *mat, const uint32_t *docs, uint32_t n
   return hipGetLastError();
 }
 hipError_t tqk_launch_docsig_batch(const TqdSegment &seg, const TqdTerm *const *selfs, const uint32_t *bits, uint32_t n,
-                                   uint64_t *mat, bool use_dpp, hipStream_t st) {
+                                   uint64_t *mat, uint32_t *const *tabs, const uint32_t *shifts, const uint32_t *dfs,
+                                   const float *cache, uint32_t *lmax_out, bool use_dpp, hipStream_t st) {
   if (n == 0) return hipSuccess;
   if (use_dpp)
-    hipLaunchKernelGGL((docsig_batch_kernel<true>), dim3(n), dim3(256), 0, st, seg, selfs, bits, mat);
+    hipLaunchKernelGGL((docsig_batch_kernel<true>), dim3(n), dim3(256), 0, st, seg, selfs, bits, mat, tabs, shifts, dfs, cache, lmax_out);
   else
-    hipLaunchKernelGGL((docsig_batch_kernel<false>), dim3(n), dim3(256), 0, st, seg, selfs, bits, mat);
+    hipLaunchKernelGGL((docsig_batch_kernel<false>), dim3(n), dim3(256), 0, st, seg, selfs, bits, mat, tabs, shifts, dfs, cache, lmax_out);
+  return hipGetLastError();
+}
+hipError_t tqk_launch_rdir_fill(const uint32_t *docs, const uint32_t *tfs, uint32_t n, uint32_t max_doc, uint32_t *dir,
+                                uint32_t S, hipStream_t st) {
+  if (n == 0) return hipSuccess;
+  hipLaunchKernelGGL(rdir_fill_kernel, dim3((n + 255) / 256), dim3(256), 0, st, docs, tfs, n, max_doc, dir, S);
   return hipGetLastError();
 }
 hipError_t tqk_launch_doccls_set(uint64_t *cls, const uint32_t *docs, const uint32_t *tfs, uint32_t n, uint32_t slot,

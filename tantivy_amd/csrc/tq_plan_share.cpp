@@ -396,18 +396,29 @@ int build_ashare_plan(tq_segment *s, Group &g, PlanScratch &ps, bool boolean) {
         {  // (list 1's own tables, or the ones built for probes: build_probe_tables)
           const TermHost &t1 = s->terms[dq.term[1]];
           const bool own = t1.dense_blob && t1.tf8_blob;
-          ld.dense_off = off_of(own ? t1.dense_blob : t1.probe_dense_blob);
-          ld.tf8_off = off_of(own ? t1.tf8_blob : t1.probe_tf8_blob);
+          static const bool kUseRdir = tune_u32("TQ_AS_RDIR", 1) != 0;
+          if (!own && dq.n_terms == 2u && t1.rdir_blob && s->rdir_span_ok && (kUseRdir || !(t1.probe_dense_blob && t1.probe_tf8_blob))) {
+            // its range directory: dense_off = the directory, tf8_off = the entries, info bits 16-20 = the shift
+            ld.info |= TQD_AL_RDIR | (t1.rdir_shift << 16);
+            ld.dense_off = off_of(t1.rdir_blob);
+            ld.tf8_off = off_of(t1.rdir_ent);
+          } else {
+            ld.dense_off = off_of(own ? t1.dense_blob : t1.probe_dense_blob);
+            ld.tf8_off = off_of(own ? t1.tf8_blob : t1.probe_tf8_blob);
+          }
         }
         {  // list 1's range maxima (tq_terms.cpp build_rmax), the split of `rest` the kernel bounds with them
           const TermHost &t1 = s->terms[dq.term[1]];
           const float w1 = dq.weight[1];
           float others = 0.0f;
           for (uint32_t m = 2; m < dq.n_terms; ++m) others += dq.weight[m];
-          ld.excl_lo = kUseRanges && t1.rmax_blob ? off_of(t1.rmax_blob) : 0u;
+          // (a list probed through its range directory: the directory says which leader blocks it has postings in —
+          // the kernel reads it through dense_off — and the list's largest tf/(tf + norm) stands in for range maxima)
+          const bool rdir = (ld.info & TQD_AL_RDIR) != 0u;
+          ld.excl_lo = kUseRanges && !rdir && t1.rmax_blob ? off_of(t1.rmax_blob) : 0u;
           memcpy(&ld.excl_hi, &w1, sizeof(float));
           memcpy(&ld.any1_lo, &others, sizeof(float));
-          ld.any1_hi = ld.excl_lo ? t1.rmax_list : 255u;
+          ld.any1_hi = (ld.excl_lo || (kUseRanges && rdir)) ? t1.rmax_list : 255u;
         }
         ld.k = dq.k;
         ld.thr_row = dq.thr_index;

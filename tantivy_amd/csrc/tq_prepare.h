@@ -70,6 +70,9 @@ hipError_t tqp_launch_bits(const uint2 *tab, uint32_t n_words, uint32_t *bits, u
 // range maxima of a list with a bitmap (tq_device.h TQD_RM_*: tq_ashare.hip's bound on the non-leader lists);
 // acc = (max_doc >> TQD_RM_SHIFT) + 1 ZEROED u32 of scratch, out = tqd_rm_level_off(max_doc, TQD_RM_LEVELS) bytes,
 // *list_max zeroed
+// *out (zeroed) = the list's largest tf/(tf + norm) under `cache`, as td_rmax_* round it (a byte, rounded up)
+hipError_t tqp_launch_list_max(const uint32_t *docs, const uint32_t *tfs, uint32_t n, const uint8_t *fieldnorm,
+                               uint32_t const_id, const float *cache, uint32_t *out, hipStream_t st);
 hipError_t tqp_launch_rmax(const uint32_t *docs, const uint32_t *tfs, uint32_t n, const uint8_t *fieldnorm,
                            uint32_t const_id, const float *cache, uint32_t *acc, uint32_t max_doc, uint8_t *out,
                            uint32_t *list_max, hipStream_t st);

@@ -403,6 +403,24 @@ __global__ __launch_bounds__(256) void td_rmax_scatter_kernel(const uint32_t *do
   const uint32_t before = (uint32_t)__shfl_up((int)r, 1, WAVE);
   if (r != 0xFFFFFFFFu && (lane == 0 || before != r)) atomicMax(acc + r, q);
 }
+// the largest of those bytes over a whole list (a list with a range directory keeps only that: rdir_plan, tq_terms.cpp)
+__global__ __launch_bounds__(256) void td_list_max_kernel(const uint32_t *docs, const uint32_t *tfs, uint32_t n,
+                                                          const uint8_t *fieldnorm, uint32_t const_id, const float *cache,
+                                                          uint32_t *out) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  uint32_t q = 0;
+  if (i < n) {
+    const float f = (float)tfs[i];
+    const float tfn = f / (f + cache[fieldnorm ? (uint32_t)fieldnorm[docs[i]] : const_id]);
+    q = (uint32_t)(tfn * 255.0f) + 1u;
+    q = q > 255u ? 255u : q;
+  }
+  for (int o = 32; o; o >>= 1) {
+    const uint32_t other = (uint32_t)__shfl_xor((int)q, o, WAVE);
+    q = other > q ? other : q;
+  }
+  if ((threadIdx.x & 63u) == 0u && q) atomicMax(out, q);
+}
 // level 0 as bytes + the list's largest entry
 __global__ void td_rmax_pack_kernel(const uint32_t *acc, uint32_t n_ranges, uint8_t *out, uint32_t n_out, uint32_t *list_max) {
   const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
@@ -488,6 +506,11 @@ hipError_t tqp_launch_bits(const uint2 *tab, uint32_t n_words, uint32_t *bits, u
 hipError_t tqp_launch_min_fieldnorm(const uint8_t *fieldnorm, uint32_t max_doc, uint32_t *out,
                                     hipStream_t st) {
   hipLaunchKernelGGL(td_min_fieldnorm_kernel, dim3(256), dim3(256), 0, st, fieldnorm, max_doc, out);
+  return hipGetLastError();
+}
+hipError_t tqp_launch_list_max(const uint32_t *docs, const uint32_t *tfs, uint32_t n, const uint8_t *fieldnorm,
+                               uint32_t const_id, const float *cache, uint32_t *out, hipStream_t st) {
+  if (n) hipLaunchKernelGGL(td_list_max_kernel, dim3((n + 255) / 256), dim3(256), 0, st, docs, tfs, n, fieldnorm, const_id, cache, out);
   return hipGetLastError();
 }
 // range maxima (td_rmax_*): acc = (max_doc >> TQD_RM_SHIFT) + 1 zeroed u32 of scratch, out = the table (all

@@ -15,6 +15,7 @@ int search_batch_impl(tq_segment *s, const tq_query *queries, uint32_t n_queries
   const auto tr0 = std::chrono::steady_clock::now();
   HIP_TRY(hipSetDevice(s->device));
   hipStream_t st = hip_stream ? (hipStream_t)hip_stream : s->stream;
+  prep_apply_lmax(s, false);
   if (s->prep_pending >= 0) {  // terms uploaded by tq_term_prepare_batch on the copy stream: this batch reads them
     if (st != s->stream) HIP_TRY(hipStreamWaitEvent(st, s->ev_prep[s->prep_pending], 0));
     s->prep_pending = -1;
@@ -78,7 +79,7 @@ int search_batch_impl(tq_segment *s, const tq_query *queries, uint32_t n_queries
       if (q.mode == TQ_MODE_AND && q.n_terms == 2 && q.terms && q.terms[0] < n_terms_known && q.terms[1] < n_terms_known) {
         const TermHost &a = s->terms[q.terms[0]], &b = s->terms[q.terms[1]];
         const TermHost &probed = b.doc_freq < a.doc_freq ? a : b;
-        if (!(probed.dense_blob && probed.tf8_blob)) ++n_sparse2;
+        if (!(probed.dense_blob && probed.tf8_blob) && !probed.rdir_blob) ++n_sparse2;
       }
     }
   }
@@ -105,6 +106,10 @@ int search_batch_impl(tq_segment *s, const tq_query *queries, uint32_t n_queries
         if (h >= s->terms.size()) continue;  // (absent, or reported by plan_query)
         const TermHost &th = s->terms[h];
         if (th.dense_blob && th.tf8_blob) continue;
+        if (and2 && th.rdir_blob && s->rdir_span_ok) continue;  // (probed through its range directory)
+        // (a list too short for a directory — rdir_plan — is too short for a max_doc / 4-byte slot of the probe pool:
+        // its queries keep the per-query kernel, whose leader has at most as many blocks)
+        if (and2 && s->opt.rdir_budget_x > 0 && th.doc_freq < 256u) continue;
         const bool had = th.probe_dense_blob && th.probe_tf8_blob;
         bool ok = false;
         const int prc = build_probe_tables(s, h, &ok);  // (tables it already has: marked as used by this batch)
@@ -182,7 +187,19 @@ int search_batch_impl(tq_segment *s, const tq_query *queries, uint32_t n_queries
           hi = std::max<uint64_t>(hi, (uint64_t)ptr);
         }
     if (lo == ~0ull) lo = hi = 8;
-    s->share_table_lo = lo - 8;
+    {  // the range directories' chunks: inside the span when it still fits with them (else the lists do without)
+      uint64_t lo2 = lo, hi2 = hi;
+      for (const auto &ch : s->rdir_chunks) {
+        lo2 = std::min<uint64_t>(lo2, (uint64_t)ch.first);
+        hi2 = std::max<uint64_t>(hi2, (uint64_t)ch.first + ch.second);
+      }
+      s->rdir_span_ok = !s->rdir_chunks.empty() && hi2 - (lo2 - 8) < (8ull << 32);
+      if (s->rdir_span_ok) {
+        lo = lo2;
+        hi = hi2;
+      }
+    }
+    s->share_table_lo = (lo - 8) & ~255ull;  // (256-byte aligned: a range directory's offset keeps its low five bits free for the shift)
     s->share_span_ok = hi - s->share_table_lo < (8ull << 32);
     s->share_span_terms = s->terms.size();
   }
@@ -225,7 +242,9 @@ int search_batch_impl(tq_segment *s, const tq_query *queries, uint32_t n_queries
     for (uint32_t i = 0; i < q.n_terms; ++i) {
       if (i == best_i) continue;
       const TermHost &th = s->terms[q.terms[i]];
-      if (!(th.dense_blob && th.tf8_blob) && !(and_probe && q.n_terms == 2 && th.probe_dense_blob && th.probe_tf8_blob)) return 0xFFFFFFFFu;
+      if (!(th.dense_blob && th.tf8_blob) && !(q.n_terms == 2 && th.rdir_blob && s->rdir_span_ok) &&
+          !(and_probe && q.n_terms == 2 && th.probe_dense_blob && th.probe_tf8_blob))
+        return 0xFFFFFFFFu;
     }
     return q.terms[best_i];
   };

@@ -85,6 +85,71 @@ void dense_release(tq_segment *s, void *ptr) {
     }
 }
 
+// Range directories (TermHost::rdir_blob; rdir_lookup in tq_common.hpp): carved out of 32 MB chunks kept until the
+// segment is closed.  rdir_plan: the list's shift S — ranges of 2^S docs, the smallest S in 2..16 that leaves at most
+// df / 2 ranges (two to four postings per range; entries keep 16 bits of the doc id) — or 0: no directory (the option is
+// off, the segment or the list is tiny, or the directories have reached "rdir_budget_x").  rdir_bytes: entries (one
+// u32 per posting) behind (max_doc >> S) + 2 directory slots (padded to four).
+size_t rdir_dir_words(const tq_segment *s, uint32_t S) { return (((size_t)(s->max_doc >> S) + 2u) + 3u) & ~(size_t)3u; }
+size_t rdir_bytes(const tq_segment *s, uint32_t doc_freq, uint32_t S) {
+  return (rdir_dir_words(s, S) + (size_t)doc_freq) * sizeof(uint32_t);
+}
+uint32_t rdir_plan(tq_segment *s, uint32_t doc_freq) {
+  static const uint32_t kRatio = tune_u32("TQ_RDIR_RATIO", 0);  // (experiments: only lists below max_doc / ratio)
+  static const uint32_t kMinDf = std::max<uint32_t>(1u, tune_u32("TQ_RDIR_MIN_DF", 256));  // (below: the directory would outweigh the list)
+  if (!s->opt.dense || s->opt.rdir_budget_x <= 0 || s->max_doc < 4096u || doc_freq < kMinDf) return 0u;
+  if (kRatio && (uint64_t)doc_freq * kRatio >= s->max_doc) return 0u;
+  uint32_t S = 2;
+  while (S < 16u && (s->max_doc >> S) + 1u > doc_freq / 2u) ++S;
+  if (s->rdir_bytes_total + rdir_bytes(s, doc_freq, S) > s->rdir_budget()) return 0u;
+  return S;
+}
+int rdir_alloc(tq_segment *s, size_t bytes, void **out) {
+  constexpr size_t kChunk = (size_t)32 << 20;
+  const size_t need = (bytes + 255) & ~(size_t)255;
+  if (need > kChunk / 2) {
+    void *own = nullptr;
+    HIP_TRY(hipMalloc(&own, need));
+    s->rdir_chunks.push_back({own, need});
+    *out = own;
+  } else {
+    if (need > s->rdir_chunk_left) {
+      void *chunk = nullptr;
+      HIP_TRY(hipMalloc(&chunk, kChunk));
+      s->rdir_chunks.push_back({chunk, kChunk});
+      s->rdir_chunk_cur = (uint8_t *)chunk;
+      s->rdir_chunk_left = kChunk;
+    }
+    *out = s->rdir_chunk_cur;
+    s->rdir_chunk_cur += need;
+    s->rdir_chunk_left -= need;
+  }
+  s->rdir_bytes_total += bytes;
+  s->bytes_term_tables += bytes;
+  s->share_span_terms = ~(size_t)0;  // (the tables' address span is taken again: tq_search.cpp)
+  return TQ_OK;
+}
+// rmax_list (the list's largest tf/(tf + norm), what the shared intersection launch bounds a probed list with) of the
+// lists whose directories an earlier tq_term_prepare_batch call built, once that call's launch has finished
+void prep_apply_lmax(tq_segment *s, bool wait) {
+  for (int bx = 0; bx < 2; ++bx) {
+    std::vector<uint32_t> &hs = s->prep_lmax_handles[bx];
+    if (hs.empty() || !s->ev_prep[bx]) continue;
+    if (wait) {
+      if (hipEventSynchronize(s->ev_prep[bx]) != hipSuccess) continue;
+    } else if (hipEventQuery(s->ev_prep[bx]) != hipSuccess) {
+      (void)hipGetLastError();
+      continue;
+    }
+    for (size_t i = 0; i < hs.size(); ++i) {
+      TermHost &t = s->terms[hs[i]];
+      const uint32_t lmax = s->prep_lmax_host[bx][i];
+      if (t.rdir_blob && !t.rmax_blob && lmax) t.rmax_list = std::min<uint32_t>(lmax, 255u);
+    }
+    hs.clear();
+  }
+}
+
 int build_tf8(tq_segment *s, uint32_t handle, const uint32_t *d_tfs) {
   TermHost &t = s->terms[handle];
   const size_t bytes = ((size_t)t.doc_freq + 7) & ~(size_t)7;
@@ -206,25 +271,51 @@ int ensure_docmat(tq_segment *s) {
 // candidate's fieldnorm id and column bits brings its signature.  Only prepared (queried) lists
 // set bits; built by one decode of the list.
 int add_to_doc_signatures(tq_segment *s, uint32_t handle) {
-  if (!s->opt.docsig || !s->opt.docmat || !s->opt.dense || s->max_doc < 4096u) return TQ_OK;
-  if ((s->h_dterms[handle].has_freq >> 8) & 0xFFu) return TQ_OK;  // the list has a column
   TermHost &t = s->terms[handle];
   if (t.doc_freq == 0) return TQ_OK;
-  int rc = ensure_docmat(s);
-  if (rc != TQ_OK) return rc;
-  if (!s->d_docmat) return TQ_OK;
+  const bool has_col = ((s->h_dterms[handle].has_freq >> 8) & 0xFFu) != 0u;
+  bool want_sig = s->opt.docsig && s->opt.docmat && s->opt.dense && s->max_doc >= 4096u && !has_col;
+  // (a list without tables of its own also gets its range directory from the same decode)
+  const uint32_t rd_shift = !(t.dense_blob && t.tf8_blob) && !t.rdir_blob ? rdir_plan(s, t.doc_freq) : 0u;
+  if (want_sig) {
+    const int rc = ensure_docmat(s);
+    if (rc != TQ_OK) return rc;
+    want_sig = s->d_docmat != nullptr;
+  }
+  if (!want_sig && !rd_shift) return TQ_OK;
   const size_t bytes = (size_t)t.doc_freq * sizeof(uint32_t);
-  rc = s->d_misc.ensure(2 * bytes + 64);
+  int rc = s->d_misc.ensure(2 * bytes + 128);
   if (rc != TQ_OK) return rc;
   uint32_t *dd = (uint32_t *)s->d_misc.p, *dt = dd + t.doc_freq;
   hipError_t e = tqk_launch_decode_list(s->dseg, t.d_self, 0u, t.n_blocks, dd, dt,
                                         s->opt.use_dpp != 0, s->stream);
   if (e != hipSuccess) return fail(TQ_ERR_HIP, "decode launch: %s", hipGetErrorString(e));
-  const uint32_t bit = (handle * 0x9E3779B1u) >> (32 - 4);  // 0 .. TQD_SIG_BITS - 1
-  e = tqk_launch_docmat_set(s->d_docmat, dd, t.doc_freq, (TQD_SIG_SHIFT - 8u) + bit, s->max_doc, s->stream);
-  if (e != hipSuccess) return fail(TQ_ERR_HIP, "docmat signature: %s", hipGetErrorString(e));
-  s->h_dterms[handle].has_freq |= (bit + 1u) << 16;
-  mark_term_dirty(s, handle);
+  if (want_sig) {
+    const uint32_t bit = (handle * 0x9E3779B1u) >> (32 - 4);  // 0 .. TQD_SIG_BITS - 1
+    e = tqk_launch_docmat_set(s->d_docmat, dd, t.doc_freq, (TQD_SIG_SHIFT - 8u) + bit, s->max_doc, s->stream);
+    if (e != hipSuccess) return fail(TQ_ERR_HIP, "docmat signature: %s", hipGetErrorString(e));
+    s->h_dterms[handle].has_freq |= (bit + 1u) << 16;
+    mark_term_dirty(s, handle);
+  }
+  if (rd_shift) {
+    void *tab = nullptr;
+    rc = rdir_alloc(s, rdir_bytes(s, t.doc_freq, rd_shift), &tab);
+    if (rc != TQ_OK) return rc;
+    e = tqk_launch_rdir_fill(dd, dt, t.doc_freq, s->max_doc, (uint32_t *)tab, rd_shift, s->stream);
+    if (e != hipSuccess) return fail(TQ_ERR_HIP, "range directory: %s", hipGetErrorString(e));
+    t.rdir_blob = tab;
+    t.rdir_ent = (uint32_t *)tab + rdir_dir_words(s, rd_shift);
+    t.rdir_shift = rd_shift;
+    if (s->d_local_cache) {  // the list's largest tf/(tf + norm): td_rmax_scatter_kernel's value, one range
+      uint32_t *acc = dt + t.doc_freq + 8u, lmax = 0;
+      e = hipMemsetAsync(acc, 0, sizeof(uint32_t), s->stream);
+      if (e == hipSuccess) e = tqp_launch_list_max(dd, dt, t.doc_freq, s->d_fn, s->dseg.const_fieldnorm_id, s->d_local_cache, acc, s->stream);
+      if (e == hipSuccess) e = hipMemcpyAsync(&lmax, acc, 4, hipMemcpyDeviceToHost, s->stream);
+      if (e == hipSuccess) e = hipStreamSynchronize(s->stream);
+      if (e != hipSuccess) return fail(TQ_ERR_HIP, "list maximum: %s", hipGetErrorString(e));
+      if (lmax) t.rmax_list = std::min<uint32_t>(lmax, 255u);
+    }
+  }
   return TQ_OK;
 }
 
@@ -520,6 +611,20 @@ int tq_term_prepare_batch(tq_segment *s, const tq_term_info *infos, uint32_t n, 
     }
   }
   if (fresh.empty()) return TQ_OK;
+  static const bool trace = getenv("TQ_TRACE") != nullptr;
+  const auto tp0 = std::chrono::steady_clock::now();
+  auto tp1 = tp0, tp2 = tp0, tp3 = tp0, tp4 = tp0;
+  struct Report {
+    bool on;
+    const std::chrono::steady_clock::time_point &a, &b, &c, &d, &e;
+    size_t n;
+    ~Report() {
+      if (!on) return;
+      auto us = [](auto x, auto y) { return (long)std::chrono::duration_cast<std::chrono::microseconds>(y - x).count(); };
+      fprintf(stderr, "[tq] prepare_batch %zu new terms: walk %ld us, lock %ld us, place %ld us, register + tables %ld us, copy + launch %ld us\n", n,
+              us(a, b), us(b, c), us(c, d), us(d, e), us(e, std::chrono::steady_clock::now()));
+    }
+  } report{trace, tp0, tp1, tp2, tp3, tp4, fresh.size()};
   // The host walk of the new lists runs WITHOUT the segment's lock (it reads the host copy of the index and a few
   // options): a second host thread can walk the next batch's terms while the first plans and enqueues this one.
   std::vector<WalkedTerm> prewalked;
@@ -528,15 +633,33 @@ int tq_term_prepare_batch(tq_segment *s, const tq_term_info *infos, uint32_t n, 
     const size_t body = s->idx_len - 8;
     prewalked.resize(fresh.size());
     prewalked_ok.assign(fresh.size(), 0);
-    for (size_t k = 0; k < fresh.size(); ++k) {
-      const tq_term_info &ti = infos[fresh[k]];
-      if (ti.doc_freq == 0 || ti.postings_off > body || (uint64_t)ti.postings_len > body - ti.postings_off) continue;  // (reported below)
-      if (s->opt.dense && s->max_doc >= 4096u && (uint64_t)ti.doc_freq * (uint64_t)s->opt.dense_ratio >= s->max_doc) continue;
-      if (host_walk_term(s, ti.postings_off, ti.postings_len, ti.positions_off, ti.positions_len, ti.doc_freq, prewalked[k]) == TQ_OK)
-        prewalked_ok[k] = 1;  // (a malformed list: walked again under the lock, where its error is reported)
+    auto walk_some = [&](size_t k0, size_t step) {
+      for (size_t k = k0; k < fresh.size(); k += step) {
+        const tq_term_info &ti = infos[fresh[k]];
+        if (ti.doc_freq == 0 || ti.postings_off > body || (uint64_t)ti.postings_len > body - ti.postings_off) continue;  // (reported below)
+        if (s->opt.dense && s->max_doc >= 4096u && (uint64_t)ti.doc_freq * (uint64_t)s->opt.dense_ratio >= s->max_doc) continue;
+        if (host_walk_term(s, ti.postings_off, ti.postings_len, ti.positions_off, ti.positions_len, ti.doc_freq, prewalked[k]) == TQ_OK)
+          prewalked_ok[k] = 1;  // (a malformed list: walked again under the lock, where its error is reported)
+      }
+    };
+    // (a batch that discovers a large vocabulary names a couple of thousand new lists, 0.8 us of walking each: a few
+    // short-lived helper threads take their share — TQ_PREP_THREADS, default 4 walkers from 512 lists on)
+    static const uint32_t kWalkers = std::max<uint32_t>(1u, tune_u32("TQ_PREP_THREADS", 4));
+    const size_t n_walk = std::min<size_t>(kWalkers, fresh.size() / 256u);
+    std::vector<std::thread> helpers;
+    for (size_t w = 1; w < n_walk; ++w) {
+      try {
+        helpers.emplace_back(walk_some, w, n_walk);
+      } catch (...) {  // (a thread limit: the caller walks that share too)
+        walk_some(w, n_walk);
+      }
     }
+    walk_some(0, std::max<size_t>(1, n_walk));
+    for (std::thread &h : helpers) h.join();
   }
+  tp1 = std::chrono::steady_clock::now();
   TQ_SEGMENT_LOCK(s);
+  tp2 = tp3 = tp4 = std::chrono::steady_clock::now();
   HIP_TRY(hipSetDevice(s->device));
   const size_t dense_bytes = (((size_t)s->max_doc + 31) / 32 + 1) * sizeof(uint2);
   auto one_by_one = [&](uint32_t i) {
@@ -553,7 +676,9 @@ int tq_term_prepare_batch(tq_segment *s, const tq_term_info *infos, uint32_t n, 
   const size_t body_len = s->idx_len - 8;
   std::vector<WalkedTerm> walked;
   std::vector<uint32_t> walked_of;
+  std::unordered_set<uint64_t> walked_offs;  // (postings offsets seen in this call: a term named twice is prepared once)
   walked.reserve(fresh.size());
+  walked_offs.reserve(fresh.size() * 2);
   size_t stage_bytes = 0;
   for (const uint32_t &i : fresh) {
     const tq_term_info &ti = infos[i];
@@ -567,8 +692,7 @@ int tq_term_prepare_batch(tq_segment *s, const tq_term_info *infos, uint32_t n, 
                   ti.postings_len, body_len);
     const bool dense = s->opt.dense && s->max_doc >= 4096u && (uint64_t)ti.doc_freq * (uint64_t)s->opt.dense_ratio >= s->max_doc &&
                        s->dense_bytes_total + dense_bytes <= s->dense_budget();
-    bool dup = false;
-    for (size_t k = 0; k < walked.size() && !dup; ++k) dup = walked[k].postings_off == ti.postings_off;
+    const bool dup = !walked_offs.insert(ti.postings_off).second;
     if (dense || dup) {
       if (!dup) {
         const int rc = one_by_one(i);
@@ -593,11 +717,14 @@ int tq_term_prepare_batch(tq_segment *s, const tq_term_info *infos, uint32_t n, 
     // builders on the segment's stream) behind the copy and the signature launch.  (A copy per term was 3 us of host
     // time each; a wait for the segment's stream stalled the batches in flight for a millisecond per call.)
     hipStream_t cs = s->copy_stream ? s->copy_stream : s->stream;
-    const size_t ptr_bytes = (walked.size() * (sizeof(const TqdTerm *) + sizeof(uint32_t)) + 255) & ~(size_t)255;
+    const size_t ptr_bytes = (walked.size() * (2 * sizeof(const TqdTerm *) + 4 * sizeof(uint32_t)) + 255) & ~(size_t)255;
+    prep_apply_lmax(s, false);
     const uint32_t bx = s->prep_calls++ & 1u;
     if (!s->ev_prep[bx]) HIP_TRY(hipEventCreateWithFlags(&s->ev_prep[bx], hipEventDisableTiming));
     if (s->prep_used[bx]) HIP_TRY(hipEventSynchronize(s->ev_prep[bx]));  // (the copy of two calls ago: long done)
-    int rc = s->h_prep_stage[bx].ensure(stage_bytes + ptr_bytes);
+    prep_apply_lmax(s, false);  // (what that call left in the buffer, before it is written again)
+    s->prep_lmax_handles[bx].clear();
+    int rc = s->h_prep_stage[bx].ensure(stage_bytes + 2 * ptr_bytes);
     if (rc != TQ_OK) return rc;
     uint8_t *hs = (uint8_t *)s->h_prep_stage[bx].p;
     size_t at = 0;
@@ -616,9 +743,14 @@ int tq_term_prepare_batch(tq_segment *s, const tq_term_info *infos, uint32_t n, 
       rc = ensure_docmat(s);
       if (rc != TQ_OK) return rc;
     }
+    tp3 = tp4 = std::chrono::steady_clock::now();
+    // per list that gets either: record pointer, range directory, signature bit, shift, doc freq, (out) list maximum
+    // — six arrays behind the blobs
     const TqdTerm **h_selfs = (const TqdTerm **)(hs + stage_bytes);
-    std::vector<uint32_t> bits;
+    std::vector<uint32_t *> tabs;
+    std::vector<uint32_t> bits, shifts, dfs;
     uint32_t n_sig = 0;
+    bool any_tab = false;
     for (size_t k = 0; k < walked.size(); ++k) {
       WalkedTerm &w = walked[k];
       const uint32_t handle = (uint32_t)s->terms.size();
@@ -628,14 +760,42 @@ int tq_term_prepare_batch(tq_segment *s, const tq_term_info *infos, uint32_t n, 
       mark_term_dirty(s, handle);
       s->term_by_off.emplace(w.postings_off, handle);
       out[walked_of[k]] = handle;
-      if (sigs && s->d_docmat && w.th.doc_freq) {
-        const uint32_t bit = (handle * 0x9E3779B1u) >> (32 - 4);  // (add_to_doc_signatures' bit)
-        h_selfs[n_sig++] = w.th.d_self;
-        bits.push_back(bit);
-        s->h_dterms[handle].has_freq |= (bit + 1u) << 16;
+      if (!w.th.doc_freq) continue;
+      const bool sig = sigs && s->d_docmat;
+      const uint32_t S = rdir_plan(s, w.th.doc_freq);
+      void *tab = nullptr;
+      if (S) {
+        if (rdir_alloc(s, rdir_bytes(s, w.th.doc_freq, S), &tab) != TQ_OK) {  // (no memory for it: the list does without)
+          (void)hipGetLastError();
+          tab = nullptr;
+        } else {
+          s->terms[handle].rdir_blob = tab;
+          s->terms[handle].rdir_ent = (uint32_t *)tab + rdir_dir_words(s, S);
+          s->terms[handle].rdir_shift = S;
+          any_tab = true;
+        }
       }
+      if (!sig && !tab) continue;
+      const uint32_t bit = (handle * 0x9E3779B1u) >> (32 - 4);  // (add_to_doc_signatures' bit)
+      h_selfs[n_sig++] = w.th.d_self;
+      tabs.push_back((uint32_t *)tab);
+      bits.push_back(sig ? bit : 0xFFFFFFFFu);
+      shifts.push_back(tab ? S : 0u);
+      dfs.push_back(w.th.doc_freq);
+      s->prep_lmax_handles[bx].push_back(handle);
+      if (sig) s->h_dterms[handle].has_freq |= (bit + 1u) << 16;
     }
-    if (n_sig) memcpy(h_selfs + n_sig, bits.data(), (size_t)n_sig * sizeof(uint32_t));
+    if (n_sig) {
+      uint8_t *at2 = (uint8_t *)(h_selfs + n_sig);
+      memcpy(at2, tabs.data(), (size_t)n_sig * sizeof(uint32_t *));
+      at2 += (size_t)n_sig * sizeof(uint32_t *);
+      for (const std::vector<uint32_t> *arr : {&bits, &shifts, &dfs}) {
+        memcpy(at2, arr->data(), (size_t)n_sig * sizeof(uint32_t));
+        at2 += (size_t)n_sig * sizeof(uint32_t);
+      }
+      memset(at2, 0, (size_t)n_sig * sizeof(uint32_t));  // (the lists' maxima: written by the launch)
+    }
+    tp4 = std::chrono::steady_clock::now();
     // (the doc matrix may just have been created on the segment's stream: the copy stream follows it)
     hipError_t e = hipSuccess;
     if (cs != s->stream) {
@@ -646,7 +806,20 @@ int tq_term_prepare_batch(tq_segment *s, const tq_term_info *infos, uint32_t n, 
     if (e == hipSuccess) e = hipMemcpyAsync(region, hs, stage_bytes + ptr_bytes, hipMemcpyHostToDevice, cs);
     if (e == hipSuccess && n_sig) {
       const TqdTerm **d_selfs = (const TqdTerm **)(region + stage_bytes);
-      e = tqk_launch_docsig_batch(s->dseg, d_selfs, (const uint32_t *)(d_selfs + n_sig), n_sig, s->d_docmat, s->opt.use_dpp != 0, cs);
+      uint32_t *const *d_tabs = (uint32_t *const *)(d_selfs + n_sig);
+      const uint32_t *d_bits = (const uint32_t *)(d_tabs + n_sig);
+      uint32_t *d_lmax = (uint32_t *)(d_bits + 3 * n_sig);
+      e = tqk_launch_docsig_batch(s->dseg, d_selfs, d_bits, n_sig, s->d_docmat, any_tab ? d_tabs : nullptr, d_bits + n_sig,
+                                  d_bits + 2 * n_sig, s->d_local_cache, d_lmax, s->opt.use_dpp != 0, cs);
+      if (e == hipSuccess && any_tab && s->d_local_cache) {
+        uint32_t *h_lmax = (uint32_t *)(hs + stage_bytes + ptr_bytes);
+        e = hipMemcpyAsync(h_lmax, d_lmax, (size_t)n_sig * sizeof(uint32_t), hipMemcpyDeviceToHost, cs);
+        s->prep_lmax_host[bx] = h_lmax;
+      } else {
+        s->prep_lmax_handles[bx].clear();
+      }
+    } else {
+      s->prep_lmax_handles[bx].clear();
     }
     if (e == hipSuccess) e = hipEventRecord(s->ev_prep[bx], cs);
     if (e == hipSuccess && cs != s->stream) e = hipStreamWaitEvent(s->stream, s->ev_prep[bx], 0);
@@ -1038,7 +1211,7 @@ int probe_slot_acquire(tq_segment *s, uint32_t handle, bool must, int32_t *slot,
       old.probe_dense_blob = old.probe_tf8_blob = old.probe_posdir_blob = nullptr;
       if (old.rmax_blob && !old.dense_blob) {  // (the range maxima lived in the slot)
         old.rmax_blob = nullptr;
-        old.rmax_list = 255;
+        if (!old.rdir_blob) old.rmax_list = 255;  // (a list with a range directory keeps its maximum)
       }
       old.probe_slot = -1;
       s->probe_slots[(size_t)pick].owner = 0xFFFFFFFFu;
