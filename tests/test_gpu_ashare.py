@@ -246,30 +246,34 @@ def test_small_batches_keep_the_per_query_kernels(ta, seg300k):
 
 
 def test_two_list_intersections_probe_a_list_without_a_bitmap(ta, seg300k):
-    """dense_ratio 8: three lists have bitmaps.  A batch of >= ashare_min_batch 2-term intersections gets
-    bitmap + tf bytes built on first use for the lists it probes (the more frequent list of each query,
-    "probe_budget_x") and runs entirely in the shared launch; with the budget at 0 the same batch keeps the
-    general per-query kernel for those queries.  Same bits either way, equal to the oracle's."""
+    """dense_ratio 8: three lists have bitmaps.  A batch of >= ashare_min_batch 2-term intersections runs entirely in
+    the shared launch: the lists it probes (the more frequent list of each query) have range directories from their
+    preparation ("rdir_budget_x", round 6) — or, without those, get bitmap + tf bytes built on first use
+    ("probe_budget_x"); with both budgets at 0 the same batch keeps the general per-query kernel for those queries.
+    Same bits every way, equal to the oracle's."""
     queries = _and_stream(1300, 2, 64, 17)
     got = {}
-    for budget in (0, 16):
+    for probe, rdir in ((0, 0), (16, 0), (0, 4)):
         dev = ta.DeviceIndex([seg300k])
         try:
             dev.set_option("timing", 1)
             dev.set_option("dense_ratio", 8)
-            dev.set_option("probe_budget_x", budget)
+            dev.set_option("probe_budget_x", probe)
+            dev.set_option("rdir_budget_x", rdir)
             dev.set_option("ashare_min_batch", 200)
             dev.set_option("exhaustive", 0)
-            got[budget] = dev.search(queries, 10)
+            got[(probe, rdir)] = dev.search(queries, 10)
             st = dev.last_batch_stats()
             assert st["kernel_mask"] & ta.binding.KERNEL_ASHARE, st
-            if budget:
+            if probe or rdir:
                 assert not (st["kernel_mask"] & ta.binding.KERNEL_AND), st
             else:
                 assert st["kernel_mask"] & ta.binding.KERNEL_AND, st
             assert dev.segment_stats(0)["n_dense_lists"] <= 4
         finally:
             dev.close()
-    for a, b in zip(got[0], got[16]):
-        assert np.array_equal(a, b)
+    for key in ((16, 0), (0, 4)):
+        for a, b in zip(got[(0, 0)], got[key]):
+            assert np.array_equal(a, b), key
+    got = {16: got[(16, 0)]}
     _check_against_oracle(seg300k, queries[::13], [x[::13] for x in got[16]], 10)
