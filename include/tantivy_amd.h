@@ -470,7 +470,7 @@ int tq_segment_get_stats(tq_segment *seg, tq_segment_stats *out);
  *        "rdir_budget_x" (default 4, 0 = never): tq_term_prepare / tq_term_prepare_batch also give a list below
  *        "dense_ratio" with at least 256 postings a RANGE DIRECTORY — one u32 per posting in posting order (16 bits of
  *        the doc id, min(tf, 0xFFFF)) and the number of postings before every 2^S-doc range, S chosen per list so
- *        that a range holds two to four postings: 5-6 bytes per posting, counted in
+ *        that a range holds one to two postings: 6-8 bytes per posting, counted in
  *        tq_segment_stats.term_table_bytes — while the directories stay below this multiple of the segment's bytes.
  *        The shared intersection launch (TQ_KERNEL_ASHARE) probes the second list of a 2-term intersection through
  *        it ("is doc d in the list, with which tf": two directory slots and the range's entries) and drops the

@@ -304,9 +304,9 @@ __device__ __forceinline__ Dec decode_block(const uint8_t *idx, const TermRef &t
 
 // ---- range directory of a sparse list (TermHost::rdir_blob, tq_terms.cpp): the list's postings as one u32 each, in
 // posting order — (doc & (2^S - 1)) << 16 | min(tf, 0xFFFF) — and dir[r] = the number of postings with doc < r << S
-// for r = 0 .. (max_doc >> S) + 1 (S <= 16, chosen per list so that a range holds two to four postings on average).
+// for r = 0 .. (max_doc >> S) + 1 (S <= 16, chosen per list so that a range holds one to two postings on average).
 // "Is doc d in the list, with which tf" is dir[d >> S], dir[(d >> S) + 1] and the few entries between them; docs that
-// are close lie close in both arrays (a bitmap's locality at 5-6 bytes per posting instead of max_doc / 4 per list).
+// are close lie close in both arrays (a bitmap's locality at 6-8 bytes per posting instead of max_doc / 4 per list).
 __device__ __forceinline__ uint32_t rdir_entry(uint32_t doc, uint32_t tf, uint32_t S) {
   return ((doc & ((1u << S) - 1u)) << 16) | (tf < 0xFFFFu ? tf : 0xFFFFu);
 }

@@ -112,7 +112,7 @@ struct TermHost {
                                       // a phrase INSIDE a boolean query names the list (tq_tree.hip)
   int32_t probe_slot = -1;            // the slot of the segment's probe pool that holds them (tq_terms.cpp), or -1
   // a list below "dense_ratio": its range directory (rdir_lookup, tq_common.hpp: one u32 per posting in posting order +
-  // a directory of posting counts per 2^rdir_shift docs; 5-6 bytes per posting), built when the term is prepared, while
+  // a directory of posting counts per 2^rdir_shift docs; 6-8 bytes per posting), built when the term is prepared, while
   // such tables stay within "rdir_budget_x": the shared intersection launch asks it "is d in the list, with which tf" —
   // what a max_doc / 4-byte bitmap + rank directory + tf bytes from the probe pool answered before
   void *rdir_blob = nullptr;          // the directory (256-byte aligned: the shift rides in the low bits of its offset)
@@ -183,7 +183,7 @@ struct Options {
   // max_doc / xunion_ratio postings (0 = never), if the batch has at least xunion_min_queries of them
   int xunion_ratio = 64;
   int xunion_min_queries = 64;
-  int rdir_budget_x = 4;    // range directories of the lists below "dense_ratio" (5-6 B per posting): at most this multiple of the segment
+  int rdir_budget_x = 4;    // range directories of the lists below "dense_ratio" (6-8 B per posting): at most this multiple of the segment
   int probe_budget_x = 16;  // bitmaps + tf bytes built on demand for the lists boolean queries probe: at most this multiple of the segment
   int count_bitmap_ratio = 128;  // Count: bitmap words instead of a scan if the driving clause holds >= max_doc / ratio postings per list
   int ashare_min_batch = 512;   // intersections: the shared launch needs this many qualifying queries in the batch
