@@ -190,7 +190,6 @@ void tq_segment_free(tq_segment *s) {
   (void)hipSetDevice(s->device);
   if (s->stream) (void)hipStreamSynchronize(s->stream);
   if (s->batch_in_flight && s->ev_batch_done) (void)hipEventSynchronize(s->ev_batch_done);
-  for (auto &ch : s->rdir_chunks) (void)hipFree(ch.first);
   for (void *slab : s->term_slabs) (void)hipFree(slab);  // (the terms' table blobs: tq_terms.cpp term_alloc)
   // (bitmaps, byte-wide tfs, position directories, plain lists: the arena and its overflow)
   if (s->dense_arena) (void)hipFree(s->dense_arena);

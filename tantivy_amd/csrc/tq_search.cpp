@@ -47,6 +47,36 @@ int search_batch_impl(tq_segment *s, const tq_query *queries, uint32_t n_queries
   // 4 096 terms) the shared launch with probe tables is 12 % faster.  TQ_AS_PROBE: 0 never, 1 from 10 % of
   // the batch (default), 2 always.
   static const uint32_t kProbeAnd = tune_u32("TQ_AS_PROBE", 1);
+  // The address span of the side tables the shared launches reach through 32-bit offsets (8-byte units from its lower
+  // end: 32 GB), taken again when tables were added.
+  auto update_table_span = [&]() {
+    if (s->share_span_terms != s->terms.size()) {  // (terms are prepared rarely)
+      uint64_t lo = ~0ull, hi = 0;
+      for (const TermHost &th : s->terms)
+        for (const void *ptr : {th.dense_blob, th.tf8_blob, th.probe_dense_blob, th.probe_tf8_blob, th.rmax_blob, th.posdir_blob, th.probe_posdir_blob})
+          if (ptr) {
+            lo = std::min<uint64_t>(lo, (uint64_t)ptr);
+            hi = std::max<uint64_t>(hi, (uint64_t)ptr);
+          }
+      if (lo == ~0ull) lo = hi = 8;
+      {  // the range directories' chunks: inside the span when it still fits with them (else the lists do without)
+        uint64_t lo2 = lo, hi2 = hi;
+        for (const auto &ch : s->rdir_chunks) {
+          lo2 = std::min<uint64_t>(lo2, (uint64_t)ch.first);
+          hi2 = std::max<uint64_t>(hi2, (uint64_t)ch.first + ch.second);
+        }
+        s->rdir_span_ok = !s->rdir_chunks.empty() && hi2 - (lo2 - 8) < (8ull << 32);
+        if (s->rdir_span_ok) {
+          lo = lo2;
+          hi = hi2;
+        }
+      }
+      s->share_table_lo = (lo - 8) & ~255ull;  // (256-byte aligned: a range directory's offset keeps its low five bits free for the shift)
+      s->share_span_ok = hi - s->share_table_lo < (8ull << 32);
+      s->share_span_terms = s->terms.size();
+    }
+  };
+  update_table_span();
   // ONE pass over the caller's queries for everything that only needs a look at them: which Bm25Weight cache each
   // uses (pointer identity; a handful per batch), how many are unions (a one-list intersection runs as one), whether
   // there are boolean queries at all, how many 2-term intersections probe a list without tables (six passes over
@@ -79,7 +109,7 @@ int search_batch_impl(tq_segment *s, const tq_query *queries, uint32_t n_queries
       if (q.mode == TQ_MODE_AND && q.n_terms == 2 && q.terms && q.terms[0] < n_terms_known && q.terms[1] < n_terms_known) {
         const TermHost &a = s->terms[q.terms[0]], &b = s->terms[q.terms[1]];
         const TermHost &probed = b.doc_freq < a.doc_freq ? a : b;
-        if (!(probed.dense_blob && probed.tf8_blob) && !probed.rdir_blob) ++n_sparse2;
+        if (!(probed.dense_blob && probed.tf8_blob) && !(probed.rdir_blob && s->rdir_span_ok)) ++n_sparse2;
       }
     }
   }
@@ -178,31 +208,7 @@ int search_batch_impl(tq_segment *s, const tq_query *queries, uint32_t n_queries
   const uint64_t kDenseRatio = kDenseRatioEnv != 0xFFFFFFFFu ? kDenseRatioEnv : (uint32_t)s->opt.xunion_ratio;
   const uint32_t kDenseMinQueries = std::max<uint32_t>(1u, kDenseMinEnv != 0xFFFFFFFFu ? kDenseMinEnv : (uint32_t)s->opt.xunion_min_queries);
   uint32_t dense_cache = 0xFFFFFFFFu;
-  if (s->share_span_terms != s->terms.size()) {  // (terms are prepared rarely)
-    uint64_t lo = ~0ull, hi = 0;
-    for (const TermHost &th : s->terms)
-      for (const void *ptr : {th.dense_blob, th.tf8_blob, th.probe_dense_blob, th.probe_tf8_blob, th.rmax_blob, th.posdir_blob, th.probe_posdir_blob})
-        if (ptr) {
-          lo = std::min<uint64_t>(lo, (uint64_t)ptr);
-          hi = std::max<uint64_t>(hi, (uint64_t)ptr);
-        }
-    if (lo == ~0ull) lo = hi = 8;
-    {  // the range directories' chunks: inside the span when it still fits with them (else the lists do without)
-      uint64_t lo2 = lo, hi2 = hi;
-      for (const auto &ch : s->rdir_chunks) {
-        lo2 = std::min<uint64_t>(lo2, (uint64_t)ch.first);
-        hi2 = std::max<uint64_t>(hi2, (uint64_t)ch.first + ch.second);
-      }
-      s->rdir_span_ok = !s->rdir_chunks.empty() && hi2 - (lo2 - 8) < (8ull << 32);
-      if (s->rdir_span_ok) {
-        lo = lo2;
-        hi = hi2;
-      }
-    }
-    s->share_table_lo = (lo - 8) & ~255ull;  // (256-byte aligned: a range directory's offset keeps its low five bits free for the shift)
-    s->share_span_ok = hi - s->share_table_lo < (8ull << 32);
-    s->share_span_terms = s->terms.size();
-  }
+  update_table_span();  // (probe tables built above moved it)
   Group(&groups)[kGroups] = s->plan->groups;
   for (Group &g : groups) g.reset();
   groups[kBool].mode = TQ_MODE_OR;

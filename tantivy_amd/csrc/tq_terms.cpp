@@ -54,7 +54,7 @@ int term_alloc(tq_segment *s, size_t bytes, uint8_t **out) {
 int dense_alloc(tq_segment *s, size_t bytes, void **out) {
   const size_t need = (bytes + 255) & ~(size_t)255;
   if (!s->dense_arena && s->dense_arena_cap == 0) {
-    const size_t cap = std::max<size_t>(s->dense_budget() + s->probe_budget(), (size_t)1 << 20) + PAD;
+    const size_t cap = std::max<size_t>(s->dense_budget() + s->probe_budget() + s->rdir_budget(), (size_t)1 << 20) + PAD;
     void *base = nullptr;
     if (hipMalloc(&base, cap) == hipSuccess) {
       s->dense_arena = (uint8_t *)base;
@@ -85,8 +85,8 @@ void dense_release(tq_segment *s, void *ptr) {
     }
 }
 
-// Range directories (TermHost::rdir_blob; rdir_lookup in tq_common.hpp): carved out of 32 MB chunks kept until the
-// segment is closed.  rdir_plan: the list's shift S — ranges of 2^S docs, the smallest S in 2..16 that leaves at most
+// Range directories (TermHost::rdir_blob; rdir_lookup in tq_common.hpp): carved out of 32 MB chunks of the segment's
+// arena, kept until the segment is closed.  rdir_plan: the list's shift S — ranges of 2^S docs, the smallest S in 2..16 that leaves at most
 // df ranges (one to two postings per range; entries keep 16 bits of the doc id) — or 0: no directory (the option is
 // off, the segment or the list is tiny, or the directories have reached "rdir_budget_x").  rdir_bytes: entries (one
 // u32 per posting) behind (max_doc >> S) + 2 directory slots (padded to four).
@@ -108,15 +108,19 @@ uint32_t rdir_plan(tq_segment *s, uint32_t doc_freq) {
 int rdir_alloc(tq_segment *s, size_t bytes, void **out) {
   constexpr size_t kChunk = (size_t)32 << 20;
   const size_t need = (bytes + 255) & ~(size_t)255;
+  // (chunks come out of the segment's arena of side tables — dense_alloc — so that they lie within the 32 GB the
+  // shared launches' table offsets span; a process with several indexes open hands out distant addresses otherwise)
   if (need > kChunk / 2) {
     void *own = nullptr;
-    HIP_TRY(hipMalloc(&own, need));
+    const int arc = dense_alloc(s, need, &own);
+    if (arc != TQ_OK) return arc;
     s->rdir_chunks.push_back({own, need});
     *out = own;
   } else {
     if (need > s->rdir_chunk_left) {
       void *chunk = nullptr;
-      HIP_TRY(hipMalloc(&chunk, kChunk));
+      const int arc = dense_alloc(s, kChunk, &chunk);
+      if (arc != TQ_OK) return arc;
       s->rdir_chunks.push_back({chunk, kChunk});
       s->rdir_chunk_cur = (uint8_t *)chunk;
       s->rdir_chunk_left = kChunk;
