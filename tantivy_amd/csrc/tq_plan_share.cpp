@@ -126,8 +126,19 @@ int build_share_plan(tq_segment *s, Group &g, PlanScratch &ps) {
       if (m < li) {
         if (col) ld.before_mask |= 1ull << col;
       } else if (m > li) {
-        ld.dense_off[m - li - 1u] = off_of(s->opt.use_dense ? s->terms[dq.term[m]].dense_blob : nullptr);
-        ld.tf8_off[m - li - 1u] = off_of(s->terms[dq.term[m]].tf8_blob);
+        {
+          const TermHost &tm = s->terms[dq.term[m]];
+          static const bool kUseRdir = tune_u32("TQ_US_RDIR", 1) != 0;
+          if (s->opt.use_dense && tm.dense_blob) {
+            ld.dense_off[m - li - 1u] = off_of(tm.dense_blob);
+            ld.tf8_off[m - li - 1u] = off_of(tm.tf8_blob);
+          } else if (kUseRdir && s->opt.use_dense && tm.rdir_blob && s->rdir_span_ok) {
+            // a list without a bitmap but with a range directory (rdir_lookup, tq_common.hpp): directory | shift (the
+            // tables' offsets are multiples of 32: low bits set = a directory), entries
+            ld.dense_off[m - li - 1u] = off_of(tm.rdir_blob) | tm.rdir_shift;
+            ld.tf8_off[m - li - 1u] = off_of(tm.rdir_ent);
+          }
+        }
         const uint32_t bitpos = col ? col : (sig1 ? TQD_SIG_SHIFT + (sig1 - 1u) : 0u);
         if (bitpos) {
           if (ncols < 4u)

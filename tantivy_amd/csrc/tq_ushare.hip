@@ -370,27 +370,87 @@ ushare_kernel(TqkShareParams p) {
         pi[u] = 0;
       }
       tb(12u);
-      // level 1: bitmap word + rank
+      // level 1: bitmap word + rank — or, a list with a range directory (doff's low bits = its shift): the two
+      // directory slots around the doc's range (round 6: such a list used to be seeked and block-searched)
       uint2 wd[CH];
 #pragma unroll
       for (uint32_t u = 0; u < CH; ++u) {
         wd[u] = make_uint2(0u, 0u);
-        if ((found[u] || probe_sparse[u]) && doff[u])
-          wd[u] = reinterpret_cast<const uint2 *>(tbase + ((uint64_t)doff[u] << 3))[doc >> 5];
+        if ((found[u] || probe_sparse[u]) && doff[u]) {
+          const uint32_t S = doff[u] & 31u;
+          if (!S) {
+            wd[u] = reinterpret_cast<const uint2 *>(tbase + ((uint64_t)doff[u] << 3))[doc >> 5];
+          } else {
+            const uint32_t *dir = reinterpret_cast<const uint32_t *>(tbase + ((uint64_t)(doff[u] & ~31u) << 3)) + (doc >> S);
+            wd[u] = make_uint2(dir[0], dir[1]);
+          }
+        }
       }
+      bool rd[CH];  // the list is probed through its range directory: entries wd.x .. wd.y - 1 are its range's
 #pragma unroll
       for (uint32_t u = 0; u < CH; ++u) {
         const uint32_t bit = doc & 31u;
-        if (probe_sparse[u] && doff[u]) {
+        rd[u] = probe_sparse[u] && (doff[u] & 31u);
+        if (probe_sparse[u] && doff[u] && !rd[u]) {
           found[u] = (wd[u].x >> bit) & 1u;
           probe_sparse[u] = false;
         }
-        pi[u] = wd[u].y + (uint32_t)__popc(wd[u].x & ((1u << bit) - 1u));
+        if (rd[u]) {
+          probe_sparse[u] = false;
+          rd[u] = wd[u].x < wd[u].y;
+        } else {
+          pi[u] = wd[u].y + (uint32_t)__popc(wd[u].x & ((1u << bit) - 1u));
+        }
       }
-      // level 2: the tf byte
+      // level 2: the tf byte / the range's first two entries
+      uint32_t e1[CH];
 #pragma unroll
-      for (uint32_t u = 0; u < CH; ++u)
+      for (uint32_t u = 0; u < CH; ++u) {
+        e1[u] = 0;
         if (found[u]) tfv[u] = (tbase + ((uint64_t)toff[u] << 3))[pi[u]];
+        if (rd[u]) {
+          const uint32_t *ent = reinterpret_cast<const uint32_t *>(tbase + ((uint64_t)toff[u] << 3)) + wd[u].x;
+          tfv[u] = ent[0];
+          if (wd[u].x + 1u < wd[u].y) e1[u] = ent[1];
+        }
+      }
+#pragma unroll
+      for (uint32_t u = 0; u < CH; ++u) {
+        if (__ballot(rd[u])) {
+          const uint32_t key = doc & ((1u << (doff[u] & 31u)) - 1u);
+          uint32_t lo = wd[u].x, e = tfv[u];
+          bool on2 = rd[u];
+          if (on2) {
+            tfv[u] = 0;
+            if ((e >> 16) != key && lo + 1u < wd[u].y) {  // (the second entry, already here)
+              e = e1[u];
+              ++lo;
+            }
+          }
+          while (__ballot(on2)) {  // (entries ascend inside a range: one to two on average)
+            if (on2) {
+              if ((e >> 16) == key) {
+                found[u] = true;
+                tfv[u] = e & 0xFFFFu;
+                pi[u] = lo;
+                on2 = false;
+              } else if ((e >> 16) > key || lo + 1u >= wd[u].y) {
+                on2 = false;
+              } else {
+                ++lo;
+                e = (reinterpret_cast<const uint32_t *>(tbase + ((uint64_t)toff[u] << 3)))[lo];
+              }
+            }
+          }
+          if (__ballot(rd[u] && found[u] && tfv[u] == 0xFFFFu)) {  // tf >= 65535: block record -> packed tf
+            if (rd[u] && found[u] && tfv[u] == 0xFFFFu) {
+              const TermRef tr = load_term_lane(p.terms, p.queries[q].term[li + a0 + u]);
+              const uint4 r = tr.rec[pi[u] >> 7];
+              tfv[u] = block_tf_at(idx, tr, make_uint2(r.y, r.z), pi[u] & 127u);
+            }
+          }
+        }
+      }
       if (TQ_US_TIMERS && tphase == 12u) {  // (the loads have to land inside the timed region)
         uint32_t acc = 0;
 #pragma unroll

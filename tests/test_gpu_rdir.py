@@ -114,3 +114,46 @@ def test_range_directories_against_the_oracle_and_the_probe_pool(ta):
     n_entries = sum(len(l) for l in lists if 256 <= len(l) < MAX_DOC // 128)  # (dense_ratio: 128)
     for key in ((False, None), (True, None)):
         assert table_bytes[key] >= table_bytes[(False, 0)] + 4 * n_entries, table_bytes
+
+
+def test_shared_unions_probe_sparse_lists_through_their_directories(ta):
+    """The shared-union launch (tq_ushare.hip) scores a candidate's later lists through bitmap word -> tf byte; a list
+    without a bitmap was seeked and block-searched, and is now asked through its range directory.  3- and 5-term unions
+    over the crafted segment's lists, pruned == exhaustive, against the oracle (block_wand_union.rs / union.rs), and the
+    same rows with "rdir_budget_x" = 0 (the block search)."""
+    rng = np.random.default_rng(607)
+    lists = _lists(rng)
+    fieldnorms = rng.integers(1, 60, size=MAX_DOC).tolist()
+    seg = O.build_segment(MAX_DOC, lists, fieldnorms=fieldnorms)
+    n = len(lists)
+    queries = []
+    for i in range(600):
+        nt = 3 if i % 2 else 5
+        queries.append((O.MODE_OR, rng.permutation(n)[:nt].tolist()))
+    k = 10
+    got = {}
+    for budget in (None, 0):
+        dev = ta.DeviceIndex([seg])
+        try:
+            if budget is not None:
+                dev.set_option("rdir_budget_x", budget)
+            dev.set_option("timing", 1)
+            dev.set_option("exhaustive", 0)
+            pr = dev.search(queries, k)
+            st = dev.last_batch_stats()
+            assert st["kernel_mask"] & ta.binding.KERNEL_USHARE, st
+            dev.set_option("exhaustive", 1)
+            ex = dev.search(queries, k)
+        finally:
+            dev.close()
+        assert np.array_equal(pr[2], ex[2]) and np.array_equal(pr[3], ex[3])
+        assert np.allclose(pr[0], ex[0], rtol=1e-5, atol=0)
+        got[budget] = pr
+    assert np.array_equal(got[None][2], got[0][2]) and np.array_equal(got[None][0], got[0][0])
+    for qi in range(0, len(queries), 7):
+        q = queries[qi]
+        want = O.search(seg, q[1], q[0], k, pruned=False)
+        rows = _rows(got[None], qi)
+        assert sorted(d for _, d in rows) == sorted(d for _, d in want), (q, rows, want)
+        for (a, _), (b, _) in zip(rows, want):
+            assert abs(a - b) <= 1e-5 * max(abs(a), abs(b)), (q, rows, want)
