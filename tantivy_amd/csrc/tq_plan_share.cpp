@@ -167,7 +167,9 @@ int build_share_plan(tq_segment *s, Group &g, PlanScratch &ps) {
   // 5120: 9.19, 6144: 9.54: its thresholds settle after a few docs, and longer tasks keep the
   // feedback inside one wave)
   static const uint32_t kPhaseTasksEnv = tune_u32("TQ_US_PHASE_TASKS", 0);
-  const uint32_t kPhaseTasks = kPhaseTasksEnv ? kPhaseTasksEnv : (g.max_k <= 16u ? 4096u : 6144u);
+  // (round 6, after the range directories: or5 4096 / 5120 / 6144 / 8192: 2.48 / 2.32 / 2.39 / 2.50 ms; mixed 2048 / 3072 /
+  // 4096 / 6144: 6.74 / 5.63 / 5.41 / 5.59)
+  const uint32_t kPhaseTasks = kPhaseTasksEnv ? kPhaseTasksEnv : (g.max_k <= 16u ? 4096u : 5120u);
   uint64_t phase_cost[TQD_US_MAX_TERMS] = {};
   for (size_t r0 = 0; r0 < keys.size();) {
     size_t r1 = r0;
