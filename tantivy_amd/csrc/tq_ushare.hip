@@ -36,6 +36,9 @@
 // k distinct real matches, so pruning stays exact: the top-k equals the exhaustive run's bits.
 #include "tq_common.hpp"
 
+#ifndef TQ_US_REFRESH
+#define TQ_US_REFRESH 8u  // blocks between two looks at the leads' thresholds (other waves raise them)
+#endif
 #ifndef TQ_US_TIMERS
 #define TQ_US_TIMERS 0  // region timers (tools/probe_ushare.sh builds a variant with them)
 #endif
@@ -692,7 +695,7 @@ ushare_kernel(TqkShareParams p) {
       while (todo) {
         const uint32_t b = (uint32_t)__builtin_ctzll(todo);
         todo &= todo - 1ull;
-        if (++since_refresh == 8u) {  // thresholds rise while the tile is walked: one word per lead
+        if (++since_refresh == TQ_US_REFRESH) {  // thresholds rise while the tile is walked: one word per lead
           since_refresh = 0;
           if ((uint32_t)lane < n_leads) {
             const uint32_t t = __hip_atomic_load(p.thr_val + L.lead[lane].query, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
