@@ -553,6 +553,7 @@ struct PlanScratch {
     std::vector<ARun> aruns;
     uint32_t a_warm_tasks = 0;  // tasks [0, a_warm_tasks) are the warm-up launch
     bool over_budget = false;   // the last plan failed because its result lists exceed TQ_AS_LIST_MB at the longest tasks
+    bool any_rdir = false;      // (boolean leads) some list of alists is probed through its range directory
   };
   ASharePlan ap[2];
   std::vector<uint32_t> q_leader;        // per query of the batch: the list that would lead it there, or 0xFFFFFFFF

@@ -86,6 +86,7 @@ struct TqkAShareParams {
   uint32_t grid;
   uint32_t debug;
   uint32_t boolean;             // the leads are (TQ_MODE_BOOL query, leading list) pairs
+  uint32_t rdir_lists;          // ... and some entry of qlists is a range directory (the instantiation that knows them)
   float bound_slack;
   uint32_t n_queues;            // task queues of this launch (1, or 8 = one per XCD)
   uint32_t bound_mode;          // TQ_AS_BOUND bits: where list 1's range maxima replace its weight as the bound

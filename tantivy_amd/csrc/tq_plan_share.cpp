@@ -374,6 +374,8 @@ int build_ashare_plan(tq_segment *s, Group &g, PlanScratch &ps, bool boolean) {
   unsorted.resize(nl);
   keys.resize(nl);
   if (boolean) A.alists.assign(nq * TQD_AS_MAX_TERMS, make_uint2(0u, 0u));
+  A.any_rdir = false;
+  std::atomic<bool> any_rdir{false};
   const uint32_t fill_slabs = nq >= 4096 ? plan_threads() : 1u;
   parallel_slabs(fill_slabs, [&](uint32_t sb) {
     const size_t q0 = nq * sb / fill_slabs, q1 = nq * (sb + 1) / fill_slabs;
@@ -446,7 +448,12 @@ int build_ashare_plan(tq_segment *s, Group &g, PlanScratch &ps, bool boolean) {
       {  // (the list's own tables, or the ones built for boolean probes: build_probe_tables)
         const TermHost &th = s->terms[dq.term[m]];
         const bool own = th.dense_blob && th.tf8_blob;
-        A.alists[q * TQD_AS_MAX_TERMS + m] = make_uint2(off_of(own ? th.dense_blob : th.probe_dense_blob), off_of(own ? th.tf8_blob : th.probe_tf8_blob));
+        if (!own && !(th.probe_dense_blob && th.probe_tf8_blob) && th.rdir_blob && s->rdir_span_ok)  // (its range directory | shift, its entries)
+        {
+          A.alists[q * TQD_AS_MAX_TERMS + m] = make_uint2(off_of(th.rdir_blob) | th.rdir_shift, off_of(th.rdir_ent));
+          any_rdir.store(true, std::memory_order_relaxed);
+        } else
+          A.alists[q * TQD_AS_MAX_TERMS + m] = make_uint2(off_of(own ? th.dense_blob : th.probe_dense_blob), off_of(own ? th.tf8_blob : th.probe_tf8_blob));
       }
       for (uint32_t li = 0; li < n_lead; ++li) {
         TqdALead ld{};
@@ -524,6 +531,7 @@ int build_ashare_plan(tq_segment *s, Group &g, PlanScratch &ps, bool boolean) {
       }
     }
   });
+  A.any_rdir = any_rdir.load(std::memory_order_relaxed);
   pt("leads");
   // ---- order: (leader, cache), then mask (the kernel keeps a block's membership ballots across consecutive
   // leads with the same mask), stable in the query index: two counting sorts, 11 bits of a hash of the mask,

@@ -40,6 +40,7 @@ int search_batch_impl(tq_segment *s, const tq_query *queries, uint32_t n_queries
   // Boolean queries ride in the shared leader-major launch if every list they probe has a bitmap + tf
   // bytes: lists below "dense_ratio" get them the first time a boolean query names them ("probe_budget_x")
   static const bool kUseBShare = tune_u32("TQ_BSHARE", 1) != 0;
+  static const bool kBsRdir = tune_u32("TQ_BS_RDIR", 1) != 0;  // ... or a range directory (0: probe tables for those too)
   // 2-term intersections that probe a list without tables of its own: on the per-query kernel they run on
   // the side stream next to the shared launch, almost for free while they are few (5 % of the headline
   // batch: pulling them into the shared launch cost 7 % of kernel time — no doc-matrix column, so nothing
@@ -137,6 +138,7 @@ int search_batch_impl(tq_segment *s, const tq_query *queries, uint32_t n_queries
         const TermHost &th = s->terms[h];
         if (th.dense_blob && th.tf8_blob) continue;
         if (and2 && th.rdir_blob && s->rdir_span_ok) continue;  // (probed through its range directory)
+
         // (a list too short for a directory — rdir_plan — is too short for a max_doc / 4-byte slot of the probe pool:
         // its queries keep the per-query kernel, whose leader has at most as many blocks)
         if (and2 && s->opt.rdir_budget_x > 0 && th.doc_freq < 256u) continue;
@@ -479,7 +481,9 @@ int search_batch_impl(tq_segment *s, const tq_query *queries, uint32_t n_queries
                dq.n_terms <= TQD_AS_MAX_TERMS && q.k <= 128u && ps_plan.q_cache[qi] < 256u && dq.n_lead >= 1;
       for (uint32_t i = 0; bshare && i < dq.n_terms; ++i) {
         const TermHost &th = s->terms[dq.term[i]];
-        if (!(th.dense_blob && th.tf8_blob) && !(th.probe_dense_blob && th.probe_tf8_blob) && !(dq.n_lead == 1 && i == 0)) bshare = false;
+        if (!(th.dense_blob && th.tf8_blob) && !(th.probe_dense_blob && th.probe_tf8_blob) && !(kBsRdir && th.rdir_blob && s->rdir_span_ok) &&
+            !(dq.n_lead == 1 && i == 0))
+          bshare = false;
       }
     }
     if (mode == TQ_MODE_OR && !bool_done) {
@@ -1042,6 +1046,7 @@ int search_batch_impl(tq_segment *s, const tq_query *queries, uint32_t n_queries
       ap.lists = (uint64_t *)((uint8_t *)sc.partials.p + part_off_bytes[gi]);
       ap.n_queries = (uint32_t)n_a;
       ap.boolean = (uint32_t)ai;
+      ap.rdir_lists = ai && s->plan->ap[ai].any_rdir ? 1u : 0u;
       static const uint32_t kDebugA = tune_u32("TQ_DEBUG", 0);
       ap.debug = s->opt.debug >= 0 ? (uint32_t)s->opt.debug : kDebugA;  // (option "debug": work counters of one batch, bench.py)
       ap.bound_slack = co.bound_slack;

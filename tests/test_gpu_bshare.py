@@ -120,37 +120,41 @@ def test_zipf_stream_of_the_bench_shapes_shares_leaders(ta):
 
 
 def test_lists_below_dense_ratio_get_probe_tables_on_first_use(ta):
-    """A boolean query naming a list without a bitmap: with "probe_budget_x" 0 it stays on the union kernel
-    (the same batch's other boolean queries take the shared launch); with the default budget the list gets a
-    bitmap + tf bytes of its own the first time a boolean query names it and every query is shared — the
-    other kernels keep seeing the list as sparse (no new dense list in the segment's stats).  Results as the
-    oracle's, and identical between the two settings."""
+    """A boolean query naming a list without a bitmap: with "probe_budget_x" 0 and "rdir_budget_x" 0 it stays on the
+    union kernel (the same batch's other boolean queries take the shared launch); with the default probe budget the
+    list gets a bitmap + tf bytes of its own the first time a boolean query names it, with no probe budget but range
+    directories (round 6) the shared launch probes those, and every query is shared — the other kernels keep seeing the
+    list as sparse (no new dense list in the segment's stats).  Results as the oracle's, and identical between the
+    settings."""
     rng = np.random.default_rng(5)
     seg = O.synth_segment(200_000, n_terms=64, with_positions=False)
     queries = _queries(ta, rng, 64, 2)
     easy = [(ta.MODE_BOOL, [1, 2, 3], [M, S, N], None, 0), (ta.MODE_BOOL, [4, 2, 0], [M, M, M], [0, 1, 1], 0)] * 4
     want = [_bool_want(seg, q[1], q[2], (), q[3], q[4]) for q in queries + easy]
     got = {}
-    for budget in (0, 16):
+    for budget, rdir in ((0, 0), (16, 0), (0, 4)):
         dev = ta.DeviceIndex([seg])
         try:
             dev.set_option("timing", 1)
             dev.set_option("dense_ratio", 32)  # lists 0..14 get a bitmap
             dev.set_option("probe_budget_x", budget)
+            dev.set_option("rdir_budget_x", rdir)
             dev.set_option("exhaustive", 0)
-            got[budget] = _device_topk(dev, queries + easy, 10)
+            got[(budget, rdir)] = _device_topk(dev, queries + easy, 10)
             st = dev.last_batch_stats()
             assert st["kernel_mask"] & ta.binding.KERNEL_BSHARE, st
-            if budget == 0:
+            if budget == 0 and rdir == 0:
                 assert st["kernel_mask"] & ta.binding.KERNEL_BOOL, st
             else:
                 assert not (st["kernel_mask"] & ta.binding.KERNEL_BOOL), st
             assert dev.segment_stats(0)["n_dense_lists"] <= 16
-            for q, g, w in zip(queries + easy, got[budget], want):
+            for q, g, w in zip(queries + easy, got[(budget, rdir)], want):
                 _assert_bool_hits(g, w, 10, q[2], q[3])
-            # an intersection over the same sparse lists still runs on the general AND kernel
+            # an intersection over the same sparse lists in a small batch still runs on the general AND kernel
             dev.search([(O.MODE_AND, [40, 50])] * 8, 10)
             assert dev.last_batch_stats()["kernels"] == ["and"], dev.last_batch_stats()
         finally:
             dev.close()
+    assert [[d for _, d in g] for g in got[(0, 0)]] == [[d for _, d in g] for g in got[(0, 4)]]
+    got = {0: got[(0, 0)], 16: got[(16, 0)]}
     assert [[d for _, d in g] for g in got[0]] == [[d for _, d in g] for g in got[16]]

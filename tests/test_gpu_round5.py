@@ -115,21 +115,28 @@ def test_full_size_large_vocabulary_intersections(ta, big_vocab):
 
 
 def test_full_size_large_vocabulary_boolean_queries(ta, big_vocab):
-    """The bench's boolean shapes over a large vocabulary: with a probe pool too small for every list they name,
-    part of the batch rides in the shared launch (bshare) and the rest stays on the union kernel (bool) — a query that
-    can run without probe tables only takes a free slot or one nobody has used for a long while (round 6; nested
-    queries, which need their bitmaps, take the least recently used one: tests/test_gpu_round6.py) — both against the
-    oracle's scorer tree, batch after batch."""
+    """The bench's boolean shapes over a large vocabulary.  Without range directories ("rdir_budget_x" 0) and with a
+    probe pool too small for every list they name, part of the batch rides in the shared launch (bshare) and the rest
+    stays on the union kernel (bool) — a query that can run without probe tables only takes a free slot or one nobody
+    has used for a long while (round 6; nested queries, which need their bitmaps, take the least recently used one:
+    tests/test_gpu_round6.py).  With range directories (the default) the shared launch probes a list without a bitmap
+    through its directory (ashare_kernel<.., true, true>) and only queries naming a list too short for one keep the
+    union kernel.  Both against the oracle's scorer tree, batch after batch."""
     vocab, seg = big_vocab
-    dev = ta.DeviceIndex([seg])
-    try:
-        dev.set_option("probe_budget_x", 2)  # (a few dozen slots: far fewer than the lists a 600-query batch names)
-        for seed in (502, 512):
-            queries = _bool_stream(ta, 600, vocab, seed)
-            st, kern, n = _check_batch(ta, dev, seg, queries, 10, 20, ta.binding.KERNEL_BSHARE | ta.binding.KERNEL_BOOL,
-                                       exact2=False)
-    finally:
-        dev.close()
+    for rdir in (0, None):
+        dev = ta.DeviceIndex([seg])
+        try:
+            dev.set_option("probe_budget_x", 2)  # (a few dozen slots: far fewer than the lists a 600-query batch names)
+            if rdir is not None:
+                dev.set_option("rdir_budget_x", rdir)
+            for seed in (502, 512):
+                queries = _bool_stream(ta, 600, vocab, seed)
+                want = ta.binding.KERNEL_BSHARE | (ta.binding.KERNEL_BOOL if rdir == 0 else 0)
+                st, kern, n = _check_batch(ta, dev, seg, queries, 10, 32, want, exact2=False)
+                if rdir is None:  # (most of the batch is shared: at 65 536 terms a fifth of the lists are too short for a directory)
+                    assert int((kern == ta.binding.KERNEL_BSHARE).sum()) >= len(queries) * 2 // 3, st
+        finally:
+            dev.close()
 
 
 def test_full_size_large_vocabulary_mixed_stream(ta, big_vocab):
