@@ -462,10 +462,13 @@ def latency_curve(dev, queries, k):
         t = t[3:]
         out["batch"][str(b)] = {"qps": round(b * len(t) / sum(t), 1), "p50_ms": pct(t, 0.5), "p99_ms": pct(t, 0.99)}
     for nthreads in (1, 16, 64, 256, 1024):
-        n = min(len(queries), 400 if nthreads == 1 else nthreads * (150 if nthreads <= 64 else 40))
-        dev.search_concurrent(queries[:min(n, 4 * nthreads)], k, nthreads)  # (threads + queue warm)
+        # (every thread gets 150 / 60 queries: the stream repeated where it is shorter; the clock starts when all
+        # threads stand at the line — a server's request threads exist before the requests do)
+        n = 400 if nthreads == 1 else nthreads * (150 if nthreads <= 64 else 60)
+        run = (queries * (n // len(queries) + 1))[:n]
+        dev.search_concurrent(run[:4 * nthreads], k, nthreads)  # (threads + queue warm)
         dev.submit_stats(reset=True)
-        _, _, _, _, lat_ms, wall_ms = dev.search_concurrent(queries[:n], k, nthreads)
+        _, _, _, _, lat_ms, wall_ms = dev.search_concurrent(run, k, nthreads)
         st = dev.submit_stats()
         v = sorted(float(x) for x in lat_ms)
         out["threads"][str(nthreads)] = {

@@ -747,7 +747,8 @@ int search_batch_host(tq_segment *s, const tq_query *queries, uint32_t n_queries
 // (no lock needed) and leaves the rows readable at out.p, out.p + o_docs, out.p + o_counts.
 struct HostBatchSlot {
   PinnedBuf out;
-  hipEvent_t done = nullptr;
+  hipEvent_t done = nullptr, done_blocking = nullptr;  // the batch's last kernel: waited for spinning / asleep
+  bool blocking = false;                               // ... which of the two this batch recorded
   size_t o_docs = 0, o_counts = 0;
   uint32_t n = 0, stride = 0;
 };

@@ -1365,16 +1365,24 @@ int search_batch_host_begin(tq_segment *s, const tq_query *queries, uint32_t n_q
   int rc = slot.out.ensure(slot.o_counts + (size_t)n_queries * sizeof(uint32_t));
   if (rc != TQ_OK) return rc;
   if (!slot.done) HIP_TRY(hipEventCreateWithFlags(&slot.done, hipEventDisableTiming));
+  if (!slot.done_blocking) HIP_TRY(hipEventCreateWithFlags(&slot.done_blocking, hipEventDisableTiming | hipEventBlockingSync));
   uint8_t *h = (uint8_t *)slot.out.p;
   rc = search_batch_impl(s, queries, n_queries, out_stride, (float *)h, (uint32_t *)(h + slot.o_docs),
                          (uint32_t *)(h + slot.o_counts), nullptr, co);
   if (rc != TQ_OK) return rc;
-  HIP_TRY(hipEventRecord(slot.done, s->stream));
+  // A batch of many callers is waited for asleep (an interrupt, some tens of microseconds later than a spinning wait
+  // would notice): with hundreds of request threads the host's cores are what runs out first — the GPU box grants 16,
+  // and a process above its quota is stopped for the rest of the 100 ms period, all its threads (p99 of 1 024 threads:
+  // 92 ms) — and a core spinning for 0.7 ms per batch is one the callers do not have.  A small batch is a few callers
+  // waiting for exactly this: the spinning wait.
+  static const uint32_t kBlockMin = tune_u32("TQ_SUBMIT_BLOCK_MIN", 128);
+  slot.blocking = n_queries >= kBlockMin;
+  HIP_TRY(hipEventRecord(slot.blocking ? slot.done_blocking : slot.done, s->stream));
   return TQ_OK;
 }
 int search_batch_host_end(tq_segment *s, HostBatchSlot &slot) {
   (void)s;
-  HIP_TRY(hipEventSynchronize(slot.done));
+  HIP_TRY(hipEventSynchronize(slot.blocking ? slot.done_blocking : slot.done));
   return TQ_OK;
 }
 }  // namespace tqi

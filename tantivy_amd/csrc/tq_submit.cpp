@@ -20,18 +20,40 @@ struct tq_ticket {
   uint32_t *out_docs = nullptr, *out_count = nullptr;
   int rc = TQ_OK;
   std::string err;
-  bool done = false;
   // its caller sleeps on its OWN condition variable: a finished batch wakes its callers and ONE thread to lead the
   // next batch — with one shared variable and notify_all every completion woke every waiter of the segment (1 024
   // threads on 16 cores: 35 k q/s at p99 94 ms, most of it the herd taking the queue's mutex in turn)
+  // ... under its OWN mutex (round 6): a caller whose rows are in goes home without touching the queue's mutex — with
+  // the queue's mutex behind every ticket's variable the few hundred callers of a finished batch still queued up for
+  // it one by one, in front of the callers trying to submit the next batch's queries.
+  std::mutex m;
   std::condition_variable cv;
-  bool waiting = false;  // its caller is blocked in tq_wait (Q.waiting holds the ticket)
+  bool signal = false;     // (m) look again: the rows are in (done), or somebody has to lead
+  bool done = false;       // (m) verdict and rows delivered
+  bool finishing = false;  // (Q.m) its batch is over, delivery is on its way: nothing left to lead or to register for
+  bool waiting = false;    // (Q.m) its caller is blocked in tq_wait: the ticket is linked into Q's waiting list
+  tq_ticket *wprev = nullptr, *wnext = nullptr;
 };
 struct SubmitQueue {
   std::mutex m;
   std::condition_variable cv_arrive;  // a query was submitted (the leader's arrival window)
   std::deque<tq_ticket *> pending;
-  std::deque<tq_ticket *> waiting;    // tickets whose callers are blocked in tq_wait, oldest first
+  tq_ticket *whead = nullptr, *wtail = nullptr;  // tickets whose callers are blocked in tq_wait, oldest first
+  void wait_link(tq_ticket *t) {
+    if (t->waiting) return;
+    t->waiting = true;
+    t->wprev = wtail;
+    t->wnext = nullptr;
+    (wtail ? wtail->wnext : whead) = t;
+    wtail = t;
+  }
+  void wait_unlink(tq_ticket *t) {
+    if (!t->waiting) return;
+    t->waiting = false;
+    (t->wprev ? t->wprev->wnext : whead) = t->wnext;
+    (t->wnext ? t->wnext->wprev : wtail) = t->wprev;
+    t->wprev = t->wnext = nullptr;
+  }
   bool leader_active = false;
   size_t last_batch = 0;  // queries the previous batch carried
   tq_submit_stats stats{};
@@ -52,7 +74,8 @@ void tq_free_submit_queue(SubmitQueue *q) {
   if (!q) return;
   for (tqi::HostBatchSlot &sl : q->slot) {  // (the segment is idle: tq_segment_free has drained its streams)
     if (sl.done) (void)hipEventDestroy(sl.done);
-    sl.done = nullptr;
+    if (sl.done_blocking) (void)hipEventDestroy(sl.done_blocking);
+    sl.done = sl.done_blocking = nullptr;
     sl.out.release();
   }
   delete q;
@@ -136,27 +159,43 @@ void run_ticket_batch(SubmitQueue &Q, tq_segment *s, std::vector<tq_ticket *> &b
   }
 }
 
-int ticket_wait(tq_ticket *t) {
+// parked: the ticket was linked into the waiting list when it was submitted (tq_search_one, somebody was leading): its
+// caller goes to sleep without taking the queue's mutex a second time
+int ticket_wait(tq_ticket *t, bool parked = false) {
   tq_segment *s = t->seg;
   SubmitQueue &Q = *s->submit;
-  std::unique_lock<std::mutex> lk(Q.m);
+  std::unique_lock<std::mutex> lk(Q.m, std::defer_lock);
+  if (!parked) lk.lock();
   std::vector<tq_ticket *> batch;
-  auto leave_waiting = [&]() {
-    if (!t->waiting) return;
-    t->waiting = false;
-    for (auto it = Q.waiting.begin(); it != Q.waiting.end(); ++it)
-      if (*it == t) {
-        Q.waiting.erase(it);
-        break;
-      }
+  auto leave_waiting = [&]() { Q.wait_unlink(t); };
+  // (under t->m) verdict and rows to a ticket's caller
+  auto deliver = [](tq_ticket *b) {
+    std::lock_guard<std::mutex> bl(b->m);
+    b->done = true;
+    b->signal = true;
+    b->cv.notify_one();
   };
-  while (!t->done) {
-    if (Q.leader_active || Q.pending.empty()) {
-      if (!t->waiting) {
-        t->waiting = true;
-        Q.waiting.push_back(t);
+  bool own_done = false;  // this caller's ticket was answered by the batch it led itself
+  while (!own_done) {
+    if (parked || t->finishing || Q.leader_active || Q.pending.empty()) {
+      if (!parked) {
+        if (!t->finishing) Q.wait_link(t);
+        lk.unlock();
       }
-      t->cv.wait(lk);
+      parked = false;
+      bool finished;
+      {
+        std::unique_lock<std::mutex> tl(t->m);
+        t->cv.wait(tl, [&] { return t->signal; });
+        t->signal = false;
+        finished = t->done;
+      }
+      if (finished) {  // (whoever finished the batch unlinked the ticket before delivering: nothing of the queue is touched)
+        const int rc = t->rc;
+        if (rc != TQ_OK) g_last_error = t->err;
+        return rc;
+      }
+      lk.lock();
       continue;
     }
     leave_waiting();
@@ -190,19 +229,34 @@ int ticket_wait(tq_ticket *t) {
       static const uint32_t kWake = std::max<uint32_t>(1u, tune_u32("TQ_SUBMIT_WAKE", 2));
       if (Q.pending.empty()) return;
       uint32_t woken = 0;
-      for (tq_ticket *w : Q.waiting)
-        if (!w->done && w != t) {
-          w->cv.notify_one();
+      for (tq_ticket *w = Q.whead; w; w = w->wnext)
+        if (w != t) {  // (a linked ticket is open: finish() unlinks what it answers)
+          {
+            std::lock_guard<std::mutex> wl(w->m);
+            w->signal = true;
+            w->cv.notify_one();
+          }
           if (++woken == kWake) break;
         }
     };
-    auto finish = [&]() {  // (under the lock) the batch's verdicts are in: its callers go home
+    // the batch's verdicts are in.  Under the lock: its tickets leave the queue's lists; off the lock (finish_deliver):
+    // their callers are woken — a few hundred wake-ups are a few hundred microseconds during which the next batch's
+    // queries must be able to arrive
+    auto finish = [&]() {
       ++Q.stats.batches;
       Q.stats.queries += batch.size();
       Q.stats.max_batch = std::max<uint64_t>(Q.stats.max_batch, batch.size());
       for (tq_ticket *b : batch) {
-        b->done = true;
-        if (b != t) b->cv.notify_one();
+        Q.wait_unlink(b);
+        b->finishing = true;
+      }
+    };
+    auto finish_deliver = [&]() {
+      for (tq_ticket *b : batch) {
+        if (b == t)
+          own_done = true;
+        else
+          deliver(b);  // (b may be gone the moment this returns)
       }
     };
     static const bool kOverlap = tune_u32("TQ_SUBMIT_OVERLAP", 1) != 0;
@@ -281,6 +335,9 @@ int ticket_wait(tq_ticket *t) {
       finish();
       if (!handed_over) Q.leader_active = false;
       if (!Q.leader_active) wake_a_leader();  // (whoever was woken at hand-over may have been in this batch)
+      lk.unlock();
+      finish_deliver();
+      lk.lock();
       continue;
     }
     // the synchronous road: no slot (TQ_SUBMIT_OVERLAP=0), or the batch could not be enqueued — a query the device
@@ -294,6 +351,9 @@ int ticket_wait(tq_ticket *t) {
     finish();
     Q.leader_active = false;
     wake_a_leader();
+    lk.unlock();
+    finish_deliver();
+    lk.lock();
   }
   leave_waiting();
   const int rc = t->rc;
@@ -304,8 +364,12 @@ int ticket_wait(tq_ticket *t) {
 
 extern "C" {
 
-int tq_submit(tq_segment *s, const tq_query *q, const tq_search_opts *opts, float *out_scores,
-              uint32_t *out_docs, uint32_t *out_count, tq_ticket **out) {
+}  // extern "C"
+namespace tqi {
+// tq_submit; park (tq_search_one: the caller waits right away): if somebody is leading, the ticket joins the waiting
+// list under the same lock that puts it on the pending list — one acquisition of the queue's mutex per query, not two
+int submit_ticket(tq_segment *s, const tq_query *q, const tq_search_opts *opts, float *out_scores,
+                  uint32_t *out_docs, uint32_t *out_count, tq_ticket **out, bool *park) {
   if (!s || !q || !out_scores || !out_docs || !out_count || !out)
     return fail(TQ_ERR_INVALID, "tq_submit: null argument");
   // what can be judged without the segment's state is judged here: a bad query never joins a batch
@@ -333,10 +397,21 @@ int tq_submit(tq_segment *s, const tq_query *q, const tq_search_opts *opts, floa
   {
     std::lock_guard<std::mutex> lk(Q->m);
     Q->pending.push_back(t);
+    if (park && Q->leader_active) {
+      Q->wait_link(t);
+      *park = true;
+    }
   }
   Q->cv_arrive.notify_one();  // (a leader may be holding its batch open for this query)
   *out = t;
   return TQ_OK;
+}
+}  // namespace tqi
+extern "C" {
+
+int tq_submit(tq_segment *s, const tq_query *q, const tq_search_opts *opts, float *out_scores,
+              uint32_t *out_docs, uint32_t *out_count, tq_ticket **out) {
+  return tqi::submit_ticket(s, q, opts, out_scores, out_docs, out_count, out, nullptr);
 }
 
 int tq_wait(tq_ticket *t) {
@@ -349,9 +424,12 @@ int tq_wait(tq_ticket *t) {
 int tq_search_one(tq_segment *s, const tq_query *q, const tq_search_opts *opts, float *out_scores,
                   uint32_t *out_docs, uint32_t *out_count) {
   tq_ticket *t = nullptr;
-  const int rc = tq_submit(s, q, opts, out_scores, out_docs, out_count, &t);
+  bool parked = false;
+  const int rc = tqi::submit_ticket(s, q, opts, out_scores, out_docs, out_count, &t, &parked);
   if (rc != TQ_OK) return rc;
-  return tq_wait(t);
+  const int wrc = tqi::ticket_wait(t, parked);
+  delete t;
+  return wrc;
 }
 
 int tq_get_submit_stats(tq_segment *s, tq_submit_stats *out, int reset) {

@@ -1,8 +1,14 @@
 // host_capi.cpp — flat C entry points over the C++ host mirror (searcher.hpp), so that the
 // Python tests/bench drive exactly the host code a C++ application would.  Exceptions never
 // cross this boundary: they become status codes + tqh_last_error().
+#include <atomic>
 #include <chrono>
+#include <condition_variable>
+#include <mutex>
 #include <cstring>
+#include <ctime>
+#include <cstdio>
+#include <cstdlib>
 #include <memory>
 #include <string>
 #include <thread>
@@ -386,8 +392,29 @@ int tqh_search_concurrent(tqh_searcher *s, const tqh_query *queries, uint32_t n,
     const TopDocs td = TopDocs::with_limit(limit).and_offset(offset);
     std::vector<std::string> errors(n_threads);
     std::vector<TantivyError::Kind> kinds(n_threads, TantivyError::InvalidArgument);
-    const auto t0 = std::chrono::steady_clock::now();
+    // (a server's request threads exist before the requests do: the clock starts when every thread stands at the
+    // line — creating 1 024 threads took a fifth of the wall time of a 10 000-query run)
+    static const bool conc_trace = getenv("TQH_CONC_TRACE") != nullptr;  // (tools/latency_threads.py: the callers' own CPU time)
+    std::atomic<uint64_t> callers_cpu_ns{0};
+    // (asleep, not spinning: a thousand threads yielding in a loop burn the process's CPU quota before the first query)
+    std::mutex line_m;
+    std::condition_variable line_cv;
+    uint32_t at_line = 0;
+    bool go = false;
+    std::chrono::steady_clock::time_point t0;
     auto work = [&](uint32_t t) {
+      {
+        std::unique_lock<std::mutex> ll(line_m);
+        if (++at_line == n_threads) {
+          t0 = std::chrono::steady_clock::now();
+          go = true;
+          line_cv.notify_all();
+        } else {
+          line_cv.wait(ll, [&] { return go; });
+        }
+      }
+      timespec c0{}, c1{};
+      if (conc_trace) clock_gettime(CLOCK_THREAD_CPUTIME_ID, &c0);
       try {
         for (uint32_t qi = t; qi < n; qi += n_threads) {
           const auto q0 = std::chrono::steady_clock::now();
@@ -408,12 +435,19 @@ int tqh_search_concurrent(tqh_searcher *s, const tqh_query *queries, uint32_t n,
       } catch (const std::exception &e) {
         errors[t] = e.what();
       }
+      if (conc_trace) {
+        clock_gettime(CLOCK_THREAD_CPUTIME_ID, &c1);
+        callers_cpu_ns.fetch_add((uint64_t)((c1.tv_sec - c0.tv_sec) * 1000000000ll + (c1.tv_nsec - c0.tv_nsec)), std::memory_order_relaxed);
+      }
     };
     std::vector<std::thread> threads;
     for (uint32_t t = 1; t < n_threads; ++t) threads.emplace_back(work, t);
     work(0);
     for (std::thread &th : threads) th.join();
     if (wall_ms) *wall_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    if (conc_trace)
+      fprintf(stderr, "[tqh] %u threads, %u queries: %.1f us of CPU per query inside the calling threads (from the starting line on)\n", n_threads, n,
+              (double)callers_cpu_ns.load() / 1e3 / (double)std::max<uint32_t>(1u, n));
     for (uint32_t t = 0; t < n_threads; ++t)
       if (!errors[t].empty()) throw TantivyError(kinds[t], errors[t]);
   });
