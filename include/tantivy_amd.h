@@ -481,10 +481,11 @@ int tq_segment_get_stats(tq_segment *seg, tq_segment_stats *out);
  *        expression over bitmap words (4-8 bytes per list per 32 docs, no postings decoded; a list
  *        without a bitmap is scattered into a scratch bitmap once per batch) when the clause a scan
  *        would walk holds at least max_doc / ratio postings per list of the query,
- *        "ashare_min_batch" (default 512): intersections take the shared leader-major launch
+ *        "ashare_min_batch" (default 16; 512 until round 6): intersections take the shared leader-major launch
  *        (TQ_KERNEL_ASHARE) when at least this many queries of the batch qualify for it — below, its
- *        two launches and per-task set-up cost more than sharing the leader blocks saves (256 queries:
- *        0.82 ms against 0.77 ms per-query; 1 024: 1.17 against 1.39; 4 096: 1.72 against 3.8),
+ *        two launches and per-task set-up cost more than sharing the leader blocks saves (round 6, synchronous
+ *        batches, shared against per-query: 8 queries 0.23 ms against 0.26; 16: 0.25 against 0.37; 64: 0.34
+ *        against 0.44; 256: 0.64 against 0.69 — the batches concurrent single-query callers coalesce into),
  *        "submit_window_us" (default 100): tq_submit / tq_search_one — how long the leader of a batch
  *        holds it open for the callers of the previous batch to come back with their next query
  *        (0 = launch with whatever is pending),

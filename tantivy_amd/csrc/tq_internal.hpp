@@ -186,7 +186,7 @@ struct Options {
   int rdir_budget_x = 4;    // range directories of the lists below "dense_ratio" (6-8 B per posting): at most this multiple of the segment
   int probe_budget_x = 16;  // bitmaps + tf bytes built on demand for the lists boolean queries probe: at most this multiple of the segment
   int count_bitmap_ratio = 128;  // Count: bitmap words instead of a scan if the driving clause holds >= max_doc / ratio postings per list
-  int ashare_min_batch = 512;   // intersections: the shared launch needs this many qualifying queries in the batch
+  int ashare_min_batch = 16;    // intersections: the shared launch needs this many qualifying queries in the batch (512 until round 6)
   // tq_submit / tq_search_one: how long the leader of a batch waits for the callers of the previous
   // batch to come back with their next query (0 = launch with whatever is pending)
   int submit_window_us = 100;

@@ -67,7 +67,7 @@ def test_shared_intersections_match_the_oracle_and_the_per_query_kernel(ta, seg3
     seg = seg300k
     queries = _and_stream(400, 2, 64, 11) + [(O.MODE_AND, [3, 3]), (O.MODE_AND, [0, 63]), (O.MODE_AND, [63, 0])] * 2
     dev = ta.DeviceIndex([seg])
-    dev.set_option("ashare_min_batch", 0)  # (these batches are smaller than the default 512)
+    dev.set_option("ashare_min_batch", 0)  # (whatever the batch size)
     try:
         dev.set_option("timing", 1)
         dev.set_option("dense_ratio", 64)
@@ -89,7 +89,7 @@ def test_every_query_of_a_dense_batch_takes_the_shared_launch(ta, seg300k):
     seg = seg300k
     queries = _and_stream(600, 2, 16, 3)
     dev = ta.DeviceIndex([seg])
-    dev.set_option("ashare_min_batch", 0)  # (these batches are smaller than the default 512)
+    dev.set_option("ashare_min_batch", 0)  # (whatever the batch size)
     try:
         dev.set_option("dense_ratio", 64)
         dev.set_option("exhaustive", 0)
@@ -109,7 +109,7 @@ def test_shared_intersections_of_three_and_more_lists(ta, seg300k, n_terms):
     seg = seg300k
     queries = _and_stream(300, n_terms, 24, 40 + n_terms)
     dev = ta.DeviceIndex([seg])
-    dev.set_option("ashare_min_batch", 0)  # (these batches are smaller than the default 512)
+    dev.set_option("ashare_min_batch", 0)  # (whatever the batch size)
     try:
         dev.set_option("dense_ratio", 64)
         pr, st_p, ex, _ = _both_modes(ta, dev, queries, 10)
@@ -130,7 +130,7 @@ def test_lists_without_a_column_use_their_signature_bit(ta, seg300k):
     queries += [(O.MODE_AND, [i, j]) for i in range(0, 40, 3) for j in range(52, 64, 2)]
     queries += [(O.MODE_AND, [45, 50, 60]), (O.MODE_AND, [41, 2, 58]), (O.MODE_AND, [40, 41, 42, 63])] * 4
     dev = ta.DeviceIndex([seg])
-    dev.set_option("ashare_min_batch", 0)  # (these batches are smaller than the default 512)
+    dev.set_option("ashare_min_batch", 0)  # (whatever the batch size)
     try:
         dev.set_option("dense_ratio", 4096)
         pr, st_p, ex, _ = _both_modes(ta, dev, queries, 10)
@@ -149,7 +149,7 @@ def test_shared_intersections_with_deletes(ta, seg300k):
     dele = np.sort(rng.choice(seg.max_doc, size=seg.max_doc // 3, replace=False))
     queries = _and_stream(300, 2, 32, 21) + _and_stream(100, 3, 16, 22)
     dev = ta.DeviceIndex([seg])
-    dev.set_option("ashare_min_batch", 0)  # (these batches are smaller than the default 512)
+    dev.set_option("ashare_min_batch", 0)  # (whatever the batch size)
     try:
         dev.set_option("dense_ratio", 64)
         dev.set_alive_bitset(_alive_bytes(seg.max_doc, dele.tolist()))
@@ -170,7 +170,7 @@ def test_shared_intersections_with_saturated_tf_bytes(ta, k):
             (O.MODE_AND, [4, 0]), (O.MODE_AND, [4, 1, 2]), (O.MODE_AND, [3, 2, 0, 1]), (O.MODE_AND, [4, 3])]
     qs = base * 6
     dev = ta.DeviceIndex([seg])
-    dev.set_option("ashare_min_batch", 0)  # (these batches are smaller than the default 512)
+    dev.set_option("ashare_min_batch", 0)  # (whatever the batch size)
     try:
         dev.set_option("dense_ratio", 32)  # lists 0..4 get bitmaps
         pr, st_p, ex, _ = _both_modes(ta, dev, qs, k)
@@ -190,7 +190,7 @@ def test_shared_intersections_next_to_shared_unions(ta, seg300k):
     o = [(O.MODE_OR, t.tolist()) for t in O.zipf_queries(300, 5, 64, seed=6)]
     queries = [x for pair in zip(a, o) for x in pair]
     dev = ta.DeviceIndex([seg])
-    dev.set_option("ashare_min_batch", 0)  # (these batches are smaller than the default 512)
+    dev.set_option("ashare_min_batch", 0)  # (whatever the batch size)
     try:
         dev.set_option("dense_ratio", 64)
         pr, st_p, ex, _ = _both_modes(ta, dev, queries, 10)
@@ -208,7 +208,7 @@ def test_full_size_shared_intersections(ta):
     seg = O.synth_segment(10_000_000, n_terms=256)
     queries = _and_stream(2000, 2, 256, 20260921)
     dev = ta.DeviceIndex([seg])
-    dev.set_option("ashare_min_batch", 0)  # (these batches are smaller than the default 512)
+    dev.set_option("ashare_min_batch", 0)  # (whatever the batch size)
     try:
         pr, st_p, ex, _ = _both_modes(ta, dev, queries, 10)
         assert st_p["kernel_mask"] & ta.binding.KERNEL_ASHARE, st_p
@@ -223,15 +223,19 @@ def test_full_size_shared_intersections(ta):
 
 
 def test_small_batches_keep_the_per_query_kernels(ta, seg300k):
-    """"ashare_min_batch" (default 512 qualifying queries): below it the batch's intersections stay on
-    the per-query kernels (two launches and per-task set-up cost more than sharing saves: 256 queries
-    0.91 ms shared against 0.75 ms per query on the 10M-doc index); same results either way."""
+    """"ashare_min_batch" (default 16 qualifying queries; 512 until round 6): below it the batch's intersections stay
+    on the per-query kernels (two launches and per-task set-up cost more than sharing saves); same results either
+    way."""
     queries = _and_stream(400, 2, 64, 13)
     dev = ta.DeviceIndex([seg300k])
     try:
         dev.set_option("timing", 1)
         dev.set_option("dense_ratio", 64)
         dev.set_option("exhaustive", 0)
+        small = dev.search(queries[:12], 10)
+        st = dev.last_batch_stats()
+        assert not (st["kernel_mask"] & ta.binding.KERNEL_ASHARE), st
+        dev.set_option("ashare_min_batch", 500)
         a = dev.search(queries, 10)
         st = dev.last_batch_stats()
         assert not (st["kernel_mask"] & ta.binding.KERNEL_ASHARE), st
@@ -241,6 +245,8 @@ def test_small_batches_keep_the_per_query_kernels(ta, seg300k):
         assert st["kernel_mask"] & ta.binding.KERNEL_ASHARE, st
         for x, y in zip(a, b):
             assert np.array_equal(x, y)
+        for x, y in zip(small, b):
+            assert np.array_equal(x, y[:12])
     finally:
         dev.close()
 
