@@ -357,7 +357,11 @@ def _fuzz_segment(rng, seed, n_terms=14):
                            positions=positions)
 
 
-@pytest.mark.parametrize("seed", [1, 2, 3, 4, 5, 6])
+# TQ_FUZZ_EXTRA=n: n more seeds for both fuzz tests (a soak run: `TQ_FUZZ_EXTRA=40 pytest -m gpu -k fuzz`)
+_EXTRA = int(os.environ.get("TQ_FUZZ_EXTRA", "0"))
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3, 4, 5, 6] + [100 + i for i in range(_EXTRA)])
 def test_fuzz_random_segments(ta, seed):
     """Random segments (dense and sparse lists, tails, runs of consecutive docs, repeated scores)
     x random AND / OR / phrase queries x k, in every execution mode (pruned / exhaustive, with and
@@ -393,7 +397,7 @@ def test_fuzz_random_segments(ta, seed):
         dev.close()
 
 
-@pytest.mark.parametrize("seed", [21, 22, 23, 24])
+@pytest.mark.parametrize("seed", [21, 22, 23, 24] + [200 + i for i in range(_EXTRA)])
 def test_fuzz_random_segments_boolean(ta, seed):
     """The same random segments under random boolean queries (occurs, nested unions,
     minimum_number_should_match), pruned / exhaustive, with and without bitmaps: the top-k and the
