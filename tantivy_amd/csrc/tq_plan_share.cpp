@@ -644,9 +644,10 @@ int build_ashare_plan(tq_segment *s, Group &g, PlanScratch &ps, bool boolean) {
       total_pairs += (uint64_t)(r1 - r0) * s->terms[(size_t)(keys[r0].k1 >> 8)].n_blocks;
       r0 = r1;
     }
-    task_pairs = (uint32_t)std::min<uint64_t>(512u, std::max<uint64_t>(64u, total_pairs / kTargetTasks));
+    static const uint32_t kTaskPairsMin = std::max<uint32_t>(4u, tune_u32("TQ_AS_TASK_PAIRS_MIN", 64));
+    task_pairs = (uint32_t)std::min<uint64_t>(512u, std::max<uint64_t>(kTaskPairsMin, total_pairs / kTargetTasks));
   }
-  task_pairs = std::max<uint32_t>(32u, task_pairs);
+  task_pairs = std::max<uint32_t>(4u, task_pairs);
   // `stretch` multiplies a run's blocks per task AFTER the cap of kTaskBlocksMax (as build_share_plan does):
   // doubling the pairs per task stopped shrinking the lists once every run sat at the cap, and a large-k batch
   // over long leaders went on to allocate gigabytes of result lists.  The kernel walks a task in
