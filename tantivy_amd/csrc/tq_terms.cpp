@@ -50,6 +50,30 @@ int term_alloc(tq_segment *s, size_t bytes, uint8_t **out) {
   return TQ_OK;
 }
 
+// A failed preparation hands its blob back (a caller retrying a term that keeps failing — a corrupt list —
+// allocated again on every attempt until tq_segment_free).  The slab's LAST allocation is rolled back (failures are
+// reported before anything else is allocated, so that is the common case); a blob with an allocation of its own is
+// freed; anything else stays in its slab.  The device may still be writing to it: the caller has synchronised.
+void term_release(tq_segment *s, uint8_t *blob, size_t bytes) {
+  if (!blob) return;
+  constexpr size_t kSlab = (size_t)4 << 20;
+  const size_t need = (bytes + 255) & ~(size_t)255;
+  if (s->bytes_term_tables >= bytes) s->bytes_term_tables -= bytes;
+  if (need > kSlab / 4) {
+    for (size_t i = s->term_slabs.size(); i-- > 0;)
+      if (s->term_slabs[i] == blob) {
+        s->term_slabs.erase(s->term_slabs.begin() + (ptrdiff_t)i);
+        (void)hipFree(blob);
+        break;
+      }
+    return;
+  }
+  if (s->term_slab_cur == blob + need) {
+    s->term_slab_cur = blob;
+    s->term_slab_left += need;
+  }
+}
+
 // a side table of a dense list: from the segment's arena, else a device allocation of its own
 int dense_alloc(tq_segment *s, size_t bytes, void **out) {
   const size_t need = (bytes + 255) & ~(size_t)255;
@@ -590,7 +614,10 @@ int tq_term_prepare(tq_segment *s, uint64_t postings_off, uint32_t postings_len,
   s->bytes_term_tables += w.total;
   place_walked_term(w, blob);
   hipError_t ce = hipMemcpy(blob, w.hb.data(), w.total, hipMemcpyHostToDevice);
-  if (ce != hipSuccess) return fail(TQ_ERR_HIP, "term upload: %s", hipGetErrorString(ce));
+  if (ce != hipSuccess) {
+    term_release(s, blob, w.total);
+    return fail(TQ_ERR_HIP, "term upload: %s", hipGetErrorString(ce));
+  }
   return register_term(s, w.dt, w.th, postings_off, out);
 }
 
@@ -922,7 +949,15 @@ int term_prepare_device(tq_segment *s, uint64_t postings_off, uint32_t postings_
     if (arc != TQ_OK) return arc;
   }
   s->bytes_term_tables += total;
-  auto bail = [&](int rc) { return rc; };  // (the blob stays in its slab)
+  uint8_t *pblob = nullptr;
+  size_t ptotal_alloc = 0;
+  // a failed preparation hands its blobs back (positions blob first: the slab's last allocation), once the stream is idle
+  auto bail = [&](int rc) {
+    (void)hipStreamSynchronize(s->stream);
+    term_release(s, pblob, ptotal_alloc);
+    term_release(s, blob, total);
+    return rc;
+  };
   hipError_t e = hipMemsetAsync(blob, 0, total, s->stream);
   TqpPostingsParams pp{};
   pp.idx = s->d_idx;
@@ -952,7 +987,6 @@ int term_prepare_device(tq_segment *s, uint64_t postings_off, uint32_t postings_
   if (e != hipSuccess) return bail(fail(TQ_ERR_HIP, "coarse table: %s", hipGetErrorString(e)));
   // positions tables, sized from the walk
   const bool want_pos = maybe_pos && info.record == TQ_WITH_FREQS_AND_POSITIONS;
-  uint8_t *pblob = nullptr;
   uint32_t n_pos_tail = 0;
   size_t o_pboff = 0, o_ptail = 0;
   if (want_pos) {
@@ -965,6 +999,7 @@ int term_prepare_device(tq_segment *s, uint64_t postings_off, uint32_t postings_
     o_ptail = ptotal;
     ptotal = align16(ptotal + 4 * (size_t)tail_cap) + PAD;
     if (term_alloc(s, ptotal, &pblob) != TQ_OK) return bail(TQ_ERR_HIP);
+    ptotal_alloc = ptotal;
     s->bytes_term_tables += ptotal;
     if (e == hipSuccess) e = hipMemsetAsync(pblob, 0, ptotal, s->stream);
     TqpPositionsParams qp{};

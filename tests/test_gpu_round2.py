@@ -379,6 +379,13 @@ def test_device_side_prepare_reports_corrupt_lists(ta):
             dev.set_option("device_prepare", device_prepare)
             with pytest.raises(ta.TantivyAmdError):
                 dev.search([(O.MODE_OR, [0])], 5)
+            # a caller that retries the failing term does not grow the segment's tables (the failed
+            # preparation's blob is handed back)
+            before = dev.segment_stats(0)["term_table_bytes"]
+            for _ in range(20):
+                with pytest.raises(ta.TantivyAmdError):
+                    dev.search([(O.MODE_OR, [0])], 5)
+            assert dev.segment_stats(0)["term_table_bytes"] == before
         finally:
             dev.close()
 
