@@ -1010,6 +1010,21 @@ static int union_seek_danger(gscorer *u, uint32_t target, uint32_t *lower) { /* 
     *lower = TO_TERMINATED;
     return 0;
   }
+  /* A second place where the code as written and the scorer tree's semantics part (found by a 500-seed fuzz soak,
+   * round 6).  A union that is a MEMBER of another union is asked seek_danger(target) by its parent whatever its own
+   * position (:296-306 has no `docset.doc() < target` guard, seek() :258-262 has one).  If it stands PAST the target —
+   * the parent's refill drained it to the parent's horizon, its own next window starts at its first doc beyond —
+   * then target < window_start, is_in_horizon (wrapping_sub, :157-161) is false, and it answers with the lower bound of
+   * its MEMBERS, which its own refill has already drained a whole window ahead: the docs it holds buffered, its
+   * current doc first, are skipped.  `+a (b c) (d e)` with minimum_number_should_match = 1 loses up to a 4096-doc
+   * window of matches at a window boundary (seed 575: 1432 of 24406 docs); with one term and one union as Should
+   * clauses, one doc.  g_reseek_invalid = 1 (default, the intended semantics: what the dense restatement and the
+   * device compute): a union standing at or past the target answers with its own position. */
+  if (g_reseek_invalid && u->doc >= target) {
+    if (u->doc == target) return 1;
+    *lower = u->doc;
+    return 0;
+  }
   if ((uint32_t)(target - u->window_start) < GS_HORIZON) {
     uint32_t d = union_seek(u, target);
     if (d == target) return 1;

@@ -268,3 +268,40 @@ def test_union_refills_a_half_seeked_intersection_as_written_in_the_reference(se
         inflated += int(bad.sum())
         assert (s3[common][bad] > s1[bad]).all()
     assert inflated + extra >= 1
+
+
+def test_union_inside_a_union_skips_its_buffered_docs_as_written_in_the_reference(seg):
+    """A second finding about the reference (a 500-seed fuzz soak, round 6), kept as a test.  BufferedUnionScorer::
+    seek_danger asks every member `seek_danger(target)` whatever the member's position (buffered_union.rs:296-306; seek
+    has a `docset.doc() < target` guard, :258-262).  A member that is itself a union and already stands PAST the target
+    (the parent's refill drained it to the parent's horizon: its next window starts at its first doc beyond) fails
+    is_in_horizon (target < window_start, :157-161) and answers with the lower bound of ITS members, which its own
+    refill has drained a whole window ahead — the docs it holds buffered are skipped.  `+a (b c) (d e)` with
+    minimum_number_should_match = 1 (the Should part becomes required: Intersection(a, Union(Union, Union))) loses up
+    to a 4096-doc window of matches at each window boundary.  The oracle's default (and what the device computes) is
+    the doc set the query means; `to_set_union_reseek_invalid(0)` runs the code path as written."""
+    rng = np.random.default_rng(3)
+    occ, cof = [M, S, S, S, S], [0, 1, 1, 2, 2]
+    lost_total = cases_with_loss = 0
+    for _ in range(40):
+        terms = rng.choice(16, size=5, replace=False).tolist()
+        a, b, c, d, e = terms
+        want = sorted(_docs(seg, a) & ((_docs(seg, b) | _docs(seg, c)) | (_docs(seg, d) | _docs(seg, e))))
+        d_np, _ = O.bool_match_all(seg, terms, occ, cof, 1)
+        d_c, _ = O.bool_match_all_c(seg, terms, occ, cof, 1)
+        assert d_np.tolist() == want and d_c.tolist() == want, terms
+        try:
+            O.lib().to_set_union_reseek_invalid(0)
+            d_w, _ = O.bool_match_all_c(seg, terms, occ, cof, 1)
+            # without the minimum the Should part is optional (RequiredOptionalScorer: the union is never asked
+            # seek_danger): nothing is lost as written either
+            d0, _ = O.bool_match_all_c(seg, terms, occ, cof, 0)
+        finally:
+            O.lib().to_set_union_reseek_invalid(1)
+        assert set(d_w.tolist()) <= set(want), terms  # never a doc too many
+        assert d0.tolist() == sorted(_docs(seg, a)), terms
+        lost = len(want) - len(d_w)
+        lost_total += lost
+        cases_with_loss += 1 if lost else 0
+    # (80 000-doc Zipf segment, this seed: 5 of 40 queries lose 45..269 docs, up to 5 % of their matches)
+    assert cases_with_loss >= 1 and lost_total >= 1
