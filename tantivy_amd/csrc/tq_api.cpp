@@ -192,7 +192,7 @@ void tq_segment_free(tq_segment *s) {
   if (s->batch_in_flight && s->ev_batch_done) (void)hipEventSynchronize(s->ev_batch_done);
   for (void *slab : s->term_slabs) (void)hipFree(slab);  // (the terms' table blobs: tq_terms.cpp term_alloc)
   // (bitmaps, byte-wide tfs, position directories, plain lists: the arena and its overflow)
-  if (s->dense_arena) (void)hipFree(s->dense_arena);
+  dense_arena_free(s);
   for (void *ptr : s->dense_extra) (void)hipFree(ptr);
   if (s->d_terms) (void)hipFree(s->d_terms);
   if (s->d_idx) (void)hipFree(s->d_idx);

@@ -277,6 +277,16 @@ struct tq_segment {
   uint8_t *dense_arena = nullptr;
   size_t dense_arena_cap = 0, dense_arena_used = 0;
   std::vector<void *> dense_extra;  // tables allocated outside the arena
+  // Round 6: the arena is a RESERVED ADDRESS RANGE (hipMemAddressReserve, 24 GB of addresses — no memory), mapped
+  // chunk by chunk as tables are added (hipMemCreate / hipMemMap): whatever the process has allocated and freed before,
+  // every table of the segment lies within the 32 GB the shared launches' and the tree kernel's 32-bit table offsets
+  // reach.  (A soak that opened and closed 230 indexes in one process got an overflow allocation more than 32 GB from
+  // its arena: flat queries fell back to the per-query kernels, a nested query was refused.)  dense_arena_cap = the
+  // reservation, dense_arena_mapped = what is backed by memory.  If the driver refuses any step: the old arena.
+  bool dense_arena_vmm = false;
+  void *dense_arena_va = nullptr;  // the reservation as the driver returned it (the arena starts at its first 32 MB multiple)
+  size_t dense_arena_mapped = 0, dense_arena_first = 0;
+  std::vector<std::pair<hipMemGenericAllocationHandle_t, size_t>> dense_arena_chunks;
   // resident bytes by kind (tq_segment_get_stats)
   size_t bytes_term_tables = 0, bytes_bitmaps = 0, bytes_docmat = 0, bytes_posdir = 0, bytes_alive = 0;
   uint32_t n_dense_lists = 0;
@@ -709,6 +719,7 @@ struct CallOpts {
   bool no_ashare = false, no_bshare = false;  // (internal) this call keeps intersections / boolean queries off the shared launch
 };
 // ---- tq_terms.cpp
+void dense_arena_free(tq_segment *s);  // (tq_terms.cpp: the arena of the dense lists' side tables — a hipMalloc or a mapped address range)
 int sync_terms(tq_segment *s, hipStream_t st);
 void mark_term_dirty(tq_segment *s, uint32_t handle);
 int build_flat(tq_segment *s, uint32_t handle, hipStream_t st, bool *ok);

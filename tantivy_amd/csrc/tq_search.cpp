@@ -459,7 +459,11 @@ int search_batch_impl(tq_segment *s, const tq_query *queries, uint32_t n_queries
       // a clause that is itself a BooleanQuery of terms (intersection inside a union / under MustNot, nested
       // minimums: tq_query.nested_occurs): evaluated over the lists' bitmaps, tq_tree.hip
       if (!s->share_span_ok || !s->opt.use_dense)
-        return fail(TQ_ERR_UNSUPPORTED, "query %u: nested boolean queries need the lists' bitmaps (\"use_dense\", one 32 GB table span)", qi);
+        return fail(TQ_ERR_UNSUPPORTED,
+                    "query %u: nested boolean queries need the lists' bitmaps (\"use_dense\" %d, one 32 GB table span: %s — tables from %llx, arena %llx + %zu MB "
+                    "mapped, %zu allocations outside it)",
+                    qi, (int)s->opt.use_dense, s->share_span_ok ? "ok" : "exceeded", (unsigned long long)s->share_table_lo, (unsigned long long)(uintptr_t)s->dense_arena,
+                    s->dense_arena_mapped >> 20, s->dense_extra.size());
       TqdTreeQuery tq;
       const int rc = plan_tree_query(s, q, qi, tq, qbytes, s->share_table_lo);
       if (rc != TQ_OK) return rc;

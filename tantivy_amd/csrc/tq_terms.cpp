@@ -74,13 +74,120 @@ void term_release(tq_segment *s, uint8_t *blob, size_t bytes) {
   }
 }
 
+// ---- the arena as a reserved address range (tq_internal.hpp: dense_arena_vmm)
+constexpr size_t kVmmChunk = (size_t)32 << 20;
+static bool vmm_map_more(tq_segment *s, size_t bytes) {
+  hipMemAllocationProp prop{};
+  prop.type = hipMemAllocationTypePinned;
+  prop.location.type = hipMemLocationTypeDevice;
+  prop.location.id = s->device;
+  size_t gran = 0;
+  if (hipMemGetAllocationGranularity(&gran, &prop, hipMemAllocationGranularityRecommended) != hipSuccess || !gran) {
+    (void)hipGetLastError();
+    gran = (size_t)2 << 20;
+  }
+  // (the driver reported 4 KB and then refused hipMemSetAccess on a chunk that started 47 MB into the range: chunks are
+  // multiples of 2 MB — the device's large page — whatever it reports)
+  // (and hipMemSetAccess refused 32 MB chunks at 2-, 4- and 16-MB-aligned addresses while it took one at a 64-MB-aligned
+  // address: every chunk is a multiple of kVmmChunk at a multiple of kVmmChunk from a kVmmChunk-aligned base; growth is
+  // mapped one kVmmChunk at a time, so every mapping but the first is aligned to its own size)
+  gran = std::max<size_t>(gran, kVmmChunk);
+  bytes = (bytes + gran - 1) / gran * gran;
+  if (s->dense_arena_mapped + bytes > s->dense_arena_cap) return false;
+  static const bool trace = getenv("TQ_TRACE") != nullptr;
+  auto why = [&](const char *what, hipError_t e) {
+    if (trace) fprintf(stderr, "[tq] arena: %s of %zu MB at +%zu MB failed: %s\n", what, bytes >> 20, s->dense_arena_mapped >> 20, hipGetErrorString(e));
+    (void)hipGetLastError();
+  };
+  hipMemGenericAllocationHandle_t h{};
+  hipError_t e = hipMemCreate(&h, bytes, &prop, 0);
+  if (e != hipSuccess) {
+    why("hipMemCreate", e);
+    return false;
+  }
+  uint8_t *at = s->dense_arena + s->dense_arena_mapped;
+  e = hipMemMap(at, bytes, 0, h, 0);
+  if (e != hipSuccess) {
+    why("hipMemMap", e);
+    (void)hipMemRelease(h);
+    return false;
+  }
+  hipMemAccessDesc ad{};
+  ad.location = prop.location;
+  ad.flags = hipMemAccessFlagsProtReadWrite;
+  // (the whole mapped prefix, not the new chunk alone: the driver refused the third chunk's own range — "invalid argument")
+  e = hipMemSetAccess(s->dense_arena, s->dense_arena_mapped + bytes, &ad, 1);
+  if (e != hipSuccess) e = hipMemSetAccess(at, bytes, &ad, 1);
+  if (e != hipSuccess) {
+    why("hipMemSetAccess", e);
+    (void)hipMemUnmap(at, bytes);
+    (void)hipMemRelease(h);
+    return false;
+  }
+  s->dense_arena_chunks.emplace_back(h, bytes);
+  s->dense_arena_mapped += bytes;
+  return true;
+}
+static bool vmm_reserve(tq_segment *s, size_t first_bytes) {
+  static const bool kVmm = tune_u32("TQ_VMM_ARENA", 1) != 0;  // 0: one hipMalloc of the budgets' size + overflow allocations (rounds 3-5)
+  if (!kVmm) return false;
+  constexpr size_t kReserve = (size_t)24 << 30;  // (the table offsets reach 32 GB)
+  void *va = nullptr;
+  // (the alignment argument is not honoured — 2 MB-aligned addresses came back for a 1 GB request: the range is a
+  // chunk longer and the arena starts at its first multiple of kVmmChunk)
+  const hipError_t re = hipMemAddressReserve(&va, kReserve + kVmmChunk, 0, nullptr, 0);
+  if (re != hipSuccess || !va) {
+    if (getenv("TQ_TRACE")) fprintf(stderr, "[tq] arena: hipMemAddressReserve of %zu GB: %s, address %p\n", kReserve >> 30, hipGetErrorString(re), va);
+    (void)hipGetLastError();
+    return false;
+  }
+  s->dense_arena_va = va;
+  va = (void *)(((uintptr_t)va + kVmmChunk - 1) & ~(uintptr_t)(kVmmChunk - 1));
+  s->dense_arena = (uint8_t *)va;
+  s->dense_arena_cap = kReserve;
+  s->dense_arena_mapped = 0;
+  s->dense_arena_first = first_bytes;
+  s->dense_arena_vmm = true;
+  if (!vmm_map_more(s, first_bytes)) {  // (nothing mapped: hand the range back, the old arena takes over)
+    if (getenv("TQ_TRACE")) fprintf(stderr, "[tq] arena: first chunk of %zu MB not mapped\n", first_bytes >> 20);
+    (void)hipMemAddressFree(s->dense_arena_va, kReserve + kVmmChunk);
+    s->dense_arena_va = nullptr;
+    s->dense_arena = nullptr;
+    s->dense_arena_cap = 0;
+    s->dense_arena_vmm = false;
+    return false;
+  }
+  return true;
+}
+void dense_arena_free(tq_segment *s) {
+  if (!s->dense_arena) return;
+  if (!s->dense_arena_vmm) {
+    (void)hipFree(s->dense_arena);
+  } else {
+    size_t off = 0;
+    for (auto &ch : s->dense_arena_chunks) {
+      (void)hipMemUnmap(s->dense_arena + off, ch.second);
+      (void)hipMemRelease(ch.first);
+      off += ch.second;
+    }
+    s->dense_arena_chunks.clear();
+    (void)hipMemAddressFree(s->dense_arena_va, s->dense_arena_cap + kVmmChunk);
+    s->dense_arena_va = nullptr;
+  }
+  s->dense_arena = nullptr;
+  s->dense_arena_cap = s->dense_arena_used = s->dense_arena_mapped = 0;
+  s->dense_arena_vmm = false;
+}
+
 // a side table of a dense list: from the segment's arena, else a device allocation of its own
 int dense_alloc(tq_segment *s, size_t bytes, void **out) {
   const size_t need = (bytes + 255) & ~(size_t)255;
   if (!s->dense_arena && s->dense_arena_cap == 0) {
     const size_t cap = std::max<size_t>(s->dense_budget() + s->probe_budget() + s->rdir_budget(), (size_t)1 << 20) + PAD;
     void *base = nullptr;
-    if (hipMalloc(&base, cap) == hipSuccess) {
+    if (vmm_reserve(s, cap)) {
+      // (the first chunk is what the old arena was: the budgets' worth in one piece)
+    } else if (hipMalloc(&base, cap) == hipSuccess) {
       s->dense_arena = (uint8_t *)base;
       s->dense_arena_cap = cap;
     } else {
@@ -88,7 +195,18 @@ int dense_alloc(tq_segment *s, size_t bytes, void **out) {
       s->dense_arena_cap = 1;  // (tried once: every table gets its own allocation)
     }
   }
-  if (s->dense_arena && s->dense_arena_used + need + PAD <= s->dense_arena_cap) {
+  if (s->dense_arena && s->dense_arena_vmm) {
+    // growth beyond the budgets (a probe pool grown by a batch that names more lists than it holds, tables of a
+    // segment whose options were raised): 32 MB at a time
+    const size_t want = s->dense_arena_used + need + PAD;
+    bool ok = want <= s->dense_arena_cap;
+    while (ok && want > s->dense_arena_mapped) ok = vmm_map_more(s, kVmmChunk);
+    if (ok) {
+      *out = s->dense_arena + s->dense_arena_used;
+      s->dense_arena_used += need;
+      return TQ_OK;
+    }
+  } else if (s->dense_arena && s->dense_arena_used + need + PAD <= s->dense_arena_cap) {
     *out = s->dense_arena + s->dense_arena_used;
     s->dense_arena_used += need;
     return TQ_OK;
