@@ -89,8 +89,8 @@ static bool vmm_map_more(tq_segment *s, size_t bytes) {
   // (the driver reported 4 KB and then refused hipMemSetAccess on a chunk that started 47 MB into the range: chunks are
   // multiples of 2 MB — the device's large page — whatever it reports)
   // (and hipMemSetAccess refused 32 MB chunks at 2-, 4- and 16-MB-aligned addresses while it took one at a 64-MB-aligned
-  // address: every chunk is a multiple of kVmmChunk at a multiple of kVmmChunk from a kVmmChunk-aligned base; growth is
-  // mapped one kVmmChunk at a time, so every mapping but the first is aligned to its own size)
+  // address: every chunk is a multiple of kVmmChunk at a multiple of kVmmChunk from a kVmmChunk-aligned base, and access
+  // is set over the whole mapped prefix)
   gran = std::max<size_t>(gran, kVmmChunk);
   bytes = (bytes + gran - 1) / gran * gran;
   if (s->dense_arena_mapped + bytes > s->dense_arena_cap) return false;
@@ -197,10 +197,13 @@ int dense_alloc(tq_segment *s, size_t bytes, void **out) {
   }
   if (s->dense_arena && s->dense_arena_vmm) {
     // growth beyond the budgets (a probe pool grown by a batch that names more lists than it holds, tables of a
-    // segment whose options were raised): 32 MB at a time
+    // segment whose options were raised): in multiples of 32 MB
     const size_t want = s->dense_arena_used + need + PAD;
     bool ok = want <= s->dense_arena_cap;
-    while (ok && want > s->dense_arena_mapped) ok = vmm_map_more(s, kVmmChunk);
+    // (a quarter of what is mapped at a time: a stream discovering a large vocabulary adds hundreds of MB of range
+    // directories, and a mapping is three driver calls)
+    while (ok && want > s->dense_arena_mapped)
+      ok = vmm_map_more(s, std::max<size_t>({want - s->dense_arena_mapped, s->dense_arena_mapped / 4, kVmmChunk}));
     if (ok) {
       *out = s->dense_arena + s->dense_arena_used;
       s->dense_arena_used += need;
