@@ -127,3 +127,27 @@ def test_concurrent_queries_over_two_segments_and_an_unsupported_one(ta):
             assert ct == min(3, len(d)) and set(dc[:ct].tolist()) <= set(d.tolist())
     finally:
         dev.close()
+
+
+def test_hundreds_of_callers_per_batch_round_after_round(ta, seg300k):
+    """The waiting side of tq_search_one as rebuilt in round 6 (a ticket's caller sleeps under the ticket's own mutex,
+    is unlinked and woken by the batch's leader off the queue's lock, submit + park take the queue's mutex once):
+    512 threads x 24 queries, three rounds on one segment — every row equal to the batch path's, every query answered
+    exactly once, batches of hundreds of callers."""
+    seg = seg300k
+    queries = _mixed_queries(512 * 24, 405)
+    dev = ta.DeviceIndex([seg])
+    try:
+        dev.set_option("dense_ratio", 64)
+        batched = dev.search(queries, 10)
+        for _ in range(3):
+            dev.submit_stats(reset=True)
+            got = dev.search_concurrent(queries, 10, 512)
+            st = dev.submit_stats()
+            assert st["queries"] == len(queries), st
+            assert st["max_batch"] >= 64, st
+            for a, b in zip(got[:4], batched):
+                assert np.array_equal(a, b)
+        _check(seg, queries[:200], got, 10)
+    finally:
+        dev.close()
