@@ -4,7 +4,7 @@ SEEDS random configurations — segment size, vocabulary, which lists get bitmap
 batch size — each a random mixed batch (2..4-term intersections, 2..6-term unions, the bench's boolean shapes, phrases), checked the way tests/test_gpu_round5.py checks the bench's streams: pruned == exhaustive on EVERY
 query (docs and counts bit for bit, scores bit for bit for two lists), and a sample of every kernel family of the batch
 against the oracle.  One line per seed; exit code 1 on the first mismatch.
-    SEEDS=40 FIRST=0 python tools/soak_shared.py"""
+    SEEDS=40 FIRST=0 python tools/soak_shared.py        (DOCS=3000000,8000000: other segment sizes)"""
 import os
 import sys
 import time
@@ -99,7 +99,8 @@ def main():
     bad = 0
     for seed in range(first, first + n_seeds):
         rng = np.random.default_rng(9000 + seed)
-        n_docs = int(rng.choice([150_000, 300_000, 700_000, 1_500_000]))
+        sizes = [int(x) for x in os.environ["DOCS"].split(",")] if os.environ.get("DOCS") else [150_000, 300_000, 700_000, 1_500_000]
+        n_docs = int(rng.choice(sizes))
         vocab = int(rng.choice([48, 256, 1024, 4096]))
         with_pos = vocab <= 256 and n_docs <= 700_000
         k = int(rng.choice([1, 10, 10, 100]))
